@@ -1,0 +1,231 @@
+"""CPU: the oracle (oracle/) against the fixtures captured from the reference itself
+(tests/golden/make_golden.py).  This is what pins the oracle; the HIP path is then compared with
+the oracle in the -m gpu tests."""
+import numpy as np
+import pytest
+import torch
+
+import _seeded as S
+from conftest import sub
+from oracle import crf_oracle as O
+from oracle import native as onative
+
+torch.set_num_threads(4)
+OUT_TOL = 2e-6      # outputs (fp32, same op sequence, possibly different reduction order)
+GRAD_TOL = 2e-5
+
+
+def t(a, dtype=None):
+    x = torch.from_numpy(np.ascontiguousarray(a))
+    return x.to(dtype) if dtype is not None else x
+
+
+def params(sd_np, requires_grad=True):
+    sd = {}
+    for k, v in sd_np.items():
+        x = t(v).clone()
+        if requires_grad and x.is_floating_point() and 'running_' not in k:
+            x.requires_grad_(True)
+        sd[k] = x
+    return sd
+
+
+def close(a, b, tol, what=''):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    err = np.abs(a - b).max() / max(1.0, np.abs(b).max())
+    assert err <= tol, '%s: rel-max err %.3e > %.1e' % (what, err, tol)
+
+
+def check_grads(sd, gold, prefix, tol=GRAD_TOL):
+    g = sub(gold, prefix)
+    assert g, prefix
+    for k, v in g.items():
+        close(sd[k].grad, v, tol, prefix + '/' + k)
+
+
+@pytest.mark.parametrize('steps,mode', [(1, 'train'), (3, 'train'), (3, 'eval'), (5, 'eval')])
+def test_crfconv_golden(golden, steps, mode):
+    g = golden('g1_crfconv.npz')
+    sd = params(sub(g, 'sd'))
+    u = t(g['unary']).requires_grad_(True)
+    p = t(g['pairwise']).requires_grad_(True)
+    out = O.crf_conv(sd, '', u, p, t(g['up_idx'], torch.long), t(g['neighbor_idx'], torch.long), steps,
+                     mode == 'train')
+    tag = 'T%d_%s' % (steps, mode)
+    close(out, g[tag + '/out'], OUT_TOL, 'out')
+    (out * t(g['gout'])).sum().backward()
+    close(u.grad, g[tag + '/d_unary'], GRAD_TOL, 'd_unary')
+    close(p.grad, g[tag + '/d_pairwise'], GRAD_TOL, 'd_pairwise')
+    check_grads(sd, g, tag + '/grad')
+    if mode == 'train':
+        for k, v in sub(g, tag + '/buf').items():
+            if 'num_batches' not in k:
+                close(sd[k], v, 1e-6, k)
+
+
+def test_meanfield_fp64_golden(golden):
+    g = golden('g2_meanfield_fp64.npz')
+    z, y, c = t(g['z']), t(g['y']), t(g['c'])
+    nbr = t(g['nbr'], torch.long)
+    close(O.crf_similarity(y, nbr), g['s'], 1e-13, 's')
+    for steps in (1, 3, 5):
+        close(O.crf_meanfield(z, y, nbr, c, steps), g['x_T%d' % steps], 1e-12, 'x_T%d' % steps)
+    # the fp32 evaluation of the same thing stays within 1e-5 of the fp64 anchor
+    x32 = O.crf_meanfield(z.float(), y.float(), nbr, c.float(), 5)
+    close(x32.double(), g['x_T5'], 1e-5, 'fp32 vs fp64')
+
+
+@pytest.mark.parametrize('form', ['plain', 'strided'])
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_pointconv_golden(golden, form, mode):
+    g = golden('g3_pointconv.npz')
+    sd = params(sub(g, 'sd'))
+    x = t(g['x']).requires_grad_(True)
+    if form == 'plain':
+        out = O.point_conv(sd, '', x, t(g['pos']), t(g['neighbor_idx'], torch.long), mode == 'train')
+    else:
+        out = O.point_conv(sd, '', x, (t(g['pos']), t(g['sub_pos'])), t(g['sub_idx'], torch.long),
+                           mode == 'train')
+    tag = '%s_%s' % (form, mode)
+    close(out, g[tag + '/out'], OUT_TOL, 'out')
+    (out * t(g[form + '/gout'])).sum().backward()
+    close(x.grad, g[tag + '/d_x'], GRAD_TOL, 'd_x')
+    check_grads(sd, g, tag + '/grad')
+
+
+@pytest.mark.parametrize('name,mode', [('a', 'train'), ('a', 'eval'), ('b', 'train'), ('c', 'train'), ('c', 'eval')])
+def test_resblock_golden(golden, name, mode):
+    g = golden('g4_resblock.npz')
+    sd = params(sub(g, name + '/sd'))
+    x = t(g[name + '/x']).requires_grad_(True)
+    if name == 'c':
+        out = O.resnet_block(sd, '', x, (t(g['pos']), t(g['sub_pos'])), t(g['sub_idx'], torch.long), mode == 'train')
+    else:
+        out = O.resnet_block(sd, '', x, t(g['pos']), t(g['neighbor_idx'], torch.long), mode == 'train')
+    tag = '%s_%s' % (name, mode)
+    close(out, g[tag + '/out'], OUT_TOL, 'out')
+    (out * t(g[name + '/gout'])).sum().backward()
+    close(x.grad, g[tag + '/d_x'], GRAD_TOL, 'd_x')
+    check_grads(sd, g, tag + '/grad')
+
+
+def g5_inputs(g):
+    B, N = g['pos'].shape[:2]
+    ms = []
+    pos = g['pos']
+    for i in range(5):
+        lvl = {'pos': t(pos)}
+        for k in ('neighbor_idx', 'sub_idx', 'up_idx'):
+            lvl[k] = t(g['ms%d/%s' % (i, k)], torch.long)
+        ms.append(lvl)
+        n = pos.shape[1]
+        choice = S.permutation(5, 'choice%d' % i, n)[: n // (4, 4, 4, 4, 2)[i]]
+        pos = np.ascontiguousarray(pos[:, choice])
+    return ms
+
+
+def g5_state(g, tagc, seed=17):
+    shapes = {k: tuple(int(s) for s in sh.split(',')) if sh else () for k, sh in zip(g[tagc + '/keys'], g[tagc + '/shapes'])}
+    return S.fill_state_dict(shapes, seed)
+
+
+@pytest.mark.parametrize('use_crf', [True, False])
+def test_pointconvbig_golden(golden, use_crf):
+    """Whole network + the training-step contract (trainval.py:99-105) at B=2, N=4096."""
+    g = golden('g5_pointconvbig.npz')
+    tagc = 'crf' if use_crf else 'ups'
+    ms = g5_inputs(g)
+    sd = params(g5_state(g, tagc))
+    sd = {k: v for k, v in sd.items()}
+    x = t(g['feats'])
+    rows = g['rows']
+    steps = int(g['steps'])
+    with torch.no_grad():
+        sd_eval = {k: v.detach().clone() for k, v in sd.items()}
+        lg = O.pointconv_resnet(sd_eval, x, ms, steps, False, use_crf).numpy()
+    close(lg[rows], g[tagc + '_eval/logits_rows'], 5e-6, 'eval logits')
+    close(lg.astype(np.float64).sum(0), g[tagc + '_eval/logits_colsum'], 5e-6, 'eval colsum')
+
+    B, N = g['pos'].shape[:2]
+    mask = np.unpackbits(g[tagc + '_train/dropout_mask'])[: B * N * 128].reshape(B, N, 128)
+    logits = O.pointconv_resnet(sd, x, ms, steps, True, use_crf, dropout_mask=t(mask).float())
+    loss = O.training_loss(logits, t(g['labels'], torch.long), t(g['class_weights']))
+    loss.backward()
+    close(logits.detach().numpy()[rows], g[tagc + '_train/logits_rows'], 1e-5, 'train logits')
+    close(loss, g[tagc + '_train/loss'], 1e-6, 'loss')
+    for k, v in sub(g, tagc + '_train/gnorm').items():
+        gr = sd[k].grad.numpy().reshape(-1).astype(np.float64)
+        nrm = float(v)
+        assert abs(np.sqrt((gr * gr).sum()) - nrm) <= 2e-4 * max(nrm, 1e-3), k
+        proj = S.projections(17, k, gr.size).astype(np.float64) @ gr
+        assert np.abs(proj - g['%s_train/gproj/%s' % (tagc, k)]).max() <= 2e-4 * max(nrm, 1e-3) * np.sqrt(gr.size), k
+    for k, v in sub(g, tagc + '_train/grad').items():
+        close(sd[k].grad, v, 5e-4, k)
+
+
+# ------------------------------------------------------------------ native checkers
+@pytest.mark.parametrize('K', [1, 16, 32])
+def test_knn_oracle_golden(golden, K):
+    g = golden('g6_knn.npz')
+    a = onative.oracle_knn_batch(g['pts'], g['pts'], K)
+    b = onative.oracle_knn_batch(g['pts'], g['qry'], K)
+    assert np.array_equal(a, g['self_K%d' % K].astype(np.int64))
+    assert np.array_equal(b, g['cross_K%d' % K].astype(np.int64))
+    assert np.array_equal(onative.oracle_knn(g['pts'][1], g['qry'][1], K), b[1])
+
+
+def test_knn_oracle_lattice_distances(golden):
+    g = golden('g6_knn.npz')
+    lat = g['lattice_pts']
+    idx = onative.oracle_knn(lat, lat, 16)
+    assert np.array_equal(onative.knn_sq_dists(lat, lat, idx), g['lattice_dists'])
+
+
+def rekey(pts_in, dl, rows_pts):
+    """voxel key of each OUTPUT row: the key of the input voxel whose barycentre it is."""
+    keys = onative.grid_keys(pts_in, dl)
+    op, _, _, okeys = onative.oracle_grid_subsample(pts_in, None, None, dl)
+    # barycentres are unique per voxel; match rows through exact float triples
+    lut = {tuple(p): k for p, k in zip(map(tuple, op), okeys)}
+    return np.array([lut[tuple(p)] for p in map(tuple, rows_pts)], dtype=np.uint64)
+
+
+@pytest.mark.parametrize('name', ['all', 'two', 'ponly', 'fonly', 'conly'])
+def test_grid_oracle_golden(golden, name):
+    g = golden('g7_grid.npz')
+    dl = float(g[name + '/dl'])
+    f = g['feats'] if name in ('all', 'two', 'fonly') else None
+    c = {'all': g['lab1'], 'two': g['lab2'], 'conly': g['lab1']}.get(name)
+    op, of, oc, okeys = onative.oracle_grid_subsample(g['pts'], f, c, dl)
+    rp = g[name + '/pts']
+    assert op.shape == rp.shape
+    order = np.argsort(rekey(g['pts'], dl, rp), kind='stable')   # reference rows -> ascending key
+    assert np.array_equal(op, rp[order])                          # barycentres bit-exact
+    if f is not None:
+        assert np.array_equal(of, g[name + '/feats'][order])      # arrival-order float sums bit-exact
+    if c is not None:
+        rc = g[name + '/classes'][order]
+        # labels must agree wherever the vote is not tied (ties: reference = hash-map order)
+        cc = c if c.ndim == 2 else c[:, None]
+        keys = onative.grid_keys(g['pts'], dl)
+        tied = np.zeros(rc.shape, dtype=bool)
+        pos_of = {k: i for i, k in enumerate(okeys)}
+        votes = [[{} for _ in range(cc.shape[1])] for _ in range(len(okeys))]
+        for i, k in enumerate(keys):
+            for l in range(cc.shape[1]):
+                d = votes[pos_of[k]][l]
+                d[cc[i, l]] = d.get(cc[i, l], 0) + 1
+        for r in range(len(okeys)):
+            for l in range(cc.shape[1]):
+                v = sorted(votes[r][l].values())
+                tied[r, l] = len(v) > 1 and v[-1] == v[-2]
+        assert np.array_equal(oc[~tied], rc[~tied])
+        assert (~tied).mean() > 0.3
+
+
+def test_ref_libs_agree_with_oracle_when_present():
+    if not onative.have_ref():
+        pytest.skip('oracle/_ref not built (needs /root/reference)')
+    rng = np.random.default_rng(3)
+    pts = rng.random((2, 1500, 3), dtype=np.float32)
+    assert np.array_equal(onative.oracle_knn_batch(pts, pts, 16), onative.ref_knn_batch(pts, pts, 16, omp=True))
