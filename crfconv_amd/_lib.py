@@ -1,0 +1,87 @@
+"""ctypes door onto libcrfconv_amd.so (the C ABI declared in include/crfconv_amd.h).
+
+The library is the product: there is no Python / PyTorch fallback.  If it is missing or a call
+fails, an exception is raised -- never a silent slow path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcrfconv_amd.so')
+
+_vp, _i, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/crfconv_amd.h one to one
+SIGNATURES = {
+    'crfconv_abi_version': (_i, []),
+    'crfconv_last_error': (ctypes.c_char_p, []),
+    'crfconv_knn': (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _vp]),
+    'crfconv_knn_omp': (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _vp]),
+    'crfconv_knn_batch': (_i, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp]),
+    'crfconv_knn_batch_omp': (_i, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp]),
+    'crfconv_knn_batch_dev_workspace': (_sz, [_sz, _sz, _sz, _sz]),
+    'crfconv_knn_batch_dev': (_i, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_grid_subsample': (_i64, [_vp, _i64, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _i64]),
+    'crfconv_grid_subsample_dev_workspace': (_sz, [_i64, _i, _i]),
+    'crfconv_grid_subsample_dev': (_i64, [_vp, _i64, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    'crfconv_index_narrow': (_i, [_vp, _i64, _i64, _i, _i64, _vp, _vp, _vp]),
+    'crfconv_reverse_csr_workspace': (_sz, [_i64, _i64]),
+    'crfconv_reverse_csr': (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_meanfield_forward': (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    'crfconv_meanfield_bwd_edge': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    'crfconv_meanfield_bwd_scatter': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp]),
+    'crfconv_similarity_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp]),
+    'crfconv_similarity_bwd_scatter': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp]),
+    'crfconv_pointconv_workspace': (_sz, [_i64, _i, _i]),
+    'crfconv_pointconv_moments': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _sz, _vp]),
+    'crfconv_pointconv_stats': (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_pointconv_forward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'crfconv_pointconv_bwd_reduce': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_pointconv_bwd_params': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_pointconv_bwd_input': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'crfconv_neighbor_maxpool_forward': (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp]),
+    'crfconv_neighbor_maxpool_backward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),
+    'crfconv_gather_rows': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    'crfconv_gather_rows_backward': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+class CrfConvError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library (once). Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CrfConvError(
+                '%s not found: build it with `make -C crfconv_amd/csrc` (or __graft_entry__.build()). '
+                'crfconv_amd has no CPU / PyTorch fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError here == header and library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        if lib.crfconv_abi_version() != 1:
+            raise CrfConvError('libcrfconv_amd.so ABI version mismatch')
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().crfconv_last_error().decode('utf-8', 'replace')
+
+
+def check(rc, what=''):
+    """Raise on a negative status; returns rc otherwise (sizes / counts pass through)."""
+    if rc < 0:
+        raise CrfConvError('%s failed (%d): %s' % (what or 'libcrfconv_amd call', rc, last_error()))
+    return rc
+
+
+def call(name, *args):
+    return check(getattr(load(), name)(*args), name)

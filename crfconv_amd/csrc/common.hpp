@@ -1,0 +1,74 @@
+// Shared device/host helpers for the gfx950 kernels of libcrfconv_amd.so.
+#pragma once
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/crfconv_amd.h"
+
+namespace crf {
+
+constexpr int WAVE = 64;  // gfx950 wavefront
+
+// ----------------------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+
+#define CRF_REQUIRE(cond, code, ...)        \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::crf::set_error(__VA_ARGS__);  \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+#define CRF_HIP(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            ::crf::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                             __FILE__, __LINE__);                                      \
+            return CRF_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+#define CRF_LAUNCH_CHECK() CRF_HIP(hipGetLastError())
+
+inline hipStream_t as_stream(crf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ----------------------------------------------------------------------------- device helpers
+// Sum over aligned groups of L consecutive lanes (L a power of two <= 64); every lane of the
+// group receives the total.
+template <int L>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+template <int L>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float4 fma4(float a, float4 b, float4 c) {
+    return make_float4(fmaf(a, b.x, c.x), fmaf(a, b.y, c.y), fmaf(a, b.z, c.z), fmaf(a, b.w, c.w));
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) {
+    return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+__device__ __forceinline__ float comp(const float4& v, int i) {
+    return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
+}  // namespace crf

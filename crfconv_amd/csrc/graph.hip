@@ -1,0 +1,110 @@
+// Neighbour-table plumbing: int64 per-cloud tables -> int32 global rows, and the reverse
+// (source-major) CSR every backward scatter walks.  Integer work, HBM-bound; the sort and the
+// scan are rocPRIM device primitives, the rest are flat coalesced kernels.
+#include "common.hpp"
+
+#include <rocprim/rocprim.hpp>
+
+namespace crf {
+
+__global__ __launch_bounds__(256) void narrow_kernel(const int64_t* __restrict__ idx64,
+                                                     int64_t total, int64_t per_cloud,
+                                                     int64_t n_src, int32_t* __restrict__ idx32,
+                                                     int32_t* __restrict__ bad) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    int64_t v = idx64[t];
+    const int64_t b = t / per_cloud;
+    if (v < 0 || v >= n_src) {
+        atomicAdd(bad, 1);
+        v = v < 0 ? 0 : n_src - 1;
+    }
+    idx32[t] = (int32_t)(b * n_src + v);
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t* __restrict__ out, int64_t n) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) out[t] = (uint32_t)t;
+}
+
+// sorted keys -> rev_ptr: ptr[v] = first position p with key[p] >= v, for v in [0, m_src].
+__global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t* __restrict__ keys,
+                                                         int64_t E, int64_t m_src,
+                                                         int32_t* __restrict__ ptr) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p > E) return;
+    // position p closes every source id in (key[p-1], key[p]]  (key[-1] = -1, key[E] = m_src)
+    const int64_t lo = p == 0 ? -1 : (int64_t)keys[p - 1];
+    int64_t hi = p == E ? m_src : (int64_t)keys[p];
+    if (hi > m_src) hi = m_src;
+    for (int64_t v = lo + 1; v <= hi; ++v) ptr[v] = (int32_t)p;
+}
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int key_bits(int64_t m_src) {
+    int bits = 1;
+    while (((int64_t)1 << bits) < m_src) ++bits;
+    return bits;
+}
+
+static size_t sort_temp_bytes(int64_t E, int64_t m_src) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                    (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)E, 0,
+                                    key_bits(m_src), (hipStream_t)0);
+    return bytes;
+}
+
+}  // namespace crf
+
+using namespace crf;
+
+extern "C" int crfconv_index_narrow(const int64_t* idx64, int64_t B, int64_t n_tgt, int K,
+                                    int64_t n_src, int32_t* idx32, int32_t* bad_count,
+                                    crf_stream_t stream) {
+    CRF_REQUIRE(idx64 && idx32 && bad_count, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(B > 0 && n_tgt > 0 && K > 0 && n_src > 0, CRF_ERR_ARG, "empty table");
+    CRF_REQUIRE(B * n_src < ((int64_t)1 << 31) && B * n_tgt * K < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED,
+                "table too large for int32 rows / edge ids (B=%lld n_src=%lld n_tgt=%lld K=%d)",
+                (long long)B, (long long)n_src, (long long)n_tgt, K);
+    const int64_t total = B * n_tgt * K;
+    hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream),
+                       idx64, total, n_tgt * K, n_src, idx32, bad_count);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" size_t crfconv_reverse_csr_workspace(int64_t E, int64_t m_src) {
+    if (E <= 0 || m_src <= 0) return 0;
+    // [keys_out E][vals_in E][sort temp]
+    return 2 * align_up(sizeof(uint32_t) * (size_t)E) + align_up(sort_temp_bytes(E, m_src)) + 256;
+}
+
+extern "C" int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_src, int32_t* rev_ptr,
+                                   int32_t* rev_eid, void* workspace, size_t workspace_bytes,
+                                   crf_stream_t stream) {
+    CRF_REQUIRE(idx32 && rev_ptr && rev_eid && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(E > 0 && m_src > 0 && E < ((int64_t)1 << 31) && m_src < ((int64_t)1 << 31), CRF_ERR_ARG,
+                "E=%lld m_src=%lld out of range", (long long)E, (long long)m_src);
+    const size_t need = crfconv_reverse_csr_workspace(E, m_src);
+    CRF_REQUIRE(workspace_bytes >= need, CRF_ERR_WORKSPACE, "reverse_csr workspace %zu < %zu",
+                workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws);
+    uint32_t* vals_in = reinterpret_cast<uint32_t*>(ws + align_up(sizeof(uint32_t) * (size_t)E));
+    void* temp = ws + 2 * align_up(sizeof(uint32_t) * (size_t)E);
+    size_t temp_bytes = sort_temp_bytes(E, m_src);
+
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, st, vals_in, E);
+    CRF_LAUNCH_CHECK();
+    // stable LSD radix sort by source row: edge ids stay ascending inside each group
+    CRF_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, reinterpret_cast<const uint32_t*>(idx32), keys_out,
+                                      vals_in, reinterpret_cast<uint32_t*>(rev_eid), (size_t)E, 0,
+                                      key_bits(m_src), st));
+    hipLaunchKernelGGL(boundaries_kernel, dim3((unsigned)cdiv(E + 1, 256)), dim3(256), 0, st, keys_out, E,
+                       m_src, rev_ptr);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}

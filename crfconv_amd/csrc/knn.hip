@@ -1,0 +1,364 @@
+// Exact batched kNN on gfx950 -- replaces the reference's nanoflann KD-tree extension
+// (utils/nearest_neighbors/knn_.cxx:22-135, knn_.h:2-19) with a uniform-grid search:
+//   1. per-cloud bounding box            (one block per cloud)
+//   2. cell id + histogram               (flat, int atomics)
+//   3. exclusive scan of cell counts     (rocPRIM)
+//   4. counting-sort scatter             (points packed as float4 {x, y, z, id})
+//   5. one thread per query: expanding Chebyshev rings of cells, register-resident top-K,
+//      stops when the K-th distance is strictly inside the searched cube.
+// Result contract (bit-exact against the oracle / the reference on tie-free input):
+//   distance = fl(fl(fl(dx*dx) + fl(dy*dy)) + fl(dz*dz)) in float32, no FMA contraction
+//   (nanoflann.hpp:342-347); neighbours ascending by (distance, point id).
+#include "common.hpp"
+
+#include <rocprim/rocprim.hpp>
+
+namespace crf {
+
+struct GridInfo {  // one per cloud, device resident
+    float ox, oy, oz;   // origin (bbox min)
+    float cell, inv;    // cell edge, 1 / cell
+    int nx, ny, nz;
+    float margin;       // absolute safety margin for the stop test
+};
+
+constexpr int QBLOCK = 128;
+
+__device__ __forceinline__ float sqdist_exact(float qx, float qy, float qz, float px, float py, float pz) {
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// ------------------------------------------------------------------ 1. bounding box -> grid
+__global__ __launch_bounds__(1024) void bbox_kernel(const float* __restrict__ pts, int64_t npts, int G0,
+                                                    GridInfo* __restrict__ info) {
+    const float* p = pts + (int64_t)blockIdx.x * npts * 3;
+    float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int64_t i = threadIdx.x; i < npts; i += 1024) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = p[3 * i + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    }
+    __shared__ float smn[16][3], smx[16][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float lo = mn[a], hi = mx[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o, WAVE));
+            hi = fmaxf(hi, __shfl_xor(hi, o, WAVE));
+        }
+        if (lane == 0) { smn[wave][a] = lo; smx[wave][a] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = smn[0][a]; hi[a] = smx[0][a];
+            for (int w = 1; w < 16; ++w) { lo[a] = fminf(lo[a], smn[w][a]); hi[a] = fmaxf(hi[a], smx[w][a]); }
+        }
+        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        float emax = fmaxf(ex, fmaxf(ey, ez));
+        if (!(emax > 0.f)) emax = 1.f;  // all points coincide (or a single point)
+        GridInfo g;
+        g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2];
+        g.cell = emax / (float)G0;
+        g.inv = 1.0f / g.cell;
+        g.nx = min(G0, (int)(ex * g.inv)) + 1;
+        g.ny = min(G0, (int)(ey * g.inv)) + 1;
+        g.nz = min(G0, (int)(ez * g.inv)) + 1;
+        const float amax = fmaxf(fmaxf(fabsf(lo[0]), fabsf(hi[0])),
+                                 fmaxf(fmaxf(fabsf(lo[1]), fabsf(hi[1])), fmaxf(fabsf(lo[2]), fabsf(hi[2]))));
+        g.margin = 1e-5f * (amax + emax) + 1e-30f;
+        info[blockIdx.x] = g;
+    }
+}
+
+__device__ __forceinline__ int3 cell_of(const GridInfo& g, float x, float y, float z) {
+    int cx = (int)floorf((x - g.ox) * g.inv), cy = (int)floorf((y - g.oy) * g.inv),
+        cz = (int)floorf((z - g.oz) * g.inv);
+    cx = min(max(cx, 0), g.nx - 1);
+    cy = min(max(cy, 0), g.ny - 1);
+    cz = min(max(cz, 0), g.nz - 1);
+    return make_int3(cx, cy, cz);
+}
+
+// ------------------------------------------------------------------ 2. histogram
+__global__ __launch_bounds__(256) void cell_count_kernel(const float* __restrict__ pts, int64_t npts,
+                                                         const GridInfo* __restrict__ info, int ncell_alloc,
+                                                         int32_t* __restrict__ cell_id,
+                                                         int32_t* __restrict__ counts) {
+    const int b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npts) return;
+    const GridInfo g = info[b];
+    const float* p = pts + ((int64_t)b * npts + i) * 3;
+    const int3 c = cell_of(g, p[0], p[1], p[2]);
+    const int cid = (c.z * g.ny + c.y) * g.nx + c.x;
+    cell_id[(int64_t)b * npts + i] = cid;
+    atomicAdd(&counts[(int64_t)b * ncell_alloc + cid], 1);
+}
+
+// ------------------------------------------------------------------ 4. scatter
+__global__ __launch_bounds__(256) void cell_scatter_kernel(const float* __restrict__ pts, int64_t npts,
+                                                           int ncell_alloc,
+                                                           const int32_t* __restrict__ cell_id,
+                                                           const int32_t* __restrict__ starts,
+                                                           int32_t* __restrict__ fill,
+                                                           float4* __restrict__ sorted) {
+    const int b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npts) return;
+    const int64_t g = (int64_t)b * npts + i;
+    const int64_t c = (int64_t)b * ncell_alloc + cell_id[g];
+    const int pos = starts[c] + atomicAdd(&fill[c], 1);
+    sorted[pos] = make_float4(pts[3 * g], pts[3 * g + 1], pts[3 * g + 2], __int_as_float((int)i));
+}
+
+// ------------------------------------------------------------------ 5. query
+template <int KM>
+struct TopK {
+    float d[KM];
+    int id[KM];
+    // Only K <= KM slots are live: the first KM - K are pinned at -inf so the live ones end at
+    // the static position KM - 1 (a runtime "d[K - 1]" would push the arrays to scratch).
+    __device__ __forceinline__ void init(int K) {
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            const bool pinned = k < KM - K;
+            d[k] = pinned ? -__builtin_inff() : 3.4e38f;
+            id[k] = pinned ? -1 : 0x7fffffff;
+        }
+    }
+    static __device__ __forceinline__ bool before(float da, int ia, float db, int ib) {
+        return da < db || (da == db && ia < ib);
+    }
+    __device__ __forceinline__ float kth() const { return d[KM - 1]; }
+    __device__ __forceinline__ void offer(float dd, int ii) {
+        if (!before(dd, ii, d[KM - 1], id[KM - 1])) return;
+        // sorted insert with selects only (static register indices, no conditional stores)
+#pragma unroll
+        for (int k = KM - 1; k > 0; --k) {
+            const bool shift = before(dd, ii, d[k - 1], id[k - 1]);   // slot k takes its upper neighbour
+            const bool place = !shift && before(dd, ii, d[k], id[k]); // or the new element lands here
+            d[k] = shift ? d[k - 1] : (place ? dd : d[k]);
+            id[k] = shift ? id[k - 1] : (place ? ii : id[k]);
+        }
+        const bool first = before(dd, ii, d[0], id[0]);
+        d[0] = first ? dd : d[0];
+        id[0] = first ? ii : id[0];
+    }
+};
+
+template <int KM>
+__global__ __launch_bounds__(QBLOCK) void knn_query_kernel(const float* __restrict__ queries, int64_t nq,
+                                                           int64_t npts, int K,
+                                                           const GridInfo* __restrict__ info,
+                                                           int ncell_alloc,
+                                                           const int32_t* __restrict__ starts,
+                                                           const float4* __restrict__ sorted,
+                                                           int64_t* __restrict__ out64,
+                                                           int32_t* __restrict__ out32) {
+    const int b = blockIdx.y;
+    const int64_t qi = (int64_t)blockIdx.x * QBLOCK + threadIdx.x;
+    if (qi >= nq) return;
+    const GridInfo g = info[b];
+    const float* qp = queries + ((int64_t)b * nq + qi) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const int3 c = cell_of(g, qx, qy, qz);
+    const int32_t* st = starts + (int64_t)b * ncell_alloc;
+
+    TopK<KM> best;
+    best.init(K);
+    const int rmax = max(g.nx, max(g.ny, g.nz));
+    for (int r = 0; r <= rmax; ++r) {
+        const int z0 = max(c.z - r, 0), z1 = min(c.z + r, g.nz - 1);
+        const int y0 = max(c.y - r, 0), y1 = min(c.y + r, g.ny - 1);
+        for (int z = z0; z <= z1; ++z) {
+            const bool zface = (z == c.z - r) || (z == c.z + r);
+            for (int y = y0; y <= y1; ++y) {
+                const bool full = zface || (y == c.y - r) || (y == c.y + r);
+                // full: whole x-span of the shell row; otherwise only its two end cells
+                const int nseg = full ? 1 : (r == 0 ? 1 : 2);
+                for (int sgi = 0; sgi < nseg; ++sgi) {
+                    int xa, xb;
+                    if (full) { xa = max(c.x - r, 0); xb = min(c.x + r, g.nx - 1); }
+                    else if (sgi == 0) { xa = xb = c.x - r; }
+                    else { xa = xb = c.x + r; }
+                    if (xa < 0 || xb >= g.nx || xa > xb) continue;
+                    const int rowbase = (z * g.ny + y) * g.nx;
+                    const int pbeg = st[rowbase + xa], pend = st[rowbase + xb + 1];
+                    for (int p = pbeg; p < pend; ++p) {
+                        const float4 s = sorted[p];
+                        best.offer(sqdist_exact(qx, qy, qz, s.x, s.y, s.z), __float_as_int(s.w));
+                    }
+                }
+            }
+        }
+        // every point outside the cube of rings <= r is at least `gap` away along some axis
+        float gap = 3.4e38f;
+        if (c.x - r > 0) gap = fminf(gap, qx - (g.ox + (float)(c.x - r) * g.cell));
+        if (c.x + r + 1 < g.nx) gap = fminf(gap, (g.ox + (float)(c.x + r + 1) * g.cell) - qx);
+        if (c.y - r > 0) gap = fminf(gap, qy - (g.oy + (float)(c.y - r) * g.cell));
+        if (c.y + r + 1 < g.ny) gap = fminf(gap, (g.oy + (float)(c.y + r + 1) * g.cell) - qy);
+        if (c.z - r > 0) gap = fminf(gap, qz - (g.oz + (float)(c.z - r) * g.cell));
+        if (c.z + r + 1 < g.nz) gap = fminf(gap, (g.oz + (float)(c.z + r + 1) * g.cell) - qz);
+        if (gap >= 3.0e38f) break;  // the cube covers the whole grid
+        const float safe = gap - g.margin;
+        if (safe > 0.f && best.kth() < safe * safe) break;
+    }
+    const int64_t o = ((int64_t)b * nq + qi) * K;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        if (k >= KM - K) {
+            if (out64) out64[o + k - (KM - K)] = best.id[k];
+            if (out32) out32[o + k - (KM - K)] = best.id[k];
+        }
+    }
+}
+
+static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int grid_g0(size_t npts) {
+    int g = (int)floor(cbrt((double)npts));
+    if (g < 1) g = 1;
+    if (g > 160) g = 160;
+    return g;
+}
+
+struct KnnLayout {
+    int G0, ncell_alloc;
+    size_t off_info, off_cellid, off_counts, off_starts, off_fill, off_sorted, off_temp, temp_bytes, total;
+};
+
+static KnnLayout knn_layout(size_t B, size_t npts) {
+    KnnLayout L;
+    L.G0 = grid_g0(npts);
+    L.ncell_alloc = (L.G0 + 1) * (L.G0 + 1) * (L.G0 + 1);
+    const size_t ncell_total = B * (size_t)L.ncell_alloc + 1;
+    size_t o = 0;
+    L.off_info = o;   o += al(sizeof(GridInfo) * B);
+    L.off_cellid = o; o += al(sizeof(int32_t) * B * npts);
+    L.off_counts = o; o += al(sizeof(int32_t) * ncell_total);
+    L.off_fill = o;   o += al(sizeof(int32_t) * ncell_total);   // counts and fill are zeroed together
+    L.off_starts = o; o += al(sizeof(int32_t) * ncell_total);
+    L.off_sorted = o; o += al(sizeof(float4) * B * npts);
+    size_t tb = 0;
+    (void)rocprim::exclusive_scan(nullptr, tb, (const int32_t*)nullptr, (int32_t*)nullptr, 0, ncell_total,
+                                  rocprim::plus<int32_t>(), (hipStream_t)0);
+    L.temp_bytes = tb;
+    L.off_temp = o;   o += al(tb);
+    L.total = o + 256;
+    return L;
+}
+
+}  // namespace crf
+
+using namespace crf;
+
+extern "C" size_t crfconv_knn_batch_dev_workspace(size_t batch_size, size_t npts, size_t nqueries, size_t K) {
+    (void)nqueries; (void)K;
+    if (batch_size == 0 || npts == 0) return 0;
+    return knn_layout(batch_size, npts).total;
+}
+
+extern "C" int crfconv_knn_batch_dev(const float* pts, size_t batch_size, size_t npts, size_t dim,
+                                     const float* queries, size_t nqueries, size_t K, int64_t* out_i64,
+                                     int32_t* out_i32, void* workspace, size_t workspace_bytes,
+                                     crf_stream_t stream) {
+    CRF_REQUIRE(pts && queries && workspace && (out_i64 || out_i32), CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(dim == 3, CRF_ERR_UNSUPPORTED, "kNN supports dim == 3 only (got %zu)", dim);
+    CRF_REQUIRE(batch_size >= 1 && batch_size <= 65535 && npts >= 1 && nqueries >= 1, CRF_ERR_ARG, "empty input");
+    CRF_REQUIRE(K >= 1 && K <= 64 && K <= npts, CRF_ERR_ARG, "K=%zu must satisfy 1 <= K <= min(64, npts=%zu)", K, npts);
+    CRF_REQUIRE(batch_size * npts < ((size_t)1 << 31), CRF_ERR_UNSUPPORTED, "B*npts too large");
+    const KnnLayout L = knn_layout(batch_size, npts);
+    CRF_REQUIRE(workspace_bytes >= L.total, CRF_ERR_WORKSPACE, "knn workspace %zu < %zu", workspace_bytes, L.total);
+    hipStream_t st = as_stream(stream);
+    char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    GridInfo* info = reinterpret_cast<GridInfo*>(ws + L.off_info);
+    int32_t* cell_id = reinterpret_cast<int32_t*>(ws + L.off_cellid);
+    int32_t* counts = reinterpret_cast<int32_t*>(ws + L.off_counts);
+    int32_t* fill = reinterpret_cast<int32_t*>(ws + L.off_fill);
+    int32_t* starts = reinterpret_cast<int32_t*>(ws + L.off_starts);
+    float4* sorted = reinterpret_cast<float4*>(ws + L.off_sorted);
+    void* temp = ws + L.off_temp;
+    const size_t ncell_total = batch_size * (size_t)L.ncell_alloc + 1;
+
+    CRF_HIP(hipMemsetAsync(counts, 0, L.off_starts - L.off_counts, st));  // counts + fill
+    hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)batch_size), dim3(1024), 0, st, pts, (int64_t)npts, L.G0, info);
+    CRF_LAUNCH_CHECK();
+    const dim3 pgrid((unsigned)cdiv((int64_t)npts, 256), (unsigned)batch_size);
+    hipLaunchKernelGGL(cell_count_kernel, pgrid, dim3(256), 0, st, pts, (int64_t)npts, info, L.ncell_alloc,
+                       cell_id, counts);
+    CRF_LAUNCH_CHECK();
+    size_t tb = L.temp_bytes;
+    CRF_HIP(rocprim::exclusive_scan(temp, tb, counts, starts, 0, ncell_total, rocprim::plus<int32_t>(), st));
+    hipLaunchKernelGGL(cell_scatter_kernel, pgrid, dim3(256), 0, st, pts, (int64_t)npts, L.ncell_alloc, cell_id,
+                       starts, fill, sorted);
+    CRF_LAUNCH_CHECK();
+    const dim3 qgrid((unsigned)cdiv((int64_t)nqueries, QBLOCK), (unsigned)batch_size);
+#define KNN_LAUNCH(KM)                                                                                     \
+    hipLaunchKernelGGL(knn_query_kernel<KM>, qgrid, dim3(QBLOCK), 0, st, queries, (int64_t)nqueries,       \
+                       (int64_t)npts, (int)K, info, L.ncell_alloc, starts, sorted, out_i64, out_i32)
+    if (K == 1) KNN_LAUNCH(1);
+    else if (K <= 8) KNN_LAUNCH(8);
+    else if (K <= 16) KNN_LAUNCH(16);
+    else if (K <= 32) KNN_LAUNCH(32);
+    else KNN_LAUNCH(64);
+#undef KNN_LAUNCH
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+// ------------------------------------------------------------------ host-buffer forms (knn_.h signatures)
+static int knn_host(const float* pts, size_t B, size_t npts, size_t dim, const float* queries, size_t nq,
+                    size_t K, long* out) {
+    CRF_REQUIRE(pts && queries && out, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(dim == 3, CRF_ERR_UNSUPPORTED, "kNN supports dim == 3 only (got %zu)", dim);
+    const size_t wsb = crfconv_knn_batch_dev_workspace(B, npts, nq, K);
+    float *dp = nullptr, *dq = nullptr;
+    int64_t* dout = nullptr;
+    void* ws = nullptr;
+    int rc = CRF_OK;
+    hipError_t e;
+#define TRY(x) if ((e = (x)) != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(e)); rc = CRF_ERR_HIP; goto done; }
+    TRY(hipMalloc(&dp, sizeof(float) * 3 * B * npts));
+    TRY(hipMalloc(&dq, sizeof(float) * 3 * B * nq));
+    TRY(hipMalloc(&dout, sizeof(int64_t) * B * nq * K));
+    TRY(hipMalloc(&ws, wsb));
+    TRY(hipMemcpy(dp, pts, sizeof(float) * 3 * B * npts, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(dq, queries, sizeof(float) * 3 * B * nq, hipMemcpyHostToDevice));
+    rc = crfconv_knn_batch_dev(dp, B, npts, dim, dq, nq, K, dout, nullptr, ws, wsb, nullptr);
+    if (rc != CRF_OK) goto done;
+    TRY(hipStreamSynchronize(nullptr));
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64 expected");
+    TRY(hipMemcpy(out, dout, sizeof(int64_t) * B * nq * K, hipMemcpyDeviceToHost));
+#undef TRY
+done:
+    if (dp) (void)hipFree(dp);
+    if (dq) (void)hipFree(dq);
+    if (dout) (void)hipFree(dout);
+    if (ws) (void)hipFree(ws);
+    return rc;
+}
+
+extern "C" int crfconv_knn(const float* points, size_t npts, size_t dim, const float* queries,
+                           size_t nqueries, size_t K, long* indices) {
+    return knn_host(points, 1, npts, dim, queries, nqueries, K, indices);
+}
+extern "C" int crfconv_knn_omp(const float* points, size_t npts, size_t dim, const float* queries,
+                               size_t nqueries, size_t K, long* indices) {
+    return knn_host(points, 1, npts, dim, queries, nqueries, K, indices);
+}
+extern "C" int crfconv_knn_batch(const float* batch_data, size_t batch_size, size_t npts, size_t dim,
+                                 const float* queries, size_t nqueries, size_t K, long* batch_indices) {
+    return knn_host(batch_data, batch_size, npts, dim, queries, nqueries, K, batch_indices);
+}
+extern "C" int crfconv_knn_batch_omp(const float* batch_data, size_t batch_size, size_t npts, size_t dim,
+                                     const float* queries, size_t nqueries, size_t K, long* batch_indices) {
+    return knn_host(batch_data, batch_size, npts, dim, queries, nqueries, K, batch_indices);
+}

@@ -1,0 +1,657 @@
+// PointConv (depth-wise point convolution with a per-edge weight MLP), gfx950.
+//
+// Reference semantics: models/point_conv_big.py:37-58.  The reference materialises
+// [B, N, K, d] tensors for rel-pos, both MLP layers, the gathered features and their product;
+// here nothing per-edge ever reaches HBM: every pass re-derives the weight MLP from the two
+// 12-byte positions, and train-mode BatchNorm statistics come from dedicated reduction passes.
+//
+// Thread mapping: the d channels of a target point sit on L = d/4 adjacent lanes (one float4
+// each); a 64-lane wavefront carries 64/L points and loops over their K neighbours.  Layer 1
+// (3 -> d) is computed per lane for its own quad; layer 2 (d -> d) broadcasts h1 over the L lanes
+// with shuffles against float4 rows of W2^T (registers for d <= 16, LDS above).
+#include "common.hpp"
+
+namespace crf {
+
+constexpr int PBLOCK = 256;
+constexpr int PWAVES = PBLOCK / WAVE;
+
+template <int D>
+struct PC {
+    static constexpr int L = D / 4;
+    static constexpr int PPW = WAVE / L;
+    static constexpr int PPB = PPW * PWAVES;
+    static constexpr bool W2_IN_REGS = (D <= 16);
+};
+
+__device__ __forceinline__ float lrelu01(float v) { return v > 0.f ? v : 0.1f * v; }
+
+// Per-thread constants of the weight MLP for this lane's channel quad.
+template <int D>
+struct EdgeMLP {
+    static constexpr int L = PC<D>::L;
+    float4 a1[4];  // a1[c] = {A1[c][0], A1[c][1], A1[c][2], b1[c]} for the quad's 4 channels
+    float4 w2t_reg[PC<D>::W2_IN_REGS ? D : 1];  // W2T[c'][quad] when held in registers
+    const float4* w2t_lds;                      // [D][L] float4 rows otherwise
+    int lane, q;
+
+    __device__ __forceinline__ void init(const float* __restrict__ A1, const float* __restrict__ b1,
+                                         const float* __restrict__ W2, float4* lds_w2t, int lane_, int q_) {
+        lane = lane_;
+        q = q_;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ch = 4 * q + c;
+            a1[c] = make_float4(A1[ch * 3 + 0], A1[ch * 3 + 1], A1[ch * 3 + 2], b1[ch]);
+        }
+        if constexpr (PC<D>::W2_IN_REGS) {
+#pragma unroll
+            for (int cp = 0; cp < D; ++cp)  // W2T[cp][4q+c] = W2[4q+c][cp]
+                w2t_reg[cp] = make_float4(W2[(4 * q + 0) * D + cp], W2[(4 * q + 1) * D + cp],
+                                          W2[(4 * q + 2) * D + cp], W2[(4 * q + 3) * D + cp]);
+            w2t_lds = nullptr;
+        } else {
+            float* s = reinterpret_cast<float*>(lds_w2t);
+            for (int t = threadIdx.x; t < D * D; t += PBLOCK) {
+                const int cp = t / D, c = t % D;
+                s[t] = W2[c * D + cp];
+            }
+            w2t_lds = lds_w2t;
+        }
+    }
+
+    // pre-activation and activation of layer 1 for this lane's quad
+    __device__ __forceinline__ void layer1(float rx, float ry, float rz, float4& pre, float4& h1) const {
+        pre.x = fmaf(a1[0].x, rx, fmaf(a1[0].y, ry, fmaf(a1[0].z, rz, a1[0].w)));
+        pre.y = fmaf(a1[1].x, rx, fmaf(a1[1].y, ry, fmaf(a1[1].z, rz, a1[1].w)));
+        pre.z = fmaf(a1[2].x, rx, fmaf(a1[2].y, ry, fmaf(a1[2].z, rz, a1[2].w)));
+        pre.w = fmaf(a1[3].x, rx, fmaf(a1[3].y, ry, fmaf(a1[3].z, rz, a1[3].w)));
+        h1 = make_float4(lrelu01(pre.x), lrelu01(pre.y), lrelu01(pre.z), lrelu01(pre.w));
+    }
+
+    // h2[quad] = sum_c' h1[c'] * W2[quad][c']
+    __device__ __forceinline__ float4 layer2(float4 h1) const {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int base = lane - q;
+#pragma unroll
+        for (int hq = 0; hq < L; ++hq) {
+            const float v0 = __shfl(h1.x, base + hq, WAVE);
+            const float v1 = __shfl(h1.y, base + hq, WAVE);
+            const float v2 = __shfl(h1.z, base + hq, WAVE);
+            const float v3 = __shfl(h1.w, base + hq, WAVE);
+            if constexpr (PC<D>::W2_IN_REGS) {
+                acc = fma4(v0, w2t_reg[4 * hq + 0], acc);
+                acc = fma4(v1, w2t_reg[4 * hq + 1], acc);
+                acc = fma4(v2, w2t_reg[4 * hq + 2], acc);
+                acc = fma4(v3, w2t_reg[4 * hq + 3], acc);
+            } else {
+                acc = fma4(v0, w2t_lds[(4 * hq + 0) * L + q], acc);
+                acc = fma4(v1, w2t_lds[(4 * hq + 1) * L + q], acc);
+                acc = fma4(v2, w2t_lds[(4 * hq + 2) * L + q], acc);
+                acc = fma4(v3, w2t_lds[(4 * hq + 3) * L + q], acc);
+            }
+        }
+        return acc;
+    }
+
+    __device__ __forceinline__ float4 h2_of(float rx, float ry, float rz) const {
+        float4 pre, h1;
+        layer1(rx, ry, rz, pre, h1);
+        return layer2(h1);
+    }
+};
+
+struct Row {
+    int64_t r;
+    bool valid;
+};
+
+template <int D>
+__device__ __forceinline__ Row my_row(int64_t m, int& lane, int& wave, int& q) {
+    lane = threadIdx.x & 63;
+    wave = threadIdx.x >> 6;
+    q = lane % PC<D>::L;
+    const int64_t row = (int64_t)blockIdx.x * PC<D>::PPB + wave * PC<D>::PPW + lane / PC<D>::L;
+    Row o;
+    o.valid = row < m;
+    o.r = o.valid ? row : m - 1;
+    return o;
+}
+
+// Sum `v` over all lanes of the wave that share the same quad index q (xor over the point bits).
+template <int D>
+__device__ __forceinline__ float over_points(float v) {
+#pragma unroll
+    for (int o = PC<D>::L; o < WAVE; o <<= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// Block-level deterministic reduction of NV per-quad float4 values into partial[block][NV][D].
+template <int D, int NV>
+__device__ __forceinline__ void block_reduce_store(const float4 (&v)[NV], float* sred /*[PWAVES][NV][D]*/,
+                                                   float* __restrict__ partial, int lane, int wave, int q) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        float4 t = v[n];
+        t.x = over_points<D>(t.x);
+        t.y = over_points<D>(t.y);
+        t.z = over_points<D>(t.z);
+        t.w = over_points<D>(t.w);
+        if (lane < PC<D>::L) st4(sred + (wave * NV + n) * D + 4 * q, t);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NV * D; t += PBLOCK) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < PWAVES; ++w) a += sred[w * NV * D + t];
+        partial[(int64_t)blockIdx.x * NV * D + t] = a;
+    }
+}
+
+// ------------------------------------------------------------------ generic partial reduction
+// out[slot] = sum_b partial[b][slot] accumulated in double, fixed order.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
+                                                              int64_t nblk, int nslots,
+                                                              double* __restrict__ out) {
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= nslots) return;
+    double a = 0.0;
+    for (int64_t b = 0; b < nblk; ++b) a += (double)partial[b * nslots + slot];
+    out[slot] = a;
+}
+
+// ------------------------------------------------------------------ rel-pos moments
+__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ pos_src,
+                                                      const float* __restrict__ pos_tgt,
+                                                      const int32_t* __restrict__ idx, int K,
+                                                      int64_t m_tgt, float* __restrict__ partial) {
+    __shared__ float sred[PWAVES][9];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float a[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < m_tgt) {
+        const float px = pos_tgt[3 * i], py = pos_tgt[3 * i + 1], pz = pos_tgt[3 * i + 2];
+        for (int k = 0; k < K; ++k) {
+            const int64_t j = idx[i * K + k];
+            const float rx = px - pos_src[3 * j], ry = py - pos_src[3 * j + 1], rz = pz - pos_src[3 * j + 2];
+            a[0] += rx; a[1] += ry; a[2] += rz;
+            a[3] = fmaf(rx, rx, a[3]); a[4] = fmaf(rx, ry, a[4]); a[5] = fmaf(rx, rz, a[5]);
+            a[6] = fmaf(ry, ry, a[6]); a[7] = fmaf(ry, rz, a[7]); a[8] = fmaf(rz, rz, a[8]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+        const float t = wave_sum(a[n]);
+        if (lane == 0) sred[wave][n] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < PWAVES; ++w) t += sred[w][threadIdx.x];
+        partial[(int64_t)blockIdx.x * 9 + threadIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------ BatchNorm-2 statistics of h2
+template <int D>
+__global__ __launch_bounds__(PBLOCK) void stats_kernel(const float* __restrict__ pos_src,
+                                                       const float* __restrict__ pos_tgt,
+                                                       const int32_t* __restrict__ idx, int K,
+                                                       int64_t m_tgt, const float* __restrict__ A1,
+                                                       const float* __restrict__ b1,
+                                                       const float* __restrict__ W2,
+                                                       const float* __restrict__ mean_rel,
+                                                       float* __restrict__ shift_out,
+                                                       float* __restrict__ partial) {
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float sred[PWAVES * 2 * D];
+    int lane, wave, q;
+    const Row rw = my_row<D>(m_tgt, lane, wave, q);
+    EdgeMLP<D> mlp;
+    mlp.init(A1, b1, W2, s_w2t, lane, q);
+    __syncthreads();
+    const float4 shift = mlp.h2_of(mean_rel[0], mean_rel[1], mean_rel[2]);
+    if (blockIdx.x == 0 && threadIdx.x < PC<D>::L) st4(shift_out + 4 * q, shift);
+
+    const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
+    const int32_t* irow = idx + rw.r * K;
+    float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    const float live = rw.valid ? 1.f : 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int64_t j = irow[k];
+        const float4 h2 = mlp.h2_of(px - pos_src[3 * j], py - pos_src[3 * j + 1], pz - pos_src[3 * j + 2]);
+        const float4 dlt = make_float4((h2.x - shift.x) * live, (h2.y - shift.y) * live,
+                                       (h2.z - shift.z) * live, (h2.w - shift.w) * live);
+        acc[0].x += dlt.x; acc[0].y += dlt.y; acc[0].z += dlt.z; acc[0].w += dlt.w;
+        acc[1] = make_float4(fmaf(dlt.x, dlt.x, acc[1].x), fmaf(dlt.y, dlt.y, acc[1].y),
+                             fmaf(dlt.z, dlt.z, acc[1].z), fmaf(dlt.w, dlt.w, acc[1].w));
+    }
+    block_reduce_store<D, 2>(acc, sred, partial, lane, wave, q);
+}
+
+// ------------------------------------------------------------------ forward
+template <int D>
+__global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ pos_src,
+                                                         const float* __restrict__ pos_tgt,
+                                                         const int32_t* __restrict__ idx, int K,
+                                                         int64_t m_tgt, const float* __restrict__ A1,
+                                                         const float* __restrict__ b1,
+                                                         const float* __restrict__ W2,
+                                                         const float* __restrict__ a2,
+                                                         const float* __restrict__ b2,
+                                                         float* __restrict__ out) {
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    int lane, wave, q;
+    const Row rw = my_row<D>(m_tgt, lane, wave, q);
+    EdgeMLP<D> mlp;
+    mlp.init(A1, b1, W2, s_w2t, lane, q);
+    __syncthreads();
+    const float4 sa = ld4(a2 + 4 * q), sb = ld4(b2 + 4 * q);
+    const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
+    const int32_t* irow = idx + rw.r * K;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+    for (int k = 0; k < K; ++k) {
+        const int64_t j = irow[k];
+        const float4 xj = ld4(x + j * D + 4 * q);
+        const float4 h2 = mlp.h2_of(px - pos_src[3 * j], py - pos_src[3 * j + 1], pz - pos_src[3 * j + 2]);
+        acc.x = fmaf(fmaf(sa.x, h2.x, sb.x), xj.x, acc.x);
+        acc.y = fmaf(fmaf(sa.y, h2.y, sb.y), xj.y, acc.y);
+        acc.z = fmaf(fmaf(sa.z, h2.z, sb.z), xj.z, acc.z);
+        acc.w = fmaf(fmaf(sa.w, h2.w, sb.w), xj.w, acc.w);
+    }
+    if (rw.valid) st4(out + rw.r * D + 4 * q, acc);
+}
+
+// ------------------------------------------------------------------ backward pass 1: reductions
+template <int D>
+__global__ __launch_bounds__(PBLOCK) void bwd_reduce_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ gout,
+                                                            const float* __restrict__ pos_src,
+                                                            const float* __restrict__ pos_tgt,
+                                                            const int32_t* __restrict__ idx, int K,
+                                                            int64_t m_tgt, const float* __restrict__ A1,
+                                                            const float* __restrict__ b1,
+                                                            const float* __restrict__ W2,
+                                                            const float* __restrict__ shift_p,
+                                                            float* __restrict__ partial) {
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float sred[PWAVES * 2 * D];
+    int lane, wave, q;
+    const Row rw = my_row<D>(m_tgt, lane, wave, q);
+    EdgeMLP<D> mlp;
+    mlp.init(A1, b1, W2, s_w2t, lane, q);
+    __syncthreads();
+    const float4 shift = ld4(shift_p + 4 * q);
+    const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
+    const int32_t* irow = idx + rw.r * K;
+    float4 g = ld4(gout + rw.r * D + 4 * q);
+    if (!rw.valid) g = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    for (int k = 0; k < K; ++k) {
+        const int64_t j = irow[k];
+        const float4 xj = ld4(x + j * D + 4 * q);
+        const float4 h2 = mlp.h2_of(px - pos_src[3 * j], py - pos_src[3 * j + 1], pz - pos_src[3 * j + 2]);
+        const float4 gw = make_float4(g.x * xj.x, g.y * xj.y, g.z * xj.z, g.w * xj.w);
+        acc[0].x += gw.x; acc[0].y += gw.y; acc[0].z += gw.z; acc[0].w += gw.w;
+        acc[1] = make_float4(fmaf(gw.x, h2.x - shift.x, acc[1].x), fmaf(gw.y, h2.y - shift.y, acc[1].y),
+                             fmaf(gw.z, h2.z - shift.z, acc[1].z), fmaf(gw.w, h2.w - shift.w, acc[1].w));
+    }
+    block_reduce_store<D, 2>(acc, sred, partial, lane, wave, q);
+}
+
+// ------------------------------------------------------------------ backward pass 2: parameters
+// Slots of a block partial: [dW2 D*D][dA1 D*3][db1 D].
+template <int D>
+__global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ gout,
+                                                            const float* __restrict__ pos_src,
+                                                            const float* __restrict__ pos_tgt,
+                                                            const int32_t* __restrict__ idx, int K,
+                                                            int64_t m_tgt, const float* __restrict__ A1,
+                                                            const float* __restrict__ b1,
+                                                            const float* __restrict__ W2,
+                                                            const float* __restrict__ ca,
+                                                            const float* __restrict__ cb,
+                                                            const float* __restrict__ cc,
+                                                            float* __restrict__ partial) {
+    constexpr int L = PC<D>::L;
+    constexpr bool ACC_REGS = (D <= 32);          // dW2 accumulators in registers vs LDS atomics
+    constexpr int NSLOT = D * D + 4 * D;
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * L];
+    constexpr bool W2_LDS = (D <= 64);            // d = 128: the 64 KB of rows stay in L1/L2 instead
+    __shared__ float4 s_w2[W2_LDS ? D * L : 1];   // W2 rows as float4: s_w2[c * L + q'] = W2[c][4q'..]
+    __shared__ float s_acc[NSLOT];                // block totals
+    int lane, wave, q;
+    const Row rw = my_row<D>(m_tgt, lane, wave, q);
+    EdgeMLP<D> mlp;
+    mlp.init(A1, b1, W2, s_w2t, lane, q);
+    {
+        float* s = reinterpret_cast<float*>(s_w2);
+        if constexpr (W2_LDS)
+            for (int t = threadIdx.x; t < D * D; t += PBLOCK) s[t] = W2[t];
+        for (int t = threadIdx.x; t < NSLOT; t += PBLOCK) s_acc[t] = 0.f;
+    }
+    __syncthreads();
+    const float4 va = ld4(ca + 4 * q), vb = ld4(cb + 4 * q), vc = ld4(cc + 4 * q);
+    const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
+    const int32_t* irow = idx + rw.r * K;
+    float4 g = ld4(gout + rw.r * D + 4 * q);
+    const float live = rw.valid ? 1.f : 0.f;
+
+    float4 dw2[ACC_REGS ? D : 1];  // dw2[c'] = {dW2[4q+0][c'], dW2[4q+1][c'], dW2[4q+2][c'], dW2[4q+3][c']}
+    if constexpr (ACC_REGS) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) dw2[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 da1[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
+                     make_float4(0.f, 0.f, 0.f, 0.f)};  // da1[axis] over the quad's 4 channels
+    float4 db = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int base = lane - q;
+
+    for (int k = 0; k < K; ++k) {
+        const int64_t j = irow[k];
+        const float4 xj = ld4(x + j * D + 4 * q);
+        const float rx = px - pos_src[3 * j], ry = py - pos_src[3 * j + 1], rz = pz - pos_src[3 * j + 2];
+        float4 pre, h1;
+        mlp.layer1(rx, ry, rz, pre, h1);
+        const float4 h2 = mlp.layer2(h1);
+        // g_h2 for this lane's quad (zero for padding rows)
+        float4 gh2;
+        gh2.x = live * fmaf(va.x, g.x * xj.x, fmaf(vb.x, h2.x, vc.x));
+        gh2.y = live * fmaf(va.y, g.y * xj.y, fmaf(vb.y, h2.y, vc.y));
+        gh2.z = live * fmaf(va.z, g.z * xj.z, fmaf(vb.z, h2.z, vc.z));
+        gh2.w = live * fmaf(va.w, g.w * xj.w, fmaf(vb.w, h2.w, vc.w));
+        // dW2[quad][c'] += g_h2[quad] * h1[c'] ;  g_h1[quad'] = sum_c g_h2[c] W2[c][quad']
+        float4 gh1 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int hq = 0; hq < L; ++hq) {
+            const float h0 = __shfl(h1.x, base + hq, WAVE), h1b = __shfl(h1.y, base + hq, WAVE);
+            const float h2b = __shfl(h1.z, base + hq, WAVE), h3 = __shfl(h1.w, base + hq, WAVE);
+            if constexpr (ACC_REGS) {
+                dw2[4 * hq + 0] = fma4(h0, gh2, dw2[4 * hq + 0]);
+                dw2[4 * hq + 1] = fma4(h1b, gh2, dw2[4 * hq + 1]);
+                dw2[4 * hq + 2] = fma4(h2b, gh2, dw2[4 * hq + 2]);
+                dw2[4 * hq + 3] = fma4(h3, gh2, dw2[4 * hq + 3]);
+            } else {
+                const float hv[4] = {h0, h1b, h2b, h3};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int cp = 4 * hq + c;
+                    atomicAdd(&s_acc[(4 * q + 0) * D + cp], gh2.x * hv[c]);
+                    atomicAdd(&s_acc[(4 * q + 1) * D + cp], gh2.y * hv[c]);
+                    atomicAdd(&s_acc[(4 * q + 2) * D + cp], gh2.z * hv[c]);
+                    atomicAdd(&s_acc[(4 * q + 3) * D + cp], gh2.w * hv[c]);
+                }
+            }
+            const float g0 = __shfl(gh2.x, base + hq, WAVE), g1 = __shfl(gh2.y, base + hq, WAVE);
+            const float g2 = __shfl(gh2.z, base + hq, WAVE), g3 = __shfl(gh2.w, base + hq, WAVE);
+            if constexpr (W2_LDS) {
+                gh1 = fma4(g0, s_w2[(4 * hq + 0) * L + q], gh1);
+                gh1 = fma4(g1, s_w2[(4 * hq + 1) * L + q], gh1);
+                gh1 = fma4(g2, s_w2[(4 * hq + 2) * L + q], gh1);
+                gh1 = fma4(g3, s_w2[(4 * hq + 3) * L + q], gh1);
+            } else {
+                gh1 = fma4(g0, ld4(W2 + (4 * hq + 0) * D + 4 * q), gh1);
+                gh1 = fma4(g1, ld4(W2 + (4 * hq + 1) * D + 4 * q), gh1);
+                gh1 = fma4(g2, ld4(W2 + (4 * hq + 2) * D + 4 * q), gh1);
+                gh1 = fma4(g3, ld4(W2 + (4 * hq + 3) * D + 4 * q), gh1);
+            }
+        }
+        // through lrelu(0.1)
+        const float4 gp = make_float4(gh1.x * (pre.x > 0.f ? 1.f : 0.1f), gh1.y * (pre.y > 0.f ? 1.f : 0.1f),
+                                      gh1.z * (pre.z > 0.f ? 1.f : 0.1f), gh1.w * (pre.w > 0.f ? 1.f : 0.1f));
+        da1[0] = fma4(rx, gp, da1[0]);
+        da1[1] = fma4(ry, gp, da1[1]);
+        da1[2] = fma4(rz, gp, da1[2]);
+        db.x += gp.x; db.y += gp.y; db.z += gp.z; db.w += gp.w;
+    }
+
+    // wave-level sums over points, then one LDS add per wave (4 adders per slot, fixed slots)
+    if constexpr (ACC_REGS) {
+#pragma unroll
+        for (int cp = 0; cp < D; ++cp) {
+            float4 t = dw2[cp];
+            t.x = over_points<D>(t.x); t.y = over_points<D>(t.y);
+            t.z = over_points<D>(t.z); t.w = over_points<D>(t.w);
+            if (lane < L) {
+                atomicAdd(&s_acc[(4 * q + 0) * D + cp], t.x);
+                atomicAdd(&s_acc[(4 * q + 1) * D + cp], t.y);
+                atomicAdd(&s_acc[(4 * q + 2) * D + cp], t.z);
+                atomicAdd(&s_acc[(4 * q + 3) * D + cp], t.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        float4 t = da1[ax];
+        t.x = over_points<D>(t.x); t.y = over_points<D>(t.y);
+        t.z = over_points<D>(t.z); t.w = over_points<D>(t.w);
+        if (lane < L) {
+            atomicAdd(&s_acc[D * D + (4 * q + 0) * 3 + ax], t.x);
+            atomicAdd(&s_acc[D * D + (4 * q + 1) * 3 + ax], t.y);
+            atomicAdd(&s_acc[D * D + (4 * q + 2) * 3 + ax], t.z);
+            atomicAdd(&s_acc[D * D + (4 * q + 3) * 3 + ax], t.w);
+        }
+    }
+    {
+        float4 t = db;
+        t.x = over_points<D>(t.x); t.y = over_points<D>(t.y);
+        t.z = over_points<D>(t.z); t.w = over_points<D>(t.w);
+        if (lane < L) {
+            atomicAdd(&s_acc[D * D + 3 * D + 4 * q + 0], t.x);
+            atomicAdd(&s_acc[D * D + 3 * D + 4 * q + 1], t.y);
+            atomicAdd(&s_acc[D * D + 3 * D + 4 * q + 2], t.z);
+            atomicAdd(&s_acc[D * D + 3 * D + 4 * q + 3], t.w);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NSLOT; t += PBLOCK) partial[(int64_t)blockIdx.x * NSLOT + t] = s_acc[t];
+}
+
+// ------------------------------------------------------------------ backward: input features
+template <int D>
+__global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restrict__ gout,
+                                                           const float* __restrict__ pos_src,
+                                                           const float* __restrict__ pos_tgt,
+                                                           const int32_t* __restrict__ rev_ptr,
+                                                           const int32_t* __restrict__ rev_eid, int K,
+                                                           int64_t m_src, const float* __restrict__ A1,
+                                                           const float* __restrict__ b1,
+                                                           const float* __restrict__ W2,
+                                                           const float* __restrict__ a2,
+                                                           const float* __restrict__ b2,
+                                                           float* __restrict__ dx) {
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    int lane, wave, q;
+    const Row rw = my_row<D>(m_src, lane, wave, q);
+    EdgeMLP<D> mlp;
+    mlp.init(A1, b1, W2, s_w2t, lane, q);
+    __syncthreads();
+    const float4 sa = ld4(a2 + 4 * q), sb = ld4(b2 + 4 * q);
+    const float sx = pos_src[3 * rw.r], sy = pos_src[3 * rw.r + 1], sz = pos_src[3 * rw.r + 2];
+    const int beg = rev_ptr[rw.r];
+    const int deg = rw.valid ? rev_ptr[rw.r + 1] - beg : 0;
+    int degmax = deg;  // uniform trip count: the MLP shuffles need every lane of a group active
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) degmax = max(degmax, __shfl_xor(degmax, o, WAVE));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < degmax; ++p) {
+        const bool act = p < deg;
+        float rx = 0.f, ry = 0.f, rz = 0.f;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act) {
+            const int64_t i = rev_eid[beg + p] / K;
+            rx = pos_tgt[3 * i] - sx;
+            ry = pos_tgt[3 * i + 1] - sy;
+            rz = pos_tgt[3 * i + 2] - sz;
+            g = ld4(gout + i * D + 4 * q);
+        }
+        const float4 h2 = mlp.h2_of(rx, ry, rz);
+        acc.x = fmaf(fmaf(sa.x, h2.x, sb.x), g.x, acc.x);  // g == 0 on inactive lanes
+        acc.y = fmaf(fmaf(sa.y, h2.y, sb.y), g.y, acc.y);
+        acc.z = fmaf(fmaf(sa.z, h2.z, sb.z), g.z, acc.z);
+        acc.w = fmaf(fmaf(sa.w, h2.w, sb.w), g.w, acc.w);
+    }
+    if (rw.valid) st4(dx + rw.r * D + 4 * q, acc);
+}
+
+static int check_pc(int64_t m, int K, int d) {
+    CRF_REQUIRE(m > 0 && m < ((int64_t)1 << 31), CRF_ERR_ARG, "rows=%lld out of range", (long long)m);
+    CRF_REQUIRE(K >= 1 && K <= 64, CRF_ERR_ARG, "K=%d out of range", K);
+    CRF_REQUIRE(d == 4 || d == 8 || d == 16 || d == 32 || d == 64 || d == 128, CRF_ERR_UNSUPPORTED,
+                "d=%d not in {4,8,16,32,64,128}", d);
+    return CRF_OK;
+}
+
+template <int D>
+constexpr int nblocks_of(int64_t m) { return (int)((m + PC<D>::PPB - 1) / PC<D>::PPB); }
+
+#define DISPATCH_D(d, ...)                                        \
+    switch (d) {                                                  \
+        case 4: { constexpr int DD = 4; __VA_ARGS__; break; }     \
+        case 8: { constexpr int DD = 8; __VA_ARGS__; break; }     \
+        case 16: { constexpr int DD = 16; __VA_ARGS__; break; }   \
+        case 32: { constexpr int DD = 32; __VA_ARGS__; break; }   \
+        case 64: { constexpr int DD = 64; __VA_ARGS__; break; }   \
+        default: { constexpr int DD = 128; __VA_ARGS__; break; }  \
+    }
+
+static int64_t blocks_for(int64_t m, int d) {
+    const int ppb = (WAVE / (d / 4)) * PWAVES;
+    return (m + ppb - 1) / ppb;
+}
+
+static int reduce_partials(const float* partial, int64_t nblk, int nslots, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(nslots, 256)), dim3(256), 0, st, partial,
+                       nblk, nslots, out);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+}  // namespace crf
+
+using namespace crf;
+
+extern "C" size_t crfconv_pointconv_workspace(int64_t m_tgt, int K, int d) {
+    if (m_tgt <= 0 || d < 4) return 0;
+    const size_t a = (size_t)cdiv(m_tgt, 256) * 9;                               // moments
+    const size_t b = (size_t)blocks_for(m_tgt, d) * ((size_t)d * d + 4 * (size_t)d);  // params (largest)
+    return sizeof(float) * (a > b ? a : b) + 256;
+}
+
+extern "C" int crfconv_pointconv_moments(const float* pos_src, const float* pos_tgt, const int32_t* idx32,
+                                         int K, int64_t m_tgt, double* out9, void* workspace,
+                                         size_t workspace_bytes, crf_stream_t stream) {
+    if (int rc = check_pc(m_tgt, K, 4)) return rc;
+    CRF_REQUIRE(pos_src && pos_tgt && idx32 && out9 && workspace, CRF_ERR_ARG, "null pointer");
+    const int64_t nblk = cdiv(m_tgt, 256);
+    CRF_REQUIRE(workspace_bytes >= sizeof(float) * 9 * (size_t)nblk, CRF_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* partial = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(moments_kernel, dim3((unsigned)nblk), dim3(256), 0, st, pos_src, pos_tgt, idx32, K,
+                       m_tgt, partial);
+    CRF_LAUNCH_CHECK();
+    return reduce_partials(partial, nblk, 9, out9, st);
+}
+
+extern "C" int crfconv_pointconv_stats(const float* pos_src, const float* pos_tgt, const int32_t* idx32,
+                                       int K, int64_t m_tgt, int d, const float* A1, const float* b1,
+                                       const float* W2, const float* mean_rel3, float* shift,
+                                       double* stats, void* workspace, size_t workspace_bytes,
+                                       crf_stream_t stream) {
+    if (int rc = check_pc(m_tgt, K, d)) return rc;
+    CRF_REQUIRE(pos_src && pos_tgt && idx32 && A1 && b1 && W2 && mean_rel3 && shift && stats && workspace,
+                CRF_ERR_ARG, "null pointer");
+    const int64_t nblk = blocks_for(m_tgt, d);
+    CRF_REQUIRE(workspace_bytes >= sizeof(float) * 2 * d * (size_t)nblk, CRF_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* partial = reinterpret_cast<float*>(workspace);
+    DISPATCH_D(d, {
+        hipLaunchKernelGGL(stats_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, pos_src, pos_tgt,
+                           idx32, K, m_tgt, A1, b1, W2, mean_rel3, shift, partial);
+    });
+    CRF_LAUNCH_CHECK();
+    return reduce_partials(partial, nblk, 2 * d, stats, st);
+}
+
+extern "C" int crfconv_pointconv_forward(const float* x, const float* pos_src, const float* pos_tgt,
+                                         const int32_t* idx32, int K, int64_t m_tgt, int d,
+                                         const float* A1, const float* b1, const float* W2,
+                                         const float* a2, const float* b2, float* out,
+                                         crf_stream_t stream) {
+    if (int rc = check_pc(m_tgt, K, d)) return rc;
+    CRF_REQUIRE(x && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && a2 && b2 && out, CRF_ERR_ARG,
+                "null pointer");
+    const int64_t nblk = blocks_for(m_tgt, d);
+    DISPATCH_D(d, {
+        hipLaunchKernelGGL(forward_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, as_stream(stream), x,
+                           pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, a2, b2, out);
+    });
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_pointconv_bwd_reduce(const float* x, const float* gout, const float* pos_src,
+                                            const float* pos_tgt, const int32_t* idx32, int K,
+                                            int64_t m_tgt, int d, const float* A1, const float* b1,
+                                            const float* W2, const float* shift, double* red1,
+                                            void* workspace, size_t workspace_bytes, crf_stream_t stream) {
+    if (int rc = check_pc(m_tgt, K, d)) return rc;
+    CRF_REQUIRE(x && gout && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && shift && red1 && workspace,
+                CRF_ERR_ARG, "null pointer");
+    const int64_t nblk = blocks_for(m_tgt, d);
+    CRF_REQUIRE(workspace_bytes >= sizeof(float) * 2 * d * (size_t)nblk, CRF_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* partial = reinterpret_cast<float*>(workspace);
+    DISPATCH_D(d, {
+        hipLaunchKernelGGL(bwd_reduce_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src,
+                           pos_tgt, idx32, K, m_tgt, A1, b1, W2, shift, partial);
+    });
+    CRF_LAUNCH_CHECK();
+    return reduce_partials(partial, nblk, 2 * d, red1, st);
+}
+
+extern "C" int crfconv_pointconv_bwd_params(const float* x, const float* gout, const float* pos_src,
+                                            const float* pos_tgt, const int32_t* idx32, int K,
+                                            int64_t m_tgt, int d, const float* A1, const float* b1,
+                                            const float* W2, const float* ca, const float* cb,
+                                            const float* cc, double* dW2, double* dA1, double* db1,
+                                            void* workspace, size_t workspace_bytes, crf_stream_t stream) {
+    if (int rc = check_pc(m_tgt, K, d)) return rc;
+    CRF_REQUIRE(x && gout && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && ca && cb && cc && dW2 && dA1 &&
+                    db1 && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(dA1 == dW2 + (size_t)d * d && db1 == dA1 + (size_t)d * 3, CRF_ERR_ARG,
+                "dW2/dA1/db1 must be one contiguous [d*d + 3d + d] float64 buffer");
+    const int64_t nblk = blocks_for(m_tgt, d);
+    const int nslot = d * d + 4 * d;
+    CRF_REQUIRE(workspace_bytes >= sizeof(float) * (size_t)nslot * (size_t)nblk, CRF_ERR_WORKSPACE,
+                "workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* partial = reinterpret_cast<float*>(workspace);
+    DISPATCH_D(d, {
+        hipLaunchKernelGGL(bwd_params_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src,
+                           pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial);
+    });
+    CRF_LAUNCH_CHECK();
+    return reduce_partials(partial, nblk, nslot, dW2, st);
+}
+
+extern "C" int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const float* pos_tgt,
+                                           const int32_t* rev_ptr, const int32_t* rev_eid, int K,
+                                           int64_t m_src, int d, const float* A1, const float* b1,
+                                           const float* W2, const float* a2, const float* b2, float* dx,
+                                           crf_stream_t stream) {
+    if (int rc = check_pc(m_src, K, d)) return rc;
+    CRF_REQUIRE(gout && pos_src && pos_tgt && rev_ptr && rev_eid && A1 && b1 && W2 && a2 && b2 && dx,
+                CRF_ERR_ARG, "null pointer");
+    const int64_t nblk = blocks_for(m_src, d);
+    DISPATCH_D(d, {
+        hipLaunchKernelGGL(bwd_input_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, as_stream(stream), gout,
+                           pos_src, pos_tgt, rev_ptr, rev_eid, K, m_src, A1, b1, W2, a2, b2, dx);
+    });
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}

@@ -1,0 +1,140 @@
+// Neighbour max-pooling (strided ResNet shortcut, point_conv_big.py:74-77) and nearest
+// up-sampling (row gather, :97-101 / continuous_crf_conv_big.py:60), forward and backward.
+// One thread per (row, 4-channel quad): 16-byte loads, a row's C/4 quads are adjacent lanes.
+#include "common.hpp"
+
+namespace crf {
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x,
+                                                          const int32_t* __restrict__ idx, int K,
+                                                          int64_t m_tgt, int C4,
+                                                          float* __restrict__ out,
+                                                          int32_t* __restrict__ arg) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= m_tgt * C4) return;
+    const int64_t i = t / C4;
+    const int q = (int)(t - i * C4);
+    const int32_t* irow = idx + i * K;
+    float4 best = ld4(x + ((int64_t)irow[0] * C4 + q) * 4);
+    int4 who = make_int4(0, 0, 0, 0);
+    for (int k = 1; k < K; ++k) {
+        const float4 v = ld4(x + ((int64_t)irow[k] * C4 + q) * 4);
+        if (v.x > best.x) { best.x = v.x; who.x = k; }
+        if (v.y > best.y) { best.y = v.y; who.y = k; }
+        if (v.z > best.z) { best.z = v.z; who.z = k; }
+        if (v.w > best.w) { best.w = v.w; who.w = k; }
+    }
+    st4(out + t * 4, best);
+    *reinterpret_cast<int4*>(arg + t * 4) = who;
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ gout,
+                                                          const int32_t* __restrict__ arg,
+                                                          const int32_t* __restrict__ rev_ptr,
+                                                          const int32_t* __restrict__ rev_eid, int K,
+                                                          int64_t m_src, int C4,
+                                                          float* __restrict__ dx) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= m_src * C4) return;
+    const int64_t j = t / C4;
+    const int q = (int)(t - j * C4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int beg = rev_ptr[j], end = rev_ptr[j + 1];
+    for (int p = beg; p < end; ++p) {
+        const int e = rev_eid[p];
+        const int i = e / K, k = e - i * K;
+        const int64_t o = ((int64_t)i * C4 + q) * 4;
+        const int4 who = *reinterpret_cast<const int4*>(arg + o);
+        const float4 g = ld4(gout + o);
+        if (who.x == k) acc.x += g.x;
+        if (who.y == k) acc.y += g.y;
+        if (who.z == k) acc.z += g.z;
+        if (who.w == k) acc.w += g.w;
+    }
+    st4(dx + t * 4, acc);
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x,
+                                                          const int32_t* __restrict__ idx,
+                                                          int64_t m_tgt, int C4,
+                                                          float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= m_tgt * C4) return;
+    const int64_t i = t / C4;
+    const int q = (int)(t - i * C4);
+    st4(out + t * 4, ld4(x + ((int64_t)idx[i] * C4 + q) * 4));
+}
+
+__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __restrict__ gout,
+                                                              const int32_t* __restrict__ rev_ptr,
+                                                              const int32_t* __restrict__ rev_eid,
+                                                              int64_t m_src, int C4,
+                                                              float* __restrict__ dx) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= m_src * C4) return;
+    const int64_t j = t / C4;
+    const int q = (int)(t - j * C4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int beg = rev_ptr[j], end = rev_ptr[j + 1];
+    for (int p = beg; p < end; ++p) {
+        const float4 g = ld4(gout + ((int64_t)rev_eid[p] * C4 + q) * 4);
+        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+    }
+    st4(dx + t * 4, acc);
+}
+
+static int check(int64_t rows, int C) {
+    CRF_REQUIRE(rows > 0 && rows < ((int64_t)1 << 31), CRF_ERR_ARG, "rows=%lld out of range", (long long)rows);
+    CRF_REQUIRE(C > 0 && C % 4 == 0, CRF_ERR_UNSUPPORTED, "channels C=%d must be a positive multiple of 4", C);
+    return CRF_OK;
+}
+
+}  // namespace crf
+
+using namespace crf;
+
+extern "C" int crfconv_neighbor_maxpool_forward(const float* x, const int32_t* idx32, int K, int64_t m_tgt,
+                                                int C, float* out, int32_t* arg, crf_stream_t stream) {
+    if (int rc = check(m_tgt, C)) return rc;
+    CRF_REQUIRE(x && idx32 && out && arg && K >= 1, CRF_ERR_ARG, "null pointer / K");
+    const int64_t n = m_tgt * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), x,
+                       idx32, K, m_tgt, C / 4, out, arg);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_neighbor_maxpool_backward(const float* gout, const int32_t* arg,
+                                                 const int32_t* rev_ptr, const int32_t* rev_eid, int K,
+                                                 int64_t m_src, int C, float* dx, crf_stream_t stream) {
+    if (int rc = check(m_src, C)) return rc;
+    CRF_REQUIRE(gout && arg && rev_ptr && rev_eid && dx && K >= 1, CRF_ERR_ARG, "null pointer / K");
+    const int64_t n = m_src * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream),
+                       gout, arg, rev_ptr, rev_eid, K, m_src, C / 4, dx);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_gather_rows(const float* x, const int32_t* idx32, int64_t m_tgt, int C, float* out,
+                                   crf_stream_t stream) {
+    if (int rc = check(m_tgt, C)) return rc;
+    CRF_REQUIRE(x && idx32 && out, CRF_ERR_ARG, "null pointer");
+    const int64_t n = m_tgt * (C / 4);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), x,
+                       idx32, m_tgt, C / 4, out);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_gather_rows_backward(const float* gout, const int32_t* rev_ptr,
+                                            const int32_t* rev_eid, int64_t m_src, int C, float* dx,
+                                            crf_stream_t stream) {
+    if (int rc = check(m_src, C)) return rc;
+    CRF_REQUIRE(gout && rev_ptr && rev_eid && dx, CRF_ERR_ARG, "null pointer");
+    const int64_t n = m_src * (C / 4);
+    hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream),
+                       gout, rev_ptr, rev_eid, m_src, C / 4, dx);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}

@@ -1,0 +1,80 @@
+"""Batch containers with the fields the reference model reads (torch_geometric ``Data`` /
+torch_points3d ``MultiScaleData`` as used in datasets/semantic3d_dataset.py:527-534) and the
+multiscale collate (``_multiscale_compute_fn``, :501-534) run on the GPU with the HIP kNN."""
+import torch
+
+from .utils import nearest_neighbors
+
+
+class Data:
+    """Attribute bag of tensors with ``.to(device)`` (the part of torch_geometric.data.Data the
+    hot path touches: trainval.py:98 ``data.to(device)``)."""
+
+    def __init__(self, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @property
+    def keys(self):
+        return [k for k in self.__dict__ if not k.startswith('_')]
+
+    def _apply(self, fn):
+        def go(v):
+            if torch.is_tensor(v):
+                return fn(v)
+            if isinstance(v, Data):
+                return v._apply(fn)
+            if isinstance(v, (list, tuple)):
+                return type(v)(go(u) for u in v)
+            return v
+        out = self.__class__.__new__(self.__class__)
+        for k, v in self.__dict__.items():
+            setattr(out, k, go(v))
+        return out
+
+    def to(self, device, non_blocking=False):
+        return self._apply(lambda t: t.to(device, non_blocking=non_blocking))
+
+    def cuda(self):
+        return self.to('cuda')
+
+    def cpu(self):
+        return self.to('cpu')
+
+    def __repr__(self):
+        parts = []
+        for k in self.keys:
+            v = getattr(self, k)
+            parts.append('%s=%s' % (k, list(v.shape) if torch.is_tensor(v) else type(v).__name__))
+        return '%s(%s)' % (self.__class__.__name__, ', '.join(parts))
+
+
+class MultiScaleData(Data):
+    """x [B,N,C], y [B,N], point_idx, cloud_idx, multiscale = [Data(pos, neighbor_idx, sub_idx, up_idx)]."""
+
+    def __init__(self, x=None, y=None, point_idx=None, cloud_idx=None, multiscale=None, **kwargs):
+        super().__init__(x=x, y=y, point_idx=point_idx, cloud_idx=cloud_idx, multiscale=multiscale, **kwargs)
+
+
+def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kernel_size=(16, 16, 16, 16, 16),
+                       ratio=(4, 4, 4, 4, 2), num_scales=5, generator=None, choices=None):
+    """The reference collate on the device (datasets/semantic3d_dataset.py:512-528):
+    per scale  neighbor_idx = knn(pos, pos, K);  one random subset shared by all clouds;
+    sub_idx = neighbor_idx[:, choice];  up_idx = knn(sub_pos, pos, 1).
+
+    pos [B, N, 3] float32 on the GPU.  `choices` (list of index tensors) overrides the random
+    permutations (tests); otherwise torch.randperm(N, generator=generator)[:N // ratio]."""
+    multiscale = []
+    for i in range(num_scales):
+        n = pos.shape[1]
+        neighbor_idx = nearest_neighbors.knn_batch_device(pos, pos, kernel_size[i])
+        if choices is not None:
+            choice = choices[i].to(pos.device)
+        else:
+            choice = torch.randperm(n, generator=generator)[: n // ratio[i]].to(pos.device)
+        sub_pos = pos[:, choice, :].contiguous()
+        sub_idx = neighbor_idx[:, choice, :].contiguous()
+        up_idx = nearest_neighbors.knn_batch_device(sub_pos, pos, 1)
+        multiscale.append(Data(pos=pos, neighbor_idx=neighbor_idx, sub_idx=sub_idx, up_idx=up_idx))
+        pos = sub_pos
+    return MultiScaleData(x=x, y=y, point_idx=point_idx, cloud_idx=cloud_idx, multiscale=multiscale)

@@ -1,0 +1,107 @@
+"""Neighbour tables in the layout the kernels consume.
+
+The reference hands the model int64 ``[B, n_tgt, K]`` per-cloud indices
+(datasets/semantic3d_dataset.py:512-528).  A ``NeighborTable`` is the device-side plan derived
+from one such tensor, built once per batch and shared by every layer that uses it:
+
+  * ``idx32``   int32 ``[B * n_tgt, K]`` GLOBAL source rows (cloud b, id j -> b * n_src + j)
+  * ``rev_ptr`` / ``rev_eid``  source-major CSR over the same edges (built lazily, on the first
+    backward that needs it) so that every backward scatter is a deterministic gather.
+"""
+import torch
+
+from . import _lib
+
+_vp = _lib.ctypes.c_void_p
+
+
+def ptr(t):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def stream_ptr():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.CrfConvError(
+                'crfconv_amd kernels run on MI355X only (got a %s tensor); there is no CPU path' % t.device)
+
+
+class NeighborTable:
+    __slots__ = ('idx32', 'B', 'n_tgt', 'n_src', 'K', '_rev', '_bad', '_checked', 'cache')
+
+    def __init__(self, idx64, n_src, check=True):
+        if idx64.dim() == 2:
+            idx64 = idx64.unsqueeze(-1)
+        if idx64.dim() != 3:
+            raise ValueError('neighbour index must be [B, N, K], got %s' % (tuple(idx64.shape),))
+        require_gpu(idx64)
+        if idx64.dtype != torch.int64:
+            idx64 = idx64.long()
+        idx64 = idx64.contiguous()
+        self.B, self.n_tgt, self.K = idx64.shape
+        self.n_src = int(n_src)
+        self.idx32 = torch.empty((self.B * self.n_tgt, self.K), dtype=torch.int32, device=idx64.device)
+        self._bad = torch.zeros(1, dtype=torch.int32, device=idx64.device)
+        _lib.call('crfconv_index_narrow', ptr(idx64), self.B, self.n_tgt, self.K, self.n_src,
+                  ptr(self.idx32), ptr(self._bad), stream_ptr())
+        self._rev = None
+        self._checked = False
+        self.cache = {}          # per-table memo (e.g. rel-pos moments shared by two ResNet blocks)
+        if check:
+            self.validate()
+
+    def validate(self):
+        """One host sync: refuses tables with out-of-range entries (they were clamped, so nothing
+        can fault, but the result would be meaningless)."""
+        if not self._checked:
+            bad = int(self._bad.item())
+            if bad:
+                raise IndexError('%d neighbour indices outside [0, %d)' % (bad, self.n_src))
+            self._checked = True
+
+    @property
+    def m_tgt(self):
+        return self.B * self.n_tgt
+
+    @property
+    def m_src(self):
+        return self.B * self.n_src
+
+    @property
+    def reverse(self):
+        if self._rev is None:
+            E = self.m_tgt * self.K
+            dev = self.idx32.device
+            rev_ptr = torch.empty(self.m_src + 1, dtype=torch.int32, device=dev)
+            rev_eid = torch.empty(E, dtype=torch.int32, device=dev)
+            nbytes = _lib.load().crfconv_reverse_csr_workspace(E, self.m_src)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.call('crfconv_reverse_csr', ptr(self.idx32), E, self.m_src, ptr(rev_ptr), ptr(rev_eid),
+                      ptr(ws), nbytes, stream_ptr())
+            self._rev = (rev_ptr, rev_eid)
+        return self._rev
+
+
+def table_of(idx, n_src):
+    """Table for an index tensor, memoised on the tensor object (a batch's neighbor_idx is used by
+    two ResNet blocks and one CRF layer; sub_idx by the strided conv and its max-pool)."""
+    if isinstance(idx, NeighborTable):
+        return idx
+    cache = getattr(idx, '_crf_tables', None)
+    if cache is None:
+        cache = {}
+        try:
+            idx._crf_tables = cache
+        except AttributeError:
+            pass
+    key = (int(n_src), idx.data_ptr(), idx._version, tuple(idx.shape))
+    tab = cache.get(key)
+    if tab is None:
+        tab = NeighborTable(idx, n_src)
+        cache.clear()
+        cache[key] = tab
+    return tab

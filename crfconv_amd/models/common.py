@@ -1,0 +1,52 @@
+"""Building blocks with the reference's names, signatures and state_dict layout
+(models/common.py:26-40, 89-97).  FastBatchNorm1d mirrors the torch_points3d module the
+reference imports (BatchNorm1d kept as ``.batch_norm``, statistics over every leading dim)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class FastBatchNorm1d(nn.Module):
+    def __init__(self, num_features, momentum=0.1, **kwargs):
+        super().__init__()
+        self.batch_norm = nn.BatchNorm1d(num_features, momentum=momentum, **kwargs)
+
+    def forward(self, x):
+        if x.dim() not in (2, 3):
+            raise ValueError('Non supported number of dimensions {}'.format(x.dim()))
+        bn = self.batch_norm
+        shape = x.shape
+        use_batch = self.training or bn.running_mean is None
+        if self.training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        y = F.batch_norm(x.reshape(-1, shape[-1]), bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                         use_batch, bn.momentum, bn.eps)
+        return y.reshape(shape)
+
+
+class MLP(nn.Module):
+    """Linear(bias = not bn) -> BatchNorm -> activation (models/common.py:26-40)."""
+
+    def __init__(self, in_channels, out_channels, bn=True, activation=None):
+        super(MLP, self).__init__()
+        self.lin = nn.Linear(in_channels, out_channels, bias=not bn)
+        self.bn = FastBatchNorm1d(out_channels) if bn else None
+        self.activation = activation
+
+    def forward(self, x, *args, **kwargs):
+        x = self.lin(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
+
+
+class Base(nn.Module):
+    """state_dict round trip (models/common.py:89-97)."""
+
+    def save(self, filename):
+        torch.save(self.state_dict(), filename)
+
+    def load(self, filename):
+        self.load_state_dict(torch.load(filename))

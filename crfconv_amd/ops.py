@@ -1,0 +1,324 @@
+"""torch.autograd bindings of the HIP kernels (through the C ABI; see include/crfconv_amd.h).
+
+Every op here runs hand-written gfx950 kernels; torch supplies device memory, the stream and the
+tiny dense algebra on H x H / d x d parameter matrices.
+"""
+import torch
+
+from . import _lib
+from .graph import NeighborTable, ptr, require_gpu, stream_ptr
+
+BN_EPS = 1e-5
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _pad_channels(t, C):
+    """Zero-pad the last dim to C (kernels take power-of-two channel counts; zeros are exact)."""
+    if t.shape[-1] == C:
+        return t
+    return torch.nn.functional.pad(t, (0, C - t.shape[-1]))
+
+
+def _next_supported(c, choices):
+    for v in choices:
+        if c <= v:
+            return v
+    raise _lib.CrfConvError('channel count %d exceeds the largest supported (%d)' % (c, choices[-1]))
+
+
+# ------------------------------------------------------------------------------ CRF mean field
+class _MeanField(torch.autograd.Function):
+    """x_T of  x_0 = z,  x_t = z Q + (A x_{t-1}) P  with A = row-softmax(-|y_i - y_j|^2) over the
+    table's columns k0..K-1  (models/continuous_crf_conv_big.py:49-54, 63-72)."""
+
+    @staticmethod
+    def forward(ctx, z, y, Q, P, table, k0, steps):
+        require_gpu(z, y, Q, P)
+        m, H = z.shape
+        z, y, Q, P = _f32c(z), _f32c(y), _f32c(Q), _f32c(P)
+        Kn = table.K - k0
+        s = torch.empty((m, Kn), dtype=torch.float32, device=z.device)
+        zq = torch.empty_like(z)
+        xs = torch.empty((max(steps, 1), m, H), dtype=torch.float32, device=z.device)
+        _lib.call('crfconv_meanfield_forward', ptr(z), ptr(y), ptr(table.idx32), table.K, k0, m, H, ptr(Q),
+                  ptr(P), steps, ptr(s), ptr(zq), ptr(xs), stream_ptr())
+        ctx.table, ctx.k0, ctx.steps = table, k0, steps
+        ctx.save_for_backward(z, y, Q, P, s, xs)
+        return xs[steps - 1].clone() if steps > 0 else z.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        z, y, Q, P, s, xs = ctx.saved_tensors
+        table, k0, T = ctx.table, ctx.k0, ctx.steps
+        m, H = z.shape
+        G = _f32c(gout)
+        if T == 0:
+            return G, torch.zeros_like(y), torch.zeros_like(Q), torch.zeros_like(P), None, None, None
+        rev_ptr, rev_eid = table.reverse
+        st = stream_ptr()
+        gm = torch.empty_like(z)
+        mt = torch.empty_like(z)
+        ds = torch.empty_like(s)
+        sumG = torch.zeros_like(z)
+        dP = torch.zeros_like(P)
+        for t in range(T, 0, -1):
+            xprev = xs[t - 2] if t >= 2 else z
+            _lib.call('crfconv_meanfield_bwd_edge', ptr(G), ptr(xprev), ptr(s), ptr(table.idx32), table.K, k0,
+                      m, H, ptr(P), ptr(gm), ptr(ds), ptr(mt), 0 if t == T else 1, st)
+            dP.addmm_(mt.t(), G)
+            sumG.add_(G)
+            Gprev = torch.empty_like(z)
+            _lib.call('crfconv_meanfield_bwd_scatter', ptr(gm), ptr(s), ptr(rev_ptr), ptr(rev_eid), table.K, k0,
+                      m, H, None, ptr(Gprev), st)
+            G = Gprev
+        dz = torch.addmm(G, sumG, Q.t())          # x_0 = z path + the z Q term of every step
+        dQ = z.t() @ sumG
+        w = torch.empty_like(s)
+        dy_self = torch.empty_like(y)
+        _lib.call('crfconv_similarity_bwd', ptr(ds), ptr(s), ptr(y), ptr(table.idx32), table.K, k0, m, H, ptr(w),
+                  ptr(dy_self), st)
+        dy = torch.empty_like(y)
+        _lib.call('crfconv_similarity_bwd_scatter', ptr(w), ptr(y), ptr(dy_self), ptr(rev_ptr), ptr(rev_eid),
+                  table.K, k0, m, H, ptr(dy), st)
+        return dz, dy, dQ, dP, None, None, None
+
+
+_CRF_H = (4, 8, 16, 32, 64)
+
+
+def crf_meanfield(z, y, c, table, steps, k0=1):
+    """z, y: [m, H] (flattened clouds);  c: [H, H] compatibility factor (C = c^T c)."""
+    H = z.shape[-1]
+    eye = torch.eye(H, dtype=c.dtype, device=c.device)
+    C = c.t() @ c
+    Q = torch.linalg.inv(eye + C)              # loop-invariant: computed once, not per step
+    P = C @ Q
+    Hp = _next_supported(H, _CRF_H)
+    if Hp != H:                                 # zero channels stay zero through every step
+        Q = torch.nn.functional.pad(Q, (0, Hp - H, 0, Hp - H))
+        P = torch.nn.functional.pad(P, (0, Hp - H, 0, Hp - H))
+    out = _MeanField.apply(_pad_channels(z, Hp), _pad_channels(y, Hp), Q, P, table, k0, steps)
+    return out[:, :H] if Hp != H else out
+
+
+# ------------------------------------------------------------------------------ gather / max-pool
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, table):
+        require_gpu(x)
+        x = _f32c(x)
+        C = x.shape[1]
+        out = torch.empty((table.m_tgt, C), dtype=torch.float32, device=x.device)
+        _lib.call('crfconv_gather_rows', ptr(x), ptr(table.idx32), table.m_tgt, C, ptr(out), stream_ptr())
+        ctx.table, ctx.m_src = table, x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        table = ctx.table
+        g = _f32c(gout)
+        rev_ptr, rev_eid = table.reverse
+        dx = torch.empty((ctx.m_src, g.shape[1]), dtype=torch.float32, device=g.device)
+        _lib.call('crfconv_gather_rows_backward', ptr(g), ptr(rev_ptr), ptr(rev_eid), ctx.m_src, g.shape[1],
+                  ptr(dx), stream_ptr())
+        return dx, None
+
+
+def gather_rows(x, table):
+    """out[i] = x[table[i, 0]] (nearest up-sampling); x [m_src, C], C % 4 == 0."""
+    if table.K != 1:
+        raise ValueError('gather_rows needs a K = 1 table')
+    C = x.shape[1]
+    Cp = (C + 3) // 4 * 4
+    out = _GatherRows.apply(_pad_channels(x, Cp), table)
+    return out[:, :C] if Cp != C else out
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, table):
+        require_gpu(x)
+        x = _f32c(x)
+        C = x.shape[1]
+        out = torch.empty((table.m_tgt, C), dtype=torch.float32, device=x.device)
+        arg = torch.empty((table.m_tgt, C), dtype=torch.int32, device=x.device)
+        _lib.call('crfconv_neighbor_maxpool_forward', ptr(x), ptr(table.idx32), table.K, table.m_tgt, C, ptr(out),
+                  ptr(arg), stream_ptr())
+        ctx.table, ctx.m_src = table, x.shape[0]
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (arg,) = ctx.saved_tensors
+        table = ctx.table
+        g = _f32c(gout)
+        rev_ptr, rev_eid = table.reverse
+        dx = torch.empty((ctx.m_src, g.shape[1]), dtype=torch.float32, device=g.device)
+        _lib.call('crfconv_neighbor_maxpool_backward', ptr(g), ptr(arg), ptr(rev_ptr), ptr(rev_eid), table.K,
+                  ctx.m_src, g.shape[1], ptr(dx), stream_ptr())
+        return dx, None
+
+
+def neighbor_maxpool(x, table):
+    """out[i, c] = max_k x[table[i, k], c]  (models/point_conv_big.py:74-77)."""
+    C = x.shape[1]
+    Cp = (C + 3) // 4 * 4
+    out = _MaxPool.apply(_pad_channels(x, Cp), table)
+    return out[:, :C] if Cp != C else out
+
+
+# ------------------------------------------------------------------------------ PointConv
+def relpos_moments(pos_src, pos_tgt, table):
+    """(mean [3], covariance [3,3], edge count) of rel = p_tgt[i] - p_src[j] over all edges, float64."""
+    require_gpu(pos_src, pos_tgt)
+    dev = pos_src.device
+    out9 = torch.empty(9, dtype=torch.float64, device=dev)
+    nbytes = _lib.load().crfconv_pointconv_workspace(table.m_tgt, table.K, 4)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.call('crfconv_pointconv_moments', ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), table.K, table.m_tgt,
+              ptr(out9), ptr(ws), nbytes, stream_ptr())
+    n = float(table.m_tgt * table.K)
+    mean = out9[:3] / n
+    sec = out9[3:] / n
+    S = torch.stack([torch.stack([sec[0], sec[1], sec[2]]), torch.stack([sec[1], sec[3], sec[4]]),
+                     torch.stack([sec[2], sec[4], sec[5]])])
+    cov = S - torch.outer(mean, mean)
+    return mean, cov, n
+
+
+class _PointConv(torch.autograd.Function):
+    """out[i,c] = sum_k w_ik[c] x[j,c],  w = BN2(W2 lrelu(A1 rel + b1)).
+
+    A1/b1 already hold Linear(3->d) folded with its BatchNorm (differentiable inputs); BatchNorm-2
+    is handled here: batch statistics (train) come from a reduction pass over all edges and their
+    gradient terms from a second one, exactly the textbook BatchNorm backward."""
+
+    @staticmethod
+    def forward(ctx, x, A1, b1, W2, gamma2, beta2, pos_src, pos_tgt, table, mean_rel, bn2_train, run_mean2,
+                run_var2, aux):
+        require_gpu(x, A1, W2, pos_src, pos_tgt)
+        dev = x.device
+        x, A1, b1, W2 = _f32c(x), _f32c(A1), _f32c(b1), _f32c(W2)
+        d = x.shape[1]
+        m_tgt, K = table.m_tgt, table.K
+        st = stream_ptr()
+        nbytes = _lib.load().crfconv_pointconv_workspace(max(m_tgt, table.m_src), K, d)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        n_e = float(m_tgt * K)
+        g2, be2 = gamma2.detach().double(), beta2.detach().double()
+        shift = torch.zeros(d, dtype=torch.float32, device=dev)
+        if bn2_train:
+            stats = torch.empty(2 * d, dtype=torch.float64, device=dev)
+            _lib.call('crfconv_pointconv_stats', ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d, ptr(A1),
+                      ptr(b1), ptr(W2), ptr(_f32c(mean_rel)), ptr(shift), ptr(stats), ptr(ws), nbytes, st)
+            m1 = stats[:d] / n_e
+            mean2 = shift.double() + m1
+            var2 = (stats[d:] / n_e - m1 * m1).clamp_min_(0.0)
+            if aux is not None:
+                aux['mean2'], aux['var2'], aux['n'] = mean2, var2, n_e
+        else:
+            mean2, var2 = run_mean2.detach().double(), run_var2.detach().double()
+        rstd2 = torch.rsqrt(var2 + BN_EPS)
+        a2 = (g2 * rstd2).float()
+        b2 = (be2 - g2 * rstd2 * mean2).float()
+        out = torch.empty((m_tgt, d), dtype=torch.float32, device=dev)
+        _lib.call('crfconv_pointconv_forward', ptr(x), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d,
+                  ptr(A1), ptr(b1), ptr(W2), ptr(a2), ptr(b2), ptr(out), st)
+        ctx.table, ctx.bn2_train, ctx.n_e = table, bn2_train, n_e
+        ctx.save_for_backward(x, A1, b1, W2, a2, b2, shift, mean2, rstd2, g2, pos_src, pos_tgt)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, A1, b1, W2, a2, b2, shift, mean2, rstd2, g2, pos_src, pos_tgt = ctx.saved_tensors
+        table, n_e = ctx.table, ctx.n_e
+        dev = x.device
+        d = x.shape[1]
+        m_tgt, K = table.m_tgt, table.K
+        g = _f32c(gout)
+        st = stream_ptr()
+        nbytes = _lib.load().crfconv_pointconv_workspace(max(m_tgt, table.m_src), K, d)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        # pass 1: sum g_w and sum g_w (h2 - shift)
+        red = torch.empty(2 * d, dtype=torch.float64, device=dev)
+        _lib.call('crfconv_pointconv_bwd_reduce', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
+                  m_tgt, d, ptr(A1), ptr(b1), ptr(W2), ptr(shift), ptr(red), ptr(ws), nbytes, st)
+        sum_gw = red[:d]
+        sum_gwh = rstd2 * (red[d:] - (mean2 - shift.double()) * sum_gw)     # sum g_w * hhat
+        dgamma2, dbeta2 = sum_gwh.float(), sum_gw.float()
+        ca = g2 * rstd2
+        if ctx.bn2_train:
+            mgw, mgh = sum_gw / n_e, sum_gwh / n_e
+            cb = -g2 * rstd2 * rstd2 * mgh
+            cc = -g2 * rstd2 * mgw + g2 * rstd2 * rstd2 * mean2 * mgh
+        else:
+            cb = torch.zeros_like(ca)
+            cc = torch.zeros_like(ca)
+        # pass 2: parameter gradients
+        par = torch.empty(d * d + 4 * d, dtype=torch.float64, device=dev)
+        dW2, dA1, db1 = par[:d * d], par[d * d:d * d + 3 * d], par[d * d + 3 * d:]
+        _lib.call('crfconv_pointconv_bwd_params', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
+                  m_tgt, d, ptr(A1), ptr(b1), ptr(W2), ptr(ca.float()), ptr(cb.float()), ptr(cc.float()),
+                  ptr(dW2), ptr(dA1), ptr(db1), ptr(ws), nbytes, st)
+        # input gradient (source-major gather over the reverse table)
+        rev_ptr, rev_eid = table.reverse
+        dx = torch.empty((table.m_src, d), dtype=torch.float32, device=dev)
+        _lib.call('crfconv_pointconv_bwd_input', ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(rev_ptr), ptr(rev_eid), K,
+                  table.m_src, d, ptr(A1), ptr(b1), ptr(W2), ptr(a2), ptr(b2), ptr(dx), st)
+        return (dx, dA1.float().view(d, 3), db1.float(), dW2.float().view(d, d), dgamma2, dbeta2, None, None, None,
+                None, None, None, None, None)
+
+
+_PC_D = (4, 8, 16, 32, 64, 128)
+
+
+def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=0.1, moments=None):
+    """Functional PointConv over flattened clouds.
+
+    x [m_src, d]; pos_* [m, 3]; W1 [d, 3], W2 [d, d] Linear weights (no bias);
+    bn1 / bn2: torch.nn.BatchNorm1d modules (affine + running statistics, updated in training)."""
+    d = x.shape[1]
+    if d not in _PC_D:
+        raise _lib.CrfConvError('PointConv width d=%d not in %s' % (d, _PC_D))
+    pos_src = _f32c(pos_src)
+    pos_tgt = pos_src if pos_tgt is None else _f32c(pos_tgt)
+    if moments is None:
+        moments = relpos_moments(pos_src, pos_tgt, table)
+    mean_rel, cov_rel, n_e = moments
+    # ---- BatchNorm-1 folded into the first Linear; batch statistics are analytic in (mean, cov) of rel
+    W1d = W1.double()
+    use_batch1 = training or bn1.running_mean is None
+    if use_batch1:
+        mean1 = W1d @ mean_rel
+        var1 = ((W1d @ cov_rel) * W1d).sum(1).clamp_min(0.0)
+        if training and bn1.running_mean is not None:
+            with torch.no_grad():
+                mom = momentum if bn1.momentum is None else bn1.momentum
+                bn1.running_mean.mul_(1 - mom).add_(mom * mean1.detach().float())
+                bn1.running_var.mul_(1 - mom).add_(mom * (var1.detach() * (n_e / max(n_e - 1.0, 1.0))).float())
+                bn1.num_batches_tracked += 1
+    else:
+        mean1, var1 = bn1.running_mean.double(), bn1.running_var.double()
+    a1 = bn1.weight.double() * torch.rsqrt(var1 + bn1.eps)
+    A1 = (a1.unsqueeze(1) * W1d).float()
+    b1 = (bn1.bias.double() - a1 * mean1).float()
+    # ---- the fused kernels (BatchNorm-2 inside)
+    use_batch2 = training or bn2.running_mean is None
+    aux = {} if use_batch2 else None
+    out = _PointConv.apply(x, A1, b1, W2, bn2.weight, bn2.bias, pos_src, pos_tgt, table, mean_rel.float(),
+                           use_batch2, bn2.running_mean, bn2.running_var, aux)
+    if training and use_batch2 and bn2.running_mean is not None:
+        with torch.no_grad():
+            mom = momentum if bn2.momentum is None else bn2.momentum
+            n = aux['n']
+            bn2.running_mean.mul_(1 - mom).add_(mom * aux['mean2'].float())
+            bn2.running_var.mul_(1 - mom).add_(mom * (aux['var2'] * (n / max(n - 1.0, 1.0))).float())
+            bn2.num_batches_tracked += 1
+    return out
+
+
+__all__ = ['crf_meanfield', 'gather_rows', 'neighbor_maxpool', 'relpos_moments', 'point_conv', 'NeighborTable']

@@ -1,0 +1,202 @@
+/* libcrfconv_amd.so -- C ABI of the MI355X (gfx950) CRFConv hot path.
+ *
+ * Plain pointers and sizes only (no torch / C++ types).  Two groups of entry points:
+ *
+ *  (A) Replacements for the reference's native extensions -- exactly what its FFI binds:
+ *        utils/nearest_neighbors/knn_.h:2-19          (cpp_knn / cpp_knn_omp / cpp_knn_batch / cpp_knn_batch_omp)
+ *        utils/cpp_wrappers/cpp_subsampling/grid_subsampling/grid_subsampling.h:84-91 (grid_subsampling)
+ *      Host-pointer forms keep the reference signatures (same argument order and meaning,
+ *      caller-owned buffers); `_dev` forms take device pointers + a hipStream_t and are what the
+ *      Python host (crfconv_amd.utils.nearest_neighbors / cpp_subsampling) drives.
+ *
+ *  (B) The fused device kernels behind the nn.Module mirrors (crfconv_amd.models):
+ *        CRF mean field   <- models/continuous_crf_conv_big.py:49-54, 63-72 (+ sparse :56-67)
+ *        PointConv        <- models/point_conv_big.py:37-58
+ *        neighbour max-pool / nearest up-sampling <- models/point_conv_big.py:74-77, 97-101
+ *      All tensors are dense row-major fp32; neighbour tables are int32 GLOBAL row ids
+ *      (cloud b, local id j  ->  b * n_src + j) produced once per batch by crfconv_index_narrow.
+ *
+ * Every function returns CRF_OK (0) or a negative error code; crfconv_last_error() gives the
+ * message (thread-local).  Device entry points only enqueue work on `stream`; they never
+ * allocate or synchronise unless their comment says so (workspace is caller-provided), so they
+ * can be captured into a hipGraph.
+ */
+#ifndef CRFCONV_AMD_H
+#define CRFCONV_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* crf_stream_t; /* hipStream_t */
+
+enum {
+    CRF_OK = 0,
+    CRF_ERR_ARG = -1,         /* bad shape / null pointer / unsupported size */
+    CRF_ERR_HIP = -2,         /* a HIP runtime call failed */
+    CRF_ERR_UNSUPPORTED = -3, /* valid request outside what the kernels implement */
+    CRF_ERR_WORKSPACE = -4    /* workspace too small (size query tells how much) */
+};
+
+#define CRFCONV_ABI_VERSION 1
+int crfconv_abi_version(void);
+const char* crfconv_last_error(void);
+
+/* ===================================================================== (A) kNN
+ * Exact K nearest neighbours, float32 squared L2 accumulated x->y->z with one rounding per
+ * operation (nanoflann.hpp:323-347), ascending distance, ties to the lower point index.
+ * dim must be 3 (every reference call site: datasets/semantic3d_dataset.py:498, s3dis_dataset.py:413).
+ * K <= 64, K <= npts. */
+
+/* Host buffers; reference signatures knn_.h:2-19 (void return there; int status here). */
+int crfconv_knn(const float* points, size_t npts, size_t dim, const float* queries, size_t nqueries,
+                size_t K, long* indices);
+int crfconv_knn_omp(const float* points, size_t npts, size_t dim, const float* queries,
+                    size_t nqueries, size_t K, long* indices);
+int crfconv_knn_batch(const float* batch_data, size_t batch_size, size_t npts, size_t dim,
+                      const float* queries, size_t nqueries, size_t K, long* batch_indices);
+int crfconv_knn_batch_omp(const float* batch_data, size_t batch_size, size_t npts, size_t dim,
+                          const float* queries, size_t nqueries, size_t K, long* batch_indices);
+
+/* Device buffers.  out_i64 / out_i32: either may be NULL; [B, nq, K] per-cloud LOCAL indices. */
+size_t crfconv_knn_batch_dev_workspace(size_t batch_size, size_t npts, size_t nqueries, size_t K);
+int crfconv_knn_batch_dev(const float* pts, size_t batch_size, size_t npts, size_t dim,
+                          const float* queries, size_t nqueries, size_t K, int64_t* out_i64,
+                          int32_t* out_i32, void* workspace, size_t workspace_bytes,
+                          crf_stream_t stream);
+
+/* ===================================================================== (A) grid subsampling
+ * Barycentre / mean feature / majority label per voxel of edge `sampleDl`
+ * (grid_subsampling.cpp:5-106).  Rows are emitted in ascending voxel key (the reference emits
+ * hash-map order).  Returns M >= 0 (rows written) or a negative error; if M > cap nothing past
+ * `cap` rows is written and -(M) ... is NOT used: the function returns CRF_ERR_WORKSPACE and
+ * crfconv_last_error() states the required capacity.  feats/classes may be NULL. */
+int64_t crfconv_grid_subsample(const float* points, int64_t N, const float* feats, int fdim,
+                               const int32_t* classes, int ldim, float sampleDl, float* out_points,
+                               float* out_feats, int32_t* out_classes, int64_t cap);
+size_t crfconv_grid_subsample_dev_workspace(int64_t N, int fdim, int ldim);
+/* Device buffers; synchronises `stream` once (the row count comes back to the host). */
+int64_t crfconv_grid_subsample_dev(const float* points, int64_t N, const float* feats, int fdim,
+                                   const int32_t* classes, int ldim, float sampleDl,
+                                   float* out_points, float* out_feats, int32_t* out_classes,
+                                   int64_t cap, void* workspace, size_t workspace_bytes,
+                                   crf_stream_t stream);
+
+/* ===================================================================== (B) neighbour tables
+ * idx64 [B, n_tgt, K] per-cloud local ids into n_src points  ->  idx32 [B*n_tgt, K] global rows.
+ * Out-of-range entries are clamped and counted into *bad_count (device int32, caller zeroes it);
+ * the host must check it before any kernel consumes the table. */
+int crfconv_index_narrow(const int64_t* idx64, int64_t B, int64_t n_tgt, int K, int64_t n_src,
+                         int32_t* idx32, int32_t* bad_count, crf_stream_t stream);
+
+/* Reverse (source-major) CSR of a table idx32 [E] with values in [0, m_src):
+ * rev_ptr [m_src + 1], rev_eid [E] = edge ids e (= row * K + k) grouped by source row, ascending
+ * e inside a group (deterministic summation order for every backward scatter). */
+size_t crfconv_reverse_csr_workspace(int64_t E, int64_t m_src);
+int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_src, int32_t* rev_ptr,
+                        int32_t* rev_eid, void* workspace, size_t workspace_bytes,
+                        crf_stream_t stream);
+
+/* ===================================================================== (B) CRF mean field
+ * Rows m = B*N (flattened clouds), H hidden channels (4, 8, 16, 32 or 64).
+ * Neighbour columns k0 .. K-1 of idx32 are used (k0 = 1 drops the self column,
+ * continuous_crf_conv_big.py:45-47); Kn = K - k0 <= 63.
+ *   s[i,k]  = softmax_k( -|y_i - y_j(i,k)|^2 )                       (:49-54)
+ *   x_0 = z ;  x_t = z Q + (sum_k s[i,k] x_{t-1}[j(i,k)]) P          (:68-72 with Q = (I+C)^-1, P = C Q)
+ * Outputs: s [m, Kn];  zq [m, H] = z Q;  xs [T, m, H] = x_1 .. x_T. */
+int crfconv_meanfield_forward(const float* z, const float* y, const int32_t* idx32, int K, int k0,
+                              int64_t m, int H, const float* Q, const float* P, int T, float* s,
+                              float* zq, float* xs, crf_stream_t stream);
+
+/* One backward step, edge half:  given G = dL/dx_t and x_{t-1}:
+ *   gm  = G P^T                              [m, H]
+ *   ds (+)= <gm_i, x_{t-1}[j(i,k)]>          [m, Kn]   (accumulate != 0 adds to ds)
+ *   mt  = sum_k s[i,k] x_{t-1}[j(i,k)]       [m, H]    (for dP = mt^T G; may be NULL) */
+int crfconv_meanfield_bwd_edge(const float* G, const float* xprev, const float* s,
+                               const int32_t* idx32, int K, int k0, int64_t m, int H,
+                               const float* P, float* gm, float* ds, float* mt, int accumulate,
+                               crf_stream_t stream);
+/* Scatter half:  Gprev[j] = (add ? add[j] : 0) + sum_{e=(i,k) in rev(j), k>=k0} s[i,k-k0] gm[i]. */
+int crfconv_meanfield_bwd_scatter(const float* gm, const float* s, const int32_t* rev_ptr,
+                                  const int32_t* rev_eid, int K, int k0, int64_t m_src, int H,
+                                  const float* add, float* Gprev, crf_stream_t stream);
+/* Softmax + distance backward.  In: ds, s.  Out: w [m, Kn] = 2 * d(loss)/d(dist_ik) (must NOT
+ * alias ds), dy_self[i] = sum_k w_ik (y_i - y_j). */
+int crfconv_similarity_bwd(const float* ds, const float* s, const float* y, const int32_t* idx32,
+                           int K, int k0, int64_t m, int H, float* w, float* dy_self,
+                           crf_stream_t stream);
+/* dy[j] = dy_self[j] + sum_{e=(i,k) in rev(j), k>=k0} w[i,k-k0] (y_j - y_i). */
+int crfconv_similarity_bwd_scatter(const float* w, const float* y, const float* dy_self,
+                                   const int32_t* rev_ptr, const int32_t* rev_eid, int K, int k0,
+                                   int64_t m_src, int H, float* dy, crf_stream_t stream);
+
+/* ===================================================================== (B) PointConv
+ * Depth-wise point convolution with its per-edge weight MLP recomputed on the fly
+ * (point_conv_big.py:37-58):  for target row i, neighbour j = idx32[i,k]:
+ *   rel = p_tgt[i] - p_src[j];  h1 = lrelu_0.1(A1 rel + b1);  h2 = W2 h1;  w = a2*h2 + b2
+ *   out[i,c] = sum_k w[c] * x[j,c]
+ * A1 [d,3], b1 [d] fold Linear(3->d) with its BatchNorm; W2 [d,d] row-major [out,in];
+ * a2,b2 [d] fold the second BatchNorm.  d in {4,8,16,32,64,128}; K <= 64. */
+
+/* First and second moments of rel over all edges: out9 = {sum x,y,z, sum xx,xy,xz,yy,yz,zz}
+ * as float64 (BatchNorm-1 batch statistics are analytic in these). */
+size_t crfconv_pointconv_workspace(int64_t m_tgt, int K, int d);
+int crfconv_pointconv_moments(const float* pos_src, const float* pos_tgt, const int32_t* idx32,
+                              int K, int64_t m_tgt, double* out9, void* workspace,
+                              size_t workspace_bytes, crf_stream_t stream);
+/* Batch statistics of h2 over all edges: stats [2, d] float64 = {sum(h2 - shift), sum (h2 - shift)^2},
+ * shift [d] float32 out (= h2 at the mean rel; variance is shift-invariant). */
+int crfconv_pointconv_stats(const float* pos_src, const float* pos_tgt, const int32_t* idx32, int K,
+                            int64_t m_tgt, int d, const float* A1, const float* b1,
+                            const float* W2, const float* mean_rel3, float* shift, double* stats,
+                            void* workspace, size_t workspace_bytes, crf_stream_t stream);
+int crfconv_pointconv_forward(const float* x, const float* pos_src, const float* pos_tgt,
+                              const int32_t* idx32, int K, int64_t m_tgt, int d, const float* A1,
+                              const float* b1, const float* W2, const float* a2, const float* b2,
+                              float* out, crf_stream_t stream);
+/* Backward reductions, pass 1:  red1 [2, d] float64 = {sum_e g_w, sum_e g_w * (h2 - shift)} with
+ * g_w[e,c] = gout[i,c] * x[j,c]  (BatchNorm-2 backward needs both before pass 2). */
+int crfconv_pointconv_bwd_reduce(const float* x, const float* gout, const float* pos_src,
+                                 const float* pos_tgt, const int32_t* idx32, int K, int64_t m_tgt,
+                                 int d, const float* A1, const float* b1, const float* W2,
+                                 const float* shift, double* red1, void* workspace, size_t workspace_bytes,
+                                 crf_stream_t stream);
+/* Pass 2:  g_h2[e,c] = ca[c] * g_w[e,c] + cb[c] * h2[e,c] + cc[c]  (the host folds BatchNorm-2's
+ * backward into ca/cb/cc; eval mode: ca = a2, cb = cc = 0), then back through W2, lrelu, A1:
+ *   dW2 [d,d], dA1 [d,3], db1 [d]  as float64 sums. */
+int crfconv_pointconv_bwd_params(const float* x, const float* gout, const float* pos_src,
+                                 const float* pos_tgt, const int32_t* idx32, int K, int64_t m_tgt,
+                                 int d, const float* A1, const float* b1, const float* W2,
+                                 const float* ca, const float* cb, const float* cc, double* dW2,
+                                 double* dA1, double* db1, void* workspace, size_t workspace_bytes,
+                                 crf_stream_t stream);
+/* dx[j,c] = sum_{e=(i,k) in rev(j)} w_e[c] * gout[i,c]   (weight MLP recomputed per incoming edge). */
+int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const float* pos_tgt,
+                                const int32_t* rev_ptr, const int32_t* rev_eid, int K,
+                                int64_t m_src, int d, const float* A1, const float* b1,
+                                const float* W2, const float* a2, const float* b2, float* dx,
+                                crf_stream_t stream);
+
+/* ===================================================================== (B) pooling / up-sampling
+ * out[i,c] = max_k x[idx32[i,k], c];  arg [m_tgt, C] int32 = winning k (first maximum). */
+int crfconv_neighbor_maxpool_forward(const float* x, const int32_t* idx32, int K, int64_t m_tgt,
+                                     int C, float* out, int32_t* arg, crf_stream_t stream);
+/* dx[j,c] = sum over incoming edges (i,k) with arg[i,c] == k of gout[i,c]. */
+int crfconv_neighbor_maxpool_backward(const float* gout, const int32_t* arg,
+                                      const int32_t* rev_ptr, const int32_t* rev_eid, int K,
+                                      int64_t m_src, int C, float* dx, crf_stream_t stream);
+/* out[i] = x[idx32[i]]  (K = 1 table: nearest up-sampling, point_conv_big.py:97-101). */
+int crfconv_gather_rows(const float* x, const int32_t* idx32, int64_t m_tgt, int C, float* out,
+                        crf_stream_t stream);
+/* dx[j] = sum_{i in rev(j)} gout[i]. */
+int crfconv_gather_rows_backward(const float* gout, const int32_t* rev_ptr,
+                                 const int32_t* rev_eid, int64_t m_src, int C, float* dx,
+                                 crf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRFCONV_AMD_H */

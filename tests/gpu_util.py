@@ -1,0 +1,33 @@
+"""Helpers shared by the -m gpu parity tests."""
+import numpy as np
+import torch
+
+DEV = 'cuda'
+
+
+def t(a, dtype=None, dev=DEV):
+    x = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        x = x.to(dtype)
+    return x.to(dev)
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+def assert_close(a, b, tol, what=''):
+    e = relerr(a, b)
+    assert e <= tol, '%s: max err (rel. to max(1,|ref|)) %.3e > %.1e' % (what, e, tol)
+
+
+def load_sd(module, sd_np):
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
+    module.load_state_dict(sd, strict=True)
+    return module
+
+
+def grads(module):
+    return {k: p.grad for k, p in module.named_parameters() if p.grad is not None}

@@ -1,0 +1,156 @@
+"""-m gpu: kNN and grid-subsampling HIP kernels against the oracle (bit-exact) and the fixtures
+captured from the reference's compiled C++ (tests/golden/g6_knn.npz, g7_grid.npz)."""
+import numpy as np
+import pytest
+import torch
+
+import _seeded as S
+from oracle import native as onative
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def nn_mod():
+    from crfconv_amd.utils import nearest_neighbors
+    return nearest_neighbors
+
+
+@pytest.mark.parametrize('K', [1, 16, 32])
+def test_knn_golden_host_api(golden, nn_mod, K):
+    g = golden('g6_knn.npz')
+    a = nn_mod.knn_batch(g['pts'], g['pts'], K, omp=True)
+    b = nn_mod.knn_batch(torch.from_numpy(g['pts']), g['qry'], K)
+    assert a.dtype == np.int64 and a.shape == (2, 2048, K)
+    assert np.array_equal(a, g['self_K%d' % K].astype(np.int64))
+    assert np.array_equal(b, g['cross_K%d' % K].astype(np.int64))
+    assert np.array_equal(nn_mod.knn(g['pts'][1], g['qry'][1], K), b[1])
+    assert np.array_equal(nn_mod.knn(g['pts'][0], g['pts'][0], K, omp=True), a[0])
+
+
+def test_knn_lattice_distance_rows(golden, nn_mod):
+    g = golden('g6_knn.npz')
+    lat = g['lattice_pts']
+    idx = nn_mod.knn(lat, lat, 16)
+    assert np.array_equal(onative.knn_sq_dists(lat, lat, idx), g['lattice_dists'])
+    # ties -> (distance, index) order, which is what the oracle restates
+    assert np.array_equal(idx, onative.oracle_knn(lat, lat, 16))
+
+
+@pytest.mark.parametrize('B,Np,Nq,K,box', [
+    (1, 16, 16, 16, (1, 1, 1)),            # K == npts
+    (3, 1000, 257, 8, (1, 1, 1)),          # K between template sizes, ragged block
+    (2, 5000, 5000, 16, (8, 8, 0)),        # planar cloud (degenerate z extent)
+    (2, 3000, 700, 33, (60, 1, 1)),        # elongated, K > 32 path
+    (1, 1, 5, 1, (1, 1, 1)),               # single support point
+    (4, 40960, 40960, 16, (8, 8, 3)),      # BASELINE config-2 level-0 shape
+])
+def test_knn_vs_oracle(nn_mod, B, Np, Nq, K, box):
+    pts = np.stack([S.make_cloud(900 + b, Np, box=box) for b in range(B)])
+    if Nq == Np:
+        qry = pts
+    else:  # queries partly outside the support bounding box
+        qry = np.stack([S.make_cloud(950 + b, Nq, box=box) * 1.3 - 0.1 for b in range(B)]).astype(np.float32)
+    dev = nn_mod.knn_batch_device(torch.from_numpy(pts).cuda(), torch.from_numpy(qry).cuda(), K)
+    want = onative.oracle_knn_batch(pts, qry, K)
+    got = dev.cpu().numpy()
+    assert got.dtype == np.int64
+    assert np.array_equal(got, want)
+    i32 = nn_mod.knn_batch_device(torch.from_numpy(pts).cuda(), torch.from_numpy(qry).cuda(), K, torch.int32)
+    assert np.array_equal(i32.cpu().numpy().astype(np.int64), want)
+
+
+def test_knn_duplicates_and_errors(nn_mod):
+    base = S.make_cloud(7, 500)
+    pts = np.concatenate([base, base[:100]])[None]           # exact duplicates
+    got = nn_mod.knn_batch(pts, pts, 8)
+    assert np.array_equal(got, onative.oracle_knn_batch(pts, pts, 8))
+    from crfconv_amd._lib import CrfConvError
+    with pytest.raises(CrfConvError):
+        nn_mod.knn_batch(pts, pts, 700)                      # K > npts
+    with pytest.raises(CrfConvError):
+        nn_mod.knn_batch(np.zeros((1, 10, 2), np.float32), np.zeros((1, 10, 2), np.float32), 2)   # dim != 3
+
+
+def test_knn_large_properties(nn_mod):
+    """~1M-point scene (BASELINE config 5 scale), K=32: size-independent properties + a sampled
+    brute-force check on the device."""
+    n = 1 << 20
+    g = torch.Generator().manual_seed(5)
+    pts = (torch.rand(1, n, 3, generator=g) * torch.tensor([60.0, 60.0, 15.0])).cuda()
+    idx = nn_mod.knn_batch_device(pts, pts, 32)
+    p = pts[0]
+    nb = p[idx[0]]                                           # [n, 32, 3]
+    d = ((p[:, None, :] - nb) ** 2).sum(-1)
+    assert bool((idx[0, :, 0] == torch.arange(n, device='cuda')).all())      # self first
+    assert bool((d[:, 1:] >= d[:, :-1] - 1e-6).all())                        # ascending
+    rows = torch.randint(0, n, (256,), generator=g).cuda()
+    full = ((p[rows][:, None, :] - p[None, :, :]) ** 2).sum(-1)              # [256, n]
+    kth = full.topk(32, largest=False).values[:, -1]
+    assert torch.allclose(d[rows, -1], kth, rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------ grid subsampling
+def _rekey_rows(pts_in, dl, rows):
+    op, _, _, okeys = onative.oracle_grid_subsample(pts_in, None, None, dl)
+    lut = {tuple(p): k for p, k in zip(map(tuple, op), okeys)}
+    return np.array([lut[tuple(p)] for p in map(tuple, rows)], dtype=np.uint64)
+
+
+@pytest.mark.parametrize('name', ['all', 'two', 'ponly', 'fonly', 'conly'])
+def test_grid_golden(golden, name):
+    from crfconv_amd.utils import cpp_subsampling
+    g = golden('g7_grid.npz')
+    dl = float(g[name + '/dl'])
+    kw = {}
+    if name in ('all', 'two', 'fonly'):
+        kw['features'] = g['feats']
+    if name in ('all', 'conly'):
+        kw['classes'] = g['lab1']
+    if name == 'two':
+        kw['classes'] = g['lab2']
+    res = cpp_subsampling.compute(g['pts'], sampleDl=dl, **kw)
+    want = onative.oracle_grid_subsample(g['pts'], kw.get('features'), kw.get('classes'), dl)
+    if name == 'ponly':
+        assert isinstance(res, np.ndarray)
+        res = (res,)
+    else:
+        assert isinstance(res, tuple) and len(res) == 1 + len(kw)
+    assert np.array_equal(res[0], want[0])                   # bit-exact vs the oracle, same row order
+    order = np.argsort(_rekey_rows(g['pts'], dl, g[name + '/pts']), kind='stable')
+    assert np.array_equal(res[0], g[name + '/pts'][order])   # bit-exact vs the reference, re-keyed
+    i = 1
+    if 'features' in kw:
+        assert res[i].dtype == np.float32
+        assert np.array_equal(res[i], want[1])
+        assert np.array_equal(res[i], g[name + '/feats'][order])
+        i += 1
+    if 'classes' in kw:
+        assert res[i].dtype == np.int32 and res[i].ndim == 2
+        assert np.array_equal(res[i], want[2])
+
+
+def test_grid_errors_and_shapes():
+    from crfconv_amd.utils import cpp_subsampling
+    pts = S.make_cloud(3, 100)
+    with pytest.raises(RuntimeError, match='points.shape is not'):
+        cpp_subsampling.compute(pts[:, :2])
+    with pytest.raises(RuntimeError, match='features.shape is not'):
+        cpp_subsampling.compute(pts, features=np.zeros((99, 3), np.float32))
+    with pytest.raises(RuntimeError, match='Error parsing method'):
+        cpp_subsampling.compute(pts, method='nope')
+    with pytest.raises(TypeError):
+        cpp_subsampling.compute(pts, np.zeros((100, 3), np.float32))      # keyword-only
+    one = cpp_subsampling.compute(pts, sampleDl=10.0)                      # everything in one voxel
+    assert one.shape == (1, 3)
+
+
+def test_grid_large_vs_oracle():
+    from crfconv_amd.utils import cpp_subsampling
+    n = 2_000_000
+    pts = S.make_cloud(11, n, box=(30.0, 30.0, 8.0))
+    feats = S.uniform(11, 'f', (n, 3), 0, 255)
+    lab = S.integers(11, 'l', (n,), 0, 9).astype(np.int32)
+    p, f, c = cpp_subsampling.compute(pts, features=feats, classes=lab, sampleDl=0.06)
+    wp, wf, wc, _ = onative.oracle_grid_subsample(pts, feats, lab, 0.06)
+    assert np.array_equal(p, wp) and np.array_equal(f, wf) and np.array_equal(c, wc)
