@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): M points/s, fwd+bwd(+SGD step) of PointConvBig with CRF decoders on
+synthetic S3DIS-like clouds -- 4 clouds x 40960 points per GPU, K=16, 3 mean-field steps.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  "roofline":     the level-0 CRF mean-field forward (similarity + T steps) against the 8 TB/s HBM peak,
+                  algorithmic bytes = m * (4 (K-1) + 4 H (2 T + 1))  (SURVEY.md 8(d)), timed with HIP events
+  "cpu_baseline": the CPU oracle (oracle/crf_oracle.py, a port of the reference op sequence) on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12           # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+BOX = (8.0, 8.0, 3.0)
+VOX = 0.04
+
+
+def synth_cloud(seed, n):
+    """One point per occupied 4 cm voxel of an 8 x 8 x 3 m box, jittered +-1 cm."""
+    rng = np.random.default_rng(seed)
+    dims = np.array([int(b / VOX) for b in BOX])
+    flat = rng.choice(int(dims.prod()), size=n, replace=False)
+    ijk = np.stack(np.unravel_index(flat, dims), -1).astype(np.float64)
+    xyz = (ijk + 0.5) * VOX + rng.uniform(-0.01, 0.01, (n, 3))
+    rgb = rng.uniform(0, 1, (n, 3))
+    lab = rng.integers(1, 14, n)
+    return xyz.astype(np.float32), rgb.astype(np.float32), lab.astype(np.int64)
+
+
+def make_batch(rank, B, N, dev, gen):
+    import crfconv_amd
+    clouds = [synth_cloud(rank * B + i, N) for i in range(B)]
+    pos = torch.from_numpy(np.stack([c[0] for c in clouds])).to(dev)
+    x = torch.cat([pos, torch.from_numpy(np.stack([c[1] for c in clouds])).to(dev)], -1)
+    y = torch.from_numpy(np.stack([c[2] for c in clouds])).to(dev)
+    t0 = time.perf_counter()
+    data = crfconv_amd.multiscale_compute(pos, x=x, y=y, generator=gen)
+    torch.cuda.synchronize()
+    return data, time.perf_counter() - t0
+
+
+def roofline_meanfield(data, dev, H=8, T=3, iters=50):
+    """Level-0 CRF mean-field forward alone, HIP-event timed on the stream it is launched on."""
+    from crfconv_amd import _lib
+    from crfconv_amd.graph import ptr, stream_ptr, table_of
+    ms0 = data.multiscale[0]
+    B, N, K = ms0.neighbor_idx.shape
+    m = B * N
+    tab = table_of(ms0.neighbor_idx, N)
+    g = torch.Generator(device='cpu').manual_seed(1)
+    z = torch.randn(m, H, generator=g).to(dev)
+    y = torch.randn(m, H, generator=g).to(dev)
+    c = torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)
+    C = c.t() @ c
+    Q = torch.linalg.inv(torch.eye(H) + C)
+    P = (C @ Q).to(dev).contiguous()
+    Q = Q.to(dev).contiguous()
+    s = torch.empty(m, K - 1, device=dev)
+    zq = torch.empty(m, H, device=dev)
+    xs = torch.empty(T, m, H, device=dev)
+    st = stream_ptr()
+
+    def launch():
+        _lib.call('crfconv_meanfield_forward', ptr(z), ptr(y), ptr(tab.idx32), K, 1, m, H, ptr(Q), ptr(P), T, ptr(s),
+                  ptr(zq), ptr(xs), st)
+    for _ in range(10):
+        launch()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        launch()
+        b.record()
+    torch.cuda.synchronize()
+    dur = np.array([a.elapsed_time(b) for a, b in evs]) * 1e-3
+    alg_bytes = m * (4 * (K - 1) + 4 * H * (2 * T + 1))
+    avg = float(dur.mean())
+    return {'bound': 'hbm', 'achieved': alg_bytes / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+            'frac': alg_bytes / avg / HBM_PEAK, 'traffic': None, 'kernel': 'crfconv_meanfield_forward level-0 '
+            '(sim_kernel + %d x step_kernel, m=%d, H=%d, K=%d)' % (T, m, H, K),
+            'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': avg * 1e6, 'min_launch_us': float(dur.min()) * 1e6}
+
+
+def cpu_baseline(data, net, steps_T, labels, n_cls):
+    """The CPU oracle's fwd+bwd on ONE of this rank's clouds (bounded sample), host cores as configured."""
+    from oracle import crf_oracle as O
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    prm = {k: v.requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    ms = [{k: getattr(l, k)[:1].cpu() for k in ('pos', 'neighbor_idx', 'sub_idx', 'up_idx')} for l in data.multiscale]
+    x = data.x[:1].cpu()
+    y = labels[:1].cpu()
+    n = x.shape[1]
+
+    def step():
+        for v in prm.values():
+            v.grad = None
+        logits = O.pointconv_resnet(prm, x, ms, steps_T, True, True)
+        O.training_loss(logits, y).backward()
+    step()                                   # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        step()
+    dt = (time.perf_counter() - t0) / reps
+    return {'value': n / dt / 1e6, 'unit': 'M points/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 cloud x %d pts, K=16, T=%d, oracle/crf_oracle.py fwd+bwd (train mode), %d reps after 1 '
+                      'warm-up, %.2f s each; os.cpu_count()=%d' % (n, steps_T, reps, dt, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=4, help='clouds per GPU')
+    ap.add_argument('--points', type=int, default=40960)
+    ap.add_argument('--crf-steps', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import crfconv_amd
+    from crfconv_amd import distributed as D
+    from crfconv_amd import models
+
+    rank, world, local = D.init_from_env()
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    B, N, T, n_cls = args.batch, args.points, args.crf_steps, 13
+
+    gen = torch.Generator().manual_seed(1234 + rank)
+    data, t_pre = make_batch(rank, B, N, dev, gen)
+    torch.manual_seed(0)
+    net = models.PointConvBig(6, n_cls, use_crf=True, steps=T).to(dev).train()
+    D.broadcast_parameters(net)
+    bucket = D.FlatGradAllReduce(net)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2, momentum=0.95, weight_decay=1e-4)
+    cw = torch.ones(n_cls, device=dev)
+
+    def step():
+        bucket.zero()
+        logits = net(data)
+        loss = torch.nn.functional.cross_entropy(logits, data.y.reshape(-1) - 1, weight=cw, ignore_index=-1)
+        loss.backward()
+        bucket.allreduce_mean()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * N / (dt / args.steps) / 1e6
+
+    if rank == 0:
+        out = {
+            'metric': 'M points/sec fwd+bwd, S3DIS 40960-pt cloud, K=16, 3 CRF iters',
+            'value': value, 'unit': 'M points/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: S3DIS-like synthetic clouds (one point per 4 cm voxel of an '
+                                   '8x8x3 m box), %d clouds x %d pts per GPU, K=16, ratios [4,4,4,4,2], '
+                                   'PointConvBig(in=6, classes=13, use_crf, steps=%d), train mode: fwd + weighted CE + '
+                                   'bwd + flat-bucket grad all-reduce + SGD(momentum) step; tables resident in HBM'
+                                   % (B, N, T),
+                       'global_batch': world * B, 'points_per_cloud': N, 'parallelism': 'dp%d (batch-sharded)' % world},
+            'final_loss': float(loss),
+            'preprocess_ms_per_batch': t_pre * 1e3,
+        }
+        out['roofline'] = roofline_meanfield(data, dev, 8, T)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(data, net, T, data.y, n_cls)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

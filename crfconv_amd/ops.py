@@ -213,8 +213,9 @@ class _PointConv(torch.autograd.Function):
         shift = torch.zeros(d, dtype=torch.float32, device=dev)
         if bn2_train:
             stats = torch.empty(2 * d, dtype=torch.float64, device=dev)
+            mean_rel = _f32c(mean_rel)          # keep every kernel operand alive in a local
             _lib.call('crfconv_pointconv_stats', ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d, ptr(A1),
-                      ptr(b1), ptr(W2), ptr(_f32c(mean_rel)), ptr(shift), ptr(stats), ptr(ws), nbytes, st)
+                      ptr(b1), ptr(W2), ptr(mean_rel), ptr(shift), ptr(stats), ptr(ws), nbytes, st)
             m1 = stats[:d] / n_e
             mean2 = shift.double() + m1
             var2 = (stats[d:] / n_e - m1 * m1).clamp_min_(0.0)
@@ -261,8 +262,11 @@ class _PointConv(torch.autograd.Function):
         # pass 2: parameter gradients
         par = torch.empty(d * d + 4 * d, dtype=torch.float64, device=dev)
         dW2, dA1, db1 = par[:d * d], par[d * d:d * d + 3 * d], par[d * d + 3 * d:]
+        # (a temporary passed as ptr(tmp.float()) would be freed -- and its block reused -- before the
+        # kernel runs; bind the float32 copies to locals)
+        ca32, cb32, cc32 = ca.float(), cb.float(), cc.float()
         _lib.call('crfconv_pointconv_bwd_params', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
-                  m_tgt, d, ptr(A1), ptr(b1), ptr(W2), ptr(ca.float()), ptr(cb.float()), ptr(cc.float()),
+                  m_tgt, d, ptr(A1), ptr(b1), ptr(W2), ptr(ca32), ptr(cb32), ptr(cc32),
                   ptr(dW2), ptr(dA1), ptr(db1), ptr(ws), nbytes, st)
         # input gradient (source-major gather over the reverse table)
         rev_ptr, rev_eid = table.reverse

@@ -31,3 +31,10 @@ def load_sd(module, sd_np):
 
 def grads(module):
     return {k: p.grad for k, p in module.named_parameters() if p.grad is not None}
+
+
+def assert_close_anchored(got, ref32, ref64, tol, what=''):
+    """`got` may deviate from the float64 truth by `tol`, or by 4x the CPU float32 oracle's own
+    rounding error where that is larger (ill-conditioned sums, e.g. gradients through BatchNorm)."""
+    e, e32 = relerr(got, ref64), relerr(ref32, ref64)
+    assert e <= max(tol, 4.0 * e32), '%s: err vs fp64 %.3e > max(%.1e, 4 x fp32-oracle err %.3e)' % (what, e, tol, e32)
