@@ -1,0 +1,134 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header
+declares, the nn.Module mirrors have the reference's state_dict layout, data containers behave,
+the product refuses to run without a GPU (no CPU fallback), and the batch-sharded gradient
+all-reduce is equivalent to one big batch (gloo, world_size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from crfconv_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, 'include', 'crfconv_amd.h')).read()
+    declared = set(re.findall(r'\b(crfconv_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.crfconv_abi_version() == 1
+    # argument validation happens before any HIP call, so it is testable without a GPU
+    rc = lib.crfconv_meanfield_forward(None, None, None, 16, 1, 10, 7, None, None, 1, None, None, None, None)
+    assert rc == -3 and b'H=7' in lib.crfconv_last_error()
+    rc = lib.crfconv_knn_batch_dev(None, 1, 10, 3, None, 10, 4, None, None, None, 0, None)
+    assert rc == -1
+
+
+def test_state_dict_layout_matches_reference(golden):
+    from crfconv_amd import models
+    g = golden('g5_pointconvbig.npz')
+    for tagc, use_crf in (('crf', True), ('ups', False)):
+        net = models.PointConvBig(6, 13, use_crf=use_crf, steps=3)
+        sd = net.state_dict()
+        want = {k: (tuple(int(s) for s in sh.split(',')) if sh else ()) for k, sh in zip(g[tagc + '/keys'], g[tagc + '/shapes'])}
+        assert set(sd) == set(want)
+        for k, shp in want.items():
+            assert tuple(sd[k].shape) == shp, k
+    assert sum(p.numel() for p in models.PointConvBig(6, 13, True, 3).parameters()) == 820141
+    crf = models.ContinuousGaussianCRFConv(64, 32, 32, steps=3)
+    assert torch.equal(crf.c.data, torch.eye(8))                     # identity init (reference :36)
+    g1 = golden('g1_crfconv.npz')
+    crf.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g1.items() if k.startswith('sd/')}, strict=True)
+
+
+def test_no_cpu_fallback():
+    from crfconv_amd import models
+    from crfconv_amd._lib import CrfConvError
+    m = models.ContinuousGaussianCRFConv(64, 32, 32, steps=1)
+    with pytest.raises(CrfConvError, match='no CPU path'):
+        m(torch.zeros(2, 8, 64), torch.zeros(2, 32, 32), torch.zeros(2, 32, 1, dtype=torch.long),
+          torch.zeros(2, 32, 16, dtype=torch.long))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'crfconv_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), os.path.join(dirpath, f)
+                assert '/root/reference' not in src, os.path.join(dirpath, f)
+
+
+def test_data_containers():
+    from crfconv_amd import Data, MultiScaleData
+    d = MultiScaleData(x=torch.zeros(2, 4, 6), y=torch.ones(2, 4, dtype=torch.long),
+                       multiscale=[Data(pos=torch.zeros(2, 4, 3), neighbor_idx=torch.zeros(2, 4, 2, dtype=torch.long))])
+    e = d.to('cpu')
+    assert e is not d and e.multiscale[0].pos.shape == (2, 4, 3) and 'x' in e.keys
+    assert 'MultiScaleData' in repr(e)
+
+
+def test_mlp_and_bn_semantics_match_oracle():
+    """MLP / FastBatchNorm1d are plain torch and run anywhere: check them against the oracle's mlp."""
+    import _seeded as S
+    from crfconv_amd.models import MLP
+    from oracle import crf_oracle as O
+    m = MLP(12, 20, activation=torch.nn.LeakyReLU(0.1))
+    sd = S.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 2)
+    m.load_state_dict(sd)
+    x = torch.from_numpy(S.uniform(2, 'x', (3, 50, 12)))
+    prm = {k: v.clone() for k, v in sd.items()}
+    m.train()
+    a = m(x)
+    b = O.mlp(prm, '', x, True, 0.1)
+    assert float((a - b).abs().max()) < 1e-5
+    assert float((m.bn.batch_norm.running_var - prm['bn.batch_norm.running_var']).abs().max()) < 1e-6
+    m.eval()
+    assert float((m(x) - O.mlp(prm, '', x, False, 0.1)).abs().max()) < 1e-5
+
+
+WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+from crfconv_amd import distributed as D
+rank, world, _ = D.init_from_env('gloo')
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.LeakyReLU(0.1), torch.nn.Linear(16, 5))
+D.broadcast_parameters(net)
+bucket = D.FlatGradAllReduce(net)
+g = torch.Generator().manual_seed(7)
+x = torch.randn(8, 6, generator=g); y = torch.randint(0, 5, (8,), generator=g)
+shard = slice(rank * 4, rank * 4 + 4)
+bucket.zero()
+torch.nn.functional.cross_entropy(net(x[shard]), y[shard]).backward()
+bucket.allreduce_mean()
+torch.save(bucket.flat.clone(), os.environ['OUT'] + '.%%d' %% rank)
+if rank == 0:
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.LeakyReLU(0.1), torch.nn.Linear(16, 5))
+    ref.load_state_dict(net.state_dict())
+    torch.nn.functional.cross_entropy(ref(x), y).backward()
+    torch.save(torch.cat([p.grad.reshape(-1) for p in ref.parameters()]), os.environ['OUT'] + '.ref')
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_sharded_grad_allreduce_equals_big_batch(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, OUT=str(tmp_path / 'g'), MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', WORLD_SIZE='2',
+               OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    g0, g1, ref = (torch.load(str(tmp_path / ('g.' + s))) for s in ('0', '1', 'ref'))
+    assert torch.equal(g0, g1)                                   # replicas hold identical averaged grads
+    assert float((g0 - ref).abs().max()) < 1e-6                  # == gradient of the un-sharded batch
