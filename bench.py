@@ -39,14 +39,14 @@ def synth_cloud(seed, n):
     return xyz.astype(np.float32), rgb.astype(np.float32), lab.astype(np.int64)
 
 
-def make_batch(rank, B, N, dev, gen):
+def make_batch(rank, B, N, dev, gen, sort='morton'):
     import crfconv_amd
     clouds = [synth_cloud(rank * B + i, N) for i in range(B)]
     pos = torch.from_numpy(np.stack([c[0] for c in clouds])).to(dev)
     x = torch.cat([pos, torch.from_numpy(np.stack([c[1] for c in clouds])).to(dev)], -1)
     y = torch.from_numpy(np.stack([c[2] for c in clouds])).to(dev)
     t0 = time.perf_counter()
-    data = crfconv_amd.multiscale_compute(pos, x=x, y=y, generator=gen)
+    data = crfconv_amd.multiscale_compute(pos, x=x, y=y, generator=gen, sort=sort)
     torch.cuda.synchronize()
     return data, time.perf_counter() - t0
 
@@ -128,6 +128,8 @@ def main():
     ap.add_argument('--points', type=int, default=40960)
     ap.add_argument('--crf-steps', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sort', default='morton', choices=['morton', 'none'],
+                    help="point order emitted by the device collate (kernels are order-agnostic)")
     args = ap.parse_args()
 
     import crfconv_amd
@@ -141,7 +143,8 @@ def main():
     B, N, T, n_cls = args.batch, args.points, args.crf_steps, 13
 
     gen = torch.Generator().manual_seed(1234 + rank)
-    data, t_pre = make_batch(rank, B, N, dev, gen)
+    make_batch(rank, B, N, dev, gen, args.sort)          # warm-up of the collate kernels
+    data, t_pre = make_batch(rank, B, N, dev, gen, args.sort)
     torch.manual_seed(0)
     net = models.PointConvBig(6, n_cls, use_crf=True, steps=T).to(dev).train()
     D.broadcast_parameters(net)

@@ -149,15 +149,19 @@ __device__ __forceinline__ void block_reduce_store(const float4 (&v)[NV], float*
 }
 
 // ------------------------------------------------------------------ generic partial reduction
-// out[slot] = sum_b partial[b][slot] accumulated in double, fixed order.
+// out[slot] = sum_b partial[b][slot] in double, fixed order: one wavefront per slot, lane l sums
+// blocks l, l+64, ... then a shuffle tree (same result every run).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
                                                               int64_t nblk, int nslots,
                                                               double* __restrict__ out) {
-    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const int slot = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (slot >= nslots) return;
     double a = 0.0;
-    for (int64_t b = 0; b < nblk; ++b) a += (double)partial[b * nslots + slot];
-    out[slot] = a;
+    for (int64_t b = lane; b < nblk; b += WAVE) a += (double)partial[b * nslots + slot];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
+    if (lane == 0) out[slot] = a;
 }
 
 // ------------------------------------------------------------------ rel-pos moments
@@ -451,6 +455,55 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
     for (int t = threadIdx.x; t < NSLOT; t += PBLOCK) partial[(int64_t)blockIdx.x * NSLOT + t] = s_acc[t];
 }
 
+// ------------------------------------------------------------------ backward pass 2 for wide layers
+// d >= 64 levels have few edges (<= 41k at config 2): write h1, g_h2 and rel per edge and let the
+// host contract them with dense GEMMs (dW2 = g_h2^T h1 etc.) instead of reducing d*d sums in-kernel.
+template <int D>
+__global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ gout,
+                                                          const float* __restrict__ pos_src,
+                                                          const float* __restrict__ pos_tgt,
+                                                          const int32_t* __restrict__ idx, int K,
+                                                          int64_t m_tgt, const float* __restrict__ A1,
+                                                          const float* __restrict__ b1,
+                                                          const float* __restrict__ W2,
+                                                          const float* __restrict__ ca,
+                                                          const float* __restrict__ cb,
+                                                          const float* __restrict__ cc,
+                                                          float* __restrict__ h1_out,
+                                                          float* __restrict__ gh2_out,
+                                                          float* __restrict__ rel_out) {
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    int lane, wave, q;
+    const Row rw = my_row<D>(m_tgt, lane, wave, q);
+    EdgeMLP<D> mlp;
+    mlp.init(A1, b1, W2, s_w2t, lane, q);
+    __syncthreads();
+    const float4 va = ld4(ca + 4 * q), vb = ld4(cb + 4 * q), vc = ld4(cc + 4 * q);
+    const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
+    const int32_t* irow = idx + rw.r * K;
+    const float4 g = ld4(gout + rw.r * D + 4 * q);
+    for (int k = 0; k < K; ++k) {
+        const int64_t j = irow[k];
+        const float4 xj = ld4(x + j * D + 4 * q);
+        const float rx = px - pos_src[3 * j], ry = py - pos_src[3 * j + 1], rz = pz - pos_src[3 * j + 2];
+        float4 pre, h1;
+        mlp.layer1(rx, ry, rz, pre, h1);
+        const float4 h2 = mlp.layer2(h1);
+        float4 gh2;
+        gh2.x = fmaf(va.x, g.x * xj.x, fmaf(vb.x, h2.x, vc.x));
+        gh2.y = fmaf(va.y, g.y * xj.y, fmaf(vb.y, h2.y, vc.y));
+        gh2.z = fmaf(va.z, g.z * xj.z, fmaf(vb.z, h2.z, vc.z));
+        gh2.w = fmaf(va.w, g.w * xj.w, fmaf(vb.w, h2.w, vc.w));
+        if (rw.valid) {
+            const int64_t e = rw.r * K + k;
+            st4(h1_out + e * D + 4 * q, h1);
+            st4(gh2_out + e * D + 4 * q, gh2);
+            if (q == 0) { rel_out[3 * e] = rx; rel_out[3 * e + 1] = ry; rel_out[3 * e + 2] = rz; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ backward: input features
 template <int D>
 __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restrict__ gout,
@@ -525,7 +578,7 @@ static int64_t blocks_for(int64_t m, int d) {
 }
 
 static int reduce_partials(const float* partial, int64_t nblk, int nslots, double* out, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(nslots, 256)), dim3(256), 0, st, partial,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(nslots, 256 / WAVE)), dim3(256), 0, st, partial,
                        nblk, nslots, out);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
@@ -625,16 +678,19 @@ extern "C" int crfconv_pointconv_bwd_params(const float* x, const float* gout, c
                     db1 && workspace, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(dA1 == dW2 + (size_t)d * d && db1 == dA1 + (size_t)d * 3, CRF_ERR_ARG,
                 "dW2/dA1/db1 must be one contiguous [d*d + 3d + d] float64 buffer");
+    CRF_REQUIRE(d <= 32, CRF_ERR_UNSUPPORTED, "in-kernel parameter reduction covers d <= 32; use crfconv_pointconv_bwd_dump for d=%d", d);
     const int64_t nblk = blocks_for(m_tgt, d);
     const int nslot = d * d + 4 * d;
     CRF_REQUIRE(workspace_bytes >= sizeof(float) * (size_t)nslot * (size_t)nblk, CRF_ERR_WORKSPACE,
                 "workspace too small");
     hipStream_t st = as_stream(stream);
     float* partial = reinterpret_cast<float*>(workspace);
-    DISPATCH_D(d, {
-        hipLaunchKernelGGL(bwd_params_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src,
-                           pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial);
-    });
+    switch (d) {
+        case 4: hipLaunchKernelGGL(bwd_params_kernel<4>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial); break;
+        case 8: hipLaunchKernelGGL(bwd_params_kernel<8>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial); break;
+        case 16: hipLaunchKernelGGL(bwd_params_kernel<16>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial); break;
+        default: hipLaunchKernelGGL(bwd_params_kernel<32>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial); break;
+    }
     CRF_LAUNCH_CHECK();
     return reduce_partials(partial, nblk, nslot, dW2, st);
 }
@@ -651,6 +707,24 @@ extern "C" int crfconv_pointconv_bwd_input(const float* gout, const float* pos_s
     DISPATCH_D(d, {
         hipLaunchKernelGGL(bwd_input_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, as_stream(stream), gout,
                            pos_src, pos_tgt, rev_ptr, rev_eid, K, m_src, A1, b1, W2, a2, b2, dx);
+    });
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_pointconv_bwd_dump(const float* x, const float* gout, const float* pos_src,
+                                          const float* pos_tgt, const int32_t* idx32, int K, int64_t m_tgt,
+                                          int d, const float* A1, const float* b1, const float* W2,
+                                          const float* ca, const float* cb, const float* cc, float* h1,
+                                          float* gh2, float* rel, crf_stream_t stream) {
+    if (int rc = check_pc(m_tgt, K, d)) return rc;
+    CRF_REQUIRE(x && gout && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && ca && cb && cc && h1 && gh2 && rel,
+                CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(m_tgt * K < ((int64_t)1 << 31), CRF_ERR_ARG, "too many edges");
+    const int64_t nblk = blocks_for(m_tgt, d);
+    DISPATCH_D(d, {
+        hipLaunchKernelGGL(bwd_dump_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, as_stream(stream), x, gout,
+                           pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, h1, gh2, rel);
     });
     CRF_LAUNCH_CHECK();
     return CRF_OK;

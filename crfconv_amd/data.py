@@ -56,14 +56,54 @@ class MultiScaleData(Data):
         super().__init__(x=x, y=y, point_idx=point_idx, cloud_idx=cloud_idx, multiscale=multiscale, **kwargs)
 
 
+def _spread3(v):
+    """Spread the low 10 bits of v so that there are two zero bits between consecutive bits."""
+    v = v & 0x3FF
+    v = (v | (v << 16)) & 0x030000FF
+    v = (v | (v << 8)) & 0x0300F00F
+    v = (v | (v << 4)) & 0x030C30C3
+    v = (v | (v << 2)) & 0x09249249
+    return v
+
+
+def morton_order(pos):
+    """Per-cloud permutation that sorts points along a 30-bit Morton (Z-order) curve.  pos [B, N, 3]."""
+    lo = pos.amin(dim=1, keepdim=True)
+    ext = (pos.amax(dim=1, keepdim=True) - lo).amax(dim=2, keepdim=True).clamp_min(1e-20)
+    q = ((pos - lo) / ext * 1023.0).clamp_(0, 1023).to(torch.int64)
+    code = _spread3(q[..., 0]) | (_spread3(q[..., 1]) << 1) | (_spread3(q[..., 2]) << 2)
+    return torch.argsort(code, dim=1, stable=True)
+
+
 def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kernel_size=(16, 16, 16, 16, 16),
-                       ratio=(4, 4, 4, 4, 2), num_scales=5, generator=None, choices=None):
+                       ratio=(4, 4, 4, 4, 2), num_scales=5, generator=None, choices=None, sort=None):
     """The reference collate on the device (datasets/semantic3d_dataset.py:512-528):
     per scale  neighbor_idx = knn(pos, pos, K);  one random subset shared by all clouds;
     sub_idx = neighbor_idx[:, choice];  up_idx = knn(sub_pos, pos, 1).
 
     pos [B, N, 3] float32 on the GPU.  `choices` (list of index tensors) overrides the random
-    permutations (tests); otherwise torch.randperm(N, generator=generator)[:N // ratio]."""
+    permutations (tests); otherwise torch.randperm(N, generator=generator)[:N // ratio].
+
+    sort='morton' (default when `choices` is None) first reorders every cloud along a Z-order curve
+    (x, y, point_idx follow; the permutation is returned as ``data.order`` [B, N]) and keeps each random
+    subset in ascending order, so that every level stays spatially sorted: neighbours then sit in
+    nearby rows and the gather kernels hit L1/L2 instead of HBM.  The reference shuffles points
+    anyway (semantic3d_dataset.py:435) and the network is permutation-equivariant, so results are
+    the same cloud-by-cloud; kernels are correct for ANY order, this only buys locality."""
+    if sort is None:
+        sort = 'morton' if choices is None else 'none'
+    order = None
+    if sort == 'morton':
+        order = morton_order(pos)
+
+        def perm(t):
+            if t is None or not torch.is_tensor(t) or t.dim() < 2 or t.shape[1] != pos.shape[1]:
+                return t
+            idx = order.reshape(order.shape + (1,) * (t.dim() - 2)).expand_as(t) if t.dim() > 2 else order
+            return torch.gather(t, 1, idx)
+        pos, x, y, point_idx = perm(pos).contiguous(), perm(x), perm(y), perm(point_idx)
+    elif sort != 'none':
+        raise ValueError("sort must be 'morton' or 'none'")
     multiscale = []
     for i in range(num_scales):
         n = pos.shape[1]
@@ -71,10 +111,13 @@ def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kern
         if choices is not None:
             choice = choices[i].to(pos.device)
         else:
-            choice = torch.randperm(n, generator=generator)[: n // ratio[i]].to(pos.device)
+            choice = torch.randperm(n, generator=generator)[: n // ratio[i]]
+            if sort == 'morton':
+                choice = choice.sort().values
+            choice = choice.to(pos.device)
         sub_pos = pos[:, choice, :].contiguous()
         sub_idx = neighbor_idx[:, choice, :].contiguous()
         up_idx = nearest_neighbors.knn_batch_device(sub_pos, pos, 1)
         multiscale.append(Data(pos=pos, neighbor_idx=neighbor_idx, sub_idx=sub_idx, up_idx=up_idx))
         pos = sub_pos
-    return MultiScaleData(x=x, y=y, point_idx=point_idx, cloud_idx=cloud_idx, multiscale=multiscale)
+    return MultiScaleData(x=x, y=y, point_idx=point_idx, cloud_idx=cloud_idx, multiscale=multiscale, order=order)

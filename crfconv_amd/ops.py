@@ -260,20 +260,33 @@ class _PointConv(torch.autograd.Function):
             cb = torch.zeros_like(ca)
             cc = torch.zeros_like(ca)
         # pass 2: parameter gradients
-        par = torch.empty(d * d + 4 * d, dtype=torch.float64, device=dev)
-        dW2, dA1, db1 = par[:d * d], par[d * d:d * d + 3 * d], par[d * d + 3 * d:]
-        # (a temporary passed as ptr(tmp.float()) would be freed -- and its block reused -- before the
-        # kernel runs; bind the float32 copies to locals)
-        ca32, cb32, cc32 = ca.float(), cb.float(), cc.float()
-        _lib.call('crfconv_pointconv_bwd_params', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
-                  m_tgt, d, ptr(A1), ptr(b1), ptr(W2), ptr(ca32), ptr(cb32), ptr(cc32),
-                  ptr(dW2), ptr(dA1), ptr(db1), ptr(ws), nbytes, st)
+        ca32, cb32, cc32 = ca.float(), cb.float(), cc.float()      # locals: operands must outlive the launch
+        if d <= 32:
+            par = torch.empty(d * d + 4 * d, dtype=torch.float64, device=dev)
+            dW2, dA1, db1 = par[:d * d], par[d * d:d * d + 3 * d], par[d * d + 3 * d:]
+            _lib.call('crfconv_pointconv_bwd_params', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32),
+                      K, m_tgt, d, ptr(A1), ptr(b1), ptr(W2), ptr(ca32), ptr(cb32), ptr(cc32), ptr(dW2), ptr(dA1),
+                      ptr(db1), ptr(ws), nbytes, st)
+            dW2, dA1, db1 = dW2.float().view(d, d), dA1.float().view(d, 3), db1.float()
+        else:
+            # wide, edge-poor levels: per-edge h1 / g_h2 / rel to HBM, contractions as dense GEMMs
+            E = m_tgt * K
+            h1 = torch.empty((E, d), dtype=torch.float32, device=dev)
+            gh2 = torch.empty((E, d), dtype=torch.float32, device=dev)
+            rel = torch.empty((E, 3), dtype=torch.float32, device=dev)
+            _lib.call('crfconv_pointconv_bwd_dump', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
+                      m_tgt, d, ptr(A1), ptr(b1), ptr(W2), ptr(ca32), ptr(cb32), ptr(cc32), ptr(h1), ptr(gh2),
+                      ptr(rel), st)
+            dW2 = gh2.t() @ h1
+            gp = (gh2 @ W2) * torch.where(h1 > 0, 1.0, 0.1)
+            dA1 = gp.t() @ rel
+            db1 = gp.sum(0)
         # input gradient (source-major gather over the reverse table)
         rev_ptr, rev_eid = table.reverse
         dx = torch.empty((table.m_src, d), dtype=torch.float32, device=dev)
         _lib.call('crfconv_pointconv_bwd_input', ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(rev_ptr), ptr(rev_eid), K,
                   table.m_src, d, ptr(A1), ptr(b1), ptr(W2), ptr(a2), ptr(b2), ptr(dx), st)
-        return (dx, dA1.float().view(d, 3), db1.float(), dW2.float().view(d, d), dgamma2, dbeta2, None, None, None,
+        return (dx, dA1, db1, dW2, dgamma2, dbeta2, None, None, None,
                 None, None, None, None, None)
 
 

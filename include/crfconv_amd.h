@@ -166,13 +166,21 @@ int crfconv_pointconv_bwd_reduce(const float* x, const float* gout, const float*
                                  crf_stream_t stream);
 /* Pass 2:  g_h2[e,c] = ca[c] * g_w[e,c] + cb[c] * h2[e,c] + cc[c]  (the host folds BatchNorm-2's
  * backward into ca/cb/cc; eval mode: ca = a2, cb = cc = 0), then back through W2, lrelu, A1:
- *   dW2 [d,d], dA1 [d,3], db1 [d]  as float64 sums. */
+ *   dW2 [d,d], dA1 [d,3], db1 [d]  as float64 sums (one contiguous buffer).  d <= 32. */
 int crfconv_pointconv_bwd_params(const float* x, const float* gout, const float* pos_src,
                                  const float* pos_tgt, const int32_t* idx32, int K, int64_t m_tgt,
                                  int d, const float* A1, const float* b1, const float* W2,
                                  const float* ca, const float* cb, const float* cc, double* dW2,
                                  double* dA1, double* db1, void* workspace, size_t workspace_bytes,
                                  crf_stream_t stream);
+/* Pass 2 for wide layers (d >= 64, few edges): instead of reducing in-kernel, write per edge e = i*K + k
+ *   h1 [E, d],  g_h2 [E, d] (same definition as above),  rel [E, 3]
+ * so the host can form dW2 = g_h2^T h1, g_h1 = g_h2 W2, dA1 = (g_h1 * lrelu')^T rel, db1 with dense GEMMs. */
+int crfconv_pointconv_bwd_dump(const float* x, const float* gout, const float* pos_src,
+                               const float* pos_tgt, const int32_t* idx32, int K, int64_t m_tgt, int d,
+                               const float* A1, const float* b1, const float* W2, const float* ca,
+                               const float* cb, const float* cc, float* h1, float* gh2, float* rel,
+                               crf_stream_t stream);
 /* dx[j,c] = sum_{e=(i,k) in rev(j)} w_e[c] * gout[i,c]   (weight MLP recomputed per incoming edge). */
 int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const float* pos_tgt,
                                 const int32_t* rev_ptr, const int32_t* rev_eid, int K,
