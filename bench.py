@@ -67,7 +67,7 @@ def roofline_meanfield(data, dev, H=8, T=3, iters=50):
     Q = torch.linalg.inv(torch.eye(H) + C)
     P = (C @ Q).to(dev).contiguous()
     Q = Q.to(dev).contiguous()
-    s = torch.empty(m, K - 1, device=dev)
+    s = torch.empty(m, K, device=dev)
     zq = torch.empty(m, H, device=dev)
     xs = torch.empty(T, m, H, device=dev)
     st = stream_ptr()
@@ -89,7 +89,7 @@ def roofline_meanfield(data, dev, H=8, T=3, iters=50):
     avg = float(dur.mean())
     return {'bound': 'hbm', 'achieved': alg_bytes / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
             'frac': alg_bytes / avg / HBM_PEAK, 'traffic': None, 'kernel': 'crfconv_meanfield_forward level-0 '
-            '(sim_kernel + %d x step_kernel, m=%d, H=%d, K=%d)' % (T, m, H, K),
+            '(sim_step_fast_kernel [similarity + step 1] + %d x step_fast_kernel, m=%d, H=%d, K=%d)' % (T - 1, m, H, K),
             'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': avg * 1e6, 'min_launch_us': float(dur.min()) * 1e6}
 
 

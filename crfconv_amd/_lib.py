@@ -38,7 +38,7 @@ SIGNATURES = {
     'crfconv_pointconv_forward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_bwd_reduce': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_bwd_params': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                                          _vp, _vp, _vp, _vp, _sz, _vp]),
+                                          _vp, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_bwd_dump': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_bwd_input': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'crfconv_neighbor_maxpool_forward': (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp]),

@@ -6,6 +6,12 @@
 // (squared distance, dot products) are xor-shuffles over the L lanes; the H x H products use
 // shuffles for the vector and LDS (float4 rows) for the matrix.
 //
+// Layout: every per-edge array (s, ds, w) is [m, K] with the SAME column index as the neighbour
+// table (columns < k0 hold 0), i.e. it is addressed by the edge id e = i*K + k.  With K = 16 a
+// row of indices and a row of weights are each one aligned 64-byte segment: the fast kernels
+// (K = 16 / 32, k0 = 1) pull them with dwordx4 loads and keep them in registers, so all K-1
+// neighbour gathers of a point are in flight together.
+//
 // Reference semantics: models/continuous_crf_conv_big.py:49-54 (similarity), :63-72 (loop).
 #include "common.hpp"
 
@@ -13,7 +19,7 @@ namespace crf {
 
 constexpr int BLOCK = 256;
 
-// v (float4 per lane, quad q of the point's H-vector)  ->  out += v_full * Mat, where
+// v (float4 per lane, quad q of the point's H-vector)  ->  acc + v_full * Mat, where
 // sM holds Mat [H][H] row-major as float4 rows: sM[h * L + q] = Mat[h][4q .. 4q+3].
 template <int H>
 __device__ __forceinline__ float4 matvec_acc(float4 v, const float4* sM, int lane, int q, float4 acc) {
@@ -43,77 +49,172 @@ __device__ __forceinline__ void load_matrix(float4* sM, const float* __restrict_
     }
 }
 
-// ------------------------------------------------------------------ similarity + z Q
-// KN > 0: neighbour count known at compile time, distances stay in registers.
-// KN == 0: any count; distances are recomputed in a second sweep (rows are L1/L2 hot by then).
-template <int H, int KN>
+template <int H>
+struct Geo {
+    static constexpr int L = H / 4, PPW = WAVE / L, PPB = PPW * (BLOCK / WAVE);
+};
+
+template <int H>
+__device__ __forceinline__ int64_t my_point(int64_t m, int& lane, int& q, bool& valid) {
+    lane = threadIdx.x & 63;
+    q = lane % Geo<H>::L;
+    const int64_t row = (int64_t)blockIdx.x * Geo<H>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / Geo<H>::L;
+    valid = row < m;
+    return valid ? row : m - 1;
+}
+
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) {
+    return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+}
+
+// K-wide row of 32-bit values (K % 4 == 0) as K/4 aligned dwordx4 loads.
+template <int K, typename T4, typename T>
+__device__ __forceinline__ void load_row(const T* __restrict__ p, T (&out)[K]) {
+#pragma unroll
+    for (int c = 0; c < K / 4; ++c) {
+        const T4 v = reinterpret_cast<const T4*>(p)[c];
+        out[4 * c + 0] = v.x; out[4 * c + 1] = v.y; out[4 * c + 2] = v.z; out[4 * c + 3] = v.w;
+    }
+}
+
+// ====================================================================== fast forward kernels
+// (K in {16, 32}, k0 == 1).  FIRST = similarity + z Q + first step fused: the index row is read
+// once, s never round-trips through memory before its first use.
+template <int H, int K, bool WITH_STEP>
+__global__ __launch_bounds__(BLOCK) void sim_step_fast_kernel(const float* __restrict__ y,
+                                                              const float* __restrict__ z,
+                                                              const int32_t* __restrict__ idx,
+                                                              const float* __restrict__ Q,
+                                                              const float* __restrict__ P,
+                                                              float* __restrict__ s,
+                                                              float* __restrict__ zq,
+                                                              float* __restrict__ x1, int64_t m) {
+    constexpr int L = Geo<H>::L;
+    __shared__ float4 sQ[H * L];
+    __shared__ float4 sP[WITH_STEP ? H * L : 1];
+    load_matrix<H>(sQ, Q, false);
+    if constexpr (WITH_STEP) load_matrix<H>(sP, P, false);
+    __syncthreads();
+    int lane, q;
+    bool valid;
+    const int64_t r = my_point<H>(m, lane, q, valid);
+
+    int j[K];
+    load_row<K, int4>(idx + r * K, j);
+    const float4 yi = ld4(y + r * H + 4 * q);
+    float4 nb[K];
+#pragma unroll
+    for (int k = 1; k < K; ++k) nb[k] = ld4(y + (int64_t)j[k] * H + 4 * q);
+    float d[K];
+    float dmin = 3.4e38f;
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        const float4 df = sub4(yi, nb[k]);
+        d[k] = group_sum<L>(dot4(df, df));
+        dmin = fminf(dmin, d[k]);
+    }
+    if constexpr (WITH_STEP) {   // issue the z-row gathers before the exp chain
+#pragma unroll
+        for (int k = 1; k < K; ++k) nb[k] = ld4(z + (int64_t)j[k] * H + 4 * q);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        d[k] = expf(dmin - d[k]);
+        den += d[k];
+    }
+    const float inv = 1.0f / den;
+    d[0] = 0.f;
+#pragma unroll
+    for (int k = 1; k < K; ++k) d[k] *= inv;
+    // s row: K floats = K/4 dwordx4 stores, spread over the L lanes of the point
+#pragma unroll
+    for (int c = 0; c < K / 4; ++c)
+        if (valid && (c % L) == q) st4(s + r * K + 4 * c, make_float4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]));
+
+    const float4 zi = ld4(z + r * H + 4 * q);
+    const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
+    if (valid) st4(zq + r * H + 4 * q, zqi);
+    if constexpr (WITH_STEP) {
+        float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 1; k < K; ++k) msg = fma4(d[k], nb[k], msg);
+        const float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
+        if (valid) st4(x1 + r * H + 4 * q, o);
+    }
+}
+
+template <int H, int K>
+__global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restrict__ xin,
+                                                          const float* __restrict__ zq,
+                                                          const float* __restrict__ s,
+                                                          const int32_t* __restrict__ idx,
+                                                          const float* __restrict__ P,
+                                                          float* __restrict__ xout, int64_t m) {
+    constexpr int L = Geo<H>::L;
+    __shared__ float4 sP[H * L];
+    load_matrix<H>(sP, P, false);
+    __syncthreads();
+    int lane, q;
+    bool valid;
+    const int64_t r = my_point<H>(m, lane, q, valid);
+    int j[K];
+    float w[K];
+    load_row<K, int4>(idx + r * K, j);
+    load_row<K, float4>(s + r * K, w);
+    float4 nb[K];
+#pragma unroll
+    for (int k = 1; k < K; ++k) nb[k] = ld4(xin + (int64_t)j[k] * H + 4 * q);
+    const float4 zqi = ld4(zq + r * H + 4 * q);
+    float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 1; k < K; ++k) msg = fma4(w[k], nb[k], msg);
+    const float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
+    if (valid) st4(xout + r * H + 4 * q, o);
+}
+
+// ====================================================================== generic forward kernels
+// any K <= 64, any k0: distances recomputed in a second sweep (rows are L1/L2 hot by then).
+template <int H>
 __global__ __launch_bounds__(BLOCK) void sim_kernel(const float* __restrict__ y,
                                                     const float* __restrict__ z,
                                                     const int32_t* __restrict__ idx, int K, int k0,
                                                     const float* __restrict__ Q,
                                                     float* __restrict__ s, float* __restrict__ zq,
                                                     int64_t m) {
-    constexpr int L = H / 4, PPW = WAVE / L, PPB = PPW * (BLOCK / WAVE);
+    constexpr int L = Geo<H>::L;
     __shared__ float4 sQ[H * L];
     load_matrix<H>(sQ, Q, false);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = lane % L;
-    const int64_t row = (int64_t)blockIdx.x * PPB + wave * PPW + lane / L;
-    const bool valid = row < m;
-    const int64_t r = valid ? row : m - 1;
-    const int Kn = KN > 0 ? KN : K - k0;
-
+    int lane, q;
+    bool valid;
+    const int64_t r = my_point<H>(m, lane, q, valid);
     const float4 yi = ld4(y + r * H + 4 * q);
-    const int32_t* irow = idx + r * K + k0;
-    float* srow = s + r * Kn;
+    const int32_t* irow = idx + r * K;
+    float* srow = s + r * K;
 
     auto dist_to = [&](int k) {
-        const int j = irow[k];
-        const float4 yj = ld4(y + (int64_t)j * H + 4 * q);
-        const float4 df = make_float4(yi.x - yj.x, yi.y - yj.y, yi.z - yj.z, yi.w - yj.w);
+        const float4 df = sub4(yi, ld4(y + (int64_t)irow[k] * H + 4 * q));
         return group_sum<L>(dot4(df, df));
     };
-
-    if constexpr (KN > 0) {
-        float d[KN];
-        float dmin = 3.4e38f;
-#pragma unroll
-        for (int k = 0; k < KN; ++k) {
-            d[k] = dist_to(k);
-            dmin = fminf(dmin, d[k]);
-        }
-        float den = 0.f;
-#pragma unroll
-        for (int k = 0; k < KN; ++k) {
-            d[k] = expf(dmin - d[k]);
-            den += d[k];
-        }
-        const float inv = 1.0f / den;
-#pragma unroll
-        for (int k = 0; k < KN; ++k)
-            if (valid && q == (k % L)) srow[k] = d[k] * inv;
-    } else {
-        float dmin = 3.4e38f;
-        for (int k = 0; k < Kn; ++k) dmin = fminf(dmin, dist_to(k));
-        float den = 0.f;
-        for (int k = 0; k < Kn; ++k) {
-            const float e = expf(dmin - dist_to(k));
-            den += e;
-            if (valid && q == 0) srow[k] = e;
-        }
-        const float inv = 1.0f / den;
-        if (valid && q == 0)  // same lane re-reads what it wrote
-            for (int k = 0; k < Kn; ++k) srow[k] *= inv;
+    float dmin = 3.4e38f;
+    for (int k = k0; k < K; ++k) dmin = fminf(dmin, dist_to(k));
+    float den = 0.f;
+    for (int k = k0; k < K; ++k) {
+        const float e = expf(dmin - dist_to(k));
+        den += e;
+        if (valid && q == 0) srow[k] = e;
     }
-
-    // zq = z Q
+    const float inv = 1.0f / den;
+    if (valid && q == 0) {  // same lane re-reads what it wrote
+        for (int k = 0; k < k0; ++k) srow[k] = 0.f;
+        for (int k = k0; k < K; ++k) srow[k] *= inv;
+    }
     const float4 zi = ld4(z + r * H + 4 * q);
     const float4 o = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
     if (valid) st4(zq + r * H + 4 * q, o);
 }
 
-// ------------------------------------------------------------------ one mean-field step
 template <int H>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const float* __restrict__ xin,
                                                      const float* __restrict__ zq,
@@ -121,31 +222,25 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const float* __restrict__ x
                                                      const int32_t* __restrict__ idx, int K, int k0,
                                                      const float* __restrict__ P,
                                                      float* __restrict__ xout, int64_t m) {
-    constexpr int L = H / 4, PPW = WAVE / L, PPB = PPW * (BLOCK / WAVE);
+    constexpr int L = Geo<H>::L;
     __shared__ float4 sP[H * L];
     load_matrix<H>(sP, P, false);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = lane % L;
-    const int64_t row = (int64_t)blockIdx.x * PPB + wave * PPW + lane / L;
-    const bool valid = row < m;
-    const int64_t r = valid ? row : m - 1;
-    const int Kn = K - k0;
-    const int32_t* irow = idx + r * K + k0;
-    const float* srow = s + r * Kn;
-
+    int lane, q;
+    bool valid;
+    const int64_t r = my_point<H>(m, lane, q, valid);
+    const int32_t* irow = idx + r * K;
+    const float* srow = s + r * K;
     float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 5
-    for (int k = 0; k < Kn; ++k) {
-        const int j = irow[k];
-        msg = fma4(srow[k], ld4(xin + (int64_t)j * H + 4 * q), msg);
-    }
+#pragma unroll 4
+    for (int k = k0; k < K; ++k) msg = fma4(srow[k], ld4(xin + (int64_t)irow[k] * H + 4 * q), msg);
     const float4 o = matvec_acc<H>(msg, sP, lane, q, ld4(zq + r * H + 4 * q));
     if (valid) st4(xout + r * H + 4 * q, o);
 }
 
-// ------------------------------------------------------------------ backward, edge half
-template <int H>
+// ====================================================================== backward, edge half
+// gm = G P^T ; ds[i,k] (+)= <gm_i, xprev_j> ; mt_i = sum_k s_ik xprev_j.   KT > 0: fast row form.
+template <int H, int KT>
 __global__ __launch_bounds__(BLOCK) void bwd_edge_kernel(const float* __restrict__ G,
                                                          const float* __restrict__ xprev,
                                                          const float* __restrict__ s,
@@ -155,64 +250,86 @@ __global__ __launch_bounds__(BLOCK) void bwd_edge_kernel(const float* __restrict
                                                          float* __restrict__ ds,
                                                          float* __restrict__ mt, int accumulate,
                                                          int64_t m) {
-    constexpr int L = H / 4, PPW = WAVE / L, PPB = PPW * (BLOCK / WAVE);
+    constexpr int L = Geo<H>::L;
     __shared__ float4 sPT[H * L];
     load_matrix<H>(sPT, P, true);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = lane % L;
-    const int64_t row = (int64_t)blockIdx.x * PPB + wave * PPW + lane / L;
-    const bool valid = row < m;
-    const int64_t r = valid ? row : m - 1;
-    const int Kn = K - k0;
-    const int32_t* irow = idx + r * K + k0;
-    const float* srow = s + r * Kn;
-    float* dsrow = ds + r * Kn;
-
+    int lane, q;
+    bool valid;
+    const int64_t r = my_point<H>(m, lane, q, valid);
     const float4 g = ld4(G + r * H + 4 * q);
     const float4 gmi = matvec_acc<H>(g, sPT, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
     if (valid) st4(gm + r * H + 4 * q, gmi);
     float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 5
-    for (int k = 0; k < Kn; ++k) {
-        const int j = irow[k];
-        const float4 xj = ld4(xprev + (int64_t)j * H + 4 * q);
-        msg = fma4(srow[k], xj, msg);
-        const float dotv = group_sum<L>(dot4(gmi, xj));
-        if (valid && q == (k % L)) dsrow[k] = accumulate ? dsrow[k] + dotv : dotv;
+    if constexpr (KT > 0) {
+        int j[KT];
+        float w[KT], dd[KT];
+        load_row<KT, int4>(idx + r * KT, j);
+        load_row<KT, float4>(s + r * KT, w);
+        float4 nb[KT];
+#pragma unroll
+        for (int k = 1; k < KT; ++k) nb[k] = ld4(xprev + (int64_t)j[k] * H + 4 * q);
+        if (accumulate) load_row<KT, float4>(ds + r * KT, dd);
+        else {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) dd[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 1; k < KT; ++k) {
+            msg = fma4(w[k], nb[k], msg);
+            dd[k] += group_sum<L>(dot4(gmi, nb[k]));
+        }
+        dd[0] = 0.f;
+#pragma unroll
+        for (int c = 0; c < KT / 4; ++c)
+            if (valid && (c % L) == q)
+                st4(ds + r * KT + 4 * c, make_float4(dd[4 * c], dd[4 * c + 1], dd[4 * c + 2], dd[4 * c + 3]));
+    } else {
+        const int32_t* irow = idx + r * K;
+        const float* srow = s + r * K;
+        float* dsrow = ds + r * K;
+#pragma unroll 4
+        for (int k = k0; k < K; ++k) {
+            const float4 xj = ld4(xprev + (int64_t)irow[k] * H + 4 * q);
+            msg = fma4(srow[k], xj, msg);
+            const float dotv = group_sum<L>(dot4(gmi, xj));
+            if (valid && q == (k % L)) dsrow[k] = accumulate ? dsrow[k] + dotv : dotv;
+        }
+        if (valid && q == 0 && !accumulate)
+            for (int k = 0; k < k0; ++k) dsrow[k] = 0.f;
     }
     if (mt != nullptr && valid) st4(mt + r * H + 4 * q, msg);
 }
 
-// ------------------------------------------------------------------ backward, scatter half
-// One source row per L lanes; walks the row's incoming edges (ascending edge id).
+// ====================================================================== backward, scatter half
+// One source row per L lanes; walks the row's incoming edges (ascending edge id, fixed order).
+// Gprev[j] = add[j] + sum_{e in rev(j)} s[e] gm[e / K]     (s is 0 on columns < k0)
 template <int H>
 __global__ __launch_bounds__(BLOCK) void bwd_scatter_kernel(const float* __restrict__ gm,
                                                             const float* __restrict__ s,
                                                             const int32_t* __restrict__ rev_ptr,
                                                             const int32_t* __restrict__ rev_eid,
-                                                            int K, int k0,
+                                                            int K, int kshift,
                                                             const float* __restrict__ add,
                                                             float* __restrict__ Gprev,
                                                             int64_t m_src) {
-    constexpr int L = H / 4, PPW = WAVE / L, PPB = PPW * (BLOCK / WAVE);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int L = Geo<H>::L;
+    const int lane = threadIdx.x & 63;
     const int q = lane % L;
-    const int64_t row = (int64_t)blockIdx.x * PPB + wave * PPW + lane / L;
+    const int64_t row = (int64_t)blockIdx.x * Geo<H>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / L;
     if (row >= m_src) return;  // no cross-lane traffic below
-    const int Kn = K - k0;
     float4 acc = add ? ld4(add + row * H + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int beg = rev_ptr[row], end = rev_ptr[row + 1];
+#pragma unroll 4
     for (int p = beg; p < end; ++p) {
         const int e = rev_eid[p];
-        const int i = e / K, k = e - i * K;
-        if (k < k0) continue;
-        acc = fma4(s[(int64_t)i * Kn + (k - k0)], ld4(gm + (int64_t)i * H + 4 * q), acc);
+        const int i = kshift >= 0 ? (e >> kshift) : (e / K);
+        acc = fma4(s[e], ld4(gm + (int64_t)i * H + 4 * q), acc);
     }
     st4(Gprev + row * H + 4 * q, acc);
 }
 
-// ------------------------------------------------------------------ softmax / distance backward
+// ====================================================================== softmax / distance backward
 template <int H>
 __global__ __launch_bounds__(BLOCK) void sim_bwd_kernel(const float* __restrict__ ds,
                                                         const float* __restrict__ s,
@@ -220,75 +337,74 @@ __global__ __launch_bounds__(BLOCK) void sim_bwd_kernel(const float* __restrict_
                                                         const int32_t* __restrict__ idx, int K,
                                                         int k0, float* __restrict__ w,
                                                         float* __restrict__ dy_self, int64_t m) {
-    constexpr int L = H / 4, PPW = WAVE / L, PPB = PPW * (BLOCK / WAVE);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = lane % L;
-    const int64_t row = (int64_t)blockIdx.x * PPB + wave * PPW + lane / L;
-    const bool valid = row < m;
-    const int64_t r = valid ? row : m - 1;
-    const int Kn = K - k0;
-    const int32_t* irow = idx + r * K + k0;
-    const float* srow = s + r * Kn;
-    const float* dsrow = ds + r * Kn;
-    float* wrow = w + r * Kn;
-
+    constexpr int L = Geo<H>::L;
+    int lane, q;
+    bool valid;
+    const int64_t r = my_point<H>(m, lane, q, valid);
+    const int32_t* irow = idx + r * K;
+    const float* srow = s + r * K;
+    const float* dsrow = ds + r * K;
+    float* wrow = w + r * K;
     float dotv = 0.f;
-    for (int k = 0; k < Kn; ++k) dotv = fmaf(srow[k], dsrow[k], dotv);
+    for (int k = k0; k < K; ++k) dotv = fmaf(srow[k], dsrow[k], dotv);
     const float4 yi = ld4(y + r * H + 4 * q);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < Kn; ++k) {
-        // d loss / d logit_k = s_k (ds_k - dot);  logit = -dist  =>  d/d dist = -that; w = 2 * d/d dist
+#pragma unroll 4
+    for (int k = k0; k < K; ++k) {
+        // d loss / d logit_k = s_k (ds_k - dot);  logit = -dist  =>  d/d dist = -that;  w = 2 * d/d dist
         const float wk = -2.0f * srow[k] * (dsrow[k] - dotv);
-        const int j = irow[k];
-        const float4 yj = ld4(y + (int64_t)j * H + 4 * q);
-        acc = fma4(wk, make_float4(yi.x - yj.x, yi.y - yj.y, yi.z - yj.z, yi.w - yj.w), acc);
+        acc = fma4(wk, sub4(yi, ld4(y + (int64_t)irow[k] * H + 4 * q)), acc);
         if (valid && q == (k % L)) wrow[k] = wk;
     }
+    if (valid && q == 0)
+        for (int k = 0; k < k0; ++k) wrow[k] = 0.f;
     if (valid) st4(dy_self + r * H + 4 * q, acc);
 }
 
+// dy[j] = dy_self[j] + sum_{e in rev(j)} w[e] (y_j - y_{e/K})       (w is 0 on columns < k0)
 template <int H>
 __global__ __launch_bounds__(BLOCK) void sim_bwd_scatter_kernel(const float* __restrict__ w,
                                                                 const float* __restrict__ y,
                                                                 const float* __restrict__ dy_self,
                                                                 const int32_t* __restrict__ rev_ptr,
                                                                 const int32_t* __restrict__ rev_eid,
-                                                                int K, int k0,
+                                                                int K, int kshift,
                                                                 float* __restrict__ dy,
                                                                 int64_t m_src) {
-    constexpr int L = H / 4, PPW = WAVE / L, PPB = PPW * (BLOCK / WAVE);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int L = Geo<H>::L;
+    const int lane = threadIdx.x & 63;
     const int q = lane % L;
-    const int64_t row = (int64_t)blockIdx.x * PPB + wave * PPW + lane / L;
+    const int64_t row = (int64_t)blockIdx.x * Geo<H>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / L;
     if (row >= m_src) return;
-    const int Kn = K - k0;
     const float4 yj = ld4(y + row * H + 4 * q);
     float4 acc = ld4(dy_self + row * H + 4 * q);
     const int beg = rev_ptr[row], end = rev_ptr[row + 1];
+#pragma unroll 4
     for (int p = beg; p < end; ++p) {
         const int e = rev_eid[p];
-        const int i = e / K, k = e - i * K;
-        if (k < k0) continue;
-        const float4 yi = ld4(y + (int64_t)i * H + 4 * q);
-        acc = fma4(w[(int64_t)i * Kn + (k - k0)],
-                   make_float4(yj.x - yi.x, yj.y - yi.y, yj.z - yi.z, yj.w - yi.w), acc);
+        const int i = kshift >= 0 ? (e >> kshift) : (e / K);
+        acc = fma4(w[e], sub4(yj, ld4(y + (int64_t)i * H + 4 * q)), acc);
     }
     st4(dy + row * H + 4 * q, acc);
 }
-
-template <int H>
-constexpr int points_per_block() { return (WAVE / (H / 4)) * (BLOCK / WAVE); }
 
 static int check_common(int64_t m, int H, int K, int k0) {
     CRF_REQUIRE(m > 0 && m < (int64_t)1 << 31, CRF_ERR_ARG, "rows m=%lld out of range", (long long)m);
     CRF_REQUIRE(H == 4 || H == 8 || H == 16 || H == 32 || H == 64, CRF_ERR_UNSUPPORTED,
                 "hidden channels H=%d not in {4,8,16,32,64}", H);
     CRF_REQUIRE(K >= 1 && K <= 64 && k0 >= 0 && k0 < K, CRF_ERR_ARG, "K=%d k0=%d invalid", K, k0);
+    CRF_REQUIRE(m * K < (int64_t)1 << 31, CRF_ERR_ARG, "edge ids exceed int32 (m=%lld K=%d)", (long long)m, K);
     return CRF_OK;
 }
 
-#define DISPATCH_H(H, ...)                         \
-    switch (H) {                                   \
+static int kshift_of(int K) {
+    for (int sft = 0; sft < 7; ++sft)
+        if ((1 << sft) == K) return sft;
+    return -1;
+}
+
+#define DISPATCH_H(H, ...)                                      \
+    switch (H) {                                                \
         case 4: { constexpr int HH = 4; __VA_ARGS__; break; }   \
         case 8: { constexpr int HH = 8; __VA_ARGS__; break; }   \
         case 16: { constexpr int HH = 16; __VA_ARGS__; break; } \
@@ -307,23 +423,31 @@ extern "C" int crfconv_meanfield_forward(const float* z, const float* y, const i
     CRF_REQUIRE(z && y && idx32 && Q && P && s && zq && (xs || T == 0), CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(T >= 0, CRF_ERR_ARG, "T=%d < 0", T);
     hipStream_t st = as_stream(stream);
+    const bool fast = (k0 == 1) && (K == 16 || K == 32);
     DISPATCH_H(H, {
-        const int ppb = points_per_block<HH>();
-        const dim3 grid((unsigned)cdiv(m, ppb));
-        switch (K - k0) {
-            case 15: hipLaunchKernelGGL((sim_kernel<HH, 15>), grid, dim3(BLOCK), 0, st, y, z, idx32, K, k0, Q, s, zq, m); break;
-            case 16: hipLaunchKernelGGL((sim_kernel<HH, 16>), grid, dim3(BLOCK), 0, st, y, z, idx32, K, k0, Q, s, zq, m); break;
-            case 31: hipLaunchKernelGGL((sim_kernel<HH, 31>), grid, dim3(BLOCK), 0, st, y, z, idx32, K, k0, Q, s, zq, m); break;
-            default: hipLaunchKernelGGL((sim_kernel<HH, 0>), grid, dim3(BLOCK), 0, st, y, z, idx32, K, k0, Q, s, zq, m); break;
+        const dim3 grid((unsigned)cdiv(m, Geo<HH>::PPB)), blk(BLOCK);
+        int t0 = 0;
+        if (fast) {
+            float* x1 = T > 0 ? xs : nullptr;
+            if (K == 16) {
+                if (T > 0) hipLaunchKernelGGL((sim_step_fast_kernel<HH, 16, true>), grid, blk, 0, st, y, z, idx32, Q, P, s, zq, x1, m);
+                else hipLaunchKernelGGL((sim_step_fast_kernel<HH, 16, false>), grid, blk, 0, st, y, z, idx32, Q, P, s, zq, x1, m);
+            } else {
+                if (T > 0) hipLaunchKernelGGL((sim_step_fast_kernel<HH, 32, true>), grid, blk, 0, st, y, z, idx32, Q, P, s, zq, x1, m);
+                else hipLaunchKernelGGL((sim_step_fast_kernel<HH, 32, false>), grid, blk, 0, st, y, z, idx32, Q, P, s, zq, x1, m);
+            }
+            t0 = 1;
+        } else {
+            hipLaunchKernelGGL(sim_kernel<HH>, grid, blk, 0, st, y, z, idx32, K, k0, Q, s, zq, m);
         }
         CRF_LAUNCH_CHECK();
-        const float* xin = z;
-        for (int t = 0; t < T; ++t) {
+        for (int t = t0; t < T; ++t) {
+            const float* xin = t == 0 ? z : xs + (int64_t)(t - 1) * m * H;
             float* xout = xs + (int64_t)t * m * H;
-            hipLaunchKernelGGL(step_kernel<HH>, grid, dim3(BLOCK), 0, st, xin, zq, s, idx32, K, k0, P,
-                               xout, m);
+            if (fast && K == 16) hipLaunchKernelGGL((step_fast_kernel<HH, 16>), grid, blk, 0, st, xin, zq, s, idx32, P, xout, m);
+            else if (fast) hipLaunchKernelGGL((step_fast_kernel<HH, 32>), grid, blk, 0, st, xin, zq, s, idx32, P, xout, m);
+            else hipLaunchKernelGGL(step_kernel<HH>, grid, blk, 0, st, xin, zq, s, idx32, K, k0, P, xout, m);
             CRF_LAUNCH_CHECK();
-            xin = xout;
         }
     });
     return CRF_OK;
@@ -336,9 +460,11 @@ extern "C" int crfconv_meanfield_bwd_edge(const float* G, const float* xprev, co
     if (int rc = check_common(m, H, K, k0)) return rc;
     CRF_REQUIRE(G && xprev && s && idx32 && P && gm && ds, CRF_ERR_ARG, "null pointer");
     DISPATCH_H(H, {
-        const dim3 grid((unsigned)cdiv(m, points_per_block<HH>()));
-        hipLaunchKernelGGL(bwd_edge_kernel<HH>, grid, dim3(BLOCK), 0, as_stream(stream), G, xprev, s,
-                           idx32, K, k0, P, gm, ds, mt, accumulate, m);
+        const dim3 grid((unsigned)cdiv(m, Geo<HH>::PPB)), blk(BLOCK);
+        if (k0 == 1 && K == 16)
+            hipLaunchKernelGGL((bwd_edge_kernel<HH, 16>), grid, blk, 0, as_stream(stream), G, xprev, s, idx32, K, k0, P, gm, ds, mt, accumulate, m);
+        else
+            hipLaunchKernelGGL((bwd_edge_kernel<HH, 0>), grid, blk, 0, as_stream(stream), G, xprev, s, idx32, K, k0, P, gm, ds, mt, accumulate, m);
         CRF_LAUNCH_CHECK();
     });
     return CRF_OK;
@@ -351,9 +477,9 @@ extern "C" int crfconv_meanfield_bwd_scatter(const float* gm, const float* s, co
     if (int rc = check_common(m_src, H, K, k0)) return rc;
     CRF_REQUIRE(gm && s && rev_ptr && rev_eid && Gprev, CRF_ERR_ARG, "null pointer");
     DISPATCH_H(H, {
-        const dim3 grid((unsigned)cdiv(m_src, points_per_block<HH>()));
+        const dim3 grid((unsigned)cdiv(m_src, Geo<HH>::PPB));
         hipLaunchKernelGGL(bwd_scatter_kernel<HH>, grid, dim3(BLOCK), 0, as_stream(stream), gm, s,
-                           rev_ptr, rev_eid, K, k0, add, Gprev, m_src);
+                           rev_ptr, rev_eid, K, kshift_of(K), add, Gprev, m_src);
         CRF_LAUNCH_CHECK();
     });
     return CRF_OK;
@@ -366,7 +492,7 @@ extern "C" int crfconv_similarity_bwd(const float* ds, const float* s, const flo
     CRF_REQUIRE(ds && s && y && idx32 && w && dy_self, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(w != ds, CRF_ERR_ARG, "w must not alias ds");
     DISPATCH_H(H, {
-        const dim3 grid((unsigned)cdiv(m, points_per_block<HH>()));
+        const dim3 grid((unsigned)cdiv(m, Geo<HH>::PPB));
         hipLaunchKernelGGL(sim_bwd_kernel<HH>, grid, dim3(BLOCK), 0, as_stream(stream), ds, s, y, idx32,
                            K, k0, w, dy_self, m);
         CRF_LAUNCH_CHECK();
@@ -381,9 +507,9 @@ extern "C" int crfconv_similarity_bwd_scatter(const float* w, const float* y, co
     if (int rc = check_common(m_src, H, K, k0)) return rc;
     CRF_REQUIRE(w && y && dy_self && rev_ptr && rev_eid && dy, CRF_ERR_ARG, "null pointer");
     DISPATCH_H(H, {
-        const dim3 grid((unsigned)cdiv(m_src, points_per_block<HH>()));
+        const dim3 grid((unsigned)cdiv(m_src, Geo<HH>::PPB));
         hipLaunchKernelGGL(sim_bwd_scatter_kernel<HH>, grid, dim3(BLOCK), 0, as_stream(stream), w, y,
-                           dy_self, rev_ptr, rev_eid, K, k0, dy, m_src);
+                           dy_self, rev_ptr, rev_eid, K, kshift_of(K), dy, m_src);
         CRF_LAUNCH_CHECK();
     });
     return CRF_OK;

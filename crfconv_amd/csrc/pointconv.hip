@@ -164,6 +164,19 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     if (lane == 0) out[slot] = a;
 }
 
+__global__ __launch_bounds__(256) void reduce_partials_d_kernel(const double* __restrict__ partial,
+                                                                int64_t nblk, int nslots,
+                                                                double* __restrict__ out) {
+    const int slot = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (slot >= nslots) return;
+    double a = 0.0;
+    for (int64_t b = lane; b < nblk; b += WAVE) a += partial[b * nslots + slot];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
+    if (lane == 0) out[slot] = a;
+}
+
 // ------------------------------------------------------------------ rel-pos moments
 __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ pos_src,
                                                       const float* __restrict__ pos_tgt,
@@ -307,7 +320,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_reduce_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------ backward pass 2: parameters
-// Slots of a block partial: [dW2 D*D][dA1 D*3][db1 D].
+// Block partials: float [dW2 D*D] and double [channel][dA1 x, y, z, db1].
 template <int D>
 __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ gout,
@@ -320,10 +333,12 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
                                                             const float* __restrict__ ca,
                                                             const float* __restrict__ cb,
                                                             const float* __restrict__ cc,
-                                                            float* __restrict__ partial) {
+                                                            float* __restrict__ partial,
+                                                            double* __restrict__ partial_d) {
     constexpr int L = PC<D>::L;
     constexpr bool ACC_REGS = (D <= 32);          // dW2 accumulators in registers vs LDS atomics
-    constexpr int NSLOT = D * D + 4 * D;
+    constexpr int NSLOT = D * D;
+    __shared__ double s_accd[PWAVES][4 * D];
     __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * L];
     constexpr bool W2_LDS = (D <= 64);            // d = 128: the 64 KB of rows stay in L1/L2 instead
     __shared__ float4 s_w2[W2_LDS ? D * L : 1];   // W2 rows as float4: s_w2[c * L + q'] = W2[c][4q'..]
@@ -350,9 +365,10 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
 #pragma unroll
         for (int c = 0; c < D; ++c) dw2[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float4 da1[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
-                     make_float4(0.f, 0.f, 0.f, 0.f)};  // da1[axis] over the quad's 4 channels
-    float4 db = make_float4(0.f, 0.f, 0.f, 0.f);
+    // dA1 / db1 feed the analytic BatchNorm-1 backward on the host, where their large common
+    // components cancel (scale / shift invariance): accumulate them in float64 end to end.
+    double da1[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};  // [axis][channel of the quad]
+    double db[4] = {0, 0, 0, 0};
     const int base = lane - q;
 
     for (int k = 0; k < K; ++k) {
@@ -407,10 +423,14 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
         // through lrelu(0.1)
         const float4 gp = make_float4(gh1.x * (pre.x > 0.f ? 1.f : 0.1f), gh1.y * (pre.y > 0.f ? 1.f : 0.1f),
                                       gh1.z * (pre.z > 0.f ? 1.f : 0.1f), gh1.w * (pre.w > 0.f ? 1.f : 0.1f));
-        da1[0] = fma4(rx, gp, da1[0]);
-        da1[1] = fma4(ry, gp, da1[1]);
-        da1[2] = fma4(rz, gp, da1[2]);
-        db.x += gp.x; db.y += gp.y; db.z += gp.z; db.w += gp.w;
+        const double gpd[4] = {gp.x, gp.y, gp.z, gp.w};
+        const double rd[3] = {rx, ry, rz};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) da1[ax][c] = fma(rd[ax], gpd[c], da1[ax][c]);
+            db[c] += gpd[c];
+        }
     }
 
     // wave-level sums over points, then one LDS add per wave (4 adders per slot, fixed slots)
@@ -428,31 +448,25 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
             }
         }
     }
+    // float64 part: shuffle tree over the wave's points, per-wave LDS slots, fixed-order block sum
 #pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-        float4 t = da1[ax];
-        t.x = over_points<D>(t.x); t.y = over_points<D>(t.y);
-        t.z = over_points<D>(t.z); t.w = over_points<D>(t.w);
-        if (lane < L) {
-            atomicAdd(&s_acc[D * D + (4 * q + 0) * 3 + ax], t.x);
-            atomicAdd(&s_acc[D * D + (4 * q + 1) * 3 + ax], t.y);
-            atomicAdd(&s_acc[D * D + (4 * q + 2) * 3 + ax], t.z);
-            atomicAdd(&s_acc[D * D + (4 * q + 3) * 3 + ax], t.w);
-        }
-    }
-    {
-        float4 t = db;
-        t.x = over_points<D>(t.x); t.y = over_points<D>(t.y);
-        t.z = over_points<D>(t.z); t.w = over_points<D>(t.w);
-        if (lane < L) {
-            atomicAdd(&s_acc[D * D + 3 * D + 4 * q + 0], t.x);
-            atomicAdd(&s_acc[D * D + 3 * D + 4 * q + 1], t.y);
-            atomicAdd(&s_acc[D * D + 3 * D + 4 * q + 2], t.z);
-            atomicAdd(&s_acc[D * D + 3 * D + 4 * q + 3], t.w);
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int ax = 0; ax < 4; ++ax) {                       // ax == 3 -> db1
+            double t = ax < 3 ? da1[ax < 3 ? ax : 0][c] : db[c];
+#pragma unroll
+            for (int o = L; o < WAVE; o <<= 1) t += __shfl_xor(t, o, WAVE);
+            if (lane < L) s_accd[wave][(4 * q + c) * 4 + ax] = t;
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < NSLOT; t += PBLOCK) partial[(int64_t)blockIdx.x * NSLOT + t] = s_acc[t];
+    for (int t = threadIdx.x; t < D * D; t += PBLOCK) partial[(int64_t)blockIdx.x * D * D + t] = s_acc[t];
+    for (int t = threadIdx.x; t < 4 * D; t += PBLOCK) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < PWAVES; ++w) a += s_accd[w][t];
+        partial_d[(int64_t)blockIdx.x * 4 * D + t] = a;        // [channel][x, y, z, bias]
+    }
 }
 
 // ------------------------------------------------------------------ backward pass 2 for wide layers
@@ -591,8 +605,8 @@ using namespace crf;
 extern "C" size_t crfconv_pointconv_workspace(int64_t m_tgt, int K, int d) {
     if (m_tgt <= 0 || d < 4) return 0;
     const size_t a = (size_t)cdiv(m_tgt, 256) * 9;                               // moments
-    const size_t b = (size_t)blocks_for(m_tgt, d) * ((size_t)d * d + 4 * (size_t)d);  // params (largest)
-    return sizeof(float) * (a > b ? a : b) + 256;
+    const size_t b = (size_t)blocks_for(m_tgt, d) * ((size_t)d * d + 8 * (size_t)d);  // params: float d*d + double 4d
+    return sizeof(float) * (a > b ? a : b) + 1024;
 }
 
 extern "C" int crfconv_pointconv_moments(const float* pos_src, const float* pos_tgt, const int32_t* idx32,
@@ -671,28 +685,32 @@ extern "C" int crfconv_pointconv_bwd_params(const float* x, const float* gout, c
                                             const float* pos_tgt, const int32_t* idx32, int K,
                                             int64_t m_tgt, int d, const float* A1, const float* b1,
                                             const float* W2, const float* ca, const float* cb,
-                                            const float* cc, double* dW2, double* dA1, double* db1,
-                                            void* workspace, size_t workspace_bytes, crf_stream_t stream) {
+                                            const float* cc, double* dW2, double* dA1b1, void* workspace,
+                                            size_t workspace_bytes, crf_stream_t stream) {
     if (int rc = check_pc(m_tgt, K, d)) return rc;
-    CRF_REQUIRE(x && gout && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && ca && cb && cc && dW2 && dA1 &&
-                    db1 && workspace, CRF_ERR_ARG, "null pointer");
-    CRF_REQUIRE(dA1 == dW2 + (size_t)d * d && db1 == dA1 + (size_t)d * 3, CRF_ERR_ARG,
-                "dW2/dA1/db1 must be one contiguous [d*d + 3d + d] float64 buffer");
+    CRF_REQUIRE(x && gout && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && ca && cb && cc && dW2 && dA1b1 &&
+                    workspace, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(d <= 32, CRF_ERR_UNSUPPORTED, "in-kernel parameter reduction covers d <= 32; use crfconv_pointconv_bwd_dump for d=%d", d);
     const int64_t nblk = blocks_for(m_tgt, d);
-    const int nslot = d * d + 4 * d;
-    CRF_REQUIRE(workspace_bytes >= sizeof(float) * (size_t)nslot * (size_t)nblk, CRF_ERR_WORKSPACE,
-                "workspace too small");
+    const size_t fbytes = (sizeof(float) * (size_t)d * d * (size_t)nblk + 255) & ~(size_t)255;
+    const size_t dbytes = sizeof(double) * 4 * (size_t)d * (size_t)nblk;
+    CRF_REQUIRE(workspace_bytes >= fbytes + dbytes + 256, CRF_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = as_stream(stream);
-    float* partial = reinterpret_cast<float*>(workspace);
+    char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    float* partial = reinterpret_cast<float*>(base);
+    double* partial_d = reinterpret_cast<double*>(base + fbytes);
     switch (d) {
-        case 4: hipLaunchKernelGGL(bwd_params_kernel<4>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial); break;
-        case 8: hipLaunchKernelGGL(bwd_params_kernel<8>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial); break;
-        case 16: hipLaunchKernelGGL(bwd_params_kernel<16>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial); break;
-        default: hipLaunchKernelGGL(bwd_params_kernel<32>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial); break;
+        case 4: hipLaunchKernelGGL(bwd_params_kernel<4>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial, partial_d); break;
+        case 8: hipLaunchKernelGGL(bwd_params_kernel<8>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial, partial_d); break;
+        case 16: hipLaunchKernelGGL(bwd_params_kernel<16>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial, partial_d); break;
+        default: hipLaunchKernelGGL(bwd_params_kernel<32>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial, partial_d); break;
     }
     CRF_LAUNCH_CHECK();
-    return reduce_partials(partial, nblk, nslot, dW2, st);
+    if (int rc = reduce_partials(partial, nblk, d * d, dW2, st)) return rc;
+    hipLaunchKernelGGL(reduce_partials_d_kernel, dim3((unsigned)cdiv(4 * d, 256 / WAVE)), dim3(256), 0, st, partial_d,
+                       nblk, 4 * d, dA1b1);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
 }
 
 extern "C" int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const float* pos_tgt,

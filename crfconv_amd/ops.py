@@ -39,8 +39,7 @@ class _MeanField(torch.autograd.Function):
         require_gpu(z, y, Q, P)
         m, H = z.shape
         z, y, Q, P = _f32c(z), _f32c(y), _f32c(Q), _f32c(P)
-        Kn = table.K - k0
-        s = torch.empty((m, Kn), dtype=torch.float32, device=z.device)
+        s = torch.empty((m, table.K), dtype=torch.float32, device=z.device)   # edge-id addressed: s[i*K + k]
         zq = torch.empty_like(z)
         xs = torch.empty((max(steps, 1), m, H), dtype=torch.float32, device=z.device)
         _lib.call('crfconv_meanfield_forward', ptr(z), ptr(y), ptr(table.idx32), table.K, k0, m, H, ptr(Q),
@@ -262,12 +261,12 @@ class _PointConv(torch.autograd.Function):
         # pass 2: parameter gradients
         ca32, cb32, cc32 = ca.float(), cb.float(), cc.float()      # locals: operands must outlive the launch
         if d <= 32:
-            par = torch.empty(d * d + 4 * d, dtype=torch.float64, device=dev)
-            dW2, dA1, db1 = par[:d * d], par[d * d:d * d + 3 * d], par[d * d + 3 * d:]
+            dW2 = torch.empty(d * d, dtype=torch.float64, device=dev)
+            dA1b1 = torch.empty((d, 4), dtype=torch.float64, device=dev)
             _lib.call('crfconv_pointconv_bwd_params', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32),
-                      K, m_tgt, d, ptr(A1), ptr(b1), ptr(W2), ptr(ca32), ptr(cb32), ptr(cc32), ptr(dW2), ptr(dA1),
-                      ptr(db1), ptr(ws), nbytes, st)
-            dW2, dA1, db1 = dW2.float().view(d, d), dA1.float().view(d, 3), db1.float()
+                      K, m_tgt, d, ptr(A1), ptr(b1), ptr(W2), ptr(ca32), ptr(cb32), ptr(cc32), ptr(dW2), ptr(dA1b1),
+                      ptr(ws), nbytes, st)
+            dW2, dA1, db1 = dW2.float().view(d, d), dA1b1[:, :3], dA1b1[:, 3]      # dA1/db1 stay float64
         else:
             # wide, edge-poor levels: per-edge h1 / g_h2 / rel to HBM, contractions as dense GEMMs
             E = m_tgt * K
@@ -279,8 +278,9 @@ class _PointConv(torch.autograd.Function):
                       ptr(rel), st)
             dW2 = gh2.t() @ h1
             gp = (gh2 @ W2) * torch.where(h1 > 0, 1.0, 0.1)
-            dA1 = gp.t() @ rel
-            db1 = gp.sum(0)
+            gpd = gp.double()
+            dA1 = gpd.t() @ rel.double()                                           # float64: see bwd_params
+            db1 = gpd.sum(0)
         # input gradient (source-major gather over the reverse table)
         rev_ptr, rev_eid = table.reverse
         dx = torch.empty((table.m_src, d), dtype=torch.float32, device=dev)
@@ -321,8 +321,8 @@ def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=
     else:
         mean1, var1 = bn1.running_mean.double(), bn1.running_var.double()
     a1 = bn1.weight.double() * torch.rsqrt(var1 + bn1.eps)
-    A1 = (a1.unsqueeze(1) * W1d).float()
-    b1 = (bn1.bias.double() - a1 * mean1).float()
+    A1 = a1.unsqueeze(1) * W1d                    # float64 nodes: their gradients come back in float64
+    b1 = bn1.bias.double() - a1 * mean1
     # ---- the fused kernels (BatchNorm-2 inside)
     use_batch2 = training or bn2.running_mean is None
     aux = {} if use_batch2 else None

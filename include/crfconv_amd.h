@@ -106,29 +106,31 @@ int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_src, int32_t*
  * continuous_crf_conv_big.py:45-47); Kn = K - k0 <= 63.
  *   s[i,k]  = softmax_k( -|y_i - y_j(i,k)|^2 )                       (:49-54)
  *   x_0 = z ;  x_t = z Q + (sum_k s[i,k] x_{t-1}[j(i,k)]) P          (:68-72 with Q = (I+C)^-1, P = C Q)
- * Outputs: s [m, Kn];  zq [m, H] = z Q;  xs [T, m, H] = x_1 .. x_T. */
+ * Outputs: s [m, K] (edge-id addressed: s[i*K + k], zero on columns < k0);  zq [m, H] = z Q;
+ * xs [T, m, H] = x_1 .. x_T.  K in {16, 32} with k0 = 1 takes the fused fast path (similarity + first
+ * step in one launch, index / weight rows as aligned dwordx4 loads). */
 int crfconv_meanfield_forward(const float* z, const float* y, const int32_t* idx32, int K, int k0,
                               int64_t m, int H, const float* Q, const float* P, int T, float* s,
                               float* zq, float* xs, crf_stream_t stream);
 
 /* One backward step, edge half:  given G = dL/dx_t and x_{t-1}:
  *   gm  = G P^T                              [m, H]
- *   ds (+)= <gm_i, x_{t-1}[j(i,k)]>          [m, Kn]   (accumulate != 0 adds to ds)
+ *   ds (+)= <gm_i, x_{t-1}[j(i,k)]>          [m, K]    (accumulate != 0 adds to ds)
  *   mt  = sum_k s[i,k] x_{t-1}[j(i,k)]       [m, H]    (for dP = mt^T G; may be NULL) */
 int crfconv_meanfield_bwd_edge(const float* G, const float* xprev, const float* s,
                                const int32_t* idx32, int K, int k0, int64_t m, int H,
                                const float* P, float* gm, float* ds, float* mt, int accumulate,
                                crf_stream_t stream);
-/* Scatter half:  Gprev[j] = (add ? add[j] : 0) + sum_{e=(i,k) in rev(j), k>=k0} s[i,k-k0] gm[i]. */
+/* Scatter half:  Gprev[j] = (add ? add[j] : 0) + sum_{e=(i,k) in rev(j)} s[e] gm[i]. */
 int crfconv_meanfield_bwd_scatter(const float* gm, const float* s, const int32_t* rev_ptr,
                                   const int32_t* rev_eid, int K, int k0, int64_t m_src, int H,
                                   const float* add, float* Gprev, crf_stream_t stream);
-/* Softmax + distance backward.  In: ds, s.  Out: w [m, Kn] = 2 * d(loss)/d(dist_ik) (must NOT
+/* Softmax + distance backward.  In: ds, s.  Out: w [m, K] = 2 * d(loss)/d(dist_ik) (must NOT
  * alias ds), dy_self[i] = sum_k w_ik (y_i - y_j). */
 int crfconv_similarity_bwd(const float* ds, const float* s, const float* y, const int32_t* idx32,
                            int K, int k0, int64_t m, int H, float* w, float* dy_self,
                            crf_stream_t stream);
-/* dy[j] = dy_self[j] + sum_{e=(i,k) in rev(j), k>=k0} w[i,k-k0] (y_j - y_i). */
+/* dy[j] = dy_self[j] + sum_{e=(i,k) in rev(j)} w[e] (y_j - y_i). */
 int crfconv_similarity_bwd_scatter(const float* w, const float* y, const float* dy_self,
                                    const int32_t* rev_ptr, const int32_t* rev_eid, int K, int k0,
                                    int64_t m_src, int H, float* dy, crf_stream_t stream);
@@ -166,12 +168,13 @@ int crfconv_pointconv_bwd_reduce(const float* x, const float* gout, const float*
                                  crf_stream_t stream);
 /* Pass 2:  g_h2[e,c] = ca[c] * g_w[e,c] + cb[c] * h2[e,c] + cc[c]  (the host folds BatchNorm-2's
  * backward into ca/cb/cc; eval mode: ca = a2, cb = cc = 0), then back through W2, lrelu, A1:
- *   dW2 [d,d], dA1 [d,3], db1 [d]  as float64 sums (one contiguous buffer).  d <= 32. */
+ *   dW2 [d,d] and dA1b1 [d,4] = {dA1[c][0..2], db1[c]} as float64 sums (the latter accumulated in
+ * float64 throughout: the host's analytic BatchNorm-1 backward cancels their large common parts).  d <= 32. */
 int crfconv_pointconv_bwd_params(const float* x, const float* gout, const float* pos_src,
                                  const float* pos_tgt, const int32_t* idx32, int K, int64_t m_tgt,
                                  int d, const float* A1, const float* b1, const float* W2,
                                  const float* ca, const float* cb, const float* cc, double* dW2,
-                                 double* dA1, double* db1, void* workspace, size_t workspace_bytes,
+                                 double* dA1b1, void* workspace, size_t workspace_bytes,
                                  crf_stream_t stream);
 /* Pass 2 for wide layers (d >= 64, few edges): instead of reducing in-kernel, write per edge e = i*K + k
  *   h1 [E, d],  g_h2 [E, d] (same definition as above),  rel [E, 3]
