@@ -68,13 +68,12 @@ def roofline_meanfield(data, dev, H=8, T=3, iters=50):
     P = (C @ Q).to(dev).contiguous()
     Q = Q.to(dev).contiguous()
     s = torch.empty(m, K, device=dev)
-    zq = torch.empty(m, H, device=dev)
     xs = torch.empty(T, m, H, device=dev)
     st = stream_ptr()
 
     def launch():
         _lib.call('crfconv_meanfield_forward', ptr(z), ptr(y), ptr(tab.idx32), K, 1, m, H, ptr(Q), ptr(P), T, ptr(s),
-                  ptr(zq), ptr(xs), st)
+                  ptr(xs), st)
     for _ in range(10):
         launch()
     torch.cuda.synchronize()

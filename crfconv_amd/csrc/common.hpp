@@ -40,6 +40,18 @@ inline hipStream_t as_stream(crf_stream_t s) { return reinterpret_cast<hipStream
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ----------------------------------------------------------------------------- device helpers
+// XCD-aware block order.  MI355X deals workgroups round-robin over its 8 XCDs (block b -> XCD b % 8),
+// each with a private 4 MiB L2.  Kernels here walk spatially sorted points and gather neighbour rows,
+// so handing every XCD one CONTIGUOUS eighth of the blocks keeps an XCD's gathers inside its own
+// eighth of the table (one L2 fill per row instead of up to eight).  Bijective for any grid size;
+// the placement assumption only affects speed, never results.
+__device__ __forceinline__ unsigned xcd_block_id() {
+    const unsigned nb = gridDim.x, b = blockIdx.x;
+    const unsigned xcd = b & 7u, within = b >> 3;
+    const unsigned base = nb >> 3, rem = nb & 7u;
+    return xcd * base + (xcd < rem ? xcd : rem) + within;
+}
+
 // Sum over aligned groups of L consecutive lanes (L a power of two <= 64); every lane of the
 // group receives the total.
 template <int L>

@@ -15,6 +15,8 @@
 // Reference semantics: models/continuous_crf_conv_big.py:49-54 (similarity), :63-72 (loop).
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace crf {
 
 constexpr int BLOCK = 256;
@@ -58,7 +60,7 @@ template <int H>
 __device__ __forceinline__ int64_t my_point(int64_t m, int& lane, int& q, bool& valid) {
     lane = threadIdx.x & 63;
     q = lane % Geo<H>::L;
-    const int64_t row = (int64_t)blockIdx.x * Geo<H>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / Geo<H>::L;
+    const int64_t row = (int64_t)xcd_block_id() * Geo<H>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / Geo<H>::L;
     valid = row < m;
     return valid ? row : m - 1;
 }
@@ -81,18 +83,17 @@ __device__ __forceinline__ void load_row(const T* __restrict__ p, T (&out)[K]) {
 // (K in {16, 32}, k0 == 1).  FIRST = similarity + z Q + first step fused: the index row is read
 // once, s never round-trips through memory before its first use.
 template <int H, int K, bool WITH_STEP>
-__global__ __launch_bounds__(BLOCK) void sim_step_fast_kernel(const float* __restrict__ y,
+__global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_fast_kernel(const float* __restrict__ y,
                                                               const float* __restrict__ z,
                                                               const int32_t* __restrict__ idx,
                                                               const float* __restrict__ Q,
                                                               const float* __restrict__ P,
                                                               float* __restrict__ s,
-                                                              float* __restrict__ zq,
                                                               float* __restrict__ x1, int64_t m) {
     constexpr int L = Geo<H>::L;
-    __shared__ float4 sQ[H * L];
+    __shared__ float4 sQ[WITH_STEP ? H * L : 1];
     __shared__ float4 sP[WITH_STEP ? H * L : 1];
-    load_matrix<H>(sQ, Q, false);
+    if constexpr (WITH_STEP) load_matrix<H>(sQ, Q, false);
     if constexpr (WITH_STEP) load_matrix<H>(sP, P, false);
     __syncthreads();
     int lane, q;
@@ -132,10 +133,9 @@ __global__ __launch_bounds__(BLOCK) void sim_step_fast_kernel(const float* __res
     for (int c = 0; c < K / 4; ++c)
         if (valid && (c % L) == q) st4(s + r * K + 4 * c, make_float4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]));
 
-    const float4 zi = ld4(z + r * H + 4 * q);
-    const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
-    if (valid) st4(zq + r * H + 4 * q, zqi);
     if constexpr (WITH_STEP) {
+        const float4 zi = ld4(z + r * H + 4 * q);
+        const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
         float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 1; k < K; ++k) msg = fma4(d[k], nb[k], msg);
@@ -146,14 +146,17 @@ __global__ __launch_bounds__(BLOCK) void sim_step_fast_kernel(const float* __res
 
 template <int H, int K>
 __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restrict__ xin,
-                                                          const float* __restrict__ zq,
+                                                          const float* __restrict__ z,
                                                           const float* __restrict__ s,
                                                           const int32_t* __restrict__ idx,
+                                                          const float* __restrict__ Q,
                                                           const float* __restrict__ P,
                                                           float* __restrict__ xout, int64_t m) {
     constexpr int L = Geo<H>::L;
     __shared__ float4 sP[H * L];
+    __shared__ float4 sQ[H * L];
     load_matrix<H>(sP, P, false);
+    load_matrix<H>(sQ, Q, false);
     __syncthreads();
     int lane, q;
     bool valid;
@@ -165,10 +168,155 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
     float4 nb[K];
 #pragma unroll
     for (int k = 1; k < K; ++k) nb[k] = ld4(xin + (int64_t)j[k] * H + 4 * q);
-    const float4 zqi = ld4(zq + r * H + 4 * q);
+    // z Q recomputed from z (same bytes as reading a stored z Q, and nothing extra to write)
+    const float4 zqi = matvec_acc<H>(ld4(z + r * H + 4 * q), sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
     float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 1; k < K; ++k) msg = fma4(w[k], nb[k], msg);
+    const float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
+    if (valid) st4(xout + r * H + 4 * q, o);
+}
+
+// ====================================================================== LDS-window forward kernels
+// With spatially sorted clouds (the device collate emits Morton order) ~80 % of a block's
+// neighbour rows lie within +-HALO rows of the block itself.  The block stages that contiguous
+// window with coalesced 16-byte loads and serves in-window neighbours from LDS (ds_read_b128);
+// only the rest goes through the vector-memory gather path.  Correct for any point order -- an
+// unsorted cloud just finds fewer neighbours in its window.
+template <int H, int NT, int HALO>
+struct Win {
+    static constexpr int L = H / 4, PPW = WAVE / L, PPB = NT / L, ROWS = PPB + 2 * HALO;
+    __device__ static __forceinline__ int64_t base(int64_t m) {
+        int64_t first = (int64_t)xcd_block_id() * PPB - HALO;
+        const int64_t hi = m - ROWS;
+        if (first > hi) first = hi;
+        if (first < 0) first = 0;
+        return first;
+    }
+    __device__ static __forceinline__ void stage(float4* dst, const float* __restrict__ src, int64_t w0, int64_t m) {
+        const float4* s4 = reinterpret_cast<const float4*>(src) + w0 * L;
+        const int64_t lim = (m - w0) * L;
+        for (int t = threadIdx.x; t < ROWS * L; t += NT)
+            dst[t] = t < lim ? s4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ static __forceinline__ float4 fetch(const float4* lds, const float* __restrict__ src, int w0, int j, int q) {
+        const int jl = j - w0;
+        return (unsigned)jl < (unsigned)ROWS ? lds[jl * L + q] : ld4(src + (int64_t)j * H + 4 * q);
+    }
+    __device__ static __forceinline__ int64_t point(int64_t m, int& lane, int& q, bool& valid) {
+        lane = threadIdx.x & 63;
+        q = lane % L;
+        const int64_t row = (int64_t)xcd_block_id() * PPB + (threadIdx.x >> 6) * PPW + lane / L;
+        valid = row < m;
+        return valid ? row : m - 1;
+    }
+};
+
+template <int H, int NT>
+__device__ __forceinline__ void load_matrix_nt(float4* sM, const float* __restrict__ Mat, bool transpose) {
+    float* s = reinterpret_cast<float*>(sM);
+    for (int t = threadIdx.x; t < H * H; t += NT) {
+        const int h = t / H, c = t % H;
+        s[t] = transpose ? Mat[c * H + h] : Mat[t];
+    }
+}
+
+template <int H, int K, int NT, int HALO, bool WITH_STEP>
+__global__ __launch_bounds__(NT) void sim_step_win_kernel(const float* __restrict__ y,
+                                                          const float* __restrict__ z,
+                                                          const int32_t* __restrict__ idx,
+                                                          const float* __restrict__ Q,
+                                                          const float* __restrict__ P,
+                                                          float* __restrict__ s,
+                                                          float* __restrict__ x1, int64_t m) {
+    using W = Win<H, NT, HALO>;
+    constexpr int L = W::L;
+    __shared__ float4 sQ[H * L];
+    __shared__ float4 sP[WITH_STEP ? H * L : 1];
+    __shared__ float4 sY[W::ROWS * L];
+    __shared__ float4 sZ[WITH_STEP ? W::ROWS * L : 1];
+    const int64_t w0 = W::base(m);
+    load_matrix_nt<H, NT>(sQ, Q, false);
+    if constexpr (WITH_STEP) load_matrix_nt<H, NT>(sP, P, false);
+    W::stage(sY, y, w0, m);
+    if constexpr (WITH_STEP) W::stage(sZ, z, w0, m);
+    int lane, q;
+    bool valid;
+    const int64_t r = W::point(m, lane, q, valid);
+    int j[K];
+    load_row<K, int4>(idx + r * K, j);
+    const float4 yi = ld4(y + r * H + 4 * q);
+    const float4 zi = ld4(z + r * H + 4 * q);
+    __syncthreads();
+
+    float4 nb[K];
+#pragma unroll
+    for (int k = 1; k < K; ++k) nb[k] = W::fetch(sY, y, (int)w0, j[k], q);
+    float d[K];
+    float dmin = 3.4e38f;
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        const float4 df = sub4(yi, nb[k]);
+        d[k] = group_sum<L>(dot4(df, df));
+        dmin = fminf(dmin, d[k]);
+    }
+    if constexpr (WITH_STEP) {
+#pragma unroll
+        for (int k = 1; k < K; ++k) nb[k] = W::fetch(sZ, z, (int)w0, j[k], q);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        d[k] = expf(dmin - d[k]);
+        den += d[k];
+    }
+    const float inv = 1.0f / den;
+    d[0] = 0.f;
+#pragma unroll
+    for (int k = 1; k < K; ++k) d[k] *= inv;
+#pragma unroll
+    for (int c = 0; c < K / 4; ++c)
+        if (valid && (c % L) == q) st4(s + r * K + 4 * c, make_float4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]));
+    if constexpr (WITH_STEP) {
+        const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
+        float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 1; k < K; ++k) msg = fma4(d[k], nb[k], msg);
+        const float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
+        if (valid) st4(x1 + r * H + 4 * q, o);
+    }
+}
+
+template <int H, int K, int NT, int HALO>
+__global__ __launch_bounds__(NT) void step_win_kernel(const float* __restrict__ xin,
+                                                      const float* __restrict__ z,
+                                                      const float* __restrict__ s,
+                                                      const int32_t* __restrict__ idx,
+                                                      const float* __restrict__ Q,
+                                                      const float* __restrict__ P,
+                                                      float* __restrict__ xout, int64_t m) {
+    using W = Win<H, NT, HALO>;
+    constexpr int L = W::L;
+    __shared__ float4 sP[H * L];
+    __shared__ float4 sQ[H * L];
+    __shared__ float4 sX[W::ROWS * L];
+    const int64_t w0 = W::base(m);
+    load_matrix_nt<H, NT>(sP, P, false);
+    load_matrix_nt<H, NT>(sQ, Q, false);
+    W::stage(sX, xin, w0, m);
+    int lane, q;
+    bool valid;
+    const int64_t r = W::point(m, lane, q, valid);
+    int j[K];
+    float w[K];
+    load_row<K, int4>(idx + r * K, j);
+    load_row<K, float4>(s + r * K, w);
+    const float4 zi = ld4(z + r * H + 4 * q);
+    __syncthreads();
+    const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
+    float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 1; k < K; ++k) msg = fma4(w[k], W::fetch(sX, xin, (int)w0, j[k], q), msg);
     const float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
     if (valid) st4(xout + r * H + 4 * q, o);
 }
@@ -177,15 +325,9 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
 // any K <= 64, any k0: distances recomputed in a second sweep (rows are L1/L2 hot by then).
 template <int H>
 __global__ __launch_bounds__(BLOCK) void sim_kernel(const float* __restrict__ y,
-                                                    const float* __restrict__ z,
                                                     const int32_t* __restrict__ idx, int K, int k0,
-                                                    const float* __restrict__ Q,
-                                                    float* __restrict__ s, float* __restrict__ zq,
-                                                    int64_t m) {
+                                                    float* __restrict__ s, int64_t m) {
     constexpr int L = Geo<H>::L;
-    __shared__ float4 sQ[H * L];
-    load_matrix<H>(sQ, Q, false);
-    __syncthreads();
     int lane, q;
     bool valid;
     const int64_t r = my_point<H>(m, lane, q, valid);
@@ -210,21 +352,21 @@ __global__ __launch_bounds__(BLOCK) void sim_kernel(const float* __restrict__ y,
         for (int k = 0; k < k0; ++k) srow[k] = 0.f;
         for (int k = k0; k < K; ++k) srow[k] *= inv;
     }
-    const float4 zi = ld4(z + r * H + 4 * q);
-    const float4 o = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
-    if (valid) st4(zq + r * H + 4 * q, o);
 }
 
 template <int H>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const float* __restrict__ xin,
-                                                     const float* __restrict__ zq,
+                                                     const float* __restrict__ z,
                                                      const float* __restrict__ s,
                                                      const int32_t* __restrict__ idx, int K, int k0,
+                                                     const float* __restrict__ Q,
                                                      const float* __restrict__ P,
                                                      float* __restrict__ xout, int64_t m) {
     constexpr int L = Geo<H>::L;
     __shared__ float4 sP[H * L];
+    __shared__ float4 sQ[H * L];
     load_matrix<H>(sP, P, false);
+    load_matrix<H>(sQ, Q, false);
     __syncthreads();
     int lane, q;
     bool valid;
@@ -234,7 +376,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const float* __restrict__ x
     float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
     for (int k = k0; k < K; ++k) msg = fma4(srow[k], ld4(xin + (int64_t)irow[k] * H + 4 * q), msg);
-    const float4 o = matvec_acc<H>(msg, sP, lane, q, ld4(zq + r * H + 4 * q));
+    const float4 zqi = matvec_acc<H>(ld4(z + r * H + 4 * q), sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
+    const float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
     if (valid) st4(xout + r * H + 4 * q, o);
 }
 
@@ -316,7 +459,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_scatter_kernel(const float* __restr
     constexpr int L = Geo<H>::L;
     const int lane = threadIdx.x & 63;
     const int q = lane % L;
-    const int64_t row = (int64_t)blockIdx.x * Geo<H>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / L;
+    const int64_t row = (int64_t)xcd_block_id() * Geo<H>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / L;
     if (row >= m_src) return;  // no cross-lane traffic below
     float4 acc = add ? ld4(add + row * H + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int beg = rev_ptr[row], end = rev_ptr[row + 1];
@@ -374,7 +517,7 @@ __global__ __launch_bounds__(BLOCK) void sim_bwd_scatter_kernel(const float* __r
     constexpr int L = Geo<H>::L;
     const int lane = threadIdx.x & 63;
     const int q = lane % L;
-    const int64_t row = (int64_t)blockIdx.x * Geo<H>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / L;
+    const int64_t row = (int64_t)xcd_block_id() * Geo<H>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / L;
     if (row >= m_src) return;
     const float4 yj = ld4(y + row * H + 4 * q);
     float4 acc = ld4(dy_self + row * H + 4 * q);
@@ -397,6 +540,12 @@ static int check_common(int64_t m, int H, int K, int k0) {
     return CRF_OK;
 }
 
+// The LDS-window kernels measured SLOWER than the plain gather kernels on MI355X (43.0 vs 39.5 us for the
+// level-0 forward, profiles/r1b): after Morton ordering + XCD-contiguous blocks the gathers are L1/L2 hits
+// and the step is bound by the idx / weight / state streams, not by gather issue.  Kept for A/B runs:
+// CRFCONV_WINDOW=1 enables them.
+static const bool g_use_window = (getenv("CRFCONV_WINDOW") != nullptr);
+
 static int kshift_of(int K) {
     for (int sft = 0; sft < 7; ++sft)
         if ((1 << sft) == K) return sft;
@@ -418,35 +567,53 @@ using namespace crf;
 
 extern "C" int crfconv_meanfield_forward(const float* z, const float* y, const int32_t* idx32, int K,
                                          int k0, int64_t m, int H, const float* Q, const float* P,
-                                         int T, float* s, float* zq, float* xs, crf_stream_t stream) {
+                                         int T, float* s, float* xs, crf_stream_t stream) {
     if (int rc = check_common(m, H, K, k0)) return rc;
-    CRF_REQUIRE(z && y && idx32 && Q && P && s && zq && (xs || T == 0), CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(z && y && idx32 && Q && P && s && (xs || T == 0), CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(T >= 0, CRF_ERR_ARG, "T=%d < 0", T);
     hipStream_t st = as_stream(stream);
     const bool fast = (k0 == 1) && (K == 16 || K == 32);
     DISPATCH_H(H, {
         const dim3 grid((unsigned)cdiv(m, Geo<HH>::PPB)), blk(BLOCK);
         int t0 = 0;
+        constexpr bool HAS_WIN = (HH == 8 || HH == 16);
+        constexpr int NT = HH == 8 ? 512 : 256, HALO = HH == 8 ? 128 : 96;
+        const bool win = fast && K == 16 && HAS_WIN && g_use_window;
+        if (win) {
+            if constexpr (HAS_WIN) {
+                using W = Win<HH, NT, HALO>;
+                const dim3 wgrid((unsigned)cdiv(m, W::PPB)), wblk(NT);
+                if (T > 0) hipLaunchKernelGGL((sim_step_win_kernel<HH, 16, NT, HALO, true>), wgrid, wblk, 0, st, y, z, idx32, Q, P, s, xs, m);
+                else hipLaunchKernelGGL((sim_step_win_kernel<HH, 16, NT, HALO, false>), wgrid, wblk, 0, st, y, z, idx32, Q, P, s, xs, m);
+                CRF_LAUNCH_CHECK();
+                for (int t = 1; t < T; ++t) {
+                    hipLaunchKernelGGL((step_win_kernel<HH, 16, NT, HALO>), wgrid, wblk, 0, st, xs + (int64_t)(t - 1) * m * HH,
+                                       z, s, idx32, Q, P, xs + (int64_t)t * m * HH, m);
+                    CRF_LAUNCH_CHECK();
+                }
+            }
+            return CRF_OK;
+        }
         if (fast) {
             float* x1 = T > 0 ? xs : nullptr;
             if (K == 16) {
-                if (T > 0) hipLaunchKernelGGL((sim_step_fast_kernel<HH, 16, true>), grid, blk, 0, st, y, z, idx32, Q, P, s, zq, x1, m);
-                else hipLaunchKernelGGL((sim_step_fast_kernel<HH, 16, false>), grid, blk, 0, st, y, z, idx32, Q, P, s, zq, x1, m);
+                if (T > 0) hipLaunchKernelGGL((sim_step_fast_kernel<HH, 16, true>), grid, blk, 0, st, y, z, idx32, Q, P, s, x1, m);
+                else hipLaunchKernelGGL((sim_step_fast_kernel<HH, 16, false>), grid, blk, 0, st, y, z, idx32, Q, P, s, x1, m);
             } else {
-                if (T > 0) hipLaunchKernelGGL((sim_step_fast_kernel<HH, 32, true>), grid, blk, 0, st, y, z, idx32, Q, P, s, zq, x1, m);
-                else hipLaunchKernelGGL((sim_step_fast_kernel<HH, 32, false>), grid, blk, 0, st, y, z, idx32, Q, P, s, zq, x1, m);
+                if (T > 0) hipLaunchKernelGGL((sim_step_fast_kernel<HH, 32, true>), grid, blk, 0, st, y, z, idx32, Q, P, s, x1, m);
+                else hipLaunchKernelGGL((sim_step_fast_kernel<HH, 32, false>), grid, blk, 0, st, y, z, idx32, Q, P, s, x1, m);
             }
             t0 = 1;
         } else {
-            hipLaunchKernelGGL(sim_kernel<HH>, grid, blk, 0, st, y, z, idx32, K, k0, Q, s, zq, m);
+            hipLaunchKernelGGL(sim_kernel<HH>, grid, blk, 0, st, y, idx32, K, k0, s, m);
         }
         CRF_LAUNCH_CHECK();
         for (int t = t0; t < T; ++t) {
             const float* xin = t == 0 ? z : xs + (int64_t)(t - 1) * m * H;
             float* xout = xs + (int64_t)t * m * H;
-            if (fast && K == 16) hipLaunchKernelGGL((step_fast_kernel<HH, 16>), grid, blk, 0, st, xin, zq, s, idx32, P, xout, m);
-            else if (fast) hipLaunchKernelGGL((step_fast_kernel<HH, 32>), grid, blk, 0, st, xin, zq, s, idx32, P, xout, m);
-            else hipLaunchKernelGGL(step_kernel<HH>, grid, blk, 0, st, xin, zq, s, idx32, K, k0, P, xout, m);
+            if (fast && K == 16) hipLaunchKernelGGL((step_fast_kernel<HH, 16>), grid, blk, 0, st, xin, z, s, idx32, Q, P, xout, m);
+            else if (fast) hipLaunchKernelGGL((step_fast_kernel<HH, 32>), grid, blk, 0, st, xin, z, s, idx32, Q, P, xout, m);
+            else hipLaunchKernelGGL(step_kernel<HH>, grid, blk, 0, st, xin, z, s, idx32, K, k0, Q, P, xout, m);
             CRF_LAUNCH_CHECK();
         }
     });

@@ -111,7 +111,7 @@ __device__ __forceinline__ Row my_row(int64_t m, int& lane, int& wave, int& q) {
     lane = threadIdx.x & 63;
     wave = threadIdx.x >> 6;
     q = lane % PC<D>::L;
-    const int64_t row = (int64_t)blockIdx.x * PC<D>::PPB + wave * PC<D>::PPW + lane / PC<D>::L;
+    const int64_t row = (int64_t)xcd_block_id() * PC<D>::PPB + wave * PC<D>::PPW + lane / PC<D>::L;
     Row o;
     o.valid = row < m;
     o.r = o.valid ? row : m - 1;

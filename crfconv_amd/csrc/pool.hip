@@ -10,7 +10,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
                                                           int64_t m_tgt, int C4,
                                                           float* __restrict__ out,
                                                           int32_t* __restrict__ arg) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t)xcd_block_id() * 256 + threadIdx.x;
     if (t >= m_tgt * C4) return;
     const int64_t i = t / C4;
     const int q = (int)(t - i * C4);
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
                                                           const int32_t* __restrict__ rev_eid, int K,
                                                           int64_t m_src, int C4,
                                                           float* __restrict__ dx) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t)xcd_block_id() * 256 + threadIdx.x;
     if (t >= m_src * C4) return;
     const int64_t j = t / C4;
     const int q = (int)(t - j * C4);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
                                                           const int32_t* __restrict__ idx,
                                                           int64_t m_tgt, int C4,
                                                           float* __restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t)xcd_block_id() * 256 + threadIdx.x;
     if (t >= m_tgt * C4) return;
     const int64_t i = t / C4;
     const int q = (int)(t - i * C4);
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __res
                                                               const int32_t* __restrict__ rev_eid,
                                                               int64_t m_src, int C4,
                                                               float* __restrict__ dx) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t)xcd_block_id() * 256 + threadIdx.x;
     if (t >= m_src * C4) return;
     const int64_t j = t / C4;
     const int q = (int)(t - j * C4);

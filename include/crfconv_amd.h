@@ -106,12 +106,12 @@ int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_src, int32_t*
  * continuous_crf_conv_big.py:45-47); Kn = K - k0 <= 63.
  *   s[i,k]  = softmax_k( -|y_i - y_j(i,k)|^2 )                       (:49-54)
  *   x_0 = z ;  x_t = z Q + (sum_k s[i,k] x_{t-1}[j(i,k)]) P          (:68-72 with Q = (I+C)^-1, P = C Q)
- * Outputs: s [m, K] (edge-id addressed: s[i*K + k], zero on columns < k0);  zq [m, H] = z Q;
- * xs [T, m, H] = x_1 .. x_T.  K in {16, 32} with k0 = 1 takes the fused fast path (similarity + first
+ * Outputs: s [m, K] (edge-id addressed: s[i*K + k], zero on columns < k0);  xs [T, m, H] = x_1 .. x_T
+ * (z Q is recomputed per step from z: same read bytes as a stored copy, nothing extra to write).  K in {16, 32} with k0 = 1 takes the fused fast path (similarity + first
  * step in one launch, index / weight rows as aligned dwordx4 loads). */
 int crfconv_meanfield_forward(const float* z, const float* y, const int32_t* idx32, int K, int k0,
                               int64_t m, int H, const float* Q, const float* P, int T, float* s,
-                              float* zq, float* xs, crf_stream_t stream);
+                              float* xs, crf_stream_t stream);
 
 /* One backward step, edge half:  given G = dL/dx_t and x_{t-1}:
  *   gm  = G P^T                              [m, H]

@@ -185,8 +185,20 @@ def test_pointconv_widths_vs_oracle(d):
     (out * t(gout)).sum().backward()
     assert_close(out, ref, OUT_TOL, 'out')
     assert_close(xd.grad, xr.grad, GRAD_TOL, 'd_x')
+    # LeakyReLU kink: a channel whose layer-1 pre-activation sits within fp32 rounding of 0 on some
+    # edge (all self edges share rel = 0, so this happens for whole groups) has a one-sided derivative
+    # that ANY fp32 evaluation order may resolve either way; such channels are compared on outputs only.
+    P64 = torch.from_numpy(pos).double()
+    rel = (P64.unsqueeze(2) - O._rows(P64, torch.from_numpy(nbr))).reshape(-1, 3)
+    h = rel @ sd['weight_nn.0.lin.weight'].double().t()
+    pre = (h - h.mean(0)) / torch.sqrt(h.var(0, unbiased=False) + 1e-5) * sd['weight_nn.0.bn.batch_norm.weight'].double() \
+        + sd['weight_nn.0.bn.batch_norm.bias'].double()
+    ok = (pre.abs().min(0).values > 1e-5).to(DEV)
     for k, v in grads(m).items():
-        assert_close_anchored(v, prm[k].grad, prm64[k].grad, GRAD_TOL, 'grad ' + k)
+        a, b, c = v, prm[k].grad.to(DEV), prm64[k].grad.to(DEV)
+        if k.startswith('weight_nn.0.'):
+            a, b, c = a[ok], b[ok], c[ok]
+        assert_close_anchored(a, b, c, GRAD_TOL, 'grad ' + k)
 
 
 @pytest.mark.parametrize('name,mode', [('a', 'train'), ('a', 'eval'), ('b', 'train'), ('c', 'train'), ('c', 'eval')])

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.crfconv_abi_version() == 1
     # argument validation happens before any HIP call, so it is testable without a GPU
-    rc = lib.crfconv_meanfield_forward(None, None, None, 16, 1, 10, 7, None, None, 1, None, None, None, None)
+    rc = lib.crfconv_meanfield_forward(None, None, None, 16, 1, 10, 7, None, None, 1, None, None, None)
     assert rc == -3 and b'H=7' in lib.crfconv_last_error()
     rc = lib.crfconv_knn_batch_dev(None, 1, 10, 3, None, 10, 4, None, None, None, 0, None)
     assert rc == -1
