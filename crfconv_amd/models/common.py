@@ -5,6 +5,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+
 
 class FastBatchNorm1d(nn.Module):
     def __init__(self, num_features, momentum=0.1, **kwargs):
@@ -34,7 +36,7 @@ class MLP(nn.Module):
         self.activation = activation
 
     def forward(self, x, *args, **kwargs):
-        x = self.lin(x)
+        x = ops.linear(x, self.lin.weight, self.lin.bias)      # fwd / dX: vendor GEMM; dW: MFMA kernel
         if self.bn is not None:
             x = self.bn(x)
         if self.activation is not None:

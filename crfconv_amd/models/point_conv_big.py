@@ -130,5 +130,6 @@ class PointConvResNet(Base):
         x = self.deconv3(x, x3, ms[2].up_idx, ms[2].neighbor_idx)
         x = self.deconv2(x, x2, ms[1].up_idx, ms[1].neighbor_idx)
         x = self.deconv1(x, x1, ms[0].up_idx, ms[0].neighbor_idx)
-        x = self.classifier(x)
+        x = self.classifier[1](self.classifier[0](x))
+        x = ops.linear(x, self.classifier[2].weight, self.classifier[2].bias)
         return x.reshape(-1, self.C)

@@ -191,6 +191,15 @@ int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const f
                                 const float* W2, const float* a2, const float* b2, float* dx,
                                 crf_stream_t stream);
 
+/* ===================================================================== (B) per-point Linear layers
+ * Weight gradient of y = x W^T (+ b), the one contraction of models/common.py:30,35 vendor GEMMs handle
+ * badly (reduction over m = 10^4..10^5 rows into a tiny [Co, Ci]):
+ *   dW[co, ci] = sum_m G[m, co] X[m, ci];   db[co] = sum_m G[m, co]  (db may be NULL)
+ * fp32 MFMA (v_mfma_f32_16x16x4_f32, exact f32), operands streamed once, fixed-order reduction. */
+size_t crfconv_linear_wgrad_workspace(int64_t M, int Co, int Ci);
+int crfconv_linear_wgrad(const float* G, const float* X, int64_t M, int Co, int Ci, float* dW, float* db,
+                         void* workspace, size_t workspace_bytes, crf_stream_t stream);
+
 /* ===================================================================== (B) pooling / up-sampling
  * out[i,c] = max_k x[idx32[i,k], c];  arg [m_tgt, C] int32 = winning k (first maximum). */
 int crfconv_neighbor_maxpool_forward(const float* x, const int32_t* idx32, int K, int64_t m_tgt,

@@ -333,3 +333,22 @@ def test_meanfield_properties_full_size():
     assert float((out - out[0]).abs().max()) < 1e-5
     # fixed point of the iteration for that field: x = (v + x C)(I + C)^-1  <=>  x = v
     assert float((out[0] - v).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('M,Ci,Co,bias', [(163840, 32, 128, False), (40960, 64, 16, False), (1000, 6, 8, False),
+                                          (2560, 512, 256, False), (777, 128, 13, True), (163840, 8, 8, False)])
+def test_linear_wgrad_mfma(M, Ci, Co, bias):
+    """dW / db of the per-point Linear layers (MFMA kernel) against float64 torch."""
+    from crfconv_amd import ops
+    g = torch.Generator().manual_seed(M + Ci)
+    x = torch.randn(M, Ci, generator=g).to(DEV).requires_grad_(True)
+    W = torch.randn(Co, Ci, generator=g).to(DEV).requires_grad_(True)
+    b = torch.randn(Co, generator=g).to(DEV).requires_grad_(True) if bias else None
+    go = torch.randn(M, Co, generator=g).to(DEV)
+    y = ops.linear(x, W, b)
+    y.backward(go)
+    assert_close(y, torch.nn.functional.linear(x, W, b), 1e-5, 'y')
+    assert_close(W.grad, go.double().t() @ x.detach().double(), 2e-5, 'dW')     # relative to max |dW|
+    assert_close(x.grad, go @ W.detach(), 1e-5, 'dX')
+    if bias:
+        assert_close(b.grad, go.double().sum(0), 2e-5, 'db')
