@@ -127,6 +127,7 @@ def main():
     ap.add_argument('--points', type=int, default=40960)
     ap.add_argument('--crf-steps', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', type=int, default=1, help='capture the training step into a hipGraph (1) or run eagerly (0)')
     ap.add_argument('--sort', default='morton', choices=['morton', 'none'],
                     help="point order emitted by the device collate (kernels are order-agnostic)")
     args = ap.parse_args()
@@ -165,6 +166,30 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    graph_note = 'eager'
+    if args.graph:
+        # Capture the whole training step (fwd + loss + bwd [+ all-reduce] + SGD) into one hipGraph: the step
+        # issues ~2000 small launches, which would otherwise leave the GPU waiting on the Python host.
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_loss = step()
+            eager_step = step
+
+            def step():                                   # noqa: F811
+                g.replay()
+                return static_loss
+            graph_note = 'hipGraph replay of the captured step'
+        except Exception as e:                            # capture not possible: stay eager, say so
+            torch.cuda.synchronize()
+            graph_note = 'eager (graph capture failed: %s)' % str(e).splitlines()[0][:120]
     for _ in range(args.warmup):
         step()
     barrier()
@@ -194,6 +219,7 @@ def main():
                        'global_batch': world * B, 'points_per_cloud': N, 'parallelism': 'dp%d (batch-sharded)' % world},
             'final_loss': float(loss),
             'preprocess_ms_per_batch': t_pre * 1e3,
+            'launch_mode': graph_note,
         }
         out['roofline'] = roofline_meanfield(data, dev, 8, T)
         if world == 1 and not args.no_cpu_baseline:

@@ -109,7 +109,7 @@ shard = slice(rank * 4, rank * 4 + 4)
 bucket.zero()
 torch.nn.functional.cross_entropy(net(x[shard]), y[shard]).backward()
 bucket.allreduce_mean()
-torch.save(bucket.flat.clone(), os.environ['OUT'] + '.%%d' %% rank)
+torch.save(torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone(), os.environ['OUT'] + '.%%d' %% rank)
 if rank == 0:
     ref = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.LeakyReLU(0.1), torch.nn.Linear(16, 5))
     ref.load_state_dict(net.state_dict())
