@@ -189,6 +189,8 @@ def main():
             graph_note = 'hipGraph replay of the captured step'
         except Exception as e:                            # capture not possible: stay eager, say so
             torch.cuda.synchronize()
+            import traceback
+            traceback.print_exc()
             graph_note = 'eager (graph capture failed: %s)' % str(e).splitlines()[0][:120]
     for _ in range(args.warmup):
         step()

@@ -178,3 +178,45 @@ extern "C" int crfconv_linear_wgrad(const float* G, const float* X, int64_t M, i
     }
     return CRF_OK;
 }
+
+// ------------------------------------------------------------------ (I + C)^-1 for the CRF layers
+// Gauss-Jordan on the H x H (H <= 64) symmetric positive definite matrix M = I + c^T c
+// (models/continuous_crf_conv_big.py:72 calls .inverse() inside the loop; it is loop invariant).
+// One workgroup, float64 in LDS, no pivoting needed (eigenvalues >= 1).  Replaces torch.linalg.inv,
+// whose rocSOLVER path synchronises and therefore cannot be captured into a hipGraph.
+namespace crf {
+__global__ __launch_bounds__(256) void spd_inverse_kernel(const float* __restrict__ Min, int H,
+                                                          float* __restrict__ Qout) {
+    extern __shared__ double aug[];  // [H][2H]
+    const int W = 2 * H;
+    for (int t = threadIdx.x; t < H * W; t += 256) {
+        const int r = t / W, c = t % W;
+        aug[t] = c < H ? (double)Min[r * H + c] : (c - H == r ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for (int p = 0; p < H; ++p) {
+        const double piv = 1.0 / aug[p * W + p];
+        __syncthreads();
+        for (int c = threadIdx.x; c < W; c += 256) aug[p * W + c] *= piv;
+        __syncthreads();
+        for (int t = threadIdx.x; t < H * W; t += 256) {
+            const int r = t / W, c = t % W;
+            if (r != p && c != p) aug[t] -= aug[r * W + p] * aug[p * W + c];
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < H; r += 256)
+            if (r != p) aug[r * W + p] = 0.0;
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < H * H; t += 256) Qout[t] = (float)aug[(t / H) * W + H + (t % H)];
+}
+}  // namespace crf
+
+extern "C" int crfconv_spd_inverse(const float* M, int H, float* Q, crf_stream_t stream) {
+    CRF_REQUIRE(M && Q, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(H >= 1 && H <= 64, CRF_ERR_UNSUPPORTED, "H=%d outside [1, 64]", H);
+    hipLaunchKernelGGL(crf::spd_inverse_kernel, dim3(1), dim3(256), sizeof(double) * 2 * H * H, crf::as_stream(stream), M,
+                       H, Q);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}

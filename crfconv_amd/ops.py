@@ -84,6 +84,24 @@ class _MeanField(torch.autograd.Function):
         return dz, dy, dQ, dP, None, None, None
 
 
+class _SpdInverse(torch.autograd.Function):
+    """Q = M^-1 (M symmetric positive definite, H <= 64) on one workgroup; dM = -Q^T dQ Q^T."""
+
+    @staticmethod
+    def forward(ctx, M):
+        require_gpu(M)
+        Mc = _f32c(M)
+        Q = torch.empty_like(Mc)
+        _lib.call('crfconv_spd_inverse', ptr(Mc), Mc.shape[0], ptr(Q), stream_ptr())
+        ctx.save_for_backward(Q)
+        return Q
+
+    @staticmethod
+    def backward(ctx, gQ):
+        (Q,) = ctx.saved_tensors
+        return -(Q.t() @ gQ @ Q.t())
+
+
 _CRF_H = (4, 8, 16, 32, 64)
 
 
@@ -92,7 +110,7 @@ def crf_meanfield(z, y, c, table, steps, k0=1):
     H = z.shape[-1]
     eye = torch.eye(H, dtype=c.dtype, device=c.device)
     C = c.t() @ c
-    Q = torch.linalg.inv(eye + C)              # loop-invariant: computed once, not per step
+    Q = _SpdInverse.apply(eye + C)             # loop-invariant: computed once, not per step
     P = C @ Q
     Hp = _next_supported(H, _CRF_H)
     if Hp != H:                                 # zero channels stay zero through every step

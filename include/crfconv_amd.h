@@ -200,6 +200,10 @@ size_t crfconv_linear_wgrad_workspace(int64_t M, int Co, int Ci);
 int crfconv_linear_wgrad(const float* G, const float* X, int64_t M, int Co, int Ci, float* dW, float* db,
                          void* workspace, size_t workspace_bytes, crf_stream_t stream);
 
+/* Q = M^-1 for the symmetric positive definite M = I + c^T c of a CRF layer (H <= 64; Gauss-Jordan in
+ * float64, one workgroup, no host sync -- capturable into a hipGraph, unlike a LAPACK-style inverse). */
+int crfconv_spd_inverse(const float* M, int H, float* Q, crf_stream_t stream);
+
 /* ===================================================================== (B) pooling / up-sampling
  * out[i,c] = max_k x[idx32[i,k], c];  arg [m_tgt, C] int32 = winning k (first maximum). */
 int crfconv_neighbor_maxpool_forward(const float* x, const int32_t* idx32, int K, int64_t m_tgt,
