@@ -34,13 +34,13 @@ SIGNATURES = {
     'crfconv_similarity_bwd_scatter': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp]),
     'crfconv_pointconv_workspace': (_sz, [_i64, _i, _i]),
     'crfconv_pointconv_moments': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _sz, _vp]),
-    'crfconv_pointconv_stats': (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'crfconv_pointconv_forward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'crfconv_pointconv_bwd_reduce': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'crfconv_pointconv_bwd_params': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+    'crfconv_pointconv_stats': (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_pointconv_forward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    'crfconv_pointconv_bwd_reduce': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_pointconv_bwd_params': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _sz, _vp]),
-    'crfconv_pointconv_bwd_dump': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'crfconv_pointconv_bwd_input': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'crfconv_pointconv_bwd_dump': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'crfconv_pointconv_bwd_input': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     'crfconv_linear_wgrad_workspace': (_sz, [_i64, _i, _i]),
     'crfconv_linear_wgrad': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_spd_inverse': (_i, [_vp, _i, _vp, _vp]),

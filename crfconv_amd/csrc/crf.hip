@@ -335,19 +335,28 @@ __global__ __launch_bounds__(BLOCK) void sim_kernel(const float* __restrict__ y,
     const int32_t* irow = idx + r * K;
     float* srow = s + r * K;
 
-    auto dist_to = [&](int k) {
-        const float4 df = sub4(yi, ld4(y + (int64_t)irow[k] * H + 4 * q));
+    // entries < 0 mark "no neighbour" (padded variable-degree tables of the sparse operators)
+    auto dist_to = [&](int k, bool& have) {
+        const int j = irow[k];
+        have = j >= 0;
+        const float4 df = sub4(yi, ld4(y + (int64_t)(have ? j : 0) * H + 4 * q));
         return group_sum<L>(dot4(df, df));
     };
     float dmin = 3.4e38f;
-    for (int k = k0; k < K; ++k) dmin = fminf(dmin, dist_to(k));
+    for (int k = k0; k < K; ++k) {
+        bool have;
+        const float dk = dist_to(k, have);
+        if (have) dmin = fminf(dmin, dk);
+    }
     float den = 0.f;
     for (int k = k0; k < K; ++k) {
-        const float e = expf(dmin - dist_to(k));
+        bool have;
+        const float dk = dist_to(k, have);
+        const float e = have ? expf(dmin - dk) : 0.f;
         den += e;
         if (valid && q == 0) srow[k] = e;
     }
-    const float inv = 1.0f / den;
+    const float inv = den > 0.f ? 1.0f / den : 0.f;      // isolated point: no message
     if (valid && q == 0) {  // same lane re-reads what it wrote
         for (int k = 0; k < k0; ++k) srow[k] = 0.f;
         for (int k = k0; k < K; ++k) srow[k] *= inv;
@@ -375,7 +384,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const float* __restrict__ x
     const float* srow = s + r * K;
     float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
-    for (int k = k0; k < K; ++k) msg = fma4(srow[k], ld4(xin + (int64_t)irow[k] * H + 4 * q), msg);
+    for (int k = k0; k < K; ++k) {
+        const int j = irow[k];
+        if (j >= 0) msg = fma4(srow[k], ld4(xin + (int64_t)j * H + 4 * q), msg);
+    }
     const float4 zqi = matvec_acc<H>(ld4(z + r * H + 4 * q), sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
     const float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
     if (valid) st4(xout + r * H + 4 * q, o);
@@ -433,7 +445,10 @@ __global__ __launch_bounds__(BLOCK) void bwd_edge_kernel(const float* __restrict
         float* dsrow = ds + r * K;
 #pragma unroll 4
         for (int k = k0; k < K; ++k) {
-            const float4 xj = ld4(xprev + (int64_t)irow[k] * H + 4 * q);
+            const int j = irow[k];
+            const bool have = j >= 0;
+            float4 xj = ld4(xprev + (int64_t)(have ? j : 0) * H + 4 * q);
+            if (!have) xj = make_float4(0.f, 0.f, 0.f, 0.f);
             msg = fma4(srow[k], xj, msg);
             const float dotv = group_sum<L>(dot4(gmi, xj));
             if (valid && q == (k % L)) dsrow[k] = accumulate ? dsrow[k] + dotv : dotv;
@@ -495,8 +510,9 @@ __global__ __launch_bounds__(BLOCK) void sim_bwd_kernel(const float* __restrict_
 #pragma unroll 4
     for (int k = k0; k < K; ++k) {
         // d loss / d logit_k = s_k (ds_k - dot);  logit = -dist  =>  d/d dist = -that;  w = 2 * d/d dist
-        const float wk = -2.0f * srow[k] * (dsrow[k] - dotv);
-        acc = fma4(wk, sub4(yi, ld4(y + (int64_t)irow[k] * H + 4 * q)), acc);
+        const float wk = -2.0f * srow[k] * (dsrow[k] - dotv);      // 0 on missing entries (s == 0)
+        const int j = irow[k];
+        acc = fma4(wk, sub4(yi, ld4(y + (int64_t)(j >= 0 ? j : 0) * H + 4 * q)), acc);
         if (valid && q == (k % L)) wrow[k] = wk;
     }
     if (valid && q == 0)

@@ -22,9 +22,15 @@ __global__ __launch_bounds__(256) void narrow_kernel(const int64_t* __restrict__
     idx32[t] = (int32_t)(b * n_src + v);
 }
 
-__global__ __launch_bounds__(256) void iota_kernel(uint32_t* __restrict__ out, int64_t n) {
+// edge ids 0..E-1 and sort keys: the source row, or m_src for "no neighbour" entries (< 0), which
+// therefore sort behind every real row and fall outside rev_ptr[0 .. m_src].
+__global__ __launch_bounds__(256) void iota_keys_kernel(const int32_t* __restrict__ idx, int64_t n, int64_t m_src,
+                                                        uint32_t* __restrict__ ids, uint32_t* __restrict__ keys) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t < n) out[t] = (uint32_t)t;
+    if (t >= n) return;
+    ids[t] = (uint32_t)t;
+    const int32_t v = idx[t];
+    keys[t] = (v < 0 || v >= m_src) ? (uint32_t)m_src : (uint32_t)v;
 }
 
 // sorted keys -> rev_ptr: ptr[v] = first position p with key[p] >= v, for v in [0, m_src].
@@ -42,9 +48,9 @@ __global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t* __restr
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static int key_bits(int64_t m_src) {
+static int key_bits(int64_t m_src) {   // keys take values 0 .. m_src (m_src = the "missing" bucket)
     int bits = 1;
-    while (((int64_t)1 << bits) < m_src) ++bits;
+    while (((int64_t)1 << bits) <= m_src) ++bits;
     return bits;
 }
 
@@ -77,8 +83,8 @@ extern "C" int crfconv_index_narrow(const int64_t* idx64, int64_t B, int64_t n_t
 
 extern "C" size_t crfconv_reverse_csr_workspace(int64_t E, int64_t m_src) {
     if (E <= 0 || m_src <= 0) return 0;
-    // [keys_out E][vals_in E][sort temp]
-    return 2 * align_up(sizeof(uint32_t) * (size_t)E) + align_up(sort_temp_bytes(E, m_src)) + 256;
+    // [keys_in E][keys_out E][vals_in E][sort temp]
+    return 3 * align_up(sizeof(uint32_t) * (size_t)E) + align_up(sort_temp_bytes(E, m_src)) + 256;
 }
 
 extern "C" int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_src, int32_t* rev_ptr,
@@ -92,17 +98,18 @@ extern "C" int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_sr
                 workspace_bytes, need);
     hipStream_t st = as_stream(stream);
     char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws);
-    uint32_t* vals_in = reinterpret_cast<uint32_t*>(ws + align_up(sizeof(uint32_t) * (size_t)E));
-    void* temp = ws + 2 * align_up(sizeof(uint32_t) * (size_t)E);
+    const size_t seg = align_up(sizeof(uint32_t) * (size_t)E);
+    uint32_t* keys_in = reinterpret_cast<uint32_t*>(ws);
+    uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + seg);
+    uint32_t* vals_in = reinterpret_cast<uint32_t*>(ws + 2 * seg);
+    void* temp = ws + 3 * seg;
     size_t temp_bytes = sort_temp_bytes(E, m_src);
 
-    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, st, vals_in, E);
+    hipLaunchKernelGGL(iota_keys_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, st, idx32, E, m_src, vals_in, keys_in);
     CRF_LAUNCH_CHECK();
     // stable LSD radix sort by source row: edge ids stay ascending inside each group
-    CRF_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, reinterpret_cast<const uint32_t*>(idx32), keys_out,
-                                      vals_in, reinterpret_cast<uint32_t*>(rev_eid), (size_t)E, 0,
-                                      key_bits(m_src), st));
+    CRF_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in,
+                                      reinterpret_cast<uint32_t*>(rev_eid), (size_t)E, 0, key_bits(m_src), st));
     hipLaunchKernelGGL(boundaries_kernel, dim3((unsigned)cdiv(E + 1, 256)), dim3(256), 0, st, keys_out, E,
                        m_src, rev_ptr);
     CRF_LAUNCH_CHECK();

@@ -24,7 +24,7 @@ struct PC {
     static constexpr bool W2_IN_REGS = (D <= 16);
 };
 
-__device__ __forceinline__ float lrelu01(float v) { return v > 0.f ? v : 0.1f * v; }
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
 
 // Per-thread constants of the weight MLP for this lane's channel quad.
 template <int D>
@@ -34,11 +34,13 @@ struct EdgeMLP {
     float4 w2t_reg[PC<D>::W2_IN_REGS ? D : 1];  // W2T[c'][quad] when held in registers
     const float4* w2t_lds;                      // [D][L] float4 rows otherwise
     int lane, q;
+    float slope;                                // LeakyReLU slope of layer 1 (0.1 dense, 0.01 sparse twin)
 
     __device__ __forceinline__ void init(const float* __restrict__ A1, const float* __restrict__ b1,
-                                         const float* __restrict__ W2, float4* lds_w2t, int lane_, int q_) {
+                                         const float* __restrict__ W2, float4* lds_w2t, int lane_, int q_, float slope_) {
         lane = lane_;
         q = q_;
+        slope = slope_;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int ch = 4 * q + c;
@@ -66,7 +68,7 @@ struct EdgeMLP {
         pre.y = fmaf(a1[1].x, rx, fmaf(a1[1].y, ry, fmaf(a1[1].z, rz, a1[1].w)));
         pre.z = fmaf(a1[2].x, rx, fmaf(a1[2].y, ry, fmaf(a1[2].z, rz, a1[2].w)));
         pre.w = fmaf(a1[3].x, rx, fmaf(a1[3].y, ry, fmaf(a1[3].z, rz, a1[3].w)));
-        h1 = make_float4(lrelu01(pre.x), lrelu01(pre.y), lrelu01(pre.z), lrelu01(pre.w));
+        h1 = make_float4(lrelu(pre.x, slope), lrelu(pre.y, slope), lrelu(pre.z, slope), lrelu(pre.w, slope));
     }
 
     // h2[quad] = sum_c' h1[c'] * W2[quad][c']
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ 
         const float px = pos_tgt[3 * i], py = pos_tgt[3 * i + 1], pz = pos_tgt[3 * i + 2];
         for (int k = 0; k < K; ++k) {
             const int64_t j = idx[i * K + k];
+            if (j < 0) continue;                       // "no neighbour" (padded variable-degree table)
             const float rx = px - pos_src[3 * j], ry = py - pos_src[3 * j + 1], rz = pz - pos_src[3 * j + 2];
             a[0] += rx; a[1] += ry; a[2] += rz;
             a[3] = fmaf(rx, rx, a[3]); a[4] = fmaf(rx, ry, a[4]); a[5] = fmaf(rx, rz, a[5]);
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(PBLOCK) void stats_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ idx, int K,
                                                        int64_t m_tgt, const float* __restrict__ A1,
                                                        const float* __restrict__ b1,
-                                                       const float* __restrict__ W2,
+                                                       const float* __restrict__ W2, float slope,
                                                        const float* __restrict__ mean_rel,
                                                        float* __restrict__ shift_out,
                                                        float* __restrict__ partial) {
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(PBLOCK) void stats_kernel(const float* __restrict__
     int lane, wave, q;
     const Row rw = my_row<D>(m_tgt, lane, wave, q);
     EdgeMLP<D> mlp;
-    mlp.init(A1, b1, W2, s_w2t, lane, q);
+    mlp.init(A1, b1, W2, s_w2t, lane, q, slope);
     __syncthreads();
     const float4 shift = mlp.h2_of(mean_rel[0], mean_rel[1], mean_rel[2]);
     if (blockIdx.x == 0 && threadIdx.x < PC<D>::L) st4(shift_out + 4 * q, shift);
@@ -234,9 +237,10 @@ __global__ __launch_bounds__(PBLOCK) void stats_kernel(const float* __restrict__
     const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
     const int32_t* irow = idx + rw.r * K;
     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    const float live = rw.valid ? 1.f : 0.f;
     for (int k = 0; k < K; ++k) {
-        const int64_t j = irow[k];
+        const int jj = irow[k];
+        const int64_t j = jj < 0 ? 0 : jj;
+        const float live = (rw.valid && jj >= 0) ? 1.f : 0.f;
         const float4 h2 = mlp.h2_of(px - pos_src[3 * j], py - pos_src[3 * j + 1], pz - pos_src[3 * j + 2]);
         const float4 dlt = make_float4((h2.x - shift.x) * live, (h2.y - shift.y) * live,
                                        (h2.z - shift.z) * live, (h2.w - shift.w) * live);
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
                                                          const int32_t* __restrict__ idx, int K,
                                                          int64_t m_tgt, const float* __restrict__ A1,
                                                          const float* __restrict__ b1,
-                                                         const float* __restrict__ W2,
+                                                         const float* __restrict__ W2, float slope,
                                                          const float* __restrict__ a2,
                                                          const float* __restrict__ b2,
                                                          float* __restrict__ out) {
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
     int lane, wave, q;
     const Row rw = my_row<D>(m_tgt, lane, wave, q);
     EdgeMLP<D> mlp;
-    mlp.init(A1, b1, W2, s_w2t, lane, q);
+    mlp.init(A1, b1, W2, s_w2t, lane, q, slope);
     __syncthreads();
     const float4 sa = ld4(a2 + 4 * q), sb = ld4(b2 + 4 * q);
     const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
@@ -271,8 +275,10 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 2
     for (int k = 0; k < K; ++k) {
-        const int64_t j = irow[k];
-        const float4 xj = ld4(x + j * D + 4 * q);
+        const int jj = irow[k];
+        const int64_t j = jj < 0 ? 0 : jj;
+        float4 xj = ld4(x + j * D + 4 * q);
+        if (jj < 0) xj = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 h2 = mlp.h2_of(px - pos_src[3 * j], py - pos_src[3 * j + 1], pz - pos_src[3 * j + 2]);
         acc.x = fmaf(fmaf(sa.x, h2.x, sb.x), xj.x, acc.x);
         acc.y = fmaf(fmaf(sa.y, h2.y, sb.y), xj.y, acc.y);
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_reduce_kernel(const float* __restr
                                                             const int32_t* __restrict__ idx, int K,
                                                             int64_t m_tgt, const float* __restrict__ A1,
                                                             const float* __restrict__ b1,
-                                                            const float* __restrict__ W2,
+                                                            const float* __restrict__ W2, float slope,
                                                             const float* __restrict__ shift_p,
                                                             float* __restrict__ partial) {
     __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_reduce_kernel(const float* __restr
     int lane, wave, q;
     const Row rw = my_row<D>(m_tgt, lane, wave, q);
     EdgeMLP<D> mlp;
-    mlp.init(A1, b1, W2, s_w2t, lane, q);
+    mlp.init(A1, b1, W2, s_w2t, lane, q, slope);
     __syncthreads();
     const float4 shift = ld4(shift_p + 4 * q);
     const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
@@ -308,8 +314,10 @@ __global__ __launch_bounds__(PBLOCK) void bwd_reduce_kernel(const float* __restr
     if (!rw.valid) g = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     for (int k = 0; k < K; ++k) {
-        const int64_t j = irow[k];
-        const float4 xj = ld4(x + j * D + 4 * q);
+        const int jj = irow[k];
+        const int64_t j = jj < 0 ? 0 : jj;
+        float4 xj = ld4(x + j * D + 4 * q);
+        if (jj < 0) xj = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 h2 = mlp.h2_of(px - pos_src[3 * j], py - pos_src[3 * j + 1], pz - pos_src[3 * j + 2]);
         const float4 gw = make_float4(g.x * xj.x, g.y * xj.y, g.z * xj.z, g.w * xj.w);
         acc[0].x += gw.x; acc[0].y += gw.y; acc[0].z += gw.z; acc[0].w += gw.w;
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
                                                             const int32_t* __restrict__ idx, int K,
                                                             int64_t m_tgt, const float* __restrict__ A1,
                                                             const float* __restrict__ b1,
-                                                            const float* __restrict__ W2,
+                                                            const float* __restrict__ W2, float slope,
                                                             const float* __restrict__ ca,
                                                             const float* __restrict__ cb,
                                                             const float* __restrict__ cc,
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
     int lane, wave, q;
     const Row rw = my_row<D>(m_tgt, lane, wave, q);
     EdgeMLP<D> mlp;
-    mlp.init(A1, b1, W2, s_w2t, lane, q);
+    mlp.init(A1, b1, W2, s_w2t, lane, q, slope);
     {
         float* s = reinterpret_cast<float*>(s_w2);
         if constexpr (W2_LDS)
@@ -358,7 +366,6 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
     const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
     const int32_t* irow = idx + rw.r * K;
     float4 g = ld4(gout + rw.r * D + 4 * q);
-    const float live = rw.valid ? 1.f : 0.f;
 
     float4 dw2[ACC_REGS ? D : 1];  // dw2[c'] = {dW2[4q+0][c'], dW2[4q+1][c'], dW2[4q+2][c'], dW2[4q+3][c']}
     if constexpr (ACC_REGS) {
@@ -372,13 +379,15 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
     const int base = lane - q;
 
     for (int k = 0; k < K; ++k) {
-        const int64_t j = irow[k];
+        const int jj = irow[k];
+        const int64_t j = jj < 0 ? 0 : jj;
+        const float live = (rw.valid && jj >= 0) ? 1.f : 0.f;
         const float4 xj = ld4(x + j * D + 4 * q);
         const float rx = px - pos_src[3 * j], ry = py - pos_src[3 * j + 1], rz = pz - pos_src[3 * j + 2];
         float4 pre, h1;
         mlp.layer1(rx, ry, rz, pre, h1);
         const float4 h2 = mlp.layer2(h1);
-        // g_h2 for this lane's quad (zero for padding rows)
+        // g_h2 for this lane's quad (zero for padding rows and missing neighbours)
         float4 gh2;
         gh2.x = live * fmaf(va.x, g.x * xj.x, fmaf(vb.x, h2.x, vc.x));
         gh2.y = live * fmaf(va.y, g.y * xj.y, fmaf(vb.y, h2.y, vc.y));
@@ -421,8 +430,8 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
             }
         }
         // through lrelu(0.1)
-        const float4 gp = make_float4(gh1.x * (pre.x > 0.f ? 1.f : 0.1f), gh1.y * (pre.y > 0.f ? 1.f : 0.1f),
-                                      gh1.z * (pre.z > 0.f ? 1.f : 0.1f), gh1.w * (pre.w > 0.f ? 1.f : 0.1f));
+        const float4 gp = make_float4(gh1.x * (pre.x > 0.f ? 1.f : slope), gh1.y * (pre.y > 0.f ? 1.f : slope),
+                                      gh1.z * (pre.z > 0.f ? 1.f : slope), gh1.w * (pre.w > 0.f ? 1.f : slope));
         const double gpd[4] = {gp.x, gp.y, gp.z, gp.w};
         const double rd[3] = {rx, ry, rz};
 #pragma unroll
@@ -480,7 +489,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restric
                                                           const int32_t* __restrict__ idx, int K,
                                                           int64_t m_tgt, const float* __restrict__ A1,
                                                           const float* __restrict__ b1,
-                                                          const float* __restrict__ W2,
+                                                          const float* __restrict__ W2, float slope,
                                                           const float* __restrict__ ca,
                                                           const float* __restrict__ cb,
                                                           const float* __restrict__ cc,
@@ -491,14 +500,16 @@ __global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restric
     int lane, wave, q;
     const Row rw = my_row<D>(m_tgt, lane, wave, q);
     EdgeMLP<D> mlp;
-    mlp.init(A1, b1, W2, s_w2t, lane, q);
+    mlp.init(A1, b1, W2, s_w2t, lane, q, slope);
     __syncthreads();
     const float4 va = ld4(ca + 4 * q), vb = ld4(cb + 4 * q), vc = ld4(cc + 4 * q);
     const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
     const int32_t* irow = idx + rw.r * K;
     const float4 g = ld4(gout + rw.r * D + 4 * q);
     for (int k = 0; k < K; ++k) {
-        const int64_t j = irow[k];
+        const int jj = irow[k];
+        const bool have = jj >= 0;
+        const int64_t j = have ? jj : 0;
         const float4 xj = ld4(x + j * D + 4 * q);
         const float rx = px - pos_src[3 * j], ry = py - pos_src[3 * j + 1], rz = pz - pos_src[3 * j + 2];
         float4 pre, h1;
@@ -511,9 +522,10 @@ __global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restric
         gh2.w = fmaf(va.w, g.w * xj.w, fmaf(vb.w, h2.w, vc.w));
         if (rw.valid) {
             const int64_t e = rw.r * K + k;
-            st4(h1_out + e * D + 4 * q, h1);
-            st4(gh2_out + e * D + 4 * q, gh2);
-            if (q == 0) { rel_out[3 * e] = rx; rel_out[3 * e + 1] = ry; rel_out[3 * e + 2] = rz; }
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            st4(h1_out + e * D + 4 * q, have ? h1 : zero);
+            st4(gh2_out + e * D + 4 * q, have ? gh2 : zero);
+            if (q == 0) { rel_out[3 * e] = have ? rx : 0.f; rel_out[3 * e + 1] = have ? ry : 0.f; rel_out[3 * e + 2] = have ? rz : 0.f; }
         }
     }
 }
@@ -527,7 +539,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restri
                                                            const int32_t* __restrict__ rev_eid, int K,
                                                            int64_t m_src, const float* __restrict__ A1,
                                                            const float* __restrict__ b1,
-                                                           const float* __restrict__ W2,
+                                                           const float* __restrict__ W2, float slope,
                                                            const float* __restrict__ a2,
                                                            const float* __restrict__ b2,
                                                            float* __restrict__ dx) {
@@ -535,7 +547,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restri
     int lane, wave, q;
     const Row rw = my_row<D>(m_src, lane, wave, q);
     EdgeMLP<D> mlp;
-    mlp.init(A1, b1, W2, s_w2t, lane, q);
+    mlp.init(A1, b1, W2, s_w2t, lane, q, slope);
     __syncthreads();
     const float4 sa = ld4(a2 + 4 * q), sb = ld4(b2 + 4 * q);
     const float sx = pos_src[3 * rw.r], sy = pos_src[3 * rw.r + 1], sz = pos_src[3 * rw.r + 2];
@@ -626,7 +638,7 @@ extern "C" int crfconv_pointconv_moments(const float* pos_src, const float* pos_
 
 extern "C" int crfconv_pointconv_stats(const float* pos_src, const float* pos_tgt, const int32_t* idx32,
                                        int K, int64_t m_tgt, int d, const float* A1, const float* b1,
-                                       const float* W2, const float* mean_rel3, float* shift,
+                                       const float* W2, float slope, const float* mean_rel3, float* shift,
                                        double* stats, void* workspace, size_t workspace_bytes,
                                        crf_stream_t stream) {
     if (int rc = check_pc(m_tgt, K, d)) return rc;
@@ -638,7 +650,7 @@ extern "C" int crfconv_pointconv_stats(const float* pos_src, const float* pos_tg
     float* partial = reinterpret_cast<float*>(workspace);
     DISPATCH_D(d, {
         hipLaunchKernelGGL(stats_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, pos_src, pos_tgt,
-                           idx32, K, m_tgt, A1, b1, W2, mean_rel3, shift, partial);
+                           idx32, K, m_tgt, A1, b1, W2, slope, mean_rel3, shift, partial);
     });
     CRF_LAUNCH_CHECK();
     return reduce_partials(partial, nblk, 2 * d, stats, st);
@@ -646,7 +658,7 @@ extern "C" int crfconv_pointconv_stats(const float* pos_src, const float* pos_tg
 
 extern "C" int crfconv_pointconv_forward(const float* x, const float* pos_src, const float* pos_tgt,
                                          const int32_t* idx32, int K, int64_t m_tgt, int d,
-                                         const float* A1, const float* b1, const float* W2,
+                                         const float* A1, const float* b1, const float* W2, float slope,
                                          const float* a2, const float* b2, float* out,
                                          crf_stream_t stream) {
     if (int rc = check_pc(m_tgt, K, d)) return rc;
@@ -655,7 +667,7 @@ extern "C" int crfconv_pointconv_forward(const float* x, const float* pos_src, c
     const int64_t nblk = blocks_for(m_tgt, d);
     DISPATCH_D(d, {
         hipLaunchKernelGGL(forward_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, as_stream(stream), x,
-                           pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, a2, b2, out);
+                           pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, a2, b2, out);
     });
     CRF_LAUNCH_CHECK();
     return CRF_OK;
@@ -664,7 +676,7 @@ extern "C" int crfconv_pointconv_forward(const float* x, const float* pos_src, c
 extern "C" int crfconv_pointconv_bwd_reduce(const float* x, const float* gout, const float* pos_src,
                                             const float* pos_tgt, const int32_t* idx32, int K,
                                             int64_t m_tgt, int d, const float* A1, const float* b1,
-                                            const float* W2, const float* shift, double* red1,
+                                            const float* W2, float slope, const float* shift, double* red1,
                                             void* workspace, size_t workspace_bytes, crf_stream_t stream) {
     if (int rc = check_pc(m_tgt, K, d)) return rc;
     CRF_REQUIRE(x && gout && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && shift && red1 && workspace,
@@ -675,7 +687,7 @@ extern "C" int crfconv_pointconv_bwd_reduce(const float* x, const float* gout, c
     float* partial = reinterpret_cast<float*>(workspace);
     DISPATCH_D(d, {
         hipLaunchKernelGGL(bwd_reduce_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src,
-                           pos_tgt, idx32, K, m_tgt, A1, b1, W2, shift, partial);
+                           pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, shift, partial);
     });
     CRF_LAUNCH_CHECK();
     return reduce_partials(partial, nblk, 2 * d, red1, st);
@@ -684,7 +696,7 @@ extern "C" int crfconv_pointconv_bwd_reduce(const float* x, const float* gout, c
 extern "C" int crfconv_pointconv_bwd_params(const float* x, const float* gout, const float* pos_src,
                                             const float* pos_tgt, const int32_t* idx32, int K,
                                             int64_t m_tgt, int d, const float* A1, const float* b1,
-                                            const float* W2, const float* ca, const float* cb,
+                                            const float* W2, float slope, const float* ca, const float* cb,
                                             const float* cc, double* dW2, double* dA1b1, void* workspace,
                                             size_t workspace_bytes, crf_stream_t stream) {
     if (int rc = check_pc(m_tgt, K, d)) return rc;
@@ -700,10 +712,10 @@ extern "C" int crfconv_pointconv_bwd_params(const float* x, const float* gout, c
     float* partial = reinterpret_cast<float*>(base);
     double* partial_d = reinterpret_cast<double*>(base + fbytes);
     switch (d) {
-        case 4: hipLaunchKernelGGL(bwd_params_kernel<4>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial, partial_d); break;
-        case 8: hipLaunchKernelGGL(bwd_params_kernel<8>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial, partial_d); break;
-        case 16: hipLaunchKernelGGL(bwd_params_kernel<16>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial, partial_d); break;
-        default: hipLaunchKernelGGL(bwd_params_kernel<32>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, partial, partial_d); break;
+        case 4: hipLaunchKernelGGL(bwd_params_kernel<4>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, partial, partial_d); break;
+        case 8: hipLaunchKernelGGL(bwd_params_kernel<8>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, partial, partial_d); break;
+        case 16: hipLaunchKernelGGL(bwd_params_kernel<16>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, partial, partial_d); break;
+        default: hipLaunchKernelGGL(bwd_params_kernel<32>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, partial, partial_d); break;
     }
     CRF_LAUNCH_CHECK();
     if (int rc = reduce_partials(partial, nblk, d * d, dW2, st)) return rc;
@@ -716,7 +728,7 @@ extern "C" int crfconv_pointconv_bwd_params(const float* x, const float* gout, c
 extern "C" int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const float* pos_tgt,
                                            const int32_t* rev_ptr, const int32_t* rev_eid, int K,
                                            int64_t m_src, int d, const float* A1, const float* b1,
-                                           const float* W2, const float* a2, const float* b2, float* dx,
+                                           const float* W2, float slope, const float* a2, const float* b2, float* dx,
                                            crf_stream_t stream) {
     if (int rc = check_pc(m_src, K, d)) return rc;
     CRF_REQUIRE(gout && pos_src && pos_tgt && rev_ptr && rev_eid && A1 && b1 && W2 && a2 && b2 && dx,
@@ -724,7 +736,7 @@ extern "C" int crfconv_pointconv_bwd_input(const float* gout, const float* pos_s
     const int64_t nblk = blocks_for(m_src, d);
     DISPATCH_D(d, {
         hipLaunchKernelGGL(bwd_input_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, as_stream(stream), gout,
-                           pos_src, pos_tgt, rev_ptr, rev_eid, K, m_src, A1, b1, W2, a2, b2, dx);
+                           pos_src, pos_tgt, rev_ptr, rev_eid, K, m_src, A1, b1, W2, slope, a2, b2, dx);
     });
     CRF_LAUNCH_CHECK();
     return CRF_OK;
@@ -732,7 +744,7 @@ extern "C" int crfconv_pointconv_bwd_input(const float* gout, const float* pos_s
 
 extern "C" int crfconv_pointconv_bwd_dump(const float* x, const float* gout, const float* pos_src,
                                           const float* pos_tgt, const int32_t* idx32, int K, int64_t m_tgt,
-                                          int d, const float* A1, const float* b1, const float* W2,
+                                          int d, const float* A1, const float* b1, const float* W2, float slope,
                                           const float* ca, const float* cb, const float* cc, float* h1,
                                           float* gh2, float* rel, crf_stream_t stream) {
     if (int rc = check_pc(m_tgt, K, d)) return rc;
@@ -742,7 +754,7 @@ extern "C" int crfconv_pointconv_bwd_dump(const float* x, const float* gout, con
     const int64_t nblk = blocks_for(m_tgt, d);
     DISPATCH_D(d, {
         hipLaunchKernelGGL(bwd_dump_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, as_stream(stream), x, gout,
-                           pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, ca, cb, cc, h1, gh2, rel);
+                           pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, h1, gh2, rel);
     });
     CRF_LAUNCH_CHECK();
     return CRF_OK;

@@ -15,15 +15,19 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const int64_t i = t / C4;
     const int q = (int)(t - i * C4);
     const int32_t* irow = idx + i * K;
-    float4 best = ld4(x + ((int64_t)irow[0] * C4 + q) * 4);
-    int4 who = make_int4(0, 0, 0, 0);
-    for (int k = 1; k < K; ++k) {
-        const float4 v = ld4(x + ((int64_t)irow[k] * C4 + q) * 4);
-        if (v.x > best.x) { best.x = v.x; who.x = k; }
-        if (v.y > best.y) { best.y = v.y; who.y = k; }
-        if (v.z > best.z) { best.z = v.z; who.z = k; }
-        if (v.w > best.w) { best.w = v.w; who.w = k; }
+    const float ninf = -__builtin_inff();
+    float4 best = make_float4(ninf, ninf, ninf, ninf);
+    int4 who = make_int4(-1, -1, -1, -1);
+    for (int k = 0; k < K; ++k) {
+        const int j = irow[k];
+        if (j < 0) continue;                                     // "no neighbour" entry of a padded table
+        const float4 v = ld4(x + ((int64_t)j * C4 + q) * 4);
+        if (v.x > best.x || who.x < 0) { best.x = v.x; who.x = k; }
+        if (v.y > best.y || who.y < 0) { best.y = v.y; who.y = k; }
+        if (v.z > best.z || who.z < 0) { best.z = v.z; who.z = k; }
+        if (v.w > best.w || who.w < 0) { best.w = v.w; who.w = k; }
     }
+    if (who.x < 0) best = make_float4(0.f, 0.f, 0.f, 0.f);      // empty group -> 0 (scatter_max convention)
     st4(out + t * 4, best);
     *reinterpret_cast<int4*>(arg + t * 4) = who;
 }

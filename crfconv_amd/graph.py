@@ -31,7 +31,7 @@ def require_gpu(*tensors):
 
 
 class NeighborTable:
-    __slots__ = ('idx32', 'B', 'n_tgt', 'n_src', 'K', '_rev', '_bad', '_checked', 'cache')
+    __slots__ = ('idx32', 'B', 'n_tgt', 'n_src', 'K', '_rev', '_bad', '_checked', 'cache', 'n_edges')
 
     def __init__(self, idx64, n_src, check=True):
         if idx64.dim() == 2:
@@ -50,6 +50,7 @@ class NeighborTable:
                   ptr(self.idx32), ptr(self._bad), stream_ptr())
         self._rev = None
         self._checked = False
+        self.n_edges = self.B * self.n_tgt * self.K
         self.cache = {}          # per-table memo (e.g. rel-pos moments shared by two ResNet blocks)
         if check:
             self.validate()
@@ -84,6 +85,41 @@ class NeighborTable:
                       ptr(ws), nbytes, stream_ptr())
             self._rev = (rev_ptr, rev_eid)
         return self._rev
+
+
+def table_from_edges(tgt, src, n_tgt, n_src, max_degree=64):
+    """Variable-degree edge list -> padded NeighborTable.
+
+    Edge e sends source row src[e] to target row tgt[e] (global row ids, int64 CUDA tensors).  Edges
+    are grouped by target (stable: a target's edges keep their input order, which fixes the float
+    summation order) into idx32 [n_tgt, Kp]; unused slots hold -1 ("no neighbour"), which every
+    generic kernel skips.  Kp = the largest in-degree, at most `max_degree` (the reference's sparse
+    layers bound it by construction: radius_graph(max_num_neighbors=k), knn_graph(k))."""
+    require_gpu(tgt, src)
+    E = tgt.numel()
+    dev = tgt.device
+    tab = NeighborTable.__new__(NeighborTable)
+    tab.B, tab.n_tgt, tab.n_src = 1, int(n_tgt), int(n_src)
+    tab._rev, tab._checked, tab.cache = None, True, {}
+    tab._bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    if E == 0:
+        tab.K, tab.n_edges = 1, 0
+        tab.idx32 = torch.full((n_tgt, 1), -1, dtype=torch.int32, device=dev)
+        return tab
+    if int(src.min()) < 0 or int(src.max()) >= n_src or int(tgt.min()) < 0 or int(tgt.max()) >= n_tgt:
+        raise IndexError('edge endpoints outside [0, n)')
+    order = torch.argsort(tgt, stable=True)
+    ts, ss = tgt[order], src[order]
+    deg = torch.bincount(ts, minlength=n_tgt)
+    kmax = int(deg.max())
+    if kmax > max_degree:
+        raise _lib.CrfConvError('in-degree %d exceeds the supported maximum %d' % (kmax, max_degree))
+    start = torch.cumsum(deg, 0) - deg
+    rank = torch.arange(E, device=dev) - start[ts]
+    idx = torch.full((n_tgt, kmax), -1, dtype=torch.int32, device=dev)
+    idx[ts, rank] = ss.to(torch.int32)
+    tab.K, tab.n_edges, tab.idx32 = kmax, E, idx
+    return tab
 
 
 def table_of(idx, n_src):

@@ -1,8 +1,13 @@
 """Same export surface as the reference's models/__init__.py:1-2 for the dense path."""
 from .common import MLP, Base, FastBatchNorm1d
+from . import continuous_crf_conv, graph_ops, point_conv
+from .continuous_crf_conv import GuideGaussianCRFConv
 from .continuous_crf_conv_big import ContinuousGaussianCRFConv
+from .point_conv import DepthwiseSeparablePointConv, build_bipartite_graph, build_graph
 from .point_conv_big import PointConv, PointConvResNet, ResNetBBlock, Upsampling
 from .point_conv_big import PointConvResNet as PointConvBig
 
-__all__ = ['MLP', 'Base', 'FastBatchNorm1d', 'ContinuousGaussianCRFConv', 'PointConv', 'ResNetBBlock',
+__all__ = ['MLP', 'Base', 'FastBatchNorm1d', 'ContinuousGaussianCRFConv', 'GuideGaussianCRFConv',
+           'DepthwiseSeparablePointConv', 'build_graph', 'build_bipartite_graph', 'continuous_crf_conv', 'point_conv',
+           'graph_ops', 'PointConv', 'ResNetBBlock',
            'Upsampling', 'PointConvResNet', 'PointConvBig']

@@ -1,0 +1,83 @@
+"""Device-side graph builders with the call signatures of the torch_cluster / torch_geometric functions the
+reference's sparse path uses (models/point_conv.py:5, 341-396; models/continuous_crf_conv.py:53):
+knn_graph, knn, radius_graph, fps -- all on top of the exact HIP grid kNN (csrc/knn.hip).
+
+Conventions (PyG): an edge_index is [2, E] with row 0 = source j ("col"), row 1 = target i ("row").
+Third-party semantics are unpinned (no version, no tests in the reference): knn_* are exact; radius_graph keeps
+the NEAREST `max_num_neighbors` inside the radius (torch_cluster keeps the first it meets); fps starts from the
+first point of each cloud unless random_start=True."""
+import torch
+
+from ..utils import nearest_neighbors as nn_
+
+
+def _segments(batch, n):
+    """[(start, end)] of each cloud; `batch` must be sorted (PyG convention). None -> one cloud."""
+    if batch is None:
+        return [(0, n)]
+    counts = torch.bincount(batch).tolist()
+    out, o = [], 0
+    for c in counts:
+        if c:
+            out.append((o, o + c))
+        o += c
+    return out
+
+
+def _knn_segments(x, y, k, seg_x, seg_y):
+    """For every y row the k nearest x rows of the same cloud -> (y_index, x_index) global ids, nearest first."""
+    rows, cols = [], []
+    for (xs, xe), (ys, ye) in zip(seg_x, seg_y):
+        kk = min(k, xe - xs)
+        idx = nn_.knn_batch_device(x[xs:xe].unsqueeze(0), y[ys:ye].unsqueeze(0), kk)[0]     # [ny, kk]
+        rows.append((torch.arange(ys, ye, device=x.device).unsqueeze(1).expand(-1, kk)).reshape(-1))
+        cols.append((idx + xs).reshape(-1))
+    return torch.cat(rows), torch.cat(cols)
+
+
+def knn(x, y, k, batch_x=None, batch_y=None):
+    """torch_cluster.knn: [2, E] = [y index; x index]."""
+    row, col = _knn_segments(x, y, k, _segments(batch_x, x.shape[0]), _segments(batch_y, y.shape[0]))
+    return torch.stack([row, col])
+
+
+def knn_graph(pos, k, batch=None, loop=False):
+    """torch_cluster.knn_graph (flow source_to_target): [2, E] = [neighbour j; node i]."""
+    seg = _segments(batch, pos.shape[0])
+    row, col = _knn_segments(pos, pos, k if loop else k + 1, seg, seg)
+    if not loop:
+        keep = row != col
+        row, col = row[keep], col[keep]
+    return torch.stack([col, row])
+
+
+def radius_graph(pos, r, batch=None, loop=False, max_num_neighbors=32):
+    """[2, E] = [neighbour j; node i] for |p_i - p_j| <= r, at most max_num_neighbors per node."""
+    seg = _segments(batch, pos.shape[0])
+    k = max_num_neighbors + (0 if loop else 1)
+    row, col = _knn_segments(pos, pos, k, seg, seg)
+    d2 = ((pos[row] - pos[col]) ** 2).sum(1)
+    keep = d2 <= r * r
+    if not loop:
+        keep &= row != col
+    return torch.stack([col[keep], row[keep]])
+
+
+def fps(pos, batch=None, ratio=0.5, random_start=False):
+    """Farthest point sampling per cloud -> sorted global indices (torch_cluster.fps).  Iterative by nature
+    (n_sample dependent steps); each step is one fused min-update + argmax over the cloud."""
+    out = []
+    for (s, e) in _segments(batch, pos.shape[0]):
+        p = pos[s:e]
+        n = e - s
+        m = max(1, int(round(n * ratio))) if isinstance(ratio, float) else int(ratio)
+        start = int(torch.randint(0, n, (1,))) if random_start else 0
+        sel = torch.empty(m, dtype=torch.long, device=pos.device)
+        dist = torch.full((n,), float('inf'), device=pos.device)
+        cur = torch.tensor(start, device=pos.device)
+        for t in range(m):
+            sel[t] = cur
+            dist = torch.minimum(dist, ((p - p[cur]) ** 2).sum(1))
+            cur = torch.argmax(dist)
+        out.append(sel.sort().values + s)
+    return torch.cat(out)

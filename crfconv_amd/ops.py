@@ -236,7 +236,7 @@ def relpos_moments(pos_src, pos_tgt, table):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     _lib.call('crfconv_pointconv_moments', ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), table.K, table.m_tgt,
               ptr(out9), ptr(ws), nbytes, stream_ptr())
-    n = float(table.m_tgt * table.K)
+    n = float(table.n_edges)
     mean = out9[:3] / n
     sec = out9[3:] / n
     S = torch.stack([torch.stack([sec[0], sec[1], sec[2]]), torch.stack([sec[1], sec[3], sec[4]]),
@@ -254,7 +254,7 @@ class _PointConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, A1, b1, W2, gamma2, beta2, pos_src, pos_tgt, table, mean_rel, bn2_train, run_mean2,
-                run_var2, aux):
+                run_var2, aux, slope):
         require_gpu(x, A1, W2, pos_src, pos_tgt)
         dev = x.device
         x, A1, b1, W2 = _f32c(x), _f32c(A1), _f32c(b1), _f32c(W2)
@@ -263,14 +263,14 @@ class _PointConv(torch.autograd.Function):
         st = stream_ptr()
         nbytes = _lib.load().crfconv_pointconv_workspace(max(m_tgt, table.m_src), K, d)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        n_e = float(m_tgt * K)
+        n_e = float(table.n_edges)
         g2, be2 = gamma2.detach().double(), beta2.detach().double()
         shift = torch.zeros(d, dtype=torch.float32, device=dev)
         if bn2_train:
             stats = torch.empty(2 * d, dtype=torch.float64, device=dev)
             mean_rel = _f32c(mean_rel)          # keep every kernel operand alive in a local
             _lib.call('crfconv_pointconv_stats', ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d, ptr(A1),
-                      ptr(b1), ptr(W2), ptr(mean_rel), ptr(shift), ptr(stats), ptr(ws), nbytes, st)
+                      ptr(b1), ptr(W2), slope, ptr(mean_rel), ptr(shift), ptr(stats), ptr(ws), nbytes, st)
             m1 = stats[:d] / n_e
             mean2 = shift.double() + m1
             var2 = (stats[d:] / n_e - m1 * m1).clamp_min_(0.0)
@@ -283,15 +283,15 @@ class _PointConv(torch.autograd.Function):
         b2 = (be2 - g2 * rstd2 * mean2).float()
         out = torch.empty((m_tgt, d), dtype=torch.float32, device=dev)
         _lib.call('crfconv_pointconv_forward', ptr(x), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d,
-                  ptr(A1), ptr(b1), ptr(W2), ptr(a2), ptr(b2), ptr(out), st)
-        ctx.table, ctx.bn2_train, ctx.n_e = table, bn2_train, n_e
+                  ptr(A1), ptr(b1), ptr(W2), slope, ptr(a2), ptr(b2), ptr(out), st)
+        ctx.table, ctx.bn2_train, ctx.n_e, ctx.slope = table, bn2_train, n_e, slope
         ctx.save_for_backward(x, A1, b1, W2, a2, b2, shift, mean2, rstd2, g2, pos_src, pos_tgt)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         x, A1, b1, W2, a2, b2, shift, mean2, rstd2, g2, pos_src, pos_tgt = ctx.saved_tensors
-        table, n_e = ctx.table, ctx.n_e
+        table, n_e, slope = ctx.table, ctx.n_e, ctx.slope
         dev = x.device
         d = x.shape[1]
         m_tgt, K = table.m_tgt, table.K
@@ -302,7 +302,7 @@ class _PointConv(torch.autograd.Function):
         # pass 1: sum g_w and sum g_w (h2 - shift)
         red = torch.empty(2 * d, dtype=torch.float64, device=dev)
         _lib.call('crfconv_pointconv_bwd_reduce', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
-                  m_tgt, d, ptr(A1), ptr(b1), ptr(W2), ptr(shift), ptr(red), ptr(ws), nbytes, st)
+                  m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(shift), ptr(red), ptr(ws), nbytes, st)
         sum_gw = red[:d]
         sum_gwh = rstd2 * (red[d:] - (mean2 - shift.double()) * sum_gw)     # sum g_w * hhat
         dgamma2, dbeta2 = sum_gwh.float(), sum_gw.float()
@@ -320,7 +320,7 @@ class _PointConv(torch.autograd.Function):
             dW2 = torch.empty(d * d, dtype=torch.float64, device=dev)
             dA1b1 = torch.empty((d, 4), dtype=torch.float64, device=dev)
             _lib.call('crfconv_pointconv_bwd_params', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32),
-                      K, m_tgt, d, ptr(A1), ptr(b1), ptr(W2), ptr(ca32), ptr(cb32), ptr(cc32), ptr(dW2), ptr(dA1b1),
+                      K, m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(ca32), ptr(cb32), ptr(cc32), ptr(dW2), ptr(dA1b1),
                       ptr(ws), nbytes, st)
             dW2, dA1, db1 = dW2.float().view(d, d), dA1b1[:, :3], dA1b1[:, 3]      # dA1/db1 stay float64
         else:
@@ -330,10 +330,10 @@ class _PointConv(torch.autograd.Function):
             gh2 = torch.empty((E, d), dtype=torch.float32, device=dev)
             rel = torch.empty((E, 3), dtype=torch.float32, device=dev)
             _lib.call('crfconv_pointconv_bwd_dump', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
-                      m_tgt, d, ptr(A1), ptr(b1), ptr(W2), ptr(ca32), ptr(cb32), ptr(cc32), ptr(h1), ptr(gh2),
+                      m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(ca32), ptr(cb32), ptr(cc32), ptr(h1), ptr(gh2),
                       ptr(rel), st)
             dW2 = gh2.t() @ h1
-            gp = (gh2 @ W2) * torch.where(h1 > 0, 1.0, 0.1)
+            gp = (gh2 @ W2) * torch.where(h1 > 0, 1.0, slope)
             # float64 sums (see bwd_params) as three column reductions -- a float64 GEMM of this
             # [E, d]^T x [E, 3] shape takes rocBLAS ~0.7 ms, the reductions a few microseconds each
             gpd, reld = gp.double(), rel.double()
@@ -343,15 +343,15 @@ class _PointConv(torch.autograd.Function):
         rev_ptr, rev_eid = table.reverse
         dx = torch.empty((table.m_src, d), dtype=torch.float32, device=dev)
         _lib.call('crfconv_pointconv_bwd_input', ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(rev_ptr), ptr(rev_eid), K,
-                  table.m_src, d, ptr(A1), ptr(b1), ptr(W2), ptr(a2), ptr(b2), ptr(dx), st)
+                  table.m_src, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(a2), ptr(b2), ptr(dx), st)
         return (dx, dA1, db1, dW2, dgamma2, dbeta2, None, None, None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 _PC_D = (4, 8, 16, 32, 64, 128)
 
 
-def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=0.1, moments=None):
+def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=0.1, moments=None, slope=0.1):
     """Functional PointConv over flattened clouds.
 
     x [m_src, d]; pos_* [m, 3]; W1 [d, 3], W2 [d, d] Linear weights (no bias);
@@ -385,7 +385,7 @@ def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=
     use_batch2 = training or bn2.running_mean is None
     aux = {} if use_batch2 else None
     out = _PointConv.apply(x, A1, b1, W2, bn2.weight, bn2.bias, pos_src, pos_tgt, table, mean_rel.float(),
-                           use_batch2, bn2.running_mean, bn2.running_var, aux)
+                           use_batch2, bn2.running_mean, bn2.running_var, aux, float(slope))
     if training and use_batch2 and bn2.running_mean is not None:
         with torch.no_grad():
             mom = momentum if bn2.momentum is None else bn2.momentum

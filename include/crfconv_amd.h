@@ -141,7 +141,9 @@ int crfconv_similarity_bwd_scatter(const float* w, const float* y, const float* 
  *   rel = p_tgt[i] - p_src[j];  h1 = lrelu_0.1(A1 rel + b1);  h2 = W2 h1;  w = a2*h2 + b2
  *   out[i,c] = sum_k w[c] * x[j,c]
  * A1 [d,3], b1 [d] fold Linear(3->d) with its BatchNorm; W2 [d,d] row-major [out,in];
- * a2,b2 [d] fold the second BatchNorm.  d in {4,8,16,32,64,128}; K <= 64. */
+ * a2,b2 [d] fold the second BatchNorm.  d in {4,8,16,32,64,128}; K <= 64.  `slope` is the LeakyReLU slope of
+ * layer 1 (0.1 in point_conv_big.py:21, nn.LeakyReLU's default 0.01 in the sparse twin point_conv.py:24).
+ * Table entries < 0 mean "no neighbour" (padded variable-degree tables): they contribute nothing. */
 
 /* First and second moments of rel over all edges: out9 = {sum x,y,z, sum xx,xy,xz,yy,yz,zz}
  * as float64 (BatchNorm-1 batch statistics are analytic in these). */
@@ -153,17 +155,17 @@ int crfconv_pointconv_moments(const float* pos_src, const float* pos_tgt, const 
  * shift [d] float32 out (= h2 at the mean rel; variance is shift-invariant). */
 int crfconv_pointconv_stats(const float* pos_src, const float* pos_tgt, const int32_t* idx32, int K,
                             int64_t m_tgt, int d, const float* A1, const float* b1,
-                            const float* W2, const float* mean_rel3, float* shift, double* stats,
+                            const float* W2, float slope, const float* mean_rel3, float* shift, double* stats,
                             void* workspace, size_t workspace_bytes, crf_stream_t stream);
 int crfconv_pointconv_forward(const float* x, const float* pos_src, const float* pos_tgt,
                               const int32_t* idx32, int K, int64_t m_tgt, int d, const float* A1,
-                              const float* b1, const float* W2, const float* a2, const float* b2,
+                              const float* b1, const float* W2, float slope, const float* a2, const float* b2,
                               float* out, crf_stream_t stream);
 /* Backward reductions, pass 1:  red1 [2, d] float64 = {sum_e g_w, sum_e g_w * (h2 - shift)} with
  * g_w[e,c] = gout[i,c] * x[j,c]  (BatchNorm-2 backward needs both before pass 2). */
 int crfconv_pointconv_bwd_reduce(const float* x, const float* gout, const float* pos_src,
                                  const float* pos_tgt, const int32_t* idx32, int K, int64_t m_tgt,
-                                 int d, const float* A1, const float* b1, const float* W2,
+                                 int d, const float* A1, const float* b1, const float* W2, float slope,
                                  const float* shift, double* red1, void* workspace, size_t workspace_bytes,
                                  crf_stream_t stream);
 /* Pass 2:  g_h2[e,c] = ca[c] * g_w[e,c] + cb[c] * h2[e,c] + cc[c]  (the host folds BatchNorm-2's
@@ -172,7 +174,7 @@ int crfconv_pointconv_bwd_reduce(const float* x, const float* gout, const float*
  * float64 throughout: the host's analytic BatchNorm-1 backward cancels their large common parts).  d <= 32. */
 int crfconv_pointconv_bwd_params(const float* x, const float* gout, const float* pos_src,
                                  const float* pos_tgt, const int32_t* idx32, int K, int64_t m_tgt,
-                                 int d, const float* A1, const float* b1, const float* W2,
+                                 int d, const float* A1, const float* b1, const float* W2, float slope,
                                  const float* ca, const float* cb, const float* cc, double* dW2,
                                  double* dA1b1, void* workspace, size_t workspace_bytes,
                                  crf_stream_t stream);
@@ -181,14 +183,14 @@ int crfconv_pointconv_bwd_params(const float* x, const float* gout, const float*
  * so the host can form dW2 = g_h2^T h1, g_h1 = g_h2 W2, dA1 = (g_h1 * lrelu')^T rel, db1 with dense GEMMs. */
 int crfconv_pointconv_bwd_dump(const float* x, const float* gout, const float* pos_src,
                                const float* pos_tgt, const int32_t* idx32, int K, int64_t m_tgt, int d,
-                               const float* A1, const float* b1, const float* W2, const float* ca,
+                               const float* A1, const float* b1, const float* W2, float slope, const float* ca,
                                const float* cb, const float* cc, float* h1, float* gh2, float* rel,
                                crf_stream_t stream);
 /* dx[j,c] = sum_{e=(i,k) in rev(j)} w_e[c] * gout[i,c]   (weight MLP recomputed per incoming edge). */
 int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const float* pos_tgt,
                                 const int32_t* rev_ptr, const int32_t* rev_eid, int K,
                                 int64_t m_src, int d, const float* A1, const float* b1,
-                                const float* W2, const float* a2, const float* b2, float* dx,
+                                const float* W2, float slope, const float* a2, const float* b2, float* dx,
                                 crf_stream_t stream);
 
 /* ===================================================================== (B) per-point Linear layers

@@ -1,0 +1,145 @@
+"""-m gpu: the edge-list (sparse) operators and the device graph builders
+against fixtures captured from the reference's sparse modules (run through third-party stubs) and
+against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import _seeded as S
+from conftest import sub
+from gpu_util import DEV, assert_close, grads, load_sd, t
+from oracle import crf_oracle as O
+from oracle import native as onative
+
+pytestmark = pytest.mark.gpu
+OUT_TOL, GRAD_TOL = 1e-4, 2e-4
+
+
+def g8_graph(g, gname):
+    tgt, src = g['tgt'].astype(np.int64), g['src'].astype(np.int64)
+    if gname == 'ragged':
+        tgt, src = tgt[g['keep']], src[g['keep']]
+    return t(tgt), t(src)
+
+
+@pytest.mark.parametrize('gname,steps,mode', [('full', 3, 'train'), ('ragged', 3, 'train'), ('ragged', 1, 'eval')])
+def test_sparse_crfconv_golden(golden, gname, steps, mode):
+    from crfconv_amd.models.continuous_crf_conv import ContinuousGaussianCRFConv, GuideGaussianCRFConv
+    g = golden('g8_sparse.npz')
+    tgt, src = g8_graph(g, gname)
+    tag = '%s_T%d_%s' % (gname, steps, mode)
+    for kind in ('crf', 'guide'):
+        if kind == 'crf':
+            m = load_sd(ContinuousGaussianCRFConv(32, 16, None, 16, steps=steps), sub(g, 'crf/sd'))
+        else:
+            m = load_sd(GuideGaussianCRFConv(32, 16, 8, radius=0.1, kernel_size=12, steps=steps), sub(g, 'guide/sd'))
+        m = m.to(DEV).train(mode == 'train')
+        x, y = t(g['x']).requires_grad_(True), t(g['y']).requires_grad_(True)
+        if kind == 'crf':
+            out = m(x, y, t(g['pos']), torch.stack([tgt, src]))
+        else:
+            out = m(x, y, t(g['pos']), t(g['batch']), edge_index=torch.stack([src, tgt]))
+        (out * t(g['%s/%s/gout' % (kind, tag)])).sum().backward()
+        assert_close(out, g['%s/%s/out' % (kind, tag)], OUT_TOL, kind + ' out')
+        assert_close(x.grad, g['%s/%s/d_x' % (kind, tag)], GRAD_TOL, kind + ' d_x')
+        assert_close(y.grad, g['%s/%s/d_y' % (kind, tag)], GRAD_TOL, kind + ' d_y')
+        gr = grads(m)
+        for k, v in sub(g, '%s/%s/grad' % (kind, tag)).items():
+            assert_close(gr[k], v, GRAD_TOL, '%s grad %s' % (kind, k))
+
+
+@pytest.mark.parametrize('form', ['sym_same', 'sym_proj', 'bip'])
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_ds_point_conv_golden(golden, form, mode):
+    from crfconv_amd.models import DepthwiseSeparablePointConv
+    g = golden('g8_sparse.npz')
+    cin, cout = (16, 16) if form == 'sym_same' else (16, 32)
+    m = load_sd(DepthwiseSeparablePointConv(cin, cout), sub(g, 'dsconv/%s/sd' % form)).to(DEV).train(mode == 'train')
+    x = t(g['dsconv/x']).requires_grad_(True)
+    pos = t(g['pos'])
+    tgt, src = g8_graph(g, 'full')
+    if form == 'bip':
+        choice = t(g['dsconv/choice'].astype(np.int64))
+        K = tgt.numel() // pos.shape[0]
+        nbr = src.reshape(pos.shape[0], K)
+        ei = torch.stack([nbr[choice].reshape(-1), torch.arange(choice.numel(), device=DEV).repeat_interleave(K)])
+        out = m(x, (pos, pos[choice]), ei)
+    else:
+        out = m(x, pos, torch.stack([src, tgt]))
+    tag = 'dsconv/%s_%s' % (form, mode)
+    (out * t(g[tag + '/gout'])).sum().backward()
+    assert_close(out, g[tag + '/out'], OUT_TOL, 'out')
+    assert_close(x.grad, g[tag + '/d_x'], GRAD_TOL, 'd_x')
+    gr = grads(m)
+    for k, v in sub(g, tag + '/grad').items():
+        assert_close(gr[k], v, 5e-4, 'grad ' + k)
+
+
+def test_sparse_meanfield_isolated_points_and_degree_limit():
+    from crfconv_amd import ops
+    from crfconv_amd._lib import CrfConvError
+    from crfconv_amd.graph import table_from_edges
+    N, H = 50, 8
+    z = t(S.uniform(1, 'z', (N, H)))
+    y = t(S.uniform(1, 'y', (N, H)))
+    c = (torch.eye(H) + 0.05).to(DEV)
+    tgt = t(np.array([0, 0, 0, 3, 3, 7], dtype=np.int64))
+    src = t(np.array([1, 2, 3, 0, 9, 7], dtype=np.int64))            # node 7 has a self loop; most nodes are isolated
+    tab = table_from_edges(tgt, src, N, N)
+    out = ops.crf_meanfield(z, y, c, tab, 2, k0=0)
+    ref = O.sparse_crf_meanfield(z.cpu(), y.cpu(), tgt.cpu(), src.cpu(), c.cpu(), 2)
+    assert_close(out, ref, 1e-5, 'isolated / tiny graph')
+    with pytest.raises(CrfConvError):
+        table_from_edges(torch.zeros(100, dtype=torch.long, device=DEV), torch.arange(100, device=DEV), N, 200)
+    with pytest.raises(IndexError):
+        table_from_edges(tgt, src + 100, N, N)
+
+
+def test_graph_builders():
+    from crfconv_amd.models import graph_ops
+    pos_np = np.concatenate([S.make_cloud(5, 700), S.make_cloud(6, 300) + 5.0]).astype(np.float32)
+    batch_np = np.concatenate([np.zeros(700, np.int64), np.ones(300, np.int64)])
+    pos, batch = t(pos_np), t(batch_np)
+    # knn_graph with loops: row-major [neighbour j; node i], K per node, inside the node's cloud
+    ei = graph_ops.knn_graph(pos, 8, batch, loop=True).cpu().numpy()
+    assert ei.shape == (2, 8000)
+    want0 = onative.oracle_knn(pos_np[:700], pos_np[:700], 8)
+    want1 = onative.oracle_knn(pos_np[700:], pos_np[700:], 8) + 700
+    assert np.array_equal(ei[0].reshape(1000, 8), np.concatenate([want0, want1]))
+    assert np.array_equal(ei[1], np.repeat(np.arange(1000), 8))
+    ei2 = graph_ops.knn_graph(pos, 8, batch, loop=False).cpu().numpy()
+    assert ei2.shape == (2, 8000) and not (ei2[0] == ei2[1]).any()
+    # radius graph: every edge within r, none missing among the nearest `max_num_neighbors`
+    r = 0.12
+    er = graph_ops.radius_graph(pos, r, batch, loop=False, max_num_neighbors=16).cpu().numpy()
+    d = np.linalg.norm(pos_np[er[0]] - pos_np[er[1]], axis=1)
+    assert (d <= r + 1e-6).all() and (batch_np[er[0]] == batch_np[er[1]]).all()
+    full = np.linalg.norm(pos_np[:700, None] - pos_np[None, :700], axis=-1)
+    np.fill_diagonal(full, np.inf)
+    deg_true = np.minimum((full <= r).sum(1), 16)
+    assert np.array_equal(np.bincount(er[1][er[1] < 700], minlength=700), deg_true)
+    # fps: right count per cloud, distinct, each pick is the farthest point from the picks before it
+    idx = graph_ops.fps(pos, batch, ratio=0.1).cpu().numpy()
+    assert len(idx) == 100 and len(set(idx.tolist())) == 100 and (idx[:70] < 700).all() and (idx[70:] >= 700).all()
+    # bipartite builder keeps the reference's [col; row] layout
+    from crfconv_amd.models import build_bipartite_graph
+    eb, sub_pos, sub_batch = build_bipartite_graph(pos, batch, 0.1, method='knn', k=6)
+    assert eb.shape == (2, 600) and sub_pos.shape == (100, 3) and int(eb[1].max()) == 99
+    assert bool((batch[eb[0]] == sub_batch[eb[1]]).all())
+
+
+def test_sparse_equals_dense_on_device():
+    """Same kNN graph through the dense fast path (fixed-K table, k0 = 1) and the padded edge-list path."""
+    from crfconv_amd import ops
+    from crfconv_amd.graph import NeighborTable, table_from_edges
+    B, N, K, H = 2, 2000, 16, 8
+    pos = np.stack([S.make_cloud(88 + b, N) for b in range(B)])
+    nbr = onative.oracle_knn_batch(pos, pos, K)
+    z, y = t(S.uniform(88, 'z', (B * N, H))), t(S.uniform(88, 'y', (B * N, H)))
+    c = (torch.eye(H) + 0.1 * torch.from_numpy(S.uniform(88, 'c', (H, H)))).to(DEV)
+    dense = ops.crf_meanfield(z, y, c, NeighborTable(t(nbr), N), 3, k0=1)
+    glob = (torch.from_numpy(nbr) + (torch.arange(B) * N).view(B, 1, 1)).reshape(B * N, K)
+    tgt = torch.arange(B * N).repeat_interleave(K - 1).to(DEV)
+    src = glob[:, 1:].reshape(-1).to(DEV)
+    sparse = ops.crf_meanfield(z, y, c, table_from_edges(tgt, src, B * N, B * N), 3, k0=0)
+    assert_close(sparse, dense, 1e-5, 'sparse vs dense')

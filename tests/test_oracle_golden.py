@@ -229,3 +229,71 @@ def test_ref_libs_agree_with_oracle_when_present():
     rng = np.random.default_rng(3)
     pts = rng.random((2, 1500, 3), dtype=np.float32)
     assert np.array_equal(onative.oracle_knn_batch(pts, pts, 16), onative.ref_knn_batch(pts, pts, 16, omp=True))
+
+
+# ------------------------------------------------------------------ sparse (edge-list) twins
+def _g8_graph(g, gname):
+    tgt = g['tgt'].astype(np.int64)
+    src = g['src'].astype(np.int64)
+    if gname == 'ragged':
+        tgt, src = tgt[g['keep']], src[g['keep']]
+    return torch.from_numpy(tgt), torch.from_numpy(src)
+
+
+@pytest.mark.parametrize('gname,steps,mode', [('full', 3, 'train'), ('ragged', 3, 'train'), ('ragged', 1, 'eval')])
+def test_sparse_crf_oracle_golden(golden, gname, steps, mode):
+    """oracle's edge-list mean field vs the reference's sparse modules run through third-party stubs
+    ("parity unpinned" at the torch_geometric / torch_scatter boundary)."""
+    g = golden('g8_sparse.npz')
+    tgt, src = _g8_graph(g, gname)
+    tag = '%s_T%d_%s' % (gname, steps, mode)
+    for kind in ('crf', 'guide'):
+        sd = params(sub(g, kind + '/sd'))
+        x = t(g['x']).requires_grad_(True)
+        y = t(g['y']).requires_grad_(True)
+        if kind == 'crf':
+            out = O.sparse_crf_conv(sd, '', x, y, torch.stack([tgt, src]), steps, mode == 'train')
+        else:
+            out = O.guide_crf_conv(sd, '', x, y, tgt, src, steps, mode == 'train')
+        close(out, g['%s/%s/out' % (kind, tag)], OUT_TOL, kind + ' out')
+        (out * t(g['%s/%s/gout' % (kind, tag)])).sum().backward()
+        close(x.grad, g['%s/%s/d_x' % (kind, tag)], GRAD_TOL, kind + ' d_x')
+        close(y.grad, g['%s/%s/d_y' % (kind, tag)], GRAD_TOL, kind + ' d_y')
+        check_grads(sd, g, '%s/%s/grad' % (kind, tag))
+
+
+@pytest.mark.parametrize('form', ['sym_same', 'sym_proj', 'bip'])
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_ds_point_conv_oracle_golden(golden, form, mode):
+    g = golden('g8_sparse.npz')
+    sd = params(sub(g, 'dsconv/%s/sd' % form))
+    x = t(g['dsconv/x']).requires_grad_(True)
+    pos = t(g['pos'])
+    tgt, src = _g8_graph(g, 'full')
+    if form == 'bip':
+        choice = g['dsconv/choice'].astype(np.int64)
+        K = len(tgt) // len(pos)
+        nbr = src.reshape(len(pos), K)
+        ei = torch.stack([nbr[choice].reshape(-1), torch.arange(len(choice)).repeat_interleave(K)])
+        out = O.ds_point_conv(sd, '', x, (pos, pos[choice]), ei, mode == 'train')
+    else:
+        out = O.ds_point_conv(sd, '', x, pos, torch.stack([src, tgt]), mode == 'train')
+    tag = 'dsconv/%s_%s' % (form, mode)
+    close(out, g[tag + '/out'], OUT_TOL, 'out')
+    (out * t(g[tag + '/gout'])).sum().backward()
+    close(x.grad, g[tag + '/d_x'], GRAD_TOL, 'd_x')
+    check_grads(sd, g, tag + '/grad')
+
+
+def test_sparse_equals_dense_on_knn_graph():
+    """A kNN graph without self loops run through the edge-list oracle == the dense oracle."""
+    B, N, K, H = 1, 300, 9, 8
+    pos = S.make_cloud(77, N)[None]
+    nbr = torch.from_numpy(onative.oracle_knn_batch(pos, pos, K))
+    z, y = t(S.uniform(77, 'z', (B, N, H))), t(S.uniform(77, 'y', (B, N, H)))
+    c = torch.eye(H) + 0.1 * t(S.uniform(77, 'c', (H, H)))
+    dense = O.crf_meanfield(z, y, nbr[:, :, 1:], c, 3)[0]
+    tgt = torch.arange(N).repeat_interleave(K - 1)
+    src = nbr[0, :, 1:].reshape(-1)
+    sparse = O.sparse_crf_meanfield(z[0], y[0], tgt, src, c, 3)
+    close(sparse, dense.numpy(), 1e-6, 'sparse vs dense')
