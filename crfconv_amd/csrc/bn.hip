@@ -1,0 +1,277 @@
+// Fused BatchNorm (+ LeakyReLU) over per-point rows [M, C] -- the normalisation inside every MLP of the path
+// (models/common.py:31,36-37: FastBatchNorm1d, statistics over all B*N rows; followed by LeakyReLU(0.1)
+// in most layers).  HBM-bound streaming kernels:
+//   forward  : stats (1 read)            -> finalize (tiny) -> apply + activation (1 read, 1 write)
+//   backward : reduce (2 reads)          -> finalize (tiny) -> apply (2 reads, 1 write)
+// against the stock sequence of 5 forward / 6 backward passes.  Reductions: per-thread fp32 over a strided
+// row slice (shifted by row 0 to avoid cancellation), fixed-order block and grid combination in float64 --
+// bitwise reproducible, no atomics.
+#include "common.hpp"
+
+namespace crf {
+
+constexpr int BN_BLOCK = 256;
+constexpr int BN_MAXBLK = 512;
+
+__device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// partial[blk][0][C] = sum(x - shift), partial[blk][1][C] = sum((x - shift)^2), shift = row 0
+__global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(const float* __restrict__ x, int64_t M, int C,
+                                                            float* __restrict__ partial) {
+    extern __shared__ float sred[];  // [rows_in_block][2][C]
+    const int C4 = C >> 2;
+    const int rpi = BN_BLOCK / C4;               // rows handled per iteration by this block
+    const int q = threadIdx.x % C4, rl = threadIdx.x / C4;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (rl < rpi) {
+        const float4 sh = ld4g(x + 4 * q);
+        for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < M; r += (int64_t)gridDim.x * rpi) {
+            const float4 v = ld4g(x + r * C + 4 * q);
+            const float4 d = make_float4(v.x - sh.x, v.y - sh.y, v.z - sh.z, v.w - sh.w);
+            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+            s2.x = fmaf(d.x, d.x, s2.x); s2.y = fmaf(d.y, d.y, s2.y); s2.z = fmaf(d.z, d.z, s2.z); s2.w = fmaf(d.w, d.w, s2.w);
+        }
+        st4(sred + (rl * 2 + 0) * C + 4 * q, s1);
+        st4(sred + (rl * 2 + 1) * C + 4 * q, s2);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += BN_BLOCK) {
+        float a = 0.f;
+        for (int r = 0; r < rpi; ++r) a += sred[r * 2 * C + t];
+        partial[(int64_t)blockIdx.x * 2 * C + t] = a;
+    }
+}
+
+// coef[0] = a = gamma * rstd, coef[1] = b = beta - a * mean, coef[2] = mean, coef[3] = rstd   (each [C])
+// running statistics updated in place when given (momentum; unbiased variance), as torch.nn.BatchNorm1d.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk,
+                                                          const float* __restrict__ x_row0, int64_t M, int C,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var, float momentum,
+                                                          float* __restrict__ coef) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += (double)partial[(int64_t)b * 2 * C + c];
+        s2 += (double)partial[(int64_t)b * 2 * C + C + c];
+    }
+    const double m1 = s1 / (double)M;
+    const double mean = (double)x_row0[c] + m1;
+    double var = s2 / (double)M - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double a = (double)gamma[c] * rstd;
+    coef[c] = (float)a;
+    coef[C + c] = (float)((double)beta[c] - a * mean);
+    coef[2 * C + c] = (float)mean;
+    coef[3 * C + c] = (float)rstd;
+    if (run_mean != nullptr) {
+        const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * mean);
+        run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * unb);
+    }
+}
+
+// eval mode: coefficients from running statistics
+__global__ __launch_bounds__(256) void bn_coef_eval_kernel(const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ run_mean,
+                                                           const float* __restrict__ run_var, float eps, int C,
+                                                           float* __restrict__ coef) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double rstd = 1.0 / sqrt((double)run_var[c] + (double)eps);
+    const double a = (double)gamma[c] * rstd;
+    coef[c] = (float)a;
+    coef[C + c] = (float)((double)beta[c] - a * (double)run_mean[c]);
+    coef[2 * C + c] = run_mean[c];
+    coef[3 * C + c] = (float)rstd;
+}
+
+// y = lrelu(a x + b, slope)   (slope == 1: no activation)
+__global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ coef, int64_t n4, int C4,
+                                                            float slope, float* __restrict__ y) {
+    for (int64_t t = (int64_t)blockIdx.x * BN_BLOCK + threadIdx.x; t < n4; t += (int64_t)gridDim.x * BN_BLOCK) {
+        const int q = (int)(t % C4);
+        const float4 a = ld4g(coef + 4 * q), b = ld4g(coef + 4 * C4 + 4 * q);
+        const float4 v = ld4g(x + 4 * t);
+        float4 o = make_float4(fmaf(a.x, v.x, b.x), fmaf(a.y, v.y, b.y), fmaf(a.z, v.z, b.z), fmaf(a.w, v.w, b.w));
+        o.x = o.x > 0.f ? o.x : slope * o.x;
+        o.y = o.y > 0.f ? o.y : slope * o.y;
+        o.z = o.z > 0.f ? o.z : slope * o.z;
+        o.w = o.w > 0.f ? o.w : slope * o.w;
+        st4(y + 4 * t, o);
+    }
+}
+
+// backward reductions: partial[blk][0][C] = sum g_pre, [1][C] = sum g_pre * xhat
+__global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(const float* __restrict__ gy,
+                                                                 const float* __restrict__ x,
+                                                                 const float* __restrict__ coef, int64_t M, int C,
+                                                                 float slope, float* __restrict__ partial) {
+    extern __shared__ float sred[];
+    const int C4 = C >> 2;
+    const int rpi = BN_BLOCK / C4;
+    const int q = threadIdx.x % C4, rl = threadIdx.x / C4;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (rl < rpi) {
+        const float4 a = ld4g(coef + 4 * q), b = ld4g(coef + C + 4 * q);
+        const float4 mu = ld4g(coef + 2 * C + 4 * q), rs = ld4g(coef + 3 * C + 4 * q);
+        for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < M; r += (int64_t)gridDim.x * rpi) {
+            const float4 v = ld4g(x + r * C + 4 * q);
+            float4 g = ld4g(gy + r * C + 4 * q);
+            g.x *= fmaf(a.x, v.x, b.x) > 0.f ? 1.f : slope;
+            g.y *= fmaf(a.y, v.y, b.y) > 0.f ? 1.f : slope;
+            g.z *= fmaf(a.z, v.z, b.z) > 0.f ? 1.f : slope;
+            g.w *= fmaf(a.w, v.w, b.w) > 0.f ? 1.f : slope;
+            s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+            s2.x = fmaf(g.x, (v.x - mu.x) * rs.x, s2.x);
+            s2.y = fmaf(g.y, (v.y - mu.y) * rs.y, s2.y);
+            s2.z = fmaf(g.z, (v.z - mu.z) * rs.z, s2.z);
+            s2.w = fmaf(g.w, (v.w - mu.w) * rs.w, s2.w);
+        }
+        st4(sred + (rl * 2 + 0) * C + 4 * q, s1);
+        st4(sred + (rl * 2 + 1) * C + 4 * q, s2);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += BN_BLOCK) {
+        float acc = 0.f;
+        for (int r = 0; r < rpi; ++r) acc += sred[r * 2 * C + t];
+        partial[(int64_t)blockIdx.x * 2 * C + t] = acc;
+    }
+}
+
+// dgamma, dbeta and the per-channel terms of dx = c1 * (g_pre - c2 - xhat * c3); bcoef = [c1 | c2 | c3]
+// training: c1 = gamma*rstd, c2 = dbeta/M, c3 = dgamma/M;  eval: c1 = gamma*rstd, c2 = c3 = 0
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk,
+                                                              const float* __restrict__ coef, int64_t M, int C,
+                                                              int training, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta,
+                                                              float* __restrict__ bcoef) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += (double)partial[(int64_t)b * 2 * C + c];
+        s2 += (double)partial[(int64_t)b * 2 * C + C + c];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    bcoef[c] = coef[c];   // a = gamma * rstd
+    bcoef[C + c] = training ? (float)(s1 / (double)M) : 0.f;
+    bcoef[2 * C + c] = training ? (float)(s2 / (double)M) : 0.f;
+}
+
+__global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(const float* __restrict__ gy,
+                                                                const float* __restrict__ x,
+                                                                const float* __restrict__ coef,
+                                                                const float* __restrict__ bcoef, int64_t n4, int C4,
+                                                                float slope, float* __restrict__ gx) {
+    const int C = 4 * C4;
+    for (int64_t t = (int64_t)blockIdx.x * BN_BLOCK + threadIdx.x; t < n4; t += (int64_t)gridDim.x * BN_BLOCK) {
+        const int q = (int)(t % C4);
+        const float4 a = ld4g(coef + 4 * q), b = ld4g(coef + C + 4 * q);
+        const float4 mu = ld4g(coef + 2 * C + 4 * q), rs = ld4g(coef + 3 * C + 4 * q);
+        const float4 c1 = ld4g(bcoef + 4 * q), c2 = ld4g(bcoef + C + 4 * q), c3 = ld4g(bcoef + 2 * C + 4 * q);
+        const float4 v = ld4g(x + 4 * t);
+        float4 g = ld4g(gy + 4 * t);
+        g.x *= fmaf(a.x, v.x, b.x) > 0.f ? 1.f : slope;
+        g.y *= fmaf(a.y, v.y, b.y) > 0.f ? 1.f : slope;
+        g.z *= fmaf(a.z, v.z, b.z) > 0.f ? 1.f : slope;
+        g.w *= fmaf(a.w, v.w, b.w) > 0.f ? 1.f : slope;
+        float4 o;
+        o.x = c1.x * (g.x - c2.x - (v.x - mu.x) * rs.x * c3.x);
+        o.y = c1.y * (g.y - c2.y - (v.y - mu.y) * rs.y * c3.y);
+        o.z = c1.z * (g.z - c2.z - (v.z - mu.z) * rs.z * c3.z);
+        o.w = c1.w * (g.w - c2.w - (v.w - mu.w) * rs.w * c3.w);
+        st4(gx + 4 * t, o);
+    }
+}
+
+static int bn_check(int64_t M, int C) {
+    CRF_REQUIRE(M > 0 && M < ((int64_t)1 << 40), CRF_ERR_ARG, "M=%lld out of range", (long long)M);
+    CRF_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024, CRF_ERR_UNSUPPORTED, "C=%d must be a multiple of 4 in [4, 1024]", C);
+    return CRF_OK;
+}
+
+static int bn_nblk(int64_t M, int C) {
+    const int rpi = BN_BLOCK / (C / 4);
+    // at least ~16 rows per thread before paying for another partial
+    int64_t nb = (M + 16 * (int64_t)rpi - 1) / (16 * (int64_t)rpi);
+    if (nb < 1) nb = 1;
+    return (int)(nb > BN_MAXBLK ? BN_MAXBLK : nb);
+}
+
+static unsigned ew_grid(int64_t n4) {
+    int64_t g = (n4 + BN_BLOCK - 1) / BN_BLOCK;
+    return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace crf
+
+using namespace crf;
+
+extern "C" size_t crfconv_bn_workspace(int64_t M, int C) {
+    if (M <= 0 || C < 4) return 0;
+    return sizeof(float) * (2 * (size_t)C * BN_MAXBLK + 3 * (size_t)C) + 512;
+}
+
+// training (use_batch_stats != 0): statistics of x, coef out, running stats updated (may be NULL);
+// eval: coef from running stats.  y = lrelu(BN(x), slope); slope = 1 -> plain BatchNorm.  y may alias x.
+extern "C" int crfconv_bn_forward(const float* x, int64_t M, int C, const float* gamma, const float* beta,
+                                  float* run_mean, float* run_var, float momentum, float eps, int use_batch_stats,
+                                  float slope, float* coef, float* y, void* workspace, size_t workspace_bytes,
+                                  crf_stream_t stream) {
+    if (int rc = bn_check(M, C)) return rc;
+    CRF_REQUIRE(x && gamma && beta && coef && y && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(use_batch_stats || (run_mean && run_var), CRF_ERR_ARG, "eval mode needs running statistics");
+    CRF_REQUIRE(workspace_bytes >= crfconv_bn_workspace(M, C), CRF_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    if (use_batch_stats) {
+        const int nblk = bn_nblk(M, C);
+        const int rpi = BN_BLOCK / (C / 4);
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(BN_BLOCK), sizeof(float) * 2 * C * (rpi > 0 ? rpi : 1), st, x, M,
+                           C, partial);
+        CRF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nblk, x, M, C, gamma, beta,
+                           eps, run_mean, run_var, momentum, coef);
+        CRF_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(bn_coef_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, run_mean, run_var, eps,
+                           C, coef);
+        CRF_LAUNCH_CHECK();
+    }
+    const int64_t n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(BN_BLOCK), 0, st, x, coef, n4, C / 4, slope, y);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_bn_backward(const float* gy, const float* x, const float* coef, int64_t M, int C,
+                                   int training, float slope, float* gx, float* dgamma, float* dbeta, void* workspace,
+                                   size_t workspace_bytes, crf_stream_t stream) {
+    if (int rc = bn_check(M, C)) return rc;
+    CRF_REQUIRE(gy && x && coef && gx && dgamma && dbeta && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(workspace_bytes >= crfconv_bn_workspace(M, C), CRF_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    float* bcoef = partial + 2 * (size_t)C * BN_MAXBLK;
+    const int nblk = bn_nblk(M, C);
+    const int rpi = BN_BLOCK / (C / 4);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(BN_BLOCK), sizeof(float) * 2 * C * (rpi > 0 ? rpi : 1), st, gy,
+                       x, coef, M, C, slope, partial);
+    CRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nblk, coef, M, C, training,
+                       dgamma, dbeta, bcoef);
+    CRF_LAUNCH_CHECK();
+    const int64_t n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(BN_BLOCK), 0, st, gy, x, coef, bcoef, n4, C / 4, slope,
+                       gx);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}

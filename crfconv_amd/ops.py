@@ -159,6 +159,56 @@ def linear(x, W, b=None):
     return y.reshape(shape[:-1] + (W.shape[0],))
 
 
+# ------------------------------------------------------------------------------ BatchNorm (+ LeakyReLU)
+class _BNAct(torch.autograd.Function):
+    """y = lrelu(BatchNorm(x), slope) over rows [m, C]: one stats pass + one fused apply pass forward, one
+    reduction + one fused pass backward (csrc/bn.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, use_batch, slope):
+        m, C = x.shape
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        coef = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+        nbytes = _lib.load().crfconv_bn_workspace(m, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        g, b = _f32c(gamma), _f32c(beta)
+        _lib.call('crfconv_bn_forward', ptr(x), m, C, ptr(g), ptr(b), ptr(run_mean) if use_batch else ptr(run_mean),
+                  ptr(run_var), float(momentum), float(eps), 1 if use_batch else 0, float(slope), ptr(coef), ptr(y),
+                  ptr(ws), nbytes, stream_ptr())
+        ctx.save_for_backward(x, coef)
+        ctx.use_batch, ctx.slope = use_batch, slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, coef = ctx.saved_tensors
+        m, C = x.shape
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        nbytes = _lib.load().crfconv_bn_workspace(m, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        _lib.call('crfconv_bn_backward', ptr(gy), ptr(x), ptr(coef), m, C, 1 if ctx.use_batch else 0, float(ctx.slope),
+                  ptr(gx), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
+        return gx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_act(x, bn, training, slope=1.0):
+    """FastBatchNorm1d semantics (statistics over every leading dim of x [..., C]) fused with LeakyReLU(slope);
+    `bn` is the torch.nn.BatchNorm1d holding the affine parameters and running statistics."""
+    shape = x.shape
+    C = shape[-1]
+    use_batch = training or bn.running_mean is None
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    y = _BNAct.apply(x.reshape(-1, C), bn.weight, bn.bias, bn.running_mean if (training or not use_batch) else None,
+                     bn.running_var if (training or not use_batch) else None, mom, bn.eps, use_batch, slope)
+    return y.reshape(shape)
+
+
 # ------------------------------------------------------------------------------ gather / max-pool
 class _GatherRows(torch.autograd.Function):
     @staticmethod
@@ -396,4 +446,4 @@ def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=
     return out
 
 
-__all__ = ['linear', 'crf_meanfield', 'gather_rows', 'neighbor_maxpool', 'relpos_moments', 'point_conv', 'NeighborTable']
+__all__ = ['linear', 'bn_act', 'crf_meanfield', 'gather_rows', 'neighbor_maxpool', 'relpos_moments', 'point_conv', 'NeighborTable']

@@ -202,6 +202,21 @@ size_t crfconv_linear_wgrad_workspace(int64_t M, int Co, int Ci);
 int crfconv_linear_wgrad(const float* G, const float* X, int64_t M, int Co, int Ci, float* dW, float* db,
                          void* workspace, size_t workspace_bytes, crf_stream_t stream);
 
+/* Fused BatchNorm (+ LeakyReLU) over rows x [M, C] (models/common.py:31,36-37; C % 4 == 0, C <= 1024).
+ * forward:  use_batch_stats != 0 -> statistics of x (biased variance), running stats updated in place when non-NULL
+ *           (momentum, unbiased variance -- torch.nn.BatchNorm1d semantics); else coefficients from running stats.
+ *           coef [4, C] out = {a = gamma*rstd, b = beta - a*mean, mean, rstd};  y = lrelu(a x + b, slope)
+ *           (slope = 1: no activation).
+ * backward: gx = d/dx, dgamma, dbeta from gy = d/dy, the saved x and coef (training != 0: batch-statistics
+ *           backward; else the affine-only backward). */
+size_t crfconv_bn_workspace(int64_t M, int C);
+int crfconv_bn_forward(const float* x, int64_t M, int C, const float* gamma, const float* beta, float* run_mean,
+                       float* run_var, float momentum, float eps, int use_batch_stats, float slope, float* coef,
+                       float* y, void* workspace, size_t workspace_bytes, crf_stream_t stream);
+int crfconv_bn_backward(const float* gy, const float* x, const float* coef, int64_t M, int C, int training,
+                        float slope, float* gx, float* dgamma, float* dbeta, void* workspace,
+                        size_t workspace_bytes, crf_stream_t stream);
+
 /* Q = M^-1 for the symmetric positive definite M = I + c^T c of a CRF layer (H <= 64; Gauss-Jordan in
  * float64, one workgroup, no host sync -- capturable into a hipGraph, unlike a LAPACK-style inverse). */
 int crfconv_spd_inverse(const float* M, int H, float* Q, crf_stream_t stream);

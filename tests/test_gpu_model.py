@@ -352,3 +352,32 @@ def test_linear_wgrad_mfma(M, Ci, Co, bias):
     assert_close(x.grad, go @ W.detach(), 1e-5, 'dX')
     if bias:
         assert_close(b.grad, go.double().sum(0), 2e-5, 'db')
+
+
+@pytest.mark.parametrize('M,C,slope,training', [(163840, 32, 0.1, True), (40960, 8, 1.0, True), (1000, 512, 0.1, True),
+                                                (777, 128, 0.1, False), (33, 1024, 1.0, True)])
+def test_fused_batchnorm_lrelu(M, C, slope, training):
+    """csrc/bn.hip against torch BatchNorm1d + LeakyReLU in float64."""
+    from crfconv_amd import ops
+    g = torch.Generator().manual_seed(C + M)
+    x = (torch.randn(M, C, generator=g) * 2 + 3).to(DEV).requires_grad_(True)      # mean >> 0: shifted sums matter
+    go = torch.randn(M, C, generator=g).to(DEV)
+    bn = torch.nn.BatchNorm1d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+        bn.running_mean.uniform_(2.5, 3.5); bn.running_var.uniform_(3.0, 5.0)
+    ref = torch.nn.BatchNorm1d(C).to(DEV).double()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    bn.train(training); ref.train(training)
+    y = ops.bn_act(x, bn, training, slope)
+    y.backward(go)
+    xr = x.detach().double().requires_grad_(True)
+    yr = torch.nn.functional.leaky_relu(ref(xr), slope) if slope != 1.0 else ref(xr)
+    yr.backward(go.double())
+    assert_close(y, yr, 1e-5, 'y')
+    assert_close(x.grad, xr.grad, 2e-5, 'dx')
+    assert_close(bn.weight.grad, ref.weight.grad, 2e-5, 'dgamma')
+    assert_close(bn.bias.grad, ref.bias.grad, 2e-5, 'dbeta')
+    assert_close(bn.running_mean, ref.running_mean, 1e-6, 'running_mean')
+    assert_close(bn.running_var, ref.running_var, 1e-6, 'running_var')
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
