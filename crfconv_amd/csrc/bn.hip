@@ -51,13 +51,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ run_mean,
                                                           float* __restrict__ run_var, float momentum,
                                                           float* __restrict__ coef) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    // one wavefront per channel: lanes stride over the block partials, fixed-order shuffle tree
+    const int c = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += WAVE) {
         s1 += (double)partial[(int64_t)b * 2 * C + c];
         s2 += (double)partial[(int64_t)b * 2 * C + C + c];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, WAVE);
+        s2 += __shfl_xor(s2, o, WAVE);
+    }
+    if (lane != 0) return;
     const double m1 = s1 / (double)M;
     const double mean = (double)x_row0[c] + m1;
     double var = s2 / (double)M - m1 * m1;
@@ -152,13 +160,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               int training, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta,
                                                               float* __restrict__ bcoef) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += WAVE) {
         s1 += (double)partial[(int64_t)b * 2 * C + c];
         s2 += (double)partial[(int64_t)b * 2 * C + C + c];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, WAVE);
+        s2 += __shfl_xor(s2, o, WAVE);
+    }
+    if (lane != 0) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     bcoef[c] = coef[c];   // a = gamma * rstd
@@ -238,7 +253,7 @@ extern "C" int crfconv_bn_forward(const float* x, int64_t M, int C, const float*
         hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(BN_BLOCK), sizeof(float) * 2 * C * (rpi > 0 ? rpi : 1), st, x, M,
                            C, partial);
         CRF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nblk, x, M, C, gamma, beta,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, nblk, x, M, C, gamma, beta,
                            eps, run_mean, run_var, momentum, coef);
         CRF_LAUNCH_CHECK();
     } else {
@@ -266,7 +281,7 @@ extern "C" int crfconv_bn_backward(const float* gy, const float* x, const float*
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(BN_BLOCK), sizeof(float) * 2 * C * (rpi > 0 ? rpi : 1), st, gy,
                        x, coef, M, C, slope, partial);
     CRF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nblk, coef, M, C, training,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, nblk, coef, M, C, training,
                        dgamma, dbeta, bcoef);
     CRF_LAUNCH_CHECK();
     const int64_t n4 = M * (C / 4);

@@ -759,3 +759,181 @@ extern "C" int crfconv_pointconv_bwd_dump(const float* x, const float* gout, con
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
+
+// ====================================================================== BatchNorm folding (tiny, one block)
+// The weight MLP's two BatchNorms are folded into per-channel affine coefficients.  BN-1 sits directly on
+// Linear(3 -> d) of rel = p_i - p_j, so its batch statistics are ANALYTIC in the first two moments of rel:
+//   mean1[c] = w_c . mu,   var1[c] = w_c^T Sigma w_c      (mu [3], Sigma [3,3] from crfconv_pointconv_moments)
+// and so is its backward.  These kernels replace ~60 tiny framework launches per convolution.
+namespace crf {
+
+// mom = {mu[3], Sigma[9]} float64.  aux1 [3, d] float64 out = {a = gamma*rstd, mean1, var1}.
+__global__ __launch_bounds__(128) void fold1_kernel(const float* __restrict__ W1, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const double* __restrict__ mom,
+                                                    double n_edges, float* __restrict__ run_mean,
+                                                    float* __restrict__ run_var, float momentum, float eps,
+                                                    int use_batch, int d, float* __restrict__ A1,
+                                                    float* __restrict__ b1, double* __restrict__ aux1) {
+    const int c = threadIdx.x;
+    if (c >= d) return;
+    const double w[3] = {W1[3 * c], W1[3 * c + 1], W1[3 * c + 2]};
+    double mean, var;
+    if (use_batch) {
+        mean = w[0] * mom[0] + w[1] * mom[1] + w[2] * mom[2];
+        var = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) var += w[a] * mom[3 + 3 * a + b] * w[b];
+        if (var < 0.0) var = 0.0;
+        if (run_mean != nullptr) {
+            const double unb = n_edges > 1.0 ? var * (n_edges / (n_edges - 1.0)) : var;
+            run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
+            run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+        }
+    } else {
+        mean = run_mean[c];
+        var = run_var[c];
+    }
+    const double a = (double)gamma[c] / sqrt(var + (double)eps);
+    A1[3 * c] = (float)(a * w[0]);
+    A1[3 * c + 1] = (float)(a * w[1]);
+    A1[3 * c + 2] = (float)(a * w[2]);
+    b1[c] = (float)((double)beta[c] - a * mean);
+    aux1[c] = a;
+    aux1[d + c] = mean;
+    aux1[2 * d + c] = var;
+}
+
+// dA1b1 [d, 4] float64 = {dA1[c][0..2], db1[c]}  ->  dW1 [d,3], dgamma1, dbeta1
+__global__ __launch_bounds__(128) void fold1_bwd_kernel(const float* __restrict__ W1, const float* __restrict__ gamma,
+                                                        const double* __restrict__ mom, const double* __restrict__ aux1,
+                                                        const double* __restrict__ dA1b1, float eps, int use_batch,
+                                                        int d, float* __restrict__ dW1, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta) {
+    const int c = threadIdx.x;
+    if (c >= d) return;
+    const double w[3] = {W1[3 * c], W1[3 * c + 1], W1[3 * c + 2]};
+    const double a = aux1[c], mean = aux1[d + c], var = aux1[2 * d + c];
+    const double r = 1.0 / sqrt(var + (double)eps);
+    const double dA[3] = {dA1b1[4 * c], dA1b1[4 * c + 1], dA1b1[4 * c + 2]};
+    const double db = dA1b1[4 * c + 3];
+    const double da = dA[0] * w[0] + dA[1] * w[1] + dA[2] * w[2] - db * mean;   // A = a w, b = beta - a mean
+    dgamma[c] = (float)(da * r);
+    dbeta[c] = (float)db;
+    double dw[3] = {a * dA[0], a * dA[1], a * dA[2]};
+    if (use_batch) {
+        const double dv = -0.5 * da * (double)gamma[c] * r * r * r;             // a = gamma (var + eps)^-1/2
+        for (int k = 0; k < 3; ++k) {
+            double sw = 0.0;
+            for (int b = 0; b < 3; ++b) sw += mom[3 + 3 * k + b] * w[b];         // (Sigma w)_k, Sigma symmetric
+            dw[k] += -db * a * mom[k] + dv * 2.0 * sw;                           // through mean1 and var1
+        }
+    }
+    dW1[3 * c] = (float)dw[0];
+    dW1[3 * c + 1] = (float)dw[1];
+    dW1[3 * c + 2] = (float)dw[2];
+}
+
+// stats [2, d] float64 = {sum(h2 - shift), sum (h2 - shift)^2}  ->  a2, b2; aux2 [2, d] = {mean2, rstd2}
+__global__ __launch_bounds__(128) void fold2_kernel(const double* __restrict__ stats, const float* __restrict__ shift,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    double n_edges, float* __restrict__ run_mean,
+                                                    float* __restrict__ run_var, float momentum, float eps,
+                                                    int use_batch, int d, float* __restrict__ a2,
+                                                    float* __restrict__ b2, double* __restrict__ aux2) {
+    const int c = threadIdx.x;
+    if (c >= d) return;
+    double mean, var;
+    if (use_batch) {
+        const double m1 = stats[c] / n_edges;
+        mean = (double)shift[c] + m1;
+        var = stats[d + c] / n_edges - m1 * m1;
+        if (var < 0.0) var = 0.0;
+        if (run_mean != nullptr) {
+            const double unb = n_edges > 1.0 ? var * (n_edges / (n_edges - 1.0)) : var;
+            run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
+            run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+        }
+    } else {
+        mean = run_mean[c];
+        var = run_var[c];
+    }
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double a = (double)gamma[c] * rstd;
+    a2[c] = (float)a;
+    b2[c] = (float)((double)beta[c] - a * mean);
+    aux2[c] = mean;
+    aux2[d + c] = rstd;
+}
+
+// red [2, d] float64 = {sum g_w, sum g_w (h2 - shift)}  ->  dgamma2, dbeta2 and the coefficients of
+// g_h2 = ca g_w + cb h2 + cc  (BatchNorm backward; eval: ca = gamma rstd, cb = cc = 0)
+__global__ __launch_bounds__(128) void fold2_bwd_kernel(const double* __restrict__ red, const float* __restrict__ shift,
+                                                        const double* __restrict__ aux2, const float* __restrict__ gamma,
+                                                        double n_edges, int use_batch, int d, float* __restrict__ ca,
+                                                        float* __restrict__ cb, float* __restrict__ cc,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = threadIdx.x;
+    if (c >= d) return;
+    const double mean = aux2[c], rstd = aux2[d + c], g = gamma[c];
+    const double sum_gw = red[c];
+    const double sum_gwh = rstd * (red[d + c] - (mean - (double)shift[c]) * sum_gw);    // sum g_w * hhat
+    dgamma[c] = (float)sum_gwh;
+    dbeta[c] = (float)sum_gw;
+    ca[c] = (float)(g * rstd);
+    if (use_batch) {
+        const double mgw = sum_gw / n_edges, mgh = sum_gwh / n_edges;
+        cb[c] = (float)(-g * rstd * rstd * mgh);
+        cc[c] = (float)(-g * rstd * mgw + g * rstd * rstd * mean * mgh);
+    } else {
+        cb[c] = 0.f;
+        cc[c] = 0.f;
+    }
+}
+
+}  // namespace crf
+
+extern "C" int crfconv_pointconv_fold1(const float* W1, const float* gamma1, const float* beta1, const double* mom,
+                                       double n_edges, float* run_mean, float* run_var, float momentum, float eps,
+                                       int use_batch, int d, float* A1, float* b1, double* aux1, crf_stream_t stream) {
+    CRF_REQUIRE(W1 && gamma1 && beta1 && mom && A1 && b1 && aux1, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(d >= 1 && d <= 128, CRF_ERR_UNSUPPORTED, "d=%d outside [1, 128]", d);
+    CRF_REQUIRE(use_batch || (run_mean && run_var), CRF_ERR_ARG, "eval mode needs running statistics");
+    hipLaunchKernelGGL(fold1_kernel, dim3(1), dim3(128), 0, as_stream(stream), W1, gamma1, beta1, mom, n_edges, run_mean,
+                       run_var, momentum, eps, use_batch, d, A1, b1, aux1);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_pointconv_fold1_bwd(const float* W1, const float* gamma1, const double* mom, const double* aux1,
+                                           const double* dA1b1, float eps, int use_batch, int d, float* dW1,
+                                           float* dgamma1, float* dbeta1, crf_stream_t stream) {
+    CRF_REQUIRE(W1 && gamma1 && mom && aux1 && dA1b1 && dW1 && dgamma1 && dbeta1, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(d >= 1 && d <= 128, CRF_ERR_UNSUPPORTED, "d=%d outside [1, 128]", d);
+    hipLaunchKernelGGL(fold1_bwd_kernel, dim3(1), dim3(128), 0, as_stream(stream), W1, gamma1, mom, aux1, dA1b1, eps,
+                       use_batch, d, dW1, dgamma1, dbeta1);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_pointconv_fold2(const double* stats, const float* shift, const float* gamma2, const float* beta2,
+                                       double n_edges, float* run_mean, float* run_var, float momentum, float eps,
+                                       int use_batch, int d, float* a2, float* b2, double* aux2, crf_stream_t stream) {
+    CRF_REQUIRE(gamma2 && beta2 && a2 && b2 && aux2 && (!use_batch || (stats && shift)), CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(d >= 1 && d <= 128, CRF_ERR_UNSUPPORTED, "d=%d outside [1, 128]", d);
+    CRF_REQUIRE(use_batch || (run_mean && run_var), CRF_ERR_ARG, "eval mode needs running statistics");
+    hipLaunchKernelGGL(fold2_kernel, dim3(1), dim3(128), 0, as_stream(stream), stats, shift, gamma2, beta2, n_edges,
+                       run_mean, run_var, momentum, eps, use_batch, d, a2, b2, aux2);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_pointconv_fold2_bwd(const double* red, const float* shift, const double* aux2,
+                                           const float* gamma2, double n_edges, int use_batch, int d, float* ca,
+                                           float* cb, float* cc, float* dgamma2, float* dbeta2, crf_stream_t stream) {
+    CRF_REQUIRE(red && shift && aux2 && gamma2 && ca && cb && cc && dgamma2 && dbeta2, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(d >= 1 && d <= 128, CRF_ERR_UNSUPPORTED, "d=%d outside [1, 128]", d);
+    hipLaunchKernelGGL(fold2_bwd_kernel, dim3(1), dim3(128), 0, as_stream(stream), red, shift, aux2, gamma2, n_edges,
+                       use_batch, d, ca, cb, cc, dgamma2, dbeta2);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}

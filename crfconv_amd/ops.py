@@ -62,18 +62,27 @@ class _MeanField(torch.autograd.Function):
         ds = torch.empty_like(s)
         sumG = torch.zeros_like(z)
         dP = torch.zeros_like(P)
+        dPt = torch.empty_like(P)
+        wbytes = _lib.load().crfconv_linear_wgrad_workspace(m, H, H)
+        wws = torch.empty(wbytes, dtype=torch.uint8, device=z.device)
+
+        def skinny_tn(A, B, out):      # out = A^T B for [m, H] operands: the MFMA row-reduction kernel
+            _lib.call('crfconv_linear_wgrad', ptr(A), ptr(B), m, H, H, ptr(out), None, ptr(wws), wbytes, st)
+
         for t in range(T, 0, -1):
             xprev = xs[t - 2] if t >= 2 else z
             _lib.call('crfconv_meanfield_bwd_edge', ptr(G), ptr(xprev), ptr(s), ptr(table.idx32), table.K, k0,
                       m, H, ptr(P), ptr(gm), ptr(ds), ptr(mt), 0 if t == T else 1, st)
-            dP.addmm_(mt.t(), G)
+            skinny_tn(mt, G, dPt)
+            dP.add_(dPt)
             sumG.add_(G)
             Gprev = torch.empty_like(z)
             _lib.call('crfconv_meanfield_bwd_scatter', ptr(gm), ptr(s), ptr(rev_ptr), ptr(rev_eid), table.K, k0,
                       m, H, None, ptr(Gprev), st)
             G = Gprev
         dz = torch.addmm(G, sumG, Q.t())          # x_0 = z path + the z Q term of every step
-        dQ = z.t() @ sumG
+        dQ = torch.empty_like(Q)
+        skinny_tn(z, sumG, dQ)
         w = torch.empty_like(s)
         dy_self = torch.empty_like(y)
         _lib.call('crfconv_similarity_bwd', ptr(ds), ptr(s), ptr(y), ptr(table.idx32), table.K, k0, m, H, ptr(w),
@@ -292,55 +301,59 @@ def relpos_moments(pos_src, pos_tgt, table):
     S = torch.stack([torch.stack([sec[0], sec[1], sec[2]]), torch.stack([sec[1], sec[3], sec[4]]),
                      torch.stack([sec[2], sec[4], sec[5]])])
     cov = S - torch.outer(mean, mean)
-    return mean, cov, n
+    return mean, cov, n, torch.cat([mean.reshape(3), cov.reshape(9)]).contiguous()
 
 
 class _PointConv(torch.autograd.Function):
-    """out[i,c] = sum_k w_ik[c] x[j,c],  w = BN2(W2 lrelu(A1 rel + b1)).
+    """out[i,c] = sum_k w_ik[c] x[j,c],  w = BN2(W2 lrelu(BN1(W1 rel))),  rel = p_tgt[i] - p_src[j].
 
-    A1/b1 already hold Linear(3->d) folded with its BatchNorm (differentiable inputs); BatchNorm-2
-    is handled here: batch statistics (train) come from a reduction pass over all edges and their
-    gradient terms from a second one, exactly the textbook BatchNorm backward."""
+    Both BatchNorms are folded into per-channel coefficients by tiny kernels (fold1 / fold2: BN-1's batch
+    statistics are analytic in the moments of rel, BN-2's come from one reduction pass over the edges);
+    the backward mirrors it: reduction pass -> fold2_bwd -> parameter pass -> fold1_bwd, plus the
+    source-major gather for dx.  Nothing per-edge is ever stored (except for d >= 64, see bwd_dump)."""
 
     @staticmethod
-    def forward(ctx, x, A1, b1, W2, gamma2, beta2, pos_src, pos_tgt, table, mean_rel, bn2_train, run_mean2,
-                run_var2, aux, slope):
-        require_gpu(x, A1, W2, pos_src, pos_tgt)
+    def forward(ctx, x, W1, g1, be1, W2, g2, be2, pos_src, pos_tgt, table, mom, bn1_state, bn2_state, slope):
+        require_gpu(x, W1, W2, pos_src, pos_tgt)
         dev = x.device
-        x, A1, b1, W2 = _f32c(x), _f32c(A1), _f32c(b1), _f32c(W2)
+        x, W1c, W2c = _f32c(x), _f32c(W1), _f32c(W2)
+        g1c, be1c, g2c, be2c = _f32c(g1), _f32c(be1), _f32c(g2), _f32c(be2)
         d = x.shape[1]
         m_tgt, K = table.m_tgt, table.K
         st = stream_ptr()
-        nbytes = _lib.load().crfconv_pointconv_workspace(max(m_tgt, table.m_src), K, d)
+        lib = _lib.load()
+        nbytes = lib.crfconv_pointconv_workspace(max(m_tgt, table.m_src), K, d)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         n_e = float(table.n_edges)
-        g2, be2 = gamma2.detach().double(), beta2.detach().double()
+        use1, rm1, rv1, mom1, eps1 = bn1_state
+        use2, rm2, rv2, mom2, eps2 = bn2_state
+        A1 = torch.empty((d, 3), dtype=torch.float32, device=dev)
+        b1 = torch.empty(d, dtype=torch.float32, device=dev)
+        aux1 = torch.empty(3 * d, dtype=torch.float64, device=dev)
+        _lib.call('crfconv_pointconv_fold1', ptr(W1c), ptr(g1c), ptr(be1c), ptr(mom), n_e, ptr(rm1), ptr(rv1),
+                  float(mom1), float(eps1), 1 if use1 else 0, d, ptr(A1), ptr(b1), ptr(aux1), st)
         shift = torch.zeros(d, dtype=torch.float32, device=dev)
-        if bn2_train:
+        stats = None
+        if use2:
             stats = torch.empty(2 * d, dtype=torch.float64, device=dev)
-            mean_rel = _f32c(mean_rel)          # keep every kernel operand alive in a local
+            mean_rel = mom[:3].float()
             _lib.call('crfconv_pointconv_stats', ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d, ptr(A1),
-                      ptr(b1), ptr(W2), slope, ptr(mean_rel), ptr(shift), ptr(stats), ptr(ws), nbytes, st)
-            m1 = stats[:d] / n_e
-            mean2 = shift.double() + m1
-            var2 = (stats[d:] / n_e - m1 * m1).clamp_min_(0.0)
-            if aux is not None:
-                aux['mean2'], aux['var2'], aux['n'] = mean2, var2, n_e
-        else:
-            mean2, var2 = run_mean2.detach().double(), run_var2.detach().double()
-        rstd2 = torch.rsqrt(var2 + BN_EPS)
-        a2 = (g2 * rstd2).float()
-        b2 = (be2 - g2 * rstd2 * mean2).float()
+                      ptr(b1), ptr(W2c), slope, ptr(mean_rel), ptr(shift), ptr(stats), ptr(ws), nbytes, st)
+        a2 = torch.empty(d, dtype=torch.float32, device=dev)
+        b2 = torch.empty(d, dtype=torch.float32, device=dev)
+        aux2 = torch.empty(2 * d, dtype=torch.float64, device=dev)
+        _lib.call('crfconv_pointconv_fold2', ptr(stats), ptr(shift), ptr(g2c), ptr(be2c), n_e, ptr(rm2), ptr(rv2),
+                  float(mom2), float(eps2), 1 if use2 else 0, d, ptr(a2), ptr(b2), ptr(aux2), st)
         out = torch.empty((m_tgt, d), dtype=torch.float32, device=dev)
         _lib.call('crfconv_pointconv_forward', ptr(x), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d,
-                  ptr(A1), ptr(b1), ptr(W2), slope, ptr(a2), ptr(b2), ptr(out), st)
-        ctx.table, ctx.bn2_train, ctx.n_e, ctx.slope = table, bn2_train, n_e, slope
-        ctx.save_for_backward(x, A1, b1, W2, a2, b2, shift, mean2, rstd2, g2, pos_src, pos_tgt)
+                  ptr(A1), ptr(b1), ptr(W2c), slope, ptr(a2), ptr(b2), ptr(out), st)
+        ctx.table, ctx.n_e, ctx.slope, ctx.use1, ctx.use2, ctx.eps1 = table, n_e, slope, use1, use2, eps1
+        ctx.save_for_backward(x, W1c, g1c, W2c, g2c, A1, b1, a2, b2, shift, aux1, aux2, mom, pos_src, pos_tgt)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        x, A1, b1, W2, a2, b2, shift, mean2, rstd2, g2, pos_src, pos_tgt = ctx.saved_tensors
+        x, W1, g1, W2, g2, A1, b1, a2, b2, shift, aux1, aux2, mom, pos_src, pos_tgt = ctx.saved_tensors
         table, n_e, slope = ctx.table, ctx.n_e, ctx.slope
         dev = x.device
         d = x.shape[1]
@@ -349,30 +362,21 @@ class _PointConv(torch.autograd.Function):
         st = stream_ptr()
         nbytes = _lib.load().crfconv_pointconv_workspace(max(m_tgt, table.m_src), K, d)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        # pass 1: sum g_w and sum g_w (h2 - shift)
+        # pass 1: sum g_w and sum g_w (h2 - shift)  ->  BatchNorm-2 backward coefficients
         red = torch.empty(2 * d, dtype=torch.float64, device=dev)
         _lib.call('crfconv_pointconv_bwd_reduce', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
                   m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(shift), ptr(red), ptr(ws), nbytes, st)
-        sum_gw = red[:d]
-        sum_gwh = rstd2 * (red[d:] - (mean2 - shift.double()) * sum_gw)     # sum g_w * hhat
-        dgamma2, dbeta2 = sum_gwh.float(), sum_gw.float()
-        ca = g2 * rstd2
-        if ctx.bn2_train:
-            mgw, mgh = sum_gw / n_e, sum_gwh / n_e
-            cb = -g2 * rstd2 * rstd2 * mgh
-            cc = -g2 * rstd2 * mgw + g2 * rstd2 * rstd2 * mean2 * mgh
-        else:
-            cb = torch.zeros_like(ca)
-            cc = torch.zeros_like(ca)
+        coef = torch.empty((5, d), dtype=torch.float32, device=dev)       # ca, cb, cc, dgamma2, dbeta2
+        _lib.call('crfconv_pointconv_fold2_bwd', ptr(red), ptr(shift), ptr(aux2), ptr(g2), n_e, 1 if ctx.use2 else 0,
+                  d, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), ptr(coef[4]), st)
         # pass 2: parameter gradients
-        ca32, cb32, cc32 = ca.float(), cb.float(), cc.float()      # locals: operands must outlive the launch
         if d <= 32:
             dW2 = torch.empty(d * d, dtype=torch.float64, device=dev)
             dA1b1 = torch.empty((d, 4), dtype=torch.float64, device=dev)
             _lib.call('crfconv_pointconv_bwd_params', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32),
-                      K, m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(ca32), ptr(cb32), ptr(cc32), ptr(dW2), ptr(dA1b1),
-                      ptr(ws), nbytes, st)
-            dW2, dA1, db1 = dW2.float().view(d, d), dA1b1[:, :3], dA1b1[:, 3]      # dA1/db1 stay float64
+                      K, m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]),
+                      ptr(dW2), ptr(dA1b1), ptr(ws), nbytes, st)
+            dW2 = dW2.float().view(d, d)
         else:
             # wide, edge-poor levels: per-edge h1 / g_h2 / rel to HBM, contractions as dense GEMMs
             E = m_tgt * K
@@ -380,25 +384,34 @@ class _PointConv(torch.autograd.Function):
             gh2 = torch.empty((E, d), dtype=torch.float32, device=dev)
             rel = torch.empty((E, 3), dtype=torch.float32, device=dev)
             _lib.call('crfconv_pointconv_bwd_dump', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
-                      m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(ca32), ptr(cb32), ptr(cc32), ptr(h1), ptr(gh2),
-                      ptr(rel), st)
+                      m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(h1),
+                      ptr(gh2), ptr(rel), st)
             dW2 = gh2.t() @ h1
-            gp = (gh2 @ W2) * torch.where(h1 > 0, 1.0, slope)
-            # float64 sums (see bwd_params) as three column reductions -- a float64 GEMM of this
-            # [E, d]^T x [E, 3] shape takes rocBLAS ~0.7 ms, the reductions a few microseconds each
-            gpd, reld = gp.double(), rel.double()
-            dA1 = torch.stack([(gpd * reld[:, a:a + 1]).sum(0) for a in range(3)], dim=1)
-            db1 = gpd.sum(0)
+            gpd = ((gh2 @ W2) * torch.where(h1 > 0, 1.0, slope)).double()
+            reld = rel.double()
+            # float64 sums as column reductions (a float64 GEMM of this shape takes rocBLAS ~0.7 ms)
+            dA1b1 = torch.stack([(gpd * reld[:, 0:1]).sum(0), (gpd * reld[:, 1:2]).sum(0), (gpd * reld[:, 2:3]).sum(0),
+                                 gpd.sum(0)], dim=1).contiguous()
+        dW1 = torch.empty((d, 3), dtype=torch.float32, device=dev)
+        dg1 = torch.empty(d, dtype=torch.float32, device=dev)
+        dbe1 = torch.empty(d, dtype=torch.float32, device=dev)
+        _lib.call('crfconv_pointconv_fold1_bwd', ptr(W1), ptr(g1), ptr(mom), ptr(aux1), ptr(dA1b1), float(ctx.eps1),
+                  1 if ctx.use1 else 0, d, ptr(dW1), ptr(dg1), ptr(dbe1), st)
         # input gradient (source-major gather over the reverse table)
         rev_ptr, rev_eid = table.reverse
         dx = torch.empty((table.m_src, d), dtype=torch.float32, device=dev)
         _lib.call('crfconv_pointconv_bwd_input', ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(rev_ptr), ptr(rev_eid), K,
                   table.m_src, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(a2), ptr(b2), ptr(dx), st)
-        return (dx, dA1, db1, dW2, dgamma2, dbeta2, None, None, None,
-                None, None, None, None, None, None)
+        return (dx, dW1, dg1, dbe1, dW2, coef[3], coef[4], None, None, None, None, None, None, None)
 
 
 _PC_D = (4, 8, 16, 32, 64, 128)
+
+
+def pack_moments(moments):
+    """(mean [3], cov [3,3], n) -> 12 float64 {mean, cov row-major} for the fold kernels."""
+    mean, cov = moments[0], moments[1]
+    return torch.cat([mean.reshape(3), cov.reshape(9)]).contiguous()
 
 
 def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=0.1, moments=None, slope=0.1):
@@ -413,37 +426,18 @@ def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=
     pos_tgt = pos_src if pos_tgt is None else _f32c(pos_tgt)
     if moments is None:
         moments = relpos_moments(pos_src, pos_tgt, table)
-    mean_rel, cov_rel, n_e = moments
-    # ---- BatchNorm-1 folded into the first Linear; batch statistics are analytic in (mean, cov) of rel
-    W1d = W1.double()
-    use_batch1 = training or bn1.running_mean is None
-    if use_batch1:
-        mean1 = W1d @ mean_rel
-        var1 = ((W1d @ cov_rel) * W1d).sum(1).clamp_min(0.0)
-        if training and bn1.running_mean is not None:
-            with torch.no_grad():
-                mom = momentum if bn1.momentum is None else bn1.momentum
-                bn1.running_mean.mul_(1 - mom).add_(mom * mean1.detach().float())
-                bn1.running_var.mul_(1 - mom).add_(mom * (var1.detach() * (n_e / max(n_e - 1.0, 1.0))).float())
-                bn1.num_batches_tracked += 1
-    else:
-        mean1, var1 = bn1.running_mean.double(), bn1.running_var.double()
-    a1 = bn1.weight.double() * torch.rsqrt(var1 + bn1.eps)
-    A1 = a1.unsqueeze(1) * W1d                    # float64 nodes: their gradients come back in float64
-    b1 = bn1.bias.double() - a1 * mean1
-    # ---- the fused kernels (BatchNorm-2 inside)
-    use_batch2 = training or bn2.running_mean is None
-    aux = {} if use_batch2 else None
-    out = _PointConv.apply(x, A1, b1, W2, bn2.weight, bn2.bias, pos_src, pos_tgt, table, mean_rel.float(),
-                           use_batch2, bn2.running_mean, bn2.running_var, aux, float(slope))
-    if training and use_batch2 and bn2.running_mean is not None:
-        with torch.no_grad():
-            mom = momentum if bn2.momentum is None else bn2.momentum
-            n = aux['n']
-            bn2.running_mean.mul_(1 - mom).add_(mom * aux['mean2'].float())
-            bn2.running_var.mul_(1 - mom).add_(mom * (aux['var2'] * (n / max(n - 1.0, 1.0))).float())
-            bn2.num_batches_tracked += 1
-    return out
+    mom = moments[3] if len(moments) > 3 else pack_moments(moments)
+
+    def state(bn):
+        use_batch = training or bn.running_mean is None
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        upd = training and bn.running_mean is not None
+        keep = upd or not use_batch
+        return (use_batch, bn.running_mean if keep else None, bn.running_var if keep else None,
+                momentum if bn.momentum is None else bn.momentum, bn.eps)
+    return _PointConv.apply(x, W1, bn1.weight, bn1.bias, W2, bn2.weight, bn2.bias, pos_src, pos_tgt, table, mom,
+                            state(bn1), state(bn2), float(slope))
 
 
 __all__ = ['linear', 'bn_act', 'crf_meanfield', 'gather_rows', 'neighbor_maxpool', 'relpos_moments', 'point_conv', 'NeighborTable']

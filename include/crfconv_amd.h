@@ -193,6 +193,26 @@ int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const f
                                 const float* W2, float slope, const float* a2, const float* b2, float* dx,
                                 crf_stream_t stream);
 
+/* BatchNorm folding of the weight MLP (one tiny workgroup each; d <= 128):
+ *  fold1      W1 [d,3], gamma1/beta1, mom = {mean[3], cov[9]} of rel (float64) -> A1 [d,3], b1 [d];
+ *             batch statistics of BN-1 are analytic in mom (mean1 = w.mu, var1 = w^T Sigma w); running
+ *             statistics updated in place when use_batch != 0 and non-NULL; aux1 [3,d] float64 saved for backward.
+ *  fold1_bwd  dA1b1 [d,4] float64 -> dW1 [d,3], dgamma1, dbeta1 (through the analytic statistics).
+ *  fold2      stats [2,d] + shift (crfconv_pointconv_stats) -> a2, b2; aux2 [2,d] = {mean2, rstd2}.
+ *  fold2_bwd  red [2,d] (crfconv_pointconv_bwd_reduce) -> ca, cb, cc for pass 2, dgamma2, dbeta2. */
+int crfconv_pointconv_fold1(const float* W1, const float* gamma1, const float* beta1, const double* mom,
+                            double n_edges, float* run_mean, float* run_var, float momentum, float eps,
+                            int use_batch, int d, float* A1, float* b1, double* aux1, crf_stream_t stream);
+int crfconv_pointconv_fold1_bwd(const float* W1, const float* gamma1, const double* mom, const double* aux1,
+                                const double* dA1b1, float eps, int use_batch, int d, float* dW1,
+                                float* dgamma1, float* dbeta1, crf_stream_t stream);
+int crfconv_pointconv_fold2(const double* stats, const float* shift, const float* gamma2, const float* beta2,
+                            double n_edges, float* run_mean, float* run_var, float momentum, float eps,
+                            int use_batch, int d, float* a2, float* b2, double* aux2, crf_stream_t stream);
+int crfconv_pointconv_fold2_bwd(const double* red, const float* shift, const double* aux2, const float* gamma2,
+                                double n_edges, int use_batch, int d, float* ca, float* cb, float* cc,
+                                float* dgamma2, float* dbeta2, crf_stream_t stream);
+
 /* ===================================================================== (B) per-point Linear layers
  * Weight gradient of y = x W^T (+ b), the one contraction of models/common.py:30,35 vendor GEMMs handle
  * badly (reduction over m = 10^4..10^5 rows into a tiny [Co, Ci]):
