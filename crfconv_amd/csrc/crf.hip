@@ -94,9 +94,8 @@ __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_f
     __shared__ float4 sQ[WITH_STEP ? H * L : 1];
     __shared__ float4 sP[WITH_STEP ? H * L : 1];
     if constexpr (WITH_STEP) load_matrix<H>(sQ, Q, false);
-    if constexpr (WITH_STEP) load_matrix<H>(sP, P, false);
-    __syncthreads();
-    int lane, q;
+    if constexpr (WITH_STEP) load_matrix<H>(sP, P, false);     // barrier deferred to the first matvec: the
+    int lane, q;                                              // matrix fetch overlaps the row loads and gathers
     bool valid;
     const int64_t r = my_point<H>(m, lane, q, valid);
 
@@ -135,10 +134,11 @@ __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_f
 
     if constexpr (WITH_STEP) {
         const float4 zi = ld4(z + r * H + 4 * q);
-        const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
         float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 1; k < K; ++k) msg = fma4(d[k], nb[k], msg);
+        __syncthreads();
+        const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
         const float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
         if (valid) st4(x1 + r * H + 4 * q, o);
     }
@@ -156,8 +156,7 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
     __shared__ float4 sP[H * L];
     __shared__ float4 sQ[H * L];
     load_matrix<H>(sP, P, false);
-    load_matrix<H>(sQ, Q, false);
-    __syncthreads();
+    load_matrix<H>(sQ, Q, false);                               // barrier deferred to the first matvec
     int lane, q;
     bool valid;
     const int64_t r = my_point<H>(m, lane, q, valid);
@@ -165,14 +164,16 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
     float w[K];
     load_row<K, int4>(idx + r * K, j);
     load_row<K, float4>(s + r * K, w);
+    const float4 zi = ld4(z + r * H + 4 * q);
     float4 nb[K];
 #pragma unroll
     for (int k = 1; k < K; ++k) nb[k] = ld4(xin + (int64_t)j[k] * H + 4 * q);
-    // z Q recomputed from z (same bytes as reading a stored z Q, and nothing extra to write)
-    const float4 zqi = matvec_acc<H>(ld4(z + r * H + 4 * q), sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
     float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 1; k < K; ++k) msg = fma4(w[k], nb[k], msg);
+    __syncthreads();
+    // z Q recomputed from z (same bytes as reading a stored z Q, and nothing extra to write)
+    const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
     const float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
     if (valid) st4(xout + r * H + 4 * q, o);
 }

@@ -124,8 +124,9 @@ static WgPlan wg_plan(int64_t M, int Co, int Ci) {
     p.tci = t_ci >= 4 ? 4 : (t_ci >= 2 ? 2 : 1);
     p.gy = (t_co + p.tco - 1) / p.tco;
     p.gz = (t_ci + p.tci - 1) / p.tci;
-    // ~1024 row-slices over the chip, at least 64 rows (4 k-steps per wave) each
-    int64_t rows = (M + 1023) / 1024;
+    // ~256 row-slices over the chip (x gy x gz output slabs), at least 64 rows (4 k-steps per wave) each:
+    // the partial slabs the second kernel sums stay a small fraction of the operand bytes
+    int64_t rows = (M + 255) / 256;
     if (rows < 64) rows = 64;
     rows = (rows + 15) / 16 * 16;
     p.rows_per_block = (int)rows;
@@ -189,23 +190,32 @@ __global__ __launch_bounds__(256) void spd_inverse_kernel(const float* __restric
                                                           float* __restrict__ Qout) {
     extern __shared__ double aug[];  // [H][2H]
     const int W = 2 * H;
-    for (int t = threadIdx.x; t < H * W; t += 256) {
+    const int n = H * W;
+    for (int t = threadIdx.x; t < n; t += 256) {
         const int r = t / W, c = t % W;
         aug[t] = c < H ? (double)Min[r * H + c] : (c - H == r ? 1.0 : 0.0);
     }
     __syncthreads();
+    // each thread owns elements t = tid, tid + 256, ... (<= 32 of them at H = 64); per pivot: read the
+    // old pivot row / column entries, barrier, write the updated element, barrier.
     for (int p = 0; p < H; ++p) {
         const double piv = 1.0 / aug[p * W + p];
-        __syncthreads();
-        for (int c = threadIdx.x; c < W; c += 256) aug[p * W + c] *= piv;
-        __syncthreads();
-        for (int t = threadIdx.x; t < H * W; t += 256) {
-            const int r = t / W, c = t % W;
-            if (r != p && c != p) aug[t] -= aug[r * W + p] * aug[p * W + c];
+        double nv[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int t = threadIdx.x + 256 * e;
+            if (t < n) {
+                const int r = t / W, c = t - r * W;
+                const double prc = aug[p * W + c] * piv;                  // normalised pivot-row entry
+                nv[e] = r == p ? prc : aug[t] - aug[r * W + p] * prc;
+            }
         }
         __syncthreads();
-        for (int r = threadIdx.x; r < H; r += 256)
-            if (r != p) aug[r * W + p] = 0.0;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int t = threadIdx.x + 256 * e;
+            if (t < n) aug[t] = nv[e];
+        }
         __syncthreads();
     }
     for (int t = threadIdx.x; t < H * H; t += 256) Qout[t] = (float)aug[(t / H) * W + H + (t % H)];
