@@ -72,8 +72,8 @@ def roofline_meanfield(data, dev, H=8, T=3, iters=50):
     st = stream_ptr()
 
     def launch():
-        _lib.call('crfconv_meanfield_forward', ptr(z), ptr(y), ptr(tab.idx32), K, 1, m, H, ptr(Q), ptr(P), T, ptr(s),
-                  ptr(xs), st)
+        _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src,
+                  K, 1, m, H, ptr(Q), ptr(P), T, ptr(s), ptr(xs), st)
     for _ in range(10):
         launch()
     torch.cuda.synchronize()

@@ -79,6 +79,29 @@ __device__ __forceinline__ void load_row(const T* __restrict__ p, T (&out)[K]) {
     }
 }
 
+// Index row in either layout: int32 global rows, or uint16 per-cloud local ids (half the bytes; valid when
+// every cloud has <= 65536 source points) decoded as  cloud * n_src + id  with cloud = row / n_tgt.
+template <int K>
+__device__ __forceinline__ void load_index_row(const int32_t* __restrict__ idx32, const uint16_t* __restrict__ idx16,
+                                               int64_t r, int n_tgt, int n_src, int (&j)[K]) {
+    if (idx16 != nullptr) {
+        const int base = (int)(r / n_tgt) * n_src;
+        const uint4* p = reinterpret_cast<const uint4*>(idx16 + r * K);
+#pragma unroll
+        for (int c = 0; c < K / 8; ++c) {
+            const uint4 v = p[c];
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                j[8 * c + 2 * e] = base + (int)(w[e] & 0xffffu);
+                j[8 * c + 2 * e + 1] = base + (int)(w[e] >> 16);
+            }
+        }
+    } else {
+        load_row<K, int4>(idx32 + r * K, j);
+    }
+}
+
 // ====================================================================== fast forward kernels
 // (K in {16, 32}, k0 == 1).  FIRST = similarity + z Q + first step fused: the index row is read
 // once, s never round-trips through memory before its first use.
@@ -86,6 +109,7 @@ template <int H, int K, bool WITH_STEP>
 __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_fast_kernel(const float* __restrict__ y,
                                                               const float* __restrict__ z,
                                                               const int32_t* __restrict__ idx,
+                                                              const uint16_t* __restrict__ idx16, int n_tgt, int n_src,
                                                               const float* __restrict__ Q,
                                                               const float* __restrict__ P,
                                                               float* __restrict__ s,
@@ -100,7 +124,7 @@ __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_f
     const int64_t r = my_point<H>(m, lane, q, valid);
 
     int j[K];
-    load_row<K, int4>(idx + r * K, j);
+    load_index_row<K>(idx, idx16, r, n_tgt, n_src, j);
     const float4 yi = ld4(y + r * H + 4 * q);
     float4 nb[K];
 #pragma unroll
@@ -149,6 +173,7 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
                                                           const float* __restrict__ z,
                                                           const float* __restrict__ s,
                                                           const int32_t* __restrict__ idx,
+                                                          const uint16_t* __restrict__ idx16, int n_tgt, int n_src,
                                                           const float* __restrict__ Q,
                                                           const float* __restrict__ P,
                                                           float* __restrict__ xout, int64_t m) {
@@ -162,7 +187,7 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
     const int64_t r = my_point<H>(m, lane, q, valid);
     int j[K];
     float w[K];
-    load_row<K, int4>(idx + r * K, j);
+    load_index_row<K>(idx, idx16, r, n_tgt, n_src, j);
     load_row<K, float4>(s + r * K, w);
     const float4 zi = ld4(z + r * H + 4 * q);
     float4 nb[K];
@@ -582,9 +607,28 @@ static int kshift_of(int K) {
 
 using namespace crf;
 
+static int meanfield_forward_impl(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16,
+                                  int n_tgt, int n_src, int K, int k0, int64_t m, int H, const float* Q,
+                                  const float* P, int T, float* s, float* xs, crf_stream_t stream);
+
 extern "C" int crfconv_meanfield_forward(const float* z, const float* y, const int32_t* idx32, int K,
                                          int k0, int64_t m, int H, const float* Q, const float* P,
                                          int T, float* s, float* xs, crf_stream_t stream) {
+    return meanfield_forward_impl(z, y, idx32, nullptr, 1, 1, K, k0, m, H, Q, P, T, s, xs, stream);
+}
+
+extern "C" int crfconv_meanfield_forward_u16(const float* z, const float* y, const int32_t* idx32,
+                                             const uint16_t* idx16, int n_tgt, int n_src, int K, int k0,
+                                             int64_t m, int H, const float* Q, const float* P, int T, float* s,
+                                             float* xs, crf_stream_t stream) {
+    CRF_REQUIRE(idx16 == nullptr || (n_tgt > 0 && n_src > 0 && n_src <= 65536 && m % n_tgt == 0), CRF_ERR_ARG,
+                "u16 table needs n_src <= 65536 and m a multiple of n_tgt (n_tgt=%d n_src=%d)", n_tgt, n_src);
+    return meanfield_forward_impl(z, y, idx32, idx16, n_tgt, n_src, K, k0, m, H, Q, P, T, s, xs, stream);
+}
+
+static int meanfield_forward_impl(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16,
+                                  int n_tgt, int n_src, int K, int k0, int64_t m, int H, const float* Q,
+                                  const float* P, int T, float* s, float* xs, crf_stream_t stream) {
     if (int rc = check_common(m, H, K, k0)) return rc;
     CRF_REQUIRE(z && y && idx32 && Q && P && s && (xs || T == 0), CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(T >= 0, CRF_ERR_ARG, "T=%d < 0", T);
@@ -614,11 +658,11 @@ extern "C" int crfconv_meanfield_forward(const float* z, const float* y, const i
         if (fast) {
             float* x1 = T > 0 ? xs : nullptr;
             if (K == 16) {
-                if (T > 0) hipLaunchKernelGGL((sim_step_fast_kernel<HH, 16, true>), grid, blk, 0, st, y, z, idx32, Q, P, s, x1, m);
-                else hipLaunchKernelGGL((sim_step_fast_kernel<HH, 16, false>), grid, blk, 0, st, y, z, idx32, Q, P, s, x1, m);
+                if (T > 0) hipLaunchKernelGGL((sim_step_fast_kernel<HH, 16, true>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
+                else hipLaunchKernelGGL((sim_step_fast_kernel<HH, 16, false>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
             } else {
-                if (T > 0) hipLaunchKernelGGL((sim_step_fast_kernel<HH, 32, true>), grid, blk, 0, st, y, z, idx32, Q, P, s, x1, m);
-                else hipLaunchKernelGGL((sim_step_fast_kernel<HH, 32, false>), grid, blk, 0, st, y, z, idx32, Q, P, s, x1, m);
+                if (T > 0) hipLaunchKernelGGL((sim_step_fast_kernel<HH, 32, true>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
+                else hipLaunchKernelGGL((sim_step_fast_kernel<HH, 32, false>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
             }
             t0 = 1;
         } else {
@@ -628,8 +672,8 @@ extern "C" int crfconv_meanfield_forward(const float* z, const float* y, const i
         for (int t = t0; t < T; ++t) {
             const float* xin = t == 0 ? z : xs + (int64_t)(t - 1) * m * H;
             float* xout = xs + (int64_t)t * m * H;
-            if (fast && K == 16) hipLaunchKernelGGL((step_fast_kernel<HH, 16>), grid, blk, 0, st, xin, z, s, idx32, Q, P, xout, m);
-            else if (fast) hipLaunchKernelGGL((step_fast_kernel<HH, 32>), grid, blk, 0, st, xin, z, s, idx32, Q, P, xout, m);
+            if (fast && K == 16) hipLaunchKernelGGL((step_fast_kernel<HH, 16>), grid, blk, 0, st, xin, z, s, idx32, idx16, n_tgt, n_src, Q, P, xout, m);
+            else if (fast) hipLaunchKernelGGL((step_fast_kernel<HH, 32>), grid, blk, 0, st, xin, z, s, idx32, idx16, n_tgt, n_src, Q, P, xout, m);
             else hipLaunchKernelGGL(step_kernel<HH>, grid, blk, 0, st, xin, z, s, idx32, K, k0, Q, P, xout, m);
             CRF_LAUNCH_CHECK();
         }

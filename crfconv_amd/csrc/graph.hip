@@ -10,6 +10,7 @@ namespace crf {
 __global__ __launch_bounds__(256) void narrow_kernel(const int64_t* __restrict__ idx64,
                                                      int64_t total, int64_t per_cloud,
                                                      int64_t n_src, int32_t* __restrict__ idx32,
+                                                     uint16_t* __restrict__ idx16,
                                                      int32_t* __restrict__ bad) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
@@ -20,6 +21,7 @@ __global__ __launch_bounds__(256) void narrow_kernel(const int64_t* __restrict__
         v = v < 0 ? 0 : n_src - 1;
     }
     idx32[t] = (int32_t)(b * n_src + v);
+    if (idx16 != nullptr) idx16[t] = (uint16_t)v;      // per-cloud local id (n_src <= 65536)
 }
 
 // edge ids 0..E-1 and sort keys: the source row, or m_src for "no neighbour" entries (< 0), which
@@ -67,16 +69,17 @@ static size_t sort_temp_bytes(int64_t E, int64_t m_src) {
 using namespace crf;
 
 extern "C" int crfconv_index_narrow(const int64_t* idx64, int64_t B, int64_t n_tgt, int K,
-                                    int64_t n_src, int32_t* idx32, int32_t* bad_count,
+                                    int64_t n_src, int32_t* idx32, uint16_t* idx16, int32_t* bad_count,
                                     crf_stream_t stream) {
     CRF_REQUIRE(idx64 && idx32 && bad_count, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(idx16 == nullptr || n_src <= 65536, CRF_ERR_ARG, "uint16 table needs n_src <= 65536");
     CRF_REQUIRE(B > 0 && n_tgt > 0 && K > 0 && n_src > 0, CRF_ERR_ARG, "empty table");
     CRF_REQUIRE(B * n_src < ((int64_t)1 << 31) && B * n_tgt * K < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED,
                 "table too large for int32 rows / edge ids (B=%lld n_src=%lld n_tgt=%lld K=%d)",
                 (long long)B, (long long)n_src, (long long)n_tgt, K);
     const int64_t total = B * n_tgt * K;
     hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream),
-                       idx64, total, n_tgt * K, n_src, idx32, bad_count);
+                       idx64, total, n_tgt * K, n_src, idx32, idx16, bad_count);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

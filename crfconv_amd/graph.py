@@ -31,7 +31,7 @@ def require_gpu(*tensors):
 
 
 class NeighborTable:
-    __slots__ = ('idx32', 'B', 'n_tgt', 'n_src', 'K', '_rev', '_bad', '_checked', 'cache', 'n_edges')
+    __slots__ = ('idx32', 'idx16', 'B', 'n_tgt', 'n_src', 'K', '_rev', '_bad', '_checked', 'cache', 'n_edges')
 
     def __init__(self, idx64, n_src, check=True):
         if idx64.dim() == 2:
@@ -46,8 +46,11 @@ class NeighborTable:
         self.n_src = int(n_src)
         self.idx32 = torch.empty((self.B * self.n_tgt, self.K), dtype=torch.int32, device=idx64.device)
         self._bad = torch.zeros(1, dtype=torch.int32, device=idx64.device)
+        # uint16 per-cloud ids as well when they fit: the streaming kernels then read half the index bytes
+        self.idx16 = (torch.empty((self.B * self.n_tgt, self.K), dtype=torch.int16, device=idx64.device)
+                      if self.n_src <= 65536 and self.K % 8 == 0 else None)
         _lib.call('crfconv_index_narrow', ptr(idx64), self.B, self.n_tgt, self.K, self.n_src,
-                  ptr(self.idx32), ptr(self._bad), stream_ptr())
+                  ptr(self.idx32), ptr(self.idx16), ptr(self._bad), stream_ptr())
         self._rev = None
         self._checked = False
         self.n_edges = self.B * self.n_tgt * self.K
@@ -100,7 +103,7 @@ def table_from_edges(tgt, src, n_tgt, n_src, max_degree=64):
     dev = tgt.device
     tab = NeighborTable.__new__(NeighborTable)
     tab.B, tab.n_tgt, tab.n_src = 1, int(n_tgt), int(n_src)
-    tab._rev, tab._checked, tab.cache = None, True, {}
+    tab._rev, tab._checked, tab.cache, tab.idx16 = None, True, {}, None
     tab._bad = torch.zeros(1, dtype=torch.int32, device=dev)
     if E == 0:
         tab.K, tab.n_edges = 1, 0

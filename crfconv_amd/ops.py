@@ -41,8 +41,8 @@ class _MeanField(torch.autograd.Function):
         z, y, Q, P = _f32c(z), _f32c(y), _f32c(Q), _f32c(P)
         s = torch.empty((m, table.K), dtype=torch.float32, device=z.device)   # edge-id addressed: s[i*K + k]
         xs = torch.empty((max(steps, 1), m, H), dtype=torch.float32, device=z.device)
-        _lib.call('crfconv_meanfield_forward', ptr(z), ptr(y), ptr(table.idx32), table.K, k0, m, H, ptr(Q),
-                  ptr(P), steps, ptr(s), ptr(xs), stream_ptr())
+        _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(table.idx32), ptr(table.idx16), table.n_tgt,
+                  table.n_src, table.K, k0, m, H, ptr(Q), ptr(P), steps, ptr(s), ptr(xs), stream_ptr())
         ctx.table, ctx.k0, ctx.steps = table, k0, steps
         ctx.save_for_backward(z, y, Q, P, s, xs)
         return xs[steps - 1].clone() if steps > 0 else z.clone()

@@ -88,9 +88,10 @@ int64_t crfconv_grid_subsample_dev(const float* points, int64_t N, const float* 
 /* ===================================================================== (B) neighbour tables
  * idx64 [B, n_tgt, K] per-cloud local ids into n_src points  ->  idx32 [B*n_tgt, K] global rows.
  * Out-of-range entries are clamped and counted into *bad_count (device int32, caller zeroes it);
- * the host must check it before any kernel consumes the table. */
+ * the host must check it before any kernel consumes the table.  idx16 (may be NULL; needs n_src <= 65536)
+ * additionally receives the per-cloud LOCAL ids as uint16 -- half the index bytes for the streaming kernels. */
 int crfconv_index_narrow(const int64_t* idx64, int64_t B, int64_t n_tgt, int K, int64_t n_src,
-                         int32_t* idx32, int32_t* bad_count, crf_stream_t stream);
+                         int32_t* idx32, uint16_t* idx16, int32_t* bad_count, crf_stream_t stream);
 
 /* Reverse (source-major) CSR of a table idx32 [E] with values in [0, m_src):
  * rev_ptr [m_src + 1], rev_eid [E] = edge ids e (= row * K + k) grouped by source row, ascending
@@ -112,6 +113,13 @@ int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_src, int32_t*
 int crfconv_meanfield_forward(const float* z, const float* y, const int32_t* idx32, int K, int k0,
                               int64_t m, int H, const float* Q, const float* P, int T, float* s,
                               float* xs, crf_stream_t stream);
+
+/* Same with the index rows read from the uint16 local-id table (idx16 [m, K]; row i belongs to cloud i / n_tgt,
+ * whose source rows start at cloud * n_src).  idx16 == NULL falls back to idx32.  Fast path only (K = 16 / 32,
+ * k0 = 1); other shapes use idx32. */
+int crfconv_meanfield_forward_u16(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16,
+                                  int n_tgt, int n_src, int K, int k0, int64_t m, int H, const float* Q,
+                                  const float* P, int T, float* s, float* xs, crf_stream_t stream);
 
 /* One backward step, edge half:  given G = dL/dx_t and x_{t-1}:
  *   gm  = G P^T                              [m, H]

@@ -26,6 +26,8 @@ def test_library_exports_every_declared_symbol():
     assert lib.crfconv_abi_version() == 1
     # argument validation happens before any HIP call, so it is testable without a GPU
     rc = lib.crfconv_meanfield_forward(None, None, None, 16, 1, 10, 7, None, None, 1, None, None, None)
+    assert rc == -3
+    rc = lib.crfconv_meanfield_forward_u16(None, None, None, None, 1, 1, 16, 1, 10, 7, None, None, 1, None, None, None)
     assert rc == -3 and b'H=7' in lib.crfconv_last_error()
     rc = lib.crfconv_knn_batch_dev(None, 1, 10, 3, None, 10, 4, None, None, None, 0, None)
     assert rc == -1
