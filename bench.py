@@ -152,13 +152,37 @@ def main():
     opt = torch.optim.SGD(net.parameters(), lr=1e-2, momentum=0.95, weight_decay=1e-4)
     cw = torch.ones(n_cls, device=dev)
 
-    def step():
-        bucket.zero()
+    # One training step = [A] zero grads, forward, weighted CE, backward, grads packed into ONE flat fp32 bucket
+    #                     [C] all-reduce of that bucket over RCCL (only when world > 1; eager, never captured)
+    #                     [B] SGD(momentum, weight decay) step on views of the bucket.
+    # A and B are each captured into a hipGraph (the step issues >1000 small launches; replaying them removes
+    # the Python host from the critical path).  The collective stays outside the graphs on purpose.
+    for p, v in zip(bucket.params, bucket.views):
+        p.grad = v
+
+    def part_a():
+        for p in bucket.params:
+            p.grad = None
         logits = net(data)
         loss = torch.nn.functional.cross_entropy(logits, data.y.reshape(-1) - 1, weight=cw, ignore_index=-1)
         loss.backward()
-        bucket.allreduce_mean()
+        torch._foreach_copy_(bucket.views, [p.grad for p in bucket.params])
+        return loss.detach()
+
+    def part_b():
+        for p, v in zip(bucket.params, bucket.views):
+            p.grad = v
         opt.step()
+
+    def collective():
+        if world > 1:
+            torch.distributed.all_reduce(bucket.flat, op=torch.distributed.ReduceOp.SUM)
+            bucket.flat.div_(world)
+
+    def step():
+        loss = part_a()
+        collective()
+        part_b()
         return loss
 
     def barrier():
@@ -168,8 +192,6 @@ def main():
 
     graph_note = 'eager'
     if args.graph:
-        # Capture the whole training step (fwd + loss + bwd [+ all-reduce] + SGD) into one hipGraph: the step
-        # issues ~2000 small launches, which would otherwise leave the GPU waiting on the Python host.
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -178,19 +200,22 @@ def main():
                     step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                static_loss = step()
-            eager_step = step
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                static_loss = part_a()
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                part_b()
 
             def step():                                   # noqa: F811
-                g.replay()
+                ga.replay()
+                collective()
+                gb.replay()
                 return static_loss
-            graph_note = 'hipGraph replay of the captured step'
+            graph_note = 'hipGraph replay (fwd+loss+bwd | eager RCCL all-reduce | SGD step)'
         except Exception as e:                            # capture not possible: stay eager, say so
-            torch.cuda.synchronize()
             import traceback
             traceback.print_exc()
+            torch.cuda.synchronize()
             graph_note = 'eager (graph capture failed: %s)' % str(e).splitlines()[0][:120]
     for _ in range(args.warmup):
         step()
@@ -216,8 +241,8 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: S3DIS-like synthetic clouds (one point per 4 cm voxel of an '
                                    '8x8x3 m box), %d clouds x %d pts per GPU, K=16, ratios [4,4,4,4,2], '
                                    'PointConvBig(in=6, classes=13, use_crf, steps=%d), train mode: fwd + weighted CE + '
-                                   'bwd + flat-bucket grad all-reduce + SGD(momentum) step; tables resident in HBM'
-                                   % (B, N, T),
+                                   'bwd + flat-bucket grad all-reduce + SGD(momentum) step; tables resident in HBM; point order from '
+                                   'the device collate: %s' % (B, N, T, args.sort),
                        'global_batch': world * B, 'points_per_cloud': N, 'parallelism': 'dp%d (batch-sharded)' % world},
             'final_loss': float(loss),
             'preprocess_ms_per_batch': t_pre * 1e3,
