@@ -1,7 +1,9 @@
-"""Dense PointConv encoder + CRF decoder -- drop-in for the reference network
-(models/point_conv_big.py:8-167): same class names, constructor arguments, forward(data)
-contract and state_dict keys, with the gather / weight-MLP / reduce chain fused into gfx950
-kernels (crfconv_amd/csrc/pointconv.hip)."""
+"""Dense PointConv encoder + CRF decoder on gfx950 kernels.
+
+Drop-in for the reference network (models/point_conv_big.py:8-167): class names, constructor
+arguments, the forward(data) contract and every state_dict key are the reference's; the gather /
+weight-MLP / reduce chain of each convolution is one family of fused kernels
+(crfconv_amd/csrc/pointconv.hip) instead of materialised [B, N, K, d] tensors."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -11,125 +13,117 @@ from ..graph import table_of
 from .common import MLP, Base
 from .continuous_crf_conv_big import ContinuousGaussianCRFConv as CRFConv
 
+WIDTHS = (32, 64, 128, 256, 512)          # channel width of encoder level 0..4 (reference :113)
+
+
+def _lrelu():
+    return nn.LeakyReLU(negative_slope=0.1)
+
+
+def _flat(t):
+    return t.reshape(-1, t.shape[-1])
+
 
 class PointConv(nn.Module):
-    """Depth-wise point convolution: out_i = sum_k weight_nn(p_i - p_j) * x_j
-    (models/point_conv_big.py:8-58).  `weight_nn` keeps the reference's module layout so
-    checkpoints load, but is never materialised per edge."""
+    """out_i = sum_k weight_nn(p_i - p_j) * x_j, depth-wise (reference :8-58).
+
+    `weight_nn` exists for its parameters (checkpoint layout: weight_nn.{0,1}.lin / .bn.batch_norm);
+    the per-edge MLP is evaluated inside the kernels and never stored."""
 
     def __init__(self, d_model):
-        super(PointConv, self).__init__()
-        self.weight_nn = nn.Sequential(MLP(3, d_model, activation=nn.LeakyReLU(negative_slope=0.1)),
-                                       MLP(d_model, d_model, activation=None))
+        super().__init__()
+        self.weight_nn = nn.Sequential(MLP(3, d_model, activation=_lrelu()), MLP(d_model, d_model, activation=None))
+
+    def _moments(self, table, p_src, p_tgt):
+        key = ('moments', p_src.data_ptr(), p_tgt.data_ptr())
+        if key not in table.cache:
+            table.cache[key] = ops.relpos_moments(p_src.float().contiguous(), p_tgt.float().contiguous(), table)
+        return table.cache[key]
 
     def forward(self, x, pos, neighbor_idx):
-        if torch.is_tensor(pos):
-            src, tgt = pos, pos
-        else:
-            src, tgt = pos
-        B, d = x.shape[0], x.shape[-1]
+        strided = not torch.is_tensor(pos)
+        src = pos[0] if strided else pos
+        p_src = _flat(src)
+        p_tgt = _flat(pos[1]) if strided else p_src
         table = table_of(neighbor_idx, src.shape[1])
-        p_src = src.reshape(-1, 3)
-        p_tgt = p_src if tgt is src else tgt.reshape(-1, 3)
-        key = ('moments', p_src.data_ptr(), p_tgt.data_ptr())
-        moments = table.cache.get(key)
-        if moments is None:
-            moments = ops.relpos_moments(p_src.float().contiguous(), p_tgt.float().contiguous(), table)
-            table.cache[key] = moments
-        l0, l1 = self.weight_nn[0], self.weight_nn[1]
-        out = ops.point_conv(x.reshape(-1, d), p_src, p_tgt, table, l0.lin.weight, l0.bn.batch_norm,
-                             l1.lin.weight, l1.bn.batch_norm, self.training, moments=moments)
-        return out.reshape(B, -1, d)
+        first, second = self.weight_nn[0], self.weight_nn[1]
+        y = ops.point_conv(_flat(x), p_src, p_tgt, table, first.lin.weight, first.bn.batch_norm, second.lin.weight,
+                           second.bn.batch_norm, self.training, moments=self._moments(table, p_src, p_tgt))
+        return y.reshape(x.shape[0], -1, x.shape[-1])
 
 
 class ResNetBBlock(nn.Module):
+    """Bottleneck: lin_in -> PointConv -> lin_out, plus (max-pooled) shortcut (reference :61-88)."""
+
     def __init__(self, in_channels, out_channels):
-        super(ResNetBBlock, self).__init__()
-        hidden_channels = out_channels // 4
-        self.lin_in = MLP(in_channels, hidden_channels, activation=nn.LeakyReLU(negative_slope=0.1))
-        self.lin_out = MLP(hidden_channels, out_channels, activation=None)
-        if in_channels != out_channels:
-            self.shortcut = MLP(in_channels, out_channels, activation=None)
-        else:
-            self.shortcut = nn.Identity()
-        self.point_conv = PointConv(hidden_channels)
+        super().__init__()
+        mid = out_channels // 4
+        self.lin_in = MLP(in_channels, mid, activation=_lrelu())
+        self.lin_out = MLP(mid, out_channels, activation=None)
+        self.shortcut = MLP(in_channels, out_channels, activation=None) if in_channels != out_channels else nn.Identity()
+        self.point_conv = PointConv(mid)
 
     @staticmethod
     def max_pooling(x, idx):
-        B, C = x.shape[0], x.shape[-1]
-        return ops.neighbor_maxpool(x.reshape(-1, C), table_of(idx, x.shape[1])).reshape(B, -1, C)
+        pooled = ops.neighbor_maxpool(_flat(x), table_of(idx, x.shape[1]))
+        return pooled.reshape(x.shape[0], -1, x.shape[-1])
 
     def forward(self, x, pos, neighbor_idx):
-        residual = self.shortcut(x)
-        if not torch.is_tensor(pos):
-            residual = self.max_pooling(residual, neighbor_idx)
-        x = self.lin_in(x)
-        x = self.point_conv(x, pos, neighbor_idx)
-        x = self.lin_out(x)
-        return F.leaky_relu(x + residual)
+        skip = self.shortcut(x)
+        if not torch.is_tensor(pos):                       # strided block: pool the shortcut onto the coarse points
+            skip = self.max_pooling(skip, neighbor_idx)
+        y = self.lin_out(self.point_conv(self.lin_in(x), pos, neighbor_idx))
+        return F.leaky_relu(y + skip)                      # default slope 0.01, as the reference
 
 
 class Upsampling(nn.Module):
+    """Non-CRF decoder stage (reference :91-107): nearest up-sampling, MLP, fusion with the skip feature."""
+
     def __init__(self, down_channels, up_channels, out_channels):
-        super(Upsampling, self).__init__()
-        self.lin = MLP(down_channels, up_channels, activation=nn.LeakyReLU(negative_slope=0.1))
-        self.fusion = MLP(up_channels * 2, out_channels, activation=nn.LeakyReLU(negative_slope=0.1))
+        super().__init__()
+        self.lin = MLP(down_channels, up_channels, activation=_lrelu())
+        self.fusion = MLP(up_channels * 2, out_channels, activation=_lrelu())
 
     @staticmethod
     def upsampling(x, idx):
-        B, C = x.shape[0], x.shape[-1]
-        return ops.gather_rows(x.reshape(-1, C), table_of(idx, x.shape[1])).reshape(B, -1, C)
+        up = ops.gather_rows(_flat(x), table_of(idx, x.shape[1]))
+        return up.reshape(x.shape[0], -1, x.shape[-1])
 
     def forward(self, x_down, x_up, up_idx, neighbor_idx=None):
-        x_down = self.upsampling(x_down, up_idx)
-        x_down = self.lin(x_down)
-        return self.fusion(torch.cat([x_up, x_down], dim=-1))
+        return self.fusion(torch.cat([x_up, self.lin(self.upsampling(x_down, up_idx))], dim=-1))
 
 
 class PointConvResNet(Base):
+    """Five encoder levels of two ResNet blocks (conv{l}_1 changes level / width, conv{l}_2 refines), four decoder
+    stages deconv4..deconv1 (CRF mean-field layers, or plain Upsampling), per-point classifier (reference :110-167)."""
+
     def __init__(self, in_channels, n_classes, use_crf=True, steps=1):
-        super(PointConvResNet, self).__init__()
-        layers = [32, 64, 128, 256, 512]
+        super().__init__()
         self.C = n_classes
-        self.conv1_1 = ResNetBBlock(in_channels, layers[0])
-        self.conv1_2 = ResNetBBlock(layers[0], layers[0])
-        self.conv2_1 = ResNetBBlock(layers[0], layers[1])
-        self.conv2_2 = ResNetBBlock(layers[1], layers[1])
-        self.conv3_1 = ResNetBBlock(layers[1], layers[2])
-        self.conv3_2 = ResNetBBlock(layers[2], layers[2])
-        self.conv4_1 = ResNetBBlock(layers[2], layers[3])
-        self.conv4_2 = ResNetBBlock(layers[3], layers[3])
-        self.conv5_1 = ResNetBBlock(layers[3], layers[4])
-        self.conv5_2 = ResNetBBlock(layers[4], layers[4])
-
-        def dec(down, up):
-            return CRFConv(down, up, up, steps=steps) if use_crf else Upsampling(down, up, up)
-
-        self.deconv4 = dec(layers[4], layers[3])
-        self.deconv3 = dec(layers[3], layers[2])
-        self.deconv2 = dec(layers[2], layers[1])
-        self.deconv1 = dec(layers[1], layers[0])
-        self.classifier = nn.Sequential(
-            MLP(layers[0], layers[0] * 4, activation=nn.LeakyReLU(negative_slope=0.1)),
-            nn.Dropout(p=0.5),
-            nn.Linear(layers[0] * 4, n_classes))
+        cin = in_channels
+        for lvl, width in enumerate(WIDTHS, start=1):
+            setattr(self, 'conv%d_1' % lvl, ResNetBBlock(cin, width))
+            setattr(self, 'conv%d_2' % lvl, ResNetBBlock(width, width))
+            cin = width
+        for lvl in range(len(WIDTHS) - 1, 0, -1):          # deconv4 .. deconv1
+            coarse, fine = WIDTHS[lvl], WIDTHS[lvl - 1]
+            stage = CRFConv(coarse, fine, fine, steps=steps) if use_crf else Upsampling(coarse, fine, fine)
+            setattr(self, 'deconv%d' % lvl, stage)
+        self.classifier = nn.Sequential(MLP(WIDTHS[0], WIDTHS[0] * 4, activation=_lrelu()), nn.Dropout(p=0.5),
+                                        nn.Linear(WIDTHS[0] * 4, n_classes))
 
     def forward(self, data):
-        x, ms = data.x, data.multiscale
-        x1 = self.conv1_1(x, ms[0].pos, ms[0].neighbor_idx)
-        x1 = self.conv1_2(x1, ms[0].pos, ms[0].neighbor_idx)
-        x2 = self.conv2_1(x1, (ms[0].pos, ms[1].pos), ms[0].sub_idx)
-        x2 = self.conv2_2(x2, ms[1].pos, ms[1].neighbor_idx)
-        x3 = self.conv3_1(x2, (ms[1].pos, ms[2].pos), ms[1].sub_idx)
-        x3 = self.conv3_2(x3, ms[2].pos, ms[2].neighbor_idx)
-        x4 = self.conv4_1(x3, (ms[2].pos, ms[3].pos), ms[2].sub_idx)
-        x4 = self.conv4_2(x4, ms[3].pos, ms[3].neighbor_idx)
-        x = self.conv5_1(x4, (ms[3].pos, ms[4].pos), ms[3].sub_idx)
-        x = self.conv5_2(x, ms[4].pos, ms[4].neighbor_idx)
-        x = self.deconv4(x, x4, ms[3].up_idx, ms[3].neighbor_idx)
-        x = self.deconv3(x, x3, ms[2].up_idx, ms[2].neighbor_idx)
-        x = self.deconv2(x, x2, ms[1].up_idx, ms[1].neighbor_idx)
-        x = self.deconv1(x, x1, ms[0].up_idx, ms[0].neighbor_idx)
-        x = self.classifier[1](self.classifier[0](x))
-        x = ops.linear(x, self.classifier[2].weight, self.classifier[2].bias)
-        return x.reshape(-1, self.C)
+        ms = data.multiscale
+        h = getattr(self, 'conv1_1')(data.x, ms[0].pos, ms[0].neighbor_idx)
+        h = getattr(self, 'conv1_2')(h, ms[0].pos, ms[0].neighbor_idx)
+        skips = [h]
+        for lvl in range(1, len(WIDTHS)):
+            fine, coarse = ms[lvl - 1], ms[lvl]
+            h = getattr(self, 'conv%d_1' % (lvl + 1))(h, (fine.pos, coarse.pos), fine.sub_idx)
+            h = getattr(self, 'conv%d_2' % (lvl + 1))(h, coarse.pos, coarse.neighbor_idx)
+            skips.append(h)
+        for lvl in range(len(WIDTHS) - 2, -1, -1):
+            h = getattr(self, 'deconv%d' % (lvl + 1))(h, skips[lvl], ms[lvl].up_idx, ms[lvl].neighbor_idx)
+        h = self.classifier[1](self.classifier[0](h))
+        h = ops.linear(h, self.classifier[2].weight, self.classifier[2].bias)
+        return h.reshape(-1, self.C)
