@@ -21,6 +21,7 @@ SIGNATURES = {
     'crfconv_knn_batch_omp': (_i, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp]),
     'crfconv_knn_batch_dev_workspace': (_sz, [_sz, _sz, _sz, _sz]),
     'crfconv_knn_batch_dev': (_i, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_fps': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'crfconv_grid_subsample': (_i64, [_vp, _i64, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _i64]),
     'crfconv_grid_subsample_dev_workspace': (_sz, [_i64, _i, _i]),
     'crfconv_grid_subsample_dev': (_i64, [_vp, _i64, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),

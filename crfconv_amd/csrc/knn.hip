@@ -362,3 +362,70 @@ extern "C" int crfconv_knn_batch_omp(const float* batch_data, size_t batch_size,
                                      const float* queries, size_t nqueries, size_t K, long* batch_indices) {
     return knn_host(batch_data, batch_size, npts, dim, queries, nqueries, K, batch_indices);
 }
+
+// ------------------------------------------------------------------ farthest point sampling
+// torch_cluster.fps as used by the reference's sparse graph builder (models/point_conv.py:381).  Inherently
+// sequential in the number of samples; one 1024-thread workgroup per cloud keeps the running min-distance
+// array in global memory (L2-resident) and does min-update + argmax (ties -> lower index) per iteration.
+namespace crf {
+__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ pos, const int64_t* __restrict__ seg_start,
+                                                   const int64_t* __restrict__ seg_count,
+                                                   const int64_t* __restrict__ out_start,
+                                                   const int64_t* __restrict__ n_sample,
+                                                   const int64_t* __restrict__ first, float* __restrict__ dist,
+                                                   int64_t* __restrict__ out) {
+    const int c = blockIdx.x;
+    const int64_t s0 = seg_start[c], n = seg_count[c], m = n_sample[c];
+    const float* p = pos + 3 * s0;
+    float* d = dist + s0;
+    int64_t* o = out + out_start[c];
+    __shared__ float sval[16];
+    __shared__ int sidx[16];
+    __shared__ int scur;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) d[i] = 3.4e38f;
+    if (threadIdx.x == 0) scur = (int)first[c];
+    __syncthreads();
+    for (int64_t t = 0; t < m; ++t) {
+        const int cur = scur;
+        if (threadIdx.x == 0) o[t] = s0 + cur;
+        const float cx = p[3 * cur], cy = p[3 * cur + 1], cz = p[3 * cur + 2];
+        float best = -1.f;
+        int bi = 0x7fffffff;
+        for (int64_t i = threadIdx.x; i < n; i += 1024) {
+            const float dx = p[3 * i] - cx, dy = p[3 * i + 1] - cy, dz = p[3 * i + 2] - cz;
+            const float dd = fminf(d[i], dx * dx + dy * dy + dz * dz);
+            d[i] = dd;
+            if (dd > best) { best = dd; bi = (int)i; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best, off, WAVE);
+            const int oi = __shfl_xor(bi, off, WAVE);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();                                   // scur consumed by everyone
+        if (lane == 0) { sval[wave] = best; sidx[wave] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float bv = sval[0];
+            int bj = sidx[0];
+            for (int w = 1; w < 16; ++w)
+                if (sval[w] > bv || (sval[w] == bv && sidx[w] < bj)) { bv = sval[w]; bj = sidx[w]; }
+            scur = bj;
+        }
+        __syncthreads();
+    }
+}
+}  // namespace crf
+
+extern "C" int crfconv_fps(const float* pos, int n_clouds, const int64_t* seg_start, const int64_t* seg_count,
+                           const int64_t* out_start, const int64_t* n_sample, const int64_t* first, float* dist_ws,
+                           int64_t* out, crf_stream_t stream) {
+    CRF_REQUIRE(pos && seg_start && seg_count && out_start && n_sample && first && dist_ws && out, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(n_clouds >= 1 && n_clouds <= 65535, CRF_ERR_ARG, "n_clouds=%d out of range", n_clouds);
+    hipLaunchKernelGGL(crf::fps_kernel, dim3(n_clouds), dim3(1024), 0, crf::as_stream(stream), pos, seg_start, seg_count,
+                       out_start, n_sample, first, dist_ws, out);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}

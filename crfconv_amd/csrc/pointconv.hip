@@ -22,6 +22,12 @@ struct PC {
     static constexpr int PPW = WAVE / L;
     static constexpr int PPB = PPW * PWAVES;
     static constexpr bool W2_IN_REGS = (D <= 16);
+    // Wide layers evaluate layer 2 for EB = 4 edges at a time: each W2^T row fetched from LDS then feeds 16 FMAs
+    // per lane instead of 4, and h1 is exchanged through a per-wave LDS scratch (broadcast reads) instead of
+    // one cross-lane shuffle per input channel -- the d x d product becomes VALU-bound instead of LDS-bound.
+    static constexpr int EB = (D >= 32) ? 4 : 1;
+    static constexpr int SCR_STRIDE = EB * L + 1;                 // float4 units per point (+1: bank spread)
+    static constexpr int SCR_SIZE = EB > 1 ? PWAVES * PPW * SCR_STRIDE : 1;
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
@@ -94,6 +100,39 @@ struct EdgeMLP {
             }
         }
         return acc;
+    }
+
+    // h2[e] = W2 h1[e] for EB edges of this lane's point at once (scratch: PC<D>::SCR_SIZE float4 in LDS)
+    __device__ __forceinline__ void layer2_batch(const float4 (&h1)[PC<D>::EB], float4 (&h2)[PC<D>::EB],
+                                                 float4* scratch) const {
+        constexpr int EB = PC<D>::EB;
+        if constexpr (EB == 1) {
+            h2[0] = layer2(h1[0]);
+        } else {
+            const int wave = threadIdx.x >> 6, pl = lane / L;
+            float4* mine = scratch + (wave * PC<D>::PPW + pl) * PC<D>::SCR_STRIDE;
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                mine[e * L + q] = h1[e];
+                h2[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            // same-wave LDS traffic is processed in order: the reads below see the writes above
+#pragma unroll 2
+            for (int cq = 0; cq < L; ++cq) {
+                float4 hv[EB];
+#pragma unroll
+                for (int e = 0; e < EB; ++e) hv[e] = mine[e * L + cq];
+                const float4 w0 = w2t_lds[(4 * cq + 0) * L + q], w1 = w2t_lds[(4 * cq + 1) * L + q];
+                const float4 w2 = w2t_lds[(4 * cq + 2) * L + q], w3 = w2t_lds[(4 * cq + 3) * L + q];
+#pragma unroll
+                for (int e = 0; e < EB; ++e) {
+                    h2[e] = fma4(hv[e].x, w0, h2[e]);
+                    h2[e] = fma4(hv[e].y, w1, h2[e]);
+                    h2[e] = fma4(hv[e].z, w2, h2[e]);
+                    h2[e] = fma4(hv[e].w, w3, h2[e]);
+                }
+            }
+        }
     }
 
     __device__ __forceinline__ float4 h2_of(float rx, float ry, float rz) const {
@@ -224,7 +263,9 @@ __global__ __launch_bounds__(PBLOCK) void stats_kernel(const float* __restrict__
                                                        const float* __restrict__ mean_rel,
                                                        float* __restrict__ shift_out,
                                                        float* __restrict__ partial) {
+    constexpr int EB = PC<D>::EB;
     __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     __shared__ float sred[PWAVES * 2 * D];
     int lane, wave, q;
     const Row rw = my_row<D>(m_tgt, lane, wave, q);
@@ -237,16 +278,26 @@ __global__ __launch_bounds__(PBLOCK) void stats_kernel(const float* __restrict__
     const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
     const int32_t* irow = idx + rw.r * K;
     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    for (int k = 0; k < K; ++k) {
-        const int jj = irow[k];
-        const int64_t j = jj < 0 ? 0 : jj;
-        const float live = (rw.valid && jj >= 0) ? 1.f : 0.f;
-        const float4 h2 = mlp.h2_of(px - pos_src[3 * j], py - pos_src[3 * j + 1], pz - pos_src[3 * j + 2]);
-        const float4 dlt = make_float4((h2.x - shift.x) * live, (h2.y - shift.y) * live,
-                                       (h2.z - shift.z) * live, (h2.w - shift.w) * live);
-        acc[0].x += dlt.x; acc[0].y += dlt.y; acc[0].z += dlt.z; acc[0].w += dlt.w;
-        acc[1] = make_float4(fmaf(dlt.x, dlt.x, acc[1].x), fmaf(dlt.y, dlt.y, acc[1].y),
-                             fmaf(dlt.z, dlt.z, acc[1].z), fmaf(dlt.w, dlt.w, acc[1].w));
+    for (int k0 = 0; k0 < K; k0 += EB) {
+        float4 h1[EB], h2[EB];
+        float live[EB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int jj = (k0 + e < K) ? irow[k0 + e] : -1;
+            const int64_t j = jj < 0 ? 0 : jj;
+            live[e] = (rw.valid && jj >= 0) ? 1.f : 0.f;
+            float4 pre;
+            mlp.layer1(px - pos_src[3 * j], py - pos_src[3 * j + 1], pz - pos_src[3 * j + 2], pre, h1[e]);
+        }
+        mlp.layer2_batch(h1, h2, s_scr);
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const float4 dlt = make_float4((h2[e].x - shift.x) * live[e], (h2[e].y - shift.y) * live[e],
+                                           (h2[e].z - shift.z) * live[e], (h2[e].w - shift.w) * live[e]);
+            acc[0].x += dlt.x; acc[0].y += dlt.y; acc[0].z += dlt.z; acc[0].w += dlt.w;
+            acc[1] = make_float4(fmaf(dlt.x, dlt.x, acc[1].x), fmaf(dlt.y, dlt.y, acc[1].y),
+                                 fmaf(dlt.z, dlt.z, acc[1].z), fmaf(dlt.w, dlt.w, acc[1].w));
+        }
     }
     block_reduce_store<D, 2>(acc, sred, partial, lane, wave, q);
 }
@@ -263,7 +314,9 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
                                                          const float* __restrict__ a2,
                                                          const float* __restrict__ b2,
                                                          float* __restrict__ out) {
+    constexpr int EB = PC<D>::EB;
     __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     int lane, wave, q;
     const Row rw = my_row<D>(m_tgt, lane, wave, q);
     EdgeMLP<D> mlp;
@@ -274,16 +327,25 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
     const int32_t* irow = idx + rw.r * K;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 2
-    for (int k = 0; k < K; ++k) {
-        const int jj = irow[k];
-        const int64_t j = jj < 0 ? 0 : jj;
-        float4 xj = ld4(x + j * D + 4 * q);
-        if (jj < 0) xj = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 h2 = mlp.h2_of(px - pos_src[3 * j], py - pos_src[3 * j + 1], pz - pos_src[3 * j + 2]);
-        acc.x = fmaf(fmaf(sa.x, h2.x, sb.x), xj.x, acc.x);
-        acc.y = fmaf(fmaf(sa.y, h2.y, sb.y), xj.y, acc.y);
-        acc.z = fmaf(fmaf(sa.z, h2.z, sb.z), xj.z, acc.z);
-        acc.w = fmaf(fmaf(sa.w, h2.w, sb.w), xj.w, acc.w);
+    for (int k0 = 0; k0 < K; k0 += EB) {
+        float4 h1[EB], h2[EB], xj[EB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int jj = (k0 + e < K) ? irow[k0 + e] : -1;
+            const int64_t j = jj < 0 ? 0 : jj;
+            xj[e] = ld4(x + j * D + 4 * q);
+            if (jj < 0) xj[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 pre;
+            mlp.layer1(px - pos_src[3 * j], py - pos_src[3 * j + 1], pz - pos_src[3 * j + 2], pre, h1[e]);
+        }
+        mlp.layer2_batch(h1, h2, s_scr);
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            acc.x = fmaf(fmaf(sa.x, h2[e].x, sb.x), xj[e].x, acc.x);
+            acc.y = fmaf(fmaf(sa.y, h2[e].y, sb.y), xj[e].y, acc.y);
+            acc.z = fmaf(fmaf(sa.z, h2[e].z, sb.z), xj[e].z, acc.z);
+            acc.w = fmaf(fmaf(sa.w, h2[e].w, sb.w), xj[e].w, acc.w);
+        }
     }
     if (rw.valid) st4(out + rw.r * D + 4 * q, acc);
 }
@@ -300,7 +362,9 @@ __global__ __launch_bounds__(PBLOCK) void bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ W2, float slope,
                                                             const float* __restrict__ shift_p,
                                                             float* __restrict__ partial) {
+    constexpr int EB = PC<D>::EB;
     __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     __shared__ float sred[PWAVES * 2 * D];
     int lane, wave, q;
     const Row rw = my_row<D>(m_tgt, lane, wave, q);
@@ -313,16 +377,25 @@ __global__ __launch_bounds__(PBLOCK) void bwd_reduce_kernel(const float* __restr
     float4 g = ld4(gout + rw.r * D + 4 * q);
     if (!rw.valid) g = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    for (int k = 0; k < K; ++k) {
-        const int jj = irow[k];
-        const int64_t j = jj < 0 ? 0 : jj;
-        float4 xj = ld4(x + j * D + 4 * q);
-        if (jj < 0) xj = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 h2 = mlp.h2_of(px - pos_src[3 * j], py - pos_src[3 * j + 1], pz - pos_src[3 * j + 2]);
-        const float4 gw = make_float4(g.x * xj.x, g.y * xj.y, g.z * xj.z, g.w * xj.w);
-        acc[0].x += gw.x; acc[0].y += gw.y; acc[0].z += gw.z; acc[0].w += gw.w;
-        acc[1] = make_float4(fmaf(gw.x, h2.x - shift.x, acc[1].x), fmaf(gw.y, h2.y - shift.y, acc[1].y),
-                             fmaf(gw.z, h2.z - shift.z, acc[1].z), fmaf(gw.w, h2.w - shift.w, acc[1].w));
+    for (int k0 = 0; k0 < K; k0 += EB) {
+        float4 h1[EB], h2[EB], xj[EB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int jj = (k0 + e < K) ? irow[k0 + e] : -1;
+            const int64_t j = jj < 0 ? 0 : jj;
+            xj[e] = ld4(x + j * D + 4 * q);
+            if (jj < 0) xj[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 pre;
+            mlp.layer1(px - pos_src[3 * j], py - pos_src[3 * j + 1], pz - pos_src[3 * j + 2], pre, h1[e]);
+        }
+        mlp.layer2_batch(h1, h2, s_scr);
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const float4 gw = make_float4(g.x * xj[e].x, g.y * xj[e].y, g.z * xj[e].z, g.w * xj[e].w);
+            acc[0].x += gw.x; acc[0].y += gw.y; acc[0].z += gw.z; acc[0].w += gw.w;
+            acc[1] = make_float4(fmaf(gw.x, h2[e].x - shift.x, acc[1].x), fmaf(gw.y, h2[e].y - shift.y, acc[1].y),
+                                 fmaf(gw.z, h2[e].z - shift.z, acc[1].z), fmaf(gw.w, h2[e].w - shift.w, acc[1].w));
+        }
     }
     block_reduce_store<D, 2>(acc, sred, partial, lane, wave, q);
 }
@@ -496,7 +569,9 @@ __global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restric
                                                           float* __restrict__ h1_out,
                                                           float* __restrict__ gh2_out,
                                                           float* __restrict__ rel_out) {
+    constexpr int EB = PC<D>::EB;
     __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     int lane, wave, q;
     const Row rw = my_row<D>(m_tgt, lane, wave, q);
     EdgeMLP<D> mlp;
@@ -506,26 +581,38 @@ __global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restric
     const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
     const int32_t* irow = idx + rw.r * K;
     const float4 g = ld4(gout + rw.r * D + 4 * q);
-    for (int k = 0; k < K; ++k) {
-        const int jj = irow[k];
-        const bool have = jj >= 0;
-        const int64_t j = have ? jj : 0;
-        const float4 xj = ld4(x + j * D + 4 * q);
-        const float rx = px - pos_src[3 * j], ry = py - pos_src[3 * j + 1], rz = pz - pos_src[3 * j + 2];
-        float4 pre, h1;
-        mlp.layer1(rx, ry, rz, pre, h1);
-        const float4 h2 = mlp.layer2(h1);
-        float4 gh2;
-        gh2.x = fmaf(va.x, g.x * xj.x, fmaf(vb.x, h2.x, vc.x));
-        gh2.y = fmaf(va.y, g.y * xj.y, fmaf(vb.y, h2.y, vc.y));
-        gh2.z = fmaf(va.z, g.z * xj.z, fmaf(vb.z, h2.z, vc.z));
-        gh2.w = fmaf(va.w, g.w * xj.w, fmaf(vb.w, h2.w, vc.w));
-        if (rw.valid) {
-            const int64_t e = rw.r * K + k;
-            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-            st4(h1_out + e * D + 4 * q, have ? h1 : zero);
-            st4(gh2_out + e * D + 4 * q, have ? gh2 : zero);
-            if (q == 0) { rel_out[3 * e] = have ? rx : 0.f; rel_out[3 * e + 1] = have ? ry : 0.f; rel_out[3 * e + 2] = have ? rz : 0.f; }
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = 0; k0 < K; k0 += EB) {
+        float4 h1[EB], h2[EB], xj[EB];
+        float rx[EB], ry[EB], rz[EB];
+        bool have[EB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int jj = (k0 + e < K) ? irow[k0 + e] : -1;
+            have[e] = jj >= 0;
+            const int64_t j = have[e] ? jj : 0;
+            xj[e] = ld4(x + j * D + 4 * q);
+            rx[e] = px - pos_src[3 * j]; ry[e] = py - pos_src[3 * j + 1]; rz[e] = pz - pos_src[3 * j + 2];
+            float4 pre;
+            mlp.layer1(rx[e], ry[e], rz[e], pre, h1[e]);
+        }
+        mlp.layer2_batch(h1, h2, s_scr);
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            if (k0 + e >= K || !rw.valid) continue;
+            float4 gh2;
+            gh2.x = fmaf(va.x, g.x * xj[e].x, fmaf(vb.x, h2[e].x, vc.x));
+            gh2.y = fmaf(va.y, g.y * xj[e].y, fmaf(vb.y, h2[e].y, vc.y));
+            gh2.z = fmaf(va.z, g.z * xj[e].z, fmaf(vb.z, h2[e].z, vc.z));
+            gh2.w = fmaf(va.w, g.w * xj[e].w, fmaf(vb.w, h2[e].w, vc.w));
+            const int64_t eid = rw.r * K + k0 + e;
+            st4(h1_out + eid * D + 4 * q, have[e] ? h1[e] : zero);
+            st4(gh2_out + eid * D + 4 * q, have[e] ? gh2 : zero);
+            if (q == 0) {
+                rel_out[3 * eid] = have[e] ? rx[e] : 0.f;
+                rel_out[3 * eid + 1] = have[e] ? ry[e] : 0.f;
+                rel_out[3 * eid + 2] = have[e] ? rz[e] : 0.f;
+            }
         }
     }
 }
@@ -543,7 +630,9 @@ __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restri
                                                            const float* __restrict__ a2,
                                                            const float* __restrict__ b2,
                                                            float* __restrict__ dx) {
+    constexpr int EB = PC<D>::EB;
     __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     int lane, wave, q;
     const Row rw = my_row<D>(m_src, lane, wave, q);
     EdgeMLP<D> mlp;
@@ -553,26 +642,34 @@ __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restri
     const float sx = pos_src[3 * rw.r], sy = pos_src[3 * rw.r + 1], sz = pos_src[3 * rw.r + 2];
     const int beg = rev_ptr[rw.r];
     const int deg = rw.valid ? rev_ptr[rw.r + 1] - beg : 0;
-    int degmax = deg;  // uniform trip count: the MLP shuffles need every lane of a group active
+    int degmax = deg;  // uniform trip count: the MLP exchange needs every lane of a group active
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) degmax = max(degmax, __shfl_xor(degmax, o, WAVE));
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = 0; p < degmax; ++p) {
-        const bool act = p < deg;
-        float rx = 0.f, ry = 0.f, rz = 0.f;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act) {
-            const int64_t i = rev_eid[beg + p] / K;
-            rx = pos_tgt[3 * i] - sx;
-            ry = pos_tgt[3 * i + 1] - sy;
-            rz = pos_tgt[3 * i + 2] - sz;
-            g = ld4(gout + i * D + 4 * q);
+    for (int p0 = 0; p0 < degmax; p0 += EB) {
+        float4 h1[EB], h2[EB], g[EB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            float rx = 0.f, ry = 0.f, rz = 0.f;
+            g[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + e < deg) {
+                const int64_t i = rev_eid[beg + p0 + e] / K;
+                rx = pos_tgt[3 * i] - sx;
+                ry = pos_tgt[3 * i + 1] - sy;
+                rz = pos_tgt[3 * i + 2] - sz;
+                g[e] = ld4(gout + i * D + 4 * q);
+            }
+            float4 pre;
+            mlp.layer1(rx, ry, rz, pre, h1[e]);
         }
-        const float4 h2 = mlp.h2_of(rx, ry, rz);
-        acc.x = fmaf(fmaf(sa.x, h2.x, sb.x), g.x, acc.x);  // g == 0 on inactive lanes
-        acc.y = fmaf(fmaf(sa.y, h2.y, sb.y), g.y, acc.y);
-        acc.z = fmaf(fmaf(sa.z, h2.z, sb.z), g.z, acc.z);
-        acc.w = fmaf(fmaf(sa.w, h2.w, sb.w), g.w, acc.w);
+        mlp.layer2_batch(h1, h2, s_scr);
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            acc.x = fmaf(fmaf(sa.x, h2[e].x, sb.x), g[e].x, acc.x);  // g == 0 on inactive slots
+            acc.y = fmaf(fmaf(sa.y, h2[e].y, sb.y), g[e].y, acc.y);
+            acc.z = fmaf(fmaf(sa.z, h2[e].z, sb.z), g[e].z, acc.z);
+            acc.w = fmaf(fmaf(sa.w, h2[e].w, sb.w), g[e].w, acc.w);
+        }
     }
     if (rw.valid) st4(dx + rw.r * D + 4 * q, acc);
 }
@@ -702,7 +799,7 @@ extern "C" int crfconv_pointconv_bwd_params(const float* x, const float* gout, c
     if (int rc = check_pc(m_tgt, K, d)) return rc;
     CRF_REQUIRE(x && gout && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && ca && cb && cc && dW2 && dA1b1 &&
                     workspace, CRF_ERR_ARG, "null pointer");
-    CRF_REQUIRE(d <= 32, CRF_ERR_UNSUPPORTED, "in-kernel parameter reduction covers d <= 32; use crfconv_pointconv_bwd_dump for d=%d", d);
+    CRF_REQUIRE(d <= 16, CRF_ERR_UNSUPPORTED, "in-kernel parameter reduction covers d <= 16; use crfconv_pointconv_bwd_dump for d=%d", d);
     const int64_t nblk = blocks_for(m_tgt, d);
     const size_t fbytes = (sizeof(float) * (size_t)d * d * (size_t)nblk + 255) & ~(size_t)255;
     const size_t dbytes = sizeof(double) * 4 * (size_t)d * (size_t)nblk;
@@ -714,8 +811,7 @@ extern "C" int crfconv_pointconv_bwd_params(const float* x, const float* gout, c
     switch (d) {
         case 4: hipLaunchKernelGGL(bwd_params_kernel<4>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, partial, partial_d); break;
         case 8: hipLaunchKernelGGL(bwd_params_kernel<8>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, partial, partial_d); break;
-        case 16: hipLaunchKernelGGL(bwd_params_kernel<16>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, partial, partial_d); break;
-        default: hipLaunchKernelGGL(bwd_params_kernel<32>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, partial, partial_d); break;
+        default: hipLaunchKernelGGL(bwd_params_kernel<16>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, partial, partial_d); break;
     }
     CRF_LAUNCH_CHECK();
     if (int rc = reduce_partials(partial, nblk, d * d, dW2, st)) return rc;

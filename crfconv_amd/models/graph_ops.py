@@ -64,20 +64,29 @@ def radius_graph(pos, r, batch=None, loop=False, max_num_neighbors=32):
 
 
 def fps(pos, batch=None, ratio=0.5, random_start=False):
-    """Farthest point sampling per cloud -> sorted global indices (torch_cluster.fps).  Iterative by nature
-    (n_sample dependent steps); each step is one fused min-update + argmax over the cloud."""
-    out = []
-    for (s, e) in _segments(batch, pos.shape[0]):
-        p = pos[s:e]
-        n = e - s
-        m = max(1, int(round(n * ratio))) if isinstance(ratio, float) else int(ratio)
-        start = int(torch.randint(0, n, (1,))) if random_start else 0
-        sel = torch.empty(m, dtype=torch.long, device=pos.device)
-        dist = torch.full((n,), float('inf'), device=pos.device)
-        cur = torch.tensor(start, device=pos.device)
-        for t in range(m):
-            sel[t] = cur
-            dist = torch.minimum(dist, ((p - p[cur]) ** 2).sum(1))
-            cur = torch.argmax(dist)
-        out.append(sel.sort().values + s)
-    return torch.cat(out)
+    """Farthest point sampling per cloud -> sorted global indices (torch_cluster.fps).  One HIP workgroup per cloud
+    (csrc/knn.hip: fps_kernel); the number of picks is ceil(ratio * n) per cloud."""
+    import math
+
+    from .. import _lib
+    from ..graph import ptr, stream_ptr
+    segs = _segments(batch, pos.shape[0])
+    dev = pos.device
+    counts = [e - s for s, e in segs]
+    picks = [max(1, int(math.ceil(ratio * n))) if isinstance(ratio, float) else min(int(ratio), n) for n in counts]
+    starts = torch.tensor([s for s, _ in segs], dtype=torch.int64, device=dev)
+    cnt = torch.tensor(counts, dtype=torch.int64, device=dev)
+    npick = torch.tensor(picks, dtype=torch.int64, device=dev)
+    ostart = torch.cumsum(npick, 0) - npick
+    first = (torch.stack([torch.randint(0, n, (1,)) for n in counts]).reshape(-1).to(dev) if random_start
+             else torch.zeros(len(segs), dtype=torch.int64, device=dev))
+    p = pos.detach().to(torch.float32).contiguous()
+    out = torch.empty(sum(picks), dtype=torch.int64, device=dev)
+    ws = torch.empty(pos.shape[0], dtype=torch.float32, device=dev)
+    _lib.call('crfconv_fps', ptr(p), len(segs), ptr(starts), ptr(cnt), ptr(ostart), ptr(npick), ptr(first), ptr(ws),
+              ptr(out), stream_ptr())
+    pieces, o = [], 0
+    for k in picks:
+        pieces.append(out[o:o + k].sort().values)
+        o += k
+    return torch.cat(pieces)

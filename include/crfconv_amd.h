@@ -68,6 +68,14 @@ int crfconv_knn_batch_dev(const float* pts, size_t batch_size, size_t npts, size
                           int32_t* out_i32, void* workspace, size_t workspace_bytes,
                           crf_stream_t stream);
 
+/* Farthest point sampling per cloud (torch_cluster.fps as called at models/point_conv.py:381).  All descriptor arrays
+ * are device int64 [n_clouds]: seg_start / seg_count = the cloud's rows in pos [N, 3]; n_sample = picks per cloud
+ * (<= seg_count); first = local index of the first pick; out_start = offset of the cloud's picks in out.  Picks are
+ * GLOBAL row ids in selection order; ties in the arg-max go to the lower index.  dist_ws: float [N] scratch. */
+int crfconv_fps(const float* pos, int n_clouds, const int64_t* seg_start, const int64_t* seg_count,
+                const int64_t* out_start, const int64_t* n_sample, const int64_t* first, float* dist_ws,
+                int64_t* out, crf_stream_t stream);
+
 /* ===================================================================== (A) grid subsampling
  * Barycentre / mean feature / majority label per voxel of edge `sampleDl`
  * (grid_subsampling.cpp:5-106).  Rows are emitted in ascending voxel key (the reference emits
@@ -179,14 +187,14 @@ int crfconv_pointconv_bwd_reduce(const float* x, const float* gout, const float*
 /* Pass 2:  g_h2[e,c] = ca[c] * g_w[e,c] + cb[c] * h2[e,c] + cc[c]  (the host folds BatchNorm-2's
  * backward into ca/cb/cc; eval mode: ca = a2, cb = cc = 0), then back through W2, lrelu, A1:
  *   dW2 [d,d] and dA1b1 [d,4] = {dA1[c][0..2], db1[c]} as float64 sums (the latter accumulated in
- * float64 throughout: the host's analytic BatchNorm-1 backward cancels their large common parts).  d <= 32. */
+ * float64 throughout: the host's analytic BatchNorm-1 backward cancels their large common parts).  d <= 16. */
 int crfconv_pointconv_bwd_params(const float* x, const float* gout, const float* pos_src,
                                  const float* pos_tgt, const int32_t* idx32, int K, int64_t m_tgt,
                                  int d, const float* A1, const float* b1, const float* W2, float slope,
                                  const float* ca, const float* cb, const float* cc, double* dW2,
                                  double* dA1b1, void* workspace, size_t workspace_bytes,
                                  crf_stream_t stream);
-/* Pass 2 for wide layers (d >= 64, few edges): instead of reducing in-kernel, write per edge e = i*K + k
+/* Pass 2 for wide layers (d >= 32, few edges): instead of reducing in-kernel, write per edge e = i*K + k
  *   h1 [E, d],  g_h2 [E, d] (same definition as above),  rel [E, 3]
  * so the host can form dW2 = g_h2^T h1, g_h1 = g_h2 W2, dA1 = (g_h1 * lrelu')^T rel, db1 with dense GEMMs. */
 int crfconv_pointconv_bwd_dump(const float* x, const float* gout, const float* pos_src,

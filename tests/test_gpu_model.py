@@ -381,7 +381,7 @@ def test_fused_batchnorm_lrelu(M, C, slope, training):
     off_kink = (pre_ref.detach().abs() > 1e-4) if slope != 1.0 else torch.ones_like(xr, dtype=torch.bool)
     assert float(off_kink.double().mean()) > 0.999
     assert_close(x.grad * off_kink, xr.grad * off_kink, 1e-4, 'dx')
-    sum_tol = 2e-5 if slope == 1.0 else 2e-4          # a kink element shifts a channel sum by O(1) of ~1e4
+    sum_tol = 2e-5 if slope == 1.0 else 1e-3          # one kink element moves a channel sum by O(|g|) of ~1e3
     assert_close(bn.weight.grad, ref.weight.grad, sum_tol, 'dgamma')
     assert_close(bn.bias.grad, ref.bias.grad, sum_tol, 'dbeta')
     assert_close(bn.running_mean, ref.running_mean, 1e-6, 'running_mean')

@@ -121,6 +121,16 @@ def test_graph_builders():
     # fps: right count per cloud, distinct, each pick is the farthest point from the picks before it
     idx = graph_ops.fps(pos, batch, ratio=0.1).cpu().numpy()
     assert len(idx) == 100 and len(set(idx.tolist())) == 100 and (idx[:70] < 700).all() and (idx[70:] >= 700).all()
+    # against a plain numpy farthest-point loop (start at local index 0, ties -> lower index)
+    def np_fps(p, m):
+        sel, dist, cur = [], np.full(len(p), np.inf, np.float32), 0
+        for _ in range(m):
+            sel.append(cur)
+            dist = np.minimum(dist, ((p - p[cur]) ** 2).sum(1).astype(np.float32))
+            cur = int(np.argmax(dist))
+        return np.sort(np.array(sel))
+    assert np.array_equal(idx[:70], np_fps(pos_np[:700], 70))
+    assert np.array_equal(idx[70:], np_fps(pos_np[700:], 30) + 700)
     # bipartite builder keeps the reference's [col; row] layout
     from crfconv_amd.models import build_bipartite_graph
     eb, sub_pos, sub_batch = build_bipartite_graph(pos, batch, 0.1, method='knn', k=6)
