@@ -386,7 +386,10 @@ class _PointConv(torch.autograd.Function):
             _lib.call('crfconv_pointconv_bwd_dump', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
                       m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(h1),
                       ptr(gh2), ptr(rel), st)
-            dW2 = gh2.t() @ h1
+            dW2 = torch.empty((d, d), dtype=torch.float32, device=dev)       # g_h2^T h1 on the MFMA row-reduction kernel
+            wbytes = _lib.load().crfconv_linear_wgrad_workspace(E, d, d)
+            wws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+            _lib.call('crfconv_linear_wgrad', ptr(gh2), ptr(h1), E, d, d, ptr(dW2), None, ptr(wws), wbytes, st)
             gpd = ((gh2 @ W2) * torch.where(h1 > 0, 1.0, slope)).double()
             reld = rel.double()
             # float64 sums as column reductions (a float64 GEMM of this shape takes rocBLAS ~0.7 ms)

@@ -357,15 +357,18 @@ def test_linear_wgrad_mfma(M, Ci, Co, bias):
 @pytest.mark.parametrize('M,C,slope,training', [(163840, 32, 0.1, True), (40960, 8, 1.0, True), (1000, 512, 0.1, True),
                                                 (777, 128, 0.1, False), (33, 1024, 1.0, True)])
 def test_fused_batchnorm_lrelu(M, C, slope, training):
-    """csrc/bn.hip against torch BatchNorm1d + LeakyReLU in float64."""
+    """csrc/bn.hip against torch BatchNorm1d + LeakyReLU in float64.  The LeakyReLU branch of the handful of
+    elements whose pre-activation is within fp32 rounding of 0 is taken from the kernel's own output sign, so the
+    comparison is exact elsewhere (otherwise one flipped element moves a channel sum by O(|g|))."""
     from crfconv_amd import ops
     g = torch.Generator().manual_seed(C + M)
     x = (torch.randn(M, C, generator=g) * 2 + 3).to(DEV).requires_grad_(True)      # mean >> 0: shifted sums matter
     go = torch.randn(M, C, generator=g).to(DEV)
-    bn = torch.nn.BatchNorm1d(C).to(DEV)
+    bn = torch.nn.BatchNorm1d(C)
     with torch.no_grad():
-        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
-        bn.running_mean.uniform_(2.5, 3.5); bn.running_var.uniform_(3.0, 5.0)
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.rand(C, generator=g) * 0.6 - 0.3)
+        bn.running_mean.copy_(torch.rand(C, generator=g) + 2.5); bn.running_var.copy_(torch.rand(C, generator=g) * 2 + 3)
+    bn = bn.to(DEV)
     ref = torch.nn.BatchNorm1d(C).to(DEV).double()
     ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
     bn.train(training); ref.train(training)
@@ -373,17 +376,13 @@ def test_fused_batchnorm_lrelu(M, C, slope, training):
     y.backward(go)
     xr = x.detach().double().requires_grad_(True)
     pre_ref = ref(xr)
-    yr = torch.nn.functional.leaky_relu(pre_ref, slope) if slope != 1.0 else pre_ref
-    yr.backward(go.double())
+    branch = torch.where(y.detach() > 0, 1.0, slope).double()
+    yr = torch.where(y.detach() > 0, pre_ref, slope * pre_ref)
+    pre_ref.backward(go.double() * branch)
     assert_close(y, yr, 1e-5, 'y')
-    # elements sitting on the LeakyReLU kink (|pre-activation| ~ fp32 rounding) may take either one-sided
-    # derivative; they are excluded from the element-wise check (the channel sums below still cover them)
-    off_kink = (pre_ref.detach().abs() > 1e-4) if slope != 1.0 else torch.ones_like(xr, dtype=torch.bool)
-    assert float(off_kink.double().mean()) > 0.999
-    assert_close(x.grad * off_kink, xr.grad * off_kink, 1e-4, 'dx')
-    sum_tol = 2e-5 if slope == 1.0 else 1e-3          # one kink element moves a channel sum by O(|g|) of ~1e3
-    assert_close(bn.weight.grad, ref.weight.grad, sum_tol, 'dgamma')
-    assert_close(bn.bias.grad, ref.bias.grad, sum_tol, 'dbeta')
+    assert_close(x.grad, xr.grad, 2e-5, 'dx')
+    assert_close(bn.weight.grad, ref.weight.grad, 2e-5, 'dgamma')
+    assert_close(bn.bias.grad, ref.bias.grad, 2e-5, 'dbeta')
     assert_close(bn.running_mean, ref.running_mean, 1e-6, 'running_mean')
     assert_close(bn.running_var, ref.running_var, 1e-6, 'running_var')
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
