@@ -52,6 +52,11 @@ SIGNATURES = {
     'crfconv_bn_workspace': (_sz, [_i64, _i]),
     'crfconv_bn_forward': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_bn_backward': (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_bn_apply': (_i, [_vp, _i64, _i, _vp, _f, _vp, _vp]),
+    'crfconv_linear_forward_supported': (_i, [_i, _i]),
+    'crfconv_linear_forward_stat_records': (_sz, [_i64]),
+    'crfconv_linear_forward': (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    'crfconv_bn_coef_from_records': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
     'crfconv_spd_inverse': (_i, [_vp, _i, _vp, _vp]),
     'crfconv_neighbor_maxpool_forward': (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp]),
     'crfconv_neighbor_maxpool_backward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),

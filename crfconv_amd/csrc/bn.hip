@@ -290,3 +290,14 @@ extern "C" int crfconv_bn_backward(const float* gy, const float* x, const float*
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
+
+// y = lrelu(a x + b, slope) with coefficients that already exist (e.g. from crfconv_bn_coef_from_records).
+extern "C" int crfconv_bn_apply(const float* x, int64_t M, int C, const float* coef, float slope, float* y,
+                                crf_stream_t stream) {
+    if (int rc = bn_check(M, C)) return rc;
+    CRF_REQUIRE(x && coef && y, CRF_ERR_ARG, "null pointer");
+    const int64_t n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(BN_BLOCK), 0, as_stream(stream), x, coef, n4, C / 4, slope, y);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}

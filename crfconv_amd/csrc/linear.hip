@@ -230,3 +230,249 @@ extern "C" int crfconv_spd_inverse(const float* M, int H, float* Q, crf_stream_t
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
+
+// ====================================================================== Y = X W^T (+ b) with BN statistics
+// The per-point Linear layers at the fine levels: m = 10^4..10^5 rows, Ci, Co <= 128.  One wavefront owns 16 rows
+// and all Co outputs; X rows are read ONCE as float4 (lane l: row l & 15, k = 16 c + 4 (l >> 4) + {0..3}), W sits in
+// LDS (rows padded by 4 floats: conflict-free ds_read_b128), and each float4 pair feeds four
+// v_mfma_f32_16x16x4_f32 steps (step s takes component s of every lane's float4: the k order inside a 16-chunk is
+// permuted identically for both operands, which a sum does not notice).  Output tile D[co][row]: lane holds 4
+// consecutive co of one row -> one float4 store.  Optional epilogue: per-block shifted sums / sums of squares of
+// every output channel, so BatchNorm needs no separate statistics pass over Y.
+namespace crf {
+
+constexpr int LF_BLOCK = 256;
+
+template <int TCO>  // 16 * TCO output channels per block slab (blockIdx.y picks the slab)
+__global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, int64_t M, int Ci, int Co,
+                                                              int transpose_w, float* __restrict__ Y,
+                                                              float* __restrict__ stat_partial /*[nblk][3][Co] or null*/) {
+    extern __shared__ float sW[];                 // [16*TCO][Cip]
+    const int Cip = ((Ci + 15) / 16) * 16 + 4;
+    const int co_base = blockIdx.y * 16 * TCO;
+    for (int t = threadIdx.x; t < 16 * TCO * Cip; t += LF_BLOCK) {
+        const int r = t / Cip, k = t - r * Cip;
+        const int co = co_base + r;
+        float v = 0.f;
+        if (co < Co && k < Ci) v = transpose_w ? W[(int64_t)k * Co + co] : W[(int64_t)co * Ci + k];
+        sW[t] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rr = lane & 15, g = lane >> 4;
+    const bool vec = (Ci % 4) == 0;
+    float bsel[TCO][4];
+#pragma unroll
+    for (int t = 0; t < TCO; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = co_base + 16 * t + 4 * g + e;
+            bsel[t][e] = (bias != nullptr && co < Co) ? bias[co] : 0.f;
+        }
+    float s1[TCO][4], s2[TCO][4], sh[TCO][4];
+#pragma unroll
+    for (int t = 0; t < TCO; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[t][e] = 0.f; s2[t][e] = 0.f; sh[t][e] = 0.f; }
+    bool have_shift = false;
+    const int nchunk = (Ci + 15) / 16;
+
+    for (int64_t row0 = ((int64_t)blockIdx.x * (LF_BLOCK / WAVE) + wave) * 16; row0 < M;
+         row0 += (int64_t)gridDim.x * (LF_BLOCK / WAVE) * 16) {
+        const int64_t r = row0 + rr;
+        const bool rv = r < M;
+        f32x4 acc[TCO];
+#pragma unroll
+        for (int t = 0; t < TCO; ++t) acc[t] = f32x4{bsel[t][0], bsel[t][1], bsel[t][2], bsel[t][3]};
+        for (int c = 0; c < nchunk; ++c) {
+            const int k0 = 16 * c + 4 * g;
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rv) {
+                if (vec) {
+                    if (k0 < Ci) xv = *reinterpret_cast<const float4*>(X + r * Ci + k0);
+                } else {
+                    const float* xp = X + r * Ci;
+                    xv.x = k0 + 0 < Ci ? xp[k0 + 0] : 0.f;
+                    xv.y = k0 + 1 < Ci ? xp[k0 + 1] : 0.f;
+                    xv.z = k0 + 2 < Ci ? xp[k0 + 2] : 0.f;
+                    xv.w = k0 + 3 < Ci ? xp[k0 + 3] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TCO; ++t) {
+                const float4 wv = *reinterpret_cast<const float4*>(sW + (16 * t + rr) * Cip + k0);
+                // D[i = co][j = row]: A = W fragment (i = lane & 15), B = X fragment (j = lane & 15)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc[t], 0, 0, 0);
+            }
+        }
+        // lane holds Y[row = row0 + rr][co = co_base + 16 t + 4 g + e], e = 0..3
+#pragma unroll
+        for (int t = 0; t < TCO; ++t) {
+            const int co = co_base + 16 * t + 4 * g;
+            if (rv) {
+                if (co + 3 < Co && (Co % 4) == 0) {
+                    *reinterpret_cast<float4*>(Y + r * Co + co) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < Co) Y[r * Co + co + e] = acc[t][e];
+                }
+            }
+        }
+        if (stat_partial != nullptr) {
+            if (!have_shift) {   // shift = this wave's first row (lane with rr == 0 of each co group)
+#pragma unroll
+                for (int t = 0; t < TCO; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sh[t][e] = __shfl(acc[t][e], 16 * g, WAVE);
+                have_shift = true;
+            }
+            if (rv) {
+#pragma unroll
+                for (int t = 0; t < TCO; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dlt = acc[t][e] - sh[t][e];
+                        s1[t][e] += dlt;
+                        s2[t][e] = fmaf(dlt, dlt, s2[t][e]);
+                    }
+            }
+        }
+    }
+    if (stat_partial != nullptr) {
+        // per WAVE partial record {shift, sum, sumsq} per channel; reduce the 16 row-lanes by shuffles
+        const int rec = blockIdx.x * (LF_BLOCK / WAVE) + wave;
+#pragma unroll
+        for (int t = 0; t < TCO; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = s1[t][e], b = s2[t][e];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    a += __shfl_xor(a, o, WAVE);
+                    b += __shfl_xor(b, o, WAVE);
+                }
+                const int co = co_base + 16 * t + 4 * g + e;
+                if (rr == 0 && co < Co) {
+                    float* p = stat_partial + (int64_t)rec * 3 * Co;
+                    p[co] = have_shift ? sh[t][e] : 0.f;
+                    p[Co + co] = a;
+                    p[2 * Co + co] = b;
+                }
+            }
+    }
+}
+
+// Combine per-wave {shift, sum, sumsq, (implicit count)} records into BatchNorm coefficients (Chan's parallel
+// variance in float64), same outputs as bn_finalize_kernel.  counts: record r covers rows r*16, r*16 + stride, ...
+__global__ __launch_bounds__(256) void bn_finalize_records_kernel(const float* __restrict__ rec, int nrec, int64_t M,
+                                                                  int C, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float eps,
+                                                                  float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                  float momentum, float* __restrict__ coef) {
+    const int c = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    // rows of record r: the 16-row groups r, r + nrec, r + 2 nrec, ... below M
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    const int64_t ngroups = (M + 15) / 16;
+    for (int r = lane; r < nrec; r += WAVE) {
+        if (r >= ngroups) continue;
+        const int64_t full = (ngroups - 1 - r) / nrec + 1;          // groups owned
+        int64_t rows = full * 16;
+        const int64_t last_group = r + (full - 1) * (int64_t)nrec;
+        if (last_group == ngroups - 1) rows -= (ngroups * 16 - M);  // ragged tail
+        if (rows <= 0) continue;
+        const double nb = (double)rows;
+        const double sh = rec[(int64_t)r * 3 * C + c], a = rec[(int64_t)r * 3 * C + C + c], b = rec[(int64_t)r * 3 * C + 2 * C + c];
+        const double mb = sh + a / nb, m2b = b - a * a / nb;
+        const double tot = n + nb, dlt = mb - mean;
+        mean += dlt * nb / tot;
+        m2 += m2b + dlt * dlt * n * nb / tot;
+        n = tot;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double n2 = __shfl_xor(n, o, WAVE), mean2 = __shfl_xor(mean, o, WAVE), m22 = __shfl_xor(m2, o, WAVE);
+        const double tot = n + n2;
+        if (tot > 0.0) {
+            const double dlt = mean2 - mean;
+            mean += dlt * n2 / tot;
+            m2 += m22 + dlt * dlt * n * n2 / tot;
+            n = tot;
+        }
+    }
+    if (lane != 0) return;
+    double var = m2 / (double)M;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double a = (double)gamma[c] * rstd;
+    coef[c] = (float)a;
+    coef[C + c] = (float)((double)beta[c] - a * mean);
+    coef[2 * C + c] = (float)mean;
+    coef[3 * C + c] = (float)rstd;
+    if (run_mean != nullptr) {
+        const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * mean);
+        run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * unb);
+    }
+}
+
+static int lf_blocks(int64_t M) {
+    int64_t nb = (M + 63) / 64;           // 64 rows per block iteration
+    if (nb > 1024) nb = 1024;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+}  // namespace crf
+
+// Supported when the weight slab fits LDS: min(Co, 128) x (Ci rounded to 16 + 4) floats <= 64 KB.
+extern "C" int crfconv_linear_forward_supported(int Ci, int Co) {
+    if (Ci < 1 || Co < 1) return 0;
+    const int cip = ((Ci + 15) / 16) * 16 + 4;
+    const int slab = Co < 128 ? ((Co + 15) / 16) * 16 : 128;
+    return (size_t)slab * cip * sizeof(float) <= 64 * 1024 ? 1 : 0;
+}
+
+extern "C" size_t crfconv_linear_forward_stat_records(int64_t M) { return (size_t)crf::lf_blocks(M) * (crf::LF_BLOCK / crf::WAVE); }
+
+// Y [M, Co] = X [M, Ci] W^T (+ bias);  W is [Co, Ci] row-major, or [Ci, Co] when transpose_w != 0 (the dX product).
+// stat_rec (may be NULL): float [records][3][Co] receives per-wave {shift, sum(y - shift), sum (y - shift)^2}.
+extern "C" int crfconv_linear_forward(const float* X, const float* W, const float* bias, int64_t M, int Ci, int Co,
+                                      int transpose_w, float* Y, float* stat_rec, crf_stream_t stream) {
+    CRF_REQUIRE(X && W && Y, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(M > 0, CRF_ERR_ARG, "M must be positive");
+    CRF_REQUIRE(crfconv_linear_forward_supported(Ci, Co), CRF_ERR_UNSUPPORTED, "weight slab %dx%d does not fit LDS", Co, Ci);
+    const int cip = ((Ci + 15) / 16) * 16 + 4;
+    const int tiles = (Co + 15) / 16;
+    const int tco = tiles >= 8 ? 8 : (tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1));
+    const int gy = (tiles + tco - 1) / tco;
+    const dim3 grid((unsigned)crf::lf_blocks(M), (unsigned)gy), blk(crf::LF_BLOCK);
+    const size_t lds = sizeof(float) * 16 * tco * cip;
+    hipStream_t st = crf::as_stream(stream);
+    switch (tco) {
+        case 1: hipLaunchKernelGGL(crf::linear_fwd_kernel<1>, grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec); break;
+        case 2: hipLaunchKernelGGL(crf::linear_fwd_kernel<2>, grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec); break;
+        case 4: hipLaunchKernelGGL(crf::linear_fwd_kernel<4>, grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec); break;
+        default: hipLaunchKernelGGL(crf::linear_fwd_kernel<8>, grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec); break;
+    }
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+// BatchNorm coefficients from the records written by crfconv_linear_forward (instead of a statistics pass).
+extern "C" int crfconv_bn_coef_from_records(const float* stat_rec, int64_t M, int C, const float* gamma,
+                                            const float* beta, float* run_mean, float* run_var, float momentum,
+                                            float eps, float* coef, crf_stream_t stream) {
+    CRF_REQUIRE(stat_rec && gamma && beta && coef, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(M > 0 && C > 0, CRF_ERR_ARG, "bad shape");
+    const int nrec = (int)crfconv_linear_forward_stat_records(M);
+    hipLaunchKernelGGL(crf::bn_finalize_records_kernel, dim3((C + 3) / 4), dim3(256), 0, crf::as_stream(stream), stat_rec, nrec,
+                       M, C, gamma, beta, eps, run_mean, run_var, momentum, coef);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}

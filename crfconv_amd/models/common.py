@@ -36,13 +36,19 @@ class MLP(nn.Module):
         self.activation = activation
 
     def forward(self, x, *args, **kwargs):
-        x = ops.linear(x, self.lin.weight, self.lin.bias)      # fwd / dX: vendor GEMM; dW: MFMA kernel
-        fusable = (self.bn is not None and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0
-                   and x.shape[-1] <= 1024 and self.bn.batch_norm.affine
+        co = self.lin.out_features
+        fusable = (self.bn is not None and x.is_cuda and x.dtype == torch.float32 and co % 4 == 0 and co <= 1024
+                   and self.bn.batch_norm.affine
                    and (self.activation is None or isinstance(self.activation, nn.LeakyReLU)))
-        if fusable:                                            # BatchNorm + LeakyReLU in one fused pass
+        if fusable:      # Linear (MFMA, BatchNorm statistics in its epilogue) -> BatchNorm + LeakyReLU in one pass
+            records = None
+            if self.training:
+                x, records = ops.linear(x, self.lin.weight, self.lin.bias, want_stats=True)
+            else:
+                x = ops.linear(x, self.lin.weight, self.lin.bias)
             slope = 1.0 if self.activation is None else self.activation.negative_slope
-            return ops.bn_act(x, self.bn.batch_norm, self.training, slope)
+            return ops.bn_act(x, self.bn.batch_norm, self.training, slope, records=records)
+        x = ops.linear(x, self.lin.weight, self.lin.bias)
         if self.bn is not None:
             x = self.bn(x)
         if self.activation is not None:

@@ -130,42 +130,83 @@ def crf_meanfield(z, y, c, table, steps, k0=1):
 
 
 # ------------------------------------------------------------------------------ per-point Linear
+_MFMA_MIN_ROWS = 4096       # below this the vendor GEMM's fixed cost is as good
+
+
+def _mfma_ok(m, ci, co):
+    return m >= _MFMA_MIN_ROWS and bool(_lib.load().crfconv_linear_forward_supported(ci, co))
+
+
+def _mfma_matmul(x, W, b, transpose_w, want_stats=False):
+    """x [m, k] @ (W^T or W) on the fp32 MFMA kernel (linear.hip); optional BatchNorm statistic records."""
+    m, ci = x.shape
+    co = W.shape[1] if transpose_w else W.shape[0]
+    y = torch.empty((m, co), dtype=torch.float32, device=x.device)
+    rec = None
+    if want_stats:
+        nrec = _lib.load().crfconv_linear_forward_stat_records(m)
+        rec = torch.empty((nrec, 3, co), dtype=torch.float32, device=x.device)
+    _lib.call('crfconv_linear_forward', ptr(x), ptr(W), ptr(b), m, ci, co, 1 if transpose_w else 0, ptr(y), ptr(rec),
+              stream_ptr())
+    return y, rec
+
+
 class _Linear(torch.autograd.Function):
-    """y = x W^T (+ b) on [m, Ci] rows.  Forward and dX go to the vendor GEMM (plain library GEMMs);
-    dW / db -- a reduction over all m rows into a tiny matrix -- run on the MFMA kernel in linear.hip."""
+    """y = x W^T (+ b) on [m, Ci] rows.  Large-m, <= 128-channel layers run on the MFMA kernels of linear.hip
+    (forward with fused BatchNorm statistics, dX, and the dW / db row reduction); small or very wide ones go to
+    the vendor GEMM for forward / dX (plain library GEMMs)."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
-        ctx.save_for_backward(x, W)
+    def forward(ctx, x, W, b, want_stats):
+        x = x.contiguous()
+        Wc = W.contiguous()
+        ctx.save_for_backward(x, Wc)
         ctx.has_bias = b is not None
-        return torch.nn.functional.linear(x, W, b)
+        m, ci = x.shape
+        rec = None
+        if _mfma_ok(m, ci, Wc.shape[0]):
+            y, rec = _mfma_matmul(x, Wc, None if b is None else b.contiguous(), False, want_stats)
+        else:
+            y = torch.nn.functional.linear(x, Wc, b)
+        if want_stats:
+            if rec is None:
+                rec = torch.empty(0, device=x.device)
+            ctx.mark_non_differentiable(rec)
+            return y, rec
+        return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, *_unused):
         x, W = ctx.saved_tensors
         g = g.contiguous()
-        gx = g @ W if ctx.needs_input_grad[0] else None
+        m, Co = g.shape
+        Ci = x.shape[1]
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = _mfma_matmul(g, W, None, True)[0] if _mfma_ok(m, Co, Ci) else g @ W
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            m, Co = g.shape
-            Ci = x.shape[1]
             dW = torch.empty((Co, Ci), dtype=torch.float32, device=g.device)
             db = torch.empty(Co, dtype=torch.float32, device=g.device) if ctx.has_bias else None
             nbytes = _lib.load().crfconv_linear_wgrad_workspace(m, Co, Ci)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
-            xc = x.contiguous()
-            _lib.call('crfconv_linear_wgrad', ptr(g), ptr(xc), m, Co, Ci, ptr(dW), ptr(db), ptr(ws), nbytes,
+            _lib.call('crfconv_linear_wgrad', ptr(g), ptr(x), m, Co, Ci, ptr(dW), ptr(db), ptr(ws), nbytes,
                       stream_ptr())
-        return gx, dW, db
+        return gx, dW, db, None
 
 
-def linear(x, W, b=None):
-    """Drop-in for F.linear on [..., Ci] CUDA float32 tensors (CPU tensors: plain F.linear)."""
-    if not x.is_cuda or x.dtype != torch.float32 or not torch.is_grad_enabled():
-        return torch.nn.functional.linear(x, W, b)
+def linear(x, W, b=None, want_stats=False):
+    """Drop-in for F.linear on [..., Ci] CUDA float32 tensors (CPU tensors: plain F.linear).  With
+    want_stats=True returns (y, records) where `records` feeds bn_act(..., records=records) (empty if unused)."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        y = torch.nn.functional.linear(x, W, b)
+        return (y, None) if want_stats else y
     shape = x.shape
-    y = _Linear.apply(x.reshape(-1, shape[-1]), W, b)
-    return y.reshape(shape[:-1] + (W.shape[0],))
+    out = _Linear.apply(x.reshape(-1, shape[-1]), W, b, want_stats)
+    if want_stats:
+        y, rec = out
+        return y.reshape(shape[:-1] + (W.shape[0],)), (rec if rec.numel() else None)
+    return out.reshape(shape[:-1] + (W.shape[0],))
 
 
 # ------------------------------------------------------------------------------ BatchNorm (+ LeakyReLU)
@@ -174,17 +215,22 @@ class _BNAct(torch.autograd.Function):
     reduction + one fused pass backward (csrc/bn.hip)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, use_batch, slope):
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, use_batch, slope, records):
         m, C = x.shape
         x = x.contiguous()
         y = torch.empty_like(x)
         coef = torch.empty(4 * C, dtype=torch.float32, device=x.device)
-        nbytes = _lib.load().crfconv_bn_workspace(m, C)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         g, b = _f32c(gamma), _f32c(beta)
-        _lib.call('crfconv_bn_forward', ptr(x), m, C, ptr(g), ptr(b), ptr(run_mean) if use_batch else ptr(run_mean),
-                  ptr(run_var), float(momentum), float(eps), 1 if use_batch else 0, float(slope), ptr(coef), ptr(y),
-                  ptr(ws), nbytes, stream_ptr())
+        if use_batch and records is not None:
+            # statistics came out of the Linear kernel's epilogue: no pass over x for them
+            _lib.call('crfconv_bn_coef_from_records', ptr(records), m, C, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
+                      float(momentum), float(eps), ptr(coef), stream_ptr())
+            _lib.call('crfconv_bn_apply', ptr(x), m, C, ptr(coef), float(slope), ptr(y), stream_ptr())
+        else:
+            nbytes = _lib.load().crfconv_bn_workspace(m, C)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            _lib.call('crfconv_bn_forward', ptr(x), m, C, ptr(g), ptr(b), ptr(run_mean), ptr(run_var), float(momentum),
+                      float(eps), 1 if use_batch else 0, float(slope), ptr(coef), ptr(y), ptr(ws), nbytes, stream_ptr())
         ctx.save_for_backward(x, coef)
         ctx.use_batch, ctx.slope = use_batch, slope
         return y
@@ -201,10 +247,10 @@ class _BNAct(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         _lib.call('crfconv_bn_backward', ptr(gy), ptr(x), ptr(coef), m, C, 1 if ctx.use_batch else 0, float(ctx.slope),
                   ptr(gx), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
-        return gx, dgamma, dbeta, None, None, None, None, None, None
+        return gx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def bn_act(x, bn, training, slope=1.0):
+def bn_act(x, bn, training, slope=1.0, records=None):
     """FastBatchNorm1d semantics (statistics over every leading dim of x [..., C]) fused with LeakyReLU(slope);
     `bn` is the torch.nn.BatchNorm1d holding the affine parameters and running statistics."""
     shape = x.shape
@@ -214,7 +260,7 @@ def bn_act(x, bn, training, slope=1.0):
         bn.num_batches_tracked += 1
     mom = 0.1 if bn.momentum is None else bn.momentum
     y = _BNAct.apply(x.reshape(-1, C), bn.weight, bn.bias, bn.running_mean if (training or not use_batch) else None,
-                     bn.running_var if (training or not use_batch) else None, mom, bn.eps, use_batch, slope)
+                     bn.running_var if (training or not use_batch) else None, mom, bn.eps, use_batch, slope, records)
     return y.reshape(shape)
 
 

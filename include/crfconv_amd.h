@@ -253,6 +253,22 @@ int crfconv_bn_backward(const float* gy, const float* x, const float* coef, int6
                         float slope, float* gx, float* dgamma, float* dbeta, void* workspace,
                         size_t workspace_bytes, crf_stream_t stream);
 
+int crfconv_bn_apply(const float* x, int64_t M, int C, const float* coef, float slope, float* y, crf_stream_t stream);
+
+/* Y [M, Co] = X [M, Ci] W^T (+ bias) on fp32 MFMA, X streamed once, W resident in LDS (needs
+ * crfconv_linear_forward_supported(Ci, Co): the <= 128-channel weight slab fits 64 KB).  W is [Co, Ci] row-major, or
+ * [Ci, Co] when transpose_w != 0 (the input-gradient product dX = G W).  stat_rec (may be NULL): float
+ * [crfconv_linear_forward_stat_records(M)][3][Co] receives per-wavefront {shift, sum(y - shift), sum (y - shift)^2},
+ * from which crfconv_bn_coef_from_records forms the BatchNorm coefficients (coef [4, Co], as crfconv_bn_forward) --
+ * the statistics pass over Y disappears. */
+int crfconv_linear_forward_supported(int Ci, int Co);
+size_t crfconv_linear_forward_stat_records(int64_t M);
+int crfconv_linear_forward(const float* X, const float* W, const float* bias, int64_t M, int Ci, int Co,
+                           int transpose_w, float* Y, float* stat_rec, crf_stream_t stream);
+int crfconv_bn_coef_from_records(const float* stat_rec, int64_t M, int C, const float* gamma, const float* beta,
+                                 float* run_mean, float* run_var, float momentum, float eps, float* coef,
+                                 crf_stream_t stream);
+
 /* Q = M^-1 for the symmetric positive definite M = I + c^T c of a CRF layer (H <= 64; Gauss-Jordan in
  * float64, one workgroup, no host sync -- capturable into a hipGraph, unlike a LAPACK-style inverse). */
 int crfconv_spd_inverse(const float* M, int H, float* Q, crf_stream_t stream);

@@ -386,3 +386,28 @@ def test_fused_batchnorm_lrelu(M, C, slope, training):
     assert_close(bn.running_mean, ref.running_mean, 1e-6, 'running_mean')
     assert_close(bn.running_var, ref.running_var, 1e-6, 'running_var')
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+@pytest.mark.parametrize('M,Ci,Co,bias', [(163840, 32, 128, False), (40960, 64, 16, False), (5000, 6, 32, False),
+                                          (4099, 128, 13, True), (10240, 128, 64, False), (8192, 8, 8, True)])
+def test_linear_forward_mfma_and_fused_stats(M, Ci, Co, bias):
+    """linear.hip forward / dX kernels vs float64 torch, and BatchNorm fed from the GEMM epilogue records."""
+    from crfconv_amd import ops
+    g = torch.Generator().manual_seed(M + Ci + Co)
+    x = (torch.randn(M, Ci, generator=g) + 0.5).to(DEV).requires_grad_(True)
+    W = (torch.randn(Co, Ci, generator=g) / Ci ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn(Co, generator=g).to(DEV).requires_grad_(True) if bias else None
+    go = torch.randn(M, Co, generator=g).to(DEV)
+    y, rec = ops.linear(x, W, b, want_stats=True)
+    assert rec is not None                                   # these shapes take the MFMA path
+    y.backward(go)
+    yr = torch.nn.functional.linear(x.detach().double(), W.detach().double(), None if b is None else b.detach().double())
+    assert_close(y, yr, 2e-6, 'y')
+    assert_close(x.grad, go.double() @ W.detach().double(), 2e-6, 'dX')
+    assert_close(W.grad, go.double().t() @ x.detach().double(), 2e-5, 'dW')
+    if Co % 4 == 0:
+        bn = torch.nn.BatchNorm1d(Co).to(DEV).train()
+        ref = torch.nn.BatchNorm1d(Co).to(DEV).double().train()
+        out = ops.bn_act(y.detach(), bn, True, 1.0, records=rec)
+        assert_close(out, ref(yr), 1e-5, 'BN from records')
+        assert_close(bn.running_var, ref.running_var, 1e-6, 'running_var from records')
