@@ -247,16 +247,27 @@ template <int TCO>  // 16 * TCO output channels per block slab (blockIdx.y picks
 __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                               const float* __restrict__ bias, int64_t M, int Ci, int Co,
                                                               int transpose_w, float* __restrict__ Y,
-                                                              float* __restrict__ stat_partial /*[nblk][3][Co] or null*/) {
+                                                              float* __restrict__ stat_partial /*[nblk][4][Co] or null*/) {
     extern __shared__ float sW[];                 // [16*TCO][Cip]
     const int Cip = ((Ci + 15) / 16) * 16 + 4;
     const int co_base = blockIdx.y * 16 * TCO;
-    for (int t = threadIdx.x; t < 16 * TCO * Cip; t += LF_BLOCK) {
-        const int r = t / Cip, k = t - r * Cip;
-        const int co = co_base + r;
-        float v = 0.f;
-        if (co < Co && k < Ci) v = transpose_w ? W[(int64_t)k * Co + co] : W[(int64_t)co * Ci + k];
-        sW[t] = v;
+    if (!transpose_w && (Ci % 4) == 0) {          // rows of W are contiguous: 16-byte loads
+        const int Cip4 = Cip / 4, Ci4 = Ci / 4;
+        for (int t = threadIdx.x; t < 16 * TCO * Cip4; t += LF_BLOCK) {
+            const int r = t / Cip4, k4 = t - r * Cip4;
+            const int co = co_base + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < Co && k4 < Ci4) v = *reinterpret_cast<const float4*>(W + (int64_t)co * Ci + 4 * k4);
+            *reinterpret_cast<float4*>(sW + r * Cip + 4 * k4) = v;
+        }
+    } else {
+        for (int t = threadIdx.x; t < 16 * TCO * Cip; t += LF_BLOCK) {
+            const int r = t / Cip, k = t - r * Cip;
+            const int co = co_base + r;
+            float v = 0.f;
+            if (co < Co && k < Ci) v = transpose_w ? W[(int64_t)k * Co + co] : W[(int64_t)co * Ci + k];
+            sW[t] = v;
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -344,8 +355,15 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
         }
     }
     if (stat_partial != nullptr) {
-        // per WAVE partial record {shift, sum, sumsq} per channel; reduce the 16 row-lanes by shuffles
-        const int rec = blockIdx.x * (LF_BLOCK / WAVE) + wave;
+        // one record {shift, n, sum, sumsq} per BLOCK and channel: the 16 row-lanes fold by shuffles, the 4 waves
+        // through LDS, re-based on wave 0's shift (sum (v - s0) = a + n d, sum (v - s0)^2 = b + 2 d a + n d^2)
+        __syncthreads();                                 // sW is dead: reuse it as [4 waves][4][16*TCO]
+        float* sw = sW + wave * 4 * 16 * TCO;
+        // rows this wave actually accumulated
+        int64_t nrows = 0;
+        for (int64_t row0 = ((int64_t)blockIdx.x * (LF_BLOCK / WAVE) + wave) * 16; row0 < M;
+             row0 += (int64_t)gridDim.x * (LF_BLOCK / WAVE) * 16)
+            nrows += (M - row0) < 16 ? (M - row0) : 16;
 #pragma unroll
         for (int t = 0; t < TCO; ++t)
 #pragma unroll
@@ -356,14 +374,35 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
                     a += __shfl_xor(a, o, WAVE);
                     b += __shfl_xor(b, o, WAVE);
                 }
-                const int co = co_base + 16 * t + 4 * g + e;
-                if (rr == 0 && co < Co) {
-                    float* p = stat_partial + (int64_t)rec * 3 * Co;
-                    p[co] = have_shift ? sh[t][e] : 0.f;
-                    p[Co + co] = a;
-                    p[2 * Co + co] = b;
+                if (rr == 0) {
+                    const int cl = 16 * t + 4 * g + e;
+                    sw[cl] = sh[t][e];
+                    sw[16 * TCO + cl] = (float)nrows;
+                    sw[2 * 16 * TCO + cl] = a;
+                    sw[3 * 16 * TCO + cl] = b;
                 }
             }
+        __syncthreads();
+        for (int cl = threadIdx.x; cl < 16 * TCO; cl += LF_BLOCK) {
+            const int co = co_base + cl;
+            if (co >= Co) continue;
+            const float s0 = sW[cl];
+            double n = 0.0, S1 = 0.0, S2 = 0.0;
+            for (int w = 0; w < LF_BLOCK / WAVE; ++w) {
+                const float* q = sW + w * 4 * 16 * TCO;
+                const double nb = q[16 * TCO + cl];
+                if (nb <= 0.0) continue;
+                const double d = (double)q[cl] - (double)s0, a = q[2 * 16 * TCO + cl], b = q[3 * 16 * TCO + cl];
+                n += nb;
+                S1 += a + nb * d;
+                S2 += b + 2.0 * d * a + nb * d * d;
+            }
+            float* p = stat_partial + (int64_t)blockIdx.x * 4 * Co;
+            p[co] = s0;
+            p[Co + co] = (float)n;
+            p[2 * Co + co] = (float)S1;
+            p[3 * Co + co] = (float)S2;
+        }
     }
 }
 
@@ -377,35 +416,26 @@ __global__ __launch_bounds__(256) void bn_finalize_records_kernel(const float* _
     const int c = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= C) return;
-    // rows of record r: the 16-row groups r, r + nrec, r + 2 nrec, ... below M
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    const int64_t ngroups = (M + 15) / 16;
+    // records [nrec][4][C] = {shift, n, sum(v - shift), sum (v - shift)^2}; every record is re-based on the shift of
+    // record 0 (a sample value, so |shift - mean| ~ sigma: no cancellation problem in float64)
+    const double s0 = rec[c];
+    double S1 = 0.0, S2 = 0.0;
     for (int r = lane; r < nrec; r += WAVE) {
-        if (r >= ngroups) continue;
-        const int64_t full = (ngroups - 1 - r) / nrec + 1;          // groups owned
-        int64_t rows = full * 16;
-        const int64_t last_group = r + (full - 1) * (int64_t)nrec;
-        if (last_group == ngroups - 1) rows -= (ngroups * 16 - M);  // ragged tail
-        if (rows <= 0) continue;
-        const double nb = (double)rows;
-        const double sh = rec[(int64_t)r * 3 * C + c], a = rec[(int64_t)r * 3 * C + C + c], b = rec[(int64_t)r * 3 * C + 2 * C + c];
-        const double mb = sh + a / nb, m2b = b - a * a / nb;
-        const double tot = n + nb, dlt = mb - mean;
-        mean += dlt * nb / tot;
-        m2 += m2b + dlt * dlt * n * nb / tot;
-        n = tot;
+        const float* p = rec + (int64_t)r * 4 * C + c;
+        const double nb = p[C];
+        if (nb <= 0.0) continue;
+        const double d = (double)p[0] - s0, a = p[2 * C], b = p[3 * C];
+        S1 += a + nb * d;
+        S2 += b + 2.0 * d * a + nb * d * d;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const double n2 = __shfl_xor(n, o, WAVE), mean2 = __shfl_xor(mean, o, WAVE), m22 = __shfl_xor(m2, o, WAVE);
-        const double tot = n + n2;
-        if (tot > 0.0) {
-            const double dlt = mean2 - mean;
-            mean += dlt * n2 / tot;
-            m2 += m22 + dlt * dlt * n * n2 / tot;
-            n = tot;
-        }
+        S1 += __shfl_xor(S1, o, WAVE);
+        S2 += __shfl_xor(S2, o, WAVE);
     }
+    const double m1 = S1 / (double)M;
+    const double mean = s0 + m1;
+    const double m2 = S2 - S1 * m1;
     if (lane != 0) return;
     double var = m2 / (double)M;
     if (var < 0.0) var = 0.0;
@@ -423,8 +453,8 @@ __global__ __launch_bounds__(256) void bn_finalize_records_kernel(const float* _
 }
 
 static int lf_blocks(int64_t M) {
-    int64_t nb = (M + 63) / 64;           // 64 rows per block iteration
-    if (nb > 1024) nb = 1024;
+    int64_t nb = (M + 63) / 64;           // 64 rows per block iteration; up to 4 blocks (16 waves) per CU keep
+    if (nb > 1024) nb = 1024;             // enough 16-byte loads in flight; one statistics record per block
     return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -438,10 +468,10 @@ extern "C" int crfconv_linear_forward_supported(int Ci, int Co) {
     return (size_t)slab * cip * sizeof(float) <= 64 * 1024 ? 1 : 0;
 }
 
-extern "C" size_t crfconv_linear_forward_stat_records(int64_t M) { return (size_t)crf::lf_blocks(M) * (crf::LF_BLOCK / crf::WAVE); }
+extern "C" size_t crfconv_linear_forward_stat_records(int64_t M) { return (size_t)crf::lf_blocks(M); }
 
 // Y [M, Co] = X [M, Ci] W^T (+ bias);  W is [Co, Ci] row-major, or [Ci, Co] when transpose_w != 0 (the dX product).
-// stat_rec (may be NULL): float [records][3][Co] receives per-wave {shift, sum(y - shift), sum (y - shift)^2}.
+// stat_rec (may be NULL): float [records][4][Co] receives per-workgroup {shift, n, sum(y - shift), sum (y - shift)^2}.
 extern "C" int crfconv_linear_forward(const float* X, const float* W, const float* bias, int64_t M, int Ci, int Co,
                                       int transpose_w, float* Y, float* stat_rec, crf_stream_t stream) {
     CRF_REQUIRE(X && W && Y, CRF_ERR_ARG, "null pointer");
@@ -452,7 +482,9 @@ extern "C" int crfconv_linear_forward(const float* X, const float* W, const floa
     const int tco = tiles >= 8 ? 8 : (tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1));
     const int gy = (tiles + tco - 1) / tco;
     const dim3 grid((unsigned)crf::lf_blocks(M), (unsigned)gy), blk(crf::LF_BLOCK);
-    const size_t lds = sizeof(float) * 16 * tco * cip;
+    size_t lds = sizeof(float) * 16 * tco * cip;
+    const size_t lds_stats = sizeof(float) * 4 * 4 * 16 * tco;           // the epilogue reuses the slab as [4][4][16 tco]
+    if (lds < lds_stats) lds = lds_stats;
     hipStream_t st = crf::as_stream(stream);
     switch (tco) {
         case 1: hipLaunchKernelGGL(crf::linear_fwd_kernel<1>, grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec); break;

@@ -133,8 +133,11 @@ def crf_meanfield(z, y, c, table, steps, k0=1):
 _MFMA_MIN_ROWS = 4096       # below this the vendor GEMM's fixed cost is as good
 
 
+_VENDOR_ONLY = bool(__import__('os').environ.get('CRFCONV_VENDOR_GEMM'))     # A/B switch: forward / dX on rocBLAS
+
+
 def _mfma_ok(m, ci, co):
-    return m >= _MFMA_MIN_ROWS and bool(_lib.load().crfconv_linear_forward_supported(ci, co))
+    return (not _VENDOR_ONLY) and m >= _MFMA_MIN_ROWS and bool(_lib.load().crfconv_linear_forward_supported(ci, co))
 
 
 def _mfma_matmul(x, W, b, transpose_w, want_stats=False):
@@ -145,7 +148,7 @@ def _mfma_matmul(x, W, b, transpose_w, want_stats=False):
     rec = None
     if want_stats:
         nrec = _lib.load().crfconv_linear_forward_stat_records(m)
-        rec = torch.empty((nrec, 3, co), dtype=torch.float32, device=x.device)
+        rec = torch.empty((nrec, 4, co), dtype=torch.float32, device=x.device)
     _lib.call('crfconv_linear_forward', ptr(x), ptr(W), ptr(b), m, ci, co, 1 if transpose_w else 0, ptr(y), ptr(rec),
               stream_ptr())
     return y, rec
