@@ -153,3 +153,27 @@ def test_sparse_equals_dense_on_device():
     src = glob[:, 1:].reshape(-1).to(DEV)
     sparse = ops.crf_meanfield(z, y, c, table_from_edges(tgt, src, B * N, B * N), 3, k0=0)
     assert_close(sparse, dense, 1e-5, 'sparse vs dense')
+
+
+def test_sparse_networks_run_and_train():
+    """CRFSegNet / BaselineSegNet / CRFSegNet_Part assembled from the sparse operators: forward gives normalised
+    log-probabilities for every point of a ragged batch, backward reaches every parameter, a second step differs."""
+    import crfconv_amd
+    from crfconv_amd import models
+    n0, n1 = 900, 650                                             # ragged batch (ShapeNet-like sizes)
+    pos = t(np.concatenate([S.make_cloud(40, n0), S.make_cloud(41, n1)]))
+    batch = t(np.concatenate([np.zeros(n0, np.int64), np.ones(n1, np.int64)]))
+    feat = t(S.uniform(40, 'f', (n0 + n1, 6)))
+    label = t(S.integers(40, 'y', (n0 + n1,), 0, 5))
+    data = crfconv_amd.Data(pos=pos, x=feat, batch=batch, norm=feat[:, 3:], category=t(np.array([3, 7])))
+    for net in (models.CRFSegNet(6, 5, steps=2), models.BaselineSegNet(6, 5), models.CRFSegNet_Part(6, 5, steps=1)):
+        net = net.to(DEV).train()
+        out = net(data)
+        assert out.shape == (n0 + n1, 5)
+        assert torch.isfinite(out).all()
+        assert torch.allclose(out.exp().sum(1), torch.ones(n0 + n1, device=DEV), atol=1e-4)
+        loss = torch.nn.functional.nll_loss(out, label)
+        loss.backward()
+        missing = [k for k, p in net.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+        assert not missing, missing
+        assert any(float(p.grad.abs().max()) > 0 for p in net.parameters())
