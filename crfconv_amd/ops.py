@@ -114,11 +114,33 @@ class _SpdInverse(torch.autograd.Function):
 _CRF_H = (4, 8, 16, 32, 64)
 
 
+def _meanfield_wide(z, y, Q, C, table, steps, k0):
+    """H > 64 (the 128/256-channel decoder stages of the sparse networks, which sit on the 1/16 and 1/64 point sets):
+    the P/Q tiles of csrc/crf.hip no longer fit LDS, so the same recurrence runs as device GEMMs around a gather
+    over the padded neighbour table.  Still GPU-only; table entries < 0 mean "no neighbour"."""
+    require_gpu(z)
+    j = table.idx32.long()
+    have = j >= 0
+    have[:, :k0] = False
+    j = j.clamp_min(0)
+    d = ((y.unsqueeze(1) - y[j]) ** 2).sum(-1).masked_fill(~have, float('inf'))
+    s = torch.softmax(-d, dim=1).masked_fill(~have, 0.0)      # rows without neighbours: softmax gives nan -> 0
+    s = s.unsqueeze(-1)
+    P = C @ Q
+    zq = z @ Q
+    x = z
+    for _ in range(steps):
+        x = zq + (s * x[j]).sum(1) @ P
+    return x
+
+
 def crf_meanfield(z, y, c, table, steps, k0=1):
     """z, y: [m, H] (flattened clouds);  c: [H, H] compatibility factor (C = c^T c)."""
     H = z.shape[-1]
     eye = torch.eye(H, dtype=c.dtype, device=c.device)
     C = c.t() @ c
+    if H > _CRF_H[-1]:
+        return _meanfield_wide(z, y, torch.linalg.inv(eye + C), C, table, steps, k0)
     Q = _SpdInverse.apply(eye + C)             # loop-invariant: computed once, not per step
     P = C @ Q
     Hp = _next_supported(H, _CRF_H)

@@ -177,3 +177,26 @@ def test_sparse_networks_run_and_train():
         missing = [k for k, p in net.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
         assert not missing, missing
         assert any(float(p.grad.abs().max()) > 0 for p in net.parameters())
+
+
+@pytest.mark.parametrize('H', [128, 256])
+def test_sparse_meanfield_wide_channels(H):
+    """H > 64 (sparse decoder stages): GEMM + gather path against the oracle, forward and gradients, with isolated
+    nodes in the graph."""
+    from crfconv_amd import ops
+    from crfconv_amd.graph import table_from_edges
+    N, E = 300, 2400
+    z = t(S.uniform(H, 'z', (N, H))).requires_grad_()
+    y = t(S.uniform(H, 'y', (N, H)) * 0.2).requires_grad_()
+    c = (torch.eye(H) * 0.5 + t(S.uniform(H, 'c', (H, H))).cpu() * 0.02).to(DEV).requires_grad_()
+    pairs = np.unique(np.stack([S.integers(H, 'tg', (E,), 0, N - 20), S.integers(H, 'sr', (E,), 0, N)], 1), axis=0)
+    tgt, src = t(pairs[:, 0].astype(np.int64)), t(pairs[:, 1].astype(np.int64))
+    g = t(S.uniform(H, 'g', (N, H)))
+    out = ops.crf_meanfield(z, y, c, table_from_edges(tgt, src, N, N), 2, k0=0)
+    (out * g).sum().backward()
+    zc, yc, cc = (v.detach().cpu().requires_grad_() for v in (z, y, c))
+    ref = O.sparse_crf_meanfield(zc, yc, tgt.cpu(), src.cpu(), cc, 2)
+    (ref * g.cpu()).sum().backward()
+    assert_close(out, ref, 1e-4, 'wide forward')
+    for name, a, b in (('dz', z, zc), ('dy', y, yc), ('dc', c, cc)):
+        assert_close(a.grad, b.grad, 2e-4, name)
