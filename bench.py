@@ -174,10 +174,13 @@ def main():
             p.grad = v
         opt.step()
 
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()
+
     def collective():
-        if world > 1:
+        if grouped:
             torch.distributed.all_reduce(bucket.flat, op=torch.distributed.ReduceOp.SUM)
-            bucket.flat.div_(world)
+            if world > 1:
+                bucket.flat.div_(world)
 
     def step():
         loss = part_a()
@@ -186,7 +189,8 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        torch.cuda.synchronize()
+        if grouped:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -201,9 +205,9 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with torch.cuda.graph(ga, capture_error_mode='thread_local'):       # RCCL's watchdog thread keeps polling events
                 static_loss = part_a()
-            with torch.cuda.graph(gb, pool=ga.pool()):
+            with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode='thread_local'):
                 part_b()
 
             def step():                                   # noqa: F811
@@ -225,7 +229,7 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -252,7 +256,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(data, net, T, data.y, n_cls)
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -13,7 +13,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    backend = backend or os.environ.get('CRFCONV_DIST_BACKEND')       # e.g. gloo: several ranks sharing one GPU in tests
+    if backend == 'gloo' and torch.cuda.is_available():
+        local %= torch.cuda.device_count()
+    # under torchrun (WORLD_SIZE exported) the group is created even for one rank: same code path at every N
+    if (world > 1 or 'WORLD_SIZE' in os.environ) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
