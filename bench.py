@@ -134,7 +134,7 @@ def main():
 
     import crfconv_amd
     from crfconv_amd import distributed as D
-    from crfconv_amd import models
+    from crfconv_amd import models, ops
 
     rank, world, local = D.init_from_env()
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
@@ -164,7 +164,7 @@ def main():
         for p in bucket.params:
             p.grad = None
         logits = net(data)
-        loss = torch.nn.functional.cross_entropy(logits, data.y.reshape(-1) - 1, weight=cw, ignore_index=-1)
+        loss = ops.training_loss(logits, data.y, cw, ignore_index=-1)          # trainval.py:101-104, fused kernel
         loss.backward()
         torch._foreach_copy_(bucket.views, [p.grad for p in bucket.params])
         return loss.detach()

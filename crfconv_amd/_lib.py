@@ -42,6 +42,8 @@ SIGNATURES = {
     'crfconv_pointconv_bwd_params': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_bwd_dump': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'crfconv_pointconv_bwd_a1_workspace': (_sz, [_i64, _i]),
+    'crfconv_pointconv_bwd_a1': (_i, [_vp, _vp, _vp, _i64, _i, _f, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_bwd_input': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_fold1': (_i, [_vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_fold1_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
@@ -57,6 +59,9 @@ SIGNATURES = {
     'crfconv_linear_forward_stat_records': (_sz, [_i64]),
     'crfconv_linear_forward': (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     'crfconv_bn_coef_from_records': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
+    'crfconv_softmax_ce_workspace': (_sz, [_i64]),
+    'crfconv_softmax_ce_forward': (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_softmax_ce_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _vp, _vp]),
     'crfconv_spd_inverse': (_i, [_vp, _i, _vp, _vp]),
     'crfconv_neighbor_maxpool_forward': (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp]),
     'crfconv_neighbor_maxpool_backward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),

@@ -10,6 +10,7 @@
 // (3 -> d) is computed per lane for its own quad; layer 2 (d -> d) broadcasts h1 over the L lanes
 // with shuffles against float4 rows of W2^T (registers for d <= 16, LDS above).
 #include "common.hpp"
+#include <algorithm>
 
 namespace crf {
 
@@ -617,6 +618,46 @@ __global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------ backward pass 2b for wide layers
+// dA1 | db1 of the dumped path: gp = (g_h2 W2) * lrelu'(h1) per edge, then the four float64 column sums
+// sum_e gp[e,c] * {rel_x, rel_y, rel_z, 1}.  gw = g_h2 W2 arrives from a dense GEMM; this is one streaming
+// pass over gw / h1 / rel (the float64 elementwise + reduction launches it replaces cost 0.6 ms a step).
+template <int D>
+__global__ __launch_bounds__(256) void a1_reduce_kernel(const float* __restrict__ gw,
+                                                        const float* __restrict__ h1,
+                                                        const float* __restrict__ rel, int64_t E, float slope,
+                                                        double* __restrict__ partial_d) {
+    constexpr int L = D / 4, RPB = 256 / L;
+    __shared__ double s_acc[256 * 16];
+    const int q = threadIdx.x % L, rl = threadIdx.x / L;
+    double acc[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[c][t] = 0.0;
+    for (int64_t r = (int64_t)blockIdx.x * RPB + rl; r < E; r += (int64_t)gridDim.x * RPB) {
+        const float4 a = ld4(gw + r * D + 4 * q), h = ld4(h1 + r * D + 4 * q);
+        const double rx = rel[3 * r], ry = rel[3 * r + 1], rz = rel[3 * r + 2];
+        const float gp[4] = {a.x * (h.x > 0.f ? 1.f : slope), a.y * (h.y > 0.f ? 1.f : slope),
+                             a.z * (h.z > 0.f ? 1.f : slope), a.w * (h.w > 0.f ? 1.f : slope)};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double v = gp[c];
+            acc[c][0] += v * rx; acc[c][1] += v * ry; acc[c][2] += v * rz; acc[c][3] += v;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s_acc[rl * (4 * D) + (4 * q + c) * 4 + t] = acc[c][t];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 4 * D; t += 256) {
+        double a = 0.0;
+        for (int i = 0; i < RPB; ++i) a += s_acc[i * (4 * D) + t];
+        partial_d[(int64_t)blockIdx.x * 4 * D + t] = a;        // [channel][x, y, z, bias]
+    }
+}
+
 // ------------------------------------------------------------------ backward: input features
 template <int D>
 __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restrict__ gout,
@@ -852,6 +893,34 @@ extern "C" int crfconv_pointconv_bwd_dump(const float* x, const float* gout, con
         hipLaunchKernelGGL(bwd_dump_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, as_stream(stream), x, gout,
                            pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, h1, gh2, rel);
     });
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" size_t crfconv_pointconv_bwd_a1_workspace(int64_t n_edges, int d) {
+    if (n_edges <= 0 || d < 32) return 0;
+    const int64_t nblk = std::min<int64_t>(1024, cdiv(n_edges, 256 / (d / 4) * 8));
+    return sizeof(double) * 4 * (size_t)d * (size_t)nblk + 256;
+}
+
+extern "C" int crfconv_pointconv_bwd_a1(const float* gw, const float* h1, const float* rel, int64_t n_edges, int d,
+                                        float slope, double* dA1b1, void* workspace, size_t workspace_bytes,
+                                        crf_stream_t stream) {
+    CRF_REQUIRE(gw && h1 && rel && dA1b1 && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(d == 32 || d == 64 || d == 128, CRF_ERR_UNSUPPORTED, "d=%d not in {32, 64, 128} (d <= 16 reduces in crfconv_pointconv_bwd_params)", d);
+    CRF_REQUIRE(n_edges > 0 && n_edges < ((int64_t)1 << 31), CRF_ERR_ARG, "n_edges=%lld out of range", (long long)n_edges);
+    CRF_REQUIRE(workspace_bytes >= crfconv_pointconv_bwd_a1_workspace(n_edges, d), CRF_ERR_WORKSPACE, "workspace too small");
+    const int64_t nblk = std::min<int64_t>(1024, cdiv(n_edges, 256 / (d / 4) * 8));
+    double* partial_d = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    hipStream_t st = as_stream(stream);
+    switch (d) {
+        case 32: hipLaunchKernelGGL(a1_reduce_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, st, gw, h1, rel, n_edges, slope, partial_d); break;
+        case 64: hipLaunchKernelGGL(a1_reduce_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, st, gw, h1, rel, n_edges, slope, partial_d); break;
+        default: hipLaunchKernelGGL(a1_reduce_kernel<128>, dim3((unsigned)nblk), dim3(256), 0, st, gw, h1, rel, n_edges, slope, partial_d); break;
+    }
+    CRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_partials_d_kernel, dim3((unsigned)cdiv(4 * d, 256 / WAVE)), dim3(256), 0, st, partial_d,
+                       nblk, 4 * d, dA1b1);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

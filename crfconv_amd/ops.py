@@ -356,6 +356,56 @@ def neighbor_maxpool(x, table):
     return out[:, :C] if Cp != C else out
 
 
+# ------------------------------------------------------------------------------ training loss
+class _SoftmaxCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, weight, ignore_index, label_shift):
+        require_gpu(logits, target)
+        z = _f32c(logits)
+        tgt = target.reshape(-1)
+        if tgt.dtype != torch.int64:
+            tgt = tgt.long()
+        tgt = tgt.contiguous()
+        m, C = z.shape
+        if tgt.numel() != m:
+            raise _lib.CrfConvError('cross_entropy: %d targets for %d rows' % (tgt.numel(), m))
+        w = None if weight is None else _f32c(weight)
+        if w is not None and w.numel() != C:
+            raise _lib.CrfConvError('cross_entropy: %d class weights for %d classes' % (w.numel(), C))
+        dev = z.device
+        lse = torch.empty(m, dtype=torch.float32, device=dev)
+        sums = torch.empty(3, dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        nbytes = _lib.load().crfconv_softmax_ce_workspace(m)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.call('crfconv_softmax_ce_forward', ptr(z), ptr(tgt), ptr(w), m, C, int(ignore_index), int(label_shift),
+                  ptr(lse), ptr(sums), ptr(loss), ptr(ws), nbytes, stream_ptr())
+        ctx.save_for_backward(z, tgt, w, lse, sums)
+        ctx.args = (int(ignore_index), int(label_shift))
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        z, tgt, w, lse, sums = ctx.saved_tensors
+        ignore_index, label_shift = ctx.args
+        g = _f32c(gloss).reshape(1)
+        dz = torch.empty_like(z)
+        _lib.call('crfconv_softmax_ce_backward', ptr(z), ptr(tgt), ptr(w), ptr(lse), ptr(sums), ptr(g), z.shape[0],
+                  z.shape[1], ignore_index, label_shift, ptr(dz), stream_ptr())
+        return dz, None, None, None, None
+
+
+def cross_entropy(logits, target, weight=None, ignore_index=-100, label_shift=0):
+    """F.cross_entropy(logits, target - label_shift, weight=weight, ignore_index=ignore_index) (mean reduction) as
+    one fused forward and one backward kernel."""
+    return _SoftmaxCE.apply(logits, target, weight, ignore_index, label_shift)
+
+
+def training_loss(logits, labels, class_weights=None, ignore_index=-1):
+    """trainval.py:101-104: labels are 1-based (0 = unlabeled -> class -1 = ignore_index after the shift)."""
+    return cross_entropy(logits, labels, class_weights, ignore_index, label_shift=1)
+
+
 # ------------------------------------------------------------------------------ PointConv
 def relpos_moments(pos_src, pos_tgt, table):
     """(mean [3], covariance [3,3], edge count) of rel = p_tgt[i] - p_src[j] over all edges, float64."""
@@ -461,11 +511,12 @@ class _PointConv(torch.autograd.Function):
             wbytes = _lib.load().crfconv_linear_wgrad_workspace(E, d, d)
             wws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
             _lib.call('crfconv_linear_wgrad', ptr(gh2), ptr(h1), E, d, d, ptr(dW2), None, ptr(wws), wbytes, st)
-            gpd = ((gh2 @ W2) * torch.where(h1 > 0, 1.0, slope)).double()
-            reld = rel.double()
-            # float64 sums as column reductions (a float64 GEMM of this shape takes rocBLAS ~0.7 ms)
-            dA1b1 = torch.stack([(gpd * reld[:, 0:1]).sum(0), (gpd * reld[:, 1:2]).sum(0), (gpd * reld[:, 2:3]).sum(0),
-                                 gpd.sum(0)], dim=1).contiguous()
+            gw = gh2 @ W2                                                  # g_h1 before the LeakyReLU mask
+            dA1b1 = torch.empty((d, 4), dtype=torch.float64, device=dev)
+            abytes = _lib.load().crfconv_pointconv_bwd_a1_workspace(E, d)
+            aws = torch.empty(abytes, dtype=torch.uint8, device=dev)
+            _lib.call('crfconv_pointconv_bwd_a1', ptr(gw), ptr(h1), ptr(rel), E, d, slope, ptr(dA1b1), ptr(aws), abytes,
+                      st)
         dW1 = torch.empty((d, 3), dtype=torch.float32, device=dev)
         dg1 = torch.empty(d, dtype=torch.float32, device=dev)
         dbe1 = torch.empty(d, dtype=torch.float32, device=dev)
@@ -514,4 +565,5 @@ def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=
                             state(bn1), state(bn2), float(slope))
 
 
-__all__ = ['linear', 'bn_act', 'crf_meanfield', 'gather_rows', 'neighbor_maxpool', 'relpos_moments', 'point_conv', 'NeighborTable']
+__all__ = ['linear', 'bn_act', 'crf_meanfield', 'gather_rows', 'neighbor_maxpool', 'relpos_moments', 'point_conv', 'cross_entropy', 'training_loss',
+           'NeighborTable']

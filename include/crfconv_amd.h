@@ -202,6 +202,12 @@ int crfconv_pointconv_bwd_dump(const float* x, const float* gout, const float* p
                                const float* A1, const float* b1, const float* W2, float slope, const float* ca,
                                const float* cb, const float* cc, float* h1, float* gh2, float* rel,
                                crf_stream_t stream);
+/* Wide-layer dA1 | db1 from the dumped tensors: with gw = g_h2 W2 [E, d] (a dense GEMM of the caller),
+ *   dA1b1[c] = sum_e gw[e,c] * lrelu'(h1[e,c]) * {rel_x, rel_y, rel_z, 1}     float64 [d, 4],  d in {32, 64, 128}. */
+size_t crfconv_pointconv_bwd_a1_workspace(int64_t n_edges, int d);
+int crfconv_pointconv_bwd_a1(const float* gw, const float* h1, const float* rel, int64_t n_edges, int d,
+                             float slope, double* dA1b1, void* workspace, size_t workspace_bytes,
+                             crf_stream_t stream);
 /* dx[j,c] = sum_{e=(i,k) in rev(j)} w_e[c] * gout[i,c]   (weight MLP recomputed per incoming edge). */
 int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const float* pos_tgt,
                                 const int32_t* rev_ptr, const int32_t* rev_eid, int K,
@@ -288,6 +294,22 @@ int crfconv_gather_rows(const float* x, const int32_t* idx32, int64_t m_tgt, int
 int crfconv_gather_rows_backward(const float* gout, const int32_t* rev_ptr,
                                  const int32_t* rev_eid, int64_t m_src, int C, float* dx,
                                  crf_stream_t stream);
+
+/* ===================================================================== (B) training loss
+ * Replaces trainval.py:101-104: F.cross_entropy(y_pred, data.y.reshape(-1) - 1, weight=class_weights,
+ * ignore_index=ignore).  logits [m, C] float32; target [m] int64, the class of row r is target[r] - label_shift
+ * (label_shift = 1 folds the reference's "- 1" into the kernel); weight [C] float32 or NULL.
+ *   loss = sum_r w[t_r] (lse_r - logits[r, t_r]) / sum_r w[t_r]   over rows with t_r != ignore_index
+ * Outputs: lse [m] (kept for the backward), sums [3] float64 = {sum w*nll, sum w, rows whose class is outside
+ * [0, C) and not ignore_index -- counted, contribute nothing}, loss [1] float32 (device).
+ * Backward: dlogits[r,c] = grad_loss[0] * w[t_r] * (softmax(logits[r])[c] - [c == t_r]) / sums[1]. */
+size_t crfconv_softmax_ce_workspace(int64_t m);
+int crfconv_softmax_ce_forward(const float* logits, const int64_t* target, const float* weight, int64_t m, int C,
+                               int64_t ignore_index, int64_t label_shift, float* lse, double* sums, float* loss,
+                               void* workspace, size_t workspace_bytes, crf_stream_t stream);
+int crfconv_softmax_ce_backward(const float* logits, const int64_t* target, const float* weight, const float* lse,
+                                const double* sums, const float* grad_loss, int64_t m, int C, int64_t ignore_index,
+                                int64_t label_shift, float* dlogits, crf_stream_t stream);
 
 #ifdef __cplusplus
 }

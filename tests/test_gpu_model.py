@@ -411,3 +411,38 @@ def test_linear_forward_mfma_and_fused_stats(M, Ci, Co, bias):
         out = ops.bn_act(y.detach(), bn, True, 1.0, records=rec)
         assert_close(out, ref(yr), 1e-5, 'BN from records')
         assert_close(bn.running_var, ref.running_var, 1e-6, 'running_var from records')
+
+
+@pytest.mark.parametrize('weighted', [True, False])
+def test_training_loss_matches_oracle(weighted):
+    """trainval.py:101-104: weighted CE over 1-based labels with 0 = unlabeled (ignored)."""
+    from crfconv_amd import ops
+    m, C = 5000, 13
+    logits = t(S.uniform(7, 'logits', (m, C)) * 6).requires_grad_()
+    labels = t(S.integers(7, 'labels', (m,), 0, C + 1))                       # 0 -> ignored
+    w = t(np.abs(S.uniform(7, 'w', (C,))) + 0.2) if weighted else None
+    loss = ops.training_loss(logits, labels, w, ignore_index=-1)
+    (loss * 1.7).backward()
+    lc = logits.detach().cpu().requires_grad_()
+    ref = O.training_loss(lc, labels.cpu(), None if w is None else w.cpu(), -1)
+    (ref * 1.7).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    assert_close(logits.grad, lc.grad, 1e-5, 'dlogits')
+    assert float(logits.grad[labels == 0].abs().max()) == 0.0                 # ignored rows get no gradient
+
+
+def test_cross_entropy_edge_cases():
+    from crfconv_amd import ops
+    from crfconv_amd._lib import CrfConvError
+    z = t(S.uniform(8, 'z', (300, 5)))
+    y = t(S.integers(8, 'y', (300,), 0, 5))
+    ref = torch.nn.functional.cross_entropy(z.cpu(), y.cpu())
+    assert abs(float(ops.cross_entropy(z, y)) - float(ref)) < 1e-6
+    # every row ignored -> nan, like the framework
+    assert torch.isnan(ops.cross_entropy(z, torch.full_like(y, -100)))
+    # one row
+    assert abs(float(ops.cross_entropy(z[:1], y[:1])) - float(torch.nn.functional.cross_entropy(z[:1].cpu(), y[:1].cpu()))) < 1e-6
+    with pytest.raises(CrfConvError):
+        ops.cross_entropy(z, y[:10])
+    with pytest.raises(CrfConvError):
+        ops.cross_entropy(z.cpu(), y.cpu())
