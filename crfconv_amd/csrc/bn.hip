@@ -25,12 +25,21 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(const float* __restr
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     if (rl < rpi) {
         const float4 sh = ld4g(x + 4 * q);
-        for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < M; r += (int64_t)gridDim.x * rpi) {
-            const float4 v = ld4g(x + r * C + 4 * q);
+        auto add = [&](const float4 v) {
             const float4 d = make_float4(v.x - sh.x, v.y - sh.y, v.z - sh.z, v.w - sh.w);
             s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
             s2.x = fmaf(d.x, d.x, s2.x); s2.y = fmaf(d.y, d.y, s2.y); s2.z = fmaf(d.z, d.z, s2.z); s2.w = fmaf(d.w, d.w, s2.w);
+        };
+        const int64_t stride = (int64_t)gridDim.x * rpi;
+        int64_t r = (int64_t)blockIdx.x * rpi + rl;
+        for (; r + 3 * stride < M; r += 4 * stride) {            // four rows in flight per thread
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ld4g(x + (r + u * stride) * C + 4 * q);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(v[u]);
         }
+        for (; r < M; r += stride) add(ld4g(x + r * C + 4 * q));
         st4(sred + (rl * 2 + 0) * C + 4 * q, s1);
         st4(sred + (rl * 2 + 1) * C + 4 * q, s2);
     }
@@ -129,9 +138,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(const float* __
     if (rl < rpi) {
         const float4 a = ld4g(coef + 4 * q), b = ld4g(coef + C + 4 * q);
         const float4 mu = ld4g(coef + 2 * C + 4 * q), rs = ld4g(coef + 3 * C + 4 * q);
-        for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < M; r += (int64_t)gridDim.x * rpi) {
-            const float4 v = ld4g(x + r * C + 4 * q);
-            float4 g = ld4g(gy + r * C + 4 * q);
+        auto add = [&](const float4 v, float4 g) {
             g.x *= fmaf(a.x, v.x, b.x) > 0.f ? 1.f : slope;
             g.y *= fmaf(a.y, v.y, b.y) > 0.f ? 1.f : slope;
             g.z *= fmaf(a.z, v.z, b.z) > 0.f ? 1.f : slope;
@@ -141,7 +148,20 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(const float* __
             s2.y = fmaf(g.y, (v.y - mu.y) * rs.y, s2.y);
             s2.z = fmaf(g.z, (v.z - mu.z) * rs.z, s2.z);
             s2.w = fmaf(g.w, (v.w - mu.w) * rs.w, s2.w);
+        };
+        const int64_t stride = (int64_t)gridDim.x * rpi;
+        int64_t r = (int64_t)blockIdx.x * rpi + rl;
+        for (; r + 3 * stride < M; r += 4 * stride) {            // four rows (eight 16-byte loads) in flight per thread
+            float4 v[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = ld4g(x + (r + u * stride) * C + 4 * q);
+                g[u] = ld4g(gy + (r + u * stride) * C + 4 * q);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(v[u], g[u]);
         }
+        for (; r < M; r += stride) add(ld4g(x + r * C + 4 * q), ld4g(gy + r * C + 4 * q));
         st4(sred + (rl * 2 + 0) * C + 4 * q, s1);
         st4(sred + (rl * 2 + 1) * C + 4 * q, s2);
     }
@@ -215,8 +235,8 @@ static int bn_check(int64_t M, int C) {
 
 static int bn_nblk(int64_t M, int C) {
     const int rpi = BN_BLOCK / (C / 4);
-    // at least ~16 rows per thread before paying for another partial
-    int64_t nb = (M + 16 * (int64_t)rpi - 1) / (16 * (int64_t)rpi);
+    // ~8 rows per thread (two unrolled trips of four) before paying for another partial
+    int64_t nb = (M + 8 * (int64_t)rpi - 1) / (8 * (int64_t)rpi);
     if (nb < 1) nb = 1;
     return (int)(nb > BN_MAXBLK ? BN_MAXBLK : nb);
 }

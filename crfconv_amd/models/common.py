@@ -19,8 +19,8 @@ class FastBatchNorm1d(nn.Module):
         bn = self.batch_norm
         shape = x.shape
         use_batch = self.training or bn.running_mean is None
-        if self.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+        if self.training:
+            ops.tick(bn)
         y = F.batch_norm(x.reshape(-1, shape[-1]), bn.running_mean, bn.running_var, bn.weight, bn.bias,
                          use_batch, bn.momentum, bn.eps)
         return y.reshape(shape)

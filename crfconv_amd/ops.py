@@ -234,6 +234,50 @@ def linear(x, W, b=None, want_stats=False):
     return out.reshape(shape[:-1] + (W.shape[0],))
 
 
+# ------------------------------------------------------------------------------ BatchNorm step counters
+_COUNTERS_ADVANCED = False
+
+
+def tick(bn):
+    """num_batches_tracked += 1 of one BatchNorm (torch.nn.BatchNorm1d.forward does this in training)."""
+    if not _COUNTERS_ADVANCED and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+
+
+class advance_counters:
+    """``with advance_counters(model):`` around a training forward: the num_batches_tracked buffers of every
+    BatchNorm in `model` become views of one int64 vector that advances with a single launch (71 one-element
+    launches a step for PointConvBig otherwise).  state_dict keys, shapes and values are unchanged."""
+
+    def __init__(self, module):
+        self.module = module
+
+    def __enter__(self):
+        global _COUNTERS_ADVANCED
+        mod = self.module
+        cache = mod.__dict__.get('_bn_counter_cache')
+        if cache is None:
+            bns = [m for m in mod.modules()
+                   if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None]
+            cache = mod.__dict__['_bn_counter_cache'] = [bns, None]
+        bns, flat = cache
+        if bns:
+            last = bns[-1].num_batches_tracked
+            if flat is None or last.device != flat.device or last.data_ptr() != flat[-1].data_ptr():
+                flat = cache[1] = torch.stack([b.num_batches_tracked.reshape(()) for b in bns])
+                for i, b in enumerate(bns):
+                    b._buffers['num_batches_tracked'] = flat[i]
+            flat += 1
+        self.prev = _COUNTERS_ADVANCED
+        _COUNTERS_ADVANCED = True
+        return self
+
+    def __exit__(self, *exc):
+        global _COUNTERS_ADVANCED
+        _COUNTERS_ADVANCED = self.prev
+        return False
+
+
 # ------------------------------------------------------------------------------ BatchNorm (+ LeakyReLU)
 class _BNAct(torch.autograd.Function):
     """y = lrelu(BatchNorm(x), slope) over rows [m, C]: one stats pass + one fused apply pass forward, one
@@ -281,8 +325,8 @@ def bn_act(x, bn, training, slope=1.0, records=None):
     shape = x.shape
     C = shape[-1]
     use_batch = training or bn.running_mean is None
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if training:
+        tick(bn)
     mom = 0.1 if bn.momentum is None else bn.momentum
     y = _BNAct.apply(x.reshape(-1, C), bn.weight, bn.bias, bn.running_mean if (training or not use_batch) else None,
                      bn.running_var if (training or not use_batch) else None, mom, bn.eps, use_batch, slope, records)
@@ -555,8 +599,8 @@ def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=
 
     def state(bn):
         use_batch = training or bn.running_mean is None
-        if training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+        if training:
+            tick(bn)
         upd = training and bn.running_mean is not None
         keep = upd or not use_batch
         return (use_batch, bn.running_mean if keep else None, bn.running_var if keep else None,

@@ -446,3 +446,20 @@ def test_cross_entropy_edge_cases():
         ops.cross_entropy(z, y[:10])
     with pytest.raises(CrfConvError):
         ops.cross_entropy(z.cpu(), y.cpu())
+
+
+@pytest.mark.parametrize('H', [1, 5, 8, 13, 16, 32, 47, 64])
+def test_spd_inverse(H):
+    """(I + c^T c)^-1 on one workgroup (continuous_crf_conv_big.py:72) against float64 LAPACK, plus its gradient."""
+    from crfconv_amd import ops
+    c = S.uniform(H, 'c', (H, H)).astype(np.float64) * 0.7 + np.eye(H)
+    M = np.eye(H) + c.T @ c
+    Mt = t(M.astype(np.float32)).requires_grad_()
+    Q = ops._SpdInverse.apply(Mt)
+    ref = np.linalg.inv(M.astype(np.float32).astype(np.float64))
+    assert_close(Q, torch.from_numpy(ref).float(), 2e-6, 'Q')
+    g = S.uniform(H, 'g', (H, H))
+    (Q * t(g)).sum().backward()
+    assert_close(Mt.grad, torch.from_numpy(-(ref.T @ g.astype(np.float64) @ ref.T)).float(), 1e-5, 'dM')
+    with pytest.raises(Exception):
+        ops._SpdInverse.apply(torch.eye(65, device=DEV))

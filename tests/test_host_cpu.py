@@ -134,3 +134,28 @@ def test_sharded_grad_allreduce_equals_big_batch(tmp_path):
     g0, g1, ref = (torch.load(str(tmp_path / ('g.' + s))) for s in ('0', '1', 'ref'))
     assert torch.equal(g0, g1)                                   # replicas hold identical averaged grads
     assert float((g0 - ref).abs().max()) < 1e-6                  # == gradient of the un-sharded batch
+
+
+def test_bn_counters_advance_as_one_vector():
+    """ops.advance_counters: num_batches_tracked of all BatchNorms advance by one per training forward, survive
+    state_dict round trips and module._apply (which breaks the shared storage and must be re-detected)."""
+    import torch
+    from crfconv_amd import ops
+    net = torch.nn.Sequential(torch.nn.BatchNorm1d(4), torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4))
+    net[2].num_batches_tracked += 5
+    for expect in (1, 2):
+        with ops.advance_counters(net):
+            ops.tick(net[0])                                   # inside the context the per-layer tick is a no-op
+        assert int(net[0].num_batches_tracked) == expect and int(net[2].num_batches_tracked) == 5 + expect
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    assert sd['0.num_batches_tracked'].shape == () and int(sd['2.num_batches_tracked']) == 7
+    net = net.double()                                         # _apply re-creates the buffers one by one
+    with ops.advance_counters(net):
+        pass
+    assert int(net[0].num_batches_tracked) == 3 and int(net[2].num_batches_tracked) == 8
+    net.load_state_dict(sd)
+    with ops.advance_counters(net):
+        pass
+    assert int(net[0].num_batches_tracked) == 3 and int(net[2].num_batches_tracked) == 8
+    ops.tick(net[0])
+    assert int(net[0].num_batches_tracked) == 4
