@@ -41,28 +41,34 @@ __global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict
 
     const int64_t row_begin = (int64_t)blockIdx.x * rows_per_block;
     const int64_t row_end = row_begin + rows_per_block < M ? row_begin + rows_per_block : M;
-    // waves interleave 4-row k-steps inside the block's slice
-    for (int64_t r0 = row_begin + 4 * wave; r0 < row_end; r0 += 4 * WG_WAVES) {
-        const int64_t r = r0 + kk;
-        const bool rv = r < row_end;
-        float av[TCO], bv[TCI];
+    // waves interleave 16-row groups (4 k-steps) inside the block's slice; all operand loads of a group are issued
+    // before its MFMAs, so each lane keeps 4 (TCO + TCI) dword loads in flight
+    for (int64_t r0 = row_begin + 16 * wave; r0 < row_end; r0 += 16 * WG_WAVES) {
+        float av[4][TCO], bv[4][TCI];
 #pragma unroll
-        for (int a = 0; a < TCO; ++a) {
-            const int co = co_base + 16 * a + cc;
-            av[a] = (rv && co < Co) ? G[r * Co + co] : 0.f;
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = r0 + 4 * u + kk;
+            const bool rv = r < row_end;
+#pragma unroll
+            for (int a = 0; a < TCO; ++a) {
+                const int co = co_base + 16 * a + cc;
+                av[u][a] = (rv && co < Co) ? G[r * Co + co] : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < TCI; ++b) {
+                const int ci = ci_base + 16 * b + cc;
+                bv[u][b] = (rv && ci < Ci) ? X[r * Ci + ci] : 0.f;
+            }
         }
 #pragma unroll
-        for (int b = 0; b < TCI; ++b) {
-            const int ci = ci_base + 16 * b + cc;
-            bv[b] = (rv && ci < Ci) ? X[r * Ci + ci] : 0.f;
-        }
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int a = 0; a < TCO; ++a) {
-            bsum[a] += av[a];
+            for (int a = 0; a < TCO; ++a) {
+                bsum[a] += av[u][a];
 #pragma unroll
-            for (int b = 0; b < TCI; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-        }
+                for (int b = 0; b < TCI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+            }
     }
     // C/D layout of 16x16x4: col = lane & 15 (j = ci), row = 4 * (lane >> 4) + reg (i = co)
     __shared__ float s_red[WG_WAVES][TCO * TCI * 256];
@@ -124,11 +130,14 @@ static WgPlan wg_plan(int64_t M, int Co, int Ci) {
     p.tci = t_ci >= 4 ? 4 : (t_ci >= 2 ? 2 : 1);
     p.gy = (t_co + p.tco - 1) / p.tco;
     p.gz = (t_ci + p.tci - 1) / p.tci;
-    // ~256 row-slices over the chip (x gy x gz output slabs), at least 64 rows (4 k-steps per wave) each:
-    // the partial slabs the second kernel sums stay a small fraction of the operand bytes
-    int64_t rows = (M + 255) / 256;
+    // ~512 workgroups over the chip = row-slices x (gy x gz output slabs); at least 32 slices, at least 64 rows
+    // (one 16-row group per wave) each: the partial slabs the second kernel sums stay a small fraction of the
+    // operand bytes
+    int64_t slices = 512 / ((int64_t)p.gy * p.gz);
+    if (slices < 32) slices = 32;
+    int64_t rows = (M + slices - 1) / slices;
     if (rows < 64) rows = 64;
-    rows = (rows + 15) / 16 * 16;
+    rows = (rows + 63) / 64 * 64;
     p.rows_per_block = (int)rows;
     p.nblk = (int)((M + rows - 1) / rows);
     return p;
@@ -266,7 +275,7 @@ template <int TCO>  // 16 * TCO output channels per block slab (blockIdx.y picks
 __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                               const float* __restrict__ bias, int64_t M, int Ci, int Co,
                                                               int transpose_w, float* __restrict__ Y,
-                                                              float* __restrict__ stat_partial /*[nblk][4][Co] or null*/) {
+                                                              float* __restrict__ stat_partial /*[nblk][Co][4] or null*/) {
     extern __shared__ float sW[];                 // [16*TCO][Cip]
     const int Cip = ((Ci + 15) / 16) * 16 + 4;
     const int co_base = blockIdx.y * 16 * TCO;
@@ -416,59 +425,62 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
                 S1 += a + nb * d;
                 S2 += b + 2.0 * d * a + nb * d * d;
             }
-            float* p = stat_partial + (int64_t)blockIdx.x * 4 * Co;
-            p[co] = s0;
-            p[Co + co] = (float)n;
-            p[2 * Co + co] = (float)S1;
-            p[3 * Co + co] = (float)S2;
+            // record layout [block][channel][4]: one aligned 16-byte tuple per (block, channel)
+            *reinterpret_cast<float4*>(stat_partial + ((int64_t)blockIdx.x * Co + co) * 4) =
+                make_float4(s0, (float)n, (float)S1, (float)S2);
         }
     }
 }
 
-// Combine per-wave {shift, sum, sumsq, (implicit count)} records into BatchNorm coefficients (Chan's parallel
-// variance in float64), same outputs as bn_finalize_kernel.  counts: record r covers rows r*16, r*16 + stride, ...
-__global__ __launch_bounds__(256) void bn_finalize_records_kernel(const float* __restrict__ rec, int nrec, int64_t M,
-                                                                  int C, const float* __restrict__ gamma,
-                                                                  const float* __restrict__ beta, float eps,
-                                                                  float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                                  float momentum, float* __restrict__ coef) {
-    const int c = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (c >= C) return;
-    // records [nrec][4][C] = {shift, n, sum(v - shift), sum (v - shift)^2}; every record is re-based on the shift of
-    // record 0 (a sample value, so |shift - mean| ~ sigma: no cancellation problem in float64)
-    const double s0 = rec[c];
+// Combine the per-block {shift, n, sum, sumsq} records into BatchNorm coefficients (Chan's parallel variance in
+// float64), same outputs as bn_finalize_kernel.  rec [nrec][C][4]: a thread reads whole 16-byte tuples, 16 adjacent
+// channels per record-lane (256 contiguous bytes), 64 record-lanes per workgroup; record-lanes fold by shuffles
+// inside a wavefront and through LDS across the 16 wavefronts, always in the same order.
+constexpr int FR_BLOCK = 1024, FR_CH = 16, FR_RL = FR_BLOCK / FR_CH;
+__global__ __launch_bounds__(FR_BLOCK) void bn_finalize_records_kernel(const float* __restrict__ rec, int nrec, int64_t M,
+                                                                       int C, const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, float eps,
+                                                                       float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                       float momentum, float* __restrict__ coef) {
+    __shared__ double s_red[FR_BLOCK / WAVE][2][FR_CH];
+    const int cl = threadIdx.x & (FR_CH - 1), rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * FR_CH + cl;
+    const bool cv = c < C;
+    const int cc = cv ? c : C - 1;
+    // every record is re-based on the shift of record 0 (a sample value, so |shift - mean| ~ sigma: no cancellation
+    // problem in float64)
+    const double s0 = rec[(int64_t)cc * 4];
     double S1 = 0.0, S2 = 0.0;
-    // 4 records per trip: 16 independent loads in flight per lane (the loop is latency-bound otherwise)
-    for (int r0 = lane; r0 < nrec; r0 += 4 * WAVE) {
-        float v[4][4];
+    for (int r0 = rl; r0 < nrec; r0 += 4 * FR_RL) {       // four tuples in flight per thread
+        float4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int r = r0 + u * WAVE;
-            const float* p = rec + (int64_t)(r < nrec ? r : r0) * 4 * C + c;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[u][k] = p[k * C];
-            if (r >= nrec) v[u][1] = 0.f;
+            const int r = r0 + u * FR_RL;
+            v[u] = r < nrec ? *reinterpret_cast<const float4*>(rec + ((int64_t)r * C + cc) * 4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const double nb = v[u][1];
+            const double nb = v[u].y;
             if (nb > 0.0) {
-                const double d = (double)v[u][0] - s0, a = v[u][2], b = v[u][3];
+                const double d = (double)v[u].x - s0, a = v[u].z, b = v[u].w;
                 S1 += a + nb * d;
                 S2 += b + 2.0 * d * a + nb * d * d;
             }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        S1 += __shfl_xor(S1, o, WAVE);
-        S2 += __shfl_xor(S2, o, WAVE);
-    }
+    // lanes l, l ^ 16, l ^ 32, l ^ 48 of a wavefront hold the same channel
+    S1 += __shfl_xor(S1, 16, WAVE); S2 += __shfl_xor(S2, 16, WAVE);
+    S1 += __shfl_xor(S1, 32, WAVE); S2 += __shfl_xor(S2, 32, WAVE);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < FR_CH) { s_red[wave][0][cl] = S1; s_red[wave][1][cl] = S2; }
+    __syncthreads();
+    if (threadIdx.x >= FR_CH || !cv) return;
+    S1 = 0.0; S2 = 0.0;
+    for (int w = 0; w < FR_BLOCK / WAVE; ++w) { S1 += s_red[w][0][cl]; S2 += s_red[w][1][cl]; }
     const double m1 = S1 / (double)M;
     const double mean = s0 + m1;
     const double m2 = S2 - S1 * m1;
-    if (lane != 0) return;
     double var = m2 / (double)M;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
@@ -503,7 +515,7 @@ extern "C" int crfconv_linear_forward_supported(int Ci, int Co) {
 extern "C" size_t crfconv_linear_forward_stat_records(int64_t M) { return (size_t)crf::lf_blocks(M); }
 
 // Y [M, Co] = X [M, Ci] W^T (+ bias);  W is [Co, Ci] row-major, or [Ci, Co] when transpose_w != 0 (the dX product).
-// stat_rec (may be NULL): float [records][4][Co] receives per-workgroup {shift, n, sum(y - shift), sum (y - shift)^2}.
+// stat_rec (may be NULL): float [records][Co][4] receives per-workgroup {shift, n, sum(y - shift), sum (y - shift)^2}.
 extern "C" int crfconv_linear_forward(const float* X, const float* W, const float* bias, int64_t M, int Ci, int Co,
                                       int transpose_w, float* Y, float* stat_rec, crf_stream_t stream) {
     CRF_REQUIRE(X && W && Y, CRF_ERR_ARG, "null pointer");
@@ -535,7 +547,7 @@ extern "C" int crfconv_bn_coef_from_records(const float* stat_rec, int64_t M, in
     CRF_REQUIRE(stat_rec && gamma && beta && coef, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(M > 0 && C > 0, CRF_ERR_ARG, "bad shape");
     const int nrec = (int)crfconv_linear_forward_stat_records(M);
-    hipLaunchKernelGGL(crf::bn_finalize_records_kernel, dim3((C + 3) / 4), dim3(256), 0, crf::as_stream(stream), stat_rec, nrec,
+    hipLaunchKernelGGL(crf::bn_finalize_records_kernel, dim3((C + crf::FR_CH - 1) / crf::FR_CH), dim3(crf::FR_BLOCK), 0, crf::as_stream(stream), stat_rec, nrec,
                        M, C, gamma, beta, eps, run_mean, run_var, momentum, coef);
     CRF_LAUNCH_CHECK();
     return CRF_OK;

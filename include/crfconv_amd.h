@@ -264,7 +264,7 @@ int crfconv_bn_apply(const float* x, int64_t M, int C, const float* coef, float 
 /* Y [M, Co] = X [M, Ci] W^T (+ bias) on fp32 MFMA, X streamed once, W resident in LDS (needs
  * crfconv_linear_forward_supported(Ci, Co): the <= 128-channel weight slab fits 64 KB).  W is [Co, Ci] row-major, or
  * [Ci, Co] when transpose_w != 0 (the input-gradient product dX = G W).  stat_rec (may be NULL): float
- * [crfconv_linear_forward_stat_records(M)][4][Co] receives per-workgroup {shift, n, sum(y - shift), sum (y - shift)^2},
+ * [crfconv_linear_forward_stat_records(M)][Co][4] receives per-workgroup {shift, n, sum(y - shift), sum (y - shift)^2},
  * from which crfconv_bn_coef_from_records forms the BatchNorm coefficients (coef [4, Co], as crfconv_bn_forward) --
  * the statistics pass over Y disappears. */
 int crfconv_linear_forward_supported(int Ci, int Co);
