@@ -37,6 +37,9 @@ SIGNATURES = {
     'crfconv_pointconv_workspace': (_sz, [_i64, _i, _i]),
     'crfconv_pointconv_moments': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_stats': (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_pointconv_forward_uv': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_pointconv_combine': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    'crfconv_pointconv_bwd_reduce_uv': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_forward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_bwd_reduce': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_bwd_params': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp,

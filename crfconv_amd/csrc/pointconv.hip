@@ -351,6 +351,125 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
     if (rw.valid) st4(out + rw.r * D + 4 * q, acc);
 }
 
+// ------------------------------------------------------------------ training forward: one edge pass
+// BatchNorm-2 is affine per channel, so the convolution separates:
+//   out_i[c] = sum_k (a2 h2_k + b2)[c] x_j[c] = a2[c] U_i[c] + (a2[c] shift[c] + b2[c]) V_i[c],
+//   U_i = sum_k (h2_k - shift) * x_j,   V_i = sum_k x_j.
+// In training a2 / b2 depend on the batch statistics of h2, which needed an edge pass of their own before the
+// convolution pass; this kernel produces U, V AND the statistics partials in ONE pass over the edges, and the
+// convolution finishes with an elementwise combine.  U and V also carry everything BatchNorm-2's backward
+// needs (sum_e g_w = sum_i g_i V_i,  sum_e g_w (h2 - shift) = sum_i g_i U_i): no edge pass there either.
+template <int D>
+__global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ pos_src,
+                                                         const float* __restrict__ pos_tgt,
+                                                         const int32_t* __restrict__ idx, int K,
+                                                         int64_t m_tgt, const float* __restrict__ A1,
+                                                         const float* __restrict__ b1,
+                                                         const float* __restrict__ W2, float slope,
+                                                         const float* __restrict__ mean_rel,
+                                                         float* __restrict__ shift_out,
+                                                         float* __restrict__ U, float* __restrict__ V,
+                                                         float* __restrict__ partial) {
+    constexpr int EB = PC<D>::EB;
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float4 s_scr[PC<D>::SCR_SIZE];
+    __shared__ float sred[PWAVES * 2 * D];
+    int lane, wave, q;
+    const Row rw = my_row<D>(m_tgt, lane, wave, q);
+    EdgeMLP<D> mlp;
+    mlp.init(A1, b1, W2, s_w2t, lane, q, slope);
+    __syncthreads();
+    const float4 shift = mlp.h2_of(mean_rel[0], mean_rel[1], mean_rel[2]);
+    if (blockIdx.x == 0 && threadIdx.x < PC<D>::L) st4(shift_out + 4 * q, shift);
+
+    const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
+    const int32_t* irow = idx + rw.r * K;
+    float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+#pragma unroll 2
+    for (int k0 = 0; k0 < K; k0 += EB) {
+        float4 h1[EB], h2[EB], xj[EB];
+        float live[EB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int jj = (k0 + e < K) ? irow[k0 + e] : -1;
+            const int64_t j = jj < 0 ? 0 : jj;
+            live[e] = (rw.valid && jj >= 0) ? 1.f : 0.f;
+            xj[e] = ld4(x + j * D + 4 * q);
+            if (jj < 0) xj[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 pre;
+            mlp.layer1(px - pos_src[3 * j], py - pos_src[3 * j + 1], pz - pos_src[3 * j + 2], pre, h1[e]);
+        }
+        mlp.layer2_batch(h1, h2, s_scr);
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const float4 dlt = make_float4((h2[e].x - shift.x) * live[e], (h2[e].y - shift.y) * live[e],
+                                           (h2[e].z - shift.z) * live[e], (h2[e].w - shift.w) * live[e]);
+            acc[0].x += dlt.x; acc[0].y += dlt.y; acc[0].z += dlt.z; acc[0].w += dlt.w;
+            acc[1] = make_float4(fmaf(dlt.x, dlt.x, acc[1].x), fmaf(dlt.y, dlt.y, acc[1].y),
+                                 fmaf(dlt.z, dlt.z, acc[1].z), fmaf(dlt.w, dlt.w, acc[1].w));
+            u = make_float4(fmaf(dlt.x, xj[e].x, u.x), fmaf(dlt.y, xj[e].y, u.y), fmaf(dlt.z, xj[e].z, u.z),
+                            fmaf(dlt.w, xj[e].w, u.w));
+            v.x += xj[e].x; v.y += xj[e].y; v.z += xj[e].z; v.w += xj[e].w;
+        }
+    }
+    if (rw.valid) {
+        st4(U + rw.r * D + 4 * q, u);
+        st4(V + rw.r * D + 4 * q, v);
+    }
+    block_reduce_store<D, 2>(acc, sred, partial, lane, wave, q);
+}
+
+// out = a2 U + (a2 shift + b2) V   over [m, d] rows (one thread per 4-channel quad)
+__global__ __launch_bounds__(256) void uv_combine_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                         const float* __restrict__ a2, const float* __restrict__ b2,
+                                                         const float* __restrict__ shift, int64_t n4, int d4,
+                                                         float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n4) return;
+    const int q = (int)(t % d4);
+    const float4 a = ld4(a2 + 4 * q), b = ld4(b2 + 4 * q), sh = ld4(shift + 4 * q);
+    const float4 u = ld4(U + 4 * t), v = ld4(V + 4 * t);
+    st4(out + 4 * t, make_float4(fmaf(a.x, u.x, fmaf(a.x, sh.x, b.x) * v.x), fmaf(a.y, u.y, fmaf(a.y, sh.y, b.y) * v.y),
+                                 fmaf(a.z, u.z, fmaf(a.z, sh.z, b.z) * v.z), fmaf(a.w, u.w, fmaf(a.w, sh.w, b.w) * v.w)));
+}
+
+// partial[blk][0][d] = sum_i g_i V_i, partial[blk][1][d] = sum_i g_i U_i over the block's row slice
+__global__ __launch_bounds__(256) void uv_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ U,
+                                                            const float* __restrict__ V, int64_t m, int d,
+                                                            float* __restrict__ partial) {
+    extern __shared__ float s_uv[];                  // [rows per trip][2][d]
+    const int d4 = d >> 2, rpi = 256 / d4;
+    const int q = threadIdx.x % d4, rl = threadIdx.x / d4;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    const int64_t stride = (int64_t)gridDim.x * rpi;
+    auto add = [&](const float4 gg, const float4 uu, const float4 vv) {
+        s1 = make_float4(fmaf(gg.x, vv.x, s1.x), fmaf(gg.y, vv.y, s1.y), fmaf(gg.z, vv.z, s1.z), fmaf(gg.w, vv.w, s1.w));
+        s2 = make_float4(fmaf(gg.x, uu.x, s2.x), fmaf(gg.y, uu.y, s2.y), fmaf(gg.z, uu.z, s2.z), fmaf(gg.w, uu.w, s2.w));
+    };
+    int64_t r = (int64_t)blockIdx.x * rpi + rl;
+    for (; r + stride < m; r += 2 * stride) {        // two rows (six 16-byte loads) in flight per thread
+        const int64_t o0 = r * d + 4 * q, o1 = (r + stride) * d + 4 * q;
+        const float4 g0 = ld4(g + o0), u0 = ld4(U + o0), v0 = ld4(V + o0);
+        const float4 g1 = ld4(g + o1), u1 = ld4(U + o1), v1 = ld4(V + o1);
+        add(g0, u0, v0);
+        add(g1, u1, v1);
+    }
+    for (; r < m; r += stride) {
+        const int64_t o0 = r * d + 4 * q;
+        add(ld4(g + o0), ld4(U + o0), ld4(V + o0));
+    }
+    st4(s_uv + (rl * 2 + 0) * d + 4 * q, s1);
+    st4(s_uv + (rl * 2 + 1) * d + 4 * q, s2);
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * d; t += 256) {
+        float a = 0.f;
+        for (int i = 0; i < rpi; ++i) a += s_uv[i * 2 * d + t];
+        partial[(int64_t)blockIdx.x * 2 * d + t] = a;
+    }
+}
+
 // ------------------------------------------------------------------ backward pass 1: reductions
 template <int D>
 __global__ __launch_bounds__(PBLOCK) void bwd_reduce_kernel(const float* __restrict__ x,
@@ -792,6 +911,59 @@ extern "C" int crfconv_pointconv_stats(const float* pos_src, const float* pos_tg
     });
     CRF_LAUNCH_CHECK();
     return reduce_partials(partial, nblk, 2 * d, stats, st);
+}
+
+static int64_t uv_reduce_blocks(int64_t m, int d) {
+    const int rpi = 256 / (d / 4);
+    const int64_t nb = cdiv(m, (int64_t)rpi * 8);              // ~8 rows per thread
+    return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+}
+
+extern "C" int crfconv_pointconv_forward_uv(const float* x, const float* pos_src, const float* pos_tgt,
+                                            const int32_t* idx32, int K, int64_t m_tgt, int d, const float* A1,
+                                            const float* b1, const float* W2, float slope, const float* mean_rel3,
+                                            float* shift, double* stats, float* U, float* V, void* workspace,
+                                            size_t workspace_bytes, crf_stream_t stream) {
+    if (int rc = check_pc(m_tgt, K, d)) return rc;
+    CRF_REQUIRE(x && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && mean_rel3 && shift && stats && U && V &&
+                    workspace, CRF_ERR_ARG, "null pointer");
+    const int64_t nblk = blocks_for(m_tgt, d);
+    CRF_REQUIRE(workspace_bytes >= sizeof(float) * 2 * d * (size_t)nblk, CRF_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* partial = reinterpret_cast<float*>(workspace);
+    DISPATCH_D(d, {
+        hipLaunchKernelGGL(uvstats_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, pos_src, pos_tgt, idx32, K,
+                           m_tgt, A1, b1, W2, slope, mean_rel3, shift, U, V, partial);
+    });
+    CRF_LAUNCH_CHECK();
+    return reduce_partials(partial, nblk, 2 * d, stats, st);
+}
+
+extern "C" int crfconv_pointconv_combine(const float* U, const float* V, const float* a2, const float* b2,
+                                         const float* shift, int64_t m_tgt, int d, float* out, crf_stream_t stream) {
+    if (int rc = check_pc(m_tgt, 1, d)) return rc;
+    CRF_REQUIRE(U && V && a2 && b2 && shift && out, CRF_ERR_ARG, "null pointer");
+    const int64_t n4 = m_tgt * (d / 4);
+    hipLaunchKernelGGL(uv_combine_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, as_stream(stream), U, V, a2, b2,
+                       shift, n4, d / 4, out);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_pointconv_bwd_reduce_uv(const float* gout, const float* U, const float* V, int64_t m_tgt, int d,
+                                               double* red1, void* workspace, size_t workspace_bytes,
+                                               crf_stream_t stream) {
+    if (int rc = check_pc(m_tgt, 1, d)) return rc;
+    CRF_REQUIRE(gout && U && V && red1 && workspace, CRF_ERR_ARG, "null pointer");
+    const int64_t nblk = uv_reduce_blocks(m_tgt, d);
+    CRF_REQUIRE(workspace_bytes >= sizeof(float) * 2 * d * (size_t)nblk, CRF_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* partial = reinterpret_cast<float*>(workspace);
+    const int rpi = 256 / (d / 4);
+    hipLaunchKernelGGL(uv_bwd_reduce_kernel, dim3((unsigned)nblk), dim3(256), sizeof(float) * 2 * d * rpi, st, gout, U, V,
+                       m_tgt, d, partial);
+    CRF_LAUNCH_CHECK();
+    return reduce_partials(partial, nblk, 2 * d, red1, st);
 }
 
 extern "C" int crfconv_pointconv_forward(const float* x, const float* pos_src, const float* pos_tgt,

@@ -498,20 +498,28 @@ class _PointConv(torch.autograd.Function):
         _lib.call('crfconv_pointconv_fold1', ptr(W1c), ptr(g1c), ptr(be1c), ptr(mom), n_e, ptr(rm1), ptr(rv1),
                   float(mom1), float(eps1), 1 if use1 else 0, d, ptr(A1), ptr(b1), ptr(aux1), st)
         shift = torch.zeros(d, dtype=torch.float32, device=dev)
-        stats = None
+        stats = U = V = None
         if use2:
+            # batch statistics of h2, U = sum_k (h2 - shift) x_j and V = sum_k x_j from ONE pass over the edges
             stats = torch.empty(2 * d, dtype=torch.float64, device=dev)
+            U = torch.empty((m_tgt, d), dtype=torch.float32, device=dev)
+            V = torch.empty((m_tgt, d), dtype=torch.float32, device=dev)
             mean_rel = mom[:3].float()
-            _lib.call('crfconv_pointconv_stats', ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d, ptr(A1),
-                      ptr(b1), ptr(W2c), slope, ptr(mean_rel), ptr(shift), ptr(stats), ptr(ws), nbytes, st)
+            _lib.call('crfconv_pointconv_forward_uv', ptr(x), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d,
+                      ptr(A1), ptr(b1), ptr(W2c), slope, ptr(mean_rel), ptr(shift), ptr(stats), ptr(U), ptr(V), ptr(ws),
+                      nbytes, st)
         a2 = torch.empty(d, dtype=torch.float32, device=dev)
         b2 = torch.empty(d, dtype=torch.float32, device=dev)
         aux2 = torch.empty(2 * d, dtype=torch.float64, device=dev)
         _lib.call('crfconv_pointconv_fold2', ptr(stats), ptr(shift), ptr(g2c), ptr(be2c), n_e, ptr(rm2), ptr(rv2),
                   float(mom2), float(eps2), 1 if use2 else 0, d, ptr(a2), ptr(b2), ptr(aux2), st)
         out = torch.empty((m_tgt, d), dtype=torch.float32, device=dev)
-        _lib.call('crfconv_pointconv_forward', ptr(x), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d,
-                  ptr(A1), ptr(b1), ptr(W2c), slope, ptr(a2), ptr(b2), ptr(out), st)
+        if use2:
+            _lib.call('crfconv_pointconv_combine', ptr(U), ptr(V), ptr(a2), ptr(b2), ptr(shift), m_tgt, d, ptr(out), st)
+        else:
+            _lib.call('crfconv_pointconv_forward', ptr(x), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d,
+                      ptr(A1), ptr(b1), ptr(W2c), slope, ptr(a2), ptr(b2), ptr(out), st)
+        ctx.uv = (U, V)
         ctx.table, ctx.n_e, ctx.slope, ctx.use1, ctx.use2, ctx.eps1 = table, n_e, slope, use1, use2, eps1
         ctx.save_for_backward(x, W1c, g1c, W2c, g2c, A1, b1, a2, b2, shift, aux1, aux2, mom, pos_src, pos_tgt)
         return out
@@ -529,8 +537,13 @@ class _PointConv(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         # pass 1: sum g_w and sum g_w (h2 - shift)  ->  BatchNorm-2 backward coefficients
         red = torch.empty(2 * d, dtype=torch.float64, device=dev)
-        _lib.call('crfconv_pointconv_bwd_reduce', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
-                  m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(shift), ptr(red), ptr(ws), nbytes, st)
+        U, V = ctx.uv
+        if U is not None:                  # training forward left U, V: the reductions are row sums, no edge pass
+            _lib.call('crfconv_pointconv_bwd_reduce_uv', ptr(g), ptr(U), ptr(V), m_tgt, d, ptr(red), ptr(ws), nbytes,
+                      st)
+        else:
+            _lib.call('crfconv_pointconv_bwd_reduce', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
+                      m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(shift), ptr(red), ptr(ws), nbytes, st)
         coef = torch.empty((5, d), dtype=torch.float32, device=dev)       # ca, cb, cc, dgamma2, dbeta2
         _lib.call('crfconv_pointconv_fold2_bwd', ptr(red), ptr(shift), ptr(aux2), ptr(g2), n_e, 1 if ctx.use2 else 0,
                   d, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), ptr(coef[4]), st)
