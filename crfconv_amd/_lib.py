@@ -65,6 +65,10 @@ SIGNATURES = {
     'crfconv_softmax_ce_workspace': (_sz, [_i64]),
     'crfconv_softmax_ce_forward': (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_softmax_ce_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _vp, _vp]),
+    'crfconv_crf_matrices': (_i, [_vp, _i, _vp, _vp, _vp]),
+    'crfconv_crf_matrices_backward': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'crfconv_add_lrelu': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
+    'crfconv_add_lrelu_backward': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
     'crfconv_spd_inverse': (_i, [_vp, _i, _vp, _vp]),
     'crfconv_neighbor_maxpool_forward': (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp]),
     'crfconv_neighbor_maxpool_backward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),

@@ -198,18 +198,9 @@ extern "C" int crfconv_linear_wgrad(const float* G, const float* X, int64_t M, i
 // ~0.1 us a pivot instead of the ~3 us of an all-in-LDS sweep.  Replaces torch.linalg.inv, whose rocSOLVER path
 // synchronises and therefore cannot be captured into a hipGraph.
 namespace crf {
-__global__ __launch_bounds__(256) void spd_inverse_kernel(const float* __restrict__ Min, int H,
-                                                          float* __restrict__ Qout) {
-    __shared__ double s_row[2][64], s_col[2][64];
+// In-place inverse of the 64 x 64 register-tiled matrix (rows / columns >= H must be identity).
+__device__ __forceinline__ void gauss_jordan_tiles(double (&t)[4][4], int H, double (*s_row)[64], double (*s_col)[64]) {
     const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
-    double t[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = tr + 16 * i, c = tc + 16 * j;
-            t[i][j] = (r < H && c < H) ? (double)Min[r * H + c] : (r == c ? 1.0 : 0.0);
-        }
 #pragma unroll
     for (int ip = 0; ip < 4; ++ip) {                     // pivot p = 16 ip + pp lives in local row / column ip
         for (int pp = 0; pp < 16; ++pp) {
@@ -241,6 +232,21 @@ __global__ __launch_bounds__(256) void spd_inverse_kernel(const float* __restric
                 }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void spd_inverse_kernel(const float* __restrict__ Min, int H,
+                                                          float* __restrict__ Qout) {
+    __shared__ double s_row[2][64], s_col[2][64];
+    const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
+    double t[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = tr + 16 * i, c = tc + 16 * j;
+            t[i][j] = (r < H && c < H) ? (double)Min[r * H + c] : (r == c ? 1.0 : 0.0);
+        }
+    gauss_jordan_tiles(t, H, s_row, s_col);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -249,12 +255,100 @@ __global__ __launch_bounds__(256) void spd_inverse_kernel(const float* __restric
             if (r < H && c < H) Qout[r * H + c] = (float)t[i][j];
         }
 }
+
+// The two loop-invariant matrices of a CRF layer from its compatibility factor c [H, H] in one launch:
+//   Q = (I + c^T c)^-1,   P = c^T c Q = I - Q            (continuous_crf_conv_big.py:67-72)
+__global__ __launch_bounds__(256) void crf_matrices_kernel(const float* __restrict__ cmat, int H,
+                                                           float* __restrict__ Qout, float* __restrict__ Pout) {
+    __shared__ double s_row[2][64], s_col[2][64];
+    __shared__ float s_c[64 * 65];
+    for (int e = threadIdx.x; e < H * H; e += 256) s_c[(e / H) * 65 + (e % H)] = cmat[e];
+    __syncthreads();
+    const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
+    double t[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = tr + 16 * i, c = tc + 16 * j;
+            double a = r == c ? 1.0 : 0.0;
+            if (r < H && c < H)
+                for (int k = 0; k < H; ++k) a += (double)s_c[k * 65 + r] * (double)s_c[k * 65 + c];
+            t[i][j] = a;
+        }
+    gauss_jordan_tiles(t, H, s_row, s_col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = tr + 16 * i, c = tc + 16 * j;
+            if (r < H && c < H) {
+                Qout[r * H + c] = (float)t[i][j];
+                Pout[r * H + c] = (float)((r == c ? 1.0 : 0.0) - t[i][j]);
+            }
+        }
+}
+
+// dc from dQ and dP (either may be NULL = zero).  With D = dQ - dP (P = I - Q), M = I + c^T c:
+//   dM = -Q^T D Q^T,   dc = c (dM + dM^T) = -c (S + S^T),   S = Q^T D Q^T.
+__global__ __launch_bounds__(256) void crf_matrices_bwd_kernel(const float* __restrict__ cmat, const float* __restrict__ Q,
+                                                               const float* __restrict__ dQ, const float* __restrict__ dP,
+                                                               int H, float* __restrict__ dc) {
+    __shared__ float s_a[64 * 65], s_b[64 * 65], s_t[64 * 65];
+    for (int e = threadIdx.x; e < H * H; e += 256) {
+        const int r = e / H, c = e % H;
+        s_a[r * 65 + c] = Q[c * H + r];                                       // Q^T
+        s_b[r * 65 + c] = (dQ ? dQ[e] : 0.f) - (dP ? dP[e] : 0.f);            // D
+    }
+    __syncthreads();
+    auto matmul = [&](const float* A, const float* B, float* out, bool sym_neg) {   // out = A B  (H x H, LDS stride 65)
+        for (int e = threadIdx.x; e < H * H; e += 256) {
+            const int r = e / H, c = e % H;
+            double acc = 0.0;
+            for (int k = 0; k < H; ++k) acc += (double)A[r * 65 + k] * (double)B[k * 65 + c];
+            out[r * 65 + c] = (float)acc;
+        }
+        __syncthreads();
+    };
+    matmul(s_a, s_b, s_t, false);                        // T = Q^T D
+    matmul(s_t, s_a, s_b, false);                        // S = T Q^T          (s_b reused)
+    for (int e = threadIdx.x; e < H * H; e += 256) {     // s_t = -(S + S^T)
+        const int r = e / H, c = e % H;
+        s_t[r * 65 + c] = -(s_b[r * 65 + c] + s_b[c * 65 + r]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < H * H; e += 256) s_a[(e / H) * 65 + (e % H)] = cmat[e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < H * H; e += 256) {
+        const int r = e / H, c = e % H;
+        double acc = 0.0;
+        for (int k = 0; k < H; ++k) acc += (double)s_a[r * 65 + k] * (double)s_t[k * 65 + c];
+        dc[e] = (float)acc;
+    }
+}
 }  // namespace crf
 
 extern "C" int crfconv_spd_inverse(const float* M, int H, float* Q, crf_stream_t stream) {
     CRF_REQUIRE(M && Q, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(H >= 1 && H <= 64, CRF_ERR_UNSUPPORTED, "H=%d outside [1, 64]", H);
     hipLaunchKernelGGL(crf::spd_inverse_kernel, dim3(1), dim3(256), 0, crf::as_stream(stream), M, H, Q);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_crf_matrices(const float* c, int H, float* Q, float* P, crf_stream_t stream) {
+    CRF_REQUIRE(c && Q && P, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(H >= 1 && H <= 64, CRF_ERR_UNSUPPORTED, "H=%d outside [1, 64]", H);
+    hipLaunchKernelGGL(crf::crf_matrices_kernel, dim3(1), dim3(256), 0, crf::as_stream(stream), c, H, Q, P);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_crf_matrices_backward(const float* c, const float* Q, const float* dQ, const float* dP, int H,
+                                             float* dc, crf_stream_t stream) {
+    CRF_REQUIRE(c && Q && dc, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(H >= 1 && H <= 64, CRF_ERR_UNSUPPORTED, "H=%d outside [1, 64]", H);
+    hipLaunchKernelGGL(crf::crf_matrices_bwd_kernel, dim3(1), dim3(256), 0, crf::as_stream(stream), c, Q, dQ, dP, H, dc);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -93,6 +93,30 @@ static int check(int64_t rows, int C) {
     return CRF_OK;
 }
 
+// Residual join of the ResNet block (point_conv_big.py:86-88): out = lrelu(a + b, slope); its backward
+// g_in = g * (out > 0 ? 1 : slope) serves both addends (slope > 0, so sign(out) = sign(a + b)).
+__global__ __launch_bounds__(256) void add_lrelu_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        int64_t n4, float slope, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n4) return;
+    const float4 u = ld4(a + 4 * t), v = ld4(b + 4 * t);
+    float4 o = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    o.x = o.x > 0.f ? o.x : slope * o.x;
+    o.y = o.y > 0.f ? o.y : slope * o.y;
+    o.z = o.z > 0.f ? o.z : slope * o.z;
+    o.w = o.w > 0.f ? o.w : slope * o.w;
+    st4(out + 4 * t, o);
+}
+
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                        int64_t n4, float slope, float* __restrict__ gin) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n4) return;
+    const float4 u = ld4(g + 4 * t), o = ld4(out + 4 * t);
+    st4(gin + 4 * t, make_float4(o.x > 0.f ? u.x : slope * u.x, o.y > 0.f ? u.y : slope * u.y,
+                                 o.z > 0.f ? u.z : slope * u.z, o.w > 0.f ? u.w : slope * u.w));
+}
+
 }  // namespace crf
 
 using namespace crf;
@@ -139,6 +163,26 @@ extern "C" int crfconv_gather_rows_backward(const float* gout, const int32_t* re
     const int64_t n = m_src * (C / 4);
     hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream),
                        gout, rev_ptr, rev_eid, m_src, C / 4, dx);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_add_lrelu(const float* a, const float* b, int64_t n, float slope, float* out, crf_stream_t stream) {
+    CRF_REQUIRE(a && b && out, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(n > 0 && n % 4 == 0 && n < ((int64_t)1 << 40), CRF_ERR_ARG, "n=%lld must be a positive multiple of 4", (long long)n);
+    CRF_REQUIRE(slope > 0.f, CRF_ERR_ARG, "slope must be positive");
+    hipLaunchKernelGGL(crf::add_lrelu_kernel, dim3((unsigned)crf::cdiv(n / 4, 256)), dim3(256), 0, crf::as_stream(stream), a, b,
+                       n / 4, slope, out);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_add_lrelu_backward(const float* gout, const float* out, int64_t n, float slope, float* gin,
+                                          crf_stream_t stream) {
+    CRF_REQUIRE(gout && out && gin, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(n > 0 && n % 4 == 0 && n < ((int64_t)1 << 40), CRF_ERR_ARG, "n=%lld must be a positive multiple of 4", (long long)n);
+    hipLaunchKernelGGL(crf::lrelu_bwd_kernel, dim3((unsigned)crf::cdiv(n / 4, 256)), dim3(256), 0, crf::as_stream(stream), gout,
+                       out, n / 4, slope, gin);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -73,7 +73,7 @@ class ResNetBBlock(nn.Module):
         if not torch.is_tensor(pos):                       # strided block: pool the shortcut onto the coarse points
             skip = self.max_pooling(skip, neighbor_idx)
         y = self.lin_out(self.point_conv(self.lin_in(x), pos, neighbor_idx))
-        return F.leaky_relu(y + skip)                      # default slope 0.01, as the reference
+        return ops.add_lrelu(y, skip, 0.01)                # F.leaky_relu default slope, as the reference
 
 
 class Upsampling(nn.Module):

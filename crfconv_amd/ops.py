@@ -58,29 +58,30 @@ class _MeanField(torch.autograd.Function):
         rev_ptr, rev_eid = table.reverse
         st = stream_ptr()
         gm = torch.empty_like(z)
-        mt = torch.empty_like(z)
         ds = torch.empty_like(s)
-        sumG = torch.zeros_like(z)
-        dP = torch.zeros_like(P)
-        dPt = torch.empty_like(P)
-        wbytes = _lib.load().crfconv_linear_wgrad_workspace(m, H, H)
-        wws = torch.empty(wbytes, dtype=torch.uint8, device=z.device)
-
-        def skinny_tn(A, B, out):      # out = A^T B for [m, H] operands: the MFMA row-reduction kernel
-            _lib.call('crfconv_linear_wgrad', ptr(A), ptr(B), m, H, H, ptr(out), None, ptr(wws), wbytes, st)
-
-        for t in range(T, 0, -1):
+        # G_t (gradient entering step t) and m_t for t = T..1 stacked row-wise: dP = sum_t m_t^T G_t and
+        # sum_t G_t then take ONE row-reduction launch each instead of T accumulate passes
+        Gs = torch.empty((T, m, H), dtype=torch.float32, device=z.device)
+        mts = torch.empty((T, m, H), dtype=torch.float32, device=z.device)
+        Gs[0].copy_(G)
+        G0 = torch.empty_like(z)
+        for i, t in enumerate(range(T, 0, -1)):
             xprev = xs[t - 2] if t >= 2 else z
-            _lib.call('crfconv_meanfield_bwd_edge', ptr(G), ptr(xprev), ptr(s), ptr(table.idx32), table.K, k0,
-                      m, H, ptr(P), ptr(gm), ptr(ds), ptr(mt), 0 if t == T else 1, st)
-            skinny_tn(mt, G, dPt)
-            dP.add_(dPt)
-            sumG.add_(G)
-            Gprev = torch.empty_like(z)
+            _lib.call('crfconv_meanfield_bwd_edge', ptr(Gs[i]), ptr(xprev), ptr(s), ptr(table.idx32), table.K, k0,
+                      m, H, ptr(P), ptr(gm), ptr(ds), ptr(mts[i]), 0 if t == T else 1, st)
             _lib.call('crfconv_meanfield_bwd_scatter', ptr(gm), ptr(s), ptr(rev_ptr), ptr(rev_eid), table.K, k0,
-                      m, H, None, ptr(Gprev), st)
-            G = Gprev
-        dz = torch.addmm(G, sumG, Q.t())          # x_0 = z path + the z Q term of every step
+                      m, H, None, ptr(Gs[i + 1] if i + 1 < T else G0), st)
+
+        def skinny_tn(A, B, out):      # out = A^T B for [rows, H] operands: the MFMA row-reduction kernel
+            rows = A.shape[0]
+            wbytes = _lib.load().crfconv_linear_wgrad_workspace(rows, H, H)
+            wws = torch.empty(wbytes, dtype=torch.uint8, device=z.device)
+            _lib.call('crfconv_linear_wgrad', ptr(A), ptr(B), rows, H, H, ptr(out), None, ptr(wws), wbytes, st)
+
+        dP = torch.empty_like(P)
+        skinny_tn(mts.view(T * m, H), Gs.view(T * m, H), dP)
+        sumG = Gs.sum(0) if T > 1 else Gs[0]
+        dz = torch.addmm(G0, sumG, Q.t())         # x_0 = z path + the z Q term of every step
         dQ = torch.empty_like(Q)
         skinny_tn(z, sumG, dQ)
         w = torch.empty_like(s)
@@ -111,6 +112,29 @@ class _SpdInverse(torch.autograd.Function):
         return -(Q.t() @ gQ @ Q.t())
 
 
+class _CrfMatrices(torch.autograd.Function):
+    """c [H, H] -> Q = (I + c^T c)^-1, P = c^T c Q = I - Q: one workgroup forward, one backward (csrc/linear.hip)."""
+
+    @staticmethod
+    def forward(ctx, c):
+        require_gpu(c)
+        cc = _f32c(c)
+        Q = torch.empty_like(cc)
+        P = torch.empty_like(cc)
+        _lib.call('crfconv_crf_matrices', ptr(cc), cc.shape[0], ptr(Q), ptr(P), stream_ptr())
+        ctx.save_for_backward(cc, Q)
+        return Q, P
+
+    @staticmethod
+    def backward(ctx, gQ, gP):
+        cc, Q = ctx.saved_tensors
+        gQ = None if gQ is None else _f32c(gQ)
+        gP = None if gP is None else _f32c(gP)
+        dc = torch.empty_like(cc)
+        _lib.call('crfconv_crf_matrices_backward', ptr(cc), ptr(Q), ptr(gQ), ptr(gP), cc.shape[0], ptr(dc), stream_ptr())
+        return dc
+
+
 _CRF_H = (4, 8, 16, 32, 64)
 
 
@@ -137,12 +161,11 @@ def _meanfield_wide(z, y, Q, C, table, steps, k0):
 def crf_meanfield(z, y, c, table, steps, k0=1):
     """z, y: [m, H] (flattened clouds);  c: [H, H] compatibility factor (C = c^T c)."""
     H = z.shape[-1]
-    eye = torch.eye(H, dtype=c.dtype, device=c.device)
-    C = c.t() @ c
     if H > _CRF_H[-1]:
-        return _meanfield_wide(z, y, torch.linalg.inv(eye + C), C, table, steps, k0)
-    Q = _SpdInverse.apply(eye + C)             # loop-invariant: computed once, not per step
-    P = C @ Q
+        C = c.t() @ c
+        return _meanfield_wide(z, y, torch.linalg.inv(torch.eye(H, dtype=c.dtype, device=c.device) + C), C, table,
+                               steps, k0)
+    Q, P = _CrfMatrices.apply(c)               # loop-invariant: computed once, not per step
     Hp = _next_supported(H, _CRF_H)
     if Hp != H:                                 # zero channels stay zero through every step
         Q = torch.nn.functional.pad(Q, (0, Hp - H, 0, Hp - H))
@@ -333,6 +356,36 @@ def bn_act(x, bn, training, slope=1.0, records=None):
     return y.reshape(shape)
 
 
+# ------------------------------------------------------------------------------ residual join
+class _AddLRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, slope):
+        require_gpu(a, b)
+        a, b = _f32c(a), _f32c(b)
+        out = torch.empty_like(a)
+        _lib.call('crfconv_add_lrelu', ptr(a), ptr(b), a.numel(), float(slope), ptr(out), stream_ptr())
+        ctx.save_for_backward(out)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = _f32c(g)
+        gin = torch.empty_like(out)
+        _lib.call('crfconv_add_lrelu_backward', ptr(g), ptr(out), out.numel(), ctx.slope, ptr(gin), stream_ptr())
+        return gin, gin, None
+
+
+def add_lrelu(a, b, slope=0.01):
+    """leaky_relu(a + b, slope) in one pass (ResNet residual join); falls back to the two framework ops for shapes
+    the kernel does not take (numel not a multiple of 4, different shapes, non-float32)."""
+    if (a.shape != b.shape or a.numel() % 4 or a.numel() == 0 or a.dtype != torch.float32 or b.dtype != torch.float32
+            or not a.is_cuda):
+        return torch.nn.functional.leaky_relu(a + b, slope)
+    return _AddLRelu.apply(a, b, slope)
+
+
 # ------------------------------------------------------------------------------ gather / max-pool
 class _GatherRows(torch.autograd.Function):
     @staticmethod
@@ -497,7 +550,7 @@ class _PointConv(torch.autograd.Function):
         aux1 = torch.empty(3 * d, dtype=torch.float64, device=dev)
         _lib.call('crfconv_pointconv_fold1', ptr(W1c), ptr(g1c), ptr(be1c), ptr(mom), n_e, ptr(rm1), ptr(rv1),
                   float(mom1), float(eps1), 1 if use1 else 0, d, ptr(A1), ptr(b1), ptr(aux1), st)
-        shift = torch.zeros(d, dtype=torch.float32, device=dev)
+        shift = (torch.empty if use2 else torch.zeros)(d, dtype=torch.float32, device=dev)
         stats = U = V = None
         if use2:
             # batch statistics of h2, U = sum_k (h2 - shift) x_j and V = sum_k x_j from ONE pass over the edges

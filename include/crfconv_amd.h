@@ -293,6 +293,12 @@ int crfconv_bn_coef_from_records(const float* stat_rec, int64_t M, int C, const 
 /* Q = M^-1 for the symmetric positive definite M = I + c^T c of a CRF layer (H <= 64; Gauss-Jordan in
  * float64, one workgroup, no host sync -- capturable into a hipGraph, unlike a LAPACK-style inverse). */
 int crfconv_spd_inverse(const float* M, int H, float* Q, crf_stream_t stream);
+/* Both loop-invariant matrices of a CRF layer from its compatibility factor c [H, H] (C = c^T c) in one launch:
+ *   Q = (I + C)^-1,  P = C Q = I - Q          (continuous_crf_conv_big.py:67-72: (z + m C)(I + C)^-1 = z Q + m P)
+ * and the matching backward: dc from dQ / dP (either may be NULL). */
+int crfconv_crf_matrices(const float* c, int H, float* Q, float* P, crf_stream_t stream);
+int crfconv_crf_matrices_backward(const float* c, const float* Q, const float* dQ, const float* dP, int H,
+                                  float* dc, crf_stream_t stream);
 
 /* ===================================================================== (B) pooling / up-sampling
  * out[i,c] = max_k x[idx32[i,k], c];  arg [m_tgt, C] int32 = winning k (first maximum). */
@@ -309,6 +315,12 @@ int crfconv_gather_rows(const float* x, const int32_t* idx32, int64_t m_tgt, int
 int crfconv_gather_rows_backward(const float* gout, const int32_t* rev_ptr,
                                  const int32_t* rev_eid, int64_t m_src, int C, float* dx,
                                  crf_stream_t stream);
+
+/* out = lrelu(a + b, slope) over n floats (n % 4 == 0): the residual join of the ResNet block
+ * (point_conv_big.py:86-88); backward gin = gout * (out > 0 ? 1 : slope), shared by both addends. */
+int crfconv_add_lrelu(const float* a, const float* b, int64_t n, float slope, float* out, crf_stream_t stream);
+int crfconv_add_lrelu_backward(const float* gout, const float* out, int64_t n, float slope, float* gin,
+                               crf_stream_t stream);
 
 /* ===================================================================== (B) training loss
  * Replaces trainval.py:101-104: F.cross_entropy(y_pred, data.y.reshape(-1) - 1, weight=class_weights,

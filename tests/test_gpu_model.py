@@ -463,3 +463,28 @@ def test_spd_inverse(H):
     assert_close(Mt.grad, torch.from_numpy(-(ref.T @ g.astype(np.float64) @ ref.T)).float(), 1e-5, 'dM')
     with pytest.raises(Exception):
         ops._SpdInverse.apply(torch.eye(65, device=DEV))
+
+
+@pytest.mark.parametrize('H', [1, 8, 13, 32, 64])
+def test_crf_matrices(H):
+    """Q = (I + c^T c)^-1, P = c^T c Q and dc, against float64 autograd."""
+    from crfconv_amd import ops
+    c0 = S.uniform(H + 100, 'c', (H, H)) * 0.4 + np.eye(H, dtype=np.float32)
+    c = t(c0).requires_grad_()
+    Q, P = ops._CrfMatrices.apply(c)
+    gq, gp = S.uniform(H, 'gq', (H, H)), S.uniform(H, 'gp', (H, H))
+    ((Q * t(gq)).sum() + (P * t(gp)).sum()).backward()
+    cd = torch.from_numpy(c0).double().requires_grad_()
+    C = cd.t() @ cd
+    Qr = torch.linalg.inv(torch.eye(H, dtype=torch.float64) + C)
+    Pr = C @ Qr
+    ((Qr * torch.from_numpy(gq).double()).sum() + (Pr * torch.from_numpy(gp).double()).sum()).backward()
+    assert_close(Q, Qr.float(), 2e-6, 'Q')
+    assert_close(P, Pr.float(), 2e-6, 'P')
+    assert_close(c.grad, cd.grad.float(), 1e-5, 'dc')
+    # only one of the outputs used
+    c2 = t(c0).requires_grad_()
+    ops._CrfMatrices.apply(c2)[1].sum().backward()
+    cd.grad = None
+    (cd.t() @ cd @ torch.linalg.inv(torch.eye(H, dtype=torch.float64) + cd.t() @ cd)).sum().backward()
+    assert_close(c2.grad, cd.grad.float(), 1e-5, 'dc from P only')
