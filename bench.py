@@ -165,7 +165,8 @@ def main():
             p.grad = None
         logits = net(data)
         loss = ops.training_loss(logits, data.y, cw, ignore_index=-1)          # trainval.py:101-104, fused kernel
-        loss.backward()
+        with ops.deferred_weight_grads():                 # one batched launch finishes all 74 dW / db reductions
+            loss.backward()
         torch._foreach_copy_(bucket.views, [p.grad for p in bucket.params])
         return loss.detach()
 

@@ -106,17 +106,58 @@ __global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict
     }
 }
 
-// out[slot] = sum_b partial[b][slot], fixed order, one wavefront per slot.
+// out[slot] = sum_b partial[b][slot] for 64 consecutive slots per workgroup: lanes run along the slots (256-byte
+// coalesced rows of the partial slabs), the 4 wavefronts take b = w, w + 4, ... with four loads in flight each, and
+// combine through LDS in the fixed order w = 0..3 -- bitwise reproducible, and identical between the single and the
+// batched entry point.
+__device__ __forceinline__ void reduce_slab64(const float* __restrict__ partial, int nblk, int nslots, int slot0,
+                                              float* __restrict__ out, float (*s_part)[64]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int slot = slot0 + lane;
+    const bool ok = slot < nslots;
+    const float* p = partial + (ok ? slot : 0);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = w;
+    for (; b + 12 < nblk; b += 16) {
+        a0 += p[(int64_t)b * nslots];
+        a1 += p[(int64_t)(b + 4) * nslots];
+        a2 += p[(int64_t)(b + 8) * nslots];
+        a3 += p[(int64_t)(b + 12) * nslots];
+    }
+    for (; b < nblk; b += 4) a0 += p[(int64_t)b * nslots];
+    s_part[w][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (w == 0 && ok) out[slot] = ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane];
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nblk,
                                                            int nslots, float* __restrict__ out) {
-    const int slot = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (slot >= nslots) return;
-    float a = 0.f;
-    for (int b = lane; b < nblk; b += WAVE) a += partial[(int64_t)b * nslots + slot];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
-    if (lane == 0) out[slot] = a;
+    __shared__ float s_part[4][64];
+    reduce_slab64(partial, nblk, nslots, blockIdx.x * 64, out, s_part);
+}
+
+// Many reductions in one launch: job j sums nblk[j] partial slabs of nslots[j] floats into out[j].  The table travels
+// in the kernel arguments (no device copy, capturable into a hipGraph); workgroup g serves one 64-slot group of one
+// job (group_begin = prefix sum of ceil(nslots / 64)).
+constexpr int RJ_MAX = 96;
+struct ReduceJobTable {
+    const float* partial[RJ_MAX];
+    float* out[RJ_MAX];
+    int nblk[RJ_MAX];
+    int nslots[RJ_MAX];
+    int group_begin[RJ_MAX + 1];
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(const ReduceJobTable tbl) {
+    __shared__ float s_part[4][64];
+    const int g = blockIdx.x;
+    int lo = 0, hi = tbl.njobs;                       // largest j with group_begin[j] <= g
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tbl.group_begin[mid] <= g) lo = mid; else hi = mid;
+    }
+    reduce_slab64(tbl.partial[lo], tbl.nblk[lo], tbl.nslots[lo], (g - tbl.group_begin[lo]) * 64, tbl.out[lo], s_part);
 }
 
 struct WgPlan {
@@ -153,16 +194,8 @@ extern "C" size_t crfconv_linear_wgrad_workspace(int64_t M, int Co, int Ci) {
     return sizeof(float) * (size_t)p.nblk * ((size_t)Co * Ci + (size_t)Co) + 256;
 }
 
-extern "C" int crfconv_linear_wgrad(const float* G, const float* X, int64_t M, int Co, int Ci, float* dW,
-                                    float* db, void* workspace, size_t workspace_bytes, crf_stream_t stream) {
-    CRF_REQUIRE(G && X && dW && workspace, CRF_ERR_ARG, "null pointer");
-    CRF_REQUIRE(M > 0 && Co > 0 && Ci > 0 && Co <= 4096 && Ci <= 4096, CRF_ERR_ARG, "bad shape M=%lld Co=%d Ci=%d",
-                (long long)M, Co, Ci);
-    CRF_REQUIRE(workspace_bytes >= crfconv_linear_wgrad_workspace(M, Co, Ci), CRF_ERR_WORKSPACE, "workspace too small");
-    const WgPlan p = wg_plan(M, Co, Ci);
-    hipStream_t st = as_stream(stream);
-    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    float* partial_b = db ? partial + (size_t)p.nblk * Co * Ci : nullptr;
+static int wgrad_launch(const float* G, const float* X, int64_t M, int Co, int Ci, const WgPlan& p, float* partial,
+                        float* partial_b, hipStream_t st) {
     const dim3 grid((unsigned)p.nblk, (unsigned)p.gy, (unsigned)p.gz), blk(WG_BLOCK);
 #define WG(TA, TB) hipLaunchKernelGGL((wgrad_kernel<TA, TB>), grid, blk, 0, st, G, X, M, Co, Ci, p.rows_per_block, partial, partial_b)
     switch (p.tco * 10 + p.tci) {
@@ -178,11 +211,67 @@ extern "C" int crfconv_linear_wgrad(const float* G, const float* X, int64_t M, i
     }
 #undef WG
     CRF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int64_t)Co * Ci, 4)), dim3(256), 0, st, partial, p.nblk,
+    return CRF_OK;
+}
+
+extern "C" int crfconv_linear_wgrad_partial(const float* G, const float* X, int64_t M, int Co, int Ci, int want_bias,
+                                            void* workspace, size_t workspace_bytes, int* nblk_out, crf_stream_t stream) {
+    CRF_REQUIRE(G && X && workspace && nblk_out, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(M > 0 && Co > 0 && Ci > 0 && Co <= 4096 && Ci <= 4096, CRF_ERR_ARG, "bad shape M=%lld Co=%d Ci=%d",
+                (long long)M, Co, Ci);
+    CRF_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, CRF_ERR_ARG, "workspace must be 256-byte aligned");
+    CRF_REQUIRE(workspace_bytes >= crfconv_linear_wgrad_workspace(M, Co, Ci), CRF_ERR_WORKSPACE, "workspace too small");
+    const WgPlan p = wg_plan(M, Co, Ci);
+    float* partial = reinterpret_cast<float*>(workspace);
+    float* partial_b = want_bias ? partial + (size_t)p.nblk * Co * Ci : nullptr;
+    *nblk_out = p.nblk;
+    return wgrad_launch(G, X, M, Co, Ci, p, partial, partial_b, as_stream(stream));
+}
+
+extern "C" int crfconv_reduce_jobs(const crf_reduce_job* jobs, int njobs, crf_stream_t stream) {
+    CRF_REQUIRE(jobs || njobs == 0, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(njobs >= 0, CRF_ERR_ARG, "njobs=%d < 0", njobs);
+    hipStream_t st = as_stream(stream);
+    for (int j0 = 0; j0 < njobs; j0 += RJ_MAX) {
+        ReduceJobTable tbl;
+        const int n = njobs - j0 < RJ_MAX ? njobs - j0 : RJ_MAX;
+        int64_t total = 0;
+        for (int j = 0; j < n; ++j) {
+            const crf_reduce_job& jb = jobs[j0 + j];
+            CRF_REQUIRE(jb.partial && jb.out && jb.nblk > 0 && jb.nslots > 0, CRF_ERR_ARG, "job %d is malformed", j0 + j);
+            tbl.partial[j] = jb.partial;
+            tbl.out[j] = jb.out;
+            tbl.nblk[j] = jb.nblk;
+            tbl.nslots[j] = jb.nslots;
+            tbl.group_begin[j] = (int)total;
+            total += (jb.nslots + 63) / 64;
+            CRF_REQUIRE(total < ((int64_t)1 << 30), CRF_ERR_ARG, "too many slots in one batch");
+        }
+        for (int j = n; j <= RJ_MAX; ++j) tbl.group_begin[j] = (int)total;
+        for (int j = n; j < RJ_MAX; ++j) { tbl.partial[j] = nullptr; tbl.out[j] = nullptr; tbl.nblk[j] = 0; tbl.nslots[j] = 0; }
+        tbl.njobs = n;
+        hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)total), dim3(256), 0, st, tbl);
+        CRF_LAUNCH_CHECK();
+    }
+    return CRF_OK;
+}
+
+extern "C" int crfconv_linear_wgrad(const float* G, const float* X, int64_t M, int Co, int Ci, float* dW,
+                                    float* db, void* workspace, size_t workspace_bytes, crf_stream_t stream) {
+    CRF_REQUIRE(G && X && dW && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(M > 0 && Co > 0 && Ci > 0 && Co <= 4096 && Ci <= 4096, CRF_ERR_ARG, "bad shape M=%lld Co=%d Ci=%d",
+                (long long)M, Co, Ci);
+    CRF_REQUIRE(workspace_bytes >= crfconv_linear_wgrad_workspace(M, Co, Ci), CRF_ERR_WORKSPACE, "workspace too small");
+    const WgPlan p = wg_plan(M, Co, Ci);
+    hipStream_t st = as_stream(stream);
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    float* partial_b = db ? partial + (size_t)p.nblk * Co * Ci : nullptr;
+    if (int rc = wgrad_launch(G, X, M, Co, Ci, p, partial, partial_b, st)) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int64_t)Co * Ci, 64)), dim3(256), 0, st, partial, p.nblk,
                        Co * Ci, dW);
     CRF_LAUNCH_CHECK();
     if (db) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int64_t)Co, 4)), dim3(256), 0, st, partial_b, p.nblk,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int64_t)Co, 64)), dim3(256), 0, st, partial_b, p.nblk,
                            Co, db);
         CRF_LAUNCH_CHECK();
     }

@@ -6,6 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..graph import require_gpu
 
 
 class FastBatchNorm1d(nn.Module):
@@ -36,8 +37,9 @@ class MLP(nn.Module):
         self.activation = activation
 
     def forward(self, x, *args, **kwargs):
+        require_gpu(x)                                    # every layer of the path runs on the device; no CPU path
         co = self.lin.out_features
-        fusable = (self.bn is not None and x.is_cuda and x.dtype == torch.float32 and co % 4 == 0 and co <= 1024
+        fusable = (self.bn is not None and x.dtype == torch.float32 and co % 4 == 0 and co <= 1024
                    and self.bn.batch_norm.affine
                    and (self.activation is None or isinstance(self.activation, nn.LeakyReLU)))
         if fusable:      # Linear (MFMA, BatchNorm statistics in its epilogue) -> BatchNorm + LeakyReLU in one pass

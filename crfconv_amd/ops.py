@@ -3,6 +3,8 @@
 Every op here runs hand-written gfx950 kernels; torch supplies device memory, the stream and the
 tiny dense algebra on H x H / d x d parameter matrices.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -174,6 +176,80 @@ def crf_meanfield(z, y, c, table, steps, k0=1):
     return out[:, :H] if Hp != H else out
 
 
+# ------------------------------------------------------------------------------ deferred weight gradients
+# Every Linear's dW = G^T X ends in a small "sum the row-slice partials" launch; PointConvBig has 74 of them per
+# backward pass, each far below the cost of launching it.  Inside ``with deferred_weight_grads():`` the MFMA kernel
+# only writes its partials, and ONE batched launch at the end of the backward pass (an autograd engine callback,
+# like DDP's) finishes all of them and installs / accumulates ``.grad`` of the weight and bias parameters directly.
+# Opt-in because it bypasses autograd for those leaves: ``torch.autograd.grad(loss, weight)`` sees nothing, and
+# gradient hooks on the weights do not fire.  ``loss.backward()`` + ``param.grad`` behave as usual.
+_DEFER = {'on': False, 'jobs': [], 'armed': False}
+
+
+class deferred_weight_grads:
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        self.prev = _DEFER['on']
+        _DEFER['on'] = bool(self.enabled)
+        return self
+
+    def __exit__(self, *exc):
+        _DEFER['on'] = self.prev
+        return False
+
+
+def _defer_ok(params):
+    W, b = params
+    return (_DEFER['on'] and isinstance(W, torch.nn.Parameter) and W.is_leaf and W.requires_grad
+            and (b is None or (isinstance(b, torch.nn.Parameter) and b.is_leaf)))
+
+
+def _defer_weight_grad(g, x, params, has_bias):
+    m, Co = g.shape
+    Ci = x.shape[1]
+    nbytes = _lib.load().crfconv_linear_wgrad_workspace(m, Co, Ci)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+    nblk = ctypes.c_int(0)
+    want_b = bool(has_bias and params[1].requires_grad)
+    _lib.call('crfconv_linear_wgrad_partial', ptr(g), ptr(x), m, Co, Ci, 1 if want_b else 0, ptr(ws), nbytes,
+              ctypes.byref(nblk), stream_ptr())
+    _DEFER['jobs'].append((params[0], params[1] if want_b else None, ws, nblk.value, Co, Ci))
+    if not _DEFER['armed']:
+        _DEFER['armed'] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_grads)
+
+
+def _flush_weight_grads():
+    jobs, _DEFER['jobs'], _DEFER['armed'] = _DEFER['jobs'], [], False
+    if not jobs:
+        return
+    dev = jobs[0][2].device
+    total = sum(Co * Ci + (Co if b is not None else 0) for _, b, _, _, Co, Ci in jobs)
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    table = (_lib.ReduceJob * (2 * len(jobs)))()
+    installs, n, o = [], 0, 0
+    for W, b, ws, nblk, Co, Ci in jobs:
+        base = ws.data_ptr()
+        table[n] = _lib.ReduceJob(base, flat.data_ptr() + 4 * o, nblk, Co * Ci)
+        installs.append((W, flat[o:o + Co * Ci].view(Co, Ci)))
+        n += 1
+        o += Co * Ci
+        if b is not None:
+            table[n] = _lib.ReduceJob(base + 4 * nblk * Co * Ci, flat.data_ptr() + 4 * o, nblk, Co)
+            installs.append((b, flat[o:o + Co]))
+            n += 1
+            o += Co
+    _lib.call('crfconv_reduce_jobs', ctypes.cast(table, ctypes.c_void_p), n, stream_ptr())
+    for prm, gr in installs:
+        gr = gr.view_as(prm)
+        if prm.grad is None:
+            prm.grad = gr
+        else:
+            prm.grad = prm.grad + gr
+
+
 # ------------------------------------------------------------------------------ per-point Linear
 _MFMA_MIN_ROWS = 4096       # below this the vendor GEMM's fixed cost is as good
 
@@ -210,6 +286,7 @@ class _Linear(torch.autograd.Function):
         Wc = W.contiguous()
         ctx.save_for_backward(x, Wc)
         ctx.has_bias = b is not None
+        ctx.params = (W, b)                      # the parameter objects themselves (deferred weight gradients)
         m, ci = x.shape
         rec = None
         if _mfma_ok(m, ci, Wc.shape[0]):
@@ -234,6 +311,9 @@ class _Linear(torch.autograd.Function):
             gx = _mfma_matmul(g, W, None, True)[0] if _mfma_ok(m, Co, Ci) else g @ W
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            if _defer_ok(ctx.params):
+                _defer_weight_grad(g, x, ctx.params, ctx.has_bias)
+                return gx, None, None, None
             dW = torch.empty((Co, Ci), dtype=torch.float32, device=g.device)
             db = torch.empty(Co, dtype=torch.float32, device=g.device) if ctx.has_bias else None
             nbytes = _lib.load().crfconv_linear_wgrad_workspace(m, Co, Ci)
@@ -244,9 +324,10 @@ class _Linear(torch.autograd.Function):
 
 
 def linear(x, W, b=None, want_stats=False):
-    """Drop-in for F.linear on [..., Ci] CUDA float32 tensors (CPU tensors: plain F.linear).  With
+    """Drop-in for F.linear on [..., Ci] CUDA tensors (CPU tensors are refused: there is no CPU path).  With
     want_stats=True returns (y, records) where `records` feeds bn_act(..., records=records) (empty if unused)."""
-    if not x.is_cuda or x.dtype != torch.float32:
+    require_gpu(x, W)
+    if x.dtype != torch.float32:
         y = torch.nn.functional.linear(x, W, b)
         return (y, None) if want_stats else y
     shape = x.shape
@@ -378,10 +459,10 @@ class _AddLRelu(torch.autograd.Function):
 
 
 def add_lrelu(a, b, slope=0.01):
-    """leaky_relu(a + b, slope) in one pass (ResNet residual join); falls back to the two framework ops for shapes
-    the kernel does not take (numel not a multiple of 4, different shapes, non-float32)."""
-    if (a.shape != b.shape or a.numel() % 4 or a.numel() == 0 or a.dtype != torch.float32 or b.dtype != torch.float32
-            or not a.is_cuda):
+    """leaky_relu(a + b, slope) in one pass (ResNet residual join) on CUDA tensors; shapes the kernel does not take
+    (numel not a multiple of 4, broadcasting, non-float32) run as the two device ops of the framework."""
+    require_gpu(a, b)
+    if a.shape != b.shape or a.numel() % 4 or a.numel() == 0 or a.dtype != torch.float32 or b.dtype != torch.float32:
         return torch.nn.functional.leaky_relu(a + b, slope)
     return _AddLRelu.apply(a, b, slope)
 

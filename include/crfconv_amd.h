@@ -258,6 +258,14 @@ int crfconv_pointconv_fold2_bwd(const double* red, const float* shift, const dou
 size_t crfconv_linear_wgrad_workspace(int64_t M, int Co, int Ci);
 int crfconv_linear_wgrad(const float* G, const float* X, int64_t M, int Co, int Ci, float* dW, float* db,
                          void* workspace, size_t workspace_bytes, crf_stream_t stream);
+/* The same contraction WITHOUT its final reduction: writes the row-slice partials to `workspace` (256-byte aligned,
+ * crfconv_linear_wgrad_workspace bytes): float [nblk][Co][Ci] followed, when want_bias, by float [nblk][Co].
+ * crfconv_reduce_jobs then finishes any number of such products (all weight gradients of a backward pass) in
+ * ONE launch: out[j][s] = sum_b partial[j][b * nslots + s]. */
+typedef struct { const float* partial; float* out; int32_t nblk; int32_t nslots; } crf_reduce_job;
+int crfconv_linear_wgrad_partial(const float* G, const float* X, int64_t M, int Co, int Ci, int want_bias,
+                                 void* workspace, size_t workspace_bytes, int* nblk_out, crf_stream_t stream);
+int crfconv_reduce_jobs(const crf_reduce_job* jobs, int njobs, crf_stream_t stream);
 
 /* Fused BatchNorm (+ LeakyReLU) over rows x [M, C] (models/common.py:31,36-37; C % 4 == 0, C <= 1024).
  * forward:  use_batch_stats != 0 -> statistics of x (biased variance), running stats updated in place when non-NULL

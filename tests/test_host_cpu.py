@@ -77,23 +77,14 @@ def test_data_containers():
     assert 'MultiScaleData' in repr(e)
 
 
-def test_mlp_and_bn_semantics_match_oracle():
-    """MLP / FastBatchNorm1d are plain torch and run anywhere: check them against the oracle's mlp."""
-    import _seeded as S
+def test_mlp_refuses_cpu_tensors():
+    """MLP is on the path (every Linear runs on the MFMA kernels): like the CRF / PointConv layers it has no CPU
+    route.  Its semantics against the oracle are checked on the GPU (tests/test_gpu_model.py)."""
     from crfconv_amd.models import MLP
-    from oracle import crf_oracle as O
+    from crfconv_amd._lib import CrfConvError
     m = MLP(12, 20, activation=torch.nn.LeakyReLU(0.1))
-    sd = S.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 2)
-    m.load_state_dict(sd)
-    x = torch.from_numpy(S.uniform(2, 'x', (3, 50, 12)))
-    prm = {k: v.clone() for k, v in sd.items()}
-    m.train()
-    a = m(x)
-    b = O.mlp(prm, '', x, True, 0.1)
-    assert float((a - b).abs().max()) < 1e-5
-    assert float((m.bn.batch_norm.running_var - prm['bn.batch_norm.running_var']).abs().max()) < 1e-6
-    m.eval()
-    assert float((m(x) - O.mlp(prm, '', x, False, 0.1)).abs().max()) < 1e-5
+    with pytest.raises(CrfConvError, match='no CPU path'):
+        m(torch.zeros(3, 50, 12))
 
 
 WORKER = r'''
