@@ -86,8 +86,18 @@ def roofline_meanfield(data, dev, H=8, T=3, iters=50):
     dur = np.array([a.elapsed_time(b) for a, b in evs]) * 1e-3
     alg_bytes = m * (4 * (K - 1) + 4 * H * (2 * T + 1))
     avg = float(dur.mean())
+    # HBM-side bytes per launch come from rocprofv3 PMC passes (cannot be read live); the committed measurement applies
+    # to exactly one configuration and is reported only for it
+    traffic = None
+    try:
+        rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_meanfield_traffic.json')))
+        cfg = rec['config']
+        if (cfg['m'], cfg['H'], cfg['K'], cfg['T']) == (m, H, K, T) and tab.idx16 is not None:
+            traffic = rec['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        pass
     return {'bound': 'hbm', 'achieved': alg_bytes / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-            'frac': alg_bytes / avg / HBM_PEAK, 'traffic': None, 'kernel': 'crfconv_meanfield_forward level-0 '
+            'frac': alg_bytes / avg / HBM_PEAK, 'traffic': traffic, 'kernel': 'crfconv_meanfield_forward level-0 '
             '(sim_step_fast_kernel [similarity + step 1] + %d x step_fast_kernel, m=%d, H=%d, K=%d)' % (T - 1, m, H, K),
             'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': avg * 1e6, 'min_launch_us': float(dur.min()) * 1e6}
 
