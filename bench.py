@@ -159,7 +159,8 @@ def main():
     net = models.PointConvBig(6, n_cls, use_crf=True, steps=T).to(dev).train()
     D.broadcast_parameters(net)
     bucket = D.FlatGradAllReduce(net)
-    opt = torch.optim.SGD(net.parameters(), lr=1e-2, momentum=0.95, weight_decay=1e-4)
+    # torch.optim.SGD(lr, momentum=0.95, weight_decay=1e-4) of trainval.py:69-72 as one launch over flat parameters
+    opt = crfconv_amd.optim.FlatSGD(bucket, lr=1e-2, momentum=0.95, weight_decay=1e-4)
     cw = torch.ones(n_cls, device=dev)
 
     # One training step = [A] zero grads, forward, weighted CE, backward, grads packed into ONE flat fp32 bucket
@@ -181,9 +182,7 @@ def main():
         return loss.detach()
 
     def part_b():
-        for p, v in zip(bucket.params, bucket.views):
-            p.grad = v
-        opt.step()
+        opt.step()                                           # reads bucket.flat, updates the flat parameter vector
 
     grouped = torch.distributed.is_available() and torch.distributed.is_initialized()
 

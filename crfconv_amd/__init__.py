@@ -6,8 +6,8 @@ Layout mirrors the reference's import surface for this path:
   crfconv_amd.utils.cpp_subsampling.compute
 All compute goes through libcrfconv_amd.so (include/crfconv_amd.h); there is no CPU fallback.
 """
-from . import _lib, data, graph, models, ops, utils
+from . import _lib, data, graph, models, ops, optim, utils
 from .data import Data, MultiScaleData, multiscale_compute
 
 __version__ = '0.1.0'
-__all__ = ['models', 'utils', 'ops', 'graph', 'data', 'Data', 'MultiScaleData', 'multiscale_compute']
+__all__ = ['models', 'utils', 'ops', 'optim', 'graph', 'data', 'Data', 'MultiScaleData', 'multiscale_compute']

@@ -136,3 +136,37 @@ extern "C" int crfconv_softmax_ce_backward(const float* logits, const int64_t* t
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
+
+// ====================================================================== optimizer step (trainval.py:69-72, 105)
+// torch.optim.SGD(lr, momentum, dampening, weight_decay, nesterov) over ONE flat parameter vector:
+//   g = grad + wd * p;  buf = first ? g : mu * buf + (1 - dampening) * g;  g = nesterov ? g + mu * buf : buf;  p -= lr * g
+// (momentum == 0: p -= lr * g, buf untouched).  One launch for the whole model instead of ~15 multi-tensor ones.
+namespace crf {
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  int64_t n, float lr, float mu, float damp, float wd, int nesterov,
+                                                  int first) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float w = p[i];
+        float d = fmaf(wd, w, g[i]);
+        if (mu != 0.f) {
+            const float b = first ? d : fmaf(mu, buf[i], (1.f - damp) * d);
+            buf[i] = b;
+            d = nesterov ? fmaf(mu, b, d) : b;
+        }
+        p[i] = fmaf(-lr, d, w);
+    }
+}
+}  // namespace crf
+
+extern "C" int crfconv_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
+                                float momentum, float dampening, float weight_decay, int nesterov, int first_step,
+                                crf_stream_t stream) {
+    CRF_REQUIRE(param && grad && (momentum_buf || momentum == 0.f), CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(n > 0, CRF_ERR_ARG, "n=%lld <= 0", (long long)n);
+    int64_t nb = cdiv(n, 256 * 4);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(crf::sgd_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), param, grad, momentum_buf, n, lr,
+                       momentum, dampening, weight_decay, nesterov, first_step);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}

@@ -346,6 +346,12 @@ int crfconv_softmax_ce_backward(const float* logits, const int64_t* target, cons
                                 const double* sums, const float* grad_loss, int64_t m, int C, int64_t ignore_index,
                                 int64_t label_shift, float* dlogits, crf_stream_t stream);
 
+/* torch.optim.SGD step (trainval.py:69-72, 105) over one flat float32 parameter vector of n elements:
+ *   g = grad + weight_decay * p;  buf = first_step ? g : momentum * buf + (1 - dampening) * g;
+ *   g = nesterov ? g + momentum * buf : buf;  p -= lr * g          (momentum == 0: buf unused, may be NULL). */
+int crfconv_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                     float dampening, float weight_decay, int nesterov, int first_step, crf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -548,3 +548,29 @@ def test_deferred_weight_grads_equal_immediate():
     w = net.conv1_1.lin_in.lin.weight
     (gw,) = torch.autograd.grad(ops.training_loss(net(data), labels, None, ignore_index=-1), [w])
     assert torch.isfinite(gw).all() and float(gw.abs().max()) > 0
+
+
+@pytest.mark.parametrize('cfg', [dict(momentum=0.95, weight_decay=1e-4), dict(momentum=0.0, weight_decay=0.0),
+                                 dict(momentum=0.9, weight_decay=1e-3, nesterov=True), dict(momentum=0.9, dampening=0.1)])
+def test_flat_sgd_matches_torch_sgd(cfg):
+    """optim.FlatSGD (one launch over flat parameters) against torch.optim.SGD, 4 steps, same gradients."""
+    from crfconv_amd import optim
+    from crfconv_amd.distributed import FlatGradAllReduce
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 33), torch.nn.BatchNorm1d(33), torch.nn.Linear(33, 5)).to(DEV)
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 33), torch.nn.BatchNorm1d(33), torch.nn.Linear(33, 5)).to(DEV)
+    ref.load_state_dict(net.state_dict())
+    bucket = FlatGradAllReduce(net)
+    opt = optim.FlatSGD(bucket, lr=0.05, **cfg)
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.05, **cfg)
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), ref.state_dict().values()))   # re-homing kept values
+    for step in range(4):
+        grads = [t(S.uniform(step, 'g%d' % i, tuple(p.shape))) for i, p in enumerate(ref.parameters())]
+        for p, v, g in zip(ref.parameters(), bucket.views, grads):
+            p.grad = g.clone()
+            v.copy_(g)
+        opt.step()
+        ropt.step()
+        for (k, a), b in zip(net.named_parameters(), ref.parameters()):
+            assert_close(a, b, 1e-6, 'step %d %s' % (step, k))
+    assert net[0].weight.data_ptr() == opt.flat.data_ptr()
