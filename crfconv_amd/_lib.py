@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libcrfconv_amd.so')
 
 _vp, _i, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+_d = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/crfconv_amd.h one to one
 SIGNATURES = {
@@ -38,8 +39,8 @@ SIGNATURES = {
     'crfconv_pointconv_moments': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_stats': (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_forward_uv': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'crfconv_pointconv_combine': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
-    'crfconv_pointconv_bwd_reduce_uv': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
+    'crfconv_pointconv_combine': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _f, _f, _i64, _i, _vp, _vp, _vp, _vp, _vp]),
+    'crfconv_pointconv_bwd_reduce_uv': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_forward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_bwd_reduce': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_bwd_params': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp,

@@ -421,18 +421,51 @@ __global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict
     block_reduce_store<D, 2>(acc, sred, partial, lane, wave, q);
 }
 
-// out = a2 U + (a2 shift + b2) V   over [m, d] rows (one thread per 4-channel quad)
+// out = a2 U + (a2 shift + b2) V   over [m, d] rows (one thread per 4-channel quad).  BatchNorm-2's batch
+// coefficients are folded from the statistics right here (a handful of flops per thread, identical in every
+// thread of a channel): a2 = gamma rstd, b2 = beta - a2 mean.  Workgroup 0 also publishes a2 / b2 / aux2 = {mean,
+// rstd} for the backward kernels and advances the running statistics.
 __global__ __launch_bounds__(256) void uv_combine_kernel(const float* __restrict__ U, const float* __restrict__ V,
-                                                         const float* __restrict__ a2, const float* __restrict__ b2,
-                                                         const float* __restrict__ shift, int64_t n4, int d4,
+                                                         const double* __restrict__ stats, const float* __restrict__ shift,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         double n_edges, float* __restrict__ run_mean,
+                                                         float* __restrict__ run_var, float momentum, float eps,
+                                                         int64_t n4, int d4, float* __restrict__ a2_out,
+                                                         float* __restrict__ b2_out, double* __restrict__ aux2,
                                                          float* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n4) return;
+    const int d = 4 * d4;
     const int q = (int)(t % d4);
-    const float4 a = ld4(a2 + 4 * q), b = ld4(b2 + 4 * q), sh = ld4(shift + 4 * q);
+    float a[4], b[4], sh[4];
+    const bool publish = blockIdx.x == 0 && threadIdx.x < d4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * q + e;
+        const double m1 = stats[c] / n_edges;
+        const double mean = (double)shift[c] + m1;
+        double var = stats[d + c] / n_edges - m1 * m1;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double aa = (double)gamma[c] * rstd;
+        a[e] = (float)aa;
+        b[e] = (float)((double)beta[c] - aa * mean);
+        sh[e] = shift[c];
+        if (publish) {
+            a2_out[c] = a[e];
+            b2_out[c] = b[e];
+            aux2[c] = mean;
+            aux2[d + c] = rstd;
+            if (run_mean != nullptr) {
+                const double unb = n_edges > 1.0 ? var * (n_edges / (n_edges - 1.0)) : var;
+                run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
+                run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+            }
+        }
+    }
+    if (t >= n4) return;
     const float4 u = ld4(U + 4 * t), v = ld4(V + 4 * t);
-    st4(out + 4 * t, make_float4(fmaf(a.x, u.x, fmaf(a.x, sh.x, b.x) * v.x), fmaf(a.y, u.y, fmaf(a.y, sh.y, b.y) * v.y),
-                                 fmaf(a.z, u.z, fmaf(a.z, sh.z, b.z) * v.z), fmaf(a.w, u.w, fmaf(a.w, sh.w, b.w) * v.w)));
+    st4(out + 4 * t, make_float4(fmaf(a[0], u.x, fmaf(a[0], sh[0], b[0]) * v.x), fmaf(a[1], u.y, fmaf(a[1], sh[1], b[1]) * v.y),
+                                 fmaf(a[2], u.z, fmaf(a[2], sh[2], b[2]) * v.z), fmaf(a[3], u.w, fmaf(a[3], sh[3], b[3]) * v.w)));
 }
 
 // partial[blk][0][d] = sum_i g_i V_i, partial[blk][1][d] = sum_i g_i U_i over the block's row slice
@@ -913,6 +946,47 @@ extern "C" int crfconv_pointconv_stats(const float* pos_src, const float* pos_tg
     return reduce_partials(partial, nblk, 2 * d, stats, st);
 }
 
+namespace crf {
+// fold2_bwd fed by the block partials of uv_bwd_reduce_kernel directly (partial [nblk][2d] float): the 16
+// wavefronts of one workgroup sum the slots in the fixed order of reduce_partials_kernel, then the first d threads
+// derive the coefficients -- one launch instead of two.
+__global__ __launch_bounds__(1024) void fold2_bwd_partials_kernel(const float* __restrict__ partial, int nblk,
+                                                                  const float* __restrict__ shift,
+                                                                  const double* __restrict__ aux2,
+                                                                  const float* __restrict__ gamma, double n_edges,
+                                                                  int use_batch, int d, float* __restrict__ ca,
+                                                                  float* __restrict__ cb, float* __restrict__ cc,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double s_red[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int slot = wave; slot < 2 * d; slot += 16) {
+        double a = 0.0;
+        for (int b = lane; b < nblk; b += WAVE) a += (double)partial[(int64_t)b * 2 * d + slot];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
+        if (lane == 0) s_red[slot] = a;
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c >= d) return;
+    const double mean = aux2[c], rstd = aux2[d + c], g = gamma[c];
+    const double sum_gw = s_red[c];
+    const double sum_gwh = rstd * (s_red[d + c] - (mean - (double)shift[c]) * sum_gw);    // sum g_w * hhat
+    dgamma[c] = (float)sum_gwh;
+    dbeta[c] = (float)sum_gw;
+    ca[c] = (float)(g * rstd);
+    if (use_batch) {
+        const double mgw = sum_gw / n_edges, mgh = sum_gwh / n_edges;
+        cb[c] = (float)(-g * rstd * rstd * mgh);
+        cc[c] = (float)(-g * rstd * mgw + g * rstd * rstd * mean * mgh);
+    } else {
+        cb[c] = 0.f;
+        cc[c] = 0.f;
+    }
+}
+
+}  // namespace crf
+
 static int64_t uv_reduce_blocks(int64_t m, int d) {
     const int rpi = 256 / (d / 4);
     const int64_t nb = cdiv(m, (int64_t)rpi * 8);              // ~8 rows per thread
@@ -939,22 +1013,28 @@ extern "C" int crfconv_pointconv_forward_uv(const float* x, const float* pos_src
     return reduce_partials(partial, nblk, 2 * d, stats, st);
 }
 
-extern "C" int crfconv_pointconv_combine(const float* U, const float* V, const float* a2, const float* b2,
-                                         const float* shift, int64_t m_tgt, int d, float* out, crf_stream_t stream) {
+extern "C" int crfconv_pointconv_combine(const float* U, const float* V, const double* stats, const float* shift,
+                                         const float* gamma2, const float* beta2, double n_edges, float* run_mean,
+                                         float* run_var, float momentum, float eps, int64_t m_tgt, int d, float* a2,
+                                         float* b2, double* aux2, float* out, crf_stream_t stream) {
     if (int rc = check_pc(m_tgt, 1, d)) return rc;
-    CRF_REQUIRE(U && V && a2 && b2 && shift && out, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(U && V && stats && shift && gamma2 && beta2 && a2 && b2 && aux2 && out, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE((run_mean == nullptr) == (run_var == nullptr), CRF_ERR_ARG, "running statistics come as a pair");
     const int64_t n4 = m_tgt * (d / 4);
-    hipLaunchKernelGGL(uv_combine_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, as_stream(stream), U, V, a2, b2,
-                       shift, n4, d / 4, out);
+    hipLaunchKernelGGL(uv_combine_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, as_stream(stream), U, V, stats,
+                       shift, gamma2, beta2, n_edges, run_mean, run_var, momentum, eps, n4, d / 4, a2, b2, aux2, out);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
 
 extern "C" int crfconv_pointconv_bwd_reduce_uv(const float* gout, const float* U, const float* V, int64_t m_tgt, int d,
-                                               double* red1, void* workspace, size_t workspace_bytes,
+                                               const float* shift, const double* aux2, const float* gamma2,
+                                               double n_edges, int use_batch, float* ca, float* cb, float* cc,
+                                               float* dgamma2, float* dbeta2, void* workspace, size_t workspace_bytes,
                                                crf_stream_t stream) {
     if (int rc = check_pc(m_tgt, 1, d)) return rc;
-    CRF_REQUIRE(gout && U && V && red1 && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(gout && U && V && shift && aux2 && gamma2 && ca && cb && cc && dgamma2 && dbeta2 && workspace,
+                CRF_ERR_ARG, "null pointer");
     const int64_t nblk = uv_reduce_blocks(m_tgt, d);
     CRF_REQUIRE(workspace_bytes >= sizeof(float) * 2 * d * (size_t)nblk, CRF_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = as_stream(stream);
@@ -963,7 +1043,10 @@ extern "C" int crfconv_pointconv_bwd_reduce_uv(const float* gout, const float* U
     hipLaunchKernelGGL(uv_bwd_reduce_kernel, dim3((unsigned)nblk), dim3(256), sizeof(float) * 2 * d * rpi, st, gout, U, V,
                        m_tgt, d, partial);
     CRF_LAUNCH_CHECK();
-    return reduce_partials(partial, nblk, 2 * d, red1, st);
+    hipLaunchKernelGGL(fold2_bwd_partials_kernel, dim3(1), dim3(1024), 0, st, partial, (int)nblk, shift, aux2, gamma2,
+                       n_edges, use_batch, d, ca, cb, cc, dgamma2, dbeta2);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
 }
 
 extern "C" int crfconv_pointconv_forward(const float* x, const float* pos_src, const float* pos_tgt,

@@ -586,7 +586,8 @@ def training_loss(logits, labels, class_weights=None, ignore_index=-1):
 
 # ------------------------------------------------------------------------------ PointConv
 def relpos_moments(pos_src, pos_tgt, table):
-    """(mean [3], covariance [3,3], edge count) of rel = p_tgt[i] - p_src[j] over all edges, float64."""
+    """(mean [3], covariance [3,3], edge count, packed float64 [12], mean float32 [3]) of rel = p_tgt[i] - p_src[j]
+    over all edges."""
     require_gpu(pos_src, pos_tgt)
     dev = pos_src.device
     out9 = torch.empty(9, dtype=torch.float64, device=dev)
@@ -600,7 +601,8 @@ def relpos_moments(pos_src, pos_tgt, table):
     S = torch.stack([torch.stack([sec[0], sec[1], sec[2]]), torch.stack([sec[1], sec[3], sec[4]]),
                      torch.stack([sec[2], sec[4], sec[5]])])
     cov = S - torch.outer(mean, mean)
-    return mean, cov, n, torch.cat([mean.reshape(3), cov.reshape(9)]).contiguous()
+    packed = torch.cat([mean.reshape(3), cov.reshape(9)]).contiguous()
+    return mean, cov, n, packed, packed[:3].float().contiguous()     # [4]: mean rel in float32 (kernel argument)
 
 
 class _PointConv(torch.autograd.Function):
@@ -612,7 +614,7 @@ class _PointConv(torch.autograd.Function):
     source-major gather for dx.  Nothing per-edge is ever stored (except for d >= 64, see bwd_dump)."""
 
     @staticmethod
-    def forward(ctx, x, W1, g1, be1, W2, g2, be2, pos_src, pos_tgt, table, mom, bn1_state, bn2_state, slope):
+    def forward(ctx, x, W1, g1, be1, W2, g2, be2, pos_src, pos_tgt, table, mom, bn1_state, bn2_state, slope, mom32=None):
         require_gpu(x, W1, W2, pos_src, pos_tgt)
         dev = x.device
         x, W1c, W2c = _f32c(x), _f32c(W1), _f32c(W2)
@@ -638,19 +640,20 @@ class _PointConv(torch.autograd.Function):
             stats = torch.empty(2 * d, dtype=torch.float64, device=dev)
             U = torch.empty((m_tgt, d), dtype=torch.float32, device=dev)
             V = torch.empty((m_tgt, d), dtype=torch.float32, device=dev)
-            mean_rel = mom[:3].float()
+            mean_rel = mom32 if mom32 is not None else mom[:3].float()
             _lib.call('crfconv_pointconv_forward_uv', ptr(x), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d,
                       ptr(A1), ptr(b1), ptr(W2c), slope, ptr(mean_rel), ptr(shift), ptr(stats), ptr(U), ptr(V), ptr(ws),
                       nbytes, st)
         a2 = torch.empty(d, dtype=torch.float32, device=dev)
         b2 = torch.empty(d, dtype=torch.float32, device=dev)
         aux2 = torch.empty(2 * d, dtype=torch.float64, device=dev)
-        _lib.call('crfconv_pointconv_fold2', ptr(stats), ptr(shift), ptr(g2c), ptr(be2c), n_e, ptr(rm2), ptr(rv2),
-                  float(mom2), float(eps2), 1 if use2 else 0, d, ptr(a2), ptr(b2), ptr(aux2), st)
         out = torch.empty((m_tgt, d), dtype=torch.float32, device=dev)
-        if use2:
-            _lib.call('crfconv_pointconv_combine', ptr(U), ptr(V), ptr(a2), ptr(b2), ptr(shift), m_tgt, d, ptr(out), st)
+        if use2:       # BatchNorm-2 folded from the statistics inside the elementwise combine
+            _lib.call('crfconv_pointconv_combine', ptr(U), ptr(V), ptr(stats), ptr(shift), ptr(g2c), ptr(be2c), n_e,
+                      ptr(rm2), ptr(rv2), float(mom2), float(eps2), m_tgt, d, ptr(a2), ptr(b2), ptr(aux2), ptr(out), st)
         else:
+            _lib.call('crfconv_pointconv_fold2', ptr(stats), ptr(shift), ptr(g2c), ptr(be2c), n_e, ptr(rm2), ptr(rv2),
+                      float(mom2), float(eps2), 0, d, ptr(a2), ptr(b2), ptr(aux2), st)
             _lib.call('crfconv_pointconv_forward', ptr(x), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d,
                       ptr(A1), ptr(b1), ptr(W2c), slope, ptr(a2), ptr(b2), ptr(out), st)
         ctx.uv = (U, V)
@@ -670,17 +673,18 @@ class _PointConv(torch.autograd.Function):
         nbytes = _lib.load().crfconv_pointconv_workspace(max(m_tgt, table.m_src), K, d)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         # pass 1: sum g_w and sum g_w (h2 - shift)  ->  BatchNorm-2 backward coefficients
-        red = torch.empty(2 * d, dtype=torch.float64, device=dev)
+        coef = torch.empty((5, d), dtype=torch.float32, device=dev)       # ca, cb, cc, dgamma2, dbeta2
         U, V = ctx.uv
         if U is not None:                  # training forward left U, V: the reductions are row sums, no edge pass
-            _lib.call('crfconv_pointconv_bwd_reduce_uv', ptr(g), ptr(U), ptr(V), m_tgt, d, ptr(red), ptr(ws), nbytes,
-                      st)
+            _lib.call('crfconv_pointconv_bwd_reduce_uv', ptr(g), ptr(U), ptr(V), m_tgt, d, ptr(shift), ptr(aux2), ptr(g2),
+                      n_e, 1 if ctx.use2 else 0, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), ptr(coef[4]),
+                      ptr(ws), nbytes, st)
         else:
+            red = torch.empty(2 * d, dtype=torch.float64, device=dev)
             _lib.call('crfconv_pointconv_bwd_reduce', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
                       m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(shift), ptr(red), ptr(ws), nbytes, st)
-        coef = torch.empty((5, d), dtype=torch.float32, device=dev)       # ca, cb, cc, dgamma2, dbeta2
-        _lib.call('crfconv_pointconv_fold2_bwd', ptr(red), ptr(shift), ptr(aux2), ptr(g2), n_e, 1 if ctx.use2 else 0,
-                  d, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), ptr(coef[4]), st)
+            _lib.call('crfconv_pointconv_fold2_bwd', ptr(red), ptr(shift), ptr(aux2), ptr(g2), n_e, 1 if ctx.use2 else 0,
+                      d, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), ptr(coef[4]), st)
         # pass 2: parameter gradients
         if d <= 16:
             dW2 = torch.empty(d * d, dtype=torch.float64, device=dev)
@@ -718,7 +722,7 @@ class _PointConv(torch.autograd.Function):
         dx = torch.empty((table.m_src, d), dtype=torch.float32, device=dev)
         _lib.call('crfconv_pointconv_bwd_input', ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(rev_ptr), ptr(rev_eid), K,
                   table.m_src, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(a2), ptr(b2), ptr(dx), st)
-        return (dx, dW1, dg1, dbe1, dW2, coef[3], coef[4], None, None, None, None, None, None, None)
+        return (dx, dW1, dg1, dbe1, dW2, coef[3], coef[4], None, None, None, None, None, None, None, None)
 
 
 _PC_D = (4, 8, 16, 32, 64, 128)
@@ -743,6 +747,7 @@ def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=
     if moments is None:
         moments = relpos_moments(pos_src, pos_tgt, table)
     mom = moments[3] if len(moments) > 3 else pack_moments(moments)
+    mom32 = moments[4] if len(moments) > 4 else None
 
     def state(bn):
         use_batch = training or bn.running_mean is None
@@ -753,7 +758,7 @@ def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=
         return (use_batch, bn.running_mean if keep else None, bn.running_var if keep else None,
                 momentum if bn.momentum is None else bn.momentum, bn.eps)
     return _PointConv.apply(x, W1, bn1.weight, bn1.bias, W2, bn2.weight, bn2.bias, pos_src, pos_tgt, table, mom,
-                            state(bn1), state(bn2), float(slope))
+                            state(bn1), state(bn2), float(slope), mom32)
 
 
 __all__ = ['linear', 'bn_act', 'crf_meanfield', 'gather_rows', 'neighbor_maxpool', 'relpos_moments', 'point_conv', 'cross_entropy', 'training_loss',

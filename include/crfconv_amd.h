@@ -176,18 +176,24 @@ int crfconv_pointconv_stats(const float* pos_src, const float* pos_tgt, const in
 /* Training forward in ONE edge pass.  BatchNorm-2 is affine per channel, so
  *   out_i = a2 * U_i + (a2 * shift + b2) * V_i,   U_i = sum_k (h2_k - shift) * x_j,   V_i = sum_k x_j
  * (U, V [m_tgt, d] float32 out) and the batch statistics of h2 (stats, shift: as crfconv_pointconv_stats) come
- * out of the same pass; crfconv_pointconv_combine finishes the convolution once fold2 has produced a2 / b2.
+ * out of the same pass; crfconv_pointconv_combine folds BatchNorm-2 (as crfconv_pointconv_fold2 in training mode:
+ * a2, b2, aux2 out, running statistics advanced) and finishes the convolution in one elementwise launch.
  * The backward reductions of BatchNorm-2 need no edge pass either:
- *   red1 [2, d] float64 = {sum_e g_w, sum_e g_w (h2 - shift)} = {sum_i gout_i * V_i, sum_i gout_i * U_i}. */
+ *   {sum_e g_w, sum_e g_w (h2 - shift)} = {sum_i gout_i * V_i, sum_i gout_i * U_i};
+ * crfconv_pointconv_bwd_reduce_uv forms them and applies crfconv_pointconv_fold2_bwd (ca, cb, cc, dgamma2, dbeta2). */
 int crfconv_pointconv_forward_uv(const float* x, const float* pos_src, const float* pos_tgt,
                                  const int32_t* idx32, int K, int64_t m_tgt, int d, const float* A1,
                                  const float* b1, const float* W2, float slope, const float* mean_rel3,
                                  float* shift, double* stats, float* U, float* V, void* workspace,
                                  size_t workspace_bytes, crf_stream_t stream);
-int crfconv_pointconv_combine(const float* U, const float* V, const float* a2, const float* b2,
-                              const float* shift, int64_t m_tgt, int d, float* out, crf_stream_t stream);
+int crfconv_pointconv_combine(const float* U, const float* V, const double* stats, const float* shift,
+                              const float* gamma2, const float* beta2, double n_edges, float* run_mean,
+                              float* run_var, float momentum, float eps, int64_t m_tgt, int d, float* a2, float* b2,
+                              double* aux2, float* out, crf_stream_t stream);
 int crfconv_pointconv_bwd_reduce_uv(const float* gout, const float* U, const float* V, int64_t m_tgt, int d,
-                                    double* red1, void* workspace, size_t workspace_bytes, crf_stream_t stream);
+                                    const float* shift, const double* aux2, const float* gamma2, double n_edges,
+                                    int use_batch, float* ca, float* cb, float* cc, float* dgamma2, float* dbeta2,
+                                    void* workspace, size_t workspace_bytes, crf_stream_t stream);
 int crfconv_pointconv_forward(const float* x, const float* pos_src, const float* pos_tgt,
                               const int32_t* idx32, int K, int64_t m_tgt, int d, const float* A1,
                               const float* b1, const float* W2, float slope, const float* a2, const float* b2,
