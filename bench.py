@@ -51,7 +51,7 @@ def make_batch(rank, B, N, dev, gen, sort='morton'):
     return data, time.perf_counter() - t0
 
 
-def roofline_meanfield(data, dev, H=8, T=3, iters=50):
+def roofline_meanfield(data, dev, H=8, T=3, iters=200):
     """Level-0 CRF mean-field forward alone, HIP-event timed on the stream it is launched on."""
     from crfconv_amd import _lib
     from crfconv_amd.graph import ptr, stream_ptr, table_of
@@ -77,13 +77,17 @@ def roofline_meanfield(data, dev, H=8, T=3, iters=50):
     for _ in range(10):
         launch()
     torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    # one event pair around `per` consecutive launches (an event pair per launch adds ~3 us of record/launch latency to
+    # a ~25 us region); average launch duration = region / per, over `iters // per` regions
+    per = 10
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(1, iters // per))]
     for a, b in evs:
         a.record()
-        launch()
+        for _ in range(per):
+            launch()
         b.record()
     torch.cuda.synchronize()
-    dur = np.array([a.elapsed_time(b) for a, b in evs]) * 1e-3
+    dur = np.array([a.elapsed_time(b) for a, b in evs]) * 1e-3 / per
     alg_bytes = m * (4 * (K - 1) + 4 * H * (2 * T + 1))
     avg = float(dur.mean())
     # HBM-side bytes per launch come from rocprofv3 PMC passes (cannot be read live); the committed measurement applies

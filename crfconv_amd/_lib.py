@@ -27,6 +27,7 @@ SIGNATURES = {
     'crfconv_grid_subsample_dev_workspace': (_sz, [_i64, _i, _i]),
     'crfconv_grid_subsample_dev': (_i64, [_vp, _i64, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     'crfconv_index_narrow': (_i, [_vp, _i64, _i64, _i, _i64, _vp, _vp, _vp, _vp]),
+    'crfconv_index_narrow_sorted': (_i, [_vp, _i64, _i64, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     'crfconv_reverse_csr_workspace': (_sz, [_i64, _i64]),
     'crfconv_reverse_csr': (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_meanfield_forward': (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -151,10 +151,23 @@ __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_f
     d[0] = 0.f;
 #pragma unroll
     for (int k = 1; k < K; ++k) d[k] *= inv;
-    // s row: K floats = K/4 dwordx4 stores, spread over the L lanes of the point
+    // s rows: the wave's PPW points own PPW * K contiguous floats.  Written straight from the owning lanes each
+    // store instruction would touch 64/L rows with 16 bytes each (measured: +2.1 us on the level-0 kernel); routed
+    // through a per-wave LDS tile instead, every store instruction writes 1 KiB of consecutive bytes.
+    {
+        constexpr int PPW = Geo<H>::PPW, CPR = K / 4, NCH = PPW * CPR;      // 16-byte chunks per row / per wave
+        __shared__ float4 sS[BLOCK / WAVE][NCH];
+        float4* mine = sS[threadIdx.x >> 6];
+        const int p = lane / L;
 #pragma unroll
-    for (int c = 0; c < K / 4; ++c)
-        if (valid && (c % L) == q) st4(s + r * K + 4 * c, make_float4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]));
+        for (int c = 0; c < CPR; ++c)
+            if ((c % L) == q) mine[p * CPR + c] = make_float4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]);
+        __builtin_amdgcn_wave_barrier();     // LDS operations of one wave complete in order
+        const int64_t row0 = (int64_t)xcd_block_id() * Geo<H>::PPB + (threadIdx.x >> 6) * PPW;
+#pragma unroll
+        for (int c = lane; c < NCH; c += WAVE)
+            if (row0 + c / CPR < m) st4(s + row0 * K + 4 * c, mine[c]);
+    }
 
     if constexpr (WITH_STEP) {
         const float4 zi = ld4(z + r * H + 4 * q);
@@ -190,12 +203,19 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
     load_index_row<K>(idx, idx16, r, n_tgt, n_src, j);
     load_row<K, float4>(s + r * K, w);
     const float4 zi = ld4(z + r * H + 4 * q);
-    float4 nb[K];
-#pragma unroll
-    for (int k = 1; k < K; ++k) nb[k] = ld4(xin + (int64_t)j[k] * H + 4 * q);
+    // gathers in two batches of K/2 (fewer live registers: 8 waves/SIMD at H = 8, K = 16; measured 0.2-0.3 us faster)
     float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        float4 nb[K / 2];
 #pragma unroll
-    for (int k = 1; k < K; ++k) msg = fma4(w[k], nb[k], msg);
+        for (int k = 1; k < K / 2; ++k) nb[k] = ld4(xin + (int64_t)j[k] * H + 4 * q);
+#pragma unroll
+        for (int k = 1; k < K / 2; ++k) msg = fma4(w[k], nb[k], msg);
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) nb[k] = ld4(xin + (int64_t)j[K / 2 + k] * H + 4 * q);
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) msg = fma4(w[K / 2 + k], nb[k], msg);
+    }
     __syncthreads();
     // z Q recomputed from z (same bytes as reading a stored z Q, and nothing extra to write)
     const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));

@@ -49,7 +49,9 @@ class NeighborTable:
         # uint16 per-cloud ids as well when they fit: the streaming kernels then read half the index bytes
         self.idx16 = (torch.empty((self.B * self.n_tgt, self.K), dtype=torch.int16, device=idx64.device)
                       if self.n_src <= 65536 and self.K % 8 == 0 else None)
-        _lib.call('crfconv_index_narrow', ptr(idx64), self.B, self.n_tgt, self.K, self.n_src,
+        # columns 1.. re-ordered by ascending source id (every consumer reduces over a row's columns; column 0,
+        # which the CRF layer drops by position, stays): adjacent target rows then gather adjacent source rows
+        _lib.call('crfconv_index_narrow_sorted', ptr(idx64), self.B, self.n_tgt, self.K, self.n_src, 1,
                   ptr(self.idx32), ptr(self.idx16), ptr(self._bad), stream_ptr())
         self._rev = None
         self._checked = False

@@ -101,6 +101,13 @@ int64_t crfconv_grid_subsample_dev(const float* points, int64_t N, const float* 
 int crfconv_index_narrow(const int64_t* idx64, int64_t B, int64_t n_tgt, int K, int64_t n_src,
                          int32_t* idx32, uint16_t* idx16, int32_t* bad_count, crf_stream_t stream);
 
+/* Same, with columns sort_from .. K-1 of every row re-ordered by ascending source id (sort_from = 1 keeps the
+ * self column of a self-query kNN table in place).  Consumers reduce over the columns of a row, so the order is
+ * free; ascending ids make the k-th gathers of adjacent target rows hit adjacent source rows. */
+int crfconv_index_narrow_sorted(const int64_t* idx64, int64_t B, int64_t n_tgt, int K, int64_t n_src,
+                                int sort_from, int32_t* idx32, uint16_t* idx16, int32_t* bad_count,
+                                crf_stream_t stream);
+
 /* Reverse (source-major) CSR of a table idx32 [E] with values in [0, m_src):
  * rev_ptr [m_src + 1], rev_eid [E] = edge ids e (= row * K + k) grouped by source row, ascending
  * e inside a group (deterministic summation order for every backward scatter). */

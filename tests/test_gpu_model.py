@@ -65,6 +65,23 @@ def test_table_rejects_bad_indices():
         NeighborTable(idx, 10)          # CPU tensor: no CPU path
 
 
+@pytest.mark.parametrize('K', [1, 5, 16, 32, 40])
+def test_table_columns_sorted_keep_row_content(K):
+    """The device table re-orders columns 1.. of a row by ascending source id (locality of the gathers): same
+    multiset per row, column 0 untouched, uint16 local ids consistent with the int32 global rows."""
+    from crfconv_amd.graph import NeighborTable
+    B, n_tgt, n_src = 3, 777, 1500
+    rng = np.random.default_rng(K)
+    idx = rng.integers(0, n_src, (B, n_tgt, K))
+    tab = NeighborTable(t(idx), n_src)
+    got = tab.idx32.cpu().numpy().reshape(B, n_tgt, K) - (np.arange(B) * n_src)[:, None, None]
+    assert np.array_equal(got[:, :, 0], idx[:, :, 0])
+    assert np.array_equal(np.sort(got[:, :, 1:], -1), np.sort(idx[:, :, 1:], -1))
+    assert np.all(np.diff(got[:, :, 1:], axis=-1) >= 0)
+    if tab.idx16 is not None:
+        assert np.array_equal(tab.idx16.cpu().numpy().astype(np.int64).reshape(B, n_tgt, K) & 0xffff, got)
+
+
 @pytest.mark.parametrize('H,K,steps,B', [(8, 16, 3, 2), (16, 16, 1, 1), (32, 32, 5, 2), (64, 16, 3, 2),
                                          (8, 16, 0, 2), (12, 9, 2, 3), (4, 16, 3, 2)])
 def test_meanfield_vs_oracle(H, K, steps, B):
