@@ -79,6 +79,13 @@ SIGNATURES = {
     'crfconv_neighbor_maxpool_backward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),
     'crfconv_gather_rows': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     'crfconv_gather_rows_backward': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    'crfconv_confusion_accumulate': (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp]),
+    'crfconv_vote_accumulate': (_i, [_vp, _vp, _vp, _i64, _i, _d, _vp, _i64, _vp, _vp]),
+    'crfconv_vote_project': (_i, [_vp, _vp, _i64, _i, _i64, _i, _vp, _vp, _vp]),
+    'crfconv_argmin_workspace': (_sz, []),
+    'crfconv_argmin_f64': (_i, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_possibility_crop_workspace': (_sz, [_i64, _i64]),
+    'crfconv_possibility_crop': (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 

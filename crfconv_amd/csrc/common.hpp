@@ -70,6 +70,31 @@ __device__ __forceinline__ float group_max(float v) {
 
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 
+// Singly rounded float operations that the compiler may NOT fuse into an FMA.  (The __fmul_rn / __fadd_rn
+// intrinsics of this toolchain are plain `*` / `+` and inherit hipcc's default -ffp-contract=fast: a product feeding
+// a sum becomes v_fma_f32.)  Bit-exact parity paths -- kNN distances, voxel keys and barycentres, the vote and
+// possibility updates -- must round every operation like the reference's scalar C++ / numpy code does.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ double dmul_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double dadd_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

@@ -65,8 +65,8 @@ __global__ void gs_dims_kernel(const unsigned* __restrict__ mnmx, float dl, Grid
     unsigned long long n[3];
     for (int a = 0; a < 3; ++a) {
         const float mn = funord(mnmx[a]), mx = funord(mnmx[3 + a]);
-        g.org[a] = __fmul_rn(floorf(__fmul_rn(mn, inv)), dl);
-        n[a] = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(mx, g.org[a]), dl)) + 1ull;
+        g.org[a] = mul_rn(floorf(mul_rn(mn, inv)), dl);
+        n[a] = (unsigned long long)floorf(__fdiv_rn(sub_rn(mx, g.org[a]), dl)) + 1ull;
     }
     g.NX = n[0]; g.NY = n[1]; g.NZ = n[2];
     *gd = g;
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(256) void gs_keys_kernel(const float* __restrict__ 
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const GridDims g = *gd;
-    const unsigned long long ix = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(pts[3 * i + 0], g.org[0]), g.dl));
-    const unsigned long long iy = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(pts[3 * i + 1], g.org[1]), g.dl));
-    const unsigned long long iz = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(pts[3 * i + 2], g.org[2]), g.dl));
+    const unsigned long long ix = (unsigned long long)floorf(__fdiv_rn(sub_rn(pts[3 * i + 0], g.org[0]), g.dl));
+    const unsigned long long iy = (unsigned long long)floorf(__fdiv_rn(sub_rn(pts[3 * i + 1], g.org[1]), g.dl));
+    const unsigned long long iz = (unsigned long long)floorf(__fdiv_rn(sub_rn(pts[3 * i + 2], g.org[2]), g.dl));
     keys[i] = ix + g.NX * iy + g.NX * g.NY * iz;   // grid_subsampling.cpp:56
     ids[i] = (uint32_t)i;
 }
@@ -125,19 +125,19 @@ __global__ __launch_bounds__(128) void gs_reduce_kernel(const float* __restrict_
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (int p = beg; p < end; ++p) {
         const int64_t i = sids[p];
-        sx = __fadd_rn(sx, pts[3 * i]);
-        sy = __fadd_rn(sy, pts[3 * i + 1]);
-        sz = __fadd_rn(sz, pts[3 * i + 2]);
+        sx = add_rn(sx, pts[3 * i]);
+        sy = add_rn(sy, pts[3 * i + 1]);
+        sz = add_rn(sz, pts[3 * i + 2]);
     }
     const float r = (float)(1.0 / (double)n);   // grid_subsampling.cpp:87: double reciprocal narrowed
-    out_pts[3 * v + 0] = __fmul_rn(sx, r);
-    out_pts[3 * v + 1] = __fmul_rn(sy, r);
-    out_pts[3 * v + 2] = __fmul_rn(sz, r);
+    out_pts[3 * v + 0] = mul_rn(sx, r);
+    out_pts[3 * v + 1] = mul_rn(sy, r);
+    out_pts[3 * v + 2] = mul_rn(sz, r);
     if (feats) {
         const float fc = (float)n;
         for (int f = 0; f < fdim; ++f) {
             float acc = 0.f;
-            for (int p = beg; p < end; ++p) acc = __fadd_rn(acc, feats[(int64_t)sids[p] * fdim + f]);
+            for (int p = beg; p < end; ++p) acc = add_rn(acc, feats[(int64_t)sids[p] * fdim + f]);
             out_feats[v * fdim + f] = __fdiv_rn(acc, fc);
         }
     }

@@ -26,7 +26,7 @@ constexpr int QBLOCK = 128;
 
 __device__ __forceinline__ float sqdist_exact(float qx, float qy, float qz, float px, float py, float pz) {
     const float dx = qx - px, dy = qy - py, dz = qz - pz;
-    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    return add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
 }
 
 // ------------------------------------------------------------------ 1. bounding box -> grid

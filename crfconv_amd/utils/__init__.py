@@ -1,4 +1,5 @@
-"""Module aliases the reference exposes from utils/__init__.py:9-10."""
+"""Module aliases the reference exposes from utils/__init__.py:9-10, plus its running metrics (:3)."""
 from . import cpp_subsampling, nearest_neighbors
+from .metrics import runningScore
 
-__all__ = ['cpp_subsampling', 'nearest_neighbors']
+__all__ = ['cpp_subsampling', 'nearest_neighbors', 'runningScore']

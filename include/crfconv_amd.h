@@ -365,6 +365,48 @@ int crfconv_softmax_ce_backward(const float* logits, const int64_t* target, cons
 int crfconv_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
                      float dampening, float weight_decay, int nesterov, int first_step, crf_stream_t stream);
 
+/* ===================================================================== (C) callers either side of the network
+ * SURVEY 8(f) rows 2-3.  All device pointers; nothing here synchronises.
+ *
+ * Confusion matrix, utils/metrics.py:13-27 (runningScore._fast_hist + update): for every row r with class
+ * t = y_true[r] - label_shift such that 0 <= t < n_class and t != ignore_index,  hist[t * n_class + p] += 1, where
+ * p = y_pred[r], or the FIRST arg-max of logits[r, 0..n_class) when logits != NULL (trainval.py:108).  hist is
+ * int64 [n_class, n_class], accumulated.  Rows whose p falls outside [0, n_class) are skipped and counted in
+ * *bad_count (np.bincount would widen and the reference's reshape raise). */
+int crfconv_confusion_accumulate(const int64_t* y_true, const int64_t* y_pred, const float* logits, int64_t n_rows,
+                                 int n_class, int64_t ignore_index, int64_t label_shift, int64_t* hist,
+                                 int32_t* bad_count, crf_stream_t stream);
+
+/* Vote accumulator, trainval.py:186-189: test_probs[point_idx[r]] = smooth * test_probs[point_idx[r]] +
+ * (1 - smooth) * prob[r] in float32 exactly as numpy evaluates it (two rounded products, one rounded sum);
+ * prob = probs[r] (float32 [n_rows, C]) or, when logits != NULL, soft-max of logits[r] (trainval.py:178).
+ * point_idx int64 [n_rows], distinct within one call; entries outside [0, n_cloud) are skipped and counted. */
+int crfconv_vote_accumulate(const float* probs, const float* logits, const int64_t* point_idx, int64_t n_rows, int C,
+                            double smooth, float* test_probs, int64_t n_cloud, int32_t* bad_count, crf_stream_t stream);
+
+/* Re-projection, trainval.py:200-203: preds[i] = uint8(first arg-max of test_probs[proj_idx[i]]) + label_offset. */
+int crfconv_vote_project(const float* test_probs, const int64_t* proj_idx, int64_t n_proj, int C, int64_t n_cloud,
+                         int label_offset, uint8_t* preds, int32_t* bad_count, crf_stream_t stream);
+
+/* np.argmin / np.min of a float64 array (first index on ties): semantic3d_dataset.py:424-425, 451. */
+size_t crfconv_argmin_workspace(void);
+int crfconv_argmin_f64(const double* values, int64_t n, double* out_value, int64_t* out_index, void* workspace,
+                       size_t workspace_bytes, crf_stream_t stream);
+
+/* One draw of the possibility sampler, semantic3d_dataset.py:426-450, for a cloud of n float32 points:
+ *   centre = float64(points[*pick_index]) + noise[0..3)   (noise may be NULL)
+ *   crop   = the k points nearest to centre by float64 squared distance (ties: lower point id first)
+ *   d      = float32 distances formed as the reference does (float64 squares rounded to float32, summed in float32)
+ *   possibility[q] += float64((1 - d / max d)^2) * point_weight[q]   (point_weight NULL = test split, weight 1)
+ * Outputs, row t describing crop element perm[t] (perm = a permutation of 0..k-1, NULL = nearest first; the
+ * reference shuffles): out_idx int64 [k]; out_xyz float32 [k, 3] with x, y centred on the seed (:436-437);
+ * out_center float64 [3] (may be NULL). */
+size_t crfconv_possibility_crop_workspace(int64_t n, int64_t k);
+int crfconv_possibility_crop(const float* points, int64_t n, int64_t k, const int64_t* pick_index, const double* noise,
+                             const int64_t* perm, const double* point_weight, double* possibility, int64_t* out_idx,
+                             float* out_xyz, double* out_center, void* workspace, size_t workspace_bytes,
+                             crf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,8 +91,9 @@ __global__ __launch_bounds__(256) void step_kernel(const float* __restrict__ xin
     if (!valid) r = m - 1;
     int j[K];
     float w[K];
-    constexpr bool NTL = MODE == 2;
-    if constexpr (MODE >= 4) {
+    constexpr bool NTL = MODE == 2 || MODE == 7;
+    constexpr bool NTS = MODE == 2 || MODE == 6 || MODE == 7;
+    if constexpr (MODE == 4 || MODE == 5) {
         // index / weight rows of the wave's 32 points as fully coalesced 1 KB loads, redistributed through LDS
         __shared__ float4 sS[4][128];
         __shared__ uint4 sI[4][64];
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void step_kernel(const float* __restrict__ xin
     }
     const float4 zi = NTL ? ld4nt(z + r * H + 4 * q) : ld4(z + r * H + 4 * q);
     float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (MODE == 3 || MODE == 5) {
+    if constexpr (MODE == 3 || MODE == 5 || MODE == 6 || MODE == 7) {
         float4 nb[8];
 #pragma unroll
         for (int k = 1; k < 8; ++k) nb[k] = ld4(xin + (int64_t)j[k] * H + 4 * q);
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void step_kernel(const float* __restrict__ xin
     const float4 zqi = matvec_acc(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
     const float4 o = matvec_acc(msg, sP, lane, q, zqi);
     if (valid) {
-        if (NTL) st4nt(xout + r * H + 4 * q, o);
+        if (NTS) st4nt(xout + r * H + 4 * q, o);
         else st4(xout + r * H + 4 * q, o);
     }
 }
@@ -390,8 +391,13 @@ __global__ __launch_bounds__(256, MINW) void sim_kernel(const float* __restrict_
         __builtin_amdgcn_wave_barrier();
         const int64_t row0 = (int64_t)xcd_block_id() * 128 + (threadIdx.x >> 6) * 32;
         const float4 a = mine[lane], b = mine[lane + 64];
-        if (row0 + (lane >> 2) < m) st4(s + row0 * K + 4 * lane, a);
-        if (row0 + 16 + (lane >> 2) < m) st4(s + row0 * K + 256 + 4 * lane, b);
+        if (FL & 32) {
+            if (row0 + (lane >> 2) < m) st4nt(s + row0 * K + 4 * lane, a);
+            if (row0 + 16 + (lane >> 2) < m) st4nt(s + row0 * K + 256 + 4 * lane, b);
+        } else {
+            if (row0 + (lane >> 2) < m) st4(s + row0 * K + 4 * lane, a);
+            if (row0 + 16 + (lane >> 2) < m) st4(s + row0 * K + 256 + 4 * lane, b);
+        }
     }
     const float4 zi = ld4(z + r * H + 4 * q);
     __syncthreads();
@@ -422,6 +428,8 @@ extern "C" int mfv_sim(int variant, const float* y, const float* z, const uint16
         case 12: hipLaunchKernelGGL((sim_kernel<3, 4, 16>), dim3(g128), dim3(256), 0, st, SARGS); break;
         case 13: hipLaunchKernelGGL((sim_kernel<0, 4, 16>), dim3(g128), dim3(256), 0, st, SARGS); break;
         case 14: hipLaunchKernelGGL((sim_kernel<1, 4, 16>), dim3(g128), dim3(256), 0, st, SARGS); break;
+        case 15: hipLaunchKernelGGL((sim_kernel<0, 4, 16 | 32>), dim3(g128), dim3(256), 0, st, SARGS); break;
+        case 16: hipLaunchKernelGGL((sim_kernel<0, 4, 16 | 32 | 8>), dim3(g128), dim3(256), 0, st, SARGS); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -439,6 +447,8 @@ extern "C" int mfv_step(int variant, const float* xin, const float* z, const flo
         case 3: hipLaunchKernelGGL(step_kernel<3>, dim3(g128), dim3(256), 0, st, ARGS); break;
         case 10: hipLaunchKernelGGL(step_kernel<4>, dim3(g128), dim3(256), 0, st, ARGS); break;
         case 11: hipLaunchKernelGGL(step_kernel<5>, dim3(g128), dim3(256), 0, st, ARGS); break;
+        case 12: hipLaunchKernelGGL(step_kernel<6>, dim3(g128), dim3(256), 0, st, ARGS); break;
+        case 13: hipLaunchKernelGGL(step_kernel<7>, dim3(g128), dim3(256), 0, st, ARGS); break;
         case 4: hipLaunchKernelGGL((step_win_kernel<512, 128>), dim3((unsigned)((m + 255) / 256)), dim3(512), 0, st, ARGS); break;
         case 5: hipLaunchKernelGGL((step_win_kernel<1024, 256>), dim3((unsigned)((m + 511) / 512)), dim3(1024), 0, st, ARGS); break;
         case 6: hipLaunchKernelGGL((step_win_kernel<256, 64>), dim3(g128), dim3(256), 0, st, ARGS); break;

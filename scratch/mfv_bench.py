@@ -25,7 +25,7 @@ c = torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)
 C = c.t() @ c; Q = torch.linalg.inv(torch.eye(H) + C); P = (C @ Q).to(dev).contiguous(); Q = Q.to(dev).contiguous()
 st = stream_ptr()
 names = {0: 'base', 1: 'own-row (no gather)', 2: 'nontemporal streams', 3: 'two gather batches', 4: 'win 512/128',
-         5: 'win 1024/256', 6: 'win 256/64', 7: 'pipe x2', 8: 'pipe x4', 9: 'win 1024/512', 10: 'coalesced rows via LDS', 11: 'coalesced rows + 2 batches'}
+         5: 'win 1024/256', 6: 'win 256/64', 7: 'pipe x2', 8: 'pipe x4', 9: 'win 1024/512', 10: 'coalesced rows via LDS', 11: 'coalesced rows + 2 batches', 12: '2 batches, nt store', 13: '2 batches, nt idx/s/z loads, nt store'}
 win = (loc[:, 1:] - torch.arange(m, device=dev).remainder(N)[:, None]).abs()
 for h in (64, 128, 256, 512, 1024):
     print('neighbour refs within +-%d rows: %.3f' % (h, float((win <= h).float().mean())))
@@ -52,7 +52,7 @@ for label, table in (('knn-order', idx16), ('sorted', srt)):
 lib.mfv_sim.argtypes = [i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]
 y = torch.randn(m, H, generator=g).to(dev)
 snames = {0: 'base occ4', 1: 'own-row', 2: 'packed idx, 8-batches, minw5', 3: 'y/z interleaved 8-batches', 4: 'packed 8-batches minw6',
-          5: 'y/z interleaved minw5', 6: 'base minw5', 7: 'own-row, no s store', 8: 'own-row, nt s store', 9: 'interleaved, nt s store', 10: 'interleaved, nt s+x store', 11: 'interleaved, no s store', 12: 'interleaved, s via LDS', 13: 'base, s via LDS', 14: 'own-row, s via LDS'}
+          5: 'y/z interleaved minw5', 6: 'base minw5', 7: 'own-row, no s store', 8: 'own-row, nt s store', 9: 'interleaved, nt s store', 10: 'interleaved, nt s+x store', 11: 'interleaved, no s store', 12: 'interleaved, s via LDS', 13: 'base, s via LDS', 14: 'own-row, s via LDS', 15: 'base, s via LDS nt', 16: 'base, s via LDS nt, x1 nt'}
 sv = [int(a) for a in os.environ.get('SIMV', '').split(',') if a] or sorted(snames)
 ref_s = ref_x = None
 for label, table in (('knn-order', idx16), ('sorted', srt)):
@@ -73,3 +73,22 @@ for label, table in (('knn-order', idx16), ('sorted', srt)):
         ok = v != 1 and label == 'knn-order' and ref_s is not None
         print('sim %-10s v%d %-30s %7.2f us/launch  err s %.1e x %.1e' % (label, v, snames.get(v, '?'), t,
               float((so - ref_s).abs().max()) if ok else float('nan'), float((xo - ref_x).abs().max()) if ok else float('nan')), flush=True)
+
+# ---- whole forward in sequence: sim variant, then two step variants
+xs = torch.empty(3, m, H, device=dev); so = torch.empty(m, K, device=dev)
+for sv_, tv_ in ((0, 0), (13, 3), (15, 3), (16, 3), (13, 12), (15, 12), (16, 12), (16, 13), (13, 13)):
+    def launch():
+        lib.mfv_sim(sv_, ptr(y), ptr(z), ptr(srt), N, N, ptr(Q), ptr(P), ptr(so), ptr(xs[0]), m, st)
+        lib.mfv_step(tv_, ptr(xs[0]), ptr(z), ptr(so), ptr(srt), N, N, ptr(Q), ptr(P), ptr(xs[1]), m, st)
+        lib.mfv_step(tv_, ptr(xs[1]), ptr(z), ptr(so), ptr(srt), N, N, ptr(Q), ptr(P), ptr(xs[2]), m, st)
+    for _ in range(5): launch()
+    torch.cuda.synchronize()
+    n = 200
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): launch()
+    b.record(); torch.cuda.synchronize()
+    print('seq sim v%d + 2 x step v%d: %7.2f us per forward (sorted table)' % (sv_, tv_, a.elapsed_time(b) / n * 1e3), flush=True)
+
+# (measured and dropped: clouds 0-1 / 2-3 on two streams with an event fork/join per forward -- 62 us per forward against
+#  25 us in one stream; the cross-queue dependencies cost far more than the launch boundaries they were meant to hide)

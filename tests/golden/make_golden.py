@@ -495,6 +495,83 @@ def g8_sparse(models):
     save('g8_sparse.npz', **out)
 
 
+def import_reference_file(relpath, name, stubs=()):
+    """Loads ONE reference source file as a module (its package __init__ would pull in half of torch_geometric)."""
+    import importlib.util
+    for mod_name, attrs in stubs:
+        m = types.ModuleType(mod_name)
+        m.__dict__.update(attrs)
+        sys.modules[mod_name] = m
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    return module
+
+
+def g9_eval(models):
+    """utils/metrics.py (pure numpy) and Semantic3D._get_random (datasets/semantic3d_dataset.py:423-460) run as they
+    are; the dataset module's module-scope imports that the method never touches are empty stubs, `Data` is an
+    attribute bag (torch_geometric.data.Data is only used as one at :456)."""
+    from sklearn.neighbors import KDTree
+    metrics = import_reference_file('utils/metrics.py', 'ref_metrics')
+    out = {}
+    n_cls = 13
+    yt = S.integers(9, 'yt', (3, 5000), -1, n_cls + 1)          # includes ignore (-1) and an out-of-range label
+    yp = S.integers(9, 'yp', (3, 5000), 0, n_cls)
+    rs = metrics.runningScore(n_cls, ignore_index=-1)
+    rs.update(yt, yp)
+    rs.update(yt[0], yp[1])
+    sc, cls_iu = rs.get_scores()
+    out.update(m_yt=yt, m_yp=yp, m_hist=rs.confusion_matrix, m_scores=np.array([sc[k] for k in sorted(sc)]),
+               m_score_names=np.array(sorted(sc)), m_cls_iu=np.array([cls_iu[c] for c in range(n_cls)]))
+    rs2 = metrics.runningScore(n_cls, ignore_index=3)
+    rs2.update(yt.reshape(-1), yp.reshape(-1))
+    out['m_hist_ignore3'] = rs2.confusion_matrix
+
+    class Bag:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+    empty = lambda *names: {n: None for n in names}
+    ds = import_reference_file('datasets/semantic3d_dataset.py', 'ref_semantic3d', stubs=[
+        ('plyfile', empty('PlyData')),
+        ('torch_geometric.data', dict(Data=Bag, Dataset=object, InMemoryDataset=object)),
+        ('torch_points_kernels', {}), ('torch_points_kernels.points_cpu', {}), ('torch_points_kernels.points_cuda', {}),
+        ('torch_points3d.datasets', {}), ('torch_points3d.datasets.batch', empty('SimpleBatch')),
+        ('torch_points3d.datasets.multiscale_data', empty('MultiScaleData', 'MultiScaleBatch')),
+        ('utils', empty('cpp_subsampling', 'nearest_neighbors', 'read_ply', 'write_ply', 'Plot')),
+    ])
+    # two clouds, crops of 1500 points, 6 consecutive draws (cloud choice, possibility bookkeeping and all)
+    clouds = [S.make_cloud(900, 6000, box=(6.0, 5.0, 2.0)), S.make_cloud(901, 4000, box=(4.0, 4.0, 2.0))]
+    labels = [S.integers(9, 'lab0', (6000,), 1, 9), S.integers(9, 'lab1', (4000,), 1, 9)]
+    rgb = [S.uniform(9, 'rgb0', (6000, 3), 0, 1), S.uniform(9, 'rgb1', (4000, 3), 0, 1)]
+    cw = 1.0 / (S.uniform(9, 'cw', (1, 8), 0.02, 0.5).astype(np.float64) + 0.02)
+    poss0 = [S.uniform(9, 'p0', (6000,), -1, 1).astype(np.float64) * 1e-3, S.uniform(9, 'p1', (4000,), -1, 1).astype(np.float64) * 1e-3]
+    for split in ('train', 'test'):
+        fake = Bag(min_possibility=[float(p.min()) for p in poss0], possibility=[p.copy() for p in poss0],
+                   input_trees=[KDTree(c, leaf_size=50) for c in clouds], input_rgb=rgb, input_labels=labels,
+                   label_to_idx={l: i for i, l in enumerate(range(1, 9))}, class_weight=cw, num_points=1500, split=split)
+        np.random.seed(1234)
+        for draw in range(6):
+            state = np.random.get_state()
+            d = ds.Semantic3D._get_random(fake)
+            np.random.set_state(state)
+            noise = np.random.normal(scale=3.5 / 10, size=(1, 3))      # the draw _get_random made first (:429)
+            np.random.shuffle(np.arange(1500))                           # ... and its shuffle (:434), to stay in step
+            tag = 's_%s_%d_' % (split, draw)
+            out[tag + 'noise'] = noise.reshape(-1)
+            out[tag + 'cloud'] = d.cloud_idx.numpy()
+            out[tag + 'point_idx'] = d.point_idx.numpy().astype(np.int32)
+            out[tag + 'pos'] = d.pos.numpy()
+            out[tag + 'y'] = d.y.numpy().astype(np.int16)
+            out[tag + 'rgb'] = d.rgb.numpy()
+            out[tag + 'min_possibility'] = np.array(fake.min_possibility)
+        out['s_%s_possibility0' % split] = fake.possibility[0]
+        out['s_%s_possibility1' % split] = fake.possibility[1]
+    out.update(s_cloud0=clouds[0], s_cloud1=clouds[1], s_labels0=labels[0].astype(np.int16), s_labels1=labels[1].astype(np.int16),
+               s_rgb0=rgb[0], s_rgb1=rgb[1], s_cw=cw, s_poss0=poss0[0], s_poss1=poss0[1])
+    save('g9_eval.npz', **out)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
     torch.manual_seed(0)
@@ -502,6 +579,6 @@ if __name__ == '__main__':
     models = import_reference_models()
     only = set(sys.argv[1:])
     for fn in (g1_crfconv, g2_meanfield_fp64, g3_pointconv, g4_resblock, g5_pointconvbig, g6_knn,
-               g7_grid, g8_sparse):
+               g7_grid, g8_sparse, g9_eval):
         if not only or fn.__name__.split('_')[0] in only:
             fn(models)

@@ -297,3 +297,49 @@ def test_sparse_equals_dense_on_knn_graph():
     src = nbr[0, :, 1:].reshape(-1)
     sparse = O.sparse_crf_meanfield(z[0], y[0], tgt, src, c, 3)
     close(sparse, dense.numpy(), 1e-6, 'sparse vs dense')
+
+
+# ----------------------------------------------------------------- callers either side of the network (8(f) rows 2-3)
+def test_metrics_oracle_golden(golden):
+    from oracle import eval_oracle as E
+    g = golden('g9_eval.npz')
+    yt, yp = g['m_yt'], g['m_yp']
+    hist = sum(E.fast_hist(a, b, 13) for a, b in zip(yt, yp)) + E.fast_hist(yt[0], yp[1], 13)
+    assert np.array_equal(hist, g['m_hist'])
+    assert np.array_equal(E.fast_hist(yt, yp, 13, ignore_index=3), g['m_hist_ignore3'])
+    sc, iu = E.scores(hist)
+    assert np.allclose([sc[k] for k in sorted(sc)], g['m_scores'], rtol=1e-14, atol=0)
+    assert np.allclose(iu, g['m_cls_iu'], rtol=1e-14, atol=0, equal_nan=True)
+    # iou_from_confusions: absent classes take the mean of the present ones
+    c = np.array([[5, 1, 0], [2, 7, 0], [0, 0, 0]], dtype=np.float64)
+    iou = E.iou_from_confusions(c)
+    assert abs(iou[2] - (iou[0] + iou[1]) / 2) < 1e-5 and abs(iou[0] - 5 / 8) < 1e-6
+
+
+@pytest.mark.parametrize('split', ['train', 'test'])
+def test_possibility_sampler_oracle_golden(golden, split):
+    """The restated draw against Semantic3D._get_random run on the same clouds / possibilities / noise: crop
+    membership, centred coordinates, labels and the possibility tables after six draws."""
+    from oracle import eval_oracle as E
+    g = golden('g9_eval.npz')
+    clouds = [g['s_cloud0'], g['s_cloud1']]
+    labels = [g['s_labels0'].astype(np.int64), g['s_labels1'].astype(np.int64)]
+    poss = [g['s_poss0'].copy(), g['s_poss1'].copy()]
+    weights = None if split == 'test' else [g['s_cw'][0][l - 1] for l in labels]
+    minp = [float(p.min()) for p in poss]
+    for draw in range(6):
+        tag = 's_%s_%d_' % (split, draw)
+        c = int(np.argmin(minp))
+        assert c == int(g[tag + 'cloud'][0])
+        idx, xyz, _ = E.possibility_draw(clouds[c], poss[c], 1500, g[tag + 'noise'],
+                                         None if weights is None else weights[c])
+        minp[c] = float(poss[c].min())
+        ref_idx = g[tag + 'point_idx'].astype(np.int64)
+        o, ro = np.argsort(idx), np.argsort(ref_idx)
+        assert np.array_equal(idx[o], ref_idx[ro])
+        assert np.array_equal(xyz[o], g[tag + 'pos'][ro])
+        if split != 'test':
+            assert np.array_equal(labels[c][idx[o]] - 1, g[tag + 'y'][ro])
+        assert np.allclose(minp, g[tag + 'min_possibility'], rtol=1e-15, atol=0)
+    for c in range(2):
+        assert np.array_equal(poss[c], g['s_%s_possibility%d' % (split, c)])
