@@ -79,6 +79,10 @@ SIGNATURES = {
     'crfconv_neighbor_maxpool_backward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),
     'crfconv_gather_rows': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     'crfconv_gather_rows_backward': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    'crfconv_meanfield_step': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp]),
+    'crfconv_kernel_weights_forward': (_i, [_vp, _vp, _i, _vp, _i, _i, _i64, _vp, _vp]),
+    'crfconv_kernel_weights_partials': (_sz, [_i64]),
+    'crfconv_kernel_weights_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp]),
     'crfconv_confusion_accumulate': (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp]),
     'crfconv_vote_accumulate': (_i, [_vp, _vp, _vp, _i64, _i, _d, _vp, _i64, _vp, _vp]),
     'crfconv_vote_project': (_i, [_vp, _vp, _i64, _i, _i64, _i, _vp, _vp, _vp]),

@@ -701,6 +701,22 @@ static int meanfield_forward_impl(const float* z, const float* y, const int32_t*
     return CRF_OK;
 }
 
+// One step with GIVEN edge weights: xout = z Q + (sum_k s_ik xin_{j(i,k)}) P  (generic kernel: any K <= 64, k0,
+// entries < 0 = no neighbour).  The discrete CRF layer (models/discrete_crf_conv.py:57-61) runs on this.
+extern "C" int crfconv_meanfield_step(const float* xin, const float* z, const float* s, const int32_t* idx32, int K,
+                                      int k0, int64_t m, int H, const float* Q, const float* P, float* xout,
+                                      crf_stream_t stream) {
+    if (int rc = check_common(m, H, K, k0)) return rc;
+    CRF_REQUIRE(xin && z && s && idx32 && Q && P && xout, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(xin != xout, CRF_ERR_ARG, "xout must not alias xin");
+    DISPATCH_H(H, {
+        const dim3 grid((unsigned)cdiv(m, Geo<HH>::PPB)), blk(BLOCK);
+        hipLaunchKernelGGL(step_kernel<HH>, grid, blk, 0, as_stream(stream), xin, z, s, idx32, K, k0, Q, P, xout, m);
+        CRF_LAUNCH_CHECK();
+    });
+    return CRF_OK;
+}
+
 extern "C" int crfconv_meanfield_bwd_edge(const float* G, const float* xprev, const float* s,
                                           const int32_t* idx32, int K, int k0, int64_t m, int H,
                                           const float* P, float* gm, float* ds, float* mt,

@@ -35,6 +35,22 @@ def _knn_segments(x, y, k, seg_x, seg_y):
     return torch.cat(rows), torch.cat(cols)
 
 
+def knn_dilated(x, y, k, dilation, batch_x=None, batch_y=None, generator=None):
+    """The reference's random dilation (models/point_conv.py:357-364, 387-394): search k * dilation neighbours, keep k
+    of them per query, drawn with replacement by torch.randint.  Done per cloud so that a cloud with fewer than
+    k * dilation points (the coarse levels of small clouds) draws from the neighbours it has instead of indexing
+    past them.  -> (y_index, x_index)."""
+    rows, cols = [], []
+    for (xs, xe), (ys, ye) in zip(_segments(batch_x, x.shape[0]), _segments(batch_y, y.shape[0])):
+        have = min(k * dilation, xe - xs)
+        idx = nn_.knn_batch_device(x[xs:xe].unsqueeze(0), y[ys:ye].unsqueeze(0), have)[0]     # [ny, have]
+        keep = min(k, have)
+        pick = torch.randint(have, (ye - ys, keep), dtype=torch.long, device=x.device, generator=generator)
+        rows.append(torch.arange(ys, ye, device=x.device).unsqueeze(1).expand(-1, keep).reshape(-1))
+        cols.append((idx.gather(1, pick) + xs).reshape(-1))
+    return torch.cat(rows), torch.cat(cols)
+
+
 def knn(x, y, k, batch_x=None, batch_y=None):
     """torch_cluster.knn: [2, E] = [y index; x index]."""
     row, col = _knn_segments(x, y, k, _segments(batch_x, x.shape[0]), _segments(batch_y, y.shape[0]))

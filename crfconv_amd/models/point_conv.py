@@ -9,6 +9,7 @@ import torch.nn.functional as F
 from .. import ops
 from ..graph import table_from_edges
 from . import graph_ops
+from .discrete_crf_conv import DiscreteCRFConv
 
 
 class DepthwiseSeparablePointConv(nn.Module):
@@ -55,13 +56,13 @@ def build_graph(pos, batch, method='radius', r=0.1, k=16, dilation=1, loop=True)
     assert method in ['radius', 'knn']
     if method == 'radius':
         return graph_ops.radius_graph(pos, r, batch, loop=loop, max_num_neighbors=k)
-    edge_index = graph_ops.knn_graph(pos, k * dilation, batch, loop=loop)
     if dilation > 1:
-        n = pos.shape[0]
-        index = torch.randint(k * dilation, (n, k), dtype=torch.long, device=edge_index.device)
-        arange = torch.arange(n, dtype=torch.long, device=edge_index.device) * (k * dilation)
-        edge_index = edge_index[:, (index + arange.view(-1, 1)).view(-1)]
-    return edge_index
+        row, col = graph_ops.knn_dilated(pos, pos, k, dilation, batch, batch)
+        if not loop:
+            keep = row != col
+            row, col = row[keep], col[keep]
+        return torch.stack([col, row])
+    return graph_ops.knn_graph(pos, k, batch, loop=loop)
 
 
 def build_bipartite_graph(pos, batch, ratio, method='radius', r=0.1, k=32, dilation=1):
@@ -69,16 +70,14 @@ def build_bipartite_graph(pos, batch, ratio, method='radius', r=0.1, k=32, dilat
     assert method in ['radius', 'knn']
     idx = graph_ops.fps(pos, batch, ratio=ratio)
     sub_pos, sub_batch = pos[idx], (batch[idx] if batch is not None else None)
-    row, col = graph_ops.knn(pos, sub_pos, k * dilation, batch, sub_batch)
     if method == 'radius':
+        row, col = graph_ops.knn(pos, sub_pos, k * dilation, batch, sub_batch)
         keep = ((sub_pos[row] - pos[col]) ** 2).sum(1) <= r * r
         row, col = row[keep], col[keep]
     elif dilation > 1:
-        n = idx.shape[0]
-        index = torch.randint(k * dilation, (n, k), dtype=torch.long, device=row.device)
-        arange = torch.arange(n, dtype=torch.long, device=row.device) * (k * dilation)
-        sel = (index + arange.view(-1, 1)).view(-1)
-        row, col = row[sel], col[sel]
+        row, col = graph_ops.knn_dilated(pos, sub_pos, k, dilation, batch, sub_batch)
+    else:
+        row, col = graph_ops.knn(pos, sub_pos, k, batch, sub_batch)
     return torch.stack([col, row], dim=0), sub_pos, sub_batch
 
 
@@ -234,3 +233,38 @@ class CRFSegNet_Part(nn.Module):
         c = F.one_hot(data.category[data.batch], num_classes=16).float()
         x = self.feature(x=torch.cat([data.pos, data.norm], dim=1), pos=data.pos, batch=data.batch)
         return F.log_softmax(self.classifier(torch.cat([x, c], dim=1)), dim=-1)
+
+
+class BaselineDiscreteCRFSegNet(nn.Module):
+    """point_conv.py:545-565: plain encoder, classifier probabilities refined by the label-space CRF; returns
+    (log p, log q)."""
+
+    def __init__(self, in_channels, n_classes=2, steps=1):
+        super().__init__()
+        self.feature = Baseline(in_channels, method='knn', ratio=[0.25, 0.375, 0.375, 0.375], radius=[0.2] * 5,
+                                kernel_size=[32, 16, 16, 16, 16], dilation=[1, 2, 4, 4, 2])
+        # the reference sizes this classifier for 64 + 64 inputs; its backbone emits 32 + 32 (same note as CRFSegNet_Part)
+        self.classifier = _head(32 + 32, 256, n_classes)
+        self.crf = DiscreteCRFConv(n_classes, in_channels, radius=0.2, kernel_size=32, steps=steps)
+
+    def forward(self, data):
+        p = torch.softmax(self.classifier(self.feature(x=data.x, pos=data.pos, batch=data.batch)), dim=-1)
+        q = self.crf(data.pos, p, f=data.x, batch=data.batch)
+        return torch.log(p), torch.log(q)
+
+
+class DualCRFSegNet(nn.Module):
+    """point_conv.py:594-617: continuous-CRF encoder + label-space CRF on its class probabilities."""
+
+    def __init__(self, in_channels, n_classes=2, steps=1):
+        super().__init__()
+        self.feature = PointConvGassuianCRFNet(in_channels, method='knn', ratio=[0.25, 0.375, 0.375, 0.375],
+                                               radius=[0.2] * 5, kernel_size=[32, 16, 16, 16, 16],
+                                               dilation=[1, 2, 4, 4, 2], steps=steps)
+        self.classifier = _head(32 + 32, 256, n_classes)
+        self.crf = DiscreteCRFConv(n_classes, in_channels, radius=0.2, kernel_size=32, steps=steps)
+
+    def forward(self, data):
+        p = torch.softmax(self.classifier(self.feature(x=data.x, pos=data.pos, batch=data.batch)), dim=-1)
+        q = self.crf(data.pos, p, f=data.x, batch=data.batch)
+        return torch.log(p), torch.log(q)

@@ -176,6 +176,95 @@ def crf_meanfield(z, y, c, table, steps, k0=1):
     return out[:, :H] if Hp != H else out
 
 
+# ------------------------------------------------------------------------------ discrete (label-space) CRF layer
+class _WeightedStep(torch.autograd.Function):
+    """xout = z Q + (sum_k w_ik x_{j(i,k)}) P with GIVEN edge weights w [m, K] (models/discrete_crf_conv.py:58-59
+    is this with Q = I, P = -C, z = -u).  Gradients to x, z, w, Q, P; scatter-free (reverse CSR)."""
+
+    @staticmethod
+    def forward(ctx, x, z, w, Q, P, table):
+        require_gpu(x, z, w, Q, P)
+        x, z, w, Q, P = _f32c(x), _f32c(z), _f32c(w), _f32c(Q), _f32c(P)
+        m, H = x.shape
+        out = torch.empty_like(x)
+        _lib.call('crfconv_meanfield_step', ptr(x), ptr(z), ptr(w), ptr(table.idx32), table.K, 0, m, H, ptr(Q), ptr(P),
+                  ptr(out), stream_ptr())
+        ctx.table = table
+        ctx.save_for_backward(x, z, w, Q, P)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, z, w, Q, P = ctx.saved_tensors
+        table = ctx.table
+        m, H = x.shape
+        G = _f32c(gout)
+        rev_ptr, rev_eid = table.reverse
+        st = stream_ptr()
+        gm, dw, mt, dx = torch.empty_like(x), torch.empty_like(w), torch.empty_like(x), torch.empty_like(x)
+        _lib.call('crfconv_meanfield_bwd_edge', ptr(G), ptr(x), ptr(w), ptr(table.idx32), table.K, 0, m, H, ptr(P),
+                  ptr(gm), ptr(dw), ptr(mt), 0, st)
+        _lib.call('crfconv_meanfield_bwd_scatter', ptr(gm), ptr(w), ptr(rev_ptr), ptr(rev_eid), table.K, 0, m, H, None,
+                  ptr(dx), st)
+        dz = G @ Q.t() if ctx.needs_input_grad[1] else None
+        dQ = z.t() @ G if ctx.needs_input_grad[3] else None
+        dP = mt.t() @ G if ctx.needs_input_grad[4] else None
+        return dx, dz, dw, dQ, dP, None
+
+
+class _KernelWeights(torch.autograd.Function):
+    """w[i,k] = sum_g Wg[g] exp(-|fk[j,g,:] - fk[i,g,:]|^2) over the table's edges (discrete_crf_conv.py:49-54)."""
+
+    @staticmethod
+    def forward(ctx, fk, Wg, table, G, H):
+        require_gpu(fk, Wg)
+        fk, Wg = _f32c(fk), _f32c(Wg)
+        m = fk.shape[0]
+        w = torch.empty((m, table.K), dtype=torch.float32, device=fk.device)
+        _lib.call('crfconv_kernel_weights_forward', ptr(fk), ptr(table.idx32), table.K, ptr(Wg), G, H, m, ptr(w),
+                  stream_ptr())
+        ctx.table, ctx.G, ctx.H = table, G, H
+        ctx.save_for_backward(fk, Wg)
+        return w
+
+    @staticmethod
+    def backward(ctx, gw):
+        fk, Wg = ctx.saved_tensors
+        table, G, H = ctx.table, ctx.G, ctx.H
+        m = fk.shape[0]
+        rev_ptr, rev_eid = table.reverse
+        gw = _f32c(gw)
+        scratch, dfk = torch.empty_like(fk), torch.empty_like(fk)
+        nblk = _lib.load().crfconv_kernel_weights_partials(m) // 8
+        part = torch.empty((nblk, 8), dtype=torch.float64, device=fk.device)
+        _lib.call('crfconv_kernel_weights_backward', ptr(gw), ptr(fk), ptr(table.idx32), ptr(rev_ptr), ptr(rev_eid),
+                  table.K, ptr(Wg), G, H, m, ptr(scratch), ptr(dfk), ptr(part), stream_ptr())
+        return dfk, part.sum(0)[:G].to(torch.float32), None, None, None
+
+
+def weighted_step(x, z, w, Q, P, table):
+    return _WeightedStep.apply(x, z, w, Q, P, table)
+
+
+def kernel_weights(fk, Wg, table, G, H):
+    return _KernelWeights.apply(fk, Wg, table, G, H)
+
+
+def discrete_meanfield(p, u, w, C, table, steps):
+    """q_0 = p;  q <- softmax(-u - (sum_e w_e q_j) C)  `steps` times (models/discrete_crf_conv.py:56-61); label
+    dimension padded to a kernel width, the soft-max taken over the real labels only."""
+    L = p.shape[1]
+    Hp = _next_supported(L, _CRF_H)
+    eye = torch.eye(Hp, dtype=torch.float32, device=p.device)
+    negC = torch.nn.functional.pad(-C, (0, Hp - L, 0, Hp - L))
+    z = _pad_channels(-u, Hp)
+    q = p
+    for _ in range(steps):
+        x = weighted_step(_pad_channels(q, Hp), z, w, eye, negC, table)
+        q = torch.softmax(x[:, :L], dim=-1)
+    return q
+
+
 # ------------------------------------------------------------------------------ deferred weight gradients
 # Every Linear's dW = G^T X ends in a small "sum the row-slice partials" launch; PointConvBig has 74 of them per
 # backward pass, each far below the cost of launching it.  Inside ``with deferred_weight_grads():`` the MFMA kernel

@@ -365,6 +365,26 @@ int crfconv_softmax_ce_backward(const float* logits, const int64_t* target, cons
 int crfconv_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
                      float dampening, float weight_decay, int nesterov, int first_step, crf_stream_t stream);
 
+/* ===================================================================== (B) discrete (label-space) CRF layer
+ * models/discrete_crf_conv.py:40-63.  One mean-field step with GIVEN edge weights s [m, K] (edge-id addressed like
+ * every per-edge array; entries of idx32 < 0 = no neighbour):  xout = z Q + (sum_k s_ik xin[idx32[i,k]]) P.
+ * The layer's update  q <- softmax(-u - (sum_e w_e q_j) C)  (:58-60) is this with z = -u, Q = I, P = -C and a row
+ * soft-max on top.  Backward through crfconv_meanfield_bwd_edge / _bwd_scatter. */
+int crfconv_meanfield_step(const float* xin, const float* z, const float* s, const int32_t* idx32, int K, int k0,
+                           int64_t m, int H, const float* Q, const float* P, float* xout, crf_stream_t stream);
+
+/* Edge weights of :49-54:  w[i,k] = sum_g Wg[g] exp(-| fk[j, g, :] - fk[i, g, :] |^2),  j = idx32[i,k]  (0 where
+ * j < 0);  fk [m, G * H] = f F_g for the G <= 8 Gaussian kernels, H <= 256 hidden channels.
+ * Backward: gw [m, K] -> dfk [m, G * H] (dfk_self is scratch of the same size; the source side walks the reverse
+ * CSR, no atomics) and dW_partial [crfconv_kernel_weights_partials(m)] float64 block partials laid out [block][8]
+ * whose column sums over blocks are dWg[0..G). */
+int crfconv_kernel_weights_forward(const float* fk, const int32_t* idx32, int K, const float* Wg, int G, int H,
+                                   int64_t m, float* w, crf_stream_t stream);
+size_t crfconv_kernel_weights_partials(int64_t m);
+int crfconv_kernel_weights_backward(const float* gw, const float* fk, const int32_t* idx32, const int32_t* rev_ptr,
+                                    const int32_t* rev_eid, int K, const float* Wg, int G, int H, int64_t m,
+                                    float* dfk_self, float* dfk, double* dW_partial, crf_stream_t stream);
+
 /* ===================================================================== (C) callers either side of the network
  * SURVEY 8(f) rows 2-3.  All device pointers; nothing here synchronises.
  *

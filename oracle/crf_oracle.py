@@ -246,3 +246,23 @@ def ds_point_conv(sd, prefix, x, pos, edge_index, training):
     msg = torch.zeros((n_dst, h.shape[1]), dtype=h.dtype).index_add_(0, row, w * h[col])
     out = _lin_bn(sd, prefix + 'mlp3.', msg, training)
     return F.leaky_relu(out + res)
+
+
+def discrete_crf(sd, prefix, p, f, tgt, src, steps):
+    """models/discrete_crf_conv.py:40-63 on an explicit edge list (tgt = ``row``, src = ``col`` of the radius graph,
+    :44): Gaussian-kernel edge weights in the hidden spaces f F_g (:49-54), then ``steps`` rounds of
+    message passing (scatter_add of w * q[col] at row, :58), label compatibility (:59) and soft-max (:60).
+    Parameters ``F`` [G, D, H], ``W`` [G, 1], ``C`` [L, L].  Pinned by g10_discrete.npz (the reference layer run
+    with the graph injected for the absent torch_cluster radius search; torch_scatter.scatter_add restated as
+    index_add -- "parity unpinned" at that third-party boundary)."""
+    Fk, Wk, C = sd[prefix + 'F'], sd[prefix + 'W'], sd[prefix + 'C']
+    n = p.shape[0]
+    u = -torch.log(p)
+    fk = torch.einsum('nd,gdh->ngh', f, Fk)                       # [N, G, H]
+    diff = fk[src] - fk[tgt]
+    w = torch.exp(-(diff ** 2).sum(-1)) @ Wk                      # [E, 1]
+    q = p
+    for _ in range(steps):
+        msg = torch.zeros((n, p.shape[1]), dtype=p.dtype).index_add_(0, tgt, q[src] * w)
+        q = torch.softmax(-u - msg @ C, dim=-1)
+    return q

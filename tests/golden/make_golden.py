@@ -495,6 +495,43 @@ def g8_sparse(models):
     save('g8_sparse.npz', **out)
 
 
+def g10_discrete(models):
+    """models/discrete_crf_conv.py run as it is; the radius graph is injected (torch_cluster absent), scatter_add is
+    the index_add restatement above."""
+    from models.discrete_crf_conv import DiscreteCRFConv
+    N, K, NA, L, D = 300, 10, 170, 13, 6
+    pos = np.concatenate([S.make_cloud(1000, NA), S.make_cloud(1001, N - NA) + np.float32(3.0)])
+    nb0 = onative.ref_knn(pos[:NA], pos[:NA], K + 1)[:, 1:]
+    nb1 = onative.ref_knn(pos[NA:], pos[NA:], K + 1)[:, 1:] + NA
+    tgt = np.repeat(np.arange(N), K)
+    src = np.concatenate([nb0, nb1]).reshape(-1)
+    keep = S.uniform(10, 'keep', (tgt.size,), 0, 1) > 0.25         # ragged degrees, some isolated targets possible
+    tgt, src = tgt[keep], src[keep]
+    out = dict(pos=pos, tgt=tgt.astype(np.int16), src=src.astype(np.int16))
+    logit = torch.from_numpy(S.uniform(10, 'logit', (N, L), -2, 2))
+    f = torch.from_numpy(S.uniform(10, 'f', (N, D), 0, 1))
+    out.update(logit=logit.numpy(), f=f.numpy())
+    for steps, hidden, kernels in ((1, 64, 5), (3, 64, 5), (5, 16, 3), (2, 96, 2)):
+        tag = 'T%d_H%d_G%d' % (steps, hidden, kernels)
+        m = DiscreteCRFConv(L, D, hidden_channels=hidden, num_kernels=kernels, radius=0.2, kernel_size=K, steps=steps)
+        sd = {'F': torch.from_numpy(S.uniform(10, 'F' + tag, (kernels, D, hidden), 0, 0.35)),
+              'W': torch.from_numpy(S.uniform(10, 'W' + tag, (kernels, 1), 0.05, 0.6)),
+              'C': torch.from_numpy((np.eye(L) + 0.3 * S.uniform(10, 'C' + tag, (L, L))).astype(np.float32))}
+        m.load_state_dict(sd, strict=True)
+        _INJECTED_GRAPH['edge_index'] = torch.stack([torch.from_numpy(src), torch.from_numpy(tgt)])
+        li, fi = logit.clone().requires_grad_(True), f.clone().requires_grad_(True)
+        q = m(torch.from_numpy(pos), torch.softmax(li, dim=-1), f=fi, batch=None)
+        gout = torch.from_numpy(S.uniform(10, 'g' + tag, tuple(q.shape)))
+        (torch.log(q) * gout).sum().backward()
+        out.update(pack(tag + '/sd', sd))
+        out.update(pack(tag + '/grad', grads_of(m)))
+        out[tag + '/q'] = q.detach().numpy()
+        out[tag + '/gout'] = gout.numpy()
+        out[tag + '/d_logit'] = li.grad.numpy()
+        out[tag + '/d_f'] = fi.grad.numpy()
+    save('g10_discrete.npz', **out)
+
+
 def import_reference_file(relpath, name, stubs=()):
     """Loads ONE reference source file as a module (its package __init__ would pull in half of torch_geometric)."""
     import importlib.util
@@ -579,6 +616,6 @@ if __name__ == '__main__':
     models = import_reference_models()
     only = set(sys.argv[1:])
     for fn in (g1_crfconv, g2_meanfield_fp64, g3_pointconv, g4_resblock, g5_pointconvbig, g6_knn,
-               g7_grid, g8_sparse, g9_eval):
+               g7_grid, g8_sparse, g9_eval, g10_discrete):
         if not only or fn.__name__.split('_')[0] in only:
             fn(models)

@@ -200,3 +200,77 @@ def test_sparse_meanfield_wide_channels(H):
     assert_close(out, ref, 1e-4, 'wide forward')
     for name, a, b in (('dz', z, zc), ('dy', y, yc), ('dc', c, cc)):
         assert_close(a.grad, b.grad, 2e-4, name)
+
+
+# ------------------------------------------------------------------ label-space (discrete) CRF layer, 8(f) row 4
+@pytest.mark.parametrize('tag', ['T1_H64_G5', 'T3_H64_G5', 'T5_H16_G3', 'T2_H96_G2'])
+def test_discrete_crf_golden(golden, tag):
+    """DiscreteCRFConv on the HIP kernels against the reference layer (fixture): q and the gradients of the input
+    logits, the kernel features and F / W / C; ragged degrees, 13 labels padded to 16 inside."""
+    from crfconv_amd.models import DiscreteCRFConv
+    g = golden('g10_discrete.npz')
+    steps, hidden, kernels = int(tag[1]), int(tag.split('_')[1][1:]), int(tag.split('_')[2][1:])
+    m = load_sd(DiscreteCRFConv(13, 6, hidden_channels=hidden, num_kernels=kernels, radius=0.2, kernel_size=10,
+                                steps=steps), sub(g, tag + '/sd')).to(DEV)
+    logit, f = t(g['logit']).requires_grad_(True), t(g['f']).requires_grad_(True)
+    ei = torch.stack([t(g['src'].astype(np.int64)), t(g['tgt'].astype(np.int64))])
+    q = m(t(g['pos']), torch.softmax(logit, -1), f=f, edge_index=ei)
+    assert_close(q, g[tag + '/q'], OUT_TOL, 'q')
+    (torch.log(q) * t(g[tag + '/gout'])).sum().backward()
+    assert_close(logit.grad, g[tag + '/d_logit'], GRAD_TOL, 'd_logit')
+    assert_close(f.grad, g[tag + '/d_f'], GRAD_TOL, 'd_f')
+    for k, v in sub(g, tag + '/grad').items():
+        assert_close(grads(m)[k], v, GRAD_TOL, 'grad ' + k)
+
+
+def test_discrete_crf_device_graph_vs_oracle():
+    """Larger ragged batch with the graph from the device radius search (no graph injected): forward and gradients
+    against the oracle on that same graph; isolated points keep q = softmax(log p) = p."""
+    from crfconv_amd.models import DiscreteCRFConv, graph_ops
+    n0, n1, L, D = 3000, 2000, 8, 6
+    pos = t(np.concatenate([S.make_cloud(50, n0), S.make_cloud(51, n1) * np.float32(4.0)]))   # 2nd cloud sparse
+    batch = t(np.concatenate([np.zeros(n0, np.int64), np.ones(n1, np.int64)]))
+    m = DiscreteCRFConv(L, D, hidden_channels=32, num_kernels=4, radius=0.12, kernel_size=16, steps=3).to(DEV)
+    with torch.no_grad():
+        m.F.mul_(0.3)
+        m.C.add_(0.2 * t(S.uniform(50, 'C', (L, L))))
+    ei = graph_ops.radius_graph(pos, 0.12, batch, loop=False, max_num_neighbors=16)
+    deg = torch.bincount(ei[1], minlength=n0 + n1)
+    assert int(deg.max()) <= 16 and int((deg == 0).sum()) > 0
+    logit, f = t(S.uniform(50, 'l', (n0 + n1, L), -2, 2)).requires_grad_(), t(S.uniform(50, 'f', (n0 + n1, D), 0, 1)).requires_grad_()
+    gout = t(S.uniform(50, 'g', (n0 + n1, L)))
+    q = m(pos, torch.softmax(logit, -1), f=f, batch=batch)
+    (torch.log(q) * gout).sum().backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_() for k, v in m.state_dict().items()}
+    lc, fc = logit.detach().cpu().requires_grad_(), f.detach().cpu().requires_grad_()
+    ref = O.discrete_crf(sd, '', torch.softmax(lc, -1), fc, ei[1].cpu(), ei[0].cpu(), 3)
+    (torch.log(ref) * gout.cpu()).sum().backward()
+    assert_close(q, ref, OUT_TOL, 'q')
+    iso = (deg == 0)
+    assert torch.allclose(q[iso], torch.softmax(logit, -1)[iso].detach(), atol=1e-6)
+    assert_close(logit.grad, lc.grad, GRAD_TOL, 'd_logit')
+    assert_close(f.grad, fc.grad, GRAD_TOL, 'd_f')
+    for k, p in m.named_parameters():
+        assert_close(p.grad, sd[k].grad, GRAD_TOL, 'grad ' + k)
+
+
+def test_discrete_crf_networks_run_and_train():
+    """BaselineDiscreteCRFSegNet / DualCRFSegNet (point_conv.py:545-565, 594-617): (log p, log q) normalised, finite,
+    gradients reach every parameter."""
+    import crfconv_amd
+    from crfconv_amd import models
+    n0, n1 = 900, 650
+    pos = t(np.concatenate([S.make_cloud(60, n0), S.make_cloud(61, n1)]))
+    batch = t(np.concatenate([np.zeros(n0, np.int64), np.ones(n1, np.int64)]))
+    feat = t(S.uniform(60, 'f', (n0 + n1, 6), 0, 1))
+    label = t(S.integers(60, 'y', (n0 + n1,), 0, 5))
+    data = crfconv_amd.Data(pos=pos, x=feat, batch=batch)
+    for net in (models.BaselineDiscreteCRFSegNet(6, 5, steps=2), models.DualCRFSegNet(6, 5, steps=2)):
+        net = net.to(DEV).train()
+        logp, logq = net(data)
+        for o in (logp, logq):
+            assert o.shape == (n0 + n1, 5) and torch.isfinite(o).all()
+            assert torch.allclose(o.exp().sum(1), torch.ones(n0 + n1, device=DEV), atol=1e-4)
+        (torch.nn.functional.nll_loss(logp, label) + torch.nn.functional.nll_loss(logq, label)).backward()
+        missing = [k for k, p in net.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+        assert not missing, missing

@@ -343,3 +343,18 @@ def test_possibility_sampler_oracle_golden(golden, split):
         assert np.allclose(minp, g[tag + 'min_possibility'], rtol=1e-15, atol=0)
     for c in range(2):
         assert np.array_equal(poss[c], g['s_%s_possibility%d' % (split, c)])
+
+
+@pytest.mark.parametrize('tag', ['T1_H64_G5', 'T3_H64_G5', 'T5_H16_G3', 'T2_H96_G2'])
+def test_discrete_crf_oracle_golden(golden, tag):
+    """oracle.discrete_crf against the reference's DiscreteCRFConv (ragged injected graph): q and every gradient."""
+    g = golden('g10_discrete.npz')
+    sd = params(sub(g, tag + '/sd'))
+    logit, f = t(g['logit']).requires_grad_(True), t(g['f']).requires_grad_(True)
+    tgt, src = t(g['tgt'].astype(np.int64)), t(g['src'].astype(np.int64))
+    q = O.discrete_crf(sd, '', torch.softmax(logit, -1), f, tgt, src, int(tag[1]))
+    close(q, g[tag + '/q'], OUT_TOL, 'q')
+    (torch.log(q) * t(g[tag + '/gout'])).sum().backward()
+    close(logit.grad, g[tag + '/d_logit'], GRAD_TOL, 'd_logit')
+    close(f.grad, g[tag + '/d_f'], GRAD_TOL, 'd_f')
+    check_grads(sd, g, tag + '/grad')
