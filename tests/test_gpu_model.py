@@ -352,6 +352,80 @@ def test_meanfield_properties_full_size():
     assert float((out[0] - v).abs().max()) < 1e-5
 
 
+# ------------------------------------------------------------------ the other BASELINE configs at their full sizes
+@pytest.mark.parametrize('name,B,N,K,T,H', [('C3 KITTI scan', 1, 122880, 16, 1, 8), ('C4 ScanNet cloud', 4, 81920, 16, 3, 8),
+                                            ('C5 Semantic3D crops', 2, 65536, 32, 5, 8), ('C5 level 1', 2, 16384, 32, 5, 16)])
+def test_meanfield_other_configs_full_size(name, B, N, K, T, H):
+    """BASELINE.json configs 3-5 at full size: the mean-field forward AND backward against the CPU oracle on the whole
+    batch (the oracle takes seconds at these sizes), through the int32 index path (clouds > 65536 points: C3, C4) and
+    the uint16 path at its limit (65536-point crops, K = 32: C5)."""
+    from crfconv_amd import ops
+    from crfconv_amd.graph import NeighborTable
+    from crfconv_amd.utils import nearest_neighbors
+    g = torch.Generator().manual_seed(N + K)
+    pos = (torch.rand(B, N, 3, generator=g) * torch.tensor([20.0, 20.0, 4.0])).to(DEV)
+    nbr = nearest_neighbors.knn_batch_device(pos, pos, K)
+    tab = NeighborTable(nbr, N)
+    assert (tab.idx16 is not None) == (N <= 65536)
+    z = torch.randn(B * N, H, generator=g).to(DEV).requires_grad_()
+    y = (0.5 * torch.randn(B * N, H, generator=g)).to(DEV).requires_grad_()
+    c = (torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)).to(DEV).requires_grad_()
+    gout = torch.randn(B * N, H, generator=g).to(DEV)
+    out = ops.crf_meanfield(z, y, c, tab, T)
+    (out * gout).sum().backward()
+    torch.set_num_threads(16)
+    zc = z.detach().cpu().reshape(B, N, H).requires_grad_()
+    yc = y.detach().cpu().reshape(B, N, H).requires_grad_()
+    cc = c.detach().cpu().requires_grad_()
+    ref = O.crf_meanfield(zc, yc, nbr.cpu()[:, :, 1:], cc, T)          # column 0 = the query itself, dropped by position
+    (ref * gout.cpu().reshape(B, N, H)).sum().backward()
+    assert_close(out, ref.reshape(B * N, H), OUT_TOL, name + ' forward')
+    assert_close(z.grad, zc.grad.reshape(B * N, H), GRAD_TOL, name + ' dz')
+    assert_close(y.grad, yc.grad.reshape(B * N, H), GRAD_TOL, name + ' dy')
+    assert_close(c.grad, cc.grad, GRAD_TOL, name + ' dc')
+
+
+def test_config3_inference_matches_oracle():
+    """BASELINE.json config 3: one KITTI-like scan of 122 880 points (ranges 2-50 m on 64 elevation rings), K = 16,
+    one mean-field step, PointConvBig in eval mode; per-point logits within 1e-4 of the CPU oracle and the same
+    arg-max labels ("mIoU parity": identical confusion matrix)."""
+    import crfconv_amd
+    from crfconv_amd import models
+    from crfconv_amd.utils import runningScore
+    g = torch.Generator().manual_seed(33)
+    N, ncls = 122880, 19
+    r = 2 + 48 * torch.rand(N, generator=g)
+    az = 2 * np.pi * torch.rand(N, generator=g)
+    el = torch.deg2rad(-25 + 28 * torch.randint(0, 64, (N,), generator=g).float() / 63)
+    pos = torch.stack([r * torch.cos(el) * torch.cos(az), r * torch.cos(el) * torch.sin(az), r * torch.sin(el)], 1)
+    pos = (pos + 0.01 * torch.randn(N, 3, generator=g)).float().unsqueeze(0)
+    feats = torch.cat([pos, torch.rand(1, N, 1, generator=g)], -1)                      # xyz + remission: in_channels = 4
+    data = crfconv_amd.multiscale_compute(pos.to(DEV), x=feats.to(DEV), generator=g)
+    net = models.PointConvBig(4, ncls, use_crf=True, steps=1)
+    sd = S.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 9)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        logits = net(data)
+    assert logits.shape == (N, ncls) and torch.isfinite(logits).all()
+    torch.set_num_threads(16)
+    ms = [{k: getattr(l, k).cpu() for k in ('pos', 'neighbor_idx', 'sub_idx', 'up_idx') if getattr(l, k, None) is not None}
+          for l in data.multiscale]
+    with torch.no_grad():
+        # the device collate emits each cloud in Morton order: the oracle gets the features in that same order
+        ref = O.pointconv_resnet({k: v.clone() for k, v in sd.items()}, data.x.cpu(), ms, 1, False, True)
+    assert_close(logits, ref, OUT_TOL, 'config-3 logits')
+    labels = torch.randint(0, ncls, (N,), generator=g)
+    a, b = runningScore(ncls), runningScore(ncls)
+    a.update_from_logits(labels.to(DEV), logits)
+    b.update(labels.to(DEV), ref.argmax(1).to(DEV))
+    # arg-max may flip only where the two largest logits are closer than the tolerance
+    top2 = ref.topk(2, dim=1).values
+    margin = 2 * OUT_TOL * max(1.0, float(ref.abs().max()))           # the tolerance of assert_close, both ways
+    ambiguous = int(((top2[:, 0] - top2[:, 1]) < margin).sum())
+    assert np.abs(a.confusion_matrix - b.confusion_matrix).sum() <= 2 * ambiguous
+
+
 @pytest.mark.parametrize('M,Ci,Co,bias', [(163840, 32, 128, False), (40960, 64, 16, False), (1000, 6, 8, False),
                                           (2560, 512, 256, False), (777, 128, 13, True), (163840, 8, 8, False)])
 def test_linear_wgrad_mfma(M, Ci, Co, bias):
