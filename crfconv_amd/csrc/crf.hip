@@ -102,6 +102,27 @@ __device__ __forceinline__ void load_index_row(const int32_t* __restrict__ idx32
     }
 }
 
+// K-wide rows of the wave's PPW points (PPW * K contiguous floats in memory) written as 1 KiB-contiguous stores.
+// Stored straight from the owning lanes, each store instruction touches 64/L rows with 16 bytes each (measured on
+// the level-0 first kernel: +2.1 us); routed through a per-wave LDS tile every instruction writes consecutive bytes.
+// One call per kernel (the tile is a single static array per instantiation).
+template <int H, int K>
+__device__ __forceinline__ void store_rows_coalesced(const float (&d)[K], float* __restrict__ dst, int lane, int q,
+                                                     int64_t m) {
+    constexpr int L = Geo<H>::L, PPW = Geo<H>::PPW, CPR = K / 4, NCH = PPW * CPR;   // 16-byte chunks per row / wave
+    __shared__ float4 tile[BLOCK / WAVE][NCH];
+    float4* mine = tile[threadIdx.x >> 6];
+    const int p = lane / L;
+#pragma unroll
+    for (int c = 0; c < CPR; ++c)
+        if ((c % L) == q) mine[p * CPR + c] = make_float4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]);
+    __builtin_amdgcn_wave_barrier();     // LDS operations of one wave complete in order
+    const int64_t row0 = (int64_t)xcd_block_id() * Geo<H>::PPB + (threadIdx.x >> 6) * PPW;
+#pragma unroll
+    for (int c = lane; c < NCH; c += WAVE)
+        if (row0 + c / CPR < m) st4(dst + row0 * K + 4 * c, mine[c]);
+}
+
 // ====================================================================== fast forward kernels
 // (K in {16, 32}, k0 == 1).  FIRST = similarity + z Q + first step fused: the index row is read
 // once, s never round-trips through memory before its first use.
@@ -151,23 +172,7 @@ __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_f
     d[0] = 0.f;
 #pragma unroll
     for (int k = 1; k < K; ++k) d[k] *= inv;
-    // s rows: the wave's PPW points own PPW * K contiguous floats.  Written straight from the owning lanes each
-    // store instruction would touch 64/L rows with 16 bytes each (measured: +2.1 us on the level-0 kernel); routed
-    // through a per-wave LDS tile instead, every store instruction writes 1 KiB of consecutive bytes.
-    {
-        constexpr int PPW = Geo<H>::PPW, CPR = K / 4, NCH = PPW * CPR;      // 16-byte chunks per row / per wave
-        __shared__ float4 sS[BLOCK / WAVE][NCH];
-        float4* mine = sS[threadIdx.x >> 6];
-        const int p = lane / L;
-#pragma unroll
-        for (int c = 0; c < CPR; ++c)
-            if ((c % L) == q) mine[p * CPR + c] = make_float4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]);
-        __builtin_amdgcn_wave_barrier();     // LDS operations of one wave complete in order
-        const int64_t row0 = (int64_t)xcd_block_id() * Geo<H>::PPB + (threadIdx.x >> 6) * PPW;
-#pragma unroll
-        for (int c = lane; c < NCH; c += WAVE)
-            if (row0 + c / CPR < m) st4(s + row0 * K + 4 * c, mine[c]);
-    }
+    store_rows_coalesced<H, K>(d, s, lane, q, m);
 
     if constexpr (WITH_STEP) {
         const float4 zi = ld4(z + r * H + 4 * q);
@@ -481,10 +486,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_edge_kernel(const float* __restrict
             dd[k] += group_sum<L>(dot4(gmi, nb[k]));
         }
         dd[0] = 0.f;
-#pragma unroll
-        for (int c = 0; c < KT / 4; ++c)
-            if (valid && (c % L) == q)
-                st4(ds + r * KT + 4 * c, make_float4(dd[4 * c], dd[4 * c + 1], dd[4 * c + 2], dd[4 * c + 3]));
+        store_rows_coalesced<H, KT>(dd, ds, lane, q, m);
     } else {
         const int32_t* irow = idx + r * K;
         const float* srow = s + r * K;
@@ -563,6 +565,40 @@ __global__ __launch_bounds__(BLOCK) void sim_bwd_kernel(const float* __restrict_
     }
     if (valid && q == 0)
         for (int k = 0; k < k0; ++k) wrow[k] = 0.f;
+    if (valid) st4(dy_self + r * H + 4 * q, acc);
+}
+
+// fast form (K = 16, k0 = 1): index / s / ds rows as aligned dwordx4 loads, all K-1 gathers in flight, w rows
+// written through the per-wave LDS tile
+template <int H, int K>
+__global__ __launch_bounds__(BLOCK) void sim_bwd_fast_kernel(const float* __restrict__ ds, const float* __restrict__ s,
+                                                             const float* __restrict__ y,
+                                                             const int32_t* __restrict__ idx, float* __restrict__ w,
+                                                             float* __restrict__ dy_self, int64_t m) {
+    int lane, q;
+    bool valid;
+    const int64_t r = my_point<H>(m, lane, q, valid);
+    int j[K];
+    float sw[K], dd[K];
+    load_row<K, int4>(idx + r * K, j);
+    const float4 yi = ld4(y + r * H + 4 * q);
+    float4 nb[K];
+#pragma unroll
+    for (int k = 1; k < K; ++k) nb[k] = ld4(y + (int64_t)j[k] * H + 4 * q);
+    load_row<K, float4>(s + r * K, sw);
+    load_row<K, float4>(ds + r * K, dd);
+    float dotv = 0.f;
+#pragma unroll
+    for (int k = 1; k < K; ++k) dotv = fmaf(sw[k], dd[k], dotv);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    dd[0] = 0.f;
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        const float wk = -2.0f * sw[k] * (dd[k] - dotv);
+        acc = fma4(wk, sub4(yi, nb[k]), acc);
+        dd[k] = wk;
+    }
+    store_rows_coalesced<H, K>(dd, w, lane, q, m);
     if (valid) st4(dy_self + r * H + 4 * q, acc);
 }
 
@@ -757,6 +793,14 @@ extern "C" int crfconv_similarity_bwd(const float* ds, const float* s, const flo
     CRF_REQUIRE(w != ds, CRF_ERR_ARG, "w must not alias ds");
     DISPATCH_H(H, {
         const dim3 grid((unsigned)cdiv(m, Geo<HH>::PPB));
+        if constexpr (HH <= 16) {
+            if (k0 == 1 && K == 16) {
+                hipLaunchKernelGGL((sim_bwd_fast_kernel<HH, 16>), grid, dim3(BLOCK), 0, as_stream(stream), ds, s, y, idx32,
+                                   w, dy_self, m);
+                CRF_LAUNCH_CHECK();
+                return CRF_OK;
+            }
+        }
         hipLaunchKernelGGL(sim_bwd_kernel<HH>, grid, dim3(BLOCK), 0, as_stream(stream), ds, s, y, idx32,
                            K, k0, w, dy_self, m);
         CRF_LAUNCH_CHECK();
