@@ -227,6 +227,161 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(const float* __r
     }
 }
 
+// ------------------------------------------------------------------ small tensors: the whole BatchNorm in ONE launch
+// The coarse levels (2560 / 640 points, 64..512 channels) are launch-bound: stats -> finalize -> apply cost three
+// launches of 4.5-6 us for a few hundred KB.  Here one 1024-thread workgroup owns ONE channel quad (16 bytes of every
+// row) and keeps its column in registers (NR rows per thread, every load in flight at once): statistics (fp32 per
+// thread over <= NR rows, float64 across threads, fixed order) -> coefficients -> apply, one memory round trip, no
+// cross-workgroup dependency.  A quad per workgroup (C/4 workgroups) rather than a wider slice: a workgroup streams at
+// one CU's ~60 GB/s, so the work has to spread over many CUs (16-channel slices measured 11-22 us, this 5-6 us).
+constexpr int BNS_BLOCK = 1024, BNS_CH = 4, BNS_ROWS = BNS_BLOCK, BNS_NR = 3, BNS_MAXM = BNS_ROWS * BNS_NR;
+
+// sum over the 1024 threads of 8 per-thread floats {a.xyzw, b.xyzw}; every thread returns the totals in out[0..8).
+// Fixed order: xor-shuffles inside a wave, then waves 0..15.
+__device__ __forceinline__ void bns_block_sum(const float4 a, const float4 b, double (&out)[8], double (*s_red)[8]) {
+    double v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) v[i] += __shfl_xor(v[i], o, WAVE);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s_red[wave][i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {                                       // thread i folds the 16 waves, fixed order
+        double t = 0.0;
+        for (int w = 0; w < BNS_BLOCK / WAVE; ++w) t += s_red[w][threadIdx.x];
+        s_red[0][threadIdx.x] = t;                               // slot [0][i] is read by this thread only, above
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = s_red[0][i];
+}
+
+template <int NR>
+__global__ __launch_bounds__(BNS_BLOCK) void bn_small_fwd_kernel(const float* __restrict__ x, int64_t M, int C,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps,
+                                                                 float* __restrict__ run_mean,
+                                                                 float* __restrict__ run_var, float momentum,
+                                                                 float slope, float* __restrict__ coef,
+                                                                 float* __restrict__ y) {
+    __shared__ double s_red[BNS_BLOCK / WAVE][8];
+    const int rl = threadIdx.x;
+    const int c = blockIdx.x * BNS_CH;
+    const float4 sh = ld4g(x + c);                               // shift = row 0 (a sample: no cancellation in the sums)
+    float4 v[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int64_t r = rl + (int64_t)u * BNS_ROWS;
+        v[u] = r < M ? ld4g(x + r * C + c) : sh;                  // rows past the end contribute d = 0
+    }
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const float4 d = make_float4(v[u].x - sh.x, v[u].y - sh.y, v[u].z - sh.z, v[u].w - sh.w);
+        s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+        s2.x = fmaf(d.x, d.x, s2.x); s2.y = fmaf(d.y, d.y, s2.y); s2.z = fmaf(d.z, d.z, s2.z); s2.w = fmaf(d.w, d.w, s2.w);
+    }
+    double t[8];
+    bns_block_sum(s1, s2, t, s_red);
+    float av[4], bv[4];
+    const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double m1 = t[i] / (double)M;
+        const double mean = (double)shv[i] + m1;
+        double var = (t[4 + i] - t[i] * m1) / (double)M;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double a = (double)gamma[c + i] * rstd;
+        av[i] = (float)a;
+        bv[i] = (float)((double)beta[c + i] - a * mean);
+        if (rl == 0) {                                           // one thread per channel quad publishes
+            coef[c + i] = av[i];
+            coef[C + c + i] = bv[i];
+            coef[2 * C + c + i] = (float)mean;
+            coef[3 * C + c + i] = (float)rstd;
+            if (run_mean != nullptr) {
+                const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+                run_mean[c + i] = (float)((1.0 - (double)momentum) * (double)run_mean[c + i] + (double)momentum * mean);
+                run_var[c + i] = (float)((1.0 - (double)momentum) * (double)run_var[c + i] + (double)momentum * unb);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int64_t r = rl + (int64_t)u * BNS_ROWS;
+        float4 o;
+        o.x = fmaf(av[0], v[u].x, bv[0]); o.y = fmaf(av[1], v[u].y, bv[1]);
+        o.z = fmaf(av[2], v[u].z, bv[2]); o.w = fmaf(av[3], v[u].w, bv[3]);
+        o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
+        o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
+        if (r < M) st4(y + r * C + c, o);
+    }
+}
+
+template <int NR>
+__global__ __launch_bounds__(BNS_BLOCK) void bn_small_bwd_kernel(const float* __restrict__ gy,
+                                                                 const float* __restrict__ x,
+                                                                 const float* __restrict__ coef, int64_t M, int C,
+                                                                 int training, float slope, float* __restrict__ gx,
+                                                                 float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta) {
+    __shared__ double s_red[BNS_BLOCK / WAVE][8];
+    const int rl = threadIdx.x;
+    const int c = blockIdx.x * BNS_CH;
+    const float4 a = ld4g(coef + c), b = ld4g(coef + C + c), mu = ld4g(coef + 2 * C + c), rs = ld4g(coef + 3 * C + c);
+    float4 xh[NR], g[NR];                                        // x-hat and the gradient in front of the activation
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int64_t r = rl + (int64_t)u * BNS_ROWS;
+        const bool in = r < M;
+        xh[u] = in ? ld4g(x + r * C + c) : mu;
+        g[u] = in ? ld4g(gy + r * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const float4 v = xh[u];
+        g[u].x *= fmaf(a.x, v.x, b.x) > 0.f ? 1.f : slope;
+        g[u].y *= fmaf(a.y, v.y, b.y) > 0.f ? 1.f : slope;
+        g[u].z *= fmaf(a.z, v.z, b.z) > 0.f ? 1.f : slope;
+        g[u].w *= fmaf(a.w, v.w, b.w) > 0.f ? 1.f : slope;
+        xh[u] = make_float4((v.x - mu.x) * rs.x, (v.y - mu.y) * rs.y, (v.z - mu.z) * rs.z, (v.w - mu.w) * rs.w);
+        s1.x += g[u].x; s1.y += g[u].y; s1.z += g[u].z; s1.w += g[u].w;
+        s2.x = fmaf(g[u].x, xh[u].x, s2.x); s2.y = fmaf(g[u].y, xh[u].y, s2.y);
+        s2.z = fmaf(g[u].z, xh[u].z, s2.z); s2.w = fmaf(g[u].w, xh[u].w, s2.w);
+    }
+    double t[8];
+    bns_block_sum(s1, s2, t, s_red);
+    float c2[4], c3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        c2[i] = training ? (float)(t[i] / (double)M) : 0.f;
+        c3[i] = training ? (float)(t[4 + i] / (double)M) : 0.f;
+        if (rl == 0) {
+            dbeta[c + i] = (float)t[i];
+            dgamma[c + i] = (float)t[4 + i];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int64_t r = rl + (int64_t)u * BNS_ROWS;
+        float4 o;
+        o.x = a.x * (g[u].x - c2[0] - xh[u].x * c3[0]);
+        o.y = a.y * (g[u].y - c2[1] - xh[u].y * c3[1]);
+        o.z = a.z * (g[u].z - c2[2] - xh[u].z * c3[2]);
+        o.w = a.w * (g[u].w - c2[3] - xh[u].w * c3[3]);
+        if (r < M) st4(gx + r * C + c, o);
+    }
+}
+
+static bool bn_small_ok(int64_t M, int C) { return M <= BNS_MAXM && C % BNS_CH == 0; }
+
 static int bn_check(int64_t M, int C) {
     CRF_REQUIRE(M > 0 && M < ((int64_t)1 << 40), CRF_ERR_ARG, "M=%lld out of range", (long long)M);
     CRF_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024, CRF_ERR_UNSUPPORTED, "C=%d must be a multiple of 4 in [4, 1024]", C);
@@ -267,6 +422,16 @@ extern "C" int crfconv_bn_forward(const float* x, int64_t M, int C, const float*
     CRF_REQUIRE(workspace_bytes >= crfconv_bn_workspace(M, C), CRF_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = as_stream(stream);
     float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    if (use_batch_stats && bn_small_ok(M, C)) {
+        if (M <= BNS_ROWS)
+            hipLaunchKernelGGL(bn_small_fwd_kernel<1>, dim3(C / BNS_CH), dim3(BNS_BLOCK), 0, st, x, M, C, gamma, beta, eps,
+                               run_mean, run_var, momentum, slope, coef, y);
+        else
+            hipLaunchKernelGGL(bn_small_fwd_kernel<BNS_NR>, dim3(C / BNS_CH), dim3(BNS_BLOCK), 0, st, x, M, C, gamma, beta, eps,
+                               run_mean, run_var, momentum, slope, coef, y);
+        CRF_LAUNCH_CHECK();
+        return CRF_OK;
+    }
     if (use_batch_stats) {
         const int nblk = bn_nblk(M, C);
         const int rpi = BN_BLOCK / (C / 4);
@@ -296,6 +461,16 @@ extern "C" int crfconv_bn_backward(const float* gy, const float* x, const float*
     hipStream_t st = as_stream(stream);
     float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     float* bcoef = partial + 2 * (size_t)C * BN_MAXBLK;
+    if (bn_small_ok(M, C)) {
+        if (M <= BNS_ROWS)
+            hipLaunchKernelGGL(bn_small_bwd_kernel<1>, dim3(C / BNS_CH), dim3(BNS_BLOCK), 0, st, gy, x, coef, M, C, training,
+                               slope, gx, dgamma, dbeta);
+        else
+            hipLaunchKernelGGL(bn_small_bwd_kernel<BNS_NR>, dim3(C / BNS_CH), dim3(BNS_BLOCK), 0, st, gy, x, coef, M, C,
+                               training, slope, gx, dgamma, dbeta);
+        CRF_LAUNCH_CHECK();
+        return CRF_OK;
+    }
     const int nblk = bn_nblk(M, C);
     const int rpi = BN_BLOCK / (C / 4);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(BN_BLOCK), sizeof(float) * 2 * C * (rpi > 0 ? rpi : 1), st, gy,

@@ -446,7 +446,9 @@ def test_linear_wgrad_mfma(M, Ci, Co, bias):
 
 
 @pytest.mark.parametrize('M,C,slope,training', [(163840, 32, 0.1, True), (40960, 8, 1.0, True), (1000, 512, 0.1, True),
-                                                (777, 128, 0.1, False), (33, 1024, 1.0, True)])
+                                                (777, 128, 0.1, False), (33, 1024, 1.0, True), (2560, 256, 0.1, True),
+                                                (640, 512, 1.0, True), (4096, 64, 0.1, True), (4097, 64, 0.1, True),
+                                                (2, 16, 0.1, True), (2560, 24, 0.1, True)])
 def test_fused_batchnorm_lrelu(M, C, slope, training):
     """csrc/bn.hip against torch BatchNorm1d + LeakyReLU in float64.  The LeakyReLU branch of the handful of
     elements whose pre-activation is within fp32 rounding of 0 is taken from the kernel's own output sign, so the
