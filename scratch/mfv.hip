@@ -405,7 +405,81 @@ __global__ __launch_bounds__(256, MINW) void sim_kernel(const float* __restrict_
     const float4 o = matvec_acc(msg, sP, lane, q, zqi);
     if (valid) { if (FL & 8) st4nt(x1 + r * H + 4 * q, o); else st4(x1 + r * H + 4 * q, o); }
 }
+// First kernel on an INTERLEAVED table yz [m, 16] = [y_i (8) | z_i (8)]: four lanes per point fetch one contiguous
+// 64-byte row per neighbour (lanes 0-1 the y half, lanes 2-3 the z half), 15 gathers instead of 30.
+__global__ __launch_bounds__(256, 4) void sim_yz_kernel(const float* __restrict__ yz, const uint16_t* __restrict__ idx16,
+                                                        int n_tgt, int n_src, const float* __restrict__ Q,
+                                                        const float* __restrict__ P, float* __restrict__ s,
+                                                        float* __restrict__ x1, int64_t m) {
+    __shared__ float4 sP[H * L];
+    __shared__ float4 sQ[H * L];
+    load_matrix<256>(sP, P);
+    load_matrix<256>(sQ, Q);
+    const int lane = threadIdx.x & 63, q4 = lane & 3;
+    int64_t r = (int64_t)xcd_block_id() * 64 + (threadIdx.x >> 6) * 16 + (lane >> 2);
+    const bool valid = r < m;
+    if (!valid) r = m - 1;
+    const int base = (int)(r / n_tgt) * n_src;
+    int j[K];
+    load_idx<false>(idx16, r, base, j);
+    const float4 own = ld4(yz + r * 16 + 4 * q4);
+    float4 nb[K];
+#pragma unroll
+    for (int k = 1; k < K; ++k) nb[k] = ld4(yz + (int64_t)j[k] * 16 + 4 * q4);
+    float d[K];
+    float dmin = 3.4e38f;
+    const bool ylane = q4 < 2;
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        const float4 df = sub4(own, nb[k]);
+        float part = ylane ? dot4(df, df) : 0.f;
+        part += __shfl_xor(part, 1, WAVE);
+        part += __shfl_xor(part, 2, WAVE);
+        d[k] = part;
+        dmin = fminf(dmin, part);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 1; k < K; ++k) { d[k] = __expf(dmin - d[k]); den += d[k]; }
+    const float inv = 1.0f / den;
+    d[0] = 0.f;
+#pragma unroll
+    for (int k = 1; k < K; ++k) d[k] *= inv;
+    float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 1; k < K; ++k) msg = fma4(d[k], nb[k], msg);      // meaningful on the z lanes
+    // s row: lane q4 of the quad owns chunk q4 -> the wave's 64 lanes write 1 KiB contiguous
+    float4 mine;
+    mine.x = q4 == 0 ? d[0] : q4 == 1 ? d[4] : q4 == 2 ? d[8] : d[12];
+    mine.y = q4 == 0 ? d[1] : q4 == 1 ? d[5] : q4 == 2 ? d[9] : d[13];
+    mine.z = q4 == 0 ? d[2] : q4 == 1 ? d[6] : q4 == 2 ? d[10] : d[14];
+    mine.w = q4 == 0 ? d[3] : q4 == 1 ? d[7] : q4 == 2 ? d[11] : d[15];
+    if (valid) st4(s + r * K + 4 * q4, mine);
+    __syncthreads();
+    // matvecs on the z lanes: vector broadcast from lanes (quad base + 2 + hq)
+    const int zb = (lane & ~3) + 2, q = q4 & 1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int hq = 0; hq < L; ++hq) {
+        const float v0 = __shfl(own.x, zb + hq, WAVE), v1 = __shfl(own.y, zb + hq, WAVE);
+        const float v2 = __shfl(own.z, zb + hq, WAVE), v3 = __shfl(own.w, zb + hq, WAVE);
+        acc = fma4(v0, sQ[(4 * hq + 0) * L + q], acc); acc = fma4(v1, sQ[(4 * hq + 1) * L + q], acc);
+        acc = fma4(v2, sQ[(4 * hq + 2) * L + q], acc); acc = fma4(v3, sQ[(4 * hq + 3) * L + q], acc);
+        const float m0 = __shfl(msg.x, zb + hq, WAVE), m1 = __shfl(msg.y, zb + hq, WAVE);
+        const float m2 = __shfl(msg.z, zb + hq, WAVE), m3 = __shfl(msg.w, zb + hq, WAVE);
+        acc = fma4(m0, sP[(4 * hq + 0) * L + q], acc); acc = fma4(m1, sP[(4 * hq + 1) * L + q], acc);
+        acc = fma4(m2, sP[(4 * hq + 2) * L + q], acc); acc = fma4(m3, sP[(4 * hq + 3) * L + q], acc);
+    }
+    if (valid && !ylane) st4(x1 + r * H + 4 * q, acc);
+}
 }  // namespace
+
+extern "C" int mfv_sim_yz(const float* yz, const uint16_t* idx16, int n_tgt, int n_src, const float* Q, const float* P,
+                          float* s, float* x1, int64_t m, void* stream) {
+    hipLaunchKernelGGL(sim_yz_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, (hipStream_t)stream, yz, idx16, n_tgt,
+                       n_src, Q, P, s, x1, m);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 extern "C" int mfv_sim(int variant, const float* y, const float* z, const uint16_t* idx16, int n_tgt, int n_src,
                        const float* Q, const float* P, float* s, float* x1, int64_t m, void* stream) {

@@ -90,5 +90,29 @@ for sv_, tv_ in ((0, 0), (13, 3), (15, 3), (16, 3), (13, 12), (15, 12), (16, 12)
     b.record(); torch.cuda.synchronize()
     print('seq sim v%d + 2 x step v%d: %7.2f us per forward (sorted table)' % (sv_, tv_, a.elapsed_time(b) / n * 1e3), flush=True)
 
+# ---- interleaved yz table, four lanes per point
+lib.mfv_sim_yz.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]
+yz = torch.cat([y, z], 1).contiguous()
+so2 = torch.empty(m, K, device=dev); xo2 = torch.empty(m, H, device=dev)
+lib.mfv_sim(13, ptr(y), ptr(z), ptr(srt), N, N, ptr(Q), ptr(P), ptr(so), ptr(xs[0]), m, st)
+lib.mfv_sim_yz(ptr(yz), ptr(srt), N, N, ptr(Q), ptr(P), ptr(so2), ptr(xo2), m, st)
+torch.cuda.synchronize()
+print('yz variant err s %.1e x %.1e' % (float((so2 - so).abs().max()), float((xo2 - xs[0]).abs().max())))
+for name, fn in (('sim v13 (separate y, z)', lambda: lib.mfv_sim(13, ptr(y), ptr(z), ptr(srt), N, N, ptr(Q), ptr(P), ptr(so), ptr(xs[0]), m, st)),
+                 ('sim yz interleaved', lambda: lib.mfv_sim_yz(ptr(yz), ptr(srt), N, N, ptr(Q), ptr(P), ptr(so2), ptr(xo2), m, st))):
+    for seq in (False, True):
+        def launch():
+            fn()
+            if seq:
+                lib.mfv_step(3, ptr(xs[0]), ptr(z), ptr(so), ptr(srt), N, N, ptr(Q), ptr(P), ptr(xs[1]), m, st)
+                lib.mfv_step(3, ptr(xs[1]), ptr(z), ptr(so), ptr(srt), N, N, ptr(Q), ptr(P), ptr(xs[2]), m, st)
+        for _ in range(5): launch()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(200): launch()
+        b.record(); torch.cuda.synchronize()
+        print('%-26s %s: %7.2f us' % (name, 'whole forward (+2 steps)' if seq else 'alone, back-to-back', a.elapsed_time(b) / 200 * 1e3), flush=True)
+
 # (measured and dropped: clouds 0-1 / 2-3 on two streams with an event fork/join per forward -- 62 us per forward against
 #  25 us in one stream; the cross-queue dependencies cost far more than the launch boundaries they were meant to hide)
