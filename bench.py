@@ -106,6 +106,23 @@ def roofline_meanfield(data, dev, H=8, T=3, iters=200):
             'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': avg * 1e6, 'min_launch_us': float(dur.min()) * 1e6}
 
 
+def copy_ceiling(dev, nbytes=1 << 28, iters=20):
+    """Measured device-copy rate of this run (reported beside the 8 TB/s spec the fraction is taken of):
+    read + written bytes of a 256 MiB float32 copy per second."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(data, net, steps_T, labels, n_cls):
     """The CPU oracle's fwd+bwd on ONE of this rank's clouds (bounded sample), host cores as configured."""
     from oracle import crf_oracle as O
@@ -267,6 +284,7 @@ def main():
             'launch_mode': graph_note,
         }
         out['roofline'] = roofline_meanfield(data, dev, 8, T)
+        out['roofline']['measured_copy_GBps'] = copy_ceiling(dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(data, net, T, data.y, n_cls)
         print(json.dumps(out))

@@ -510,6 +510,25 @@ __global__ __launch_bounds__(BLOCK) void bwd_edge_kernel(const float* __restrict
 // ====================================================================== backward, scatter half
 // One source row per L lanes; walks the row's incoming edges (ascending edge id, fixed order).
 // Gprev[j] = add[j] + sum_{e in rev(j)} s[e] gm[e / K]     (s is 0 on columns < k0)
+// EP edge-lanes per row walk the row's incoming edges EP at a time (edge p = beg + lane-group, += EP) and fold their
+// partial sums by xor-shuffles (fixed tree): in-degrees of a kNN graph spread from 0 to ~40, and with one lane
+// group per row a wavefront iterates to the LARGEST in-degree of its 64/L rows.
+template <int H>
+struct Scat {
+    static constexpr int L = H / 4, EP = (L <= 4) ? 4 : 1, RPW = WAVE / (L * EP), RPB = RPW * (BLOCK / WAVE);
+};
+
+template <int H>
+__device__ __forceinline__ float4 fold_edge_lanes(float4 a) {
+    constexpr int L = Scat<H>::L;
+#pragma unroll
+    for (int o = L; o < L * Scat<H>::EP; o <<= 1) {
+        a.x += __shfl_xor(a.x, o, WAVE); a.y += __shfl_xor(a.y, o, WAVE);
+        a.z += __shfl_xor(a.z, o, WAVE); a.w += __shfl_xor(a.w, o, WAVE);
+    }
+    return a;
+}
+
 template <int H>
 __global__ __launch_bounds__(BLOCK) void bwd_scatter_kernel(const float* __restrict__ gm,
                                                             const float* __restrict__ s,
@@ -519,20 +538,28 @@ __global__ __launch_bounds__(BLOCK) void bwd_scatter_kernel(const float* __restr
                                                             const float* __restrict__ add,
                                                             float* __restrict__ Gprev,
                                                             int64_t m_src) {
-    constexpr int L = Geo<H>::L;
+    constexpr int L = Scat<H>::L, EP = Scat<H>::EP;
     const int lane = threadIdx.x & 63;
-    const int q = lane % L;
-    const int64_t row = (int64_t)xcd_block_id() * Geo<H>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / L;
-    if (row >= m_src) return;  // no cross-lane traffic below
-    float4 acc = add ? ld4(add + row * H + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int beg = rev_ptr[row], end = rev_ptr[row + 1];
-#pragma unroll 4
-    for (int p = beg; p < end; ++p) {
+    const int q = lane % L, el = (lane / L) % EP;
+    int64_t row = (int64_t)xcd_block_id() * Scat<H>::RPB + (threadIdx.x >> 6) * Scat<H>::RPW + lane / (L * EP);
+    const bool valid = row < m_src;
+    if (!valid) row = m_src - 1;                    // keep every lane in the shuffles below
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int beg = rev_ptr[row], end = valid ? rev_ptr[row + 1] : beg;
+#pragma unroll 2
+    for (int p = beg + el; p < end; p += EP) {
         const int e = rev_eid[p];
         const int i = kshift >= 0 ? (e >> kshift) : (e / K);
         acc = fma4(s[e], ld4(gm + (int64_t)i * H + 4 * q), acc);
     }
-    st4(Gprev + row * H + 4 * q, acc);
+    acc = fold_edge_lanes<H>(acc);
+    if (valid && el == 0) {
+        if (add) {
+            const float4 a0 = ld4(add + row * H + 4 * q);
+            acc = make_float4(acc.x + a0.x, acc.y + a0.y, acc.z + a0.z, acc.w + a0.w);
+        }
+        st4(Gprev + row * H + 4 * q, acc);
+    }
 }
 
 // ====================================================================== softmax / distance backward
@@ -612,21 +639,26 @@ __global__ __launch_bounds__(BLOCK) void sim_bwd_scatter_kernel(const float* __r
                                                                 int K, int kshift,
                                                                 float* __restrict__ dy,
                                                                 int64_t m_src) {
-    constexpr int L = Geo<H>::L;
+    constexpr int L = Scat<H>::L, EP = Scat<H>::EP;
     const int lane = threadIdx.x & 63;
-    const int q = lane % L;
-    const int64_t row = (int64_t)xcd_block_id() * Geo<H>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / L;
-    if (row >= m_src) return;
+    const int q = lane % L, el = (lane / L) % EP;
+    int64_t row = (int64_t)xcd_block_id() * Scat<H>::RPB + (threadIdx.x >> 6) * Scat<H>::RPW + lane / (L * EP);
+    const bool valid = row < m_src;
+    if (!valid) row = m_src - 1;
     const float4 yj = ld4(y + row * H + 4 * q);
-    float4 acc = ld4(dy_self + row * H + 4 * q);
-    const int beg = rev_ptr[row], end = rev_ptr[row + 1];
-#pragma unroll 4
-    for (int p = beg; p < end; ++p) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int beg = rev_ptr[row], end = valid ? rev_ptr[row + 1] : beg;
+#pragma unroll 2
+    for (int p = beg + el; p < end; p += EP) {
         const int e = rev_eid[p];
         const int i = kshift >= 0 ? (e >> kshift) : (e / K);
         acc = fma4(w[e], sub4(yj, ld4(y + (int64_t)i * H + 4 * q)), acc);
     }
-    st4(dy + row * H + 4 * q, acc);
+    acc = fold_edge_lanes<H>(acc);
+    if (valid && el == 0) {
+        const float4 a0 = ld4(dy_self + row * H + 4 * q);
+        st4(dy + row * H + 4 * q, make_float4(acc.x + a0.x, acc.y + a0.y, acc.z + a0.z, acc.w + a0.w));
+    }
 }
 
 static int check_common(int64_t m, int H, int K, int k0) {
@@ -777,7 +809,7 @@ extern "C" int crfconv_meanfield_bwd_scatter(const float* gm, const float* s, co
     if (int rc = check_common(m_src, H, K, k0)) return rc;
     CRF_REQUIRE(gm && s && rev_ptr && rev_eid && Gprev, CRF_ERR_ARG, "null pointer");
     DISPATCH_H(H, {
-        const dim3 grid((unsigned)cdiv(m_src, Geo<HH>::PPB));
+        const dim3 grid((unsigned)cdiv(m_src, Scat<HH>::RPB));
         hipLaunchKernelGGL(bwd_scatter_kernel<HH>, grid, dim3(BLOCK), 0, as_stream(stream), gm, s,
                            rev_ptr, rev_eid, K, kshift_of(K), add, Gprev, m_src);
         CRF_LAUNCH_CHECK();
@@ -815,7 +847,7 @@ extern "C" int crfconv_similarity_bwd_scatter(const float* w, const float* y, co
     if (int rc = check_common(m_src, H, K, k0)) return rc;
     CRF_REQUIRE(w && y && dy_self && rev_ptr && rev_eid && dy, CRF_ERR_ARG, "null pointer");
     DISPATCH_H(H, {
-        const dim3 grid((unsigned)cdiv(m_src, Geo<HH>::PPB));
+        const dim3 grid((unsigned)cdiv(m_src, Scat<HH>::RPB));
         hipLaunchKernelGGL(sim_bwd_scatter_kernel<HH>, grid, dim3(BLOCK), 0, as_stream(stream), w, y,
                            dy_self, rev_ptr, rev_eid, K, kshift_of(K), dy, m_src);
         CRF_LAUNCH_CHECK();
