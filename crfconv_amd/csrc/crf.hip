@@ -172,7 +172,7 @@ __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_f
     d[0] = 0.f;
 #pragma unroll
     for (int k = 1; k < K; ++k) d[k] *= inv;
-    store_rows_coalesced<H, K>(d, s, lane, q, m);
+    if (s != nullptr) store_rows_coalesced<H, K>(d, s, lane, q, m);       // NULL: inference with T <= 1, nobody re-reads s
 
     if constexpr (WITH_STEP) {
         const float4 zi = ld4(z + r * H + 4 * q);
@@ -718,7 +718,10 @@ static int meanfield_forward_impl(const float* z, const float* y, const int32_t*
                                   int n_tgt, int n_src, int K, int k0, int64_t m, int H, const float* Q,
                                   const float* P, int T, float* s, float* xs, crf_stream_t stream) {
     if (int rc = check_common(m, H, K, k0)) return rc;
-    CRF_REQUIRE(z && y && idx32 && Q && P && s && (xs || T == 0), CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(z && y && idx32 && Q && P && (xs || T == 0), CRF_ERR_ARG, "null pointer");
+    // s may be NULL when nothing reads it back: a single fused step (T == 1) on the fast path, no backward pass
+    CRF_REQUIRE(s || (T == 1 && k0 == 1 && (K == 16 || K == 32) && !g_use_window), CRF_ERR_ARG,
+                "s == NULL needs T == 1 on the fused first-step kernel (K in {16, 32}, k0 == 1)");
     CRF_REQUIRE(T >= 0, CRF_ERR_ARG, "T=%d < 0", T);
     hipStream_t st = as_stream(stream);
     const bool fast = (k0 == 1) && (K == 16 || K == 32);

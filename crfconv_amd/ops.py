@@ -41,13 +41,20 @@ class _MeanField(torch.autograd.Function):
         require_gpu(z, y, Q, P)
         m, H = z.shape
         z, y, Q, P = _f32c(z), _f32c(y), _f32c(Q), _f32c(P)
-        s = torch.empty((m, table.K), dtype=torch.float32, device=z.device)   # edge-id addressed: s[i*K + k]
+        needs_grad = any(ctx.needs_input_grad[:4])
+        # inference with one step: the similarity weights are consumed inside the fused first kernel and never
+        # re-read -- skip their 4K bytes/point store (a third of that kernel's traffic)
+        keep_s = needs_grad or steps != 1 or k0 != 1 or table.K not in (16, 32) or _WINDOW_ENV
+        s = torch.empty((m, table.K), dtype=torch.float32, device=z.device) if keep_s else None   # s[i*K + k]
         xs = torch.empty((max(steps, 1), m, H), dtype=torch.float32, device=z.device)
         _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(table.idx32), ptr(table.idx16), table.n_tgt,
                   table.n_src, table.K, k0, m, H, ptr(Q), ptr(P), steps, ptr(s), ptr(xs), stream_ptr())
         ctx.table, ctx.k0, ctx.steps = table, k0, steps
-        ctx.save_for_backward(z, y, Q, P, s, xs)
-        return xs[steps - 1].clone() if steps > 0 else z.clone()
+        if needs_grad:
+            ctx.save_for_backward(z, y, Q, P, s, xs)
+        if steps == 0:
+            return z.clone()
+        return xs[steps - 1] if (steps == 1 and not needs_grad) else xs[steps - 1].clone()
 
     @staticmethod
     def backward(ctx, gout):
@@ -138,6 +145,7 @@ class _CrfMatrices(torch.autograd.Function):
 
 
 _CRF_H = (4, 8, 16, 32, 64)
+_WINDOW_ENV = __import__('os').environ.get('CRFCONV_WINDOW') is not None     # A/B kernels of csrc/crf.hip: always keep s
 
 
 def _meanfield_wide(z, y, Q, C, table, steps, k0):

@@ -124,7 +124,8 @@ int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_src, int32_t*
  *   x_0 = z ;  x_t = z Q + (sum_k s[i,k] x_{t-1}[j(i,k)]) P          (:68-72 with Q = (I+C)^-1, P = C Q)
  * Outputs: s [m, K] (edge-id addressed: s[i*K + k], zero on columns < k0);  xs [T, m, H] = x_1 .. x_T
  * (z Q is recomputed per step from z: same read bytes as a stored copy, nothing extra to write).  K in {16, 32} with k0 = 1 takes the fused fast path (similarity + first
- * step in one launch, index / weight rows as aligned dwordx4 loads). */
+ * step in one launch, index / weight rows as aligned dwordx4 loads).  s may be NULL on that path when T == 1
+ * (single-step inference: the weights are consumed inside the fused kernel and never re-read). */
 int crfconv_meanfield_forward(const float* z, const float* y, const int32_t* idx32, int K, int k0,
                               int64_t m, int H, const float* Q, const float* P, int T, float* s,
                               float* xs, crf_stream_t stream);

@@ -352,6 +352,21 @@ def test_meanfield_properties_full_size():
     assert float((out[0] - v).abs().max()) < 1e-5
 
 
+def test_meanfield_single_step_inference_skips_s():
+    """T = 1 without gradients takes the no-s-store form of the fused kernel: same x_1 as the training form."""
+    from crfconv_amd import ops
+    from crfconv_amd.graph import NeighborTable
+    pos, nbr = knn_tables(2, 3000, 16, 77)
+    tab = NeighborTable(t(nbr), 3000)
+    g = torch.Generator().manual_seed(5)
+    z, y = torch.randn(6000, 8, generator=g).to(DEV), torch.randn(6000, 8, generator=g).to(DEV)
+    c = (torch.eye(8) + 0.1 * torch.randn(8, 8, generator=g)).to(DEV)
+    with torch.no_grad():
+        a = ops.crf_meanfield(z, y, c, tab, 1)
+    b = ops.crf_meanfield(z.clone().requires_grad_(), y, c, tab, 1)
+    assert torch.equal(a, b.detach())
+
+
 # ------------------------------------------------------------------ the other BASELINE configs at their full sizes
 @pytest.mark.parametrize('name,B,N,K,T,H', [('C3 KITTI scan', 1, 122880, 16, 1, 8), ('C4 ScanNet cloud', 4, 81920, 16, 3, 8),
                                             ('C5 Semantic3D crops', 2, 65536, 32, 5, 8), ('C5 level 1', 2, 16384, 32, 5, 16)])
