@@ -54,7 +54,9 @@ class _MeanField(torch.autograd.Function):
             ctx.save_for_backward(z, y, Q, P, s, xs)
         if steps == 0:
             return z.clone()
-        return xs[steps - 1] if (steps == 1 and not needs_grad) else xs[steps - 1].clone()
+        # a view of the saved iterates: an in-place edit downstream trips autograd's version check instead of
+        # silently corrupting the backward pass, and the copy (m * H floats per layer) is saved
+        return xs[steps - 1]
 
     @staticmethod
     def backward(ctx, gout):
@@ -90,7 +92,7 @@ class _MeanField(torch.autograd.Function):
         dP = torch.empty_like(P)
         skinny_tn(mts.view(T * m, H), Gs.view(T * m, H), dP)
         sumG = Gs.sum(0) if T > 1 else Gs[0]
-        dz = torch.addmm(G0, sumG, Q.t())         # x_0 = z path + the z Q term of every step
+        dz = G0.addmm_(sumG, Q.t())               # x_0 = z path + the z Q term of every step (in place: no copy of G0)
         dQ = torch.empty_like(Q)
         skinny_tn(z, sumG, dQ)
         w = torch.empty_like(s)
@@ -382,6 +384,9 @@ class _Linear(torch.autograd.Function):
         x = x.contiguous()
         Wc = W.contiguous()
         ctx.save_for_backward(x, Wc)
+        # the statistic records are a non-differentiable second output: without this autograd zero-fills a gradient
+        # for them on every backward call (33 fill launches per training step of PointConvBig)
+        ctx.set_materialize_grads(False)
         ctx.has_bias = b is not None
         ctx.params = (W, b)                      # the parameter objects themselves (deferred weight gradients)
         m, ci = x.shape
@@ -399,6 +404,8 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, *_unused):
+        if g is None:
+            return None, None, None, None
         x, W = ctx.saved_tensors
         g = g.contiguous()
         m, Co = g.shape
