@@ -11,6 +11,7 @@
 //   (nanoflann.hpp:342-347); neighbours ascending by (distance, point id).
 #include "common.hpp"
 
+#include <cstdlib>
 #include <rocprim/rocprim.hpp>
 
 namespace crf {
@@ -223,8 +224,17 @@ __global__ __launch_bounds__(QBLOCK) void knn_query_kernel(const float* __restri
 
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
+static double knn_points_per_cell() {
+    static const double v = [] {
+        const char* e = getenv("CRFCONV_KNN_PPC");
+        const double x = e ? atof(e) : 1.0;
+        return x > 0.0 ? x : 1.0;
+    }();
+    return v;
+}
+
 static int grid_g0(size_t npts) {
-    int g = (int)floor(cbrt((double)npts));
+    int g = (int)floor(cbrt((double)npts / knn_points_per_cell()));
     if (g < 1) g = 1;
     if (g > 160) g = 160;
     return g;
