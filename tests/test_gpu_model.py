@@ -8,7 +8,7 @@ import torch.nn as nn
 
 import _seeded as S
 from conftest import sub
-from gpu_util import DEV, assert_close, assert_close_anchored, grads, load_sd, t
+from gpu_util import DEV, assert_close, assert_close_anchored, grads, load_sd, relerr, t
 from oracle import crf_oracle as O
 from oracle import native as onative
 
@@ -398,6 +398,50 @@ def test_meanfield_other_configs_full_size(name, B, N, K, T, H):
     assert_close(z.grad, zc.grad.reshape(B * N, H), GRAD_TOL, name + ' dz')
     assert_close(y.grad, yc.grad.reshape(B * N, H), GRAD_TOL, name + ' dy')
     assert_close(c.grad, cc.grad, GRAD_TOL, name + ' dc')
+
+
+def test_config5_shape_network_k32_t5_vs_oracle():
+    """BASELINE.json config 5's operator shapes at a size the oracle trains in seconds: K = 32 at every level
+    (kernel_size=[32]*5), five mean-field steps; eval logits, then loss and every parameter gradient in train mode."""
+    import crfconv_amd
+    from crfconv_amd import models
+    B, N, ncls = 2, 8192, 8
+    pos = np.stack([S.make_cloud(90 + b, N, box=(6.0, 6.0, 1.5)) for b in range(B)])
+    feats = np.concatenate([pos, S.uniform(90, 'rgb', (B, N, 3), 0, 1)], -1).astype(np.float32)
+    labels = S.integers(90, 'y', (B, N), 0, ncls + 1)
+    choices, n = [], N
+    for i, r in enumerate((4, 4, 4, 4, 2)):
+        choices.append(torch.from_numpy(S.permutation(90, 'c%d' % i, n)[: n // r]))
+        n //= r
+    data = crfconv_amd.multiscale_compute(t(pos), x=t(feats), choices=choices, kernel_size=(32,) * 5)
+    assert data.multiscale[0].neighbor_idx.shape == (B, N, 32) and data.multiscale[4].neighbor_idx.shape == (B, 32, 32)
+    net = models.PointConvBig(6, ncls, use_crf=True, steps=5)
+    sd = S.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 11)
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    ms = [{k: getattr(l, k).cpu() for k in ('pos', 'neighbor_idx', 'sub_idx', 'up_idx')} for l in data.multiscale]
+    torch.set_num_threads(16)
+    net.eval()
+    with torch.no_grad():
+        got = net(data)
+        ref = O.pointconv_resnet({k: v.clone() for k, v in sd.items()}, torch.from_numpy(feats), ms, 5, False, True)
+    assert_close(got, ref, OUT_TOL, 'K=32 T=5 eval logits')
+    net.train()
+    net.classifier[1] = nn.Identity()                      # dropout draws from different RNG streams: compare without
+    logits = net(data)
+    y = t(labels, torch.long).reshape(-1) - 1
+    loss = torch.nn.functional.cross_entropy(logits, y, ignore_index=-1)
+    loss.backward()
+    prm = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    mask = torch.full((B, N, 128), 0.5)                    # oracle: h * mask * 2 = identity
+    ref_t = O.pointconv_resnet(prm, torch.from_numpy(feats), ms, 5, True, True, dropout_mask=mask)
+    ref_loss = O.training_loss(ref_t, torch.from_numpy(labels))
+    ref_loss.backward()
+    assert_close(logits, ref_t, 5e-4, 'K=32 T=5 train logits')
+    assert_close(loss, ref_loss, 1e-4, 'loss')
+    gr = grads(net)
+    worst = max((relerr(gr[k], prm[k].grad), k) for k in gr)
+    assert worst[0] <= 3e-3, 'worst gradient %s: %.2e' % (worst[1], worst[0])
 
 
 def test_config3_inference_matches_oracle():
