@@ -634,16 +634,17 @@ __global__ __launch_bounds__(FR_BLOCK) void bn_finalize_records_kernel(const flo
     // problem in float64)
     const double s0 = rec[(int64_t)cc * 4];
     double S1 = 0.0, S2 = 0.0;
-    for (int r0 = rl; r0 < nrec; r0 += 4 * FR_RL) {       // four tuples in flight per thread
-        float4 v[4];
+    constexpr int FR_UN = 8;                                // eight tuples of a thread in flight at once (nrec <= 1024: two
+    for (int r0 = rl; r0 < nrec; r0 += FR_UN * FR_RL) {     // round trips instead of four dependent ones)
+        float4 v[FR_UN];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FR_UN; ++u) {
             const int r = r0 + u * FR_RL;
             v[u] = r < nrec ? *reinterpret_cast<const float4*>(rec + ((int64_t)r * C + cc) * 4)
                             : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FR_UN; ++u) {
             const double nb = v[u].y;
             if (nb > 0.0) {
                 const double d = (double)v[u].x - s0, a = v[u].z, b = v[u].w;
