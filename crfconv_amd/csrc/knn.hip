@@ -193,7 +193,17 @@ __global__ __launch_bounds__(QBLOCK) void knn_query_kernel(const float* __restri
                     if (xa < 0 || xb >= g.nx || xa > xb) continue;
                     const int rowbase = (z * g.ny + y) * g.nx;
                     const int pbeg = st[rowbase + xa], pend = st[rowbase + xb + 1];
-                    for (int p = pbeg; p < pend; ++p) {
+                    // four candidates requested before the first is ranked: the insertion is a long select chain
+                    // and the loop is otherwise one exposed load latency per candidate
+                    int p = pbeg;
+                    for (; p + 4 <= pend; p += 4) {
+                        const float4 s0 = sorted[p], s1 = sorted[p + 1], s2 = sorted[p + 2], s3 = sorted[p + 3];
+                        best.offer(sqdist_exact(qx, qy, qz, s0.x, s0.y, s0.z), __float_as_int(s0.w));
+                        best.offer(sqdist_exact(qx, qy, qz, s1.x, s1.y, s1.z), __float_as_int(s1.w));
+                        best.offer(sqdist_exact(qx, qy, qz, s2.x, s2.y, s2.z), __float_as_int(s2.w));
+                        best.offer(sqdist_exact(qx, qy, qz, s3.x, s3.y, s3.z), __float_as_int(s3.w));
+                    }
+                    for (; p < pend; ++p) {
                         const float4 s = sorted[p];
                         best.offer(sqdist_exact(qx, qy, qz, s.x, s.y, s.z), __float_as_int(s.w));
                     }
