@@ -121,39 +121,39 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ 5. query
+// Candidates are ranked by ONE 64-bit key = (float32 distance bits << 32) | point id: squared distances are
+// non-negative, so their bit patterns order like the values, and the key order is exactly (distance, id).
+__device__ __forceinline__ unsigned long long knn_key(float d, int id) {
+    return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)id;
+}
+constexpr unsigned long long KNN_KEY_INF = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;
+
 template <int KM>
 struct TopK {
-    float d[KM];
-    int id[KM];
-    // Only K <= KM slots are live: the first KM - K are pinned at -inf so the live ones end at
-    // the static position KM - 1 (a runtime "d[K - 1]" would push the arrays to scratch).
+    unsigned long long key[KM];     // ascending
+    // Only K <= KM slots are live: the first KM - K are pinned at key 0 (nothing is < 0, so nothing displaces them)
+    // and the live ones end at the static position KM - 1 (a runtime "key[K - 1]" would push the array to scratch).
     __device__ __forceinline__ void init(int K) {
 #pragma unroll
-        for (int k = 0; k < KM; ++k) {
-            const bool pinned = k < KM - K;
-            d[k] = pinned ? -__builtin_inff() : 3.4e38f;
-            id[k] = pinned ? -1 : 0x7fffffff;
-        }
+        for (int k = 0; k < KM; ++k) key[k] = (k < KM - K) ? 0ull : KNN_KEY_INF;
     }
-    static __device__ __forceinline__ bool before(float da, int ia, float db, int ib) {
-        return da < db || (da == db && ia < ib);
-    }
-    __device__ __forceinline__ float kth() const { return d[KM - 1]; }
-    __device__ __forceinline__ void offer(float dd, int ii) {
-        if (!before(dd, ii, d[KM - 1], id[KM - 1])) return;
+    __device__ __forceinline__ unsigned long long kth_key() const { return key[KM - 1]; }
+    __device__ __forceinline__ float kth() const { return __uint_as_float((unsigned int)(key[KM - 1] >> 32)); }
+    __device__ __forceinline__ void offer(unsigned long long c) {
+        if (!(c < key[KM - 1])) return;
         // sorted insert with selects only (static register indices, no conditional stores)
+        bool below = c < key[KM - 1];                       // c < key[k], carried down the slots
 #pragma unroll
         for (int k = KM - 1; k > 0; --k) {
-            const bool shift = before(dd, ii, d[k - 1], id[k - 1]);   // slot k takes its upper neighbour
-            const bool place = !shift && before(dd, ii, d[k], id[k]); // or the new element lands here
-            d[k] = shift ? d[k - 1] : (place ? dd : d[k]);
-            id[k] = shift ? id[k - 1] : (place ? ii : id[k]);
+            const bool below_prev = c < key[k - 1];         // slot k takes its upper neighbour
+            key[k] = below_prev ? key[k - 1] : (below ? c : key[k]);
+            below = below_prev;
         }
-        const bool first = before(dd, ii, d[0], id[0]);
-        d[0] = first ? dd : d[0];
-        id[0] = first ? ii : id[0];
+        key[0] = below ? c : key[0];
     }
 };
+
+constexpr int QCAP = 8;     // accepted candidates a lane may hold before the wavefront inserts them
 
 template <int KM>
 __global__ __launch_bounds__(QBLOCK) void knn_query_kernel(const float* __restrict__ queries, int64_t nq,
@@ -164,6 +164,12 @@ __global__ __launch_bounds__(QBLOCK) void knn_query_kernel(const float* __restri
                                                            const float4* __restrict__ sorted,
                                                            int64_t* __restrict__ out64,
                                                            int32_t* __restrict__ out32) {
+    // The sorted insert is a ~100-instruction select chain and a wavefront runs it whenever ANY of its 64 queries
+    // accepts a candidate -- with independent queries that is nearly every candidate.  Accepted keys are therefore
+    // parked in a per-lane LDS queue (a cheap predicated store) and inserted in wave-wide batches: when some lane's
+    // queue is full, and at the end of every ring (the stop test needs the true K-th distance).
+    constexpr bool QUEUED = KM > 1;
+    __shared__ unsigned long long s_queue[QUEUED ? QCAP * QBLOCK : 1];
     const int b = blockIdx.y;
     const int64_t qi = (int64_t)blockIdx.x * QBLOCK + threadIdx.x;
     if (qi >= nq) return;
@@ -175,6 +181,30 @@ __global__ __launch_bounds__(QBLOCK) void knn_query_kernel(const float* __restri
 
     TopK<KM> best;
     best.init(K);
+    int cnt = 0;
+    unsigned long long bound = KNN_KEY_INF;                 // K-th key as of the last flush (only ever too large)
+    auto flush = [&]() {
+        if constexpr (QUEUED) {
+            for (int i = 0; i < QCAP; ++i) {
+                if (!__any(i < cnt)) break;
+                if (i < cnt) best.offer(s_queue[i * QBLOCK + threadIdx.x]);
+            }
+            cnt = 0;
+            bound = best.kth_key();
+        }
+    };
+    auto consider = [&](const float4 s) {
+        const unsigned long long key = knn_key(sqdist_exact(qx, qy, qz, s.x, s.y, s.z), __float_as_int(s.w));
+        if constexpr (QUEUED) {
+            if (key < bound) {
+                s_queue[cnt * QBLOCK + threadIdx.x] = key;
+                ++cnt;
+            }
+            if (__any(cnt == QCAP)) flush();
+        } else {
+            best.offer(key);
+        }
+    };
     const int rmax = max(g.nx, max(g.ny, g.nz));
     for (int r = 0; r <= rmax; ++r) {
         const int z0 = max(c.z - r, 0), z1 = min(c.z + r, g.nz - 1);
@@ -193,23 +223,16 @@ __global__ __launch_bounds__(QBLOCK) void knn_query_kernel(const float* __restri
                     if (xa < 0 || xb >= g.nx || xa > xb) continue;
                     const int rowbase = (z * g.ny + y) * g.nx;
                     const int pbeg = st[rowbase + xa], pend = st[rowbase + xb + 1];
-                    // four candidates requested before the first is ranked: the insertion is a long select chain
-                    // and the loop is otherwise one exposed load latency per candidate
                     int p = pbeg;
-                    for (; p + 4 <= pend; p += 4) {
+                    for (; p + 4 <= pend; p += 4) {          // four candidate loads in flight
                         const float4 s0 = sorted[p], s1 = sorted[p + 1], s2 = sorted[p + 2], s3 = sorted[p + 3];
-                        best.offer(sqdist_exact(qx, qy, qz, s0.x, s0.y, s0.z), __float_as_int(s0.w));
-                        best.offer(sqdist_exact(qx, qy, qz, s1.x, s1.y, s1.z), __float_as_int(s1.w));
-                        best.offer(sqdist_exact(qx, qy, qz, s2.x, s2.y, s2.z), __float_as_int(s2.w));
-                        best.offer(sqdist_exact(qx, qy, qz, s3.x, s3.y, s3.z), __float_as_int(s3.w));
+                        consider(s0); consider(s1); consider(s2); consider(s3);
                     }
-                    for (; p < pend; ++p) {
-                        const float4 s = sorted[p];
-                        best.offer(sqdist_exact(qx, qy, qz, s.x, s.y, s.z), __float_as_int(s.w));
-                    }
+                    for (; p < pend; ++p) consider(sorted[p]);
                 }
             }
         }
+        flush();
         // every point outside the cube of rings <= r is at least `gap` away along some axis
         float gap = 3.4e38f;
         if (c.x - r > 0) gap = fminf(gap, qx - (g.ox + (float)(c.x - r) * g.cell));
@@ -226,8 +249,9 @@ __global__ __launch_bounds__(QBLOCK) void knn_query_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
         if (k >= KM - K) {
-            if (out64) out64[o + k - (KM - K)] = best.id[k];
-            if (out32) out32[o + k - (KM - K)] = best.id[k];
+            const int id = (int)(unsigned int)(best.key[k] & 0xffffffffull);
+            if (out64) out64[o + k - (KM - K)] = id;
+            if (out32) out32[o + k - (KM - K)] = id;
         }
     }
 }
