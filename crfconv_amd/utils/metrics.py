@@ -76,6 +76,51 @@ class runningScore(object):
         self._bad.zero_()
 
 
+class runningScoreShapeNet(object):
+    """Per-shape part IoU of the reference (utils/metrics.py:59-119): ``update(label_trues, label_preds, category)``
+    scores ONE shape -- the mean over the parts of its object category of |true & pred| / |true | pred|, both counts
+    offset by float32 eps as there -- and ``get_scores()`` returns (instance mIoU, category mIoU, per-category table).
+    The per-part intersections / unions come from the device confusion kernel (one 50 x 50 histogram per shape)."""
+
+    obj_classes = {'Airplane': 0, 'Bag': 1, 'Cap': 2, 'Car': 3, 'Chair': 4, 'Earphone': 5, 'Guitar': 6, 'Knife': 7,
+                   'Lamp': 8, 'Laptop': 9, 'Motorbike': 10, 'Mug': 11, 'Pistol': 12, 'Rocket': 13, 'Skateboard': 14,
+                   'Table': 15}
+    seg_classes = {'Earphone': [16, 17, 18], 'Motorbike': [30, 31, 32, 33, 34, 35], 'Rocket': [41, 42, 43],
+                   'Car': [8, 9, 10, 11], 'Laptop': [28, 29], 'Cap': [6, 7], 'Skateboard': [44, 45, 46],
+                   'Mug': [36, 37], 'Guitar': [19, 20, 21], 'Bag': [4, 5], 'Lamp': [24, 25, 26, 27],
+                   'Table': [47, 48, 49], 'Airplane': [0, 1, 2, 3], 'Pistol': [38, 39, 40],
+                   'Chair': [12, 13, 14, 15], 'Knife': [22, 23]}
+    N_PARTS = 50
+
+    def __init__(self, device='cuda'):
+        self._names = {v: k for k, v in self.obj_classes.items()}
+        self._score = runningScore(self.N_PARTS, ignore_index=-1, device=device)
+        self.category_IoU = np.zeros(16, dtype=np.float32)
+        self.category_num = np.zeros(16, dtype=np.int32)
+
+    def update(self, label_trues, label_preds, category):
+        parts = self.seg_classes[self._names[int(category)]]
+        self._score.reset()
+        self._score.update(label_trues, label_preds)
+        cm = self._score.confusion_matrix
+        eps = np.finfo(np.float32).eps
+        iu = 0.0
+        for l in parts:
+            inter = cm[l, l]
+            union = cm[l, :].sum() + cm[:, l].sum() - inter
+            iu += (inter + eps) / (union + eps)
+        iu /= len(parts)
+        self.category_IoU[int(category)] += iu
+        self.category_num[int(category)] += 1
+        return iu
+
+    def get_scores(self):
+        with np.errstate(divide='ignore', invalid='ignore'):
+            per_class = self.category_IoU / self.category_num
+            pIoU = self.category_IoU.sum() / self.category_num.sum()
+        return pIoU, per_class.mean(), {k: per_class[v] for k, v in self.obj_classes.items()}
+
+
 def iou_from_confusions(confusions, eps=1e-6):
     """Trainer._iou_from_confusions (trainval.py:76-90): per-class IoU from [..., n, n] confusion counts, where a
     class that never occurs in the ground truth (row sum < 1e-3) is given the mean IoU of the classes that do."""

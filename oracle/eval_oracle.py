@@ -3,7 +3,7 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; the product
 (crfconv_amd/) never does.  Each function cites the reference lines it follows.
 
-Pinned: ``fast_hist`` / ``scores`` against utils/metrics.py run from /root/reference, and ``possibility_draw``
+Pinned: ``fast_hist`` / ``scores`` / ``shapenet_part_iou`` (g11) against utils/metrics.py run from /root/reference, and ``possibility_draw``
 against ``Semantic3D._get_random`` run from /root/reference with sklearn's KDTree (tests/golden/g9_eval.npz, made by
 tests/golden/make_golden.py).  ``iou_from_confusions`` and ``vote_update`` / ``vote_project`` restate
 trainval.py:76-90 and :186-203, whose module cannot be imported here (it pulls torch_points3d / torch_geometric
@@ -80,3 +80,14 @@ def possibility_draw(points, possibility, num_points, noise, weights=None):
     delta = np.square(1 - dists / np.max(dists)) * (1 if weights is None else weights[order])
     possibility[order] += delta
     return order, xyz.astype(np.float32), pick.reshape(-1)
+
+
+def shapenet_part_iou(label_trues, label_preds, parts):
+    """utils/metrics.py:87-103 (runningScoreShapeNet.update) for one shape: mean over the category's part labels of
+    (|true & pred| + eps) / (|true | pred| + eps), eps = float32 machine epsilon."""
+    eps = np.finfo(np.float32).eps
+    total = 0.0
+    for l in parts:
+        t, p = (label_trues == l), (label_preds == l)
+        total += (np.sum(np.logical_and(t, p)) + eps) / (np.sum(np.logical_or(t, p)) + eps)
+    return total / len(parts)

@@ -495,6 +495,28 @@ def g8_sparse(models):
     save('g8_sparse.npz', **out)
 
 
+def g11_shapenet(models):
+    """utils/metrics.py runningScoreShapeNet (pure numpy) on seeded part labels of eight shapes."""
+    metrics = import_reference_file('utils/metrics.py', 'ref_metrics')
+    rs = metrics.runningScoreShapeNet()
+    out, cats, ious = {}, [0, 4, 4, 10, 15, 8, 0, 13], []
+    for i, c in enumerate(cats):
+        name = [k for k, v in rs.obj_classes.items() if v == c][0]
+        parts = np.array(rs.seg_classes[name])
+        yt = parts[S.integers(11, 'yt%d' % i, (2048,), 0, len(parts))]
+        yp = parts[S.integers(11, 'yp%d' % i, (2048,), 0, len(parts))]
+        yp = np.where(S.uniform(11, 'k%d' % i, (2048,), 0, 1) < 0.6, yt, yp)
+        if i == 3:
+            yp[:] = parts[0]                                   # parts that are never predicted
+        out['yt%d' % i] = yt.astype(np.int16)
+        out['yp%d' % i] = yp.astype(np.int16)
+        ious.append(rs.update(yt, yp, c))
+    p, mp, cls = rs.get_scores()
+    out.update(cats=np.array(cats), ious=np.array(ious), pIoU=np.float64(p), mpIoU=np.float64(mp),
+               cls=np.array([cls[k] for k in sorted(cls)]), cls_names=np.array(sorted(cls)))
+    save('g11_shapenet_score.npz', **out)
+
+
 def g10_discrete(models):
     """models/discrete_crf_conv.py run as it is; the radius graph is injected (torch_cluster absent), scatter_add is
     the index_add restatement above."""
@@ -616,6 +638,6 @@ if __name__ == '__main__':
     models = import_reference_models()
     only = set(sys.argv[1:])
     for fn in (g1_crfconv, g2_meanfield_fp64, g3_pointconv, g4_resblock, g5_pointconvbig, g6_knn,
-               g7_grid, g8_sparse, g9_eval, g10_discrete):
+               g7_grid, g8_sparse, g9_eval, g10_discrete, g11_shapenet):
         if not only or fn.__name__.split('_')[0] in only:
             fn(models)

@@ -125,3 +125,19 @@ def test_possibility_sampler_full_size_properties():
     assert torch.equal(d.pos[:, 2], pts[idx, 2])
     d_b = smp.get_random()
     assert not torch.equal(d_b.center, d.center)
+
+
+def test_running_score_shapenet_golden(golden):
+    """runningScoreShapeNet on the device confusion kernel against the reference class (fixture): per-shape IoU,
+    instance mean, category table (categories never seen stay nan, as there)."""
+    from crfconv_amd.utils import runningScoreShapeNet
+    g = golden('g11_shapenet_score.npz')
+    rs = runningScoreShapeNet()
+    for i, c in enumerate(g['cats']):
+        iou = rs.update(t(g['yt%d' % i].astype(np.int64)), t(g['yp%d' % i].astype(np.int64)), int(c))
+        assert abs(iou - g['ious'][i]) <= 1e-12
+    p, mp, cls = rs.get_scores()
+    assert abs(p - float(g['pIoU'])) <= 1e-6
+    assert np.isnan(mp) and np.isnan(float(g['mpIoU']))
+    assert np.allclose([cls[k] for k in sorted(cls)], g['cls'], rtol=1e-6, equal_nan=True)
+    assert list(sorted(cls)) == list(g['cls_names'])

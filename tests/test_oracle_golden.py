@@ -358,3 +358,12 @@ def test_discrete_crf_oracle_golden(golden, tag):
     close(logit.grad, g[tag + '/d_logit'], GRAD_TOL, 'd_logit')
     close(f.grad, g[tag + '/d_f'], GRAD_TOL, 'd_f')
     check_grads(sd, g, tag + '/grad')
+
+
+def test_shapenet_part_iou_oracle_golden(golden):
+    from oracle import eval_oracle as E
+    g = golden('g11_shapenet_score.npz')
+    seg = {0: [0, 1, 2, 3], 4: [12, 13, 14, 15], 10: [30, 31, 32, 33, 34, 35], 15: [47, 48, 49], 8: [24, 25, 26, 27], 13: [41, 42, 43]}
+    for i, c in enumerate(g['cats']):
+        got = E.shapenet_part_iou(g['yt%d' % i].astype(np.int64), g['yp%d' % i].astype(np.int64), seg[int(c)])
+        assert abs(got - g['ious'][i]) <= 1e-15
