@@ -7,8 +7,12 @@ from crfconv_amd.utils import nearest_neighbors as nn_
 dev = torch.device('cuda', 0)
 clouds = [bench.synth_cloud(i, 40960) for i in range(4)]
 pos = torch.from_numpy(np.stack([c[0] for c in clouds])).to(dev)
+if os.environ.get('KNN_SORTED', '1') == '1':      # Morton order, as the device collate hands them to the kNN
+    from crfconv_amd.data import morton_order
+    order = morton_order(pos)
+    pos = torch.gather(pos, 1, order.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
 for N in (40960, 10240, 2560):
-    p = pos[:, :N].contiguous()
+    p = pos[:, ::40960 // N].contiguous()          # every (40960/N)-th point: still spatially sorted
     for K in (16, 1):
         for _ in range(3): out = nn_.knn_batch_device(p, p, K)
         torch.cuda.synchronize()
