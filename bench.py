@@ -189,17 +189,13 @@ def main():
     #                     [B] SGD(momentum, weight decay) step on views of the bucket.
     # A and B are each captured into a hipGraph (the step issues >1000 small launches; replaying them removes
     # the Python host from the critical path).  The collective stays outside the graphs on purpose.
-    for p, v in zip(bucket.params, bucket.views):
-        p.grad = v
-
     def part_a():
-        for p in bucket.params:
-            p.grad = None
+        opt.zero_grad()
         logits = net(data)
         loss = ops.training_loss(logits, data.y, cw, ignore_index=-1)          # trainval.py:101-104, fused kernel
         with ops.deferred_weight_grads():                 # one batched launch finishes all 74 dW / db reductions
             loss.backward()
-        torch._foreach_copy_(bucket.views, [p.grad for p in bucket.params])
+        bucket.pack()                                     # one batched copy into the flat bucket; .grad -> bucket views
         return loss.detach()
 
     def part_b():

@@ -32,6 +32,9 @@ SIGNATURES = {
     'crfconv_reverse_csr': (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_meanfield_forward': (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     'crfconv_meanfield_forward_u16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    'crfconv_meanfield_fused_workspace': (_sz, []),
+    'crfconv_meanfield_fused_supported': (_i, [_i64, _i, _i, _i, _i]),
+    'crfconv_meanfield_forward_fused': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_meanfield_bwd_edge': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     'crfconv_meanfield_bwd_scatter': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp]),
     'crfconv_similarity_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp]),
@@ -74,6 +77,7 @@ SIGNATURES = {
     'crfconv_add_lrelu': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
     'crfconv_add_lrelu_backward': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
     'crfconv_sgd_step': (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _i, _vp]),
+    'crfconv_sgd_step_hyper': (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp]),
     'crfconv_spd_inverse': (_i, [_vp, _i, _vp, _vp]),
     'crfconv_neighbor_maxpool_forward': (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp]),
     'crfconv_neighbor_maxpool_backward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),

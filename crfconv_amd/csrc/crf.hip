@@ -41,26 +41,26 @@ __device__ __forceinline__ float4 matvec_acc(float4 v, const float4* sM, int lan
     return acc;
 }
 
-template <int H>
+template <int H, int NT = BLOCK>
 __device__ __forceinline__ void load_matrix(float4* sM, const float* __restrict__ Mat, bool transpose) {
     // sM[h][c] = transpose ? Mat[c][h] : Mat[h][c]
     float* s = reinterpret_cast<float*>(sM);
-    for (int t = threadIdx.x; t < H * H; t += BLOCK) {
+    for (int t = threadIdx.x; t < H * H; t += NT) {
         const int h = t / H, c = t % H;
         s[t] = transpose ? Mat[c * H + h] : Mat[t];
     }
 }
 
-template <int H>
+template <int H, int NT = BLOCK>
 struct Geo {
-    static constexpr int L = H / 4, PPW = WAVE / L, PPB = PPW * (BLOCK / WAVE);
+    static constexpr int L = H / 4, PPW = WAVE / L, PPB = PPW * (NT / WAVE);
 };
 
-template <int H>
+template <int H, int NT = BLOCK>
 __device__ __forceinline__ int64_t my_point(int64_t m, int& lane, int& q, bool& valid) {
     lane = threadIdx.x & 63;
     q = lane % Geo<H>::L;
-    const int64_t row = (int64_t)xcd_block_id() * Geo<H>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / Geo<H>::L;
+    const int64_t row = (int64_t)xcd_block_id() * Geo<H, NT>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / Geo<H>::L;
     valid = row < m;
     return valid ? row : m - 1;
 }
@@ -106,18 +106,18 @@ __device__ __forceinline__ void load_index_row(const int32_t* __restrict__ idx32
 // Stored straight from the owning lanes, each store instruction touches 64/L rows with 16 bytes each (measured on
 // the level-0 first kernel: +2.1 us); routed through a per-wave LDS tile every instruction writes consecutive bytes.
 // One call per kernel (the tile is a single static array per instantiation).
-template <int H, int K>
+template <int H, int K, int NT = BLOCK>
 __device__ __forceinline__ void store_rows_coalesced(const float (&d)[K], float* __restrict__ dst, int lane, int q,
                                                      int64_t m) {
     constexpr int L = Geo<H>::L, PPW = Geo<H>::PPW, CPR = K / 4, NCH = PPW * CPR;   // 16-byte chunks per row / wave
-    __shared__ float4 tile[BLOCK / WAVE][NCH];
+    __shared__ float4 tile[NT / WAVE][NCH];
     float4* mine = tile[threadIdx.x >> 6];
     const int p = lane / L;
 #pragma unroll
     for (int c = 0; c < CPR; ++c)
         if ((c % L) == q) mine[p * CPR + c] = make_float4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]);
     __builtin_amdgcn_wave_barrier();     // LDS operations of one wave complete in order
-    const int64_t row0 = (int64_t)xcd_block_id() * Geo<H>::PPB + (threadIdx.x >> 6) * PPW;
+    const int64_t row0 = (int64_t)xcd_block_id() * Geo<H, NT>::PPB + (threadIdx.x >> 6) * PPW;
 #pragma unroll
     for (int c = lane; c < NCH; c += WAVE)
         if (row0 + c / CPR < m) st4(dst + row0 * K + 4 * c, mine[c]);
@@ -226,6 +226,313 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
     const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
     const float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
     if (valid) st4(xout + r * H + 4 * q, o);
+}
+
+// ====================================================================== fused forward: all T steps in ONE launch
+// The per-step launches re-read the index row, the weight row and z of every point T times and write / re-read s; here
+// a point's index row, its softmax weights and z Q stay in REGISTERS of the lanes that own it for the whole loop, so
+// per step only x_{t-1} rows move (gathered) and x_t rows are written.  Step t needs every neighbour's x_{t-1}: a
+// grid-wide dependency, served by a two-level arrival barrier between steps (groups of blockIdx % 8 -- one XCD under the
+// dispatcher's round-robin placement, for speed only -- then one top counter).  Visibility across CUs / XCDs without
+// any cache flush: x rows are stored write-through (`sc1`) and drained (`s_waitcnt vmcnt(0)`) by every storing wave
+// before the workgroup arrives; they are only ever read by `sc1` buffer loads (L1 bypassed), and no line of xs[t] is
+// read by anyone before the barrier that follows its last store (MI355X_MICROARCH.md, inter-workgroup visibility).
+// Every workgroup must be resident at once: the host checks the grid against the occupancy query and refuses otherwise.
+constexpr int FW_LINE = 32;                   // words per 128-byte line
+constexpr int FW_CNT = 0, FW_TOP = 8, FW_GEN = 9, FW_FAIL = 17, FW_EXIT = 18, FW_WORDS = 19 * FW_LINE;
+constexpr unsigned FW_SPIN_LIMIT = 1u << 21;  // ~1 s: a stranded workgroup gives up with a code instead of hanging
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, sbase, 16);    // aux 16 = sc1
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float4 ld4_buf(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void st4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, float4 v) {
+    const u32x4_t u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 16);
+}
+
+// phase = 1, 2, ...: counters only grow within a launch (zero at entry: the previous launch's last workgroup out resets
+// them, fused_exit_reset).  Returns false (for the whole workgroup) when the spin gave up.
+// (Polling the generation word with a returning atomic, or a fresh word per phase, measured the same: the barrier costs
+// 1.0-1.3 us after the last arrival either way -- profiles/r2a_fused_meanfield_stamps.txt.)
+template <bool STAMP>
+__device__ __forceinline__ bool fused_grid_sync(unsigned* ws, unsigned phase, unsigned n_in_group, unsigned n_groups,
+                                                int* s_ok, unsigned long long* dbg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if constexpr (STAMP) dbg[(size_t)blockIdx.x * 64 + 8 * phase + 4] = __builtin_amdgcn_s_memrealtime();
+        const unsigned g = blockIdx.x & 7u;
+        unsigned* gen = ws + (FW_GEN + g) * FW_LINE;
+        const unsigned old = __hip_atomic_fetch_add(ws + (FW_CNT + g) * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == n_in_group * phase) {
+            const unsigned o2 = __hip_atomic_fetch_add(ws + FW_TOP * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (o2 + 1 == n_groups * phase) {
+                if constexpr (STAMP) dbg[(size_t)blockIdx.x * 64 + 8 * phase + 6] = __builtin_amdgcn_s_memrealtime();
+                for (unsigned g2 = 0; g2 < n_groups; ++g2)
+                    __hip_atomic_store(ws + (FW_GEN + g2) * FW_LINE, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if constexpr (STAMP) dbg[(size_t)blockIdx.x * 64 + 8 * phase + 5] = __builtin_amdgcn_s_memrealtime();
+        int ok = 1;
+        unsigned spins = 0;
+        for (;;) {
+            if (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= phase) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > FW_SPIN_LIMIT) {
+                __hip_atomic_store(ws + FW_FAIL * FW_LINE, 0x100u | phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+// Last workgroup out zeroes the barrier words for the next launch (every workgroup has passed every barrier by then):
+// no memset node in front of the kernel (4 us of stream time per forward).  ws must be zero before the FIRST launch.
+__device__ __forceinline__ void fused_exit_reset(unsigned* ws, unsigned nblk, int T) {
+    if (threadIdx.x == 0 && T > 1) {
+        const unsigned old = __hip_atomic_fetch_add(ws + FW_EXIT * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == nblk) {
+            for (int l = 0; l < FW_WORDS / FW_LINE; ++l)
+                if (l != FW_FAIL) __hip_atomic_store(ws + l * FW_LINE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// Thread mapping of the fused kernel: EIGHT channels per lane (two float4), so a point takes LPP = H/8 lanes (one lane
+// at H = 8 or 4).  At the headline shape (163 840 points, H = 8) that is 2560 wavefronts = ten per CU: one 640-thread
+// workgroup per CU, 256 arrivals per barrier.  (Four channels per lane, as the per-step kernels use, needs two 10-wave
+// workgroups per CU; their wavefronts are dealt 3,3,2,2 over the SIMDs from a varying start, so the pair does not fit
+// the per-SIMD register file although the occupancy query says it does -- measured: the barrier never completed.)
+template <int H>
+struct FGeo {
+    static constexpr int CPL = H >= 8 ? 8 : 4, NV = CPL / 4, LPP = H / CPL, PPW = WAVE / LPP;
+};
+
+// acc[c] += sum_h vfull[h] * M[h][c0 + c]  (h ascending: the summation order of matvec_acc), M row-major [H][H] floats
+// in LDS; vfull[h] sits in lane (group base + h / CPL), element h % CPL.
+template <int H>
+__device__ __forceinline__ void fused_matvec(const float (&v)[FGeo<H>::CPL], const float* sM, int lane, int q,
+                                             float (&acc)[FGeo<H>::CPL]) {
+    constexpr int CPL = FGeo<H>::CPL, LPP = FGeo<H>::LPP;
+    const int base = lane - q;
+#pragma unroll
+    for (int hl = 0; hl < LPP; ++hl) {
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) {
+            const float vh = LPP == 1 ? v[e] : __shfl(v[e], base + hl, WAVE);
+            const float* row = sM + (hl * CPL + e) * H + q * CPL;
+#pragma unroll
+            for (int c4 = 0; c4 < CPL / 4; ++c4) {
+                const float4 mr = *reinterpret_cast<const float4*>(row + 4 * c4);
+                acc[4 * c4 + 0] = fmaf(vh, mr.x, acc[4 * c4 + 0]);
+                acc[4 * c4 + 1] = fmaf(vh, mr.y, acc[4 * c4 + 1]);
+                acc[4 * c4 + 2] = fmaf(vh, mr.z, acc[4 * c4 + 2]);
+                acc[4 * c4 + 3] = fmaf(vh, mr.w, acc[4 * c4 + 3]);
+            }
+        }
+    }
+}
+
+template <int CPL, int AUX>
+__device__ __forceinline__ void ld_row(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase, float (&v)[CPL]) {
+#pragma unroll
+    for (int c = 0; c < CPL / 4; ++c) {
+        const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, sbase + 16 * c, AUX);   // +16 on the
+        // SCALAR offset: added to the VGPR it is hoisted out of the step loop as one more live register per row
+        v[4 * c + 0] = __uint_as_float(u.x); v[4 * c + 1] = __uint_as_float(u.y);
+        v[4 * c + 2] = __uint_as_float(u.z); v[4 * c + 3] = __uint_as_float(u.w);
+    }
+}
+template <int CPL>
+__device__ __forceinline__ void st_row_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase, const float (&v)[CPL]) {
+#pragma unroll
+    for (int c = 0; c < CPL / 4; ++c) {
+        const u32x4_t u = {__float_as_uint(v[4 * c]), __float_as_uint(v[4 * c + 1]), __float_as_uint(v[4 * c + 2]),
+                           __float_as_uint(v[4 * c + 3])};
+        __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, sbase + 16 * c, 16);
+    }
+}
+
+// Orders the next gather batch behind the use of the current one: the empty statement makes the batch's row offsets
+// "results" of a value computed from the current batch, so neither the DAG builder nor the scheduler can hoist its
+// loads (hipcc otherwise issues all K-1 rows at once and spills: the rows of ONE batch are the register budget).
+template <int N, int K, int GB>
+__device__ __forceinline__ void fused_tie(float (&res)[N], int r0, int r1, int (&j)[K], int k_next) {
+    float dep = 0.f;
+#pragma unroll
+    for (int c = r0; c < r1 && c < N; ++c) asm volatile("" : "+v"(dep), "+v"(res[c]));      // every result of the batch
+#pragma unroll
+    for (int k = k_next; k < k_next + GB && k < K; ++k) asm volatile("" : "+v"(dep), "+v"(j[k]));
+}
+
+// STAMP: diagnostic build only (crfconv_meanfield_forward_fused_stamps): lane 0 of every workgroup writes 100 MHz
+// s_memrealtime stamps of its phases to dbg[block][8 + 8 t]; no output depends on them.
+#define FUSED_STAMP(slot)                                                                         \
+    do {                                                                                          \
+        if constexpr (STAMP) {                                                                    \
+            const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                       \
+            if (threadIdx.x == 0) dbg[(size_t)blockIdx.x * 64 + (slot)] = t_;                     \
+        }                                                                                         \
+    } while (0)
+
+template <int H, int K, int NT, bool STAMP = false>
+__global__ __launch_bounds__(NT) void mf_fused_kernel(const float* __restrict__ y, const float* __restrict__ z,
+                                                      const int32_t* __restrict__ idx,
+                                                      const uint16_t* __restrict__ idx16, int n_tgt, int n_src,
+                                                      const float* __restrict__ Q, const float* __restrict__ P,
+                                                      float* __restrict__ s, float* xs, int64_t m, int T,
+                                                      unsigned* ws, unsigned long long* dbg) {
+    FUSED_STAMP(0);
+    constexpr int CPL = FGeo<H>::CPL, LPP = FGeo<H>::LPP, PPW = FGeo<H>::PPW, PPB = PPW * (NT / WAVE);
+    constexpr int GB = (H <= 8 && K <= 16) ? 8 : 4;   // neighbour rows in flight per lane (register budget)
+    __shared__ __attribute__((aligned(16))) float sQ[H * H];
+    __shared__ __attribute__((aligned(16))) float sP[H * H];
+    __shared__ float4 tile[NT / WAVE][PPW * (K / 4)];   // s rows of a wavefront, written out as contiguous 1 KiB stores
+    __shared__ int s_ok;
+    for (int t = threadIdx.x; t < H * H; t += NT) { sQ[t] = Q[t]; sP[t] = P[t]; }
+    const int lane = threadIdx.x & 63, q = lane % LPP, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = (int)xcd_block_id() * PPB + wave * PPW;         // wave-uniform (SGPRs)
+    int r = row0 + lane / LPP;
+    const bool valid = r < (int)m;
+    if (!valid) r = (int)m - 1;
+
+    // neighbour rows as 32-bit byte offsets into the [m, H] arrays (y, z and every xs[t] share the row stride): buffer
+    // loads with an SGPR base keep one VGPR per address instead of a 64-bit pointer pair
+    int j[K];
+    load_index_row<K>(idx, idx16, r, n_tgt, n_src, j);
+    const int step_bytes = (int)(m * H * 4);
+    const int own = (r * H + q * CPL) * 4;
+#pragma unroll
+    for (int k = 1; k < K; ++k) j[k] = (j[k] * H + q * CPL) * 4;
+    const __amdgpu_buffer_rsrc_t yr = make_rsrc(y, step_bytes), zr = make_rsrc(z, step_bytes);
+    float yi[CPL], zi[CPL];
+    ld_row<CPL, 0>(yr, own, 0, yi);
+    ld_row<CPL, 0>(zr, own, 0, zi);
+    float d[K];
+    float dmin = 3.4e38f;
+#pragma unroll
+    for (int k0 = 1; k0 < K; k0 += GB) {
+        float g[GB][CPL];
+#pragma unroll
+        for (int k = k0; k < k0 + GB && k < K; ++k) ld_row<CPL, 0>(yr, j[k], 0, g[k - k0]);
+#pragma unroll
+        for (int k = k0; k < k0 + GB && k < K; ++k) {
+            float part = 0.f;
+#pragma unroll
+            for (int c4 = CPL / 4 - 1; c4 >= 0; --c4) {          // = dot4 per float4, quads added low to high
+                const float a0 = yi[4 * c4] - g[k - k0][4 * c4], a1 = yi[4 * c4 + 1] - g[k - k0][4 * c4 + 1];
+                const float a2 = yi[4 * c4 + 2] - g[k - k0][4 * c4 + 2], a3 = yi[4 * c4 + 3] - g[k - k0][4 * c4 + 3];
+                const float dq = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, a3 * a3)));
+                part = c4 == CPL / 4 - 1 ? dq : dq + part;
+            }
+            d[k] = group_sum<LPP>(part);
+            dmin = fminf(dmin, d[k]);
+        }
+        fused_tie<K, K, GB>(d, k0, k0 + GB, j, k0 + GB);             // the next batch's loads stay behind this batch's use
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        d[k] = __expf(dmin - d[k]);
+        den += d[k];
+    }
+    const float inv = 1.0f / den;
+    d[0] = 0.f;
+#pragma unroll
+    for (int k = 1; k < K; ++k) d[k] *= inv;
+    if (s != nullptr) {
+        constexpr int CPR = K / 4, NCH = PPW * CPR;
+        float4* mine = tile[wave];
+        const int pl = lane / LPP;
+#pragma unroll
+        for (int c = 0; c < CPR; ++c)
+            if ((c % LPP) == q) mine[pl * CPR + c] = make_float4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = lane; c < NCH; c += WAVE)
+            if (row0 + c / CPR < (int)m) st4(s + (int64_t)row0 * K + 4 * c, mine[c]);
+    }
+
+    float msg[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) msg[c] = 0.f;
+#pragma unroll
+    for (int k0 = 1; k0 < K; k0 += GB) {
+        float g[GB][CPL];
+#pragma unroll
+        for (int k = k0; k < k0 + GB && k < K; ++k) ld_row<CPL, 0>(zr, j[k], 0, g[k - k0]);
+#pragma unroll
+        for (int k = k0; k < k0 + GB && k < K; ++k)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) msg[c] = fmaf(d[k], g[k - k0][c], msg[c]);
+        fused_tie<CPL, K, GB>(msg, 0, CPL, j, k0 + GB);
+    }
+    __syncthreads();                                    // sQ / sP
+    float zq[CPL], o[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) zq[c] = 0.f;
+    fused_matvec<H>(zi, sQ, lane, q, zq);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) o[c] = zq[c];
+    fused_matvec<H>(msg, sP, lane, q, o);
+
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(xs, step_bytes * T);
+    FUSED_STAMP(1);
+    if (valid) st_row_sc1<CPL>(xr, own, 0, o);
+
+    const unsigned nblk = gridDim.x, grp = blockIdx.x & 7u;
+    const unsigned n_in_group = nblk / 8u + (grp < (nblk & 7u) ? 1u : 0u), n_groups = nblk < 8u ? nblk : 8u;
+    for (int t = 1; t < T; ++t) {
+        if constexpr (STAMP) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FUSED_STAMP(8 * t + 0);                                  // own stores drained
+        }
+        if (!fused_grid_sync<STAMP>(ws, (unsigned)t, n_in_group, n_groups, &s_ok, dbg)) return;
+        FUSED_STAMP(8 * t + 1);                                      // barrier left
+        const int base = (t - 1) * step_bytes;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) msg[c] = 0.f;
+#pragma unroll
+        for (int k0 = 1; k0 < K; k0 += GB) {
+            float g[GB][CPL];
+#pragma unroll
+            for (int k = k0; k < k0 + GB && k < K; ++k) ld_row<CPL, 16>(xr, j[k], base, g[k - k0]);     // aux 16 = sc1
+#pragma unroll
+            for (int k = k0; k < k0 + GB && k < K; ++k)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) msg[c] = fmaf(d[k], g[k - k0][c], msg[c]);
+            fused_tie<CPL, K, GB>(msg, 0, CPL, j, k0 + GB);
+        }
+        if constexpr (STAMP) {
+            float keep = msg[0];
+            asm volatile("" : "+v"(keep));
+            FUSED_STAMP(8 * t + 2);                                  // gathers consumed
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) o[c] = zq[c];
+        fused_matvec<H>(msg, sP, lane, q, o);
+        if (valid) st_row_sc1<CPL>(xr, own, base + step_bytes, o);
+        FUSED_STAMP(8 * t + 3);
+    }
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FUSED_STAMP(7);
+    }
+    fused_exit_reset(ws, nblk, T);
 }
 
 // ====================================================================== LDS-window forward kernels
@@ -855,5 +1162,82 @@ extern "C" int crfconv_similarity_bwd_scatter(const float* w, const float* y, co
                            dy_self, rev_ptr, rev_eid, K, kshift_of(K), dy, m_src);
         CRF_LAUNCH_CHECK();
     });
+    return CRF_OK;
+}
+
+// ---------------------------------------------------------------------- fused forward (one launch for all T steps)
+constexpr int FUSED_NT = 640;        // 10 wavefronts: 640 points (H = 8) per workgroup, one workgroup per CU at the headline shape
+
+template <int H, int K>
+static int fused_capacity() {        // workgroups that can be resident at once (occupancy query x CUs), -1 on error
+    static int cap = 0;
+    if (cap == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_fused_kernel<H, K, FUSED_NT>, FUSED_NT, 0) != hipSuccess)
+            cap = -1;
+        else
+            cap = per_cu * cus;
+    }
+    return cap;
+}
+
+static int fused_check(int64_t m, int H, int K, int k0, int T) {
+    if (!(k0 == 1 && (K == 16 || K == 32) && T >= 1)) return 0;
+    if (!(H == 4 || H == 8 || (H == 16 && K == 16))) return 0;      // wider rows: the per-step kernels (register budget)
+    if (m <= 0 || m * H * 4 * (int64_t)T >= ((int64_t)1 << 31)) return 0;          // 32-bit buffer offsets
+    int cap = 0;
+    int64_t grid = 0;
+    DISPATCH_H(H, {
+        cap = K == 16 ? fused_capacity<HH, 16>() : fused_capacity<HH, 32>();
+        grid = cdiv(m, FGeo<HH>::PPW * (FUSED_NT / WAVE));
+    });
+    return cap > 0 && grid <= cap ? 1 : 0;
+}
+
+extern "C" size_t crfconv_meanfield_fused_workspace(void) { return FW_WORDS * sizeof(unsigned); }
+
+extern "C" int crfconv_meanfield_fused_supported(int64_t m, int H, int K, int k0, int T) {
+    return fused_check(m, H, K, k0, T);
+}
+
+extern "C" int crfconv_meanfield_forward_fused(const float* z, const float* y, const int32_t* idx32,
+                                               const uint16_t* idx16, int n_tgt, int n_src, int K, int k0, int64_t m,
+                                               int H, const float* Q, const float* P, int T, float* s, float* xs,
+                                               void* ws, size_t ws_bytes, crf_stream_t stream) {
+    if (int rc = check_common(m, H, K, k0)) return rc;
+    CRF_REQUIRE(z && y && idx32 && Q && P && xs && ws, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(ws_bytes >= FW_WORDS * sizeof(unsigned), CRF_ERR_ARG, "workspace of %zu bytes, need %zu", ws_bytes,
+                FW_WORDS * sizeof(unsigned));
+    CRF_REQUIRE(idx16 == nullptr || (n_tgt > 0 && n_src > 0 && n_src <= 65536 && m % n_tgt == 0), CRF_ERR_ARG,
+                "u16 table needs n_src <= 65536 and m a multiple of n_tgt (n_tgt=%d n_src=%d)", n_tgt, n_src);
+    CRF_REQUIRE(fused_check(m, H, K, k0, T) == 1, CRF_ERR_UNSUPPORTED,
+                "fused mean-field forward: shape not supported or grid not co-resident (m=%lld H=%d K=%d k0=%d T=%d)",
+                (long long)m, H, K, k0, T);
+    hipStream_t st = as_stream(stream);
+    DISPATCH_H(H, {
+        const dim3 grid((unsigned)cdiv(m, FGeo<HH>::PPW * (FUSED_NT / WAVE))), blk(FUSED_NT);
+        if (K == 16)
+            hipLaunchKernelGGL((mf_fused_kernel<HH, 16, FUSED_NT>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, (unsigned*)ws, (unsigned long long*)nullptr);
+        else
+            hipLaunchKernelGGL((mf_fused_kernel<HH, 32, FUSED_NT>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, (unsigned*)ws, (unsigned long long*)nullptr);
+        CRF_LAUNCH_CHECK();
+    });
+    return CRF_OK;
+}
+
+/* Diagnostic build of the fused forward (H = 8, K = 16 only): the same kernel with 100 MHz time stamps per workgroup in
+ * dbg [grid][64] (uint64): [0] start, [1] phase-0 result ready, [7] end, per step t: [8t] own stores drained, [8t+1] left
+ * the barrier, [8t+2] gathers consumed, [8t+3] x_t stored.  Not part of the product path (scratch/mff_bench.py). */
+extern "C" int crfconv_meanfield_forward_fused_stamps(const float* z, const float* y, const int32_t* idx32,
+                                                      const uint16_t* idx16, int n_tgt, int n_src, int64_t m,
+                                                      const float* Q, const float* P, int T, float* s, float* xs,
+                                                      void* ws, unsigned long long* dbg, crf_stream_t stream) {
+    CRF_REQUIRE(fused_check(m, 8, 16, 1, T) == 1 && T <= 7, CRF_ERR_UNSUPPORTED, "stamps: shape not supported");
+    hipStream_t st = as_stream(stream);
+    const dim3 grid((unsigned)cdiv(m, FGeo<8>::PPW * (FUSED_NT / WAVE))), blk(FUSED_NT);
+    hipLaunchKernelGGL((mf_fused_kernel<8, 16, FUSED_NT, true>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, (unsigned*)ws, dbg);
+    CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -156,7 +156,36 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
         p[i] = fmaf(-lr, d, w);
     }
 }
+// the same update with {lr, momentum, dampening, weight_decay} read from device memory: a captured hipGraph of the step
+// then follows a learning-rate schedule (trainval.py:73 ExponentialLR) -- launch scalars are frozen at capture time
+__global__ __launch_bounds__(256) void sgd_hyper_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ buf, int64_t n,
+                                                        const float* __restrict__ hyper, int nesterov, int first) {
+    const float lr = hyper[0], mu = hyper[1], damp = hyper[2], wd = hyper[3];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float w = p[i];
+        float d = fmaf(wd, w, g[i]);
+        if (mu != 0.f) {
+            const float b = first ? d : fmaf(mu, buf[i], (1.f - damp) * d);
+            buf[i] = b;
+            d = nesterov ? fmaf(mu, b, d) : b;
+        }
+        p[i] = fmaf(-lr, d, w);
+    }
+}
 }  // namespace crf
+
+extern "C" int crfconv_sgd_step_hyper(float* param, const float* grad, float* momentum_buf, int64_t n,
+                                      const float* hyper, int nesterov, int first_step, crf_stream_t stream) {
+    CRF_REQUIRE(param && grad && momentum_buf && hyper, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(n > 0, CRF_ERR_ARG, "n=%lld <= 0", (long long)n);
+    int64_t nb = cdiv(n, 256 * 4);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(crf::sgd_hyper_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), param, grad, momentum_buf,
+                       n, hyper, nesterov, first_step);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
 
 extern "C" int crfconv_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
                                 float momentum, float dampening, float weight_decay, int nesterov, int first_step,

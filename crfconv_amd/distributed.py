@@ -30,10 +30,11 @@ def init_from_env(backend=None):
 
 class FlatGradAllReduce:
     """One contiguous fp32 bucket for the whole model (820 141 floats = 3.3 MB for PointConvBig(6, 13)):
-    a single all-reduce per step.  Gradients are left as autograd produces them (``zero()`` sets them to
-    None, so backward installs fresh tensors instead of launching one accumulate kernel per parameter --
-    426 launches a step otherwise) and are packed / unpacked with batched foreach copies only when there
-    is more than one rank."""
+    a single all-reduce per step.  ``zero()`` sets the gradients to None, so backward installs fresh tensors
+    instead of launching one accumulate kernel per parameter (426 launches a step otherwise); ``pack()`` --
+    called by ``allreduce_mean()`` at EVERY world size -- copies them into the bucket with one batched foreach
+    copy and re-points every ``param.grad`` at its slice of the bucket, which is what ``FlatSGD.step()`` reads.
+    The documented step is therefore  zero() -> backward -> allreduce_mean() -> opt.step()  on one GPU too."""
 
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -49,15 +50,23 @@ class FlatGradAllReduce:
         for p in self.params:
             p.grad = None
 
-    def allreduce_mean(self):
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-            return
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        torch._foreach_copy_(self.views, grads)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(dist.get_world_size())
+    def pack(self):
+        """param.grad -> bucket (missing gradients count as zero); afterwards every param.grad IS its bucket slice."""
+        have = [(v, p.grad) for p, v in zip(self.params, self.views)
+                if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        missing = [v for p, v in zip(self.params, self.views) if p.grad is None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        if missing:
+            torch._foreach_zero_(missing)
         for p, v in zip(self.params, self.views):
             p.grad = v
+
+    def allreduce_mean(self):
+        self.pack()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
 
 
 def broadcast_parameters(module, src=0):

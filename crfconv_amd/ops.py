@@ -47,8 +47,14 @@ class _MeanField(torch.autograd.Function):
         keep_s = needs_grad or steps != 1 or k0 != 1 or table.K not in (16, 32) or _WINDOW_ENV
         s = torch.empty((m, table.K), dtype=torch.float32, device=z.device) if keep_s else None   # s[i*K + k]
         xs = torch.empty((max(steps, 1), m, H), dtype=torch.float32, device=z.device)
-        _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(table.idx32), ptr(table.idx16), table.n_tgt,
-                  table.n_src, table.K, k0, m, H, ptr(Q), ptr(P), steps, ptr(s), ptr(xs), stream_ptr())
+        if _FUSED_ENV and steps >= 1 and _lib.load().crfconv_meanfield_fused_supported(m, H, table.K, k0, steps) == 1:
+            # one launch for all steps: measured slower than the per-step launches, opt-in for A/B runs
+            _lib.call('crfconv_meanfield_forward_fused', ptr(z), ptr(y), ptr(table.idx32), ptr(table.idx16), table.n_tgt,
+                      table.n_src, table.K, k0, m, H, ptr(Q), ptr(P), steps, ptr(s), ptr(xs), ptr(_fused_ws(z.device)),
+                      _lib.load().crfconv_meanfield_fused_workspace(), stream_ptr())
+        else:
+            _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(table.idx32), ptr(table.idx16), table.n_tgt,
+                      table.n_src, table.K, k0, m, H, ptr(Q), ptr(P), steps, ptr(s), ptr(xs), stream_ptr())
         ctx.table, ctx.k0, ctx.steps = table, k0, steps
         if needs_grad:
             ctx.save_for_backward(z, y, Q, P, s, xs)
@@ -147,6 +153,16 @@ class _CrfMatrices(torch.autograd.Function):
 
 
 _CRF_H = (4, 8, 16, 32, 64)
+_FUSED_ENV = __import__('os').environ.get('CRFCONV_FUSED') is not None       # one-launch forward (crfconv_meanfield_forward_fused)
+_FUSED_WS = {}
+
+
+def _fused_ws(device):
+    """Barrier words of the fused forward: zero once, the kernel leaves them zeroed."""
+    ws = _FUSED_WS.get(device)
+    if ws is None:
+        ws = _FUSED_WS[device] = torch.zeros(_lib.load().crfconv_meanfield_fused_workspace(), dtype=torch.uint8, device=device)
+    return ws
 _WINDOW_ENV = __import__('os').environ.get('CRFCONV_WINDOW') is not None     # A/B kernels of csrc/crf.hip: always keep s
 
 

@@ -367,11 +367,62 @@ def test_meanfield_single_step_inference_skips_s():
     assert torch.equal(a, b.detach())
 
 
+@pytest.mark.parametrize('H,K,T,B,N', [(8, 16, 3, 4, 40960), (8, 16, 5, 2, 5000), (8, 32, 3, 2, 4096), (4, 16, 2, 1, 3001),
+                                       (16, 16, 3, 2, 2560)])
+def test_meanfield_fused_launch_equals_per_step_launches(H, K, T, B, N):
+    """crfconv_meanfield_forward_fused (all steps in one launch, x_t rows exchanged between workgroups through
+    write-through stores and L1-bypassing loads) against the per-step launches: bit-identical at H <= 8 (same operation
+    order), 1e-6 at H = 16 (different reduction tree), on the SAME output buffers with inputs that change between
+    back-to-back launches -- a reader that picked up a stale x_{t-1} row would show up as a mismatch."""
+    from crfconv_amd import _lib
+    from crfconv_amd.graph import NeighborTable, ptr, stream_ptr
+    from crfconv_amd.utils import nearest_neighbors
+    lib = _lib.load()
+    m = B * N
+    if lib.crfconv_meanfield_fused_supported(m, H, K, 1, T) != 1:
+        pytest.skip('grid not co-resident on this device')
+    g = torch.Generator().manual_seed(H * K + T)
+    pos = (torch.rand(B, N, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])).to(DEV)
+    tab = NeighborTable(nearest_neighbors.knn_batch_device(pos, pos, K), N)
+    y = torch.randn(m, H, generator=g).to(DEV)
+    c = torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)
+    C = c.t() @ c
+    Q = torch.linalg.inv(torch.eye(H) + C)
+    P = (C @ Q).to(DEV).contiguous()
+    Q = Q.to(DEV).contiguous()
+    wsb = lib.crfconv_meanfield_fused_workspace()
+    ws = torch.zeros(wsb // 4, dtype=torch.int32, device=DEV)
+    st = stream_ptr()
+    zs = [torch.randn(m, H, generator=g).to(DEV) for _ in range(4)]
+    s_ref, xs_ref = torch.empty(m, K, device=DEV), torch.empty(T, m, H, device=DEV)
+    s_f, xs_f = torch.empty(m, K, device=DEV), torch.empty(T, m, H, device=DEV)
+    refs = []
+    for z in zs:
+        _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src, K, 1,
+                  m, H, ptr(Q), ptr(P), T, ptr(s_ref), ptr(xs_ref), st)
+        refs.append((s_ref.clone(), xs_ref.clone()))
+    outs = []
+    for rep in range(3):
+        for z in zs:                       # back to back, no host synchronisation in between
+            _lib.call('crfconv_meanfield_forward_fused', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src,
+                      K, 1, m, H, ptr(Q), ptr(P), T, ptr(s_f), ptr(xs_f), ptr(ws), wsb, st)
+            outs.append((s_f.clone(), xs_f.clone()))
+    torch.cuda.synchronize()
+    assert int(ws[17 * 32]) == 0, 'a workgroup gave up at the barrier'
+    assert int(ws.abs().sum()) == 0, 'barrier words not reset by the last workgroup out'
+    for i, (so, xo) in enumerate(outs):
+        sr, xr = refs[i % len(zs)]
+        if H <= 8:
+            assert torch.equal(so, sr) and torch.equal(xo, xr), 'launch %d differs' % i
+        else:
+            assert float((so - sr).abs().max()) < 1e-6 and float((xo - xr).abs().max()) < 1e-5, 'launch %d differs' % i
+
+
 # ------------------------------------------------------------------ the other BASELINE configs at their full sizes
-@pytest.mark.parametrize('name,B,N,K,T,H', [('C3 KITTI scan', 1, 122880, 16, 1, 8), ('C4 ScanNet cloud', 4, 81920, 16, 3, 8),
+@pytest.mark.parametrize('name,B,N,K,T,H', [('C2 S3DIS batch (headline)', 4, 40960, 16, 3, 8), ('C3 KITTI scan', 1, 122880, 16, 1, 8), ('C4 ScanNet cloud', 4, 81920, 16, 3, 8),
                                             ('C5 Semantic3D crops', 2, 65536, 32, 5, 8), ('C5 level 1', 2, 16384, 32, 5, 16)])
 def test_meanfield_other_configs_full_size(name, B, N, K, T, H):
-    """BASELINE.json configs 3-5 at full size: the mean-field forward AND backward against the CPU oracle on the whole
+    """BASELINE.json configs 2-5 at full size: the mean-field forward AND backward against the CPU oracle on the whole
     batch (the oracle takes seconds at these sizes), through the int32 index path (clouds > 65536 points: C3, C4) and
     the uint16 path at its limit (65536-point crops, K = 32: C5)."""
     from crfconv_amd import ops
@@ -444,37 +495,29 @@ def test_config5_shape_network_k32_t5_vs_oracle():
     assert worst[0] <= 3e-3, 'worst gradient %s: %.2e' % (worst[1], worst[0])
 
 
-def test_config3_inference_matches_oracle():
-    """BASELINE.json config 3: one KITTI-like scan of 122 880 points (ranges 2-50 m on 64 elevation rings), K = 16,
-    one mean-field step, PointConvBig in eval mode; per-point logits within 1e-4 of the CPU oracle and the same
-    arg-max labels ("mIoU parity": identical confusion matrix)."""
+def _eval_net_vs_oracle(pos, feats, in_ch, ncls, steps, seed, name, g):
+    """Whole PointConvBig in eval mode on `pos` [B, N, 3] / `feats` [B, N, in_ch]: per-point logits within 1e-4 of the
+    CPU oracle and the same arg-max labels ("mIoU parity": identical confusion matrix up to provably ambiguous rows)."""
     import crfconv_amd
     from crfconv_amd import models
     from crfconv_amd.utils import runningScore
-    g = torch.Generator().manual_seed(33)
-    N, ncls = 122880, 19
-    r = 2 + 48 * torch.rand(N, generator=g)
-    az = 2 * np.pi * torch.rand(N, generator=g)
-    el = torch.deg2rad(-25 + 28 * torch.randint(0, 64, (N,), generator=g).float() / 63)
-    pos = torch.stack([r * torch.cos(el) * torch.cos(az), r * torch.cos(el) * torch.sin(az), r * torch.sin(el)], 1)
-    pos = (pos + 0.01 * torch.randn(N, 3, generator=g)).float().unsqueeze(0)
-    feats = torch.cat([pos, torch.rand(1, N, 1, generator=g)], -1)                      # xyz + remission: in_channels = 4
+    B, N = pos.shape[:2]
     data = crfconv_amd.multiscale_compute(pos.to(DEV), x=feats.to(DEV), generator=g)
-    net = models.PointConvBig(4, ncls, use_crf=True, steps=1)
-    sd = S.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 9)
+    net = models.PointConvBig(in_ch, ncls, use_crf=True, steps=steps)
+    sd = S.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed)
     net.load_state_dict(sd)
     net = net.to(DEV).eval()
     with torch.no_grad():
         logits = net(data)
-    assert logits.shape == (N, ncls) and torch.isfinite(logits).all()
+    assert logits.shape == (B * N, ncls) and torch.isfinite(logits).all()
     torch.set_num_threads(16)
     ms = [{k: getattr(l, k).cpu() for k in ('pos', 'neighbor_idx', 'sub_idx', 'up_idx') if getattr(l, k, None) is not None}
           for l in data.multiscale]
     with torch.no_grad():
         # the device collate emits each cloud in Morton order: the oracle gets the features in that same order
-        ref = O.pointconv_resnet({k: v.clone() for k, v in sd.items()}, data.x.cpu(), ms, 1, False, True)
-    assert_close(logits, ref, OUT_TOL, 'config-3 logits')
-    labels = torch.randint(0, ncls, (N,), generator=g)
+        ref = O.pointconv_resnet({k: v.clone() for k, v in sd.items()}, data.x.cpu(), ms, steps, False, True)
+    assert_close(logits, ref, OUT_TOL, name + ' logits')
+    labels = torch.randint(0, ncls, (B * N,), generator=g)
     a, b = runningScore(ncls), runningScore(ncls)
     a.update_from_logits(labels.to(DEV), logits)
     b.update(labels.to(DEV), ref.argmax(1).to(DEV))
@@ -483,6 +526,69 @@ def test_config3_inference_matches_oracle():
     margin = 2 * OUT_TOL * max(1.0, float(ref.abs().max()))           # the tolerance of assert_close, both ways
     ambiguous = int(((top2[:, 0] - top2[:, 1]) < margin).sum())
     assert np.abs(a.confusion_matrix - b.confusion_matrix).sum() <= 2 * ambiguous
+    return data, net, sd, ms
+
+
+def test_config3_inference_matches_oracle():
+    """BASELINE.json config 3: one KITTI-like scan of 122 880 points (ranges 2-50 m on 64 elevation rings), K = 16,
+    one mean-field step, PointConvBig in eval mode."""
+    g = torch.Generator().manual_seed(33)
+    N, ncls = 122880, 19
+    r = 2 + 48 * torch.rand(N, generator=g)
+    az = 2 * np.pi * torch.rand(N, generator=g)
+    el = torch.deg2rad(-25 + 28 * torch.randint(0, 64, (N,), generator=g).float() / 63)
+    pos = torch.stack([r * torch.cos(el) * torch.cos(az), r * torch.cos(el) * torch.sin(az), r * torch.sin(el)], 1)
+    pos = (pos + 0.01 * torch.randn(N, 3, generator=g)).float().unsqueeze(0)
+    feats = torch.cat([pos, torch.rand(1, N, 1, generator=g)], -1)                      # xyz + remission: in_channels = 4
+    _eval_net_vs_oracle(pos, feats, 4, ncls, 1, 9, 'config-3', g)
+
+
+def test_config2_headline_inference_matches_oracle():
+    """BASELINE.json config 2 -- the shape the bench line is quoted on: 4 clouds x 40 960 points, one point per 4 cm
+    voxel of an 8 x 8 x 3 m box, K = 16, three mean-field steps, 13 classes.  Whole-network eval logits
+    vs the CPU oracle at FULL size, and the confusion matrix."""
+    g = torch.Generator().manual_seed(2)
+    B, N = 4, 40960
+    rng = np.random.default_rng(2)
+    dims = np.array([200, 200, 75])
+    pos = np.empty((B, N, 3), np.float32)
+    for b in range(B):
+        flat = rng.choice(int(dims.prod()), size=N, replace=False)
+        ijk = np.stack(np.unravel_index(flat, dims), -1).astype(np.float64)
+        pos[b] = ((ijk + 0.5) * 0.04 + rng.uniform(-0.01, 0.01, (N, 3))).astype(np.float32)
+    pos = torch.from_numpy(pos)
+    feats = torch.cat([pos, torch.rand(B, N, 3, generator=g)], -1)
+    _eval_net_vs_oracle(pos, feats, 6, 13, 3, 12, 'config-2', g)
+
+
+def test_config1_shape_eval_and_train_vs_oracle():
+    """BASELINE.json config 1's exact shape: 2 x 2048 points on the unit sphere's interior, xyz + unit normals
+    (in_channels 6), K = 16, ONE mean-field step, 50 part classes: eval logits + confusion, then train-mode logits,
+    loss and every parameter gradient against the oracle."""
+    g = torch.Generator().manual_seed(1)
+    B, N, ncls = 2, 2048, 50
+    pos = torch.rand(B, N, 3, generator=g) - 0.5
+    pos = pos / pos.norm(dim=-1).max()
+    nrm = torch.randn(B, N, 3, generator=g)
+    nrm = nrm / nrm.norm(dim=-1, keepdim=True)
+    feats = torch.cat([pos, nrm], -1)
+    data, net, sd, ms = _eval_net_vs_oracle(pos, feats, 6, ncls, 1, 21, 'config-1', g)
+    labels = torch.randint(0, ncls + 1, (B, N), generator=g)
+    net.train()
+    net.classifier[1] = nn.Identity()                      # dropout draws from different RNG streams: compare without
+    logits = net(data)
+    loss = torch.nn.functional.cross_entropy(logits, labels.reshape(-1).to(DEV) - 1, ignore_index=-1)
+    loss.backward()
+    prm = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    mask = torch.full((B, N, 128), 0.5)                    # oracle: h * mask * 2 = identity
+    ref_t = O.pointconv_resnet(prm, data.x.cpu(), ms, 1, True, True, dropout_mask=mask)
+    ref_loss = O.training_loss(ref_t, labels)
+    ref_loss.backward()
+    assert_close(logits, ref_t, 5e-4, 'config-1 train logits')
+    assert_close(loss, ref_loss, 1e-4, 'config-1 loss')
+    gr = grads(net)
+    worst = max((relerr(gr[k], prm[k].grad), k) for k in gr)
+    assert worst[0] <= 3e-3, 'worst gradient %s: %.2e' % (worst[1], worst[0])
 
 
 @pytest.mark.parametrize('M,Ci,Co,bias', [(163840, 32, 128, False), (40960, 64, 16, False), (1000, 6, 8, False),
