@@ -74,6 +74,41 @@ class _MeanField(torch.autograd.Function):
             return G, torch.zeros_like(y), torch.zeros_like(Q), torch.zeros_like(P), None, None, None
         rev_ptr, rev_eid = table.reverse
         st = stream_ptr()
+        lib = _lib.load()
+
+        def skinny_tn(A, B, out):      # out = A^T B for [rows, H] operands: the MFMA row-reduction kernel
+            rows = A.shape[0]
+            wbytes = lib.crfconv_linear_wgrad_workspace(rows, H, H)
+            wws = torch.empty(wbytes, dtype=torch.uint8, device=z.device)
+            _lib.call('crfconv_linear_wgrad', ptr(A), ptr(B), rows, H, H, ptr(out), None, ptr(wws), wbytes, st)
+
+        if lib.crfconv_meanfield_backward_supported(H, table.K, k0) == 1 and not _OLD_BWD_ENV:
+            # T + 3 launches: prepare | T chain steps | one edge pass over all steps + softmax backward | dy scatter
+            # (+ one small reduction when dP / dQ are accumulated inside those launches: H in {8, 16})
+            dev = z.device
+            inside = lib.crfconv_meanfield_backward_param_grads_inside(H) == 1
+            Gs = torch.empty((T, m, H), dtype=torch.float32, device=dev)        # entry 0 unused: G_T = gout
+            gms = torch.empty((T, m, H), dtype=torch.float32, device=dev)
+            dz, dy_self, dy = (torch.empty_like(z) for _ in range(3))
+            w = torch.empty_like(s)
+            dP, dQ = torch.empty_like(P), torch.empty_like(Q)
+            mts = sumG = None
+            if not inside:
+                mts = torch.empty((T, m, H), dtype=torch.float32, device=dev)
+                sumG = torch.empty_like(z)
+            wsb = lib.crfconv_meanfield_backward_workspace(m, H, table.K)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            _lib.call('crfconv_meanfield_backward', ptr(G), ptr(z), ptr(y), ptr(s), ptr(xs), ptr(table.idx32),
+                      ptr(table.idx16), table.n_tgt, table.n_src, ptr(rev_ptr), ptr(rev_eid), table.K, k0, m, H, ptr(Q),
+                      ptr(P), T, ptr(Gs), ptr(gms), ptr(mts), ptr(sumG), ptr(dz), ptr(w), ptr(dy_self), ptr(dy), ptr(dP),
+                      ptr(dQ), ptr(ws), wsb, ptr(_ticket(dev)), st)
+            if not inside:
+                Gs[0].copy_(G)
+                skinny_tn(mts.view(T * m, H), Gs.view(T * m, H), dP)
+                skinny_tn(z, sumG, dQ)
+            return dz, dy, dQ, dP, None, None, None
+
+        # generic shapes (any K <= 64 / k0, padded variable-degree tables): one edge + one scatter launch per step
         gm = torch.empty_like(z)
         ds = torch.empty_like(s)
         # G_t (gradient entering step t) and m_t for t = T..1 stacked row-wise: dP = sum_t m_t^T G_t and
@@ -88,13 +123,6 @@ class _MeanField(torch.autograd.Function):
                       m, H, ptr(P), ptr(gm), ptr(ds), ptr(mts[i]), 0 if t == T else 1, st)
             _lib.call('crfconv_meanfield_bwd_scatter', ptr(gm), ptr(s), ptr(rev_ptr), ptr(rev_eid), table.K, k0,
                       m, H, None, ptr(Gs[i + 1] if i + 1 < T else G0), st)
-
-        def skinny_tn(A, B, out):      # out = A^T B for [rows, H] operands: the MFMA row-reduction kernel
-            rows = A.shape[0]
-            wbytes = _lib.load().crfconv_linear_wgrad_workspace(rows, H, H)
-            wws = torch.empty(wbytes, dtype=torch.uint8, device=z.device)
-            _lib.call('crfconv_linear_wgrad', ptr(A), ptr(B), rows, H, H, ptr(out), None, ptr(wws), wbytes, st)
-
         dP = torch.empty_like(P)
         skinny_tn(mts.view(T * m, H), Gs.view(T * m, H), dP)
         sumG = Gs.sum(0) if T > 1 else Gs[0]
@@ -153,8 +181,20 @@ class _CrfMatrices(torch.autograd.Function):
 
 
 _CRF_H = (4, 8, 16, 32, 64)
+_OLD_BWD_ENV = __import__('os').environ.get('CRFCONV_OLD_BWD') is not None     # A/B: the step-by-step backward launches
 _FUSED_ENV = __import__('os').environ.get('CRFCONV_FUSED') is not None       # one-launch forward (crfconv_meanfield_forward_fused)
 _FUSED_WS = {}
+
+
+_TICKETS = {}
+
+
+def _ticket(device):
+    """One zero word per device for the "last workgroup finishes" reductions (left zero by the kernels)."""
+    t = _TICKETS.get(device)
+    if t is None:
+        t = _TICKETS[device] = torch.zeros(64, dtype=torch.int32, device=device)
+    return t
 
 
 def _fused_ws(device):
