@@ -106,6 +106,228 @@ __global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict
     }
 }
 
+// ====================================================================== backward of Linear -> BatchNorm -> LeakyReLU
+// (models/common.py:34-40, training mode) in TWO passes over the activations instead of four.  With
+//   g1 = gA * lrelu'(a y + b),   yh = (y - mean) rstd,   dbeta = sum g1,   dgamma = sum g1 yh,
+//   gY = a (g1 - dbeta / M - yh dgamma / M),   dX = gY W,   dW = gY^T X
+// the weight gradient expands to   dW = diag(a) [ G1^T X - (dbeta / M) (1^T X) - diag(dgamma / M) Yh^T X ]:
+// G1^T X, Yh^T X, 1^T X, sum g1 and sum g1 yh are all plain row reductions, so ONE streaming pass over (gA, Y, X)
+// produces every partial (mlp_bwd_p1_kernel: two MFMA accumulator sets sharing the X fragment); a small finalize turns
+// them into dgamma, dbeta, dW and the per-channel coefficients of gY; and dX = gY W is one more pass in which gY is
+// formed in registers from (gA, Y) while loading the operand (linear_fwd_kernel<.., true>).  The step-by-step form
+// (bn_bwd_reduce -> finalize -> bn_bwd_apply -> dX -> wgrad) reads or writes nine [M, C] arrays; this one six, with
+// three launches instead of five, and gY never reaches memory.
+template <int TCO, int TCI>
+__global__ __launch_bounds__(WG_BLOCK) void mlp_bwd_p1_kernel(const float* __restrict__ GA, const float* __restrict__ Y,
+                                                              const float* __restrict__ X,
+                                                              const float* __restrict__ coef /*[4][Co]: a, b, mean, rstd*/,
+                                                              float slope, int64_t M, int Co, int Ci, int rows_per_block,
+                                                              float* __restrict__ PA /*[nblk][Co][Ci]*/,
+                                                              float* __restrict__ PB /*[nblk][Co][Ci]*/,
+                                                              float* __restrict__ PG /*[nblk][2][Co]*/,
+                                                              float* __restrict__ PX /*[nblk][Ci]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int co_base = blockIdx.y * 16 * TCO, ci_base = blockIdx.z * 16 * TCI;
+    const int kk = lane >> 4, cc = lane & 15;
+    f32x4 accA[TCO][TCI], accB[TCO][TCI];
+#pragma unroll
+    for (int a = 0; a < TCO; ++a)
+#pragma unroll
+        for (int b = 0; b < TCI; ++b) { accA[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; accB[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float ca[TCO], cb[TCO], cm[TCO], cr[TCO], sg[TCO], sgy[TCO], sx[TCI];
+#pragma unroll
+    for (int a = 0; a < TCO; ++a) {
+        const int co = co_base + 16 * a + cc;
+        const bool ok = co < Co;
+        ca[a] = ok ? coef[co] : 0.f;
+        cb[a] = ok ? coef[Co + co] : 0.f;
+        cm[a] = ok ? coef[2 * Co + co] : 0.f;
+        cr[a] = ok ? coef[3 * Co + co] : 0.f;
+        sg[a] = 0.f;
+        sgy[a] = 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < TCI; ++b) sx[b] = 0.f;
+
+    const int64_t row_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t row_end = row_begin + rows_per_block < M ? row_begin + rows_per_block : M;
+    for (int64_t r0 = row_begin + 16 * wave; r0 < row_end; r0 += 16 * WG_WAVES) {
+        float gv[4][TCO], yv[4][TCO], bv[4][TCI];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = r0 + 4 * u + kk;
+            const bool rv = r < row_end;
+#pragma unroll
+            for (int a = 0; a < TCO; ++a) {
+                const int co = co_base + 16 * a + cc;
+                const bool ok = rv && co < Co;
+                gv[u][a] = ok ? GA[r * Co + co] : 0.f;
+                yv[u][a] = ok ? Y[r * Co + co] : cm[a];          // yh = 0 on padding
+            }
+#pragma unroll
+            for (int b = 0; b < TCI; ++b) {
+                const int ci = ci_base + 16 * b + cc;
+                bv[u][b] = (rv && ci < Ci) ? X[r * Ci + ci] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int b = 0; b < TCI; ++b) sx[b] += bv[u][b];
+#pragma unroll
+            for (int a = 0; a < TCO; ++a) {
+                const float g1 = gv[u][a] * (fmaf(ca[a], yv[u][a], cb[a]) > 0.f ? 1.f : slope);
+                const float yh = (yv[u][a] - cm[a]) * cr[a];
+                sg[a] += g1;
+                sgy[a] = fmaf(g1, yh, sgy[a]);
+#pragma unroll
+                for (int b = 0; b < TCI; ++b) {
+                    accA[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1, bv[u][b], accA[a][b], 0, 0, 0);
+                    accB[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(yh, bv[u][b], accB[a][b], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // C/D layout of 16x16x4: col = lane & 15 (j = ci), row = 4 * (lane >> 4) + reg (i = co)
+    __shared__ float s_red[WG_WAVES][TCO * TCI * 256];
+    __shared__ float s_v[WG_WAVES][(2 * TCO + TCI) * 16];
+    const int64_t pb = (int64_t)blockIdx.x;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int a = 0; a < TCO; ++a)
+#pragma unroll
+            for (int b = 0; b < TCI; ++b)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    s_red[wave][(a * TCI + b) * 256 + (4 * kk + g) * 16 + cc] = pass ? accB[a][b][g] : accA[a][b][g];
+        if (pass == 0) {
+            // per-channel sums: lanes with the same cc over the 4 k-groups
+#pragma unroll
+            for (int a = 0; a < TCO; ++a) {
+                float t1 = sg[a], t2 = sgy[a];
+                t1 += __shfl_xor(t1, 16, WAVE); t1 += __shfl_xor(t1, 32, WAVE);
+                t2 += __shfl_xor(t2, 16, WAVE); t2 += __shfl_xor(t2, 32, WAVE);
+                if (kk == 0) { s_v[wave][a * 16 + cc] = t1; s_v[wave][(TCO + a) * 16 + cc] = t2; }
+            }
+#pragma unroll
+            for (int b = 0; b < TCI; ++b) {
+                float t1 = sx[b];
+                t1 += __shfl_xor(t1, 16, WAVE); t1 += __shfl_xor(t1, 32, WAVE);
+                if (kk == 0) s_v[wave][(2 * TCO + b) * 16 + cc] = t1;
+            }
+        }
+        __syncthreads();
+        float* dst = pass ? PB : PA;
+        for (int t = threadIdx.x; t < TCO * TCI * 256; t += WG_BLOCK) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WG_WAVES; ++w) v += s_red[w][t];
+            const int tile = t >> 8, a = tile / TCI, b = tile % TCI, i = (t >> 4) & 15, j = t & 15;
+            const int co = co_base + 16 * a + i, ci = ci_base + 16 * b + j;
+            if (co < Co && ci < Ci) dst[(pb * Co + co) * Ci + ci] = v;
+        }
+    }
+    for (int t = threadIdx.x; t < (2 * TCO + TCI) * 16; t += WG_BLOCK) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WG_WAVES; ++w) v += s_v[w][t];
+        const int grp = t >> 4, c16 = t & 15;
+        if (grp < 2 * TCO) {                                   // sum g1 | sum g1 yh: slabs of ci-slab 0 only
+            const int which = grp / TCO, co = co_base + 16 * (grp % TCO) + c16;
+            if (blockIdx.z == 0 && co < Co) PG[(pb * 2 + which) * Co + co] = v;
+        } else {                                               // column sums of X: slabs of co-slab 0 only
+            const int ci = ci_base + 16 * (grp - 2 * TCO) + c16;
+            if (blockIdx.y == 0 && ci < Ci) PX[pb * Ci + ci] = v;
+        }
+    }
+}
+
+// Finalize of the pass above, ONE launch of two kinds of workgroups:
+//   blockIdx.x <  nw : 64 slots (co, ci) of dW = a [ sum A - c2 sum sx - c3 sum B ],  c2 = dbeta / M, c3 = dgamma / M
+//                      (each workgroup re-derives c2 / c3 of the one or two co rows it touches: no ordering between the
+//                      two kinds of workgroups is needed)
+//   blockIdx.x >= nw : four channels each: dgamma, dbeta and the coefficients of
+//                      gY = alpha * lrelu'(a y + b) * gA + bet * y + del   (bcoef [5][Co] = a | b | alpha | bet | del)
+constexpr int MF_BLOCK = 1024, MF_WAVES = MF_BLOCK / WAVE;
+__global__ __launch_bounds__(MF_BLOCK) void mlp_bwd_finalize_kernel(const float* __restrict__ PA, const float* __restrict__ PB,
+                                                                    const float* __restrict__ PG, const float* __restrict__ PX,
+                                                                    int nblk, const float* __restrict__ coef, int64_t M, int Co,
+                                                                    int Ci, int nw, float* __restrict__ dW,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                    float* __restrict__ bcoef) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= nw) {                               // one wavefront per channel
+        const int c = ((int)blockIdx.x - nw) * MF_WAVES + w;
+        if (c >= Co) return;
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = lane; b < nblk; b += WAVE) {
+            s1 += (double)PG[((int64_t)b * 2 + 0) * Co + c];
+            s2 += (double)PG[((int64_t)b * 2 + 1) * Co + c];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, WAVE);
+            s2 += __shfl_xor(s2, o, WAVE);
+        }
+        if (lane != 0) return;
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)s2;
+        const double a = coef[c], mu = coef[2 * Co + c], rs = coef[3 * Co + c];
+        const double c2 = s1 / (double)M, c3 = s2 / (double)M;
+        bcoef[c] = coef[c];
+        bcoef[Co + c] = coef[Co + c];
+        bcoef[2 * Co + c] = (float)a;
+        bcoef[3 * Co + c] = (float)(-a * c3 * rs);
+        bcoef[4 * Co + c] = (float)(-a * c2 + a * c3 * rs * mu);
+        return;
+    }
+    // 64 slots per workgroup; the sixteen wavefronts split the slabs (b = w, w + 16, ..), four slabs of each of the five
+    // streams in flight per lane: a 512-slab reduction is eight dependent round trips (the 256-thread form
+    // measured 16.5 us per layer, more than the pass that produced the slabs)
+    __shared__ float s_part[MF_WAVES][5][64];
+    const int nslots = Co * Ci;
+    const int slot = blockIdx.x * 64 + lane;
+    const bool ok = slot < nslots;
+    const int sl = ok ? slot : nslots - 1;
+    const int co = sl / Ci, ci = sl - co * Ci;
+    float a0 = 0.f, b0 = 0.f, x0 = 0.f, g1 = 0.f, g2 = 0.f;
+    // four slabs of each stream in flight (20 loads per lane; eight spill at the 128-register budget of a 1024-thread block)
+    const int64_t sa = (int64_t)MF_WAVES * Co * Ci, sx = (int64_t)MF_WAVES * Ci, sg = (int64_t)MF_WAVES * 2 * Co;
+    const float* pa = PA + ((int64_t)w * Co + co) * Ci + ci;
+    const float* pb = PB + ((int64_t)w * Co + co) * Ci + ci;
+    const float* px = PX + (int64_t)w * Ci + ci;
+    const float* pg = PG + (int64_t)w * 2 * Co + co;
+#pragma unroll 1
+    for (int b = w; b < nblk; b += 4 * MF_WAVES) {
+        float va[4], vb[4], vx[4], vg[4], vh[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = b + MF_WAVES * u < nblk;
+            va[u] = in ? pa[u * sa] : 0.f;
+            vb[u] = in ? pb[u * sa] : 0.f;
+            vx[u] = in ? px[u * sx] : 0.f;
+            vg[u] = in ? pg[u * sg] : 0.f;
+            vh[u] = in ? pg[u * sg + Co] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a0 += va[u]; b0 += vb[u]; x0 += vx[u]; g1 += vg[u]; g2 += vh[u]; }
+        pa += 4 * sa; pb += 4 * sa; px += 4 * sx; pg += 4 * sg;
+    }
+    s_part[w][0][lane] = a0; s_part[w][1][lane] = b0; s_part[w][2][lane] = x0;
+    s_part[w][3][lane] = g1; s_part[w][4][lane] = g2;
+    __syncthreads();
+    if (w == 0 && ok) {
+        double A = 0.0, B = 0.0, Xs = 0.0, G1 = 0.0, G2 = 0.0;
+        for (int k = 0; k < MF_WAVES; ++k) {
+            A += s_part[k][0][lane]; B += s_part[k][1][lane]; Xs += s_part[k][2][lane];
+            G1 += s_part[k][3][lane]; G2 += s_part[k][4][lane];
+        }
+        const double a = coef[co], c2 = G1 / (double)M, c3 = G2 / (double)M;
+        dW[slot] = (float)(a * (A - c2 * Xs - c3 * B));
+    }
+}
+
 // out[slot] = sum_b partial[b][slot] for 64 consecutive slots per workgroup: lanes run along the slots (256-byte
 // coalesced rows of the partial slabs), the 4 wavefronts take b = w, w + 4, ... with four loads in flight each, and
 // combine through LDS in the fixed order w = 0..3 -- bitwise reproducible, and identical between the single and the
@@ -463,13 +685,26 @@ namespace crf {
 
 constexpr int LF_BLOCK = 256;
 
-template <int TCO>  // 16 * TCO output channels per block slab (blockIdx.y picks the slab)
+// PRO: the operand is not read but formed while loading (dX of the fused MLP backward): row r, channel k of
+//   gY = alpha[k] * lrelu'(a[k] y + b[k]) * X[r][k] + bet[k] * Y2[r][k] + del[k]     (X = gA, Y2 = the Linear's output y)
+// pro = [5][Ci] floats a | b | alpha | bet | del, staged in LDS behind the weight slab (Ci % 4 == 0 required).
+template <int TCO, bool PRO = false>  // 16 * TCO output channels per block slab (blockIdx.y picks the slab)
 __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                               const float* __restrict__ bias, int64_t M, int Ci, int Co,
                                                               int transpose_w, float* __restrict__ Y,
-                                                              float* __restrict__ stat_partial /*[nblk][Co][4] or null*/) {
-    extern __shared__ float sW[];                 // [16*TCO][Cip]
+                                                              float* __restrict__ stat_partial /*[nblk][Co][4] or null*/,
+                                                              const float* __restrict__ Y2 = nullptr,
+                                                              const float* __restrict__ pro = nullptr, float slope = 1.f) {
+    extern __shared__ float sW[];                 // [16*TCO][Cip] (+ [5][Cik] prologue coefficients)
     const int Cip = ((Ci + 15) / 16) * 16 + 4;
+    const int Cik = ((Ci + 15) / 16) * 16;
+    float* sPro = sW + 16 * TCO * Cip;
+    if constexpr (PRO) {
+        for (int t = threadIdx.x; t < 5 * Cik; t += LF_BLOCK) {
+            const int which = t / Cik, k = t - which * Cik;
+            sPro[t] = k < Ci ? pro[which * Ci + k] : 0.f;
+        }
+    }
     const int co_base = blockIdx.y * 16 * TCO;
     if (!transpose_w && (Ci % 4) == 0) {          // rows of W are contiguous: 16-byte loads
         const int Cip4 = Cip / 4, Ci4 = Ci / 4;
@@ -519,7 +754,19 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
         for (int c = 0; c < nchunk; ++c) {
             const int k0 = 16 * c + 4 * g;
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rv) {
+            if constexpr (PRO) {
+                if (rv && k0 < Ci) {
+                    const float4 gv = *reinterpret_cast<const float4*>(X + r * Ci + k0);
+                    const float4 yv = *reinterpret_cast<const float4*>(Y2 + r * Ci + k0);
+                    const float4 pa = *reinterpret_cast<const float4*>(sPro + k0), pb = *reinterpret_cast<const float4*>(sPro + Cik + k0);
+                    const float4 al = *reinterpret_cast<const float4*>(sPro + 2 * Cik + k0), be = *reinterpret_cast<const float4*>(sPro + 3 * Cik + k0);
+                    const float4 de = *reinterpret_cast<const float4*>(sPro + 4 * Cik + k0);
+                    xv.x = fmaf(al.x * (fmaf(pa.x, yv.x, pb.x) > 0.f ? 1.f : slope), gv.x, fmaf(be.x, yv.x, de.x));
+                    xv.y = fmaf(al.y * (fmaf(pa.y, yv.y, pb.y) > 0.f ? 1.f : slope), gv.y, fmaf(be.y, yv.y, de.y));
+                    xv.z = fmaf(al.z * (fmaf(pa.z, yv.z, pb.z) > 0.f ? 1.f : slope), gv.z, fmaf(be.z, yv.z, de.z));
+                    xv.w = fmaf(al.w * (fmaf(pa.w, yv.w, pb.w) > 0.f ? 1.f : slope), gv.w, fmaf(be.w, yv.w, de.w));
+                }
+            } else if (rv) {
                 if (vec) {
                     if (k0 < Ci) xv = *reinterpret_cast<const float4*>(X + r * Ci + k0);
                 } else {
@@ -743,5 +990,113 @@ extern "C" int crfconv_bn_coef_from_records(const float* stat_rec, int64_t M, in
     hipLaunchKernelGGL(crf::bn_finalize_records_kernel, dim3((C + crf::FR_CH - 1) / crf::FR_CH), dim3(crf::FR_BLOCK), 0, crf::as_stream(stream), stat_rec, nrec,
                        M, C, gamma, beta, eps, run_mean, run_var, momentum, coef);
     CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+// ---------------------------------------------------------------------- fused backward of Linear -> BatchNorm -> LeakyReLU
+namespace crf {
+struct MlpPlan {
+    int tco, tci, gy, gz, nblk, rows_per_block;
+};
+static MlpPlan mlp_plan(int64_t M, int Co, int Ci) {
+    MlpPlan p;
+    const int t_co = (Co + 15) / 16, t_ci = (Ci + 15) / 16;
+    p.tco = t_co >= 4 ? 4 : (t_co >= 2 ? 2 : 1);
+    p.tci = t_ci >= 4 ? 4 : (t_ci >= 2 ? 2 : 1);
+    if (p.tco * p.tci == 16) p.tci = 2;              // two accumulator sets: at most 8 tiles (64 registers) each
+    p.gy = (t_co + p.tco - 1) / p.tco;
+    p.gz = (t_ci + p.tci - 1) / p.tci;
+    int64_t slices = 512 / ((int64_t)p.gy * p.gz);
+    if (slices < 32) slices = 32;
+    int64_t rows = (M + slices - 1) / slices;
+    if (rows < 64) rows = 64;
+    rows = (rows + 63) / 64 * 64;
+    p.rows_per_block = (int)rows;
+    p.nblk = (int)((M + rows - 1) / rows);
+    return p;
+}
+static size_t mlp_ws_layout(int64_t M, int Co, int Ci, size_t off[5]) {
+    const MlpPlan p = mlp_plan(M, Co, Ci);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t o = 0;
+    off[0] = o; o = up(o + sizeof(float) * (size_t)p.nblk * Co * Ci);      // PA
+    off[1] = o; o = up(o + sizeof(float) * (size_t)p.nblk * Co * Ci);      // PB
+    off[2] = o; o = up(o + sizeof(float) * (size_t)p.nblk * 2 * Co);       // PG
+    off[3] = o; o = up(o + sizeof(float) * (size_t)p.nblk * Ci);           // PX
+    off[4] = o; o = up(o + sizeof(float) * 5 * (size_t)Co);                // prologue coefficients
+    return o;
+}
+}  // namespace crf
+
+extern "C" int crfconv_mlp_backward_supported(int64_t M, int Ci, int Co) {
+    if (!(M > 0 && Co % 4 == 0 && Ci >= 1 && Co >= 4 && Co <= 1024 && Ci <= 1024)) return 0;
+    // dX runs on linear_fwd_kernel<., true> with k = Co: weight slab (<= 128 output rows) + 5 coefficient rows in 64 KB
+    const int cip = ((Co + 15) / 16) * 16 + 4, cik = ((Co + 15) / 16) * 16;
+    const int rows = Ci < 128 ? ((Ci + 15) / 16) * 16 : 128;
+    return sizeof(float) * ((size_t)rows * cip + 5 * (size_t)cik) <= 64 * 1024 ? 1 : 0;
+}
+
+extern "C" size_t crfconv_mlp_backward_workspace(int64_t M, int Ci, int Co) {
+    if (M <= 0 || Co <= 0 || Ci <= 0) return 0;
+    size_t off[5];
+    return crf::mlp_ws_layout(M, Co, Ci, off) + 256;
+}
+
+extern "C" int crfconv_mlp_backward(const float* gA, const float* Y, const float* X, const float* W, const float* coef,
+                                    float slope, int64_t M, int Ci, int Co, float* dX, float* dW, float* dgamma,
+                                    float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream) {
+    CRF_REQUIRE(gA && Y && X && W && coef && dW && dgamma && dbeta && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(crfconv_mlp_backward_supported(M, Ci, Co) == 1, CRF_ERR_UNSUPPORTED, "shape M=%lld Ci=%d Co=%d not supported",
+                (long long)M, Ci, Co);
+    CRF_REQUIRE(workspace_bytes >= crfconv_mlp_backward_workspace(M, Ci, Co), CRF_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = crf::as_stream(stream);
+    char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    size_t off[5];
+    crf::mlp_ws_layout(M, Co, Ci, off);
+    float* PA = reinterpret_cast<float*>(base + off[0]);
+    float* PB = reinterpret_cast<float*>(base + off[1]);
+    float* PG = reinterpret_cast<float*>(base + off[2]);
+    float* PX = reinterpret_cast<float*>(base + off[3]);
+    float* pro = reinterpret_cast<float*>(base + off[4]);
+    const crf::MlpPlan p = crf::mlp_plan(M, Co, Ci);
+    {
+        const dim3 grid((unsigned)p.nblk, (unsigned)p.gy, (unsigned)p.gz), blk(crf::WG_BLOCK);
+#define P1(TA, TB) hipLaunchKernelGGL((crf::mlp_bwd_p1_kernel<TA, TB>), grid, blk, 0, st, gA, Y, X, coef, slope, M, Co, Ci, p.rows_per_block, PA, PB, PG, PX)
+        switch (p.tco * 10 + p.tci) {
+            case 11: P1(1, 1); break;
+            case 12: P1(1, 2); break;
+            case 14: P1(1, 4); break;
+            case 21: P1(2, 1); break;
+            case 22: P1(2, 2); break;
+            case 24: P1(2, 4); break;
+            case 41: P1(4, 1); break;
+            default: P1(4, 2); break;
+        }
+#undef P1
+        CRF_LAUNCH_CHECK();
+    }
+    const int nw = (int)crf::cdiv((int64_t)Co * Ci, 64);
+    hipLaunchKernelGGL(crf::mlp_bwd_finalize_kernel, dim3((unsigned)(nw + (Co + crf::MF_WAVES - 1) / crf::MF_WAVES)), dim3(crf::MF_BLOCK), 0, st, PA, PB, PG, PX,
+                       p.nblk, coef, M, Co, Ci, nw, dW, dgamma, dbeta, pro);
+    CRF_LAUNCH_CHECK();
+    if (dX != nullptr) {
+        // dX [M, Ci] = gY [M, Co] W [Co, Ci]: the forward kernel with k = Co, outputs = Ci, W read transposed
+        const int gCi = Co, gCo = Ci;
+        const int cip = ((gCi + 15) / 16) * 16 + 4, cik = ((gCi + 15) / 16) * 16;
+        const int tiles = (gCo + 15) / 16;
+        const int tco = tiles >= 8 ? 8 : (tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1));
+        const int gy = (tiles + tco - 1) / tco;
+        const dim3 grid((unsigned)crf::lf_blocks(M), (unsigned)gy), blk(crf::LF_BLOCK);
+        const size_t lds = sizeof(float) * ((size_t)16 * tco * cip + 5 * (size_t)cik);
+#define DX(T) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, true>), grid, blk, lds, st, gA, W, (const float*)nullptr, M, gCi, gCo, 1, dX, (float*)nullptr, Y, pro, slope)
+        switch (tco) {
+            case 1: DX(1); break;
+            case 2: DX(2); break;
+            case 4: DX(4); break;
+            default: DX(8); break;
+        }
+#undef DX
+        CRF_LAUNCH_CHECK();
+    }
     return CRF_OK;
 }

@@ -43,6 +43,9 @@ class MLP(nn.Module):
                    and self.bn.batch_norm.affine
                    and (self.activation is None or isinstance(self.activation, nn.LeakyReLU)))
         if fusable:      # Linear (MFMA, BatchNorm statistics in its epilogue) -> BatchNorm + LeakyReLU in one pass
+            slope = 1.0 if self.activation is None else self.activation.negative_slope
+            if ops.mlp_block_ok(x, self.lin.weight, self.lin.bias, self.bn.batch_norm, self.training):
+                return ops.mlp_block(x, self.lin.weight, self.bn.batch_norm, slope)      # one autograd node, fused backward
             records = None
             if self.training:
                 x, records = ops.linear(x, self.lin.weight, self.lin.bias, want_stats=True)

@@ -597,6 +597,71 @@ def bn_act(x, bn, training, slope=1.0, records=None):
     return y.reshape(shape)
 
 
+# ------------------------------------------------------------------------------ Linear -> BatchNorm -> LeakyReLU as one op
+_UNFUSED_MLP_ENV = __import__('os').environ.get('CRFCONV_UNFUSED_MLP') is not None      # A/B: separate Linear / BatchNorm ops
+
+
+class _MLPBlock(torch.autograd.Function):
+    """A = lrelu(BN_train(x W^T), slope) (models/common.py:34-40).  Forward: the MFMA Linear with statistic records in its
+    epilogue, coefficients, one fused apply pass.  Backward: crfconv_mlp_backward -- one pass over (gA, y, x) for dgamma,
+    dbeta, dW, one pass over (gA, y) for dX; the BatchNorm input gradient never reaches memory."""
+
+    @staticmethod
+    def forward(ctx, x, W, gamma, beta, run_mean, run_var, momentum, eps, slope):
+        x = x.contiguous()
+        Wc = W.contiguous()
+        m, ci = x.shape
+        co = Wc.shape[0]
+        y, rec = _mfma_matmul(x, Wc, None, False, True)
+        coef = torch.empty(4 * co, dtype=torch.float32, device=x.device)
+        g, b = _f32c(gamma), _f32c(beta)
+        _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
+                  float(momentum), float(eps), ptr(coef), stream_ptr())
+        out = torch.empty_like(y)
+        _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), stream_ptr())
+        ctx.save_for_backward(x, Wc, y, coef)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, gA):
+        x, W, y, coef = ctx.saved_tensors
+        m, ci = x.shape
+        co = W.shape[0]
+        gA = gA.contiguous()
+        dev = x.device
+        dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(dW),
+                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
+        return dX, dW, dgamma, dbeta, None, None, None, None, None
+
+
+def mlp_block_ok(x, W, bias, bn, training):
+    """The fused block applies to the training-mode MLPs of the fine levels (MFMA-sized rows, affine BatchNorm, no bias)."""
+    if _UNFUSED_MLP_ENV or not training or bias is not None or x.dtype != torch.float32 or not bn.affine:
+        return False
+    m = x.numel() // x.shape[-1]
+    ci, co = x.shape[-1], W.shape[0]
+    return (_mfma_ok(m, ci, co) and co % 4 == 0 and bn.running_mean is not None
+            and _lib.load().crfconv_mlp_backward_supported(m, ci, co) == 1)
+
+
+def mlp_block(x, W, bn, slope=1.0):
+    """lrelu(BatchNorm_train(x W^T), slope) on [..., Ci] rows; `bn`: the torch.nn.BatchNorm1d with the parameters."""
+    require_gpu(x, W)
+    shape = x.shape
+    tick(bn)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    out = _MLPBlock.apply(x.reshape(-1, shape[-1]), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps,
+                          slope)
+    return out.reshape(shape[:-1] + (W.shape[0],))
+
+
 # ------------------------------------------------------------------------------ residual join
 class _AddLRelu(torch.autograd.Function):
     @staticmethod

@@ -326,6 +326,20 @@ int crfconv_linear_wgrad_partial(const float* G, const float* X, int64_t M, int 
                                  void* workspace, size_t workspace_bytes, int* nblk_out, crf_stream_t stream);
 int crfconv_reduce_jobs(const crf_reduce_job* jobs, int njobs, crf_stream_t stream);
 
+/* Backward of one MLP block  A = lrelu(BN_train(X W^T), slope)  (models/common.py:34-40, batch statistics) in two passes
+ * over the activations and three launches: pass 1 streams (gA, Y, X) once and leaves the partials of sum g1, sum g1 yh,
+ * G1^T X, Yh^T X and 1^T X (g1 = gA lrelu'(a y + b), yh = (y - mean) rstd; two MFMA accumulator sets share the X
+ * fragment); the finalize launch turns them into dgamma, dbeta, dW = diag(a) [G1^T X - (dbeta / M) 1^T X -
+ * diag(dgamma / M) Yh^T X] and the per-channel coefficients of gY; pass 2 forms gY in registers while loading (gA, Y)
+ * and writes dX = gY W (skipped when dX is NULL).  gA, Y [M, Co]; X [M, Ci]; W [Co, Ci]; coef = the [4, Co] block of
+ * crfconv_bn_forward / crfconv_bn_coef_from_records for Y.  Same results as crfconv_bn_backward ->
+ * crfconv_linear_forward(transpose) + crfconv_linear_wgrad up to summation order. */
+int crfconv_mlp_backward_supported(int64_t M, int Ci, int Co);
+size_t crfconv_mlp_backward_workspace(int64_t M, int Ci, int Co);
+int crfconv_mlp_backward(const float* gA, const float* Y, const float* X, const float* W, const float* coef, float slope,
+                         int64_t M, int Ci, int Co, float* dX, float* dW, float* dgamma, float* dbeta, void* workspace,
+                         size_t workspace_bytes, crf_stream_t stream);
+
 /* Fused BatchNorm (+ LeakyReLU) over rows x [M, C] (models/common.py:31,36-37; C % 4 == 0, C <= 1024).
  * forward:  use_batch_stats != 0 -> statistics of x (biased variance), running stats updated in place when non-NULL
  *           (momentum, unbiased variance -- torch.nn.BatchNorm1d semantics); else coefficients from running stats.

@@ -1,0 +1,19 @@
+"""One replayed training step out of a rocprofv3 kernel trace: launches, wall, per-kernel totals.
+usage: python3 scratch/step_table.py <dir> [top]"""
+import csv, re, glob, collections, sys
+f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+names = [re.sub(r"\(.*", "", r['Kernel_Name']).replace('void ', '') for r in rows]
+sg = [i for i, n in enumerate(names) if 'sgd' in n]
+a, b = sg[-2] + 1, sg[-1] + 1
+step, sn = rows[a:b], names[a:b]
+t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
+busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in step)
+print('one replayed step: %d launches, wall %.2f ms, sum of kernel durations %.2f ms' % (len(step), (t1 - t0) / 1e6, busy / 1e6))
+c = collections.Counter(sn); d = collections.defaultdict(float)
+for r, n in zip(step, sn):
+    d[n] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+for n, k in sorted(c.items(), key=lambda kv: -d[kv[0]])[:top]:
+    print('%-72s x%3d  %8.1f us total  %6.1f avg' % (n[:72], k, d[n], d[n] / k))

@@ -621,6 +621,46 @@ def test_linear_wgrad_mfma(M, Ci, Co, bias):
         assert_close(b.grad, go.double().sum(0), 2e-5, 'db')
 
 
+@pytest.mark.parametrize('M,Ci,Co,slope,need_dx', [(163840, 32, 8, 0.1, True), (163840, 6, 32, 0.1, False), (40960, 64, 16, 1.0, True),
+                                                   (163840, 32, 128, 0.1, True), (10240, 128, 32, 0.1, True), (4100, 24, 64, 0.1, True),
+                                                   (40963, 16, 64, 1.0, True), (10240, 32, 128, 1.0, True)])
+def test_mlp_block_fused_backward(M, Ci, Co, slope, need_dx):
+    """ops.mlp_block (Linear -> train-mode BatchNorm -> LeakyReLU as one node, csrc/linear.hip: mlp_bwd_p1 / finalize /
+    dX with the BatchNorm-backward prologue) against float64 torch.  As in test_fused_batchnorm_lrelu the LeakyReLU
+    branch of elements within rounding of 0 is taken from the kernel's own output."""
+    from crfconv_amd import ops
+    g = torch.Generator().manual_seed(M + Ci + Co)
+    x = (torch.randn(M, Ci, generator=g) + 0.5).to(DEV).requires_grad_(need_dx)
+    W = (torch.randn(Co, Ci, generator=g) / np.sqrt(Ci)).to(DEV).requires_grad_(True)
+    go = torch.randn(M, Co, generator=g).to(DEV)
+    bn = torch.nn.BatchNorm1d(Co)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Co, generator=g) + 0.5); bn.bias.copy_(torch.rand(Co, generator=g) * 0.6 - 0.3)
+    bn = bn.to(DEV).train()
+    assert ops.mlp_block_ok(x, W, None, bn, True)
+    out = ops.mlp_block(x, W, bn, slope)
+    out.backward(go)
+    ref = torch.nn.BatchNorm1d(Co).to(DEV).double().train()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in torch.nn.BatchNorm1d(Co).state_dict().items()})
+    with torch.no_grad():
+        ref.weight.copy_(bn.weight.double()); ref.bias.copy_(bn.bias.double())
+    xr = x.detach().double().requires_grad_(True)
+    Wr = W.detach().double().requires_grad_(True)
+    pre = ref(xr @ Wr.t())
+    branch = torch.where(out.detach() > 0, 1.0, slope).double()
+    yr = torch.where(out.detach() > 0, pre, slope * pre)
+    pre.backward(go.double() * branch)
+    assert_close(out, yr, 1e-5, 'out')
+    assert_close(W.grad, Wr.grad, 2e-5, 'dW')
+    assert_close(bn.weight.grad, ref.weight.grad, 2e-5, 'dgamma')
+    assert_close(bn.bias.grad, ref.bias.grad, 2e-5, 'dbeta')
+    if need_dx:
+        assert_close(x.grad, xr.grad, 2e-5, 'dx')
+    assert_close(bn.running_mean, ref.running_mean, 1e-6, 'running_mean')
+    assert_close(bn.running_var, ref.running_var, 1e-5, 'running_var')
+    assert int(bn.num_batches_tracked) == 1
+
+
 @pytest.mark.parametrize('M,C,slope,training', [(163840, 32, 0.1, True), (40960, 8, 1.0, True), (1000, 512, 0.1, True),
                                                 (777, 128, 0.1, False), (33, 1024, 1.0, True), (2560, 256, 0.1, True),
                                                 (640, 512, 1.0, True), (4096, 64, 0.1, True), (4097, 64, 0.1, True),
