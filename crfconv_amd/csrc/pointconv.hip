@@ -600,8 +600,11 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
     }
     // dA1 / db1 feed the analytic BatchNorm-1 backward on the host, where their large common
     // components cancel (scale / shift invariance): accumulate them in float64 end to end.
-    double da1[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};  // [axis][channel of the quad]
-    double db[4] = {0, 0, 0, 0};
+    // Within ONE point (the K edges of this loop) they are summed in float32 -- K terms of like magnitude, relative error
+    // ~1e-7 per point, random across points -- and only the sums over points run in float64: the float64 FMAs of the
+    // per-edge form were a third of this kernel's vector work.
+    float da1[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // [axis][channel of the quad]
+    float db[4] = {0, 0, 0, 0};
     const int base = lane - q;
 
     for (int k = 0; k < K; ++k) {
@@ -658,12 +661,12 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
         // through lrelu(0.1)
         const float4 gp = make_float4(gh1.x * (pre.x > 0.f ? 1.f : slope), gh1.y * (pre.y > 0.f ? 1.f : slope),
                                       gh1.z * (pre.z > 0.f ? 1.f : slope), gh1.w * (pre.w > 0.f ? 1.f : slope));
-        const double gpd[4] = {gp.x, gp.y, gp.z, gp.w};
-        const double rd[3] = {rx, ry, rz};
+        const float gpd[4] = {gp.x, gp.y, gp.z, gp.w};
+        const float rd[3] = {rx, ry, rz};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) da1[ax][c] = fma(rd[ax], gpd[c], da1[ax][c]);
+            for (int ax = 0; ax < 3; ++ax) da1[ax][c] = fmaf(rd[ax], gpd[c], da1[ax][c]);
             db[c] += gpd[c];
         }
     }
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
         for (int ax = 0; ax < 4; ++ax) {                       // ax == 3 -> db1
-            double t = ax < 3 ? da1[ax < 3 ? ax : 0][c] : db[c];
+            double t = (double)(ax < 3 ? da1[ax < 3 ? ax : 0][c] : db[c]);
 #pragma unroll
             for (int o = L; o < WAVE; o <<= 1) t += __shfl_xor(t, o, WAVE);
             if (lane < L) s_accd[wave][(4 * q + c) * 4 + ax] = t;

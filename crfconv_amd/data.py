@@ -55,6 +55,43 @@ class MultiScaleData(Data):
     def __init__(self, x=None, y=None, point_idx=None, cloud_idx=None, multiscale=None, **kwargs):
         super().__init__(x=x, y=y, point_idx=point_idx, cloud_idx=cloud_idx, multiscale=multiscale, **kwargs)
 
+    def load_(self, other):
+        """Copies another batch of the SAME shapes into this batch's tensors (in place) and refreshes the neighbour
+        tables / reverse CSRs / rel-pos moments derived from them into their existing buffers.  This batch's tensors
+        are thereby static buffers: a hipGraph captured on a training step over ``self`` trains on ``other`` at its
+        next replay.  (All table sizes are fixed for fixed B, N, K and ratios.)"""
+        from .graph import table_of
+
+        def copy(dst, src, what):
+            if dst is None or src is None:
+                if dst is not src:
+                    raise ValueError('load_: %s present in one batch only' % what)
+                return
+            if dst.shape != src.shape or dst.dtype != src.dtype:
+                raise ValueError('load_: %s is %s %s here, %s %s there' % (what, tuple(dst.shape), dst.dtype,
+                                                                           tuple(src.shape), src.dtype))
+            dst.copy_(src)
+        for name in ('x', 'y', 'point_idx', 'cloud_idx', 'order'):
+            a, b = getattr(self, name, None), getattr(other, name, None)
+            if torch.is_tensor(a) or torch.is_tensor(b):
+                copy(a, b, name)
+        if len(self.multiscale) != len(other.multiscale):
+            raise ValueError('load_: different number of scales')
+        for i, (mine, theirs) in enumerate(zip(self.multiscale, other.multiscale)):
+            copy(mine.pos, theirs.pos, 'multiscale[%d].pos' % i)
+        for i, (mine, theirs) in enumerate(zip(self.multiscale, other.multiscale)):
+            n_here = mine.pos.shape[1]
+            n_next = self.multiscale[i + 1].pos.shape[1] if i + 1 < len(self.multiscale) else None
+            for name, n_src in (('neighbor_idx', n_here), ('sub_idx', n_here), ('up_idx', n_next)):
+                a, b = getattr(mine, name, None), getattr(theirs, name, None)
+                if not (torch.is_tensor(a) or torch.is_tensor(b)):
+                    continue
+                copy(a, b, 'multiscale[%d].%s' % (i, name))
+                if getattr(a, '_crf_tables', None):          # a table was derived from it: same buffers, new content
+                    for key in list(a._crf_tables):
+                        table_of(a, key[0])
+        return self
+
 
 def _spread3(v):
     """Spread the low 10 bits of v so that there are two zero bits between consecutive bits."""

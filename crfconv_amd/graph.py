@@ -31,7 +31,7 @@ def require_gpu(*tensors):
 
 
 class NeighborTable:
-    __slots__ = ('idx32', 'idx16', 'B', 'n_tgt', 'n_src', 'K', '_rev', '_bad', '_checked', 'cache', 'n_edges')
+    __slots__ = ('idx32', 'idx16', 'B', 'n_tgt', 'n_src', 'K', '_rev', '_bad', '_checked', 'cache', 'n_edges', 'padded')
 
     def __init__(self, idx64, n_src, check=True):
         if idx64.dim() == 2:
@@ -55,10 +55,37 @@ class NeighborTable:
                   ptr(self.idx32), ptr(self.idx16), ptr(self._bad), stream_ptr())
         self._rev = None
         self._checked = False
+        self.padded = False      # True: entries < 0 mean "no neighbour" (table_from_edges) -> generic kernels only
         self.n_edges = self.B * self.n_tgt * self.K
         self.cache = {}          # per-table memo (e.g. rel-pos moments shared by two ResNet blocks)
         if check:
             self.validate()
+
+    def refresh_(self, idx64, check=True):
+        """New index values of the SAME shape into the SAME device buffers (narrowed table, and the reverse CSR and
+        the memoised rel-pos moments if they exist): everything a captured hipGraph holds pointers to stays valid
+        and now describes the new batch."""
+        if idx64.dim() == 2:
+            idx64 = idx64.unsqueeze(-1)
+        if tuple(idx64.shape) != (self.B, self.n_tgt, self.K):
+            raise ValueError('refresh_ needs the shape the table was built with %s, got %s'
+                             % ((self.B, self.n_tgt, self.K), tuple(idx64.shape)))
+        require_gpu(idx64)
+        if idx64.dtype != torch.int64:
+            idx64 = idx64.long()
+        idx64 = idx64.contiguous()
+        self._bad.zero_()
+        _lib.call('crfconv_index_narrow_sorted', ptr(idx64), self.B, self.n_tgt, self.K, self.n_src, 1,
+                  ptr(self.idx32), ptr(self.idx16), ptr(self._bad), stream_ptr())
+        self._checked = False
+        if self._rev is not None:
+            self._build_reverse(*self._rev)
+        for key, entry in list(self.cache.items()):
+            if callable(getattr(entry, 'refresh_', None)):
+                entry.refresh_(self)
+        if check:
+            self.validate()
+        return self
 
     def validate(self):
         """One host sync: refuses tables with out-of-range entries (they were clamped, so nothing
@@ -77,17 +104,20 @@ class NeighborTable:
     def m_src(self):
         return self.B * self.n_src
 
+    def _build_reverse(self, rev_ptr, rev_eid):
+        E = self.m_tgt * self.K
+        nbytes = _lib.load().crfconv_reverse_csr_workspace(E, self.m_src)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.idx32.device)
+        _lib.call('crfconv_reverse_csr', ptr(self.idx32), E, self.m_src, ptr(rev_ptr), ptr(rev_eid),
+                  ptr(ws), nbytes, stream_ptr())
+
     @property
     def reverse(self):
         if self._rev is None:
-            E = self.m_tgt * self.K
             dev = self.idx32.device
             rev_ptr = torch.empty(self.m_src + 1, dtype=torch.int32, device=dev)
-            rev_eid = torch.empty(E, dtype=torch.int32, device=dev)
-            nbytes = _lib.load().crfconv_reverse_csr_workspace(E, self.m_src)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            _lib.call('crfconv_reverse_csr', ptr(self.idx32), E, self.m_src, ptr(rev_ptr), ptr(rev_eid),
-                      ptr(ws), nbytes, stream_ptr())
+            rev_eid = torch.empty(self.m_tgt * self.K, dtype=torch.int32, device=dev)
+            self._build_reverse(rev_ptr, rev_eid)
             self._rev = (rev_ptr, rev_eid)
         return self._rev
 
@@ -106,6 +136,7 @@ def table_from_edges(tgt, src, n_tgt, n_src, max_degree=64):
     tab = NeighborTable.__new__(NeighborTable)
     tab.B, tab.n_tgt, tab.n_src = 1, int(n_tgt), int(n_src)
     tab._rev, tab._checked, tab.cache, tab.idx16 = None, True, {}, None
+    tab.padded = True                     # -1 entries: the fast row kernels (no j < 0 test) must not see this table
     tab._bad = torch.zeros(1, dtype=torch.int32, device=dev)
     if E == 0:
         tab.K, tab.n_edges = 1, 0
@@ -129,7 +160,9 @@ def table_from_edges(tgt, src, n_tgt, n_src, max_degree=64):
 
 def table_of(idx, n_src):
     """Table for an index tensor, memoised on the tensor object (a batch's neighbor_idx is used by
-    two ResNet blocks and one CRF layer; sub_idx by the strided conv and its max-pool)."""
+    two ResNet blocks and one CRF layer; sub_idx by the strided conv and its max-pool).  When the tensor was written
+    in place since (a new batch copied into static buffers, ``_version`` changed) the existing table is REFRESHED in
+    place -- same device buffers, so pointers recorded in a captured graph stay valid -- instead of replaced."""
     if isinstance(idx, NeighborTable):
         return idx
     cache = getattr(idx, '_crf_tables', None)
@@ -139,10 +172,14 @@ def table_of(idx, n_src):
             idx._crf_tables = cache
         except AttributeError:
             pass
-    key = (int(n_src), idx.data_ptr(), idx._version, tuple(idx.shape))
-    tab = cache.get(key)
-    if tab is None:
+    key = (int(n_src), idx.data_ptr(), tuple(idx.shape))
+    hit = cache.get(key)
+    if hit is None:
         tab = NeighborTable(idx, n_src)
         cache.clear()
-        cache[key] = tab
-    return tab
+        cache[key] = [tab, idx._version]
+        return tab
+    if hit[1] != idx._version:
+        hit[0].refresh_(idx)
+        hit[1] = idx._version
+    return hit[0]

@@ -35,10 +35,19 @@ class PointConv(nn.Module):
         self.weight_nn = nn.Sequential(MLP(3, d_model, activation=_lrelu()), MLP(d_model, d_model, activation=None))
 
     def _moments(self, table, p_src, p_tgt):
-        key = ('moments', p_src.data_ptr(), p_tgt.data_ptr())
-        if key not in table.cache:
-            table.cache[key] = ops.relpos_moments(p_src.float().contiguous(), p_tgt.float().contiguous(), table)
-        return table.cache[key]
+        """BatchNorm-1 statistics of rel = p_tgt[i] - p_src[j] (analytic in the moments), memoised per table: the two
+        ResNet blocks of a level share them.  Positions edited in place since (jitter, a new batch in static buffers)
+        are noticed through the tensors' version counters and the entry is recomputed into the same tensors."""
+        key = ('moments', p_src.data_ptr(), p_tgt.data_ptr(), tuple(p_src.shape), tuple(p_tgt.shape))
+        entry = table.cache.get(key)
+        if entry is None:
+            ps, pt = p_src.float().contiguous(), p_tgt.float().contiguous()
+            keep_s = p_src if ps.data_ptr() == p_src.data_ptr() else ps      # version tracking needs the caller's tensor
+            keep_t = p_tgt if pt.data_ptr() == p_tgt.data_ptr() else pt
+            entry = table.cache[key] = ops.MomentsEntry(ops.relpos_moments(ps, pt, table), keep_s, keep_t)
+        elif entry.stale():
+            entry.refresh_(table)
+        return entry
 
     def forward(self, x, pos, neighbor_idx):
         strided = not torch.is_tensor(pos)

@@ -40,6 +40,11 @@ class _MeanField(torch.autograd.Function):
     def forward(ctx, z, y, Q, P, table, k0, steps):
         require_gpu(z, y, Q, P)
         m, H = z.shape
+        if m != table.m_tgt or y.shape[0] != m or table.m_src != m:
+            raise _lib.CrfConvError('mean field: %d / %d rows for a table of %d targets over %d sources (the CRF graph '
+                                    'lives on one point set)' % (m, y.shape[0], table.m_tgt, table.m_src))
+        if table.padded and k0 != 0:
+            raise _lib.CrfConvError('a padded (variable-degree) table has no self column: use k0 = 0')
         z, y, Q, P = _f32c(z), _f32c(y), _f32c(Q), _f32c(P)
         needs_grad = any(ctx.needs_input_grad[:4])
         # inference with one step: the similarity weights are consumed inside the fused first kernel and never
@@ -406,7 +411,7 @@ def _flush_weight_grads():
 
 
 # ------------------------------------------------------------------------------ per-point Linear
-_MFMA_MIN_ROWS = 4096       # below this the vendor GEMM's fixed cost is as good
+_MFMA_MIN_ROWS = int(__import__('os').environ.get('CRFCONV_MFMA_MIN_ROWS', 4096))       # below this the vendor GEMM's fixed cost is as good
 
 
 _VENDOR_ONLY = bool(__import__('os').environ.get('CRFCONV_VENDOR_GEMM'))     # A/B switch: forward / dX on rocBLAS
@@ -810,6 +815,28 @@ def training_loss(logits, labels, class_weights=None, ignore_index=-1):
 
 
 # ------------------------------------------------------------------------------ PointConv
+class MomentsEntry(tuple):
+    """relpos_moments(...) as a tuple plus the inputs it came from: ``refresh_`` recomputes it INTO the same tensors
+    (NeighborTable.refresh_ and the version check of PointConv._moments call it), so kernels launched from a captured
+    graph read the statistics of the batch that is in the buffers now."""
+
+    def __new__(cls, values, pos_src, pos_tgt):
+        obj = super().__new__(cls, values)
+        obj.pos_src, obj.pos_tgt = pos_src, pos_tgt
+        obj.versions = (pos_src._version, pos_tgt._version)
+        return obj
+
+    def refresh_(self, table):
+        fresh = relpos_moments(self.pos_src, self.pos_tgt, table)
+        for old, new in zip(self, fresh):
+            if torch.is_tensor(old):
+                old.copy_(new)
+        self.versions = (self.pos_src._version, self.pos_tgt._version)
+
+    def stale(self):
+        return self.versions != (self.pos_src._version, self.pos_tgt._version)
+
+
 def relpos_moments(pos_src, pos_tgt, table):
     """(mean [3], covariance [3,3], edge count, packed float64 [12], mean float32 [3]) of rel = p_tgt[i] - p_src[j]
     over all edges."""
@@ -841,6 +868,9 @@ class _PointConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W1, g1, be1, W2, g2, be2, pos_src, pos_tgt, table, mom, bn1_state, bn2_state, slope, mom32=None):
         require_gpu(x, W1, W2, pos_src, pos_tgt)
+        if x.shape[0] != table.m_src or pos_src.shape[0] != table.m_src or pos_tgt.shape[0] != table.m_tgt:
+            raise _lib.CrfConvError('point_conv: x %d / pos_src %d rows for %d sources, pos_tgt %d rows for %d targets'
+                                    % (x.shape[0], pos_src.shape[0], table.m_src, pos_tgt.shape[0], table.m_tgt))
         dev = x.device
         x, W1c, W2c = _f32c(x), _f32c(W1), _f32c(W2)
         g1c, be1c, g2c, be2c = _f32c(g1), _f32c(be1), _f32c(g2), _f32c(be2)

@@ -325,6 +325,56 @@ def test_b1_is_supported():
     assert_close(one, two[:4096], OUT_TOL, 'B=1 vs B=2')
 
 
+def test_static_batch_load_refreshes_tables_reverse_csr_and_moments():
+    """MultiScaleData.load_: a second batch copied into the first batch's tensors must give exactly what that batch
+    gives when collated on its own -- logits, loss and every gradient -- although the neighbour tables, reverse CSRs and
+    rel-pos moments of the first batch already exist (they are refreshed into the same buffers, which is what lets a
+    captured hipGraph of the step be replayed on fresh batches).  Also the in-place edit of `pos` alone (jitter) must
+    be noticed by the memoised BatchNorm-1 moments (version counters), not silently ignored."""
+    import crfconv_amd
+    from crfconv_amd import models, ops
+    B, N = 2, 4096
+
+    def collate(seed):
+        pos = np.stack([S.make_cloud(seed + b, N, box=(2, 2, 1)) for b in range(B)])
+        feats = np.concatenate([pos, S.uniform(seed, 'rgb', (B, N, 3), 0, 1)], -1)
+        labels = S.integers(seed, 'y', (B, N), 0, 14)
+        g = torch.Generator().manual_seed(seed)
+        return crfconv_amd.multiscale_compute(t(pos), x=t(feats), y=t(labels), generator=g)
+
+    net = models.PointConvBig(6, 13, True, 3)
+    net.load_state_dict(S.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 4))
+    net = net.to(DEV).train()
+    net.classifier[1] = nn.Identity()
+
+    def run(data):
+        for p in net.parameters():
+            p.grad = None
+        for mod in net.modules():                       # same BatchNorm running state for every run
+            if isinstance(mod, nn.BatchNorm1d):
+                mod.reset_running_stats()
+        logits = net(data)
+        loss = ops.training_loss(logits, data.y, None, ignore_index=-1)
+        loss.backward()
+        return logits.detach().clone(), float(loss.detach()), {k: v.clone() for k, v in grads(net).items()}
+
+    a = collate(100)
+    run(a)                                              # tables, reverse CSRs, moments of batch A now exist
+    ref_logits, ref_loss, ref_grads = run(collate(200))
+    a.load_(collate(200))
+    got_logits, got_loss, got_grads = run(a)
+    assert torch.equal(got_logits, ref_logits) and got_loss == ref_loss
+    for k in ref_grads:      # (dW2 of a PointConv sums wavefront partials with LDS float atomics: last-bit order effects)
+        assert_close(got_grads[k], ref_grads[k], 1e-6, k)
+    # positions edited in place: the next forward must see them (it does not equal the stale result)
+    a.multiscale[0].pos.mul_(1.5)
+    moved_logits, _, _ = run(a)
+    b = collate(200)
+    b.multiscale[0].pos.mul_(1.5)
+    fresh_logits, _, _ = run(b)
+    assert torch.equal(moved_logits, fresh_logits) and not torch.equal(moved_logits, ref_logits)
+
+
 # ------------------------------------------------------------------ full-size properties (config 2)
 def test_meanfield_properties_full_size():
     from crfconv_amd import ops
