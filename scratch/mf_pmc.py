@@ -1,0 +1,21 @@
+"""Level-0 mean-field forward + backward, 5 calls each (for the rocprofv3 --pmc passes of scratch/pmc.sh)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
+from crfconv_amd import ops
+from crfconv_amd.graph import table_of
+dev = torch.device('cuda', 0)
+gen = torch.Generator().manual_seed(1234)
+data, _ = bench.make_batch(0, 4, 40960, dev, gen, 'morton')
+tab = table_of(data.multiscale[0].neighbor_idx, 40960); tab.reverse
+g = torch.Generator().manual_seed(1)
+m, H, T = 4 * 40960, 8, 3
+z = torch.randn(m, H, generator=g).to(dev).requires_grad_()
+y = (0.5 * torch.randn(m, H, generator=g)).to(dev).requires_grad_()
+c = (torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)).to(dev).requires_grad_()
+gout = torch.randn(m, H, generator=g).to(dev)
+for it in range(5):
+    for t in (z, y, c): t.grad = None
+    ops.crf_meanfield(z, y, c, tab, T).backward(gout)
+torch.cuda.synchronize()
+print('done')

@@ -1,0 +1,152 @@
+"""-m gpu: the batch-sharded training step on more than one rank.  No multi-GPU box is available to these tests, so
+two ranks SHARE the one GPU and talk over gloo (CRFCONV_DIST_BACKEND=gloo, the documented test path of
+distributed.init_from_env); the code under test -- FlatGradAllReduce.pack / allreduce_mean, FlatSGD -- is the code
+bench.py runs over RCCL."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import _seeded as S
+from gpu_util import DEV, assert_close, t
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests', 'golden'))
+import numpy as np, torch
+import _seeded as S
+import crfconv_amd
+from crfconv_amd import distributed as D, models, ops, optim
+rank, world, local = D.init_from_env()
+dev = torch.device('cuda', local)
+torch.cuda.set_device(dev)
+B, N = 2, 2048
+pos = np.stack([S.make_cloud(300 + b, N, box=(2, 2, 1)) for b in range(B)])
+feats = np.concatenate([pos, S.uniform(300, 'rgb', (B, N, 3), 0, 1)], -1).astype(np.float32)
+labels = S.integers(300, 'y', (B, N), 1, 14)
+choices, n = [], N
+for i, r in enumerate((4, 4, 4, 2, 2)):
+    choices.append(torch.from_numpy(S.permutation(300, 'c%%d' %% i, n)[: n // r]))
+    n //= r
+def batch(sl):
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev)
+    return crfconv_amd.multiscale_compute(f(pos), x=f(feats), y=f(labels), choices=choices, ratio=(4, 4, 4, 2, 2))
+torch.manual_seed(11)                          # the constructor's own initialisation (what training starts from), same on
+net = models.PointConvBig(6, 13, True, 3)      # both ranks; a random-GAIN state dict makes the CRF soft-max so sensitive
+net = net.to(dev).eval()                       # that vendor-GEMM rounding at the 16-row level moves gradients by percents
+# eval mode = running-statistics BatchNorm: shards and the big batch see the same network
+def grads_of(data):
+    for p in net.parameters():
+        p.grad = None
+    loss = ops.training_loss(net(data), data.y, None, ignore_index=-1)
+    loss.backward()
+    return loss
+# reference: the un-sharded batch on this rank
+grads_of(batch(slice(0, B)))
+ref = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.requires_grad]).clone()
+# sharded: one cloud per rank, ONE flat all-reduce, then the SGD step on the flat vectors
+bucket = D.FlatGradAllReduce(net)
+opt = optim.FlatSGD(bucket, lr=0.01, momentum=0.9, weight_decay=1e-4)
+before = opt.flat.clone()
+opt.zero_grad()
+grads_of(batch(slice(rank, rank + 1)))
+bucket.allreduce_mean()
+opt.step()
+torch.cuda.synchronize()
+torch.save({'flat': bucket.flat.cpu(), 'ref': ref.cpu(), 'before': before.cpu(), 'after': opt.flat.cpu()}, os.environ['OUT'] + '.%%d' %% rank)
+D.dist.barrier()
+D.dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_sharing_the_gpu_match_the_big_batch(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % (ROOT, ROOT))
+    env = dict(os.environ, OUT=str(tmp_path / 'g'), MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', WORLD_SIZE='2',
+               CRFCONV_DIST_BACKEND='gloo', OMP_NUM_THREADS='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r0, r1 = (torch.load(str(tmp_path / ('g.%d' % r))) for r in range(2))
+    assert torch.equal(r0['flat'], r1['flat'])                                 # replicas hold identical averaged gradients
+    scale = max(1.0, float(r0['ref'].abs().max()))
+    assert float((r0['flat'] - r0['ref']).abs().max()) <= 1e-4 * scale          # == gradient of the un-sharded batch
+    assert torch.equal(r0['after'], r1['after'])                               # and take the same SGD step
+    want = r0['before'] - 0.01 * (r0['flat'] + 1e-4 * r0['before'])            # first step: buf = g + wd p
+    assert float((r0['after'] - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))
+
+
+def test_single_rank_documented_step_moves_the_parameters():
+    """INTEGRATION.md's loop  zero_grad -> backward -> allreduce_mean -> step  on ONE rank (no process group): the
+    gradients must reach the flat bucket and the parameters must move by -lr * grad (round-1 ADVICE: allreduce_mean used
+    to return early at world size 1 and the step then saw zeros)."""
+    from crfconv_amd import optim
+    from crfconv_amd.distributed import FlatGradAllReduce
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 9), torch.nn.Linear(9, 3)).to(DEV)
+    bucket = FlatGradAllReduce(net)
+    opt = optim.FlatSGD(bucket, lr=0.1)
+    x = torch.randn(16, 5, device=DEV)
+    before = opt.flat.clone()
+    opt.zero_grad()
+    net(x).square().mean().backward()
+    g = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+    assert float(g.abs().max()) > 0
+    bucket.allreduce_mean()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+    opt.step()
+    assert_close(opt.flat, before - 0.1 * g, 1e-6, 'p - lr g')
+
+
+def test_flat_sgd_follows_exponential_lr_scheduler_eager_and_captured():
+    """trainval.py:69-73: SGD wrapped by ExponentialLR.  FlatSGD is a torch.optim.Optimizer (param_groups / lr), the
+    scheduler drives it, and a CAPTURED step honours the new rate after push_hyper() because the kernel reads the
+    hyper-parameters from device memory."""
+    from crfconv_amd import optim
+    from crfconv_amd.distributed import FlatGradAllReduce
+    torch.manual_seed(2)
+    net = torch.nn.Linear(6, 4).to(DEV)
+    ref = torch.nn.Linear(6, 4).to(DEV)
+    ref.load_state_dict(net.state_dict())
+    bucket = FlatGradAllReduce(net)
+    opt = optim.FlatSGD(bucket, lr=0.05, momentum=0.9, weight_decay=1e-3)
+    assert isinstance(opt, torch.optim.Optimizer)
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3)
+    sch, rsch = (torch.optim.lr_scheduler.ExponentialLR(o, gamma=0.5) for o in (opt, ropt))
+    graph = None
+    for step in range(5):
+        grads = [t(S.uniform(step, 'h%d' % i, tuple(p.shape))) for i, p in enumerate(ref.parameters())]
+        for p, v, g in zip(ref.parameters(), bucket.views, grads):
+            p.grad = g.clone()
+            v.copy_(g)
+        if step < 2:
+            opt.step()
+        else:
+            if graph is None:                                 # capture ONE step; the following ones are replays
+                snap, msnap = opt.flat.clone(), opt.buf.clone()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    opt.step()
+                torch.cuda.current_stream().wait_stream(side)
+                with torch.no_grad():
+                    opt.flat.copy_(snap); opt.buf.copy_(msnap)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    opt.step()
+                with torch.no_grad():
+                    opt.flat.copy_(snap); opt.buf.copy_(msnap)
+            graph.replay()
+        ropt.step()
+        sch.step(); rsch.step()
+        opt.push_hyper()
+        assert abs(opt.lr - ropt.param_groups[0]['lr']) < 1e-12
+        for a, b in zip(net.parameters(), ref.parameters()):
+            assert_close(a, b, 1e-6, 'step %d' % step)
