@@ -112,14 +112,37 @@ def morton_order(pos):
     return torch.argsort(code, dim=1, stable=True)
 
 
+def _fps_choice(pos, n_sample):
+    """[B, n_sample] per-cloud farthest-point picks in pick order, first pick = point 0 -- what the reference's
+    ``tpcuda.furthest_point_sampling(pos, n)`` returns (datasets/semantic3d_dataset.py:520) -- on csrc/knn.hip: fps_kernel
+    (one workgroup per cloud; ties -> lower index)."""
+    from . import _lib
+    from .graph import ptr, stream_ptr
+    B, N, _ = pos.shape
+    dev = pos.device
+    ar = torch.arange(B, dtype=torch.int64, device=dev)
+    starts, cnt = ar * N, torch.full((B,), N, dtype=torch.int64, device=dev)
+    ostart, npick = ar * n_sample, torch.full((B,), n_sample, dtype=torch.int64, device=dev)
+    first = torch.zeros(B, dtype=torch.int64, device=dev)
+    p = pos.detach().to(torch.float32).contiguous().reshape(B * N, 3)
+    out = torch.empty(B * n_sample, dtype=torch.int64, device=dev)
+    ws = torch.empty(B * N, dtype=torch.float32, device=dev)
+    _lib.call('crfconv_fps', ptr(p), B, ptr(starts), ptr(cnt), ptr(ostart), ptr(npick), ptr(first), ptr(ws), ptr(out),
+              stream_ptr())
+    return out.reshape(B, n_sample) - starts[:, None]          # the kernel reports global rows
+
+
 def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kernel_size=(16, 16, 16, 16, 16),
-                       ratio=(4, 4, 4, 4, 2), num_scales=5, generator=None, choices=None, sort=None):
+                       ratio=(4, 4, 4, 4, 2), num_scales=5, generator=None, choices=None, sort=None,
+                       sample_method='random'):
     """The reference collate on the device (datasets/semantic3d_dataset.py:512-528):
     per scale  neighbor_idx = knn(pos, pos, K);  one random subset shared by all clouds;
     sub_idx = neighbor_idx[:, choice];  up_idx = knn(sub_pos, pos, 1).
 
     pos [B, N, 3] float32 on the GPU.  `choices` (list of index tensors) overrides the random
     permutations (tests); otherwise torch.randperm(N, generator=generator)[:N // ratio].
+    sample_method='fps' is the reference's other branch (:520-523): a farthest-point subset PER CLOUD ([B, S] picks,
+    first pick = point 0) instead of one random subset shared by all clouds.
 
     sort='morton' (default when `choices` is None) first reorders every cloud along a Z-order curve
     (x, y, point_idx follow; the permutation is returned as ``data.order`` [B, N]) and keeps each random
@@ -145,6 +168,19 @@ def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kern
     for i in range(num_scales):
         n = pos.shape[1]
         neighbor_idx = nearest_neighbors.knn_batch_device(pos, pos, kernel_size[i])
+        method = sample_method.lower()
+        if method not in ('random', 'fps'):
+            raise NotImplementedError('Only `random` or `fps` sampling method is implemented!')      # the reference's message
+        if choices is None and method == 'fps':
+            choice = _fps_choice(pos, n // ratio[i])                               # [B, S], per cloud
+            if sort == 'morton':
+                choice = choice.sort(dim=1).values
+            sub_pos = pos.gather(1, choice.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+            sub_idx = neighbor_idx.gather(1, choice.unsqueeze(-1).expand(-1, -1, neighbor_idx.shape[-1])).contiguous()
+            up_idx = nearest_neighbors.knn_batch_device(sub_pos, pos, 1)
+            multiscale.append(Data(pos=pos, neighbor_idx=neighbor_idx, sub_idx=sub_idx, up_idx=up_idx))
+            pos = sub_pos
+            continue
         if choices is not None:
             choice = choices[i].to(pos.device)
         else:

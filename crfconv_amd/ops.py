@@ -353,10 +353,16 @@ class deferred_weight_grads:
     def __enter__(self):
         self.prev = _DEFER['on']
         _DEFER['on'] = bool(self.enabled)
+        if not self.prev:                 # outermost context: nothing of an earlier (failed) backward may linger
+            _DEFER['jobs'], _DEFER['armed'] = [], False
         return self
 
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, *exc):
         _DEFER['on'] = self.prev
+        if exc_type is not None and not self.prev:
+            # the backward raised after arming the engine callback: drop its queued partials, or every later backward
+            # would find 'armed' set, never queue the callback again and silently lose all Linear weight gradients
+            _DEFER['jobs'], _DEFER['armed'] = [], False
         return False
 
 
@@ -407,7 +413,7 @@ def _flush_weight_grads():
         if prm.grad is None:
             prm.grad = gr
         else:
-            prm.grad = prm.grad + gr
+            prm.grad.add_(gr)             # in place: views of .grad held by the caller (flat buckets) stay valid
 
 
 # ------------------------------------------------------------------------------ per-point Linear

@@ -325,6 +325,36 @@ def test_b1_is_supported():
     assert_close(one, two[:4096], OUT_TOL, 'B=1 vs B=2')
 
 
+def test_multiscale_compute_fps_branch():
+    """sample_method='fps' (datasets/semantic3d_dataset.py:520-523): per-cloud farthest-point subsets, first pick point 0,
+    each later pick the farthest from the picks before it (numpy restatement); sub_pos / sub_idx gathered per cloud and
+    up_idx = nearest sampled point."""
+    import crfconv_amd
+    B, N = 2, 600
+    pos = np.stack([S.make_cloud(40 + b, N) for b in range(B)])
+    data = crfconv_amd.multiscale_compute(t(pos), sample_method='fps', sort='none', num_scales=2, ratio=(4, 3))
+    with pytest.raises(NotImplementedError):
+        crfconv_amd.multiscale_compute(t(pos), sample_method='grid', num_scales=1)
+
+    def np_fps(p, m):
+        d = ((p - p[0]) ** 2).sum(1)
+        picks = [0]
+        for _ in range(m - 1):
+            j = int(np.argmax(d))
+            picks.append(j)
+            d = np.minimum(d, ((p - p[j]) ** 2).sum(1))
+        return np.array(picks)
+    lvl0, lvl1 = data.multiscale
+    assert lvl1.pos.shape == (B, N // 4, 3) and lvl0.sub_idx.shape == (B, N // 4, 16)
+    for b in range(B):
+        want = np_fps(pos[b].astype(np.float64), N // 4)
+        got_pos = lvl1.pos[b].cpu().numpy()
+        assert np.array_equal(got_pos, pos[b][want])
+        assert np.array_equal(lvl0.sub_idx[b].cpu().numpy(), lvl0.neighbor_idx[b].cpu().numpy()[want])
+        d = ((pos[b][:, None, :].astype(np.float64) - got_pos[None].astype(np.float64)) ** 2).sum(-1)
+        assert np.array_equal(lvl0.up_idx[b, :, 0].cpu().numpy(), d.argmin(1))
+
+
 def test_static_batch_load_refreshes_tables_reverse_csr_and_moments():
     """MultiScaleData.load_: a second batch copied into the first batch's tensors must give exactly what that batch
     gives when collated on its own -- logits, loss and every gradient -- although the neighbour tables, reverse CSRs and

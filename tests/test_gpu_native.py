@@ -154,3 +154,36 @@ def test_grid_large_vs_oracle():
     p, f, c = cpp_subsampling.compute(pts, features=feats, classes=lab, sampleDl=0.06)
     wp, wf, wc, _ = onative.oracle_grid_subsample(pts, feats, lab, 0.06)
     assert np.array_equal(p, wp) and np.array_equal(f, wf) and np.array_equal(c, wc)
+
+
+def test_knn_batch_from_forked_dataloader_style_worker():
+    """SURVEY 8(b) threading row: importing the package creates no HIP context, so a fork()ed worker process can call the
+    kNN extension (the reference calls it inside the DataLoader collate function, datasets/semantic3d_dataset.py:498).  The
+    parent must not have initialised the GPU, so the parent side runs in a fresh interpreter: it imports crfconv_amd, forks
+    two workers, and each worker's first kNN call creates its own context."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import multiprocessing as mp, sys
+sys.path.insert(0, %r)
+import numpy as np
+import crfconv_amd                                   # import only: no HIP call in the parent
+from crfconv_amd.utils import nearest_neighbors
+
+def worker(q):
+    rng = np.random.default_rng(7)
+    pts = rng.random((2, 500, 3)).astype(np.float32)
+    idx = nearest_neighbors.knn_batch(pts, pts, 8, omp=True)
+    d = ((pts[:, :, None, :] - pts[:, None, :, :]) ** 2).sum(-1)
+    q.put(bool(np.array_equal(np.sort(idx, -1), np.sort(np.argsort(d, -1, kind='stable')[:, :, :8], -1))))
+
+ctx = mp.get_context('fork'); q = ctx.Queue()
+ps = [ctx.Process(target=worker, args=(q,)) for _ in range(2)]
+[p.start() for p in ps]; res = [q.get(timeout=120) for _ in ps]; [p.join() for p in ps]
+assert all(res) and all(p.exitcode == 0 for p in ps), (res, [p.exitcode for p in ps])
+print('fork ok')
+""" % root
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'fork ok' in out.stdout, out.stderr[-2000:]
