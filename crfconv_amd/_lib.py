@@ -41,6 +41,11 @@ SIGNATURES = {
     'crfconv_meanfield_backward_param_grads_inside': (_i, [_i]),
     'crfconv_meanfield_backward_workspace': (_sz, [_i64, _i, _i]),
     'crfconv_meanfield_backward': (_i, [_vp] * 7 + [_i, _i, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _i] + [_vp] * 11 + [_sz, _vp, _vp]),
+    'crfconv_wide_similarity': (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp]),
+    'crfconv_wide_aggregate': (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp]),
+    'crfconv_wide_bwd_edge': (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _vp, _i, _vp]),
+    'crfconv_wide_scatter': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _i, _vp, _vp]),
+    'crfconv_wide_similarity_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp]),
     'crfconv_similarity_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp]),
     'crfconv_similarity_bwd_scatter': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp]),
     'crfconv_pointconv_workspace': (_sz, [_i64, _i, _i]),

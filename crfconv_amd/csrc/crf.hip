@@ -1309,6 +1309,173 @@ __global__ __launch_bounds__(BLOCK) void bwd_edge_all_kernel(const float* __rest
     if constexpr (INK) oa.store_partial(s_red, dp_partial, lane);
 }
 
+// ====================================================================== wide rows (H = 128, 256)
+// The 128- and 256-channel decoder stages of the sparse networks (models/point_conv.py:318-339: GCRFConv(512, 256),
+// GCRFConv(256, 128)) sit on the coarsest point sets (a few thousand points at most).  Their H x H matrices no longer
+// fit the LDS tiles of the kernels above, and the H x H products are genuinely dense [m, H] x [H, H] contractions: they
+// run as plain library GEMMs (ops.py), while everything that touches the graph stays here -- ONE point per wavefront,
+// VW = H / 64 channels per lane, any K <= 64 / k0, entries < 0 = no neighbour:
+//   wide_sim      s = softmax_k(-|y_i - y_j|^2)            wide_agg          m_i = sum_k s_ik x_j
+//   wide_bwd_edge ds (+)= <gm_i, x_j>                      wide_bwd_scatter  G'[j] = sum_{e in rev(j)} s[e] gm[e / K]
+//   wide_sim_bwd  w = -2 s (ds - <s, ds>), dy_self         wide_sim_bwd_scatter  dy[j] = dy_self[j] + sum w[e] (y_j - y_i)
+template <int VW>
+struct WideVec {
+    float v[VW];
+    __device__ __forceinline__ void load(const float* __restrict__ p, int lane) {
+        if constexpr (VW == 4) { const float4 t = ld4(p + 4 * lane); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else if constexpr (VW == 2) { const float2 t = *reinterpret_cast<const float2*>(p + 2 * lane); v[0] = t.x; v[1] = t.y; }
+        else v[0] = p[lane];
+    }
+    __device__ __forceinline__ void store(float* __restrict__ p, int lane) const {
+        if constexpr (VW == 4) st4(p + 4 * lane, make_float4(v[0], v[1], v[2], v[3]));
+        else if constexpr (VW == 2) *reinterpret_cast<float2*>(p + 2 * lane) = make_float2(v[0], v[1]);
+        else p[lane] = v[0];
+    }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int c = 0; c < VW; ++c) v[c] = 0.f;
+    }
+};
+
+template <int VW>
+__global__ __launch_bounds__(BLOCK) void wide_sim_kernel(const float* __restrict__ y, const int32_t* __restrict__ idx,
+                                                         int K, int k0, float* __restrict__ s, int64_t m) {
+    constexpr int H = 64 * VW;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (i >= m) return;                                    // wave-uniform
+    WideVec<VW> yi;
+    yi.load(y + i * H, lane);
+    float mine = 3.4e38f;                                  // lane k keeps the distance of column k
+    bool have_mine = false;
+    for (int k = k0; k < K; ++k) {
+        const int j = idx[i * K + k];
+        if (j < 0) continue;                               // wave-uniform
+        WideVec<VW> yj;
+        yj.load(y + (int64_t)j * H, lane);
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < VW; ++c) { const float d = yi.v[c] - yj.v[c]; part = fmaf(d, d, part); }
+        const float d2 = wave_sum(part);
+        if (lane == k) { mine = d2; have_mine = true; }
+    }
+    float dmin = mine;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, WAVE));
+    const float e = have_mine ? expf(dmin - mine) : 0.f;
+    const float den = wave_sum(e);
+    if (lane < K) s[i * K + lane] = den > 0.f ? e / den : 0.f;     // isolated point: no message
+}
+
+template <int VW>
+__global__ __launch_bounds__(BLOCK) void wide_agg_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                         const int32_t* __restrict__ idx, int K, int k0,
+                                                         float* __restrict__ out, int64_t m) {
+    constexpr int H = 64 * VW;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (i >= m) return;
+    WideVec<VW> acc;
+    acc.zero();
+    for (int k = k0; k < K; ++k) {
+        const int j = idx[i * K + k];
+        if (j < 0) continue;
+        const float w = s[i * K + k];
+        WideVec<VW> xj;
+        xj.load(x + (int64_t)j * H, lane);
+#pragma unroll
+        for (int c = 0; c < VW; ++c) acc.v[c] = fmaf(w, xj.v[c], acc.v[c]);
+    }
+    acc.store(out + i * H, lane);
+}
+
+template <int VW>
+__global__ __launch_bounds__(BLOCK) void wide_bwd_edge_kernel(const float* __restrict__ gm, const float* __restrict__ xprev,
+                                                              const int32_t* __restrict__ idx, int K, int k0,
+                                                              float* __restrict__ ds, int accumulate, int64_t m) {
+    constexpr int H = 64 * VW;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (i >= m) return;
+    WideVec<VW> g;
+    g.load(gm + i * H, lane);
+    float mine = (accumulate && lane < K) ? ds[i * K + lane] : 0.f;
+    for (int k = k0; k < K; ++k) {
+        const int j = idx[i * K + k];
+        if (j < 0) continue;
+        WideVec<VW> xj;
+        xj.load(xprev + (int64_t)j * H, lane);
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < VW; ++c) part = fmaf(g.v[c], xj.v[c], part);
+        const float dotv = wave_sum(part);
+        if (lane == k) mine += dotv;
+    }
+    if (lane < K) ds[i * K + lane] = mine;
+}
+
+// rows = source rows; coef[e] weights gathered rows of `src` addressed by the edge's TARGET row e / K:
+//   out[j] = (add ? add[j] : 0) + sum_{p in rev(j)} coef[e_p] * (SIM ? (y_j - src[e_p / K]) : src[e_p / K])
+template <int VW, bool SIM>
+__global__ __launch_bounds__(BLOCK) void wide_scatter_kernel(const float* __restrict__ src, const float* __restrict__ coef,
+                                                             const int32_t* __restrict__ rev_ptr,
+                                                             const int32_t* __restrict__ rev_eid, int K,
+                                                             const float* __restrict__ add, float* __restrict__ out,
+                                                             int64_t m_src) {
+    constexpr int H = 64 * VW;
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (j >= m_src) return;
+    WideVec<VW> acc, self;
+    acc.zero();
+    if constexpr (SIM) self.load(src + j * H, lane);
+    const int beg = rev_ptr[j], end = rev_ptr[j + 1];
+    for (int p = beg; p < end; ++p) {
+        const int e = rev_eid[p];
+        const float w = coef[e];
+        WideVec<VW> r;
+        r.load(src + (int64_t)(e / K) * H, lane);
+#pragma unroll
+        for (int c = 0; c < VW; ++c) acc.v[c] = fmaf(w, SIM ? (self.v[c] - r.v[c]) : r.v[c], acc.v[c]);
+    }
+    if (add != nullptr) {
+        WideVec<VW> a;
+        a.load(add + j * H, lane);
+#pragma unroll
+        for (int c = 0; c < VW; ++c) acc.v[c] += a.v[c];
+    }
+    acc.store(out + j * H, lane);
+}
+
+template <int VW>
+__global__ __launch_bounds__(BLOCK) void wide_sim_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s,
+                                                             const float* __restrict__ y, const int32_t* __restrict__ idx,
+                                                             int K, int k0, float* __restrict__ w,
+                                                             float* __restrict__ dy_self, int64_t m) {
+    constexpr int H = 64 * VW;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const bool col = lane >= k0 && lane < K;
+    const float sk = col ? s[i * K + lane] : 0.f, dk = col ? ds[i * K + lane] : 0.f;
+    const float dotv = wave_sum(sk * dk);
+    const float wk = -2.0f * sk * (dk - dotv);             // 0 on missing entries (s == 0) and columns < k0
+    if (lane < K) w[i * K + lane] = wk;
+    WideVec<VW> yi, acc;
+    yi.load(y + i * H, lane);
+    acc.zero();
+    for (int k = k0; k < K; ++k) {
+        const int j = idx[i * K + k];
+        if (j < 0) continue;
+        const float wv = __shfl(wk, k, WAVE);
+        WideVec<VW> yj;
+        yj.load(y + (int64_t)j * H, lane);
+#pragma unroll
+        for (int c = 0; c < VW; ++c) acc.v[c] = fmaf(wv, yi.v[c] - yj.v[c], acc.v[c]);
+    }
+    acc.store(dy_self + i * H, lane);
+}
+
 static int check_common(int64_t m, int H, int K, int k0) {
     CRF_REQUIRE(m > 0 && m < (int64_t)1 << 31, CRF_ERR_ARG, "rows m=%lld out of range", (long long)m);
     CRF_REQUIRE(H == 4 || H == 8 || H == 16 || H == 32 || H == 64, CRF_ERR_UNSUPPORTED,
@@ -1663,5 +1830,80 @@ extern "C" int crfconv_meanfield_backward(const float* gout, const float* z, con
             CRF_LAUNCH_CHECK();
         }
     });
+    return CRF_OK;
+}
+
+// ---------------------------------------------------------------------- wide rows (H in {128, 256}): graph kernels only
+#define DISPATCH_VW(H, ...)                                     \
+    switch (H) {                                                \
+        case 128: { constexpr int VV = 2; __VA_ARGS__; break; } \
+        default: { constexpr int VV = 4; __VA_ARGS__; break; }  \
+    }
+
+static int check_wide(int64_t m, int H, int K, int k0) {
+    CRF_REQUIRE(m > 0 && m < (int64_t)1 << 31, CRF_ERR_ARG, "rows m=%lld out of range", (long long)m);
+    CRF_REQUIRE(H == 128 || H == 256, CRF_ERR_UNSUPPORTED, "wide mean-field kernels take H in {128, 256}, got %d", H);
+    CRF_REQUIRE(K >= 1 && K <= 64 && k0 >= 0 && k0 < K, CRF_ERR_ARG, "K=%d k0=%d invalid", K, k0);
+    CRF_REQUIRE(m * K < (int64_t)1 << 31, CRF_ERR_ARG, "edge ids exceed int32 (m=%lld K=%d)", (long long)m, K);
+    return CRF_OK;
+}
+
+extern "C" int crfconv_wide_similarity(const float* y, const int32_t* idx32, int K, int k0, int64_t m, int H, float* s,
+                                       crf_stream_t stream) {
+    if (int rc = check_wide(m, H, K, k0)) return rc;
+    CRF_REQUIRE(y && idx32 && s, CRF_ERR_ARG, "null pointer");
+    const dim3 grid((unsigned)cdiv(m, BLOCK / WAVE));
+    DISPATCH_VW(H, hipLaunchKernelGGL(wide_sim_kernel<VV>, grid, dim3(BLOCK), 0, as_stream(stream), y, idx32, K, k0, s, m));
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_wide_aggregate(const float* x, const float* s, const int32_t* idx32, int K, int k0, int64_t m, int H,
+                                      float* out, crf_stream_t stream) {
+    if (int rc = check_wide(m, H, K, k0)) return rc;
+    CRF_REQUIRE(x && s && idx32 && out && out != x, CRF_ERR_ARG, "null pointer or aliasing");
+    const dim3 grid((unsigned)cdiv(m, BLOCK / WAVE));
+    DISPATCH_VW(H, hipLaunchKernelGGL(wide_agg_kernel<VV>, grid, dim3(BLOCK), 0, as_stream(stream), x, s, idx32, K, k0, out, m));
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_wide_bwd_edge(const float* gm, const float* xprev, const int32_t* idx32, int K, int k0, int64_t m,
+                                     int H, float* ds, int accumulate, crf_stream_t stream) {
+    if (int rc = check_wide(m, H, K, k0)) return rc;
+    CRF_REQUIRE(gm && xprev && idx32 && ds, CRF_ERR_ARG, "null pointer");
+    const dim3 grid((unsigned)cdiv(m, BLOCK / WAVE));
+    DISPATCH_VW(H, hipLaunchKernelGGL(wide_bwd_edge_kernel<VV>, grid, dim3(BLOCK), 0, as_stream(stream), gm, xprev, idx32, K,
+                                      k0, ds, accumulate, m));
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+/* out[j] = (add ? add[j] : 0) + sum_{e in rev(j)} coef[e] * src[e / K]          (similarity == 0: A^T gm)
+ * out[j] = add[j] + sum_{e in rev(j)} coef[e] * (src[j] - src[e / K])           (similarity != 0: dy, src = y, add = dy_self) */
+extern "C" int crfconv_wide_scatter(const float* src, const float* coef, const int32_t* rev_ptr, const int32_t* rev_eid,
+                                    int K, int64_t m_src, int H, const float* add, int similarity, float* out,
+                                    crf_stream_t stream) {
+    if (int rc = check_wide(m_src, H, K, 0)) return rc;
+    CRF_REQUIRE(src && coef && rev_ptr && rev_eid && out && out != src, CRF_ERR_ARG, "null pointer or aliasing");
+    const dim3 grid((unsigned)cdiv(m_src, BLOCK / WAVE));
+    DISPATCH_VW(H, {
+        if (similarity)
+            hipLaunchKernelGGL((wide_scatter_kernel<VV, true>), grid, dim3(BLOCK), 0, as_stream(stream), src, coef, rev_ptr, rev_eid, K, add, out, m_src);
+        else
+            hipLaunchKernelGGL((wide_scatter_kernel<VV, false>), grid, dim3(BLOCK), 0, as_stream(stream), src, coef, rev_ptr, rev_eid, K, add, out, m_src);
+    });
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_wide_similarity_bwd(const float* ds, const float* s, const float* y, const int32_t* idx32, int K,
+                                           int k0, int64_t m, int H, float* w, float* dy_self, crf_stream_t stream) {
+    if (int rc = check_wide(m, H, K, k0)) return rc;
+    CRF_REQUIRE(ds && s && y && idx32 && w && dy_self && w != ds, CRF_ERR_ARG, "null pointer or aliasing");
+    const dim3 grid((unsigned)cdiv(m, BLOCK / WAVE));
+    DISPATCH_VW(H, hipLaunchKernelGGL(wide_sim_bwd_kernel<VV>, grid, dim3(BLOCK), 0, as_stream(stream), ds, s, y, idx32, K, k0,
+                                      w, dy_self, m));
+    CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -47,8 +47,8 @@ class GuideGaussianCRFConv(nn.Module):
             edge_index = graph_ops.radius_graph(pos, self.radius, batch, loop=False, max_num_neighbors=self.kernel_size)
         src, tgt = edge_index[0], edge_index[1]
         n = pos.shape[0]
-        field = ops.crf_meanfield(self.unary(x), self.pairwise(y), self.c, table_from_edges(tgt, src, n, n), self.steps,
-                                  k0=0)
+        field = ops.crf_meanfield(ops.run_lin_bn(self.unary, x), ops.run_lin_bn(self.pairwise, y), self.c,
+                                  table_from_edges(tgt, src, n, n), self.steps, k0=0)
         return F.leaky_relu(field)
 
 
@@ -73,5 +73,6 @@ class ContinuousGaussianCRFConv(nn.Module):
         """Node i = edge_index[0] aggregates from j = edge_index[1] (reference :114, 126)."""
         n = pos.shape[0]
         table = table_from_edges(edge_index[0], edge_index[1], n, n)
-        field = ops.crf_meanfield(self.unary_net(x), self.pairwise_net(y), self.c, table, self.steps, k0=0)
-        return self.fusion_net(torch.cat([self.mlp(field), y], dim=-1))
+        field = ops.crf_meanfield(ops.run_lin_bn(self.unary_net, x), ops.run_lin_bn(self.pairwise_net, y), self.c, table,
+                                  self.steps, k0=0)
+        return ops.run_lin_bn(self.fusion_net, torch.cat([ops.run_lin_bn(self.mlp, field), y], dim=-1))

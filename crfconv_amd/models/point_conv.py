@@ -44,11 +44,11 @@ class DepthwiseSeparablePointConv(nn.Module):
         if bipartite:
             residual = ops.neighbor_maxpool(residual, table)          # scatter_max(x[col], row)
         if self.in_channels != self.out_channels:
-            residual = self.mlp4(residual)
-        h = self.mlp2(x)
+            residual = ops.run_lin_bn(self.mlp4, residual)
+        h = ops.run_lin_bn(self.mlp2, x)
         msg = ops.point_conv(h, pos_src, pos_dst, table, self.mlp1[0].weight, self.mlp1[1], self.mlp1[3].weight,
                              self.mlp1[4], self.training, slope=self.mlp1[2].negative_slope)
-        return F.leaky_relu(self.mlp3(msg) + residual)
+        return ops.add_lrelu(ops.run_lin_bn(self.mlp3, msg), residual, 0.01)      # F.leaky_relu default slope
 
 
 def build_graph(pos, batch, method='radius', r=0.1, k=16, dilation=1, loop=True):
@@ -155,9 +155,9 @@ class Baseline(_SparseEncoder):
         h = levels[4][0]
         for lvl in range(3, -1, -1):
             if lvl < 3:
-                h = getattr(self, 'fusion%d' % (lvl + 1))(torch.cat([h, levels[lvl + 1][0]], dim=1))
+                h = ops.run_lin_bn(getattr(self, 'fusion%d' % (lvl + 1)), torch.cat([h, levels[lvl + 1][0]], dim=1))
             h = knn_interpolate(h, levels[lvl + 1][1], levels[lvl][1], levels[lvl + 1][2], levels[lvl][2], k=3)
-            h = getattr(self, 'lin%d' % (lvl + 1))(h)
+            h = ops.run_lin_bn(getattr(self, 'lin%d' % (lvl + 1)), h)
         return torch.cat([h, levels[0][0]], dim=1)
 
 
@@ -178,7 +178,7 @@ class PointConvGassuianCRFNet(_SparseEncoder):
         h = levels[4][0]
         for lvl in range(3, -1, -1):
             if lvl < 3:
-                h = getattr(self, 'fusion%d' % (lvl + 1))(torch.cat([h, levels[lvl + 1][0]], dim=1))
+                h = ops.run_lin_bn(getattr(self, 'fusion%d' % (lvl + 1)), torch.cat([h, levels[lvl + 1][0]], dim=1))
             h = knn_interpolate(h, levels[lvl + 1][1], levels[lvl][1], levels[lvl + 1][2], levels[lvl][2], k=3)
             feat, p, b = levels[lvl]
             h = getattr(self, 'deconv%d' % (lvl + 1))(h, feat, p, b)
@@ -187,6 +187,11 @@ class PointConvGassuianCRFNet(_SparseEncoder):
 
 def _head(cin, hidden, n_classes):
     return nn.Sequential(nn.Linear(cin, hidden), nn.ReLU(inplace=True), nn.Linear(hidden, n_classes))
+
+
+def _run_head(head, x):
+    """Linear -> ReLU -> Linear of the classifier heads on ops.linear (MFMA kernels for the per-point rows)."""
+    return ops.linear(F.relu(ops.linear(x, head[0].weight, head[0].bias)), head[2].weight, head[2].bias)
 
 
 class CRFSegNet(nn.Module):
@@ -200,7 +205,7 @@ class CRFSegNet(nn.Module):
 
     def forward(self, data):
         x = self.feature(x=data.x, pos=data.pos, batch=data.batch)
-        return F.log_softmax(self.classifier(x), dim=-1)
+        return F.log_softmax(_run_head(self.classifier, x), dim=-1)
 
 
 class BaselineSegNet(nn.Module):
@@ -214,7 +219,7 @@ class BaselineSegNet(nn.Module):
 
     def forward(self, data):
         x = self.feature(x=data.x, pos=data.pos, batch=data.batch)
-        return F.log_softmax(self.classifier(x), dim=-1)
+        return F.log_softmax(_run_head(self.classifier, x), dim=-1)
 
 
 class CRFSegNet_Part(nn.Module):
@@ -232,7 +237,7 @@ class CRFSegNet_Part(nn.Module):
     def forward(self, data):
         c = F.one_hot(data.category[data.batch], num_classes=16).float()
         x = self.feature(x=torch.cat([data.pos, data.norm], dim=1), pos=data.pos, batch=data.batch)
-        return F.log_softmax(self.classifier(torch.cat([x, c], dim=1)), dim=-1)
+        return F.log_softmax(_run_head(self.classifier, torch.cat([x, c], dim=1)), dim=-1)
 
 
 class BaselineDiscreteCRFSegNet(nn.Module):
@@ -248,7 +253,7 @@ class BaselineDiscreteCRFSegNet(nn.Module):
         self.crf = DiscreteCRFConv(n_classes, in_channels, radius=0.2, kernel_size=32, steps=steps)
 
     def forward(self, data):
-        p = torch.softmax(self.classifier(self.feature(x=data.x, pos=data.pos, batch=data.batch)), dim=-1)
+        p = torch.softmax(_run_head(self.classifier, self.feature(x=data.x, pos=data.pos, batch=data.batch)), dim=-1)
         q = self.crf(data.pos, p, f=data.x, batch=data.batch)
         return torch.log(p), torch.log(q)
 
@@ -265,6 +270,6 @@ class DualCRFSegNet(nn.Module):
         self.crf = DiscreteCRFConv(n_classes, in_channels, radius=0.2, kernel_size=32, steps=steps)
 
     def forward(self, data):
-        p = torch.softmax(self.classifier(self.feature(x=data.x, pos=data.pos, batch=data.batch)), dim=-1)
+        p = torch.softmax(_run_head(self.classifier, self.feature(x=data.x, pos=data.pos, batch=data.batch)), dim=-1)
         q = self.crf(data.pos, p, f=data.x, batch=data.batch)
         return torch.log(p), torch.log(q)

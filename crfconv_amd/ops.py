@@ -186,6 +186,7 @@ class _CrfMatrices(torch.autograd.Function):
 
 
 _CRF_H = (4, 8, 16, 32, 64)
+_CRF_WIDE_H = (128, 256)                    # one point per wavefront (crfconv_wide_*), H x H products as library GEMMs
 _OLD_BWD_ENV = __import__('os').environ.get('CRFCONV_OLD_BWD') is not None     # A/B: the step-by-step backward launches
 _FUSED_ENV = __import__('os').environ.get('CRFCONV_FUSED') is not None       # one-launch forward (crfconv_meanfield_forward_fused)
 _FUSED_WS = {}
@@ -211,33 +212,86 @@ def _fused_ws(device):
 _WINDOW_ENV = __import__('os').environ.get('CRFCONV_WINDOW') is not None     # A/B kernels of csrc/crf.hip: always keep s
 
 
-def _meanfield_wide(z, y, Q, C, table, steps, k0):
-    """H > 64 (the 128/256-channel decoder stages of the sparse networks, which sit on the 1/16 and 1/64 point sets):
-    the P/Q tiles of csrc/crf.hip no longer fit LDS, so the same recurrence runs as device GEMMs around a gather
-    over the padded neighbour table.  Still GPU-only; table entries < 0 mean "no neighbour"."""
-    require_gpu(z)
-    j = table.idx32.long()
-    have = j >= 0
-    have[:, :k0] = False
-    j = j.clamp_min(0)
-    d = ((y.unsqueeze(1) - y[j]) ** 2).sum(-1).masked_fill(~have, float('inf'))
-    s = torch.softmax(-d, dim=1).masked_fill(~have, 0.0)      # rows without neighbours: softmax gives nan -> 0
-    s = s.unsqueeze(-1)
-    P = C @ Q
-    zq = z @ Q
-    x = z
-    for _ in range(steps):
-        x = zq + (s * x[j]).sum(1) @ P
-    return x
+class _MeanFieldWide(torch.autograd.Function):
+    """The mean-field loop for H in {128, 256} (the 256- / 128-channel GCRFConv stages of the sparse networks,
+    models/point_conv.py:318-339, on the coarsest point sets): the H x H tiles of csrc/crf.hip's kernels no longer fit
+    LDS, so the graph work -- similarity soft-max, neighbour aggregation, the reverse-CSR scatters and the soft-max
+    backward -- runs on the one-point-per-wavefront kernels (crfconv_wide_*), and the genuinely dense [m, H] x [H, H]
+    products of each step are library GEMMs.  Same recurrence and gradients as _MeanField."""
+
+    @staticmethod
+    def forward(ctx, z, y, Q, P, table, k0, steps):
+        require_gpu(z, y, Q, P)
+        m, H = z.shape
+        if m != table.m_tgt or y.shape[0] != m or table.m_src != m:
+            raise _lib.CrfConvError('mean field: %d / %d rows for a table of %d targets over %d sources'
+                                    % (m, y.shape[0], table.m_tgt, table.m_src))
+        z, y, Q, P = _f32c(z), _f32c(y), _f32c(Q), _f32c(P)
+        st = stream_ptr()
+        K = table.K
+        s = torch.empty((m, K), dtype=torch.float32, device=z.device)
+        _lib.call('crfconv_wide_similarity', ptr(y), ptr(table.idx32), K, k0, m, H, ptr(s), st)
+        zq = z @ Q
+        xs, msgs = [z], []
+        for _ in range(steps):
+            msg = torch.empty_like(z)
+            _lib.call('crfconv_wide_aggregate', ptr(xs[-1]), ptr(s), ptr(table.idx32), K, k0, m, H, ptr(msg), st)
+            msgs.append(msg)
+            xs.append(torch.addmm(zq, msg, P))
+        ctx.table, ctx.k0, ctx.steps = table, k0, steps
+        ctx.save_for_backward(z, y, Q, P, s, *xs[:-1], *msgs)
+        return xs[-1] if steps > 0 else z.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        table, k0, T = ctx.table, ctx.k0, ctx.steps
+        z, y, Q, P, s = ctx.saved_tensors[:5]
+        xs, msgs = ctx.saved_tensors[5:5 + T], ctx.saved_tensors[5 + T:]
+        m, H = z.shape
+        K = table.K
+        G = _f32c(gout)
+        if T == 0:
+            return G, torch.zeros_like(y), torch.zeros_like(Q), torch.zeros_like(P), None, None, None
+        rev_ptr, rev_eid = table.reverse
+        st = stream_ptr()
+        ds = torch.empty_like(s)
+        dP = torch.zeros_like(P)
+        sumG = torch.zeros_like(z)
+        for t in range(T, 0, -1):
+            gm = G @ P.t()
+            _lib.call('crfconv_wide_bwd_edge', ptr(gm), ptr(xs[t - 1]), ptr(table.idx32), K, k0, m, H, ptr(ds),
+                      0 if t == T else 1, st)
+            dP.addmm_(msgs[t - 1].t(), G)
+            sumG += G
+            Gprev = torch.empty_like(z)
+            _lib.call('crfconv_wide_scatter', ptr(gm), ptr(s), ptr(rev_ptr), ptr(rev_eid), K, m, H, None, 0, ptr(Gprev), st)
+            G = Gprev
+        dz = G.addmm_(sumG, Q.t())
+        dQ = z.t() @ sumG
+        w = torch.empty_like(s)
+        dy_self, dy = torch.empty_like(y), torch.empty_like(y)
+        _lib.call('crfconv_wide_similarity_bwd', ptr(ds), ptr(s), ptr(y), ptr(table.idx32), K, k0, m, H, ptr(w),
+                  ptr(dy_self), st)
+        _lib.call('crfconv_wide_scatter', ptr(y), ptr(w), ptr(rev_ptr), ptr(rev_eid), K, m, H, ptr(dy_self), 1, ptr(dy), st)
+        return dz, dy, dQ, dP, None, None, None
 
 
 def crf_meanfield(z, y, c, table, steps, k0=1):
     """z, y: [m, H] (flattened clouds);  c: [H, H] compatibility factor (C = c^T c)."""
     H = z.shape[-1]
+    if H > _CRF_WIDE_H[-1]:
+        raise _lib.CrfConvError('mean field: H = %d exceeds the widest kernel (%d)' % (H, _CRF_WIDE_H[-1]))
     if H > _CRF_H[-1]:
-        C = c.t() @ c
-        return _meanfield_wide(z, y, torch.linalg.inv(torch.eye(H, dtype=c.dtype, device=c.device) + C), C, table,
-                               steps, k0)
+        # Q = (I + c^T c)^-1 and P = I - Q by the library inverse (H x H, once per call); zero-padded channels stay zero
+        Hp = _next_supported(H, _CRF_WIDE_H)
+        eye = torch.eye(H, dtype=c.dtype, device=c.device)
+        Q = torch.linalg.inv(eye + c.t() @ c)
+        P = eye - Q
+        if Hp != H:
+            Q = torch.nn.functional.pad(Q, (0, Hp - H, 0, Hp - H))
+            P = torch.nn.functional.pad(P, (0, Hp - H, 0, Hp - H))
+        out = _MeanFieldWide.apply(_pad_channels(z, Hp), _pad_channels(y, Hp), Q, P, table, k0, steps)
+        return out[:, :H] if Hp != H else out
     Q, P = _CrfMatrices.apply(c)               # loop-invariant: computed once, not per step
     Hp = _next_supported(H, _CRF_H)
     if Hp != H:                                 # zero channels stay zero through every step
@@ -671,6 +725,42 @@ def mlp_block(x, W, bn, slope=1.0):
     out = _MLPBlock.apply(x.reshape(-1, shape[-1]), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps,
                           slope)
     return out.reshape(shape[:-1] + (W.shape[0],))
+
+
+def run_lin_bn(seq, x):
+    """Runs an ``nn.Sequential`` of the reference's sparse layers -- [Linear, BatchNorm1d(, LeakyReLU)] groups, e.g.
+    models/continuous_crf_conv.py:24-38, models/point_conv.py:21-41 -- on the HIP operators: the Sequential only keeps
+    the parameters (its indices ARE the checkpoint keys); each group becomes ops.mlp_block (fused MFMA Linear +
+    BatchNorm + LeakyReLU with the two-pass backward) when it applies, else ops.linear + ops.bn_act."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        lin = mods[i]
+        if not isinstance(lin, torch.nn.Linear):
+            raise _lib.CrfConvError('run_lin_bn: expected a Linear at position %d, got %s' % (i, type(lin).__name__))
+        bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.BatchNorm1d) else None
+        j = i + 1 + (bn is not None)
+        act = mods[j] if j < len(mods) and isinstance(mods[j], torch.nn.LeakyReLU) else None
+        slope = act.negative_slope if act is not None else 1.0
+        co = lin.out_features
+        if bn is not None and co % 4 == 0 and co <= 1024 and bn.affine and x.dtype == torch.float32:
+            if mlp_block_ok(x, lin.weight, lin.bias, bn, seq.training):
+                x = mlp_block(x, lin.weight, bn, slope)
+            else:
+                records = None
+                if seq.training:
+                    x, records = linear(x, lin.weight, lin.bias, want_stats=True)
+                else:
+                    x = linear(x, lin.weight, lin.bias)
+                x = bn_act(x, bn, seq.training, slope, records=records)
+        else:
+            x = linear(x, lin.weight, lin.bias)
+            if bn is not None:
+                x = bn(x)
+            if act is not None:
+                x = torch.nn.functional.leaky_relu(x, slope)
+        i = j + (act is not None)
+    return x
 
 
 # ------------------------------------------------------------------------------ residual join

@@ -194,6 +194,26 @@ int crfconv_meanfield_backward(const float* gout, const float* z, const float* y
                                float* dz, float* w, float* dy_self, float* dy, float* dP, float* dQ, void* ws,
                                size_t ws_bytes, unsigned* ticket, crf_stream_t stream);
 
+/* Wide rows, H in {128, 256} (the GCRFConv(512, 256) / (256, 128) stages of the sparse networks,
+ * models/point_conv.py:318-339): the graph part of the mean-field loop and its backward, one point per wavefront, any
+ * K <= 64 / k0, entries of idx32 < 0 = no neighbour.  The H x H products of a step (x = z Q + m P) are plain dense GEMMs
+ * left to the caller.
+ *   similarity:      s[i,k] = softmax_k(-|y_i - y_j|^2)              aggregate:  out_i = sum_k s[i,k] x[j(i,k)]
+ *   bwd_edge:        ds[i,k] (+)= <gm_i, xprev_j>
+ *   scatter:         out[j] = (add ? add[j] : 0) + sum_{e in rev(j)} coef[e] src[e / K]        (similarity == 0)
+ *                    out[j] = add[j] + sum_{e in rev(j)} coef[e] (src[j] - src[e / K])         (similarity != 0)
+ *   similarity_bwd:  w = -2 s (ds - <s, ds>),  dy_self_i = sum_k w_ik (y_i - y_j) */
+int crfconv_wide_similarity(const float* y, const int32_t* idx32, int K, int k0, int64_t m, int H, float* s,
+                            crf_stream_t stream);
+int crfconv_wide_aggregate(const float* x, const float* s, const int32_t* idx32, int K, int k0, int64_t m, int H,
+                           float* out, crf_stream_t stream);
+int crfconv_wide_bwd_edge(const float* gm, const float* xprev, const int32_t* idx32, int K, int k0, int64_t m, int H,
+                          float* ds, int accumulate, crf_stream_t stream);
+int crfconv_wide_scatter(const float* src, const float* coef, const int32_t* rev_ptr, const int32_t* rev_eid, int K,
+                         int64_t m_src, int H, const float* add, int similarity, float* out, crf_stream_t stream);
+int crfconv_wide_similarity_bwd(const float* ds, const float* s, const float* y, const int32_t* idx32, int K, int k0,
+                                int64_t m, int H, float* w, float* dy_self, crf_stream_t stream);
+
 /* Softmax + distance backward.  In: ds, s.  Out: w [m, K] = 2 * d(loss)/d(dist_ik) (must NOT
  * alias ds), dy_self[i] = sum_k w_ik (y_i - y_j). */
 int crfconv_similarity_bwd(const float* ds, const float* s, const float* y, const int32_t* idx32,

@@ -181,8 +181,8 @@ def test_sparse_networks_run_and_train():
 
 @pytest.mark.parametrize('H', [128, 256])
 def test_sparse_meanfield_wide_channels(H):
-    """H > 64 (sparse decoder stages): GEMM + gather path against the oracle, forward and gradients, with isolated
-    nodes in the graph."""
+    """H in {128, 256} (sparse decoder stages): the one-point-per-wavefront graph kernels (crfconv_wide_*) + library GEMMs
+    for the H x H products, against the oracle, forward and gradients, with isolated nodes in the graph."""
     from crfconv_amd import ops
     from crfconv_amd.graph import table_from_edges
     N, E = 300, 2400
