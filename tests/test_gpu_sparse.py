@@ -179,6 +179,104 @@ def test_sparse_networks_run_and_train():
         assert any(float(p.grad.abs().max()) > 0 for p in net.parameters())
 
 
+def test_crfsegnet_whole_network_against_oracle_composition():
+    """CRFSegNet (models/point_conv.py:566-591: sparse PointConv encoder over an fps pyramid, knn_interpolate + guided
+    Gaussian-CRF decoder incl. the 256- and 128-channel stages, classifier head) end to end against the CPU oracle's
+    operators composed the same way.  The graphs (kNN / bipartite kNN on fps subsets / radius graphs / the k = 3
+    interpolation neighbours) are RECORDED from the HIP run and injected into the oracle composition, so the comparison
+    pins the layer arithmetic and wiring; the graph builders have their own parity tests.  Parity stays "unpinned" at the
+    torch_geometric boundary (the reference cannot construct this network): the oracle is the restatement of
+    continuous_crf_conv.py:50-69 and point_conv.py:43-66, not the reference run."""
+    import crfconv_amd
+    from crfconv_amd import models
+    from crfconv_amd.models import continuous_crf_conv as ccc, graph_ops, point_conv as pc
+    n0, n1 = 700, 500
+    pos = t(np.concatenate([S.make_cloud(60, n0), S.make_cloud(61, n1)]))
+    batch = t(np.concatenate([np.zeros(n0, np.int64), np.ones(n1, np.int64)]))
+    feat = t(S.uniform(60, 'f', (n0 + n1, 6)))
+    data = crfconv_amd.Data(pos=pos, x=feat, batch=batch)
+    torch.manual_seed(5)
+    net = models.CRFSegNet(6, 5, steps=2).to(DEV).eval()
+    for mod in net.modules():                                    # non-trivial running statistics
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.uniform_(-0.2, 0.2)
+            mod.running_var.uniform_(0.6, 1.4)
+    rec = []
+    orig = (pc.build_graph, pc.build_bipartite_graph, graph_ops.knn, graph_ops.radius_graph)
+
+    def wrap(fn, name):
+        def inner(*a, **k):
+            out = fn(*a, **k)
+            if name != 'knn' or not rec or rec[-1][0] != 'lock':
+                rec.append((name, out))
+            return out
+        return inner
+    # build_bipartite_graph calls graph_ops.knn internally: record knn only when knn_interpolate calls it (top level)
+    def bip(*a, **k):
+        rec.append(('lock', None))
+        out = orig[1](*a, **k)
+        rec.pop([i for i, r in enumerate(rec) if r[0] == 'lock'][-1])
+        rec.append(('bip', out))
+        return out
+    def bg(*a, **k):
+        rec.append(('lock', None))
+        out = orig[0](*a, **k)
+        rec.pop([i for i, r in enumerate(rec) if r[0] == 'lock'][-1])
+        rec.append(('graph', out))
+        return out
+    def knn_rec(*a, **k):
+        out = orig[2](*a, **k)
+        if not any(r[0] == 'lock' for r in rec):
+            rec.append(('knn', out))
+        return out
+    def rad_rec(*a, **k):
+        out = orig[3](*a, **k)
+        if not any(r[0] == 'lock' for r in rec):
+            rec.append(('radius', out))
+        return out
+    pc.build_graph, pc.build_bipartite_graph, graph_ops.knn, graph_ops.radius_graph = bg, bip, knn_rec, rad_rec
+    try:
+        with torch.no_grad():
+            got = net(data)
+    finally:
+        pc.build_graph, pc.build_bipartite_graph, graph_ops.knn, graph_ops.radius_graph = orig
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    it = iter(rec)
+
+    def take(kind):
+        k, v = next(it)
+        assert k == kind, (k, kind)
+        return v
+    cpu = lambda v: v.cpu() if torch.is_tensor(v) else v
+    x, p, b = feat.cpu(), pos.cpu(), batch.cpu()
+    levels = []
+    for lvl in range(5):
+        if lvl > 0:
+            ei, pos_c, batch_c = (cpu(v) for v in take('bip'))
+            x = O.ds_point_conv(sd, 'feature.conv%d_1.' % (lvl + 1), x, (p, pos_c), ei, False)
+            p, b = pos_c, batch_c
+        ei = take('graph').cpu()
+        if lvl == 0:
+            x = O.ds_point_conv(sd, 'feature.conv1_1.', x, p, ei, False)
+        x = O.ds_point_conv(sd, 'feature.conv%d_2.' % (lvl + 1), x, p, ei, False)
+        levels.append((x, p, b))
+    h = levels[4][0]
+    for lvl in range(3, -1, -1):
+        if lvl < 3:
+            h = torch.nn.functional.leaky_relu(O._lin_bn(sd, 'feature.fusion%d.' % (lvl + 1), torch.cat([h, levels[lvl + 1][0]], 1), False))
+        row, col = (v.cpu() for v in take('knn'))
+        px, py = levels[lvl + 1][1], levels[lvl][1]
+        w = 1.0 / ((py[row] - px[col]) ** 2).sum(1, keepdim=True).clamp_min(1e-16)
+        num = torch.zeros((py.shape[0], h.shape[1])).index_add_(0, row, h[col] * w)
+        h = num / torch.zeros((py.shape[0], 1)).index_add_(0, row, w)
+        ei = take('radius').cpu()
+        h = O.guide_crf_conv(sd, 'feature.deconv%d.' % (lvl + 1), h, levels[lvl][0], ei[1], ei[0], 2, False)
+    f = torch.cat([h, levels[0][0]], 1)
+    hid = torch.relu(torch.nn.functional.linear(f, sd['classifier.0.weight'], sd['classifier.0.bias']))
+    ref = torch.log_softmax(torch.nn.functional.linear(hid, sd['classifier.2.weight'], sd['classifier.2.bias']), -1)
+    assert_close(got, ref, 1e-4, 'CRFSegNet log-probabilities')
+
+
 @pytest.mark.parametrize('H', [128, 256])
 def test_sparse_meanfield_wide_channels(H):
     """H in {128, 256} (sparse decoder stages): the one-point-per-wavefront graph kernels (crfconv_wide_*) + library GEMMs
