@@ -578,8 +578,8 @@ __global__ __launch_bounds__(256) void spd_inverse_kernel(const float* __restric
 
 // The two loop-invariant matrices of a CRF layer from its compatibility factor c [H, H] in one launch:
 //   Q = (I + c^T c)^-1,   P = c^T c Q = I - Q            (continuous_crf_conv_big.py:67-72)
-__global__ __launch_bounds__(256) void crf_matrices_kernel(const float* __restrict__ cmat, int H,
-                                                           float* __restrict__ Qout, float* __restrict__ Pout) {
+__device__ __forceinline__ void crf_matrices_body(const float* __restrict__ cmat, int H,
+                                                  float* __restrict__ Qout, float* __restrict__ Pout) {
     __shared__ double s_row[2][64], s_col[2][64];
     __shared__ float s_c[64 * 65];
     for (int e = threadIdx.x; e < H * H; e += 256) s_c[(e / H) * 65 + (e % H)] = cmat[e];
@@ -611,9 +611,32 @@ __global__ __launch_bounds__(256) void crf_matrices_kernel(const float* __restri
 
 // dc from dQ and dP (either may be NULL = zero).  With D = dQ - dP (P = I - Q), M = I + c^T c:
 //   dM = -Q^T D Q^T,   dc = c (dM + dM^T) = -c (S + S^T),   S = Q^T D Q^T.
-__global__ __launch_bounds__(256) void crf_matrices_bwd_kernel(const float* __restrict__ cmat, const float* __restrict__ Q,
-                                                               const float* __restrict__ dQ, const float* __restrict__ dP,
-                                                               int H, float* __restrict__ dc) {
+__global__ __launch_bounds__(256) void crf_matrices_kernel(const float* __restrict__ cmat, int H,
+                                                           float* __restrict__ Qout, float* __restrict__ Pout) {
+    crf_matrices_body(cmat, H, Qout, Pout);
+}
+
+// All CRF layers of a network in ONE launch (one workgroup each): the Gauss-Jordan sweep is a latency chain of ~20 us
+// whatever H is, so four layers cost what one does.
+constexpr int CM_MAX = 8;
+struct CrfMatJobs {
+    const float* c[CM_MAX];
+    const float* Q_in[CM_MAX];
+    const float* gQ[CM_MAX];
+    const float* gP[CM_MAX];
+    float* Q[CM_MAX];
+    float* P[CM_MAX];
+    float* dc[CM_MAX];
+    int H[CM_MAX];
+};
+__global__ __launch_bounds__(256) void crf_matrices_batched_kernel(const CrfMatJobs j) {
+    const int b = blockIdx.x;
+    crf_matrices_body(j.c[b], j.H[b], j.Q[b], j.P[b]);
+}
+
+__device__ __forceinline__ void crf_matrices_bwd_body(const float* __restrict__ cmat, const float* __restrict__ Q,
+                                                      const float* __restrict__ dQ, const float* __restrict__ dP,
+                                                      int H, float* __restrict__ dc) {
     __shared__ float s_a[64 * 65], s_b[64 * 65], s_t[64 * 65];
     for (int e = threadIdx.x; e < H * H; e += 256) {
         const int r = e / H, c = e % H;
@@ -646,7 +669,43 @@ __global__ __launch_bounds__(256) void crf_matrices_bwd_kernel(const float* __re
         dc[e] = (float)acc;
     }
 }
+__global__ __launch_bounds__(256) void crf_matrices_bwd_kernel(const float* __restrict__ cmat, const float* __restrict__ Q,
+                                                               const float* __restrict__ dQ, const float* __restrict__ dP,
+                                                               int H, float* __restrict__ dc) {
+    crf_matrices_bwd_body(cmat, Q, dQ, dP, H, dc);
+}
+__global__ __launch_bounds__(256) void crf_matrices_bwd_batched_kernel(const CrfMatJobs j) {
+    const int b = blockIdx.x;
+    crf_matrices_bwd_body(j.c[b], j.Q_in[b], j.gQ[b], j.gP[b], j.H[b], j.dc[b]);
+}
 }  // namespace crf
+
+extern "C" int crfconv_crf_matrices_batched(const float* const* c, const int* H, int n, float* const* Q, float* const* P,
+                                            crf_stream_t stream) {
+    CRF_REQUIRE(c && H && Q && P && n >= 1 && n <= crf::CM_MAX, CRF_ERR_ARG, "null pointer or n=%d outside [1, %d]", n, crf::CM_MAX);
+    crf::CrfMatJobs j = {};
+    for (int i = 0; i < n; ++i) {
+        CRF_REQUIRE(c[i] && Q[i] && P[i] && H[i] >= 1 && H[i] <= 64, CRF_ERR_ARG, "job %d: null pointer or H=%d outside [1, 64]", i, H[i]);
+        j.c[i] = c[i]; j.Q[i] = Q[i]; j.P[i] = P[i]; j.H[i] = H[i];
+    }
+    hipLaunchKernelGGL(crf::crf_matrices_batched_kernel, dim3((unsigned)n), dim3(256), 0, crf::as_stream(stream), j);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_crf_matrices_backward_batched(const float* const* c, const float* const* Q, const float* const* gQ,
+                                                     const float* const* gP, const int* H, int n, float* const* dc,
+                                                     crf_stream_t stream) {
+    CRF_REQUIRE(c && Q && gQ && gP && H && dc && n >= 1 && n <= crf::CM_MAX, CRF_ERR_ARG, "null pointer or n=%d outside [1, %d]", n, crf::CM_MAX);
+    crf::CrfMatJobs j = {};
+    for (int i = 0; i < n; ++i) {
+        CRF_REQUIRE(c[i] && Q[i] && dc[i] && H[i] >= 1 && H[i] <= 64, CRF_ERR_ARG, "job %d: null pointer or H=%d outside [1, 64]", i, H[i]);
+        j.c[i] = c[i]; j.Q_in[i] = Q[i]; j.gQ[i] = gQ[i]; j.gP[i] = gP[i]; j.dc[i] = dc[i]; j.H[i] = H[i];
+    }
+    hipLaunchKernelGGL(crf::crf_matrices_bwd_batched_kernel, dim3((unsigned)n), dim3(256), 0, crf::as_stream(stream), j);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
 
 extern "C" int crfconv_spd_inverse(const float* M, int H, float* Q, crf_stream_t stream) {
     CRF_REQUIRE(M && Q, CRF_ERR_ARG, "null pointer");

@@ -1156,7 +1156,7 @@ extern "C" int crfconv_pointconv_bwd_dump(const float* x, const float* gout, con
 }
 
 extern "C" size_t crfconv_pointconv_bwd_a1_workspace(int64_t n_edges, int d) {
-    if (n_edges <= 0 || d < 32) return 0;
+    if (n_edges <= 0 || d < 8) return 0;
     const int64_t nblk = std::min<int64_t>(1024, cdiv(n_edges, 256 / (d / 4) * 8));
     return sizeof(double) * 4 * (size_t)d * (size_t)nblk + 256;
 }
@@ -1165,13 +1165,15 @@ extern "C" int crfconv_pointconv_bwd_a1(const float* gw, const float* h1, const 
                                         float slope, double* dA1b1, void* workspace, size_t workspace_bytes,
                                         crf_stream_t stream) {
     CRF_REQUIRE(gw && h1 && rel && dA1b1 && workspace, CRF_ERR_ARG, "null pointer");
-    CRF_REQUIRE(d == 32 || d == 64 || d == 128, CRF_ERR_UNSUPPORTED, "d=%d not in {32, 64, 128} (d <= 16 reduces in crfconv_pointconv_bwd_params)", d);
+    CRF_REQUIRE(d == 8 || d == 16 || d == 32 || d == 64 || d == 128, CRF_ERR_UNSUPPORTED, "d=%d not in {8, 16, 32, 64, 128}", d);
     CRF_REQUIRE(n_edges > 0 && n_edges < ((int64_t)1 << 31), CRF_ERR_ARG, "n_edges=%lld out of range", (long long)n_edges);
     CRF_REQUIRE(workspace_bytes >= crfconv_pointconv_bwd_a1_workspace(n_edges, d), CRF_ERR_WORKSPACE, "workspace too small");
     const int64_t nblk = std::min<int64_t>(1024, cdiv(n_edges, 256 / (d / 4) * 8));
     double* partial_d = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     hipStream_t st = as_stream(stream);
     switch (d) {
+        case 8: hipLaunchKernelGGL(a1_reduce_kernel<8>, dim3((unsigned)nblk), dim3(256), 0, st, gw, h1, rel, n_edges, slope, partial_d); break;
+        case 16: hipLaunchKernelGGL(a1_reduce_kernel<16>, dim3((unsigned)nblk), dim3(256), 0, st, gw, h1, rel, n_edges, slope, partial_d); break;
         case 32: hipLaunchKernelGGL(a1_reduce_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, st, gw, h1, rel, n_edges, slope, partial_d); break;
         case 64: hipLaunchKernelGGL(a1_reduce_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, st, gw, h1, rel, n_edges, slope, partial_d); break;
         default: hipLaunchKernelGGL(a1_reduce_kernel<128>, dim3((unsigned)nblk), dim3(256), 0, st, gw, h1, rel, n_edges, slope, partial_d); break;

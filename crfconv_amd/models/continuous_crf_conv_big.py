@@ -35,14 +35,16 @@ class ContinuousGaussianCRFConv(nn.Module):
     def _reset_parameters(self):
         nn.init.eye_(self.c)
 
-    def forward(self, unary, pairwise, up_idx, neighbor_idx):
+    def forward(self, unary, pairwise, up_idx, neighbor_idx, matrices=None):
         """unary [B, N', U] (coarse level), pairwise [B, N, P], up_idx [B, N, 1] -> nearest coarse point,
-        neighbor_idx [B, N, K] whose column 0 is the query itself.  Returns [B, N, O]."""
+        neighbor_idx [B, N, K] whose column 0 is the query itself.  Returns [B, N, O].  `matrices`: this layer's
+        (Q, P) = ((I + c^T c)^-1, I - Q) when the network has computed all its layers' in one launch."""
         B, N, _ = pairwise.shape
         H = self.hidden_channels
         coarse = self.unary_nn(unary).reshape(-1, H)
         guide = self.pairwise_nn(pairwise).reshape(-1, H)
         z = ops.gather_rows(coarse, table_of(up_idx, unary.shape[1]))                      # up-sample the unary term
-        field = ops.crf_meanfield(z, guide, self.c, table_of(neighbor_idx, N), self.steps, k0=1)   # k0 = 1: no self edge
+        field = ops.crf_meanfield(z, guide, self.c, table_of(neighbor_idx, N), self.steps, k0=1,      # k0 = 1: no self edge
+                                  matrices=matrices)
         refined = self.out_nn(field.reshape(B, N, H))
         return self.fusion_nn(torch.cat([refined, pairwise], dim=-1))

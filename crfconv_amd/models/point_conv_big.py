@@ -137,8 +137,15 @@ class PointConvResNet(Base):
             h = getattr(self, 'conv%d_1' % (lvl + 1))(h, (fine.pos, coarse.pos), fine.sub_idx)
             h = getattr(self, 'conv%d_2' % (lvl + 1))(h, coarse.pos, coarse.neighbor_idx)
             skips.append(h)
-        for lvl in range(len(WIDTHS) - 2, -1, -1):
-            h = getattr(self, 'deconv%d' % (lvl + 1))(h, skips[lvl], ms[lvl].up_idx, ms[lvl].neighbor_idx)
+        decoders = [getattr(self, 'deconv%d' % (lvl + 1)) for lvl in range(len(WIDTHS) - 2, -1, -1)]
+        mats = [None] * len(decoders)
+        if all(isinstance(d, CRFConv) for d in decoders):      # (I + c^T c)^-1 of every CRF layer: ONE launch (and one back)
+            mats = ops.crf_matrices_batched([d.c for d in decoders])
+        for d, mat, lvl in zip(decoders, mats, range(len(WIDTHS) - 2, -1, -1)):
+            if mat is not None:
+                h = d(h, skips[lvl], ms[lvl].up_idx, ms[lvl].neighbor_idx, matrices=mat)
+            else:
+                h = d(h, skips[lvl], ms[lvl].up_idx, ms[lvl].neighbor_idx)
         h = self.classifier[1](self.classifier[0](h))
         h = ops.linear(h, self.classifier[2].weight, self.classifier[2].bias)
         return h.reshape(-1, self.C)

@@ -185,6 +185,56 @@ class _CrfMatrices(torch.autograd.Function):
         return dc
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+class _CrfMatricesBatched(torch.autograd.Function):
+    """(Q_i, P_i) of several CRF layers from their factors c_i in ONE launch, and one launch for all dc_i: every
+    layer's matrices depend on parameters only, so a network computes them together before its first layer
+    (PointConvBig: four ~20 us single-workgroup launches each way become one)."""
+
+    @staticmethod
+    def forward(ctx, *cs):
+        require_gpu(*cs)
+        ccs = [_f32c(c) for c in cs]
+        Qs = [torch.empty_like(c) for c in ccs]
+        Ps = [torch.empty_like(c) for c in ccs]
+        Hs = (ctypes.c_int * len(ccs))(*[c.shape[0] for c in ccs])
+        _lib.call('crfconv_crf_matrices_batched', _ptr_array(ccs), Hs, len(ccs), _ptr_array(Qs), _ptr_array(Ps), stream_ptr())
+        ctx.save_for_backward(*ccs, *Qs)
+        ctx.n = len(ccs)
+        out = []
+        for Q, P in zip(Qs, Ps):
+            out += [Q, P]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = ctx.n
+        ccs, Qs = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        gQ = [None if g is None else _f32c(g) for g in grads[0::2]]
+        gP = [None if g is None else _f32c(g) for g in grads[1::2]]
+        dcs = [torch.empty_like(c) for c in ccs]
+        Hs = (ctypes.c_int * n)(*[c.shape[0] for c in ccs])
+        _lib.call('crfconv_crf_matrices_backward_batched', _ptr_array(ccs), _ptr_array(Qs), _ptr_array(gQ), _ptr_array(gP), Hs, n,
+                  _ptr_array(dcs), stream_ptr())
+        return tuple(dcs)
+
+
+def crf_matrices_batched(cs):
+    """[(Q, P)] for the compatibility factors `cs` (each [H, H], H <= 64) in one launch; None where a layer's H is wider
+    (crf_meanfield then falls back to its own path)."""
+    idx = [i for i, c in enumerate(cs) if c.shape[0] <= _CRF_H[-1]]
+    out = [None] * len(cs)
+    for lo in range(0, len(idx), 8):
+        part = idx[lo:lo + 8]
+        res = _CrfMatricesBatched.apply(*[cs[i] for i in part])
+        for k, i in enumerate(part):
+            out[i] = (res[2 * k], res[2 * k + 1])
+    return out
+
+
 _CRF_H = (4, 8, 16, 32, 64)
 _CRF_WIDE_H = (128, 256)                    # one point per wavefront (crfconv_wide_*), H x H products as library GEMMs
 _OLD_BWD_ENV = __import__('os').environ.get('CRFCONV_OLD_BWD') is not None     # A/B: the step-by-step backward launches
@@ -276,8 +326,9 @@ class _MeanFieldWide(torch.autograd.Function):
         return dz, dy, dQ, dP, None, None, None
 
 
-def crf_meanfield(z, y, c, table, steps, k0=1):
-    """z, y: [m, H] (flattened clouds);  c: [H, H] compatibility factor (C = c^T c)."""
+def crf_meanfield(z, y, c, table, steps, k0=1, matrices=None):
+    """z, y: [m, H] (flattened clouds);  c: [H, H] compatibility factor (C = c^T c).  `matrices` = (Q, P) of this c when
+    the caller already has them (crf_matrices_batched)."""
     H = z.shape[-1]
     if H > _CRF_WIDE_H[-1]:
         raise _lib.CrfConvError('mean field: H = %d exceeds the widest kernel (%d)' % (H, _CRF_WIDE_H[-1]))
@@ -292,7 +343,7 @@ def crf_meanfield(z, y, c, table, steps, k0=1):
             P = torch.nn.functional.pad(P, (0, Hp - H, 0, Hp - H))
         out = _MeanFieldWide.apply(_pad_channels(z, Hp), _pad_channels(y, Hp), Q, P, table, k0, steps)
         return out[:, :H] if Hp != H else out
-    Q, P = _CrfMatrices.apply(c)               # loop-invariant: computed once, not per step
+    Q, P = matrices if matrices is not None else _CrfMatrices.apply(c)      # loop-invariant: once, not per step
     Hp = _next_supported(H, _CRF_H)
     if Hp != H:                                 # zero channels stay zero through every step
         Q = torch.nn.functional.pad(Q, (0, Hp - H, 0, Hp - H))
@@ -1037,7 +1088,7 @@ class _PointConv(torch.autograd.Function):
             _lib.call('crfconv_pointconv_fold2_bwd', ptr(red), ptr(shift), ptr(aux2), ptr(g2), n_e, 1 if ctx.use2 else 0,
                       d, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), ptr(coef[4]), st)
         # pass 2: parameter gradients
-        if d <= 16:
+        if d <= _PC_PARAMS_INKERNEL_MAX_D:
             dW2 = torch.empty(d * d, dtype=torch.float64, device=dev)
             dA1b1 = torch.empty((d, 4), dtype=torch.float64, device=dev)
             _lib.call('crfconv_pointconv_bwd_params', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32),
@@ -1077,6 +1128,7 @@ class _PointConv(torch.autograd.Function):
 
 
 _PC_D = (4, 8, 16, 32, 64, 128)
+_PC_PARAMS_INKERNEL_MAX_D = int(__import__('os').environ.get('CRFCONV_PC_INKERNEL_D', 16))   # wider: per-edge dump + MFMA reductions
 
 
 def pack_moments(moments):

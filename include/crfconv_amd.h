@@ -400,6 +400,13 @@ int crfconv_spd_inverse(const float* M, int H, float* Q, crf_stream_t stream);
 int crfconv_crf_matrices(const float* c, int H, float* Q, float* P, crf_stream_t stream);
 int crfconv_crf_matrices_backward(const float* c, const float* Q, const float* dQ, const float* dP, int H,
                                   float* dc, crf_stream_t stream);
+/* The same for n <= 8 layers in ONE launch each way (one workgroup per layer: the Gauss-Jordan sweep is a ~20 us latency
+ * chain whatever H is).  Host arrays of n device pointers / sizes; gQ[i] / gP[i] may be NULL (= zero). */
+int crfconv_crf_matrices_batched(const float* const* c, const int* H, int n, float* const* Q, float* const* P,
+                                 crf_stream_t stream);
+int crfconv_crf_matrices_backward_batched(const float* const* c, const float* const* Q, const float* const* gQ,
+                                          const float* const* gP, const int* H, int n, float* const* dc,
+                                          crf_stream_t stream);
 
 /* ===================================================================== (B) pooling / up-sampling
  * out[i,c] = max_k x[idx32[i,k], c];  arg [m_tgt, C] int32 = winning k (first maximum). */
