@@ -13,6 +13,8 @@
 // are summed in a fixed order by a second kernel (bitwise reproducible, no float atomics).
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace crf {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -996,8 +998,9 @@ __global__ __launch_bounds__(FR_BLOCK) void bn_finalize_records_kernel(const flo
 }
 
 static int lf_blocks(int64_t M) {
-    int64_t nb = (M + 63) / 64;           // 64 rows per block iteration; up to 4 blocks (16 waves) per CU keep
-    if (nb > 1024) nb = 1024;             // enough 16-byte loads in flight; one statistics record per block
+    static const int cap = getenv("CRFCONV_LF_BLOCKS") ? atoi(getenv("CRFCONV_LF_BLOCKS")) : 512;   // swept 128..2048 on the training step: 512 (two blocks per CU, half the statistic records of 1024) is the optimum
+    int64_t nb = (M + 63) / 64;           // 64 rows per block iteration; two blocks (8 waves) per CU keep
+    if (nb > cap) nb = cap;               // enough 16-byte loads in flight; one statistics record per block
     return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -1065,7 +1068,8 @@ static MlpPlan mlp_plan(int64_t M, int Co, int Ci) {
     if (p.tco * p.tci == 16) p.tci = 2;              // two accumulator sets: at most 8 tiles (64 registers) each
     p.gy = (t_co + p.tco - 1) / p.tco;
     p.gz = (t_ci + p.tci - 1) / p.tci;
-    int64_t slices = 512 / ((int64_t)p.gy * p.gz);
+    static const int target = getenv("CRFCONV_MLP_SLICES") ? atoi(getenv("CRFCONV_MLP_SLICES")) : 512;
+    int64_t slices = target / ((int64_t)p.gy * p.gz);
     if (slices < 32) slices = 32;
     int64_t rows = (M + slices - 1) / slices;
     if (rows < 64) rows = 64;
