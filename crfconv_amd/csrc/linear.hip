@@ -122,6 +122,7 @@ __global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict
 template <int TCO, int TCI>
 __global__ __launch_bounds__(WG_BLOCK) void mlp_bwd_p1_kernel(const float* __restrict__ GA, const float* __restrict__ Y,
                                                               const float* __restrict__ X,
+                                                              const float* __restrict__ X2, int split /*X = [X | X2] at column split (X2 may be null)*/,
                                                               const float* __restrict__ coef /*[4][Co]: a, b, mean, rstd*/,
                                                               float slope, int64_t M, int Co, int Ci, int rows_per_block,
                                                               float* __restrict__ PA /*[nblk][Co][Ci]*/,
@@ -169,7 +170,9 @@ __global__ __launch_bounds__(WG_BLOCK) void mlp_bwd_p1_kernel(const float* __res
 #pragma unroll
             for (int b = 0; b < TCI; ++b) {
                 const int ci = ci_base + 16 * b + cc;
-                bv[u][b] = (rv && ci < Ci) ? X[r * Ci + ci] : 0.f;
+                float xv = 0.f;
+                if (rv && ci < Ci) xv = (X2 == nullptr || ci < split) ? X[r * (X2 ? split : Ci) + ci] : X2[r * (Ci - split) + (ci - split)];
+                bv[u][b] = xv;
             }
         }
 #pragma unroll
@@ -755,7 +758,12 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
                                                               int transpose_w, float* __restrict__ Y,
                                                               float* __restrict__ stat_partial /*[nblk][Co][4] or null*/,
                                                               const float* __restrict__ Y2 = nullptr,
-                                                              const float* __restrict__ pro = nullptr, float slope = 1.f) {
+                                                              const float* __restrict__ pro = nullptr, float slope = 1.f,
+                                                              const float* __restrict__ Xb = nullptr, int xsplit = 0,
+                                                              float* __restrict__ Yb = nullptr, int ysplit = 0) {
+    // Xb / xsplit: the operand is the column concatenation [X | Xb] split at column xsplit (the fusion layers' torch.cat,
+    // never materialised); Yb / ysplit: the output columns >= ysplit go to Yb [M, Co - ysplit] (dX of such a layer).
+    // Both splits are multiples of 4.
     extern __shared__ float sW[];                 // [16*TCO][Cip] (+ [5][Cik] prologue coefficients)
     const int Cip = ((Ci + 15) / 16) * 16 + 4;
     const int Cik = ((Ci + 15) / 16) * 16;
@@ -828,7 +836,10 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
                     xv.w = fmaf(al.w * (fmaf(pa.w, yv.w, pb.w) > 0.f ? 1.f : slope), gv.w, fmaf(be.w, yv.w, de.w));
                 }
             } else if (rv) {
-                if (vec) {
+                if (Xb != nullptr) {
+                    if (k0 < xsplit) xv = *reinterpret_cast<const float4*>(X + r * xsplit + k0);
+                    else if (k0 < Ci) xv = *reinterpret_cast<const float4*>(Xb + r * (Ci - xsplit) + (k0 - xsplit));
+                } else if (vec) {
                     if (k0 < Ci) xv = *reinterpret_cast<const float4*>(X + r * Ci + k0);
                 } else {
                     const float* xp = X + r * Ci;
@@ -853,7 +864,11 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
         for (int t = 0; t < TCO; ++t) {
             const int co = co_base + 16 * t + 4 * g;
             if (rv) {
-                if (co + 3 < Co && (Co % 4) == 0) {
+                if (Yb != nullptr) {
+                    const float4 o4 = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+                    if (co < ysplit) *reinterpret_cast<float4*>(Y + r * ysplit + co) = o4;
+                    else if (co < Co) *reinterpret_cast<float4*>(Yb + r * (Co - ysplit) + (co - ysplit)) = o4;
+                } else if (co + 3 < Co && (Co % 4) == 0) {
                     *reinterpret_cast<float4*>(Y + r * Co + co) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
                 } else {
 #pragma unroll
@@ -1018,11 +1033,13 @@ extern "C" size_t crfconv_linear_forward_stat_records(int64_t M) { return (size_
 
 // Y [M, Co] = X [M, Ci] W^T (+ bias);  W is [Co, Ci] row-major, or [Ci, Co] when transpose_w != 0 (the dX product).
 // stat_rec (may be NULL): float [records][Co][4] receives per-workgroup {shift, n, sum(y - shift), sum (y - shift)^2}.
-extern "C" int crfconv_linear_forward(const float* X, const float* W, const float* bias, int64_t M, int Ci, int Co,
-                                      int transpose_w, float* Y, float* stat_rec, crf_stream_t stream) {
+static int linear_forward_impl(const float* X, const float* Xb, int xsplit, const float* W, const float* bias, int64_t M,
+                               int Ci, int Co, int transpose_w, float* Y, float* stat_rec, crf_stream_t stream) {
     CRF_REQUIRE(X && W && Y, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(M > 0, CRF_ERR_ARG, "M must be positive");
     CRF_REQUIRE(crfconv_linear_forward_supported(Ci, Co), CRF_ERR_UNSUPPORTED, "weight slab %dx%d does not fit LDS", Co, Ci);
+    CRF_REQUIRE(Xb == nullptr || (xsplit > 0 && xsplit < Ci && xsplit % 4 == 0 && Ci % 4 == 0), CRF_ERR_ARG,
+                "two-operand form needs 0 < split < Ci, both multiples of 4 (split=%d Ci=%d)", xsplit, Ci);
     const int cip = ((Ci + 15) / 16) * 16 + 4;
     const int tiles = (Co + 15) / 16;
     const int tco = tiles >= 8 ? 8 : (tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1));
@@ -1032,14 +1049,30 @@ extern "C" int crfconv_linear_forward(const float* X, const float* W, const floa
     const size_t lds_stats = sizeof(float) * 4 * 4 * 16 * tco;           // the epilogue reuses the slab as [4][4][16 tco]
     if (lds < lds_stats) lds = lds_stats;
     hipStream_t st = crf::as_stream(stream);
+#define LF(T) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, false>), grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec, (const float*)nullptr, (const float*)nullptr, 1.f, Xb, xsplit, (float*)nullptr, 0)
     switch (tco) {
-        case 1: hipLaunchKernelGGL(crf::linear_fwd_kernel<1>, grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec); break;
-        case 2: hipLaunchKernelGGL(crf::linear_fwd_kernel<2>, grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec); break;
-        case 4: hipLaunchKernelGGL(crf::linear_fwd_kernel<4>, grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec); break;
-        default: hipLaunchKernelGGL(crf::linear_fwd_kernel<8>, grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec); break;
+        case 1: LF(1); break;
+        case 2: LF(2); break;
+        case 4: LF(4); break;
+        default: LF(8); break;
     }
+#undef LF
     CRF_LAUNCH_CHECK();
     return CRF_OK;
+}
+
+// Y [M, Co] = X [M, Ci] W^T (+ bias);  W is [Co, Ci] row-major, or [Ci, Co] when transpose_w != 0 (the dX product).
+// stat_rec (may be NULL): float [records][Co][4] receives per-workgroup {shift, n, sum(y - shift), sum (y - shift)^2}.
+extern "C" int crfconv_linear_forward(const float* X, const float* W, const float* bias, int64_t M, int Ci, int Co,
+                                      int transpose_w, float* Y, float* stat_rec, crf_stream_t stream) {
+    return linear_forward_impl(X, nullptr, 0, W, bias, M, Ci, Co, transpose_w, Y, stat_rec, stream);
+}
+
+// The same on the column concatenation [Xa | Xb] (Xa [M, split], Xb [M, Ci - split]) without materialising it.
+extern "C" int crfconv_linear_forward_cat(const float* Xa, const float* Xb, int split, const float* W, const float* bias,
+                                          int64_t M, int Ci, int Co, float* Y, float* stat_rec, crf_stream_t stream) {
+    CRF_REQUIRE(Xb, CRF_ERR_ARG, "null pointer");
+    return linear_forward_impl(Xa, Xb, split, W, bias, M, Ci, Co, 0, Y, stat_rec, stream);
 }
 
 // BatchNorm coefficients from the records written by crfconv_linear_forward (instead of a statistics pass).
@@ -1105,9 +1138,31 @@ extern "C" size_t crfconv_mlp_backward_workspace(int64_t M, int Ci, int Co) {
     return crf::mlp_ws_layout(M, Co, Ci, off) + 256;
 }
 
+static int mlp_backward_impl(const float* gA, const float* Y, const float* X, const float* Xb, int xsplit, const float* W,
+                             const float* coef, float slope, int64_t M, int Ci, int Co, float* dX, float* dXb, float* dW,
+                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream);
+
 extern "C" int crfconv_mlp_backward(const float* gA, const float* Y, const float* X, const float* W, const float* coef,
                                     float slope, int64_t M, int Ci, int Co, float* dX, float* dW, float* dgamma,
                                     float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream) {
+    return mlp_backward_impl(gA, Y, X, nullptr, 0, W, coef, slope, M, Ci, Co, dX, nullptr, dW, dgamma, dbeta, workspace,
+                             workspace_bytes, stream);
+}
+
+// The block's input was the column concatenation [Xa | Xb]: dXa [M, split], dXb [M, Ci - split] (both or neither NULL).
+extern "C" int crfconv_mlp_backward_cat(const float* gA, const float* Y, const float* Xa, const float* Xb, int split,
+                                        const float* W, const float* coef, float slope, int64_t M, int Ci, int Co,
+                                        float* dXa, float* dXb, float* dW, float* dgamma, float* dbeta, void* workspace,
+                                        size_t workspace_bytes, crf_stream_t stream) {
+    CRF_REQUIRE(Xb && split > 0 && split < Ci && split % 4 == 0 && Ci % 4 == 0 && ((dXa == nullptr) == (dXb == nullptr)),
+                CRF_ERR_ARG, "two-operand form: split=%d Ci=%d must be multiples of 4, dXa / dXb both or neither", split, Ci);
+    return mlp_backward_impl(gA, Y, Xa, Xb, split, W, coef, slope, M, Ci, Co, dXa, dXb, dW, dgamma, dbeta, workspace,
+                             workspace_bytes, stream);
+}
+
+static int mlp_backward_impl(const float* gA, const float* Y, const float* X, const float* Xb, int xsplit, const float* W,
+                             const float* coef, float slope, int64_t M, int Ci, int Co, float* dX, float* dXb, float* dW,
+                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream) {
     CRF_REQUIRE(gA && Y && X && W && coef && dW && dgamma && dbeta && workspace, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(crfconv_mlp_backward_supported(M, Ci, Co) == 1, CRF_ERR_UNSUPPORTED, "shape M=%lld Ci=%d Co=%d not supported",
                 (long long)M, Ci, Co);
@@ -1124,7 +1179,7 @@ extern "C" int crfconv_mlp_backward(const float* gA, const float* Y, const float
     const crf::MlpPlan p = crf::mlp_plan(M, Co, Ci);
     {
         const dim3 grid((unsigned)p.nblk, (unsigned)p.gy, (unsigned)p.gz), blk(crf::WG_BLOCK);
-#define P1(TA, TB) hipLaunchKernelGGL((crf::mlp_bwd_p1_kernel<TA, TB>), grid, blk, 0, st, gA, Y, X, coef, slope, M, Co, Ci, p.rows_per_block, PA, PB, PG, PX)
+#define P1(TA, TB) hipLaunchKernelGGL((crf::mlp_bwd_p1_kernel<TA, TB>), grid, blk, 0, st, gA, Y, X, Xb, xsplit, coef, slope, M, Co, Ci, p.rows_per_block, PA, PB, PG, PX)
         switch (p.tco * 10 + p.tci) {
             case 11: P1(1, 1); break;
             case 12: P1(1, 2); break;
@@ -1151,7 +1206,7 @@ extern "C" int crfconv_mlp_backward(const float* gA, const float* Y, const float
         const int gy = (tiles + tco - 1) / tco;
         const dim3 grid((unsigned)crf::lf_blocks(M), (unsigned)gy), blk(crf::LF_BLOCK);
         const size_t lds = sizeof(float) * ((size_t)16 * tco * cip + 5 * (size_t)cik);
-#define DX(T) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, true>), grid, blk, lds, st, gA, W, (const float*)nullptr, M, gCi, gCo, 1, dX, (float*)nullptr, Y, pro, slope)
+#define DX(T) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, true>), grid, blk, lds, st, gA, W, (const float*)nullptr, M, gCi, gCo, 1, dX, (float*)nullptr, Y, pro, slope, (const float*)nullptr, 0, dXb, xsplit)
         switch (tco) {
             case 1: DX(1); break;
             case 2: DX(2); break;

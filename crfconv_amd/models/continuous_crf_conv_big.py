@@ -47,4 +47,11 @@ class ContinuousGaussianCRFConv(nn.Module):
         field = ops.crf_meanfield(z, guide, self.c, table_of(neighbor_idx, N), self.steps, k0=1,      # k0 = 1: no self edge
                                   matrices=matrices)
         refined = self.out_nn(field.reshape(B, N, H))
-        return self.fusion_nn(torch.cat([refined, pairwise], dim=-1))
+        fus = self.fusion_nn
+        if fus.bn is not None and fus.lin.bias is None and isinstance(fus.activation, nn.LeakyReLU):
+            # fusion_nn(cat[refined, pairwise]) with the concatenation left implicit (two operand pointers)
+            out = ops.mlp_block_cat(refined, pairwise, fus.lin.weight, fus.bn.batch_norm, fus.training,
+                                    fus.activation.negative_slope)
+            if out is not None:
+                return out
+        return fus(torch.cat([refined, pairwise], dim=-1))

@@ -757,6 +757,74 @@ class _MLPBlock(torch.autograd.Function):
         return dX, dW, dgamma, dbeta, None, None, None, None, None
 
 
+_NO_CAT_ENV = __import__('os').environ.get('CRFCONV_NO_CAT_FUSION') is not None      # A/B: materialise torch.cat
+
+
+class _MLPBlockCat(torch.autograd.Function):
+    """_MLPBlock on the column concatenation [xa | xb] without materialising it (the CRF layers'
+    fusion_nn(cat[x, pairwise]), models/continuous_crf_conv_big.py:76): the MFMA kernels read the two operands through
+    two pointers and the backward writes the two input gradients separately -- no torch.cat, no slice copies."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, W, gamma, beta, run_mean, run_var, momentum, eps, slope):
+        xa, xb, Wc = xa.contiguous(), xb.contiguous(), W.contiguous()
+        m, split = xa.shape
+        ci, co = split + xb.shape[1], Wc.shape[0]
+        y = torch.empty((m, co), dtype=torch.float32, device=xa.device)
+        nrec = _lib.load().crfconv_linear_forward_stat_records(m)
+        rec = torch.empty((nrec, 4, co), dtype=torch.float32, device=xa.device)
+        st = stream_ptr()
+        _lib.call('crfconv_linear_forward_cat', ptr(xa), ptr(xb), split, ptr(Wc), None, m, ci, co, ptr(y), ptr(rec), st)
+        coef = torch.empty(4 * co, dtype=torch.float32, device=xa.device)
+        _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
+                  ptr(run_var), float(momentum), float(eps), ptr(coef), st)
+        out = torch.empty_like(y)
+        _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), st)
+        ctx.save_for_backward(xa, xb, Wc, y, coef)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, gA):
+        xa, xb, W, y, coef = ctx.saved_tensors
+        m, split = xa.shape
+        ci, co = split + xb.shape[1], W.shape[0]
+        gA = gA.contiguous()
+        dev = xa.device
+        want_dx = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        dxa = torch.empty_like(xa) if want_dx else None
+        dxb = torch.empty_like(xb) if want_dx else None
+        dW = torch.empty_like(W)
+        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.call('crfconv_mlp_backward_cat', ptr(gA), ptr(y), ptr(xa), ptr(xb), split, ptr(W), ptr(coef), ctx.slope, m, ci, co,
+                  ptr(dxa), ptr(dxb), ptr(dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
+        return (dxa if ctx.needs_input_grad[0] else None, dxb if ctx.needs_input_grad[1] else None, dW, dgamma, dbeta,
+                None, None, None, None, None)
+
+
+def mlp_block_cat(xa, xb, W, bn, training, slope=1.0):
+    """lrelu(BatchNorm(cat[xa, xb] W^T), slope): the two-pointer fused block where it applies (training, MFMA-sized rows,
+    widths multiples of 4), else torch.cat + the one-operand path.  Returns None when the caller should run its own
+    module path (so that non-fusable configurations keep their exact semantics)."""
+    if _NO_CAT_ENV or xa.dim() != xb.dim() or xa.shape[:-1] != xb.shape[:-1]:
+        return None
+    ca, cb = xa.shape[-1], xb.shape[-1]
+    m = xa.numel() // ca
+    probe = xa.new_empty((1, ca + cb))
+    if not (ca % 4 == 0 and cb % 4 == 0 and xb.dtype == torch.float32 and m >= _MFMA_MIN_ROWS
+            and mlp_block_ok(probe.expand(m, ca + cb), W, None, bn, training)):
+        return None
+    require_gpu(xa, xb, W)
+    tick(bn)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    out = _MLPBlockCat.apply(xa.reshape(-1, ca), xb.reshape(-1, cb), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom,
+                             bn.eps, slope)
+    return out.reshape(xa.shape[:-1] + (W.shape[0],))
+
+
 def mlp_block_ok(x, W, bias, bn, training):
     """The fused block applies to the training-mode MLPs of the fine levels (MFMA-sized rows, affine BatchNorm, no bias)."""
     if _UNFUSED_MLP_ENV or not training or bias is not None or x.dtype != torch.float32 or not bn.affine:

@@ -359,6 +359,14 @@ size_t crfconv_mlp_backward_workspace(int64_t M, int Ci, int Co);
 int crfconv_mlp_backward(const float* gA, const float* Y, const float* X, const float* W, const float* coef, float slope,
                          int64_t M, int Ci, int Co, float* dX, float* dW, float* dgamma, float* dbeta, void* workspace,
                          size_t workspace_bytes, crf_stream_t stream);
+/* The block whose input is the column concatenation [Xa | Xb] (the CRF layers' fusion_nn(cat[x, pairwise]),
+ * models/continuous_crf_conv_big.py:76) without materialising it: Xa [M, split], Xb [M, Ci - split], split % 4 == 0;
+ * the forward product is crfconv_linear_forward_cat, the backward writes dXa / dXb separately. */
+int crfconv_linear_forward_cat(const float* Xa, const float* Xb, int split, const float* W, const float* bias, int64_t M,
+                               int Ci, int Co, float* Y, float* stat_rec, crf_stream_t stream);
+int crfconv_mlp_backward_cat(const float* gA, const float* Y, const float* Xa, const float* Xb, int split, const float* W,
+                             const float* coef, float slope, int64_t M, int Ci, int Co, float* dXa, float* dXb, float* dW,
+                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream);
 
 /* Fused BatchNorm (+ LeakyReLU) over rows x [M, C] (models/common.py:31,36-37; C % 4 == 0, C <= 1024).
  * forward:  use_batch_stats != 0 -> statistics of x (biased variance), running stats updated in place when non-NULL

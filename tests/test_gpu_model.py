@@ -741,6 +741,33 @@ def test_mlp_block_fused_backward(M, Ci, Co, slope, need_dx):
     assert int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize('M,Ca,Cb,Co', [(163840, 32, 32, 32), (40960, 64, 64, 64), (10240, 64, 32, 128), (5000, 8, 24, 16)])
+def test_mlp_block_cat_equals_block_on_concatenation(M, Ca, Cb, Co):
+    """ops.mlp_block_cat([xa | xb]) (two operand pointers, separate input gradients) against ops.mlp_block on the
+    materialised torch.cat: same kernels, same summation order -> outputs and every gradient bit-identical."""
+    from crfconv_amd import ops
+    g = torch.Generator().manual_seed(M + Ca)
+    xa = torch.randn(M, Ca, generator=g).to(DEV).requires_grad_(True)
+    xb = torch.randn(M, Cb, generator=g).to(DEV).requires_grad_(True)
+    W = (torch.randn(Co, Ca + Cb, generator=g) / 8).to(DEV).requires_grad_(True)
+    go = torch.randn(M, Co, generator=g).to(DEV)
+    bns = [torch.nn.BatchNorm1d(Co).to(DEV).train() for _ in range(2)]
+    assert ops.mlp_block_cat(xa, xb[:, :3], W, bns[0], True, 0.1) is None      # width not a multiple of 4: caller's own path
+    out = ops.mlp_block_cat(xa, xb, W, bns[0], True, 0.1)
+    assert out is not None
+    out.backward(go)
+    got = [t_.grad.clone() for t_ in (xa, xb, W)] + [bns[0].weight.grad.clone(), bns[0].bias.grad.clone()]
+    for t_ in (xa, xb, W):
+        t_.grad = None
+    ref = ops.mlp_block(torch.cat([xa, xb], 1), W, bns[1], 0.1)
+    ref.backward(go)
+    want = [xa.grad, xb.grad, W.grad, bns[1].weight.grad, bns[1].bias.grad]
+    assert torch.equal(out, ref)
+    for name, a, b in zip(('dxa', 'dxb', 'dW', 'dgamma', 'dbeta'), got, want):
+        assert torch.equal(a, b), name
+    assert torch.equal(bns[0].running_var, bns[1].running_var)
+
+
 @pytest.mark.parametrize('M,C,slope,training', [(163840, 32, 0.1, True), (40960, 8, 1.0, True), (1000, 512, 0.1, True),
                                                 (777, 128, 0.1, False), (33, 1024, 1.0, True), (2560, 256, 0.1, True),
                                                 (640, 512, 1.0, True), (4096, 64, 0.1, True), (4097, 64, 0.1, True),
