@@ -203,6 +203,24 @@ def _median_time(fn, warm, reps):
     return float(np.median(ts)), ts
 
 
+def cpu_share():
+    """Host threads this process may really run: the cgroup CPU quota when there is one (a one-GPU box exposes all of the
+    host's cores but grants a share of them; idle-spinning worker threads beyond the quota get the whole process throttled
+    for the rest of the scheduler period -- seen as 70-90 ms stalls in the per-batch host code), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()                       # cgroup v2
+    except (OSError, ValueError):
+        try:
+            quota = open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read().strip()               # cgroup v1
+            period = open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read().strip()
+        except OSError:
+            return n
+    if quota not in ('max', '-1'):
+        n = min(n, max(1, int(quota) // int(period)))
+    return n
+
+
 def cpu_baseline(data, net, steps_T, labels, n_cls, dev):
     """SURVEY 8(d) CPU plan on this host's cores, bounded to ~30 s: (1) the oracle's fwd+bwd of PointConvBig on ONE of
     the batch's clouds (each cloud is independent work for the reference too: 4 clouds cost 4x; 1 warm-up + 3 timed,
@@ -288,6 +306,7 @@ def main():
     from crfconv_amd import models, ops
 
     rank, world, local = D.init_from_env()
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), cpu_share() // max(1, world), 16)))     # 16 = the share per GPU of the pool's boxes
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -409,6 +428,44 @@ def main():
         torch.cuda.synchronize()
         t_collate.append(tc)
         t_load.append(time.perf_counter() - t0)
+    # the same per-batch work as ONE hipGraph replay (data.CollateGraph: collate + in-place refresh of the static batch)
+    from crfconv_amd.data import CollateGraph
+    t_graph, cg_parts = None, None
+    try:
+        cg = CollateGraph(data, generator=torch.Generator().manual_seed(99 + rank))
+        raw = [synth_cloud(7000 + rank * B + i, N) for i in range(B)]
+        pos_r = torch.from_numpy(np.stack([c[0] for c in raw])).to(dev)
+        x_r = torch.cat([pos_r, torch.from_numpy(np.stack([c[1] for c in raw])).to(dev)], -1)
+        y_r = torch.from_numpy(np.stack([c[2] for c in raw])).to(dev)
+        cg.run(pos_r, x_r, y_r)                           # captures
+        torch.cuda.synchronize()
+        ts = []
+        for rep in range(7):
+            t0 = time.perf_counter()
+            cg.run(pos_r, x_r, y_r)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        t_graph = float(np.median(ts))
+
+        def part(fn):
+            torch.cuda.synchronize()
+            v = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                v.append(time.perf_counter() - t0)
+            return float(np.median(v)) * 1e3
+        from crfconv_amd.data import morton_order
+        cg_parts = {'host_randperm_and_upload_ms': part(cg._draw),
+                    'morton_argsort_eager_ms': part(lambda: cg.order.copy_(morton_order(cg.pos))),
+                    'graph_replay_ms': part(cg.graph.replay), 'all_runs_ms': [round(t * 1e3, 2) for t in ts]}
+    except Exception as e:                                # capture not possible: the eager figures above stand
+        import traceback
+        traceback.print_exc()
+        torch.cuda.synchronize()
+    data.load_(nd)                                        # back to the batch of seed 5200 for the comparison below
+    torch.cuda.synchronize()
     buffers = {k: v.clone() for k, v in net.named_buffers()}
     flat0, mom0 = opt.flat.clone(), opt.buf.clone()
     loss_graph = float(step())                          # replay on the batch loaded last (seed 5200)
@@ -444,7 +501,10 @@ def main():
              'note': 'fresh batch -> MultiScaleData.load_ into the static buffers -> hipGraph replay, against an eager step '
                      'from the same weights on an independent collate of the same clouds; the two losses differ only by the '
                      'Dropout(0.5) draws of the classifier (different RNG offsets), the refreshed tables are compared bit for bit'}
-    per_batch_ms = ms_per_step + fresh['collate_ms_per_batch'] + fresh['table_refresh_ms_per_batch']
+    fresh['collate_plus_refresh_graph_ms_per_batch'] = None if t_graph is None else t_graph * 1e3
+    fresh['collate_graph_parts'] = cg_parts if t_graph is not None else None
+    per_batch_ms = ms_per_step + (t_graph * 1e3 if t_graph is not None else
+                                  fresh['collate_ms_per_batch'] + fresh['table_refresh_ms_per_batch'])
 
     if rank == 0:
         out = {
@@ -461,6 +521,7 @@ def main():
             'final_loss': float(loss),
             'preprocess_ms_per_batch': fresh['collate_ms_per_batch'],
             'table_refresh_ms_per_batch': fresh['table_refresh_ms_per_batch'],
+            'preprocess_plus_refresh_graph_ms_per_batch': fresh['collate_plus_refresh_graph_ms_per_batch'],
             'value_incl_preprocessing': world * B * N / (per_batch_ms * 1e-3) / 1e6,
             'fresh_batch_replay': fresh,
             'launch_mode': graph_note,

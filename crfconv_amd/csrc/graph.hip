@@ -3,7 +3,7 @@
 // scan are rocPRIM device primitives, the rest are flat coalesced kernels.
 #include "common.hpp"
 
-#include <rocprim/rocprim.hpp>
+#include "scan.hpp"
 
 namespace crf {
 
@@ -67,42 +67,57 @@ __global__ __launch_bounds__(256) void narrow_sorted_kernel(const int64_t* __res
 
 // edge ids 0..E-1 and sort keys: the source row, or m_src for "no neighbour" entries (< 0), which
 // therefore sort behind every real row and fall outside rev_ptr[0 .. m_src].
-__global__ __launch_bounds__(256) void iota_keys_kernel(const int32_t* __restrict__ idx, int64_t n, int64_t m_src,
-                                                        uint32_t* __restrict__ ids, uint32_t* __restrict__ keys) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    ids[t] = (uint32_t)t;
-    const int32_t v = idx[t];
-    keys[t] = (v < 0 || v >= m_src) ? (uint32_t)m_src : (uint32_t)v;
-}
-
-// sorted keys -> rev_ptr: ptr[v] = first position p with key[p] >= v, for v in [0, m_src].
-__global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t* __restrict__ keys,
-                                                         int64_t E, int64_t m_src,
-                                                         int32_t* __restrict__ ptr) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p > E) return;
-    // position p closes every source id in (key[p-1], key[p]]  (key[-1] = -1, key[E] = m_src)
-    const int64_t lo = p == 0 ? -1 : (int64_t)keys[p - 1];
-    int64_t hi = p == E ? m_src : (int64_t)keys[p];
-    if (hi > m_src) hi = m_src;
-    for (int64_t v = lo + 1; v <= hi; ++v) ptr[v] = (int32_t)p;
-}
-
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static int key_bits(int64_t m_src) {   // keys take values 0 .. m_src (m_src = the "missing" bucket)
-    int bits = 1;
-    while (((int64_t)1 << bits) <= m_src) ++bits;
-    return bits;
+// ------------------------------------------------------------------ reverse CSR by counting sort (no library sort)
+// keys (source rows, m_src = "missing") are bounded and a kNN-style graph has ~K edges per row: histogram -> exclusive
+// scan -> fill (cursor atomics: arbitrary order inside a row) -> per-row rank sort of the edge ids, which restores the
+// ascending (= stable) order every consumer's fixed summation order relies on.  Seven small launches, none of which needs
+// scratch memory: rocPRIM's onesweep radix sort (eleven launches per table, private segment of 80 B) FAULTED when it was
+// replayed from a captured hipGraph with eager launches in between (ROCm 7.2; data.CollateGraph), and was the largest
+// single cost of the per-batch table refresh.
+__global__ __launch_bounds__(256) void rev_count_kernel(const int32_t* __restrict__ idx, int64_t E, int64_t m_src,
+                                                        int32_t* __restrict__ cnt) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int32_t v = idx[e];
+    atomicAdd(&cnt[(v < 0 || v >= m_src) ? m_src : v], 1);
 }
 
-static size_t sort_temp_bytes(int64_t E, int64_t m_src) {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                    (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)E, 0,
-                                    key_bits(m_src), (hipStream_t)0);
-    return bytes;
+__global__ __launch_bounds__(256) void rev_fill_kernel(const int32_t* __restrict__ idx, int64_t E, int64_t m_src,
+                                                       const int32_t* __restrict__ ptrs, int32_t* __restrict__ cursor,
+                                                       int32_t* __restrict__ tmp_eid) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int32_t v = idx[e];
+    if (v < 0 || v >= m_src) return;
+    tmp_eid[ptrs[v] + atomicAdd(&cursor[v], 1)] = (int32_t)e;
+}
+
+// one wavefront per source row: rank of every edge id among the row's ids (ids are distinct) = its sorted position
+__global__ __launch_bounds__(256) void rev_sort_rows_kernel(const int32_t* __restrict__ ptrs, const int32_t* __restrict__ tmp_eid,
+                                                            int64_t m_src, int32_t* __restrict__ rev_eid) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= m_src) return;
+    const int beg = ptrs[j], len = ptrs[j + 1] - beg;
+    if (len <= 64) {
+        const int32_t v = lane < len ? tmp_eid[beg + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int k = 0; k < len; ++k) rank += __shfl(v, k, WAVE) < v ? 1 : 0;
+        if (lane < len) rev_eid[beg + rank] = v;
+    } else {                                            // long rows (rare): every lane ranks its ids against the whole row
+        for (int i = lane; i < len; i += 64) {
+            const int32_t v = tmp_eid[beg + i];
+            int rank = 0;
+            for (int k = 0; k < len; ++k) rank += tmp_eid[beg + k] < v ? 1 : 0;
+            rev_eid[beg + rank] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* __restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0;
 }
 
 }  // namespace crf
@@ -152,8 +167,10 @@ extern "C" int crfconv_index_narrow_sorted(const int64_t* idx64, int64_t B, int6
 
 extern "C" size_t crfconv_reverse_csr_workspace(int64_t E, int64_t m_src) {
     if (E <= 0 || m_src <= 0) return 0;
-    // [keys_in E][keys_out E][vals_in E][sort temp]
-    return 3 * align_up(sizeof(uint32_t) * (size_t)E) + align_up(sort_temp_bytes(E, m_src)) + 256;
+    // [cnt m_src + 1][cursor m_src + 1][block sums][tmp_eid E]
+    const size_t nb = (size_t)cdiv(m_src + 1, SCAN_EPB);
+    return 2 * align_up(sizeof(int32_t) * (size_t)(m_src + 1)) + align_up(sizeof(int32_t) * nb) +
+           align_up(sizeof(int32_t) * (size_t)E) + 256;
 }
 
 extern "C" int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_src, int32_t* rev_ptr,
@@ -167,20 +184,20 @@ extern "C" int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_sr
                 workspace_bytes, need);
     hipStream_t st = as_stream(stream);
     char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    const size_t seg = align_up(sizeof(uint32_t) * (size_t)E);
-    uint32_t* keys_in = reinterpret_cast<uint32_t*>(ws);
-    uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + seg);
-    uint32_t* vals_in = reinterpret_cast<uint32_t*>(ws + 2 * seg);
-    void* temp = ws + 3 * seg;
-    size_t temp_bytes = sort_temp_bytes(E, m_src);
-
-    hipLaunchKernelGGL(iota_keys_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, st, idx32, E, m_src, vals_in, keys_in);
-    CRF_LAUNCH_CHECK();
-    // stable LSD radix sort by source row: edge ids stay ascending inside each group
-    CRF_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in,
-                                      reinterpret_cast<uint32_t*>(rev_eid), (size_t)E, 0, key_bits(m_src), st));
-    hipLaunchKernelGGL(boundaries_kernel, dim3((unsigned)cdiv(E + 1, 256)), dim3(256), 0, st, keys_out, E,
-                       m_src, rev_ptr);
+    const int64_t n = m_src + 1, nb = cdiv(n, SCAN_EPB);
+    const size_t seg = align_up(sizeof(int32_t) * (size_t)n);
+    int32_t* cnt = reinterpret_cast<int32_t*>(ws);
+    int32_t* cursor = reinterpret_cast<int32_t*>(ws + seg);
+    int32_t* sums = reinterpret_cast<int32_t*>(ws + 2 * seg);
+    int32_t* tmp_eid = reinterpret_cast<int32_t*>(ws + 2 * seg + align_up(sizeof(int32_t) * (size_t)nb));
+    const dim3 blk(256), egrid((unsigned)cdiv(E, 256));
+    int64_t zg = cdiv((int64_t)(2 * seg / 4), 256);
+    if (zg > 1024) zg = 1024;
+    hipLaunchKernelGGL(zero_i32_kernel, dim3((unsigned)zg), blk, 0, st, cnt, (int64_t)(2 * seg / 4));          // cnt + cursor
+    hipLaunchKernelGGL(rev_count_kernel, egrid, blk, 0, st, idx32, E, m_src, cnt);
+    exclusive_scan_i32(cnt, rev_ptr, n, sums, st);
+    hipLaunchKernelGGL(rev_fill_kernel, egrid, blk, 0, st, idx32, E, m_src, rev_ptr, cursor, tmp_eid);
+    hipLaunchKernelGGL(rev_sort_rows_kernel, dim3((unsigned)cdiv(m_src, 4)), blk, 0, st, rev_ptr, tmp_eid, m_src, rev_eid);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

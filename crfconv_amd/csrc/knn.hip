@@ -11,8 +11,9 @@
 //   (nanoflann.hpp:342-347); neighbours ascending by (distance, point id).
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
-#include <rocprim/rocprim.hpp>
+#include "scan.hpp"
 
 namespace crf {
 
@@ -86,6 +87,10 @@ __device__ __forceinline__ int3 cell_of(const GridInfo& g, float x, float y, flo
     cy = min(max(cy, 0), g.ny - 1);
     cz = min(max(cz, 0), g.nz - 1);
     return make_int3(cx, cy, cz);
+}
+
+__global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------ 2. histogram
@@ -291,9 +296,7 @@ static KnnLayout knn_layout(size_t B, size_t npts) {
     L.off_fill = o;   o += al(sizeof(int32_t) * ncell_total);   // counts and fill are zeroed together
     L.off_starts = o; o += al(sizeof(int32_t) * ncell_total);
     L.off_sorted = o; o += al(sizeof(float4) * B * npts);
-    size_t tb = 0;
-    (void)rocprim::exclusive_scan(nullptr, tb, (const int32_t*)nullptr, (int32_t*)nullptr, 0, ncell_total,
-                                  rocprim::plus<int32_t>(), (hipStream_t)0);
+    const size_t tb = sizeof(int32_t) * scan_block_sums((int64_t)ncell_total);
     L.temp_bytes = tb;
     L.off_temp = o;   o += al(tb);
     L.total = o + 256;
@@ -332,15 +335,22 @@ extern "C" int crfconv_knn_batch_dev(const float* pts, size_t batch_size, size_t
     void* temp = ws + L.off_temp;
     const size_t ncell_total = batch_size * (size_t)L.ncell_alloc + 1;
 
-    CRF_HIP(hipMemsetAsync(counts, 0, L.off_starts - L.off_counts, st));  // counts + fill
+    // counts + fill.  A kernel, not hipMemsetAsync: captured into a hipGraph, the memset NODE of this call faulted ("Memory
+    // access fault ... write access to a read-only page") as soon as any eager launch ran between two replays (ROCm 7.2,
+    // scratch/cg_diag2.py), while kernel nodes replay fine.
+    {
+        const size_t n16 = (L.off_starts - L.off_counts) / 16;            // the regions are 256-byte aligned
+        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)std::min<size_t>(1024, (n16 + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<uint4*>(counts), n16);
+        CRF_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)batch_size), dim3(1024), 0, st, pts, (int64_t)npts, L.G0, info);
     CRF_LAUNCH_CHECK();
     const dim3 pgrid((unsigned)cdiv((int64_t)npts, 256), (unsigned)batch_size);
     hipLaunchKernelGGL(cell_count_kernel, pgrid, dim3(256), 0, st, pts, (int64_t)npts, info, L.ncell_alloc,
                        cell_id, counts);
     CRF_LAUNCH_CHECK();
-    size_t tb = L.temp_bytes;
-    CRF_HIP(rocprim::exclusive_scan(temp, tb, counts, starts, 0, ncell_total, rocprim::plus<int32_t>(), st));
+    exclusive_scan_i32(counts, starts, (int64_t)ncell_total, reinterpret_cast<int32_t*>(temp), st);
     hipLaunchKernelGGL(cell_scatter_kernel, pgrid, dim3(256), 0, st, pts, (int64_t)npts, L.ncell_alloc, cell_id,
                        starts, fill, sorted);
     CRF_LAUNCH_CHECK();

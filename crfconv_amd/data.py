@@ -134,7 +134,7 @@ def _fps_choice(pos, n_sample):
 
 def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kernel_size=(16, 16, 16, 16, 16),
                        ratio=(4, 4, 4, 4, 2), num_scales=5, generator=None, choices=None, sort=None,
-                       sample_method='random'):
+                       sample_method='random', order=None):
     """The reference collate on the device (datasets/semantic3d_dataset.py:512-528):
     per scale  neighbor_idx = knn(pos, pos, K);  one random subset shared by all clouds;
     sub_idx = neighbor_idx[:, choice];  up_idx = knn(sub_pos, pos, 1).
@@ -152,9 +152,9 @@ def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kern
     the same cloud-by-cloud; kernels are correct for ANY order, this only buys locality."""
     if sort is None:
         sort = 'morton' if choices is None else 'none'
-    order = None
     if sort == 'morton':
-        order = morton_order(pos)
+        if order is None:                      # `order` [B, N]: a Morton permutation the caller already has (CollateGraph)
+            order = morton_order(pos)
 
         def perm(t):
             if t is None or not torch.is_tensor(t) or t.dim() < 2 or t.shape[1] != pos.shape[1]:
@@ -194,3 +194,71 @@ def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kern
         multiscale.append(Data(pos=pos, neighbor_idx=neighbor_idx, sub_idx=sub_idx, up_idx=up_idx))
         pos = sub_pos
     return MultiScaleData(x=x, y=y, point_idx=point_idx, cloud_idx=cloud_idx, multiscale=multiscale, order=order)
+
+
+class CollateGraph:
+    """The per-batch preprocessing of a FIXED batch shape as ONE hipGraph replay: the device collate
+    (``multiscale_compute``: Morton sort, kNN at every scale, subsets, up-indices) followed by ``target.load_`` (copies into
+    the static batch a captured training step reads + in-place refresh of its neighbour tables, reverse CSRs and rel-pos
+    moments).  Run eagerly the same work is ~470 launches and host-bound (5 ms of wall time for 3 ms of kernels).
+
+    The Morton argsort and the random subsets stay OUTSIDE the graph; the subsets are drawn on the host (``torch.randperm`` with the caller's generator, as the
+    reference does at datasets/semantic3d_dataset.py:517) and copied into static index tensors; everything data-dependent
+    inside the graph is shape-static.
+
+        cg = CollateGraph(static_batch, generator=g)      # static_batch: the MultiScaleData the training graph was captured on
+        cg.run(pos, x, y)                                 # new clouds [B, N, 3] / [B, N, C] / [B, N] on the device
+        train_graph.replay()
+    """
+
+    def __init__(self, target, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), generator=None):
+        self.target, self.kernel_size, self.ratio, self.generator = target, tuple(kernel_size), tuple(ratio), generator
+        ms = target.multiscale
+        dev = ms[0].pos.device
+        self.pos = torch.empty_like(ms[0].pos)
+        self.x = None if target.x is None else torch.empty_like(target.x)
+        self.y = None if target.y is None else torch.empty_like(target.y)
+        self.sizes = [lvl.pos.shape[1] for lvl in ms]
+        self.order = torch.empty(ms[0].pos.shape[:2], dtype=torch.int64, device=dev)
+        self.choices = [torch.empty(n // r, dtype=torch.int64, device=dev) for n, r in zip(self.sizes, self.ratio)]
+        self._pinned = [torch.empty(c.shape, dtype=torch.int64).pin_memory() for c in self.choices]
+        # host buffers allocated once: a process that holds GPU memory pays for every large host malloc/free pair (the
+        # unmap goes through the driver's MMU notifier -- measured 70-90 ms stalls in a loop that allocated per batch)
+        self._perm = [torch.empty(n, dtype=torch.int64) for n in self.sizes]
+        self._rank = [torch.empty(c.shape, dtype=torch.int64) for c in self.choices]
+        self.graph = None
+
+    def _draw(self):
+        for n, r, dst, pin, perm, rank in zip(self.sizes, self.ratio, self.choices, self._pinned, self._perm, self._rank):
+            torch.randperm(n, generator=self.generator, out=perm)
+            torch.sort(perm[: n // r], out=(pin, rank))                                          # ascending: levels stay sorted
+            dst.copy_(pin, non_blocking=True)
+
+    def _work(self):
+        new = multiscale_compute(self.pos, x=self.x, y=self.y, kernel_size=self.kernel_size, ratio=self.ratio,
+                                 num_scales=len(self.sizes), choices=self.choices, sort='morton', order=self.order)
+        self.target.load_(new)
+
+    def run(self, pos, x=None, y=None):
+        self.pos.copy_(pos)
+        if self.x is not None:
+            self.x.copy_(x)
+        if self.y is not None:
+            self.y.copy_(y)
+        self._draw()
+        # the Morton argsort stays OUTSIDE the graph: the framework's radix sort needs scratch memory, and kernel nodes
+        # with a private segment are not safe to replay between eager launches on ROCm 7.2 (csrc/graph.hip); everything
+        # inside the graph is this library's own scratch-free kernels plus elementwise / index framework kernels
+        self.order.copy_(morton_order(self.pos))
+        if self.graph is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._work()                                  # warm-up outside the capture (allocator, lazy tables)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._work()
+        self.graph.replay()
+        return self.target

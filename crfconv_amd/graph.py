@@ -91,6 +91,9 @@ class NeighborTable:
         """One host sync: refuses tables with out-of-range entries (they were clamped, so nothing
         can fault, but the result would be meaningless)."""
         if not self._checked:
+            if torch.cuda.is_current_stream_capturing():
+                return             # no host sync inside a capture: out-of-range entries were clamped (nothing can fault),
+                                   # the count stays in self._bad for a later validate()
             bad = int(self._bad.item())
             if bad:
                 raise IndexError('%d neighbour indices outside [0, %d)' % (bad, self.n_src))

@@ -7,7 +7,8 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [re.sub(r"\(.*", "", r['Kernel_Name']).replace('void ', '') for r in rows]
 sg = [i for i, n in enumerate(names) if 'sgd' in n]
-a, b = sg[-2] + 1, sg[-1] + 1
+which = int(sys.argv[3]) if len(sys.argv) > 3 else len(sg) // 2      # a replay in the middle of the timed loop (the tail of bench.py runs eager steps)
+a, b = sg[which - 1] + 1, sg[which] + 1
 step, sn = rows[a:b], names[a:b]
 t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
 busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in step)

@@ -325,6 +325,43 @@ def test_b1_is_supported():
     assert_close(one, two[:4096], OUT_TOL, 'B=1 vs B=2')
 
 
+def test_collate_graph_replay_equals_eager_collate():
+    """data.CollateGraph: the device collate + the in-place refresh of the static batch as ONE hipGraph replay.  After
+    cg.run(new clouds) the static batch (tensors AND derived tables / reverse CSRs / moments) must equal an eager collate of
+    the same clouds with the same subsets, for several successive batches through the same captured graph."""
+    import crfconv_amd
+    from crfconv_amd import models, ops
+    from crfconv_amd.data import CollateGraph
+    from crfconv_amd.graph import table_of
+    B, N = 2, 4096
+
+    def clouds(seed):
+        pos = np.stack([S.make_cloud(seed + b, N, box=(2, 2, 1)) for b in range(B)])
+        feats = np.concatenate([pos, S.uniform(seed, 'rgb', (B, N, 3), 0, 1)], -1)
+        return t(pos), t(feats), t(S.integers(seed, 'y', (B, N), 0, 14))
+    pos0, x0, y0 = clouds(500)
+    static = crfconv_amd.multiscale_compute(pos0, x=x0, y=y0, generator=torch.Generator().manual_seed(1))
+    net = models.PointConvBig(6, 13, True, 3).to(DEV).train()
+    ops.training_loss(net(static), static.y, None, ignore_index=-1).backward()       # every table / CSR / moment exists
+    cg = CollateGraph(static, generator=torch.Generator().manual_seed(7))
+    for seed in (510, 520, 530):
+        pos, x, y = clouds(seed)
+        cg.run(pos, x, y)
+        ref = crfconv_amd.multiscale_compute(pos, x=x, y=y, choices=[c.clone() for c in cg.choices], sort='morton')
+        assert torch.equal(static.x, ref.x) and torch.equal(static.y, ref.y)
+        for a, b in zip(static.multiscale, ref.multiscale):
+            for name in ('pos', 'neighbor_idx', 'sub_idx', 'up_idx'):
+                assert torch.equal(getattr(a, name), getattr(b, name)), (seed, name)
+            for name in ('neighbor_idx', 'sub_idx', 'up_idx'):
+                idx_s, idx_r = getattr(a, name), getattr(b, name)
+                for key, (tab_s, _) in getattr(idx_s, '_crf_tables', {}).items():      # (the last level's sub / up tables are never built)
+                    tab_r = table_of(idx_r, key[0])
+                    assert torch.equal(tab_s.idx32, tab_r.idx32)
+                    if tab_s._rev is not None:
+                        assert all(torch.equal(u, v) for u, v in zip(tab_s.reverse, tab_r.reverse))
+                    assert int(tab_s._bad.item()) == 0
+
+
 def test_multiscale_compute_fps_branch():
     """sample_method='fps' (datasets/semantic3d_dataset.py:520-523): per-cloud farthest-point subsets, first pick point 0,
     each later pick the farthest from the picks before it (numpy restatement); sub_pos / sub_idx gathered per cloud and
