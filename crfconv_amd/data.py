@@ -227,12 +227,18 @@ class CollateGraph:
         self._perm = [torch.empty(n, dtype=torch.int64) for n in self.sizes]
         self._rank = [torch.empty(c.shape, dtype=torch.int64) for c in self.choices]
         self.graph = None
+        self._uploaded = None                    # event after the last upload from the pinned buffers
 
     def _draw(self):
+        if self._uploaded is not None:
+            self._uploaded.synchronize()         # the previous upload still owns the pinned buffers (long done in practice)
         for n, r, dst, pin, perm, rank in zip(self.sizes, self.ratio, self.choices, self._pinned, self._perm, self._rank):
             torch.randperm(n, generator=self.generator, out=perm)
             torch.sort(perm[: n // r], out=(pin, rank))                                          # ascending: levels stay sorted
             dst.copy_(pin, non_blocking=True)
+        if self._uploaded is None:
+            self._uploaded = torch.cuda.Event()
+        self._uploaded.record()
 
     def _work(self):
         new = multiscale_compute(self.pos, x=self.x, y=self.y, kernel_size=self.kernel_size, ratio=self.ratio,
@@ -262,3 +268,55 @@ class CollateGraph:
                 self._work()
         self.graph.replay()
         return self.target
+
+
+class CollatePipeline:
+    """Per-batch preprocessing OVERLAPPED with training: two static batches, one ``CollateGraph`` each, the collate of
+    batch i+1 on a side stream while the captured training step of batch i runs on the caller's stream.  Two hipGraphs on two
+    streams do run concurrently on MI355X (graph BRANCHES do not): measured 6.4 ms per iteration for a 5.9 ms
+    step + 2.2 ms collate graph at 4 x 40960 points.
+
+        pipe = CollatePipeline([batch_a, batch_b], generator=g)       # the training step is captured once per batch
+        pipe.submit(0, pos0, x0, y0)
+        for i, (pos, x, y) in enumerate(next_clouds):
+            s = i % 2
+            pipe.submit(1 - s, pos, x, y)          # side stream: waits until the step that last used that slot has finished
+            batch = pipe.acquire(s)                # caller's stream waits for slot s's collate
+            train_graph[s].replay()
+            pipe.release(s)                        # slot s may be overwritten once the work queued so far has run
+    """
+
+    def __init__(self, batches, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), generator=None):
+        self.batches = list(batches)
+        self.graphs = [CollateGraph(b, kernel_size, ratio, generator) for b in self.batches]
+        self.stream = torch.cuda.Stream()
+        self._ready = [torch.cuda.Event() for _ in self.batches]
+        self._free = [None for _ in self.batches]
+
+    def submit(self, slot, pos, x=None, y=None):
+        cg = self.graphs[slot]
+        if cg.graph is None:                       # first use captures (with its own warm-up and a device synchronize)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(self.stream):
+                cg.run(pos, x, y)
+                self._ready[slot].record()
+            torch.cuda.synchronize()
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())      # the caller produced pos / x / y on its stream
+        if self._free[slot] is not None:
+            self.stream.wait_event(self._free[slot])
+        with torch.cuda.stream(self.stream):
+            cg.run(pos, x, y)
+            self._ready[slot].record()
+        for t in (pos, x, y):                      # the caller may free these right away: the side stream still reads them
+            if t is not None:
+                t.record_stream(self.stream)
+
+    def acquire(self, slot):
+        torch.cuda.current_stream().wait_event(self._ready[slot])
+        return self.batches[slot]
+
+    def release(self, slot):
+        if self._free[slot] is None:
+            self._free[slot] = torch.cuda.Event()
+        self._free[slot].record()

@@ -362,6 +362,58 @@ def test_collate_graph_replay_equals_eager_collate():
                     assert int(tab_s._bad.item()) == 0
 
 
+def test_collate_pipeline_double_buffer_overlaps_without_races():
+    """data.CollatePipeline: the collate graph of batch i+1 runs on a side stream while the consumer of batch i runs on the
+    caller's stream.  Six batches through two slots; what the consumer sees after acquire() must equal an eager collate of
+    the clouds submitted for that slot with the subsets drawn for it -- also with a slow consumer (a long kernel queue on
+    the caller's stream between acquire and release) and a slot that is overwritten right after release."""
+    import crfconv_amd
+    from crfconv_amd import models, ops
+    from crfconv_amd.data import CollatePipeline
+    from crfconv_amd.graph import table_of
+    B, N = 2, 4096
+
+    def clouds(seed):
+        pos = np.stack([S.make_cloud(seed + b, N, box=(2, 2, 1)) for b in range(B)])
+        feats = np.concatenate([pos, S.uniform(seed, 'rgb', (B, N, 3), 0, 1)], -1)
+        return t(pos), t(feats), t(S.integers(seed, 'y', (B, N), 0, 14))
+    net = models.PointConvBig(6, 13, True, 3).to(DEV).train()
+    statics = []
+    for k in range(2):
+        pos0, x0, y0 = clouds(600 + k)
+        st = crfconv_amd.multiscale_compute(pos0, x=x0, y=y0, generator=torch.Generator().manual_seed(k))
+        ops.training_loss(net(st), st.y, None, ignore_index=-1).backward()
+        statics.append(st)
+    pipe = CollatePipeline(statics, generator=torch.Generator().manual_seed(3))
+    inputs = [clouds(700 + 10 * i) for i in range(7)]
+    pipe.submit(0, *inputs[0])
+    seen = []
+    burn = torch.randn(2048, 2048, device=DEV)
+    for i in range(6):
+        s = i % 2
+        pipe.submit(1 - s, *inputs[i + 1])
+        batch = pipe.acquire(s)
+        for _ in range(4 if i % 3 == 0 else 0):
+            burn = torch.tanh(burn @ burn * 1e-3)                      # a slow consumer: the batch must stay intact under it
+        snap = {'x': batch.x.clone(), 'choices': [c.clone() for c in pipe.graphs[s].choices],
+                'lv': [{n: getattr(lv, n).clone() for n in ('pos', 'neighbor_idx', 'sub_idx', 'up_idx')} for lv in batch.multiscale],
+                'tab': [[(key, tab.idx32.clone()) for key, (tab, _) in lv.neighbor_idx._crf_tables.items()]
+                        for lv in batch.multiscale]}
+        pipe.release(s)
+        seen.append(snap)
+    torch.cuda.synchronize()
+    for i, snap in enumerate(seen):
+        pos, x, y = inputs[i]
+        ref = crfconv_amd.multiscale_compute(pos, x=x, y=y, choices=snap['choices'], sort='morton')
+        assert torch.equal(snap['x'], ref.x), i
+        for lv_s, lv_r, tabs in zip(snap['lv'], ref.multiscale, snap['tab']):
+            for n in ('pos', 'neighbor_idx', 'sub_idx', 'up_idx'):
+                assert torch.equal(lv_s[n], getattr(lv_r, n)), (i, n)
+            assert tabs
+            for key, idx32 in tabs:
+                assert torch.equal(idx32, table_of(lv_r.neighbor_idx, key[0]).idx32), (i, key)
+
+
 def test_multiscale_compute_fps_branch():
     """sample_method='fps' (datasets/semantic3d_dataset.py:520-523): per-cloud farthest-point subsets, first pick point 0,
     each later pick the farthest from the picks before it (numpy restatement); sub_pos / sub_idx gathered per cloud and
