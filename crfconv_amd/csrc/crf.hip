@@ -14,6 +14,7 @@
 //
 // Reference semantics: models/continuous_crf_conv_big.py:49-54 (similarity), :63-72 (loop).
 #include "common.hpp"
+#include "gridsync.hpp"
 
 #include <cstdlib>
 
@@ -238,80 +239,6 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
 // before the workgroup arrives; they are only ever read by `sc1` buffer loads (L1 bypassed), and no line of xs[t] is
 // read by anyone before the barrier that follows its last store (MI355X_MICROARCH.md, inter-workgroup visibility).
 // Every workgroup must be resident at once: the host checks the grid against the occupancy query and refuses otherwise.
-constexpr int FW_LINE = 32;                   // words per 128-byte line
-constexpr int FW_CNT = 0, FW_TOP = 8, FW_GEN = 9, FW_FAIL = 17, FW_EXIT = 18, FW_WORDS = 19 * FW_LINE;
-constexpr unsigned FW_SPIN_LIMIT = 1u << 21;  // ~1 s: a stranded workgroup gives up with a code instead of hanging
-
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, sbase, 16);    // aux 16 = sc1
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ float4 ld4_buf(__amdgpu_buffer_rsrc_t r, int byte_off) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ void st4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, float4 v) {
-    const u32x4_t u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 16);
-}
-
-// phase = 1, 2, ...: counters only grow within a launch (zero at entry: the previous launch's last workgroup out resets
-// them, fused_exit_reset).  Returns false (for the whole workgroup) when the spin gave up.
-// (Polling the generation word with a returning atomic, or a fresh word per phase, measured the same: the barrier costs
-// 1.0-1.3 us after the last arrival either way -- profiles/r2a_fused_meanfield_stamps.txt.)
-template <bool STAMP>
-__device__ __forceinline__ bool fused_grid_sync(unsigned* ws, unsigned phase, unsigned n_in_group, unsigned n_groups,
-                                                int* s_ok, unsigned long long* dbg) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if constexpr (STAMP) dbg[(size_t)blockIdx.x * 64 + 8 * phase + 4] = __builtin_amdgcn_s_memrealtime();
-        const unsigned g = blockIdx.x & 7u;
-        unsigned* gen = ws + (FW_GEN + g) * FW_LINE;
-        const unsigned old = __hip_atomic_fetch_add(ws + (FW_CNT + g) * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1 == n_in_group * phase) {
-            const unsigned o2 = __hip_atomic_fetch_add(ws + FW_TOP * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (o2 + 1 == n_groups * phase) {
-                if constexpr (STAMP) dbg[(size_t)blockIdx.x * 64 + 8 * phase + 6] = __builtin_amdgcn_s_memrealtime();
-                for (unsigned g2 = 0; g2 < n_groups; ++g2)
-                    __hip_atomic_store(ws + (FW_GEN + g2) * FW_LINE, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        if constexpr (STAMP) dbg[(size_t)blockIdx.x * 64 + 8 * phase + 5] = __builtin_amdgcn_s_memrealtime();
-        int ok = 1;
-        unsigned spins = 0;
-        for (;;) {
-            if (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= phase) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > FW_SPIN_LIMIT) {
-                __hip_atomic_store(ws + FW_FAIL * FW_LINE, 0x100u | phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-        }
-        *s_ok = ok;
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
-
-// Last workgroup out zeroes the barrier words for the next launch (every workgroup has passed every barrier by then):
-// no memset node in front of the kernel (4 us of stream time per forward).  ws must be zero before the FIRST launch.
-__device__ __forceinline__ void fused_exit_reset(unsigned* ws, unsigned nblk, int T) {
-    if (threadIdx.x == 0 && T > 1) {
-        const unsigned old = __hip_atomic_fetch_add(ws + FW_EXIT * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1 == nblk) {
-            for (int l = 0; l < FW_WORDS / FW_LINE; ++l)
-                if (l != FW_FAIL) __hip_atomic_store(ws + l * FW_LINE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 // Thread mapping of the fused kernel: EIGHT channels per lane (two float4), so a point takes LPP = H/8 lanes (one lane
 // at H = 8 or 4).  At the headline shape (163 840 points, H = 8) that is 2560 wavefronts = ten per CU: one 640-thread
 // workgroup per CU, 256 arrivals per barrier.  (Four channels per lane, as the per-step kernels use, needs two 10-wave
@@ -501,7 +428,7 @@ __global__ __launch_bounds__(NT) void mf_fused_kernel(const float* __restrict__ 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             FUSED_STAMP(8 * t + 0);                                  // own stores drained
         }
-        if (!fused_grid_sync<STAMP>(ws, (unsigned)t, n_in_group, n_groups, &s_ok, dbg)) return;
+        if (!fused_grid_sync<STAMP>(ws, (unsigned)t, n_in_group, n_groups, &s_ok, dbg, blockIdx.x)) return;
         FUSED_STAMP(8 * t + 1);                                      // barrier left
         const int base = (t - 1) * step_bytes;
 #pragma unroll

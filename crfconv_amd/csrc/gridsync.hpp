@@ -1,0 +1,96 @@
+// Grid-wide arrival barrier for kernels whose workgroups are ALL resident at once (the host checks the grid against the
+// occupancy query), plus the write-through / L1-bypassing buffer accesses that carry data between workgroups inside one
+// launch.  Used by the one-launch mean-field forward (crf.hip) and the small-level Linear + BatchNorm kernels
+// (mlp_small.hip).
+//
+// Protocol (MI355X_MICROARCH.md, inter-workgroup visibility): a producer stores write-through (`sc1`), drains its stores
+// (`s_waitcnt vmcnt(0)`), the workgroup arrives; consumers read what other workgroups produced with `sc1` loads (L1 is
+// never refreshed by another CU's stores) after leaving the barrier.  Two levels: groups of blockIdx % 8 (one XCD under
+// the dispatcher's round-robin placement -- for speed only), then one top counter; 1.0-1.7 us after the last arrival.
+#pragma once
+#include "common.hpp"
+
+namespace crf {
+
+constexpr int FW_LINE = 32;                   // words per 128-byte line
+constexpr int FW_CNT = 0, FW_TOP = 8, FW_GEN = 9, FW_FAIL = 17, FW_EXIT = 18, FW_WORDS = 19 * FW_LINE;
+constexpr unsigned FW_SPIN_LIMIT = 1u << 21;  // ~1 s: a stranded workgroup gives up with a code instead of hanging
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, sbase, 16);    // aux 16 = sc1
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float4 ld4_buf(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void st4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, float4 v) {
+    const u32x4_t u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 16);
+}
+
+// phase = 1, 2, ...: counters only grow within a launch (zero at entry: the previous launch's last workgroup out resets
+// them, fused_exit_reset).  Returns false (for the whole workgroup) when the spin gave up.
+// (Polling the generation word with a returning atomic, or a fresh word per phase, measured the same: the barrier costs
+// 1.0-1.3 us after the last arrival either way -- profiles/r2a_fused_meanfield_stamps.txt.)
+template <bool STAMP>
+__device__ __forceinline__ bool fused_grid_sync(unsigned* ws, unsigned phase, unsigned n_in_group, unsigned n_groups,
+                                                int* s_ok, unsigned long long* dbg, unsigned bid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if constexpr (STAMP) dbg[(size_t)bid * 64 + 8 * phase + 4] = __builtin_amdgcn_s_memrealtime();
+        const unsigned g = bid & 7u;
+        unsigned* gen = ws + (FW_GEN + g) * FW_LINE;
+        const unsigned old = __hip_atomic_fetch_add(ws + (FW_CNT + g) * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == n_in_group * phase) {
+            const unsigned o2 = __hip_atomic_fetch_add(ws + FW_TOP * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (o2 + 1 == n_groups * phase) {
+                if constexpr (STAMP) dbg[(size_t)bid * 64 + 8 * phase + 6] = __builtin_amdgcn_s_memrealtime();
+                for (unsigned g2 = 0; g2 < n_groups; ++g2)
+                    __hip_atomic_store(ws + (FW_GEN + g2) * FW_LINE, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if constexpr (STAMP) dbg[(size_t)bid * 64 + 8 * phase + 5] = __builtin_amdgcn_s_memrealtime();
+        int ok = 1;
+        unsigned spins = 0;
+        for (;;) {
+            if (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= phase) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > FW_SPIN_LIMIT) {
+                __hip_atomic_store(ws + FW_FAIL * FW_LINE, 0x100u | phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+// Last workgroup out zeroes the barrier words for the next launch (every workgroup has passed every barrier by then):
+// no memset node in front of the kernel (4 us of stream time per forward).  ws must be zero before the FIRST launch.
+// Group sizes for a launch of nblk workgroups numbered bid = 0..nblk-1 (group = bid % 8).
+__device__ __forceinline__ void grid_sync_groups(unsigned nblk, unsigned bid, unsigned& n_in_group, unsigned& n_groups) {
+    const unsigned grp = bid & 7u;
+    n_in_group = nblk / 8u + (grp < (nblk & 7u) ? 1u : 0u);
+    n_groups = nblk < 8u ? nblk : 8u;
+}
+
+__device__ __forceinline__ void fused_exit_reset(unsigned* ws, unsigned nblk, int T) {
+    if (threadIdx.x == 0 && T > 1) {
+        const unsigned old = __hip_atomic_fetch_add(ws + FW_EXIT * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == nblk) {
+            for (int l = 0; l < FW_WORDS / FW_LINE; ++l)
+                if (l != FW_FAIL) __hip_atomic_store(ws + l * FW_LINE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace crf

@@ -757,6 +757,72 @@ class _MLPBlock(torch.autograd.Function):
         return dX, dW, dgamma, dbeta, None, None, None, None, None
 
 
+_NO_SMALL_MLP_ENV = __import__('os').environ.get('CRFCONV_NO_SMALL_MLP') is not None      # A/B: vendor GEMM + bn_small at the coarse levels
+_sync_ws = {}
+
+
+def gridsync_ws(dev):
+    """The barrier words of the one-launch kernels (csrc/gridsync.hpp): zeroed once, left zero by every launch.  One buffer
+    per device: launches that use it must be ordered (one training stream per process -- the collate side stream of
+    data.CollatePipeline launches no such kernel).  Created by the un-captured warm-up pass every graph capture needs."""
+    key = dev.index
+    ws = _sync_ws.get(key)
+    if ws is None:
+        nbytes = _lib.load().crfconv_gridsync_workspace()
+        ws = _sync_ws[key] = torch.zeros(nbytes // 4, dtype=torch.int32, device=dev)
+    return ws
+
+
+def _mlp_small_ok(m, ci, co):
+    return (not _NO_SMALL_MLP_ENV) and m < _MFMA_MIN_ROWS and _lib.load().crfconv_mlp_small_supported(m, ci, co) == 1
+
+
+class _MLPSmall(torch.autograd.Function):
+    """_MLPBlock for the coarse levels (m <= 4096 rows): forward in ONE launch (csrc/mlp_small.hip: MFMA tile, statistic
+    records, grid barrier, BatchNorm + LeakyReLU on the tile in registers)."""
+
+    @staticmethod
+    def forward(ctx, x, W, gamma, beta, run_mean, run_var, momentum, eps, slope):
+        x = x.contiguous()
+        Wc = W.contiguous()
+        m, ci = x.shape
+        co = Wc.shape[0]
+        dev = x.device
+        y = torch.empty((m, co), dtype=torch.float32, device=dev)
+        out = torch.empty_like(y)
+        coef = torch.empty(4 * co, dtype=torch.float32, device=dev)
+        nbytes = _lib.load().crfconv_mlp_small_workspace(m, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        sync = gridsync_ws(dev)
+        _lib.call('crfconv_mlp_small_forward', ptr(x), ptr(Wc), m, ci, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
+                  ptr(run_var), float(momentum), float(eps), float(slope), ptr(y), ptr(out), ptr(coef), ptr(ws), nbytes,
+                  ptr(sync), sync.numel() * 4, stream_ptr())
+        ctx.save_for_backward(x, Wc, y, coef)
+        ctx.slope = float(slope)
+        ctx.params = (W, None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gA):
+        x, W, y, coef = ctx.saved_tensors
+        m, ci = x.shape
+        co = W.shape[0]
+        gA = gA.contiguous()
+        dev = x.device
+        gY = torch.empty_like(y)
+        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        nbytes = _lib.load().crfconv_bn_workspace(m, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.call('crfconv_bn_backward', ptr(gA), ptr(y), ptr(coef), m, co, 1, ctx.slope, ptr(gY), ptr(dgamma), ptr(dbeta),
+                  ptr(ws), nbytes, stream_ptr())
+        dX = gY @ W if ctx.needs_input_grad[0] else None
+        if _defer_ok(ctx.params):
+            _defer_weight_grad(gY, x, ctx.params, False)
+            return dX, None, dgamma, dbeta, None, None, None, None, None
+        return dX, gY.t() @ x, dgamma, dbeta, None, None, None, None, None
+
+
 _NO_CAT_ENV = __import__('os').environ.get('CRFCONV_NO_CAT_FUSION') is not None      # A/B: materialise torch.cat
 
 
@@ -831,7 +897,11 @@ def mlp_block_ok(x, W, bias, bn, training):
         return False
     m = x.numel() // x.shape[-1]
     ci, co = x.shape[-1], W.shape[0]
-    return (_mfma_ok(m, ci, co) and co % 4 == 0 and bn.running_mean is not None
+    if bn.running_mean is None:
+        return False
+    if _mlp_small_ok(m, ci, co):
+        return True
+    return (_mfma_ok(m, ci, co) and co % 4 == 0
             and _lib.load().crfconv_mlp_backward_supported(m, ci, co) == 1)
 
 
@@ -841,8 +911,9 @@ def mlp_block(x, W, bn, slope=1.0):
     shape = x.shape
     tick(bn)
     mom = 0.1 if bn.momentum is None else bn.momentum
-    out = _MLPBlock.apply(x.reshape(-1, shape[-1]), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps,
-                          slope)
+    x2 = x.reshape(-1, shape[-1])
+    fn = _MLPSmall if _mlp_small_ok(x2.shape[0], shape[-1], W.shape[0]) else _MLPBlock
+    out = fn.apply(x2, W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, slope)
     return out.reshape(shape[:-1] + (W.shape[0],))
 
 

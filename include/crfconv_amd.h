@@ -346,6 +346,22 @@ int crfconv_linear_wgrad_partial(const float* G, const float* X, int64_t M, int 
                                  void* workspace, size_t workspace_bytes, int* nblk_out, crf_stream_t stream);
 int crfconv_reduce_jobs(const crf_reduce_job* jobs, int njobs, crf_stream_t stream);
 
+/* Linear -> BatchNorm(train) -> LeakyReLU of the coarse levels as ONE launch (csrc/mlp_small.hip): replaces the
+ * nn.Linear + FastBatchNorm1d + activation chain of models/common.py:34-40 where m <= 4096 rows (encoder / decoder
+ * levels 3-5 of models/point_conv_big.py:113-131).  A 64 x 64 tile of Y = X W^T per workgroup on the fp32 matrix cores,
+ * per-tile statistic records, a grid barrier (every workgroup resident: _supported checks the device), float64
+ * coefficients, BatchNorm + LeakyReLU applied to the tile still in registers.  Y [M, Co] (kept for the backward),
+ * A [M, Co], coef [4, Co] = a | b | mean | rstd as crfconv_bn_forward writes it; running statistics updated when given.
+ * workspace: crfconv_mlp_small_workspace bytes.  sync_ws: crfconv_gridsync_workspace() bytes that are ZERO before the
+ * first launch using them (the kernel leaves them zero; word 17 * 32 is non-zero only after a barrier that gave up). */
+size_t crfconv_gridsync_workspace(void);
+int crfconv_mlp_small_supported(int64_t M, int Ci, int Co);
+size_t crfconv_mlp_small_workspace(int64_t M, int Co);
+int crfconv_mlp_small_forward(const float* X, const float* W, int64_t M, int Ci, int Co, const float* gamma,
+                              const float* beta, float* run_mean, float* run_var, float momentum, float eps, float slope,
+                              float* Y, float* A, float* coef, void* workspace, size_t workspace_bytes, void* sync_ws,
+                              size_t sync_bytes, crf_stream_t stream);
+
 /* Backward of one MLP block  A = lrelu(BN_train(X W^T), slope)  (models/common.py:34-40, batch statistics) in two passes
  * over the activations and three launches: pass 1 streams (gA, Y, X) once and leaves the partials of sum g1, sum g1 yh,
  * G1^T X, Yh^T X and 1^T X (g1 = gA lrelu'(a y + b), yh = (y - mean) rstd; two MFMA accumulator sets share the X

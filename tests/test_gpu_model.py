@@ -792,7 +792,11 @@ def test_linear_wgrad_mfma(M, Ci, Co, bias):
 
 @pytest.mark.parametrize('M,Ci,Co,slope,need_dx', [(163840, 32, 8, 0.1, True), (163840, 6, 32, 0.1, False), (40960, 64, 16, 1.0, True),
                                                    (163840, 32, 128, 0.1, True), (10240, 128, 32, 0.1, True), (4100, 24, 64, 0.1, True),
-                                                   (40963, 16, 64, 1.0, True), (10240, 32, 128, 1.0, True)])
+                                                   (40963, 16, 64, 1.0, True), (10240, 32, 128, 1.0, True),
+                                                   # coarse levels: the one-launch forward of csrc/mlp_small.hip (grid barrier)
+                                                   (2560, 256, 64, 0.1, True), (2560, 64, 256, 1.0, True), (1280, 512, 128, 0.1, True),
+                                                   (1280, 128, 512, 1.0, True), (4095, 512, 512, 0.1, True), (1000, 80, 192, 0.2, True),
+                                                   (64, 16, 64, 0.1, True), (37, 144, 64, 1.0, False)])
 def test_mlp_block_fused_backward(M, Ci, Co, slope, need_dx):
     """ops.mlp_block (Linear -> train-mode BatchNorm -> LeakyReLU as one node, csrc/linear.hip: mlp_bwd_p1 / finalize /
     dX with the BatchNorm-backward prologue) against float64 torch.  As in test_fused_batchnorm_lrelu the LeakyReLU
@@ -807,7 +811,12 @@ def test_mlp_block_fused_backward(M, Ci, Co, slope, need_dx):
         bn.weight.copy_(torch.rand(Co, generator=g) + 0.5); bn.bias.copy_(torch.rand(Co, generator=g) * 0.6 - 0.3)
     bn = bn.to(DEV).train()
     assert ops.mlp_block_ok(x, W, None, bn, True)
+    small = M < ops._MFMA_MIN_ROWS
+    assert ops._mlp_small_ok(M, Ci, Co) == small
     out = ops.mlp_block(x, W, bn, slope)
+    if small:
+        assert '_MLPSmall' in out.grad_fn.next_functions[0][0].name()
+        assert int(ops.gridsync_ws(DEV).abs().sum()) == 0          # no barrier gave up, and the words are back to zero
     out.backward(go)
     ref = torch.nn.BatchNorm1d(Co).to(DEV).double().train()
     ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in torch.nn.BatchNorm1d(Co).state_dict().items()})
