@@ -1085,6 +1085,9 @@ __global__ __launch_bounds__(BLOCK) void bwd_prepare_kernel(const float* __restr
 
 // One source row per L * EP lanes (Scat<H>).  LAST (t = 1): also sum_t G_t, dz = G_0 + (sum_t G_t) Q^T and, for
 // H in {8, 16}, this block's partial of dQ = z^T sum_t G_t (OuterAcc) -- otherwise sumG is written for the caller.
+#ifndef CHAIN_TAIL
+#define CHAIN_TAIL 1
+#endif
 template <int H, bool LAST>
 __global__ __launch_bounds__(BLOCK) void bwd_chain_kernel(const float* __restrict__ gm, const RevRec* __restrict__ rec,
                                                           const int32_t* __restrict__ rev_ptr,
@@ -1111,8 +1114,12 @@ __global__ __launch_bounds__(BLOCK) void bwd_chain_kernel(const float* __restric
     // UB records per lane first, then their UB row gathers: two dependent memory phases per EP * UB edges of a row (a
     // kNN graph's in-degree is ~K, so one or two rounds) instead of one record -> gather chain per EP edges.  (A lane
     // taking UB CONSECUTIVE records as two dwordx4 loads measured slower, 18.3 vs 14.8 us: the tail rounds diverge.)
+    // The kernel is bound by vector-memory issue (a wave-wide load costs its ~22 clk whether or not lanes are masked), so
+    // the first round takes EP * UB = 16 edges of a row and later rounds -- only the rows of above-average in-degree
+    // need them -- EP * TB edges: 8 + 2 TB ceil((max degree - 16) / (EP TB)) load instructions per wave instead of 16.
     constexpr int UB = 4;
-    for (int p0 = beg + el; p0 < end; p0 += EP * UB) {
+    int p0 = beg + el;
+    if (p0 < end) {
         RevRec rr[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -1125,6 +1132,21 @@ __global__ __launch_bounds__(BLOCK) void bwd_chain_kernel(const float* __restric
         for (int u = 0; u < UB; ++u) g[u] = ld4(gm + (int64_t)rr[u].i * H + 4 * q);
 #pragma unroll
         for (int u = 0; u < UB; ++u) acc = fma4(rr[u].s, g[u], acc);
+    }
+    constexpr int TB = CHAIN_TAIL;
+    for (p0 += EP * UB; p0 < end; p0 += EP * TB) {
+        RevRec rr[TB];
+#pragma unroll
+        for (int u = 0; u < TB; ++u) {
+            const int p = p0 + u * EP;
+            rr[u] = rec[p < end ? p : beg];
+            if (p >= end) rr[u].s = 0.f;
+        }
+        float4 g[TB];
+#pragma unroll
+        for (int u = 0; u < TB; ++u) g[u] = ld4(gm + (int64_t)rr[u].i * H + 4 * q);
+#pragma unroll
+        for (int u = 0; u < TB; ++u) acc = fma4(rr[u].s, g[u], acc);
     }
     acc = fold_edge_lanes<H>(acc);                  // every edge-lane group holds the row's sum
     __syncthreads();
