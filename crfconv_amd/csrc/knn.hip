@@ -261,6 +261,119 @@ __global__ __launch_bounds__(QBLOCK) void knn_query_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------ small clouds: no grid, sixteen lanes per query
+// The grid search above is ONE lane per query walking ~100 dependent (cell start -> candidates) round trips: its time
+// barely depends on the number of queries (213 us for 4 x 40960 self-queries, still 123 us for 4 x 320), so the coarse
+// levels of the collate cost as much as the fine ones.  For clouds of <= BRUTE_MAX points every query instead looks at
+// EVERY point of its cloud, sixteen lanes per query: lane l ranks candidates l, l + 16, ... (same 64-bit (distance, id)
+// keys, same parked-insert queue), starting at the query's own neighbourhood in memory order -- the collate keeps every
+// level Morton-sorted, so the first window already gives a tight bound -- then the sixteen sorted lists are merged by
+// K rounds of group-wide minimum.  No grid construction (seven launches less per call), results identical: the K smallest
+// keys of a set do not depend on the order they are offered in.
+constexpr int BRUTE_MAX = 4096, BRUTE_LPQ = 16, BRUTE_BLOCK = 256, BRUTE_QPB = BRUTE_BLOCK / BRUTE_LPQ;
+
+__device__ __forceinline__ unsigned long long group16_min(unsigned long long v) {
+#pragma unroll
+    for (int o = 1; o < BRUTE_LPQ; o <<= 1) {
+        const unsigned long long w = __shfl_xor(v, o, WAVE);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+template <int KM>      // K == KM exactly
+__global__ __launch_bounds__(BRUTE_BLOCK) void knn_brute_kernel(const float* __restrict__ pts, int64_t npts,
+                                                                const float* __restrict__ queries, int64_t nq,
+                                                                int64_t* __restrict__ out64, int32_t* __restrict__ out32) {
+    constexpr bool QUEUED = KM > 1;
+    __shared__ unsigned long long s_queue[QUEUED ? QCAP * BRUTE_BLOCK : 1];
+    const int b = blockIdx.y;
+    const int l = threadIdx.x & (BRUTE_LPQ - 1);
+    int64_t qi = (int64_t)blockIdx.x * BRUTE_QPB + (threadIdx.x >> 4);
+    const bool qvalid = qi < nq;
+    if (!qvalid) qi = nq - 1;                              // keep every lane in the wave-wide votes and shuffles
+    const float* qp = queries + ((int64_t)b * nq + qi) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const float* P = pts + (int64_t)b * npts * 3;
+    const int n = (int)npts;
+    // scan order: start 32 points before the query's proportional position in the candidate array, wrap around
+    int start = ((int)((qi * npts) / nq) - 32) % n;
+    if (start < 0) start += n;
+
+    TopK<KM> best;
+    best.init(KM);
+    int cnt = 0;
+    unsigned long long bound = KNN_KEY_INF;
+    auto flush = [&]() {
+        if constexpr (QUEUED) {
+            for (int i = 0; i < QCAP; ++i) {
+                if (!__any(i < cnt)) break;
+                if (i < cnt) best.offer(s_queue[i * BRUTE_BLOCK + threadIdx.x]);
+            }
+            cnt = 0;
+            // every lane of the group may use the smallest K-th key among the sixteen lists: that list alone already
+            // holds K candidates at or below it
+            bound = group16_min(best.kth_key());
+        }
+    };
+    auto consider = [&](float px, float py, float pz, int id, bool live) {
+        const unsigned long long key = knn_key(sqdist_exact(qx, qy, qz, px, py, pz), id);
+        if constexpr (QUEUED) {
+            if (live && key < bound) {
+                s_queue[cnt * BRUTE_BLOCK + threadIdx.x] = key;
+                ++cnt;
+            }
+            if (__any(cnt == QCAP)) flush();
+        } else {
+            if (live) best.offer(key);
+        }
+    };
+    const int rounds = (n + BRUTE_LPQ - 1) / BRUTE_LPQ;
+    int t = 0;
+    for (; t + 4 <= rounds; t += 4) {                      // four candidates per lane in flight
+        int id[4];
+        float c[4][3];
+        bool live[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = (t + u) * BRUTE_LPQ + l;
+            live[u] = i < n;
+            int j = start + (live[u] ? i : 0);
+            if (j >= n) j -= n;
+            id[u] = j;
+            c[u][0] = P[3 * j]; c[u][1] = P[3 * j + 1]; c[u][2] = P[3 * j + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) consider(c[u][0], c[u][1], c[u][2], id[u], live[u]);
+        if (t == 0) flush();                               // the first window fixes a tight bound early
+    }
+    for (; t < rounds; ++t) {
+        const int i = t * BRUTE_LPQ + l;
+        const bool live = i < n;
+        int j = start + (live ? i : 0);
+        if (j >= n) j -= n;
+        consider(P[3 * j], P[3 * j + 1], P[3 * j + 2], j, live);
+    }
+    flush();
+    // merge: K rounds, each takes the smallest head of the sixteen lists; the owning lane drops it
+    const int64_t o = ((int64_t)b * nq + qi) * KM;
+#pragma unroll 1
+    for (int k = 0; k < KM; ++k) {
+        const unsigned long long mine = best.key[0];
+        const unsigned long long mn = group16_min(mine);
+        if (mine == mn) {                                  // keys are unique (ids are): exactly one lane
+#pragma unroll
+            for (int i = 0; i + 1 < KM; ++i) best.key[i] = best.key[i + 1];
+            best.key[KM - 1] = KNN_KEY_INF;
+        }
+        if (l == 0 && qvalid) {
+            const int id = (int)(unsigned int)(mn & 0xffffffffull);
+            if (out64) out64[o + k] = id;
+            if (out32) out32[o + k] = id;
+        }
+    }
+}
+
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static double knn_points_per_cell() {
@@ -325,6 +438,20 @@ extern "C" int crfconv_knn_batch_dev(const float* pts, size_t batch_size, size_t
     const KnnLayout L = knn_layout(batch_size, npts);
     CRF_REQUIRE(workspace_bytes >= L.total, CRF_ERR_WORKSPACE, "knn workspace %zu < %zu", workspace_bytes, L.total);
     hipStream_t st = as_stream(stream);
+    static const bool no_brute = getenv("CRFCONV_KNN_NO_BRUTE") != nullptr;       // A/B: always the grid search
+    if (!no_brute && npts <= (size_t)BRUTE_MAX && (K == 1 || K == 8 || K == 16 || K == 32)) {
+        const dim3 bgrid((unsigned)cdiv((int64_t)nqueries, BRUTE_QPB), (unsigned)batch_size);
+#define KNN_BRUTE(KM)                                                                                       \
+    hipLaunchKernelGGL(knn_brute_kernel<KM>, bgrid, dim3(BRUTE_BLOCK), 0, st, pts, (int64_t)npts, queries, \
+                       (int64_t)nqueries, out_i64, out_i32)
+        if (K == 1) KNN_BRUTE(1);
+        else if (K == 8) KNN_BRUTE(8);
+        else if (K == 16) KNN_BRUTE(16);
+        else KNN_BRUTE(32);
+#undef KNN_BRUTE
+        CRF_LAUNCH_CHECK();
+        return CRF_OK;
+    }
     char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     GridInfo* info = reinterpret_cast<GridInfo*>(ws + L.off_info);
     int32_t* cell_id = reinterpret_cast<int32_t*>(ws + L.off_cellid);

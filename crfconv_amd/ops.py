@@ -820,7 +820,11 @@ class _MLPSmall(torch.autograd.Function):
         if _defer_ok(ctx.params):
             _defer_weight_grad(gY, x, ctx.params, False)
             return dX, None, dgamma, dbeta, None, None, None, None, None
-        return dX, gY.t() @ x, dgamma, dbeta, None, None, None, None, None
+        dW = torch.empty((co, ci), dtype=torch.float32, device=dev)          # same partials + reduction as the deferred form
+        nb = _lib.load().crfconv_linear_wgrad_workspace(m, co, ci)
+        wsw = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _lib.call('crfconv_linear_wgrad', ptr(gY), ptr(x), m, co, ci, ptr(dW), None, ptr(wsw), nb, stream_ptr())
+        return dX, dW, dgamma, dbeta, None, None, None, None, None
 
 
 _NO_CAT_ENV = __import__('os').environ.get('CRFCONV_NO_CAT_FUSION') is not None      # A/B: materialise torch.cat
