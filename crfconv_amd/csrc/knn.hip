@@ -261,6 +261,180 @@ __global__ __launch_bounds__(QBLOCK) void knn_query_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------ 5b. query, sixteen lanes per query (K <= 16)
+// The one-lane search above is a chain of ~100 dependent round trips per query (cell start -> candidates, segment by
+// segment).  Here the row segments of a ring are dealt over the SIXTEEN lanes of a query group (four queries per
+// wavefront): ring 1 = the 3 x 3 x 3 cube as nine x-rows, ring r >= 2 = the shell's 8r face rows (full x-span, one
+// contiguous candidate range each) plus two end cells for each of its (2r - 1)^2 inner rows.  (A first round of the
+// nine centre rows FIVE cells wide, so that cube 2 needs only its sixteen face rows afterwards, measured slower -- 371
+// against 233 us: indoor clouds are surfaces, an occupied cell holds several points, and the rank selection is quadratic
+// in the candidates that arrive before a bound exists.)  Accepted keys
+// (key < bound) are appended to a per-query LDS pool (LDS atomic slot counter); after every ring -- and whenever the
+// pool could overflow -- the group ranks the pool entries against each other (entry i's rank = number of smaller keys)
+// and the sixteen smallest land, sorted, in slots 0..15: that is the running top-K, its last key the new bound, and
+// at the end the output row.  Same keys, same stop test -> same tables as the one-lane kernel.
+constexpr int CO_LPQ = 16, CO_BLOCK = 256, CO_QPB = CO_BLOCK / CO_LPQ, CO_CAP = 128, CO_CHUNK = 4;
+constexpr int CO_ROUND = CO_LPQ * CO_CHUNK;          // appends of one chunk round at most
+
+template <int KM>      // K <= KM <= 16
+__global__ __launch_bounds__(CO_BLOCK) void knn_coop_kernel(const float* __restrict__ queries, int64_t nq, int K,
+                                                            const GridInfo* __restrict__ info, int ncell_alloc,
+                                                            const int32_t* __restrict__ starts,
+                                                            const float4* __restrict__ sorted,
+                                                            int64_t* __restrict__ out64, int32_t* __restrict__ out32) {
+    static_assert(KM <= 16, "the running top-K lives in pool slots 0..15");
+    __shared__ unsigned long long s_pool[2][CO_QPB][CO_CAP];       // double-buffered: a compaction writes the other buffer
+    __shared__ int s_cnt[CO_QPB];
+    const int b = blockIdx.y;
+    const int l = threadIdx.x & (CO_LPQ - 1), qs = threadIdx.x >> 4;
+    const int gshift = (threadIdx.x & 63) & ~(CO_LPQ - 1);         // first lane of this group inside its wavefront
+    int64_t qi = (int64_t)blockIdx.x * CO_QPB + qs;
+    const bool qvalid = qi < nq;
+    if (!qvalid) qi = nq - 1;
+    const GridInfo g = info[b];
+    const float* qp = queries + ((int64_t)b * nq + qi) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const int3 c = cell_of(g, qx, qy, qz);
+    const int32_t* st = starts + (int64_t)b * ncell_alloc;
+    unsigned long long* pool = s_pool[0][qs];
+    int which = 0;
+    if (l == 0) s_cnt[qs] = 0;
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long bound = KNN_KEY_INF;
+
+    // rank selection: slots 0..min(n, 16)-1 of the OTHER buffer <- the smallest keys in ascending order
+    auto compact = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        const int n = s_cnt[qs];
+        unsigned long long* dst = s_pool[which ^ 1][qs];
+        for (int i = l; i < n; i += CO_LPQ) {                    // this lane's entries, one after the other
+            const unsigned long long mine = pool[i];
+            int rank = 0;
+            int j = 0;
+            for (; j + 4 <= n; j += 4) {                         // one address per group and read: LDS broadcasts
+                const unsigned long long p0 = pool[j], p1 = pool[j + 1], p2 = pool[j + 2], p3 = pool[j + 3];
+                rank += (p0 < mine ? 1 : 0) + (p1 < mine ? 1 : 0) + (p2 < mine ? 1 : 0) + (p3 < mine ? 1 : 0);
+            }
+            for (; j < n; ++j) rank += pool[j] < mine ? 1 : 0;
+            if (rank < 16) dst[rank] = mine;
+        }
+        const int m = n < 16 ? n : 16;
+        if (l == 0) s_cnt[qs] = m;
+        which ^= 1;
+        pool = dst;
+        __builtin_amdgcn_wave_barrier();
+        bound = m >= K ? pool[K - 1] : KNN_KEY_INF;
+    };
+    // this lane's candidate range [pb, pe) of the ring's slot `s`; empty when the slot lies outside the grid
+    auto segment = [&](int r, int s, int& pb, int& pe) {
+        pb = pe = 0;
+        int dz, dy, xa, xb;
+        const int side = 2 * r + 1;
+        if (r == 1) {
+            if (s >= 9) return;
+            dz = s / 3 - 1; dy = s % 3 - 1; xa = c.x - 1; xb = c.x + 1;
+        } else {
+            const int nface = 8 * r, inner = side - 2;
+            if (s < nface) {
+                if (s < side) { dz = -r; dy = s - r; }
+                else if (s < 2 * side) { dz = r; dy = s - side - r; }
+                else { const int k = s - 2 * side; dz = (k >> 1) - r + 1; dy = (k & 1) ? r : -r; }
+                xa = c.x - r; xb = c.x + r;
+            } else {
+                const int k = s - nface;
+                if (k >= 2 * inner * inner) return;
+                const int row = k >> 1;
+                const int rq = (int)(((float)row + 0.5f) / (float)inner);      // row / inner (the margin 0.5 / inner >> float error)
+                dz = rq - r + 1; dy = row - rq * inner - r + 1;
+                xa = xb = (k & 1) ? c.x + r : c.x - r;
+                if (xa < 0 || xa >= g.nx) return;
+            }
+        }
+        const int z = c.z + dz, y = c.y + dy;
+        if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) return;
+        xa = max(xa, 0); xb = min(xb, g.nx - 1);
+        if (xa > xb) return;
+        const int rowbase = (z * g.ny + y) * g.nx;
+        pb = st[rowbase + xa];
+        pe = st[rowbase + xb + 1];
+    };
+    const int rmax = max(g.nx, max(g.ny, g.nz));
+    int room = CO_CAP;                                  // free pool slots, counted conservatively (group-uniform)
+    for (int r = 1; r <= rmax; ++r) {
+        const int side = 2 * r + 1;
+        const int nslot = r == 1 ? 9 : 8 * r + 2 * (side - 2) * (side - 2);
+        for (int s0 = 0; s0 < nslot; s0 += CO_LPQ) {
+            int pb, pe;
+            segment(r, s0 + l, pb, pe);
+            for (;;) {
+                const unsigned long long vote = __ballot(pb < pe);
+                if (((vote >> gshift) & 0xffffull) == 0ull) break;
+                if (room < CO_ROUND) {                              // the conservative count says the pool could overflow
+                    __builtin_amdgcn_wave_barrier();
+                    room = CO_CAP - s_cnt[qs];
+                    if (room < CO_ROUND) {
+                        compact();
+                        room = CO_CAP - 16;
+                    }
+                }
+                if (bound == KNN_KEY_INF && CO_CAP - room >= K) {
+                    // no exact K-th key yet (fewer than K candidates at the last compaction), but the pool may hold K
+                    // entries by now: the largest of ANY K candidates is an upper bound of the K-th smallest
+                    __builtin_amdgcn_wave_barrier();
+                    if (s_cnt[qs] >= K) {
+                        unsigned long long v = l < K ? pool[l] : 0ull;
+#pragma unroll
+                        for (int o = 1; o < CO_LPQ; o <<= 1) {
+                            const unsigned long long w = __shfl_xor(v, o, WAVE);
+                            v = w > v ? w : v;
+                        }
+                        bound = v + 1ull;                           // the entry itself stays eligible (it is in the pool already)
+                    }
+                }
+                float4 cand[CO_CHUNK];
+#pragma unroll
+                for (int u = 0; u < CO_CHUNK; ++u) cand[u] = sorted[pb + u < pe ? pb + u : (pb < pe ? pb : 0)];
+                unsigned long long key[CO_CHUNK];
+                bool ok[CO_CHUNK];
+                int k = 0;
+#pragma unroll
+                for (int u = 0; u < CO_CHUNK; ++u) {
+                    key[u] = knn_key(sqdist_exact(qx, qy, qz, cand[u].x, cand[u].y, cand[u].z), __float_as_int(cand[u].w));
+                    ok[u] = pb + u < pe && key[u] < bound;
+                    k += ok[u] ? 1 : 0;
+                }
+                if (k > 0) {                                        // one slot reservation per lane and round
+                    int slot = atomicAdd(&s_cnt[qs], k);
+#pragma unroll
+                    for (int u = 0; u < CO_CHUNK; ++u)
+                        if (ok[u]) pool[slot++] = key[u];
+                }
+                room -= CO_ROUND;
+                pb += CO_CHUNK;
+            }
+        }
+        compact();
+        room = CO_CAP - 16;
+        float gap = 3.4e38f;                // as the one-lane kernel: distance to the nearest face of the searched cube
+        if (c.x - r > 0) gap = fminf(gap, qx - (g.ox + (float)(c.x - r) * g.cell));
+        if (c.x + r + 1 < g.nx) gap = fminf(gap, (g.ox + (float)(c.x + r + 1) * g.cell) - qx);
+        if (c.y - r > 0) gap = fminf(gap, qy - (g.oy + (float)(c.y - r) * g.cell));
+        if (c.y + r + 1 < g.ny) gap = fminf(gap, (g.oy + (float)(c.y + r + 1) * g.cell) - qy);
+        if (c.z - r > 0) gap = fminf(gap, qz - (g.oz + (float)(c.z - r) * g.cell));
+        if (c.z + r + 1 < g.nz) gap = fminf(gap, (g.oz + (float)(c.z + r + 1) * g.cell) - qz);
+        if (gap >= 3.0e38f) break;
+        const float safe = gap - g.margin;
+        const float kth = __uint_as_float((unsigned int)(bound >> 32));
+        if (safe > 0.f && bound != KNN_KEY_INF && kth < safe * safe) break;
+    }
+    if (qvalid && l < K) {
+        const int id = (int)(unsigned int)(pool[l] & 0xffffffffull);
+        const int64_t o = ((int64_t)b * nq + qi) * K + l;
+        if (out64) out64[o] = id;
+        if (out32) out32[o] = id;
+    }
+}
+
 // ------------------------------------------------------------------ small clouds: no grid, sixteen lanes per query
 // The grid search above is ONE lane per query walking ~100 dependent (cell start -> candidates) round trips: its time
 // barely depends on the number of queries (213 us for 4 x 40960 self-queries, still 123 us for 4 x 320), so the coarse
@@ -485,6 +659,14 @@ extern "C" int crfconv_knn_batch_dev(const float* pts, size_t batch_size, size_t
 #define KNN_LAUNCH(KM)                                                                                     \
     hipLaunchKernelGGL(knn_query_kernel<KM>, qgrid, dim3(QBLOCK), 0, st, queries, (int64_t)nqueries,       \
                        (int64_t)npts, (int)K, info, L.ncell_alloc, starts, sorted, out_i64, out_i32)
+    static const bool no_coop = getenv("CRFCONV_KNN_NO_COOP") != nullptr;         // A/B: one lane per query
+    if (!no_coop && K > 1 && K <= 16) {
+        const dim3 cgrid((unsigned)cdiv((int64_t)nqueries, CO_QPB), (unsigned)batch_size);
+        hipLaunchKernelGGL(knn_coop_kernel<16>, cgrid, dim3(CO_BLOCK), 0, st, queries, (int64_t)nqueries, (int)K, info,
+                           L.ncell_alloc, starts, sorted, out_i64, out_i32);
+        CRF_LAUNCH_CHECK();
+        return CRF_OK;
+    }
     if (K == 1) KNN_LAUNCH(1);
     else if (K <= 8) KNN_LAUNCH(8);
     else if (K <= 16) KNN_LAUNCH(16);
