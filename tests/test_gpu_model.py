@@ -839,6 +839,49 @@ def test_mlp_block_fused_backward(M, Ci, Co, slope, need_dx):
     assert int(bn.num_batches_tracked) == 1
 
 
+def test_mlp_small_one_launch_kernel_under_graph_replay():
+    """The coarse-level one-launch forward synchronises its workgroups through device words that every launch must leave
+    zero, and exchanges statistic records past L1: captured into a hipGraph and replayed back to back on CHANGING inputs
+    (and between eager launches of the same kernel) every replay must reproduce the eager result bit for bit."""
+    from crfconv_amd import ops
+    M, Ci, Co = 2560, 256, 512
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(M, Ci, generator=g).to(DEV) for _ in range(4)]
+    W = (torch.randn(Co, Ci, generator=g) / 16).to(DEV).requires_grad_(True)
+    go = torch.randn(M, Co, generator=g).to(DEV)
+    bn = torch.nn.BatchNorm1d(Co).to(DEV).train()
+    x_static = xs[0].clone().requires_grad_(True)
+
+    def step():
+        W.grad = x_static.grad = bn.weight.grad = bn.bias.grad = None
+        out = ops.mlp_block(x_static, W, bn, 0.1)
+        out.backward(go)
+        return out.detach(), x_static.grad, W.grad
+
+    eager = []
+    for x in xs:
+        x_static.data.copy_(x)
+        eager.append([t.clone() for t in step()])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = step()
+    for rep in range(3):
+        for i, x in enumerate(xs):
+            x_static.data.copy_(x)
+            graph.replay()
+            if i % 2:
+                ops.mlp_block(xs[(i + 1) % 4], W.detach(), bn, 0.1)           # an eager launch of the same kernel in between
+            for name, a, b in zip(('out', 'dx', 'dW'), outs, eager[i]):
+                assert torch.equal(a, b), (rep, i, name, float((a - b).abs().max()))
+    assert int(ops.gridsync_ws(DEV).abs().sum()) == 0
+
+
 @pytest.mark.parametrize('M,Ca,Cb,Co', [(163840, 32, 32, 32), (40960, 64, 64, 64), (10240, 64, 32, 128), (5000, 8, 24, 16)])
 def test_mlp_block_cat_equals_block_on_concatenation(M, Ca, Cb, Co):
     """ops.mlp_block_cat([xa | xb]) (two operand pointers, separate input gradients) against ops.mlp_block on the

@@ -72,6 +72,30 @@ def test_knn_duplicates_and_errors(nn_mod):
         nn_mod.knn_batch(np.zeros((1, 10, 2), np.float32), np.zeros((1, 10, 2), np.float32), 2)   # dim != 3
 
 
+@pytest.mark.parametrize('Np,K', [(6000, 16), (6000, 8), (6000, 2), (6000, 24), (6000, 1), (3000, 16), (3000, 8), (3000, 32),
+                                  (3000, 1), (4096, 16), (4097, 16), (40, 16)])
+def test_knn_clustered_duplicates_every_search_path(nn_mod, Np, K):
+    """The three searches of csrc/knn.hip on hostile input -- blobs of very different density, a planar sheet, 10 % exact
+    duplicates (ties -> lower id), queries far outside the support -- against the oracle, bit for bit: sixteen lanes per
+    query over the whole cloud (<= 4096 points, K in {1, 8, 16, 32}), sixteen lanes per query on the grid with the LDS
+    rank selection (larger clouds, 1 < K <= 16; the dense blob overflows the candidate pool and forces mid-ring
+    compactions), one lane per query (everything else)."""
+    rng = np.random.default_rng(Np * 131 + K)
+    parts = [rng.normal(0, 0.01, (Np // 4, 3)), rng.normal(2, 0.5, (Np // 4, 3)),
+             np.concatenate([rng.uniform(-3, 3, (Np // 4, 2)), np.full((Np // 4, 1), 0.25)], 1)]
+    rest = Np - 3 * (Np // 4)
+    n_dup = rest // 2
+    parts.append(rng.uniform(-4, 4, (rest - n_dup, 3)))
+    pts = np.concatenate(parts).astype(np.float32)
+    pts = np.concatenate([pts, pts[rng.integers(0, len(pts), n_dup)]])[rng.permutation(Np)]
+    assert pts.shape == (Np, 3)
+    pts = np.stack([pts, pts[::-1] * np.float32(1.5)])                         # two clouds, different scales
+    qry = np.concatenate([pts[:, : Np // 2], pts[:, : Np // 4] * np.float32(3.0) + np.float32(7.0)], 1)
+    for q in (pts, qry):
+        got = nn_mod.knn_batch_device(torch.from_numpy(pts).cuda(), torch.from_numpy(np.ascontiguousarray(q)).cuda(), K)
+        assert np.array_equal(got.cpu().numpy(), onative.oracle_knn_batch(pts, np.ascontiguousarray(q), K))
+
+
 def test_knn_large_properties(nn_mod):
     """~1M-point scene (BASELINE config 5 scale), K=32: size-independent properties + a sampled
     brute-force check on the device."""
