@@ -768,6 +768,7 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
     const int Cip = ((Ci + 15) / 16) * 16 + 4;
     const int Cik = ((Ci + 15) / 16) * 16;
     float* sPro = sW + 16 * TCO * Cip;
+    [[maybe_unused]] float* sTile = sPro + (PRO ? 5 * Cik : 0);          // [4 waves][16][16 TCO + 4] output staging (TCO >= 2)
     if constexpr (PRO) {
         for (int t = threadIdx.x; t < 5 * Cik; t += LF_BLOCK) {
             const int which = t / Cik, k = t - which * Cik;
@@ -813,6 +814,51 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
     bool have_shift = false;
     const int nchunk = (Ci + 15) / 16;
 
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // raw operand fragment(s) of chunk c for row r: X (either layout / the two-pointer form), or (gA, y) with PRO
+    auto load_raw = [&](int64_t r, bool rv, int c, float4& xa, float4& xb2) {
+        const int k0 = 16 * c + 4 * g;
+        xa = zero4;
+        xb2 = zero4;
+        if (!rv || k0 >= Ci) return;
+        if constexpr (PRO) {
+            xa = *reinterpret_cast<const float4*>(X + r * Ci + k0);
+            xb2 = *reinterpret_cast<const float4*>(Y2 + r * Ci + k0);
+        } else if (Xb != nullptr) {
+            if (k0 < xsplit) xa = *reinterpret_cast<const float4*>(X + r * xsplit + k0);
+            else xa = *reinterpret_cast<const float4*>(Xb + r * (Ci - xsplit) + (k0 - xsplit));
+        } else if (vec) {
+            xa = *reinterpret_cast<const float4*>(X + r * Ci + k0);
+        } else {
+            const float* xp = X + r * Ci;
+            xa.x = xp[k0];
+            xa.y = k0 + 1 < Ci ? xp[k0 + 1] : 0.f;
+            xa.z = k0 + 2 < Ci ? xp[k0 + 2] : 0.f;
+            xa.w = k0 + 3 < Ci ? xp[k0 + 3] : 0.f;
+        }
+    };
+    // the MFMA operand of chunk c: the raw fragment, or gY formed from (gA, y) and the staged coefficients
+    auto operand = [&](bool rv, int c, float4 gv, float4 yv) -> float4 {
+        if constexpr (PRO) {
+            const int k0 = 16 * c + 4 * g;
+            float4 xv = zero4;
+            if (rv && k0 < Ci) {
+                const float4 pa = *reinterpret_cast<const float4*>(sPro + k0), pb = *reinterpret_cast<const float4*>(sPro + Cik + k0);
+                const float4 al = *reinterpret_cast<const float4*>(sPro + 2 * Cik + k0), be = *reinterpret_cast<const float4*>(sPro + 3 * Cik + k0);
+                const float4 de = *reinterpret_cast<const float4*>(sPro + 4 * Cik + k0);
+                xv.x = fmaf(al.x * (fmaf(pa.x, yv.x, pb.x) > 0.f ? 1.f : slope), gv.x, fmaf(be.x, yv.x, de.x));
+                xv.y = fmaf(al.y * (fmaf(pa.y, yv.y, pb.y) > 0.f ? 1.f : slope), gv.y, fmaf(be.y, yv.y, de.y));
+                xv.z = fmaf(al.z * (fmaf(pa.z, yv.z, pb.z) > 0.f ? 1.f : slope), gv.z, fmaf(be.z, yv.z, de.z));
+                xv.w = fmaf(al.w * (fmaf(pa.w, yv.w, pb.w) > 0.f ? 1.f : slope), gv.w, fmaf(be.w, yv.w, de.w));
+            }
+            return xv;
+        } else {
+            return gv;
+        }
+    };
+    // (Issuing the operand loads of four row groups in one burst, or prefetching the next group, measured no faster: the
+    // write-heavy shapes run at the ~2.7 TB/s HBM WRITE rate -- 163840 x 8 -> 32 moves 21 MB out in 13 us -- not at a
+    // per-wavefront latency limit.)
     for (int64_t row0 = ((int64_t)blockIdx.x * (LF_BLOCK / WAVE) + wave) * 16; row0 < M;
          row0 += (int64_t)gridDim.x * (LF_BLOCK / WAVE) * 16) {
         const int64_t r = row0 + rr;
@@ -822,33 +868,9 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
         for (int t = 0; t < TCO; ++t) acc[t] = f32x4{bsel[t][0], bsel[t][1], bsel[t][2], bsel[t][3]};
         for (int c = 0; c < nchunk; ++c) {
             const int k0 = 16 * c + 4 * g;
-            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (PRO) {
-                if (rv && k0 < Ci) {
-                    const float4 gv = *reinterpret_cast<const float4*>(X + r * Ci + k0);
-                    const float4 yv = *reinterpret_cast<const float4*>(Y2 + r * Ci + k0);
-                    const float4 pa = *reinterpret_cast<const float4*>(sPro + k0), pb = *reinterpret_cast<const float4*>(sPro + Cik + k0);
-                    const float4 al = *reinterpret_cast<const float4*>(sPro + 2 * Cik + k0), be = *reinterpret_cast<const float4*>(sPro + 3 * Cik + k0);
-                    const float4 de = *reinterpret_cast<const float4*>(sPro + 4 * Cik + k0);
-                    xv.x = fmaf(al.x * (fmaf(pa.x, yv.x, pb.x) > 0.f ? 1.f : slope), gv.x, fmaf(be.x, yv.x, de.x));
-                    xv.y = fmaf(al.y * (fmaf(pa.y, yv.y, pb.y) > 0.f ? 1.f : slope), gv.y, fmaf(be.y, yv.y, de.y));
-                    xv.z = fmaf(al.z * (fmaf(pa.z, yv.z, pb.z) > 0.f ? 1.f : slope), gv.z, fmaf(be.z, yv.z, de.z));
-                    xv.w = fmaf(al.w * (fmaf(pa.w, yv.w, pb.w) > 0.f ? 1.f : slope), gv.w, fmaf(be.w, yv.w, de.w));
-                }
-            } else if (rv) {
-                if (Xb != nullptr) {
-                    if (k0 < xsplit) xv = *reinterpret_cast<const float4*>(X + r * xsplit + k0);
-                    else if (k0 < Ci) xv = *reinterpret_cast<const float4*>(Xb + r * (Ci - xsplit) + (k0 - xsplit));
-                } else if (vec) {
-                    if (k0 < Ci) xv = *reinterpret_cast<const float4*>(X + r * Ci + k0);
-                } else {
-                    const float* xp = X + r * Ci;
-                    xv.x = k0 + 0 < Ci ? xp[k0 + 0] : 0.f;
-                    xv.y = k0 + 1 < Ci ? xp[k0 + 1] : 0.f;
-                    xv.z = k0 + 2 < Ci ? xp[k0 + 2] : 0.f;
-                    xv.w = k0 + 3 < Ci ? xp[k0 + 3] : 0.f;
-                }
-            }
+            float4 ra, rb;
+            load_raw(r, rv, c, ra, rb);
+            const float4 xv = operand(rv, c, ra, rb);
 #pragma unroll
             for (int t = 0; t < TCO; ++t) {
                 const float4 wv = *reinterpret_cast<const float4*>(sW + (16 * t + rr) * Cip + k0);
@@ -860,6 +882,38 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
             }
         }
         // lane holds Y[row = row0 + rr][co = co_base + 16 t + 4 g + e], e = 0..3
+        if constexpr (TCO >= 2) {
+            // Stored straight from the accumulators every store instruction writes 64 bytes into each of 16 rows (measured
+            // 1.5-1.7 TB/s on write-heavy shapes); through a per-wave LDS tile [16 rows][16 TCO] every instruction writes
+            // whole 128 / 256-byte row segments, consecutive lanes consecutive addresses.
+            constexpr int TW = 16 * TCO, TLD = TW + 4, F4R = TW / 4;       // tile width, padded row, float4 per row
+            float* tile = sTile + wave * 16 * TLD;
+#pragma unroll
+            for (int t = 0; t < TCO; ++t)
+                *reinterpret_cast<float4*>(tile + rr * TLD + 16 * t + 4 * g) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+            __builtin_amdgcn_wave_barrier();               // LDS operations of one wave complete in order
+#pragma unroll
+            for (int i = 0; i < (16 * F4R) / WAVE; ++i) {
+                const int qd = lane + WAVE * i, trow = qd / F4R, tc4 = qd - trow * F4R;
+                const int64_t orow = row0 + trow;
+                const int co = co_base + 4 * tc4;
+                if (orow < M && co < Co) {
+                    const float4 o4 = *reinterpret_cast<const float4*>(tile + trow * TLD + 4 * tc4);
+                    if (Yb != nullptr) {
+                        if (co < ysplit) *reinterpret_cast<float4*>(Y + orow * ysplit + co) = o4;
+                        else *reinterpret_cast<float4*>(Yb + orow * (Co - ysplit) + (co - ysplit)) = o4;
+                    } else if ((Co % 4) == 0) {
+                        *reinterpret_cast<float4*>(Y + orow * Co + co) = o4;
+                    } else {
+                        const float ov[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (co + e < Co) Y[orow * Co + co + e] = ov[e];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();               // the tile is rewritten by the next row group
+        } else {
 #pragma unroll
         for (int t = 0; t < TCO; ++t) {
             const int co = co_base + 16 * t + 4 * g;
@@ -876,6 +930,7 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
                         if (co + e < Co) Y[r * Co + co + e] = acc[t][e];
                 }
             }
+        }
         }
         if (stat_partial != nullptr) {
             if (!have_shift) {   // shift = this wave's first row (lane with rr == 0 of each co group)
@@ -1022,11 +1077,30 @@ static int lf_blocks(int64_t M) {
 }  // namespace crf
 
 // Supported when the weight slab fits LDS: min(Co, 128) x (Ci rounded to 16 + 4) floats <= 64 KB.
+// Output tiles per workgroup and the dynamic LDS of linear_fwd_kernel for k = Ci inputs, Co outputs: weight slab
+// [16 tco][Ci rounded to 16, + 4], the five prologue coefficient rows (dX form), the four output staging tiles (tco >= 2).
+// 64 output channels per workgroup at most: the 128-channel form (tco = 8) needs 167 + 98 registers with the statistic
+// accumulators, i.e. ONE wavefront per SIMD (measured 68 -> 49 us for 163840 x 32 -> 128; 5.85 -> 5.80 ms per step).
+static int lf_tco(int Co) {
+    static const int max_tco = getenv("CRFCONV_LF_MAX_TCO") ? atoi(getenv("CRFCONV_LF_MAX_TCO")) : 4;
+    const int tiles = (Co + 15) / 16;
+    const int tco = tiles >= 8 ? 8 : (tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1));
+    return tco > max_tco ? max_tco : tco;
+}
+static size_t lf_lds_bytes(int Ci, int Co, bool pro) {
+    const int tco = lf_tco(Co);
+    const size_t cip = (size_t)((Ci + 15) / 16) * 16 + 4, cik = cip - 4;
+    size_t floats = 16 * (size_t)tco * cip;
+    const size_t stats = 4 * 4 * 16 * (size_t)tco;                   // the statistics epilogue reuses the slab as [4][4][16 tco]
+    if (floats < stats) floats = stats;
+    if (pro) floats += 5 * cik;
+    if (tco >= 2) floats += 4 * 16 * (16 * (size_t)tco + 4);
+    return sizeof(float) * floats;
+}
+
 extern "C" int crfconv_linear_forward_supported(int Ci, int Co) {
     if (Ci < 1 || Co < 1) return 0;
-    const int cip = ((Ci + 15) / 16) * 16 + 4;
-    const int slab = Co < 128 ? ((Co + 15) / 16) * 16 : 128;
-    return (size_t)slab * cip * sizeof(float) <= 64 * 1024 ? 1 : 0;
+    return lf_lds_bytes(Ci, Co, false) <= 64 * 1024 ? 1 : 0;
 }
 
 extern "C" size_t crfconv_linear_forward_stat_records(int64_t M) { return (size_t)crf::lf_blocks(M); }
@@ -1040,14 +1114,11 @@ static int linear_forward_impl(const float* X, const float* Xb, int xsplit, cons
     CRF_REQUIRE(crfconv_linear_forward_supported(Ci, Co), CRF_ERR_UNSUPPORTED, "weight slab %dx%d does not fit LDS", Co, Ci);
     CRF_REQUIRE(Xb == nullptr || (xsplit > 0 && xsplit < Ci && xsplit % 4 == 0 && Ci % 4 == 0), CRF_ERR_ARG,
                 "two-operand form needs 0 < split < Ci, both multiples of 4 (split=%d Ci=%d)", xsplit, Ci);
-    const int cip = ((Ci + 15) / 16) * 16 + 4;
     const int tiles = (Co + 15) / 16;
-    const int tco = tiles >= 8 ? 8 : (tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1));
+    const int tco = lf_tco(Co);
     const int gy = (tiles + tco - 1) / tco;
     const dim3 grid((unsigned)crf::lf_blocks(M), (unsigned)gy), blk(crf::LF_BLOCK);
-    size_t lds = sizeof(float) * 16 * tco * cip;
-    const size_t lds_stats = sizeof(float) * 4 * 4 * 16 * tco;           // the epilogue reuses the slab as [4][4][16 tco]
-    if (lds < lds_stats) lds = lds_stats;
+    const size_t lds = lf_lds_bytes(Ci, Co, false);
     hipStream_t st = crf::as_stream(stream);
 #define LF(T) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, false>), grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec, (const float*)nullptr, (const float*)nullptr, 1.f, Xb, xsplit, (float*)nullptr, 0)
     switch (tco) {
@@ -1126,10 +1197,8 @@ static size_t mlp_ws_layout(int64_t M, int Co, int Ci, size_t off[5]) {
 
 extern "C" int crfconv_mlp_backward_supported(int64_t M, int Ci, int Co) {
     if (!(M > 0 && Co % 4 == 0 && Ci >= 1 && Co >= 4 && Co <= 1024 && Ci <= 1024)) return 0;
-    // dX runs on linear_fwd_kernel<., true> with k = Co: weight slab (<= 128 output rows) + 5 coefficient rows in 64 KB
-    const int cip = ((Co + 15) / 16) * 16 + 4, cik = ((Co + 15) / 16) * 16;
-    const int rows = Ci < 128 ? ((Ci + 15) / 16) * 16 : 128;
-    return sizeof(float) * ((size_t)rows * cip + 5 * (size_t)cik) <= 64 * 1024 ? 1 : 0;
+    // dX runs on linear_fwd_kernel<., true> with k = Co inputs and Ci outputs: its LDS must fit 64 KB
+    return lf_lds_bytes(Co, Ci, true) <= 64 * 1024 ? 1 : 0;
 }
 
 extern "C" size_t crfconv_mlp_backward_workspace(int64_t M, int Ci, int Co) {
@@ -1200,12 +1269,11 @@ static int mlp_backward_impl(const float* gA, const float* Y, const float* X, co
     if (dX != nullptr) {
         // dX [M, Ci] = gY [M, Co] W [Co, Ci]: the forward kernel with k = Co, outputs = Ci, W read transposed
         const int gCi = Co, gCo = Ci;
-        const int cip = ((gCi + 15) / 16) * 16 + 4, cik = ((gCi + 15) / 16) * 16;
         const int tiles = (gCo + 15) / 16;
-        const int tco = tiles >= 8 ? 8 : (tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1));
+        const int tco = lf_tco(gCo);
         const int gy = (tiles + tco - 1) / tco;
         const dim3 grid((unsigned)crf::lf_blocks(M), (unsigned)gy), blk(crf::LF_BLOCK);
-        const size_t lds = sizeof(float) * ((size_t)16 * tco * cip + 5 * (size_t)cik);
+        const size_t lds = lf_lds_bytes(gCi, gCo, true);
 #define DX(T) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, true>), grid, blk, lds, st, gA, W, (const float*)nullptr, M, gCi, gCo, 1, dX, (float*)nullptr, Y, pro, slope, (const float*)nullptr, 0, dXb, xsplit)
         switch (tco) {
             case 1: DX(1); break;
