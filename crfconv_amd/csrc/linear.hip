@@ -755,16 +755,7 @@ constexpr int LF_BLOCK = 256;
 // VEC4: Ci % 4 == 0 and Co % 4 == 0 -- every access is a 16-byte one and the element-wise tail code does not exist.  (With
 // both forms in one kernel the compiler merges the float4 store into the four predicated dword stores of the tail path:
 // 4x the store instructions and 3x the write requests, 983 k instead of 328 k per 21 MB -- TCP_TCC_WRITE_REQ.)
-// NCH > 0 (VEC4 shapes with Ci <= 16 NCH): a wavefront issues the operand loads of RG = lf_rg(NCH, PRO) of its 16-row groups
-// in ONE burst -- branch-free: out-of-range rows / chunks load a clamped address and are zeroed by a select, so no
-// control flow (and no conservative s_waitcnt) sits between the loads -- and then works through the groups in a ROLLED loop
-// whose body always consumes register slot 0 and rotates the slots (unrolled, the body needed 180-256 registers; a
-// runtime register index would send the fragments to scratch).  NCH = 0: any Ci, one group at a time.
-constexpr int lf_rg(int nch, bool pro) {
-    const int per_group = nch * (pro ? 2 : 1);          // float4 registers per row group
-    return per_group >= 8 ? 1 : (per_group >= 4 ? 2 : 4);
-}
-template <int TCO, bool PRO = false, bool VEC4 = true, int NCH = 0>  // 16 * TCO output channels per block slab (blockIdx.y picks the slab)
+template <int TCO, bool PRO = false, bool VEC4 = true>  // 16 * TCO output channels per block slab (blockIdx.y picks the slab)
 __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                               const float* __restrict__ bias, int64_t M, int Ci, int Co,
                                                               int transpose_w, float* __restrict__ Y,
@@ -868,71 +859,16 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
             return gv;
         }
     };
-    constexpr int RG = NCH > 0 ? lf_rg(NCH, PRO) : 1, NB = NCH > 0 ? NCH : 1;
-    const int64_t row_first = ((int64_t)blockIdx.x * (LF_BLOCK / WAVE) + wave) * 16;
-    const int64_t row_stride = (int64_t)gridDim.x * (LF_BLOCK / WAVE) * 16;
-    for (int64_t rowb = row_first; rowb < M; rowb += RG * row_stride) {
-    [[maybe_unused]] float4 fa[RG][NB], fb[PRO ? RG : 1][PRO ? NB : 1];
-    if constexpr (NCH > 0) {
-#pragma unroll
-        for (int i = 0; i < RG; ++i) {
-            const int64_t ri = rowb + i * row_stride + rr;
-            const int64_t rc = ri < M ? ri : M - 1;             // clamped: always a valid row
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int k0 = 16 * c + 4 * g;
-                const int kc = k0 < Ci ? k0 : 0;                // clamped: always a valid, 16-byte aligned column
-                float4 a, b2 = zero4;
-                if constexpr (PRO) {
-                    a = *reinterpret_cast<const float4*>(X + rc * Ci + kc);
-                    b2 = *reinterpret_cast<const float4*>(Y2 + rc * Ci + kc);
-                } else if (Xb != nullptr) {
-                    const float* src = kc < xsplit ? X + rc * xsplit + kc : Xb + rc * (Ci - xsplit) + (kc - xsplit);
-                    a = *reinterpret_cast<const float4*>(src);
-                } else {
-                    a = *reinterpret_cast<const float4*>(X + rc * Ci + kc);
-                }
-                const bool ok = ri < M && k0 < Ci;
-                fa[i][c] = ok ? a : zero4;
-                if constexpr (PRO) fb[i][c] = ok ? b2 : zero4;
-            }
-        }
-    }
-#pragma unroll 1
-    for (int i = 0; i < RG; ++i) {
-        const int64_t row0 = rowb + i * row_stride;
-        if (row0 >= M) break;
+    // (Issuing the operand loads of four row groups in one burst, or prefetching the next group, measured no faster: the
+    // write-heavy shapes run at the ~2.7 TB/s HBM WRITE rate -- 163840 x 8 -> 32 moves 21 MB out in 13 us -- not at a
+    // per-wavefront latency limit.)
+    for (int64_t row0 = ((int64_t)blockIdx.x * (LF_BLOCK / WAVE) + wave) * 16; row0 < M;
+         row0 += (int64_t)gridDim.x * (LF_BLOCK / WAVE) * 16) {
         const int64_t r = row0 + rr;
         const bool rv = r < M;
         f32x4 acc[TCO];
 #pragma unroll
         for (int t = 0; t < TCO; ++t) acc[t] = f32x4{bsel[t][0], bsel[t][1], bsel[t][2], bsel[t][3]};
-        if constexpr (NCH > 0) {
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if (c < nchunk) {
-                    const int k0 = 16 * c + 4 * g;
-                    float4 gb = zero4;                          // slot 0 always holds the current group (rotated below)
-                    if constexpr (PRO) gb = fb[0][c];
-                    const float4 xv = operand(rv, c, fa[0][c], gb);
-#pragma unroll
-                    for (int t = 0; t < TCO; ++t) {
-                        const float4 wv = *reinterpret_cast<const float4*>(sW + (16 * t + rr) * Cip + k0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc[t], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j + 1 < RG; ++j)
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    fa[j][c] = fa[j + 1][c];
-                    if constexpr (PRO) fb[j][c] = fb[j + 1][c];
-                }
-        } else {
         for (int c = 0; c < nchunk; ++c) {
             const int k0 = 16 * c + 4 * g;
             float4 ra, rb;
@@ -947,7 +883,6 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc[t], 0, 0, 0);
             }
-        }
         }
         // lane holds Y[row = row0 + rr][co = co_base + 16 t + 4 g + e], e = 0..3
         if constexpr (TCO >= 2) {
@@ -1021,7 +956,6 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
                     }
             }
         }
-    }
     }
     if (stat_partial != nullptr) {
         // one record {shift, n, sum, sumsq} per BLOCK and channel: the 16 row-lanes fold by shuffles, the 4 waves
@@ -1192,10 +1126,8 @@ static int linear_forward_impl(const float* X, const float* Xb, int xsplit, cons
     const size_t lds = lf_lds_bytes(Ci, Co, false);
     hipStream_t st = crf::as_stream(stream);
     const bool vec4 = (Ci % 4) == 0 && (Co % 4) == 0;
-    static const bool no_burst = getenv("CRFCONV_LF_NO_BURST") != nullptr;            // A/B: one row group's loads in flight at a time
-    const int nch = (no_burst || !vec4) ? 99 : (Ci + 15) / 16;
-#define LF2(T, V, N) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, false, V, N>), grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec, (const float*)nullptr, (const float*)nullptr, 1.f, Xb, xsplit, (float*)nullptr, 0)
-#define LF(T) do { if (!vec4) LF2(T, false, 0); else if (nch <= 1) LF2(T, true, 1); else if (nch <= 2) LF2(T, true, 2); else if (nch <= 4) LF2(T, true, 4); else LF2(T, true, 0); } while (0)
+#define LF2(T, V) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, false, V>), grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec, (const float*)nullptr, (const float*)nullptr, 1.f, Xb, xsplit, (float*)nullptr, 0)
+#define LF(T) do { if (vec4) LF2(T, true); else LF2(T, false); } while (0)
     switch (tco) {
         case 1: LF(1); break;
         case 2: LF(2); break;
@@ -1351,10 +1283,8 @@ static int mlp_backward_impl(const float* gA, const float* Y, const float* X, co
         const dim3 grid((unsigned)crf::lf_blocks(M), (unsigned)gy), blk(crf::LF_BLOCK);
         const size_t lds = lf_lds_bytes(gCi, gCo, true);
         const bool vec4 = (gCi % 4) == 0 && (gCo % 4) == 0;
-        static const bool dx_no_burst = getenv("CRFCONV_LF_NO_BURST") != nullptr;
-        const int dx_nch = (dx_no_burst || !vec4) ? 99 : (gCi + 15) / 16;
-#define DX2(T, V, N) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, true, V, N>), grid, blk, lds, st, gA, W, (const float*)nullptr, M, gCi, gCo, 1, dX, (float*)nullptr, Y, pro, slope, (const float*)nullptr, 0, dXb, xsplit)
-#define DX(T) do { if (!vec4) DX2(T, false, 0); else if (dx_nch <= 1) DX2(T, true, 1); else if (dx_nch <= 2) DX2(T, true, 2); else if (dx_nch <= 4) DX2(T, true, 4); else DX2(T, true, 0); } while (0)
+#define DX2(T, V) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, true, V>), grid, blk, lds, st, gA, W, (const float*)nullptr, M, gCi, gCo, 1, dX, (float*)nullptr, Y, pro, slope, (const float*)nullptr, 0, dXb, xsplit)
+#define DX(T) do { if (vec4) DX2(T, true); else DX2(T, false); } while (0)
         switch (tco) {
             case 1: DX(1); break;
             case 2: DX(2); break;
