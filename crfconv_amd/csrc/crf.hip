@@ -747,9 +747,15 @@ __global__ __launch_bounds__(BLOCK) void bwd_edge_kernel(const float* __restrict
 // EP edge-lanes per row walk the row's incoming edges EP at a time (edge p = beg + lane-group, += EP) and fold their
 // partial sums by xor-shuffles (fixed tree): in-degrees of a kNN graph spread from 0 to ~40, and with one lane
 // group per row a wavefront iterates to the LARGEST in-degree of its 64/L rows.
+#ifndef SCAT_EP
+#define SCAT_EP 2          // edge lanes per row (L <= 4); swept with SCAT_UB on the level-0 backward: (4,4) 104.8, (2,8) 98.5, (2,4) 106, (4,8) 106, (1,16) 107 us
+#endif
+#ifndef SCAT_UB
+#define SCAT_UB 8          // records / rows in flight per lane and round
+#endif
 template <int H>
 struct Scat {
-    static constexpr int L = H / 4, EP = (L <= 4) ? 4 : 1, RPW = WAVE / (L * EP), RPB = RPW * (BLOCK / WAVE);
+    static constexpr int L = H / 4, EP = (L <= 4) ? SCAT_EP : 1, RPW = WAVE / (L * EP), RPB = RPW * (BLOCK / WAVE);
 };
 
 template <int H>
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(BLOCK) void sim_bwd_scatter_kernel(const float* __r
     const float4 yj = ld4(y + row * H + 4 * q);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int beg = rev_ptr[row], end = valid ? rev_ptr[row + 1] : beg;
-    constexpr int UB = 4;                           // edge ids, then weights + rows, in batches (see bwd_chain_kernel)
+    constexpr int UB = SCAT_UB;                     // edge ids, then weights + rows, in batches (see bwd_chain_kernel)
     for (int p0 = beg + el; p0 < end; p0 += EP * UB) {
         int e[UB];
 #pragma unroll
@@ -1100,7 +1106,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_chain_kernel(const float* __restric
     constexpr int L = Scat<H>::L, EP = Scat<H>::EP;
     constexpr bool INK = LAST && (H == 8 || H == 16);
     __shared__ float4 sM[H * L];                       // P^T (chain) or Q^T (last)
-    __shared__ __attribute__((aligned(16))) float s_tile[INK ? 2 * (BLOCK / WAVE) * 64 : 4];
+    constexpr int TILE = Scat<H>::RPW * H;             // floats per operand and wavefront (a multiple of 64)
+    __shared__ __attribute__((aligned(16))) float s_tile[INK ? 2 * (BLOCK / WAVE) * TILE : 4];
     __shared__ float s_red[INK ? (BLOCK / WAVE) * H * H : 1];
     load_matrix<H>(sM, LAST ? Q : P, true);
     const int lane = threadIdx.x & 63;
@@ -1117,7 +1124,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_chain_kernel(const float* __restric
     // The kernel is bound by vector-memory issue (a wave-wide load costs its ~22 clk whether or not lanes are masked), so
     // the first round takes EP * UB = 16 edges of a row and later rounds -- only the rows of above-average in-degree
     // need them -- EP * TB edges: 8 + 2 TB ceil((max degree - 16) / (EP TB)) load instructions per wave instead of 16.
-    constexpr int UB = 4;
+    constexpr int UB = SCAT_UB;
     int p0 = beg + el;
     if (p0 < end) {
         RevRec rr[UB];
@@ -1166,9 +1173,9 @@ __global__ __launch_bounds__(BLOCK) void bwd_chain_kernel(const float* __restric
         const float4 dzv = matvec_acc<H>(sg, sM, lane0, q, acc);      // G_0 + (sum_t G_t) Q^T
         if (valid && el == 0) st4(dz + row * H + 4 * q, dzv);
         if constexpr (INK) {
-            // the wave's RPW rows x H channels = 64 floats per operand: one MFMA
-            float* ta = s_tile + (threadIdx.x >> 6) * 128;
-            float* tb = ta + 64;
+            // the wave's RPW rows x H channels = TILE floats per operand: TILE / 64 MFMAs
+            float* ta = s_tile + (threadIdx.x >> 6) * 2 * TILE;
+            float* tb = ta + TILE;
             if (el == 0) {
                 const int slot = (lane / (L * EP)) * H + 4 * q;
                 const float4 zr = ld4(z + row * H + 4 * q);
@@ -1177,7 +1184,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_chain_kernel(const float* __restric
             }
             __builtin_amdgcn_wave_barrier();
             OuterAcc<H> oa;
-            oa.add_tile64(ta, tb, lane);
+#pragma unroll
+            for (int n = 0; n < TILE / 64; ++n) oa.add_tile64(ta + 64 * n, tb + 64 * n, lane);
             oa.store_partial(s_red, dq_partial, lane);
         } else {
             if (valid && el == 0) st4(sumG + row * H + 4 * q, sg);
@@ -1214,13 +1222,16 @@ __global__ __launch_bounds__(BLOCK) void bwd_edge_all_kernel(const float* __rest
         const float* __restrict__ xprev = t >= 2 ? xs + (int64_t)(t - 2) * step : z;
         const float4 gmi = ld4(gms + (int64_t)i * step + r * H + 4 * q);
         float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef EDGE_NB
+#define EDGE_NB 8          // neighbour rows in flight per lane
+#endif
 #pragma unroll
-        for (int k0 = 1; k0 < K; k0 += 8) {
-            float4 nb[8];
+        for (int k0 = 1; k0 < K; k0 += EDGE_NB) {
+            float4 nb[EDGE_NB];
 #pragma unroll
-            for (int k = k0; k < k0 + 8 && k < K; ++k) nb[k - k0] = ld4(xprev + (int64_t)j[k] * H + 4 * q);
+            for (int k = k0; k < k0 + EDGE_NB && k < K; ++k) nb[k - k0] = ld4(xprev + (int64_t)j[k] * H + 4 * q);
 #pragma unroll
-            for (int k = k0; k < k0 + 8 && k < K; ++k) {
+            for (int k = k0; k < k0 + EDGE_NB && k < K; ++k) {
                 msg = fma4(sw[k], nb[k - k0], msg);
                 dd[k] += group_sum<L>(dot4(gmi, nb[k - k0]));
             }

@@ -842,21 +842,36 @@ __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restri
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) degmax = max(degmax, __shfl_xor(degmax, o, WAVE));
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p0 = 0; p0 < degmax; p0 += EB) {
+    // UB edges per trip: their edge ids first, then all their position / gradient rows -- two dependent memory phases per
+    // UB edges instead of two per edge (a wavefront iterates to the largest in-degree of its rows, ~35 trips of one edge)
+    constexpr int UB = EB > 1 ? EB : 4;
+    const int kshift = (K & (K - 1)) == 0 ? __ffs(K) - 1 : -1;
+    for (int p0 = 0; p0 < degmax; p0 += UB) {
+        int eid[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) eid[u] = p0 + u < deg ? rev_eid[beg + p0 + u] : -1;
+        float rxs[UB], rys[UB], rzs[UB];
+        float4 gs[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            rxs[u] = rys[u] = rzs[u] = 0.f;
+            gs[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (eid[u] >= 0) {
+                const int64_t i = kshift >= 0 ? (eid[u] >> kshift) : (eid[u] / K);
+                rxs[u] = pos_tgt[3 * i] - sx;
+                rys[u] = pos_tgt[3 * i + 1] - sy;
+                rzs[u] = pos_tgt[3 * i + 2] - sz;
+                gs[u] = ld4(gout + i * D + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int ub = 0; ub < UB; ub += EB) {
         float4 h1[EB], h2[EB], g[EB];
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
-            float rx = 0.f, ry = 0.f, rz = 0.f;
-            g[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p0 + e < deg) {
-                const int64_t i = rev_eid[beg + p0 + e] / K;
-                rx = pos_tgt[3 * i] - sx;
-                ry = pos_tgt[3 * i + 1] - sy;
-                rz = pos_tgt[3 * i + 2] - sz;
-                g[e] = ld4(gout + i * D + 4 * q);
-            }
+            g[e] = gs[ub + e];
             float4 pre;
-            mlp.layer1(rx, ry, rz, pre, h1[e]);
+            mlp.layer1(rxs[ub + e], rys[ub + e], rzs[ub + e], pre, h1[e]);
         }
         mlp.layer2_batch(h1, h2, s_scr);
 #pragma unroll
@@ -865,6 +880,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restri
             acc.y = fmaf(fmaf(sa.y, h2[e].y, sb.y), g[e].y, acc.y);
             acc.z = fmaf(fmaf(sa.z, h2[e].z, sb.z), g[e].z, acc.z);
             acc.w = fmaf(fmaf(sa.w, h2[e].w, sb.w), g[e].w, acc.w);
+        }
         }
     }
     if (rw.valid) st4(dx + rw.r * D + 4 * q, acc);
