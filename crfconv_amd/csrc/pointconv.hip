@@ -14,6 +14,9 @@
 
 namespace crf {
 
+#ifndef PARAMS_PB
+#define PARAMS_PB 4
+#endif
 constexpr int PBLOCK = 256;
 constexpr int PWAVES = PBLOCK / WAVE;
 
@@ -607,12 +610,27 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
     float db[4] = {0, 0, 0, 0};
     const int base = lane - q;
 
-    for (int k = 0; k < K; ++k) {
-        const int jj = irow[k];
-        const int64_t j = jj < 0 ? 0 : jj;
+    // PB edges per trip: their index entries first, then all their feature / position rows, then the arithmetic -- two
+    // dependent memory phases per PB edges instead of two per edge (one or two wavefronts per SIMD hide nothing)
+    constexpr int PB = PARAMS_PB;
+    for (int k0 = 0; k0 < K; k0 += PB) {
+        int jj_[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) jj_[u] = k0 + u < K ? irow[k0 + u] : -1;
+        float4 xj_[PB];
+        float rx_[PB], ry_[PB], rz_[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int64_t j = jj_[u] < 0 ? 0 : jj_[u];
+            xj_[u] = ld4(x + j * D + 4 * q);
+            rx_[u] = px - pos_src[3 * j]; ry_[u] = py - pos_src[3 * j + 1]; rz_[u] = pz - pos_src[3 * j + 2];
+        }
+#pragma unroll 1
+    for (int u = 0; u < PB; ++u) {                  // rolled: the body exists once (unrolled it took 256 + 256 registers);
+        const int jj = jj_[0];                      // slot 0 is the current edge, the slots rotate at the end
         const float live = (rw.valid && jj >= 0) ? 1.f : 0.f;
-        const float4 xj = ld4(x + j * D + 4 * q);
-        const float rx = px - pos_src[3 * j], ry = py - pos_src[3 * j + 1], rz = pz - pos_src[3 * j + 2];
+        const float4 xj = xj_[0];
+        const float rx = rx_[0], ry = ry_[0], rz = rz_[0];
         float4 pre, h1;
         mlp.layer1(rx, ry, rz, pre, h1);
         const float4 h2 = mlp.layer2(h1);
@@ -669,6 +687,12 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
             for (int ax = 0; ax < 3; ++ax) da1[ax][c] = fmaf(rd[ax], gpd[c], da1[ax][c]);
             db[c] += gpd[c];
         }
+#pragma unroll
+        for (int v = 0; v + 1 < PB; ++v) {
+            jj_[v] = jj_[v + 1]; xj_[v] = xj_[v + 1];
+            rx_[v] = rx_[v + 1]; ry_[v] = ry_[v + 1]; rz_[v] = rz_[v + 1];
+        }
+    }
     }
 
     // wave-level sums over points, then one LDS add per wave (4 adders per slot, fixed slots)
