@@ -18,14 +18,23 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const float ninf = -__builtin_inff();
     float4 best = make_float4(ninf, ninf, ninf, ninf);
     int4 who = make_int4(-1, -1, -1, -1);
-    for (int k = 0; k < K; ++k) {
-        const int j = irow[k];
-        if (j < 0) continue;                                     // "no neighbour" entry of a padded table
-        const float4 v = ld4(x + ((int64_t)j * C4 + q) * 4);
-        if (v.x > best.x || who.x < 0) { best.x = v.x; who.x = k; }
-        if (v.y > best.y || who.y < 0) { best.y = v.y; who.y = k; }
-        if (v.z > best.z || who.z < 0) { best.z = v.z; who.z = k; }
-        if (v.w > best.w || who.w < 0) { best.w = v.w; who.w = k; }
+    for (int k0 = 0; k0 < K; k0 += 4) {                         // four neighbours per trip: index entries, then rows
+        int jn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) jn[u] = k0 + u < K ? irow[k0 + u] : -1;
+        float4 vn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vn[u] = ld4(x + ((int64_t)(jn[u] < 0 ? 0 : jn[u]) * C4 + q) * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (jn[u] < 0) continue;                             // "no neighbour" entry of a padded table
+            const float4 v = vn[u];
+            const int k = k0 + u;
+            if (v.x > best.x || who.x < 0) { best.x = v.x; who.x = k; }
+            if (v.y > best.y || who.y < 0) { best.y = v.y; who.y = k; }
+            if (v.z > best.z || who.z < 0) { best.z = v.z; who.z = k; }
+            if (v.w > best.w || who.w < 0) { best.w = v.w; who.w = k; }
+        }
     }
     if (who.x < 0) best = make_float4(0.f, 0.f, 0.f, 0.f);      // empty group -> 0 (scatter_max convention)
     st4(out + t * 4, best);
@@ -44,16 +53,32 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     const int q = (int)(t - j * C4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int beg = rev_ptr[j], end = rev_ptr[j + 1];
-    for (int p = beg; p < end; ++p) {
-        const int e = rev_eid[p];
-        const int i = e / K, k = e - i * K;
-        const int64_t o = ((int64_t)i * C4 + q) * 4;
-        const int4 who = *reinterpret_cast<const int4*>(arg + o);
-        const float4 g = ld4(gout + o);
-        if (who.x == k) acc.x += g.x;
-        if (who.y == k) acc.y += g.y;
-        if (who.z == k) acc.z += g.z;
-        if (who.w == k) acc.w += g.w;
+    // four reverse edges per trip: their edge ids first, then the four (arg, gradient) row pairs -- two dependent memory
+    // phases per four edges instead of two per edge; summed in edge order as before
+    const int kshift = (K & (K - 1)) == 0 ? __ffs(K) - 1 : -1;
+    for (int p = beg; p < end; p += 4) {
+        int e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = p + u < end ? rev_eid[p + u] : -1;
+        int4 who[4];
+        float4 g[4];
+        int kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ee = e[u] < 0 ? 0 : e[u];
+            const int i = kshift >= 0 ? (ee >> kshift) : (ee / K);
+            kk[u] = e[u] < 0 ? -2 : ee - i * K;                 // -2 matches no arg entry
+            const int64_t o = ((int64_t)i * C4 + q) * 4;
+            who[u] = *reinterpret_cast<const int4*>(arg + o);
+            g[u] = ld4(gout + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (who[u].x == kk[u]) acc.x += g[u].x;
+            if (who[u].y == kk[u]) acc.y += g[u].y;
+            if (who[u].z == kk[u]) acc.z += g[u].z;
+            if (who[u].w == kk[u]) acc.w += g[u].w;
+        }
     }
     st4(dx + t * 4, acc);
 }
@@ -80,9 +105,16 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __res
     const int q = (int)(t - j * C4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int beg = rev_ptr[j], end = rev_ptr[j + 1];
-    for (int p = beg; p < end; ++p) {
-        const float4 g = ld4(gout + ((int64_t)rev_eid[p] * C4 + q) * 4);
-        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+    for (int p = beg; p < end; p += 4) {              // four reverse edges per trip (ids, then rows), summed in edge order
+        int e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = p + u < end ? rev_eid[p + u] : -1;
+        float4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = ld4(gout + ((int64_t)(e[u] < 0 ? 0 : e[u]) * C4 + q) * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e[u] >= 0) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
     }
     st4(dx + t * 4, acc);
 }
