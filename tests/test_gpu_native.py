@@ -96,21 +96,22 @@ def test_knn_clustered_duplicates_every_search_path(nn_mod, Np, K):
         assert np.array_equal(got.cpu().numpy(), onative.oracle_knn_batch(pts, np.ascontiguousarray(q), K))
 
 
-def test_knn_large_properties(nn_mod):
-    """~1M-point scene (BASELINE config 5 scale), K=32: size-independent properties + a sampled
-    brute-force check on the device."""
+@pytest.mark.parametrize('K', [32, 16])
+def test_knn_large_properties(nn_mod, K):
+    """~1M-point scene (BASELINE config 5 scale): size-independent properties + a sampled brute-force check on the
+    device.  K = 32 runs the one-lane grid search, K = 16 the sixteen-lanes-per-query one."""
     n = 1 << 20
     g = torch.Generator().manual_seed(5)
     pts = (torch.rand(1, n, 3, generator=g) * torch.tensor([60.0, 60.0, 15.0])).cuda()
-    idx = nn_mod.knn_batch_device(pts, pts, 32)
+    idx = nn_mod.knn_batch_device(pts, pts, K)
     p = pts[0]
-    nb = p[idx[0]]                                           # [n, 32, 3]
+    nb = p[idx[0]]                                           # [n, K, 3]
     d = ((p[:, None, :] - nb) ** 2).sum(-1)
     assert bool((idx[0, :, 0] == torch.arange(n, device='cuda')).all())      # self first
     assert bool((d[:, 1:] >= d[:, :-1] - 1e-6).all())                        # ascending
     rows = torch.randint(0, n, (256,), generator=g).cuda()
     full = ((p[rows][:, None, :] - p[None, :, :]) ** 2).sum(-1)              # [256, n]
-    kth = full.topk(32, largest=False).values[:, -1]
+    kth = full.topk(K, largest=False).values[:, -1]
     assert torch.allclose(d[rows, -1], kth, rtol=1e-5, atol=1e-7)
 
 
