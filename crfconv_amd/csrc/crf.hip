@@ -274,6 +274,13 @@ __device__ __forceinline__ void fused_matvec(const float (&v)[FGeo<H>::CPL], con
     }
 }
 
+// Gathers of rows that OTHER workgroups stored inside the same launch: aux 16 = sc1 (past L1).  -DFUSED_GATHER_AUX=0 reads
+// them through L1 -- no line of xs[t] can be in any L1 / foreign L2 before the barrier that follows its last store, and the
+// variant passed the bit-equality and staleness checks of scratch/mff_bench.py at 30.0 us (sc1: 40.5 us; per-step launches:
+// 25.0 us) -- but that argument leans on the kernel-boundary cache invalidation, so sc1 stays the default of this opt-in path.
+#ifndef FUSED_GATHER_AUX
+#define FUSED_GATHER_AUX 16
+#endif
 template <int CPL, int AUX>
 __device__ __forceinline__ void ld_row(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase, float (&v)[CPL]) {
 #pragma unroll
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(NT) void mf_fused_kernel(const float* __restrict__ 
         for (int k0 = 1; k0 < K; k0 += GB) {
             float g[GB][CPL];
 #pragma unroll
-            for (int k = k0; k < k0 + GB && k < K; ++k) ld_row<CPL, 16>(xr, j[k], base, g[k - k0]);     // aux 16 = sc1
+            for (int k = k0; k < k0 + GB && k < K; ++k) ld_row<CPL, FUSED_GATHER_AUX>(xr, j[k], base, g[k - k0]);
 #pragma unroll
             for (int k = k0; k < k0 + GB && k < K; ++k)
 #pragma unroll
