@@ -15,9 +15,16 @@ namespace crf {
 
 using f32x4s = __attribute__((ext_vector_type(4))) float;
 
-constexpr int SM_BLOCK = 256, SM_ROWS = 64, SM_COLS = 64, SM_KC = 64, SM_LD = SM_KC + 4, SM_TCO = SM_COLS / 16;
+constexpr int SM_BLOCK = 256, SM_ROWS = 64, SM_COLS = 64, SM_KC = 64, SM_LD = SM_KC + 4;   // SM_COLS: the widest tile
 constexpr int64_t SM_MAX_ROWS = 4096;
+#ifndef SM_MIN_BLOCKS
+#define SM_MIN_BLOCKS 256
+#endif
 
+// TCO: 16-channel output tiles per workgroup (tile = 64 rows x 16 TCO channels).  A wavefront issues Ci / 4 x TCO MFMAs, so
+// at Ci = 512 the 64-wide tile is 7 us of matrix pipe per wavefront while most CUs idle (40 workgroups for 1280 x 128
+// outputs): the host picks the narrowest tile that still gives the device >= SM_MIN_BLOCKS workgroups.
+template <int TCO>
 __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                                  int M, int Ci, int Co, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float* __restrict__ run_mean,
@@ -26,36 +33,37 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
                                                                  float* __restrict__ coef, float* __restrict__ rec,
                                                                  unsigned* __restrict__ sync_ws) {
     __shared__ float sWbuf[2][SM_COLS * SM_LD];                // W chunk [64 co][64 k] (+4 pad: conflict-free b128 reads), double-buffered
-    __shared__ double s_comb[4][2][SM_COLS];
+    __shared__ double s_comb[2][SM_BLOCK];
     __shared__ float s_ab[2][SM_COLS];
     __shared__ int s_ok;
     float* const sW = sWbuf[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rr = lane & 15, g = lane >> 4;
-    const int rb = blockIdx.x, co_base = blockIdx.y * SM_COLS;
+    constexpr int COLS = 16 * TCO;
+    const int rb = blockIdx.x, co_base = blockIdx.y * COLS;
     const int r = rb * SM_ROWS + wave * 16 + rr;
     const bool rv = r < M;
     const float* xrow = X + (int64_t)(rv ? r : 0) * Ci;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    f32x4s acc[SM_TCO];
+    f32x4s acc[TCO];
 #pragma unroll
-    for (int t = 0; t < SM_TCO; ++t) acc[t] = f32x4s{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TCO; ++t) acc[t] = f32x4s{0.f, 0.f, 0.f, 0.f};
 
     // software pipeline over 64-wide K chunks: the next chunk's weight slab (four float4 per thread) and X fragments are
     // in flight while the matrix cores work on the current one; one __syncthreads per chunk
     const int wr = threadIdx.x >> 4, k4 = threadIdx.x & 15;      // this thread stages W rows wr, wr + 16, wr + 32, wr + 48
     const float* wsrc = W + (int64_t)(co_base + wr) * Ci + 4 * k4;
-    float4 wreg[4], xv[4], xn[4];
+    float4 wreg[TCO], xv[4], xn[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wreg[i] = 4 * k4 < Ci ? ld4(wsrc + (int64_t)16 * i * Ci) : zero4;
+    for (int i = 0; i < TCO; ++i) wreg[i] = 4 * k4 < Ci ? ld4(wsrc + (int64_t)16 * i * Ci) : zero4;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int k0 = 16 * c + 4 * g;
         xv[c] = (rv && k0 < Ci) ? ld4(xrow + k0) : zero4;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) st4(sWbuf[0] + (wr + 16 * i) * SM_LD + 4 * k4, wreg[i]);
+    for (int i = 0; i < TCO; ++i) st4(sWbuf[0] + (wr + 16 * i) * SM_LD + 4 * k4, wreg[i]);
     __syncthreads();
     int cur = 0;
     for (int kc = 0; kc < Ci; kc += SM_KC) {
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
         const bool more = kn < Ci;
         if (more) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wreg[i] = kn + 4 * k4 < Ci ? ld4(wsrc + (int64_t)16 * i * Ci + kn) : zero4;
+            for (int i = 0; i < TCO; ++i) wreg[i] = kn + 4 * k4 < Ci ? ld4(wsrc + (int64_t)16 * i * Ci + kn) : zero4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int k0 = kn + 16 * c + 4 * g;
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int t = 0; t < SM_TCO; ++t) {
+            for (int t = 0; t < TCO; ++t) {
                 const float4 wv = ld4(sWc + (16 * t + rr) * SM_LD + 16 * c + 4 * g);
                 // D[i = co][j = row]: A = W fragment (i = lane & 15), B = X fragment (j = lane & 15)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv[c].x, acc[t], 0, 0, 0);
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
         }
         if (more) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) st4(sWbuf[cur ^ 1] + (wr + 16 * i) * SM_LD + 4 * k4, wreg[i]);
+            for (int i = 0; i < TCO; ++i) st4(sWbuf[cur ^ 1] + (wr + 16 * i) * SM_LD + 4 * k4, wreg[i]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) xv[c] = xn[c];
         }
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
     // lane holds Y[row r][co_base + 16 t + 4 g + e], e = 0..3
     if (rv) {
 #pragma unroll
-        for (int t = 0; t < SM_TCO; ++t)
+        for (int t = 0; t < TCO; ++t)
             st4(Y + (int64_t)r * Co + co_base + 16 * t + 4 * g, make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]));
     }
 
@@ -103,10 +111,10 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
     // in float64 re-based on wave 0's shift, one {shift, n, sum, sumsq} tuple per (row block, channel)
     __syncthreads();                                            // sW is dead: reuse it as [4 waves][4][64]
     {
-        float* sw = sW + wave * 4 * SM_COLS;
+        float* sw = sW + wave * 4 * COLS;
         const int nrows = M - (rb * SM_ROWS + wave * 16) < 16 ? (M - (rb * SM_ROWS + wave * 16) < 0 ? 0 : M - (rb * SM_ROWS + wave * 16)) : 16;
 #pragma unroll
-        for (int t = 0; t < SM_TCO; ++t)
+        for (int t = 0; t < TCO; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float sh = __shfl(acc[t][e], 16 * g, WAVE);
@@ -120,23 +128,23 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
                 if (rr == 0) {
                     const int cl = 16 * t + 4 * g + e;
                     sw[cl] = sh;
-                    sw[SM_COLS + cl] = (float)nrows;
-                    sw[2 * SM_COLS + cl] = a;
-                    sw[3 * SM_COLS + cl] = b;
+                    sw[COLS + cl] = (float)nrows;
+                    sw[2 * COLS + cl] = a;
+                    sw[3 * COLS + cl] = b;
                 }
             }
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rrec = make_rsrc(rec, (int)((size_t)gridDim.x * Co * 4 * sizeof(float)));
-    if (threadIdx.x < SM_COLS) {
+    if (threadIdx.x < COLS) {
         const int cl = threadIdx.x;
         const float s0 = sW[cl];
         double n = 0.0, S1 = 0.0, S2 = 0.0;
         for (int w = 0; w < 4; ++w) {
-            const float* q = sW + w * 4 * SM_COLS;
-            const double nb = q[SM_COLS + cl];
+            const float* q = sW + w * 4 * COLS;
+            const double nb = q[COLS + cl];
             if (nb <= 0.0) continue;
-            const double d = (double)q[cl] - (double)s0, a = q[2 * SM_COLS + cl], b = q[3 * SM_COLS + cl];
+            const double d = (double)q[cl] - (double)s0, a = q[2 * COLS + cl], b = q[3 * COLS + cl];
             n += nb;
             S1 += a + nb * d;
             S2 += b + 2.0 * d * a + nb * d * d;
@@ -150,16 +158,16 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
     grid_sync_groups(nblk, bid, n_in_group, n_groups);
     if (!fused_grid_sync<false>(sync_ws, 1u, n_in_group, n_groups, &s_ok, nullptr, bid)) return;
 
-    // ---- coefficients of this workgroup's 64 channels: wave w folds row blocks w, w + 4, ... (fixed order), re-based on
-    // row block 0's shift
+    // ---- coefficients of this workgroup's COLS channels: 256 / COLS groups of COLS threads, group p folds row blocks p,
+    // p + parts, ... (fixed order, every load in flight at once), re-based on row block 0's shift
     {
-        const int cl = lane, co = co_base + cl;
-        constexpr int NB = (int)(SM_MAX_ROWS / SM_ROWS) / 4;       // <= 16 row blocks per wave, all loads in flight at once
+        constexpr int PARTS = SM_BLOCK / COLS, NB = (int)(SM_MAX_ROWS / SM_ROWS) / PARTS;
+        const int cl = threadIdx.x % COLS, part = threadIdx.x / COLS, co = co_base + cl;
         const float4 r0 = ld4_sc1(rrec, (int)(((size_t)co) * 16), 0);
         float4 v[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int b = wave + 4 * i;
+            const int b = part + PARTS * i;
             v[i] = b < (int)gridDim.x ? ld4_sc1(rrec, (int)(((size_t)b * Co + co) * 16), 0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const double s0 = r0.x;
@@ -173,12 +181,13 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
                 S2 += bb + 2.0 * d * a + nb * d * d;
             }
         }
-        s_comb[wave][0][cl] = S1;
-        s_comb[wave][1][cl] = S2;
+        s_comb[0][threadIdx.x] = S1;                              // slot part * COLS + cl
+        s_comb[1][threadIdx.x] = S2;
         __syncthreads();
-        if (threadIdx.x < SM_COLS) {
-            S1 = s_comb[0][0][cl] + s_comb[1][0][cl] + s_comb[2][0][cl] + s_comb[3][0][cl];
-            S2 = s_comb[0][1][cl] + s_comb[1][1][cl] + s_comb[2][1][cl] + s_comb[3][1][cl];
+        if (threadIdx.x < COLS) {
+            S1 = 0.0; S2 = 0.0;
+#pragma unroll
+            for (int p2 = 0; p2 < PARTS; ++p2) { S1 += s_comb[0][p2 * COLS + cl]; S2 += s_comb[1][p2 * COLS + cl]; }
             const double m1 = S1 / (double)M;
             const double mean = s0 + m1;
             double var = (S2 - S1 * m1) / (double)M;
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
     }
     if (rv) {
 #pragma unroll
-        for (int t = 0; t < SM_TCO; ++t) {
+        for (int t = 0; t < TCO; ++t) {
             const float4 a4 = ld4(&s_ab[0][16 * t + 4 * g]), b4 = ld4(&s_ab[1][16 * t + 4 * g]);
             float4 o;
             o.x = fmaf(a4.x, acc[t][0], b4.x); o.y = fmaf(a4.y, acc[t][1], b4.y);
@@ -224,7 +233,7 @@ static int mlp_small_capacity() {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_small_fwd_kernel, SM_BLOCK, 0) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_small_fwd_kernel<4>, SM_BLOCK, 0) != hipSuccess) return 0;
         if (per_cu > 2) per_cu = 2;                                // stay well inside what the dispatcher really co-schedules
         cap = cus * per_cu;
     }
@@ -233,6 +242,17 @@ static int mlp_small_capacity() {
 
 static bool mlp_small_shape_ok(int64_t M, int Ci, int Co) {
     return M >= 1 && M <= SM_MAX_ROWS && Ci >= 16 && Ci % 16 == 0 && Ci <= 1024 && Co >= SM_COLS && Co % SM_COLS == 0 && Co <= 1024;
+}
+
+// 16-channel tiles per workgroup: the widest of {4, 2, 1} that still spreads the layer over >= SM_MIN_BLOCKS workgroups (and fits)
+static int mlp_small_tco(int64_t M, int Co, int cap) {
+    const int64_t rb = cdiv(M, SM_ROWS);
+    for (int tco = 4; tco >= 1; tco >>= 1) {
+        const int64_t nblk = rb * (Co / (16 * tco));
+        if (nblk > cap) return 0;                                  // narrower tiles only make more workgroups
+        if (nblk >= SM_MIN_BLOCKS || tco == 1) return tco;
+    }
+    return 0;
 }
 
 }  // namespace crf
@@ -245,8 +265,7 @@ extern "C" size_t crfconv_gridsync_workspace(void) { return FW_WORDS * sizeof(un
 // the (m / 64) x (Co / 64) workgroups fit the device at once.  Needs a GPU (occupancy query); 0 otherwise.
 extern "C" int crfconv_mlp_small_supported(int64_t M, int Ci, int Co) {
     if (!mlp_small_shape_ok(M, Ci, Co)) return 0;
-    const int64_t nblk = cdiv(M, SM_ROWS) * (Co / SM_COLS);
-    return nblk <= mlp_small_capacity() ? 1 : 0;
+    return mlp_small_tco(M, Co, mlp_small_capacity()) > 0 ? 1 : 0;
 }
 
 extern "C" size_t crfconv_mlp_small_workspace(int64_t M, int Co) {
@@ -267,12 +286,17 @@ extern "C" int crfconv_mlp_small_forward(const float* X, const float* W, int64_t
     CRF_REQUIRE(ws_bytes >= crfconv_mlp_small_workspace(M, Co), CRF_ERR_WORKSPACE, "workspace too small");
     CRF_REQUIRE(sync_bytes >= crfconv_gridsync_workspace(), CRF_ERR_WORKSPACE, "barrier words: %zu bytes, need %zu", sync_bytes,
                 crfconv_gridsync_workspace());
-    const dim3 grid((unsigned)cdiv(M, SM_ROWS), (unsigned)(Co / SM_COLS));
-    CRF_REQUIRE((int64_t)grid.x * grid.y <= mlp_small_capacity(), CRF_ERR_UNSUPPORTED,
-                "%u workgroups cannot all be resident (capacity %d)", grid.x * grid.y, mlp_small_capacity());
-    hipLaunchKernelGGL(mlp_small_fwd_kernel, grid, dim3(SM_BLOCK), 0, as_stream(stream), X, W, (int)M, Ci, Co, gamma, beta,
-                       run_mean, run_var, momentum, eps, slope, Y, A, coef, reinterpret_cast<float*>(ws),
-                       reinterpret_cast<unsigned*>(sync_ws));
+    const int tco = mlp_small_tco(M, Co, mlp_small_capacity());
+    CRF_REQUIRE(tco > 0, CRF_ERR_UNSUPPORTED, "the workgroups of m=%lld Co=%d cannot all be resident (capacity %d)", (long long)M, Co,
+                mlp_small_capacity());
+    const dim3 grid((unsigned)cdiv(M, SM_ROWS), (unsigned)(Co / (16 * tco)));
+#define SMF(T) hipLaunchKernelGGL(mlp_small_fwd_kernel<T>, grid, dim3(SM_BLOCK), 0, as_stream(stream), X, W, (int)M, Ci, Co, gamma, beta, \
+                                  run_mean, run_var, momentum, eps, slope, Y, A, coef, reinterpret_cast<float*>(ws),               \
+                                  reinterpret_cast<unsigned*>(sync_ws))
+    if (tco == 4) SMF(4);
+    else if (tco == 2) SMF(2);
+    else SMF(1);
+#undef SMF
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
