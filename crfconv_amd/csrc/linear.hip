@@ -583,30 +583,67 @@ __global__ __launch_bounds__(256) void spd_inverse_kernel(const float* __restric
 
 // The two loop-invariant matrices of a CRF layer from its compatibility factor c [H, H] in one launch:
 //   Q = (I + c^T c)^-1,   P = c^T c Q = I - Q            (continuous_crf_conv_big.py:67-72)
+// 1024-thread form of the Gauss-Jordan sweep above: 32 x 32 threads, a 2 x 2 tile of the (<= 64 x 64) matrix each -- four
+// float64 updates per thread and pivot instead of sixteen (the 64 pivots are sequential: 42 us with 256 threads).
+constexpr int CMF_BLOCK = 1024;
+__device__ __forceinline__ void gauss_jordan_tiles32(double (&t)[2][2], int H, double (*s_row)[64], double (*s_col)[64]) {
+    const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
+#pragma unroll
+    for (int ip = 0; ip < 2; ++ip) {                     // pivot p = 32 ip + pp lives in local row / column ip
+        for (int pp = 0; pp < 32; ++pp) {
+            const int p = 32 * ip + pp;
+            if (p >= H) break;                           // uniform: rows beyond H are identity already
+            const int b = p & 1;
+            if (tr == pp) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) s_row[b][tc + 32 * j] = t[ip][j];
+            }
+            if (tc == pp) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) s_col[b][tr + 32 * i] = t[i][ip];
+            }
+            __syncthreads();
+            const double piv = 1.0 / s_row[b][p];
+            double rowv[2], colv[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rowv[j] = s_row[b][tc + 32 * j] * piv;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) colv[i] = s_col[b][tr + 32 * i];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bool rp = (i == ip) && (tr == pp), cp = (j == ip) && (tc == pp);
+                    const double upd = t[i][j] - colv[i] * rowv[j];
+                    t[i][j] = rp ? (cp ? piv : rowv[j]) : (cp ? -colv[i] * piv : upd);
+                }
+        }
+    }
+}
 __device__ __forceinline__ void crf_matrices_body(const float* __restrict__ cmat, int H,
                                                   float* __restrict__ Qout, float* __restrict__ Pout) {
     __shared__ double s_row[2][64], s_col[2][64];
     __shared__ float s_c[64 * 65];
-    for (int e = threadIdx.x; e < H * H; e += 256) s_c[(e / H) * 65 + (e % H)] = cmat[e];
+    for (int e = threadIdx.x; e < H * H; e += CMF_BLOCK) s_c[(e / H) * 65 + (e % H)] = cmat[e];
     __syncthreads();
-    const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
-    double t[4][4];
+    const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
+    double t[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = tr + 16 * i, c = tc + 16 * j;
+        for (int j = 0; j < 2; ++j) {
+            const int r = tr + 32 * i, c = tc + 32 * j;
             double a = r == c ? 1.0 : 0.0;
             if (r < H && c < H)
                 for (int k = 0; k < H; ++k) a += (double)s_c[k * 65 + r] * (double)s_c[k * 65 + c];
             t[i][j] = a;
         }
-    gauss_jordan_tiles(t, H, s_row, s_col);
+    gauss_jordan_tiles32(t, H, s_row, s_col);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = tr + 16 * i, c = tc + 16 * j;
+        for (int j = 0; j < 2; ++j) {
+            const int r = tr + 32 * i, c = tc + 32 * j;
             if (r < H && c < H) {
                 Qout[r * H + c] = (float)t[i][j];
                 Pout[r * H + c] = (float)((r == c ? 1.0 : 0.0) - t[i][j]);
@@ -616,7 +653,7 @@ __device__ __forceinline__ void crf_matrices_body(const float* __restrict__ cmat
 
 // dc from dQ and dP (either may be NULL = zero).  With D = dQ - dP (P = I - Q), M = I + c^T c:
 //   dM = -Q^T D Q^T,   dc = c (dM + dM^T) = -c (S + S^T),   S = Q^T D Q^T.
-__global__ __launch_bounds__(256) void crf_matrices_kernel(const float* __restrict__ cmat, int H,
+__global__ __launch_bounds__(CMF_BLOCK) void crf_matrices_kernel(const float* __restrict__ cmat, int H,
                                                            float* __restrict__ Qout, float* __restrict__ Pout) {
     crf_matrices_body(cmat, H, Qout, Pout);
 }
@@ -634,23 +671,24 @@ struct CrfMatJobs {
     float* dc[CM_MAX];
     int H[CM_MAX];
 };
-__global__ __launch_bounds__(256) void crf_matrices_batched_kernel(const CrfMatJobs j) {
+__global__ __launch_bounds__(CMF_BLOCK) void crf_matrices_batched_kernel(const CrfMatJobs j) {
     const int b = blockIdx.x;
     crf_matrices_body(j.c[b], j.H[b], j.Q[b], j.P[b]);
 }
 
+constexpr int CMB_BLOCK = 1024;      // three H^3 float64 products: 4 output elements per thread at H = 64 (16 with 256 threads: 55 us)
 __device__ __forceinline__ void crf_matrices_bwd_body(const float* __restrict__ cmat, const float* __restrict__ Q,
                                                       const float* __restrict__ dQ, const float* __restrict__ dP,
                                                       int H, float* __restrict__ dc) {
     __shared__ float s_a[64 * 65], s_b[64 * 65], s_t[64 * 65];
-    for (int e = threadIdx.x; e < H * H; e += 256) {
+    for (int e = threadIdx.x; e < H * H; e += CMB_BLOCK) {
         const int r = e / H, c = e % H;
         s_a[r * 65 + c] = Q[c * H + r];                                       // Q^T
         s_b[r * 65 + c] = (dQ ? dQ[e] : 0.f) - (dP ? dP[e] : 0.f);            // D
     }
     __syncthreads();
     auto matmul = [&](const float* A, const float* B, float* out, bool sym_neg) {   // out = A B  (H x H, LDS stride 65)
-        for (int e = threadIdx.x; e < H * H; e += 256) {
+        for (int e = threadIdx.x; e < H * H; e += CMB_BLOCK) {
             const int r = e / H, c = e % H;
             double acc = 0.0;
             for (int k = 0; k < H; ++k) acc += (double)A[r * 65 + k] * (double)B[k * 65 + c];
@@ -660,26 +698,26 @@ __device__ __forceinline__ void crf_matrices_bwd_body(const float* __restrict__ 
     };
     matmul(s_a, s_b, s_t, false);                        // T = Q^T D
     matmul(s_t, s_a, s_b, false);                        // S = T Q^T          (s_b reused)
-    for (int e = threadIdx.x; e < H * H; e += 256) {     // s_t = -(S + S^T)
+    for (int e = threadIdx.x; e < H * H; e += CMB_BLOCK) {     // s_t = -(S + S^T)
         const int r = e / H, c = e % H;
         s_t[r * 65 + c] = -(s_b[r * 65 + c] + s_b[c * 65 + r]);
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < H * H; e += 256) s_a[(e / H) * 65 + (e % H)] = cmat[e];
+    for (int e = threadIdx.x; e < H * H; e += CMB_BLOCK) s_a[(e / H) * 65 + (e % H)] = cmat[e];
     __syncthreads();
-    for (int e = threadIdx.x; e < H * H; e += 256) {
+    for (int e = threadIdx.x; e < H * H; e += CMB_BLOCK) {
         const int r = e / H, c = e % H;
         double acc = 0.0;
         for (int k = 0; k < H; ++k) acc += (double)s_a[r * 65 + k] * (double)s_t[k * 65 + c];
         dc[e] = (float)acc;
     }
 }
-__global__ __launch_bounds__(256) void crf_matrices_bwd_kernel(const float* __restrict__ cmat, const float* __restrict__ Q,
+__global__ __launch_bounds__(CMB_BLOCK) void crf_matrices_bwd_kernel(const float* __restrict__ cmat, const float* __restrict__ Q,
                                                                const float* __restrict__ dQ, const float* __restrict__ dP,
                                                                int H, float* __restrict__ dc) {
     crf_matrices_bwd_body(cmat, Q, dQ, dP, H, dc);
 }
-__global__ __launch_bounds__(256) void crf_matrices_bwd_batched_kernel(const CrfMatJobs j) {
+__global__ __launch_bounds__(CMB_BLOCK) void crf_matrices_bwd_batched_kernel(const CrfMatJobs j) {
     const int b = blockIdx.x;
     crf_matrices_bwd_body(j.c[b], j.Q_in[b], j.gQ[b], j.gP[b], j.H[b], j.dc[b]);
 }
@@ -693,7 +731,7 @@ extern "C" int crfconv_crf_matrices_batched(const float* const* c, const int* H,
         CRF_REQUIRE(c[i] && Q[i] && P[i] && H[i] >= 1 && H[i] <= 64, CRF_ERR_ARG, "job %d: null pointer or H=%d outside [1, 64]", i, H[i]);
         j.c[i] = c[i]; j.Q[i] = Q[i]; j.P[i] = P[i]; j.H[i] = H[i];
     }
-    hipLaunchKernelGGL(crf::crf_matrices_batched_kernel, dim3((unsigned)n), dim3(256), 0, crf::as_stream(stream), j);
+    hipLaunchKernelGGL(crf::crf_matrices_batched_kernel, dim3((unsigned)n), dim3(crf::CMF_BLOCK), 0, crf::as_stream(stream), j);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
@@ -707,7 +745,7 @@ extern "C" int crfconv_crf_matrices_backward_batched(const float* const* c, cons
         CRF_REQUIRE(c[i] && Q[i] && dc[i] && H[i] >= 1 && H[i] <= 64, CRF_ERR_ARG, "job %d: null pointer or H=%d outside [1, 64]", i, H[i]);
         j.c[i] = c[i]; j.Q_in[i] = Q[i]; j.gQ[i] = gQ[i]; j.gP[i] = gP[i]; j.dc[i] = dc[i]; j.H[i] = H[i];
     }
-    hipLaunchKernelGGL(crf::crf_matrices_bwd_batched_kernel, dim3((unsigned)n), dim3(256), 0, crf::as_stream(stream), j);
+    hipLaunchKernelGGL(crf::crf_matrices_bwd_batched_kernel, dim3((unsigned)n), dim3(crf::CMB_BLOCK), 0, crf::as_stream(stream), j);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
@@ -723,7 +761,7 @@ extern "C" int crfconv_spd_inverse(const float* M, int H, float* Q, crf_stream_t
 extern "C" int crfconv_crf_matrices(const float* c, int H, float* Q, float* P, crf_stream_t stream) {
     CRF_REQUIRE(c && Q && P, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(H >= 1 && H <= 64, CRF_ERR_UNSUPPORTED, "H=%d outside [1, 64]", H);
-    hipLaunchKernelGGL(crf::crf_matrices_kernel, dim3(1), dim3(256), 0, crf::as_stream(stream), c, H, Q, P);
+    hipLaunchKernelGGL(crf::crf_matrices_kernel, dim3(1), dim3(crf::CMF_BLOCK), 0, crf::as_stream(stream), c, H, Q, P);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
@@ -732,7 +770,7 @@ extern "C" int crfconv_crf_matrices_backward(const float* c, const float* Q, con
                                              float* dc, crf_stream_t stream) {
     CRF_REQUIRE(c && Q && dc, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(H >= 1 && H <= 64, CRF_ERR_UNSUPPORTED, "H=%d outside [1, 64]", H);
-    hipLaunchKernelGGL(crf::crf_matrices_bwd_kernel, dim3(1), dim3(256), 0, crf::as_stream(stream), c, Q, dQ, dP, H, dc);
+    hipLaunchKernelGGL(crf::crf_matrices_bwd_kernel, dim3(1), dim3(crf::CMB_BLOCK), 0, crf::as_stream(stream), c, Q, dQ, dP, H, dc);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
