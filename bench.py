@@ -333,7 +333,7 @@ def main():
         opt.zero_grad()
         logits = net(d)
         loss = ops.training_loss(logits, d.y, cw, ignore_index=-1)             # trainval.py:101-104, fused kernel
-        with ops.deferred_weight_grads():                 # one batched launch finishes all 74 dW / db reductions
+        with ops.deferred_weight_grads(sink=bucket.view_of):     # one batched launch finishes all 74 dW / db reductions, into the bucket
             loss.backward()
         bucket.pack()                                     # one batched copy into the flat bucket; .grad -> bucket views
         return loss.detach()

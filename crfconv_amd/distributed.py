@@ -45,6 +45,13 @@ class FlatGradAllReduce:
         for p in self.params:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
             o += p.numel()
+        self._view_of = {id(p): v for p, v in zip(self.params, self.views)}
+
+    def view_of(self, param):
+        """The bucket slice of `param` (None for a parameter outside the bucket): pass as
+        ``ops.deferred_weight_grads(sink=bucket.view_of)`` and the batched weight-gradient reduction writes straight into
+        the bucket -- ``pack()`` then has nothing to copy for those parameters."""
+        return self._view_of.get(id(param))
 
     def zero(self):
         for p in self.params:

@@ -452,18 +452,27 @@ _DEFER = {'on': False, 'jobs': [], 'armed': False}
 
 
 class deferred_weight_grads:
-    def __init__(self, enabled=True):
+    """``sink``: optional callable  parameter -> preallocated gradient tensor (or None), e.g.
+    ``FlatGradAllReduce.view_of``: the batched reduction then writes a weight gradient straight into the caller's flat
+    bucket slice and installs that slice as ``.grad`` (no copy at pack time); parameters whose ``.grad`` already exists
+    accumulate through a temporary as before."""
+
+    def __init__(self, enabled=True, sink=None):
         self.enabled = enabled
+        self.sink = sink
 
     def __enter__(self):
         self.prev = _DEFER['on']
+        self.prev_sink = _DEFER.get('sink')
         _DEFER['on'] = bool(self.enabled)
+        _DEFER['sink'] = self.sink
         if not self.prev:                 # outermost context: nothing of an earlier (failed) backward may linger
             _DEFER['jobs'], _DEFER['armed'] = [], False
         return self
 
     def __exit__(self, exc_type, *exc):
         _DEFER['on'] = self.prev
+        _DEFER['sink'] = self.prev_sink
         if exc_type is not None and not self.prev:
             # the backward raised after arming the engine callback: drop its queued partials, or every later backward
             # would find 'armed' set, never queue the callback again and silently lose all Linear weight gradients
@@ -497,21 +506,36 @@ def _flush_weight_grads():
     if not jobs:
         return
     dev = jobs[0][2].device
-    total = sum(Co * Ci + (Co if b is not None else 0) for _, b, _, _, Co, Ci in jobs)
-    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    sink = _DEFER.get('sink')
+
+    def direct(prm):                       # the caller's own gradient storage for this parameter, if it can be used as is
+        if sink is None or prm.grad is not None:
+            return None
+        dst = sink(prm)
+        if dst is None or dst.dtype != torch.float32 or not dst.is_contiguous() or dst.numel() != prm.numel():
+            return None
+        return dst
+    targets = [(direct(W), direct(b) if b is not None else None) for W, b, _, _, _, _ in jobs]
+    total = sum((Co * Ci if tw is None else 0) + (Co if (b is not None and tb is None) else 0)
+                for (_, b, _, _, Co, Ci), (tw, tb) in zip(jobs, targets))
+    flat = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
     table = (_lib.ReduceJob * (2 * len(jobs)))()
     installs, n, o = [], 0, 0
-    for W, b, ws, nblk, Co, Ci in jobs:
+    for (W, b, ws, nblk, Co, Ci), (tw, tb) in zip(jobs, targets):
         base = ws.data_ptr()
-        table[n] = _lib.ReduceJob(base, flat.data_ptr() + 4 * o, nblk, Co * Ci)
-        installs.append((W, flat[o:o + Co * Ci].view(Co, Ci)))
+        if tw is None:
+            tw = flat[o:o + Co * Ci].view(Co, Ci)
+            o += Co * Ci
+        table[n] = _lib.ReduceJob(base, tw.data_ptr(), nblk, Co * Ci)
+        installs.append((W, tw))
         n += 1
-        o += Co * Ci
         if b is not None:
-            table[n] = _lib.ReduceJob(base + 4 * nblk * Co * Ci, flat.data_ptr() + 4 * o, nblk, Co)
-            installs.append((b, flat[o:o + Co]))
+            if tb is None:
+                tb = flat[o:o + Co]
+                o += Co
+            table[n] = _lib.ReduceJob(base + 4 * nblk * Co * Ci, tb.data_ptr(), nblk, Co)
+            installs.append((b, tb))
             n += 1
-            o += Co
     _lib.call('crfconv_reduce_jobs', ctypes.cast(table, ctypes.c_void_p), n, stream_ptr())
     for prm, gr in installs:
         gr = gr.view_as(prm)

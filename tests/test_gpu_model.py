@@ -1107,6 +1107,44 @@ def test_deferred_weight_grads_equal_immediate():
     assert torch.isfinite(gw).all() and float(gw.abs().max()) > 0
 
 
+def test_deferred_weight_grads_into_the_flat_bucket():
+    """ops.deferred_weight_grads(sink=bucket.view_of): the batched dW / db reduction writes straight into the flat
+    gradient bucket.  Same values as without the sink, every Linear weight's .grad IS its bucket slice afterwards, pack()
+    leaves the bucket equal to the gradients, and a second (accumulating) pass still adds up."""
+    import crfconv_amd
+    from crfconv_amd import distributed as D, models, ops
+    B, N = 2, 4096
+    pos = np.stack([S.make_cloud(95 + b, N, box=(2, 2, 1)) for b in range(B)])
+    feats = np.concatenate([pos, S.uniform(95, 'rgb', (B, N, 3), 0, 1)], -1)
+    data = crfconv_amd.multiscale_compute(t(pos), t(feats), generator=torch.Generator().manual_seed(5))
+    labels = t(S.integers(95, 'y', (B, N), 0, 14))
+    net = models.PointConvBig(6, 13, use_crf=True, steps=2).to(DEV).train()
+    net.classifier[1] = FixedDropout(torch.ones(B, N, 128, device=DEV) * 0.5)
+    bucket = D.FlatGradAllReduce(net)
+
+    def run(sink, passes=1):
+        bucket.zero()
+        for _ in range(passes):
+            loss = ops.training_loss(net(data), labels, None, ignore_index=-1)
+            with ops.deferred_weight_grads(sink=sink):
+                loss.backward()
+        return {k: p.grad for k, p in net.named_parameters()}
+
+    ref = {k: v.clone() for k, v in run(None).items()}
+    got = run(bucket.view_of)
+    direct = 0
+    for (k, p), v in zip(net.named_parameters(), bucket.views):
+        assert float((got[k] - ref[k]).abs().max()) <= 1e-6 * float(ref[k].abs().max()) + 1e-9, k
+        direct += int(p.grad.data_ptr() == v.data_ptr())
+    assert direct >= 40                                   # every Linear weight went straight into the bucket
+    bucket.pack()
+    for (k, p), v in zip(net.named_parameters(), bucket.views):
+        assert p.grad.data_ptr() == v.data_ptr() and torch.equal(v, got[k])
+    two = run(bucket.view_of, passes=2)                   # second pass: .grad exists -> accumulate through a temporary
+    for k in ref:
+        assert float((two[k] - 2 * ref[k]).abs().max()) <= 1e-5 * float(ref[k].abs().max()) + 1e-9, k
+
+
 @pytest.mark.parametrize('cfg', [dict(momentum=0.95, weight_decay=1e-4), dict(momentum=0.0, weight_decay=0.0),
                                  dict(momentum=0.9, weight_decay=1e-3, nesterov=True), dict(momentum=0.9, dampening=0.1)])
 def test_flat_sgd_matches_torch_sgd(cfg):
