@@ -95,6 +95,7 @@ SIGNATURES = {
     'crfconv_crf_matrices_batched': (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     'crfconv_crf_matrices_backward_batched': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'crfconv_add_lrelu': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
+    'crfconv_bn_apply_add': (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp]),
     'crfconv_add_lrelu_backward': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
     'crfconv_sgd_step': (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _i, _vp]),
     'crfconv_sgd_step_hyper': (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp]),

@@ -126,6 +126,26 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(const float* __restr
 }
 
 // backward reductions: partial[blk][0][C] = sum g_pre, [1][C] = sum g_pre * xhat
+// The ResNet join  out = lrelu(BN(y) + skip, slope)  (models/point_conv_big.py:84-88: lin_out has no activation, then
+// F.leaky_relu(x + shortcut)): BatchNorm's affine, the residual add and the activation in ONE pass -- the normalised
+// tensor never reaches memory.  Same arithmetic, operation for operation, as bn_apply (slope 1) followed by add_lrelu.
+__global__ __launch_bounds__(BN_BLOCK) void bn_apply_add_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                                const float* __restrict__ skip, int64_t n4, int C4,
+                                                                float slope, float* __restrict__ y) {
+    for (int64_t t = (int64_t)blockIdx.x * BN_BLOCK + threadIdx.x; t < n4; t += (int64_t)gridDim.x * BN_BLOCK) {
+        const int q = (int)(t % C4);
+        const float4 a = ld4g(coef + 4 * q), b = ld4g(coef + 4 * C4 + 4 * q);
+        const float4 v = ld4g(x + 4 * t), k = ld4g(skip + 4 * t);
+        float4 o = make_float4(add_rn(fmaf(a.x, v.x, b.x), k.x), add_rn(fmaf(a.y, v.y, b.y), k.y),
+                               add_rn(fmaf(a.z, v.z, b.z), k.z), add_rn(fmaf(a.w, v.w, b.w), k.w));
+        o.x = o.x > 0.f ? o.x : slope * o.x;
+        o.y = o.y > 0.f ? o.y : slope * o.y;
+        o.z = o.z > 0.f ? o.z : slope * o.z;
+        o.w = o.w > 0.f ? o.w : slope * o.w;
+        st4(y + 4 * t, o);
+    }
+}
+
 __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(const float* __restrict__ gy,
                                                                  const float* __restrict__ x,
                                                                  const float* __restrict__ coef, int64_t M, int C,
@@ -493,6 +513,19 @@ extern "C" int crfconv_bn_apply(const float* x, int64_t M, int C, const float* c
     CRF_REQUIRE(x && coef && y, CRF_ERR_ARG, "null pointer");
     const int64_t n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(BN_BLOCK), 0, as_stream(stream), x, coef, n4, C / 4, slope, y);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+// out = lrelu(a x + b + skip, slope) with existing coefficients: BatchNorm (no activation of its own), the residual add and
+// the join's LeakyReLU in one pass.  out may alias skip.
+extern "C" int crfconv_bn_apply_add(const float* x, int64_t M, int C, const float* coef, const float* skip, float slope,
+                                    float* out, crf_stream_t stream) {
+    if (int rc = bn_check(M, C)) return rc;
+    CRF_REQUIRE(x && coef && skip && out, CRF_ERR_ARG, "null pointer");
+    const int64_t n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_add_kernel, dim3(ew_grid(n4)), dim3(BN_BLOCK), 0, as_stream(stream), x, coef, skip, n4, C / 4,
+                       slope, out);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

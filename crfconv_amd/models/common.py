@@ -61,6 +61,18 @@ class MLP(nn.Module):
         return x
 
 
+def mlp_join(mlp, x, skip, slope=0.01):
+    """leaky_relu(mlp(x) + skip, slope) for an MLP without activation -- the tail of a ResNet block
+    (models/point_conv_big.py:84-88).  One fused node (BatchNorm + add + LeakyReLU in a single pass) where it applies
+    (training, MFMA-sized rows), else the module followed by ops.add_lrelu."""
+    if (mlp.training and mlp.bn is not None and mlp.activation is None and mlp.lin.bias is None and x.dtype == torch.float32
+            and mlp.bn.batch_norm.affine and mlp.lin.out_features % 4 == 0):
+        out = ops.mlp_block_join(x, mlp.lin.weight, mlp.bn.batch_norm, skip, slope)
+        if out is not None:
+            return out
+    return ops.add_lrelu(mlp(x), skip, slope)
+
+
 class Base(nn.Module):
     """state_dict round trip (models/common.py:89-97)."""
 

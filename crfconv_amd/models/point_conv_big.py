@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..graph import table_of
-from .common import MLP, Base
+from .common import MLP, Base, mlp_join
 from .continuous_crf_conv_big import ContinuousGaussianCRFConv as CRFConv
 
 WIDTHS = (32, 64, 128, 256, 512)          # channel width of encoder level 0..4 (reference :113)
@@ -81,8 +81,8 @@ class ResNetBBlock(nn.Module):
         skip = self.shortcut(x)
         if not torch.is_tensor(pos):                       # strided block: pool the shortcut onto the coarse points
             skip = self.max_pooling(skip, neighbor_idx)
-        y = self.lin_out(self.point_conv(self.lin_in(x), pos, neighbor_idx))
-        return ops.add_lrelu(y, skip, 0.01)                # F.leaky_relu default slope, as the reference
+        y = self.point_conv(self.lin_in(x), pos, neighbor_idx)
+        return mlp_join(self.lin_out, y, skip, 0.01)       # lin_out + add + F.leaky_relu (default slope), as the reference
 
 
 class Upsampling(nn.Module):

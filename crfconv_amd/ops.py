@@ -781,6 +781,69 @@ class _MLPBlock(torch.autograd.Function):
         return dX, dW, dgamma, dbeta, None, None, None, None, None
 
 
+_NO_JOIN_ENV = __import__('os').environ.get('CRFCONV_NO_JOIN_FUSION') is not None      # A/B: bn_apply + add_lrelu as two passes
+
+
+class _MLPBlockJoin(torch.autograd.Function):
+    """out = lrelu(BN_train(x W^T) + skip, slope): the tail of a ResNet block (models/point_conv_big.py:84-88: lin_out has no
+    activation, then F.leaky_relu(x + shortcut)) as one node -- forward: MFMA Linear with statistic records, coefficients, ONE
+    pass for BatchNorm + residual add + LeakyReLU (crfconv_bn_apply_add; the normalised tensor never reaches memory);
+    backward: g1 = g lrelu'(out) is both the skip gradient and the gA of crfconv_mlp_backward (BatchNorm without activation)."""
+
+    @staticmethod
+    def forward(ctx, x, W, gamma, beta, run_mean, run_var, momentum, eps, skip, slope):
+        x, Wc, skip = x.contiguous(), W.contiguous(), skip.contiguous()
+        m, ci = x.shape
+        co = Wc.shape[0]
+        y, rec = _mfma_matmul(x, Wc, None, False, True)
+        coef = torch.empty(4 * co, dtype=torch.float32, device=x.device)
+        st = stream_ptr()
+        _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
+                  ptr(run_var), float(momentum), float(eps), ptr(coef), st)
+        out = torch.empty_like(y)
+        _lib.call('crfconv_bn_apply_add', ptr(y), m, co, ptr(coef), ptr(skip), float(slope), ptr(out), st)
+        ctx.save_for_backward(x, Wc, y, coef, out)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, y, coef, out = ctx.saved_tensors
+        m, ci = x.shape
+        co = W.shape[0]
+        dev = x.device
+        g = g.contiguous()
+        g1 = torch.empty_like(g)
+        st = stream_ptr()
+        _lib.call('crfconv_add_lrelu_backward', ptr(g), ptr(out), out.numel(), ctx.slope, ptr(g1), st)
+        dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.call('crfconv_mlp_backward', ptr(g1), ptr(y), ptr(x), ptr(W), ptr(coef), 1.0, m, ci, co, ptr(dX), ptr(dW),
+                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
+        return dX, dW, dgamma, dbeta, None, None, None, None, (g1 if ctx.needs_input_grad[8] else None), None
+
+
+def mlp_block_join(x, W, bn, skip, slope):
+    """lrelu(BatchNorm_train(x W^T) + skip, slope) as one node where the big-level fused block applies, else None (the
+    caller then runs its own lin_out + add_lrelu)."""
+    if _NO_JOIN_ENV or skip.shape[:-1] != x.shape[:-1] or skip.shape[-1] != W.shape[0] or skip.dtype != torch.float32:
+        return None
+    m = x.numel() // x.shape[-1]
+    ci, co = x.shape[-1], W.shape[0]
+    if not (mlp_block_ok(x, W, None, bn, True) and not _mlp_small_ok(m, ci, co)):
+        return None
+    require_gpu(x, W, skip)
+    tick(bn)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    out = _MLPBlockJoin.apply(x.reshape(-1, ci), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps,
+                              skip.reshape(-1, co), slope)
+    return out.reshape(x.shape[:-1] + (co,))
+
+
 _NO_SMALL_MLP_ENV = __import__('os').environ.get('CRFCONV_NO_SMALL_MLP') is not None      # A/B: vendor GEMM + bn_small at the coarse levels
 _sync_ws = {}
 

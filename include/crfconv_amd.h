@@ -451,6 +451,11 @@ int crfconv_gather_rows_backward(const float* gout, const int32_t* rev_ptr,
 /* out = lrelu(a + b, slope) over n floats (n % 4 == 0): the residual join of the ResNet block
  * (point_conv_big.py:86-88); backward gin = gout * (out > 0 ? 1 : slope), shared by both addends. */
 int crfconv_add_lrelu(const float* a, const float* b, int64_t n, float slope, float* out, crf_stream_t stream);
+/* The ResNet join of models/point_conv_big.py:84-88 in one pass: out = lrelu(a x + b + skip, slope), coef = the [4, C]
+ * block of crfconv_bn_forward / crfconv_bn_coef_from_records for x (a BatchNorm without activation), skip / out [M, C].
+ * Same arithmetic as crfconv_bn_apply(slope 1) followed by crfconv_add_lrelu, without the intermediate tensor. */
+int crfconv_bn_apply_add(const float* x, int64_t M, int C, const float* coef, const float* skip, float slope, float* out,
+                         crf_stream_t stream);
 int crfconv_add_lrelu_backward(const float* gout, const float* out, int64_t n, float slope, float* gin,
                                crf_stream_t stream);
 

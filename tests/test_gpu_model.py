@@ -839,6 +839,54 @@ def test_mlp_block_fused_backward(M, Ci, Co, slope, need_dx):
     assert int(bn.num_batches_tracked) == 1
 
 
+def test_resnet_join_fused_equals_two_passes():
+    """models.common.mlp_join: lin_out's BatchNorm + the residual add + LeakyReLU as ONE pass (crfconv_bn_apply_add, one
+    autograd node) against bn_apply followed by add_lrelu: the same arithmetic operation for operation, so outputs and every
+    gradient are bit-identical -- for a block with an identity skip and for one whose shortcut is an MLP."""
+    from crfconv_amd import models, ops
+    from crfconv_amd.models.point_conv_big import ResNetBBlock
+    import crfconv_amd
+    B, N = 2, 4096
+    pos = np.stack([S.make_cloud(300 + b, N, box=(2, 2, 1)) for b in range(B)])
+    data = crfconv_amd.multiscale_compute(t(pos), generator=torch.Generator().manual_seed(2))
+    lvl = data.multiscale[0]
+    for cin, cout in ((32, 32), (16, 32)):
+        torch.manual_seed(cin)
+        blk = ResNetBBlock(cin, cout).to(DEV).train()
+        x0 = torch.randn(B, N, cin, generator=torch.Generator().manual_seed(9)).to(DEV)
+        go = torch.randn(B, N, cout, generator=torch.Generator().manual_seed(10)).to(DEV)
+        res = []
+        for fused in (True, False):
+            ops._NO_JOIN_ENV = not fused
+            for p in blk.parameters():
+                p.grad = None
+            for m in blk.modules():                                  # same running statistics in both runs
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.reset_running_stats()
+            x = x0.clone().requires_grad_(True)
+            out = blk(x, lvl.pos, lvl.neighbor_idx)
+            if fused:
+                names = set()
+                stack = [out.grad_fn]
+                while stack:
+                    f = stack.pop()
+                    if f is None or f in names:
+                        continue
+                    names.add(f)
+                    stack.extend(g for g, _ in f.next_functions)
+                assert any('_MLPBlockJoin' in f.name() for f in names)
+            out.backward(go)
+            res.append((out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}))
+        ops._NO_JOIN_ENV = False
+        (o1, gx1, gp1), (o2, gx2, gp2) = res
+        assert torch.equal(o1, o2) and torch.equal(gx1, gx2)
+        for k in gp1:
+            if 'point_conv' in k and 'weight_nn.1.lin' in k:
+                assert_close(gp1[k], gp2[k], 1e-6, k)                # dW2 of a narrow PointConv: LDS float atomics
+            else:
+                assert torch.equal(gp1[k], gp2[k]), k
+
+
 def test_mlp_small_one_launch_kernel_under_graph_replay():
     """The coarse-level one-launch forward synchronises its workgroups through device words that every launch must leave
     zero, and exchanges statistic records past L1: captured into a hipGraph and replayed back to back on CHANGING inputs
