@@ -101,6 +101,7 @@ SIGNATURES = {
     'crfconv_sgd_step_hyper': (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp]),
     'crfconv_spd_inverse': (_i, [_vp, _i, _vp, _vp]),
     'crfconv_neighbor_maxpool_forward': (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp]),
+    'crfconv_neighbor_maxpool_affine_forward': (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp]),
     'crfconv_neighbor_maxpool_backward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),
     'crfconv_gather_rows': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     'crfconv_gather_rows_backward': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),

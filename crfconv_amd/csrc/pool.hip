@@ -5,16 +5,23 @@
 
 namespace crf {
 
+// AFFINE: the pooled quantity is a x + b per channel (coef = [a | b | ..] rows of C floats: a BatchNorm without activation
+// applied while gathering -- the strided shortcut of a ResNet block, models/point_conv_big.py:74-83 -- so the normalised
+// fine-level tensor never reaches memory; fmaf(a, x, b) is exactly what bn_apply would have stored).
+template <bool AFFINE>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x,
                                                           const int32_t* __restrict__ idx, int K,
                                                           int64_t m_tgt, int C4,
                                                           float* __restrict__ out,
-                                                          int32_t* __restrict__ arg) {
+                                                          int32_t* __restrict__ arg,
+                                                          const float* __restrict__ coef) {
     const int64_t t = (int64_t)xcd_block_id() * 256 + threadIdx.x;
     if (t >= m_tgt * C4) return;
     const int64_t i = t / C4;
     const int q = (int)(t - i * C4);
     const int32_t* irow = idx + i * K;
+    float4 ca = make_float4(1.f, 1.f, 1.f, 1.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (AFFINE) { ca = ld4(coef + 4 * q); cb = ld4(coef + 4 * C4 + 4 * q); }
     const float ninf = -__builtin_inff();
     float4 best = make_float4(ninf, ninf, ninf, ninf);
     int4 who = make_int4(-1, -1, -1, -1);
@@ -28,7 +35,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (jn[u] < 0) continue;                             // "no neighbour" entry of a padded table
-            const float4 v = vn[u];
+            float4 v = vn[u];
+            if constexpr (AFFINE) v = make_float4(fmaf(ca.x, v.x, cb.x), fmaf(ca.y, v.y, cb.y), fmaf(ca.z, v.z, cb.z), fmaf(ca.w, v.w, cb.w));
             const int k = k0 + u;
             if (v.x > best.x || who.x < 0) { best.x = v.x; who.x = k; }
             if (v.y > best.y || who.y < 0) { best.y = v.y; who.y = k; }
@@ -158,8 +166,20 @@ extern "C" int crfconv_neighbor_maxpool_forward(const float* x, const int32_t* i
     if (int rc = check(m_tgt, C)) return rc;
     CRF_REQUIRE(x && idx32 && out && arg && K >= 1, CRF_ERR_ARG, "null pointer / K");
     const int64_t n = m_tgt * (C / 4);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), x,
-                       idx32, K, m_tgt, C / 4, out, arg);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<false>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), x,
+                       idx32, K, m_tgt, C / 4, out, arg, (const float*)nullptr);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+// out[i,c] = max_k (a[c] x[idx32[i,k], c] + b[c]),  coef = [a | b | ...] (the [4, C] block of crfconv_bn_coef_from_records).
+extern "C" int crfconv_neighbor_maxpool_affine_forward(const float* x, const float* coef, const int32_t* idx32, int K,
+                                                       int64_t m_tgt, int C, float* out, int32_t* arg, crf_stream_t stream) {
+    if (int rc = check(m_tgt, C)) return rc;
+    CRF_REQUIRE(x && coef && idx32 && out && arg && K >= 1, CRF_ERR_ARG, "null pointer / K");
+    const int64_t n = m_tgt * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), x,
+                       idx32, K, m_tgt, C / 4, out, arg, coef);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -78,9 +78,19 @@ class ResNetBBlock(nn.Module):
         return pooled.reshape(x.shape[0], -1, x.shape[-1])
 
     def forward(self, x, pos, neighbor_idx):
-        skip = self.shortcut(x)
-        if not torch.is_tensor(pos):                       # strided block: pool the shortcut onto the coarse points
-            skip = self.max_pooling(skip, neighbor_idx)
+        strided = not torch.is_tensor(pos)
+        skip = None
+        sc = self.shortcut
+        if (strided and self.training and isinstance(sc, MLP) and sc.bn is not None and sc.activation is None
+                and sc.lin.bias is None and x.dtype == torch.float32 and sc.bn.batch_norm.affine):
+            # shortcut MLP + max-pool as one node: BatchNorm applied while the pool gathers (ops.mlp_block_pool)
+            pooled = ops.mlp_block_pool(_flat(x), sc.lin.weight, sc.bn.batch_norm, table_of(neighbor_idx, x.shape[1]))
+            if pooled is not None:
+                skip = pooled.reshape(x.shape[0], -1, pooled.shape[-1])
+        if skip is None:
+            skip = sc(x)
+            if strided:                                    # strided block: pool the shortcut onto the coarse points
+                skip = self.max_pooling(skip, neighbor_idx)
         y = self.point_conv(self.lin_in(x), pos, neighbor_idx)
         return mlp_join(self.lin_out, y, skip, 0.01)       # lin_out + add + F.leaky_relu (default slope), as the reference
 

@@ -827,6 +827,69 @@ class _MLPBlockJoin(torch.autograd.Function):
         return dX, dW, dgamma, dbeta, None, None, None, None, (g1 if ctx.needs_input_grad[8] else None), None
 
 
+class _MLPBlockPool(torch.autograd.Function):
+    """max over the table's neighbours of BN_train(x W^T): the strided shortcut of a ResNet block
+    (models/point_conv_big.py:74-83) as one node.  Forward: MFMA Linear with statistic records, coefficients, max-pool that
+    applies the BatchNorm affine while gathering (crfconv_neighbor_maxpool_affine_forward) -- the normalised fine-level
+    tensor never reaches memory; backward: the pool's scatter gives gA, then crfconv_mlp_backward (BatchNorm, no activation)."""
+
+    @staticmethod
+    def forward(ctx, x, W, gamma, beta, run_mean, run_var, momentum, eps, table):
+        x, Wc = x.contiguous(), W.contiguous()
+        m, ci = x.shape
+        co = Wc.shape[0]
+        dev = x.device
+        y, rec = _mfma_matmul(x, Wc, None, False, True)
+        coef = torch.empty(4 * co, dtype=torch.float32, device=dev)
+        st = stream_ptr()
+        _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
+                  ptr(run_var), float(momentum), float(eps), ptr(coef), st)
+        out = torch.empty((table.m_tgt, co), dtype=torch.float32, device=dev)
+        arg = torch.empty((table.m_tgt, co), dtype=torch.int32, device=dev)
+        _lib.call('crfconv_neighbor_maxpool_affine_forward', ptr(y), ptr(coef), ptr(table.idx32), table.K, table.m_tgt, co,
+                  ptr(out), ptr(arg), st)
+        ctx.table = table
+        ctx.save_for_backward(x, Wc, y, coef, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, y, coef, arg = ctx.saved_tensors
+        table = ctx.table
+        m, ci = x.shape
+        co = W.shape[0]
+        dev = x.device
+        g = _f32c(g)
+        st = stream_ptr()
+        rev_ptr, rev_eid = table.reverse
+        gA = torch.empty((m, co), dtype=torch.float32, device=dev)
+        _lib.call('crfconv_neighbor_maxpool_backward', ptr(g), ptr(arg), ptr(rev_ptr), ptr(rev_eid), table.K, m, co, ptr(gA), st)
+        dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), 1.0, m, ci, co, ptr(dX), ptr(dW),
+                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
+        return dX, dW, dgamma, dbeta, None, None, None, None, None
+
+
+def mlp_block_pool(x, W, bn, table):
+    """neighbor_maxpool(BatchNorm_train(x W^T), table) as one node where the big-level fused block applies (x [m_src, Ci]
+    rows of the table's source level), else None."""
+    if _NO_JOIN_ENV or table.padded:
+        return None
+    m, ci = x.shape
+    co = W.shape[0]
+    if m != table.m_src or not (mlp_block_ok(x, W, None, bn, True) and not _mlp_small_ok(m, ci, co)):
+        return None
+    require_gpu(x, W)
+    tick(bn)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    return _MLPBlockPool.apply(x, W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, table)
+
+
 def mlp_block_join(x, W, bn, skip, slope):
     """lrelu(BatchNorm_train(x W^T) + skip, slope) as one node where the big-level fused block applies, else None (the
     caller then runs its own lin_out + add_lrelu)."""

@@ -436,6 +436,11 @@ int crfconv_crf_matrices_backward_batched(const float* const* c, const float* co
  * out[i,c] = max_k x[idx32[i,k], c];  arg [m_tgt, C] int32 = winning k (first maximum). */
 int crfconv_neighbor_maxpool_forward(const float* x, const int32_t* idx32, int K, int64_t m_tgt,
                                      int C, float* out, int32_t* arg, crf_stream_t stream);
+/* The strided shortcut of a ResNet block (models/point_conv_big.py:74-83: shortcut MLP, then max over the sub_idx
+ * neighbours) without the normalised fine-level tensor: out[i,c] = max_k (a[c] x[idx32[i,k], c] + b[c]) with coef = the
+ * [4, C] block of crfconv_bn_coef_from_records for x.  arg as above; the backward is crfconv_neighbor_maxpool_backward. */
+int crfconv_neighbor_maxpool_affine_forward(const float* x, const float* coef, const int32_t* idx32, int K, int64_t m_tgt,
+                                            int C, float* out, int32_t* arg, crf_stream_t stream);
 /* dx[j,c] = sum over incoming edges (i,k) with arg[i,c] == k of gout[i,c]. */
 int crfconv_neighbor_maxpool_backward(const float* gout, const int32_t* arg,
                                       const int32_t* rev_ptr, const int32_t* rev_eid, int K,

@@ -842,7 +842,8 @@ def test_mlp_block_fused_backward(M, Ci, Co, slope, need_dx):
 def test_resnet_join_fused_equals_two_passes():
     """models.common.mlp_join: lin_out's BatchNorm + the residual add + LeakyReLU as ONE pass (crfconv_bn_apply_add, one
     autograd node) against bn_apply followed by add_lrelu: the same arithmetic operation for operation, so outputs and every
-    gradient are bit-identical -- for a block with an identity skip and for one whose shortcut is an MLP."""
+    gradient are bit-identical -- for a block with an identity skip, for one whose shortcut is an MLP, and for a strided
+    block, whose shortcut MLP + neighbour max-pool is one node too (BatchNorm applied while the pool gathers)."""
     from crfconv_amd import models, ops
     from crfconv_amd.models.point_conv_big import ResNetBBlock
     import crfconv_amd
@@ -850,11 +851,14 @@ def test_resnet_join_fused_equals_two_passes():
     pos = np.stack([S.make_cloud(300 + b, N, box=(2, 2, 1)) for b in range(B)])
     data = crfconv_amd.multiscale_compute(t(pos), generator=torch.Generator().manual_seed(2))
     lvl = data.multiscale[0]
-    for cin, cout in ((32, 32), (16, 32)):
+    for cin, cout, strided in ((32, 32, False), (16, 32, False), (32, 64, True)):
         torch.manual_seed(cin)
         blk = ResNetBBlock(cin, cout).to(DEV).train()
+        blk_pos = (lvl.pos, data.multiscale[1].pos) if strided else lvl.pos      # strided: shortcut MLP + max-pool as one node
+        blk_idx = lvl.sub_idx if strided else lvl.neighbor_idx
+        n_out = data.multiscale[1].pos.shape[1] if strided else N
         x0 = torch.randn(B, N, cin, generator=torch.Generator().manual_seed(9)).to(DEV)
-        go = torch.randn(B, N, cout, generator=torch.Generator().manual_seed(10)).to(DEV)
+        go = torch.randn(B, n_out, cout, generator=torch.Generator().manual_seed(10)).to(DEV)
         res = []
         for fused in (True, False):
             ops._NO_JOIN_ENV = not fused
@@ -864,7 +868,7 @@ def test_resnet_join_fused_equals_two_passes():
                 if isinstance(m, torch.nn.BatchNorm1d):
                     m.reset_running_stats()
             x = x0.clone().requires_grad_(True)
-            out = blk(x, lvl.pos, lvl.neighbor_idx)
+            out = blk(x, blk_pos, blk_idx)
             if fused:
                 names = set()
                 stack = [out.grad_fn]
@@ -874,7 +878,9 @@ def test_resnet_join_fused_equals_two_passes():
                         continue
                     names.add(f)
                     stack.extend(g for g, _ in f.next_functions)
-                assert any('_MLPBlockJoin' in f.name() for f in names)
+                # (the join applies at MFMA-sized levels; the strided block's output level here has 2048 rows -> one-launch MLP)
+                assert any('_MLPBlockJoin' in f.name() for f in names) == (B * n_out >= ops._MFMA_MIN_ROWS)
+                assert any('_MLPBlockPool' in f.name() for f in names) == strided
             out.backward(go)
             res.append((out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}))
         ops._NO_JOIN_ENV = False
