@@ -273,7 +273,13 @@ __global__ __launch_bounds__(QBLOCK) void knn_query_kernel(const float* __restri
 // pool could overflow -- the group ranks the pool entries against each other (entry i's rank = number of smaller keys)
 // and the sixteen smallest land, sorted, in slots 0..15: that is the running top-K, its last key the new bound, and
 // at the end the output row.  Same keys, same stop test -> same tables as the one-lane kernel.
-constexpr int CO_LPQ = 16, CO_BLOCK = 256, CO_QPB = CO_BLOCK / CO_LPQ, CO_CAP = 128, CO_CHUNK = 4;
+#ifndef CO_LPQ_
+#define CO_LPQ_ 16          // lanes per query; swept on 4 x 40960 self-queries: 8 lanes 262 us, 16 lanes 232 us, 32 lanes 289 us per call
+#endif
+#ifndef CO_CAP_
+#define CO_CAP_ 128
+#endif
+constexpr int CO_LPQ = CO_LPQ_, CO_BLOCK = 256, CO_QPB = CO_BLOCK / CO_LPQ, CO_CAP = CO_CAP_, CO_CHUNK = 4;
 constexpr int CO_ROUND = CO_LPQ * CO_CHUNK;          // appends of one chunk round at most
 
 template <int KM>      // K <= KM <= 16
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(CO_BLOCK) void knn_coop_kernel(const float* __restr
     __shared__ unsigned long long s_pool[2][CO_QPB][CO_CAP];       // double-buffered: a compaction writes the other buffer
     __shared__ int s_cnt[CO_QPB];
     const int b = blockIdx.y;
-    const int l = threadIdx.x & (CO_LPQ - 1), qs = threadIdx.x >> 4;
+    const int l = threadIdx.x & (CO_LPQ - 1), qs = threadIdx.x / CO_LPQ;
     const int gshift = (threadIdx.x & 63) & ~(CO_LPQ - 1);         // first lane of this group inside its wavefront
     int64_t qi = (int64_t)blockIdx.x * CO_QPB + qs;
     const bool qvalid = qi < nq;
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(CO_BLOCK) void knn_coop_kernel(const float* __restr
             segment(r, s0 + l, pb, pe);
             for (;;) {
                 const unsigned long long vote = __ballot(pb < pe);
-                if (((vote >> gshift) & 0xffffull) == 0ull) break;
+                if (((vote >> gshift) & ((1ull << CO_LPQ) - 1ull)) == 0ull) break;
                 if (room < CO_ROUND) {                              // the conservative count says the pool could overflow
                     __builtin_amdgcn_wave_barrier();
                     room = CO_CAP - s_cnt[qs];
@@ -382,7 +388,8 @@ __global__ __launch_bounds__(CO_BLOCK) void knn_coop_kernel(const float* __restr
                     // entries by now: the largest of ANY K candidates is an upper bound of the K-th smallest
                     __builtin_amdgcn_wave_barrier();
                     if (s_cnt[qs] >= K) {
-                        unsigned long long v = l < K ? pool[l] : 0ull;
+                        unsigned long long v = 0ull;
+                        for (int i = l; i < K; i += CO_LPQ) v = pool[i] > v ? pool[i] : v;
 #pragma unroll
                         for (int o = 1; o < CO_LPQ; o <<= 1) {
                             const unsigned long long w = __shfl_xor(v, o, WAVE);
@@ -427,11 +434,13 @@ __global__ __launch_bounds__(CO_BLOCK) void knn_coop_kernel(const float* __restr
         const float kth = __uint_as_float((unsigned int)(bound >> 32));
         if (safe > 0.f && bound != KNN_KEY_INF && kth < safe * safe) break;
     }
-    if (qvalid && l < K) {
-        const int id = (int)(unsigned int)(pool[l] & 0xffffffffull);
-        const int64_t o = ((int64_t)b * nq + qi) * K + l;
-        if (out64) out64[o] = id;
-        if (out32) out32[o] = id;
+    if (qvalid) {
+        for (int i = l; i < K; i += CO_LPQ) {
+            const int id = (int)(unsigned int)(pool[i] & 0xffffffffull);
+            const int64_t o = ((int64_t)b * nq + qi) * K + i;
+            if (out64) out64[o] = id;
+            if (out32) out32[o] = id;
+        }
     }
 }
 
