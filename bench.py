@@ -532,9 +532,11 @@ def main():
             def run_pipe(n, i0):
                 for i in range(i0, i0 + n):
                     slot = i % 2
-                    pipe.submit(1 - slot, *raws[(i + 1) % 2])
                     pipe.acquire(slot)
                     gas[slot].replay()
+                    # next batch: its host part (subset draw, argsort launches) now runs while the step above computes; the
+                    # side stream waits only for the release of the slot it overwrites (the clouds were uploaded long ago)
+                    pipe.submit(1 - slot, *raws[(i + 1) % 2], wait_current=False)
                     collective()
                     gb.replay()
                     pipe.release(slot)

@@ -280,9 +280,10 @@ class CollatePipeline:
         pipe.submit(0, pos0, x0, y0)
         for i, (pos, x, y) in enumerate(next_clouds):
             s = i % 2
-            pipe.submit(1 - s, pos, x, y)          # side stream: waits until the step that last used that slot has finished
             batch = pipe.acquire(s)                # caller's stream waits for slot s's collate
-            train_graph[s].replay()
+            train_graph[s].replay()                # (launch first: the host part of the next collate hides behind it)
+            pipe.submit(1 - s, pos, x, y, wait_current=False)   # side stream: waits only for slot 1 - s's release
+            optimizer_graph.replay()
             pipe.release(s)                        # slot s may be overwritten once the work queued so far has run
     """
 
@@ -293,7 +294,11 @@ class CollatePipeline:
         self._ready = [torch.cuda.Event() for _ in self.batches]
         self._free = [None for _ in self.batches]
 
-    def submit(self, slot, pos, x=None, y=None):
+    def submit(self, slot, pos, x=None, y=None, wait_current=True):
+        """Queue the collate of `pos` / `x` / `y` into slot `slot` on the side stream.  wait_current=False: the inputs are
+        known to be complete already (e.g. produced long ago, or on another stream the caller has synchronised with), so the
+        side stream only waits for the slot's release -- call it AFTER launching the current training step and the host part
+        of the collate (subset draw, argsort launches) hides behind that step too."""
         cg = self.graphs[slot]
         if cg.graph is None:                       # first use captures (with its own warm-up and a device synchronize)
             torch.cuda.synchronize()
@@ -302,7 +307,8 @@ class CollatePipeline:
                 self._ready[slot].record()
             torch.cuda.synchronize()
             return
-        self.stream.wait_stream(torch.cuda.current_stream())      # the caller produced pos / x / y on its stream
+        if wait_current:
+            self.stream.wait_stream(torch.cuda.current_stream())  # the caller produced pos / x / y on its stream
         if self._free[slot] is not None:
             self.stream.wait_event(self._free[slot])
         with torch.cuda.stream(self.stream):
