@@ -499,8 +499,9 @@ def main():
              'collate_ms_per_batch': float(np.median(t_collate)) * 1e3,
              'table_refresh_ms_per_batch': float(np.median(t_load)) * 1e3,
              'note': 'fresh batch -> MultiScaleData.load_ into the static buffers -> hipGraph replay, against an eager step '
-                     'from the same weights on an independent collate of the same clouds; the two losses differ only by the '
-                     'Dropout(0.5) draws of the classifier (different RNG offsets), the refreshed tables are compared bit for bit'}
+                     'from the same weights and BatchNorm counters on an independent collate of the same clouds; the classifier\'s dropout mask '
+                     'is keyed on (seed, step counter, element), so both runs draw the same mask and the losses agree; the refreshed '
+                     'tables are compared bit for bit'}
     fresh['collate_plus_refresh_graph_ms_per_batch'] = None if t_graph is None else t_graph * 1e3
     fresh['collate_graph_parts'] = cg_parts if t_graph is not None else None
     per_batch_ms = ms_per_step + (t_graph * 1e3 if t_graph is not None else

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'libcrfconv_amd.so')
 
 _vp, _i, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 _d = ctypes.c_double
+_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); mirrors include/crfconv_amd.h one to one
 SIGNATURES = {
@@ -96,6 +97,8 @@ SIGNATURES = {
     'crfconv_crf_matrices_backward_batched': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'crfconv_add_lrelu': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
     'crfconv_bn_apply_add': (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp]),
+    'crfconv_bn_apply_dropout': (_i, [_vp, _i64, _i, _vp, _f, _f, _u64, _vp, _vp, _vp]),
+    'crfconv_dropout_backward': (_i, [_vp, _i64, _f, _u64, _vp, _vp, _vp]),
     'crfconv_add_lrelu_backward': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
     'crfconv_sgd_step': (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _i, _vp]),
     'crfconv_sgd_step_hyper': (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp]),

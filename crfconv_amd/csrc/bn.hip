@@ -146,6 +146,58 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply_add_kernel(const float* __r
     }
 }
 
+// Counter-based dropout mask shared by the forward and the backward pass: element e of the call with (seed, *counter) is kept
+// iff the top 32 bits of a splitmix64 round of (seed, counter, e) reach `threshold` = p 2^32.  *counter is a DEVICE word that
+// the caller advances between training steps (the classifier BatchNorm's num_batches_tracked), so a captured hipGraph draws a
+// new mask at every replay while forward and backward of one step agree without a stored mask.
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long ctr, unsigned long long e, unsigned threshold) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1ull) + e * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32) >= threshold;
+}
+
+// y = dropout(lrelu(a x + b, slope), p) in one pass (models/point_conv_big.py:131-134: MLP -> nn.Dropout(0.5)).
+__global__ __launch_bounds__(BN_BLOCK) void bn_apply_dropout_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                                    int64_t n4, int C4, float slope, unsigned long long seed,
+                                                                    const long long* __restrict__ counter, unsigned threshold,
+                                                                    float scale, float* __restrict__ y) {
+    const unsigned long long ctr = (unsigned long long)counter[0];
+    for (int64_t t = (int64_t)blockIdx.x * BN_BLOCK + threadIdx.x; t < n4; t += (int64_t)gridDim.x * BN_BLOCK) {
+        const int q = (int)(t % C4);
+        const float4 a = ld4g(coef + 4 * q), b = ld4g(coef + 4 * C4 + 4 * q);
+        const float4 v = ld4g(x + 4 * t);
+        float4 o = make_float4(fmaf(a.x, v.x, b.x), fmaf(a.y, v.y, b.y), fmaf(a.z, v.z, b.z), fmaf(a.w, v.w, b.w));
+        o.x = o.x > 0.f ? o.x : slope * o.x;
+        o.y = o.y > 0.f ? o.y : slope * o.y;
+        o.z = o.z > 0.f ? o.z : slope * o.z;
+        o.w = o.w > 0.f ? o.w : slope * o.w;
+        const unsigned long long e = 4ull * (unsigned long long)t;
+        o.x = dropout_keep(seed, ctr, e, threshold) ? o.x * scale : 0.f;
+        o.y = dropout_keep(seed, ctr, e + 1, threshold) ? o.y * scale : 0.f;
+        o.z = dropout_keep(seed, ctr, e + 2, threshold) ? o.z * scale : 0.f;
+        o.w = dropout_keep(seed, ctr, e + 3, threshold) ? o.w * scale : 0.f;
+        st4(y + 4 * t, o);
+    }
+}
+
+// gin = g * keep * scale with the mask of the matching forward call.
+__global__ __launch_bounds__(BN_BLOCK) void dropout_bwd_kernel(const float* __restrict__ g, int64_t n4, unsigned long long seed,
+                                                               const long long* __restrict__ counter, unsigned threshold,
+                                                               float scale, float* __restrict__ gin) {
+    const unsigned long long ctr = (unsigned long long)counter[0];
+    for (int64_t t = (int64_t)blockIdx.x * BN_BLOCK + threadIdx.x; t < n4; t += (int64_t)gridDim.x * BN_BLOCK) {
+        float4 o = ld4g(g + 4 * t);
+        const unsigned long long e = 4ull * (unsigned long long)t;
+        o.x = dropout_keep(seed, ctr, e, threshold) ? o.x * scale : 0.f;
+        o.y = dropout_keep(seed, ctr, e + 1, threshold) ? o.y * scale : 0.f;
+        o.z = dropout_keep(seed, ctr, e + 2, threshold) ? o.z * scale : 0.f;
+        o.w = dropout_keep(seed, ctr, e + 3, threshold) ? o.w * scale : 0.f;
+        st4(gin + 4 * t, o);
+    }
+}
+
 __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(const float* __restrict__ gy,
                                                                  const float* __restrict__ x,
                                                                  const float* __restrict__ coef, int64_t M, int C,
@@ -526,6 +578,36 @@ extern "C" int crfconv_bn_apply_add(const float* x, int64_t M, int C, const floa
     const int64_t n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_apply_add_kernel, dim3(ew_grid(n4)), dim3(BN_BLOCK), 0, as_stream(stream), x, coef, skip, n4, C / 4,
                        slope, out);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+static unsigned dropout_threshold(float p) {
+    const double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 0xffffffffu : (t <= 0.0 ? 0u : (unsigned)t);
+}
+
+// out = dropout(lrelu(a x + b, slope), p): the mask of element e is a hash of (seed, *counter, e); counter = one int64 DEVICE word
+// the caller advances between steps.  crfconv_dropout_backward with the same (seed, counter value, p) applies the same mask.
+extern "C" int crfconv_bn_apply_dropout(const float* x, int64_t M, int C, const float* coef, float slope, float p,
+                                        uint64_t seed, const int64_t* counter, float* out, crf_stream_t stream) {
+    if (int rc = bn_check(M, C)) return rc;
+    CRF_REQUIRE(x && coef && counter && out, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(p >= 0.f && p < 1.f, CRF_ERR_ARG, "dropout probability %g outside [0, 1)", (double)p);
+    const int64_t n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_dropout_kernel, dim3(ew_grid(n4)), dim3(BN_BLOCK), 0, as_stream(stream), x, coef, n4, C / 4, slope,
+                       (unsigned long long)seed, reinterpret_cast<const long long*>(counter), dropout_threshold(p), 1.f / (1.f - p), out);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_dropout_backward(const float* g, int64_t n, float p, uint64_t seed, const int64_t* counter, float* gin,
+                                        crf_stream_t stream) {
+    CRF_REQUIRE(g && counter && gin && n > 0 && n % 4 == 0, CRF_ERR_ARG, "null pointer / n=%lld not a positive multiple of 4", (long long)n);
+    CRF_REQUIRE(p >= 0.f && p < 1.f, CRF_ERR_ARG, "dropout probability %g outside [0, 1)", (double)p);
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid(n4)), dim3(BN_BLOCK), 0, as_stream(stream), g, n4, (unsigned long long)seed,
+                       reinterpret_cast<const long long*>(counter), dropout_threshold(p), 1.f / (1.f - p), gin);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -827,6 +827,72 @@ class _MLPBlockJoin(torch.autograd.Function):
         return dX, dW, dgamma, dbeta, None, None, None, None, (g1 if ctx.needs_input_grad[8] else None), None
 
 
+_NO_DROPOUT_FUSION_ENV = __import__('os').environ.get('CRFCONV_NO_DROPOUT_FUSION') is not None     # A/B: bn_apply + nn.Dropout
+
+
+class _MLPBlockDropout(torch.autograd.Function):
+    """dropout(lrelu(BN_train(x W^T), slope), p): the classifier's MLP -> nn.Dropout (models/point_conv_big.py:131-134) as one
+    node.  Forward: MFMA Linear with statistic records, coefficients, ONE pass for BatchNorm + LeakyReLU + dropout
+    (crfconv_bn_apply_dropout); the mask is a hash of (seed, the BatchNorm's step counter, element index), so nothing is
+    stored, forward and backward of a step agree, and a replayed hipGraph draws a new mask every step (the counter is a
+    device word that the forward advances).  Backward: the same mask on the incoming gradient, then crfconv_mlp_backward."""
+
+    @staticmethod
+    def forward(ctx, x, W, gamma, beta, run_mean, run_var, momentum, eps, slope, p, seed, counter):
+        x, Wc = x.contiguous(), W.contiguous()
+        m, ci = x.shape
+        co = Wc.shape[0]
+        y, rec = _mfma_matmul(x, Wc, None, False, True)
+        coef = torch.empty(4 * co, dtype=torch.float32, device=x.device)
+        st = stream_ptr()
+        _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
+                  ptr(run_var), float(momentum), float(eps), ptr(coef), st)
+        out = torch.empty_like(y)
+        _lib.call('crfconv_bn_apply_dropout', ptr(y), m, co, ptr(coef), float(slope), float(p), int(seed), ptr(counter), ptr(out), st)
+        ctx.save_for_backward(x, Wc, y, coef, counter)
+        ctx.slope, ctx.p, ctx.seed = float(slope), float(p), int(seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, y, coef, counter = ctx.saved_tensors
+        m, ci = x.shape
+        co = W.shape[0]
+        dev = x.device
+        g = g.contiguous()
+        gA = torch.empty_like(g)
+        st = stream_ptr()
+        _lib.call('crfconv_dropout_backward', ptr(g), g.numel(), ctx.p, ctx.seed, ptr(counter), ptr(gA), st)
+        dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(dW),
+                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
+        return dX, dW, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def mlp_block_dropout(x, W, bn, slope, p):
+    """dropout(lrelu(BatchNorm_train(x W^T), slope), p) as one node where the big-level fused block applies, else None (the
+    caller then runs its own MLP and nn.Dropout).  The mask stream is seeded from torch.initial_seed() and advances with the
+    BatchNorm's num_batches_tracked -- reproducible under torch.manual_seed, but NOT the draws nn.Dropout would have made."""
+    if _NO_DROPOUT_FUSION_ENV or not (0.0 <= p < 1.0) or bn.num_batches_tracked is None:
+        return None
+    m = x.numel() // x.shape[-1]
+    ci, co = x.shape[-1], W.shape[0]
+    if not (mlp_block_ok(x, W, None, bn, True) and not _mlp_small_ok(m, ci, co)):
+        return None
+    require_gpu(x, W)
+    tick(bn)                                              # advances the counter the mask is keyed on (unless the model already did)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + co * 7919 + ci) & 0xFFFFFFFFFFFFFFFF     # stable per layer shape
+    out = _MLPBlockDropout.apply(x.reshape(-1, ci), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, slope,
+                                 p, seed, bn.num_batches_tracked)
+    return out.reshape(x.shape[:-1] + (co,))
+
+
 class _MLPBlockPool(torch.autograd.Function):
     """max over the table's neighbours of BN_train(x W^T): the strided shortcut of a ResNet block
     (models/point_conv_big.py:74-83) as one node.  Forward: MFMA Linear with statistic records, coefficients, max-pool that

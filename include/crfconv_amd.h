@@ -456,6 +456,15 @@ int crfconv_gather_rows_backward(const float* gout, const int32_t* rev_ptr,
 /* out = lrelu(a + b, slope) over n floats (n % 4 == 0): the residual join of the ResNet block
  * (point_conv_big.py:86-88); backward gin = gout * (out > 0 ? 1 : slope), shared by both addends. */
 int crfconv_add_lrelu(const float* a, const float* b, int64_t n, float slope, float* out, crf_stream_t stream);
+/* The classifier's  MLP -> nn.Dropout(p)  (models/point_conv_big.py:131-134) without the intermediate tensor:
+ * out = dropout(lrelu(a x + b, slope), p).  The mask is counter-based -- element e is kept iff a hash of (seed, *counter, e)
+ * reaches p 2^32 -- with `counter` one int64 DEVICE word the caller advances between training steps (so a captured graph
+ * draws a new mask at every replay); crfconv_dropout_backward(g, n = M C, p, seed, counter) applies the same mask to the
+ * gradient, nothing is stored.  Kept elements are scaled by 1 / (1 - p). */
+int crfconv_bn_apply_dropout(const float* x, int64_t M, int C, const float* coef, float slope, float p, uint64_t seed,
+                             const int64_t* counter, float* out, crf_stream_t stream);
+int crfconv_dropout_backward(const float* g, int64_t n, float p, uint64_t seed, const int64_t* counter, float* gin,
+                             crf_stream_t stream);
 /* The ResNet join of models/point_conv_big.py:84-88 in one pass: out = lrelu(a x + b + skip, slope), coef = the [4, C]
  * block of crfconv_bn_forward / crfconv_bn_coef_from_records for x (a BatchNorm without activation), skip / out [M, C].
  * Same arithmetic as crfconv_bn_apply(slope 1) followed by crfconv_add_lrelu, without the intermediate tensor. */

@@ -839,6 +839,52 @@ def test_mlp_block_fused_backward(M, Ci, Co, slope, need_dx):
     assert int(bn.num_batches_tracked) == 1
 
 
+def test_mlp_block_dropout_fused_mask_is_consistent():
+    """ops.mlp_block_dropout: the classifier's MLP -> Dropout(0.5) as one node with a counter-based mask.  Every output is
+    either 0 or twice the un-dropped activation, about half are kept, forward and backward use the SAME mask (gradients equal
+    the reference's with that mask applied), the next step draws a different mask, and a captured graph draws a new one at
+    every replay."""
+    from crfconv_amd import ops
+    M, Ci, Co, slope = 40960, 32, 128, 0.1
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, Ci, generator=g).to(DEV).requires_grad_(True)
+    W = (torch.randn(Co, Ci, generator=g) / 6).to(DEV).requires_grad_(True)
+    go = torch.randn(M, Co, generator=g).to(DEV)
+    bn, bn_ref = (torch.nn.BatchNorm1d(Co).to(DEV).train() for _ in range(2))
+    out = ops.mlp_block_dropout(x, W, bn, slope, 0.5)
+    assert out is not None and int(bn.num_batches_tracked) == 1
+    out.backward(go)
+    got = [t.grad.clone() for t in (x, W, bn.weight, bn.bias)]
+    for t in (x, W):
+        t.grad = None
+    act = ops.mlp_block(x, W, bn_ref, slope)                       # the same block without dropout
+    keep = out.detach() != 0
+    assert 0.49 < float(keep.float().mean()) < 0.51
+    assert torch.equal(out.detach()[keep], (2.0 * act.detach())[keep])
+    (act * keep * 2.0).backward(go)
+    for name, a, b in zip(('dx', 'dW', 'dgamma', 'dbeta'), got, (x.grad, W.grad, bn_ref.weight.grad, bn_ref.bias.grad)):
+        assert_close(a, b, 1e-6, name)
+    out2 = ops.mlp_block_dropout(x.detach(), W.detach(), bn, slope, 0.5)          # next step: another mask
+    assert 0.45 < float(((out2 != 0) != keep).float().mean()) < 0.55
+    # under a captured graph the counter advances inside the graph: every replay has its own mask
+    xs = x.detach().clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.mlp_block_dropout(xs, W.detach(), bn, slope, 0.5)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_out = ops.mlp_block_dropout(xs, W.detach(), bn, slope, 0.5)
+    masks = []
+    for _ in range(3):
+        graph.replay()
+        masks.append((static_out != 0).clone())
+    assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
+    assert ops.mlp_block_dropout(x[:100], W, bn, slope, 0.5) is None             # below the fused block's row count: caller's path
+
+
 def test_resnet_join_fused_equals_two_passes():
     """models.common.mlp_join: lin_out's BatchNorm + the residual add + LeakyReLU as ONE pass (crfconv_bn_apply_add, one
     autograd node) against bn_apply followed by add_lrelu: the same arithmetic operation for operation, so outputs and every
