@@ -20,12 +20,25 @@ namespace crf {
 constexpr int PBLOCK = 256;
 constexpr int PWAVES = PBLOCK / WAVE;
 
+// Wide layers live on the coarse levels (d = 64: 2560 points, d = 128: 1280 points at config 2): with a point on d/4 lanes a
+// launch has a few hundred wavefronts, each one walking ALL K edges of its points through the d x d layer-2 product --
+// one wavefront per SIMD running serially for 30-50 us (uvstats / bwd_dump / bwd_input at d = 128).  From PC_KS_MIN_D on, the
+// four wavefronts of a workgroup therefore share the SAME points and split their edges (wavefront w takes edge batches
+// w, w + 4, ...); what a point accumulates is summed across the wavefronts through LDS (ks_sum) or by the block reductions
+// that exist anyway.
+#ifndef PC_KS_MIN_D
+#define PC_KS_MIN_D 64
+#endif
 template <int D>
 struct PC {
     static constexpr int L = D / 4;
     static constexpr int PPW = WAVE / L;
-    static constexpr int PPB = PPW * PWAVES;
+    static constexpr int KS = D >= PC_KS_MIN_D ? PWAVES : 1;       // wavefronts sharing a point's edges
+    static constexpr int PPB = PPW * PWAVES / KS;
     static constexpr bool W2_IN_REGS = (D <= 16);
+    // W2^T rows in LDS: [D input channels][L + 1 float4] -- one float4 of padding per row, so that the transposing stage
+    // (coalesced global reads of W2 rows, scattered LDS writes) spreads over eight banks instead of one
+    static constexpr int W2LD = L + 1;
     // Wide layers evaluate layer 2 for EB = 4 edges at a time: each W2^T row fetched from LDS then feeds 16 FMAs
     // per lane instead of 4, and h1 is exchanged through a per-wave LDS scratch (broadcast reads) instead of
     // one cross-lane shuffle per input channel -- the d x d product becomes VALU-bound instead of LDS-bound.
@@ -42,7 +55,7 @@ struct EdgeMLP {
     static constexpr int L = PC<D>::L;
     float4 a1[4];  // a1[c] = {A1[c][0], A1[c][1], A1[c][2], b1[c]} for the quad's 4 channels
     float4 w2t_reg[PC<D>::W2_IN_REGS ? D : 1];  // W2T[c'][quad] when held in registers
-    const float4* w2t_lds;                      // [D][L] float4 rows otherwise
+    const float4* w2t_lds;                      // [D][L + 1] float4 rows otherwise (PC<D>::W2LD)
     int lane, q;
     float slope;                                // LeakyReLU slope of layer 1 (0.1 dense, 0.01 sparse twin)
 
@@ -64,9 +77,12 @@ struct EdgeMLP {
             w2t_lds = nullptr;
         } else {
             float* s = reinterpret_cast<float*>(lds_w2t);
+            // W2 is read the way it lies in memory (consecutive threads, consecutive addresses) and transposed on the way
+            // into LDS: staged the other way round -- LDS order, i.e. a 4 D-byte stride between the lanes' global reads --
+            // this prologue was ~15 us of every d = 128 kernel (64 KB through 64-line gathers)
             for (int t = threadIdx.x; t < D * D; t += PBLOCK) {
-                const int cp = t / D, c = t % D;
-                s[t] = W2[c * D + cp];
+                const int c = t / D, cp = t % D;               // W2[c][cp] -> row cp (input channel), column c (output)
+                s[cp * 4 * PC<D>::W2LD + c] = W2[t];
             }
             w2t_lds = lds_w2t;
         }
@@ -97,10 +113,10 @@ struct EdgeMLP {
                 acc = fma4(v2, w2t_reg[4 * hq + 2], acc);
                 acc = fma4(v3, w2t_reg[4 * hq + 3], acc);
             } else {
-                acc = fma4(v0, w2t_lds[(4 * hq + 0) * L + q], acc);
-                acc = fma4(v1, w2t_lds[(4 * hq + 1) * L + q], acc);
-                acc = fma4(v2, w2t_lds[(4 * hq + 2) * L + q], acc);
-                acc = fma4(v3, w2t_lds[(4 * hq + 3) * L + q], acc);
+                acc = fma4(v0, w2t_lds[(4 * hq + 0) * PC<D>::W2LD + q], acc);
+                acc = fma4(v1, w2t_lds[(4 * hq + 1) * PC<D>::W2LD + q], acc);
+                acc = fma4(v2, w2t_lds[(4 * hq + 2) * PC<D>::W2LD + q], acc);
+                acc = fma4(v3, w2t_lds[(4 * hq + 3) * PC<D>::W2LD + q], acc);
             }
         }
         return acc;
@@ -126,8 +142,8 @@ struct EdgeMLP {
                 float4 hv[EB];
 #pragma unroll
                 for (int e = 0; e < EB; ++e) hv[e] = mine[e * L + cq];
-                const float4 w0 = w2t_lds[(4 * cq + 0) * L + q], w1 = w2t_lds[(4 * cq + 1) * L + q];
-                const float4 w2 = w2t_lds[(4 * cq + 2) * L + q], w3 = w2t_lds[(4 * cq + 3) * L + q];
+                const float4 w0 = w2t_lds[(4 * cq + 0) * PC<D>::W2LD + q], w1 = w2t_lds[(4 * cq + 1) * PC<D>::W2LD + q];
+                const float4 w2 = w2t_lds[(4 * cq + 2) * PC<D>::W2LD + q], w3 = w2t_lds[(4 * cq + 3) * PC<D>::W2LD + q];
 #pragma unroll
                 for (int e = 0; e < EB; ++e) {
                     h2[e] = fma4(hv[e].x, w0, h2[e]);
@@ -156,7 +172,7 @@ __device__ __forceinline__ Row my_row(int64_t m, int& lane, int& wave, int& q) {
     lane = threadIdx.x & 63;
     wave = threadIdx.x >> 6;
     q = lane % PC<D>::L;
-    const int64_t row = (int64_t)xcd_block_id() * PC<D>::PPB + wave * PC<D>::PPW + lane / PC<D>::L;
+    const int64_t row = (int64_t)xcd_block_id() * PC<D>::PPB + (PC<D>::KS == 1 ? wave * PC<D>::PPW : 0) + lane / PC<D>::L;
     Row o;
     o.valid = row < m;
     o.r = o.valid ? row : m - 1;
@@ -169,6 +185,26 @@ __device__ __forceinline__ float over_points(float v) {
 #pragma unroll
     for (int o = PC<D>::L; o < WAVE; o <<= 1) v += __shfl_xor(v, o, WAVE);
     return v;
+}
+
+// Sum of a per-lane float4 over the KS wavefronts that share the same points (fixed order w = 0..KS-1); every wavefront
+// returns the total.  s_ks: [PWAVES][WAVE] float4 in LDS.  All threads of the workgroup must call it.
+template <int D>
+__device__ __forceinline__ float4 ks_sum(float4 v, float4* s_ks, int lane, int wave) {
+    if constexpr (PC<D>::KS == 1) {
+        return v;
+    } else {
+        __syncthreads();                                   // s_ks may still be read from an earlier call
+        s_ks[wave * WAVE + lane] = v;
+        __syncthreads();
+        float4 t = s_ks[lane];
+#pragma unroll
+        for (int w = 1; w < PC<D>::KS; ++w) {
+            const float4 o = s_ks[w * WAVE + lane];
+            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        return t;
+    }
 }
 
 // Block-level deterministic reduction of NV per-quad float4 values into partial[block][NV][D].
@@ -268,7 +304,7 @@ __global__ __launch_bounds__(PBLOCK) void stats_kernel(const float* __restrict__
                                                        float* __restrict__ shift_out,
                                                        float* __restrict__ partial) {
     constexpr int EB = PC<D>::EB;
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     __shared__ float sred[PWAVES * 2 * D];
     int lane, wave, q;
@@ -282,7 +318,7 @@ __global__ __launch_bounds__(PBLOCK) void stats_kernel(const float* __restrict__
     const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
     const int32_t* irow = idx + rw.r * K;
     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    for (int k0 = 0; k0 < K; k0 += EB) {
+    for (int k0 = (PC<D>::KS > 1 ? wave : 0) * EB; k0 < K; k0 += PC<D>::KS * EB) {
         float4 h1[EB], h2[EB];
         float live[EB];
 #pragma unroll
@@ -319,7 +355,7 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
                                                          const float* __restrict__ b2,
                                                          float* __restrict__ out) {
     constexpr int EB = PC<D>::EB;
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     int lane, wave, q;
     const Row rw = my_row<D>(m_tgt, lane, wave, q);
@@ -331,7 +367,7 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
     const int32_t* irow = idx + rw.r * K;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 2
-    for (int k0 = 0; k0 < K; k0 += EB) {
+    for (int k0 = (PC<D>::KS > 1 ? wave : 0) * EB; k0 < K; k0 += PC<D>::KS * EB) {
         float4 h1[EB], h2[EB], xj[EB];
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
@@ -351,7 +387,9 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
             acc.w = fmaf(fmaf(sa.w, h2[e].w, sb.w), xj[e].w, acc.w);
         }
     }
-    if (rw.valid) st4(out + rw.r * D + 4 * q, acc);
+    __shared__ float4 s_ks[PC<D>::KS > 1 ? PWAVES * WAVE : 1];
+    acc = ks_sum<D>(acc, s_ks, lane, wave);
+    if (rw.valid && (PC<D>::KS == 1 || wave == 0)) st4(out + rw.r * D + 4 * q, acc);
 }
 
 // ------------------------------------------------------------------ training forward: one edge pass
@@ -375,7 +413,7 @@ __global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict
                                                          float* __restrict__ U, float* __restrict__ V,
                                                          float* __restrict__ partial) {
     constexpr int EB = PC<D>::EB;
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     __shared__ float sred[PWAVES * 2 * D];
     int lane, wave, q;
@@ -391,7 +429,7 @@ __global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict
     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
 #pragma unroll 2
-    for (int k0 = 0; k0 < K; k0 += EB) {
+    for (int k0 = (PC<D>::KS > 1 ? wave : 0) * EB; k0 < K; k0 += PC<D>::KS * EB) {
         float4 h1[EB], h2[EB], xj[EB];
         float live[EB];
 #pragma unroll
@@ -417,7 +455,10 @@ __global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict
             v.x += xj[e].x; v.y += xj[e].y; v.z += xj[e].z; v.w += xj[e].w;
         }
     }
-    if (rw.valid) {
+    __shared__ float4 s_ks[PC<D>::KS > 1 ? PWAVES * WAVE : 1];
+    u = ks_sum<D>(u, s_ks, lane, wave);
+    v = ks_sum<D>(v, s_ks, lane, wave);
+    if (rw.valid && (PC<D>::KS == 1 || wave == 0)) {
         st4(U + rw.r * D + 4 * q, u);
         st4(V + rw.r * D + 4 * q, v);
     }
@@ -519,7 +560,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ shift_p,
                                                             float* __restrict__ partial) {
     constexpr int EB = PC<D>::EB;
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     __shared__ float sred[PWAVES * 2 * D];
     int lane, wave, q;
@@ -533,7 +574,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_reduce_kernel(const float* __restr
     float4 g = ld4(gout + rw.r * D + 4 * q);
     if (!rw.valid) g = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    for (int k0 = 0; k0 < K; k0 += EB) {
+    for (int k0 = (PC<D>::KS > 1 ? wave : 0) * EB; k0 < K; k0 += PC<D>::KS * EB) {
         float4 h1[EB], h2[EB], xj[EB];
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
@@ -576,7 +617,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
     constexpr bool ACC_REGS = (D <= 32);          // dW2 accumulators in registers vs LDS atomics
     constexpr int NSLOT = D * D;
     __shared__ double s_accd[PWAVES][4 * D];
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * L];
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
     constexpr bool W2_LDS = (D <= 64);            // d = 128: the 64 KB of rows stay in L1/L2 instead
     __shared__ float4 s_w2[W2_LDS ? D * L : 1];   // W2 rows as float4: s_w2[c * L + q'] = W2[c][4q'..]
     __shared__ float s_acc[NSLOT];                // block totals
@@ -613,7 +654,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
     // PB edges per trip: their index entries first, then all their feature / position rows, then the arithmetic -- two
     // dependent memory phases per PB edges instead of two per edge (one or two wavefronts per SIMD hide nothing)
     constexpr int PB = PARAMS_PB;
-    for (int k0 = 0; k0 < K; k0 += PB) {
+    for (int k0 = (PC<D>::KS > 1 ? wave : 0) * PB; k0 < K; k0 += PC<D>::KS * PB) {
         int jj_[PB];
 #pragma unroll
         for (int u = 0; u < PB; ++u) jj_[u] = k0 + u < K ? irow[k0 + u] : -1;
@@ -750,7 +791,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restric
                                                           float* __restrict__ gh2_out,
                                                           float* __restrict__ rel_out) {
     constexpr int EB = PC<D>::EB;
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     int lane, wave, q;
     const Row rw = my_row<D>(m_tgt, lane, wave, q);
@@ -762,7 +803,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restric
     const int32_t* irow = idx + rw.r * K;
     const float4 g = ld4(gout + rw.r * D + 4 * q);
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k0 = 0; k0 < K; k0 += EB) {
+    for (int k0 = (PC<D>::KS > 1 ? wave : 0) * EB; k0 < K; k0 += PC<D>::KS * EB) {
         float4 h1[EB], h2[EB], xj[EB];
         float rx[EB], ry[EB], rz[EB];
         bool have[EB];
@@ -851,7 +892,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restri
                                                            const float* __restrict__ b2,
                                                            float* __restrict__ dx) {
     constexpr int EB = PC<D>::EB;
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::L];
+    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     int lane, wave, q;
     const Row rw = my_row<D>(m_src, lane, wave, q);
@@ -870,7 +911,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restri
     // UB edges instead of two per edge (a wavefront iterates to the largest in-degree of its rows, ~35 trips of one edge)
     constexpr int UB = EB > 1 ? EB : 4;
     const int kshift = (K & (K - 1)) == 0 ? __ffs(K) - 1 : -1;
-    for (int p0 = 0; p0 < degmax; p0 += UB) {
+    for (int p0 = (PC<D>::KS > 1 ? wave : 0) * UB; p0 < degmax; p0 += PC<D>::KS * UB) {
         int eid[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) eid[u] = p0 + u < deg ? rev_eid[beg + p0 + u] : -1;
@@ -907,7 +948,9 @@ __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restri
         }
         }
     }
-    if (rw.valid) st4(dx + rw.r * D + 4 * q, acc);
+    __shared__ float4 s_ks[PC<D>::KS > 1 ? PWAVES * WAVE : 1];
+    acc = ks_sum<D>(acc, s_ks, lane, wave);
+    if (rw.valid && (PC<D>::KS == 1 || wave == 0)) st4(dx + rw.r * D + 4 * q, acc);
 }
 
 static int check_pc(int64_t m, int K, int d) {
@@ -932,7 +975,8 @@ constexpr int nblocks_of(int64_t m) { return (int)((m + PC<D>::PPB - 1) / PC<D>:
     }
 
 static int64_t blocks_for(int64_t m, int d) {
-    const int ppb = (WAVE / (d / 4)) * PWAVES;
+    const int ks = d >= PC_KS_MIN_D ? PWAVES : 1;             // PC<D>::KS
+    const int ppb = (WAVE / (d / 4)) * PWAVES / ks;
     return (m + ppb - 1) / ppb;
 }
 
