@@ -22,18 +22,21 @@ constexpr int PWAVES = PBLOCK / WAVE;
 
 // Wide layers live on the coarse levels (d = 64: 2560 points, d = 128: 1280 points at config 2): with a point on d/4 lanes a
 // launch has a few hundred wavefronts, each one walking ALL K edges of its points through the d x d layer-2 product --
-// one wavefront per SIMD running serially for 30-50 us (uvstats / bwd_dump / bwd_input at d = 128).  From PC_KS_MIN_D on, the
-// four wavefronts of a workgroup therefore share the SAME points and split their edges (wavefront w takes edge batches
-// w, w + 4, ...); what a point accumulates is summed across the wavefronts through LDS (ks_sum) or by the block reductions
+// one wavefront per SIMD running serially for 30-50 us (uvstats / bwd_dump / bwd_input at d = 128).  From d = 64 on, KS
+// wavefronts of a workgroup therefore share the SAME points and split their edges (wavefront w of a group takes edge
+// batches w, w + KS, ...); what a point accumulates is summed across the wavefronts through LDS (ks_sum) or by the block reductions
 // that exist anyway.
-#ifndef PC_KS_MIN_D
-#define PC_KS_MIN_D 64
+#ifndef PC_KS_64
+#define PC_KS_64 4
+#endif
+#ifndef PC_KS_128
+#define PC_KS_128 2          // swept with PC_KS_64 on the training step: (4, 4) 5.285, (2, 2) 5.249, (2, 4) 5.267, (4, 2) 5.235, (1, 2) 5.271 ms
 #endif
 template <int D>
 struct PC {
     static constexpr int L = D / 4;
     static constexpr int PPW = WAVE / L;
-    static constexpr int KS = D >= PC_KS_MIN_D ? PWAVES : 1;       // wavefronts sharing a point's edges
+    static constexpr int KS = D >= 128 ? PC_KS_128 : (D >= 64 ? PC_KS_64 : 1);       // wavefronts sharing a point's edges (1, 2 or 4)
     static constexpr int PPB = PPW * PWAVES / KS;
     static constexpr bool W2_IN_REGS = (D <= 16);
     // W2^T rows in LDS: [D input channels][L + 1 float4] -- one float4 of padding per row, so that the transposing stage
@@ -172,7 +175,7 @@ __device__ __forceinline__ Row my_row(int64_t m, int& lane, int& wave, int& q) {
     lane = threadIdx.x & 63;
     wave = threadIdx.x >> 6;
     q = lane % PC<D>::L;
-    const int64_t row = (int64_t)xcd_block_id() * PC<D>::PPB + (PC<D>::KS == 1 ? wave * PC<D>::PPW : 0) + lane / PC<D>::L;
+    const int64_t row = (int64_t)xcd_block_id() * PC<D>::PPB + (wave / PC<D>::KS) * PC<D>::PPW + lane / PC<D>::L;
     Row o;
     o.valid = row < m;
     o.r = o.valid ? row : m - 1;
@@ -197,10 +200,11 @@ __device__ __forceinline__ float4 ks_sum(float4 v, float4* s_ks, int lane, int w
         __syncthreads();                                   // s_ks may still be read from an earlier call
         s_ks[wave * WAVE + lane] = v;
         __syncthreads();
-        float4 t = s_ks[lane];
+        const int w0 = wave - wave % PC<D>::KS;            // first wavefront of this group
+        float4 t = s_ks[w0 * WAVE + lane];
 #pragma unroll
         for (int w = 1; w < PC<D>::KS; ++w) {
-            const float4 o = s_ks[w * WAVE + lane];
+            const float4 o = s_ks[(w0 + w) * WAVE + lane];
             t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
         }
         return t;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(PBLOCK) void stats_kernel(const float* __restrict__
     const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
     const int32_t* irow = idx + rw.r * K;
     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    for (int k0 = (PC<D>::KS > 1 ? wave : 0) * EB; k0 < K; k0 += PC<D>::KS * EB) {
+    for (int k0 = (wave % PC<D>::KS) * EB; k0 < K; k0 += PC<D>::KS * EB) {
         float4 h1[EB], h2[EB];
         float live[EB];
 #pragma unroll
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
     const int32_t* irow = idx + rw.r * K;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 2
-    for (int k0 = (PC<D>::KS > 1 ? wave : 0) * EB; k0 < K; k0 += PC<D>::KS * EB) {
+    for (int k0 = (wave % PC<D>::KS) * EB; k0 < K; k0 += PC<D>::KS * EB) {
         float4 h1[EB], h2[EB], xj[EB];
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
     }
     __shared__ float4 s_ks[PC<D>::KS > 1 ? PWAVES * WAVE : 1];
     acc = ks_sum<D>(acc, s_ks, lane, wave);
-    if (rw.valid && (PC<D>::KS == 1 || wave == 0)) st4(out + rw.r * D + 4 * q, acc);
+    if (rw.valid && (wave % PC<D>::KS == 0)) st4(out + rw.r * D + 4 * q, acc);
 }
 
 // ------------------------------------------------------------------ training forward: one edge pass
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict
     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
 #pragma unroll 2
-    for (int k0 = (PC<D>::KS > 1 ? wave : 0) * EB; k0 < K; k0 += PC<D>::KS * EB) {
+    for (int k0 = (wave % PC<D>::KS) * EB; k0 < K; k0 += PC<D>::KS * EB) {
         float4 h1[EB], h2[EB], xj[EB];
         float live[EB];
 #pragma unroll
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict
     __shared__ float4 s_ks[PC<D>::KS > 1 ? PWAVES * WAVE : 1];
     u = ks_sum<D>(u, s_ks, lane, wave);
     v = ks_sum<D>(v, s_ks, lane, wave);
-    if (rw.valid && (PC<D>::KS == 1 || wave == 0)) {
+    if (rw.valid && (wave % PC<D>::KS == 0)) {
         st4(U + rw.r * D + 4 * q, u);
         st4(V + rw.r * D + 4 * q, v);
     }
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_reduce_kernel(const float* __restr
     float4 g = ld4(gout + rw.r * D + 4 * q);
     if (!rw.valid) g = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    for (int k0 = (PC<D>::KS > 1 ? wave : 0) * EB; k0 < K; k0 += PC<D>::KS * EB) {
+    for (int k0 = (wave % PC<D>::KS) * EB; k0 < K; k0 += PC<D>::KS * EB) {
         float4 h1[EB], h2[EB], xj[EB];
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
     // PB edges per trip: their index entries first, then all their feature / position rows, then the arithmetic -- two
     // dependent memory phases per PB edges instead of two per edge (one or two wavefronts per SIMD hide nothing)
     constexpr int PB = PARAMS_PB;
-    for (int k0 = (PC<D>::KS > 1 ? wave : 0) * PB; k0 < K; k0 += PC<D>::KS * PB) {
+    for (int k0 = (wave % PC<D>::KS) * PB; k0 < K; k0 += PC<D>::KS * PB) {
         int jj_[PB];
 #pragma unroll
         for (int u = 0; u < PB; ++u) jj_[u] = k0 + u < K ? irow[k0 + u] : -1;
@@ -803,7 +807,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restric
     const int32_t* irow = idx + rw.r * K;
     const float4 g = ld4(gout + rw.r * D + 4 * q);
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k0 = (PC<D>::KS > 1 ? wave : 0) * EB; k0 < K; k0 += PC<D>::KS * EB) {
+    for (int k0 = (wave % PC<D>::KS) * EB; k0 < K; k0 += PC<D>::KS * EB) {
         float4 h1[EB], h2[EB], xj[EB];
         float rx[EB], ry[EB], rz[EB];
         bool have[EB];
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restri
     // UB edges instead of two per edge (a wavefront iterates to the largest in-degree of its rows, ~35 trips of one edge)
     constexpr int UB = EB > 1 ? EB : 4;
     const int kshift = (K & (K - 1)) == 0 ? __ffs(K) - 1 : -1;
-    for (int p0 = (PC<D>::KS > 1 ? wave : 0) * UB; p0 < degmax; p0 += PC<D>::KS * UB) {
+    for (int p0 = (wave % PC<D>::KS) * UB; p0 < degmax; p0 += PC<D>::KS * UB) {
         int eid[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) eid[u] = p0 + u < deg ? rev_eid[beg + p0 + u] : -1;
@@ -950,7 +954,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restri
     }
     __shared__ float4 s_ks[PC<D>::KS > 1 ? PWAVES * WAVE : 1];
     acc = ks_sum<D>(acc, s_ks, lane, wave);
-    if (rw.valid && (PC<D>::KS == 1 || wave == 0)) st4(dx + rw.r * D + 4 * q, acc);
+    if (rw.valid && (wave % PC<D>::KS == 0)) st4(dx + rw.r * D + 4 * q, acc);
 }
 
 static int check_pc(int64_t m, int K, int d) {
@@ -975,7 +979,7 @@ constexpr int nblocks_of(int64_t m) { return (int)((m + PC<D>::PPB - 1) / PC<D>:
     }
 
 static int64_t blocks_for(int64_t m, int d) {
-    const int ks = d >= PC_KS_MIN_D ? PWAVES : 1;             // PC<D>::KS
+    const int ks = d >= 128 ? PC_KS_128 : (d >= 64 ? PC_KS_64 : 1);            // PC<D>::KS
     const int ppb = (WAVE / (d / 4)) * PWAVES / ks;
     return (m + ppb - 1) / ppb;
 }
