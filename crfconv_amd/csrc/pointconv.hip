@@ -26,6 +26,9 @@ constexpr int PWAVES = PBLOCK / WAVE;
 // wavefronts of a workgroup therefore share the SAME points and split their edges (wavefront w of a group takes edge
 // batches w, w + KS, ...); what a point accumulates is summed across the wavefronts through LDS (ks_sum) or by the block reductions
 // that exist anyway.
+#ifndef PC_KS_32
+#define PC_KS_32 1
+#endif
 #ifndef PC_KS_64
 #define PC_KS_64 4
 #endif
@@ -36,7 +39,7 @@ template <int D>
 struct PC {
     static constexpr int L = D / 4;
     static constexpr int PPW = WAVE / L;
-    static constexpr int KS = D >= 128 ? PC_KS_128 : (D >= 64 ? PC_KS_64 : 1);       // wavefronts sharing a point's edges (1, 2 or 4)
+    static constexpr int KS = D >= 128 ? PC_KS_128 : (D >= 64 ? PC_KS_64 : (D >= 32 ? PC_KS_32 : 1));       // wavefronts sharing a point's edges (1, 2 or 4)
     static constexpr int PPB = PPW * PWAVES / KS;
     static constexpr bool W2_IN_REGS = (D <= 16);
     // W2^T rows in LDS: [D input channels][L + 1 float4] -- one float4 of padding per row, so that the transposing stage
@@ -979,7 +982,7 @@ constexpr int nblocks_of(int64_t m) { return (int)((m + PC<D>::PPB - 1) / PC<D>:
     }
 
 static int64_t blocks_for(int64_t m, int d) {
-    const int ks = d >= 128 ? PC_KS_128 : (d >= 64 ? PC_KS_64 : 1);            // PC<D>::KS
+    const int ks = d >= 128 ? PC_KS_128 : (d >= 64 ? PC_KS_64 : (d >= 32 ? PC_KS_32 : 1));            // PC<D>::KS
     const int ppb = (WAVE / (d / 4)) * PWAVES / ks;
     return (m + ppb - 1) / ppb;
 }
