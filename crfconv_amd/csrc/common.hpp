@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <type_traits>
 
 #include "../../include/crfconv_amd.h"
 
@@ -69,6 +70,38 @@ __device__ __forceinline__ float group_max(float v) {
 }
 
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+
+// static_for<N>(f): f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>) -- a loop whose index is a
+// compile-time constant inside the body (template arguments, DPP controls).
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_impl(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_impl<I + 1, N>(f);
+    }
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<0, N>(f); }
+
+// Value of lane (group base + HQ) for every lane of an aligned group of L adjacent lanes, HQ a compile-time constant.  For
+// L <= 4 the group lies inside a DPP quad: one full-rate v_mov_b32_dpp with a quad_perm control instead of a
+// ds_bpermute_b32 through the LDS pipeline (what __shfl compiles to) -- the narrow PointConv kernels issue 48 such
+// broadcasts per edge.  Wider groups fall back to the shuffle.
+template <int L, int HQ>
+__device__ __forceinline__ float group_bcast(float v, int base_lane) {
+    if constexpr (L == 1) {
+        return v;
+    } else if constexpr (L == 2) {
+        constexpr int ctrl = HQ | (HQ << 2) | ((2 + HQ) << 4) | ((2 + HQ) << 6);           // quad_perm [HQ, HQ, 2 + HQ, 2 + HQ]
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true));
+    } else if constexpr (L == 4) {
+        constexpr int ctrl = HQ * 0x55;                                                  // quad_perm [HQ, HQ, HQ, HQ]
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true));
+    } else {
+        return __shfl(v, base_lane + HQ, WAVE);
+    }
+}
+
 
 // Singly rounded float operations that the compiler may NOT fuse into an FMA.  (The __fmul_rn / __fadd_rn
 // intrinsics of this toolchain are plain `*` / `+` and inherit hipcc's default -ffp-contract=fast: a product feeding

@@ -107,12 +107,12 @@ struct EdgeMLP {
     __device__ __forceinline__ float4 layer2(float4 h1) const {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const int base = lane - q;
-#pragma unroll
-        for (int hq = 0; hq < L; ++hq) {
-            const float v0 = __shfl(h1.x, base + hq, WAVE);
-            const float v1 = __shfl(h1.y, base + hq, WAVE);
-            const float v2 = __shfl(h1.z, base + hq, WAVE);
-            const float v3 = __shfl(h1.w, base + hq, WAVE);
+        static_for<L>([&](auto HQ) {
+            constexpr int hq = decltype(HQ)::value;
+            const float v0 = group_bcast<L, hq>(h1.x, base);
+            const float v1 = group_bcast<L, hq>(h1.y, base);
+            const float v2 = group_bcast<L, hq>(h1.z, base);
+            const float v3 = group_bcast<L, hq>(h1.w, base);
             if constexpr (PC<D>::W2_IN_REGS) {
                 acc = fma4(v0, w2t_reg[4 * hq + 0], acc);
                 acc = fma4(v1, w2t_reg[4 * hq + 1], acc);
@@ -124,7 +124,7 @@ struct EdgeMLP {
                 acc = fma4(v2, w2t_lds[(4 * hq + 2) * PC<D>::W2LD + q], acc);
                 acc = fma4(v3, w2t_lds[(4 * hq + 3) * PC<D>::W2LD + q], acc);
             }
-        }
+        });
         return acc;
     }
 
@@ -690,10 +690,10 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
         gh2.w = live * fmaf(va.w, g.w * xj.w, fmaf(vb.w, h2.w, vc.w));
         // dW2[quad][c'] += g_h2[quad] * h1[c'] ;  g_h1[quad'] = sum_c g_h2[c] W2[c][quad']
         float4 gh1 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int hq = 0; hq < L; ++hq) {
-            const float h0 = __shfl(h1.x, base + hq, WAVE), h1b = __shfl(h1.y, base + hq, WAVE);
-            const float h2b = __shfl(h1.z, base + hq, WAVE), h3 = __shfl(h1.w, base + hq, WAVE);
+        static_for<L>([&](auto HQ) {
+            constexpr int hq = decltype(HQ)::value;
+            const float h0 = group_bcast<L, hq>(h1.x, base), h1b = group_bcast<L, hq>(h1.y, base);
+            const float h2b = group_bcast<L, hq>(h1.z, base), h3 = group_bcast<L, hq>(h1.w, base);
             if constexpr (ACC_REGS) {
                 dw2[4 * hq + 0] = fma4(h0, gh2, dw2[4 * hq + 0]);
                 dw2[4 * hq + 1] = fma4(h1b, gh2, dw2[4 * hq + 1]);
@@ -710,8 +710,8 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
                     atomicAdd(&s_acc[(4 * q + 3) * D + cp], gh2.w * hv[c]);
                 }
             }
-            const float g0 = __shfl(gh2.x, base + hq, WAVE), g1 = __shfl(gh2.y, base + hq, WAVE);
-            const float g2 = __shfl(gh2.z, base + hq, WAVE), g3 = __shfl(gh2.w, base + hq, WAVE);
+            const float g0 = group_bcast<L, hq>(gh2.x, base), g1 = group_bcast<L, hq>(gh2.y, base);
+            const float g2 = group_bcast<L, hq>(gh2.z, base), g3 = group_bcast<L, hq>(gh2.w, base);
             if constexpr (W2_LDS) {
                 gh1 = fma4(g0, s_w2[(4 * hq + 0) * L + q], gh1);
                 gh1 = fma4(g1, s_w2[(4 * hq + 1) * L + q], gh1);
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
                 gh1 = fma4(g2, ld4(W2 + (4 * hq + 2) * D + 4 * q), gh1);
                 gh1 = fma4(g3, ld4(W2 + (4 * hq + 3) * D + 4 * q), gh1);
             }
-        }
+        });
         // through lrelu(0.1)
         const float4 gp = make_float4(gh1.x * (pre.x > 0.f ? 1.f : slope), gh1.y * (pre.y > 0.f ? 1.f : slope),
                                       gh1.z * (pre.z > 0.f ? 1.f : slope), gh1.w * (pre.w > 0.f ? 1.f : slope));
