@@ -55,11 +55,25 @@ __device__ __forceinline__ unsigned xcd_block_id() {
 
 // Sum over aligned groups of L consecutive lanes (L a power of two <= 64); every lane of the
 // group receives the total.
+// lane ^ 1 / lane ^ 2 inside a DPP quad: one v_mov_b32_dpp instead of a ds_bpermute_b32
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));      // quad_perm [1, 0, 3, 2]
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));      // quad_perm [2, 3, 0, 1]
+}
 template <int L>
 __device__ __forceinline__ float group_sum(float v) {
+    if constexpr (L == 2) {
+        return v + quad_xor1(v);
+    } else if constexpr (L == 4) {
+        v += quad_xor2(v);
+        return v + quad_xor1(v);
+    } else {
 #pragma unroll
-    for (int o = L / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+        for (int o = L / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+        return v;
+    }
 }
 
 template <int L>

@@ -28,17 +28,17 @@ template <int H>
 __device__ __forceinline__ float4 matvec_acc(float4 v, const float4* sM, int lane, int q, float4 acc) {
     constexpr int L = H / 4;
     const int base = lane - q;
-#pragma unroll
-    for (int hq = 0; hq < L; ++hq) {
-        const float v0 = __shfl(v.x, base + hq, WAVE);
-        const float v1 = __shfl(v.y, base + hq, WAVE);
-        const float v2 = __shfl(v.z, base + hq, WAVE);
-        const float v3 = __shfl(v.w, base + hq, WAVE);
+    static_for<L>([&](auto HQ) {                     // broadcasts inside a DPP quad for H <= 16 (group_bcast), shuffles above
+        constexpr int hq = decltype(HQ)::value;
+        const float v0 = group_bcast<L, hq>(v.x, base);
+        const float v1 = group_bcast<L, hq>(v.y, base);
+        const float v2 = group_bcast<L, hq>(v.z, base);
+        const float v3 = group_bcast<L, hq>(v.w, base);
         acc = fma4(v0, sM[(4 * hq + 0) * L + q], acc);
         acc = fma4(v1, sM[(4 * hq + 1) * L + q], acc);
         acc = fma4(v2, sM[(4 * hq + 2) * L + q], acc);
         acc = fma4(v3, sM[(4 * hq + 3) * L + q], acc);
-    }
+    });
     return acc;
 }
 
