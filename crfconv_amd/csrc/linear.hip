@@ -603,7 +603,12 @@ __device__ __forceinline__ void gauss_jordan_tiles32(double (&t)[2][2], int H, d
                 for (int i = 0; i < 2; ++i) s_col[b][tr + 32 * i] = t[i][ip];
             }
             __syncthreads();
-            const double piv = 1.0 / s_row[b][p];
+            // 1 / pivot: hardware estimate + two Newton steps (full double precision for a well-scaled SPD pivot) instead of
+            // the ~40-instruction IEEE division every thread would run on each of the 64 sequential pivots
+            const double pv = s_row[b][p];
+            double piv = __builtin_amdgcn_rcp(pv);
+            piv = fma(piv, fma(-pv, piv, 1.0), piv);
+            piv = fma(piv, fma(-pv, piv, 1.0), piv);
             double rowv[2], colv[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) rowv[j] = s_row[b][tc + 32 * j] * piv;
