@@ -31,7 +31,8 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
                                                                  float* __restrict__ run_var, float momentum, float eps,
                                                                  float slope, float* __restrict__ Y, float* __restrict__ A,
                                                                  float* __restrict__ coef, float* __restrict__ rec,
-                                                                 unsigned* __restrict__ sync_ws) {
+                                                                 unsigned* __restrict__ sync_ws,
+                                                                 const float* __restrict__ skip, float join_slope) {
     __shared__ float sWbuf[2][SM_COLS * SM_LD];                // W chunk [64 co][64 k] (+4 pad: conflict-free b128 reads), double-buffered
     __shared__ double s_comb[2][SM_BLOCK];
     __shared__ float s_ab[2][SM_COLS];
@@ -220,6 +221,12 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
             o.z = fmaf(a4.z, acc[t][2], b4.z); o.w = fmaf(a4.w, acc[t][3], b4.w);
             o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
             o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
+            if (skip != nullptr) {                              // the ResNet join: lrelu(. + skip, join_slope), as add_lrelu computes it
+                const float4 k4 = ld4(skip + (int64_t)r * Co + co_base + 16 * t + 4 * g);
+                o.x = add_rn(o.x, k4.x); o.y = add_rn(o.y, k4.y); o.z = add_rn(o.z, k4.z); o.w = add_rn(o.w, k4.w);
+                o.x = o.x > 0.f ? o.x : o.x * join_slope; o.y = o.y > 0.f ? o.y : o.y * join_slope;
+                o.z = o.z > 0.f ? o.z : o.z * join_slope; o.w = o.w > 0.f ? o.w : o.w * join_slope;
+            }
             st4(A + (int64_t)r * Co + co_base + 16 * t + 4 * g, o);
         }
     }
@@ -276,10 +283,10 @@ extern "C" size_t crfconv_mlp_small_workspace(int64_t M, int Co) {
 // A = lrelu(BatchNorm_train(X W^T), slope); Y = X W^T is kept for the backward; coef [4][Co] = a | b | mean | rstd;
 // running statistics updated when given.  sync_ws: crfconv_gridsync_workspace() bytes, ZERO before the first launch
 // that uses it (the kernel leaves it zero); one such buffer per stream of concurrent launches.
-extern "C" int crfconv_mlp_small_forward(const float* X, const float* W, int64_t M, int Ci, int Co, const float* gamma,
-                                         const float* beta, float* run_mean, float* run_var, float momentum, float eps,
-                                         float slope, float* Y, float* A, float* coef, void* ws, size_t ws_bytes,
-                                         void* sync_ws, size_t sync_bytes, crf_stream_t stream) {
+static int mlp_small_forward_impl(const float* X, const float* W, int64_t M, int Ci, int Co, const float* gamma,
+                                  const float* beta, float* run_mean, float* run_var, float momentum, float eps,
+                                  float slope, const float* skip, float join_slope, float* Y, float* A, float* coef, void* ws,
+                                  size_t ws_bytes, void* sync_ws, size_t sync_bytes, crf_stream_t stream) {
     CRF_REQUIRE(X && W && gamma && beta && Y && A && coef && ws && sync_ws, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(mlp_small_shape_ok(M, Ci, Co), CRF_ERR_UNSUPPORTED, "shape m=%lld Ci=%d Co=%d outside the one-launch kernel",
                 (long long)M, Ci, Co);
@@ -292,11 +299,30 @@ extern "C" int crfconv_mlp_small_forward(const float* X, const float* W, int64_t
     const dim3 grid((unsigned)cdiv(M, SM_ROWS), (unsigned)(Co / (16 * tco)));
 #define SMF(T) hipLaunchKernelGGL(mlp_small_fwd_kernel<T>, grid, dim3(SM_BLOCK), 0, as_stream(stream), X, W, (int)M, Ci, Co, gamma, beta, \
                                   run_mean, run_var, momentum, eps, slope, Y, A, coef, reinterpret_cast<float*>(ws),               \
-                                  reinterpret_cast<unsigned*>(sync_ws))
+                                  reinterpret_cast<unsigned*>(sync_ws), skip, join_slope)
     if (tco == 4) SMF(4);
     else if (tco == 2) SMF(2);
     else SMF(1);
 #undef SMF
     CRF_LAUNCH_CHECK();
     return CRF_OK;
+}
+
+extern "C" int crfconv_mlp_small_forward(const float* X, const float* W, int64_t M, int Ci, int Co, const float* gamma,
+                                         const float* beta, float* run_mean, float* run_var, float momentum, float eps,
+                                         float slope, float* Y, float* A, float* coef, void* ws, size_t ws_bytes,
+                                         void* sync_ws, size_t sync_bytes, crf_stream_t stream) {
+    return mlp_small_forward_impl(X, W, M, Ci, Co, gamma, beta, run_mean, run_var, momentum, eps, slope, nullptr, 1.f, Y, A, coef, ws,
+                                  ws_bytes, sync_ws, sync_bytes, stream);
+}
+
+// The same launch with the ResNet join folded in: A = lrelu(lrelu(BN_train(X W^T), slope) + skip, join_slope), skip [M, Co]
+// (models/point_conv_big.py:84-88 with slope = 1: lin_out has no activation of its own).
+extern "C" int crfconv_mlp_small_forward_join(const float* X, const float* W, int64_t M, int Ci, int Co, const float* gamma,
+                                              const float* beta, float* run_mean, float* run_var, float momentum, float eps,
+                                              float slope, const float* skip, float join_slope, float* Y, float* A, float* coef,
+                                              void* ws, size_t ws_bytes, void* sync_ws, size_t sync_bytes, crf_stream_t stream) {
+    CRF_REQUIRE(skip, CRF_ERR_ARG, "null pointer");
+    return mlp_small_forward_impl(X, W, M, Ci, Co, gamma, beta, run_mean, run_var, momentum, eps, slope, skip, join_slope, Y, A, coef,
+                                  ws, ws_bytes, sync_ws, sync_bytes, stream);
 }

@@ -956,6 +956,59 @@ def mlp_block_pool(x, W, bn, table):
     return _MLPBlockPool.apply(x, W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, table)
 
 
+class _MLPSmallJoin(torch.autograd.Function):
+    """_MLPBlockJoin at the coarse levels: the one-launch Linear + BatchNorm kernel (csrc/mlp_small.hip) also adds the skip and
+    applies the join's LeakyReLU to the tile it holds in registers (crfconv_mlp_small_forward_join)."""
+
+    @staticmethod
+    def forward(ctx, x, W, gamma, beta, run_mean, run_var, momentum, eps, skip, slope):
+        x, Wc, skip = x.contiguous(), W.contiguous(), skip.contiguous()
+        m, ci = x.shape
+        co = Wc.shape[0]
+        dev = x.device
+        y = torch.empty((m, co), dtype=torch.float32, device=dev)
+        out = torch.empty_like(y)
+        coef = torch.empty(4 * co, dtype=torch.float32, device=dev)
+        nbytes = _lib.load().crfconv_mlp_small_workspace(m, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        sync = gridsync_ws(dev)
+        _lib.call('crfconv_mlp_small_forward_join', ptr(x), ptr(Wc), m, ci, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
+                  ptr(run_var), float(momentum), float(eps), 1.0, ptr(skip), float(slope), ptr(y), ptr(out), ptr(coef), ptr(ws),
+                  nbytes, ptr(sync), sync.numel() * 4, stream_ptr())
+        ctx.save_for_backward(x, Wc, y, coef, out)
+        ctx.slope = float(slope)
+        ctx.params = (W, None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, y, coef, out = ctx.saved_tensors
+        m, ci = x.shape
+        co = W.shape[0]
+        dev = x.device
+        g = g.contiguous()
+        st = stream_ptr()
+        g1 = torch.empty_like(g)
+        _lib.call('crfconv_add_lrelu_backward', ptr(g), ptr(out), out.numel(), ctx.slope, ptr(g1), st)
+        gY = torch.empty_like(y)
+        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        nbytes = _lib.load().crfconv_bn_workspace(m, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.call('crfconv_bn_backward', ptr(g1), ptr(y), ptr(coef), m, co, 1, 1.0, ptr(gY), ptr(dgamma), ptr(dbeta), ptr(ws),
+                  nbytes, st)
+        dX = gY @ W if ctx.needs_input_grad[0] else None
+        gskip = g1 if ctx.needs_input_grad[8] else None
+        if _defer_ok(ctx.params):
+            _defer_weight_grad(gY, x, ctx.params, False)
+            return dX, None, dgamma, dbeta, None, None, None, None, gskip, None
+        dW = torch.empty((co, ci), dtype=torch.float32, device=dev)
+        nb = _lib.load().crfconv_linear_wgrad_workspace(m, co, ci)
+        wsw = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _lib.call('crfconv_linear_wgrad', ptr(gY), ptr(x), m, co, ci, ptr(dW), None, ptr(wsw), nb, st)
+        return dX, dW, dgamma, dbeta, None, None, None, None, gskip, None
+
+
 def mlp_block_join(x, W, bn, skip, slope):
     """lrelu(BatchNorm_train(x W^T) + skip, slope) as one node where the big-level fused block applies, else None (the
     caller then runs its own lin_out + add_lrelu)."""
@@ -963,13 +1016,14 @@ def mlp_block_join(x, W, bn, skip, slope):
         return None
     m = x.numel() // x.shape[-1]
     ci, co = x.shape[-1], W.shape[0]
-    if not (mlp_block_ok(x, W, None, bn, True) and not _mlp_small_ok(m, ci, co)):
+    if not mlp_block_ok(x, W, None, bn, True):
         return None
     require_gpu(x, W, skip)
     tick(bn)
     mom = 0.1 if bn.momentum is None else bn.momentum
-    out = _MLPBlockJoin.apply(x.reshape(-1, ci), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps,
-                              skip.reshape(-1, co), slope)
+    fn = _MLPSmallJoin if _mlp_small_ok(m, ci, co) else _MLPBlockJoin      # coarse levels: folded into the one-launch kernel
+    out = fn.apply(x.reshape(-1, ci), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps,
+                   skip.reshape(-1, co), slope)
     return out.reshape(x.shape[:-1] + (co,))
 
 

@@ -362,6 +362,13 @@ int crfconv_mlp_small_forward(const float* X, const float* W, int64_t M, int Ci,
                               float* Y, float* A, float* coef, void* workspace, size_t workspace_bytes, void* sync_ws,
                               size_t sync_bytes, crf_stream_t stream);
 
+/* crfconv_mlp_small_forward with the ResNet join folded into the same launch:
+ * A = lrelu(lrelu(BN_train(X W^T), slope) + skip, join_slope)  (models/point_conv_big.py:84-88: slope = 1, join_slope = 0.01). */
+int crfconv_mlp_small_forward_join(const float* X, const float* W, int64_t M, int Ci, int Co, const float* gamma,
+                                   const float* beta, float* run_mean, float* run_var, float momentum, float eps, float slope,
+                                   const float* skip, float join_slope, float* Y, float* A, float* coef, void* workspace,
+                                   size_t workspace_bytes, void* sync_ws, size_t sync_bytes, crf_stream_t stream);
+
 /* Backward of one MLP block  A = lrelu(BN_train(X W^T), slope)  (models/common.py:34-40, batch statistics) in two passes
  * over the activations and three launches: pass 1 streams (gA, Y, X) once and leaves the partials of sum g1, sum g1 yh,
  * G1^T X, Yh^T X and 1^T X (g1 = gA lrelu'(a y + b), yh = (y - mean) rstd; two MFMA accumulator sets share the X
