@@ -78,6 +78,7 @@ SIGNATURES = {
     'crfconv_mlp_backward_workspace': (_sz, [_i64, _i, _i]),
     'crfconv_mlp_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_linear_forward_cat': (_i, [_vp, _vp, _i, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    'crfconv_mlp_backward_add': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_mlp_backward_cat': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_bn_workspace': (_sz, [_i64, _i]),
     'crfconv_bn_forward': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _vp, _vp, _vp, _sz, _vp]),

@@ -806,7 +806,10 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
                                                               const float* __restrict__ Y2 = nullptr,
                                                               const float* __restrict__ pro = nullptr, float slope = 1.f,
                                                               const float* __restrict__ Xb = nullptr, int xsplit = 0,
-                                                              float* __restrict__ Yb = nullptr, int ysplit = 0) {
+                                                              float* __restrict__ Yb = nullptr, int ysplit = 0,
+                                                              const float* __restrict__ addend = nullptr) {
+    // addend [M, Co] (PRO only, one-pointer output): Y = X W^T + addend -- the gradient the other consumer of the block's input
+    // sent back, so that autograd's accumulation pass over three [M, Co] tensors never runs.
     // Xb / xsplit: the operand is the column concatenation [X | Xb] split at column xsplit (the fusion layers' torch.cat,
     // never materialised); Yb / ysplit: the output columns >= ysplit go to Yb [M, Co - ysplit] (dX of such a layer).
     // Both splits are multiples of 4.
@@ -944,7 +947,20 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
                 const int64_t orow = row0 + trow;
                 const int co = co_base + 4 * tc4;
                 if (orow < M && co < Co) {
-                    const float4 o4 = *reinterpret_cast<const float4*>(tile + trow * TLD + 4 * tc4);
+                    float4 o4 = *reinterpret_cast<const float4*>(tile + trow * TLD + 4 * tc4);
+                    if constexpr (PRO) {
+                        if (addend != nullptr) {
+                            if (VEC4 || (Co % 4) == 0) {
+                                const float4 a4 = *reinterpret_cast<const float4*>(addend + orow * Co + co);
+                                o4.x += a4.x; o4.y += a4.y; o4.z += a4.z; o4.w += a4.w;
+                            } else {
+                                o4.x += addend[orow * Co + co];
+                                if (co + 1 < Co) o4.y += addend[orow * Co + co + 1];
+                                if (co + 2 < Co) o4.z += addend[orow * Co + co + 2];
+                                if (co + 3 < Co) o4.w += addend[orow * Co + co + 3];
+                            }
+                        }
+                    }
                     if (Yb != nullptr) {
                         if (co < ysplit) *reinterpret_cast<float4*>(Y + orow * ysplit + co) = o4;
                         else *reinterpret_cast<float4*>(Yb + orow * (Co - ysplit) + (co - ysplit)) = o4;
@@ -963,6 +979,13 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
 #pragma unroll
         for (int t = 0; t < TCO; ++t) {
             const int co = co_base + 16 * t + 4 * g;
+            if constexpr (PRO) {
+                if (addend != nullptr && rv) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < Co) acc[t][e] += addend[r * Co + co + e];
+                }
+            }
             if (rv) {
                 if (Yb != nullptr) {
                     const float4 o4 = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
@@ -1260,13 +1283,25 @@ extern "C" size_t crfconv_mlp_backward_workspace(int64_t M, int Ci, int Co) {
 
 static int mlp_backward_impl(const float* gA, const float* Y, const float* X, const float* Xb, int xsplit, const float* W,
                              const float* coef, float slope, int64_t M, int Ci, int Co, float* dX, float* dXb, float* dW,
-                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream);
+                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream,
+                             const float* dX_add = nullptr);
 
 extern "C" int crfconv_mlp_backward(const float* gA, const float* Y, const float* X, const float* W, const float* coef,
                                     float slope, int64_t M, int Ci, int Co, float* dX, float* dW, float* dgamma,
                                     float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream) {
     return mlp_backward_impl(gA, Y, X, nullptr, 0, W, coef, slope, M, Ci, Co, dX, nullptr, dW, dgamma, dbeta, workspace,
                              workspace_bytes, stream);
+}
+
+// dX = (the block's input gradient) + dX_add [M, Ci]: the block's input has a second consumer (the shortcut of a ResNet block)
+// whose gradient is already known -- the sum autograd would form in a pass of its own is made while dX is written.
+extern "C" int crfconv_mlp_backward_add(const float* gA, const float* Y, const float* X, const float* W, const float* coef,
+                                        float slope, int64_t M, int Ci, int Co, const float* dX_add, float* dX, float* dW,
+                                        float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                        crf_stream_t stream) {
+    CRF_REQUIRE(dX != nullptr || dX_add == nullptr, CRF_ERR_ARG, "dX_add without dX");
+    return mlp_backward_impl(gA, Y, X, nullptr, 0, W, coef, slope, M, Ci, Co, dX, nullptr, dW, dgamma, dbeta, workspace,
+                             workspace_bytes, stream, dX_add);
 }
 
 // The block's input was the column concatenation [Xa | Xb]: dXa [M, split], dXb [M, Ci - split] (both or neither NULL).
@@ -1282,8 +1317,10 @@ extern "C" int crfconv_mlp_backward_cat(const float* gA, const float* Y, const f
 
 static int mlp_backward_impl(const float* gA, const float* Y, const float* X, const float* Xb, int xsplit, const float* W,
                              const float* coef, float slope, int64_t M, int Ci, int Co, float* dX, float* dXb, float* dW,
-                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream) {
+                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream,
+                             const float* dX_add) {
     CRF_REQUIRE(gA && Y && X && W && coef && dW && dgamma && dbeta && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(dX_add == nullptr || dXb == nullptr, CRF_ERR_ARG, "dX_add is for the one-operand form");
     CRF_REQUIRE(crfconv_mlp_backward_supported(M, Ci, Co) == 1, CRF_ERR_UNSUPPORTED, "shape M=%lld Ci=%d Co=%d not supported",
                 (long long)M, Ci, Co);
     CRF_REQUIRE(workspace_bytes >= crfconv_mlp_backward_workspace(M, Ci, Co), CRF_ERR_WORKSPACE, "workspace too small");
@@ -1326,7 +1363,7 @@ static int mlp_backward_impl(const float* gA, const float* Y, const float* X, co
         const dim3 grid((unsigned)crf::lf_blocks(M), (unsigned)gy), blk(crf::LF_BLOCK);
         const size_t lds = lf_lds_bytes(gCi, gCo, true);
         const bool vec4 = (gCi % 4) == 0 && (gCo % 4) == 0;
-#define DX2(T, V) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, true, V>), grid, blk, lds, st, gA, W, (const float*)nullptr, M, gCi, gCo, 1, dX, (float*)nullptr, Y, pro, slope, (const float*)nullptr, 0, dXb, xsplit)
+#define DX2(T, V) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, true, V>), grid, blk, lds, st, gA, W, (const float*)nullptr, M, gCi, gCo, 1, dX, (float*)nullptr, Y, pro, slope, (const float*)nullptr, 0, dXb, xsplit, dX_add)
 #define DX(T) do { if (vec4) DX2(T, true); else DX2(T, false); } while (0)
         switch (tco) {
             case 1: DX(1); break;

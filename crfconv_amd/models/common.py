@@ -61,6 +61,20 @@ class MLP(nn.Module):
         return x
 
 
+def mlp_fork(mlp, x):
+    """(mlp(x), x') for an input with a second consumer (the ResNet block: lin_in(x) and shortcut(x),
+    models/point_conv_big.py:83-88).  x' is x; where the fused block applies it is an alias whose gradient is added inside the
+    block's backward while dX is written, instead of by an accumulation pass of autograd's (ops._MLPBlock, fork)."""
+    if (mlp.training and mlp.bn is not None and x.dtype == torch.float32 and mlp.bn.batch_norm.affine and x.requires_grad
+            and mlp.lin.out_features % 4 == 0 and mlp.lin.out_features <= 1024
+            and (mlp.activation is None or isinstance(mlp.activation, nn.LeakyReLU))
+            and ops.mlp_block_ok(x, mlp.lin.weight, mlp.lin.bias, mlp.bn.batch_norm, True)):
+        require_gpu(x)
+        slope = 1.0 if mlp.activation is None else mlp.activation.negative_slope
+        return ops.mlp_block(x, mlp.lin.weight, mlp.bn.batch_norm, slope, fork=True)
+    return mlp(x), x
+
+
 def mlp_join(mlp, x, skip, slope=0.01):
     """leaky_relu(mlp(x) + skip, slope) for an MLP without activation -- the tail of a ResNet block
     (models/point_conv_big.py:84-88).  One fused node (BatchNorm + add + LeakyReLU in a single pass) where it applies

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..graph import table_of
-from .common import MLP, Base, mlp_join
+from .common import MLP, Base, mlp_fork, mlp_join
 from .continuous_crf_conv_big import ContinuousGaussianCRFConv as CRFConv
 
 WIDTHS = (32, 64, 128, 256, 512)          # channel width of encoder level 0..4 (reference :113)
@@ -81,6 +81,7 @@ class ResNetBBlock(nn.Module):
         strided = not torch.is_tensor(pos)
         skip = None
         sc = self.shortcut
+        h_in, x = mlp_fork(self.lin_in, x)                 # x: now the alias whose gradient lin_in's backward adds to its own
         if (strided and self.training and isinstance(sc, MLP) and sc.bn is not None and sc.activation is None
                 and sc.lin.bias is None and x.dtype == torch.float32 and sc.bn.batch_norm.affine):
             # shortcut MLP + max-pool as one node: BatchNorm applied while the pool gathers (ops.mlp_block_pool)
@@ -91,7 +92,7 @@ class ResNetBBlock(nn.Module):
             skip = sc(x)
             if strided:                                    # strided block: pool the shortcut onto the coarse points
                 skip = self.max_pooling(skip, neighbor_idx)
-        y = self.point_conv(self.lin_in(x), pos, neighbor_idx)
+        y = self.point_conv(h_in, pos, neighbor_idx)
         return mlp_join(self.lin_out, y, skip, 0.01)       # lin_out + add + F.leaky_relu (default slope), as the reference
 
 

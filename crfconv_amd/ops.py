@@ -744,11 +744,15 @@ _UNFUSED_MLP_ENV = __import__('os').environ.get('CRFCONV_UNFUSED_MLP') is not No
 class _MLPBlock(torch.autograd.Function):
     """A = lrelu(BN_train(x W^T), slope) (models/common.py:34-40).  Forward: the MFMA Linear with statistic records in its
     epilogue, coefficients, one fused apply pass.  Backward: crfconv_mlp_backward -- one pass over (gA, y, x) for dgamma,
-    dbeta, dW, one pass over (gA, y) for dX; the BatchNorm input gradient never reaches memory."""
+    dbeta, dW, one pass over (gA, y) for dX; the BatchNorm input gradient never reaches memory.
+
+    fork: the node also returns its input (as an alias) for the input's OTHER consumer -- the shortcut of a ResNet block --
+    so that the gradient coming back through the alias reaches this node's backward, which adds it while writing dX
+    (crfconv_mlp_backward_add) instead of autograd running an accumulation pass over three [M, Ci] tensors."""
 
     @staticmethod
-    def forward(ctx, x, W, gamma, beta, run_mean, run_var, momentum, eps, slope):
-        x = x.contiguous()
+    def forward(ctx, x_in, W, gamma, beta, run_mean, run_var, momentum, eps, slope, fork=False):
+        x = x_in.contiguous()
         Wc = W.contiguous()
         m, ci = x.shape
         co = Wc.shape[0]
@@ -761,24 +765,28 @@ class _MLPBlock(torch.autograd.Function):
         _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), stream_ptr())
         ctx.save_for_backward(x, Wc, y, coef)
         ctx.slope = float(slope)
+        if fork:
+            ctx.set_materialize_grads(False)           # an unused alias must not cost a zero fill
+            return out, x_in
         return out
 
     @staticmethod
-    def backward(ctx, gA):
+    def backward(ctx, gA, g_alias=None):
         x, W, y, coef = ctx.saved_tensors
         m, ci = x.shape
         co = W.shape[0]
-        gA = gA.contiguous()
         dev = x.device
+        gA = torch.zeros_like(y) if gA is None else gA.contiguous()
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        add = _f32c(g_alias) if (g_alias is not None and dX is not None) else None
         dW = torch.empty_like(W)
         dgamma = torch.empty(co, dtype=torch.float32, device=dev)
         dbeta = torch.empty(co, dtype=torch.float32, device=dev)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(dW),
-                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
-        return dX, dW, dgamma, dbeta, None, None, None, None, None
+        _lib.call('crfconv_mlp_backward_add', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(add), ptr(dX),
+                  ptr(dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
+        return dX, dW, dgamma, dbeta, None, None, None, None, None, None
 
 
 _NO_JOIN_ENV = __import__('os').environ.get('CRFCONV_NO_JOIN_FUSION') is not None      # A/B: bn_apply + add_lrelu as two passes
@@ -1049,11 +1057,12 @@ def _mlp_small_ok(m, ci, co):
 
 class _MLPSmall(torch.autograd.Function):
     """_MLPBlock for the coarse levels (m <= 4096 rows): forward in ONE launch (csrc/mlp_small.hip: MFMA tile, statistic
-    records, grid barrier, BatchNorm + LeakyReLU on the tile in registers)."""
+    records, grid barrier, BatchNorm + LeakyReLU on the tile in registers).  fork: as _MLPBlock -- the alias' gradient is the
+    addend of the dX product (the GEMM's beta = 1 epilogue)."""
 
     @staticmethod
-    def forward(ctx, x, W, gamma, beta, run_mean, run_var, momentum, eps, slope):
-        x = x.contiguous()
+    def forward(ctx, x_in, W, gamma, beta, run_mean, run_var, momentum, eps, slope, fork=False):
+        x = x_in.contiguous()
         Wc = W.contiguous()
         m, ci = x.shape
         co = Wc.shape[0]
@@ -1070,15 +1079,18 @@ class _MLPSmall(torch.autograd.Function):
         ctx.save_for_backward(x, Wc, y, coef)
         ctx.slope = float(slope)
         ctx.params = (W, None)
+        if fork:
+            ctx.set_materialize_grads(False)
+            return out, x_in
         return out
 
     @staticmethod
-    def backward(ctx, gA):
+    def backward(ctx, gA, g_alias=None):
         x, W, y, coef = ctx.saved_tensors
         m, ci = x.shape
         co = W.shape[0]
-        gA = gA.contiguous()
         dev = x.device
+        gA = torch.zeros_like(y) if gA is None else gA.contiguous()
         gY = torch.empty_like(y)
         dgamma = torch.empty(co, dtype=torch.float32, device=dev)
         dbeta = torch.empty(co, dtype=torch.float32, device=dev)
@@ -1086,15 +1098,17 @@ class _MLPSmall(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_bn_backward', ptr(gA), ptr(y), ptr(coef), m, co, 1, ctx.slope, ptr(gY), ptr(dgamma), ptr(dbeta),
                   ptr(ws), nbytes, stream_ptr())
-        dX = gY @ W if ctx.needs_input_grad[0] else None
+        dX = None
+        if ctx.needs_input_grad[0]:
+            dX = gY @ W if g_alias is None else torch.addmm(g_alias.reshape(m, ci), gY, W)
         if _defer_ok(ctx.params):
             _defer_weight_grad(gY, x, ctx.params, False)
-            return dX, None, dgamma, dbeta, None, None, None, None, None
+            return dX, None, dgamma, dbeta, None, None, None, None, None, None
         dW = torch.empty((co, ci), dtype=torch.float32, device=dev)          # same partials + reduction as the deferred form
         nb = _lib.load().crfconv_linear_wgrad_workspace(m, co, ci)
         wsw = torch.empty(nb, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_linear_wgrad', ptr(gY), ptr(x), m, co, ci, ptr(dW), None, ptr(wsw), nb, stream_ptr())
-        return dX, dW, dgamma, dbeta, None, None, None, None, None
+        return dX, dW, dgamma, dbeta, None, None, None, None, None, None
 
 
 _NO_CAT_ENV = __import__('os').environ.get('CRFCONV_NO_CAT_FUSION') is not None      # A/B: materialise torch.cat
@@ -1179,16 +1193,25 @@ def mlp_block_ok(x, W, bias, bn, training):
             and _lib.load().crfconv_mlp_backward_supported(m, ci, co) == 1)
 
 
-def mlp_block(x, W, bn, slope=1.0):
-    """lrelu(BatchNorm_train(x W^T), slope) on [..., Ci] rows; `bn`: the torch.nn.BatchNorm1d with the parameters."""
+_NO_FORK_ENV = __import__('os').environ.get('CRFCONV_NO_FORK_FUSION') is not None      # A/B: autograd's own accumulation pass
+
+
+def mlp_block(x, W, bn, slope=1.0, fork=False):
+    """lrelu(BatchNorm_train(x W^T), slope) on [..., Ci] rows; `bn`: the torch.nn.BatchNorm1d with the parameters.
+    fork=True returns (out, x_alias): hand x_alias to the OTHER consumer of x and its gradient is added inside this block's
+    backward (see _MLPBlock)."""
     require_gpu(x, W)
     shape = x.shape
     tick(bn)
     mom = 0.1 if bn.momentum is None else bn.momentum
     x2 = x.reshape(-1, shape[-1])
     fn = _MLPSmall if _mlp_small_ok(x2.shape[0], shape[-1], W.shape[0]) else _MLPBlock
-    out = fn.apply(x2, W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, slope)
-    return out.reshape(shape[:-1] + (W.shape[0],))
+    if fork and x2.requires_grad and torch.is_grad_enabled() and not _NO_FORK_ENV:
+        out, alias = fn.apply(x2, W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, slope, True)
+        return out.reshape(shape[:-1] + (W.shape[0],)), alias.reshape(shape)
+    out = fn.apply(x2, W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, slope, False)
+    out = out.reshape(shape[:-1] + (W.shape[0],))
+    return (out, x) if fork else out
 
 
 def run_lin_bn(seq, x):

@@ -382,6 +382,12 @@ size_t crfconv_mlp_backward_workspace(int64_t M, int Ci, int Co);
 int crfconv_mlp_backward(const float* gA, const float* Y, const float* X, const float* W, const float* coef, float slope,
                          int64_t M, int Ci, int Co, float* dX, float* dW, float* dgamma, float* dbeta, void* workspace,
                          size_t workspace_bytes, crf_stream_t stream);
+/* The same backward for a block whose input x has a second consumer -- the shortcut of a ResNet block
+ * (models/point_conv_big.py:83-88: lin_in(x) and shortcut(x)): dX = gY W + dX_add, dX_add [M, Ci] the gradient that other
+ * consumer already sent back (NULL: as crfconv_mlp_backward).  Replaces the accumulation pass autograd would run. */
+int crfconv_mlp_backward_add(const float* gA, const float* Y, const float* X, const float* W, const float* coef, float slope,
+                             int64_t M, int Ci, int Co, const float* dX_add, float* dX, float* dW, float* dgamma, float* dbeta,
+                             void* workspace, size_t workspace_bytes, crf_stream_t stream);
 /* The block whose input is the column concatenation [Xa | Xb] (the CRF layers' fusion_nn(cat[x, pairwise]),
  * models/continuous_crf_conv_big.py:76) without materialising it: Xa [M, split], Xb [M, Ci - split], split % 4 == 0;
  * the forward product is crfconv_linear_forward_cat, the backward writes dXa / dXb separately. */

@@ -939,6 +939,70 @@ def test_resnet_join_fused_equals_two_passes():
                 assert torch.equal(gp1[k], gp2[k]), k
 
 
+def test_resnet_fork_input_gradient_added_inside_the_block_backward():
+    """models.common.mlp_fork: the input of a ResNet block feeds lin_in AND the shortcut; the shortcut's gradient comes back
+    through an alias that lin_in's node returned and is added while lin_in's backward writes dX (crfconv_mlp_backward_add; the
+    beta = 1 epilogue of the GEMM at the coarse levels) instead of in an accumulation pass of autograd's.  One float addition
+    either way: outputs, the input gradient and every parameter gradient are bit-identical to the un-forked graph at the MFMA
+    levels; at the coarse levels (vendor GEMM, different epilogue) within float rounding."""
+    from crfconv_amd import ops
+    from crfconv_amd.models.point_conv_big import ResNetBBlock
+    import crfconv_amd
+    B, N = 2, 4096
+    pos = np.stack([S.make_cloud(310 + b, N, box=(2, 2, 1)) for b in range(B)])
+    data = crfconv_amd.multiscale_compute(t(pos), generator=torch.Generator().manual_seed(3))
+    cases = [(0, 32, 32, False), (0, 32, 64, True), (1, 64, 256, False), (0, 24, 32, False)]      # level 1: 2048 rows, one-launch MLP
+    for lv, cin, cout, strided in cases:
+        lvl, nxt = data.multiscale[lv], data.multiscale[lv + 1]
+        n_in = lvl.pos.shape[1]
+        torch.manual_seed(cin + cout)
+        blk = ResNetBBlock(cin, cout).to(DEV).train()
+        blk_pos = (lvl.pos, nxt.pos) if strided else lvl.pos
+        blk_idx = lvl.sub_idx if strided else lvl.neighbor_idx
+        n_out = nxt.pos.shape[1] if strided else n_in
+        x0 = torch.randn(B, n_in, cin, generator=torch.Generator().manual_seed(19)).to(DEV)
+        go = torch.randn(B, n_out, cout, generator=torch.Generator().manual_seed(20)).to(DEV)
+        res = []
+        for fork in (True, False):
+            ops._NO_FORK_ENV = not fork
+            try:
+                for p in blk.parameters():
+                    p.grad = None
+                for m in blk.modules():
+                    if isinstance(m, torch.nn.BatchNorm1d):
+                        m.reset_running_stats()
+                x = x0.clone().requires_grad_(True)
+                xin = x * 1.0                                        # a non-leaf input, as inside the network
+                out = blk(xin, blk_pos, blk_idx)
+                seen, stack, adds = set(), [out.grad_fn], 0
+                while stack:
+                    f = stack.pop()
+                    if f is None or f in seen:
+                        continue
+                    seen.add(f)
+                    stack.extend(g for g, _ in f.next_functions)
+                mul = [f for f in seen if f.name() == 'MulBackward0']
+                assert len(mul) == 1
+                users = sum(1 for f in seen for g, _ in f.next_functions if g is mul[0])
+                assert users == (1 if fork else 2), (users, fork, lv, cin, cout, strided)   # forked: lin_in's node is the only consumer of the input
+                out.backward(go)
+            finally:
+                ops._NO_FORK_ENV = False
+            res.append((out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}))
+        (o1, gx1, gp1), (o2, gx2, gp2) = res
+        assert torch.equal(o1, o2)
+        small = B * n_in < ops._MFMA_MIN_ROWS
+        if small:
+            assert_close(gx1, gx2, 1e-6, 'dX (coarse level)')
+        else:
+            assert torch.equal(gx1, gx2), (lv, cin, cout, strided)
+        for k in gp1:
+            if 'point_conv' in k and 'weight_nn.1.lin' in k:
+                assert_close(gp1[k], gp2[k], 1e-6, k)
+            else:
+                assert torch.equal(gp1[k], gp2[k]), k
+
+
 def test_mlp_small_one_launch_kernel_under_graph_replay():
     """The coarse-level one-launch forward synchronises its workgroups through device words that every launch must leave
     zero, and exchanges statistic records past L1: captured into a hipGraph and replayed back to back on CHANGING inputs
