@@ -146,18 +146,6 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply_add_kernel(const float* __r
     }
 }
 
-// Counter-based dropout mask shared by the forward and the backward pass: element e of the call with (seed, *counter) is kept
-// iff the top 32 bits of a splitmix64 round of (seed, counter, e) reach `threshold` = p 2^32.  *counter is a DEVICE word that
-// the caller advances between training steps (the classifier BatchNorm's num_batches_tracked), so a captured hipGraph draws a
-// new mask at every replay while forward and backward of one step agree without a stored mask.
-__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long ctr, unsigned long long e, unsigned threshold) {
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1ull) + e * 0xD1B54A32D192ED03ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (unsigned)(z >> 32) >= threshold;
-}
-
 // y = dropout(lrelu(a x + b, slope), p) in one pass (models/point_conv_big.py:131-134: MLP -> nn.Dropout(0.5)).
 __global__ __launch_bounds__(BN_BLOCK) void bn_apply_dropout_kernel(const float* __restrict__ x, const float* __restrict__ coef,
                                                                     int64_t n4, int C4, float slope, unsigned long long seed,
@@ -582,11 +570,6 @@ extern "C" int crfconv_bn_apply_add(const float* x, int64_t M, int C, const floa
     return CRF_OK;
 }
 
-static unsigned dropout_threshold(float p) {
-    const double t = (double)p * 4294967296.0;
-    return t >= 4294967295.0 ? 0xffffffffu : (t <= 0.0 ? 0u : (unsigned)t);
-}
-
 // out = dropout(lrelu(a x + b, slope), p): the mask of element e is a hash of (seed, *counter, e); counter = one int64 DEVICE word
 // the caller advances between steps.  crfconv_dropout_backward with the same (seed, counter value, p) applies the same mask.
 extern "C" int crfconv_bn_apply_dropout(const float* x, int64_t M, int C, const float* coef, float slope, float p,
@@ -596,7 +579,7 @@ extern "C" int crfconv_bn_apply_dropout(const float* x, int64_t M, int C, const 
     CRF_REQUIRE(p >= 0.f && p < 1.f, CRF_ERR_ARG, "dropout probability %g outside [0, 1)", (double)p);
     const int64_t n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_apply_dropout_kernel, dim3(ew_grid(n4)), dim3(BN_BLOCK), 0, as_stream(stream), x, coef, n4, C / 4, slope,
-                       (unsigned long long)seed, reinterpret_cast<const long long*>(counter), dropout_threshold(p), 1.f / (1.f - p), out);
+                       (unsigned long long)seed, reinterpret_cast<const long long*>(counter), crf::dropout_threshold(p), 1.f / (1.f - p), out);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
@@ -607,7 +590,7 @@ extern "C" int crfconv_dropout_backward(const float* g, int64_t n, float p, uint
     CRF_REQUIRE(p >= 0.f && p < 1.f, CRF_ERR_ARG, "dropout probability %g outside [0, 1)", (double)p);
     const int64_t n4 = n / 4;
     hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid(n4)), dim3(BN_BLOCK), 0, as_stream(stream), g, n4, (unsigned long long)seed,
-                       reinterpret_cast<const long long*>(counter), dropout_threshold(p), 1.f / (1.f - p), gin);
+                       reinterpret_cast<const long long*>(counter), crf::dropout_threshold(p), 1.f / (1.f - p), gin);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -155,4 +155,21 @@ __device__ __forceinline__ float comp(const float4& v, int i) {
     return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
+// Counter-based dropout mask shared by the forward and the backward pass: element e of the call with (seed, *counter) is kept
+// iff the top 32 bits of a splitmix64 round of (seed, counter, e) reach `threshold` = p 2^32.  *counter is a DEVICE word that
+// the caller advances between training steps (the classifier BatchNorm's num_batches_tracked), so a captured hipGraph draws a
+// new mask at every replay while forward and backward of one step agree without a stored mask.
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long ctr, unsigned long long e, unsigned threshold) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1ull) + e * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32) >= threshold;
+}
+
+inline unsigned dropout_threshold(float p) {
+    const double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 0xffffffffu : (t <= 0.0 ? 0u : (unsigned)t);
+}
+
 }  // namespace crf

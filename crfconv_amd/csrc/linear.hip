@@ -798,7 +798,10 @@ constexpr int LF_BLOCK = 256;
 // VEC4: Ci % 4 == 0 and Co % 4 == 0 -- every access is a 16-byte one and the element-wise tail code does not exist.  (With
 // both forms in one kernel the compiler merges the float4 store into the four predicated dword stores of the tail path:
 // 4x the store instructions and 3x the write requests, 983 k instead of 328 k per 21 MB -- TCP_TCC_WRITE_REQ.)
-template <int TCO, bool PRO = false, bool VEC4 = true>  // 16 * TCO output channels per block slab (blockIdx.y picks the slab)
+// EPI: 0 plain store; 1 (PRO) Y += addend; 2 (not PRO) dropout mask on Y.  Template forms, so that the common kernels keep their
+// register budget (as run-time branches the two epilogues cost <2, false> and <4, true> one wavefront per SIMD each).
+constexpr int EPI_NONE = 0, EPI_ADD = 1, EPI_DROPOUT = 2;
+template <int TCO, bool PRO = false, bool VEC4 = true, int EPI = EPI_NONE>  // 16 * TCO output channels per block slab (blockIdx.y picks the slab)
 __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                               const float* __restrict__ bias, int64_t M, int Ci, int Co,
                                                               int transpose_w, float* __restrict__ Y,
@@ -807,7 +810,13 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
                                                               const float* __restrict__ pro = nullptr, float slope = 1.f,
                                                               const float* __restrict__ Xb = nullptr, int xsplit = 0,
                                                               float* __restrict__ Yb = nullptr, int ysplit = 0,
-                                                              const float* __restrict__ addend = nullptr) {
+                                                              const float* __restrict__ addend = nullptr,
+                                                              const long long* __restrict__ drop_counter = nullptr,
+                                                              unsigned long long drop_seed = 0ull, unsigned drop_threshold = 0u,
+                                                              float drop_scale = 1.f) {
+    // drop_counter (not PRO, one-pointer output): Y = dropout_mask .* (X W^T) * drop_scale with the counter-based mask of
+    // common.hpp (element e = row * Co + column) -- the backward of nn.Dropout applied while the gradient of the Linear
+    // BEHIND the dropout is written, instead of in a pass of its own over [M, Co].
     // addend [M, Co] (PRO only, one-pointer output): Y = X W^T + addend -- the gradient the other consumer of the block's input
     // sent back, so that autograd's accumulation pass over three [M, Co] tensors never runs.
     // Xb / xsplit: the operand is the column concatenation [X | Xb] split at column xsplit (the fusion layers' torch.cat,
@@ -948,8 +957,8 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
                 const int co = co_base + 4 * tc4;
                 if (orow < M && co < Co) {
                     float4 o4 = *reinterpret_cast<const float4*>(tile + trow * TLD + 4 * tc4);
-                    if constexpr (PRO) {
-                        if (addend != nullptr) {
+                    if constexpr (EPI == EPI_ADD) {
+                        {
                             if (VEC4 || (Co % 4) == 0) {
                                 const float4 a4 = *reinterpret_cast<const float4*>(addend + orow * Co + co);
                                 o4.x += a4.x; o4.y += a4.y; o4.z += a4.z; o4.w += a4.w;
@@ -959,6 +968,16 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
                                 if (co + 2 < Co) o4.z += addend[orow * Co + co + 2];
                                 if (co + 3 < Co) o4.w += addend[orow * Co + co + 3];
                             }
+                        }
+                    }
+                    if constexpr (EPI == EPI_DROPOUT) {
+                        {
+                            const unsigned long long ctr = (unsigned long long)drop_counter[0];
+                            const unsigned long long e = (unsigned long long)(orow * Co + co);
+                            o4.x = dropout_keep(drop_seed, ctr, e, drop_threshold) ? o4.x * drop_scale : 0.f;
+                            o4.y = dropout_keep(drop_seed, ctr, e + 1, drop_threshold) ? o4.y * drop_scale : 0.f;
+                            o4.z = dropout_keep(drop_seed, ctr, e + 2, drop_threshold) ? o4.z * drop_scale : 0.f;
+                            o4.w = dropout_keep(drop_seed, ctr, e + 3, drop_threshold) ? o4.w * drop_scale : 0.f;
                         }
                     }
                     if (Yb != nullptr) {
@@ -979,11 +998,21 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
 #pragma unroll
         for (int t = 0; t < TCO; ++t) {
             const int co = co_base + 16 * t + 4 * g;
-            if constexpr (PRO) {
-                if (addend != nullptr && rv) {
+            if constexpr (EPI == EPI_ADD) {
+                if (rv) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (co + e < Co) acc[t][e] += addend[r * Co + co + e];
+                }
+            }
+            if constexpr (EPI == EPI_DROPOUT) {
+                if (rv) {
+                    const unsigned long long ctr = (unsigned long long)drop_counter[0];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < Co)
+                            acc[t][e] = dropout_keep(drop_seed, ctr, (unsigned long long)(r * Co + co + e), drop_threshold)
+                                            ? acc[t][e] * drop_scale : 0.f;
                 }
             }
             if (rv) {
@@ -1178,8 +1207,16 @@ extern "C" size_t crfconv_linear_forward_stat_records(int64_t M) { return (size_
 
 // Y [M, Co] = X [M, Ci] W^T (+ bias);  W is [Co, Ci] row-major, or [Ci, Co] when transpose_w != 0 (the dX product).
 // stat_rec (may be NULL): float [records][Co][4] receives per-workgroup {shift, n, sum(y - shift), sum (y - shift)^2}.
+struct LinearDropout {
+    const long long* counter = nullptr;
+    unsigned long long seed = 0ull;
+    unsigned threshold = 0u;
+    float scale = 1.f;
+};
+
 static int linear_forward_impl(const float* X, const float* Xb, int xsplit, const float* W, const float* bias, int64_t M,
-                               int Ci, int Co, int transpose_w, float* Y, float* stat_rec, crf_stream_t stream) {
+                               int Ci, int Co, int transpose_w, float* Y, float* stat_rec, crf_stream_t stream,
+                               LinearDropout drop = LinearDropout()) {
     CRF_REQUIRE(X && W && Y, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(M > 0, CRF_ERR_ARG, "M must be positive");
     CRF_REQUIRE(crfconv_linear_forward_supported(Ci, Co), CRF_ERR_UNSUPPORTED, "weight slab %dx%d does not fit LDS", Co, Ci);
@@ -1192,7 +1229,8 @@ static int linear_forward_impl(const float* X, const float* Xb, int xsplit, cons
     const size_t lds = lf_lds_bytes(Ci, Co, false);
     hipStream_t st = crf::as_stream(stream);
     const bool vec4 = (Ci % 4) == 0 && (Co % 4) == 0;
-#define LF2(T, V) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, false, V>), grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec, (const float*)nullptr, (const float*)nullptr, 1.f, Xb, xsplit, (float*)nullptr, 0)
+#define LF3(T, V, E) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, false, V, E>), grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec, (const float*)nullptr, (const float*)nullptr, 1.f, Xb, xsplit, (float*)nullptr, 0, (const float*)nullptr, drop.counter, drop.seed, drop.threshold, drop.scale)
+#define LF2(T, V) do { if (drop.counter != nullptr) LF3(T, V, crf::EPI_DROPOUT); else LF3(T, V, crf::EPI_NONE); } while (0)
 #define LF(T) do { if (vec4) LF2(T, true); else LF2(T, false); } while (0)
     switch (tco) {
         case 1: LF(1); break;
@@ -1202,6 +1240,7 @@ static int linear_forward_impl(const float* X, const float* Xb, int xsplit, cons
     }
 #undef LF
 #undef LF2
+#undef LF3
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
@@ -1211,6 +1250,20 @@ static int linear_forward_impl(const float* X, const float* Xb, int xsplit, cons
 extern "C" int crfconv_linear_forward(const float* X, const float* W, const float* bias, int64_t M, int Ci, int Co,
                                       int transpose_w, float* Y, float* stat_rec, crf_stream_t stream) {
     return linear_forward_impl(X, nullptr, 0, W, bias, M, Ci, Co, transpose_w, Y, stat_rec, stream);
+}
+
+// Y = dropout_mask .* (X W^T or X W) / (1 - p): the input gradient of a Linear that sits BEHIND an nn.Dropout, masked while it
+// is written (the mask of crfconv_bn_apply_dropout with the same p, seed and *counter).
+extern "C" int crfconv_linear_forward_dropout(const float* X, const float* W, int64_t M, int Ci, int Co, int transpose_w,
+                                              float p, uint64_t seed, const int64_t* counter, float* Y, crf_stream_t stream) {
+    CRF_REQUIRE(counter, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(p >= 0.f && p < 1.f, CRF_ERR_ARG, "dropout probability %g outside [0, 1)", (double)p);
+    LinearDropout d;
+    d.counter = reinterpret_cast<const long long*>(counter);
+    d.seed = (unsigned long long)seed;
+    d.threshold = crf::dropout_threshold(p);
+    d.scale = 1.f / (1.f - p);
+    return linear_forward_impl(X, nullptr, 0, W, nullptr, M, Ci, Co, transpose_w, Y, nullptr, stream, d);
 }
 
 // The same on the column concatenation [Xa | Xb] (Xa [M, split], Xb [M, Ci - split]) without materialising it.
@@ -1363,7 +1416,8 @@ static int mlp_backward_impl(const float* gA, const float* Y, const float* X, co
         const dim3 grid((unsigned)crf::lf_blocks(M), (unsigned)gy), blk(crf::LF_BLOCK);
         const size_t lds = lf_lds_bytes(gCi, gCo, true);
         const bool vec4 = (gCi % 4) == 0 && (gCo % 4) == 0;
-#define DX2(T, V) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, true, V>), grid, blk, lds, st, gA, W, (const float*)nullptr, M, gCi, gCo, 1, dX, (float*)nullptr, Y, pro, slope, (const float*)nullptr, 0, dXb, xsplit, dX_add)
+#define DX3(T, V, E) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, true, V, E>), grid, blk, lds, st, gA, W, (const float*)nullptr, M, gCi, gCo, 1, dX, (float*)nullptr, Y, pro, slope, (const float*)nullptr, 0, dXb, xsplit, dX_add)
+#define DX2(T, V) do { if (dX_add != nullptr) DX3(T, V, crf::EPI_ADD); else DX3(T, V, crf::EPI_NONE); } while (0)
 #define DX(T) do { if (vec4) DX2(T, true); else DX2(T, false); } while (0)
         switch (tco) {
             case 1: DX(1); break;
@@ -1373,6 +1427,7 @@ static int mlp_backward_impl(const float* gA, const float* Y, const float* X, co
         }
 #undef DX
 #undef DX2
+#undef DX3
         CRF_LAUNCH_CHECK();
     }
     return CRF_OK;

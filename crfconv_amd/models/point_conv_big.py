@@ -157,13 +157,20 @@ class PointConvResNet(Base):
                 h = d(h, skips[lvl], ms[lvl].up_idx, ms[lvl].neighbor_idx, matrices=mat)
             else:
                 h = d(h, skips[lvl], ms[lvl].up_idx, ms[lvl].neighbor_idx)
-        head, drop = self.classifier[0], self.classifier[1]
-        fused = None
+        head, drop, last = self.classifier[0], self.classifier[1], self.classifier[2]
+        fused = logits = None
         if (self.training and type(drop) is nn.Dropout and not drop.inplace and isinstance(head, MLP) and head.bn is not None
                 and head.lin.bias is None and isinstance(head.activation, nn.LeakyReLU) and head.bn.batch_norm.affine
                 and h.dtype == torch.float32):
-            # MLP -> Dropout as one node: BatchNorm + LeakyReLU + a counter-based dropout mask in a single pass
-            fused = ops.mlp_block_dropout(h, head.lin.weight, head.bn.batch_norm, head.activation.negative_slope, drop.p)
-        h = fused if fused is not None else drop(head(h))
-        h = ops.linear(h, self.classifier[2].weight, self.classifier[2].bias)
+            # MLP -> Dropout -> Linear as ONE node (BatchNorm + LeakyReLU + a counter-based dropout mask in a single pass; the
+            # mask's backward folded into the last Linear's input gradient), else MLP -> Dropout as one node
+            slope = head.activation.negative_slope
+            if type(last) is nn.Linear:
+                logits = ops.mlp_dropout_linear(h, head.lin.weight, head.bn.batch_norm, slope, drop.p, last.weight, last.bias)
+            if logits is None:
+                fused = ops.mlp_block_dropout(h, head.lin.weight, head.bn.batch_norm, slope, drop.p)
+        if logits is None:
+            h = fused if fused is not None else drop(head(h))
+            logits = ops.linear(h, last.weight, last.bias)
+        h = logits
         return h.reshape(-1, self.C)

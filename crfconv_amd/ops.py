@@ -836,6 +836,7 @@ class _MLPBlockJoin(torch.autograd.Function):
 
 
 _NO_DROPOUT_FUSION_ENV = __import__('os').environ.get('CRFCONV_NO_DROPOUT_FUSION') is not None     # A/B: bn_apply + nn.Dropout
+_NO_DROPOUT_LINEAR_ENV = __import__('os').environ.get('CRFCONV_NO_DROPOUT_LINEAR') is not None     # A/B: dropout backward as its own pass
 
 
 class _MLPBlockDropout(torch.autograd.Function):
@@ -880,6 +881,80 @@ class _MLPBlockDropout(torch.autograd.Function):
         _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(dW),
                   ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
         return dX, dW, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+class _MLPDropoutLinear(torch.autograd.Function):
+    """logits = dropout(lrelu(BN_train(x W1^T), slope), p) W2^T + b2: the whole classifier (models/point_conv_big.py:131-134,
+    MLP -> nn.Dropout -> nn.Linear) as one node.  Forward: _MLPBlockDropout's three launches plus the MFMA Linear.  Backward: the
+    input gradient of the last Linear is masked WHILE IT IS WRITTEN (crfconv_linear_forward_dropout: same counter-based mask)
+    -- the separate dropout-backward pass over [m, 4 C] is gone --, then crfconv_mlp_backward; (dW2, db2) as _Linear."""
+
+    @staticmethod
+    def forward(ctx, x, W, gamma, beta, run_mean, run_var, momentum, eps, slope, p, seed, counter, W2, b2):
+        x, Wc, W2c = x.contiguous(), W.contiguous(), W2.contiguous()
+        m, ci = x.shape
+        co = Wc.shape[0]
+        y, rec = _mfma_matmul(x, Wc, None, False, True)
+        coef = torch.empty(4 * co, dtype=torch.float32, device=x.device)
+        st = stream_ptr()
+        _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
+                  ptr(run_var), float(momentum), float(eps), ptr(coef), st)
+        h = torch.empty_like(y)
+        _lib.call('crfconv_bn_apply_dropout', ptr(y), m, co, ptr(coef), float(slope), float(p), int(seed), ptr(counter), ptr(h), st)
+        logits = _mfma_matmul(h, W2c, None if b2 is None else b2.contiguous(), False)[0]
+        ctx.save_for_backward(x, Wc, y, coef, counter, h, W2c)
+        ctx.slope, ctx.p, ctx.seed = float(slope), float(p), int(seed)
+        ctx.params2 = (W2, b2)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, y, coef, counter, h, W2 = ctx.saved_tensors
+        m, ci = x.shape
+        co, c2 = W.shape[0], W2.shape[0]
+        dev = x.device
+        g = g.contiguous()
+        st = stream_ptr()
+        gA = torch.empty((m, co), dtype=torch.float32, device=dev)       # = dropout'(g W2): masked by the kernel that forms it
+        _lib.call('crfconv_linear_forward_dropout', ptr(g), ptr(W2), m, c2, co, 1, ctx.p, ctx.seed, ptr(counter), ptr(gA), st)
+        W2p, b2p = ctx.params2
+        dW2 = db2 = None
+        if _defer_ok(ctx.params2):
+            _defer_weight_grad(g, h, ctx.params2, b2p is not None)
+        else:
+            dW2 = torch.empty((c2, co), dtype=torch.float32, device=dev)
+            db2 = torch.empty(c2, dtype=torch.float32, device=dev) if b2p is not None else None
+            nb = _lib.load().crfconv_linear_wgrad_workspace(m, c2, co)
+            wsw = torch.empty(nb, dtype=torch.uint8, device=dev)
+            _lib.call('crfconv_linear_wgrad', ptr(g), ptr(h), m, c2, co, ptr(dW2), ptr(db2), ptr(wsw), nb, st)
+        dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(dW),
+                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
+        return dX, dW, dgamma, dbeta, None, None, None, None, None, None, None, None, dW2, db2
+
+
+def mlp_dropout_linear(x, W, bn, slope, p, W2, b2):
+    """Linear(dropout(lrelu(BatchNorm_train(x W^T), slope), p)) as one node (see _MLPDropoutLinear) where the fused dropout
+    block and the MFMA Linear both apply, else None."""
+    if _NO_DROPOUT_FUSION_ENV or _NO_DROPOUT_LINEAR_ENV or not (0.0 <= p < 1.0) or bn.num_batches_tracked is None:
+        return None
+    m = x.numel() // x.shape[-1]
+    ci, co, c2 = x.shape[-1], W.shape[0], W2.shape[0]
+    if not (mlp_block_ok(x, W, None, bn, True) and not _mlp_small_ok(m, ci, co) and _mfma_ok(m, co, c2) and _mfma_ok(m, c2, co)
+            and W2.dtype == torch.float32):
+        return None
+    require_gpu(x, W, W2)
+    tick(bn)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + co * 7919 + ci) & 0xFFFFFFFFFFFFFFFF     # as mlp_block_dropout
+    out = _MLPDropoutLinear.apply(x.reshape(-1, ci), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, slope,
+                                  p, seed, bn.num_batches_tracked, W2, b2)
+    return out.reshape(x.shape[:-1] + (c2,))
 
 
 def mlp_block_dropout(x, W, bn, slope, p):

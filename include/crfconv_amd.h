@@ -478,6 +478,11 @@ int crfconv_bn_apply_dropout(const float* x, int64_t M, int C, const float* coef
                              const int64_t* counter, float* out, crf_stream_t stream);
 int crfconv_dropout_backward(const float* g, int64_t n, float p, uint64_t seed, const int64_t* counter, float* gin,
                              crf_stream_t stream);
+/* The same mask applied by the kernel that PRODUCES g: Y = mask .* (X W^T, or X W when transpose_w != 0) / (1 - p), element
+ * e = row * Co + column -- the input gradient of the Linear behind the dropout (the classifier's last layer,
+ * models/point_conv_big.py:131-134), so that no separate pass over [M, Co] runs.  Shapes as crfconv_linear_forward. */
+int crfconv_linear_forward_dropout(const float* X, const float* W, int64_t M, int Ci, int Co, int transpose_w, float p,
+                                   uint64_t seed, const int64_t* counter, float* Y, crf_stream_t stream);
 /* The ResNet join of models/point_conv_big.py:84-88 in one pass: out = lrelu(a x + b + skip, slope), coef = the [4, C]
  * block of crfconv_bn_forward / crfconv_bn_coef_from_records for x (a BatchNorm without activation), skip / out [M, C].
  * Same arithmetic as crfconv_bn_apply(slope 1) followed by crfconv_add_lrelu, without the intermediate tensor. */

@@ -885,6 +885,45 @@ def test_mlp_block_dropout_fused_mask_is_consistent():
     assert ops.mlp_block_dropout(x[:100], W, bn, slope, 0.5) is None             # below the fused block's row count: caller's path
 
 
+def test_classifier_dropout_backward_folded_into_last_linear():
+    """ops.mlp_dropout_linear: MLP -> Dropout -> Linear as one node whose backward masks the last Linear's input gradient while
+    the MFMA kernel writes it (crfconv_linear_forward_dropout) instead of in a pass of its own.  Same mask (same seed, same
+    counter), same arithmetic: logits and every gradient are bit-identical to ops.mlp_block_dropout followed by ops.linear;
+    with deferred weight gradients the flushed (dW2, db2) match too."""
+    from crfconv_amd import ops
+    M, Ci, Co, C2, slope = 40960, 32, 128, 13, 0.1
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(M, Ci, generator=g).to(DEV)
+    W0 = (torch.randn(Co, Ci, generator=g) / 6).to(DEV)
+    W20 = (torch.randn(C2, Co, generator=g) / 11).to(DEV)
+    b20 = torch.randn(C2, generator=g).to(DEV)
+    go = torch.randn(M, C2, generator=g).to(DEV)
+    res = []
+    for fused in (True, False):
+        x, W, W2, b2 = (v.clone().requires_grad_(True) for v in (x0, W0, W20, b20))
+        bn = torch.nn.BatchNorm1d(Co).to(DEV).train()
+        if fused:
+            out = ops.mlp_dropout_linear(x, W, bn, slope, 0.5, W2, b2)
+            assert out is not None and '_MLPDropoutLinear' in out.grad_fn.next_functions[0][0].name()
+        else:
+            out = ops.linear(ops.mlp_block_dropout(x, W, bn, slope, 0.5), W2, b2)
+        assert int(bn.num_batches_tracked) == 1
+        out.backward(go)
+        res.append([out.detach().clone()] + [v.grad.clone() for v in (x, W, W2, b2, bn.weight, bn.bias)])
+    for name, a, b in zip(('logits', 'dx', 'dW', 'dW2', 'db2', 'dgamma', 'dbeta'), *res):
+        assert torch.equal(a, b), name
+    # deferred weight gradients: (dW2, db2) of the fused node travel through the same batched reduction as _Linear's
+    x, W = x0.clone().requires_grad_(True), W0.clone().requires_grad_(True)
+    W2, b2 = torch.nn.Parameter(W20.clone()), torch.nn.Parameter(b20.clone())
+    bn = torch.nn.BatchNorm1d(Co).to(DEV).train()
+    with ops.deferred_weight_grads():
+        ops.mlp_dropout_linear(x, W, bn, slope, 0.5, W2, b2).backward(go)
+    assert_close(W2.grad, res[0][3], 1e-6, 'deferred dW2')
+    assert_close(b2.grad, res[0][4], 1e-6, 'deferred db2')
+    assert torch.equal(x.grad, res[0][1])
+    assert ops.mlp_dropout_linear(x[:100], W, bn, slope, 0.5, W2, b2) is None      # below the MFMA row count: caller's path
+
+
 def test_resnet_join_fused_equals_two_passes():
     """models.common.mlp_join: lin_out's BatchNorm + the residual add + LeakyReLU as ONE pass (crfconv_bn_apply_add, one
     autograd node) against bn_apply followed by add_lrelu: the same arithmetic operation for operation, so outputs and every
