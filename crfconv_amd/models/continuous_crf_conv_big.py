@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..graph import table_of
-from .common import MLP
+from .common import MLP, mlp_fork
 
 
 def _embed(cin, hidden):
@@ -42,7 +42,9 @@ class ContinuousGaussianCRFConv(nn.Module):
         B, N, _ = pairwise.shape
         H = self.hidden_channels
         coarse = self.unary_nn(unary).reshape(-1, H)
-        guide = self.pairwise_nn(pairwise).reshape(-1, H)
+        # `pairwise` feeds pairwise_nn and fusion_nn: the second reads the alias the first hands on (common.mlp_fork)
+        guide, pairwise = mlp_fork(self.pairwise_nn[0], pairwise)
+        guide = self.pairwise_nn[1](guide).reshape(-1, H)
         z = ops.gather_rows(coarse, table_of(up_idx, unary.shape[1]))                      # up-sample the unary term
         field = ops.crf_meanfield(z, guide, self.c, table_of(neighbor_idx, N), self.steps, k0=1,      # k0 = 1: no self edge
                                   matrices=matrices)

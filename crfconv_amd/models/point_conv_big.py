@@ -77,7 +77,10 @@ class ResNetBBlock(nn.Module):
         pooled = ops.neighbor_maxpool(_flat(x), table_of(idx, x.shape[1]))
         return pooled.reshape(x.shape[0], -1, x.shape[-1])
 
-    def forward(self, x, pos, neighbor_idx):
+    def forward(self, x, pos, neighbor_idx, return_input_alias=False):
+        """return_input_alias=True: also returns the block's input as the LAST alias of its fork chain (x -> lin_in -> strided
+        shortcut): a further consumer of x -- the decoder stage that takes it as skip feature -- reads the alias, and its
+        gradient is added inside this block's backward kernels instead of by an accumulation pass of autograd's."""
         strided = not torch.is_tensor(pos)
         skip = None
         sc = self.shortcut
@@ -85,15 +88,20 @@ class ResNetBBlock(nn.Module):
         if (strided and self.training and isinstance(sc, MLP) and sc.bn is not None and sc.activation is None
                 and sc.lin.bias is None and x.dtype == torch.float32 and sc.bn.batch_norm.affine):
             # shortcut MLP + max-pool as one node: BatchNorm applied while the pool gathers (ops.mlp_block_pool)
-            pooled = ops.mlp_block_pool(_flat(x), sc.lin.weight, sc.bn.batch_norm, table_of(neighbor_idx, x.shape[1]))
+            pooled = ops.mlp_block_pool(_flat(x), sc.lin.weight, sc.bn.batch_norm, table_of(neighbor_idx, x.shape[1]),
+                                        fork=return_input_alias)
             if pooled is not None:
+                if return_input_alias:
+                    pooled, alias = pooled
+                    x = alias.reshape(x.shape)
                 skip = pooled.reshape(x.shape[0], -1, pooled.shape[-1])
         if skip is None:
             skip = sc(x)
             if strided:                                    # strided block: pool the shortcut onto the coarse points
                 skip = self.max_pooling(skip, neighbor_idx)
         y = self.point_conv(h_in, pos, neighbor_idx)
-        return mlp_join(self.lin_out, y, skip, 0.01)       # lin_out + add + F.leaky_relu (default slope), as the reference
+        out = mlp_join(self.lin_out, y, skip, 0.01)        # lin_out + add + F.leaky_relu (default slope), as the reference
+        return (out, x) if return_input_alias else out
 
 
 class Upsampling(nn.Module):
@@ -145,7 +153,8 @@ class PointConvResNet(Base):
         skips = [h]
         for lvl in range(1, len(WIDTHS)):
             fine, coarse = ms[lvl - 1], ms[lvl]
-            h = getattr(self, 'conv%d_1' % (lvl + 1))(h, (fine.pos, coarse.pos), fine.sub_idx)
+            # the level's output has three consumers (this block's lin_in and shortcut, the decoder): one fork chain, no add pass
+            h, skips[-1] = getattr(self, 'conv%d_1' % (lvl + 1))(h, (fine.pos, coarse.pos), fine.sub_idx, return_input_alias=True)
             h = getattr(self, 'conv%d_2' % (lvl + 1))(h, coarse.pos, coarse.neighbor_idx)
             skips.append(h)
         decoders = [getattr(self, 'deconv%d' % (lvl + 1)) for lvl in range(len(WIDTHS) - 2, -1, -1)]

@@ -980,11 +980,12 @@ class _MLPBlockPool(torch.autograd.Function):
     """max over the table's neighbours of BN_train(x W^T): the strided shortcut of a ResNet block
     (models/point_conv_big.py:74-83) as one node.  Forward: MFMA Linear with statistic records, coefficients, max-pool that
     applies the BatchNorm affine while gathering (crfconv_neighbor_maxpool_affine_forward) -- the normalised fine-level
-    tensor never reaches memory; backward: the pool's scatter gives gA, then crfconv_mlp_backward (BatchNorm, no activation)."""
+    tensor never reaches memory; backward: the pool's scatter gives gA, then crfconv_mlp_backward (BatchNorm, no activation).
+    fork: as _MLPBlock -- the node hands its input on as an alias and adds the alias' gradient while writing dX."""
 
     @staticmethod
-    def forward(ctx, x, W, gamma, beta, run_mean, run_var, momentum, eps, table):
-        x, Wc = x.contiguous(), W.contiguous()
+    def forward(ctx, x_in, W, gamma, beta, run_mean, run_var, momentum, eps, table, fork=False):
+        x, Wc = x_in.contiguous(), W.contiguous()
         m, ci = x.shape
         co = Wc.shape[0]
         dev = x.device
@@ -999,34 +1000,38 @@ class _MLPBlockPool(torch.autograd.Function):
                   ptr(out), ptr(arg), st)
         ctx.table = table
         ctx.save_for_backward(x, Wc, y, coef, arg)
+        if fork:
+            ctx.set_materialize_grads(False)
+            return out, x_in
         return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_alias=None):
         x, W, y, coef, arg = ctx.saved_tensors
         table = ctx.table
         m, ci = x.shape
         co = W.shape[0]
         dev = x.device
-        g = _f32c(g)
+        g = torch.zeros((table.m_tgt, co), dtype=torch.float32, device=dev) if g is None else _f32c(g)
         st = stream_ptr()
         rev_ptr, rev_eid = table.reverse
         gA = torch.empty((m, co), dtype=torch.float32, device=dev)
         _lib.call('crfconv_neighbor_maxpool_backward', ptr(g), ptr(arg), ptr(rev_ptr), ptr(rev_eid), table.K, m, co, ptr(gA), st)
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        add = _f32c(g_alias) if (g_alias is not None and dX is not None) else None
         dW = torch.empty_like(W)
         dgamma = torch.empty(co, dtype=torch.float32, device=dev)
         dbeta = torch.empty(co, dtype=torch.float32, device=dev)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), 1.0, m, ci, co, ptr(dX), ptr(dW),
-                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
-        return dX, dW, dgamma, dbeta, None, None, None, None, None
+        _lib.call('crfconv_mlp_backward_add', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), 1.0, m, ci, co, ptr(add), ptr(dX),
+                  ptr(dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
+        return dX, dW, dgamma, dbeta, None, None, None, None, None, None
 
 
-def mlp_block_pool(x, W, bn, table):
+def mlp_block_pool(x, W, bn, table, fork=False):
     """neighbor_maxpool(BatchNorm_train(x W^T), table) as one node where the big-level fused block applies (x [m_src, Ci]
-    rows of the table's source level), else None."""
+    rows of the table's source level), else None.  fork=True: returns (pooled, x_alias) -- see mlp_block."""
     if _NO_JOIN_ENV or table.padded:
         return None
     m, ci = x.shape
@@ -1036,7 +1041,10 @@ def mlp_block_pool(x, W, bn, table):
     require_gpu(x, W)
     tick(bn)
     mom = 0.1 if bn.momentum is None else bn.momentum
-    return _MLPBlockPool.apply(x, W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, table)
+    if fork and x.requires_grad and torch.is_grad_enabled() and not _NO_FORK_ENV:
+        return _MLPBlockPool.apply(x, W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, table, True)
+    out = _MLPBlockPool.apply(x, W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, table, False)
+    return (out, x) if fork else out
 
 
 class _MLPSmallJoin(torch.autograd.Function):
