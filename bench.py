@@ -322,6 +322,7 @@ def main():
     # torch.optim.SGD(lr, momentum=0.95, weight_decay=1e-4) of trainval.py:69-72 as one launch over flat parameters
     opt = crfconv_amd.optim.FlatSGD(bucket, lr=1e-2, momentum=0.95, weight_decay=1e-4)
     cw = torch.ones(n_cls, device=dev)
+    unit = torch.ones((), device=dev)                        # d loss / d loss, made once (loss.backward() fills a new one per call)
 
     # One training step = [A] zero grads, forward, weighted CE, backward, grads packed into ONE flat fp32 bucket
     #                     [C] all-reduce of that bucket over RCCL (only when world > 1; eager, never captured)
@@ -334,7 +335,7 @@ def main():
         logits = net(d)
         loss = ops.training_loss(logits, d.y, cw, ignore_index=-1)             # trainval.py:101-104, fused kernel
         with ops.deferred_weight_grads(sink=bucket.view_of):     # one batched launch finishes all 74 dW / db reductions, into the bucket
-            loss.backward()
+            loss.backward(unit)
         bucket.pack()                                     # one batched copy into the flat bucket; .grad -> bucket views
         return loss.detach()
 

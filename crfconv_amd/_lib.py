@@ -64,7 +64,7 @@ SIGNATURES = {
     'crfconv_pointconv_bwd_a1': (_i, [_vp, _vp, _vp, _i64, _i, _f, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_bwd_input': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_fold1': (_i, [_vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
-    'crfconv_pointconv_fold1_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
+    'crfconv_pointconv_fold1_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_fold2': (_i, [_vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_fold2_bwd': (_i, [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'crfconv_linear_wgrad_workspace': (_sz, [_i64, _i, _i]),

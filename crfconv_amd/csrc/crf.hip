@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_prepare_kernel(const float* __restr
                                                             const float* __restrict__ s,
                                                             const int32_t* __restrict__ rev_eid, int K, int kshift,
                                                             float* __restrict__ gm, RevRec* __restrict__ rec, int64_t m,
-                                                            int64_t E) {
+                                                            int64_t E, float* __restrict__ Gcopy) {
     constexpr int L = Geo<H>::L;
     __shared__ float4 sPT[H * L];
     load_matrix<H>(sPT, P, true);
@@ -1073,6 +1073,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_prepare_kernel(const float* __restr
     bool valid;
     const int64_t r = my_point<H>(m, lane, q, valid);
     const float4 g = ld4(G + r * H + 4 * q);
+    if (Gcopy != nullptr && valid) st4(Gcopy + r * H + 4 * q, g);      // G_T into the stacked [T, m, H] array (wide H: dP = m^T G outside)
     // this block's share of the reverse edge list, four consecutive edges per thread and round (E = m K is a multiple of
     // 4): one dwordx4 of edge ids, four weight gathers in flight, two dwordx4 record stores
     const int64_t quads = E >> 2, per_block = (quads + gridDim.x - 1) / gridDim.x;
@@ -1773,9 +1774,10 @@ extern "C" int crfconv_meanfield_backward(const float* gout, const float* z, con
     const int64_t E = m * K, step = m * H;
     DISPATCH_H(H, {
         const dim3 grid((unsigned)cdiv(m, Geo<HH>::PPB)), sgrid((unsigned)cdiv(m, Scat<HH>::RPB)), blk(BLOCK);
-        hipLaunchKernelGGL(bwd_prepare_kernel<HH>, grid, blk, 0, st, gout, P, s, rev_eid, K, kshift_of(K), gms, rec, m, E);
+        hipLaunchKernelGGL(bwd_prepare_kernel<HH>, grid, blk, 0, st, gout, P, s, rev_eid, K, kshift_of(K), gms, rec, m, E,
+                           mts != nullptr ? Gs : (float*)nullptr);     // callers that form dP = m^T G themselves read G_T as Gs[0]
         CRF_LAUNCH_CHECK();
-        for (int i = 0; i < T; ++i) {            // entry i of Gs / gms belongs to step t = T - i (Gs[0] is never written: G_T = gout)
+        for (int i = 0; i < T; ++i) {            // entry i of Gs / gms belongs to step t = T - i (Gs[0] = G_T = gout: written by the prepare launch only when mts is given)
             if (i + 1 < T)
                 hipLaunchKernelGGL((bwd_chain_kernel<HH, false>), sgrid, blk, 0, st, gms + i * step, rec, rev_ptr, P, Q,
                                    Gs + (i + 1) * step, gms + (i + 1) * step, gout, Gs, T, z, sumG, dz, dq_partial, m);

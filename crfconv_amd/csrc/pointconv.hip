@@ -1324,7 +1324,10 @@ __global__ __launch_bounds__(128) void fold1_bwd_kernel(const float* __restrict_
                                                         const double* __restrict__ mom, const double* __restrict__ aux1,
                                                         const double* __restrict__ dA1b1, float eps, int use_batch,
                                                         int d, float* __restrict__ dW1, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta) {
+                                                        float* __restrict__ dbeta, const double* __restrict__ dW2_f64,
+                                                        float* __restrict__ dW2_f32) {
+    if (dW2_f64 != nullptr)                 // the float64 accumulator of bwd_params -> the float32 gradient (no cast launch)
+        for (int i = threadIdx.x; i < d * d; i += 128) dW2_f32[i] = (float)dW2_f64[i];
     const int c = threadIdx.x;
     if (c >= d) return;
     const double w[3] = {W1[3 * c], W1[3 * c + 1], W1[3 * c + 2]};
@@ -1422,11 +1425,13 @@ extern "C" int crfconv_pointconv_fold1(const float* W1, const float* gamma1, con
 
 extern "C" int crfconv_pointconv_fold1_bwd(const float* W1, const float* gamma1, const double* mom, const double* aux1,
                                            const double* dA1b1, float eps, int use_batch, int d, float* dW1,
-                                           float* dgamma1, float* dbeta1, crf_stream_t stream) {
+                                           float* dgamma1, float* dbeta1, const double* dW2_f64, float* dW2_f32,
+                                           crf_stream_t stream) {
     CRF_REQUIRE(W1 && gamma1 && mom && aux1 && dA1b1 && dW1 && dgamma1 && dbeta1, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE((dW2_f64 == nullptr) == (dW2_f32 == nullptr), CRF_ERR_ARG, "dW2_f64 / dW2_f32: both or neither");
     CRF_REQUIRE(d >= 1 && d <= 128, CRF_ERR_UNSUPPORTED, "d=%d outside [1, 128]", d);
     hipLaunchKernelGGL(fold1_bwd_kernel, dim3(1), dim3(128), 0, as_stream(stream), W1, gamma1, mom, aux1, dA1b1, eps,
-                       use_batch, d, dW1, dgamma1, dbeta1);
+                       use_batch, d, dW1, dgamma1, dbeta1, dW2_f64, dW2_f32);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

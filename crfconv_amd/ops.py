@@ -107,8 +107,7 @@ class _MeanField(torch.autograd.Function):
                       ptr(table.idx16), table.n_tgt, table.n_src, ptr(rev_ptr), ptr(rev_eid), table.K, k0, m, H, ptr(Q),
                       ptr(P), T, ptr(Gs), ptr(gms), ptr(mts), ptr(sumG), ptr(dz), ptr(w), ptr(dy_self), ptr(dy), ptr(dP),
                       ptr(dQ), ptr(ws), wsb, ptr(_ticket(dev)), st)
-            if not inside:
-                Gs[0].copy_(G)
+            if not inside:                                  # (Gs[0] = G was written by the prepare launch)
                 skinny_tn(mts.view(T * m, H), Gs.view(T * m, H), dP)
                 skinny_tn(z, sumG, dQ)
             return dz, dy, dQ, dP, None, None, None
@@ -1607,13 +1606,14 @@ class _PointConv(torch.autograd.Function):
             _lib.call('crfconv_pointconv_fold2_bwd', ptr(red), ptr(shift), ptr(aux2), ptr(g2), n_e, 1 if ctx.use2 else 0,
                       d, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), ptr(coef[4]), st)
         # pass 2: parameter gradients
+        dW2_64 = None
         if d <= _PC_PARAMS_INKERNEL_MAX_D:
             dW2 = torch.empty(d * d, dtype=torch.float64, device=dev)
             dA1b1 = torch.empty((d, 4), dtype=torch.float64, device=dev)
             _lib.call('crfconv_pointconv_bwd_params', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32),
                       K, m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]),
                       ptr(dW2), ptr(dA1b1), ptr(ws), nbytes, st)
-            dW2 = dW2.float().view(d, d)
+            dW2_64, dW2 = dW2, torch.empty((d, d), dtype=torch.float32, device=dev)      # cast by the fold kernel below
         else:
             # wide, edge-poor levels: per-edge h1 / g_h2 / rel to HBM, contractions as dense GEMMs
             E = m_tgt * K
@@ -1637,7 +1637,7 @@ class _PointConv(torch.autograd.Function):
         dg1 = torch.empty(d, dtype=torch.float32, device=dev)
         dbe1 = torch.empty(d, dtype=torch.float32, device=dev)
         _lib.call('crfconv_pointconv_fold1_bwd', ptr(W1), ptr(g1), ptr(mom), ptr(aux1), ptr(dA1b1), float(ctx.eps1),
-                  1 if ctx.use1 else 0, d, ptr(dW1), ptr(dg1), ptr(dbe1), st)
+                  1 if ctx.use1 else 0, d, ptr(dW1), ptr(dg1), ptr(dbe1), ptr(dW2_64), ptr(dW2) if dW2_64 is not None else None, st)
         # input gradient (source-major gather over the reverse table)
         rev_ptr, rev_eid = table.reverse
         dx = torch.empty((table.m_src, d), dtype=torch.float32, device=dev)

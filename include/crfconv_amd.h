@@ -182,8 +182,8 @@ int crfconv_meanfield_bwd_scatter(const float* gm, const float* s, const int32_t
  * are accumulated inside edge-all / the last chain launch on the matrix pipe (16x16x4 f32 MFMA outer products through a
  * per-wave LDS tile) and finished by one small reduction launch into dP, dQ [H, H]; mts and sumG are not touched and
  * may be NULL; ticket = one device word that is ZERO on entry (left zero).  Otherwise mts [T, m, H] and sumG [m, H]
- * are written and the caller finishes dP = sum_i mts[i]^T G_i, dQ = z^T sumG (crfconv_linear_wgrad); dP, dQ, ticket
- * may be NULL.  ws: crfconv_meanfield_backward_workspace(m, H, K) bytes, 16-byte aligned. */
+ * are written -- and Gs[0] = G_T = gout, so that Gs is the whole stacked [T, m, H] operand -- and the caller finishes
+ * dP = sum_i mts[i]^T Gs[i], dQ = z^T sumG (crfconv_linear_wgrad); dP, dQ, ticket may be NULL.  ws: crfconv_meanfield_backward_workspace(m, H, K) bytes, 16-byte aligned. */
 int crfconv_meanfield_backward_supported(int H, int K, int k0);
 int crfconv_meanfield_backward_param_grads_inside(int H);
 size_t crfconv_meanfield_backward_workspace(int64_t m, int H, int K);
@@ -313,7 +313,8 @@ int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const f
  *  fold1      W1 [d,3], gamma1/beta1, mom = {mean[3], cov[9]} of rel (float64) -> A1 [d,3], b1 [d];
  *             batch statistics of BN-1 are analytic in mom (mean1 = w.mu, var1 = w^T Sigma w); running
  *             statistics updated in place when use_batch != 0 and non-NULL; aux1 [3,d] float64 saved for backward.
- *  fold1_bwd  dA1b1 [d,4] float64 -> dW1 [d,3], dgamma1, dbeta1 (through the analytic statistics).
+ *  fold1_bwd  dA1b1 [d,4] float64 -> dW1 [d,3], dgamma1, dbeta1 (through the analytic statistics); when dW2_f64 [d,d] (the
+ *             float64 accumulator of crfconv_pointconv_bwd_params) is given, also dW2_f32 = (float) dW2_f64 (both or neither NULL).
  *  fold2      stats [2,d] + shift (crfconv_pointconv_stats) -> a2, b2; aux2 [2,d] = {mean2, rstd2}.
  *  fold2_bwd  red [2,d] (crfconv_pointconv_bwd_reduce) -> ca, cb, cc for pass 2, dgamma2, dbeta2. */
 int crfconv_pointconv_fold1(const float* W1, const float* gamma1, const float* beta1, const double* mom,
@@ -321,7 +322,7 @@ int crfconv_pointconv_fold1(const float* W1, const float* gamma1, const float* b
                             int use_batch, int d, float* A1, float* b1, double* aux1, crf_stream_t stream);
 int crfconv_pointconv_fold1_bwd(const float* W1, const float* gamma1, const double* mom, const double* aux1,
                                 const double* dA1b1, float eps, int use_batch, int d, float* dW1,
-                                float* dgamma1, float* dbeta1, crf_stream_t stream);
+                                float* dgamma1, float* dbeta1, const double* dW2_f64, float* dW2_f32, crf_stream_t stream);
 int crfconv_pointconv_fold2(const double* stats, const float* shift, const float* gamma2, const float* beta2,
                             double n_edges, float* run_mean, float* run_var, float momentum, float eps,
                             int use_batch, int d, float* a2, float* b2, double* aux2, crf_stream_t stream);
