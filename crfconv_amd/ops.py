@@ -485,6 +485,27 @@ def _defer_ok(params):
             and (b is None or (isinstance(b, torch.nn.Parameter) and b.is_leaf)))
 
 
+def _param_out(prm, shape, dev):
+    """Where a kernel writes the gradient of parameter `prm`: inside ``deferred_weight_grads(sink=...)`` the caller's own
+    storage for it (a flat-bucket slice), if `prm` is a leaf whose ``.grad`` is still unset -- then no copy at pack time --,
+    else a new tensor that goes back through autograd.  Returns (tensor, direct)."""
+    sink = _DEFER.get('sink') if _DEFER['on'] else None
+    if (sink is not None and isinstance(prm, torch.nn.Parameter) and prm.is_leaf and prm.requires_grad and prm.grad is None
+            and prm.dtype == torch.float32):
+        dst = sink(prm)
+        if dst is not None and dst.dtype == torch.float32 and dst.is_contiguous() and dst.numel() == prm.numel():
+            return dst.view(shape), True
+    return torch.empty(shape, dtype=torch.float32, device=dev), False
+
+
+def _param_ret(prm, buf, direct):
+    """The value a backward returns for `prm`: None once the gradient sits in the caller's storage (installed as ``.grad``)."""
+    if direct:
+        prm.grad = buf.view_as(prm)
+        return None
+    return buf
+
+
 def _defer_weight_grad(g, x, params, has_bias):
     m, Co = g.shape
     Ci = x.shape[1]
@@ -762,6 +783,7 @@ class _MLPBlock(torch.autograd.Function):
                   float(momentum), float(eps), ptr(coef), stream_ptr())
         out = torch.empty_like(y)
         _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), stream_ptr())
+        ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef)
         ctx.slope = float(slope)
         if fork:
@@ -778,14 +800,12 @@ class _MLPBlock(torch.autograd.Function):
         gA = torch.zeros_like(y) if gA is None else gA.contiguous()
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         add = _f32c(g_alias) if (g_alias is not None and dX is not None) else None
-        dW = torch.empty_like(W)
-        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward_add', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(add), ptr(dX),
                   ptr(dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
-        return dX, dW, dgamma, dbeta, None, None, None, None, None, None
+        return dX, _param_ret(ctx.prm[0], dW, kW), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None
 
 
 _NO_JOIN_ENV = __import__('os').environ.get('CRFCONV_NO_JOIN_FUSION') is not None      # A/B: bn_apply + add_lrelu as two passes
@@ -809,6 +829,7 @@ class _MLPBlockJoin(torch.autograd.Function):
                   ptr(run_var), float(momentum), float(eps), ptr(coef), st)
         out = torch.empty_like(y)
         _lib.call('crfconv_bn_apply_add', ptr(y), m, co, ptr(coef), ptr(skip), float(slope), ptr(out), st)
+        ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef, out)
         ctx.slope = float(slope)
         return out
@@ -824,14 +845,12 @@ class _MLPBlockJoin(torch.autograd.Function):
         st = stream_ptr()
         _lib.call('crfconv_add_lrelu_backward', ptr(g), ptr(out), out.numel(), ctx.slope, ptr(g1), st)
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dW = torch.empty_like(W)
-        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward', ptr(g1), ptr(y), ptr(x), ptr(W), ptr(coef), 1.0, m, ci, co, ptr(dX), ptr(dW),
                   ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
-        return dX, dW, dgamma, dbeta, None, None, None, None, (g1 if ctx.needs_input_grad[8] else None), None
+        return dX, _param_ret(ctx.prm[0], dW, kW), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, (g1 if ctx.needs_input_grad[8] else None), None
 
 
 _NO_DROPOUT_FUSION_ENV = __import__('os').environ.get('CRFCONV_NO_DROPOUT_FUSION') is not None     # A/B: bn_apply + nn.Dropout
@@ -857,6 +876,7 @@ class _MLPBlockDropout(torch.autograd.Function):
                   ptr(run_var), float(momentum), float(eps), ptr(coef), st)
         out = torch.empty_like(y)
         _lib.call('crfconv_bn_apply_dropout', ptr(y), m, co, ptr(coef), float(slope), float(p), int(seed), ptr(counter), ptr(out), st)
+        ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef, counter)
         ctx.slope, ctx.p, ctx.seed = float(slope), float(p), int(seed)
         return out
@@ -872,14 +892,12 @@ class _MLPBlockDropout(torch.autograd.Function):
         st = stream_ptr()
         _lib.call('crfconv_dropout_backward', ptr(g), g.numel(), ctx.p, ctx.seed, ptr(counter), ptr(gA), st)
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dW = torch.empty_like(W)
-        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(dW),
                   ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
-        return dX, dW, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dX, _param_ret(ctx.prm[0], dW, kW), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None, None, None
 
 
 class _MLPDropoutLinear(torch.autograd.Function):
@@ -901,6 +919,7 @@ class _MLPDropoutLinear(torch.autograd.Function):
         h = torch.empty_like(y)
         _lib.call('crfconv_bn_apply_dropout', ptr(y), m, co, ptr(coef), float(slope), float(p), int(seed), ptr(counter), ptr(h), st)
         logits = _mfma_matmul(h, W2c, None if b2 is None else b2.contiguous(), False)[0]
+        ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef, counter, h, W2c)
         ctx.slope, ctx.p, ctx.seed = float(slope), float(p), int(seed)
         ctx.params2 = (W2, b2)
@@ -927,14 +946,12 @@ class _MLPDropoutLinear(torch.autograd.Function):
             wsw = torch.empty(nb, dtype=torch.uint8, device=dev)
             _lib.call('crfconv_linear_wgrad', ptr(g), ptr(h), m, c2, co, ptr(dW2), ptr(db2), ptr(wsw), nb, st)
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dW = torch.empty_like(W)
-        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(dW),
                   ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
-        return dX, dW, dgamma, dbeta, None, None, None, None, None, None, None, None, dW2, db2
+        return dX, _param_ret(ctx.prm[0], dW, kW), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None, None, None, dW2, db2
 
 
 def mlp_dropout_linear(x, W, bn, slope, p, W2, b2):
@@ -998,6 +1015,7 @@ class _MLPBlockPool(torch.autograd.Function):
         _lib.call('crfconv_neighbor_maxpool_affine_forward', ptr(y), ptr(coef), ptr(table.idx32), table.K, table.m_tgt, co,
                   ptr(out), ptr(arg), st)
         ctx.table = table
+        ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef, arg)
         if fork:
             ctx.set_materialize_grads(False)
@@ -1018,14 +1036,12 @@ class _MLPBlockPool(torch.autograd.Function):
         _lib.call('crfconv_neighbor_maxpool_backward', ptr(g), ptr(arg), ptr(rev_ptr), ptr(rev_eid), table.K, m, co, ptr(gA), st)
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         add = _f32c(g_alias) if (g_alias is not None and dX is not None) else None
-        dW = torch.empty_like(W)
-        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward_add', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), 1.0, m, ci, co, ptr(add), ptr(dX),
                   ptr(dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
-        return dX, dW, dgamma, dbeta, None, None, None, None, None, None
+        return dX, _param_ret(ctx.prm[0], dW, kW), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None
 
 
 def mlp_block_pool(x, W, bn, table, fork=False):
@@ -1065,6 +1081,7 @@ class _MLPSmallJoin(torch.autograd.Function):
         _lib.call('crfconv_mlp_small_forward_join', ptr(x), ptr(Wc), m, ci, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
                   ptr(run_var), float(momentum), float(eps), 1.0, ptr(skip), float(slope), ptr(y), ptr(out), ptr(coef), ptr(ws),
                   nbytes, ptr(sync), sync.numel() * 4, stream_ptr())
+        ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef, out)
         ctx.slope = float(slope)
         ctx.params = (W, None)
@@ -1081,8 +1098,7 @@ class _MLPSmallJoin(torch.autograd.Function):
         g1 = torch.empty_like(g)
         _lib.call('crfconv_add_lrelu_backward', ptr(g), ptr(out), out.numel(), ctx.slope, ptr(g1), st)
         gY = torch.empty_like(y)
-        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
         nbytes = _lib.load().crfconv_bn_workspace(m, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_bn_backward', ptr(g1), ptr(y), ptr(coef), m, co, 1, 1.0, ptr(gY), ptr(dgamma), ptr(dbeta), ptr(ws),
@@ -1091,12 +1107,12 @@ class _MLPSmallJoin(torch.autograd.Function):
         gskip = g1 if ctx.needs_input_grad[8] else None
         if _defer_ok(ctx.params):
             _defer_weight_grad(gY, x, ctx.params, False)
-            return dX, None, dgamma, dbeta, None, None, None, None, gskip, None
+            return dX, None, _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, gskip, None
         dW = torch.empty((co, ci), dtype=torch.float32, device=dev)
         nb = _lib.load().crfconv_linear_wgrad_workspace(m, co, ci)
         wsw = torch.empty(nb, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_linear_wgrad', ptr(gY), ptr(x), m, co, ci, ptr(dW), None, ptr(wsw), nb, st)
-        return dX, dW, dgamma, dbeta, None, None, None, None, gskip, None
+        return dX, dW, _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, gskip, None
 
 
 def mlp_block_join(x, W, bn, skip, slope):
@@ -1158,6 +1174,7 @@ class _MLPSmall(torch.autograd.Function):
         _lib.call('crfconv_mlp_small_forward', ptr(x), ptr(Wc), m, ci, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
                   ptr(run_var), float(momentum), float(eps), float(slope), ptr(y), ptr(out), ptr(coef), ptr(ws), nbytes,
                   ptr(sync), sync.numel() * 4, stream_ptr())
+        ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef)
         ctx.slope = float(slope)
         ctx.params = (W, None)
@@ -1174,8 +1191,7 @@ class _MLPSmall(torch.autograd.Function):
         dev = x.device
         gA = torch.zeros_like(y) if gA is None else gA.contiguous()
         gY = torch.empty_like(y)
-        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
         nbytes = _lib.load().crfconv_bn_workspace(m, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_bn_backward', ptr(gA), ptr(y), ptr(coef), m, co, 1, ctx.slope, ptr(gY), ptr(dgamma), ptr(dbeta),
@@ -1185,12 +1201,12 @@ class _MLPSmall(torch.autograd.Function):
             dX = gY @ W if g_alias is None else torch.addmm(g_alias.reshape(m, ci), gY, W)
         if _defer_ok(ctx.params):
             _defer_weight_grad(gY, x, ctx.params, False)
-            return dX, None, dgamma, dbeta, None, None, None, None, None, None
+            return dX, None, _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None
         dW = torch.empty((co, ci), dtype=torch.float32, device=dev)          # same partials + reduction as the deferred form
         nb = _lib.load().crfconv_linear_wgrad_workspace(m, co, ci)
         wsw = torch.empty(nb, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_linear_wgrad', ptr(gY), ptr(x), m, co, ci, ptr(dW), None, ptr(wsw), nb, stream_ptr())
-        return dX, dW, dgamma, dbeta, None, None, None, None, None, None
+        return dX, dW, _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None
 
 
 _NO_CAT_ENV = __import__('os').environ.get('CRFCONV_NO_CAT_FUSION') is not None      # A/B: materialise torch.cat
@@ -1216,6 +1232,7 @@ class _MLPBlockCat(torch.autograd.Function):
                   ptr(run_var), float(momentum), float(eps), ptr(coef), st)
         out = torch.empty_like(y)
         _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), st)
+        ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(xa, xb, Wc, y, coef)
         ctx.slope = float(slope)
         return out
@@ -1230,14 +1247,12 @@ class _MLPBlockCat(torch.autograd.Function):
         want_dx = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         dxa = torch.empty_like(xa) if want_dx else None
         dxb = torch.empty_like(xb) if want_dx else None
-        dW = torch.empty_like(W)
-        dgamma = torch.empty(co, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(co, dtype=torch.float32, device=dev)
+        (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward_cat', ptr(gA), ptr(y), ptr(xa), ptr(xb), split, ptr(W), ptr(coef), ctx.slope, m, ci, co,
                   ptr(dxa), ptr(dxb), ptr(dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
-        return (dxa if ctx.needs_input_grad[0] else None, dxb if ctx.needs_input_grad[1] else None, dW, dgamma, dbeta,
+        return (dxa if ctx.needs_input_grad[0] else None, dxb if ctx.needs_input_grad[1] else None, _param_ret(ctx.prm[0], dW, kW), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb),
                 None, None, None, None, None)
 
 

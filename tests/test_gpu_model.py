@@ -1339,7 +1339,10 @@ def test_deferred_weight_grads_into_the_flat_bucket():
     for (k, p), v in zip(net.named_parameters(), bucket.views):
         assert float((got[k] - ref[k]).abs().max()) <= 1e-6 * float(ref[k].abs().max()) + 1e-9, k
         direct += int(p.grad.data_ptr() == v.data_ptr())
-    assert direct >= 40                                   # every Linear weight went straight into the bucket
+    assert direct >= 60              # every Linear weight, and (dW, dgamma, dbeta) of the fused MLP blocks, went straight into the bucket
+    fused_bn = [k for k, p in net.named_parameters() if k.startswith('conv1_2.lin_in.bn')]      # a fused block of level 0
+    assert fused_bn and all(dict(net.named_parameters())[k].grad.data_ptr() == bucket.view_of(dict(net.named_parameters())[k]).data_ptr()
+                            for k in fused_bn)
     bucket.pack()
     for (k, p), v in zip(net.named_parameters(), bucket.views):
         assert p.grad.data_ptr() == v.data_ptr() and torch.equal(v, got[k])
