@@ -64,6 +64,7 @@ SIGNATURES = {
     'crfconv_pointconv_bwd_a1': (_i, [_vp, _vp, _vp, _i64, _i, _f, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_bwd_input': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_fold1': (_i, [_vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
+    'crfconv_pointconv_fold1_bwd_batched': (_i, [_vp, _i, _vp]),
     'crfconv_pointconv_fold1_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_fold2': (_i, [_vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_fold2_bwd': (_i, [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -129,6 +130,14 @@ SIGNATURES = {
 class ReduceJob(ctypes.Structure):
     """crf_reduce_job of include/crfconv_amd.h."""
     _fields_ = [('partial', ctypes.c_void_p), ('out', ctypes.c_void_p), ('nblk', ctypes.c_int32), ('nslots', ctypes.c_int32)]
+
+
+class Fold1BwdJob(ctypes.Structure):
+    """crf_fold1_bwd_job of include/crfconv_amd.h."""
+    _fields_ = [('W1', ctypes.c_void_p), ('gamma1', ctypes.c_void_p), ('mom', ctypes.c_void_p), ('aux1', ctypes.c_void_p),
+                ('dA1b1', ctypes.c_void_p), ('eps', ctypes.c_float), ('use_batch', ctypes.c_int32), ('d', ctypes.c_int32),
+                ('pad_', ctypes.c_int32), ('dW1', ctypes.c_void_p), ('dgamma1', ctypes.c_void_p), ('dbeta1', ctypes.c_void_p),
+                ('dW2_f64', ctypes.c_void_p), ('dW2_f32', ctypes.c_void_p)]
 
 
 _lib = None

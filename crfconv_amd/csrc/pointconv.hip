@@ -1320,12 +1320,12 @@ __global__ __launch_bounds__(128) void fold1_kernel(const float* __restrict__ W1
 }
 
 // dA1b1 [d, 4] float64 = {dA1[c][0..2], db1[c]}  ->  dW1 [d,3], dgamma1, dbeta1
-__global__ __launch_bounds__(128) void fold1_bwd_kernel(const float* __restrict__ W1, const float* __restrict__ gamma,
-                                                        const double* __restrict__ mom, const double* __restrict__ aux1,
-                                                        const double* __restrict__ dA1b1, float eps, int use_batch,
-                                                        int d, float* __restrict__ dW1, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta, const double* __restrict__ dW2_f64,
-                                                        float* __restrict__ dW2_f32) {
+__device__ __forceinline__ void fold1_bwd_body(const float* __restrict__ W1, const float* __restrict__ gamma,
+                                               const double* __restrict__ mom, const double* __restrict__ aux1,
+                                               const double* __restrict__ dA1b1, float eps, int use_batch,
+                                               int d, float* __restrict__ dW1, float* __restrict__ dgamma,
+                                               float* __restrict__ dbeta, const double* __restrict__ dW2_f64,
+                                               float* __restrict__ dW2_f32) {
     if (dW2_f64 != nullptr)                 // the float64 accumulator of bwd_params -> the float32 gradient (no cast launch)
         for (int i = threadIdx.x; i < d * d; i += 128) dW2_f32[i] = (float)dW2_f64[i];
     const int c = threadIdx.x;
@@ -1350,6 +1350,27 @@ __global__ __launch_bounds__(128) void fold1_bwd_kernel(const float* __restrict_
     dW1[3 * c] = (float)dw[0];
     dW1[3 * c + 1] = (float)dw[1];
     dW1[3 * c + 2] = (float)dw[2];
+}
+
+__global__ __launch_bounds__(128) void fold1_bwd_kernel(const float* __restrict__ W1, const float* __restrict__ gamma,
+                                                        const double* __restrict__ mom, const double* __restrict__ aux1,
+                                                        const double* __restrict__ dA1b1, float eps, int use_batch,
+                                                        int d, float* __restrict__ dW1, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, const double* __restrict__ dW2_f64,
+                                                        float* __restrict__ dW2_f32) {
+    fold1_bwd_body(W1, gamma, mom, aux1, dA1b1, eps, use_batch, d, dW1, dgamma, dbeta, dW2_f64, dW2_f32);
+}
+
+// The same for ALL PointConv layers of a backward pass in one launch (a workgroup per layer): nothing in the pass waits for
+// dW1 / dgamma1 / dbeta1, so the caller queues the jobs and runs them once at the end (ops.deferred_weight_grads).
+constexpr int F1_MAX = 24;
+struct Fold1BwdTable {
+    crf_fold1_bwd_job job[F1_MAX];
+};
+__global__ __launch_bounds__(128) void fold1_bwd_batched_kernel(const Fold1BwdTable t) {
+    const crf_fold1_bwd_job& j = t.job[blockIdx.x];
+    fold1_bwd_body(j.W1, j.gamma1, j.mom, j.aux1, j.dA1b1, j.eps, j.use_batch, j.d, j.dW1, j.dgamma1, j.dbeta1, j.dW2_f64,
+                   j.dW2_f32);
 }
 
 // stats [2, d] float64 = {sum(h2 - shift), sum (h2 - shift)^2}  ->  a2, b2; aux2 [2, d] = {mean2, rstd2}
@@ -1433,6 +1454,27 @@ extern "C" int crfconv_pointconv_fold1_bwd(const float* W1, const float* gamma1,
     hipLaunchKernelGGL(fold1_bwd_kernel, dim3(1), dim3(128), 0, as_stream(stream), W1, gamma1, mom, aux1, dA1b1, eps,
                        use_batch, d, dW1, dgamma1, dbeta1, dW2_f64, dW2_f32);
     CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_pointconv_fold1_bwd_batched(const crf_fold1_bwd_job* jobs, int njobs, crf_stream_t stream) {
+    CRF_REQUIRE(jobs || njobs == 0, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(njobs >= 0, CRF_ERR_ARG, "njobs=%d < 0", njobs);
+    for (int j = 0; j < njobs; ++j) {
+        const crf_fold1_bwd_job& b = jobs[j];
+        CRF_REQUIRE(b.W1 && b.gamma1 && b.mom && b.aux1 && b.dA1b1 && b.dW1 && b.dgamma1 && b.dbeta1, CRF_ERR_ARG,
+                    "job %d: null pointer", j);
+        CRF_REQUIRE((b.dW2_f64 == nullptr) == (b.dW2_f32 == nullptr), CRF_ERR_ARG, "job %d: dW2_f64 / dW2_f32: both or neither", j);
+        CRF_REQUIRE(b.d >= 1 && b.d <= 128, CRF_ERR_UNSUPPORTED, "job %d: d=%d outside [1, 128]", j, b.d);
+    }
+    for (int j0 = 0; j0 < njobs; j0 += F1_MAX) {
+        Fold1BwdTable t;
+        const int n = njobs - j0 < F1_MAX ? njobs - j0 : F1_MAX;
+        for (int j = 0; j < n; ++j) t.job[j] = jobs[j0 + j];
+        for (int j = n; j < F1_MAX; ++j) t.job[j] = jobs[j0];
+        hipLaunchKernelGGL(fold1_bwd_batched_kernel, dim3((unsigned)n), dim3(128), 0, as_stream(stream), t);
+        CRF_LAUNCH_CHECK();
+    }
     return CRF_OK;
 }
 

@@ -447,7 +447,7 @@ def discrete_meanfield(p, u, w, C, table, steps):
 # like DDP's) finishes all of them and installs / accumulates ``.grad`` of the weight and bias parameters directly.
 # Opt-in because it bypasses autograd for those leaves: ``torch.autograd.grad(loss, weight)`` sees nothing, and
 # gradient hooks on the weights do not fire.  ``loss.backward()`` + ``param.grad`` behave as usual.
-_DEFER = {'on': False, 'jobs': [], 'armed': False}
+_DEFER = {'on': False, 'jobs': [], 'folds': [], 'armed': False}
 
 
 class deferred_weight_grads:
@@ -466,7 +466,7 @@ class deferred_weight_grads:
         _DEFER['on'] = bool(self.enabled)
         _DEFER['sink'] = self.sink
         if not self.prev:                 # outermost context: nothing of an earlier (failed) backward may linger
-            _DEFER['jobs'], _DEFER['armed'] = [], False
+            _DEFER['jobs'], _DEFER['folds'], _DEFER['armed'] = [], [], False
         return self
 
     def __exit__(self, exc_type, *exc):
@@ -475,7 +475,7 @@ class deferred_weight_grads:
         if exc_type is not None and not self.prev:
             # the backward raised after arming the engine callback: drop its queued partials, or every later backward
             # would find 'armed' set, never queue the callback again and silently lose all Linear weight gradients
-            _DEFER['jobs'], _DEFER['armed'] = [], False
+            _DEFER['jobs'], _DEFER['folds'], _DEFER['armed'] = [], [], False
         return False
 
 
@@ -516,13 +516,40 @@ def _defer_weight_grad(g, x, params, has_bias):
     _lib.call('crfconv_linear_wgrad_partial', ptr(g), ptr(x), m, Co, Ci, 1 if want_b else 0, ptr(ws), nbytes,
               ctypes.byref(nblk), stream_ptr())
     _DEFER['jobs'].append((params[0], params[1] if want_b else None, ws, nblk.value, Co, Ci))
+    _arm_flush()
+
+
+def _arm_flush():
     if not _DEFER['armed']:
         _DEFER['armed'] = True
         torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_grads)
 
 
+def _defer_fold1_bwd(job, keep, installs):
+    """Queues one PointConv layer's fold1_bwd (a _lib.Fold1BwdJob; `keep`: the tensors its pointers refer to; `installs`:
+    (parameter, gradient tensor, direct) triples) for the single batched launch at the end of the backward pass."""
+    _DEFER['folds'].append((job, keep, installs))
+    _arm_flush()
+
+
+def _flush_fold1_bwd():
+    folds, _DEFER['folds'] = _DEFER['folds'], []
+    if not folds:
+        return
+    table = (_lib.Fold1BwdJob * len(folds))(*[f[0] for f in folds])
+    _lib.call('crfconv_pointconv_fold1_bwd_batched', ctypes.cast(table, ctypes.c_void_p), len(folds), stream_ptr())
+    for _, _, installs in folds:
+        for prm, gr, direct in installs:
+            gr = gr.view_as(prm)
+            if direct or prm.grad is None:
+                prm.grad = gr
+            else:
+                prm.grad.add_(gr)
+
+
 def _flush_weight_grads():
     jobs, _DEFER['jobs'], _DEFER['armed'] = _DEFER['jobs'], [], False
+    _flush_fold1_bwd()
     if not jobs:
         return
     dev = jobs[0][2].device
@@ -1592,6 +1619,7 @@ class _PointConv(torch.autograd.Function):
             _lib.call('crfconv_pointconv_forward', ptr(x), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d,
                       ptr(A1), ptr(b1), ptr(W2c), slope, ptr(a2), ptr(b2), ptr(out), st)
         ctx.uv = (U, V)
+        ctx.prm = (W1, g1, be1, W2)                        # the parameter objects themselves (deferred / direct gradients)
         ctx.table, ctx.n_e, ctx.slope, ctx.use1, ctx.use2, ctx.eps1 = table, n_e, slope, use1, use2, eps1
         ctx.save_for_backward(x, W1c, g1c, W2c, g2c, A1, b1, a2, b2, shift, aux1, aux2, mom, pos_src, pos_tgt)
         return out
@@ -1600,6 +1628,7 @@ class _PointConv(torch.autograd.Function):
     def backward(ctx, gout):
         x, W1, g1, W2, g2, A1, b1, a2, b2, shift, aux1, aux2, mom, pos_src, pos_tgt = ctx.saved_tensors
         table, n_e, slope = ctx.table, ctx.n_e, ctx.slope
+        pW1, pg1, pbe1, pW2 = ctx.prm
         dev = x.device
         d = x.shape[1]
         m_tgt, K = table.m_tgt, table.K
@@ -1638,21 +1667,41 @@ class _PointConv(torch.autograd.Function):
             _lib.call('crfconv_pointconv_bwd_dump', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
                       m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(h1),
                       ptr(gh2), ptr(rel), st)
-            dW2 = torch.empty((d, d), dtype=torch.float32, device=dev)       # g_h2^T h1 on the MFMA row-reduction kernel
-            wbytes = _lib.load().crfconv_linear_wgrad_workspace(E, d, d)
-            wws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-            _lib.call('crfconv_linear_wgrad', ptr(gh2), ptr(h1), E, d, d, ptr(dW2), None, ptr(wws), wbytes, st)
+            if _defer_ok((pW2, None)):                                     # g_h2^T h1: partials now, the reduction with all others
+                _defer_weight_grad(gh2, h1, (pW2, None), False)
+                dW2 = None
+            else:
+                dW2 = torch.empty((d, d), dtype=torch.float32, device=dev)   # ... on the MFMA row-reduction kernel
+                wbytes = _lib.load().crfconv_linear_wgrad_workspace(E, d, d)
+                wws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+                _lib.call('crfconv_linear_wgrad', ptr(gh2), ptr(h1), E, d, d, ptr(dW2), None, ptr(wws), wbytes, st)
             gw = gh2 @ W2                                                  # g_h1 before the LeakyReLU mask
             dA1b1 = torch.empty((d, 4), dtype=torch.float64, device=dev)
             abytes = _lib.load().crfconv_pointconv_bwd_a1_workspace(E, d)
             aws = torch.empty(abytes, dtype=torch.uint8, device=dev)
             _lib.call('crfconv_pointconv_bwd_a1', ptr(gw), ptr(h1), ptr(rel), E, d, slope, ptr(dA1b1), ptr(aws), abytes,
                       st)
-        dW1 = torch.empty((d, 3), dtype=torch.float32, device=dev)
-        dg1 = torch.empty(d, dtype=torch.float32, device=dev)
-        dbe1 = torch.empty(d, dtype=torch.float32, device=dev)
-        _lib.call('crfconv_pointconv_fold1_bwd', ptr(W1), ptr(g1), ptr(mom), ptr(aux1), ptr(dA1b1), float(ctx.eps1),
-                  1 if ctx.use1 else 0, d, ptr(dW1), ptr(dg1), ptr(dbe1), ptr(dW2_64), ptr(dW2) if dW2_64 is not None else None, st)
+        defer_fold = all(_defer_ok((q, None)) for q in (pW1, pg1, pbe1)) and (dW2_64 is None or _defer_ok((pW2, None)))
+        if defer_fold:
+            # nothing in this pass reads dW1 / dgamma1 / dbeta1 (or the float32 dW2 of the narrow layers): ONE batched fold launch
+            # for all PointConv layers at the end of the backward, written straight into the caller's bucket where there is one
+            outs = [(q,) + _param_out(q, shp, dev) for q, shp in ((pW1, (d, 3)), (pg1, (d,)), (pbe1, (d,)))]
+            if dW2_64 is not None:
+                outs.append((pW2,) + _param_out(pW2, (d, d), dev))
+            adr = lambda t: None if t is None else t.data_ptr()
+            job = _lib.Fold1BwdJob(adr(W1), adr(g1), adr(mom), adr(aux1), adr(dA1b1), float(ctx.eps1), 1 if ctx.use1 else 0, d, 0,
+                                   adr(outs[0][1]), adr(outs[1][1]), adr(outs[2][1]), adr(dW2_64),
+                                   adr(outs[3][1]) if dW2_64 is not None else None)
+            _defer_fold1_bwd(job, (W1, g1, mom, aux1, dA1b1, dW2_64), outs)
+            dW1 = dg1 = dbe1 = None
+            if dW2_64 is not None:
+                dW2 = None
+        else:
+            dW1 = torch.empty((d, 3), dtype=torch.float32, device=dev)
+            dg1 = torch.empty(d, dtype=torch.float32, device=dev)
+            dbe1 = torch.empty(d, dtype=torch.float32, device=dev)
+            _lib.call('crfconv_pointconv_fold1_bwd', ptr(W1), ptr(g1), ptr(mom), ptr(aux1), ptr(dA1b1), float(ctx.eps1),
+                      1 if ctx.use1 else 0, d, ptr(dW1), ptr(dg1), ptr(dbe1), ptr(dW2_64), ptr(dW2) if dW2_64 is not None else None, st)
         # input gradient (source-major gather over the reverse table)
         rev_ptr, rev_eid = table.reverse
         dx = torch.empty((table.m_src, d), dtype=torch.float32, device=dev)
