@@ -79,6 +79,7 @@ SIGNATURES = {
     'crfconv_mlp_backward_workspace': (_sz, [_i64, _i, _i]),
     'crfconv_mlp_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_linear_forward_cat': (_i, [_vp, _vp, _i, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    'crfconv_mlp_dw_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_mlp_backward_add': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_mlp_backward_cat': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_bn_workspace': (_sz, [_i64, _i]),
@@ -130,6 +131,12 @@ SIGNATURES = {
 class ReduceJob(ctypes.Structure):
     """crf_reduce_job of include/crfconv_amd.h."""
     _fields_ = [('partial', ctypes.c_void_p), ('out', ctypes.c_void_p), ('nblk', ctypes.c_int32), ('nslots', ctypes.c_int32)]
+
+
+class MlpDwJob(ctypes.Structure):
+    """crf_mlp_dw_job of include/crfconv_amd.h."""
+    _fields_ = [('workspace', ctypes.c_void_p), ('coef', ctypes.c_void_p), ('dW', ctypes.c_void_p), ('M', ctypes.c_int64),
+                ('Ci', ctypes.c_int32), ('Co', ctypes.c_int32)]
 
 
 class Fold1BwdJob(ctypes.Structure):

@@ -248,51 +248,20 @@ __global__ __launch_bounds__(WG_BLOCK) void mlp_bwd_p1_kernel(const float* __res
     }
 }
 
-// Finalize of the pass above, ONE launch of two kinds of workgroups:
-//   blockIdx.x <  nw : 64 slots (co, ci) of dW = a [ sum A - c2 sum sx - c3 sum B ],  c2 = dbeta / M, c3 = dgamma / M
-//                      (each workgroup re-derives c2 / c3 of the one or two co rows it touches: no ordering between the
-//                      two kinds of workgroups is needed)
-//   blockIdx.x >= nw : four channels each: dgamma, dbeta and the coefficients of
-//                      gY = alpha * lrelu'(a y + b) * gA + bet * y + del   (bcoef [5][Co] = a | b | alpha | bet | del)
+// dW slots [64 block, 64 block + 64) of one MLP block's backward from its partial slabs (see mlp_bwd_finalize_kernel): shared by
+// the per-layer finalize launch and the batched launch over all layers of a backward pass (mlp_dw_jobs_kernel).
 constexpr int MF_BLOCK = 1024, MF_WAVES = MF_BLOCK / WAVE;
-__global__ __launch_bounds__(MF_BLOCK) void mlp_bwd_finalize_kernel(const float* __restrict__ PA, const float* __restrict__ PB,
-                                                                    const float* __restrict__ PG, const float* __restrict__ PX,
-                                                                    int nblk, const float* __restrict__ coef, int64_t M, int Co,
-                                                                    int Ci, int nw, float* __restrict__ dW,
-                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                    float* __restrict__ bcoef) {
+__device__ __forceinline__ void mlp_dw_slots(const float* __restrict__ PA, const float* __restrict__ PB,
+                                             const float* __restrict__ PG, const float* __restrict__ PX, int nblk,
+                                             const float* __restrict__ coef, int64_t M, int Co, int Ci, int block,
+                                             float* __restrict__ dW) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if ((int)blockIdx.x >= nw) {                               // one wavefront per channel
-        const int c = ((int)blockIdx.x - nw) * MF_WAVES + w;
-        if (c >= Co) return;
-        double s1 = 0.0, s2 = 0.0;
-        for (int b = lane; b < nblk; b += WAVE) {
-            s1 += (double)PG[((int64_t)b * 2 + 0) * Co + c];
-            s2 += (double)PG[((int64_t)b * 2 + 1) * Co + c];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            s1 += __shfl_xor(s1, o, WAVE);
-            s2 += __shfl_xor(s2, o, WAVE);
-        }
-        if (lane != 0) return;
-        dbeta[c] = (float)s1;
-        dgamma[c] = (float)s2;
-        const double a = coef[c], mu = coef[2 * Co + c], rs = coef[3 * Co + c];
-        const double c2 = s1 / (double)M, c3 = s2 / (double)M;
-        bcoef[c] = coef[c];
-        bcoef[Co + c] = coef[Co + c];
-        bcoef[2 * Co + c] = (float)a;
-        bcoef[3 * Co + c] = (float)(-a * c3 * rs);
-        bcoef[4 * Co + c] = (float)(-a * c2 + a * c3 * rs * mu);
-        return;
-    }
     // 64 slots per workgroup; the sixteen wavefronts split the slabs (b = w, w + 16, ..), four slabs of each of the five
     // streams in flight per lane: a 512-slab reduction is eight dependent round trips (the 256-thread form
     // measured 16.5 us per layer, more than the pass that produced the slabs)
     __shared__ float s_part[MF_WAVES][5][64];
     const int nslots = Co * Ci;
-    const int slot = blockIdx.x * 64 + lane;
+    const int slot = block * 64 + lane;
     const bool ok = slot < nslots;
     const int sl = ok ? slot : nslots - 1;
     const int co = sl / Ci, ci = sl - co * Ci;
@@ -331,6 +300,74 @@ __global__ __launch_bounds__(MF_BLOCK) void mlp_bwd_finalize_kernel(const float*
         const double a = coef[co], c2 = G1 / (double)M, c3 = G2 / (double)M;
         dW[slot] = (float)(a * (A - c2 * Xs - c3 * B));
     }
+}
+
+// Finalize of the pass above, ONE launch of two kinds of workgroups:
+//   blockIdx.x <  nw : 64 slots (co, ci) of dW = a [ sum A - c2 sum sx - c3 sum B ],  c2 = dbeta / M, c3 = dgamma / M
+//                      (each workgroup re-derives c2 / c3 of the one or two co rows it touches: no ordering between the
+//                      two kinds of workgroups is needed)
+//   blockIdx.x >= nw : four channels each: dgamma, dbeta and the coefficients of
+//                      gY = alpha * lrelu'(a y + b) * gA + bet * y + del   (bcoef [5][Co] = a | b | alpha | bet | del)
+__global__ __launch_bounds__(MF_BLOCK) void mlp_bwd_finalize_kernel(const float* __restrict__ PA, const float* __restrict__ PB,
+                                                                    const float* __restrict__ PG, const float* __restrict__ PX,
+                                                                    int nblk, const float* __restrict__ coef, int64_t M, int Co,
+                                                                    int Ci, int nw, float* __restrict__ dW,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                    float* __restrict__ bcoef) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= nw) {                               // one wavefront per channel
+        const int c = ((int)blockIdx.x - nw) * MF_WAVES + w;
+        if (c >= Co) return;
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = lane; b < nblk; b += WAVE) {
+            s1 += (double)PG[((int64_t)b * 2 + 0) * Co + c];
+            s2 += (double)PG[((int64_t)b * 2 + 1) * Co + c];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, WAVE);
+            s2 += __shfl_xor(s2, o, WAVE);
+        }
+        if (lane != 0) return;
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)s2;
+        const double a = coef[c], mu = coef[2 * Co + c], rs = coef[3 * Co + c];
+        const double c2 = s1 / (double)M, c3 = s2 / (double)M;
+        bcoef[c] = coef[c];
+        bcoef[Co + c] = coef[Co + c];
+        bcoef[2 * Co + c] = (float)a;
+        bcoef[3 * Co + c] = (float)(-a * c3 * rs);
+        bcoef[4 * Co + c] = (float)(-a * c2 + a * c3 * rs * mu);
+        return;
+    }
+    mlp_dw_slots(PA, PB, PG, PX, nblk, coef, M, Co, Ci, (int)blockIdx.x, dW);
+}
+
+// The dW parts of ALL MLP blocks of a backward pass in ONE launch: nothing inside the pass reads a weight gradient, so the
+// per-layer finalize launch only does its channel part (dgamma, dbeta, the dX coefficients) and the slab reductions --
+// 32 launches of ~8 dependent round trips each -- run side by side at the end.  group_begin = prefix sum of ceil(Co Ci / 64).
+constexpr int MDW_MAX = 40;
+struct MlpDwTable {
+    const float* PA[MDW_MAX];
+    const float* PB[MDW_MAX];
+    const float* PG[MDW_MAX];
+    const float* PX[MDW_MAX];
+    const float* coef[MDW_MAX];
+    float* dW[MDW_MAX];
+    long long M[MDW_MAX];
+    int nblk[MDW_MAX], Co[MDW_MAX], Ci[MDW_MAX];
+    int group_begin[MDW_MAX + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(MF_BLOCK) void mlp_dw_jobs_kernel(const MlpDwTable t) {
+    const int g = blockIdx.x;
+    int lo = 0, hi = t.njobs;                          // largest j with group_begin[j] <= g
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t.group_begin[mid] <= g) lo = mid; else hi = mid;
+    }
+    mlp_dw_slots(t.PA[lo], t.PB[lo], t.PG[lo], t.PX[lo], t.nblk[lo], t.coef[lo], (int64_t)t.M[lo], t.Co[lo], t.Ci[lo],
+                 g - t.group_begin[lo], t.dW[lo]);
 }
 
 // out[slot] = sum_b partial[b][slot] for 64 consecutive slots per workgroup: lanes run along the slots (256-byte
@@ -1368,11 +1405,53 @@ extern "C" int crfconv_mlp_backward_cat(const float* gA, const float* Y, const f
                              workspace_bytes, stream);
 }
 
+// dW of any number of MLP blocks whose crfconv_mlp_backward(_add / _cat) call was given dW = NULL, from the workspaces those
+// calls left behind (untouched since), in ONE launch.
+extern "C" int crfconv_mlp_dw_jobs(const crf_mlp_dw_job* jobs, int njobs, crf_stream_t stream) {
+    CRF_REQUIRE(jobs || njobs == 0, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(njobs >= 0, CRF_ERR_ARG, "njobs=%d < 0", njobs);
+    hipStream_t st = crf::as_stream(stream);
+    for (int j0 = 0; j0 < njobs; j0 += crf::MDW_MAX) {
+        crf::MlpDwTable t;
+        const int n = njobs - j0 < crf::MDW_MAX ? njobs - j0 : crf::MDW_MAX;
+        int64_t total = 0;
+        for (int j = 0; j < crf::MDW_MAX; ++j) {
+            const crf_mlp_dw_job& jb = jobs[j0 + (j < n ? j : 0)];
+            if (j < n) {
+                CRF_REQUIRE(jb.workspace && jb.coef && jb.dW, CRF_ERR_ARG, "job %d: null pointer", j0 + j);
+                CRF_REQUIRE(crfconv_mlp_backward_supported(jb.M, jb.Ci, jb.Co) == 1, CRF_ERR_UNSUPPORTED,
+                            "job %d: shape M=%lld Ci=%d Co=%d not supported", j0 + j, (long long)jb.M, jb.Ci, jb.Co);
+            }
+            const char* base = reinterpret_cast<const char*>((reinterpret_cast<uintptr_t>(jb.workspace) + 255) & ~(uintptr_t)255);
+            size_t off[5];
+            crf::mlp_ws_layout(jb.M, jb.Co, jb.Ci, off);
+            t.PA[j] = reinterpret_cast<const float*>(base + off[0]);
+            t.PB[j] = reinterpret_cast<const float*>(base + off[1]);
+            t.PG[j] = reinterpret_cast<const float*>(base + off[2]);
+            t.PX[j] = reinterpret_cast<const float*>(base + off[3]);
+            t.coef[j] = jb.coef;
+            t.dW[j] = jb.dW;
+            t.M[j] = (long long)jb.M;
+            t.nblk[j] = crf::mlp_plan(jb.M, jb.Co, jb.Ci).nblk;
+            t.Co[j] = jb.Co;
+            t.Ci[j] = jb.Ci;
+            t.group_begin[j] = (int)total;
+            if (j < n) total += crf::cdiv((int64_t)jb.Co * jb.Ci, 64);
+            CRF_REQUIRE(total < ((int64_t)1 << 30), CRF_ERR_ARG, "too many slots in one batch");
+        }
+        t.group_begin[crf::MDW_MAX] = (int)total;
+        t.njobs = n;
+        hipLaunchKernelGGL(crf::mlp_dw_jobs_kernel, dim3((unsigned)total), dim3(crf::MF_BLOCK), 0, st, t);
+        CRF_LAUNCH_CHECK();
+    }
+    return CRF_OK;
+}
+
 static int mlp_backward_impl(const float* gA, const float* Y, const float* X, const float* Xb, int xsplit, const float* W,
                              const float* coef, float slope, int64_t M, int Ci, int Co, float* dX, float* dXb, float* dW,
                              float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream,
                              const float* dX_add) {
-    CRF_REQUIRE(gA && Y && X && W && coef && dW && dgamma && dbeta && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(gA && Y && X && W && coef && dgamma && dbeta && workspace, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(dX_add == nullptr || dXb == nullptr, CRF_ERR_ARG, "dX_add is for the one-operand form");
     CRF_REQUIRE(crfconv_mlp_backward_supported(M, Ci, Co) == 1, CRF_ERR_UNSUPPORTED, "shape M=%lld Ci=%d Co=%d not supported",
                 (long long)M, Ci, Co);
@@ -1403,7 +1482,8 @@ static int mlp_backward_impl(const float* gA, const float* Y, const float* X, co
 #undef P1
         CRF_LAUNCH_CHECK();
     }
-    const int nw = (int)crf::cdiv((int64_t)Co * Ci, 64);
+    // dW == NULL: the channel part only; the caller finishes dW later from the workspace (crfconv_mlp_dw_jobs)
+    const int nw = dW != nullptr ? (int)crf::cdiv((int64_t)Co * Ci, 64) : 0;
     hipLaunchKernelGGL(crf::mlp_bwd_finalize_kernel, dim3((unsigned)(nw + (Co + crf::MF_WAVES - 1) / crf::MF_WAVES)), dim3(crf::MF_BLOCK), 0, st, PA, PB, PG, PX,
                        p.nblk, coef, M, Co, Ci, nw, dW, dgamma, dbeta, pro);
     CRF_LAUNCH_CHECK();

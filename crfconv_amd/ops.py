@@ -447,7 +447,7 @@ def discrete_meanfield(p, u, w, C, table, steps):
 # like DDP's) finishes all of them and installs / accumulates ``.grad`` of the weight and bias parameters directly.
 # Opt-in because it bypasses autograd for those leaves: ``torch.autograd.grad(loss, weight)`` sees nothing, and
 # gradient hooks on the weights do not fire.  ``loss.backward()`` + ``param.grad`` behave as usual.
-_DEFER = {'on': False, 'jobs': [], 'folds': [], 'armed': False}
+_DEFER = {'on': False, 'jobs': [], 'folds': [], 'mlpdw': [], 'armed': False}
 
 
 class deferred_weight_grads:
@@ -466,7 +466,7 @@ class deferred_weight_grads:
         _DEFER['on'] = bool(self.enabled)
         _DEFER['sink'] = self.sink
         if not self.prev:                 # outermost context: nothing of an earlier (failed) backward may linger
-            _DEFER['jobs'], _DEFER['folds'], _DEFER['armed'] = [], [], False
+            _DEFER['jobs'], _DEFER['folds'], _DEFER['mlpdw'], _DEFER['armed'] = [], [], [], False
         return self
 
     def __exit__(self, exc_type, *exc):
@@ -475,7 +475,7 @@ class deferred_weight_grads:
         if exc_type is not None and not self.prev:
             # the backward raised after arming the engine callback: drop its queued partials, or every later backward
             # would find 'armed' set, never queue the callback again and silently lose all Linear weight gradients
-            _DEFER['jobs'], _DEFER['folds'], _DEFER['armed'] = [], [], False
+            _DEFER['jobs'], _DEFER['folds'], _DEFER['mlpdw'], _DEFER['armed'] = [], [], [], False
         return False
 
 
@@ -532,6 +532,31 @@ def _defer_fold1_bwd(job, keep, installs):
     _arm_flush()
 
 
+def _mlp_dw_ret(deferred, prm, dW, direct, ws, m, ci, co, coef):
+    """The weight gradient a fused MLP block's backward returns.  `deferred` (the C call was given dW = NULL): queue the slab
+    reduction -- workspace, coefficients and target stay alive until then -- for the ONE launch that finishes the weight
+    gradients of all blocks at the end of the backward pass (crfconv_mlp_dw_jobs), and return None."""
+    if not deferred:
+        return _param_ret(prm, dW, direct)
+    _DEFER['mlpdw'].append((_lib.MlpDwJob(ws.data_ptr(), coef.data_ptr(), dW.data_ptr(), m, ci, co), (ws, coef), (prm, dW, direct)))
+    _arm_flush()
+    return None
+
+
+def _flush_mlp_dw():
+    jobs, _DEFER['mlpdw'] = _DEFER['mlpdw'], []
+    if not jobs:
+        return
+    table = (_lib.MlpDwJob * len(jobs))(*[j[0] for j in jobs])
+    _lib.call('crfconv_mlp_dw_jobs', ctypes.cast(table, ctypes.c_void_p), len(jobs), stream_ptr())
+    for _, _, (prm, gr, direct) in jobs:
+        gr = gr.view_as(prm)
+        if direct or prm.grad is None:
+            prm.grad = gr
+        else:
+            prm.grad.add_(gr)
+
+
 def _flush_fold1_bwd():
     folds, _DEFER['folds'] = _DEFER['folds'], []
     if not folds:
@@ -550,6 +575,7 @@ def _flush_fold1_bwd():
 def _flush_weight_grads():
     jobs, _DEFER['jobs'], _DEFER['armed'] = _DEFER['jobs'], [], False
     _flush_fold1_bwd()
+    _flush_mlp_dw()
     if not jobs:
         return
     dev = jobs[0][2].device
@@ -828,11 +854,12 @@ class _MLPBlock(torch.autograd.Function):
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         add = _f32c(g_alias) if (g_alias is not None and dX is not None) else None
         (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
+        dfr = _defer_ok((ctx.prm[0], None))                  # dW: finished with all other blocks' at the end of the pass
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward_add', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(add), ptr(dX),
-                  ptr(dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
-        return dX, _param_ret(ctx.prm[0], dW, kW), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None
+                  ptr(None if dfr else dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
+        return dX, _mlp_dw_ret(dfr, ctx.prm[0], dW, kW, ws, m, ci, co, coef), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None
 
 
 _NO_JOIN_ENV = __import__('os').environ.get('CRFCONV_NO_JOIN_FUSION') is not None      # A/B: bn_apply + add_lrelu as two passes
@@ -873,11 +900,12 @@ class _MLPBlockJoin(torch.autograd.Function):
         _lib.call('crfconv_add_lrelu_backward', ptr(g), ptr(out), out.numel(), ctx.slope, ptr(g1), st)
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
+        dfr = _defer_ok((ctx.prm[0], None))                  # dW: finished with all other blocks' at the end of the pass
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.call('crfconv_mlp_backward', ptr(g1), ptr(y), ptr(x), ptr(W), ptr(coef), 1.0, m, ci, co, ptr(dX), ptr(dW),
+        _lib.call('crfconv_mlp_backward', ptr(g1), ptr(y), ptr(x), ptr(W), ptr(coef), 1.0, m, ci, co, ptr(dX), ptr(None if dfr else dW),
                   ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
-        return dX, _param_ret(ctx.prm[0], dW, kW), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, (g1 if ctx.needs_input_grad[8] else None), None
+        return dX, _mlp_dw_ret(dfr, ctx.prm[0], dW, kW, ws, m, ci, co, coef), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, (g1 if ctx.needs_input_grad[8] else None), None
 
 
 _NO_DROPOUT_FUSION_ENV = __import__('os').environ.get('CRFCONV_NO_DROPOUT_FUSION') is not None     # A/B: bn_apply + nn.Dropout
@@ -920,11 +948,12 @@ class _MLPBlockDropout(torch.autograd.Function):
         _lib.call('crfconv_dropout_backward', ptr(g), g.numel(), ctx.p, ctx.seed, ptr(counter), ptr(gA), st)
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
+        dfr = _defer_ok((ctx.prm[0], None))                  # dW: finished with all other blocks' at the end of the pass
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(dW),
+        _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(None if dfr else dW),
                   ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
-        return dX, _param_ret(ctx.prm[0], dW, kW), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None, None, None
+        return dX, _mlp_dw_ret(dfr, ctx.prm[0], dW, kW, ws, m, ci, co, coef), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None, None, None
 
 
 class _MLPDropoutLinear(torch.autograd.Function):
@@ -974,11 +1003,12 @@ class _MLPDropoutLinear(torch.autograd.Function):
             _lib.call('crfconv_linear_wgrad', ptr(g), ptr(h), m, c2, co, ptr(dW2), ptr(db2), ptr(wsw), nb, st)
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
+        dfr = _defer_ok((ctx.prm[0], None))                  # dW: finished with all other blocks' at the end of the pass
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(dW),
+        _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(None if dfr else dW),
                   ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
-        return dX, _param_ret(ctx.prm[0], dW, kW), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None, None, None, dW2, db2
+        return dX, _mlp_dw_ret(dfr, ctx.prm[0], dW, kW, ws, m, ci, co, coef), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None, None, None, dW2, db2
 
 
 def mlp_dropout_linear(x, W, bn, slope, p, W2, b2):
@@ -1064,11 +1094,12 @@ class _MLPBlockPool(torch.autograd.Function):
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         add = _f32c(g_alias) if (g_alias is not None and dX is not None) else None
         (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
+        dfr = _defer_ok((ctx.prm[0], None))                  # dW: finished with all other blocks' at the end of the pass
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward_add', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), 1.0, m, ci, co, ptr(add), ptr(dX),
-                  ptr(dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
-        return dX, _param_ret(ctx.prm[0], dW, kW), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None
+                  ptr(None if dfr else dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
+        return dX, _mlp_dw_ret(dfr, ctx.prm[0], dW, kW, ws, m, ci, co, coef), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None
 
 
 def mlp_block_pool(x, W, bn, table, fork=False):
@@ -1275,11 +1306,12 @@ class _MLPBlockCat(torch.autograd.Function):
         dxa = torch.empty_like(xa) if want_dx else None
         dxb = torch.empty_like(xb) if want_dx else None
         (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
+        dfr = _defer_ok((ctx.prm[0], None))                  # dW: finished with all other blocks' at the end of the pass
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward_cat', ptr(gA), ptr(y), ptr(xa), ptr(xb), split, ptr(W), ptr(coef), ctx.slope, m, ci, co,
-                  ptr(dxa), ptr(dxb), ptr(dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
-        return (dxa if ctx.needs_input_grad[0] else None, dxb if ctx.needs_input_grad[1] else None, _param_ret(ctx.prm[0], dW, kW), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb),
+                  ptr(dxa), ptr(dxb), ptr(None if dfr else dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
+        return (dxa if ctx.needs_input_grad[0] else None, dxb if ctx.needs_input_grad[1] else None, _mlp_dw_ret(dfr, ctx.prm[0], dW, kW, ws, m, ci, co, coef), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb),
                 None, None, None, None, None)
 
 

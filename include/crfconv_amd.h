@@ -392,6 +392,11 @@ size_t crfconv_mlp_backward_workspace(int64_t M, int Ci, int Co);
 int crfconv_mlp_backward(const float* gA, const float* Y, const float* X, const float* W, const float* coef, float slope,
                          int64_t M, int Ci, int Co, float* dX, float* dW, float* dgamma, float* dbeta, void* workspace,
                          size_t workspace_bytes, crf_stream_t stream);
+/* dW may be NULL in crfconv_mlp_backward / _add / _cat: the finalize launch then does its channel part only (dgamma, dbeta, the
+ * coefficients dX needs) and the weight gradient is finished later, for any number of blocks in ONE launch, from the
+ * workspaces those calls left behind (which must be untouched since): nothing inside a backward pass reads a weight gradient. */
+typedef struct { const void* workspace; const float* coef; float* dW; int64_t M; int32_t Ci; int32_t Co; } crf_mlp_dw_job;
+int crfconv_mlp_dw_jobs(const crf_mlp_dw_job* jobs, int njobs, crf_stream_t stream);
 /* The same backward for a block whose input x has a second consumer -- the shortcut of a ResNet block
  * (models/point_conv_big.py:83-88: lin_in(x) and shortcut(x)): dX = gY W + dX_add, dX_add [M, Ci] the gradient that other
  * consumer already sent back (NULL: as crfconv_mlp_backward).  Replaces the accumulation pass autograd would run. */
