@@ -319,9 +319,19 @@ __global__ __launch_bounds__(MF_BLOCK) void mlp_bwd_finalize_kernel(const float*
         const int c = ((int)blockIdx.x - nw) * MF_WAVES + w;
         if (c >= Co) return;
         double s1 = 0.0, s2 = 0.0;
-        for (int b = lane; b < nblk; b += WAVE) {
-            s1 += (double)PG[((int64_t)b * 2 + 0) * Co + c];
-            s2 += (double)PG[((int64_t)b * 2 + 1) * Co + c];
+        // eight slabs of both sums in flight per lane (nblk <= 512: ONE round trip; the rolled loop was eight dependent ones --
+        // this launch sits between the two passes of every MLP block's backward)
+        for (int b0 = lane; b0 < nblk; b0 += 8 * WAVE) {
+            float v1[8], v2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + u * WAVE;
+                const bool in = b < nblk;
+                v1[u] = in ? PG[((int64_t)b * 2 + 0) * Co + c] : 0.f;
+                v2[u] = in ? PG[((int64_t)b * 2 + 1) * Co + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
