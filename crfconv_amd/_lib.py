@@ -64,6 +64,7 @@ SIGNATURES = {
     'crfconv_pointconv_bwd_a1': (_i, [_vp, _vp, _vp, _i64, _i, _f, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_bwd_input': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_fold1': (_i, [_vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
+    'crfconv_pointconv_fold1_batched': (_i, [_vp, _i, _vp]),
     'crfconv_pointconv_fold1_bwd_batched': (_i, [_vp, _i, _vp]),
     'crfconv_pointconv_fold1_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_fold2': (_i, [_vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
@@ -137,6 +138,14 @@ class MlpDwJob(ctypes.Structure):
     """crf_mlp_dw_job of include/crfconv_amd.h."""
     _fields_ = [('workspace', ctypes.c_void_p), ('coef', ctypes.c_void_p), ('dW', ctypes.c_void_p), ('M', ctypes.c_int64),
                 ('Ci', ctypes.c_int32), ('Co', ctypes.c_int32)]
+
+
+class Fold1Job(ctypes.Structure):
+    """crf_fold1_job of include/crfconv_amd.h."""
+    _fields_ = [('W1', ctypes.c_void_p), ('gamma1', ctypes.c_void_p), ('beta1', ctypes.c_void_p), ('mom', ctypes.c_void_p),
+                ('n_edges', ctypes.c_double), ('run_mean', ctypes.c_void_p), ('run_var', ctypes.c_void_p),
+                ('momentum', ctypes.c_float), ('eps', ctypes.c_float), ('use_batch', ctypes.c_int32), ('d', ctypes.c_int32),
+                ('A1', ctypes.c_void_p), ('b1', ctypes.c_void_p), ('aux1', ctypes.c_void_p)]
 
 
 class Fold1BwdJob(ctypes.Structure):

@@ -1284,12 +1284,12 @@ extern "C" int crfconv_pointconv_bwd_a1(const float* gw, const float* h1, const 
 namespace crf {
 
 // mom = {mu[3], Sigma[9]} float64.  aux1 [3, d] float64 out = {a = gamma*rstd, mean1, var1}.
-__global__ __launch_bounds__(128) void fold1_kernel(const float* __restrict__ W1, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, const double* __restrict__ mom,
-                                                    double n_edges, float* __restrict__ run_mean,
-                                                    float* __restrict__ run_var, float momentum, float eps,
-                                                    int use_batch, int d, float* __restrict__ A1,
-                                                    float* __restrict__ b1, double* __restrict__ aux1) {
+__device__ __forceinline__ void fold1_body(const float* __restrict__ W1, const float* __restrict__ gamma,
+                                           const float* __restrict__ beta, const double* __restrict__ mom,
+                                           double n_edges, float* __restrict__ run_mean,
+                                           float* __restrict__ run_var, float momentum, float eps,
+                                           int use_batch, int d, float* __restrict__ A1,
+                                           float* __restrict__ b1, double* __restrict__ aux1) {
     const int c = threadIdx.x;
     if (c >= d) return;
     const double w[3] = {W1[3 * c], W1[3 * c + 1], W1[3 * c + 2]};
@@ -1317,6 +1317,27 @@ __global__ __launch_bounds__(128) void fold1_kernel(const float* __restrict__ W1
     aux1[c] = a;
     aux1[d + c] = mean;
     aux1[2 * d + c] = var;
+}
+
+__global__ __launch_bounds__(128) void fold1_kernel(const float* __restrict__ W1, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const double* __restrict__ mom,
+                                                    double n_edges, float* __restrict__ run_mean,
+                                                    float* __restrict__ run_var, float momentum, float eps,
+                                                    int use_batch, int d, float* __restrict__ A1,
+                                                    float* __restrict__ b1, double* __restrict__ aux1) {
+    fold1_body(W1, gamma, beta, mom, n_edges, run_mean, run_var, momentum, eps, use_batch, d, A1, b1, aux1);
+}
+
+// fold1 of ALL PointConv layers of a network in one launch (a workgroup per layer): its inputs -- the weight MLP's first
+// layer and the rel-pos moments of the layer's table -- are known before the forward pass starts.
+constexpr int F1F_MAX = 24;
+struct Fold1Table {
+    crf_fold1_job job[F1F_MAX];
+};
+__global__ __launch_bounds__(128) void fold1_batched_kernel(const Fold1Table t) {
+    const crf_fold1_job& j = t.job[blockIdx.x];
+    fold1_body(j.W1, j.gamma1, j.beta1, j.mom, j.n_edges, j.run_mean, j.run_var, j.momentum, j.eps, j.use_batch, j.d, j.A1, j.b1,
+               j.aux1);
 }
 
 // dA1b1 [d, 4] float64 = {dA1[c][0..2], db1[c]}  ->  dW1 [d,3], dgamma1, dbeta1
@@ -1441,6 +1462,25 @@ extern "C" int crfconv_pointconv_fold1(const float* W1, const float* gamma1, con
     hipLaunchKernelGGL(fold1_kernel, dim3(1), dim3(128), 0, as_stream(stream), W1, gamma1, beta1, mom, n_edges, run_mean,
                        run_var, momentum, eps, use_batch, d, A1, b1, aux1);
     CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_pointconv_fold1_batched(const crf_fold1_job* jobs, int njobs, crf_stream_t stream) {
+    CRF_REQUIRE(jobs || njobs == 0, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(njobs >= 0, CRF_ERR_ARG, "njobs=%d < 0", njobs);
+    for (int j = 0; j < njobs; ++j) {
+        const crf_fold1_job& b = jobs[j];
+        CRF_REQUIRE(b.W1 && b.gamma1 && b.beta1 && b.mom && b.A1 && b.b1 && b.aux1, CRF_ERR_ARG, "job %d: null pointer", j);
+        CRF_REQUIRE(b.d >= 1 && b.d <= 128, CRF_ERR_UNSUPPORTED, "job %d: d=%d outside [1, 128]", j, b.d);
+        CRF_REQUIRE(b.use_batch || (b.run_mean && b.run_var), CRF_ERR_ARG, "job %d: eval mode needs running statistics", j);
+    }
+    for (int j0 = 0; j0 < njobs; j0 += F1F_MAX) {
+        Fold1Table t;
+        const int n = njobs - j0 < F1F_MAX ? njobs - j0 : F1F_MAX;
+        for (int j = 0; j < F1F_MAX; ++j) t.job[j] = jobs[j0 + (j < n ? j : 0)];
+        hipLaunchKernelGGL(fold1_batched_kernel, dim3((unsigned)n), dim3(128), 0, as_stream(stream), t);
+        CRF_LAUNCH_CHECK();
+    }
     return CRF_OK;
 }
 

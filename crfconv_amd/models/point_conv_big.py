@@ -49,15 +49,24 @@ class PointConv(nn.Module):
             entry.refresh_(table)
         return entry
 
-    def forward(self, x, pos, neighbor_idx):
+    def _geometry(self, pos, neighbor_idx):
         strided = not torch.is_tensor(pos)
         src = pos[0] if strided else pos
         p_src = _flat(src)
         p_tgt = _flat(pos[1]) if strided else p_src
-        table = table_of(neighbor_idx, src.shape[1])
+        return table_of(neighbor_idx, src.shape[1]), p_src, p_tgt
+
+    def prefold_entry(self, pos, neighbor_idx):
+        """This layer's (W1, bn1, moments, table) for ops.point_conv_prefold."""
+        table, p_src, p_tgt = self._geometry(pos, neighbor_idx)
+        first = self.weight_nn[0]
+        return first.lin.weight, first.bn.batch_norm, self._moments(table, p_src, p_tgt), table
+
+    def forward(self, x, pos, neighbor_idx, prefold=None):
+        table, p_src, p_tgt = self._geometry(pos, neighbor_idx)
         first, second = self.weight_nn[0], self.weight_nn[1]
         y = ops.point_conv(_flat(x), p_src, p_tgt, table, first.lin.weight, first.bn.batch_norm, second.lin.weight,
-                           second.bn.batch_norm, self.training, moments=self._moments(table, p_src, p_tgt))
+                           second.bn.batch_norm, self.training, moments=self._moments(table, p_src, p_tgt), prefold=prefold)
         return y.reshape(x.shape[0], -1, x.shape[-1])
 
 
@@ -77,7 +86,7 @@ class ResNetBBlock(nn.Module):
         pooled = ops.neighbor_maxpool(_flat(x), table_of(idx, x.shape[1]))
         return pooled.reshape(x.shape[0], -1, x.shape[-1])
 
-    def forward(self, x, pos, neighbor_idx, return_input_alias=False):
+    def forward(self, x, pos, neighbor_idx, return_input_alias=False, prefold=None):
         """return_input_alias=True: also returns the block's input as the LAST alias of its fork chain (x -> lin_in -> strided
         shortcut): a further consumer of x -- the decoder stage that takes it as skip feature -- reads the alias, and its
         gradient is added inside this block's backward kernels instead of by an accumulation pass of autograd's."""
@@ -99,7 +108,7 @@ class ResNetBBlock(nn.Module):
             skip = sc(x)
             if strided:                                    # strided block: pool the shortcut onto the coarse points
                 skip = self.max_pooling(skip, neighbor_idx)
-        y = self.point_conv(h_in, pos, neighbor_idx)
+        y = self.point_conv(h_in, pos, neighbor_idx, prefold=prefold)
         out = mlp_join(self.lin_out, y, skip, 0.01)        # lin_out + add + F.leaky_relu (default slope), as the reference
         return (out, x) if return_input_alias else out
 
@@ -148,14 +157,23 @@ class PointConvResNet(Base):
 
     def _forward(self, data):
         ms = data.multiscale
-        h = getattr(self, 'conv1_1')(data.x, ms[0].pos, ms[0].neighbor_idx)
-        h = getattr(self, 'conv1_2')(h, ms[0].pos, ms[0].neighbor_idx)
-        skips = [h]
+        # geometry of the ten encoder blocks: (block, positions, table indices)
+        plan = [(self.conv1_1, ms[0].pos, ms[0].neighbor_idx), (self.conv1_2, ms[0].pos, ms[0].neighbor_idx)]
         for lvl in range(1, len(WIDTHS)):
             fine, coarse = ms[lvl - 1], ms[lvl]
+            plan.append((getattr(self, 'conv%d_1' % (lvl + 1)), (fine.pos, coarse.pos), fine.sub_idx))
+            plan.append((getattr(self, 'conv%d_2' % (lvl + 1)), coarse.pos, coarse.neighbor_idx))
+        pre = [None] * len(plan)
+        if self.training and data.x.is_cuda and not ops._NO_PREFOLD_ENV:      # BatchNorm-1 of all ten weight MLPs folded in ONE launch, up front
+            pre = ops.point_conv_prefold([blk.point_conv.prefold_entry(p, i) for blk, p, i in plan], True)
+        h = plan[0][0](data.x, plan[0][1], plan[0][2], prefold=pre[0])
+        h = plan[1][0](h, plan[1][1], plan[1][2], prefold=pre[1])
+        skips = [h]
+        for lvl in range(1, len(WIDTHS)):
+            (b1, p1, i1), (b2, p2, i2) = plan[2 * lvl], plan[2 * lvl + 1]
             # the level's output has three consumers (this block's lin_in and shortcut, the decoder): one fork chain, no add pass
-            h, skips[-1] = getattr(self, 'conv%d_1' % (lvl + 1))(h, (fine.pos, coarse.pos), fine.sub_idx, return_input_alias=True)
-            h = getattr(self, 'conv%d_2' % (lvl + 1))(h, coarse.pos, coarse.neighbor_idx)
+            h, skips[-1] = b1(h, p1, i1, return_input_alias=True, prefold=pre[2 * lvl])
+            h = b2(h, p2, i2, prefold=pre[2 * lvl + 1])
             skips.append(h)
         decoders = [getattr(self, 'deconv%d' % (lvl + 1)) for lvl in range(len(WIDTHS) - 2, -1, -1)]
         mats = [None] * len(decoders)

@@ -1605,7 +1605,7 @@ class _PointConv(torch.autograd.Function):
     source-major gather for dx.  Nothing per-edge is ever stored (except for d >= 64, see bwd_dump)."""
 
     @staticmethod
-    def forward(ctx, x, W1, g1, be1, W2, g2, be2, pos_src, pos_tgt, table, mom, bn1_state, bn2_state, slope, mom32=None):
+    def forward(ctx, x, W1, g1, be1, W2, g2, be2, pos_src, pos_tgt, table, mom, bn1_state, bn2_state, slope, mom32=None, prefold=None):
         require_gpu(x, W1, W2, pos_src, pos_tgt)
         if x.shape[0] != table.m_src or pos_src.shape[0] != table.m_src or pos_tgt.shape[0] != table.m_tgt:
             raise _lib.CrfConvError('point_conv: x %d / pos_src %d rows for %d sources, pos_tgt %d rows for %d targets'
@@ -1622,11 +1622,14 @@ class _PointConv(torch.autograd.Function):
         n_e = float(table.n_edges)
         use1, rm1, rv1, mom1, eps1 = bn1_state
         use2, rm2, rv2, mom2, eps2 = bn2_state
-        A1 = torch.empty((d, 3), dtype=torch.float32, device=dev)
-        b1 = torch.empty(d, dtype=torch.float32, device=dev)
-        aux1 = torch.empty(3 * d, dtype=torch.float64, device=dev)
-        _lib.call('crfconv_pointconv_fold1', ptr(W1c), ptr(g1c), ptr(be1c), ptr(mom), n_e, ptr(rm1), ptr(rv1),
-                  float(mom1), float(eps1), 1 if use1 else 0, d, ptr(A1), ptr(b1), ptr(aux1), st)
+        if prefold is not None:                            # BatchNorm-1 folded for all layers of the network in one launch
+            A1, b1, aux1 = prefold                         # (point_conv_prefold), incl. the running-statistics update
+        else:
+            A1 = torch.empty((d, 3), dtype=torch.float32, device=dev)
+            b1 = torch.empty(d, dtype=torch.float32, device=dev)
+            aux1 = torch.empty(3 * d, dtype=torch.float64, device=dev)
+            _lib.call('crfconv_pointconv_fold1', ptr(W1c), ptr(g1c), ptr(be1c), ptr(mom), n_e, ptr(rm1), ptr(rv1),
+                      float(mom1), float(eps1), 1 if use1 else 0, d, ptr(A1), ptr(b1), ptr(aux1), st)
         shift = (torch.empty if use2 else torch.zeros)(d, dtype=torch.float32, device=dev)
         stats = U = V = None
         if use2:
@@ -1739,7 +1742,7 @@ class _PointConv(torch.autograd.Function):
         dx = torch.empty((table.m_src, d), dtype=torch.float32, device=dev)
         _lib.call('crfconv_pointconv_bwd_input', ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(rev_ptr), ptr(rev_eid), K,
                   table.m_src, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(a2), ptr(b2), ptr(dx), st)
-        return (dx, dW1, dg1, dbe1, dW2, coef[3], coef[4], None, None, None, None, None, None, None, None)
+        return (dx, dW1, dg1, dbe1, dW2, coef[3], coef[4], None, None, None, None, None, None, None, None, None)
 
 
 _PC_D = (4, 8, 16, 32, 64, 128)
@@ -1752,11 +1755,58 @@ def pack_moments(moments):
     return torch.cat([mean.reshape(3), cov.reshape(9)]).contiguous()
 
 
-def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=0.1, moments=None, slope=0.1):
+_NO_PREFOLD_ENV = __import__('os').environ.get('CRFCONV_NO_PREFOLD') is not None      # A/B: one fold launch inside every PointConv layer
+
+
+def _bn_state(bn, training, momentum, advance=True):
+    """(use batch statistics, running mean / var to read or update -- or None --, momentum, eps) of one BatchNorm1d."""
+    use_batch = training or bn.running_mean is None
+    if training and advance:
+        tick(bn)
+    upd = training and bn.running_mean is not None
+    keep = upd or not use_batch
+    return (use_batch, bn.running_mean if keep else None, bn.running_var if keep else None,
+            momentum if bn.momentum is None else bn.momentum, bn.eps)
+
+
+def point_conv_prefold(layers, training, momentum=0.1):
+    """BatchNorm-1 folding (crfconv_pointconv_fold1) of SEVERAL PointConv layers in one launch.  Everything it reads -- the
+    first weight-MLP layer and the rel-pos moments of the layer's table -- exists before the forward pass starts, so a
+    network folds all its layers up front (models/point_conv_big.py:113-131 has ten) instead of one tiny launch inside every
+    layer.  layers: (W1 [d, 3], bn1, moments, table) per layer; returns one ``prefold`` for each, to be passed to point_conv
+    (which then skips its own fold; it still advances the BatchNorm's step counter).  Running statistics are updated here."""
+    if not layers:
+        return []
+    dev = layers[0][0].device
+    ds = [int(W1.shape[0]) for W1, _, _, _ in layers]
+    tot = sum(ds)
+    A1 = torch.empty((tot, 3), dtype=torch.float32, device=dev)
+    b1 = torch.empty(tot, dtype=torch.float32, device=dev)
+    aux1 = torch.empty(3 * tot, dtype=torch.float64, device=dev)
+    jobs, keep, out, o = [], [], [], 0
+    adr = lambda t: None if t is None else t.data_ptr()
+    for (W1, bn1, moments, table), d in zip(layers, ds):
+        require_gpu(W1)
+        mom = moments[3] if len(moments) > 3 else pack_moments(moments)
+        use1, rm1, rv1, mom1, eps1 = _bn_state(bn1, training, momentum, advance=False)
+        W1c, g1c, be1c = _f32c(W1), _f32c(bn1.weight), _f32c(bn1.bias)
+        pre = (A1[o:o + d], b1[o:o + d], aux1[3 * o:3 * o + 3 * d])
+        jobs.append(_lib.Fold1Job(adr(W1c), adr(g1c), adr(be1c), adr(mom), float(table.n_edges), adr(rm1), adr(rv1), float(mom1),
+                                  float(eps1), 1 if use1 else 0, d, adr(pre[0]), adr(pre[1]), adr(pre[2])))
+        keep.append((W1c, g1c, be1c, mom))
+        out.append(pre)
+        o += d
+    table_ = (_lib.Fold1Job * len(jobs))(*jobs)
+    _lib.call('crfconv_pointconv_fold1_batched', ctypes.cast(table_, ctypes.c_void_p), len(jobs), stream_ptr())
+    return out
+
+
+def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=0.1, moments=None, slope=0.1, prefold=None):
     """Functional PointConv over flattened clouds.
 
     x [m_src, d]; pos_* [m, 3]; W1 [d, 3], W2 [d, d] Linear weights (no bias);
-    bn1 / bn2: torch.nn.BatchNorm1d modules (affine + running statistics, updated in training)."""
+    bn1 / bn2: torch.nn.BatchNorm1d modules (affine + running statistics, updated in training);
+    prefold: this layer's entry of point_conv_prefold (same W1, bn1, moments, table and mode), or None."""
     d = x.shape[1]
     if d not in _PC_D:
         raise _lib.CrfConvError('PointConv width d=%d not in %s' % (d, _PC_D))
@@ -1766,18 +1816,9 @@ def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=
         moments = relpos_moments(pos_src, pos_tgt, table)
     mom = moments[3] if len(moments) > 3 else pack_moments(moments)
     mom32 = moments[4] if len(moments) > 4 else None
-
-    def state(bn):
-        use_batch = training or bn.running_mean is None
-        if training:
-            tick(bn)
-        upd = training and bn.running_mean is not None
-        keep = upd or not use_batch
-        return (use_batch, bn.running_mean if keep else None, bn.running_var if keep else None,
-                momentum if bn.momentum is None else bn.momentum, bn.eps)
     return _PointConv.apply(x, W1, bn1.weight, bn1.bias, W2, bn2.weight, bn2.bias, pos_src, pos_tgt, table, mom,
-                            state(bn1), state(bn2), float(slope), mom32)
+                            _bn_state(bn1, training, momentum), _bn_state(bn2, training, momentum), float(slope), mom32, prefold)
 
 
-__all__ = ['linear', 'bn_act', 'crf_meanfield', 'gather_rows', 'neighbor_maxpool', 'relpos_moments', 'point_conv', 'cross_entropy', 'training_loss',
+__all__ = ['linear', 'bn_act', 'crf_meanfield', 'gather_rows', 'neighbor_maxpool', 'relpos_moments', 'point_conv', 'point_conv_prefold', 'cross_entropy', 'training_loss',
            'NeighborTable']

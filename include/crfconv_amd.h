@@ -323,6 +323,14 @@ int crfconv_pointconv_fold1(const float* W1, const float* gamma1, const float* b
 int crfconv_pointconv_fold1_bwd(const float* W1, const float* gamma1, const double* mom, const double* aux1,
                                 const double* dA1b1, float eps, int use_batch, int d, float* dW1,
                                 float* dgamma1, float* dbeta1, const double* dW2_f64, float* dW2_f32, crf_stream_t stream);
+/* fold1 of ALL PointConv layers of a network in one launch (a workgroup per job; fields as the arguments of
+ * crfconv_pointconv_fold1): every input is known before the forward pass starts (models/point_conv_big.py:113-131 has ten). */
+typedef struct {
+    const float* W1; const float* gamma1; const float* beta1; const double* mom; double n_edges;
+    float* run_mean; float* run_var; float momentum; float eps; int32_t use_batch; int32_t d;
+    float* A1; float* b1; double* aux1;
+} crf_fold1_job;
+int crfconv_pointconv_fold1_batched(const crf_fold1_job* jobs, int njobs, crf_stream_t stream);
 /* fold1_bwd of ALL PointConv layers of a backward pass in one launch (a workgroup per job; fields as the arguments of
  * crfconv_pointconv_fold1_bwd).  Nothing inside the pass reads dW1 / dgamma1 / dbeta1, so ops.deferred_weight_grads queues
  * the jobs and runs them once at the end. */

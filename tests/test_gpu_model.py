@@ -924,6 +924,44 @@ def test_classifier_dropout_backward_folded_into_last_linear():
     assert ops.mlp_dropout_linear(x[:100], W, bn, slope, 0.5, W2, b2) is None      # below the MFMA row count: caller's path
 
 
+def test_pointconv_prefold_one_launch_equals_per_layer_folds():
+    """ops.point_conv_prefold: BatchNorm-1 of all ten weight MLPs folded in ONE launch before the forward pass (the network does
+    it in training mode) against the per-layer fold inside every PointConv: logits, every gradient and every BatchNorm buffer
+    (running statistics, step counters) bit-identical."""
+    import copy
+    import crfconv_amd
+    from crfconv_amd import models, ops
+    B, N = 2, 4096
+    pos = np.stack([S.make_cloud(120 + b, N, box=(2, 2, 1)) for b in range(B)])
+    feats = np.concatenate([pos, S.uniform(120, 'rgb', (B, N, 3), 0, 1)], -1)
+    data = crfconv_amd.multiscale_compute(t(pos), t(feats), generator=torch.Generator().manual_seed(6))
+    labels = t(S.integers(120, 'y', (B, N), 0, 14))
+    torch.manual_seed(4)
+    net0 = models.PointConvBig(6, 13, use_crf=True, steps=2).to(DEV).train()
+    res = []
+    for pre in (True, False):
+        net = copy.deepcopy(net0)
+        ops._NO_PREFOLD_ENV = not pre
+        try:
+            torch.manual_seed(9)                                     # same dropout stream
+            logits = net(data)
+            ops.training_loss(logits, labels, None, ignore_index=-1).backward()
+        finally:
+            ops._NO_PREFOLD_ENV = False
+        res.append((logits.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()},
+                    {k: b.clone() for k, b in net.named_buffers()}))
+    (l1, g1, b1), (l2, g2, b2) = res
+    assert torch.equal(l1, l2)
+    for k in g1:
+        if 'point_conv' in k and 'weight_nn.1.lin' in k:
+            assert_close(g1[k], g2[k], 1e-6, k)                      # dW2 of a narrow PointConv: LDS float atomics
+        else:
+            assert torch.equal(g1[k], g2[k]), k
+    for k in b1:
+        assert torch.equal(b1[k], b2[k]), k
+    assert any('point_conv.weight_nn.0.bn.batch_norm.running_var' in k and not torch.equal(b1[k], torch.ones_like(b1[k])) for k in b1)
+
+
 def test_resnet_join_fused_equals_two_passes():
     """models.common.mlp_join: lin_out's BatchNorm + the residual add + LeakyReLU as ONE pass (crfconv_bn_apply_add, one
     autograd node) against bn_apply followed by add_lrelu: the same arithmetic operation for operation, so outputs and every
