@@ -50,6 +50,7 @@ SIGNATURES = {
     'crfconv_similarity_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp]),
     'crfconv_similarity_bwd_scatter': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp]),
     'crfconv_pointconv_workspace': (_sz, [_i64, _i, _i]),
+    'crfconv_pointconv_moments_packed': (_i, [_vp, _vp, _vp, _i, _i64, ctypes.c_double, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_moments': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_stats': (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_forward_uv': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

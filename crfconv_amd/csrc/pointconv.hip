@@ -1020,6 +1020,60 @@ extern "C" int crfconv_pointconv_moments(const float* pos_src, const float* pos_
     return reduce_partials(partial, nblk, 9, out9, st);
 }
 
+// The nine block-partial sums of moments_kernel -> mean [3], covariance [3, 3], packed {mean, cov} [12] (float64) and the mean in
+// float32, in ONE single-workgroup launch: slot sums exactly as reduce_partials_kernel forms them (one wavefront per slot, lane l
+// takes blocks l, l + 64, ..., shuffle tree), then mean = S1 / n, cov = S2 / n - mean mean^T with every operation rounded on its
+// own (what the chain of framework ops this replaces computed: ~15 launches and, on a refresh, four copies per table).
+__global__ __launch_bounds__(1024) void moments_finish_kernel(const float* __restrict__ partial, int64_t nblk, double n_edges,
+                                                              double* __restrict__ mean, double* __restrict__ cov,
+                                                              double* __restrict__ packed, float* __restrict__ mean32) {
+    __shared__ double s_sum[9];
+    const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (slot < 9) {
+        double a = 0.0;
+        for (int64_t b = lane; b < nblk; b += WAVE) a += (double)partial[b * 9 + slot];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
+        if (lane == 0) s_sum[slot] = a;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= 12) return;
+    double v;
+    if (t < 3) {
+        v = s_sum[t] / n_edges;
+    } else {
+        const int a = (t - 3) / 3, b = (t - 3) % 3;
+        // second moments arrive as the upper triangle xx xy xz yy yz zz (index arithmetic, not a table: no private segment,
+        // which a replayed hipGraph does not survive on ROCm 7.2 -- DESIGN.md 5b)
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        const int tri = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);
+        const double sec = s_sum[3 + tri] / n_edges;
+        v = dadd_rn(sec, -dmul_rn(s_sum[a] / n_edges, s_sum[b] / n_edges));
+    }
+    packed[t] = v;
+    if (t < 3) { mean[t] = v; mean32[t] = (float)v; }
+    else cov[t - 3] = v;
+}
+
+extern "C" int crfconv_pointconv_moments_packed(const float* pos_src, const float* pos_tgt, const int32_t* idx32, int K,
+                                                int64_t m_tgt, double n_edges, double* mean, double* cov, double* packed,
+                                                float* mean32, void* workspace, size_t workspace_bytes,
+                                                crf_stream_t stream) {
+    if (int rc = check_pc(m_tgt, K, 4)) return rc;
+    CRF_REQUIRE(pos_src && pos_tgt && idx32 && mean && cov && packed && mean32 && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(n_edges > 0.0, CRF_ERR_ARG, "n_edges must be positive");
+    const int64_t nblk = cdiv(m_tgt, 256);
+    CRF_REQUIRE(workspace_bytes >= sizeof(float) * 9 * (size_t)nblk, CRF_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* partial = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(moments_kernel, dim3((unsigned)nblk), dim3(256), 0, st, pos_src, pos_tgt, idx32, K, m_tgt, partial);
+    CRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(moments_finish_kernel, dim3(1), dim3(1024), 0, st, partial, nblk, n_edges, mean, cov, packed, mean32);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
 extern "C" int crfconv_pointconv_stats(const float* pos_src, const float* pos_tgt, const int32_t* idx32,
                                        int K, int64_t m_tgt, int d, const float* A1, const float* b1,
                                        const float* W2, float slope, const float* mean_rel3, float* shift,

@@ -1566,34 +1566,32 @@ class MomentsEntry(tuple):
         return obj
 
     def refresh_(self, table):
-        fresh = relpos_moments(self.pos_src, self.pos_tgt, table)
-        for old, new in zip(self, fresh):
-            if torch.is_tensor(old):
-                old.copy_(new)
+        relpos_moments(self.pos_src, self.pos_tgt, table, out=self)       # in place: no temporaries, no copies
         self.versions = (self.pos_src._version, self.pos_tgt._version)
 
     def stale(self):
         return self.versions != (self.pos_src._version, self.pos_tgt._version)
 
 
-def relpos_moments(pos_src, pos_tgt, table):
+def relpos_moments(pos_src, pos_tgt, table, out=None):
     """(mean [3], covariance [3,3], edge count, packed float64 [12], mean float32 [3]) of rel = p_tgt[i] - p_src[j]
-    over all edges."""
+    over all edges: one pass over the edges, one finishing launch (crfconv_pointconv_moments_packed).  ``out``: an earlier
+    result whose tensors are overwritten in place (refresh of a static batch)."""
     require_gpu(pos_src, pos_tgt)
     dev = pos_src.device
-    out9 = torch.empty(9, dtype=torch.float64, device=dev)
+    n = float(table.n_edges)
+    if out is not None:
+        mean, cov, packed, mean32 = out[0], out[1], out[3], out[4]
+    else:
+        mean = torch.empty(3, dtype=torch.float64, device=dev)
+        cov = torch.empty((3, 3), dtype=torch.float64, device=dev)
+        packed = torch.empty(12, dtype=torch.float64, device=dev)
+        mean32 = torch.empty(3, dtype=torch.float32, device=dev)
     nbytes = _lib.load().crfconv_pointconv_workspace(table.m_tgt, table.K, 4)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    _lib.call('crfconv_pointconv_moments', ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), table.K, table.m_tgt,
-              ptr(out9), ptr(ws), nbytes, stream_ptr())
-    n = float(table.n_edges)
-    mean = out9[:3] / n
-    sec = out9[3:] / n
-    S = torch.stack([torch.stack([sec[0], sec[1], sec[2]]), torch.stack([sec[1], sec[3], sec[4]]),
-                     torch.stack([sec[2], sec[4], sec[5]])])
-    cov = S - torch.outer(mean, mean)
-    packed = torch.cat([mean.reshape(3), cov.reshape(9)]).contiguous()
-    return mean, cov, n, packed, packed[:3].float().contiguous()     # [4]: mean rel in float32 (kernel argument)
+    _lib.call('crfconv_pointconv_moments_packed', ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), table.K, table.m_tgt, n,
+              ptr(mean), ptr(cov), ptr(packed), ptr(mean32), ptr(ws), nbytes, stream_ptr())
+    return mean, cov, n, packed, mean32                   # [4]: mean rel in float32 (kernel argument)
 
 
 class _PointConv(torch.autograd.Function):

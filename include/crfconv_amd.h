@@ -240,6 +240,12 @@ size_t crfconv_pointconv_workspace(int64_t m_tgt, int K, int d);
 int crfconv_pointconv_moments(const float* pos_src, const float* pos_tgt, const int32_t* idx32,
                               int K, int64_t m_tgt, double* out9, void* workspace,
                               size_t workspace_bytes, crf_stream_t stream);
+/* The same sums finished on the device: mean [3] and covariance [3, 3] of rel over the n_edges edges, packed = {mean, cov} [12]
+ * (the `mom` argument of fold1 / fold1_bwd) in float64 and the mean in float32, written into the CALLER's tensors -- a refresh
+ * of a static batch recomputes them in place (two launches instead of ~17 and four copies). */
+int crfconv_pointconv_moments_packed(const float* pos_src, const float* pos_tgt, const int32_t* idx32, int K, int64_t m_tgt,
+                                     double n_edges, double* mean, double* cov, double* packed, float* mean32,
+                                     void* workspace, size_t workspace_bytes, crf_stream_t stream);
 /* Batch statistics of h2 over all edges: stats [2, d] float64 = {sum(h2 - shift), sum (h2 - shift)^2},
  * shift [d] float32 out (= h2 at the mean rel; variance is shift-invariant). */
 int crfconv_pointconv_stats(const float* pos_src, const float* pos_tgt, const int32_t* idx32, int K,
