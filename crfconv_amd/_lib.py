@@ -89,6 +89,7 @@ SIGNATURES = {
     'crfconv_bn_backward': (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_bn_apply': (_i, [_vp, _i64, _i, _vp, _f, _vp, _vp]),
     'crfconv_linear_wgrad_partial': (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    'crfconv_copy_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_reduce_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_linear_forward_supported': (_i, [_i, _i]),
     'crfconv_linear_forward_stat_records': (_sz, [_i64]),
@@ -133,6 +134,11 @@ SIGNATURES = {
 class ReduceJob(ctypes.Structure):
     """crf_reduce_job of include/crfconv_amd.h."""
     _fields_ = [('partial', ctypes.c_void_p), ('out', ctypes.c_void_p), ('nblk', ctypes.c_int32), ('nslots', ctypes.c_int32)]
+
+
+class CopyJob(ctypes.Structure):
+    """crf_copy_job of include/crfconv_amd.h."""
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('nbytes', ctypes.c_int64)]
 
 
 class MlpDwJob(ctypes.Structure):

@@ -120,9 +120,72 @@ __global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* __restrict__ p, 
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0;
 }
 
+// Any number of device-to-device copies in ONE launch (MultiScaleData.load_: the ~25 tensors of a freshly collated batch into
+// the static buffers a captured training step reads).  A workgroup moves one 64 KB chunk; chunk_begin = prefix sum of the jobs'
+// chunk counts.  16-byte accesses when both pointers are 16-byte aligned, bytes otherwise and for the tail.
+constexpr int CJ_MAX = 96, CJ_CHUNK = 65536;
+struct CopyJobTable {
+    const char* src[CJ_MAX];
+    char* dst[CJ_MAX];
+    long long nbytes[CJ_MAX];
+    int chunk_begin[CJ_MAX + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void copy_jobs_kernel(const CopyJobTable t) {
+    const int g = blockIdx.x;
+    int lo = 0, hi = t.njobs;                          // largest j with chunk_begin[j] <= g
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t.chunk_begin[mid] <= g) lo = mid; else hi = mid;
+    }
+    const long long off = (long long)(g - t.chunk_begin[lo]) * CJ_CHUNK;
+    long long n = t.nbytes[lo] - off;
+    if (n > CJ_CHUNK) n = CJ_CHUNK;
+    const char* s = t.src[lo] + off;
+    char* d = t.dst[lo] + off;
+    long long done = 0;
+    if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+        const long long n16 = n >> 4;
+        for (long long i = threadIdx.x; i < n16; i += 256) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+        done = n16 << 4;
+    }
+    for (long long i = done + threadIdx.x; i < n; i += 256) d[i] = s[i];
+}
+
 }  // namespace crf
 
 using namespace crf;
+
+extern "C" int crfconv_copy_jobs(const crf_copy_job* jobs, int njobs, crf_stream_t stream) {
+    CRF_REQUIRE(jobs || njobs == 0, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(njobs >= 0, CRF_ERR_ARG, "njobs=%d < 0", njobs);
+    hipStream_t st = as_stream(stream);
+    for (int j0 = 0; j0 < njobs; j0 += CJ_MAX) {
+        CopyJobTable t;
+        const int n = njobs - j0 < CJ_MAX ? njobs - j0 : CJ_MAX;
+        long long total = 0;
+        for (int j = 0; j < CJ_MAX; ++j) {
+            t.chunk_begin[j] = (int)total;
+            if (j < n) {
+                const crf_copy_job& jb = jobs[j0 + j];
+                CRF_REQUIRE(jb.nbytes >= 0 && (jb.nbytes == 0 || (jb.src && jb.dst)), CRF_ERR_ARG, "job %d is malformed", j0 + j);
+                t.src[j] = reinterpret_cast<const char*>(jb.src);
+                t.dst[j] = reinterpret_cast<char*>(jb.dst);
+                t.nbytes[j] = jb.nbytes;
+                total += (jb.nbytes + CJ_CHUNK - 1) / CJ_CHUNK;
+                CRF_REQUIRE(total < ((long long)1 << 30), CRF_ERR_ARG, "too many bytes in one batch");
+            } else {
+                t.src[j] = nullptr; t.dst[j] = nullptr; t.nbytes[j] = 0;
+            }
+        }
+        t.chunk_begin[CJ_MAX] = (int)total;
+        t.njobs = n;
+        if (total == 0) continue;
+        hipLaunchKernelGGL(copy_jobs_kernel, dim3((unsigned)total), dim3(256), 0, st, t);
+        CRF_LAUNCH_CHECK();
+    }
+    return CRF_OK;
+}
 
 extern "C" int crfconv_index_narrow(const int64_t* idx64, int64_t B, int64_t n_tgt, int K,
                                     int64_t n_src, int32_t* idx32, uint16_t* idx16, int32_t* bad_count,

@@ -62,6 +62,8 @@ class MultiScaleData(Data):
         next replay.  (All table sizes are fixed for fixed B, N, K and ratios.)"""
         from .graph import table_of
 
+        pairs, tables = [], []
+
         def copy(dst, src, what):
             if dst is None or src is None:
                 if dst is not src:
@@ -70,7 +72,10 @@ class MultiScaleData(Data):
             if dst.shape != src.shape or dst.dtype != src.dtype:
                 raise ValueError('load_: %s is %s %s here, %s %s there' % (what, tuple(dst.shape), dst.dtype,
                                                                            tuple(src.shape), src.dtype))
-            dst.copy_(src)
+            if dst.is_cuda and src.is_cuda and dst.is_contiguous() and src.is_contiguous():
+                pairs.append((dst, src))                   # all of them in ONE launch below
+            else:
+                dst.copy_(src)
         for name in ('x', 'y', 'point_idx', 'cloud_idx', 'order'):
             a, b = getattr(self, name, None), getattr(other, name, None)
             if torch.is_tensor(a) or torch.is_tensor(b):
@@ -88,8 +93,18 @@ class MultiScaleData(Data):
                     continue
                 copy(a, b, 'multiscale[%d].%s' % (i, name))
                 if getattr(a, '_crf_tables', None):          # a table was derived from it: same buffers, new content
-                    for key in list(a._crf_tables):
-                        table_of(a, key[0])
+                    tables.extend((a, key[0]) for key in list(a._crf_tables))
+        if pairs:
+            import ctypes
+            from . import _lib
+            from .graph import stream_ptr
+            jobs = (_lib.CopyJob * len(pairs))(*[_lib.CopyJob(src.data_ptr(), dst.data_ptr(), dst.numel() * dst.element_size())
+                                                 for dst, src in pairs])
+            _lib.call('crfconv_copy_jobs', ctypes.cast(jobs, ctypes.c_void_p), len(pairs), stream_ptr())
+            for dst, _ in pairs:                           # written by a custom kernel: the version counters (table / moments
+                torch.autograd.graph.increment_version(dst)    # memos compare them) must say so
+        for a, n_src in tables:                            # after the copies: the refreshes read the new content
+            table_of(a, n_src)
         return self
 
 

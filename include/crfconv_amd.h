@@ -108,6 +108,11 @@ int crfconv_index_narrow_sorted(const int64_t* idx64, int64_t B, int64_t n_tgt, 
                                 int sort_from, int32_t* idx32, uint16_t* idx16, int32_t* bad_count,
                                 crf_stream_t stream);
 
+/* Any number of device-to-device copies (dst[j] <- src[j], nbytes[j] bytes, non-overlapping) in ONE launch: the ~25 tensors of a
+ * freshly collated batch into the static buffers of a captured training step (crfconv_amd.data.MultiScaleData.load_). */
+typedef struct { const void* src; void* dst; int64_t nbytes; } crf_copy_job;
+int crfconv_copy_jobs(const crf_copy_job* jobs, int njobs, crf_stream_t stream);
+
 /* Reverse (source-major) CSR of a table idx32 [E] with values in [0, m_src):
  * rev_ptr [m_src + 1], rev_eid [E] = edge ids e (= row * K + k) grouped by source row, ascending
  * e inside a group (deterministic summation order for every backward scatter). */
