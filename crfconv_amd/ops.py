@@ -543,6 +543,21 @@ def _mlp_dw_ret(deferred, prm, dW, direct, ws, m, ci, co, coef):
     return None
 
 
+def _mlp_param_outs(prm, W, dev):
+    """Targets of (dW, dgamma, dbeta) of one fused MLP block -- [(tensor, direct)] * 3, see _param_out -- and whether the dW slab
+    reduction is left to the batched launch at the end of the backward pass (then the C call gets dW = NULL)."""
+    co = W.shape[0]
+    outs = [_param_out(prm[0], tuple(W.shape), dev), _param_out(prm[1], (co,), dev), _param_out(prm[2], (co,), dev)]
+    return outs, _defer_ok((prm[0], None))
+
+
+def _mlp_param_rets(prm, outs, deferred, ws, m, ci, co, coef):
+    """What the block's backward returns for (W, gamma, beta)."""
+    (dW, kW), (dgamma, kg), (dbeta, kb) = outs
+    return (_mlp_dw_ret(deferred, prm[0], dW, kW, ws, m, ci, co, coef), _param_ret(prm[1], dgamma, kg),
+            _param_ret(prm[2], dbeta, kb))
+
+
 def _flush_mlp_dw():
     jobs, _DEFER['mlpdw'] = _DEFER['mlpdw'], []
     if not jobs:
@@ -853,13 +868,13 @@ class _MLPBlock(torch.autograd.Function):
         gA = torch.zeros_like(y) if gA is None else gA.contiguous()
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         add = _f32c(g_alias) if (g_alias is not None and dX is not None) else None
-        (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
-        dfr = _defer_ok((ctx.prm[0], None))                  # dW: finished with all other blocks' at the end of the pass
+        outs, dfr = _mlp_param_outs(ctx.prm, W, dev)       # (dW, dgamma, dbeta) targets; dfr: dW finished at the end of the pass
+        dW, dgamma, dbeta = (o[0] for o in outs)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward_add', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(add), ptr(dX),
                   ptr(None if dfr else dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
-        return dX, _mlp_dw_ret(dfr, ctx.prm[0], dW, kW, ws, m, ci, co, coef), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None
+        return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, None, None
 
 
 _NO_JOIN_ENV = __import__('os').environ.get('CRFCONV_NO_JOIN_FUSION') is not None      # A/B: bn_apply + add_lrelu as two passes
@@ -899,13 +914,14 @@ class _MLPBlockJoin(torch.autograd.Function):
         st = stream_ptr()
         _lib.call('crfconv_add_lrelu_backward', ptr(g), ptr(out), out.numel(), ctx.slope, ptr(g1), st)
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
-        dfr = _defer_ok((ctx.prm[0], None))                  # dW: finished with all other blocks' at the end of the pass
+        outs, dfr = _mlp_param_outs(ctx.prm, W, dev)       # (dW, dgamma, dbeta) targets; dfr: dW finished at the end of the pass
+        dW, dgamma, dbeta = (o[0] for o in outs)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward', ptr(g1), ptr(y), ptr(x), ptr(W), ptr(coef), 1.0, m, ci, co, ptr(dX), ptr(None if dfr else dW),
                   ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
-        return dX, _mlp_dw_ret(dfr, ctx.prm[0], dW, kW, ws, m, ci, co, coef), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, (g1 if ctx.needs_input_grad[8] else None), None
+        gskip = g1 if ctx.needs_input_grad[8] else None
+        return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, gskip, None
 
 
 _NO_DROPOUT_FUSION_ENV = __import__('os').environ.get('CRFCONV_NO_DROPOUT_FUSION') is not None     # A/B: bn_apply + nn.Dropout
@@ -947,13 +963,13 @@ class _MLPBlockDropout(torch.autograd.Function):
         st = stream_ptr()
         _lib.call('crfconv_dropout_backward', ptr(g), g.numel(), ctx.p, ctx.seed, ptr(counter), ptr(gA), st)
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
-        dfr = _defer_ok((ctx.prm[0], None))                  # dW: finished with all other blocks' at the end of the pass
+        outs, dfr = _mlp_param_outs(ctx.prm, W, dev)       # (dW, dgamma, dbeta) targets; dfr: dW finished at the end of the pass
+        dW, dgamma, dbeta = (o[0] for o in outs)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(None if dfr else dW),
                   ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
-        return dX, _mlp_dw_ret(dfr, ctx.prm[0], dW, kW, ws, m, ci, co, coef), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None, None, None
+        return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, None, None, None, None
 
 
 class _MLPDropoutLinear(torch.autograd.Function):
@@ -1002,13 +1018,13 @@ class _MLPDropoutLinear(torch.autograd.Function):
             wsw = torch.empty(nb, dtype=torch.uint8, device=dev)
             _lib.call('crfconv_linear_wgrad', ptr(g), ptr(h), m, c2, co, ptr(dW2), ptr(db2), ptr(wsw), nb, st)
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
-        dfr = _defer_ok((ctx.prm[0], None))                  # dW: finished with all other blocks' at the end of the pass
+        outs, dfr = _mlp_param_outs(ctx.prm, W, dev)       # (dW, dgamma, dbeta) targets; dfr: dW finished at the end of the pass
+        dW, dgamma, dbeta = (o[0] for o in outs)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(None if dfr else dW),
                   ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
-        return dX, _mlp_dw_ret(dfr, ctx.prm[0], dW, kW, ws, m, ci, co, coef), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None, None, None, dW2, db2
+        return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, None, None, None, None, dW2, db2
 
 
 def mlp_dropout_linear(x, W, bn, slope, p, W2, b2):
@@ -1093,13 +1109,13 @@ class _MLPBlockPool(torch.autograd.Function):
         _lib.call('crfconv_neighbor_maxpool_backward', ptr(g), ptr(arg), ptr(rev_ptr), ptr(rev_eid), table.K, m, co, ptr(gA), st)
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         add = _f32c(g_alias) if (g_alias is not None and dX is not None) else None
-        (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
-        dfr = _defer_ok((ctx.prm[0], None))                  # dW: finished with all other blocks' at the end of the pass
+        outs, dfr = _mlp_param_outs(ctx.prm, W, dev)       # (dW, dgamma, dbeta) targets; dfr: dW finished at the end of the pass
+        dW, dgamma, dbeta = (o[0] for o in outs)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward_add', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), 1.0, m, ci, co, ptr(add), ptr(dX),
                   ptr(None if dfr else dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
-        return dX, _mlp_dw_ret(dfr, ctx.prm[0], dW, kW, ws, m, ci, co, coef), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None
+        return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, None, None
 
 
 def mlp_block_pool(x, W, bn, table, fork=False):
@@ -1156,7 +1172,8 @@ class _MLPSmallJoin(torch.autograd.Function):
         g1 = torch.empty_like(g)
         _lib.call('crfconv_add_lrelu_backward', ptr(g), ptr(out), out.numel(), ctx.slope, ptr(g1), st)
         gY = torch.empty_like(y)
-        (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
+        outs = [_param_out(q, (co,), dev) for q in ctx.prm[1:]]      # (dgamma, dbeta) targets
+        dgamma, dbeta = outs[0][0], outs[1][0]
         nbytes = _lib.load().crfconv_bn_workspace(m, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_bn_backward', ptr(g1), ptr(y), ptr(coef), m, co, 1, 1.0, ptr(gY), ptr(dgamma), ptr(dbeta), ptr(ws),
@@ -1165,12 +1182,12 @@ class _MLPSmallJoin(torch.autograd.Function):
         gskip = g1 if ctx.needs_input_grad[8] else None
         if _defer_ok(ctx.params):
             _defer_weight_grad(gY, x, ctx.params, False)
-            return dX, None, _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, gskip, None
+            return dX, None, *(_param_ret(q, o, k) for q, (o, k) in zip(ctx.prm[1:], outs)), None, None, None, None, gskip, None
         dW = torch.empty((co, ci), dtype=torch.float32, device=dev)
         nb = _lib.load().crfconv_linear_wgrad_workspace(m, co, ci)
         wsw = torch.empty(nb, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_linear_wgrad', ptr(gY), ptr(x), m, co, ci, ptr(dW), None, ptr(wsw), nb, st)
-        return dX, dW, _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, gskip, None
+        return dX, dW, *(_param_ret(q, o, k) for q, (o, k) in zip(ctx.prm[1:], outs)), None, None, None, None, gskip, None
 
 
 def mlp_block_join(x, W, bn, skip, slope):
@@ -1249,7 +1266,8 @@ class _MLPSmall(torch.autograd.Function):
         dev = x.device
         gA = torch.zeros_like(y) if gA is None else gA.contiguous()
         gY = torch.empty_like(y)
-        (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
+        outs = [_param_out(q, (co,), dev) for q in ctx.prm[1:]]      # (dgamma, dbeta) targets
+        dgamma, dbeta = outs[0][0], outs[1][0]
         nbytes = _lib.load().crfconv_bn_workspace(m, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_bn_backward', ptr(gA), ptr(y), ptr(coef), m, co, 1, ctx.slope, ptr(gY), ptr(dgamma), ptr(dbeta),
@@ -1259,12 +1277,12 @@ class _MLPSmall(torch.autograd.Function):
             dX = gY @ W if g_alias is None else torch.addmm(g_alias.reshape(m, ci), gY, W)
         if _defer_ok(ctx.params):
             _defer_weight_grad(gY, x, ctx.params, False)
-            return dX, None, _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None
+            return dX, None, *(_param_ret(q, o, k) for q, (o, k) in zip(ctx.prm[1:], outs)), None, None, None, None, None, None
         dW = torch.empty((co, ci), dtype=torch.float32, device=dev)          # same partials + reduction as the deferred form
         nb = _lib.load().crfconv_linear_wgrad_workspace(m, co, ci)
         wsw = torch.empty(nb, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_linear_wgrad', ptr(gY), ptr(x), m, co, ci, ptr(dW), None, ptr(wsw), nb, stream_ptr())
-        return dX, dW, _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb), None, None, None, None, None, None
+        return dX, dW, *(_param_ret(q, o, k) for q, (o, k) in zip(ctx.prm[1:], outs)), None, None, None, None, None, None
 
 
 _NO_CAT_ENV = __import__('os').environ.get('CRFCONV_NO_CAT_FUSION') is not None      # A/B: materialise torch.cat
@@ -1305,13 +1323,14 @@ class _MLPBlockCat(torch.autograd.Function):
         want_dx = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         dxa = torch.empty_like(xa) if want_dx else None
         dxb = torch.empty_like(xb) if want_dx else None
-        (dW, kW), (dgamma, kg), (dbeta, kb) = _param_out(ctx.prm[0], tuple(W.shape), dev), _param_out(ctx.prm[1], (co,), dev), _param_out(ctx.prm[2], (co,), dev)
-        dfr = _defer_ok((ctx.prm[0], None))                  # dW: finished with all other blocks' at the end of the pass
+        outs, dfr = _mlp_param_outs(ctx.prm, W, dev)       # (dW, dgamma, dbeta) targets; dfr: dW finished at the end of the pass
+        dW, dgamma, dbeta = (o[0] for o in outs)
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward_cat', ptr(gA), ptr(y), ptr(xa), ptr(xb), split, ptr(W), ptr(coef), ctx.slope, m, ci, co,
                   ptr(dxa), ptr(dxb), ptr(None if dfr else dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
-        return (dxa if ctx.needs_input_grad[0] else None, dxb if ctx.needs_input_grad[1] else None, _mlp_dw_ret(dfr, ctx.prm[0], dW, kW, ws, m, ci, co, coef), _param_ret(ctx.prm[1], dgamma, kg), _param_ret(ctx.prm[2], dbeta, kb),
+        return (dxa if ctx.needs_input_grad[0] else None, dxb if ctx.needs_input_grad[1] else None,
+                *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef),
                 None, None, None, None, None)
 
 
@@ -1818,5 +1837,5 @@ def point_conv(x, pos_src, pos_tgt, table, W1, bn1, W2, bn2, training, momentum=
                             _bn_state(bn1, training, momentum), _bn_state(bn2, training, momentum), float(slope), mom32, prefold)
 
 
-__all__ = ['linear', 'bn_act', 'crf_meanfield', 'gather_rows', 'neighbor_maxpool', 'relpos_moments', 'point_conv', 'point_conv_prefold', 'cross_entropy', 'training_loss',
-           'NeighborTable']
+__all__ = ['linear', 'bn_act', 'crf_meanfield', 'gather_rows', 'neighbor_maxpool', 'relpos_moments', 'point_conv',
+           'point_conv_prefold', 'cross_entropy', 'training_loss', 'NeighborTable']
