@@ -61,11 +61,36 @@ __global__ __launch_bounds__(256) void scan_add_kernel(int32_t* __restrict__ out
 }
 
 
+// scan_sums + scan_add in one launch for up to SCAN_FUSED_MAX blocks: every block sums the totals of the blocks before it
+// itself (integer sums: any order gives the same result) -- one launch less per scan, and the scans here are a few thousand
+// to a few hundred thousand elements, i.e. pure launch latency.
+constexpr int SCAN_FUSED_MAX = 8192;
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void scan_add_fused_kernel(int32_t* __restrict__ out, int64_t n, const int32_t* __restrict__ block_sum) {
+    __shared__ int32_t s_w[4];
+    int32_t t = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) t += block_sum[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, WAVE);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
+    __syncthreads();
+    const int32_t add = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (blockIdx.x == 0) return;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_EPB + 4 * threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < n) out[base + k] += add;
+}
+
 // out[i] = sum_{k < i} in[k], i in [0, n).  block_sums: cdiv(n, SCAN_EPB) int32 of scratch.  in != out.
 inline size_t scan_block_sums(int64_t n) { return (size_t)cdiv(n, SCAN_EPB); }
 inline void exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* block_sums, hipStream_t st) {
     const int64_t nb = cdiv(n, SCAN_EPB);
     hipLaunchKernelGGL(scan_local_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, in, out, n, block_sums);
+    if (nb == 1) return;                               // one block: its local scan is the scan
+    if (nb <= SCAN_FUSED_MAX) {
+        hipLaunchKernelGGL(scan_add_fused_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, out, n, block_sums);
+        return;
+    }
     hipLaunchKernelGGL(scan_sums_kernel<0>, dim3(1), dim3(256), 0, st, block_sums, nb);
     hipLaunchKernelGGL(scan_add_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, out, n, block_sums);
 }
