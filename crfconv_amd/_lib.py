@@ -89,6 +89,7 @@ SIGNATURES = {
     'crfconv_bn_backward': (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_bn_apply': (_i, [_vp, _i64, _i, _vp, _f, _vp, _vp]),
     'crfconv_linear_wgrad_partial': (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    'crfconv_morton_codes': (_i, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'crfconv_copy_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_reduce_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_linear_forward_supported': (_i, [_i, _i]),

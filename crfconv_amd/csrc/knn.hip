@@ -80,6 +80,72 @@ __global__ __launch_bounds__(1024) void bbox_kernel(const float* __restrict__ pt
     }
 }
 
+// ------------------------------------------------------------------ Morton (Z-order) codes of a batch of clouds
+// code = 30 bits, ten per axis, of q = clamp((p - lo) / ext * 1023, 0, 1023) with lo = the cloud's per-axis minimum and ext =
+// its largest extent (>= 1e-20): what data.morton_order computed with ~45 framework launches (min / max reductions, the bit
+// spreading one elementwise op at a time), in two.  Every float operation is rounded on its own, as the framework's were.
+__global__ __launch_bounds__(1024) void morton_bbox_kernel(const float* __restrict__ pts, int64_t npts, float* __restrict__ box) {
+    const float* p = pts + (int64_t)blockIdx.x * npts * 3;
+    float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int64_t i = threadIdx.x; i < npts; i += 1024) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = p[3 * i + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    }
+    __shared__ float smn[16][3], smx[16][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float lo = mn[a], hi = mx[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o, WAVE));
+            hi = fmaxf(hi, __shfl_xor(hi, o, WAVE));
+        }
+        if (lane == 0) { smn[wave][a] = lo; smx[wave][a] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ext = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            float lo = smn[0][a], hi = smx[0][a];
+            for (int w = 1; w < 16; ++w) { lo = fminf(lo, smn[w][a]); hi = fmaxf(hi, smx[w][a]); }
+            box[4 * blockIdx.x + a] = lo;
+            ext = fmaxf(ext, sub_rn(hi, lo));
+        }
+        box[4 * blockIdx.x + 3] = fmaxf(ext, 1e-20f);
+    }
+}
+
+__device__ __forceinline__ long long morton_spread3(long long v) {
+    v &= 0x3FF;
+    v = (v | (v << 16)) & 0x030000FF;
+    v = (v | (v << 8)) & 0x0300F00F;
+    v = (v | (v << 4)) & 0x030C30C3;
+    v = (v | (v << 2)) & 0x09249249;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void morton_code_kernel(const float* __restrict__ pts, int64_t npts,
+                                                          const float* __restrict__ box, long long* __restrict__ code) {
+    const int b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npts) return;
+    const float* p = pts + ((int64_t)b * npts + i) * 3;
+    const float ext = box[4 * b + 3];
+    long long q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float t = mul_rn(sub_rn(p[a], box[4 * b + a]) / ext, 1023.0f);
+        t = fminf(fmaxf(t, 0.f), 1023.f);
+        q[a] = (long long)t;                               // truncation, as Tensor.to(int64)
+    }
+    code[(int64_t)b * npts + i] = morton_spread3(q[0]) | (morton_spread3(q[1]) << 1) | (morton_spread3(q[2]) << 2);
+}
+
 __device__ __forceinline__ int3 cell_of(const GridInfo& g, float x, float y, float z) {
     int cx = (int)floorf((x - g.ox) * g.inv), cy = (int)floorf((y - g.oy) * g.inv),
         cz = (int)floorf((z - g.oz) * g.inv);
@@ -602,6 +668,18 @@ static KnnLayout knn_layout(size_t B, size_t npts) {
 }  // namespace crf
 
 using namespace crf;
+
+extern "C" int crfconv_morton_codes(const float* pts, int64_t B, int64_t npts, float* box_ws, int64_t* codes,
+                                    crf_stream_t stream) {
+    CRF_REQUIRE(pts && box_ws && codes, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(B > 0 && npts > 0 && B < 65536, CRF_ERR_ARG, "bad shape B=%lld npts=%lld", (long long)B, (long long)npts);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(morton_bbox_kernel, dim3((unsigned)B), dim3(1024), 0, st, pts, npts, box_ws);
+    hipLaunchKernelGGL(morton_code_kernel, dim3((unsigned)cdiv(npts, 256), (unsigned)B), dim3(256), 0, st, pts, npts, box_ws,
+                       reinterpret_cast<long long*>(codes));
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
 
 extern "C" size_t crfconv_knn_batch_dev_workspace(size_t batch_size, size_t npts, size_t nqueries, size_t K) {
     (void)nqueries; (void)K;

@@ -118,13 +118,27 @@ def _spread3(v):
     return v
 
 
-def morton_order(pos):
-    """Per-cloud permutation that sorts points along a 30-bit Morton (Z-order) curve.  pos [B, N, 3]."""
-    lo = pos.amin(dim=1, keepdim=True)
+def morton_codes(pos):
+    """30-bit Morton (Z-order) codes [B, N] int64 of pos [B, N, 3]: ten bits per axis of the position inside the cloud's
+    bounding cube.  On the device: two launches (csrc/knn.hip: crfconv_morton_codes)."""
+    if pos.is_cuda and pos.dtype == torch.float32 and pos.dim() == 3 and pos.shape[-1] == 3 and pos.shape[1] > 0:
+        from . import _lib
+        from .graph import ptr, stream_ptr
+        p = pos.detach().contiguous()
+        B, N, _ = p.shape
+        box = torch.empty((B, 4), dtype=torch.float32, device=p.device)
+        code = torch.empty((B, N), dtype=torch.int64, device=p.device)
+        _lib.call('crfconv_morton_codes', ptr(p), B, N, ptr(box), ptr(code), stream_ptr())
+        return code
+    lo = pos.amin(dim=1, keepdim=True)                     # host tensors (tests, tools): the same arithmetic, op by op
     ext = (pos.amax(dim=1, keepdim=True) - lo).amax(dim=2, keepdim=True).clamp_min(1e-20)
     q = ((pos - lo) / ext * 1023.0).clamp_(0, 1023).to(torch.int64)
-    code = _spread3(q[..., 0]) | (_spread3(q[..., 1]) << 1) | (_spread3(q[..., 2]) << 2)
-    return torch.argsort(code, dim=1, stable=True)
+    return _spread3(q[..., 0]) | (_spread3(q[..., 1]) << 1) | (_spread3(q[..., 2]) << 2)
+
+
+def morton_order(pos):
+    """Per-cloud permutation that sorts points along a 30-bit Morton (Z-order) curve.  pos [B, N, 3]."""
+    return torch.argsort(morton_codes(pos), dim=1, stable=True)
 
 
 def _fps_choice(pos, n_sample):

@@ -108,6 +108,11 @@ int crfconv_index_narrow_sorted(const int64_t* idx64, int64_t B, int64_t n_tgt, 
                                 int sort_from, int32_t* idx32, uint16_t* idx16, int32_t* bad_count,
                                 crf_stream_t stream);
 
+/* 30-bit Morton (Z-order) codes of B clouds of npts points (pts [B, npts, 3]): ten bits per axis of
+ * clamp((p - lo) / ext * 1023, 0, 1023), lo = the cloud's per-axis minimum, ext = its largest extent.  The device collate sorts
+ * every cloud along this curve (crfconv_amd.data.morton_order) so that neighbours sit in nearby rows.  box_ws: 4 B floats. */
+int crfconv_morton_codes(const float* pts, int64_t B, int64_t npts, float* box_ws, int64_t* codes, crf_stream_t stream);
+
 /* Any number of device-to-device copies (dst[j] <- src[j], nbytes[j] bytes, non-overlapping) in ONE launch: the ~25 tensors of a
  * freshly collated batch into the static buffers of a captured training step (crfconv_amd.data.MultiScaleData.load_). */
 typedef struct { const void* src; void* dst; int64_t nbytes; } crf_copy_job;

@@ -8,6 +8,7 @@ import _seeded as S
 from oracle import native as onative
 
 pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
 
 
 @pytest.fixture(scope='module')
@@ -212,3 +213,20 @@ print('fork ok')
 """ % root
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'fork ok' in out.stdout, out.stderr[-2000:]
+
+
+def test_morton_codes_kernel_equals_the_op_by_op_form():
+    """crfconv_morton_codes (two launches) against the framework-op form it replaced (data.morton_codes on a host copy): the
+    same codes bit for bit -- random clouds, a degenerate cloud (all points equal), a planar one, negative coordinates."""
+    from crfconv_amd import data
+    g = torch.Generator().manual_seed(21)
+    clouds = [torch.rand(3, 5000, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0]) - torch.tensor([4.0, 1.0, 0.5]),
+              torch.ones(2, 257, 3) * 0.37,
+              torch.cat([torch.rand(2, 1000, 2, generator=g), torch.zeros(2, 1000, 1)], -1),
+              torch.randn(1, 40960, 3, generator=g) * 100.0]
+    for pos in clouds:
+        ref = data.morton_codes(pos)                                   # host tensor: op-by-op path
+        got = data.morton_codes(pos.to(DEV))
+        assert got.dtype == torch.int64 and torch.equal(got.cpu(), ref)
+        assert torch.equal(data.morton_order(pos.to(DEV)).cpu(), torch.argsort(ref, dim=1, stable=True))
+
