@@ -145,8 +145,8 @@ def roofline_meanfield(data, dev, H=8, T=3):
 
 
 def roofline_meanfield_bwd(data, dev, H=8, T=3):
-    """Level-0 CRF mean-field BACKWARD (crfconv_meanfield_backward: prepare | T chain steps | edge pass over all steps +
-    softmax backward | dy scatter | dP / dQ reduction), HIP-event timed.  Algorithmic bytes per point:
+    """Level-0 CRF mean-field BACKWARD (crfconv_meanfield_backward, csrc/crf_bwd.hip: T - 1 reverse walks | edge pass over
+    all steps + softmax backward | last reverse walk with the dy scatter and the dP / dQ reduction), HIP-event timed.  Algorithmic bytes per point:
     twice the forward's compulsory bytes plus the reverse index, 2 (4 (K-1) + 4 H (2 T + 1)) + 4 K + 4."""
     from crfconv_amd import _lib, ops
     from crfconv_amd.graph import ptr, stream_ptr
@@ -161,7 +161,7 @@ def roofline_meanfield_bwd(data, dev, H=8, T=3):
     st = stream_ptr()
     _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src,
               K, 1, m, H, ptr(Q), ptr(P), T, ptr(s), ptr(xs), st)
-    Gs, gms = torch.empty(T, m, H, device=dev), torch.empty(T, m, H, device=dev)
+    Gs, dzq = torch.empty(T, m, H, device=dev), torch.empty(m, H, device=dev)
     dz, dy_self, dy = (torch.empty(m, H, device=dev) for _ in range(3))
     w = torch.empty(m, K, device=dev)
     dP, dQ = torch.empty(H, H, device=dev), torch.empty(H, H, device=dev)
@@ -171,15 +171,15 @@ def roofline_meanfield_bwd(data, dev, H=8, T=3):
 
     def launch():
         _lib.call('crfconv_meanfield_backward', ptr(gout), ptr(z), ptr(y), ptr(s), ptr(xs), ptr(tab.idx32), ptr(tab.idx16),
-                  tab.n_tgt, tab.n_src, ptr(rev_ptr), ptr(rev_eid), K, 1, m, H, ptr(Q), ptr(P), T, ptr(Gs), ptr(gms), None,
+                  tab.n_tgt, tab.n_src, ptr(rev_ptr), ptr(rev_eid), K, 1, m, H, ptr(Q), ptr(P), T, ptr(Gs), ptr(dzq), None,
                   None, ptr(dz), ptr(w), ptr(dy_self), ptr(dy), ptr(dP), ptr(dQ), ptr(ws), wsb, ptr(ticket), st)
     avg, lo = _event_time(launch, per=5)
     alg_bytes = m * (2 * (4 * (K - 1) + 4 * H * (2 * T + 1)) + 4 * K + 4)
     traffic, note = _measured_traffic('r2_meanfield_bwd_traffic.json', {'m': m, 'H': H, 'K': K, 'T': T})
     return {'bound': 'hbm', 'achieved': alg_bytes / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
             'frac': alg_bytes / avg / HBM_PEAK, 'traffic': traffic, 'traffic_source': note,
-            'kernel': 'crfconv_meanfield_backward level-0 (bwd_prepare + %d x bwd_chain + bwd_edge_all + sim_bwd_scatter + '
-                      'reduce_small, m=%d, H=%d, K=%d)' % (T, m, H, K),
+            'kernel': 'crfconv_meanfield_backward level-0 (%d x bwd_rev<chain> + bwd_edge_all + bwd_rev<final>, '
+                      'm=%d, H=%d, K=%d)' % (T - 1, m, H, K),
             'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': avg * 1e6, 'min_launch_us': lo * 1e6}
 
 

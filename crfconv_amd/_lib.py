@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcrfconv_amd.so')
+LIB_PATH = os.environ.get('CRFCONV_LIB') or os.path.join(_HERE, 'libcrfconv_amd.so')      # CRFCONV_LIB: A/B builds of scratch/
 
 _vp, _i, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 _d = ctypes.c_double

@@ -13,121 +13,15 @@
 // neighbour gathers of a point are in flight together.
 //
 // Reference semantics: models/continuous_crf_conv_big.py:49-54 (similarity), :63-72 (loop).
-#include "common.hpp"
-#include "gridsync.hpp"
-
-#include <cstdlib>
+#include "crf_common.hpp"
 
 namespace crf {
 
-constexpr int BLOCK = 256;
-
-// v (float4 per lane, quad q of the point's H-vector)  ->  acc + v_full * Mat, where
-// sM holds Mat [H][H] row-major as float4 rows: sM[h * L + q] = Mat[h][4q .. 4q+3].
-template <int H>
-__device__ __forceinline__ float4 matvec_acc(float4 v, const float4* sM, int lane, int q, float4 acc) {
-    constexpr int L = H / 4;
-    const int base = lane - q;
-    static_for<L>([&](auto HQ) {                     // broadcasts inside a DPP quad for H <= 16 (group_bcast), shuffles above
-        constexpr int hq = decltype(HQ)::value;
-        const float v0 = group_bcast<L, hq>(v.x, base);
-        const float v1 = group_bcast<L, hq>(v.y, base);
-        const float v2 = group_bcast<L, hq>(v.z, base);
-        const float v3 = group_bcast<L, hq>(v.w, base);
-        acc = fma4(v0, sM[(4 * hq + 0) * L + q], acc);
-        acc = fma4(v1, sM[(4 * hq + 1) * L + q], acc);
-        acc = fma4(v2, sM[(4 * hq + 2) * L + q], acc);
-        acc = fma4(v3, sM[(4 * hq + 3) * L + q], acc);
-    });
-    return acc;
-}
-
-template <int H, int NT = BLOCK>
-__device__ __forceinline__ void load_matrix(float4* sM, const float* __restrict__ Mat, bool transpose) {
-    // sM[h][c] = transpose ? Mat[c][h] : Mat[h][c]
-    float* s = reinterpret_cast<float*>(sM);
-    for (int t = threadIdx.x; t < H * H; t += NT) {
-        const int h = t / H, c = t % H;
-        s[t] = transpose ? Mat[c * H + h] : Mat[t];
-    }
-}
-
-template <int H, int NT = BLOCK>
-struct Geo {
-    static constexpr int L = H / 4, PPW = WAVE / L, PPB = PPW * (NT / WAVE);
-};
-
-template <int H, int NT = BLOCK>
-__device__ __forceinline__ int64_t my_point(int64_t m, int& lane, int& q, bool& valid) {
-    lane = threadIdx.x & 63;
-    q = lane % Geo<H>::L;
-    const int64_t row = (int64_t)xcd_block_id() * Geo<H, NT>::PPB + (threadIdx.x >> 6) * Geo<H>::PPW + lane / Geo<H>::L;
-    valid = row < m;
-    return valid ? row : m - 1;
-}
-
-__device__ __forceinline__ float4 sub4(float4 a, float4 b) {
-    return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-}
-
-// K-wide row of 32-bit values (K % 4 == 0) as K/4 aligned dwordx4 loads.
-template <int K, typename T4, typename T>
-__device__ __forceinline__ void load_row(const T* __restrict__ p, T (&out)[K]) {
-#pragma unroll
-    for (int c = 0; c < K / 4; ++c) {
-        const T4 v = reinterpret_cast<const T4*>(p)[c];
-        out[4 * c + 0] = v.x; out[4 * c + 1] = v.y; out[4 * c + 2] = v.z; out[4 * c + 3] = v.w;
-    }
-}
-
-// Index row in either layout: int32 global rows, or uint16 per-cloud local ids (half the bytes; valid when
-// every cloud has <= 65536 source points) decoded as  cloud * n_src + id  with cloud = row / n_tgt.
-template <int K>
-__device__ __forceinline__ void load_index_row(const int32_t* __restrict__ idx32, const uint16_t* __restrict__ idx16,
-                                               int64_t r, int n_tgt, int n_src, int (&j)[K]) {
-    if (idx16 != nullptr) {
-        const int base = (int)(r / n_tgt) * n_src;
-        const uint4* p = reinterpret_cast<const uint4*>(idx16 + r * K);
-#pragma unroll
-        for (int c = 0; c < K / 8; ++c) {
-            const uint4 v = p[c];
-            const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                j[8 * c + 2 * e] = base + (int)(w[e] & 0xffffu);
-                j[8 * c + 2 * e + 1] = base + (int)(w[e] >> 16);
-            }
-        }
-    } else {
-        load_row<K, int4>(idx32 + r * K, j);
-    }
-}
-
-// K-wide rows of the wave's PPW points (PPW * K contiguous floats in memory) written as 1 KiB-contiguous stores.
-// Stored straight from the owning lanes, each store instruction touches 64/L rows with 16 bytes each (measured on
-// the level-0 first kernel: +2.1 us); routed through a per-wave LDS tile every instruction writes consecutive bytes.
-// One call per kernel (the tile is a single static array per instantiation).
-template <int H, int K, int NT = BLOCK>
-__device__ __forceinline__ void store_rows_coalesced(const float (&d)[K], float* __restrict__ dst, int lane, int q,
-                                                     int64_t m) {
-    constexpr int L = Geo<H>::L, PPW = Geo<H>::PPW, CPR = K / 4, NCH = PPW * CPR;   // 16-byte chunks per row / wave
-    __shared__ float4 tile[NT / WAVE][NCH];
-    float4* mine = tile[threadIdx.x >> 6];
-    const int p = lane / L;
-#pragma unroll
-    for (int c = 0; c < CPR; ++c)
-        if ((c % L) == q) mine[p * CPR + c] = make_float4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]);
-    __builtin_amdgcn_wave_barrier();     // LDS operations of one wave complete in order
-    const int64_t row0 = (int64_t)xcd_block_id() * Geo<H, NT>::PPB + (threadIdx.x >> 6) * PPW;
-#pragma unroll
-    for (int c = lane; c < NCH; c += WAVE)
-        if (row0 + c / CPR < m) st4(dst + row0 * K + 4 * c, mine[c]);
-}
 
 // ====================================================================== fast forward kernels
 // (K in {16, 32}, k0 == 1).  FIRST = similarity + z Q + first step fused: the index row is read
 // once, s never round-trips through memory before its first use.
-template <int H, int K, bool WITH_STEP>
+template <int H, int K, bool WITH_STEP, bool U16>
 __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_fast_kernel(const float* __restrict__ y,
                                                               const float* __restrict__ z,
                                                               const int32_t* __restrict__ idx,
@@ -137,17 +31,24 @@ __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_f
                                                               float* __restrict__ s,
                                                               float* __restrict__ x1, int64_t m) {
     constexpr int L = Geo<H>::L;
-    __shared__ float4 sQ[WITH_STEP ? H * L : 1];
-    __shared__ float4 sP[WITH_STEP ? H * L : 1];
-    if constexpr (WITH_STEP) load_matrix<H>(sQ, Q, false);
-    if constexpr (WITH_STEP) load_matrix<H>(sP, P, false);     // barrier deferred to the first matvec: the
-    int lane, q;                                              // matrix fetch overlaps the row loads and gathers
+    __shared__ float4 sQ[WITH_STEP ? MatStage<H>::F4 : 1];
+    __shared__ float4 sP[WITH_STEP ? MatStage<H>::F4 : 1];
+    int lane, q;
     bool valid;
     const int64_t r = my_point<H>(m, lane, q, valid);
 
+    // issue order = arrival order: the index row first (the gathers wait for nothing else), then the own rows and the
+    // matrices, which are only needed behind the gathers
     int j[K];
-    load_index_row<K>(idx, idx16, r, n_tgt, n_src, j);
+    load_index_row_t<K, U16>(idx, idx16, r, n_tgt, n_src, j);
     const float4 yi = ld4(y + r * H + 4 * q);
+    [[maybe_unused]] float4 zi = make_float4(0.f, 0.f, 0.f, 0.f);
+    [[maybe_unused]] MatStage<H> mq, mp;
+    if constexpr (WITH_STEP) {
+        zi = ld4(z + r * H + 4 * q);
+        mq.fetch(Q, false);
+        mp.fetch(P, false);
+    }
     float4 nb[K];
 #pragma unroll
     for (int k = 1; k < K; ++k) nb[k] = ld4(y + (int64_t)j[k] * H + 4 * q);
@@ -162,6 +63,8 @@ __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_f
     if constexpr (WITH_STEP) {   // issue the z-row gathers before the exp chain
 #pragma unroll
         for (int k = 1; k < K; ++k) nb[k] = ld4(z + (int64_t)j[k] * H + 4 * q);
+        mq.park(sQ);
+        mp.park(sP);
     }
     float den = 0.f;
 #pragma unroll
@@ -176,7 +79,6 @@ __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_f
     if (s != nullptr) store_rows_coalesced<H, K>(d, s, lane, q, m);       // NULL: inference with T <= 1, nobody re-reads s
 
     if constexpr (WITH_STEP) {
-        const float4 zi = ld4(z + r * H + 4 * q);
         float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 1; k < K; ++k) msg = fma4(d[k], nb[k], msg);
@@ -187,7 +89,7 @@ __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_f
     }
 }
 
-template <int H, int K>
+template <int H, int K, bool U16>
 __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restrict__ xin,
                                                           const float* __restrict__ z,
                                                           const float* __restrict__ s,
@@ -196,25 +98,27 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
                                                           const float* __restrict__ Q,
                                                           const float* __restrict__ P,
                                                           float* __restrict__ xout, int64_t m) {
-    constexpr int L = Geo<H>::L;
-    __shared__ float4 sP[H * L];
-    __shared__ float4 sQ[H * L];
-    load_matrix<H>(sP, P, false);
-    load_matrix<H>(sQ, Q, false);                               // barrier deferred to the first matvec
+    __shared__ float4 sP[MatStage<H>::F4];
+    __shared__ float4 sQ[MatStage<H>::F4];
     int lane, q;
     bool valid;
     const int64_t r = my_point<H>(m, lane, q, valid);
     int j[K];
     float w[K];
-    load_index_row<K>(idx, idx16, r, n_tgt, n_src, j);
+    load_index_row_t<K, U16>(idx, idx16, r, n_tgt, n_src, j);              // first: the gathers wait for this row only
     load_row<K, float4>(s + r * K, w);
     const float4 zi = ld4(z + r * H + 4 * q);
+    MatStage<H> mp, mq;
+    mp.fetch(P, false);
+    mq.fetch(Q, false);
     // gathers in two batches of K/2 (fewer live registers: 8 waves/SIMD at H = 8, K = 16; measured 0.2-0.3 us faster)
     float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
     {
         float4 nb[K / 2];
 #pragma unroll
         for (int k = 1; k < K / 2; ++k) nb[k] = ld4(xin + (int64_t)j[k] * H + 4 * q);
+        mp.park(sP);
+        mq.park(sQ);
 #pragma unroll
         for (int k = 1; k < K / 2; ++k) msg = fma4(w[k], nb[k], msg);
 #pragma unroll
@@ -749,32 +653,6 @@ __global__ __launch_bounds__(BLOCK) void bwd_edge_kernel(const float* __restrict
 }
 
 // ====================================================================== backward, scatter half
-// One source row per L lanes; walks the row's incoming edges (ascending edge id, fixed order).
-// Gprev[j] = add[j] + sum_{e in rev(j)} s[e] gm[e / K]     (s is 0 on columns < k0)
-// EP edge-lanes per row walk the row's incoming edges EP at a time (edge p = beg + lane-group, += EP) and fold their
-// partial sums by xor-shuffles (fixed tree): in-degrees of a kNN graph spread from 0 to ~40, and with one lane
-// group per row a wavefront iterates to the LARGEST in-degree of its 64/L rows.
-#ifndef SCAT_EP
-#define SCAT_EP 2          // edge lanes per row (L <= 4); swept with SCAT_UB on the level-0 backward: (4,4) 104.8, (2,8) 98.5, (2,4) 106, (4,8) 106, (1,16) 107 us
-#endif
-#ifndef SCAT_UB
-#define SCAT_UB 8          // records / rows in flight per lane and round
-#endif
-template <int H>
-struct Scat {
-    static constexpr int L = H / 4, EP = (L <= 4) ? SCAT_EP : 1, RPW = WAVE / (L * EP), RPB = RPW * (BLOCK / WAVE);
-};
-
-template <int H>
-__device__ __forceinline__ float4 fold_edge_lanes(float4 a) {
-    constexpr int L = Scat<H>::L;
-#pragma unroll
-    for (int o = L; o < L * Scat<H>::EP; o <<= 1) {
-        a.x += __shfl_xor(a.x, o, WAVE); a.y += __shfl_xor(a.y, o, WAVE);
-        a.z += __shfl_xor(a.z, o, WAVE); a.w += __shfl_xor(a.w, o, WAVE);
-    }
-    return a;
-}
 
 template <int H>
 __global__ __launch_bounds__(BLOCK) void bwd_scatter_kernel(const float* __restrict__ gm,
@@ -920,361 +798,6 @@ __global__ __launch_bounds__(BLOCK) void sim_bwd_scatter_kernel(const float* __r
         const float4 a0 = ld4(dy_self + row * H + 4 * q);
         st4(dy + row * H + 4 * q, make_float4(acc.x + a0.x, acc.y + a0.y, acc.z + a0.z, acc.w + a0.w));
     }
-}
-
-// ====================================================================== backward, restructured (K in {16, 32}, k0 = 1)
-// The step-by-step form above runs, per step, an edge kernel (x gathers, ds read-modify-write) and a scatter kernel
-// (three dependent loads per reverse edge).  Only the chain  G_t -> gm_t = G_t P^T -> G_{t-1} = A^T gm_t  is sequential,
-// and it needs no x row at all; everything that gathers x (ds, m_t) and the whole softmax / distance backward only needs
-// the gm_t of the point itself.  So:
-//   bwd_prepare_kernel   G_T copy, gm_T = G_T P^T, and the reverse edge records {target row, weight} in CSR order (8 B per
-//                        edge, ONE load instead of rev_eid -> s[e], reused by all T chain launches)
-//   bwd_chain_kernel x T G_{t-1}[j] = sum_{p in rev(j)} rec[p].s gm_t[rec[p].i];  gm_{t-1} = G_{t-1} P^T; the last one
-//                        (t = 1) also forms sum_t G_t and dz = G_0 + (sum_t G_t) Q^T
-//   bwd_edge_all_kernel  per point: index row, weight row and ds stay in registers over all T gather passes
-//                        (ds += <gm_t, x_{t-1}[j]>, m_t), then the softmax / distance backward straight from those
-//                        registers (w row, dy_self): ds never exists in memory
-//   sim_bwd_scatter_kernel (above) finishes dy.
-struct __attribute__((aligned(8))) RevRec {
-    int i;        // target row of the edge (e / K)
-    float s;      // its softmax weight s[e]
-};
-
-// Sum over a wavefront's points of the outer products a_p^T b_p (H x H, H in {8, 16}) on the matrix pipe, which is idle in
-// these gather-bound kernels: the wave's a / b rows go through a per-wave LDS tile [64 / L points][H] whose row-major
-// order IS the 16x16x4 fragment layout (lane l reads float 64 n + l of the tile), 64 / H points per MFMA, four MFMAs per
-// call.  At H = 8 a tile row pair fills the 16 fragment rows, so D holds two valid 8 x 8 diagonal blocks that are added
-// at the end.  Replaces the separate  dP = m^T G  /  dQ = z^T sum G  streaming reductions (and the m_t arrays they read).
-using f32x4_t = __attribute__((ext_vector_type(4))) float;
-
-template <int H>
-struct OuterAcc {
-    static_assert(H == 8 || H == 16, "in-kernel outer products: H in {8, 16}");
-    f32x4_t d = {0.f, 0.f, 0.f, 0.f};
-    // every lane holds a float4 of its point's row (lane order = tile order)
-    __device__ __forceinline__ void add_rows(float4 a, float4 b, float* tile_a, float* tile_b, int lane) {
-        *reinterpret_cast<float4*>(tile_a + 4 * lane) = a;
-        *reinterpret_cast<float4*>(tile_b + 4 * lane) = b;
-        __builtin_amdgcn_wave_barrier();           // LDS operations of one wave complete in order
-#pragma unroll
-        for (int n = 0; n < 4; ++n) d = __builtin_amdgcn_mfma_f32_16x16x4f32(tile_a[64 * n + lane], tile_b[64 * n + lane], d, 0, 0, 0);
-        __builtin_amdgcn_wave_barrier();
-    }
-    // 64 floats of each operand already in the tiles (one MFMA)
-    __device__ __forceinline__ void add_tile64(const float* tile_a, const float* tile_b, int lane) {
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(tile_a[lane], tile_b[lane], d, 0, 0, 0);
-    }
-    // block sum -> partial[blockIdx.x][H * H]; s_red: [BLOCK / WAVE][H * H] floats
-    __device__ __forceinline__ void store_partial(float* s_red, float* __restrict__ partial, int lane) {
-        const int wave = threadIdx.x >> 6;
-        float* mine = s_red + wave * H * H;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * (lane >> 4) + r, col = lane & 15;       // D layout of 16x16x4
-            if constexpr (H == 16) {
-                mine[row * 16 + col] = d[r];
-            } else {
-                const float other = __shfl(d[r], lane + 40, WAVE);      // D[row + 8][col + 8]
-                if (lane < 32 && col < 8) mine[row * 8 + col] = d[r] + other;
-            }
-        }
-        __syncthreads();
-        for (int t = threadIdx.x; t < H * H; t += BLOCK) {
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < BLOCK / WAVE; ++w) v += s_red[w * H * H + t];
-            partial[(size_t)blockIdx.x * H * H + t] = v;
-        }
-    }
-};
-
-// out[job][slot] = sum_b partial[job][b][slot] for two jobs of few slots (H * H <= 256) and MANY slabs (one per
-// workgroup of the producing kernel): RS_CHUNKS workgroups each sum a contiguous range of slabs (eight loads in flight
-// per lane), publish the chunk sums write-through, take a ticket; the last one adds the chunk sums in chunk order --
-// one launch, bitwise reproducible.  ticket: one zero word, reset by the last workgroup.
-constexpr int RS_CHUNKS = 128;
-struct SmallJob {
-    const float* partial;
-    float* out;
-    int nblk;
-};
-
-__global__ __launch_bounds__(256) void reduce_small_kernel(SmallJob j0, SmallJob j1, int nslots, float* scratch,
-                                                           unsigned* ticket) {
-    __shared__ float s_part[256];
-    __shared__ int s_last;
-    const int groups = 256 / nslots, grp = threadIdx.x / nslots, slot = threadIdx.x % nslots;   // nslots in {64, 256}
-    const __amdgpu_buffer_rsrc_t sr = make_rsrc(scratch, 2 * RS_CHUNKS * nslots * 4);
-    for (int job = 0; job < 2; ++job) {
-        const SmallJob jb = job == 0 ? j0 : j1;
-        const int per = (jb.nblk + RS_CHUNKS - 1) / RS_CHUNKS;
-        const int lo = blockIdx.x * per, hi = lo + per < jb.nblk ? lo + per : jb.nblk;
-        float acc = 0.f;
-        for (int b = lo + grp; b < hi; b += 8 * groups) {        // eight slabs in flight per lane, added in slab order
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = b + u * groups < hi ? jb.partial[(size_t)(b + u * groups) * nslots + slot] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
-        }
-        __syncthreads();
-        s_part[threadIdx.x] = acc;
-        __syncthreads();
-        if (grp == 0) {
-            float v = s_part[slot];
-            for (int g2 = 1; g2 < groups; ++g2) v += s_part[g2 * nslots + slot];
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), sr, ((job * RS_CHUNKS + (int)blockIdx.x) * nslots + slot) * 4, 0, 16);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old + 1 == gridDim.x;
-        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // the last workgroup: chunk sums in chunk order, `groups` interleaved sub-sums of 16 loads in flight each
-    for (int job = 0; job < 2; ++job) {
-        float* out = job == 0 ? j0.out : j1.out;
-        float acc = 0.f;
-        for (int c = grp; c < RS_CHUNKS; c += 16 * groups) {
-            float u[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                u[k] = c + k * groups < RS_CHUNKS
-                           ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sr, ((job * RS_CHUNKS + c + k * groups) * nslots + slot) * 4, 0, 16))
-                           : 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc += u[k];
-        }
-        __syncthreads();
-        s_part[threadIdx.x] = acc;
-        __syncthreads();
-        if (grp == 0) {
-            float v = s_part[slot];
-            for (int g2 = 1; g2 < groups; ++g2) v += s_part[g2 * nslots + slot];
-            out[slot] = v;
-        }
-    }
-}
-
-template <int H>
-__global__ __launch_bounds__(BLOCK) void bwd_prepare_kernel(const float* __restrict__ G, const float* __restrict__ P,
-                                                            const float* __restrict__ s,
-                                                            const int32_t* __restrict__ rev_eid, int K, int kshift,
-                                                            float* __restrict__ gm, RevRec* __restrict__ rec, int64_t m,
-                                                            int64_t E, float* __restrict__ Gcopy) {
-    constexpr int L = Geo<H>::L;
-    __shared__ float4 sPT[H * L];
-    load_matrix<H>(sPT, P, true);
-    int lane, q;
-    bool valid;
-    const int64_t r = my_point<H>(m, lane, q, valid);
-    const float4 g = ld4(G + r * H + 4 * q);
-    if (Gcopy != nullptr && valid) st4(Gcopy + r * H + 4 * q, g);      // G_T into the stacked [T, m, H] array (wide H: dP = m^T G outside)
-    // this block's share of the reverse edge list, four consecutive edges per thread and round (E = m K is a multiple of
-    // 4): one dwordx4 of edge ids, four weight gathers in flight, two dwordx4 record stores
-    const int64_t quads = E >> 2, per_block = (quads + gridDim.x - 1) / gridDim.x;
-    const int64_t q0 = (int64_t)xcd_block_id() * per_block, q1 = q0 + per_block < quads ? q0 + per_block : quads;
-    for (int64_t qq = q0 + threadIdx.x; qq < q1; qq += BLOCK) {
-        const int4 e4 = reinterpret_cast<const int4*>(rev_eid)[qq];
-        const int e[4] = {e4.x, e4.y, e4.z, e4.w};
-        float sv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) sv[u] = s[e[u]];
-        int4 o0, o1;
-        o0.x = kshift >= 0 ? (e[0] >> kshift) : (e[0] / K); o0.y = __float_as_int(sv[0]);
-        o0.z = kshift >= 0 ? (e[1] >> kshift) : (e[1] / K); o0.w = __float_as_int(sv[1]);
-        o1.x = kshift >= 0 ? (e[2] >> kshift) : (e[2] / K); o1.y = __float_as_int(sv[2]);
-        o1.z = kshift >= 0 ? (e[3] >> kshift) : (e[3] / K); o1.w = __float_as_int(sv[3]);
-        reinterpret_cast<int4*>(rec)[2 * qq] = o0;
-        reinterpret_cast<int4*>(rec)[2 * qq + 1] = o1;
-    }
-    __syncthreads();
-    const float4 gmi = matvec_acc<H>(g, sPT, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
-    if (valid) st4(gm + r * H + 4 * q, gmi);
-}
-
-// One source row per L * EP lanes (Scat<H>).  LAST (t = 1): also sum_t G_t, dz = G_0 + (sum_t G_t) Q^T and, for
-// H in {8, 16}, this block's partial of dQ = z^T sum_t G_t (OuterAcc) -- otherwise sumG is written for the caller.
-#ifndef CHAIN_TAIL
-#define CHAIN_TAIL 1
-#endif
-template <int H, bool LAST>
-__global__ __launch_bounds__(BLOCK) void bwd_chain_kernel(const float* __restrict__ gm, const RevRec* __restrict__ rec,
-                                                          const int32_t* __restrict__ rev_ptr,
-                                                          const float* __restrict__ P, const float* __restrict__ Q,
-                                                          float* __restrict__ Gprev, float* __restrict__ gm_prev,
-                                                          const float* __restrict__ gout, const float* __restrict__ Gs,
-                                                          int T, const float* __restrict__ z, float* __restrict__ sumG,
-                                                          float* __restrict__ dz, float* __restrict__ dq_partial,
-                                                          int64_t m_src) {
-    constexpr int L = Scat<H>::L, EP = Scat<H>::EP;
-    constexpr bool INK = LAST && (H == 8 || H == 16);
-    __shared__ float4 sM[H * L];                       // P^T (chain) or Q^T (last)
-    constexpr int TILE = Scat<H>::RPW * H;             // floats per operand and wavefront (a multiple of 64)
-    __shared__ __attribute__((aligned(16))) float s_tile[INK ? 2 * (BLOCK / WAVE) * TILE : 4];
-    __shared__ float s_red[INK ? (BLOCK / WAVE) * H * H : 1];
-    load_matrix<H>(sM, LAST ? Q : P, true);
-    const int lane = threadIdx.x & 63;
-    const int q = lane % L, el = (lane / L) % EP;
-    int64_t row = (int64_t)xcd_block_id() * Scat<H>::RPB + (threadIdx.x >> 6) * Scat<H>::RPW + lane / (L * EP);
-    const bool valid = row < m_src;
-    if (!valid) row = m_src - 1;                    // keep every lane in the shuffles below
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int2 be = valid ? *reinterpret_cast<const int2*>(rev_ptr + row) : make_int2(0, 0);      // [beg, end)
-    const int beg = be.x, end = be.y;
-    // UB records per lane first, then their UB row gathers: two dependent memory phases per EP * UB edges of a row (a
-    // kNN graph's in-degree is ~K, so one or two rounds) instead of one record -> gather chain per EP edges.  (A lane
-    // taking UB CONSECUTIVE records as two dwordx4 loads measured slower, 18.3 vs 14.8 us: the tail rounds diverge.)
-    // The kernel is bound by vector-memory issue (a wave-wide load costs its ~22 clk whether or not lanes are masked), so
-    // the first round takes EP * UB = 16 edges of a row and later rounds -- only the rows of above-average in-degree
-    // need them -- EP * TB edges: 8 + 2 TB ceil((max degree - 16) / (EP TB)) load instructions per wave instead of 16.
-    constexpr int UB = SCAT_UB;
-    int p0 = beg + el;
-    if (p0 < end) {
-        RevRec rr[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int p = p0 + u * EP;
-            rr[u] = rec[p < end ? p : beg];         // clamped: in range, weight zeroed below
-            if (p >= end) rr[u].s = 0.f;
-        }
-        float4 g[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) g[u] = ld4(gm + (int64_t)rr[u].i * H + 4 * q);
-#pragma unroll
-        for (int u = 0; u < UB; ++u) acc = fma4(rr[u].s, g[u], acc);
-    }
-    constexpr int TB = CHAIN_TAIL;
-    for (p0 += EP * UB; p0 < end; p0 += EP * TB) {
-        RevRec rr[TB];
-#pragma unroll
-        for (int u = 0; u < TB; ++u) {
-            const int p = p0 + u * EP;
-            rr[u] = rec[p < end ? p : beg];
-            if (p >= end) rr[u].s = 0.f;
-        }
-        float4 g[TB];
-#pragma unroll
-        for (int u = 0; u < TB; ++u) g[u] = ld4(gm + (int64_t)rr[u].i * H + 4 * q);
-#pragma unroll
-        for (int u = 0; u < TB; ++u) acc = fma4(rr[u].s, g[u], acc);
-    }
-    acc = fold_edge_lanes<H>(acc);                  // every edge-lane group holds the row's sum
-    __syncthreads();
-    const int lane0 = lane - el * L;                // the el = 0 twin of this lane (same q)
-    if constexpr (!LAST) {
-        const float4 gmv = matvec_acc<H>(acc, sM, lane0, q, make_float4(0.f, 0.f, 0.f, 0.f));
-        if (valid && el == 0) {
-            st4(Gprev + row * H + 4 * q, acc);
-            st4(gm_prev + row * H + 4 * q, gmv);
-        }
-    } else {
-        float4 sg = ld4(gout + row * H + 4 * q);    // G_T, then G_{T-1} .. G_1 in that order
-        for (int t = 1; t < T; ++t) {
-            const float4 gt = ld4(Gs + ((int64_t)t * m_src + row) * H + 4 * q);
-            sg = make_float4(sg.x + gt.x, sg.y + gt.y, sg.z + gt.z, sg.w + gt.w);
-        }
-        const float4 dzv = matvec_acc<H>(sg, sM, lane0, q, acc);      // G_0 + (sum_t G_t) Q^T
-        if (valid && el == 0) st4(dz + row * H + 4 * q, dzv);
-        if constexpr (INK) {
-            // the wave's RPW rows x H channels = TILE floats per operand: TILE / 64 MFMAs
-            float* ta = s_tile + (threadIdx.x >> 6) * 2 * TILE;
-            float* tb = ta + TILE;
-            if (el == 0) {
-                const int slot = (lane / (L * EP)) * H + 4 * q;
-                const float4 zr = ld4(z + row * H + 4 * q);
-                *reinterpret_cast<float4*>(ta + slot) = valid ? zr : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(tb + slot) = valid ? sg : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            __builtin_amdgcn_wave_barrier();
-            OuterAcc<H> oa;
-#pragma unroll
-            for (int n = 0; n < TILE / 64; ++n) oa.add_tile64(ta + 64 * n, tb + 64 * n, lane);
-            oa.store_partial(s_red, dq_partial, lane);
-        } else {
-            if (valid && el == 0) st4(sumG + row * H + 4 * q, sg);
-        }
-    }
-}
-
-template <int H, int K>
-__global__ __launch_bounds__(BLOCK) void bwd_edge_all_kernel(const float* __restrict__ gms, const float* __restrict__ gout,
-                                                             const float* __restrict__ Gs, const float* __restrict__ xs,
-                                                             const float* __restrict__ z, const float* __restrict__ y,
-                                                             const float* __restrict__ s,
-                                                             const int32_t* __restrict__ idx,
-                                                             const uint16_t* __restrict__ idx16, int n_tgt, int n_src,
-                                                             int T, float* __restrict__ mts, float* __restrict__ dp_partial,
-                                                             float* __restrict__ w, float* __restrict__ dy_self, int64_t m) {
-    constexpr int L = Geo<H>::L;
-    constexpr bool INK = H == 8 || H == 16;          // dP = sum_t m_t^T G_t accumulated here (OuterAcc); else m_t is stored
-    __shared__ __attribute__((aligned(16))) float s_tile[INK ? 2 * (BLOCK / WAVE) * 256 : 4];
-    __shared__ float s_red[INK ? (BLOCK / WAVE) * H * H : 1];
-    int lane, q;
-    bool valid;
-    const int64_t r = my_point<H>(m, lane, q, valid);
-    int j[K];
-    float sw[K], dd[K];
-    load_index_row<K>(idx, idx16, r, n_tgt, n_src, j);
-    load_row<K, float4>(s + r * K, sw);
-#pragma unroll
-    for (int k = 0; k < K; ++k) dd[k] = 0.f;
-    const int64_t step = m * H;
-    [[maybe_unused]] OuterAcc<INK ? H : 8> oa;
-    for (int i = 0; i < T; ++i) {                   // i-th entry of gms / Gs is step t = T - i
-        const int t = T - i;
-        const float* __restrict__ xprev = t >= 2 ? xs + (int64_t)(t - 2) * step : z;
-        const float4 gmi = ld4(gms + (int64_t)i * step + r * H + 4 * q);
-        float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef EDGE_NB
-#define EDGE_NB 8          // neighbour rows in flight per lane
-#endif
-#pragma unroll
-        for (int k0 = 1; k0 < K; k0 += EDGE_NB) {
-            float4 nb[EDGE_NB];
-#pragma unroll
-            for (int k = k0; k < k0 + EDGE_NB && k < K; ++k) nb[k - k0] = ld4(xprev + (int64_t)j[k] * H + 4 * q);
-#pragma unroll
-            for (int k = k0; k < k0 + EDGE_NB && k < K; ++k) {
-                msg = fma4(sw[k], nb[k - k0], msg);
-                dd[k] += group_sum<L>(dot4(gmi, nb[k - k0]));
-            }
-        }
-        if constexpr (INK) {
-            float4 gi = ld4((i == 0 ? gout : Gs + (int64_t)i * step) + r * H + 4 * q);
-            if (!valid) { msg = make_float4(0.f, 0.f, 0.f, 0.f); gi = msg; }
-            float* ta = s_tile + (threadIdx.x >> 6) * 512;
-            oa.add_rows(msg, gi, ta, ta + 256, lane);
-        } else {
-            if (valid) st4(mts + (int64_t)i * step + r * H + 4 * q, msg);
-        }
-    }
-    // softmax / distance backward from the registers (sim_bwd_fast_kernel's arithmetic)
-    const float4 yi = ld4(y + r * H + 4 * q);
-    float dotv = 0.f;
-#pragma unroll
-    for (int k = 1; k < K; ++k) dotv = fmaf(sw[k], dd[k], dotv);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    dd[0] = 0.f;
-#pragma unroll
-    for (int k0 = 1; k0 < K; k0 += 8) {
-        float4 nb[8];
-#pragma unroll
-        for (int k = k0; k < k0 + 8 && k < K; ++k) nb[k - k0] = ld4(y + (int64_t)j[k] * H + 4 * q);
-#pragma unroll
-        for (int k = k0; k < k0 + 8 && k < K; ++k) {
-            const float wk = -2.0f * sw[k] * (dd[k] - dotv);
-            acc = fma4(wk, sub4(yi, nb[k - k0]), acc);
-            dd[k] = wk;
-        }
-    }
-    store_rows_coalesced<H, K>(dd, w, lane, q, m);
-    if (valid) st4(dy_self + r * H + 4 * q, acc);
-    if constexpr (INK) oa.store_partial(s_red, dp_partial, lane);
 }
 
 // ====================================================================== wide rows (H = 128, 256)
@@ -1444,14 +967,6 @@ __global__ __launch_bounds__(BLOCK) void wide_sim_bwd_kernel(const float* __rest
     acc.store(dy_self + i * H, lane);
 }
 
-static int check_common(int64_t m, int H, int K, int k0) {
-    CRF_REQUIRE(m > 0 && m < (int64_t)1 << 31, CRF_ERR_ARG, "rows m=%lld out of range", (long long)m);
-    CRF_REQUIRE(H == 4 || H == 8 || H == 16 || H == 32 || H == 64, CRF_ERR_UNSUPPORTED,
-                "hidden channels H=%d not in {4,8,16,32,64}", H);
-    CRF_REQUIRE(K >= 1 && K <= 64 && k0 >= 0 && k0 < K, CRF_ERR_ARG, "K=%d k0=%d invalid", K, k0);
-    CRF_REQUIRE(m * K < (int64_t)1 << 31, CRF_ERR_ARG, "edge ids exceed int32 (m=%lld K=%d)", (long long)m, K);
-    return CRF_OK;
-}
 
 // The LDS-window kernels measured SLOWER than the plain gather kernels on MI355X (43.0 vs 39.5 us for the
 // level-0 forward, profiles/r1b): after Morton ordering + XCD-contiguous blocks the gathers are L1/L2 hits
@@ -1459,20 +974,6 @@ static int check_common(int64_t m, int H, int K, int k0) {
 // CRFCONV_WINDOW=1 enables them.
 static const bool g_use_window = (getenv("CRFCONV_WINDOW") != nullptr);
 
-static int kshift_of(int K) {
-    for (int sft = 0; sft < 7; ++sft)
-        if ((1 << sft) == K) return sft;
-    return -1;
-}
-
-#define DISPATCH_H(H, ...)                                      \
-    switch (H) {                                                \
-        case 4: { constexpr int HH = 4; __VA_ARGS__; break; }   \
-        case 8: { constexpr int HH = 8; __VA_ARGS__; break; }   \
-        case 16: { constexpr int HH = 16; __VA_ARGS__; break; } \
-        case 32: { constexpr int HH = 32; __VA_ARGS__; break; } \
-        default: { constexpr int HH = 64; __VA_ARGS__; break; } \
-    }
 
 }  // namespace crf
 
@@ -1495,6 +996,22 @@ extern "C" int crfconv_meanfield_forward_u16(const float* z, const float* y, con
     CRF_REQUIRE(idx16 == nullptr || (n_tgt > 0 && n_src > 0 && n_src <= 65536 && m % n_tgt == 0), CRF_ERR_ARG,
                 "u16 table needs n_src <= 65536 and m a multiple of n_tgt (n_tgt=%d n_src=%d)", n_tgt, n_src);
     return meanfield_forward_impl(z, y, idx32, idx16, n_tgt, n_src, K, k0, m, H, Q, P, T, s, xs, stream);
+}
+
+// the index layout (uint16 local ids / int32 global rows) is a template argument of the fast kernels
+template <int HH, int KK, bool WS>
+static void launch_sim_step(dim3 grid, hipStream_t st, const float* y, const float* z, const int32_t* idx32,
+                            const uint16_t* idx16, int n_tgt, int n_src, const float* Q, const float* P, float* s,
+                            float* x1, int64_t m) {
+    if (idx16) hipLaunchKernelGGL((sim_step_fast_kernel<HH, KK, WS, true>), grid, dim3(BLOCK), 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
+    else hipLaunchKernelGGL((sim_step_fast_kernel<HH, KK, WS, false>), grid, dim3(BLOCK), 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
+}
+template <int HH, int KK>
+static void launch_step(dim3 grid, hipStream_t st, const float* xin, const float* z, const float* s, const int32_t* idx32,
+                        const uint16_t* idx16, int n_tgt, int n_src, const float* Q, const float* P, float* xout,
+                        int64_t m) {
+    if (idx16) hipLaunchKernelGGL((step_fast_kernel<HH, KK, true>), grid, dim3(BLOCK), 0, st, xin, z, s, idx32, idx16, n_tgt, n_src, Q, P, xout, m);
+    else hipLaunchKernelGGL((step_fast_kernel<HH, KK, false>), grid, dim3(BLOCK), 0, st, xin, z, s, idx32, idx16, n_tgt, n_src, Q, P, xout, m);
 }
 
 static int meanfield_forward_impl(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16,
@@ -1532,11 +1049,11 @@ static int meanfield_forward_impl(const float* z, const float* y, const int32_t*
         if (fast) {
             float* x1 = T > 0 ? xs : nullptr;
             if (K == 16) {
-                if (T > 0) hipLaunchKernelGGL((sim_step_fast_kernel<HH, 16, true>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
-                else hipLaunchKernelGGL((sim_step_fast_kernel<HH, 16, false>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
+                if (T > 0) launch_sim_step<HH, 16, true>(grid, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
+                else launch_sim_step<HH, 16, false>(grid, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
             } else {
-                if (T > 0) hipLaunchKernelGGL((sim_step_fast_kernel<HH, 32, true>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
-                else hipLaunchKernelGGL((sim_step_fast_kernel<HH, 32, false>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
+                if (T > 0) launch_sim_step<HH, 32, true>(grid, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
+                else launch_sim_step<HH, 32, false>(grid, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, x1, m);
             }
             t0 = 1;
         } else {
@@ -1546,8 +1063,8 @@ static int meanfield_forward_impl(const float* z, const float* y, const int32_t*
         for (int t = t0; t < T; ++t) {
             const float* xin = t == 0 ? z : xs + (int64_t)(t - 1) * m * H;
             float* xout = xs + (int64_t)t * m * H;
-            if (fast && K == 16) hipLaunchKernelGGL((step_fast_kernel<HH, 16>), grid, blk, 0, st, xin, z, s, idx32, idx16, n_tgt, n_src, Q, P, xout, m);
-            else if (fast) hipLaunchKernelGGL((step_fast_kernel<HH, 32>), grid, blk, 0, st, xin, z, s, idx32, idx16, n_tgt, n_src, Q, P, xout, m);
+            if (fast && K == 16) launch_step<HH, 16>(grid, st, xin, z, s, idx32, idx16, n_tgt, n_src, Q, P, xout, m);
+            else if (fast) launch_step<HH, 32>(grid, st, xin, z, s, idx32, idx16, n_tgt, n_src, Q, P, xout, m);
             else hipLaunchKernelGGL(step_kernel<HH>, grid, blk, 0, st, xin, z, s, idx32, K, k0, Q, P, xout, m);
             CRF_LAUNCH_CHECK();
         }
@@ -1715,90 +1232,6 @@ extern "C" int crfconv_meanfield_forward_fused_stamps(const float* z, const floa
     const dim3 grid((unsigned)cdiv(m, FGeo<8>::PPW * (FUSED_NT / WAVE))), blk(FUSED_NT);
     hipLaunchKernelGGL((mf_fused_kernel<8, 16, FUSED_NT, true>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, (unsigned*)ws, dbg);
     CRF_LAUNCH_CHECK();
-    return CRF_OK;
-}
-
-// ---------------------------------------------------------------------- restructured backward (fast shapes)
-extern "C" int crfconv_meanfield_backward_supported(int H, int K, int k0) {
-    return (k0 == 1 && (K == 16 || K == 32) && (H == 4 || H == 8 || H == 16 || H == 32 || H == 64)) ? 1 : 0;
-}
-
-// 1 when dP and dQ come out of the backward launches themselves (H in {8, 16}); 0 when the caller finishes them from
-// mts / Gs / sumG with crfconv_linear_wgrad
-extern "C" int crfconv_meanfield_backward_param_grads_inside(int H) { return (H == 8 || H == 16) ? 1 : 0; }
-
-static size_t bwd_ws_layout(int64_t m, int H, int K, size_t* off_dp, size_t* off_dq, size_t* off_scratch) {
-    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    size_t o = up((size_t)m * K * sizeof(RevRec));
-    size_t nb_edge = 0, nb_chain = 0;
-    DISPATCH_H(H, { nb_edge = (size_t)cdiv(m, Geo<HH>::PPB); nb_chain = (size_t)cdiv(m, Scat<HH>::RPB); });
-    *off_dp = o; o = up(o + nb_edge * H * H * 4);
-    *off_dq = o; o = up(o + nb_chain * H * H * 4);
-    *off_scratch = o; o = up(o + 2 * RS_CHUNKS * (size_t)H * H * 4);
-    return o;
-}
-
-extern "C" size_t crfconv_meanfield_backward_workspace(int64_t m, int H, int K) {
-    size_t a, b, c;
-    return bwd_ws_layout(m, H, K, &a, &b, &c);
-}
-
-extern "C" int crfconv_meanfield_backward(const float* gout, const float* z, const float* y, const float* s,
-                                          const float* xs, const int32_t* idx32, const uint16_t* idx16, int n_tgt,
-                                          int n_src, const int32_t* rev_ptr, const int32_t* rev_eid, int K, int k0,
-                                          int64_t m, int H, const float* Q, const float* P, int T, float* Gs,
-                                          float* gms, float* mts, float* sumG, float* dz, float* w, float* dy_self,
-                                          float* dy, float* dP, float* dQ, void* ws, size_t ws_bytes,
-                                          unsigned* ticket, crf_stream_t stream) {
-    if (int rc = check_common(m, H, K, k0)) return rc;
-    CRF_REQUIRE(crfconv_meanfield_backward_supported(H, K, k0) == 1 && T >= 1, CRF_ERR_UNSUPPORTED,
-                "restructured mean-field backward: K=%d k0=%d T=%d not supported", K, k0, T);
-    const bool inside = crfconv_meanfield_backward_param_grads_inside(H) == 1;
-    CRF_REQUIRE(gout && z && y && s && xs && idx32 && rev_ptr && rev_eid && Q && P && Gs && gms && dz && w && dy_self &&
-                dy && ws, CRF_ERR_ARG, "null pointer");
-    CRF_REQUIRE(inside ? (dP && dQ && ticket) : (mts && sumG), CRF_ERR_ARG,
-                "H=%d: %s", H, inside ? "dP, dQ and ticket are required" : "mts and sumG are required");
-    size_t off_dp, off_dq, off_scratch;
-    const size_t need = bwd_ws_layout(m, H, K, &off_dp, &off_dq, &off_scratch);
-    CRF_REQUIRE(ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, CRF_ERR_ARG,
-                "workspace of %zu bytes (16-byte aligned), need %zu", ws_bytes, need);
-    CRF_REQUIRE(idx16 == nullptr || (n_tgt > 0 && n_src > 0 && n_src <= 65536 && m % n_tgt == 0), CRF_ERR_ARG,
-                "u16 table needs n_src <= 65536 and m a multiple of n_tgt (n_tgt=%d n_src=%d)", n_tgt, n_src);
-    CRF_REQUIRE((m * K) % 4 == 0, CRF_ERR_ARG, "m K = %lld must be a multiple of 4", (long long)(m * K));
-    hipStream_t st = as_stream(stream);
-    char* wsb = static_cast<char*>(ws);
-    RevRec* rec = reinterpret_cast<RevRec*>(wsb);
-    float* dp_partial = reinterpret_cast<float*>(wsb + off_dp);
-    float* dq_partial = reinterpret_cast<float*>(wsb + off_dq);
-    float* scratch = reinterpret_cast<float*>(wsb + off_scratch);
-    const int64_t E = m * K, step = m * H;
-    DISPATCH_H(H, {
-        const dim3 grid((unsigned)cdiv(m, Geo<HH>::PPB)), sgrid((unsigned)cdiv(m, Scat<HH>::RPB)), blk(BLOCK);
-        hipLaunchKernelGGL(bwd_prepare_kernel<HH>, grid, blk, 0, st, gout, P, s, rev_eid, K, kshift_of(K), gms, rec, m, E,
-                           mts != nullptr ? Gs : (float*)nullptr);     // callers that form dP = m^T G themselves read G_T as Gs[0]
-        CRF_LAUNCH_CHECK();
-        for (int i = 0; i < T; ++i) {            // entry i of Gs / gms belongs to step t = T - i (Gs[0] = G_T = gout: written by the prepare launch only when mts is given)
-            if (i + 1 < T)
-                hipLaunchKernelGGL((bwd_chain_kernel<HH, false>), sgrid, blk, 0, st, gms + i * step, rec, rev_ptr, P, Q,
-                                   Gs + (i + 1) * step, gms + (i + 1) * step, gout, Gs, T, z, sumG, dz, dq_partial, m);
-            else                                 // G_0 = dz's x_0 part; + (sum_t G_t) Q^T; dQ partials
-                hipLaunchKernelGGL((bwd_chain_kernel<HH, true>), sgrid, blk, 0, st, gms + i * step, rec, rev_ptr, P, Q,
-                                   (float*)nullptr, (float*)nullptr, gout, Gs, T, z, sumG, dz, dq_partial, m);
-            CRF_LAUNCH_CHECK();
-        }
-        if (K == 16)
-            hipLaunchKernelGGL((bwd_edge_all_kernel<HH, 16>), grid, blk, 0, st, gms, gout, Gs, xs, z, y, s, idx32, idx16, n_tgt, n_src, T, mts, dp_partial, w, dy_self, m);
-        else
-            hipLaunchKernelGGL((bwd_edge_all_kernel<HH, 32>), grid, blk, 0, st, gms, gout, Gs, xs, z, y, s, idx32, idx16, n_tgt, n_src, T, mts, dp_partial, w, dy_self, m);
-        CRF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(sim_bwd_scatter_kernel<HH>, sgrid, blk, 0, st, w, y, dy_self, rev_ptr, rev_eid, K, kshift_of(K), dy, m);
-        CRF_LAUNCH_CHECK();
-        if (inside) {
-            SmallJob j0{dp_partial, dP, (int)grid.x}, j1{dq_partial, dQ, (int)sgrid.x};
-            hipLaunchKernelGGL(reduce_small_kernel, dim3(RS_CHUNKS), dim3(256), 0, st, j0, j1, HH * HH, scratch, ticket);
-            CRF_LAUNCH_CHECK();
-        }
-    });
     return CRF_OK;
 }
 

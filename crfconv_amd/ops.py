@@ -88,12 +88,12 @@ class _MeanField(torch.autograd.Function):
             _lib.call('crfconv_linear_wgrad', ptr(A), ptr(B), rows, H, H, ptr(out), None, ptr(wws), wbytes, st)
 
         if lib.crfconv_meanfield_backward_supported(H, table.K, k0) == 1 and not _OLD_BWD_ENV:
-            # T + 3 launches: prepare | T chain steps | one edge pass over all steps + softmax backward | dy scatter
-            # (+ one small reduction when dP / dQ are accumulated inside those launches: H in {8, 16})
+            # T + 1 launches (csrc/crf_bwd.hip): T - 1 reverse walks | one edge pass over all steps + softmax backward |
+            # the last reverse walk with the dy scatter and the dP / dQ reduction riding along
             dev = z.device
             inside = lib.crfconv_meanfield_backward_param_grads_inside(H) == 1
             Gs = torch.empty((T, m, H), dtype=torch.float32, device=dev)        # entry 0 unused: G_T = gout
-            gms = torch.empty((T, m, H), dtype=torch.float32, device=dev)
+            dzq = torch.empty((m, H), dtype=torch.float32, device=dev)
             dz, dy_self, dy = (torch.empty_like(z) for _ in range(3))
             w = torch.empty_like(s)
             dP, dQ = torch.empty_like(P), torch.empty_like(Q)
@@ -105,9 +105,9 @@ class _MeanField(torch.autograd.Function):
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             _lib.call('crfconv_meanfield_backward', ptr(G), ptr(z), ptr(y), ptr(s), ptr(xs), ptr(table.idx32),
                       ptr(table.idx16), table.n_tgt, table.n_src, ptr(rev_ptr), ptr(rev_eid), table.K, k0, m, H, ptr(Q),
-                      ptr(P), T, ptr(Gs), ptr(gms), ptr(mts), ptr(sumG), ptr(dz), ptr(w), ptr(dy_self), ptr(dy), ptr(dP),
+                      ptr(P), T, ptr(Gs), ptr(dzq), ptr(mts), ptr(sumG), ptr(dz), ptr(w), ptr(dy_self), ptr(dy), ptr(dP),
                       ptr(dQ), ptr(ws), wsb, ptr(_ticket(dev)), st)
-            if not inside:                                  # (Gs[0] = G was written by the prepare launch)
+            if not inside:                                  # (Gs[0] = G was written by the edge launch)
                 skinny_tn(mts.view(T * m, H), Gs.view(T * m, H), dP)
                 skinny_tn(z, sumG, dQ)
             return dz, dy, dQ, dP, None, None, None

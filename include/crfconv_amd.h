@@ -178,29 +178,32 @@ int crfconv_meanfield_bwd_edge(const float* G, const float* xprev, const float* 
 int crfconv_meanfield_bwd_scatter(const float* gm, const float* s, const int32_t* rev_ptr,
                                   const int32_t* rev_eid, int K, int k0, int64_t m_src, int H,
                                   const float* add, float* Gprev, crf_stream_t stream);
-/* The whole backward of the mean-field loop + similarity for the fast shapes (K in {16, 32}, k0 = 1) as T + 3 (+ 1)
- * launches instead of 2 T + 2 (+ 4 reduction launches) -- autograd of models/continuous_crf_conv_big.py:49-54, 63-72:
- *   prepare: gms[0] = gout P^T; reverse edge records {target row, s[e]} in CSR order (ws)
- *   chain x T: Gs[i+1][j] = sum_{p in rev(j)} s gms[i][target];  gms[i+1] = Gs[i+1] P^T;  the last one forms
- *            sum_i G_i (G_T = gout, Gs[0] is never touched) and dz = G_0 + (sum_i G_i) Q^T instead
+/* The whole backward of the mean-field loop + similarity for the fast shapes (K in {16, 32}, k0 = 1) as T + 1 launches
+ * (csrc/crf_bwd.hip) -- autograd of models/continuous_crf_conv_big.py:49-54, 63-72.  With G_T = gout:
+ *   reverse walk x (T-1): Gs[i+1] = (A^T Gs[i]) P^T for steps t = T .. 2 (G_{t-1} = A^T (G_t P^T) = (A^T G_t) P^T);
+ *            the first one reads rev_eid -> s[e] and leaves {e, s[e]} records in CSR order in ws for the later walks
  *   edge-all: per point, over all T steps with the index / weight rows and ds in registers:
- *            m_i = sum_k s_ik x_{T-i-1}[j]  (x_0 = z), ds += <gms[i], x[j]>, then w = -2 s (ds - <s, ds>),
- *            dy_self = sum_k w_k (y_i - y_j)
- *   scatter: dy[j] = dy_self[j] + sum_{e in rev(j)} w[e] (y_j - y_i).
- * Entry i of Gs / gms / mts [T, m, H] belongs to step t = T - i.
+ *            gm_i = Gs[i] P^T, m_i = sum_k s_ik x_{T-i-1}[j] (x_0 = z), ds += <gm_i, x[j]>, dzq = (sum_i Gs[i]) Q^T,
+ *            then w = -2 s (ds - <s, ds>), dy_self = sum_k w_k (y_i - y_j)
+ *   last reverse walk: dz = (A^T G_1) P^T + dzq and dy[j] = dy_self[j] + sum_{e in rev(j)} w[e] (y_j - y_i) from ONE
+ *            pass over the reverse edge list; extra workgroups of the same launch finish dP, dQ.
+ * The walks are load-balanced (a wavefront takes a contiguous range of the reverse edge list edge by edge and its rows sum
+ * their segments from an LDS tile in edge order): bitwise reproducible, any in-degree.
+ * Entry i of Gs / mts [T, m, H] belongs to step t = T - i; dzq [m, H] is scratch.
  * crfconv_meanfield_backward_param_grads_inside(H) == 1 (H in {8, 16}): dP = sum_i m_i^T G_i and dQ = z^T sum_i G_i
- * are accumulated inside edge-all / the last chain launch on the matrix pipe (16x16x4 f32 MFMA outer products through a
- * per-wave LDS tile) and finished by one small reduction launch into dP, dQ [H, H]; mts and sumG are not touched and
- * may be NULL; ticket = one device word that is ZERO on entry (left zero).  Otherwise mts [T, m, H] and sumG [m, H]
- * are written -- and Gs[0] = G_T = gout, so that Gs is the whole stacked [T, m, H] operand -- and the caller finishes
- * dP = sum_i mts[i]^T Gs[i], dQ = z^T sumG (crfconv_linear_wgrad); dP, dQ, ticket may be NULL.  ws: crfconv_meanfield_backward_workspace(m, H, K) bytes, 16-byte aligned. */
+ * are accumulated inside edge-all on the matrix pipe (16x16x4 f32 MFMA outer products through a per-wave LDS tile) and
+ * finished inside the last launch into dP, dQ [H, H]; mts and sumG are not touched and may be NULL; ticket = one device
+ * word that is ZERO on entry (left zero).  Otherwise mts [T, m, H] and sumG [m, H] are written -- and Gs[0] = G_T = gout,
+ * so that Gs is the whole stacked [T, m, H] operand -- and the caller finishes dP = sum_i mts[i]^T Gs[i], dQ = z^T sumG
+ * (crfconv_linear_wgrad); dP, dQ, ticket may be NULL.  ws: crfconv_meanfield_backward_workspace(m, H, K) bytes, 16-byte
+ * aligned.  m H 4 < 2^31. */
 int crfconv_meanfield_backward_supported(int H, int K, int k0);
 int crfconv_meanfield_backward_param_grads_inside(int H);
 size_t crfconv_meanfield_backward_workspace(int64_t m, int H, int K);
 int crfconv_meanfield_backward(const float* gout, const float* z, const float* y, const float* s, const float* xs,
                                const int32_t* idx32, const uint16_t* idx16, int n_tgt, int n_src,
                                const int32_t* rev_ptr, const int32_t* rev_eid, int K, int k0, int64_t m, int H,
-                               const float* Q, const float* P, int T, float* Gs, float* gms, float* mts, float* sumG,
+                               const float* Q, const float* P, int T, float* Gs, float* dzq, float* mts, float* sumG,
                                float* dz, float* w, float* dy_self, float* dy, float* dP, float* dQ, void* ws,
                                size_t ws_bytes, unsigned* ticket, crf_stream_t stream);
 
