@@ -100,10 +100,12 @@ def _measured_traffic(name, config):
     path = os.path.join(ROOT, 'profiles', name)
     try:
         rec = json.load(open(path))
-        src = os.path.join(ROOT, rec['source'])
-        sha = hashlib.sha1(open(src, 'rb').read()).hexdigest()
-        if sha != rec['source_sha1']:
-            return None, 'stale: %s changed since the PMC passes of %s' % (rec['source'], name)
+        srcs = rec['source'] if isinstance(rec['source'], list) else [rec['source']]
+        h = hashlib.sha1()
+        for src in srcs:                      # sha1 over the concatenation of the kernel sources the measurement covers
+            h.update(open(os.path.join(ROOT, src), 'rb').read())
+        if h.hexdigest() != rec['source_sha1']:
+            return None, 'stale: %s changed since the PMC passes of %s' % (', '.join(srcs), name)
         if any(rec['config'].get(k) != v for k, v in config.items()):
             return None, 'PMC passes of %s cover %s only' % (name, rec['config'])
         return rec['traffic_bytes_per_launch'], 'rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, %s' % rec.get('profile', name)
@@ -125,7 +127,7 @@ def roofline_meanfield(data, dev, H=8, T=3):
                   K, 1, m, H, ptr(Q), ptr(P), T, ptr(s), ptr(xs), st)
     avg, lo = _event_time(launch)
     alg_bytes = m * (4 * (K - 1) + 4 * H * (2 * T + 1))
-    traffic, note = _measured_traffic('r2_meanfield_traffic.json', {'m': m, 'H': H, 'K': K, 'T': T, 'u16': tab.idx16 is not None})
+    traffic, note = _measured_traffic('r3_meanfield_traffic.json', {'m': m, 'H': H, 'K': K, 'T': T, 'u16': tab.idx16 is not None})
     out = {'bound': 'hbm', 'achieved': alg_bytes / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
            'frac': alg_bytes / avg / HBM_PEAK, 'traffic': traffic, 'traffic_source': note,
            'kernel': 'crfconv_meanfield_forward level-0 (sim_step_fast_kernel [similarity + step 1] + %d x step_fast_kernel, '
@@ -175,7 +177,7 @@ def roofline_meanfield_bwd(data, dev, H=8, T=3):
                   None, ptr(dz), ptr(w), ptr(dy_self), ptr(dy), ptr(dP), ptr(dQ), ptr(ws), wsb, ptr(ticket), st)
     avg, lo = _event_time(launch, per=5)
     alg_bytes = m * (2 * (4 * (K - 1) + 4 * H * (2 * T + 1)) + 4 * K + 4)
-    traffic, note = _measured_traffic('r2_meanfield_bwd_traffic.json', {'m': m, 'H': H, 'K': K, 'T': T})
+    traffic, note = _measured_traffic('r3_meanfield_bwd_traffic.json', {'m': m, 'H': H, 'K': K, 'T': T})
     return {'bound': 'hbm', 'achieved': alg_bytes / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
             'frac': alg_bytes / avg / HBM_PEAK, 'traffic': traffic, 'traffic_source': note,
             'kernel': 'crfconv_meanfield_backward level-0 (%d x bwd_rev<chain> + bwd_edge_all + bwd_rev<final>, '
@@ -592,6 +594,17 @@ def main():
         out['roofline'] = roofline_meanfield(data, dev, 8, T)
         out['roofline']['measured_copy_GBps'] = copy_ceiling(dev)
         out['roofline_bwd'] = roofline_meanfield_bwd(data, dev, 8, T)
+        if out['roofline_bwd'] is not None:
+            # forward and backward of the level-0 layer as ONE figure: algorithmic bytes of both over the sum of their
+            # average times (each timed on its own, back to back on the launching stream)
+            rf, rb = out['roofline'], out['roofline_bwd']
+            alg = rf['alg_bytes_per_launch'] + rb['alg_bytes_per_launch']
+            t = (rf['avg_launch_us'] + rb['avg_launch_us']) * 1e-6
+            tr = None if rf['traffic'] is None or rb['traffic'] is None else rf['traffic'] + rb['traffic']
+            out['roofline_fwd_bwd'] = {'bound': 'hbm', 'achieved': alg / t / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                                       'frac': alg / t / HBM_PEAK, 'traffic': tr, 'alg_bytes_per_launch': alg,
+                                       'avg_launch_us': t * 1e6,
+                                       'kernel': 'level-0 mean-field forward + backward (roofline + roofline_bwd)'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(data, net, T, data.y, n_cls, dev)
         print(json.dumps(out))

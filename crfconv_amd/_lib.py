@@ -73,6 +73,7 @@ SIGNATURES = {
     'crfconv_linear_wgrad_workspace': (_sz, [_i64, _i, _i]),
     'crfconv_linear_wgrad': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_gridsync_workspace': (_sz, []),
+    'crfconv_gridsync_fail_word': (_i, []),
     'crfconv_mlp_small_supported': (_i, [_i64, _i, _i]),
     'crfconv_mlp_small_workspace': (_sz, [_i64, _i]),
     'crfconv_mlp_small_forward': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),

@@ -106,12 +106,20 @@ __global__ __launch_bounds__(256) void rev_sort_rows_kernel(const int32_t* __res
         int rank = 0;
         for (int k = 0; k < len; ++k) rank += __shfl(v, k, WAVE) < v ? 1 : 0;
         if (lane < len) rev_eid[beg + rank] = v;
-    } else {                                            // long rows (rare): every lane ranks its ids against the whole row
-        for (int i = lane; i < len; i += 64) {
-            const int32_t v = tmp_eid[beg + i];
+    } else {
+        // long rows (hubs: up_idx tables when many fine points share a coarse one, degenerate clouds): 64 ids of the row per
+        // lane-chunk, ranked against the row in tiles of 64 -- one coalesced load per tile and 64 lane broadcasts, no
+        // dependent global load per comparison (a row of 40960 ids: ~0.1 s instead of ~1e9 dependent loads)
+        for (int i0 = 0; i0 < len; i0 += 64) {
+            const int i = i0 + lane;
+            const int32_t v = i < len ? tmp_eid[beg + i] : 0x7fffffff;
             int rank = 0;
-            for (int k = 0; k < len; ++k) rank += tmp_eid[beg + k] < v ? 1 : 0;
-            rev_eid[beg + rank] = v;
+            for (int t0 = 0; t0 < len; t0 += 64) {
+                const int32_t u = t0 + lane < len ? tmp_eid[beg + t0 + lane] : 0x7fffffff;
+                const int nt = len - t0 < 64 ? len - t0 : 64;
+                for (int k = 0; k < nt; ++k) rank += __shfl(u, k, WAVE) < v ? 1 : 0;
+            }
+            if (i < len) rev_eid[beg + rank] = v;
         }
     }
 }

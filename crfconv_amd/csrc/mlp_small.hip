@@ -157,7 +157,19 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
     const unsigned nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
     unsigned n_in_group, n_groups;
     grid_sync_groups(nblk, bid, n_in_group, n_groups);
-    if (!fused_grid_sync<false>(sync_ws, 1u, n_in_group, n_groups, &s_ok, nullptr, bid)) return;
+    if (!fused_grid_sync<false>(sync_ws, 1u, n_in_group, n_groups, &s_ok, nullptr, bid)) {
+        // The barrier gave up (a workgroup of the launch was never resident: CU mask, reserved CUs, a wrong capacity).  The
+        // FW_FAIL word is set (sticky: ops.check_gridsync / FlatSGD.step raise on it); poison this tile so that the loss
+        // turns NaN instead of training on garbage, and still count out -- the last workgroup out zeroes the barrier
+        // words, so the next launch does not inherit a broken count.
+        if (rv) {
+            const float qnan = __int_as_float(0x7fc00000);
+#pragma unroll
+            for (int t = 0; t < TCO; ++t) st4(A + (int64_t)r * Co + co_base + 16 * t + 4 * g, make_float4(qnan, qnan, qnan, qnan));
+        }
+        fused_exit_reset(sync_ws, nblk, 2);
+        return;
+    }
 
     // ---- coefficients of this workgroup's COLS channels: 256 / COLS groups of COLS threads, group p folds row blocks p,
     // p + parts, ... (fixed order, every load in flight at once), re-based on row block 0's shift
@@ -267,6 +279,10 @@ static int mlp_small_tco(int64_t M, int Co, int cap) {
 using namespace crf;
 
 extern "C" size_t crfconv_gridsync_workspace(void) { return FW_WORDS * sizeof(unsigned); }
+
+// index (in 32-bit words) of the sticky failure word inside a barrier workspace: non-zero after a launch whose grid
+// barrier gave up (0x100 | phase).  The host reads it once per step / every few steps and raises.
+extern "C" int crfconv_gridsync_fail_word(void) { return FW_FAIL * FW_LINE; }
 
 // 1 when crfconv_mlp_small_forward applies: m <= 4096 rows, Ci a multiple of 16, Co a multiple of 64 (both <= 1024), and
 // the (m / 64) x (Co / 64) workgroups fit the device at once.  Needs a GPU (occupancy query); 0 otherwise.

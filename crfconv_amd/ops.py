@@ -447,7 +447,7 @@ def discrete_meanfield(p, u, w, C, table, steps):
 # like DDP's) finishes all of them and installs / accumulates ``.grad`` of the weight and bias parameters directly.
 # Opt-in because it bypasses autograd for those leaves: ``torch.autograd.grad(loss, weight)`` sees nothing, and
 # gradient hooks on the weights do not fire.  ``loss.backward()`` + ``param.grad`` behave as usual.
-_DEFER = {'on': False, 'jobs': [], 'folds': [], 'mlpdw': [], 'armed': False}
+_DEFER = {'on': False, 'jobs': [], 'folds': [], 'mlpdw': [], 'armed': False, 'claimed': set()}
 
 
 class deferred_weight_grads:
@@ -466,7 +466,7 @@ class deferred_weight_grads:
         _DEFER['on'] = bool(self.enabled)
         _DEFER['sink'] = self.sink
         if not self.prev:                 # outermost context: nothing of an earlier (failed) backward may linger
-            _DEFER['jobs'], _DEFER['folds'], _DEFER['mlpdw'], _DEFER['armed'] = [], [], [], False
+            _DEFER['jobs'], _DEFER['folds'], _DEFER['mlpdw'], _DEFER['armed'], _DEFER['claimed'] = [], [], [], False, set()
         return self
 
     def __exit__(self, exc_type, *exc):
@@ -475,7 +475,7 @@ class deferred_weight_grads:
         if exc_type is not None and not self.prev:
             # the backward raised after arming the engine callback: drop its queued partials, or every later backward
             # would find 'armed' set, never queue the callback again and silently lose all Linear weight gradients
-            _DEFER['jobs'], _DEFER['folds'], _DEFER['mlpdw'], _DEFER['armed'] = [], [], [], False
+            _DEFER['jobs'], _DEFER['folds'], _DEFER['mlpdw'], _DEFER['armed'], _DEFER['claimed'] = [], [], [], False, set()
         return False
 
 
@@ -491,9 +491,10 @@ def _param_out(prm, shape, dev):
     else a new tensor that goes back through autograd.  Returns (tensor, direct)."""
     sink = _DEFER.get('sink') if _DEFER['on'] else None
     if (sink is not None and isinstance(prm, torch.nn.Parameter) and prm.is_leaf and prm.requires_grad and prm.grad is None
-            and prm.dtype == torch.float32):
+            and prm.dtype == torch.float32 and id(prm) not in _DEFER['claimed']):
         dst = sink(prm)
         if dst is not None and dst.dtype == torch.float32 and dst.is_contiguous() and dst.numel() == prm.numel():
+            _DEFER['claimed'].add(id(prm))     # a second use of the parameter in this backward (shared weights) sums into it
             return dst.view(shape), True
     return torch.empty(shape, dtype=torch.float32, device=dev), False
 
@@ -558,6 +559,21 @@ def _mlp_param_rets(prm, outs, deferred, ws, m, ci, co, coef):
             _param_ret(prm[2], dbeta, kb))
 
 
+def _install_grad(prm, gr, direct):
+    """Gradient `gr` of one use of `prm` becomes / joins ``prm.grad``.  direct: `gr` IS the caller's storage for the
+    parameter (a flat-bucket slice) -- it stays the ``.grad`` tensor and earlier contributions are added INTO it, so that
+    views held by the caller stay valid; a parameter used twice in one backward (shared weights) sums."""
+    gr = gr.view_as(prm)
+    if prm.grad is None:
+        prm.grad = gr
+    elif direct:
+        if prm.grad.data_ptr() != gr.data_ptr():
+            gr.add_(prm.grad)
+            prm.grad = gr
+    else:
+        prm.grad.add_(gr)
+
+
 def _flush_mlp_dw():
     jobs, _DEFER['mlpdw'] = _DEFER['mlpdw'], []
     if not jobs:
@@ -565,11 +581,7 @@ def _flush_mlp_dw():
     table = (_lib.MlpDwJob * len(jobs))(*[j[0] for j in jobs])
     _lib.call('crfconv_mlp_dw_jobs', ctypes.cast(table, ctypes.c_void_p), len(jobs), stream_ptr())
     for _, _, (prm, gr, direct) in jobs:
-        gr = gr.view_as(prm)
-        if direct or prm.grad is None:
-            prm.grad = gr
-        else:
-            prm.grad.add_(gr)
+        _install_grad(prm, gr, direct)
 
 
 def _flush_fold1_bwd():
@@ -580,11 +592,7 @@ def _flush_fold1_bwd():
     _lib.call('crfconv_pointconv_fold1_bwd_batched', ctypes.cast(table, ctypes.c_void_p), len(folds), stream_ptr())
     for _, _, installs in folds:
         for prm, gr, direct in installs:
-            gr = gr.view_as(prm)
-            if direct or prm.grad is None:
-                prm.grad = gr
-            else:
-                prm.grad.add_(gr)
+            _install_grad(prm, gr, direct)
 
 
 def _flush_weight_grads():
@@ -592,16 +600,18 @@ def _flush_weight_grads():
     _flush_fold1_bwd()
     _flush_mlp_dw()
     if not jobs:
+        _DEFER['claimed'] = set()
         return
     dev = jobs[0][2].device
     sink = _DEFER.get('sink')
 
     def direct(prm):                       # the caller's own gradient storage for this parameter, if it can be used as is
-        if sink is None or prm.grad is not None:
-            return None
+        if sink is None or prm.grad is not None or id(prm) in _DEFER['claimed']:
+            return None                    # (claimed: an earlier job of this pass already writes there -- this one is added)
         dst = sink(prm)
         if dst is None or dst.dtype != torch.float32 or not dst.is_contiguous() or dst.numel() != prm.numel():
             return None
+        _DEFER['claimed'].add(id(prm))
         return dst
     targets = [(direct(W), direct(b) if b is not None else None) for W, b, _, _, _, _ in jobs]
     total = sum((Co * Ci if tw is None else 0) + (Co if (b is not None and tb is None) else 0)
@@ -611,26 +621,25 @@ def _flush_weight_grads():
     installs, n, o = [], 0, 0
     for (W, b, ws, nblk, Co, Ci), (tw, tb) in zip(jobs, targets):
         base = ws.data_ptr()
+        dw = tw is not None
         if tw is None:
             tw = flat[o:o + Co * Ci].view(Co, Ci)
             o += Co * Ci
         table[n] = _lib.ReduceJob(base, tw.data_ptr(), nblk, Co * Ci)
-        installs.append((W, tw))
+        installs.append((W, tw, dw))
         n += 1
         if b is not None:
+            db = tb is not None
             if tb is None:
                 tb = flat[o:o + Co]
                 o += Co
             table[n] = _lib.ReduceJob(base + 4 * nblk * Co * Ci, tb.data_ptr(), nblk, Co)
-            installs.append((b, tb))
+            installs.append((b, tb, db))
             n += 1
     _lib.call('crfconv_reduce_jobs', ctypes.cast(table, ctypes.c_void_p), n, stream_ptr())
-    for prm, gr in installs:
-        gr = gr.view_as(prm)
-        if prm.grad is None:
-            prm.grad = gr
-        else:
-            prm.grad.add_(gr)             # in place: views of .grad held by the caller (flat buckets) stay valid
+    for prm, gr, was_direct in installs:
+        _install_grad(prm, gr, was_direct)
+    _DEFER['claimed'] = set()
 
 
 # ------------------------------------------------------------------------------ per-point Linear
@@ -1027,6 +1036,31 @@ class _MLPDropoutLinear(torch.autograd.Function):
         return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, None, None, None, None, dW2, db2
 
 
+def dropout_seed(ci, co):
+    """Seed of the counter-based dropout mask of a fused MLP -> Dropout block with `ci` inputs and `co` outputs (a
+    function of torch.initial_seed() and the layer shape)."""
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + co * 7919 + ci) & 0xFFFFFFFFFFFFFFFF
+
+
+def dropout_keep_mask(seed, counter, n, p):
+    """The mask csrc/common.hpp::dropout_keep draws for elements 0 .. n-1 of the call with (seed, counter), evaluated on
+    the HOST (numpy bool array, True = kept): element e is kept iff the top 32 bits of a splitmix64 round of
+    (seed, counter, e) reach p 2^32.  `counter` = the classifier BatchNorm's num_batches_tracked AFTER the forward (the
+    forward advances it before the kernel reads it).  A caller -- the parity tests -- hands the same mask to another
+    implementation of the network."""
+    import numpy as np
+    t = float(p) * 4294967296.0
+    thr = np.uint64(0xffffffff if t >= 4294967295.0 else (0 if t <= 0.0 else int(t)))
+    with np.errstate(over='ignore'):
+        e = np.arange(int(n), dtype=np.uint64)
+        z = (e * np.uint64(0xD1B54A32D192ED03)
+             + np.uint64((int(seed) + 0x9E3779B97F4A7C15 * (int(counter) + 1)) & 0xFFFFFFFFFFFFFFFF))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return (z >> np.uint64(32)) >= thr
+
+
 def mlp_dropout_linear(x, W, bn, slope, p, W2, b2):
     """Linear(dropout(lrelu(BatchNorm_train(x W^T), slope), p)) as one node (see _MLPDropoutLinear) where the fused dropout
     block and the MFMA Linear both apply, else None."""
@@ -1040,7 +1074,7 @@ def mlp_dropout_linear(x, W, bn, slope, p, W2, b2):
     require_gpu(x, W, W2)
     tick(bn)
     mom = 0.1 if bn.momentum is None else bn.momentum
-    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + co * 7919 + ci) & 0xFFFFFFFFFFFFFFFF     # as mlp_block_dropout
+    seed = dropout_seed(ci, co)                          # as mlp_block_dropout
     out = _MLPDropoutLinear.apply(x.reshape(-1, ci), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, slope,
                                   p, seed, bn.num_batches_tracked, W2, b2)
     return out.reshape(x.shape[:-1] + (c2,))
@@ -1059,7 +1093,7 @@ def mlp_block_dropout(x, W, bn, slope, p):
     require_gpu(x, W)
     tick(bn)                                              # advances the counter the mask is keyed on (unless the model already did)
     mom = 0.1 if bn.momentum is None else bn.momentum
-    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + co * 7919 + ci) & 0xFFFFFFFFFFFFFFFF     # stable per layer shape
+    seed = dropout_seed(ci, co)                          # stable per layer shape
     out = _MLPBlockDropout.apply(x.reshape(-1, ci), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, slope,
                                  p, seed, bn.num_batches_tracked)
     return out.reshape(x.shape[:-1] + (co,))
@@ -1224,8 +1258,38 @@ def gridsync_ws(dev):
     return ws
 
 
+_small_mlp_disabled = False       # set by check_gridsync after a barrier failure: the two-launch path from then on
+
+
 def _mlp_small_ok(m, ci, co):
-    return (not _NO_SMALL_MLP_ENV) and m < _MFMA_MIN_ROWS and _lib.load().crfconv_mlp_small_supported(m, ci, co) == 1
+    return (not _NO_SMALL_MLP_ENV) and (not _small_mlp_disabled) and m < _MFMA_MIN_ROWS \
+        and _lib.load().crfconv_mlp_small_supported(m, ci, co) == 1
+
+
+def check_gridsync(dev=None):
+    """Raises CrfConvError when a one-launch kernel's grid barrier has timed out on `dev` since the last check (its
+    workgroups were not all resident -- CU mask, reserved CUs; the launch's outputs were NaN-poisoned).  One 4-byte
+    device read (a synchronisation): FlatSGD.step() calls it every `check_every` eager steps, a loop that replays
+    captured graphs should call it once per epoch / logging interval.  After a failure the one-launch MLP path is
+    switched off for the rest of the process (vendor GEMM + bn_small instead), so a caller that catches the error can
+    re-run the step."""
+    global _small_mlp_disabled
+    word = _lib.load().crfconv_gridsync_fail_word()
+    bad = []
+    for table in (_sync_ws, {getattr(d, 'index', d): w.view(torch.int32) for d, w in _FUSED_WS.items()}):
+        for key, ws in table.items():
+            if dev is not None and getattr(dev, 'index', dev) not in (None, key):
+                continue
+            code = int(ws[word].item())
+            if code != 0:
+                ws.zero_()                                    # barrier counts and the flag: a clean slate for the retry
+                bad.append((key, code))
+    if bad:
+        _small_mlp_disabled = True
+        raise _lib.CrfConvError('grid barrier timed out on device(s) %s (code 0x%x): a one-launch kernel could not get all its '
+                                'workgroups resident; its outputs were poisoned with NaN.  The one-launch MLP path is now '
+                                'disabled for this process (CRFCONV_NO_SMALL_MLP=1 does the same up front).'
+                                % ([k for k, _ in bad], bad[0][1]))
 
 
 class _MLPSmall(torch.autograd.Function):

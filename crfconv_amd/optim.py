@@ -22,8 +22,9 @@ from .graph import ptr, require_gpu, stream_ptr
 
 
 class FlatSGD(torch.optim.Optimizer):
-    def __init__(self, bucket, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
-        """`bucket`: distributed.FlatGradAllReduce of the model (owns the flat gradient vector)."""
+    def __init__(self, bucket, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, check_every=64):
+        """`bucket`: distributed.FlatGradAllReduce of the model (owns the flat gradient vector).  check_every: eager steps
+        between two reads of the grid-barrier failure flag (ops.check_gridsync; 0 = never)."""
         if nesterov and (momentum <= 0 or dampening != 0):
             raise ValueError('Nesterov momentum requires a momentum and zero dampening')
         self.bucket = bucket
@@ -40,6 +41,7 @@ class FlatSGD(torch.optim.Optimizer):
             o += p.numel()
         self.buf = torch.zeros_like(self.flat)
         self.steps = 0
+        self.check_every = int(check_every)
         super().__init__(params, dict(lr=float(lr), momentum=float(momentum), dampening=float(dampening),
                                       weight_decay=float(weight_decay), nesterov=bool(nesterov)))
         self._hyper = torch.zeros(4, dtype=torch.float32, device=self.flat.device)
@@ -90,6 +92,9 @@ class FlatSGD(torch.optim.Optimizer):
         _lib.call('crfconv_sgd_step_hyper', ptr(self.flat), ptr(self.bucket.flat), ptr(self.buf), self.flat.numel(),
                   ptr(self._hyper), 1 if g['nesterov'] else 0, 1 if first else 0, stream_ptr())   # zero buffer: mu * 0 + g = g
         self.steps += 1
+        if not capturing and self.check_every > 0 and self.steps % self.check_every == 0:
+            from . import ops
+            ops.check_gridsync(self.flat.device)            # a one-launch kernel whose barrier gave up must not train on
         return loss
 
     def state_dict(self):

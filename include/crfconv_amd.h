@@ -392,6 +392,9 @@ int crfconv_reduce_jobs(const crf_reduce_job* jobs, int njobs, crf_stream_t stre
  * workspace: crfconv_mlp_small_workspace bytes.  sync_ws: crfconv_gridsync_workspace() bytes that are ZERO before the
  * first launch using them (the kernel leaves them zero; word 17 * 32 is non-zero only after a barrier that gave up). */
 size_t crfconv_gridsync_workspace(void);
+/* word index of the sticky failure flag inside that workspace (non-zero once a grid barrier timed out: the launch's
+ * outputs are NaN-poisoned; the host must raise -- crfconv_amd.ops.check_gridsync) */
+int crfconv_gridsync_fail_word(void);
 int crfconv_mlp_small_supported(int64_t M, int Ci, int Co);
 size_t crfconv_mlp_small_workspace(int64_t M, int Co);
 int crfconv_mlp_small_forward(const float* X, const float* W, int64_t M, int Ci, int Co, const float* gamma,

@@ -1,7 +1,7 @@
 """Turns the summary of scratch/pmc.sh (level-0 mean-field passes of scratch/mf_pmc.py) into the committed provenance
-files: profiles/r2_meanfield_traffic.json, profiles/r2_meanfield_bwd_traffic.json (HBM-side bytes per launch + sha1 of the
-kernel source they were measured on) and profiles/r2b_meanfield_pmc.md (the raw counter means).
-usage: python3 scratch/traffic_json.py gpurun_out/pmc_r2g_summary.txt"""
+files: profiles/r3_meanfield_traffic.json, profiles/r3_meanfield_bwd_traffic.json (HBM-side bytes per launch + sha1 of the
+kernel source they were measured on) and profiles/r3a_meanfield_pmc.md (the raw counter means).
+usage: python3 scratch/traffic_json.py gpurun_out/pmc_r3a_summary.txt"""
 import hashlib, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 txt = open(sys.argv[1]).read()
@@ -15,25 +15,36 @@ def hbm_bytes(name):           # FETCH_SIZE counts half the bytes on gfx950 (MI3
 
 
 T = 3
-fwd = hbm_bytes('crf::sim_step_fast_kernel<8, 16, true>') + (T - 1) * hbm_bytes('crf::step_fast_kernel<8, 16>')
-bwd = (hbm_bytes('crf::bwd_prepare_kernel<8>') + (T - 1) * hbm_bytes('crf::bwd_chain_kernel<8, false>')
-       + hbm_bytes('crf::bwd_chain_kernel<8, true>') + hbm_bytes('crf::bwd_edge_all_kernel<8, 16>')
-       + hbm_bytes('crf::sim_bwd_scatter_kernel<8>') + hbm_bytes('crf::reduce_small_kernel'))
-src = 'crfconv_amd/csrc/crf.hip'
-sha = hashlib.sha1(open(os.path.join(ROOT, src), 'rb').read()).hexdigest()
+FWD_FIRST, FWD_STEP = 'crf::sim_step_fast_kernel<8, 16, true, true>', 'crf::step_fast_kernel<8, 16, true>'
+REV_FIRST, REV_CHAIN, REV_FINAL = ('crf::bwd_rev_kernel<8, 2, 3, 0, true, 4>', 'crf::bwd_rev_kernel<8, 2, 3, 0, false, 4>',
+                                   'crf::bwd_rev_kernel<8, 4, 2, 1, false, 4>')
+EDGE = 'crf::bwd_edge_all_kernel<8, 16, true>'
+fwd = hbm_bytes(FWD_FIRST) + (T - 1) * hbm_bytes(FWD_STEP)
+bwd = hbm_bytes(REV_FIRST) + (T - 2) * hbm_bytes(REV_CHAIN) + hbm_bytes(EDGE) + hbm_bytes(REV_FINAL)
+fsrc = ['crfconv_amd/csrc/crf.hip', 'crfconv_amd/csrc/crf_common.hpp']
+bsrc = ['crfconv_amd/csrc/crf_bwd.hip', 'crfconv_amd/csrc/crf_common.hpp']
+
+
+def sha_of(srcs):
+    h = hashlib.sha1()
+    for src in srcs:
+        h.update(open(os.path.join(ROOT, src), 'rb').read())
+    return h.hexdigest()
+
+
 how = ('rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (scratch/pmc.sh, scratch/mf_pmc.py, scratch/traffic_json.py); '
        'bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per the gfx950 correction of MI355X_MICROARCH.md; ')
 cfg = {'m': 163840, 'H': 8, 'K': 16, 'T': T, 'u16': True}
-for name, val, what in (('r2_meanfield_traffic.json', fwd, 'sim_step_fast_kernel + 2 x step_fast_kernel'),
-                        ('r2_meanfield_bwd_traffic.json', bwd, 'bwd_prepare + 2 x bwd_chain<false> + bwd_chain<true> + bwd_edge_all + sim_bwd_scatter + reduce_small')):
-    json.dump({'config': cfg, 'source': src, 'source_sha1': sha, 'traffic_bytes_per_launch': val,
-               'profile': 'profiles/r2b_meanfield_pmc.md', 'how': how + what}, open(os.path.join(ROOT, 'profiles', name), 'w'), indent=1)
+for name, val, srcs, what in (('r3_meanfield_traffic.json', fwd, fsrc, 'sim_step_fast_kernel + 2 x step_fast_kernel'),
+                              ('r3_meanfield_bwd_traffic.json', bwd, bsrc, 'bwd_rev<chain, first> + bwd_rev<chain> + bwd_edge_all + bwd_rev<final>')):
+    json.dump({'config': cfg, 'source': srcs, 'source_sha1': sha_of(srcs), 'traffic_bytes_per_launch': val,
+               'profile': 'profiles/r3a_meanfield_pmc.md', 'how': how + what}, open(os.path.join(ROOT, 'profiles', name), 'w'), indent=1)
     print(name, '%.1f MB' % (val / 1e6))
-with open(os.path.join(ROOT, 'profiles', 'r2b_meanfield_pmc.md'), 'w') as f:
-    f.write('# rocprofv3 --pmc passes, level-0 mean-field forward + backward (m = 163840, H = 8, K = 16, T = 3), MI355X, round 2\n'
+with open(os.path.join(ROOT, 'profiles', 'r3a_meanfield_pmc.md'), 'w') as f:
+    f.write('# rocprofv3 --pmc passes, level-0 mean-field forward + backward (m = 163840, H = 8, K = 16, T = 3), MI355X, round 3\n'
             '# scratch/pmc.sh <outdir> <regex> scratch/mf_pmc.py ; FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE counts half the bytes on gfx950;\n'
-            '# SQ_* counters as rocprofv3 reports them (counter units not converted).  crf.hip sha1 %s\n'
-            '# forward HBM-side bytes per call = %.1f MB, backward = %.1f MB (algorithmic: 46.5 MB / 104.2 MB)\n\n' % (sha, fwd / 1e6, bwd / 1e6))
+            '# SQ_* counters as rocprofv3 reports them (counter units not converted).  sha1 forward sources %s, backward sources %s\n'
+            '# forward HBM-side bytes per call = %.1f MB, backward = %.1f MB (algorithmic: 46.5 MB / 104.2 MB)\n\n' % (sha_of(fsrc), sha_of(bsrc), fwd / 1e6, bwd / 1e6))
     f.write('| kernel | waves | SQ_WAVE_CYCLES / SQ_WAVES | waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES) | vector-memory reads | fetched MB | written MB |\n|---|---|---|---|---|---|---|\n')
     for k in sorted(blocks):
         d = blocks[k]

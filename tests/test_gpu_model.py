@@ -17,6 +17,14 @@ OUT_TOL = 1e-4
 GRAD_TOL = 2e-4
 
 
+def _report_err(what, got, ref64):
+    """max |got - ref| per element (absolute) beside the normalised figure the tolerances are stated on."""
+    a = float((got.detach().cpu().double() - ref64).abs().max())
+    n = a / max(1.0, float(ref64.abs().max()))
+    print('%-40s max abs err %.3e   normalised %.3e   (max |ref| %.3e)' % (what, a, n, float(ref64.abs().max())))
+    return a, n
+
+
 def knn_tables(B, N, K, seed):
     pos = np.stack([S.make_cloud(seed + b, N) for b in range(B)])
     return pos, onative.oracle_knn_batch(pos, pos, K)
@@ -664,14 +672,14 @@ def test_config5_shape_network_k32_t5_vs_oracle():
     assert worst[0] <= 3e-3, 'worst gradient %s: %.2e' % (worst[1], worst[0])
 
 
-def _eval_net_vs_oracle(pos, feats, in_ch, ncls, steps, seed, name, g, ratio=(4, 4, 4, 4, 2)):
+def _eval_net_vs_oracle(pos, feats, in_ch, ncls, steps, seed, name, g, ratio=(4, 4, 4, 4, 2), kernel_size=(16,) * 5):
     """Whole PointConvBig in eval mode on `pos` [B, N, 3] / `feats` [B, N, in_ch]: per-point logits within 1e-4 of the
     CPU oracle and the same arg-max labels ("mIoU parity": identical confusion matrix up to provably ambiguous rows)."""
     import crfconv_amd
     from crfconv_amd import models
     from crfconv_amd.utils import runningScore
     B, N = pos.shape[:2]
-    data = crfconv_amd.multiscale_compute(pos.to(DEV), x=feats.to(DEV), generator=g, ratio=ratio)
+    data = crfconv_amd.multiscale_compute(pos.to(DEV), x=feats.to(DEV), generator=g, ratio=ratio, kernel_size=kernel_size)
     net = models.PointConvBig(in_ch, ncls, use_crf=True, steps=steps)
     sd = S.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed)
     net.load_state_dict(sd)
@@ -691,6 +699,7 @@ def _eval_net_vs_oracle(pos, feats, in_ch, ncls, steps, seed, name, g, ratio=(4,
         ms64 = [{k: (v.double() if v.is_floating_point() else v) for k, v in l.items()} for l in ms]
         ref64 = O.pointconv_resnet({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()},
                                    data.x.cpu().double(), ms64, steps, False, True)
+    _report_err(name + ' eval logits', logits, ref64)
     assert_close_anchored(logits, ref, ref64, OUT_TOL, name + ' logits')
     scale = max(1.0, float(ref64.abs().max()))
     row_err = (logits.detach().cpu().double() - ref64).abs().max(1).values / scale
@@ -721,6 +730,39 @@ def test_config3_inference_matches_oracle():
     _eval_net_vs_oracle(pos, feats, 4, ncls, 1, 9, 'config-3', g)
 
 
+def _voxel_cloud(rng, n, dims, vox=0.04):
+    flat = rng.choice(int(np.prod(dims)), size=n, replace=False)
+    ijk = np.stack(np.unravel_index(flat, dims), -1).astype(np.float64)
+    return ((ijk + 0.5) * vox + rng.uniform(-0.01, 0.01, (n, 3))).astype(np.float32)
+
+
+def test_config4_whole_network_matches_oracle_full_size():
+    """BASELINE.json config 4 at one GPU's share: 4 clouds x 81 920 points of a 6 x 6 x 3 m indoor box (one point per
+    4 cm voxel), K = 16, three mean-field steps, 20 classes -- the WHOLE PointConvBig in eval mode against the CPU
+    oracle (float32, anchored on float64), and the confusion matrix."""
+    g = torch.Generator().manual_seed(4)
+    rng = np.random.default_rng(4)
+    B, N = 4, 81920
+    pos = torch.from_numpy(np.stack([_voxel_cloud(rng, N, (150, 150, 75)) for _ in range(B)]))
+    feats = torch.cat([pos, torch.rand(B, N, 3, generator=g)], -1)
+    _eval_net_vs_oracle(pos, feats, 6, 20, 3, 14, 'config-4', g)
+
+
+def test_config5_crop_whole_network_matches_oracle_full_size():
+    """BASELINE.json config 5, ONE crop at full size: the 65 536 points of a 1 M-point-per-(60 x 60 x 15 m)-scene density
+    nearest to a seed (semantic3d_dataset.py:433: a kNN ball), K = 32 at every level, FIVE mean-field steps, 8 classes,
+    eval mode (B = 1) -- whole-network logits against the CPU oracle."""
+    g = torch.Generator().manual_seed(5)
+    N, ncls = 65536, 8
+    # scene density: 1 048 576 points in 54 000 m^3 -> a ball of 65 536 points has radius ~9.3 m, clipped by the 15 m ceiling;
+    # draw 3x the points in the bounding cylinder and keep the N nearest to the seed
+    cand = torch.rand(6 * N, 3, generator=g) * torch.tensor([24.0, 24.0, 15.0]) - torch.tensor([12.0, 12.0, 7.5])
+    near = cand.norm(dim=1).argsort()[:N]
+    pos = cand[near].unsqueeze(0).contiguous()
+    feats = torch.cat([pos, torch.rand(1, N, 3, generator=g)], -1)
+    _eval_net_vs_oracle(pos, feats, 6, ncls, 5, 15, 'config-5 crop', g, kernel_size=(32,) * 5)
+
+
 def test_config2_headline_inference_matches_oracle():
     """BASELINE.json config 2 -- the shape the bench line is quoted on: 4 clouds x 40 960 points, one point per 4 cm
     voxel of an 8 x 8 x 3 m box, K = 16, three mean-field steps, 13 classes.  Whole-network eval logits
@@ -737,6 +779,98 @@ def test_config2_headline_inference_matches_oracle():
     pos = torch.from_numpy(pos)
     feats = torch.cat([pos, torch.rand(B, N, 3, generator=g)], -1)
     _eval_net_vs_oracle(pos, feats, 6, 13, 3, 12, 'config-2', g)
+
+
+def test_benchmarked_training_step_replayed_graph_matches_oracle_config2():
+    """The path bench.py TIMES, end to end, against the oracle at BASELINE config 2 (4 x 40 960 points, K = 16, T = 3):
+    `part_a` exactly as bench.py builds it -- zero grads, PointConvBig forward in train mode (BatchNorm-1 prefold, fork
+    chain, classifier MLP -> Dropout -> Linear as ONE node with the counter-based mask), weighted cross entropy, backward
+    under ``deferred_weight_grads(sink=bucket.view_of)``, ``bucket.pack()`` -- captured into a hipGraph and REPLAYED.  The
+    oracle (trainval.py:99-106 on oracle/crf_oracle.py) gets the same dropout mask (ops.dropout_keep_mask: the mask is a
+    function of (seed, num_batches_tracked, element)); logits, loss and the WHOLE flat gradient bucket are compared, the
+    float32 oracle anchored on its own float64 run."""
+    import bench
+    import crfconv_amd
+    from crfconv_amd import distributed as D
+    from crfconv_amd import models, ops
+    B, N, T, ncls = 4, 40960, 3, 13
+    dev = torch.device('cuda', 0)
+    gen = torch.Generator().manual_seed(77)
+    data, _ = bench.make_batch(0, B, N, dev, gen, 'morton')
+    torch.manual_seed(5)
+    net = models.PointConvBig(6, ncls, use_crf=True, steps=T)
+    sd = S.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 31)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    assert type(net.classifier[1]) is nn.Dropout            # the fused MLP -> Dropout -> Linear node is what runs
+    bucket = D.FlatGradAllReduce(net)
+    cw = (0.5 + torch.rand(ncls, generator=gen)).to(dev)    # non-uniform class weights (configure.py:44-47 style)
+    unit = torch.ones((), device=dev)
+    keep = {}
+
+    def part_a():
+        bucket.zero()
+        logits = net(data)
+        keep['logits'] = logits
+        loss = ops.training_loss(logits, data.y, cw, ignore_index=-1)
+        with ops.deferred_weight_grads(sink=bucket.view_of):
+            loss.backward(unit)
+        bucket.pack()
+        return loss.detach()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            part_a()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ga = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(ga):
+        static_loss = part_a()
+    ga.replay()
+    ga.replay()
+    torch.cuda.synchronize()
+    logits, loss, flat = keep['logits'].clone(), static_loss.clone(), bucket.flat.clone()
+    bn = net.classifier[0].bn.batch_norm
+    ctr = int(bn.num_batches_tracked)
+    assert ctr >= 4                                         # 2 warm-up passes + 2 replays (the capture itself runs nothing): a device word
+    mask = ops.dropout_keep_mask(ops.dropout_seed(32, 128), ctr, B * N * 128, 0.5).reshape(B, N, 128)
+    kept = float(mask.mean())
+    assert 0.499 < kept < 0.501
+    # the mask the kernel drew: dropped elements of the classifier's hidden tensor are exact zeros
+    # (checked through the oracle comparison below: a wrong mask moves the logits by O(1))
+    ms = [{k: getattr(l, k).cpu() for k in ('pos', 'neighbor_idx', 'sub_idx', 'up_idx') if getattr(l, k, None) is not None}
+          for l in data.multiscale]
+    names = [k for k, p in net.named_parameters() if p.requires_grad]
+    assert [id(p) for p in bucket.params] == [id(dict(net.named_parameters())[k]) for k in names]
+    torch.set_num_threads(16)
+    res = {}
+    for tag, cast in (('f32', lambda v: v.clone()), ('f64', lambda v: v.double() if v.is_floating_point() else v.clone())):
+        prm = {k: cast(v).requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+        msx = [{k: cast(v) for k, v in l.items()} for l in ms]
+        ref_t = O.pointconv_resnet(prm, cast(data.x.cpu()), msx, T, True, True, dropout_mask=cast(torch.from_numpy(mask).float()))
+        ref_loss = O.training_loss(ref_t, data.y.cpu(), cast(cw.cpu()))
+        ref_loss.backward()
+        res[tag] = (ref_t.detach(), ref_loss.detach(), torch.cat([prm[k].grad.reshape(-1) for k in names]).detach())
+        del prm, msx, ref_t, ref_loss
+    (t32, l32, g32), (t64, l64, g64) = res['f32'], res['f64']
+    _report_err('config-2 replayed train logits', logits, t64)
+    _report_err('config-2 replayed loss', loss, l64)
+    _report_err('config-2 replayed flat gradient bucket', flat, g64)
+    assert_close_anchored(logits, t32, t64, 5e-4, 'replayed train logits')          # BatchNorm in train mode: see DESIGN 4
+    assert_close_anchored(loss, l32, l64, 1e-4, 'replayed loss')
+    assert flat.numel() == g64.numel()
+    # per parameter tensor, relative to that tensor's largest gradient entry
+    o, worst = 0, (0.0, '')
+    for k in names:
+        n = dict(net.named_parameters())[k].numel()
+        e = relerr(flat[o:o + n], g64[o:o + n])
+        e32 = relerr(g32[o:o + n], g64[o:o + n])
+        assert e <= max(3e-3, 4.0 * e32), '%s: gradient err %.2e (fp32 oracle %.2e)' % (k, e, e32)
+        worst = max(worst, (e, k))
+        o += n
+    print('worst parameter gradient: %s %.2e' % (worst[1], worst[0]))
 
 
 def test_config1_shape_eval_and_train_vs_oracle():
@@ -1413,3 +1547,43 @@ def test_flat_sgd_matches_torch_sgd(cfg):
         for (k, a), b in zip(net.named_parameters(), ref.parameters()):
             assert_close(a, b, 1e-6, 'step %d %s' % (step, k))
     assert net[0].weight.data_ptr() == opt.flat.data_ptr()
+
+
+def test_shared_weight_gradients_sum_inside_the_sink():
+    """A parameter used TWICE in one backward under ``deferred_weight_grads(sink=...)``: the first use writes straight into the
+    caller's slice, the second is added to it (both uses once aimed at the same slice and raced)."""
+    from crfconv_amd import ops
+    g = torch.Generator().manual_seed(3)
+    M, Ci, Co = 8192, 16, 32
+    W = nn.Parameter(torch.randn(Co, Ci, generator=g).to(DEV))
+    b = nn.Parameter(torch.randn(Co, generator=g).to(DEV))
+    x1 = torch.randn(M, Ci, generator=g).to(DEV)
+    x2 = torch.randn(M, Ci, generator=g).to(DEV)
+    slab = {id(W): torch.zeros(Co, Ci, device=DEV), id(b): torch.zeros(Co, device=DEV)}
+    y = ops.linear(x1, W, b).sum() + 2.0 * ops.linear(x2, W, b).sum()
+    with ops.deferred_weight_grads(sink=lambda p: slab.get(id(p))):
+        y.backward()
+    assert W.grad.data_ptr() == slab[id(W)].data_ptr() and b.grad.data_ptr() == slab[id(b)].data_ptr()
+    ones = torch.ones(M, Co, device=DEV, dtype=torch.float64)
+    assert_close(W.grad, ones.t() @ x1.double() + 2.0 * ones.t() @ x2.double(), 2e-5, 'shared dW')
+    assert_close(b.grad, torch.full((Co,), 3.0 * M, dtype=torch.float64), 1e-6, 'shared db')
+
+
+def test_grid_barrier_failure_is_raised_and_disables_the_one_launch_path():
+    """The sticky failure word of the grid-barrier workspace (set by a one-launch kernel whose barrier timed out) must
+    reach the host: ops.check_gridsync raises, zeroes the workspace and switches the one-launch MLP path off."""
+    from crfconv_amd import _lib, ops
+    dev = torch.device('cuda', 0)
+    ws = ops.gridsync_ws(dev)
+    ops.check_gridsync(dev)                                 # clean: no exception
+    word = _lib.load().crfconv_gridsync_fail_word()
+    was = ops._small_mlp_disabled
+    try:
+        ws[word] = 0x101
+        with pytest.raises(_lib.CrfConvError, match='grid barrier timed out'):
+            ops.check_gridsync(dev)
+        assert int(ws.abs().sum()) == 0 and ops._small_mlp_disabled
+        assert not ops._mlp_small_ok(1280, 512, 128)
+        ops.check_gridsync(dev)
+    finally:
+        ops._small_mlp_disabled = was

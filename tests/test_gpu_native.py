@@ -230,3 +230,22 @@ def test_morton_codes_kernel_equals_the_op_by_op_form():
         assert got.dtype == torch.int64 and torch.equal(got.cpu(), ref)
         assert torch.equal(data.morton_order(pos.to(DEV)).cpu(), torch.argsort(ref, dim=1, stable=True))
 
+
+
+def test_reverse_csr_hub_rows():
+    """Rows of very large in-degree (every target also points at row 0 / row 1 of its cloud) take the tiled ranking path of
+    rev_sort_rows_kernel: the reverse lists must still be every row's incoming edge ids in ascending order."""
+    from crfconv_amd.graph import NeighborTable
+    g = torch.Generator().manual_seed(9)
+    B, N, K = 2, 5000, 16
+    idx = torch.randint(0, N, (B, N, K), generator=g)
+    idx[:, :, 1] = 0
+    idx[:, ::2, 2] = 1
+    tab = NeighborTable(idx.to('cuda'), N)
+    rev_ptr, rev_eid = (v.cpu().long() for v in tab.reverse)
+    src = tab.idx32.cpu().long().reshape(-1)
+    order = torch.argsort(src, stable=True)                 # stable sort by source row = ascending edge id inside a row
+    assert torch.equal(rev_eid, order)
+    cnt = torch.bincount(src, minlength=B * N)
+    assert torch.equal(rev_ptr, torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]))
+    assert int(cnt.max()) == N
