@@ -16,15 +16,8 @@ import os
 import sys
 import time
 
-# Three streams are busy at once in the pipelined loop under a process group (training graphs, the collate graph, RCCL's own
-# stream).  ROCm deals streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin: with 4 the collective's stream
-# shares a queue with the collate stream and waits behind a whole collate graph (7.1 ms per iteration instead of 5.8,
-# measured under torch.distributed.run + RCCL).  Only there: WITHOUT a process group the default is the good mapping (5.8 ms;
-# 8 queues measured 15 ms).  The primary loop does not depend on it.  Must be set before the HIP runtime initialises.
-if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ:
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
-
 import numpy as np
+import crfconv_amd        # noqa: F401  (first: picks the hardware-queue mapping for a launch under a process group, crfconv_amd/__init__.py)
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -232,9 +225,9 @@ def cpu_share():
 
 
 def cpu_baseline(data, net, steps_T, labels, n_cls, dev):
-    """SURVEY 8(d) CPU plan on this host's cores, bounded to ~30 s: (1) the oracle's fwd+bwd of PointConvBig on ONE of
-    the batch's clouds (each cloud is independent work for the reference too: 4 clouds cost 4x; 1 warm-up + 3 timed,
-    median); (2) the reference's OWN kNN (knn_.cxx cpp_knn_batch_omp, compiled unchanged into oracle/_ref) on the
+    """SURVEY 8(d) CPU plan on this host's cores, bounded to ~40 s: (1) the oracle's fwd+bwd of PointConvBig on the SAME
+    batch the GPU line is quoted on (all clouds: BatchNorm statistics span the batch), 3 warm-up + 5 timed, median;
+    (2) the reference's OWN kNN (knn_.cxx cpp_knn_batch_omp, compiled unchanged into oracle/_ref) on the
     batch's level-0 self-query, K = 16; (3) the reference's own grid subsampling core on 2 M points, each 1 warm-up +
     3 timed, median, with the HIP kernels' times on the same inputs beside them."""
     from oracle import crf_oracle as O
@@ -244,21 +237,22 @@ def cpu_baseline(data, net, steps_T, labels, n_cls, dev):
     threads = torch.get_num_threads()
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     prm = {k: v.requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
-    ms = [{k: getattr(l, k)[:1].cpu() for k in ('pos', 'neighbor_idx', 'sub_idx', 'up_idx')} for l in data.multiscale]
-    x = data.x[:1].cpu()
-    y = labels[:1].cpu()
-    n = x.shape[1]
+    ms = [{k: getattr(l, k).cpu() for k in ('pos', 'neighbor_idx', 'sub_idx', 'up_idx')} for l in data.multiscale]
+    x = data.x.cpu()
+    y = labels.cpu()
+    n = x.shape[0] * x.shape[1]
 
     def step():
         for v in prm.values():
             v.grad = None
         logits = O.pointconv_resnet(prm, x, ms, steps_T, True, True)
         O.training_loss(logits, y).backward()
-    dt, ts = _median_time(step, 1, 3)
+    dt, ts = _median_time(step, 3, 5)
     out = {'value': n / dt / 1e6, 'unit': 'M points/s', 'cores': threads, 'kind': 'port',
-           'sample': '1 of the %d clouds (%d pts, K=16, T=%d): oracle/crf_oracle.py fwd+bwd, train mode, 1 warm-up + 3 timed '
-                     '(%s s), median; os.cpu_count()=%d, torch threads=%d, OMP_NUM_THREADS=%s'
-                     % (data.x.shape[0], n, steps_T, ', '.join('%.2f' % t for t in ts), os.cpu_count(), threads,
+           'sample': 'the whole batch (%d clouds x %d pts, K=16, T=%d): oracle/crf_oracle.py fwd+bwd, train mode, 3 warm-up + 5 timed '
+                     '(%s s), median; os.cpu_count()=%d, torch intra-op threads actually used=%d (torch.get_num_threads(), sized '
+                     'from the cgroup CPU quota), OMP_NUM_THREADS=%s'
+                     % (x.shape[0], x.shape[1], steps_T, ', '.join('%.2f' % t for t in ts), os.cpu_count(), threads,
                         os.environ.get('OMP_NUM_THREADS', 'unset'))}
     # (2) kNN: the whole level-0 query of the batch
     pos = data.multiscale[0].pos
@@ -330,7 +324,7 @@ def main():
     D.broadcast_parameters(net)
     bucket = D.FlatGradAllReduce(net)
     # torch.optim.SGD(lr, momentum=0.95, weight_decay=1e-4) of trainval.py:69-72 as one launch over flat parameters
-    opt = crfconv_amd.optim.FlatSGD(bucket, lr=1e-2, momentum=0.95, weight_decay=1e-4)
+    opt = crfconv_amd.optim.FlatSGD(bucket, lr=1e-2, momentum=0.95, weight_decay=1e-4, grad_scale=1.0 / world)   # mean of the ranks' gradients inside the update
     cw = torch.ones(n_cls, device=dev)
     unit = torch.ones((), device=dev)                        # d loss / d loss, made once (loss.backward() fills a new one per call)
 
@@ -356,9 +350,7 @@ def main():
 
     def collective():
         if grouped:
-            torch.distributed.all_reduce(bucket.flat, op=torch.distributed.ReduceOp.SUM)
-            if world > 1:
-                bucket.flat.div_(world)
+            torch.distributed.all_reduce(bucket.flat, op=torch.distributed.ReduceOp.SUM)     # the 1 / world factor sits in the SGD kernel
 
     def step():
         loss = part_a()

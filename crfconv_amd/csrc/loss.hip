@@ -161,10 +161,12 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 __global__ __launch_bounds__(256) void sgd_hyper_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ buf, int64_t n,
                                                         const float* __restrict__ hyper, int nesterov, int first) {
-    const float lr = hyper[0], mu = hyper[1], damp = hyper[2], wd = hyper[3];
+    // hyper[4] = gradient scale: 1 / world size when the bucket holds the all-reduce SUM of the ranks' gradients (the mean
+    // then never exists as a pass of its own over the bucket); 1 otherwise (x * 1.0f is exact)
+    const float lr = hyper[0], mu = hyper[1], damp = hyper[2], wd = hyper[3], gs = hyper[4];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float w = p[i];
-        float d = fmaf(wd, w, g[i]);
+        float d = fmaf(wd, w, g[i] * gs);
         if (mu != 0.f) {
             const float b = first ? d : fmaf(mu, buf[i], (1.f - damp) * d);
             buf[i] = b;

@@ -69,6 +69,13 @@ class FlatGradAllReduce:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
+    def allreduce_sum(self):
+        """pack() + ONE all-reduce (sum) of the flat bucket.  The mean is taken inside the optimizer's kernel:
+        ``FlatSGD(bucket, ..., grad_scale=1 / world_size)`` -- no separate pass over the bucket."""
+        self.pack()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+
     def allreduce_mean(self):
         self.pack()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -22,9 +22,10 @@ from .graph import ptr, require_gpu, stream_ptr
 
 
 class FlatSGD(torch.optim.Optimizer):
-    def __init__(self, bucket, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, check_every=64):
+    def __init__(self, bucket, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, check_every=64, grad_scale=1.0):
         """`bucket`: distributed.FlatGradAllReduce of the model (owns the flat gradient vector).  check_every: eager steps
-        between two reads of the grid-barrier failure flag (ops.check_gridsync; 0 = never)."""
+        between two reads of the grid-barrier failure flag (ops.check_gridsync; 0 = never).  grad_scale: factor on the
+        gradient inside the update -- 1 / world size after ``bucket.allreduce_sum()`` (no separate averaging pass)."""
         if nesterov and (momentum <= 0 or dampening != 0):
             raise ValueError('Nesterov momentum requires a momentum and zero dampening')
         self.bucket = bucket
@@ -42,9 +43,10 @@ class FlatSGD(torch.optim.Optimizer):
         self.buf = torch.zeros_like(self.flat)
         self.steps = 0
         self.check_every = int(check_every)
+        self.grad_scale = float(grad_scale)
         super().__init__(params, dict(lr=float(lr), momentum=float(momentum), dampening=float(dampening),
                                       weight_decay=float(weight_decay), nesterov=bool(nesterov)))
-        self._hyper = torch.zeros(4, dtype=torch.float32, device=self.flat.device)
+        self._hyper = torch.zeros(5, dtype=torch.float32, device=self.flat.device)
         self._hyper_host = None
         self.push_hyper()
 
@@ -63,10 +65,10 @@ class FlatSGD(torch.optim.Optimizer):
         super().add_param_group(group)
 
     def push_hyper(self):
-        """Copies the group's {lr, momentum, dampening, weight_decay} to the device block the kernel reads, if they
+        """Copies the group's {lr, momentum, dampening, weight_decay} (and grad_scale) to the device block the kernel reads, if they
         changed.  step() does this itself when run eagerly; call it explicitly between replays of a captured step."""
         g = self.param_groups[0]
-        cur = (float(g['lr']), float(g['momentum']), float(g['dampening']), float(g['weight_decay']))
+        cur = (float(g['lr']), float(g['momentum']), float(g['dampening']), float(g['weight_decay']), float(self.grad_scale))
         if cur != self._hyper_host:
             self._hyper.copy_(torch.tensor(cur, dtype=torch.float32), non_blocking=False)
             self._hyper_host = cur

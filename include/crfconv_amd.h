@@ -557,8 +557,9 @@ int crfconv_softmax_ce_backward(const float* logits, const int64_t* target, cons
  *   g = nesterov ? g + momentum * buf : buf;  p -= lr * g          (momentum == 0: buf unused, may be NULL). */
 int crfconv_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
                      float dampening, float weight_decay, int nesterov, int first_step, crf_stream_t stream);
-/* The same with hyper = {lr, momentum, dampening, weight_decay} (4 floats) in DEVICE memory, so that a captured graph
- * of the step honours a learning-rate scheduler; momentum_buf is required (zero-filled when momentum is 0). */
+/* The same with hyper = {lr, momentum, dampening, weight_decay, grad_scale} (5 floats) in DEVICE memory, so that a
+ * captured graph of the step honours a learning-rate scheduler; grad is multiplied by grad_scale first (1 / world size
+ * when the bucket holds the all-reduce SUM; 1 otherwise); momentum_buf is required (zero-filled when momentum is 0). */
 int crfconv_sgd_step_hyper(float* param, const float* grad, float* momentum_buf, int64_t n, const float* hyper,
                            int nesterov, int first_step, crf_stream_t stream);
 

@@ -150,3 +150,27 @@ def test_flat_sgd_follows_exponential_lr_scheduler_eager_and_captured():
         assert abs(opt.lr - ropt.param_groups[0]['lr']) < 1e-12
         for a, b in zip(net.parameters(), ref.parameters()):
             assert_close(a, b, 1e-6, 'step %d' % step)
+
+
+def test_bench_pipelined_loop_on_two_ranks(tmp_path):
+    """bench.py as the driver launches it for N = 2 (one process per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment), here with both ranks on the one GPU over gloo and a small batch: the captured step with the flat all-reduce
+    between its two graphs AND the pipelined loop (CollatePipeline: every iteration collates a fresh batch on a side stream
+    and trains on it) must run to the end on both ranks and rank 0 must print the one JSON line."""
+    import json
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29547', WORLD_SIZE='2', CRFCONV_DIST_BACKEND='gloo',
+               OMP_NUM_THREADS='2')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--batch', '2',
+           '--points', '8192', '--no-cpu-baseline']
+    outs = [open(str(tmp_path / ('out.%d' % r)), 'w') for r in range(2)]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=outs[r], stderr=subprocess.STDOUT, cwd=ROOT)
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0, open(str(tmp_path / 'out.0')).read()[-2000:]
+    lines = [l for l in open(str(tmp_path / 'out.0')).read().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['value'] > 0 and rec['scaling'] == 'weak'
+    assert rec['pipelined_ms_per_batch'] is not None and rec['pipelined_ms_per_batch'] > 0
+    assert rec['config']['global_batch'] == 4
+    assert not [l for l in open(str(tmp_path / 'out.1')).read().splitlines() if l.startswith('{')]      # rank 0 alone reports

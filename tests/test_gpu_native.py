@@ -248,4 +248,4 @@ def test_reverse_csr_hub_rows():
     assert torch.equal(rev_eid, order)
     cnt = torch.bincount(src, minlength=B * N)
     assert torch.equal(rev_ptr, torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]))
-    assert int(cnt.max()) == N
+    assert int(cnt.max()) >= N
