@@ -178,6 +178,57 @@ def roofline_meanfield_bwd(data, dev, H=8, T=3):
             'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': avg * 1e6, 'min_launch_us': lo * 1e6}
 
 
+def roofline_pointconv(data, dev, d=8):
+    """Level-0 PointConv (d = 8: conv1_1 / conv1_2 of models/point_conv_big.py:116-117) in train mode, forward and
+    forward + backward captured into hipGraphs (the op is four to ten launches; eagerly the host would be timed) and
+    replayed, HIP-event timed.  Algorithmic bytes per target point, forward: 4 K (index row) + 12 (p_i) +
+    4 d (output) + (12 + 4 d) (the source row, each read once) = 152 B at d = 8, K = 16; backward counted as 3 x that
+    (the gradient row in, dx out, the rows again, plus the weight-MLP parameter sums)."""
+    from crfconv_amd import ops
+    from crfconv_amd.graph import table_of
+    ms0 = data.multiscale[0]
+    B, N, K = ms0.neighbor_idx.shape
+    m = B * N
+    tab = table_of(ms0.neighbor_idx, N)
+    tab.reverse
+    pos = ms0.pos.reshape(-1, 3).contiguous()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(m, d, generator=g).to(dev).requires_grad_()
+    W1 = (0.5 * torch.randn(d, 3, generator=g)).to(dev).requires_grad_()
+    W2 = (0.5 * torch.randn(d, d, generator=g)).to(dev).requires_grad_()
+    bn1, bn2 = torch.nn.BatchNorm1d(d).to(dev), torch.nn.BatchNorm1d(d).to(dev)
+    gout = torch.randn(m, d, generator=g).to(dev)
+    moments = ops.relpos_moments(pos, pos, tab)
+
+    def fwd():
+        return ops.point_conv(x, pos, None, tab, W1, bn1, W2, bn2, True, moments=moments)
+
+    def fwd_bwd():
+        for t in (x, W1, W2, bn1.weight, bn1.bias, bn2.weight, bn2.bias):
+            t.grad = None
+        fwd().backward(gout)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fwd_bwd()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gf, gfb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(gf):
+        fwd()
+    with torch.cuda.graph(gfb):
+        fwd_bwd()
+    tf, tf_lo = _event_time(gf.replay, per=5)
+    tfb, _ = _event_time(gfb.replay, per=5)
+    alg = m * (4 * K + 12 + 4 * d + 12 + 4 * d)
+    return {'bound': 'hbm', 'achieved': alg / tf / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': alg / tf / HBM_PEAK,
+            'traffic': None, 'kernel': 'PointConv level 0, d=%d, train mode (uvstats + combine; m=%d, K=%d), graph replay' % (d, m, K),
+            'alg_bytes_per_launch': alg, 'avg_launch_us': tf * 1e6, 'min_launch_us': tf_lo * 1e6,
+            'fwd_bwd_us': tfb * 1e6, 'bwd_frac_on_3x_bytes': 3 * alg / max(tfb - tf, 1e-9) / HBM_PEAK}
+
+
 def copy_ceiling(dev, nbytes=1 << 28, iters=20):
     """Measured device-copy rate of this run (reported beside the 8 TB/s spec the fraction is taken of):
     read + written bytes of a 256 MiB float32 copy per second."""
@@ -597,6 +648,10 @@ def main():
                                        'frac': alg / t / HBM_PEAK, 'traffic': tr, 'alg_bytes_per_launch': alg,
                                        'avg_launch_us': t * 1e6,
                                        'kernel': 'level-0 mean-field forward + backward (roofline + roofline_bwd)'}
+        try:
+            out['roofline_pointconv'] = roofline_pointconv(data, dev, 8)
+        except Exception as e:                             # a measurement beside the contract line, never fatal
+            out['roofline_pointconv'] = {'error': str(e).splitlines()[0][:200]}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(data, net, T, data.y, n_cls, dev)
         print(json.dumps(out))
