@@ -1,7 +1,7 @@
 """One replayed training step out of a rocprofv3 kernel trace: launches, wall, per-kernel totals.
 usage: python3 scratch/step_table.py <dir> [top]"""
 import csv, re, glob, collections, sys
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+f = (glob.glob(sys.argv[1] + '/*/*kernel_trace.csv') + glob.glob(sys.argv[1] + '/*kernel_trace.csv'))[0]
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
