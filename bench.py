@@ -511,8 +511,8 @@ def main():
                 v.append(time.perf_counter() - t0)
             return float(np.median(v)) * 1e3
         from crfconv_amd.data import morton_order
-        cg_parts = {'host_randperm_and_upload_ms': part(cg._draw),
-                    'morton_argsort_eager_ms': part(lambda: cg.order.copy_(morton_order(cg.pos))),
+        cg_parts = {'host_work_ms': 0.0 if cg.device_draw else part(cg._draw),      # device_draw: subsets drawn inside the graph
+                    'morton_argsort_alone_ms': part(lambda: morton_order(cg.pos, out=cg.order)),     # (inside the graph too)
                     'graph_replay_ms': part(cg.graph.replay), 'all_runs_ms': [round(t * 1e3, 2) for t in ts]}
     except Exception as e:                                # capture not possible: the eager figures above stand
         import traceback

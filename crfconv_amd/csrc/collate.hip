@@ -1,0 +1,202 @@
+// Device-side pieces of the collate (datasets/semantic3d_dataset.py:512-528) that used to run on the host or in framework
+// kernels with scratch memory, so that data.CollateGraph is ONE hipGraph replay with no host work per batch:
+//
+//   crfconv_random_subsets   the per-level random subsets `randperm(n)[: n // ratio]` (:517), kept in ascending order:
+//                            every point gets a 64-bit counter-based key (splitmix64 of seed, batch counter, level, point),
+//                            the s smallest keys are selected by a radix select and a block-wide scan writes their indices
+//                            in ascending order.  One workgroup per level, all levels in one launch.  The DRAWS differ from
+//                            torch.randperm's (any uniform subset is the reference's semantics); reproducible from the seed.
+//   crfconv_argsort_codes    stable argsort of the 30-bit Morton codes per cloud (torch.argsort(stable=True) needs a private
+//                            segment: not replayable from a captured graph on ROCm 7.2): bucket by the top 16 bits
+//                            (histogram -> exclusive scan -> fill), then every element ranks itself inside its bucket by
+//                            (code, index).  Deterministic, scratch-free, six small launches.
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace crf {
+
+__device__ __forceinline__ unsigned long long subset_key(unsigned long long seed, unsigned long long ctr, unsigned level,
+                                                         unsigned i) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1ull) + (unsigned long long)level * 0xC2B2AE3D27D4EB4Full
+                           + (unsigned long long)i * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (z & ~0xFFFFFull) | (unsigned long long)i;        // low 20 bits = the point: keys are distinct (n <= 2^20)
+}
+
+constexpr int SUB_MAX_LEVELS = 8, SUB_NT = 1024;
+struct SubsetJobs {
+    int n[SUB_MAX_LEVELS];
+    int s[SUB_MAX_LEVELS];
+    long long* out[SUB_MAX_LEVELS];
+    int nlevels;
+};
+
+// One workgroup per level.  Radix select (8-bit digits from the top) of the s-th smallest key, the keys recomputed in
+// every pass instead of stored; it stops as soon as the selected bin is taken whole (two or three passes for uniform
+// 64-bit keys).  Then flags -> block scan -> ascending indices.
+__global__ __launch_bounds__(SUB_NT) void random_subsets_kernel(const SubsetJobs jobs, unsigned long long seed,
+                                                                const long long* __restrict__ counter) {
+    const int level = blockIdx.x;
+    const int n = jobs.n[level], s = jobs.s[level];
+    long long* __restrict__ out = jobs.out[level];
+    if (s <= 0) return;
+    const unsigned long long ctr = (unsigned long long)counter[0];
+    __shared__ int s_hist[256];
+    __shared__ int s_sel[2];                                   // selected digit, keys strictly below the selected bin so far
+    __shared__ int s_cnt[SUB_NT];
+    const int tid = threadIdx.x;
+    const int per = (n + SUB_NT - 1) / SUB_NT, lo = tid * per, hi = lo + per < n ? lo + per : n;   // a contiguous chunk per thread
+    unsigned long long prefix = 0ull, mask = 0ull;             // keys with (key & mask) == prefix are still candidates
+    int need = s;                                              // how many of the candidates belong to the subset
+    bool whole = (s >= n);                                     // every candidate is in: nothing left to select
+    for (int shift = 56; shift >= 0 && !whole; shift -= 8) {
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        for (int i = lo; i < hi; ++i) {
+            const unsigned long long k = subset_key(seed, ctr, level, i);
+            if ((k & mask) == prefix) atomicAdd(&s_hist[(int)((k >> shift) & 0xFF)], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int below = 0, d = 0;
+            for (; d < 256; ++d) {
+                if (below + s_hist[d] >= need) break;
+                below += s_hist[d];
+            }
+            s_sel[0] = d;
+            s_sel[1] = below;
+        }
+        __syncthreads();
+        const int d = s_sel[0], below = s_sel[1], in_bin = s_hist[d];
+        need -= below;                                         // bins below d are taken whole
+        prefix |= (unsigned long long)d << shift;
+        mask |= 0xFFull << shift;
+        whole = (need == in_bin);                              // the selected bin is taken whole too: the threshold is its top
+        __syncthreads();
+    }
+    // subset = {k : (k & mask) <= prefix}  (equal prefix = the last selected bin, taken whole)
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += ((subset_key(seed, ctr, level, i) & mask) <= prefix) ? 1 : 0;
+    s_cnt[tid] = c;
+    __syncthreads();
+    for (int o = 1; o < SUB_NT; o <<= 1) {                     // inclusive scan of the per-thread counts
+        const int v = tid >= o ? s_cnt[tid - o] : 0;
+        __syncthreads();
+        s_cnt[tid] += v;
+        __syncthreads();
+    }
+    int pos = s_cnt[tid] - c;
+    for (int i = lo; i < hi; ++i)
+        if ((subset_key(seed, ctr, level, i) & mask) <= prefix) {
+            if (pos < s) out[pos] = i;
+            ++pos;
+        }
+}
+
+// ------------------------------------------------------------------ stable argsort of 30-bit codes, per cloud
+constexpr int AS_BITS = 16, AS_SHIFT = 30 - AS_BITS, AS_BUCKETS = 1 << AS_BITS;
+
+__global__ __launch_bounds__(256) void as_zero_kernel(int32_t* __restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0;
+}
+__global__ __launch_bounds__(256) void as_count_kernel(const long long* __restrict__ code, int64_t N, int32_t* __restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= N) return;
+    const int bucket = (int)((code[b * N + i] >> AS_SHIFT) & (AS_BUCKETS - 1));
+    atomicAdd(&cnt[(int64_t)b * AS_BUCKETS + bucket], 1);
+}
+__global__ __launch_bounds__(256) void as_fill_kernel(const long long* __restrict__ code, int64_t N, const int32_t* __restrict__ ptrs,
+                                                      int32_t* __restrict__ cursor, int32_t* __restrict__ tmp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= N) return;
+    const int64_t g = (int64_t)b * AS_BUCKETS + (int)((code[b * N + i] >> AS_SHIFT) & (AS_BUCKETS - 1));
+    tmp[ptrs[g] + atomicAdd(&cursor[g], 1)] = (int32_t)i;      // global slot (clouds are consecutive bucket ranges)
+}
+// every slot of tmp: rank of its element inside the bucket by (code, index) -> its place in the stable order
+__global__ __launch_bounds__(256) void as_rank_kernel(const long long* __restrict__ code, int64_t N, int64_t total,
+                                                      const int32_t* __restrict__ ptrs, const int32_t* __restrict__ cnt,
+                                                      const int32_t* __restrict__ tmp, long long* __restrict__ order) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= total) return;
+    const int b = (int)(slot / N);
+    const int i = tmp[slot];
+    const long long ci = code[b * N + i];
+    const int64_t g = (int64_t)b * AS_BUCKETS + (int)((ci >> AS_SHIFT) & (AS_BUCKETS - 1));
+    const int beg = ptrs[g], len = cnt[g];
+    int rank = 0;
+    for (int k = 0; k < len; ++k) {                            // buckets hold ~N / 65536 elements; a degenerate cloud (one
+        const int j = tmp[beg + k];                            // bucket) costs N^2 broadcast loads, bounded by the caller's N
+        const long long cj = code[b * N + j];
+        rank += (cj < ci || (cj == ci && j < i)) ? 1 : 0;
+    }
+    order[(int64_t)beg + rank] = i;                            // bucket offsets count from the start of ALL clouds: cloud b's slots are [b N, (b + 1) N)
+}
+
+}  // namespace crf
+
+using namespace crf;
+
+extern "C" int crfconv_random_subsets(const int* n, const int* s, int64_t* const* out, int nlevels, uint64_t seed,
+                                      const int64_t* counter, crf_stream_t stream) {
+    CRF_REQUIRE(n && s && out && counter, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(nlevels >= 1 && nlevels <= SUB_MAX_LEVELS, CRF_ERR_ARG, "nlevels=%d outside [1, %d]", nlevels, SUB_MAX_LEVELS);
+    SubsetJobs jobs;
+    jobs.nlevels = nlevels;
+    for (int l = 0; l < SUB_MAX_LEVELS; ++l) {
+        jobs.n[l] = 0; jobs.s[l] = 0; jobs.out[l] = nullptr;
+        if (l < nlevels) {
+            CRF_REQUIRE(n[l] >= 1 && n[l] <= (1 << 20) && s[l] >= 0 && s[l] <= n[l] && (s[l] == 0 || out[l]), CRF_ERR_ARG,
+                        "level %d: n=%d s=%d (1 <= n <= 2^20, 0 <= s <= n)", l, n[l], s[l]);
+            jobs.n[l] = n[l]; jobs.s[l] = s[l]; jobs.out[l] = reinterpret_cast<long long*>(out[l]);
+        }
+    }
+    hipLaunchKernelGGL(random_subsets_kernel, dim3((unsigned)nlevels), dim3(SUB_NT), 0, as_stream(stream), jobs,
+                       (unsigned long long)seed, reinterpret_cast<const long long*>(counter));
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" size_t crfconv_argsort_codes_workspace(int64_t B, int64_t N) {
+    if (B < 1 || N < 1) return 0;
+    const int64_t nb = B * AS_BUCKETS;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return up(sizeof(int32_t) * (size_t)nb) * 3 + up(sizeof(int32_t) * scan_block_sums(nb)) + up(sizeof(int32_t) * (size_t)(B * N));
+}
+
+// order [B, N] int64 = per-cloud stable argsort of code [B, N] int64 (values < 2^30).
+extern "C" int crfconv_argsort_codes(const int64_t* code, int64_t B, int64_t N, int64_t* order, void* workspace,
+                                     size_t workspace_bytes, crf_stream_t stream) {
+    CRF_REQUIRE(code && order && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(B >= 1 && N >= 1 && B * N < ((int64_t)1 << 31) && B * AS_BUCKETS < ((int64_t)1 << 31), CRF_ERR_ARG, "bad shape");
+    CRF_REQUIRE(workspace_bytes >= crfconv_argsort_codes_workspace(B, N) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+                CRF_ERR_WORKSPACE, "workspace too small or misaligned");
+    hipStream_t st = as_stream(stream);
+    const int64_t nb = B * AS_BUCKETS;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    char* w = static_cast<char*>(workspace);
+    int32_t* cnt = reinterpret_cast<int32_t*>(w); w += up(sizeof(int32_t) * (size_t)nb);
+    int32_t* ptrs = reinterpret_cast<int32_t*>(w); w += up(sizeof(int32_t) * (size_t)nb);
+    int32_t* cursor = reinterpret_cast<int32_t*>(w); w += up(sizeof(int32_t) * (size_t)nb);
+    int32_t* bsum = reinterpret_cast<int32_t*>(w); w += up(sizeof(int32_t) * scan_block_sums(nb));
+    int32_t* tmp = reinterpret_cast<int32_t*>(w);
+    const long long* c = reinterpret_cast<const long long*>(code);
+    // cnt and cursor are adjacent-by-layout but not contiguous (ptrs sits between): two zero launches merged into one by
+    // zeroing [cnt, cursor + nb) would also wipe nothing else, ptrs being rewritten by the scan below
+    hipLaunchKernelGGL(as_zero_kernel, dim3(512), dim3(256), 0, st, cnt, (int64_t)(reinterpret_cast<char*>(cursor + nb) - reinterpret_cast<char*>(cnt)) / 4);
+    CRF_LAUNCH_CHECK();
+    const dim3 grid((unsigned)cdiv(N, 256), (unsigned)B);
+    hipLaunchKernelGGL(as_count_kernel, grid, dim3(256), 0, st, c, N, cnt);
+    CRF_LAUNCH_CHECK();
+    exclusive_scan_i32(cnt, ptrs, nb, bsum, st);
+    CRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(as_fill_kernel, grid, dim3(256), 0, st, c, N, ptrs, cursor, tmp);
+    CRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(as_rank_kernel, dim3((unsigned)cdiv(B * N, 256)), dim3(256), 0, st, c, N, B * N, ptrs, cnt, tmp,
+                       reinterpret_cast<long long*>(order));
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}

@@ -136,9 +136,43 @@ def morton_codes(pos):
     return _spread3(q[..., 0]) | (_spread3(q[..., 1]) << 1) | (_spread3(q[..., 2]) << 2)
 
 
-def morton_order(pos):
-    """Per-cloud permutation that sorts points along a 30-bit Morton (Z-order) curve.  pos [B, N, 3]."""
-    return torch.argsort(morton_codes(pos), dim=1, stable=True)
+def morton_order(pos, out=None):
+    """Per-cloud permutation that sorts points along a 30-bit Morton (Z-order) curve.  pos [B, N, 3].  On the device the stable
+    argsort is this library's own (csrc/collate.hip: crfconv_argsort_codes -- bit-identical to torch.argsort(stable=True),
+    no scratch memory, so it can sit inside a captured graph); `out` [B, N] int64 receives it when given."""
+    code = morton_codes(pos)
+    if code.is_cuda and code.dim() == 2 and code.shape[1] > 0:
+        from . import _lib
+        from .graph import ptr, stream_ptr
+        B, N = code.shape
+        order = out if out is not None else torch.empty((B, N), dtype=torch.int64, device=code.device)
+        nbytes = _lib.load().crfconv_argsort_codes_workspace(B, N)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=code.device)
+        _lib.call('crfconv_argsort_codes', ptr(code), B, N, ptr(order), ptr(ws), nbytes, stream_ptr())
+        return order
+    order = torch.argsort(code, dim=1, stable=True)
+    if out is not None:
+        out.copy_(order)
+        return out
+    return order
+
+
+def random_subsets_device(sizes, counts, seed, counter, outs):
+    """outs[l] [counts[l]] int64 (device) <- a uniformly random subset of range(sizes[l]) in ascending order, one launch for all
+    levels (csrc/collate.hip: crfconv_random_subsets).  A function of (seed, counter[0], l): `counter` is a one-element int64
+    DEVICE tensor the caller advances per batch.  Not torch.randperm's draws."""
+    import ctypes
+    from . import _lib
+    from .graph import stream_ptr
+    L = len(sizes)
+    n = (ctypes.c_int * L)(*[int(v) for v in sizes])
+    s = (ctypes.c_int * L)(*[int(v) for v in counts])
+    o = (ctypes.c_void_p * L)(*[t.data_ptr() for t in outs])
+    for t, c in zip(outs, counts):
+        if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.numel() >= c):
+            raise _lib.CrfConvError('random_subsets_device: outputs must be contiguous int64 device tensors of the subset sizes')
+    _lib.call('crfconv_random_subsets', ctypes.cast(n, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p),
+              ctypes.cast(o, ctypes.c_void_p), L, int(seed) & 0xFFFFFFFFFFFFFFFF, counter.data_ptr(), stream_ptr())
 
 
 def _fps_choice(pos, n_sample):
@@ -231,17 +265,24 @@ class CollateGraph:
     the static batch a captured training step reads + in-place refresh of its neighbour tables, reverse CSRs and rel-pos
     moments).  Run eagerly the same work is ~470 launches and host-bound (5 ms of wall time for 3 ms of kernels).
 
-    The Morton argsort and the random subsets stay OUTSIDE the graph; the subsets are drawn on the host (``torch.randperm`` with the caller's generator, as the
-    reference does at datasets/semantic3d_dataset.py:517) and copied into static index tensors; everything data-dependent
-    inside the graph is shape-static.
+    Nothing runs on the host per batch (device_draw=True, the default): the random subsets of
+    datasets/semantic3d_dataset.py:517 are drawn INSIDE the graph by a counter-based kernel (crfconv_random_subsets: seeded
+    from the caller's generator -- ``generator.initial_seed()`` -- and a device counter the graph advances, so every replay
+    draws new subsets; the draws are NOT ``torch.randperm``'s) and the Morton argsort is this library's own scratch-free
+    sort (crfconv_argsort_codes).  ``run`` = three copies into the static inputs + one replay.  device_draw=False keeps
+    round 2's form: ``torch.randperm`` with the caller's generator on the host + a pinned upload, outside the graph.
 
         cg = CollateGraph(static_batch, generator=g)      # static_batch: the MultiScaleData the training graph was captured on
         cg.run(pos, x, y)                                 # new clouds [B, N, 3] / [B, N, C] / [B, N] on the device
         train_graph.replay()
     """
 
-    def __init__(self, target, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), generator=None):
+    def __init__(self, target, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), generator=None, device_draw=True, slot=0):
         self.target, self.kernel_size, self.ratio, self.generator = target, tuple(kernel_size), tuple(ratio), generator
+        self.device_draw = bool(device_draw)
+        # `slot`: several graphs fed from one generator (CollatePipeline's slots) must not draw the same subsets
+        self.seed = (int(generator.initial_seed() if generator is not None else torch.initial_seed())
+                     + 0x632BE59BD9B4E019 * int(slot)) & 0xFFFFFFFFFFFFFFFF
         ms = target.multiscale
         dev = ms[0].pos.device
         self.pos = torch.empty_like(ms[0].pos)
@@ -257,6 +298,7 @@ class CollateGraph:
         self._rank = [torch.empty(c.shape, dtype=torch.int64) for c in self.choices]
         self.graph = None
         self._uploaded = None                    # event after the last upload from the pinned buffers
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)      # batches collated so far (device_draw: keys the subsets)
 
     def _draw(self):
         if self._uploaded is not None:
@@ -270,6 +312,10 @@ class CollateGraph:
         self._uploaded.record()
 
     def _work(self):
+        if self.device_draw:
+            self.counter.add_(1)
+            random_subsets_device(self.sizes, [c.numel() for c in self.choices], self.seed, self.counter, self.choices)
+            morton_order(self.pos, out=self.order)
         new = multiscale_compute(self.pos, x=self.x, y=self.y, kernel_size=self.kernel_size, ratio=self.ratio,
                                  num_scales=len(self.sizes), choices=self.choices, sort='morton', order=self.order)
         self.target.load_(new)
@@ -280,11 +326,9 @@ class CollateGraph:
             self.x.copy_(x)
         if self.y is not None:
             self.y.copy_(y)
-        self._draw()
-        # the Morton argsort stays OUTSIDE the graph: the framework's radix sort needs scratch memory, and kernel nodes
-        # with a private segment are not safe to replay between eager launches on ROCm 7.2 (csrc/graph.hip); everything
-        # inside the graph is this library's own scratch-free kernels plus elementwise / index framework kernels
-        self.order.copy_(morton_order(self.pos))
+        if not self.device_draw:
+            self._draw()                          # host torch.randperm + pinned upload; the argsort eagerly in front of the graph
+            morton_order(self.pos, out=self.order)
         if self.graph is None:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -316,7 +360,7 @@ class CollatePipeline:
             pipe.release(s)                        # slot s may be overwritten once the work queued so far has run
     """
 
-    def __init__(self, batches, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), generator=None):
+    def __init__(self, batches, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), generator=None, device_draw=True):
         import os
         import warnings
         if (torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -326,7 +370,7 @@ class CollatePipeline:
                           'hardware queue with the collate stream (measured 7.1 instead of 5.8 ms per iteration); import '
                           'crfconv_amd before torch initialises the GPU, or export GPU_MAX_HW_QUEUES=8')
         self.batches = list(batches)
-        self.graphs = [CollateGraph(b, kernel_size, ratio, generator) for b in self.batches]
+        self.graphs = [CollateGraph(b, kernel_size, ratio, generator, device_draw=device_draw, slot=k) for k, b in enumerate(self.batches)]
         self.stream = torch.cuda.Stream()
         self._ready = [torch.cuda.Event() for _ in self.batches]
         self._free = [None for _ in self.batches]

@@ -563,6 +563,20 @@ int crfconv_sgd_step(float* param, const float* grad, float* momentum_buf, int64
 int crfconv_sgd_step_hyper(float* param, const float* grad, float* momentum_buf, int64_t n, const float* hyper,
                            int nesterov, int first_step, crf_stream_t stream);
 
+/* ---- device-side pieces of the collate (datasets/semantic3d_dataset.py:512-528), csrc/collate.hip
+ * crfconv_random_subsets: for each level l < nlevels, out[l][0 .. s[l]) (device int64) = a uniformly random subset of
+ *   {0 .. n[l]-1} of size s[l] in ASCENDING order -- `torch.randperm(n)[: n // ratio]` of :517 followed by the sort the
+ *   device collate applies.  Counter-based: the subset is a function of (seed, *counter, l) -- *counter is a DEVICE word the
+ *   caller advances per batch, so a captured graph draws new subsets at every replay.  The draws are NOT torch.randperm's.
+ *   n, s, out are host arrays; n[l] <= 2^20; nlevels <= 8.
+ * crfconv_argsort_codes: order [B, N] int64 = per-cloud stable argsort of code [B, N] int64 (30-bit Morton codes):
+ *   bit-identical to torch.argsort(code, dim=1, stable=True), without scratch memory (capturable on ROCm 7.2). */
+int crfconv_random_subsets(const int* n, const int* s, int64_t* const* out, int nlevels, uint64_t seed,
+                           const int64_t* counter, crf_stream_t stream);
+size_t crfconv_argsort_codes_workspace(int64_t B, int64_t N);
+int crfconv_argsort_codes(const int64_t* code, int64_t B, int64_t N, int64_t* order, void* workspace,
+                          size_t workspace_bytes, crf_stream_t stream);
+
 /* ===================================================================== (B) discrete (label-space) CRF layer
  * models/discrete_crf_conv.py:40-63.  One mean-field step with GIVEN edge weights s [m, K] (edge-id addressed like
  * every per-edge array; entries of idx32 < 0 = no neighbour):  xout = z Q + (sum_k s_ik xin[idx32[i,k]]) P.

@@ -249,3 +249,56 @@ def test_reverse_csr_hub_rows():
     cnt = torch.bincount(src, minlength=B * N)
     assert torch.equal(rev_ptr, torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]))
     assert int(cnt.max()) >= N
+
+
+def test_argsort_codes_equals_torch_stable_argsort():
+    """crfconv_argsort_codes (bucket by the top 16 bits, rank inside the bucket by (code, index)) against
+    torch.argsort(stable=True): random 30-bit codes, heavy ties, one value only, and real Morton codes."""
+    from crfconv_amd.data import morton_codes, morton_order
+    from crfconv_amd import _lib
+    from crfconv_amd.graph import ptr, stream_ptr
+    g = torch.Generator().manual_seed(4)
+
+    def run(code):
+        B, N = code.shape
+        order = torch.empty_like(code)
+        nbytes = _lib.load().crfconv_argsort_codes_workspace(B, N)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=code.device)
+        _lib.call('crfconv_argsort_codes', ptr(code), B, N, ptr(order), ptr(ws), nbytes, stream_ptr())
+        return order
+    for code in (torch.randint(0, 1 << 30, (3, 5000), generator=g), torch.randint(0, 7, (2, 4096), generator=g) << 20,
+                 torch.full((1, 3000), 12345), torch.randint(0, 1 << 30, (1, 1), generator=g),
+                 torch.randint(0, 1 << 14, (2, 9000), generator=g)):
+        code = code.to('cuda')
+        assert torch.equal(run(code), torch.argsort(code, dim=1, stable=True))
+    pos = torch.rand(4, 40960, 3, generator=g).to('cuda')
+    assert torch.equal(morton_order(pos), torch.argsort(morton_codes(pos), dim=1, stable=True))
+
+
+def test_random_subsets_device():
+    """crfconv_random_subsets: exact sizes, ascending, distinct, in range; a function of (seed, counter, level); new subsets
+    when the counter advances; every point is drawn about equally often."""
+    from crfconv_amd.data import random_subsets_device
+    sizes, counts = [40960, 10240, 2560, 640, 160, 7], [10240, 2560, 640, 160, 80, 7]
+    ctr = torch.zeros(1, dtype=torch.int64, device='cuda')
+
+    def draw(seed):
+        outs = [torch.full((c,), -1, dtype=torch.int64, device='cuda') for c in counts]
+        random_subsets_device(sizes, counts, seed, ctr, outs)
+        return outs
+    a, a2, b = draw(11), draw(11), draw(12)
+    for n, c, t_ in zip(sizes, counts, a):
+        v = t_.cpu()
+        assert v.numel() == c and int(v.min()) >= 0 and int(v.max()) < n
+        assert bool((v[1:] > v[:-1]).all())                  # ascending and distinct
+    assert all(torch.equal(u, v) for u, v in zip(a, a2))      # reproducible
+    assert not torch.equal(a[0], b[0])                        # another seed, another subset
+    assert not torch.equal(a[1][:640], a[2])                  # levels draw independently
+    ctr += 1
+    c = draw(11)
+    assert not torch.equal(a[0], c[0])                        # the counter advances the stream
+    hits = torch.zeros(2560, dtype=torch.int64)
+    for it in range(200):                                     # uniformity: each of 2560 points is in a quarter of the draws
+        ctr += 1
+        hits += torch.bincount(draw(5)[2].cpu(), minlength=2560)
+    assert abs(float(hits.float().mean()) - 50.0) < 1e-6 and int(hits.min()) >= 20 and int(hits.max()) <= 85
