@@ -31,6 +31,8 @@ SIGNATURES = {
     'crfconv_index_narrow_sorted': (_i, [_vp, _i64, _i64, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     'crfconv_reverse_csr_workspace': (_sz, [_i64, _i64]),
     'crfconv_reverse_csr': (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_reverse_csr_batched_workspace': (_sz, [_vp, _i]),
+    'crfconv_reverse_csr_batched': (_i, [_vp, _i, _vp, _sz, _vp]),
     'crfconv_meanfield_forward': (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     'crfconv_meanfield_forward_u16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     'crfconv_meanfield_fused_workspace': (_sz, []),
@@ -150,6 +152,12 @@ class MlpDwJob(ctypes.Structure):
     """crf_mlp_dw_job of include/crfconv_amd.h."""
     _fields_ = [('workspace', ctypes.c_void_p), ('coef', ctypes.c_void_p), ('dW', ctypes.c_void_p), ('M', ctypes.c_int64),
                 ('Ci', ctypes.c_int32), ('Co', ctypes.c_int32)]
+
+
+class RevJob(ctypes.Structure):
+    """crf_rev_job of include/crfconv_amd.h."""
+    _fields_ = [('idx32', ctypes.c_void_p), ('E', ctypes.c_int64), ('m_src', ctypes.c_int64), ('rev_ptr', ctypes.c_void_p),
+                ('rev_eid', ctypes.c_void_p)]
 
 
 class Fold1Job(ctypes.Structure):

@@ -124,6 +124,93 @@ __global__ __launch_bounds__(256) void rev_sort_rows_kernel(const int32_t* __res
     }
 }
 
+// ------------------------------------------------------------------ the same for SEVERAL tables in one set of launches
+// A batch refresh rebuilds the reverse CSR of every table of the batch (14 for PointConvBig's five levels): as separate
+// builds that is ~100 launches of a few microseconds each.  Batched: the tables' row ranges (m_src + 1 counters each) and
+// edge ranges are laid end to end -- ONE histogram, ONE scan, ONE fill, ONE rank pass; rows and edges find their table by
+// a binary search over <= RB_MAX prefix entries.
+constexpr int RB_MAX = 32, RB_EPB = 1024;           // edges per workgroup of the count / fill passes
+struct RevBatch {
+    const int32_t* idx[RB_MAX];
+    int32_t* rev_ptr[RB_MAX];
+    int32_t* rev_eid[RB_MAX];
+    int m_src[RB_MAX];
+    int row_base[RB_MAX + 1];                      // prefix of (m_src + 1)
+    int edge_base[RB_MAX + 1];                     // prefix of E
+    int chunk_base[RB_MAX + 1];                    // prefix of ceil(E / RB_EPB)
+    int njobs;
+};
+__device__ __forceinline__ int rb_find(const int* prefix, int n, int v) {      // largest j with prefix[j] <= v
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= v) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void revb_count_kernel(const RevBatch t, int32_t* __restrict__ cnt) {
+    const int j = rb_find(t.chunk_base, t.njobs, (int)blockIdx.x);
+    const int E = t.edge_base[j + 1] - t.edge_base[j], m_src = t.m_src[j];
+    const int e0 = ((int)blockIdx.x - t.chunk_base[j]) * RB_EPB;
+#pragma unroll
+    for (int u = 0; u < RB_EPB / 256; ++u) {
+        const int e = e0 + u * 256 + (int)threadIdx.x;
+        if (e < E) {
+            const int32_t v = t.idx[j][e];
+            atomicAdd(&cnt[t.row_base[j] + ((v < 0 || v >= m_src) ? m_src : v)], 1);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void revb_fill_kernel(const RevBatch t, const int32_t* __restrict__ ptrs,
+                                                        int32_t* __restrict__ cursor, int32_t* __restrict__ tmp) {
+    const int j = rb_find(t.chunk_base, t.njobs, (int)blockIdx.x);
+    const int E = t.edge_base[j + 1] - t.edge_base[j], m_src = t.m_src[j];
+    const int e0 = ((int)blockIdx.x - t.chunk_base[j]) * RB_EPB;
+#pragma unroll
+    for (int u = 0; u < RB_EPB / 256; ++u) {
+        const int e = e0 + u * 256 + (int)threadIdx.x;
+        if (e < E) {
+            const int32_t v = t.idx[j][e];
+            if (v >= 0 && v < m_src) {
+                const int r = t.row_base[j] + v;
+                tmp[ptrs[r] + atomicAdd(&cursor[r], 1)] = e;            // global slot, LOCAL edge id
+            }
+        }
+    }
+}
+// one wavefront per row of the concatenation: the table's own rev_ptr entry, and (real rows) its edge ids ranked
+__global__ __launch_bounds__(256) void revb_rows_kernel(const RevBatch t, const int32_t* __restrict__ ptrs,
+                                                        const int32_t* __restrict__ tmp) {
+    const int lane = threadIdx.x & 63;
+    const int r = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (r >= t.row_base[t.njobs]) return;
+    const int j = rb_find(t.row_base, t.njobs, r);
+    const int v = r - t.row_base[j], eb = t.edge_base[j];
+    const int beg = ptrs[r];
+    if (lane == 0) t.rev_ptr[j][v] = beg - eb;
+    if (v >= t.m_src[j]) return;                       // the "no neighbour" bucket: an offset only
+    const int len = ptrs[r + 1] - beg;
+    int32_t* __restrict__ out = t.rev_eid[j] + (beg - eb);
+    if (len <= 64) {
+        const int32_t x = lane < len ? tmp[beg + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int k = 0; k < len; ++k) rank += __shfl(x, k, WAVE) < x ? 1 : 0;
+        if (lane < len) out[rank] = x;
+    } else {                                           // hub rows: tiles of 64 (see rev_sort_rows_kernel)
+        for (int i0 = 0; i0 < len; i0 += 64) {
+            const int i = i0 + lane;
+            const int32_t x = i < len ? tmp[beg + i] : 0x7fffffff;
+            int rank = 0;
+            for (int t0 = 0; t0 < len; t0 += 64) {
+                const int32_t u = t0 + lane < len ? tmp[beg + t0 + lane] : 0x7fffffff;
+                const int nt = len - t0 < 64 ? len - t0 : 64;
+                for (int k = 0; k < nt; ++k) rank += __shfl(u, k, WAVE) < x ? 1 : 0;
+            }
+            if (i < len) out[rank] = x;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* __restrict__ p, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0;
 }
@@ -269,6 +356,61 @@ extern "C" int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_sr
     exclusive_scan_i32(cnt, rev_ptr, n, sums, st);
     hipLaunchKernelGGL(rev_fill_kernel, egrid, blk, 0, st, idx32, E, m_src, rev_ptr, cursor, tmp_eid);
     hipLaunchKernelGGL(rev_sort_rows_kernel, dim3((unsigned)cdiv(m_src, 4)), blk, 0, st, rev_ptr, tmp_eid, m_src, rev_eid);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" size_t crfconv_reverse_csr_batched_workspace(const crf_rev_job* jobs, int njobs) {
+    if (!jobs || njobs < 1) return 0;
+    int64_t rows = 0, edges = 0;
+    for (int j = 0; j < njobs; ++j) { rows += jobs[j].m_src + 1; edges += jobs[j].E; }
+    return 3 * align_up(sizeof(int32_t) * (size_t)(rows + 1)) + align_up(sizeof(int32_t) * scan_block_sums(rows + 1)) +
+           align_up(sizeof(int32_t) * (size_t)edges) + 256;
+}
+
+// rev_ptr [m_src + 1] / rev_eid [E] of every job, as crfconv_reverse_csr builds them one table at a time (same contents),
+// in five launches for the whole batch.  At most 32 tables per call; rows and edges of the batch must stay below 2^31.
+extern "C" int crfconv_reverse_csr_batched(const crf_rev_job* jobs, int njobs, void* workspace, size_t workspace_bytes,
+                                           crf_stream_t stream) {
+    CRF_REQUIRE(jobs && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(njobs >= 1 && njobs <= RB_MAX, CRF_ERR_ARG, "njobs=%d outside [1, %d]", njobs, RB_MAX);
+    CRF_REQUIRE(workspace_bytes >= crfconv_reverse_csr_batched_workspace(jobs, njobs), CRF_ERR_WORKSPACE, "workspace too small");
+    RevBatch t;
+    int64_t rows = 0, edges = 0, chunks = 0;
+    for (int j = 0; j <= RB_MAX; ++j) {
+        if (j <= njobs) { t.row_base[j] = (int)rows; t.edge_base[j] = (int)edges; t.chunk_base[j] = (int)chunks; }
+        else { t.row_base[j] = t.row_base[njobs]; t.edge_base[j] = t.edge_base[njobs]; t.chunk_base[j] = t.chunk_base[njobs]; }
+        if (j < njobs) {
+            const crf_rev_job& jb = jobs[j];
+            CRF_REQUIRE(jb.idx32 && jb.rev_ptr && jb.rev_eid && jb.E > 0 && jb.m_src > 0, CRF_ERR_ARG, "job %d is malformed", j);
+            t.idx[j] = jb.idx32; t.rev_ptr[j] = jb.rev_ptr; t.rev_eid[j] = jb.rev_eid; t.m_src[j] = (int)jb.m_src;
+            rows += jb.m_src + 1; edges += jb.E; chunks += cdiv(jb.E, RB_EPB);
+            CRF_REQUIRE(rows < ((int64_t)1 << 31) - 1 && edges < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "batch too large for int32 offsets");
+        } else if (j < RB_MAX) {
+            t.idx[j] = nullptr; t.rev_ptr[j] = nullptr; t.rev_eid[j] = nullptr; t.m_src[j] = 0;
+        }
+    }
+    t.njobs = njobs;
+    hipStream_t st = as_stream(stream);
+    char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int64_t n = rows + 1;                        // one extra counter: ptrs[rows] = all edges that have a source
+    const size_t seg = align_up(sizeof(int32_t) * (size_t)n);
+    int32_t* cnt = reinterpret_cast<int32_t*>(ws);
+    int32_t* cursor = reinterpret_cast<int32_t*>(ws + seg);
+    int32_t* ptrs = reinterpret_cast<int32_t*>(ws + 2 * seg);
+    int32_t* sums = reinterpret_cast<int32_t*>(ws + 3 * seg);
+    int32_t* tmp = reinterpret_cast<int32_t*>(ws + 3 * seg + align_up(sizeof(int32_t) * scan_block_sums(n)));
+    int64_t zg = cdiv((int64_t)(2 * seg / 4), 256);
+    if (zg > 1024) zg = 1024;
+    hipLaunchKernelGGL(zero_i32_kernel, dim3((unsigned)zg), dim3(256), 0, st, cnt, (int64_t)(2 * seg / 4));
+    CRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(revb_count_kernel, dim3((unsigned)chunks), dim3(256), 0, st, t, cnt);
+    CRF_LAUNCH_CHECK();
+    exclusive_scan_i32(cnt, ptrs, n, sums, st);
+    CRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(revb_fill_kernel, dim3((unsigned)chunks), dim3(256), 0, st, t, ptrs, cursor, tmp);
+    CRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(revb_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, t, ptrs, tmp);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -103,8 +103,10 @@ class MultiScaleData(Data):
             _lib.call('crfconv_copy_jobs', ctypes.cast(jobs, ctypes.c_void_p), len(pairs), stream_ptr())
             for dst, _ in pairs:                           # written by a custom kernel: the version counters (table / moments
                 torch.autograd.graph.increment_version(dst)    # memos compare them) must say so
-        for a, n_src in tables:                            # after the copies: the refreshes read the new content
-            table_of(a, n_src)
+        from .graph import batched_reverse
+        with batched_reverse():                            # every table's reverse CSR in one set of launches at the end
+            for a, n_src in tables:                        # after the copies: the refreshes read the new content
+                table_of(a, n_src)
         return self
 
 

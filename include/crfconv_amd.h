@@ -125,6 +125,12 @@ size_t crfconv_reverse_csr_workspace(int64_t E, int64_t m_src);
 int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_src, int32_t* rev_ptr,
                         int32_t* rev_eid, void* workspace, size_t workspace_bytes,
                         crf_stream_t stream);
+/* The same for up to 32 tables in ONE set of five launches (a batch refresh rebuilds every table's reverse CSR: 14 tables =
+ * ~100 launches one by one): identical rev_ptr / rev_eid contents.  jobs is a host array. */
+typedef struct { const int32_t* idx32; int64_t E; int64_t m_src; int32_t* rev_ptr; int32_t* rev_eid; } crf_rev_job;
+size_t crfconv_reverse_csr_batched_workspace(const crf_rev_job* jobs, int njobs);
+int crfconv_reverse_csr_batched(const crf_rev_job* jobs, int njobs, void* workspace, size_t workspace_bytes,
+                                crf_stream_t stream);
 
 /* ===================================================================== (B) CRF mean field
  * Rows m = B*N (flattened clouds), H hidden channels (4, 8, 16, 32 or 64).

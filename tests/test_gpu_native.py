@@ -302,3 +302,26 @@ def test_random_subsets_device():
         ctr += 1
         hits += torch.bincount(draw(5)[2].cpu(), minlength=2560)
     assert abs(float(hits.float().mean()) - 50.0) < 1e-6 and int(hits.min()) >= 20 and int(hits.max()) <= 85
+
+
+def test_reverse_csr_batched_equals_one_by_one():
+    """graph.batched_reverse: the reverse CSRs of several tables of different shapes (a hub row, K = 1, K = 32)
+    built by one crfconv_reverse_csr_batched call must equal the one-table-at-a-time builds bit for bit."""
+    from crfconv_amd.graph import NeighborTable, batched_reverse
+    g = torch.Generator().manual_seed(21)
+    specs = [(2, 3000, 3000, 16), (2, 700, 3000, 16), (2, 3000, 700, 1), (1, 64, 64, 32), (3, 1000, 1000, 16)]
+    tabs = []
+    for B, n_tgt, n_src, K in specs:
+        idx = torch.randint(0, n_src, (B, n_tgt, K), generator=g)
+        if K == 16 and n_tgt == 1000:
+            idx[:, :, 3] = 5                                  # a hub
+        tabs.append(NeighborTable(idx.to('cuda'), n_src))
+    ref = [tuple(v.clone() for v in t.reverse) for t in tabs]
+    for t in tabs:
+        for v in t._rev:
+            v.fill_(-7)
+    with batched_reverse():
+        for t in tabs:
+            t._build_reverse(*t._rev)
+    for t, (rp, re) in zip(tabs, ref):
+        assert torch.equal(t._rev[0], rp) and torch.equal(t._rev[1], re)
