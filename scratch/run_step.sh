@@ -13,4 +13,4 @@ r = json.loads([l for l in open('$out/bench.log') if l.startswith('{')][0])
 print('value %.2f M pts/s  %.3f ms/step  pipelined %.3f ms  fwd %.1f us  bwd %.1f us  pc %s' % (r['value'], r['ms_per_step'], r['pipelined_ms_per_batch'], r['roofline']['avg_launch_us'], r['roofline_bwd']['avg_launch_us'], r.get('roofline_pointconv')))
 " | tee $out/summary.log
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $out/trace -o t -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/trace.log 2>&1 || { tail -20 $out/trace.log; exit 1; }
-python3 scratch/step_table.py $out/trace 400 > $out/step_table.txt 2>&1; head -40 $out/step_table.txt
+python3 scratch/step_table.py $out/trace 400 10 > $out/step_table.txt 2>&1; head -12 $out/step_table.txt
