@@ -111,7 +111,7 @@ SIGNATURES = {
     'crfconv_crf_matrices_backward_batched': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'crfconv_add_lrelu': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
     'crfconv_bn_apply_add': (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp]),
-    'crfconv_bn_apply_dropout': (_i, [_vp, _i64, _i, _vp, _f, _f, _u64, _vp, _vp, _vp]),
+    'crfconv_bn_apply_dropout': (_i, [_vp, _i64, _i, _vp, _f, _f, _u64, _vp, _vp, _vp, _vp]),
     'crfconv_linear_forward_dropout': (_i, [_vp, _vp, _i64, _i, _i, _i, _f, _u64, _vp, _vp, _vp]),
     'crfconv_dropout_backward': (_i, [_vp, _i64, _f, _u64, _vp, _vp, _vp]),
     'crfconv_add_lrelu_backward': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),

@@ -150,8 +150,12 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply_add_kernel(const float* __r
 __global__ __launch_bounds__(BN_BLOCK) void bn_apply_dropout_kernel(const float* __restrict__ x, const float* __restrict__ coef,
                                                                     int64_t n4, int C4, float slope, unsigned long long seed,
                                                                     const long long* __restrict__ counter, unsigned threshold,
-                                                                    float scale, float* __restrict__ y) {
+                                                                    float scale, float* __restrict__ y,
+                                                                    long long* __restrict__ counter_used) {
     const unsigned long long ctr = (unsigned long long)counter[0];
+    // the counter value this call masked with, for ITS backward: the live word may have advanced by then (a second training
+    // forward before the first backward -- multi-view losses, forward-all-then-backward accumulation)
+    if (counter_used != nullptr && blockIdx.x == 0 && threadIdx.x == 0) counter_used[0] = (long long)ctr;
     for (int64_t t = (int64_t)blockIdx.x * BN_BLOCK + threadIdx.x; t < n4; t += (int64_t)gridDim.x * BN_BLOCK) {
         const int q = (int)(t % C4);
         const float4 a = ld4g(coef + 4 * q), b = ld4g(coef + 4 * C4 + 4 * q);
@@ -573,13 +577,15 @@ extern "C" int crfconv_bn_apply_add(const float* x, int64_t M, int C, const floa
 // out = dropout(lrelu(a x + b, slope), p): the mask of element e is a hash of (seed, *counter, e); counter = one int64 DEVICE word
 // the caller advances between steps.  crfconv_dropout_backward with the same (seed, counter value, p) applies the same mask.
 extern "C" int crfconv_bn_apply_dropout(const float* x, int64_t M, int C, const float* coef, float slope, float p,
-                                        uint64_t seed, const int64_t* counter, float* out, crf_stream_t stream) {
+                                        uint64_t seed, const int64_t* counter, float* out, int64_t* counter_used,
+                                        crf_stream_t stream) {
     if (int rc = bn_check(M, C)) return rc;
     CRF_REQUIRE(x && coef && counter && out, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(p >= 0.f && p < 1.f, CRF_ERR_ARG, "dropout probability %g outside [0, 1)", (double)p);
     const int64_t n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_apply_dropout_kernel, dim3(ew_grid(n4)), dim3(BN_BLOCK), 0, as_stream(stream), x, coef, n4, C / 4, slope,
-                       (unsigned long long)seed, reinterpret_cast<const long long*>(counter), crf::dropout_threshold(p), 1.f / (1.f - p), out);
+                       (unsigned long long)seed, reinterpret_cast<const long long*>(counter), crf::dropout_threshold(p), 1.f / (1.f - p), out,
+                       reinterpret_cast<long long*>(counter_used));
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

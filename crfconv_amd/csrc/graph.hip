@@ -1,6 +1,6 @@
 // Neighbour-table plumbing: int64 per-cloud tables -> int32 global rows, and the reverse
-// (source-major) CSR every backward scatter walks.  Integer work, HBM-bound; the sort and the
-// scan are rocPRIM device primitives, the rest are flat coalesced kernels.
+// (source-major) CSR every backward scatter walks.  Integer work, HBM-bound; counting sort + scan.hpp's exclusive scan
+// (no library sort, no scratch memory), flat coalesced kernels.
 #include "common.hpp"
 
 #include "scan.hpp"

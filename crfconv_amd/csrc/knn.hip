@@ -2,7 +2,7 @@
 // (utils/nearest_neighbors/knn_.cxx:22-135, knn_.h:2-19) with a uniform-grid search:
 //   1. per-cloud bounding box            (one block per cloud)
 //   2. cell id + histogram               (flat, int atomics)
-//   3. exclusive scan of cell counts     (rocPRIM)
+//   3. exclusive scan of cell counts     (scan.hpp: this library's own scratch-free scan)
 //   4. counting-sort scatter             (points packed as float4 {x, y, z, id})
 //   5. one thread per query: expanding Chebyshev rings of cells, register-resident top-K,
 //      stops when the K-th distance is strictly inside the searched cube.

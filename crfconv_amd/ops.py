@@ -955,7 +955,10 @@ class _MLPBlockDropout(torch.autograd.Function):
         _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
                   ptr(run_var), float(momentum), float(eps), ptr(coef), st)
         out = torch.empty_like(y)
-        _lib.call('crfconv_bn_apply_dropout', ptr(y), m, co, ptr(coef), float(slope), float(p), int(seed), ptr(counter), ptr(out), st)
+        used = torch.empty(1, dtype=torch.int64, device=x.device)     # the counter value of THIS call's mask, for its backward
+        _lib.call('crfconv_bn_apply_dropout', ptr(y), m, co, ptr(coef), float(slope), float(p), int(seed), ptr(counter), ptr(out),
+                  ptr(used), st)
+        counter = used
         ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef, counter)
         ctx.slope, ctx.p, ctx.seed = float(slope), float(p), int(seed)
@@ -998,7 +1001,10 @@ class _MLPDropoutLinear(torch.autograd.Function):
         _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
                   ptr(run_var), float(momentum), float(eps), ptr(coef), st)
         h = torch.empty_like(y)
-        _lib.call('crfconv_bn_apply_dropout', ptr(y), m, co, ptr(coef), float(slope), float(p), int(seed), ptr(counter), ptr(h), st)
+        used = torch.empty(1, dtype=torch.int64, device=x.device)     # the counter value of THIS call's mask, for its backward
+        _lib.call('crfconv_bn_apply_dropout', ptr(y), m, co, ptr(coef), float(slope), float(p), int(seed), ptr(counter), ptr(h),
+                  ptr(used), st)
+        counter = used
         logits = _mfma_matmul(h, W2c, None if b2 is None else b2.contiguous(), False)[0]
         ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef, counter, h, W2c)

@@ -524,9 +524,11 @@ int crfconv_add_lrelu(const float* a, const float* b, int64_t n, float slope, fl
  * out = dropout(lrelu(a x + b, slope), p).  The mask is counter-based -- element e is kept iff a hash of (seed, *counter, e)
  * reaches p 2^32 -- with `counter` one int64 DEVICE word the caller advances between training steps (so a captured graph
  * draws a new mask at every replay); crfconv_dropout_backward(g, n = M C, p, seed, counter) applies the same mask to the
- * gradient, nothing is stored.  Kept elements are scaled by 1 / (1 - p). */
+ * gradient, nothing is stored.  Kept elements are scaled by 1 / (1 - p).  counter_used (may be NULL): one int64 device
+ * word that receives the counter value this call masked with -- hand THAT to the backward, so that a second forward before
+ * the first backward (which advances the live counter) cannot change the first one's mask. */
 int crfconv_bn_apply_dropout(const float* x, int64_t M, int C, const float* coef, float slope, float p, uint64_t seed,
-                             const int64_t* counter, float* out, crf_stream_t stream);
+                             const int64_t* counter, float* out, int64_t* counter_used, crf_stream_t stream);
 int crfconv_dropout_backward(const float* g, int64_t n, float p, uint64_t seed, const int64_t* counter, float* gin,
                              crf_stream_t stream);
 /* The same mask applied by the kernel that PRODUCES g: Y = mask .* (X W^T, or X W when transpose_w != 0) / (1 - p), element

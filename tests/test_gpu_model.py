@@ -1587,3 +1587,37 @@ def test_grid_barrier_failure_is_raised_and_disables_the_one_launch_path():
         ops.check_gridsync(dev)
     finally:
         ops._small_mlp_disabled = was
+
+
+def test_two_training_forwards_before_backward_keep_their_own_dropout_masks():
+    """The fused MLP -> Dropout node keys its mask on the BatchNorm's step counter, a device word later forwards advance: the
+    backward of a call must use the counter value ITS forward saw (two forwards, then one backward -- multi-view losses,
+    forward-all-then-backward accumulation -- used to trip autograd's in-place check, and would have masked with the wrong counter)."""
+    from crfconv_amd import ops
+    g = torch.Generator().manual_seed(8)
+    m, ci, co = 8192, 32, 128
+    W = nn.Parameter((torch.randn(co, ci, generator=g) / 6).to(DEV))
+    bn = nn.BatchNorm1d(co).to(DEV).train()
+    x1 = torch.randn(m, ci, generator=g).to(DEV).requires_grad_()
+    x2 = torch.randn(m, ci, generator=g).to(DEV).requires_grad_()
+    r1, r2 = torch.randn(m, co, generator=g).to(DEV), torch.randn(m, co, generator=g).to(DEV)
+
+    def reset():
+        for t_ in (W, bn.weight, bn.bias, x1, x2):
+            t_.grad = None
+        bn.num_batches_tracked.fill_(10)
+    reset()
+    o1 = ops.mlp_block_dropout(x1, W, bn, 0.1, 0.5)
+    assert o1 is not None
+    (o1 * r1).sum().backward()                               # one after the other: counters 11, then 12
+    o2 = ops.mlp_block_dropout(x2, W, bn, 0.1, 0.5)
+    (o2 * r2).sum().backward()
+    ref = [t_.grad.clone() for t_ in (W, bn.weight, bn.bias, x1, x2)]
+    keep1, keep2 = (o1 != 0), (o2 != 0)
+    reset()
+    a1 = ops.mlp_block_dropout(x1, W, bn, 0.1, 0.5)          # both forwards first (the counter is at 12 when the backward runs)
+    a2 = ops.mlp_block_dropout(x2, W, bn, 0.1, 0.5)
+    assert torch.equal(a1 != 0, keep1) and torch.equal(a2 != 0, keep2) and not torch.equal(keep1, keep2)
+    ((a1 * r1).sum() + (a2 * r2).sum()).backward()
+    for got, want, name in zip((W, bn.weight, bn.bias, x1, x2), ref, ('dW', 'dgamma', 'dbeta', 'dx1', 'dx2')):
+        assert_close(got.grad, want, 1e-5, name)
