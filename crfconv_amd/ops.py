@@ -244,12 +244,33 @@ _FUSED_WS = {}
 _TICKETS = {}
 
 
+def _stream_key(device):
+    """(device index, handle of the stream the caller launches on): the inter-workgroup scratch words below are per stream,
+    so that launches on two streams of one device (a second training stream, evaluation beside training) never share
+    barrier / ticket counts.  Two hipGraphs CAPTURED on the same stream and replayed concurrently would still share --
+    capture each on its own stream."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if torch.cuda.is_current_stream_capturing():
+        return idx, 'capture'                      # captured launches: one buffer per device, created by the eager warm-up pass
+    return idx, int(torch.cuda.current_stream(idx).cuda_stream)
+
+
+def _stream_buf(table, device, make):
+    """table[(device, stream)] (see _stream_key), created on first use; the eager pass that creates a stream's buffer also
+    creates the device's capture buffer, so that a capture never allocates."""
+    key = _stream_key(device)
+    buf = table.get(key)
+    if buf is None:
+        buf = table[key] = make()
+        if key[1] != 'capture' and (key[0], 'capture') not in table:
+            table[(key[0], 'capture')] = make()
+    return buf
+
+
 def _ticket(device):
-    """One zero word per device for the "last workgroup finishes" reductions (left zero by the kernels)."""
-    t = _TICKETS.get(device)
-    if t is None:
-        t = _TICKETS[device] = torch.zeros(64, dtype=torch.int32, device=device)
-    return t
+    """Zero words for the "last workgroup finishes" reductions (left zero by the kernels), per (device, stream)."""
+    return _stream_buf(_TICKETS, device, lambda: torch.zeros(64, dtype=torch.int32, device=device))
 
 
 def _fused_ws(device):
@@ -1254,14 +1275,8 @@ _sync_ws = {}
 
 def gridsync_ws(dev):
     """The barrier words of the one-launch kernels (csrc/gridsync.hpp): zeroed once, left zero by every launch.  One buffer
-    per device: launches that use it must be ordered (one training stream per process -- the collate side stream of
-    data.CollatePipeline launches no such kernel).  Created by the un-captured warm-up pass every graph capture needs."""
-    key = dev.index
-    ws = _sync_ws.get(key)
-    if ws is None:
-        nbytes = _lib.load().crfconv_gridsync_workspace()
-        ws = _sync_ws[key] = torch.zeros(nbytes // 4, dtype=torch.int32, device=dev)
-    return ws
+    per (device, stream): launches that share one are ordered by their stream (see _stream_key for captured graphs)."""
+    return _stream_buf(_sync_ws, dev, lambda: torch.zeros(_lib.load().crfconv_gridsync_workspace() // 4, dtype=torch.int32, device=dev))
 
 
 _small_mlp_disabled = False       # set by check_gridsync after a barrier failure: the two-launch path from then on
@@ -1282,9 +1297,10 @@ def check_gridsync(dev=None):
     global _small_mlp_disabled
     word = _lib.load().crfconv_gridsync_fail_word()
     bad = []
-    for table in (_sync_ws, {getattr(d, 'index', d): w.view(torch.int32) for d, w in _FUSED_WS.items()}):
-        for key, ws in table.items():
-            if dev is not None and getattr(dev, 'index', dev) not in (None, key):
+    want = None if dev is None else torch.device(dev).index
+    for table in (_sync_ws, {(torch.device(d).index, 0): w.view(torch.int32) for d, w in _FUSED_WS.items()}):
+        for key, ws in list(table.items()):
+            if want is not None and key[0] is not None and key[0] != want:
                 continue
             code = int(ws[word].item())
             if code != 0:
@@ -1295,7 +1311,7 @@ def check_gridsync(dev=None):
         raise _lib.CrfConvError('grid barrier timed out on device(s) %s (code 0x%x): a one-launch kernel could not get all its '
                                 'workgroups resident; its outputs were poisoned with NaN.  The one-launch MLP path is now '
                                 'disabled for this process (CRFCONV_NO_SMALL_MLP=1 does the same up front).'
-                                % ([k for k, _ in bad], bad[0][1]))
+                                % (sorted({k[0] for k, _ in bad}), bad[0][1]))
 
 
 class _MLPSmall(torch.autograd.Function):
