@@ -10,6 +10,7 @@
 // (3 -> d) is computed per lane for its own quad; layer 2 (d -> d) broadcasts h1 over the L lanes
 // with shuffles against float4 rows of W2^T (registers for d <= 16, LDS above).
 #include "common.hpp"
+#include "outer_acc.hpp"
 #include <algorithm>
 
 namespace crf {
@@ -621,8 +622,16 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
                                                             float* __restrict__ partial,
                                                             double* __restrict__ partial_d) {
     constexpr int L = PC<D>::L;
-    constexpr bool ACC_REGS = (D <= 32);          // dW2 accumulators in registers vs LDS atomics
+    // dW2 = sum_e g_h2^T h1 -- a reduction over edges of d x d outer products: for d in {8, 16} on the MATRIX pipe (OuterAcc:
+    // the wave's g_h2 / h1 rows of one edge per point through a per-wave LDS tile that IS the 16x16x4 fragment layout, four
+    // MFMAs per edge round), which takes d FMAs + d/4 broadcasts per lane and edge off the vector ALU and 4 d accumulator
+    // registers off the wave (d = 16: 256 -> fewer than 200 registers); other widths keep registers / LDS atomics.
+    constexpr bool ACC_MFMA = (D == 8 || D == 16);
+    constexpr bool ACC_REGS = (D <= 32) && !ACC_MFMA;          // dW2 accumulators in registers vs LDS atomics
     constexpr int NSLOT = D * D;
+    __shared__ __attribute__((aligned(16))) float s_otile[ACC_MFMA ? 2 * PWAVES * 256 : 4];
+    __shared__ float s_ored[ACC_MFMA ? PWAVES * D * D : 1];
+    [[maybe_unused]] OuterAcc<ACC_MFMA ? D : 8, PBLOCK> oa;
     __shared__ double s_accd[PWAVES][4 * D];
     __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
     constexpr bool W2_LDS = (D <= 64);            // d = 128: the 64 KB of rows stay in L1/L2 instead
@@ -689,12 +698,18 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
         gh2.z = live * fmaf(va.z, g.z * xj.z, fmaf(vb.z, h2.z, vc.z));
         gh2.w = live * fmaf(va.w, g.w * xj.w, fmaf(vb.w, h2.w, vc.w));
         // dW2[quad][c'] += g_h2[quad] * h1[c'] ;  g_h1[quad'] = sum_c g_h2[c] W2[c][quad']
+        if constexpr (ACC_MFMA) {
+            float* ta = s_otile + wave * 512;
+            oa.add_rows(gh2, h1, ta, ta + 256, lane);          // g_h2 is zero for padding rows and missing neighbours
+        }
         float4 gh1 = make_float4(0.f, 0.f, 0.f, 0.f);
         static_for<L>([&](auto HQ) {
             constexpr int hq = decltype(HQ)::value;
             const float h0 = group_bcast<L, hq>(h1.x, base), h1b = group_bcast<L, hq>(h1.y, base);
             const float h2b = group_bcast<L, hq>(h1.z, base), h3 = group_bcast<L, hq>(h1.w, base);
-            if constexpr (ACC_REGS) {
+            if constexpr (ACC_MFMA) {
+                (void)h0; (void)h1b; (void)h2b; (void)h3;                  // (the outer product runs once per edge below)
+            } else if constexpr (ACC_REGS) {
                 dw2[4 * hq + 0] = fma4(h0, gh2, dw2[4 * hq + 0]);
                 dw2[4 * hq + 1] = fma4(h1b, gh2, dw2[4 * hq + 1]);
                 dw2[4 * hq + 2] = fma4(h2b, gh2, dw2[4 * hq + 2]);
@@ -770,7 +785,11 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < D * D; t += PBLOCK) partial[(int64_t)blockIdx.x * D * D + t] = s_acc[t];
+    if constexpr (ACC_MFMA) {
+        oa.store_partial(s_ored, partial, lane);               // block sum of the waves' accumulators -> partial[block][d * d]
+    } else {
+        for (int t = threadIdx.x; t < D * D; t += PBLOCK) partial[(int64_t)blockIdx.x * D * D + t] = s_acc[t];
+    }
     for (int t = threadIdx.x; t < 4 * D; t += PBLOCK) {
         double a = 0.0;
 #pragma unroll
