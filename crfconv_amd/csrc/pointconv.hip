@@ -18,6 +18,12 @@ namespace crf {
 #ifndef PARAMS_PB
 #define PARAMS_PB 4
 #endif
+#ifndef UV_GROUP
+#define UV_GROUP 4            // edges per trip of the narrow statistics / convolution pass (uvstats_kernel): 2 (round 2) 28.8, 8 27.5, 6 ~26, 4 24.9 us at d = 8
+#endif
+#ifndef PARAMS_PB_NARROW
+#define PARAMS_PB_NARROW 4      // (d <= 8 with eight edges per trip, 240 registers: 51.5 vs 49.2 us -- not the trips)
+#endif
 constexpr int PBLOCK = 256;
 constexpr int PWAVES = PBLOCK / WAVE;
 
@@ -436,6 +442,40 @@ __global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict
     const int32_t* irow = idx + rw.r * K;
     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+    if constexpr (EB == 1 && PC<D>::KS == 1) {
+        // narrow layers (d <= 16): UG edges per trip -- their index entries, then ALL their feature / position rows, then the
+        // arithmetic.  The two-edges-per-trip form below waited on memory 69 % of its cycles at four waves per SIMD
+        // (SQ_WAIT_ANY, scratch/run_pcpmc.sh): sixteen dependent load rounds per point, two rows in flight each.
+        constexpr int UG = UV_GROUP;
+        for (int k0 = 0; k0 < K; k0 += UG) {
+            int jj[UG];
+#pragma unroll
+            for (int e = 0; e < UG; ++e) jj[e] = (k0 + e < K) ? irow[k0 + e] : -1;
+            float4 xj[UG];
+            float rx[UG], ry[UG], rz[UG];
+#pragma unroll
+            for (int e = 0; e < UG; ++e) {
+                const int64_t j = jj[e] < 0 ? 0 : jj[e];
+                xj[e] = ld4(x + j * D + 4 * q);
+                rx[e] = px - pos_src[3 * j]; ry[e] = py - pos_src[3 * j + 1]; rz[e] = pz - pos_src[3 * j + 2];
+            }
+#pragma unroll
+            for (int e = 0; e < UG; ++e) {
+                const float live = (rw.valid && jj[e] >= 0) ? 1.f : 0.f;
+                const float4 xe = jj[e] < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : xj[e];
+                float4 pre, h1;
+                mlp.layer1(rx[e], ry[e], rz[e], pre, h1);
+                const float4 h2 = mlp.layer2(h1);
+                const float4 dlt = make_float4((h2.x - shift.x) * live, (h2.y - shift.y) * live, (h2.z - shift.z) * live,
+                                               (h2.w - shift.w) * live);
+                acc[0].x += dlt.x; acc[0].y += dlt.y; acc[0].z += dlt.z; acc[0].w += dlt.w;
+                acc[1] = make_float4(fmaf(dlt.x, dlt.x, acc[1].x), fmaf(dlt.y, dlt.y, acc[1].y),
+                                     fmaf(dlt.z, dlt.z, acc[1].z), fmaf(dlt.w, dlt.w, acc[1].w));
+                u = make_float4(fmaf(dlt.x, xe.x, u.x), fmaf(dlt.y, xe.y, u.y), fmaf(dlt.z, xe.z, u.z), fmaf(dlt.w, xe.w, u.w));
+                v.x += xe.x; v.y += xe.y; v.z += xe.z; v.w += xe.w;
+            }
+        }
+    } else
 #pragma unroll 2
     for (int k0 = (wave % PC<D>::KS) * EB; k0 < K; k0 += PC<D>::KS * EB) {
         float4 h1[EB], h2[EB], xj[EB];
@@ -669,7 +709,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
 
     // PB edges per trip: their index entries first, then all their feature / position rows, then the arithmetic -- two
     // dependent memory phases per PB edges instead of two per edge (one or two wavefronts per SIMD hide nothing)
-    constexpr int PB = PARAMS_PB;
+    constexpr int PB = (D <= 8) ? PARAMS_PB_NARROW : PARAMS_PB;
     for (int k0 = (wave % PC<D>::KS) * PB; k0 < K; k0 += PC<D>::KS * PB) {
         int jj_[PB];
 #pragma unroll
