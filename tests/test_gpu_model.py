@@ -858,8 +858,8 @@ def test_benchmarked_training_step_replayed_graph_matches_oracle_config2():
     _report_err('config-2 replayed train logits', logits, t64)
     _report_err('config-2 replayed loss', loss, l64)
     _report_err('config-2 replayed flat gradient bucket', flat, g64)
-    assert_close_anchored(logits, t32, t64, 5e-4, 'replayed train logits')          # BatchNorm in train mode: see DESIGN 4
-    assert_close_anchored(loss, l32, l64, 1e-4, 'replayed loss')
+    assert_close_anchored(logits, t32, t64, OUT_TOL, 'replayed train logits')       # the stated 1e-4 (measured: 2e-6 normalised, 7e-5 absolute)
+    assert_close_anchored(loss, l32, l64, 1e-5, 'replayed loss')
     assert flat.numel() == g64.numel()
     # per parameter tensor, relative to that tensor's largest gradient entry
     o, worst = 0, (0.0, '')
@@ -867,7 +867,7 @@ def test_benchmarked_training_step_replayed_graph_matches_oracle_config2():
         n = dict(net.named_parameters())[k].numel()
         e = relerr(flat[o:o + n], g64[o:o + n])
         e32 = relerr(g32[o:o + n], g64[o:o + n])
-        assert e <= max(3e-3, 4.0 * e32), '%s: gradient err %.2e (fp32 oracle %.2e)' % (k, e, e32)
+        assert e <= max(5e-4, 4.0 * e32), '%s: gradient err %.2e (fp32 oracle %.2e)' % (k, e, e32)      # measured worst: 4e-5
         worst = max(worst, (e, k))
         o += n
     print('worst parameter gradient: %s %.2e' % (worst[1], worst[0]))
