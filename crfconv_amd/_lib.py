@@ -101,6 +101,13 @@ SIGNATURES = {
     'crfconv_linear_forward_supported': (_i, [_i, _i]),
     'crfconv_linear_forward_stat_records': (_sz, [_i64]),
     'crfconv_linear_forward': (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    'crfconv_cat2': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
+    'crfconv_split2': (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
+    'crfconv_copy_batched_max_jobs': (_i, []),
+    'crfconv_copy_batched': (_i, [_vp, _vp, _vp, _i, _vp]),
+    'crfconv_add_i64': (_i, [_vp, _i64, _i64, _vp]),
+    'crfconv_gemm_supported': (_i, [_i64, _i, _i]),
+    'crfconv_gemm': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     'crfconv_bn_coef_from_records': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
     'crfconv_softmax_ce_workspace': (_sz, [_i64]),
     'crfconv_softmax_ce_forward': (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),

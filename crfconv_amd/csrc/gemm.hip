@@ -1,0 +1,210 @@
+// Small dense products of the per-point layers on the coarse levels:  C [M, N] = A [M, K] · B (+ bias [N]) (+ addend [M, N])
+//
+// The shapes the row-streaming kernels of linear.hip do not take: the coarse-level forward (models/common.py:30,35 -- MLP.lin
+// at 640 .. 10 240 rows, up to 512 channels) and every dX = gY · W of the MLP / ResNet-block backward (autograd of the same
+// lines), plus the per-edge g_h1 = g_h2 · W2 of the wide PointConv layers (models/point_conv_big.py:45-47).  M is small
+// (10^2 .. 10^5), K and N are 32 .. 512: a few hundred MFLOP each, bounded by dependent memory round trips and by how many
+// wavefronts the grid gives the 1024 SIMDs, not by the matrix pipe.
+//
+// Both operands go through LDS, fetched with whole-cache-line loads (8 lanes per 128-byte row segment of a 32-wide K chunk;
+// 64-byte row pieces read straight into the fragment layout measured 2 TB/s: 46 us for 2560 x 256 x 512), chunks c + 1 and
+// c + 2 in registers while chunk c is on the matrix pipe.  Four wavefronts per workgroup, WR x WC, each WM x WN tiles of
+// v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulation), D[i = n][j = row]:
+//   A operand lane l = (rr = l & 15, g = l >> 4):  B-matrix element [k = kc + 4 g + e][n = 16 tn + rr]
+//   B operand lane l:                              A-matrix element [row = 16 tm + rr][k = kc + 4 g + e]
+//   lane l ends with C[row = 16 tm + rr][n = 16 tn + 4 g + 0..3]: one 16-byte store.
+// The B tile keeps the layout its storage order gives for free ([n][k] for B = W [N, K], [k][n] for B = W [K, N]): no
+// transposing scalar traffic.  The tile shape is picked per problem so that the grid covers the chip.  Summation order
+// over k is fixed by the shape alone: results are bitwise reproducible.
+#include "common.hpp"
+
+#include <cstdlib>
+
+namespace crf {
+
+using gf32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int GM_BLOCK = 256, GM_BK = 32;
+
+template <int WM, int WN, int WR, int WC, bool BNK>
+__global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                        const float* __restrict__ bias, const float* __restrict__ addend,
+                                                        int M, int N, int K, float* __restrict__ C) {
+    static_assert(WR * WC * WAVE == GM_BLOCK, "four wavefronts");
+    constexpr int BM = 16 * WM * WR, BN = 16 * WN * WC;
+    constexpr int LDA = GM_BK + 4;                      // [BM][LDA]: 16-byte fragment reads along k, 8 lanes cover the 32 banks
+    constexpr int LDN = GM_BK + 4;                      // BNK: [BN][LDN], read like A
+    constexpr int LDK = BN + 4;                         // else: [GM_BK][LDK], scalar reads of rows 4 g + e: banks 16 g apart
+    constexpr int TA = BM * LDA, TB = BNK ? BN * LDN : GM_BK * LDK;
+    constexpr int NA4 = BM * GM_BK / 4, NB4 = BN * GM_BK / 4;       // float4 per tile
+    constexpr int PA = (NA4 + GM_BLOCK - 1) / GM_BLOCK, PB = (NB4 + GM_BLOCK - 1) / GM_BLOCK;
+    __shared__ float sA[2][TA];
+    __shared__ float sB[2][TB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rr = lane & 15, g = lane >> 4;
+    const int wr = wave / WC, wc = wave - wr * WC;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    struct Regs { float4 a[PA], b[PB]; };
+    auto fetch = [&](int kc, Regs& r) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int q = threadIdx.x + GM_BLOCK * i;
+            r.a[i] = zero4;
+            if (NA4 % GM_BLOCK != 0 && q >= NA4) continue;
+            const int row = m0 + q / (GM_BK / 4), k = kc + 4 * (q % (GM_BK / 4));
+            if (row < M && k < K) r.a[i] = *reinterpret_cast<const float4*>(A + (int64_t)row * K + k);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int q = threadIdx.x + GM_BLOCK * i;
+            r.b[i] = zero4;
+            if (NB4 % GM_BLOCK != 0 && q >= NB4) continue;
+            if constexpr (BNK) {
+                const int n = n0 + q / (GM_BK / 4), k = kc + 4 * (q % (GM_BK / 4));
+                if (n < N && k < K) r.b[i] = *reinterpret_cast<const float4*>(B + (int64_t)n * K + k);
+            } else {
+                const int k = kc + q / (BN / 4), n = n0 + 4 * (q % (BN / 4));
+                if (k < K && n < N) r.b[i] = *reinterpret_cast<const float4*>(B + (int64_t)k * N + n);
+            }
+        }
+    };
+    auto park = [&](int buf, const Regs& r) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int q = threadIdx.x + GM_BLOCK * i;
+            if (NA4 % GM_BLOCK != 0 && q >= NA4) continue;
+            *reinterpret_cast<float4*>(sA[buf] + (q / (GM_BK / 4)) * LDA + 4 * (q % (GM_BK / 4))) = r.a[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int q = threadIdx.x + GM_BLOCK * i;
+            if (NB4 % GM_BLOCK != 0 && q >= NB4) continue;
+            if constexpr (BNK) *reinterpret_cast<float4*>(sB[buf] + (q / (GM_BK / 4)) * LDN + 4 * (q % (GM_BK / 4))) = r.b[i];
+            else *reinterpret_cast<float4*>(sB[buf] + (q / (BN / 4)) * LDK + 4 * (q % (BN / 4))) = r.b[i];
+        }
+    };
+
+    gf32x4 acc[WM][WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + 16 * (wc * WN + j) + 4 * g;
+        float4 bv = zero4;
+        if (bias != nullptr && n < N) bv = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) acc[i][j] = gf32x4{bv.x, bv.y, bv.z, bv.w};
+    }
+    auto compute = [&](int buf) {
+        const float* ta = sA[buf] + (16 * wr * WM + rr) * LDA + 4 * g;
+        const float* tb = BNK ? sB[buf] + (16 * wc * WN + rr) * LDN + 4 * g : sB[buf] + 4 * g * LDK + 16 * wc * WN + rr;
+#pragma unroll
+        for (int s = 0; s < GM_BK / 16; ++s) {
+            float av[WM][4], wv[WN][4];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const float4 a4 = *reinterpret_cast<const float4*>(ta + 16 * i * LDA + 16 * s);
+                av[i][0] = a4.x; av[i][1] = a4.y; av[i][2] = a4.z; av[i][3] = a4.w;
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if constexpr (BNK) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(tb + 16 * j * LDN + 16 * s);
+                    wv[j][0] = w4.x; wv[j][1] = w4.y; wv[j][2] = w4.z; wv[j][3] = w4.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wv[j][e] = tb[(16 * s + e) * LDK + 16 * j];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j][e], av[i][e], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nchunk = (K + GM_BK - 1) / GM_BK;
+    Regs r0, r1;
+    fetch(0, r0);
+    if (nchunk > 1) fetch(GM_BK, r1);
+    park(0, r0);
+    __syncthreads();
+    // iteration c: chunk c sits in LDS buffer c & 1, chunk c + 1 in registers (fetched one iteration ago), chunk c + 2 is
+    // requested now; two iterations per trip so the two register sets keep their names
+    for (int c = 0; c < nchunk; c += 2) {
+        if (c + 2 < nchunk) fetch(GM_BK * (c + 2), r0);
+        compute(0);
+        if (c + 1 < nchunk) {
+            park(1, r1);                                 // buffer 1: its readers passed the barrier that ended chunk c - 1
+            __syncthreads();
+            if (c + 3 < nchunk) fetch(GM_BK * (c + 3), r1);
+            compute(1);
+            if (c + 2 < nchunk) {
+                park(0, r0);
+                __syncthreads();
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int row = m0 + 16 * (wr * WM + i) + rr;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + 16 * (wc * WN + j) + 4 * g;
+            if (n >= N) continue;
+            float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if (addend != nullptr) {
+                const float4 a4 = *reinterpret_cast<const float4*>(addend + (int64_t)row * N + n);
+                o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
+            }
+            *reinterpret_cast<float4*>(C + (int64_t)row * N + n) = o;
+        }
+    }
+}
+
+}  // namespace crf
+
+extern "C" int crfconv_gemm_supported(int64_t M, int N, int K) {
+    return (M >= 1 && M < (int64_t)1 << 31 && N >= 4 && K >= 4 && N % 4 == 0 && K % 4 == 0) ? 1 : 0;
+}
+
+// C [M, N] = A [M, K] · B + bias + addend.  b_is_nk != 0: B is [N, K] row-major (the F.linear weight: C = A Bᵀ),
+// else [K, N] row-major (C = A B: dX = gY · W with W [Co, Ci]).  bias [N] and addend [M, N] may be NULL; addend may alias C.
+extern "C" int crfconv_gemm(const float* A, const float* B, const float* bias, const float* addend, int64_t M, int N, int K,
+                            int b_is_nk, float* C, void* stream) {
+    CRF_REQUIRE(A != nullptr && B != nullptr && C != nullptr, CRF_ERR_ARG, "null operand");
+    CRF_REQUIRE(crfconv_gemm_supported(M, N, K), CRF_ERR_UNSUPPORTED, "gemm %lld x %d x %d: N and K must be multiples of 4",
+                (long long)M, N, K);
+    // tile shapes (rows x columns per workgroup): 64 x 64, 32 x 64, 64 x 32, 32 x 32 -- the largest that still gives the
+    // grid `min_blocks` workgroups.  Measured on the shapes of the training step (scratch/gemm_bench.py, graph replays): 32 x 32 is the
+    // fastest or within 0.5 us of it from 640 x 64 to 163 840 x 32 -- these launches are latency-bound, many short wavefronts win
+    static const int min_blocks = getenv("CRFCONV_GEMM_MIN_BLOCKS") ? atoi(getenv("CRFCONV_GEMM_MIN_BLOCKS")) : 4096;
+    static const int force = getenv("CRFCONV_GEMM_TILE") ? atoi(getenv("CRFCONV_GEMM_TILE")) : -1;
+    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (int64_t)((N + bn - 1) / bn); };
+    int shape = 3;
+    if (N > 32 && blocks(64, 64) >= min_blocks) shape = 0;
+    else if (N > 32 && blocks(32, 64) >= min_blocks) shape = 1;
+    else if (blocks(64, 32) >= min_blocks) shape = 2;
+    if (force >= 0 && force <= 3) shape = force;
+    hipStream_t st = crf::as_stream(stream);
+    const dim3 blk(crf::GM_BLOCK);
+#define GM(WM, WN, WR, WC)                                                                                                    \
+    do {                                                                                                                      \
+        const dim3 grid((unsigned)((M + 16 * WM * WR - 1) / (16 * WM * WR)), (unsigned)((N + 16 * WN * WC - 1) / (16 * WN * WC))); \
+        if (b_is_nk) hipLaunchKernelGGL((crf::gemm_kernel<WM, WN, WR, WC, true>), grid, blk, 0, st, A, B, bias, addend, (int)M, N, K, C); \
+        else hipLaunchKernelGGL((crf::gemm_kernel<WM, WN, WR, WC, false>), grid, blk, 0, st, A, B, bias, addend, (int)M, N, K, C);         \
+    } while (0)
+    switch (shape) {
+        case 0: GM(2, 2, 2, 2); break;       // 64 x 64
+        case 1: GM(1, 2, 2, 2); break;       // 32 x 64
+        case 2: GM(1, 2, 4, 1); break;       // 64 x 32
+        default: GM(1, 1, 2, 2); break;      // 32 x 32
+    }
+#undef GM
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}

@@ -1223,19 +1223,12 @@ static int lf_blocks(int64_t M) {
 
 }  // namespace crf
 
-// Supported when the weight slab fits LDS: min(Co, 128) x (Ci rounded to 16 + 4) floats <= 64 KB.
+// Supported when a 16-channel weight slab fits LDS: 16 x (Ci rounded to 16 + 4) floats (+ prologue rows) <= 64 KB, i.e. Ci <= ~1000.
 // Output tiles per workgroup and the dynamic LDS of linear_fwd_kernel for k = Ci inputs, Co outputs: weight slab
 // [16 tco][Ci rounded to 16, + 4], the five prologue coefficient rows (dX form), the four output staging tiles (tco >= 2).
 // 64 output channels per workgroup at most: the 128-channel form (tco = 8) needs 167 + 98 registers with the statistic
 // accumulators, i.e. ONE wavefront per SIMD (measured 68 -> 49 us for 163840 x 32 -> 128; 5.85 -> 5.80 ms per step).
-static int lf_tco(int Co) {
-    static const int max_tco = getenv("CRFCONV_LF_MAX_TCO") ? atoi(getenv("CRFCONV_LF_MAX_TCO")) : 4;
-    const int tiles = (Co + 15) / 16;
-    const int tco = tiles >= 8 ? 8 : (tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1));
-    return tco > max_tco ? max_tco : tco;
-}
-static size_t lf_lds_bytes(int Ci, int Co, bool pro) {
-    const int tco = lf_tco(Co);
+static size_t lf_lds_bytes_at(int Ci, int tco, bool pro) {
     const size_t cip = (size_t)((Ci + 15) / 16) * 16 + 4, cik = cip - 4;
     size_t floats = 16 * (size_t)tco * cip;
     const size_t stats = 4 * 4 * 16 * (size_t)tco;                   // the statistics epilogue reuses the slab as [4][4][16 tco]
@@ -1244,6 +1237,17 @@ static size_t lf_lds_bytes(int Ci, int Co, bool pro) {
     if (tco >= 2) floats += 4 * 16 * (16 * (size_t)tco + 4);
     return sizeof(float) * floats;
 }
+// Output tiles per workgroup: by Co, then halved until the slab of k = Ci inputs fits 64 KB (256 inputs: 32 channels per
+// workgroup, 512: 16 -- the operand rows are then read once per column slab, from L2).
+static int lf_tco(int Ci, int Co, bool pro) {
+    static const int max_tco = getenv("CRFCONV_LF_MAX_TCO") ? atoi(getenv("CRFCONV_LF_MAX_TCO")) : 4;
+    const int tiles = (Co + 15) / 16;
+    int tco = tiles >= 8 ? 8 : (tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1));
+    if (tco > max_tco) tco = max_tco;
+    while (tco > 1 && lf_lds_bytes_at(Ci, tco, pro) > 64 * 1024) tco >>= 1;
+    return tco;
+}
+static size_t lf_lds_bytes(int Ci, int Co, bool pro) { return lf_lds_bytes_at(Ci, lf_tco(Ci, Co, pro), pro); }
 
 extern "C" int crfconv_linear_forward_supported(int Ci, int Co) {
     if (Ci < 1 || Co < 1) return 0;
@@ -1270,7 +1274,7 @@ static int linear_forward_impl(const float* X, const float* Xb, int xsplit, cons
     CRF_REQUIRE(Xb == nullptr || (xsplit > 0 && xsplit < Ci && xsplit % 4 == 0 && Ci % 4 == 0), CRF_ERR_ARG,
                 "two-operand form needs 0 < split < Ci, both multiples of 4 (split=%d Ci=%d)", xsplit, Ci);
     const int tiles = (Co + 15) / 16;
-    const int tco = lf_tco(Co);
+    const int tco = lf_tco(Ci, Co, false);
     const int gy = (tiles + tco - 1) / tco;
     const dim3 grid((unsigned)crf::lf_blocks(M), (unsigned)gy), blk(crf::LF_BLOCK);
     const size_t lds = lf_lds_bytes(Ci, Co, false);
@@ -1501,7 +1505,7 @@ static int mlp_backward_impl(const float* gA, const float* Y, const float* X, co
         // dX [M, Ci] = gY [M, Co] W [Co, Ci]: the forward kernel with k = Co, outputs = Ci, W read transposed
         const int gCi = Co, gCo = Ci;
         const int tiles = (gCo + 15) / 16;
-        const int tco = lf_tco(gCo);
+        const int tco = lf_tco(gCi, gCo, true);
         const int gy = (tiles + tco - 1) / tco;
         const dim3 grid((unsigned)crf::lf_blocks(M), (unsigned)gy), blk(crf::LF_BLOCK);
         const size_t lds = lf_lds_bytes(gCi, gCo, true);

@@ -28,6 +28,22 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def _copy_batched(dsts, srcs):
+    """dsts[i].copy_(srcs[i]) for contiguous float32 CUDA tensors: one library launch per 96 pairs (rows.hip)."""
+    import ctypes
+    from . import _lib
+    from .graph import stream_ptr
+    cap = _lib.load().crfconv_copy_batched_max_jobs()
+    for o in range(0, len(dsts), cap):
+        d, s_ = dsts[o:o + cap], srcs[o:o + cap]
+        n = len(d)
+        src = (ctypes.c_void_p * n)(*[t.data_ptr() for t in s_])
+        dst = (ctypes.c_void_p * n)(*[t.data_ptr() for t in d])
+        cnt = (ctypes.c_int64 * n)(*[t.numel() for t in d])
+        _lib.call('crfconv_copy_batched', ctypes.cast(src, ctypes.c_void_p), ctypes.cast(dst, ctypes.c_void_p),
+                  ctypes.cast(cnt, ctypes.c_void_p), n, stream_ptr())
+
+
 class FlatGradAllReduce:
     """One contiguous fp32 bucket for the whole model (820 141 floats = 3.3 MB for PointConvBig(6, 13)):
     a single all-reduce per step.  ``zero()`` sets the gradients to None, so backward installs fresh tensors
@@ -63,7 +79,10 @@ class FlatGradAllReduce:
                 if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         missing = [v for p, v in zip(self.params, self.views) if p.grad is None]
         if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            if self.flat.is_cuda and all(g.is_cuda and g.dtype == torch.float32 for _, g in have):
+                _copy_batched([v for v, _ in have], [g.contiguous() for _, g in have])
+            else:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         if missing:
             torch._foreach_zero_(missing)
         for p, v in zip(self.params, self.views):

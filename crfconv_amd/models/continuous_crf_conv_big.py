@@ -56,4 +56,4 @@ class ContinuousGaussianCRFConv(nn.Module):
                                     fus.activation.negative_slope)
             if out is not None:
                 return out
-        return fus(torch.cat([refined, pairwise], dim=-1))
+        return fus(ops.cat2(refined, pairwise))

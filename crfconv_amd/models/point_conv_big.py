@@ -105,7 +105,10 @@ class ResNetBBlock(nn.Module):
                     x = alias.reshape(x.shape)
                 skip = pooled.reshape(x.shape[0], -1, pooled.shape[-1])
         if skip is None:
-            skip = sc(x)
+            if return_input_alias and isinstance(sc, MLP):
+                skip, x = mlp_fork(sc, x)                  # coarse levels: the decoder's gradient joins inside the shortcut's dX product
+            else:
+                skip = sc(x)
             if strided:                                    # strided block: pool the shortcut onto the coarse points
                 skip = self.max_pooling(skip, neighbor_idx)
         y = self.point_conv(h_in, pos, neighbor_idx, prefold=prefold)
@@ -127,7 +130,7 @@ class Upsampling(nn.Module):
         return up.reshape(x.shape[0], -1, x.shape[-1])
 
     def forward(self, x_down, x_up, up_idx, neighbor_idx=None):
-        return self.fusion(torch.cat([x_up, self.lin(self.upsampling(x_down, up_idx))], dim=-1))
+        return self.fusion(ops.cat2(x_up, self.lin(self.upsampling(x_down, up_idx))))
 
 
 class PointConvResNet(Base):

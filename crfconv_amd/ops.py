@@ -674,6 +674,22 @@ def _mfma_ok(m, ci, co):
     return (not _VENDOR_ONLY) and m >= _MFMA_MIN_ROWS and bool(_lib.load().crfconv_linear_forward_supported(ci, co))
 
 
+def _gemm(A, B, bias=None, addend=None, nk=False):
+    """A [M, K] @ B (+ bias) (+ addend) on the tiled fp32 MFMA kernel of gemm.hip -- the products the row-streaming kernel of
+    linear.hip does not take (coarse levels, wide layers).  nk: B is [N, K] (the F.linear weight), else [K, N].  Shapes the
+    kernel does not cover (N or K not a multiple of 4) go to the vendor GEMM."""
+    M, K = A.shape
+    N = B.shape[0] if nk else B.shape[1]
+    if _VENDOR_ONLY or M == 0 or not _lib.load().crfconv_gemm_supported(M, N, K):
+        C = torch.nn.functional.linear(A, B, bias) if nk else (A @ B if bias is None else torch.addmm(bias, A, B))
+        return C if addend is None else C.add_(addend)
+    A, B = A.contiguous(), B.contiguous()
+    C = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    _lib.call('crfconv_gemm', ptr(A), ptr(B), ptr(None if bias is None else bias.contiguous()),
+              ptr(None if addend is None else addend.contiguous()), M, N, K, 1 if nk else 0, ptr(C), stream_ptr())
+    return C
+
+
 def _mfma_matmul(x, W, b, transpose_w, want_stats=False):
     """x [m, k] @ (W^T or W) on the fp32 MFMA kernel (linear.hip); optional BatchNorm statistic records."""
     m, ci = x.shape
@@ -708,7 +724,7 @@ class _Linear(torch.autograd.Function):
         if _mfma_ok(m, ci, Wc.shape[0]):
             y, rec = _mfma_matmul(x, Wc, None if b is None else b.contiguous(), False, want_stats)
         else:
-            y = torch.nn.functional.linear(x, Wc, b)
+            y = _gemm(x, Wc, b, nk=True)
         if want_stats:
             if rec is None:
                 rec = torch.empty(0, device=x.device)
@@ -726,7 +742,7 @@ class _Linear(torch.autograd.Function):
         Ci = x.shape[1]
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = _mfma_matmul(g, W, None, True)[0] if _mfma_ok(m, Co, Ci) else g @ W
+            gx = _mfma_matmul(g, W, None, True)[0] if _mfma_ok(m, Co, Ci) else _gemm(g, W)
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             if _defer_ok(ctx.params):
@@ -789,7 +805,10 @@ class advance_counters:
                 flat = cache[1] = torch.stack([b.num_batches_tracked.reshape(()) for b in bns])
                 for i, b in enumerate(bns):
                     b._buffers['num_batches_tracked'] = flat[i]
-            flat += 1
+            if flat.is_cuda:
+                _lib.call('crfconv_add_i64', ptr(flat), flat.numel(), 1, stream_ptr())
+            else:
+                flat += 1
         self.prev = _COUNTERS_ADVANCED
         _COUNTERS_ADVANCED = True
         return self
@@ -1239,7 +1258,7 @@ class _MLPSmallJoin(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_bn_backward', ptr(g1), ptr(y), ptr(coef), m, co, 1, 1.0, ptr(gY), ptr(dgamma), ptr(dbeta), ptr(ws),
                   nbytes, st)
-        dX = gY @ W if ctx.needs_input_grad[0] else None
+        dX = _gemm(gY, W) if ctx.needs_input_grad[0] else None
         gskip = g1 if ctx.needs_input_grad[8] else None
         if _defer_ok(ctx.params):
             _defer_weight_grad(gY, x, ctx.params, False)
@@ -1360,7 +1379,7 @@ class _MLPSmall(torch.autograd.Function):
                   ptr(ws), nbytes, stream_ptr())
         dX = None
         if ctx.needs_input_grad[0]:
-            dX = gY @ W if g_alias is None else torch.addmm(g_alias.reshape(m, ci), gY, W)
+            dX = _gemm(gY, W, addend=None if g_alias is None else g_alias.reshape(m, ci))
         if _defer_ok(ctx.params):
             _defer_weight_grad(gY, x, ctx.params, False)
             return dX, None, *(_param_ret(q, o, k) for q, (o, k) in zip(ctx.prm[1:], outs)), None, None, None, None, None, None
@@ -1418,6 +1437,42 @@ class _MLPBlockCat(torch.autograd.Function):
         return (dxa if ctx.needs_input_grad[0] else None, dxb if ctx.needs_input_grad[1] else None,
                 *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef),
                 None, None, None, None, None)
+
+
+class _Cat2(torch.autograd.Function):
+    """torch.cat([xa, xb], -1) on [m, ca] / [m, cb] rows as one library launch; the backward hands back two CONTIGUOUS
+    gradients from one pass (autograd's own backward returns strided slices, which every consumer then copies)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb):
+        xa, xb = xa.contiguous(), xb.contiguous()
+        m, ca = xa.shape
+        cb = xb.shape[1]
+        out = torch.empty((m, ca + cb), dtype=torch.float32, device=xa.device)
+        _lib.call('crfconv_cat2', ptr(xa), ptr(xb), m, ca, cb, ptr(out), stream_ptr())
+        ctx.widths = (ca, cb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ca, cb = ctx.widths
+        g = g.contiguous()
+        m = g.shape[0]
+        ga = torch.empty((m, ca), dtype=torch.float32, device=g.device)
+        gb = torch.empty((m, cb), dtype=torch.float32, device=g.device)
+        _lib.call('crfconv_split2', ptr(g), m, ca, cb, ptr(ga), ptr(gb), stream_ptr())
+        return ga, gb
+
+
+def cat2(xa, xb):
+    """torch.cat([xa, xb], dim=-1) for two float32 CUDA tensors of equal leading shape (the fusion layers' input where the
+    two-pointer Linear does not apply); other inputs go to torch.cat."""
+    ca, cb = xa.shape[-1], xb.shape[-1]
+    if not (xa.is_cuda and xb.is_cuda and xa.dtype == torch.float32 and xb.dtype == torch.float32
+            and xa.shape[:-1] == xb.shape[:-1] and ca % 4 == 0 and cb % 4 == 0 and ca >= 4 and cb >= 4 and xa.numel() > 0):
+        return torch.cat([xa, xb], dim=-1)
+    out = _Cat2.apply(xa.reshape(-1, ca), xb.reshape(-1, cb))
+    return out.reshape(xa.shape[:-1] + (ca + cb,))
 
 
 def mlp_block_cat(xa, xb, W, bn, training, slope=1.0):
@@ -1813,7 +1868,7 @@ class _PointConv(torch.autograd.Function):
                 wbytes = _lib.load().crfconv_linear_wgrad_workspace(E, d, d)
                 wws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
                 _lib.call('crfconv_linear_wgrad', ptr(gh2), ptr(h1), E, d, d, ptr(dW2), None, ptr(wws), wbytes, st)
-            gw = gh2 @ W2                                                  # g_h1 before the LeakyReLU mask
+            gw = _gemm(gh2, W2)                                            # g_h1 before the LeakyReLU mask
             dA1b1 = torch.empty((d, 4), dtype=torch.float64, device=dev)
             abytes = _lib.load().crfconv_pointconv_bwd_a1_workspace(E, d)
             aws = torch.empty(abytes, dtype=torch.uint8, device=dev)

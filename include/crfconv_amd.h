@@ -466,7 +466,8 @@ int crfconv_bn_backward(const float* gy, const float* x, const float* coef, int6
 int crfconv_bn_apply(const float* x, int64_t M, int C, const float* coef, float slope, float* y, crf_stream_t stream);
 
 /* Y [M, Co] = X [M, Ci] W^T (+ bias) on fp32 MFMA, X streamed once, W resident in LDS (needs
- * crfconv_linear_forward_supported(Ci, Co): the <= 128-channel weight slab fits 64 KB).  W is [Co, Ci] row-major, or
+ * crfconv_linear_forward_supported(Ci, Co): a 16-channel weight slab of Ci inputs fits 64 KB; the slab is 64 channels
+ * wide where that fits, else 32 / 16).  W is [Co, Ci] row-major, or
  * [Ci, Co] when transpose_w != 0 (the input-gradient product dX = G W).  stat_rec (may be NULL): float
  * [crfconv_linear_forward_stat_records(M)][Co][4] receives per-workgroup {shift, n, sum(y - shift), sum (y - shift)^2},
  * from which crfconv_bn_coef_from_records forms the BatchNorm coefficients (coef [4, Co], as crfconv_bn_forward) --
@@ -475,6 +476,29 @@ int crfconv_linear_forward_supported(int Ci, int Co);
 size_t crfconv_linear_forward_stat_records(int64_t M);
 int crfconv_linear_forward(const float* X, const float* W, const float* bias, int64_t M, int Ci, int Co,
                            int transpose_w, float* Y, float* stat_rec, crf_stream_t stream);
+/* Row plumbing of the training step (csrc/rows.hip), so that a captured step launches no framework kernel:
+ *  crfconv_cat2: out [m, ca + cb] = [xa | xb] -- the torch.cat in front of the fusion layers
+ *    (models/continuous_crf_conv_big.py:71, models/point_conv_big.py:107) on the levels where the two-pointer Linear does not
+ *    apply; crfconv_split2 is its backward (two contiguous gradients in one pass).  ca, cb multiples of 4.
+ *  crfconv_copy_batched: dst[j][0 .. n[j]) = src[j][...] for up to crfconv_copy_batched_max_jobs() contiguous float ranges in
+ *    one launch (gradients into the flat all-reduce bucket; replaces torch._foreach_copy_).  src / dst / n are HOST arrays.
+ *  crfconv_add_i64: x[0 .. n) += delta (the num_batches_tracked counters of all BatchNorm layers, one launch). */
+int crfconv_cat2(const float* xa, const float* xb, int64_t m, int ca, int cb, float* out, crf_stream_t stream);
+int crfconv_split2(const float* g, int64_t m, int ca, int cb, float* ga, float* gb, crf_stream_t stream);
+int crfconv_copy_batched_max_jobs(void);
+int crfconv_copy_batched(const float* const* src, float* const* dst, const int64_t* n, int njobs, crf_stream_t stream);
+int crfconv_add_i64(int64_t* x, int64_t n, int64_t delta, crf_stream_t stream);
+
+/* C [M, N] = A [M, K] B (+ bias [N]) (+ addend [M, N]) on fp32 MFMA for the shapes crfconv_linear_forward does not take:
+ * the coarse-level Linear forward (models/common.py:30,35 at 640 .. 10 240 rows, up to 512 channels), every dX = gY W of
+ * the MLP / ResNet-block backward and g_h1 = g_h2 W2 of the wide PointConv layers (models/point_conv_big.py:45-47) --
+ * replaces the rocBLAS / hipBLASLt call behind torch.nn.functional.linear / torch.mm / torch.addmm at those sites.
+ * b_is_nk != 0: B is [N, K] row-major (C = A B^T, the F.linear weight layout), else [K, N] row-major.  bias and addend
+ * may be NULL; addend may alias C.  N and K multiples of 4 (crfconv_gemm_supported).  64 rows x 16/32/64 columns per
+ * workgroup, the B tile double-buffered in LDS, the slab width picked so the grid covers the chip; fixed summation order. */
+int crfconv_gemm_supported(int64_t M, int N, int K);
+int crfconv_gemm(const float* A, const float* B, const float* bias, const float* addend, int64_t M, int N, int K,
+                 int b_is_nk, float* C, crf_stream_t stream);
 int crfconv_bn_coef_from_records(const float* stat_rec, int64_t M, int C, const float* gamma, const float* beta,
                                  float* run_mean, float* run_var, float momentum, float eps, float* coef,
                                  crf_stream_t stream);

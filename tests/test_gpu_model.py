@@ -927,6 +927,8 @@ def test_linear_wgrad_mfma(M, Ci, Co, bias):
 @pytest.mark.parametrize('M,Ci,Co,slope,need_dx', [(163840, 32, 8, 0.1, True), (163840, 6, 32, 0.1, False), (40960, 64, 16, 1.0, True),
                                                    (163840, 32, 128, 0.1, True), (10240, 128, 32, 0.1, True), (4100, 24, 64, 0.1, True),
                                                    (40963, 16, 64, 1.0, True), (10240, 32, 128, 1.0, True),
+                                                   # wide layers of the 2 560-point level: narrower weight slabs (32 / 16 channels per workgroup)
+                                                   (10240, 256, 128, 0.1, True), (10240, 128, 256, 1.0, True), (4100, 512, 64, 0.1, True), (4100, 64, 512, 0.1, True),
                                                    # coarse levels: the one-launch forward of csrc/mlp_small.hip (grid barrier)
                                                    (2560, 256, 64, 0.1, True), (2560, 64, 256, 1.0, True), (1280, 512, 128, 0.1, True),
                                                    (1280, 128, 512, 1.0, True), (4095, 512, 512, 0.1, True), (1000, 80, 192, 0.2, True),
@@ -1343,6 +1345,81 @@ def test_linear_forward_mfma_and_fused_stats(M, Ci, Co, bias):
         out = ops.bn_act(y.detach(), bn, True, 1.0, records=rec)
         assert_close(out, ref(yr), 1e-5, 'BN from records')
         assert_close(bn.running_var, ref.running_var, 1e-6, 'running_var from records')
+
+
+@pytest.mark.parametrize('M,N,K,nk', [(640, 128, 512, 0), (2560, 512, 256, 0), (2560, 256, 512, 0), (640, 64, 64, 0), (10240, 128, 128, 0),
+                                      (163840, 32, 32, 0), (2560, 32, 256, 1), (10240, 128, 256, 1), (1000, 36, 20, 0), (77, 12, 8, 1),
+                                      (1, 4, 4, 0), (65, 68, 100, 1), (33, 132, 36, 0)])
+def test_gemm_kernel_vs_float64(M, N, K, nk):
+    """crfconv_gemm (csrc/gemm.hip: the coarse-level Linear forward and every dX / g_h1 product that used to be a vendor
+    GEMM) against float64 torch, with and without the bias / addend epilogue, ragged tile edges included; bitwise
+    reproducible; every tile shape (CRFCONV_GEMM_TILE is read once, so the shapes are forced through the row count)."""
+    from crfconv_amd import _lib
+    from crfconv_amd.ops import ptr, stream_ptr, _gemm
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    B = (torch.randn(N, K, generator=g) if nk else torch.randn(K, N, generator=g)).to(DEV)
+    bias, add = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    Bd = B.double().t() if nk else B.double()
+    ref = A.double() @ Bd
+    scale = float(ref.abs().max())
+    C = _gemm(A, B, nk=bool(nk))
+    assert float((C.double() - ref).abs().max()) <= 2e-6 * scale
+    C2 = _gemm(A, B, bias, add, nk=bool(nk))
+    assert float((C2.double() - (ref + bias.double() + add.double())).abs().max()) <= 2e-6 * (scale + 8.0)
+    assert torch.equal(C, _gemm(A, B, nk=bool(nk)))
+    # addend aliasing the output (the in-place accumulate form)
+    acc = add.clone()
+    _lib.call('crfconv_gemm', ptr(A), ptr(B), None, ptr(acc), M, N, K, nk, ptr(acc), stream_ptr())
+    torch.cuda.synchronize()
+    assert float((acc.double() - (ref + add.double())).abs().max()) <= 2e-6 * (scale + 8.0)
+
+
+def test_gemm_refuses_unaligned_widths_and_linear_falls_back():
+    from crfconv_amd import _lib, ops
+    from crfconv_amd.ops import ptr, stream_ptr
+    assert _lib.load().crfconv_gemm_supported(10, 6, 8) == 0 and _lib.load().crfconv_gemm_supported(10, 8, 6) == 0
+    A, B, C = torch.randn(10, 8, device=DEV), torch.randn(8, 6, device=DEV), torch.empty(10, 6, device=DEV)
+    with pytest.raises(_lib.CrfConvError):
+        _lib.call('crfconv_gemm', ptr(A), ptr(B), None, None, 10, 6, 8, 0, ptr(C), stream_ptr())
+    assert_close(ops._gemm(A, B), A.double() @ B.double(), 1e-5, 'fallback product')
+
+
+@pytest.mark.parametrize('m,ca,cb', [(2560, 256, 256), (10240, 128, 128), (7, 4, 12), (1, 8, 4)])
+def test_cat2_and_its_backward(m, ca, cb):
+    """ops.cat2 (rows.hip) == torch.cat, forward and backward (contiguous gradients), 3-D leading shape kept."""
+    from crfconv_amd import ops
+    g = torch.Generator().manual_seed(m + ca)
+    xa = torch.randn(1, m, ca, generator=g).to(DEV).requires_grad_(True)
+    xb = torch.randn(1, m, cb, generator=g).to(DEV).requires_grad_(True)
+    go = torch.randn(1, m, ca + cb, generator=g).to(DEV)
+    out = ops.cat2(xa, xb)
+    assert out.shape == (1, m, ca + cb) and torch.equal(out, torch.cat([xa, xb], -1))
+    out.backward(go)
+    assert xa.grad.is_contiguous() and xb.grad.is_contiguous()
+    assert torch.equal(xa.grad, go[..., :ca]) and torch.equal(xb.grad, go[..., ca:])
+    # widths that are not multiples of 4: the framework's cat
+    assert ops.cat2(xa[..., :3], xb).shape == (1, m, 3 + cb)
+
+
+def test_bucket_pack_and_counters_use_library_launches():
+    """FlatGradAllReduce.pack() (crfconv_copy_batched, more pairs than one launch takes) and advance_counters (crfconv_add_i64)."""
+    from crfconv_amd import distributed as D, ops
+    net = torch.nn.ModuleList([torch.nn.Linear(3 + i % 5, 2 + i % 3) for i in range(60)]).to(DEV)     # 120 parameters > 96 jobs
+    bucket = D.FlatGradAllReduce(net)
+    grads = []
+    for i, p in enumerate(net.parameters()):
+        p.grad = torch.full_like(p, float(i + 1)) if i % 7 else None
+        grads.append(None if p.grad is None else p.grad.clone())
+    bucket.pack()
+    for p, v, g0 in zip(bucket.params, bucket.views, grads):
+        assert p.grad.data_ptr() == v.data_ptr()
+        assert torch.equal(v, torch.zeros_like(v) if g0 is None else g0)
+    bns = torch.nn.Sequential(*[torch.nn.BatchNorm1d(4) for _ in range(5)]).to(DEV).train()
+    for _ in range(3):
+        with ops.advance_counters(bns):
+            pass
+    assert [int(b.num_batches_tracked) for b in bns] == [3] * 5
 
 
 @pytest.mark.parametrize('weighted', [True, False])
