@@ -103,8 +103,6 @@ SIGNATURES = {
     'crfconv_linear_forward': (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     'crfconv_cat2': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     'crfconv_split2': (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
-    'crfconv_copy_batched_max_jobs': (_i, []),
-    'crfconv_copy_batched': (_i, [_vp, _vp, _vp, _i, _vp]),
     'crfconv_add_i64': (_i, [_vp, _i64, _i64, _vp]),
     'crfconv_gemm_supported': (_i, [_i64, _i, _i]),
     'crfconv_gemm': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),

@@ -1,11 +1,9 @@
 // Row plumbing of the training step that is neither a contraction nor a normalisation: column concatenation of two per-point
 // feature tensors and its inverse (the fusion layers' torch.cat, models/continuous_crf_conv_big.py:71 and
-// models/point_conv_big.py:107, on the levels where the two-pointer Linear does not apply), the batched copy of gradients
-// into the flat all-reduce bucket, and the step-counter increment of the BatchNorm layers.  All HBM-bound streaming passes;
+// models/point_conv_big.py:107, on the levels where the two-pointer Linear does not apply) and the step-counter increment of
+// the BatchNorm layers (the batched gradient copy into the all-reduce bucket is crfconv_copy_jobs of graph.hip).  All HBM-bound streaming passes;
 // they exist so that a captured training step launches no framework kernel.
 #include "common.hpp"
-
-#define CRF_COPY_MAX_JOBS 96      /* 96 x (8 + 8 + 4) bytes of kernel arguments */
 
 namespace crf {
 
@@ -35,21 +33,6 @@ __global__ __launch_bounds__(RW_BLOCK) void split2_kernel(const float* __restric
         if (q < ca4) *reinterpret_cast<float4*>(ga + 4 * (r * ca4 + q)) = v;
         else *reinterpret_cast<float4*>(gb + 4 * (r * cb4 + (q - ca4))) = v;
     }
-}
-
-struct CopyJobs {
-    const float* src[CRF_COPY_MAX_JOBS];
-    float* dst[CRF_COPY_MAX_JOBS];
-    int n[CRF_COPY_MAX_JOBS];
-};
-
-// blockIdx.y = job; grid-stride over its elements
-__global__ __launch_bounds__(RW_BLOCK) void copy_jobs_kernel(CopyJobs jobs) {
-    const int j = blockIdx.y;
-    const float* __restrict__ s = jobs.src[j];
-    float* __restrict__ d = jobs.dst[j];
-    const int n = jobs.n[j];
-    for (int t = blockIdx.x * RW_BLOCK + threadIdx.x; t < n; t += gridDim.x * RW_BLOCK) d[t] = s[t];
 }
 
 __global__ __launch_bounds__(RW_BLOCK) void add_i64_kernel(long long* __restrict__ x, int n, long long delta) {
@@ -84,32 +67,6 @@ extern "C" int crfconv_split2(const float* g, int64_t m, int ca, int cb, float* 
     const int64_t n4 = m * (int64_t)((ca + cb) / 4);
     hipLaunchKernelGGL(crf::split2_kernel, dim3(crf::stream_grid(n4)), dim3(crf::RW_BLOCK), 0, crf::as_stream(stream), g, n4,
                        ca / 4, cb / 4, ga, gb);
-    CRF_LAUNCH_CHECK();
-    return CRF_OK;
-}
-
-extern "C" int crfconv_copy_batched_max_jobs(void) { return CRF_COPY_MAX_JOBS; }
-
-// dst[j][0 .. n[j]) = src[j][...] for njobs <= CRF_COPY_MAX_JOBS contiguous float ranges, one launch.
-extern "C" int crfconv_copy_batched(const float* const* src, float* const* dst, const int64_t* n, int njobs, void* stream) {
-    CRF_REQUIRE(njobs >= 0 && njobs <= CRF_COPY_MAX_JOBS, CRF_ERR_ARG, "at most %d copy jobs per launch (got %d)",
-                CRF_COPY_MAX_JOBS, njobs);
-    if (njobs == 0) return CRF_OK;
-    crf::CopyJobs jobs;
-    int64_t longest = 0;
-    for (int j = 0; j < njobs; ++j) {
-        CRF_REQUIRE(n[j] >= 0 && n[j] < ((int64_t)1 << 31) && (n[j] == 0 || (src[j] != nullptr && dst[j] != nullptr)), CRF_ERR_ARG,
-                    "copy job %d: bad range", j);
-        jobs.src[j] = src[j];
-        jobs.dst[j] = dst[j];
-        jobs.n[j] = (int)n[j];
-        if (n[j] > longest) longest = n[j];
-    }
-    if (longest == 0) return CRF_OK;
-    int64_t gx = (longest + crf::RW_BLOCK - 1) / crf::RW_BLOCK;
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(crf::copy_jobs_kernel, dim3((unsigned)gx, (unsigned)njobs), dim3(crf::RW_BLOCK), 0, crf::as_stream(stream),
-                       jobs);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -29,19 +29,13 @@ def init_from_env(backend=None):
 
 
 def _copy_batched(dsts, srcs):
-    """dsts[i].copy_(srcs[i]) for contiguous float32 CUDA tensors: one library launch per 96 pairs (rows.hip)."""
+    """dsts[i].copy_(srcs[i]) for contiguous CUDA tensors of equal dtype: one library launch (crfconv_copy_jobs, graph.hip)."""
     import ctypes
     from . import _lib
     from .graph import stream_ptr
-    cap = _lib.load().crfconv_copy_batched_max_jobs()
-    for o in range(0, len(dsts), cap):
-        d, s_ = dsts[o:o + cap], srcs[o:o + cap]
-        n = len(d)
-        src = (ctypes.c_void_p * n)(*[t.data_ptr() for t in s_])
-        dst = (ctypes.c_void_p * n)(*[t.data_ptr() for t in d])
-        cnt = (ctypes.c_int64 * n)(*[t.numel() for t in d])
-        _lib.call('crfconv_copy_batched', ctypes.cast(src, ctypes.c_void_p), ctypes.cast(dst, ctypes.c_void_p),
-                  ctypes.cast(cnt, ctypes.c_void_p), n, stream_ptr())
+    jobs = (_lib.CopyJob * len(dsts))(*[_lib.CopyJob(s_.data_ptr(), d.data_ptr(), d.numel() * d.element_size())
+                                        for d, s_ in zip(dsts, srcs)])
+    _lib.call('crfconv_copy_jobs', ctypes.cast(jobs, ctypes.c_void_p), len(dsts), stream_ptr())
 
 
 class FlatGradAllReduce:

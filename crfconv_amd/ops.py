@@ -130,7 +130,7 @@ class _MeanField(torch.autograd.Function):
         dP = torch.empty_like(P)
         skinny_tn(mts.view(T * m, H), Gs.view(T * m, H), dP)
         sumG = Gs.sum(0) if T > 1 else Gs[0]
-        dz = G0.addmm_(sumG, Q.t())               # x_0 = z path + the z Q term of every step (in place: no copy of G0)
+        dz = _gemm(sumG, Q, addend=G0, nk=True)   # x_0 = z path + the z Q term of every step: G_0 + (sum_t G_t) Q^T
         dQ = torch.empty_like(Q)
         skinny_tn(z, sumG, dQ)
         w = torch.empty_like(s)
@@ -287,7 +287,8 @@ class _MeanFieldWide(torch.autograd.Function):
     models/point_conv.py:318-339, on the coarsest point sets): the H x H tiles of csrc/crf.hip's kernels no longer fit
     LDS, so the graph work -- similarity soft-max, neighbour aggregation, the reverse-CSR scatters and the soft-max
     backward -- runs on the one-point-per-wavefront kernels (crfconv_wide_*), and the genuinely dense [m, H] x [H, H]
-    products of each step are library GEMMs.  Same recurrence and gradients as _MeanField."""
+    products of each step run on this library's tiled MFMA product (csrc/gemm.hip) and row-reduction kernel (dP, dQ).  Same
+    recurrence and gradients as _MeanField."""
 
     @staticmethod
     def forward(ctx, z, y, Q, P, table, k0, steps):
@@ -301,13 +302,13 @@ class _MeanFieldWide(torch.autograd.Function):
         K = table.K
         s = torch.empty((m, K), dtype=torch.float32, device=z.device)
         _lib.call('crfconv_wide_similarity', ptr(y), ptr(table.idx32), K, k0, m, H, ptr(s), st)
-        zq = z @ Q
+        zq = _gemm(z, Q)
         xs, msgs = [z], []
         for _ in range(steps):
             msg = torch.empty_like(z)
             _lib.call('crfconv_wide_aggregate', ptr(xs[-1]), ptr(s), ptr(table.idx32), K, k0, m, H, ptr(msg), st)
             msgs.append(msg)
-            xs.append(torch.addmm(zq, msg, P))
+            xs.append(_gemm(msg, P, addend=zq))
         ctx.table, ctx.k0, ctx.steps = table, k0, steps
         ctx.save_for_backward(z, y, Q, P, s, *xs[:-1], *msgs)
         return xs[-1] if steps > 0 else z.clone()
@@ -325,19 +326,25 @@ class _MeanFieldWide(torch.autograd.Function):
         rev_ptr, rev_eid = table.reverse
         st = stream_ptr()
         ds = torch.empty_like(s)
-        dP = torch.zeros_like(P)
-        sumG = torch.zeros_like(z)
+
+        def add(a, b):                 # a + b in one library launch (the residual-join kernel at slope 1)
+            out = torch.empty_like(a)
+            _lib.call('crfconv_add_lrelu', ptr(a), ptr(b), a.numel(), 1.0, ptr(out), st)
+            return out
+
+        dP = sumG = None
         for t in range(T, 0, -1):
-            gm = G @ P.t()
+            gm = _gemm(G, P, nk=True)                      # G P^T
             _lib.call('crfconv_wide_bwd_edge', ptr(gm), ptr(xs[t - 1]), ptr(table.idx32), K, k0, m, H, ptr(ds),
                       0 if t == T else 1, st)
-            dP.addmm_(msgs[t - 1].t(), G)
-            sumG += G
+            dPt = _gemm_tn(msgs[t - 1], G)
+            dP = dPt if dP is None else add(dP, dPt)
+            sumG = G if sumG is None else add(sumG, G)
             Gprev = torch.empty_like(z)
             _lib.call('crfconv_wide_scatter', ptr(gm), ptr(s), ptr(rev_ptr), ptr(rev_eid), K, m, H, None, 0, ptr(Gprev), st)
             G = Gprev
-        dz = G.addmm_(sumG, Q.t())
-        dQ = z.t() @ sumG
+        dz = _gemm(sumG, Q, addend=G, nk=True)             # G_0 + sum_t G_t Q^T
+        dQ = _gemm_tn(z, sumG)
         w = torch.empty_like(s)
         dy_self, dy = torch.empty_like(y), torch.empty_like(y)
         _lib.call('crfconv_wide_similarity_bwd', ptr(ds), ptr(s), ptr(y), ptr(table.idx32), K, k0, m, H, ptr(w),
@@ -402,9 +409,9 @@ class _WeightedStep(torch.autograd.Function):
                   ptr(gm), ptr(dw), ptr(mt), 0, st)
         _lib.call('crfconv_meanfield_bwd_scatter', ptr(gm), ptr(w), ptr(rev_ptr), ptr(rev_eid), table.K, 0, m, H, None,
                   ptr(dx), st)
-        dz = G @ Q.t() if ctx.needs_input_grad[1] else None
-        dQ = z.t() @ G if ctx.needs_input_grad[3] else None
-        dP = mt.t() @ G if ctx.needs_input_grad[4] else None
+        dz = _gemm(G, Q, nk=True) if ctx.needs_input_grad[1] else None
+        dQ = _gemm_tn(z, G) if ctx.needs_input_grad[3] else None
+        dP = _gemm_tn(mt, G) if ctx.needs_input_grad[4] else None
         return dx, dz, dw, dQ, dP, None
 
 
@@ -688,6 +695,21 @@ def _gemm(A, B, bias=None, addend=None, nk=False):
     _lib.call('crfconv_gemm', ptr(A), ptr(B), ptr(None if bias is None else bias.contiguous()),
               ptr(None if addend is None else addend.contiguous()), M, N, K, 1 if nk else 0, ptr(C), stream_ptr())
     return C
+
+
+def _gemm_tn(A, B):
+    """A^T B for [m, Ca] / [m, Cb] row operands (a reduction over the long dimension): the MFMA row-reduction kernel of
+    linear.hip (crfconv_linear_wgrad), fixed summation order."""
+    m, ca = A.shape
+    cb = B.shape[1]
+    if _VENDOR_ONLY or m == 0:
+        return A.t() @ B
+    A, B = A.contiguous(), B.contiguous()
+    out = torch.empty((ca, cb), dtype=torch.float32, device=A.device)
+    wbytes = _lib.load().crfconv_linear_wgrad_workspace(m, ca, cb)
+    wws = torch.empty(wbytes, dtype=torch.uint8, device=A.device)
+    _lib.call('crfconv_linear_wgrad', ptr(A), ptr(B), m, ca, cb, ptr(out), None, ptr(wws), wbytes, stream_ptr())
+    return out
 
 
 def _mfma_matmul(x, W, b, transpose_w, want_stats=False):

@@ -480,13 +480,9 @@ int crfconv_linear_forward(const float* X, const float* W, const float* bias, in
  *  crfconv_cat2: out [m, ca + cb] = [xa | xb] -- the torch.cat in front of the fusion layers
  *    (models/continuous_crf_conv_big.py:71, models/point_conv_big.py:107) on the levels where the two-pointer Linear does not
  *    apply; crfconv_split2 is its backward (two contiguous gradients in one pass).  ca, cb multiples of 4.
- *  crfconv_copy_batched: dst[j][0 .. n[j]) = src[j][...] for up to crfconv_copy_batched_max_jobs() contiguous float ranges in
- *    one launch (gradients into the flat all-reduce bucket; replaces torch._foreach_copy_).  src / dst / n are HOST arrays.
  *  crfconv_add_i64: x[0 .. n) += delta (the num_batches_tracked counters of all BatchNorm layers, one launch). */
 int crfconv_cat2(const float* xa, const float* xb, int64_t m, int ca, int cb, float* out, crf_stream_t stream);
 int crfconv_split2(const float* g, int64_t m, int ca, int cb, float* ga, float* gb, crf_stream_t stream);
-int crfconv_copy_batched_max_jobs(void);
-int crfconv_copy_batched(const float* const* src, float* const* dst, const int64_t* n, int njobs, crf_stream_t stream);
 int crfconv_add_i64(int64_t* x, int64_t n, int64_t delta, crf_stream_t stream);
 
 /* C [M, N] = A [M, K] B (+ bias [N]) (+ addend [M, N]) on fp32 MFMA for the shapes crfconv_linear_forward does not take:

@@ -1403,7 +1403,7 @@ def test_cat2_and_its_backward(m, ca, cb):
 
 
 def test_bucket_pack_and_counters_use_library_launches():
-    """FlatGradAllReduce.pack() (crfconv_copy_batched, more pairs than one launch takes) and advance_counters (crfconv_add_i64)."""
+    """FlatGradAllReduce.pack() (crfconv_copy_jobs, more pairs than one launch takes) and advance_counters (crfconv_add_i64)."""
     from crfconv_amd import distributed as D, ops
     net = torch.nn.ModuleList([torch.nn.Linear(3 + i % 5, 2 + i % 3) for i in range(60)]).to(DEV)     # 120 parameters > 96 jobs
     bucket = D.FlatGradAllReduce(net)
