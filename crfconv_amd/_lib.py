@@ -97,6 +97,9 @@ SIGNATURES = {
     'crfconv_linear_wgrad_partial': (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp, _vp]),
     'crfconv_morton_codes': (_i, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'crfconv_copy_jobs': (_i, [_vp, _i, _vp]),
+    'crfconv_index_narrow_batched': (_i, [_vp, _i, _vp]),
+    'crfconv_pointconv_moments_batched_workspace': (_sz, [_vp, _i]),
+    'crfconv_pointconv_moments_batched': (_i, [_vp, _i, _vp, _sz, _vp]),
     'crfconv_reduce_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_linear_forward_supported': (_i, [_i, _i]),
     'crfconv_linear_forward_stat_records': (_sz, [_i64]),
@@ -163,6 +166,20 @@ class RevJob(ctypes.Structure):
     """crf_rev_job of include/crfconv_amd.h."""
     _fields_ = [('idx32', ctypes.c_void_p), ('E', ctypes.c_int64), ('m_src', ctypes.c_int64), ('rev_ptr', ctypes.c_void_p),
                 ('rev_eid', ctypes.c_void_p)]
+
+
+class NarrowJob(ctypes.Structure):
+    """crf_narrow_job of include/crfconv_amd.h."""
+    _fields_ = [('idx64', ctypes.c_void_p), ('B', ctypes.c_int64), ('n_tgt', ctypes.c_int64), ('K', ctypes.c_int32),
+                ('n_src', ctypes.c_int64), ('sort_from', ctypes.c_int32), ('idx32', ctypes.c_void_p), ('idx16', ctypes.c_void_p),
+                ('bad_count', ctypes.c_void_p)]
+
+
+class MomentsJob(ctypes.Structure):
+    """crf_moments_job of include/crfconv_amd.h."""
+    _fields_ = [('pos_src', ctypes.c_void_p), ('pos_tgt', ctypes.c_void_p), ('idx32', ctypes.c_void_p), ('K', ctypes.c_int32),
+                ('m_tgt', ctypes.c_int64), ('n_edges', ctypes.c_double), ('mean', ctypes.c_void_p), ('cov', ctypes.c_void_p),
+                ('packed', ctypes.c_void_p), ('mean32', ctypes.c_void_p)]
 
 
 class Fold1Job(ctypes.Structure):

@@ -30,12 +30,9 @@ __global__ __launch_bounds__(256) void narrow_kernel(const int64_t* __restrict__
 // neighbouring cache lines (measured on the level-0 mean-field kernels: -4..-7 %).  Column 0 (the query itself in
 // a self-query kNN table, which the CRF layer drops by POSITION, continuous_crf_conv_big.py:45-47) stays put.
 template <int KT>
-__global__ __launch_bounds__(256) void narrow_sorted_kernel(const int64_t* __restrict__ idx64, int64_t rows,
-                                                            int64_t rows_per_cloud, int K, int sort_from,
-                                                            int64_t n_src, int32_t* __restrict__ idx32,
-                                                            uint16_t* __restrict__ idx16, int32_t* __restrict__ bad) {
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (row >= rows) return;
+__device__ __forceinline__ void narrow_sorted_row(const int64_t* __restrict__ idx64, int64_t row, int64_t rows_per_cloud, int K,
+                                                  int sort_from, int64_t n_src, int32_t* __restrict__ idx32,
+                                                  uint16_t* __restrict__ idx16, int32_t* __restrict__ bad) {
     const int64_t b = row / rows_per_cloud;
     int v[KT];
     int nbad = 0;
@@ -63,6 +60,42 @@ __global__ __launch_bounds__(256) void narrow_sorted_kernel(const int64_t* __res
             idx32[row * K + k] = (int32_t)(b * n_src + v[k]);
             if (idx16 != nullptr) idx16[row * K + k] = (uint16_t)v[k];
         }
+}
+template <int KT>
+__global__ __launch_bounds__(256) void narrow_sorted_kernel(const int64_t* __restrict__ idx64, int64_t rows,
+                                                            int64_t rows_per_cloud, int K, int sort_from,
+                                                            int64_t n_src, int32_t* __restrict__ idx32,
+                                                            uint16_t* __restrict__ idx16, int32_t* __restrict__ bad) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    narrow_sorted_row<KT>(idx64, row, rows_per_cloud, K, sort_from, n_src, idx32, idx16, bad);
+}
+
+// The same for SEVERAL tables in one launch (a batch refresh narrows every table of the batch: 13 for PointConvBig's five
+// levels, most of them a few thousand rows = one launch of ~5 us each).  A workgroup's 256 rows belong to one table, found by
+// a binary search over the chunk prefix; tables that keep their column order (K = 1 up-sampling tables, sort_from >= K - 1)
+// run the same body with nothing to exchange -- identical idx32 / idx16 / bad counts to the one-table entry points.
+constexpr int NB_MAX = 32;
+struct NarrowBatch {
+    const int64_t* idx64[NB_MAX];
+    int32_t* idx32[NB_MAX];
+    uint16_t* idx16[NB_MAX];
+    int32_t* bad[NB_MAX];
+    int rows[NB_MAX], rows_per_cloud[NB_MAX], K[NB_MAX], sort_from[NB_MAX], n_src[NB_MAX];
+    int chunk_base[NB_MAX + 1];
+    int njobs;
+};
+template <int KT>
+__global__ __launch_bounds__(256) void narrow_batched_kernel(const NarrowBatch t) {
+    int lo = 0, hi = t.njobs;                          // largest j with chunk_base[j] <= blockIdx.x
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t.chunk_base[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int row = ((int)blockIdx.x - t.chunk_base[lo]) * 256 + (int)threadIdx.x;
+    if (row >= t.rows[lo]) return;
+    narrow_sorted_row<KT>(t.idx64[lo], row, t.rows_per_cloud[lo], t.K[lo], t.sort_from[lo], t.n_src[lo], t.idx32[lo], t.idx16[lo],
+                          t.bad[lo]);
 }
 
 // edge ids 0..E-1 and sort keys: the source row, or m_src for "no neighbour" entries (< 0), which
@@ -404,6 +437,45 @@ extern "C" int crfconv_index_narrow_sorted(const int64_t* idx64, int64_t B, int6
         hipLaunchKernelGGL(narrow_sorted_kernel<32>, grid, blk, 0, st, idx64, rows, n_tgt, K, sort_from, n_src, idx32, idx16, bad_count);
     else
         hipLaunchKernelGGL(narrow_sorted_kernel<64>, grid, blk, 0, st, idx64, rows, n_tgt, K, sort_from, n_src, idx32, idx16, bad_count);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+// crfconv_index_narrow_sorted for up to 32 tables in ONE launch (jobs: host array).  K <= 64 for every job.
+extern "C" int crfconv_index_narrow_batched(const crf_narrow_job* jobs, int njobs, crf_stream_t stream) {
+    CRF_REQUIRE(jobs, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(njobs >= 1 && njobs <= NB_MAX, CRF_ERR_ARG, "njobs=%d outside [1, %d]", njobs, NB_MAX);
+    NarrowBatch t;
+    int64_t chunks = 0;
+    int kmax = 1;
+    for (int j = 0; j <= NB_MAX; ++j) {
+        t.chunk_base[j] = (int)chunks;
+        if (j < njobs) {
+            const crf_narrow_job& jb = jobs[j];
+            CRF_REQUIRE(jb.idx64 && jb.idx32 && jb.bad_count, CRF_ERR_ARG, "job %d: null pointer", j);
+            CRF_REQUIRE(jb.idx16 == nullptr || jb.n_src <= 65536, CRF_ERR_ARG, "job %d: uint16 table needs n_src <= 65536", j);
+            CRF_REQUIRE(jb.B > 0 && jb.n_tgt > 0 && jb.K > 0 && jb.K <= 64 && jb.n_src > 0 && jb.sort_from >= 0, CRF_ERR_ARG,
+                        "job %d: bad shape (B=%lld n_tgt=%lld K=%d n_src=%lld sort_from=%d)", j, (long long)jb.B,
+                        (long long)jb.n_tgt, jb.K, (long long)jb.n_src, jb.sort_from);
+            CRF_REQUIRE(jb.B * jb.n_src < ((int64_t)1 << 31) && jb.B * jb.n_tgt * jb.K < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED,
+                        "job %d: table too large for int32 rows / edge ids", j);
+            t.idx64[j] = jb.idx64; t.idx32[j] = jb.idx32; t.idx16[j] = jb.idx16; t.bad[j] = jb.bad_count;
+            t.rows[j] = (int)(jb.B * jb.n_tgt); t.rows_per_cloud[j] = (int)jb.n_tgt; t.K[j] = jb.K;
+            t.sort_from[j] = jb.sort_from; t.n_src[j] = (int)jb.n_src;
+            chunks += cdiv(jb.B * jb.n_tgt, 256);
+            CRF_REQUIRE(chunks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "batch too large");
+            if (jb.K > kmax) kmax = jb.K;
+        } else if (j < NB_MAX) {
+            t.idx64[j] = nullptr; t.idx32[j] = nullptr; t.idx16[j] = nullptr; t.bad[j] = nullptr;
+            t.rows[j] = 0; t.rows_per_cloud[j] = 1; t.K[j] = 1; t.sort_from[j] = 0; t.n_src[j] = 1;
+        }
+    }
+    t.njobs = njobs;
+    const dim3 grid((unsigned)chunks), blk(256);
+    hipStream_t st = as_stream(stream);
+    if (kmax <= 16) hipLaunchKernelGGL(narrow_batched_kernel<16>, grid, blk, 0, st, t);
+    else if (kmax <= 32) hipLaunchKernelGGL(narrow_batched_kernel<32>, grid, blk, 0, st, t);
+    else hipLaunchKernelGGL(narrow_batched_kernel<64>, grid, blk, 0, st, t);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -273,12 +273,11 @@ __global__ __launch_bounds__(256) void reduce_partials_d_kernel(const double* __
 }
 
 // ------------------------------------------------------------------ rel-pos moments
-__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ pos_src,
-                                                      const float* __restrict__ pos_tgt,
-                                                      const int32_t* __restrict__ idx, int K,
-                                                      int64_t m_tgt, float* __restrict__ partial) {
+__device__ __forceinline__ void moments_block(const float* __restrict__ pos_src, const float* __restrict__ pos_tgt,
+                                              const int32_t* __restrict__ idx, int K, int64_t m_tgt, int64_t blk,
+                                              float* __restrict__ partial_row) {
     __shared__ float sred[PWAVES][9];
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = blk * 256 + threadIdx.x;
     float a[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i < m_tgt) {
         const float px = pos_tgt[3 * i], py = pos_tgt[3 * i + 1], pz = pos_tgt[3 * i + 2];
@@ -302,8 +301,40 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ 
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < PWAVES; ++w) t += sred[w][threadIdx.x];
-        partial[(int64_t)blockIdx.x * 9 + threadIdx.x] = t;
+        partial_row[threadIdx.x] = t;
     }
+}
+__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ pos_src,
+                                                      const float* __restrict__ pos_tgt,
+                                                      const int32_t* __restrict__ idx, int K,
+                                                      int64_t m_tgt, float* __restrict__ partial) {
+    moments_block(pos_src, pos_tgt, idx, K, m_tgt, blockIdx.x, partial + (int64_t)blockIdx.x * 9);
+}
+
+// The moments of SEVERAL tables (a batch refresh recomputes them for every PointConv layer's table: nine pairs of launches one
+// by one): the same per-workgroup partials and the same finishing order per table, two launches for all of them.
+constexpr int MB_MAX = 16;
+struct MomentsBatch {
+    const float* pos_src[MB_MAX];
+    const float* pos_tgt[MB_MAX];
+    const int32_t* idx[MB_MAX];
+    double* mean[MB_MAX];
+    double* cov[MB_MAX];
+    double* packed[MB_MAX];
+    float* mean32[MB_MAX];
+    double n_edges[MB_MAX];
+    int K[MB_MAX], m_tgt[MB_MAX];
+    int blk_base[MB_MAX + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void moments_batched_kernel(const MomentsBatch t, float* __restrict__ partial) {
+    int lo = 0, hi = t.njobs;                          // largest j with blk_base[j] <= blockIdx.x
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t.blk_base[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    moments_block(t.pos_src[lo], t.pos_tgt[lo], t.idx[lo], t.K[lo], t.m_tgt[lo], (int)blockIdx.x - t.blk_base[lo],
+                  partial + (int64_t)blockIdx.x * 9);
 }
 
 // ------------------------------------------------------------------ BatchNorm-2 statistics of h2
@@ -1083,9 +1114,9 @@ extern "C" int crfconv_pointconv_moments(const float* pos_src, const float* pos_
 // float32, in ONE single-workgroup launch: slot sums exactly as reduce_partials_kernel forms them (one wavefront per slot, lane l
 // takes blocks l, l + 64, ..., shuffle tree), then mean = S1 / n, cov = S2 / n - mean mean^T with every operation rounded on its
 // own (what the chain of framework ops this replaces computed: ~15 launches and, on a refresh, four copies per table).
-__global__ __launch_bounds__(1024) void moments_finish_kernel(const float* __restrict__ partial, int64_t nblk, double n_edges,
-                                                              double* __restrict__ mean, double* __restrict__ cov,
-                                                              double* __restrict__ packed, float* __restrict__ mean32) {
+__device__ __forceinline__ void moments_finish_block(const float* __restrict__ partial, int64_t nblk, double n_edges,
+                                                     double* __restrict__ mean, double* __restrict__ cov,
+                                                     double* __restrict__ packed, float* __restrict__ mean32) {
     __shared__ double s_sum[9];
     const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (slot < 9) {
@@ -1114,6 +1145,16 @@ __global__ __launch_bounds__(1024) void moments_finish_kernel(const float* __res
     if (t < 3) { mean[t] = v; mean32[t] = (float)v; }
     else cov[t - 3] = v;
 }
+__global__ __launch_bounds__(1024) void moments_finish_kernel(const float* __restrict__ partial, int64_t nblk, double n_edges,
+                                                              double* __restrict__ mean, double* __restrict__ cov,
+                                                              double* __restrict__ packed, float* __restrict__ mean32) {
+    moments_finish_block(partial, nblk, n_edges, mean, cov, packed, mean32);
+}
+__global__ __launch_bounds__(1024) void moments_finish_batched_kernel(const MomentsBatch t, const float* __restrict__ partial) {
+    const int j = blockIdx.x;
+    moments_finish_block(partial + (int64_t)t.blk_base[j] * 9, t.blk_base[j + 1] - t.blk_base[j], t.n_edges[j], t.mean[j], t.cov[j],
+                         t.packed[j], t.mean32[j]);
+}
 
 extern "C" int crfconv_pointconv_moments_packed(const float* pos_src, const float* pos_tgt, const int32_t* idx32, int K,
                                                 int64_t m_tgt, double n_edges, double* mean, double* cov, double* packed,
@@ -1129,6 +1170,48 @@ extern "C" int crfconv_pointconv_moments_packed(const float* pos_src, const floa
     hipLaunchKernelGGL(moments_kernel, dim3((unsigned)nblk), dim3(256), 0, st, pos_src, pos_tgt, idx32, K, m_tgt, partial);
     CRF_LAUNCH_CHECK();
     hipLaunchKernelGGL(moments_finish_kernel, dim3(1), dim3(1024), 0, st, partial, nblk, n_edges, mean, cov, packed, mean32);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" size_t crfconv_pointconv_moments_batched_workspace(const crf_moments_job* jobs, int njobs) {
+    if (!jobs || njobs < 1) return 0;
+    int64_t nblk = 0;
+    for (int j = 0; j < njobs; ++j) nblk += cdiv(jobs[j].m_tgt, 256);
+    return sizeof(float) * 9 * (size_t)nblk;
+}
+
+// crfconv_pointconv_moments_packed for up to 16 tables in two launches: identical outputs (same partials, same order).
+extern "C" int crfconv_pointconv_moments_batched(const crf_moments_job* jobs, int njobs, void* workspace, size_t workspace_bytes,
+                                                 crf_stream_t stream) {
+    CRF_REQUIRE(jobs && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(njobs >= 1 && njobs <= MB_MAX, CRF_ERR_ARG, "njobs=%d outside [1, %d]", njobs, MB_MAX);
+    CRF_REQUIRE(workspace_bytes >= crfconv_pointconv_moments_batched_workspace(jobs, njobs), CRF_ERR_WORKSPACE, "workspace too small");
+    MomentsBatch t;
+    int64_t nblk = 0;
+    for (int j = 0; j <= MB_MAX; ++j) {
+        t.blk_base[j] = (int)nblk;
+        if (j < njobs) {
+            const crf_moments_job& jb = jobs[j];
+            if (int rc = check_pc(jb.m_tgt, jb.K, 4)) return rc;
+            CRF_REQUIRE(jb.pos_src && jb.pos_tgt && jb.idx32 && jb.mean && jb.cov && jb.packed && jb.mean32, CRF_ERR_ARG,
+                        "job %d: null pointer", j);
+            CRF_REQUIRE(jb.n_edges > 0.0 && jb.m_tgt < ((int64_t)1 << 31), CRF_ERR_ARG, "job %d: bad size", j);
+            t.pos_src[j] = jb.pos_src; t.pos_tgt[j] = jb.pos_tgt; t.idx[j] = jb.idx32; t.mean[j] = jb.mean; t.cov[j] = jb.cov;
+            t.packed[j] = jb.packed; t.mean32[j] = jb.mean32; t.n_edges[j] = jb.n_edges; t.K[j] = jb.K; t.m_tgt[j] = (int)jb.m_tgt;
+            nblk += cdiv(jb.m_tgt, 256);
+            CRF_REQUIRE(nblk < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "batch too large");
+        } else if (j < MB_MAX) {
+            t.pos_src[j] = nullptr; t.pos_tgt[j] = nullptr; t.idx[j] = nullptr; t.mean[j] = nullptr; t.cov[j] = nullptr;
+            t.packed[j] = nullptr; t.mean32[j] = nullptr; t.n_edges[j] = 1.0; t.K[j] = 1; t.m_tgt[j] = 0;
+        }
+    }
+    t.njobs = njobs;
+    hipStream_t st = as_stream(stream);
+    float* partial = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(moments_batched_kernel, dim3((unsigned)nblk), dim3(256), 0, st, t, partial);
+    CRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(moments_finish_batched_kernel, dim3((unsigned)njobs), dim3(1024), 0, st, t, (const float*)partial);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

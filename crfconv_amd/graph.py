@@ -74,15 +74,22 @@ class NeighborTable:
         if idx64.dtype != torch.int64:
             idx64 = idx64.long()
         idx64 = idx64.contiguous()
-        self._bad.zero_()
-        _lib.call('crfconv_index_narrow_sorted', ptr(idx64), self.B, self.n_tgt, self.K, self.n_src, 1,
-                  ptr(self.idx32), ptr(self.idx16), ptr(self._bad), stream_ptr())
+        # (self._bad is cumulative: validate() resets it when it raises -- no one-word fill launch per table and refresh)
+        if _BATCH['on']:                       # inside batched_reverse(): ONE narrowing launch for all tables at the exit
+            _BATCH['narrow'].append((self, idx64, check))
+            check = False                      # ... which also validates, once the counts exist
+        else:
+            _lib.call('crfconv_index_narrow_sorted', ptr(idx64), self.B, self.n_tgt, self.K, self.n_src, 1,
+                      ptr(self.idx32), ptr(self.idx16), ptr(self._bad), stream_ptr())
         self._checked = False
         if self._rev is not None:
             self._build_reverse(*self._rev)
         for key, entry in list(self.cache.items()):
             if callable(getattr(entry, 'refresh_', None)):
-                entry.refresh_(self)
+                if _BATCH['on'] and callable(getattr(entry, 'batch_job', None)):
+                    _BATCH['moments'].append((entry, self))      # after the narrowing, two launches for all tables
+                else:
+                    entry.refresh_(self)
         if check:
             self.validate()
         return self
@@ -96,6 +103,7 @@ class NeighborTable:
                                    # the count stays in self._bad for a later validate()
             bad = int(self._bad.item())
             if bad:
+                self._bad.zero_()
                 raise IndexError('%d neighbour indices outside [0, %d)' % (bad, self.n_src))
             self._checked = True
 
@@ -128,13 +136,15 @@ class NeighborTable:
         return self._rev
 
 
-_BATCH = {'on': False, 'jobs': []}
+_BATCH = {'on': False, 'jobs': [], 'narrow': [], 'moments': []}
 
 
 class batched_reverse:
-    """``with batched_reverse():`` around the refresh of several tables (MultiScaleData.load_): their reverse CSRs are rebuilt
-    by ONE crfconv_reverse_csr_batched call on exit -- five launches for all tables (at most 32 per call) instead of seven per
-    table -- with the same contents.  The tables' narrowed indices must have been written before the exit (stream order)."""
+    """``with batched_reverse():`` around the refresh of several tables (MultiScaleData.load_): the per-table launches of
+    NeighborTable.refresh_ are collected and issued on exit as batched calls with the same results -- ONE index-narrowing
+    launch (crfconv_index_narrow_batched), the reverse CSRs by ONE crfconv_reverse_csr_batched call (five launches instead of
+    seven per table), the rel-pos moments of the PointConv layers by ONE crfconv_pointconv_moments_batched call (two launches
+    instead of two per table).  Nothing may read the refreshed tables before the exit."""
 
     def __enter__(self):
         self.prev = _BATCH['on']
@@ -145,18 +155,39 @@ class batched_reverse:
         _BATCH['on'] = self.prev
         if self.prev:
             return False                       # nested: the outermost context flushes
+        narrow, _BATCH['narrow'] = _BATCH['narrow'], []
         jobs, _BATCH['jobs'] = _BATCH['jobs'], []
-        if exc_type is not None or not jobs:
+        moments, _BATCH['moments'] = _BATCH['moments'], []
+        if exc_type is not None:
             return False
         import ctypes
+        lib = _lib.load()
+        adr = lambda t: None if t is None else t.data_ptr()
+        for i in range(0, len(narrow), 32):
+            part = narrow[i:i + 32]
+            arr = (_lib.NarrowJob * len(part))(*[_lib.NarrowJob(idx64.data_ptr(), t.B, t.n_tgt, t.K, t.n_src, 1, t.idx32.data_ptr(),
+                                                                adr(t.idx16), t._bad.data_ptr()) for t, idx64, _ in part])
+            _lib.call('crfconv_index_narrow_batched', ctypes.cast(arr, ctypes.c_void_p), len(part), stream_ptr())
         for i in range(0, len(jobs), 32):
             part = jobs[i:i + 32]
             arr = (_lib.RevJob * len(part))(*[_lib.RevJob(t.idx32.data_ptr(), t.m_tgt * t.K, t.m_src, rp.data_ptr(), re.data_ptr())
                                               for t, rp, re in part])
             p = ctypes.cast(arr, ctypes.c_void_p)
-            nbytes = _lib.load().crfconv_reverse_csr_batched_workspace(p, len(part))
+            nbytes = lib.crfconv_reverse_csr_batched_workspace(p, len(part))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=part[0][0].idx32.device)
             _lib.call('crfconv_reverse_csr_batched', p, len(part), ptr(ws), nbytes, stream_ptr())
+        for i in range(0, len(moments), 16):
+            part = moments[i:i + 16]
+            arr = (_lib.MomentsJob * len(part))(*[entry.batch_job(t) for entry, t in part])
+            p = ctypes.cast(arr, ctypes.c_void_p)
+            nbytes = lib.crfconv_pointconv_moments_batched_workspace(p, len(part))
+            ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=part[0][1].idx32.device)
+            _lib.call('crfconv_pointconv_moments_batched', p, len(part), ptr(ws), nbytes, stream_ptr())
+            for entry, _ in part:
+                entry.mark_fresh()
+        for t, _, check in narrow:             # (one host sync per table outside a capture, as refresh_ does on its own)
+            if check:
+                t.validate()
         return False
 
 

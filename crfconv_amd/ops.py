@@ -1751,6 +1751,14 @@ class MomentsEntry(tuple):
         relpos_moments(self.pos_src, self.pos_tgt, table, out=self)       # in place: no temporaries, no copies
         self.versions = (self.pos_src._version, self.pos_tgt._version)
 
+    def batch_job(self, table):
+        """This entry's refresh as one job of crfconv_pointconv_moments_batched (graph.batched_reverse issues them together)."""
+        return _lib.MomentsJob(self.pos_src.data_ptr(), self.pos_tgt.data_ptr(), table.idx32.data_ptr(), table.K, table.m_tgt,
+                               float(table.n_edges), self[0].data_ptr(), self[1].data_ptr(), self[3].data_ptr(), self[4].data_ptr())
+
+    def mark_fresh(self):
+        self.versions = (self.pos_src._version, self.pos_tgt._version)
+
     def stale(self):
         return self.versions != (self.pos_src._version, self.pos_tgt._version)
 

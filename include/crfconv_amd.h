@@ -125,6 +125,11 @@ size_t crfconv_reverse_csr_workspace(int64_t E, int64_t m_src);
 int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_src, int32_t* rev_ptr,
                         int32_t* rev_eid, void* workspace, size_t workspace_bytes,
                         crf_stream_t stream);
+/* crfconv_index_narrow_sorted for up to 32 tables in ONE launch (a batch refresh narrows every table of the batch); same idx32 /
+ * idx16 / bad counts as the one-table entry point, K <= 64.  jobs is a host array. */
+typedef struct { const int64_t* idx64; int64_t B; int64_t n_tgt; int K; int64_t n_src; int sort_from; int32_t* idx32;
+                 uint16_t* idx16; int32_t* bad_count; } crf_narrow_job;
+int crfconv_index_narrow_batched(const crf_narrow_job* jobs, int njobs, crf_stream_t stream);
 /* The same for up to 32 tables in ONE set of five launches (a batch refresh rebuilds every table's reverse CSR: 14 tables =
  * ~100 launches one by one): identical rev_ptr / rev_eid contents.  jobs is a host array. */
 typedef struct { const int32_t* idx32; int64_t E; int64_t m_src; int32_t* rev_ptr; int32_t* rev_eid; } crf_rev_job;
@@ -265,6 +270,13 @@ int crfconv_pointconv_moments(const float* pos_src, const float* pos_tgt, const 
 int crfconv_pointconv_moments_packed(const float* pos_src, const float* pos_tgt, const int32_t* idx32, int K, int64_t m_tgt,
                                      double n_edges, double* mean, double* cov, double* packed, float* mean32,
                                      void* workspace, size_t workspace_bytes, crf_stream_t stream);
+/* The same for up to 16 tables in two launches (a batch refresh recomputes the moments of every PointConv layer's table):
+ * identical outputs.  jobs is a host array. */
+typedef struct { const float* pos_src; const float* pos_tgt; const int32_t* idx32; int K; int64_t m_tgt; double n_edges;
+                 double* mean; double* cov; double* packed; float* mean32; } crf_moments_job;
+size_t crfconv_pointconv_moments_batched_workspace(const crf_moments_job* jobs, int njobs);
+int crfconv_pointconv_moments_batched(const crf_moments_job* jobs, int njobs, void* workspace, size_t workspace_bytes,
+                                      crf_stream_t stream);
 /* Batch statistics of h2 over all edges: stats [2, d] float64 = {sum(h2 - shift), sum (h2 - shift)^2},
  * shift [d] float32 out (= h2 at the mean rel; variance is shift-invariant). */
 int crfconv_pointconv_stats(const float* pos_src, const float* pos_tgt, const int32_t* idx32, int K,
