@@ -136,6 +136,34 @@ __global__ __launch_bounds__(256) void as_rank_kernel(const long long* __restric
     order[(int64_t)beg + rank] = i;                            // bucket offsets count from the start of ALL clouds: cloud b's slots are [b N, (b + 1) N)
 }
 
+
+// Rows of SEVERAL [B, N, *] tensors picked by ONE index list in one launch: the Morton permutation of (pos, x, y, point_idx)
+// and, at every scale, the subset of (pos, neighbor_idx) (datasets/semantic3d_dataset.py:524-526: pos[:, choice],
+// neighbor_idx[:, choice]).  dst[b][s] = src[b][index[s]] (shared index) or src[b][index[b][s]] (per-cloud index); a row is
+// row_bytes / 4 dwords; consecutive threads write consecutive dwords.
+constexpr int GR_MAX = 8;
+struct GatherRowsJobs {
+    const uint32_t* src[GR_MAX];
+    uint32_t* dst[GR_MAX];
+    int words[GR_MAX];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void gather_rows_batched_kernel(const GatherRowsJobs t, const int64_t* __restrict__ index,
+                                                                  int per_cloud, int64_t B, int64_t N, int64_t S) {
+    const int j = blockIdx.y;
+    const int w = t.words[j];
+    const uint32_t* __restrict__ src = t.src[j];
+    uint32_t* __restrict__ dst = t.dst[j];
+    const int64_t total = B * S * w;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int64_t row = q / w;
+        const int c = (int)(q - row * w);
+        const int64_t b = row / S, sl = row - b * S;
+        int64_t pick = per_cloud ? index[row] : index[sl];
+        pick = pick < 0 ? 0 : (pick >= N ? N - 1 : pick);     // clamped: a bad index cannot fault (the tables are validated elsewhere)
+        dst[q] = src[(b * N + pick) * w + c];
+    }
+}
 }  // namespace crf
 
 using namespace crf;
@@ -197,6 +225,36 @@ extern "C" int crfconv_argsort_codes(const int64_t* code, int64_t B, int64_t N, 
     CRF_LAUNCH_CHECK();
     hipLaunchKernelGGL(as_rank_kernel, dim3((unsigned)cdiv(B * N, 256)), dim3(256), 0, st, c, N, B * N, ptrs, cnt, tmp,
                        reinterpret_cast<long long*>(order));
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+// dst[j] [B, S, row_bytes[j]] = rows of src[j] [B, N, row_bytes[j]] picked by index ([S] shared by all clouds, or [B, S] when
+// per_cloud != 0), for up to 8 tensors in one launch.  row_bytes multiples of 4; src / dst / row_bytes are host arrays.
+extern "C" int crfconv_gather_rows_batched(const void* const* src, void* const* dst, const int* row_bytes, int njobs,
+                                           const int64_t* index, int per_cloud, int64_t B, int64_t N, int64_t S, void* stream) {
+    CRF_REQUIRE(njobs >= 1 && njobs <= crf::GR_MAX, CRF_ERR_ARG, "njobs=%d outside [1, %d]", njobs, crf::GR_MAX);
+    CRF_REQUIRE(src && dst && row_bytes && index, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(B > 0 && N > 0 && S >= 0, CRF_ERR_ARG, "bad shape B=%lld N=%lld S=%lld", (long long)B, (long long)N, (long long)S);
+    if (S == 0) return CRF_OK;
+    crf::GatherRowsJobs t;
+    int wmax = 1;
+    for (int j = 0; j < crf::GR_MAX; ++j) {
+        if (j < njobs) {
+            CRF_REQUIRE(src[j] && dst[j] && row_bytes[j] >= 4 && row_bytes[j] % 4 == 0, CRF_ERR_ARG, "job %d: bad row", j);
+            t.src[j] = reinterpret_cast<const uint32_t*>(src[j]);
+            t.dst[j] = reinterpret_cast<uint32_t*>(dst[j]);
+            t.words[j] = row_bytes[j] / 4;
+            if (t.words[j] > wmax) wmax = t.words[j];
+        } else {
+            t.src[j] = nullptr; t.dst[j] = nullptr; t.words[j] = 1;
+        }
+    }
+    t.njobs = njobs;
+    int64_t gx = (B * S * wmax + 255) / 256;
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(crf::gather_rows_batched_kernel, dim3((unsigned)gx, (unsigned)njobs), dim3(256), 0, crf::as_stream(stream), t,
+                       index, per_cloud, B, N, S);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -36,11 +36,25 @@ __device__ __forceinline__ void narrow_sorted_row(const int64_t* __restrict__ id
     const int64_t b = row / rows_per_cloud;
     int v[KT];
     int nbad = 0;
+    const bool full = K == KT;                          // the usual case (K = 16 / 32 / 64): whole-row 16-byte accesses
+    if (full) {
+        const longlong2* __restrict__ src = reinterpret_cast<const longlong2*>(idx64 + row * KT);      // KT * 8 bytes: 16-byte aligned
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-        int64_t x = k < K ? idx64[row * K + k] : n_src;        // padding sorts behind every real id
-        if (k < K && (x < 0 || x >= n_src)) { ++nbad; x = x < 0 ? 0 : n_src - 1; }
-        v[k] = (int)x;
+        for (int k = 0; k < KT; k += 2) {
+            const longlong2 x2 = src[k / 2];
+            int64_t x = x2.x, y = x2.y;
+            if (x < 0 || x >= n_src) { ++nbad; x = x < 0 ? 0 : n_src - 1; }
+            if (y < 0 || y >= n_src) { ++nbad; y = y < 0 ? 0 : n_src - 1; }
+            v[k] = (int)x;
+            v[k + 1] = (int)y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            int64_t x = k < K ? idx64[row * K + k] : n_src;        // padding sorts behind every real id
+            if (k < K && (x < 0 || x >= n_src)) { ++nbad; x = x < 0 ? 0 : n_src - 1; }
+            v[k] = (int)x;
+        }
     }
     if (nbad) atomicAdd(bad, nbad);
     // odd-even transposition network on the registers (KT compile-time: no scratch)
@@ -53,6 +67,20 @@ __device__ __forceinline__ void narrow_sorted_row(const int64_t* __restrict__ id
             v[k] = in ? lo : v[k];
             v[k + 1] = in ? hi : v[k + 1];
         }
+    }
+    if (full) {
+        const int base = (int)(b * n_src);
+        int4* __restrict__ d32 = reinterpret_cast<int4*>(idx32 + row * KT);
+#pragma unroll
+        for (int k = 0; k < KT; k += 4) d32[k / 4] = make_int4(base + v[k], base + v[k + 1], base + v[k + 2], base + v[k + 3]);
+        if (idx16 != nullptr) {
+            uint4* __restrict__ d16 = reinterpret_cast<uint4*>(idx16 + row * KT);
+#pragma unroll
+            for (int k = 0; k < KT; k += 8)
+                d16[k / 8] = make_uint4((unsigned)v[k] | ((unsigned)v[k + 1] << 16), (unsigned)v[k + 2] | ((unsigned)v[k + 3] << 16),
+                                        (unsigned)v[k + 4] | ((unsigned)v[k + 5] << 16), (unsigned)v[k + 6] | ((unsigned)v[k + 7] << 16));
+        }
+        return;
     }
 #pragma unroll
     for (int k = 0; k < KT; ++k)

@@ -197,6 +197,43 @@ def _fps_choice(pos, n_sample):
     return out.reshape(B, n_sample) - starts[:, None]          # the kernel reports global rows
 
 
+def pick_rows(tensors, index, per_cloud):
+    """[t[:, index] for t in tensors] (index [S] shared by all clouds) or per-cloud picks (index [B, S]) for [B, N, ...]
+    CUDA tensors, as ONE library launch per 8 tensors (crfconv_gather_rows_batched); None entries pass through."""
+    import ctypes
+    from . import _lib
+    from .graph import ptr, stream_ptr
+    out = [None] * len(tensors)
+    live = [(i, t.contiguous()) for i, t in enumerate(tensors) if t is not None]
+    if not live:
+        return out
+    index = index.contiguous()
+    B, N = live[0][1].shape[:2]
+    S = index.shape[-1]
+    ok = all(t.is_cuda and t.dim() >= 2 and t.shape[0] == B and t.shape[1] == N and (t[0, 0].numel() * t.element_size()) % 4 == 0
+             and t.numel() > 0 for _, t in live) and index.is_cuda and index.dtype == torch.int64 and S > 0
+    if not ok:
+        for i, t in live:
+            if per_cloud:
+                idx = index.reshape(index.shape + (1,) * (t.dim() - 2)).expand(index.shape + t.shape[2:])
+                out[i] = torch.gather(t, 1, idx)
+            else:
+                out[i] = t[:, index].contiguous()
+        return out
+    for o in range(0, len(live), 8):
+        part = live[o:o + 8]
+        dsts = [torch.empty((B, S) + tuple(t.shape[2:]), dtype=t.dtype, device=t.device) for _, t in part]
+        n = len(part)
+        src = (ctypes.c_void_p * n)(*[t.data_ptr() for _, t in part])
+        dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
+        rb = (ctypes.c_int * n)(*[t[0, 0].numel() * t.element_size() for _, t in part])
+        _lib.call('crfconv_gather_rows_batched', ctypes.cast(src, ctypes.c_void_p), ctypes.cast(dst, ctypes.c_void_p),
+                  ctypes.cast(rb, ctypes.c_void_p), n, ptr(index), 1 if per_cloud else 0, B, N, S, stream_ptr())
+        for (i, _), d in zip(part, dsts):
+            out[i] = d
+    return out
+
+
 def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kernel_size=(16, 16, 16, 16, 16),
                        ratio=(4, 4, 4, 4, 2), num_scales=5, generator=None, choices=None, sort=None,
                        sample_method='random', order=None):
@@ -221,12 +258,10 @@ def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kern
         if order is None:                      # `order` [B, N]: a Morton permutation the caller already has (CollateGraph)
             order = morton_order(pos)
 
-        def perm(t):
-            if t is None or not torch.is_tensor(t) or t.dim() < 2 or t.shape[1] != pos.shape[1]:
-                return t
-            idx = order.reshape(order.shape + (1,) * (t.dim() - 2)).expand_as(t) if t.dim() > 2 else order
-            return torch.gather(t, 1, idx)
-        pos, x, y, point_idx = perm(pos).contiguous(), perm(x), perm(y), perm(point_idx)
+        movable = [t if (t is not None and torch.is_tensor(t) and t.dim() >= 2 and t.shape[1] == pos.shape[1]) else None
+                   for t in (pos, x, y, point_idx)]
+        moved = pick_rows(movable, order, per_cloud=True)
+        pos, x, y, point_idx = [m if mv is not None else t for t, mv, m in zip((pos, x, y, point_idx), movable, moved)]
     elif sort != 'none':
         raise ValueError("sort must be 'morton' or 'none'")
     multiscale = []
@@ -240,8 +275,7 @@ def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kern
             choice = _fps_choice(pos, n // ratio[i])                               # [B, S], per cloud
             if sort == 'morton':
                 choice = choice.sort(dim=1).values
-            sub_pos = pos.gather(1, choice.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
-            sub_idx = neighbor_idx.gather(1, choice.unsqueeze(-1).expand(-1, -1, neighbor_idx.shape[-1])).contiguous()
+            sub_pos, sub_idx = pick_rows([pos, neighbor_idx], choice, per_cloud=True)
             up_idx = nearest_neighbors.knn_batch_device(sub_pos, pos, 1)
             multiscale.append(Data(pos=pos, neighbor_idx=neighbor_idx, sub_idx=sub_idx, up_idx=up_idx))
             pos = sub_pos
@@ -253,8 +287,7 @@ def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kern
             if sort == 'morton':
                 choice = choice.sort().values
             choice = choice.to(pos.device)
-        sub_pos = pos[:, choice, :].contiguous()
-        sub_idx = neighbor_idx[:, choice, :].contiguous()
+        sub_pos, sub_idx = pick_rows([pos, neighbor_idx], choice, per_cloud=False)
         up_idx = nearest_neighbors.knn_batch_device(sub_pos, pos, 1)
         multiscale.append(Data(pos=pos, neighbor_idx=neighbor_idx, sub_idx=sub_idx, up_idx=up_idx))
         pos = sub_pos

@@ -613,6 +613,12 @@ int crfconv_sgd_step_hyper(float* param, const float* grad, float* momentum_buf,
  *   bit-identical to torch.argsort(code, dim=1, stable=True), without scratch memory (capturable on ROCm 7.2). */
 int crfconv_random_subsets(const int* n, const int* s, int64_t* const* out, int nlevels, uint64_t seed,
                            const int64_t* counter, crf_stream_t stream);
+/* Rows of up to 8 [B, N, row_bytes[j]] tensors picked by one index list in one launch: dst[j][b][s] = src[j][b][index[s]]
+ * (index [S], shared by all clouds: datasets/semantic3d_dataset.py:524-526 pos[:, choice], neighbor_idx[:, choice]) or
+ * src[j][b][index[b][s]] (per_cloud != 0: the Morton permutation, farthest-point picks).  row_bytes multiples of 4; src, dst,
+ * row_bytes are host arrays; out-of-range picks are clamped. */
+int crfconv_gather_rows_batched(const void* const* src, void* const* dst, const int* row_bytes, int njobs, const int64_t* index,
+                                int per_cloud, int64_t B, int64_t N, int64_t S, crf_stream_t stream);
 size_t crfconv_argsort_codes_workspace(int64_t B, int64_t N);
 int crfconv_argsort_codes(const int64_t* code, int64_t B, int64_t N, int64_t* order, void* workspace,
                           size_t workspace_bytes, crf_stream_t stream);

@@ -325,3 +325,26 @@ def test_reverse_csr_batched_equals_one_by_one():
             t._build_reverse(*t._rev)
     for t, (rp, re) in zip(tabs, ref):
         assert torch.equal(t._rev[0], rp) and torch.equal(t._rev[1], re)
+
+
+def test_pick_rows_batched_gather_equals_framework_indexing():
+    """data.pick_rows (crfconv_gather_rows_batched): shared and per-cloud picks of several tensors in one launch."""
+    from crfconv_amd.data import pick_rows
+    g = torch.Generator().manual_seed(5)
+    B, N, S = 3, 1000, 257
+    pos = torch.randn(B, N, 3, generator=g).to(DEV)
+    x = torch.randn(B, N, 6, generator=g).to(DEV)
+    y = torch.randint(0, 13, (B, N), generator=g).to(DEV)                 # int64 [B, N]: 8-byte rows
+    nb = torch.randint(0, N, (B, N, 16), generator=g).to(DEV)
+    choice = torch.randperm(N, generator=g)[:S].sort().values.to(DEV)
+    a = pick_rows([pos, None, nb], choice, per_cloud=False)
+    assert a[1] is None and torch.equal(a[0], pos[:, choice]) and torch.equal(a[2], nb[:, choice])
+    order = torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).to(DEV)
+    p, xx, yy, none = pick_rows([pos, x, y, None], order, per_cloud=True)
+    assert none is None
+    assert torch.equal(p, torch.gather(pos, 1, order[..., None].expand(-1, -1, 3)))
+    assert torch.equal(xx, torch.gather(x, 1, order[..., None].expand(-1, -1, 6)))
+    assert torch.equal(yy, torch.gather(y, 1, order))
+    # rows that are not a whole number of dwords: the framework path
+    h = torch.randint(0, 100, (B, N, 3), generator=g, dtype=torch.int16).to(DEV)
+    assert torch.equal(pick_rows([h], choice, per_cloud=False)[0], h[:, choice])
