@@ -580,7 +580,9 @@ def main():
             pos_q = torch.from_numpy(np.stack([c[0] for c in raw])).to(dev)
             raws.append((pos_q, torch.cat([pos_q, torch.from_numpy(np.stack([c[1] for c in raw])).to(dev)], -1),
                          torch.from_numpy(np.stack([c[2] for c in raw])).to(dev)))
-            pipe = CollatePipeline([data, data2], generator=torch.Generator().manual_seed(77 + rank))
+            prio = os.environ.get('CRFCONV_BENCH_COLLATE_PRIORITY')     # A/B: side-stream priority (default: the lowest)
+            pipe = CollatePipeline([data, data2], generator=torch.Generator().manual_seed(77 + rank),
+                                   priority=None if prio is None else int(prio))
             pipe.submit(0, *raws[0])
             pipe.submit(1, *raws[1])                      # both collate graphs captured
 
@@ -596,12 +598,23 @@ def main():
                     gb.replay()
                     pipe.release(slot)
             pipe.submit(0, *raws[0])
-            run_pipe(4, 0)
-            barrier()
-            t0 = time.perf_counter()
-            run_pipe(args.steps, 4)
-            barrier()
-            pipe_ms = (time.perf_counter() - t0) / args.steps * 1e3
+            sprio = os.environ.get('CRFCONV_BENCH_STEP_PRIORITY')       # A/B: the training graphs on a stream of this priority
+            if sprio is not None:
+                hp = torch.cuda.Stream(priority=int(sprio))
+                hp.wait_stream(torch.cuda.current_stream())
+                ctx = torch.cuda.stream(hp)
+            else:
+                import contextlib
+                ctx = contextlib.nullcontext()
+            with ctx:
+                run_pipe(4, 0)
+                barrier()
+                t0 = time.perf_counter()
+                run_pipe(args.steps, 4)
+                barrier()
+                pipe_ms = (time.perf_counter() - t0) / args.steps * 1e3
+            if sprio is not None:
+                torch.cuda.current_stream().wait_stream(hp)
             if grouped:
                 tt = torch.tensor([pipe_ms], device=dev, dtype=torch.float64)
                 torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)

@@ -395,7 +395,8 @@ class CollatePipeline:
             pipe.release(s)                        # slot s may be overwritten once the work queued so far has run
     """
 
-    def __init__(self, batches, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), generator=None, device_draw=True):
+    def __init__(self, batches, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), generator=None, device_draw=True,
+                 priority=None):
         import os
         import warnings
         if (torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -406,7 +407,11 @@ class CollatePipeline:
                           'crfconv_amd before torch initialises the GPU, or export GPU_MAX_HW_QUEUES=8')
         self.batches = list(batches)
         self.graphs = [CollateGraph(b, kernel_size, ratio, generator, device_draw=device_draw, slot=k) for k, b in enumerate(self.batches)]
-        self.stream = torch.cuda.Stream()
+        # the side stream at the LOWEST priority the device offers by default: the collate fills the CUs the training step
+        # leaves idle (its many small launches) instead of taking turns with it
+        if priority is None:
+            priority = max(torch.cuda.Stream.priority_range())
+        self.stream = torch.cuda.Stream(priority=priority)
         self._ready = [torch.cuda.Event() for _ in self.batches]
         self._free = [None for _ in self.batches]
 
