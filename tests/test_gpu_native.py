@@ -348,3 +348,63 @@ def test_pick_rows_batched_gather_equals_framework_indexing():
     # rows that are not a whole number of dwords: the framework path
     h = torch.randint(0, 100, (B, N, 3), generator=g, dtype=torch.int16).to(DEV)
     assert torch.equal(pick_rows([h], choice, per_cloud=False)[0], h[:, choice])
+
+
+def test_batched_refresh_equals_table_by_table():
+    """graph.batched_reverse around NeighborTable.refresh_: narrowed indices (int32 / uint16), reverse CSRs and the memoised
+    rel-pos moments written by the three batched calls must equal the one-table-at-a-time refresh bit for bit, bad entries are
+    counted (and clamped) the same way, and a locality-free table (every source far from its target: the LDS window of the
+    reverse-CSR passes misses) takes the fallback atomics."""
+    from crfconv_amd import ops
+    from crfconv_amd.graph import NeighborTable, batched_reverse
+    g = torch.Generator().manual_seed(33)
+    specs = [(2, 3000, 3000, 16), (2, 700, 3000, 16), (2, 3000, 700, 1), (1, 64, 64, 32), (2, 5000, 5000, 16)]
+
+    def draw(B, n_tgt, n_src, K, local):
+        if local:                                             # Morton-like: sources near the target's own row
+            base = (torch.arange(n_tgt) * n_src // n_tgt)[None, :, None]
+            return (base + torch.randint(-40, 40, (B, n_tgt, K), generator=g)).clamp_(0, n_src - 1)
+        return torch.randint(0, n_src, (B, n_tgt, K), generator=g)
+
+    def build(batched, bad):
+        gs = torch.Generator().manual_seed(7)
+        tabs, poss = [], []
+        for i, (B, n_tgt, n_src, K) in enumerate(specs):
+            t = NeighborTable(draw(B, n_tgt, n_src, K, i == 4).to(DEV), n_src)
+            t.reverse
+            if K == 16:
+                ps, pt = torch.randn(B * n_src, 3, generator=gs).to(DEV), torch.randn(B * n_tgt, 3, generator=gs).to(DEV)
+                t.cache['m'] = ops.MomentsEntry(ops.relpos_moments(ps, pt, t), ps, pt)
+            tabs.append(t)
+        new = [draw(*s, i == 4) for i, s in enumerate(specs)]
+        if bad:
+            new[1][0, 5, 2] = 10 ** 6
+            new[1][1, 9, 0] = -3
+        if batched:
+            with batched_reverse():
+                for t, idx in zip(tabs, new):
+                    t.refresh_(idx.to(DEV), check=False)
+        else:
+            for t, idx in zip(tabs, new):
+                t.refresh_(idx.to(DEV), check=False)
+        torch.cuda.synchronize()
+        return tabs
+
+    for bad in (False, True):
+        g.manual_seed(33)
+        a = build(False, bad)
+        g.manual_seed(33)
+        b = build(True, bad)
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta.idx32, tb.idx32)
+            assert (ta.idx16 is None) == (tb.idx16 is None) and (ta.idx16 is None or torch.equal(ta.idx16, tb.idx16))
+            assert torch.equal(ta._rev[0], tb._rev[0]) and torch.equal(ta._rev[1], tb._rev[1])
+            assert int(ta._bad) == int(tb._bad)
+            if 'm' in ta.cache:
+                for u, v in zip(ta.cache['m'], tb.cache['m']):
+                    assert (u == v) if not torch.is_tensor(u) else torch.equal(u, v)
+        assert int(a[1]._bad) == (2 if bad else 0)
+        if bad:
+            with pytest.raises(IndexError):
+                b[1].validate()
+            b[1].validate()                                   # the count was reset by the raise
