@@ -348,7 +348,9 @@ class CollateGraph:
 
     def _work(self):
         if self.device_draw:
-            self.counter.add_(1)
+            from . import _lib
+            from .graph import ptr, stream_ptr
+            _lib.call('crfconv_add_i64', ptr(self.counter), 1, 1, stream_ptr())       # counter += 1 (a library launch: no framework kernel in the graph)
             random_subsets_device(self.sizes, [c.numel() for c in self.choices], self.seed, self.counter, self.choices)
             morton_order(self.pos, out=self.order)
         new = multiscale_compute(self.pos, x=self.x, y=self.y, kernel_size=self.kernel_size, ratio=self.ratio,
