@@ -26,7 +26,23 @@ using gf32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int GM_BLOCK = 256, GM_BK = 32;
 
-template <int WM, int WN, int WR, int WC, bool BNK>
+// four consecutive floats of which the first `valid` exist (VEC: widths are multiples of 4, so it is all or nothing and the
+// address is 16-byte aligned; else element by element -- odd widths such as the 13-class logits)
+template <bool VEC>
+__device__ __forceinline__ float4 gm_ld4(const float* __restrict__ p, int valid) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (VEC) {
+        if (valid > 0) v = *reinterpret_cast<const float4*>(p);
+    } else {
+        if (valid > 0) v.x = p[0];
+        if (valid > 1) v.y = p[1];
+        if (valid > 2) v.z = p[2];
+        if (valid > 3) v.w = p[3];
+    }
+    return v;
+}
+
+template <int WM, int WN, int WR, int WC, bool BNK, bool VEC>
 __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                         const float* __restrict__ bias, const float* __restrict__ addend,
                                                         int M, int N, int K, float* __restrict__ C) {
@@ -54,7 +70,7 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
             r.a[i] = zero4;
             if (NA4 % GM_BLOCK != 0 && q >= NA4) continue;
             const int row = m0 + q / (GM_BK / 4), k = kc + 4 * (q % (GM_BK / 4));
-            if (row < M && k < K) r.a[i] = *reinterpret_cast<const float4*>(A + (int64_t)row * K + k);
+            if (row < M) r.a[i] = gm_ld4<VEC>(A + (int64_t)row * K + k, K - k);
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -63,10 +79,10 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
             if (NB4 % GM_BLOCK != 0 && q >= NB4) continue;
             if constexpr (BNK) {
                 const int n = n0 + q / (GM_BK / 4), k = kc + 4 * (q % (GM_BK / 4));
-                if (n < N && k < K) r.b[i] = *reinterpret_cast<const float4*>(B + (int64_t)n * K + k);
+                if (n < N) r.b[i] = gm_ld4<VEC>(B + (int64_t)n * K + k, K - k);
             } else {
                 const int k = kc + q / (BN / 4), n = n0 + 4 * (q % (BN / 4));
-                if (k < K && n < N) r.b[i] = *reinterpret_cast<const float4*>(B + (int64_t)k * N + n);
+                if (k < K) r.b[i] = gm_ld4<VEC>(B + (int64_t)k * N + n, N - n);
             }
         }
     };
@@ -91,7 +107,7 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
     for (int j = 0; j < WN; ++j) {
         const int n = n0 + 16 * (wc * WN + j) + 4 * g;
         float4 bv = zero4;
-        if (bias != nullptr && n < N) bv = *reinterpret_cast<const float4*>(bias + n);
+        if (bias != nullptr) bv = gm_ld4<VEC>(bias + n, N - n);
 #pragma unroll
         for (int i = 0; i < WM; ++i) acc[i][j] = gf32x4{bv.x, bv.y, bv.z, bv.w};
     }
@@ -158,10 +174,18 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
             if (n >= N) continue;
             float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             if (addend != nullptr) {
-                const float4 a4 = *reinterpret_cast<const float4*>(addend + (int64_t)row * N + n);
+                const float4 a4 = gm_ld4<VEC>(addend + (int64_t)row * N + n, N - n);
                 o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
             }
-            *reinterpret_cast<float4*>(C + (int64_t)row * N + n) = o;
+            float* cp = C + (int64_t)row * N + n;
+            if constexpr (VEC) {
+                *reinterpret_cast<float4*>(cp) = o;
+            } else {
+                cp[0] = o.x;
+                if (n + 1 < N) cp[1] = o.y;
+                if (n + 2 < N) cp[2] = o.z;
+                if (n + 3 < N) cp[3] = o.w;
+            }
         }
     }
 }
@@ -169,7 +193,7 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
 }  // namespace crf
 
 extern "C" int crfconv_gemm_supported(int64_t M, int N, int K) {
-    return (M >= 1 && M < (int64_t)1 << 31 && N >= 4 && K >= 4 && N % 4 == 0 && K % 4 == 0) ? 1 : 0;
+    return (M >= 1 && M < (int64_t)1 << 31 && N >= 1 && K >= 1 && N < (1 << 24) && K < (1 << 24)) ? 1 : 0;
 }
 
 // C [M, N] = A [M, K] · B + bias + addend.  b_is_nk != 0: B is [N, K] row-major (the F.linear weight: C = A Bᵀ),
@@ -177,8 +201,7 @@ extern "C" int crfconv_gemm_supported(int64_t M, int N, int K) {
 extern "C" int crfconv_gemm(const float* A, const float* B, const float* bias, const float* addend, int64_t M, int N, int K,
                             int b_is_nk, float* C, void* stream) {
     CRF_REQUIRE(A != nullptr && B != nullptr && C != nullptr, CRF_ERR_ARG, "null operand");
-    CRF_REQUIRE(crfconv_gemm_supported(M, N, K), CRF_ERR_UNSUPPORTED, "gemm %lld x %d x %d: N and K must be multiples of 4",
-                (long long)M, N, K);
+    CRF_REQUIRE(crfconv_gemm_supported(M, N, K), CRF_ERR_UNSUPPORTED, "gemm %lld x %d x %d: shape out of range", (long long)M, N, K);
     // tile shapes (rows x columns per workgroup): 64 x 64, 32 x 64, 64 x 32, 32 x 32 -- the largest that still gives the
     // grid `min_blocks` workgroups.  Measured on the shapes of the training step (scratch/gemm_bench.py, graph replays): 32 x 32 is the
     // fastest or within 0.5 us of it from 640 x 64 to 163 840 x 32 -- these launches are latency-bound, many short wavefronts win
@@ -192,11 +215,14 @@ extern "C" int crfconv_gemm(const float* A, const float* B, const float* bias, c
     if (force >= 0 && force <= 3) shape = force;
     hipStream_t st = crf::as_stream(stream);
     const dim3 blk(crf::GM_BLOCK);
+    const bool vec = N % 4 == 0 && K % 4 == 0;           // 16-byte accesses; odd widths (13-class logits) go element by element
+#define GM2(WM, WN, WR, WC, NK, V) \
+    hipLaunchKernelGGL((crf::gemm_kernel<WM, WN, WR, WC, NK, V>), grid, blk, 0, st, A, B, bias, addend, (int)M, N, K, C)
 #define GM(WM, WN, WR, WC)                                                                                                    \
     do {                                                                                                                      \
         const dim3 grid((unsigned)((M + 16 * WM * WR - 1) / (16 * WM * WR)), (unsigned)((N + 16 * WN * WC - 1) / (16 * WN * WC))); \
-        if (b_is_nk) hipLaunchKernelGGL((crf::gemm_kernel<WM, WN, WR, WC, true>), grid, blk, 0, st, A, B, bias, addend, (int)M, N, K, C); \
-        else hipLaunchKernelGGL((crf::gemm_kernel<WM, WN, WR, WC, false>), grid, blk, 0, st, A, B, bias, addend, (int)M, N, K, C);         \
+        if (b_is_nk) { if (vec) GM2(WM, WN, WR, WC, true, true); else GM2(WM, WN, WR, WC, true, false); }                    \
+        else { if (vec) GM2(WM, WN, WR, WC, false, true); else GM2(WM, WN, WR, WC, false, false); }                           \
     } while (0)
     switch (shape) {
         case 0: GM(2, 2, 2, 2); break;       // 64 x 64
@@ -205,6 +231,7 @@ extern "C" int crfconv_gemm(const float* A, const float* B, const float* bias, c
         default: GM(1, 1, 2, 2); break;      // 32 x 32
     }
 #undef GM
+#undef GM2
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

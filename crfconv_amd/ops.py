@@ -683,8 +683,8 @@ def _mfma_ok(m, ci, co):
 
 def _gemm(A, B, bias=None, addend=None, nk=False):
     """A [M, K] @ B (+ bias) (+ addend) on the tiled fp32 MFMA kernel of gemm.hip -- the products the row-streaming kernel of
-    linear.hip does not take (coarse levels, wide layers).  nk: B is [N, K] (the F.linear weight), else [K, N].  Shapes the
-    kernel does not cover (N or K not a multiple of 4) go to the vendor GEMM."""
+    linear.hip does not take (coarse levels, wide layers; any widths).  nk: B is [N, K] (the F.linear weight), else [K, N].
+    CRFCONV_VENDOR_GEMM=1 is the A/B switch to the vendor library."""
     M, K = A.shape
     N = B.shape[0] if nk else B.shape[1]
     if _VENDOR_ONLY or M == 0 or not _lib.load().crfconv_gemm_supported(M, N, K):

@@ -502,8 +502,9 @@ int crfconv_add_i64(int64_t* x, int64_t n, int64_t delta, crf_stream_t stream);
  * the MLP / ResNet-block backward and g_h1 = g_h2 W2 of the wide PointConv layers (models/point_conv_big.py:45-47) --
  * replaces the rocBLAS / hipBLASLt call behind torch.nn.functional.linear / torch.mm / torch.addmm at those sites.
  * b_is_nk != 0: B is [N, K] row-major (C = A B^T, the F.linear weight layout), else [K, N] row-major.  bias and addend
- * may be NULL; addend may alias C.  N and K multiples of 4 (crfconv_gemm_supported).  64 rows x 16/32/64 columns per
- * workgroup, the B tile double-buffered in LDS, the slab width picked so the grid covers the chip; fixed summation order. */
+ * may be NULL; addend may alias C.  Any N, K >= 1 (16-byte accesses when both are multiples of 4, element-wise otherwise --
+ * the 13-class logits).  32 x 32 ... 64 x 64 outputs per workgroup, both operands through double-buffered LDS tiles, the tile
+ * shape picked so the grid covers the chip; fixed summation order. */
 int crfconv_gemm_supported(int64_t M, int N, int K);
 int crfconv_gemm(const float* A, const float* B, const float* bias, const float* addend, int64_t M, int N, int K,
                  int b_is_nk, float* C, crf_stream_t stream);

@@ -1375,14 +1375,26 @@ def test_gemm_kernel_vs_float64(M, N, K, nk):
     assert float((acc.double() - (ref + add.double())).abs().max()) <= 2e-6 * (scale + 8.0)
 
 
-def test_gemm_refuses_unaligned_widths_and_linear_falls_back():
+@pytest.mark.parametrize('M,N,K,nk', [(10, 6, 8, 0), (10, 8, 6, 0), (2000, 13, 128, 1), (2000, 128, 13, 0), (333, 7, 5, 1), (65, 1, 1, 0),
+                                      (100, 3, 130, 0)])
+def test_gemm_odd_widths(M, N, K, nk):
+    """Widths that are not multiples of 4 (the 13-class logits below 4096 rows, their dX): the element-wise form of the same
+    kernel, bias / addend included; and the Linear layer built on it."""
     from crfconv_amd import _lib, ops
-    from crfconv_amd.ops import ptr, stream_ptr
-    assert _lib.load().crfconv_gemm_supported(10, 6, 8) == 0 and _lib.load().crfconv_gemm_supported(10, 8, 6) == 0
-    A, B, C = torch.randn(10, 8, device=DEV), torch.randn(8, 6, device=DEV), torch.empty(10, 6, device=DEV)
-    with pytest.raises(_lib.CrfConvError):
-        _lib.call('crfconv_gemm', ptr(A), ptr(B), None, None, 10, 6, 8, 0, ptr(C), stream_ptr())
-    assert_close(ops._gemm(A, B), A.double() @ B.double(), 1e-5, 'fallback product')
+    assert _lib.load().crfconv_gemm_supported(M, N, K) == 1
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    B = (torch.randn(N, K, generator=g) if nk else torch.randn(K, N, generator=g)).to(DEV)
+    bias, add = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    ref = A.double() @ (B.double().t() if nk else B.double())
+    assert_close(ops._gemm(A, B, nk=bool(nk)), ref, 2e-6, 'product')
+    assert_close(ops._gemm(A, B, bias, add, nk=bool(nk)), ref + bias.double() + add.double(), 2e-6, 'product + bias + addend')
+    if nk:
+        x, W = A.clone().requires_grad_(True), B.clone().requires_grad_(True)
+        y = ops.linear(x, W, bias)
+        y.backward(add)
+        assert_close(y, ref + bias.double(), 2e-6, 'linear')
+        assert_close(x.grad, add.double() @ B.double(), 2e-6, 'dX')
 
 
 @pytest.mark.parametrize('m,ca,cb', [(2560, 256, 256), (10240, 128, 128), (7, 4, 12), (1, 8, 4)])
