@@ -155,14 +155,78 @@ __global__ __launch_bounds__(256) void rev_fill_kernel(const int32_t* __restrict
     tmp_eid[ptrs[v] + atomicAdd(&cursor[v], 1)] = (int32_t)e;
 }
 
+// Hub rows (more than HUB_LEN entries: duplicate / degenerate clouds, where thousands of targets name one source): the all-pairs
+// ranking is quadratic (a 40 960-entry row = 26 M tile comparisons on one wavefront, ~0.1 s), so such a row is sorted by a
+// wavefront-wide LSD radix sort instead -- 8-bit digits, ceil(key_bits / 8) stable passes ping-ponging between the slot array
+// `a` (where the fill left the ids) and the output row `b`, linear in the row length.  `hist`: 256 LDS ints of this wavefront.
+constexpr int HUB_LEN = 512;
+__device__ __forceinline__ void hub_sort_row(int32_t* __restrict__ a, int32_t* __restrict__ b, int len, int key_bits,
+                                             int* __restrict__ hist, int lane) {
+    const int passes = key_bits <= 8 ? 1 : (key_bits <= 16 ? 2 : (key_bits <= 24 ? 3 : 4));
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int32_t* src = a;
+    int32_t* dst = b;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int shift = 8 * pass;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hist[4 * lane + u] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < len; i += WAVE) atomicAdd(&hist[((unsigned)src[i] >> shift) & 255u], 1);
+        __builtin_amdgcn_wave_barrier();
+        {   // exclusive scan of the 256 bins: four consecutive bins per lane + a wavefront scan of the lane totals
+            const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const int tot = h0 + h1 + h2 + h3;
+            int incl = tot;
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const int up = __shfl_up(incl, d, WAVE);
+                if (lane >= d) incl += up;
+            }
+            const int ex = incl - tot;
+            __builtin_amdgcn_wave_barrier();
+            hist[4 * lane] = ex; hist[4 * lane + 1] = ex + h0; hist[4 * lane + 2] = ex + h0 + h1; hist[4 * lane + 3] = ex + h0 + h1 + h2;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i0 = 0; i0 < len; i0 += WAVE) {              // in order: the pass is stable
+            const int i = i0 + lane;
+            const bool valid = i < len;
+            const int32_t k = valid ? src[i] : 0;
+            const int d = valid ? (int)(((unsigned)k >> shift) & 255u) : 256;
+            unsigned long long todo = __ballot(valid);
+            int slot = 0;
+            while (todo != 0ull) {                            // one round per distinct digit of the 64 keys
+                const int leader = __ffsll((long long)todo) - 1;
+                const int ld = __shfl(d, leader, WAVE);
+                const unsigned long long m = __ballot(valid && d == ld);
+                const int base = hist[ld];                    // every lane reads (one address), the group's lanes use it
+                if (valid && d == ld) slot = base + __popcll(m & lt);
+                __builtin_amdgcn_wave_barrier();              // LDS operations of a wavefront complete in order: read, then update
+                if (lane == leader) hist[ld] = base + __popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                todo &= ~m;
+            }
+            if (valid) dst[slot] = k;
+        }
+        __threadfence();                                      // this wavefront re-reads what it wrote: past L1
+        int32_t* t = src; src = dst; dst = t;
+    }
+    if (src != b) {                                           // an even number of passes ended in `a`
+        for (int i = lane; i < len; i += WAVE) b[i] = src[i];
+    }
+}
+
 // one wavefront per source row: rank of every edge id among the row's ids (ids are distinct) = its sorted position
-__global__ __launch_bounds__(256) void rev_sort_rows_kernel(const int32_t* __restrict__ ptrs, const int32_t* __restrict__ tmp_eid,
-                                                            int64_t m_src, int32_t* __restrict__ rev_eid) {
+__global__ __launch_bounds__(256) void rev_sort_rows_kernel(const int32_t* __restrict__ ptrs, int32_t* __restrict__ tmp_eid,
+                                                            int64_t m_src, int key_bits, int32_t* __restrict__ rev_eid) {
+    __shared__ int s_hist[4][256];
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= m_src) return;
     const int beg = ptrs[j], len = ptrs[j + 1] - beg;
-    if (len <= 64) {
+    if (len > HUB_LEN) {
+        hub_sort_row(tmp_eid + beg, rev_eid + beg, len, key_bits, s_hist[threadIdx.x >> 6], lane);
+    } else if (len <= 64) {
         const int32_t v = lane < len ? tmp_eid[beg + lane] : 0x7fffffff;
         int rank = 0;
         for (int k = 0; k < len; ++k) rank += __shfl(v, k, WAVE) < v ? 1 : 0;
@@ -303,7 +367,7 @@ __global__ __launch_bounds__(256) void revb_fill_kernel(const RevBatch t, const 
 // longer than the tile (hub rows) fall back to the tiled all-pairs form of rev_sort_rows_kernel, row by row.
 constexpr int RB_RR = 4, RB_TILE = 256;
 __global__ __launch_bounds__(256) void revb_rows_kernel(const RevBatch t, const int32_t* __restrict__ ptrs,
-                                                        const int32_t* __restrict__ tmp) {
+                                                        int32_t* __restrict__ tmp) {
     __shared__ int s_tile[4][RB_TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = (int)blockIdx.x * 4 + wave;
@@ -340,8 +404,15 @@ __global__ __launch_bounds__(256) void revb_rows_kernel(const RevBatch t, const 
             out[rb_ + rank] = x;
         }
     } else {
+        int key_bits = 1;                                  // local edge ids are < E of this table
+        while (key_bits < 31 && (1 << key_bits) < t.edge_base[j + 1] - eb) ++key_bits;
         for (int q = 0; q < nreal; ++q) {
             const int b = bnd[q], len = bnd[q + 1] - b;
+            if (len > HUB_LEN) {                           // a hub: radix sort, linear in the row length
+                static_assert(RB_TILE >= 256, "the tile doubles as the 256-bin histogram");
+                hub_sort_row(tmp + b, out + b, len, key_bits, s_tile[wave], lane);
+                continue;
+            }
             for (int i0 = 0; i0 < len; i0 += 64) {
                 const int i = i0 + lane;
                 const int32_t x = i < len ? tmp[b + i] : 0x7fffffff;
@@ -540,7 +611,9 @@ extern "C" int crfconv_reverse_csr(const int32_t* idx32, int64_t E, int64_t m_sr
     hipLaunchKernelGGL(rev_count_kernel, egrid, blk, 0, st, idx32, E, m_src, cnt);
     exclusive_scan_i32(cnt, rev_ptr, n, sums, st);
     hipLaunchKernelGGL(rev_fill_kernel, egrid, blk, 0, st, idx32, E, m_src, rev_ptr, cursor, tmp_eid);
-    hipLaunchKernelGGL(rev_sort_rows_kernel, dim3((unsigned)cdiv(m_src, 4)), blk, 0, st, rev_ptr, tmp_eid, m_src, rev_eid);
+    int key_bits = 1;                                     // edge ids are < E
+    while (key_bits < 31 && ((int64_t)1 << key_bits) < E) ++key_bits;
+    hipLaunchKernelGGL(rev_sort_rows_kernel, dim3((unsigned)cdiv(m_src, 4)), blk, 0, st, rev_ptr, tmp_eid, m_src, key_bits, rev_eid);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

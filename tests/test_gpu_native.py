@@ -251,6 +251,32 @@ def test_reverse_csr_hub_rows():
     assert int(cnt.max()) >= N
 
 
+def test_reverse_csr_degenerate_cloud_one_hub_of_every_edge():
+    """All 40 960 x 16 entries of a table name the same source (a cloud of coincident points): ONE reverse row of 655 360 edge ids.
+    The wavefront-wide radix sort of graph.hip handles it in linear time (the all-pairs ranking would be ~1e9 tile comparisons),
+    through the single-table build and the batched one; both must give the ascending edge ids."""
+    import time
+    from crfconv_amd.graph import NeighborTable, batched_reverse
+    N, K = 40960, 16
+    idx = torch.full((1, N, K), 7, dtype=torch.int64)
+    idx[0, 123, 5] = 9                                        # and one ordinary row
+    tab = NeighborTable(idx.to('cuda'), N)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rev_ptr, rev_eid = tab.reverse
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    src = tab.idx32.cpu().long().reshape(-1)
+    want = torch.argsort(src, stable=True)
+    assert torch.equal(rev_eid.cpu().long(), want)
+    assert int(rev_ptr[8] - rev_ptr[7]) == N * K - 1 and int(rev_ptr[10] - rev_ptr[9]) == 1
+    assert dt < 0.5, 'hub row took %.3f s' % dt
+    rev_eid.fill_(-1)
+    with batched_reverse():
+        tab._build_reverse(*tab._rev)
+    assert torch.equal(tab._rev[1].cpu().long(), want)
+
+
 def test_argsort_codes_equals_torch_stable_argsort():
     """crfconv_argsort_codes (bucket by the top 16 bits, rank inside the bucket by (code, index)) against
     torch.argsort(stable=True): random 30-bit codes, heavy ties, one value only, and real Morton codes."""
