@@ -837,7 +837,10 @@ extern "C" int crfconv_crf_matrices_backward(const float* c, const float* Q, con
 // every output channel, so BatchNorm needs no separate statistics pass over Y.
 namespace crf {
 
-constexpr int LF_BLOCK = 256;
+#ifndef LF_BLOCK_
+#define LF_BLOCK_ 256
+#endif
+constexpr int LF_BLOCK = LF_BLOCK_, LF_WAVES = LF_BLOCK / WAVE;
 
 // PRO: the operand is not read but formed while loading (dX of the fused MLP backward): row r, channel k of
 //   gY = alpha[k] * lrelu'(a[k] y + b[k]) * X[r][k] + bet[k] * Y2[r][k] + del[k]     (X = gA, Y2 = the Linear's output y)
@@ -1216,7 +1219,7 @@ __global__ __launch_bounds__(FR_BLOCK) void bn_finalize_records_kernel(const flo
 
 static int lf_blocks(int64_t M) {
     static const int cap = getenv("CRFCONV_LF_BLOCKS") ? atoi(getenv("CRFCONV_LF_BLOCKS")) : 512;   // swept 128..2048 on the training step: 512 (two blocks per CU, half the statistic records of 1024) is the optimum
-    int64_t nb = (M + 63) / 64;           // 64 rows per block iteration; two blocks (8 waves) per CU keep
+    int64_t nb = (M + 16 * LF_WAVES - 1) / (16 * LF_WAVES);           // 16 rows per wave and iteration; two blocks per CU keep
     if (nb > cap) nb = cap;               // enough 16-byte loads in flight; one statistics record per block
     return (int)(nb < 1 ? 1 : nb);
 }
@@ -1231,10 +1234,10 @@ static int lf_blocks(int64_t M) {
 static size_t lf_lds_bytes_at(int Ci, int tco, bool pro) {
     const size_t cip = (size_t)((Ci + 15) / 16) * 16 + 4, cik = cip - 4;
     size_t floats = 16 * (size_t)tco * cip;
-    const size_t stats = 4 * 4 * 16 * (size_t)tco;                   // the statistics epilogue reuses the slab as [4][4][16 tco]
+    const size_t stats = (size_t)crf::LF_WAVES * 4 * 16 * (size_t)tco;   // the statistics epilogue reuses the slab as [waves][4][16 tco]
     if (floats < stats) floats = stats;
     if (pro) floats += 5 * cik;
-    if (tco >= 2) floats += 4 * 16 * (16 * (size_t)tco + 4);
+    if (tco >= 2) floats += (size_t)crf::LF_WAVES * 16 * (16 * (size_t)tco + 4);
     return sizeof(float) * floats;
 }
 // Output tiles per workgroup: by Co, then halved until the slab of k = Ci inputs fits 64 KB (256 inputs: 32 channels per
