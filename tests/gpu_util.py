@@ -1,4 +1,6 @@
 """Helpers shared by the -m gpu parity tests."""
+import os
+
 import numpy as np
 import torch
 
@@ -20,6 +22,8 @@ def relerr(a, b):
 
 def assert_close(a, b, tol, what=''):
     e = relerr(a, b)
+    if os.environ.get('CRFCONV_TEST_REPORT'):             # measured error beside the bound (pytest -s): how much room a bound has
+        print('[assert_close] %-44s err %.3e  tol %.1e' % (what, e, tol), flush=True)
     assert e <= tol, '%s: max err (rel. to max(1,|ref|)) %.3e > %.1e' % (what, e, tol)
 
 

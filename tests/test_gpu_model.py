@@ -1,6 +1,8 @@
 """-m gpu: the HIP model path (through the C ABI) against the CPU oracle and the fixtures captured
 from the reference.  Tolerances: outputs / logits 1e-4 (BASELINE.json north_star), gradients 2e-4
 of the tensor's largest magnitude (fp32, different but fixed summation orders)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -295,9 +297,9 @@ def test_pointconvbig_golden(golden, use_crf):
     y = t(g['labels'], torch.long).reshape(-1) - 1
     loss = torch.nn.functional.cross_entropy(logits, y, weight=t(g['class_weights']), ignore_index=-1)
     loss.backward()
-    # train-mode BatchNorm over as few as 32 rows (level 4) amplifies fp32 reduction-order noise:
-    # the reference-vs-oracle gap on the CPU is already ~1e-4 here (tests/test_oracle_golden.py)
-    assert_close(logits[rows], g[tagc + '_train/logits_rows'], 5e-4, 'train logits')
+    # the stated bar (north_star: 1e-4).  Measured on MI355X, round 3 (CRFCONV_TEST_REPORT=1): 1.3e-6 -- rounds 1-2 allowed
+    # 5e-4 here (train-mode BatchNorm over as few as 32 rows at level 4) without ever needing it
+    assert_close(logits[rows], g[tagc + '_train/logits_rows'], 1e-4, 'train logits')
     assert_close(loss, g[tagc + '_train/loss'], 1e-4, 'loss')
     gr = grads(net)
     for k, v in sub(g, tagc + '_train/gnorm').items():
@@ -309,7 +311,7 @@ def test_pointconvbig_golden(golden, use_crf):
         want = torch.from_numpy(g['%s_train/gproj/%s' % (tagc, k)]).to(DEV)
         assert float((proj - want).abs().max()) <= 2e-3 * scale * np.sqrt(got.numel()), k
     for k, v in sub(g, tagc + '_train/grad').items():
-        assert_close(gr[k], v, 2e-3, 'grad ' + k)
+        assert_close(gr[k], v, 2e-4, 'grad ' + k)            # measured worst: 1.6e-5 (conv1_2.lin_in.lin.weight); was 2e-3
 
 
 def test_b1_is_supported():
@@ -665,11 +667,13 @@ def test_config5_shape_network_k32_t5_vs_oracle():
     ref_t = O.pointconv_resnet(prm, torch.from_numpy(feats), ms, 5, True, True, dropout_mask=mask)
     ref_loss = O.training_loss(ref_t, torch.from_numpy(labels))
     ref_loss.backward()
-    assert_close(logits, ref_t, 5e-4, 'K=32 T=5 train logits')
+    assert_close(logits, ref_t, 1e-4, 'K=32 T=5 train logits')      # measured 2.4e-6; was 5e-4
     assert_close(loss, ref_loss, 1e-4, 'loss')
     gr = grads(net)
     worst = max((relerr(gr[k], prm[k].grad), k) for k in gr)
-    assert worst[0] <= 3e-3, 'worst gradient %s: %.2e' % (worst[1], worst[0])
+    if os.environ.get('CRFCONV_TEST_REPORT'):
+        print('[worst gradient] %s %.3e' % (worst[1], worst[0]), flush=True)
+    assert worst[0] <= 2e-4, 'worst gradient %s: %.2e' % (worst[1], worst[0])      # measured 4.8e-6; was 3e-3
 
 
 def _eval_net_vs_oracle(pos, feats, in_ch, ncls, steps, seed, name, g, ratio=(4, 4, 4, 4, 2), kernel_size=(16,) * 5):
@@ -898,11 +902,14 @@ def test_config1_shape_eval_and_train_vs_oracle():
     ref_t = O.pointconv_resnet(prm, data.x.cpu(), ms, 1, True, True, dropout_mask=mask)
     ref_loss = O.training_loss(ref_t, labels)
     ref_loss.backward()
-    assert_close(logits, ref_t, 5e-4, 'config-1 train logits')
+    assert_close(logits, ref_t, 1e-4, 'config-1 train logits')      # measured 2.6e-6; was 5e-4
     assert_close(loss, ref_loss, 1e-4, 'config-1 loss')
     gr = grads(net)
     worst = max((relerr(gr[k], prm[k].grad), k) for k in gr)
-    assert worst[0] <= 3e-3, 'worst gradient %s: %.2e' % (worst[1], worst[0])
+    if os.environ.get('CRFCONV_TEST_REPORT'):
+        print('[worst gradient] %s %.3e' % (worst[1], worst[0]), flush=True)
+    # 2048-point clouds: level 5 has 4 points per cloud, BatchNorm there is ill-conditioned for the float32 oracle too
+    assert worst[0] <= 1e-3, 'worst gradient %s: %.2e' % (worst[1], worst[0])      # measured 1.8e-4; was 3e-3
 
 
 @pytest.mark.parametrize('M,Ci,Co,bias', [(163840, 32, 128, False), (40960, 64, 16, False), (1000, 6, 8, False),
