@@ -108,6 +108,9 @@ SIGNATURES = {
     'crfconv_cat2': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     'crfconv_split2': (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
     'crfconv_add_i64': (_i, [_vp, _i64, _i64, _vp]),
+    'crfconv_mlp_small_backward_supported': (_i, [_i64, _i, _i]),
+    'crfconv_mlp_small_backward_workspace': (_sz, [_i64, _i]),
+    'crfconv_mlp_small_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_gemm_supported': (_i, [_i64, _i, _i]),
     'crfconv_gemm': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     'crfconv_bn_coef_from_records': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),

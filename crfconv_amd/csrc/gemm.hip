@@ -42,11 +42,31 @@ __device__ __forceinline__ float4 gm_ld4(const float* __restrict__ p, int valid)
     return v;
 }
 
-template <int WM, int WN, int WR, int WC, bool BNK, bool VEC>
+// PRO form (crfconv_mlp_small_backward): the A operand is not read but FORMED while it is loaded -- gY, the gradient in front of a
+// train-mode BatchNorm + LeakyReLU, from (gA, Y) and per-channel coefficients: g1 = gA * lrelu'(a y + b), yh = (y - mean) rstd,
+// gY = a (g1 - sum g1 / M - yh sum g1 yh / M).  Every workgroup first sums the row-tile partials of the two channel sums
+// (bn_bwd_tile_sums_kernel, float64) for all K channels into LDS; the workgroups of the first column slab also store the gY tiles
+// they form (the weight gradient needs them), workgroup (0, 0) dgamma / dbeta.
+constexpr int GM_PRO_MAXK = 512;
+struct GemmPro {
+    const float* Y;            // [M, K] pre-BatchNorm activations
+    const float* coef;         // [4][K]: a | b | mean | rstd
+    const double* partial;     // [ntile][2][K]: sum g1, sum g1 yh per row tile
+    int ntile;
+    int training;              // eval-mode BatchNorm: the two mean terms vanish
+    float slope, inv_m;
+    float* gY;                 // [M, K] out
+    float* dgamma;             // [K] out
+    float* dbeta;              // [K] out
+};
+
+template <int WM, int WN, int WR, int WC, bool BNK, bool VEC, bool PRO = false>
 __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                         const float* __restrict__ bias, const float* __restrict__ addend,
-                                                        int M, int N, int K, float* __restrict__ C) {
+                                                        int M, int N, int K, float* __restrict__ C, const GemmPro pro = GemmPro()) {
     static_assert(WR * WC * WAVE == GM_BLOCK, "four wavefronts");
+    static_assert(!PRO || (VEC && !BNK), "the prologue form is the dX product of aligned widths");
+    __shared__ float sPro[PRO ? 6 * GM_PRO_MAXK : 1];      // a | b | mean | rstd | sum g1 / M | sum g1 yh / M
     constexpr int BM = 16 * WM * WR, BN = 16 * WN * WC;
     constexpr int LDA = GM_BK + 4;                      // [BM][LDA]: 16-byte fragment reads along k, 8 lanes cover the 32 banks
     constexpr int LDN = GM_BK + 4;                      // BNK: [BN][LDN], read like A
@@ -62,15 +82,20 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    struct Regs { float4 a[PA], b[PB]; };
+    struct Regs { float4 a[PA], b[PB], y[PRO ? PA : 1]; int kc; };
     auto fetch = [&](int kc, Regs& r) {
+        r.kc = kc;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int q = threadIdx.x + GM_BLOCK * i;
             r.a[i] = zero4;
+            if constexpr (PRO) r.y[i] = zero4;
             if (NA4 % GM_BLOCK != 0 && q >= NA4) continue;
             const int row = m0 + q / (GM_BK / 4), k = kc + 4 * (q % (GM_BK / 4));
             if (row < M) r.a[i] = gm_ld4<VEC>(A + (int64_t)row * K + k, K - k);
+            if constexpr (PRO) {
+                if (row < M) r.y[i] = gm_ld4<VEC>(pro.Y + (int64_t)row * K + k, K - k);
+            }
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -91,7 +116,27 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
         for (int i = 0; i < PA; ++i) {
             const int q = threadIdx.x + GM_BLOCK * i;
             if (NA4 % GM_BLOCK != 0 && q >= NA4) continue;
-            *reinterpret_cast<float4*>(sA[buf] + (q / (GM_BK / 4)) * LDA + 4 * (q % (GM_BK / 4))) = r.a[i];
+            float4 av = r.a[i];
+            if constexpr (PRO) {
+                const int row = m0 + q / (GM_BK / 4), k = r.kc + 4 * (q % (GM_BK / 4));
+                if (row < M && k < K) {                  // (rows / channels past the end stay zero)
+                    const float4 ca = *reinterpret_cast<const float4*>(sPro + k), cb = *reinterpret_cast<const float4*>(sPro + GM_PRO_MAXK + k);
+                    const float4 mu = *reinterpret_cast<const float4*>(sPro + 2 * GM_PRO_MAXK + k), rs = *reinterpret_cast<const float4*>(sPro + 3 * GM_PRO_MAXK + k);
+                    const float4 c2 = *reinterpret_cast<const float4*>(sPro + 4 * GM_PRO_MAXK + k), c3 = *reinterpret_cast<const float4*>(sPro + 5 * GM_PRO_MAXK + k);
+                    const float4 yv = r.y[i];
+                    float4 g1 = av;
+                    g1.x *= fmaf(ca.x, yv.x, cb.x) > 0.f ? 1.f : pro.slope;
+                    g1.y *= fmaf(ca.y, yv.y, cb.y) > 0.f ? 1.f : pro.slope;
+                    g1.z *= fmaf(ca.z, yv.z, cb.z) > 0.f ? 1.f : pro.slope;
+                    g1.w *= fmaf(ca.w, yv.w, cb.w) > 0.f ? 1.f : pro.slope;
+                    av.x = ca.x * (g1.x - c2.x - (yv.x - mu.x) * rs.x * c3.x);
+                    av.y = ca.y * (g1.y - c2.y - (yv.y - mu.y) * rs.y * c3.y);
+                    av.z = ca.z * (g1.z - c2.z - (yv.z - mu.z) * rs.z * c3.z);
+                    av.w = ca.w * (g1.w - c2.w - (yv.w - mu.w) * rs.w * c3.w);
+                    if (blockIdx.y == 0) *reinterpret_cast<float4*>(pro.gY + (int64_t)row * K + k) = av;
+                }
+            }
+            *reinterpret_cast<float4*>(sA[buf] + (q / (GM_BK / 4)) * LDA + 4 * (q % (GM_BK / 4))) = av;
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -146,6 +191,33 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
     Regs r0, r1;
     fetch(0, r0);
     if (nchunk > 1) fetch(GM_BK, r1);
+    if constexpr (PRO) {                                 // behind the first operand loads' issue: channel coefficients into LDS
+        for (int k = threadIdx.x; k < K; k += GM_BLOCK) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int t0 = 0; t0 < pro.ntile; t0 += 24) {    // 24 tiles (3072 rows) of both sums in flight: one round trip; tile order
+                double v1[24], v2[24];
+#pragma unroll
+                for (int u = 0; u < 24; ++u) {
+                    const bool in = t0 + u < pro.ntile;
+                    v1[u] = in ? pro.partial[((int64_t)(t0 + u) * 2) * K + k] : 0.0;
+                    v2[u] = in ? pro.partial[((int64_t)(t0 + u) * 2 + 1) * K + k] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 24; ++u) { s1 += v1[u]; s2 += v2[u]; }
+            }
+            sPro[k] = pro.coef[k];
+            sPro[GM_PRO_MAXK + k] = pro.coef[K + k];
+            sPro[2 * GM_PRO_MAXK + k] = pro.coef[2 * K + k];
+            sPro[3 * GM_PRO_MAXK + k] = pro.coef[3 * K + k];
+            sPro[4 * GM_PRO_MAXK + k] = pro.training ? (float)(s1 * (double)pro.inv_m) : 0.f;
+            sPro[5 * GM_PRO_MAXK + k] = pro.training ? (float)(s2 * (double)pro.inv_m) : 0.f;
+            if (blockIdx.x == 0 && blockIdx.y == 0) {
+                pro.dbeta[k] = (float)s1;
+                pro.dgamma[k] = (float)s2;
+            }
+        }
+        __syncthreads();
+    }
     park(0, r0);
     __syncthreads();
     // iteration c: chunk c sits in LDS buffer c & 1, chunk c + 1 in registers (fetched one iteration ago), chunk c + 2 is
@@ -191,6 +263,96 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
 }
 
 }  // namespace crf
+
+namespace crf {
+
+// Row-tile partials of the two channel sums of a BatchNorm backward: partial[tile][0][c] = sum g1, [1][c] = sum g1 yh over the tile's
+// BT_ROWS rows (g1 = gA lrelu'(a y + b), yh = (y - mean) rstd).  A workgroup = one tile x 64 channels: 16 lanes x 16 bytes per row
+// (whole 256-byte row segments), 16 rows per pass; float32 inside a thread's eight rows, float64 across the 16 row threads.
+constexpr int BT_ROWS = 128, BT_CH = 64, BT_NR = BT_ROWS / 16;
+__global__ __launch_bounds__(256) void bn_bwd_tile_sums_kernel(const float* __restrict__ gA, const float* __restrict__ Y,
+                                                               const float* __restrict__ coef, int M, int K, float slope,
+                                                               double* __restrict__ partial) {
+    __shared__ float s_red[16][2][BT_CH];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * BT_CH + 4 * cq;
+    const int row0 = blockIdx.x * BT_ROWS;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (c < K) {
+        float4 g[BT_NR], y[BT_NR];                           // every load of the thread in flight at once: one round trip
+#pragma unroll
+        for (int u = 0; u < BT_NR; ++u) {
+            const int r = row0 + rl + 16 * u;
+            const bool in = r < M;
+            g[u] = in ? *reinterpret_cast<const float4*>(gA + (int64_t)r * K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            y[u] = in ? *reinterpret_cast<const float4*>(Y + (int64_t)r * K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float4 ca = *reinterpret_cast<const float4*>(coef + c), cb = *reinterpret_cast<const float4*>(coef + K + c);
+        const float4 mu = *reinterpret_cast<const float4*>(coef + 2 * K + c), rs = *reinterpret_cast<const float4*>(coef + 3 * K + c);
+#pragma unroll
+        for (int u = 0; u < BT_NR; ++u) {                    // (rows past the end hold g = 0: they add nothing)
+            float4 v = g[u];
+            v.x *= fmaf(ca.x, y[u].x, cb.x) > 0.f ? 1.f : slope;
+            v.y *= fmaf(ca.y, y[u].y, cb.y) > 0.f ? 1.f : slope;
+            v.z *= fmaf(ca.z, y[u].z, cb.z) > 0.f ? 1.f : slope;
+            v.w *= fmaf(ca.w, y[u].w, cb.w) > 0.f ? 1.f : slope;
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            s2.x = fmaf(v.x, (y[u].x - mu.x) * rs.x, s2.x); s2.y = fmaf(v.y, (y[u].y - mu.y) * rs.y, s2.y);
+            s2.z = fmaf(v.z, (y[u].z - mu.z) * rs.z, s2.z); s2.w = fmaf(v.w, (y[u].w - mu.w) * rs.w, s2.w);
+        }
+    }
+    *reinterpret_cast<float4*>(&s_red[rl][0][4 * cq]) = s1;
+    *reinterpret_cast<float4*>(&s_red[rl][1][4 * cq]) = s2;
+    __syncthreads();
+    if (threadIdx.x < 2 * BT_CH) {
+        const int which = threadIdx.x / BT_CH, ch = threadIdx.x - which * BT_CH;
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += (double)s_red[w][which][ch];           // fixed order
+        if (blockIdx.y * BT_CH + ch < K) partial[((int64_t)blockIdx.x * 2 + which) * K + blockIdx.y * BT_CH + ch] = t;
+    }
+}
+
+}  // namespace crf
+
+extern "C" int crfconv_mlp_small_backward_supported(int64_t M, int Ci, int Co) {
+    return (M >= 1 && M < (int64_t)1 << 24 && Ci >= 4 && Co >= 4 && Ci % 4 == 0 && Co % 4 == 0 && Co <= crf::GM_PRO_MAXK) ? 1 : 0;
+}
+
+extern "C" size_t crfconv_mlp_small_backward_workspace(int64_t M, int Co) {
+    if (M < 1 || Co < 1) return 0;
+    return sizeof(double) * 2 * (size_t)Co * (size_t)((M + crf::BT_ROWS - 1) / crf::BT_ROWS) + 256;
+}
+
+// Backward of one coarse-level MLP block A = lrelu(BN(X W^T), slope) behind its one-launch forward (crfconv_mlp_small_forward),
+// in TWO launches: row-tile partials of the channel sums, then dX [M, Ci] = gY W (+ addend) with gY [M, Co] formed in the
+// product's operand load (and stored for the weight gradient), dgamma / dbeta on the way.  Same results as
+// crfconv_bn_backward followed by crfconv_gemm up to summation order.  coef: the [4][Co] block of the forward.
+extern "C" int crfconv_mlp_small_backward(const float* gA, const float* Y, const float* coef, const float* W, const float* addend,
+                                          int64_t M, int Ci, int Co, int training, float slope, float* gY, float* dX, float* dgamma,
+                                          float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    CRF_REQUIRE(gA && Y && coef && W && gY && dX && dgamma && dbeta && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(crfconv_mlp_small_backward_supported(M, Ci, Co), CRF_ERR_UNSUPPORTED,
+                "mlp_small_backward %lld x %d -> %d: widths must be multiples of 4, Co <= %d", (long long)M, Ci, Co, crf::GM_PRO_MAXK);
+    CRF_REQUIRE(workspace_bytes >= crfconv_mlp_small_backward_workspace(M, Co), CRF_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = crf::as_stream(stream);
+    double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int ntile = (int)((M + crf::BT_ROWS - 1) / crf::BT_ROWS);
+    hipLaunchKernelGGL(crf::bn_bwd_tile_sums_kernel, dim3((unsigned)ntile, (unsigned)((Co + crf::BT_CH - 1) / crf::BT_CH)), dim3(256), 0, st,
+                       gA, Y, coef, (int)M, Co, slope, partial);
+    CRF_LAUNCH_CHECK();
+    crf::GemmPro pro;
+    pro.Y = Y; pro.coef = coef; pro.partial = partial; pro.ntile = ntile; pro.training = training; pro.slope = slope;
+    pro.inv_m = (float)(1.0 / (double)M); pro.gY = gY; pro.dgamma = dgamma; pro.dbeta = dbeta;
+    const int N = Ci, K = Co;
+    // 32 x 32 tiles as the plain product (32 x 64 for wide outputs, where every column slab forms the gY tile of its rows again,
+    // measured the same: 4.75 ms per step either way)
+    const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32)), blk(crf::GM_BLOCK);
+    hipLaunchKernelGGL((crf::gemm_kernel<1, 1, 2, 2, false, true, true>), grid, blk, 0, st, gA, W, (const float*)nullptr, addend, (int)M, N, K,
+                       dX, pro);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
 
 extern "C" int crfconv_gemm_supported(int64_t M, int N, int K) {
     return (M >= 1 && M < (int64_t)1 << 31 && N >= 1 && K >= 1 && N < (1 << 24) && K < (1 << 24)) ? 1 : 0;

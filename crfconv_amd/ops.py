@@ -1238,6 +1238,32 @@ def mlp_block_pool(x, W, bn, table, fork=False):
     return (out, x) if fork else out
 
 
+_NO_SMALL_BWD_ENV = __import__('os').environ.get('CRFCONV_NO_SMALL_BWD_FUSION') is not None      # A/B: bn_backward + gemm
+
+
+def _small_bwd(gA, y, coef, W, addend, slope, dgamma, dbeta, need_dx):
+    """(gY, dX) of a coarse-level MLP block: BatchNorm(+LeakyReLU) backward and dX = gY W (+ addend) as TWO launches
+    (crfconv_mlp_small_backward: tile sums, then the product with gY formed in its operand load), else -- no dX wanted, widths the
+    fused form does not take -- crfconv_bn_backward followed by the plain product."""
+    m, co = y.shape
+    ci = W.shape[1]
+    dev = y.device
+    gY = torch.empty_like(y)
+    lib = _lib.load()
+    if need_dx and not _NO_SMALL_BWD_ENV and not _VENDOR_ONLY and lib.crfconv_mlp_small_backward_supported(m, ci, co) == 1:
+        dX = torch.empty((m, ci), dtype=torch.float32, device=dev)
+        nbytes = lib.crfconv_mlp_small_backward_workspace(m, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.call('crfconv_mlp_small_backward', ptr(gA), ptr(y), ptr(coef), ptr(W), ptr(None if addend is None else addend.contiguous()),
+                  m, ci, co, 1, float(slope), ptr(gY), ptr(dX), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
+        return gY, dX
+    nbytes = lib.crfconv_bn_workspace(m, co)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.call('crfconv_bn_backward', ptr(gA), ptr(y), ptr(coef), m, co, 1, float(slope), ptr(gY), ptr(dgamma), ptr(dbeta), ptr(ws),
+              nbytes, stream_ptr())
+    return gY, (_gemm(gY, W, addend=addend) if need_dx else None)
+
+
 class _MLPSmallJoin(torch.autograd.Function):
     """_MLPBlockJoin at the coarse levels: the one-launch Linear + BatchNorm kernel (csrc/mlp_small.hip) also adds the skip and
     applies the join's LeakyReLU to the tile it holds in registers (crfconv_mlp_small_forward_join)."""
@@ -1273,14 +1299,9 @@ class _MLPSmallJoin(torch.autograd.Function):
         st = stream_ptr()
         g1 = torch.empty_like(g)
         _lib.call('crfconv_add_lrelu_backward', ptr(g), ptr(out), out.numel(), ctx.slope, ptr(g1), st)
-        gY = torch.empty_like(y)
         outs = [_param_out(q, (co,), dev) for q in ctx.prm[1:]]      # (dgamma, dbeta) targets
         dgamma, dbeta = outs[0][0], outs[1][0]
-        nbytes = _lib.load().crfconv_bn_workspace(m, co)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.call('crfconv_bn_backward', ptr(g1), ptr(y), ptr(coef), m, co, 1, 1.0, ptr(gY), ptr(dgamma), ptr(dbeta), ptr(ws),
-                  nbytes, st)
-        dX = _gemm(gY, W) if ctx.needs_input_grad[0] else None
+        gY, dX = _small_bwd(g1, y, coef, W, None, 1.0, dgamma, dbeta, ctx.needs_input_grad[0])
         gskip = g1 if ctx.needs_input_grad[8] else None
         if _defer_ok(ctx.params):
             _defer_weight_grad(gY, x, ctx.params, False)
@@ -1392,16 +1413,10 @@ class _MLPSmall(torch.autograd.Function):
         co = W.shape[0]
         dev = x.device
         gA = torch.zeros_like(y) if gA is None else gA.contiguous()
-        gY = torch.empty_like(y)
         outs = [_param_out(q, (co,), dev) for q in ctx.prm[1:]]      # (dgamma, dbeta) targets
         dgamma, dbeta = outs[0][0], outs[1][0]
-        nbytes = _lib.load().crfconv_bn_workspace(m, co)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.call('crfconv_bn_backward', ptr(gA), ptr(y), ptr(coef), m, co, 1, ctx.slope, ptr(gY), ptr(dgamma), ptr(dbeta),
-                  ptr(ws), nbytes, stream_ptr())
-        dX = None
-        if ctx.needs_input_grad[0]:
-            dX = _gemm(gY, W, addend=None if g_alias is None else g_alias.reshape(m, ci))
+        gY, dX = _small_bwd(gA, y, coef, W, None if g_alias is None else g_alias.reshape(m, ci), ctx.slope, dgamma, dbeta,
+                            ctx.needs_input_grad[0])
         if _defer_ok(ctx.params):
             _defer_weight_grad(gY, x, ctx.params, False)
             return dX, None, *(_param_ret(q, o, k) for q, (o, k) in zip(ctx.prm[1:], outs)), None, None, None, None, None, None

@@ -505,6 +505,16 @@ int crfconv_add_i64(int64_t* x, int64_t n, int64_t delta, crf_stream_t stream);
  * may be NULL; addend may alias C.  Any N, K >= 1 (16-byte accesses when both are multiples of 4, element-wise otherwise --
  * the 13-class logits).  32 x 32 ... 64 x 64 outputs per workgroup, both operands through double-buffered LDS tiles, the tile
  * shape picked so the grid covers the chip; fixed summation order. */
+/* Backward of one coarse-level MLP block A = lrelu(BN_train(X W^T), slope) (models/common.py:34-40) behind its one-launch forward, in
+ * two launches: row-tile partials of the two BatchNorm channel sums, then dX [M, Ci] = gY W (+ addend [M, Ci], may be NULL) on the
+ * tiled product with gY [M, Co] -- the gradient in front of the BatchNorm -- formed in its operand load from (gA, Y, coef) and stored
+ * for the weight gradient; dgamma / dbeta on the way.  Same results as crfconv_bn_backward + crfconv_gemm up to summation order.
+ * Ci, Co multiples of 4, Co <= 512; workspace: crfconv_mlp_small_backward_workspace(M, Co) bytes. */
+int crfconv_mlp_small_backward_supported(int64_t M, int Ci, int Co);
+size_t crfconv_mlp_small_backward_workspace(int64_t M, int Co);
+int crfconv_mlp_small_backward(const float* gA, const float* Y, const float* coef, const float* W, const float* addend, int64_t M,
+                               int Ci, int Co, int training, float slope, float* gY, float* dX, float* dgamma, float* dbeta,
+                               void* workspace, size_t workspace_bytes, crf_stream_t stream);
 int crfconv_gemm_supported(int64_t M, int N, int K);
 int crfconv_gemm(const float* A, const float* B, const float* bias, const float* addend, int64_t M, int N, int K,
                  int b_is_nk, float* C, crf_stream_t stream);

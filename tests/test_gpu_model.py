@@ -1404,6 +1404,48 @@ def test_gemm_odd_widths(M, N, K, nk):
         assert_close(x.grad, add.double() @ B.double(), 2e-6, 'dX')
 
 
+@pytest.mark.parametrize('M,Ci,Co,slope,addend', [(2560, 256, 64, 0.1, False), (2560, 64, 256, 1.0, True), (640, 512, 128, 0.1, True),
+                                                   (2561, 128, 512, 0.2, False), (100, 8, 4, 0.1, True), (3000, 36, 132, 1.0, False)])
+def test_mlp_small_backward_two_launch_form(M, Ci, Co, slope, addend):
+    """crfconv_mlp_small_backward (tile sums + the dX product with gY formed in its operand load) against float64 torch and against
+    the form it replaces (crfconv_bn_backward + crfconv_gemm): gY, dX (+ addend), dgamma, dbeta."""
+    from crfconv_amd import ops, _lib
+    from crfconv_amd.ops import ptr, stream_ptr
+    g = torch.Generator().manual_seed(M + Ci + Co)
+    y = (torch.randn(M, Co, generator=g) * 1.5 + 0.3).to(DEV)
+    gA = torch.randn(M, Co, generator=g).to(DEV)
+    W = (torch.randn(Co, Ci, generator=g) / Co ** 0.5).to(DEV)
+    add = torch.randn(M, Ci, generator=g).to(DEV) if addend else None
+    gamma, beta = (torch.rand(Co, generator=g) + 0.5).to(DEV), torch.randn(Co, generator=g).to(DEV)
+    yd = y.double()
+    mean, var = yd.mean(0), yd.var(0, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    a = gamma.double() * rstd
+    coef = torch.cat([a, beta.double() - a * mean, mean, rstd]).float().contiguous()
+    # float64 reference of the BatchNorm + LeakyReLU backward, with the kernel's own LeakyReLU branch (float32 coefficients)
+    pre32 = torch.addcmul(coef[Co:2 * Co], coef[:Co], y)
+    g1 = gA.double() * torch.where(pre32 > 0, 1.0, slope).double()
+    yh = (yd - coef[2 * Co:3 * Co].double()) * coef[3 * Co:].double()
+    dbeta_r, dgamma_r = g1.sum(0), (g1 * yh).sum(0)
+    gY_r = coef[:Co].double() * (g1 - dbeta_r / M - yh * dgamma_r / M)
+    dX_r = gY_r @ W.double() + (0 if add is None else add.double())
+    dgamma, dbeta = torch.empty(Co, device=DEV), torch.empty(Co, device=DEV)
+    gY, dX = ops._small_bwd(gA, y, coef, W, add, slope, dgamma, dbeta, True)
+    assert_close(gY, gY_r, 2e-5, 'gY')
+    assert_close(dX, dX_r, 2e-5, 'dX')
+    assert_close(dgamma, dgamma_r, 2e-5, 'dgamma')
+    assert_close(dbeta, dbeta_r, 2e-5, 'dbeta')
+    # the form it replaces
+    gY0 = torch.empty_like(y)
+    dg0, db0 = torch.empty(Co, device=DEV), torch.empty(Co, device=DEV)
+    nb = _lib.load().crfconv_bn_workspace(M, Co)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    _lib.call('crfconv_bn_backward', ptr(gA), ptr(y), ptr(coef), M, Co, 1, float(slope), ptr(gY0), ptr(dg0), ptr(db0), ptr(ws), nb, stream_ptr())
+    assert_close(gY, gY0, 1e-5, 'gY vs bn_backward')
+    assert_close(dX, ops._gemm(gY0, W, addend=add), 1e-5, 'dX vs bn_backward + gemm')
+    assert torch.equal(ops._small_bwd(gA, y, coef, W, add, slope, dgamma, dbeta, True)[1], dX)       # reproducible
+
+
 @pytest.mark.parametrize('m,ca,cb', [(2560, 256, 256), (10240, 128, 128), (7, 4, 12), (1, 8, 4)])
 def test_cat2_and_its_backward(m, ca, cb):
     """ops.cat2 (rows.hip) == torch.cat, forward and backward (contiguous gradients), 3-D leading shape kept."""
