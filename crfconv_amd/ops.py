@@ -671,7 +671,7 @@ def _flush_weight_grads():
 
 
 # ------------------------------------------------------------------------------ per-point Linear
-_MFMA_MIN_ROWS = int(__import__('os').environ.get('CRFCONV_MFMA_MIN_ROWS', 4096))       # below this the vendor GEMM's fixed cost is as good
+_MFMA_MIN_ROWS = int(__import__('os').environ.get('CRFCONV_MFMA_MIN_ROWS', 12288))      # below this the tiled product (gemm.hip) and the small-MLP nodes; swept on the step: 4096 -> 4.733 ms, 12288 (the 10 240-row level joins the small forms) -> 4.694 ms, 65536 -> 4.736 ms
 
 
 _VENDOR_ONLY = bool(__import__('os').environ.get('CRFCONV_VENDOR_GEMM'))     # A/B switch: forward / dX on rocBLAS
@@ -1264,6 +1264,45 @@ def _small_bwd(gA, y, coef, W, addend, slope, dgamma, dbeta, need_dx):
     return gY, (_gemm(gY, W, addend=addend) if need_dx else None)
 
 
+def _small_fwd(x, Wc, gamma, beta, run_mean, run_var, momentum, eps, slope, skip=None, join_slope=1.0):
+    """(y, out, coef) of a coarse-level MLP block: the one-launch kernel of csrc/mlp_small.hip where its workgroups are co-resident
+    (crfconv_mlp_small_supported), else -- the rows between that limit and the switch-over to the row-streaming forms -- the tiled
+    product followed by the BatchNorm launches (statistics, coefficients, apply; the join's add + LeakyReLU as one more pass)."""
+    m, ci = x.shape
+    co = Wc.shape[0]
+    dev = x.device
+    lib = _lib.load()
+    y = torch.empty((m, co), dtype=torch.float32, device=dev)
+    out = torch.empty_like(y)
+    coef = torch.empty(4 * co, dtype=torch.float32, device=dev)
+    g, b = _f32c(gamma), _f32c(beta)
+    if not _small_mlp_disabled and lib.crfconv_mlp_small_supported(m, ci, co) == 1:
+        nbytes = lib.crfconv_mlp_small_workspace(m, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        sync = gridsync_ws(dev)
+        if skip is None:
+            _lib.call('crfconv_mlp_small_forward', ptr(x), ptr(Wc), m, ci, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
+                      float(momentum), float(eps), float(slope), ptr(y), ptr(out), ptr(coef), ptr(ws), nbytes, ptr(sync),
+                      sync.numel() * 4, stream_ptr())
+        else:
+            _lib.call('crfconv_mlp_small_forward_join', ptr(x), ptr(Wc), m, ci, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
+                      float(momentum), float(eps), float(slope), ptr(skip), float(join_slope), ptr(y), ptr(out), ptr(coef), ptr(ws),
+                      nbytes, ptr(sync), sync.numel() * 4, stream_ptr())
+        return y, out, coef
+    _lib.call('crfconv_gemm', ptr(x), ptr(Wc), None, None, m, co, ci, 1, ptr(y), stream_ptr())
+    nbytes = lib.crfconv_bn_workspace(m, co)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if skip is None:
+        _lib.call('crfconv_bn_forward', ptr(y), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var), float(momentum), float(eps), 1,
+                  float(slope), ptr(coef), ptr(out), ptr(ws), nbytes, stream_ptr())
+    else:
+        tmp = torch.empty_like(y)                           # statistics + coefficients (+ an apply pass whose output the join pass replaces)
+        _lib.call('crfconv_bn_forward', ptr(y), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var), float(momentum), float(eps), 1,
+                  float(slope), ptr(coef), ptr(tmp), ptr(ws), nbytes, stream_ptr())
+        _lib.call('crfconv_bn_apply_add', ptr(y), m, co, ptr(coef), ptr(skip), float(join_slope), ptr(out), stream_ptr())
+    return y, out, coef
+
+
 class _MLPSmallJoin(torch.autograd.Function):
     """_MLPBlockJoin at the coarse levels: the one-launch Linear + BatchNorm kernel (csrc/mlp_small.hip) also adds the skip and
     applies the join's LeakyReLU to the tile it holds in registers (crfconv_mlp_small_forward_join)."""
@@ -1271,18 +1310,7 @@ class _MLPSmallJoin(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, gamma, beta, run_mean, run_var, momentum, eps, skip, slope):
         x, Wc, skip = x.contiguous(), W.contiguous(), skip.contiguous()
-        m, ci = x.shape
-        co = Wc.shape[0]
-        dev = x.device
-        y = torch.empty((m, co), dtype=torch.float32, device=dev)
-        out = torch.empty_like(y)
-        coef = torch.empty(4 * co, dtype=torch.float32, device=dev)
-        nbytes = _lib.load().crfconv_mlp_small_workspace(m, co)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        sync = gridsync_ws(dev)
-        _lib.call('crfconv_mlp_small_forward_join', ptr(x), ptr(Wc), m, ci, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
-                  ptr(run_var), float(momentum), float(eps), 1.0, ptr(skip), float(slope), ptr(y), ptr(out), ptr(coef), ptr(ws),
-                  nbytes, ptr(sync), sync.numel() * 4, stream_ptr())
+        y, out, coef = _small_fwd(x, Wc, gamma, beta, run_mean, run_var, momentum, eps, 1.0, skip, slope)
         ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef, out)
         ctx.slope = float(slope)
@@ -1345,17 +1373,23 @@ _small_mlp_disabled = False       # set by check_gridsync after a barrier failur
 
 
 def _mlp_small_ok(m, ci, co):
-    return (not _NO_SMALL_MLP_ENV) and (not _small_mlp_disabled) and m < _MFMA_MIN_ROWS \
-        and _lib.load().crfconv_mlp_small_supported(m, ci, co) == 1
+    if _NO_SMALL_MLP_ENV or m >= _MFMA_MIN_ROWS:
+        return False
+    lib = _lib.load()
+    if not _small_mlp_disabled and lib.crfconv_mlp_small_supported(m, ci, co) == 1:
+        return True                                          # forward in one launch
+    # past the one-launch kernel's co-residency limit (or after a barrier failure): the same autograd nodes, forward as product +
+    # BatchNorm launches (_small_fwd), backward as always (_small_bwd)
+    return ci % 4 == 0 and co % 4 == 0 and lib.crfconv_mlp_small_backward_supported(m, ci, co) == 1
 
 
 def check_gridsync(dev=None):
     """Raises CrfConvError when a one-launch kernel's grid barrier has timed out on `dev` since the last check (its
     workgroups were not all resident -- CU mask, reserved CUs; the launch's outputs were NaN-poisoned).  One 4-byte
     device read (a synchronisation): FlatSGD.step() calls it every `check_every` eager steps, a loop that replays
-    captured graphs should call it once per epoch / logging interval.  After a failure the one-launch MLP path is
-    switched off for the rest of the process (vendor GEMM + bn_small instead), so a caller that catches the error can
-    re-run the step."""
+    captured graphs should call it once per epoch / logging interval.  After a failure the one-launch KERNEL is
+    switched off for the rest of the process (the small-MLP nodes go on with a launch-separated forward: tiled product +
+    BatchNorm launches, _small_fwd), so a caller that catches the error can re-run the step."""
     global _small_mlp_disabled
     word = _lib.load().crfconv_gridsync_fail_word()
     bad = []
@@ -1385,18 +1419,7 @@ class _MLPSmall(torch.autograd.Function):
     def forward(ctx, x_in, W, gamma, beta, run_mean, run_var, momentum, eps, slope, fork=False):
         x = x_in.contiguous()
         Wc = W.contiguous()
-        m, ci = x.shape
-        co = Wc.shape[0]
-        dev = x.device
-        y = torch.empty((m, co), dtype=torch.float32, device=dev)
-        out = torch.empty_like(y)
-        coef = torch.empty(4 * co, dtype=torch.float32, device=dev)
-        nbytes = _lib.load().crfconv_mlp_small_workspace(m, co)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        sync = gridsync_ws(dev)
-        _lib.call('crfconv_mlp_small_forward', ptr(x), ptr(Wc), m, ci, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
-                  ptr(run_var), float(momentum), float(eps), float(slope), ptr(y), ptr(out), ptr(coef), ptr(ws), nbytes,
-                  ptr(sync), sync.numel() * 4, stream_ptr())
+        y, out, coef = _small_fwd(x, Wc, gamma, beta, run_mean, run_var, momentum, eps, slope)
         ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef)
         ctx.slope = float(slope)

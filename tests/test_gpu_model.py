@@ -15,6 +15,15 @@ from oracle import crf_oracle as O
 from oracle import native as onative
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def big_forms_from_4096(monkeypatch):
+    """Kernel-level tests of the row-streaming (big-level) forms use 4 100 ... 10 240 rows to stay quick; the shipped switch-over
+    between the small and the big forms is at 12 288 rows (ops._MFMA_MIN_ROWS, swept on the training step), so they pin it."""
+    from crfconv_amd import ops
+    monkeypatch.setattr(ops, '_MFMA_MIN_ROWS', 4096)
+
 OUT_TOL = 1e-4
 GRAD_TOL = 2e-4
 
@@ -931,6 +940,7 @@ def test_linear_wgrad_mfma(M, Ci, Co, bias):
         assert_close(b.grad, go.double().sum(0), 2e-5, 'db')
 
 
+@pytest.mark.parametrize('min_rows', [4096, 12288])
 @pytest.mark.parametrize('M,Ci,Co,slope,need_dx', [(163840, 32, 8, 0.1, True), (163840, 6, 32, 0.1, False), (40960, 64, 16, 1.0, True),
                                                    (163840, 32, 128, 0.1, True), (10240, 128, 32, 0.1, True), (4100, 24, 64, 0.1, True),
                                                    (40963, 16, 64, 1.0, True), (10240, 32, 128, 1.0, True),
@@ -940,7 +950,7 @@ def test_linear_wgrad_mfma(M, Ci, Co, bias):
                                                    (2560, 256, 64, 0.1, True), (2560, 64, 256, 1.0, True), (1280, 512, 128, 0.1, True),
                                                    (1280, 128, 512, 1.0, True), (4095, 512, 512, 0.1, True), (1000, 80, 192, 0.2, True),
                                                    (64, 16, 64, 0.1, True), (37, 144, 64, 1.0, False)])
-def test_mlp_block_fused_backward(M, Ci, Co, slope, need_dx):
+def test_mlp_block_fused_backward(M, Ci, Co, slope, need_dx, min_rows, monkeypatch):
     """ops.mlp_block (Linear -> train-mode BatchNorm -> LeakyReLU as one node, csrc/linear.hip: mlp_bwd_p1 / finalize /
     dX with the BatchNorm-backward prologue) against float64 torch.  As in test_fused_batchnorm_lrelu the LeakyReLU
     branch of elements within rounding of 0 is taken from the kernel's own output."""
@@ -953,9 +963,14 @@ def test_mlp_block_fused_backward(M, Ci, Co, slope, need_dx):
     with torch.no_grad():
         bn.weight.copy_(torch.rand(Co, generator=g) + 0.5); bn.bias.copy_(torch.rand(Co, generator=g) * 0.6 - 0.3)
     bn = bn.to(DEV).train()
-    assert ops.mlp_block_ok(x, W, None, bn, True)
-    small = M < ops._MFMA_MIN_ROWS
-    assert ops._mlp_small_ok(M, Ci, Co) == small
+    monkeypatch.setattr(ops, '_MFMA_MIN_ROWS', min_rows)      # 4096: the row-streaming forms from 4 100 rows on; 12 288: the shipped switch-over
+    small = ops._mlp_small_ok(M, Ci, Co)
+    if not ops.mlp_block_ok(x, W, None, bn, True):
+        # between the one-launch kernel's co-residency limit and the switch-over no fused block applies (the layer runs as
+        # Linear + BatchNorm nodes: covered by test_mlp_and_bn_semantics_match_oracle and the whole-network tests)
+        assert min_rows == 12288 and 4096 <= M < 12288 and not small
+        pytest.skip('no fused block for %d rows at a switch-over of %d' % (M, min_rows))
+    assert small == (M < 4096) or (small and M < min_rows)
     out = ops.mlp_block(x, W, bn, slope)
     if small:
         assert '_MLPSmall' in out.grad_fn.next_functions[0][0].name()
@@ -1105,6 +1120,7 @@ def test_pointconv_prefold_one_launch_equals_per_layer_folds():
     assert any('point_conv.weight_nn.0.bn.batch_norm.running_var' in k and not torch.equal(b1[k], torch.ones_like(b1[k])) for k in b1)
 
 
+@pytest.mark.usefixtures('big_forms_from_4096')
 def test_resnet_join_fused_equals_two_passes():
     """models.common.mlp_join: lin_out's BatchNorm + the residual add + LeakyReLU as ONE pass (crfconv_bn_apply_add, one
     autograd node) against bn_apply followed by add_lrelu: the same arithmetic operation for operation, so outputs and every
@@ -1159,6 +1175,7 @@ def test_resnet_join_fused_equals_two_passes():
                 assert torch.equal(gp1[k], gp2[k]), k
 
 
+@pytest.mark.usefixtures('big_forms_from_4096')
 def test_resnet_fork_input_gradient_added_inside_the_block_backward():
     """models.common.mlp_fork: the input of a ResNet block feeds lin_in AND the shortcut; the shortcut's gradient comes back
     through an alias that lin_in's node returned and is added while lin_in's backward writes dX (crfconv_mlp_backward_add; the
@@ -1266,6 +1283,7 @@ def test_mlp_small_one_launch_kernel_under_graph_replay():
     assert int(ops.gridsync_ws(DEV).abs().sum()) == 0
 
 
+@pytest.mark.usefixtures('big_forms_from_4096')
 @pytest.mark.parametrize('M,Ca,Cb,Co', [(163840, 32, 32, 32), (40960, 64, 64, 64), (10240, 64, 32, 128), (5000, 8, 24, 16)])
 def test_mlp_block_cat_equals_block_on_concatenation(M, Ca, Cb, Co):
     """ops.mlp_block_cat([xa | xb]) (two operand pointers, separate input gradients) against ops.mlp_block on the
@@ -1331,6 +1349,7 @@ def test_fused_batchnorm_lrelu(M, C, slope, training):
 
 @pytest.mark.parametrize('M,Ci,Co,bias', [(163840, 32, 128, False), (40960, 64, 16, False), (5000, 6, 32, False),
                                           (4099, 128, 13, True), (10240, 128, 64, False), (8192, 8, 8, True)])
+@pytest.mark.usefixtures('big_forms_from_4096')
 def test_linear_forward_mfma_and_fused_stats(M, Ci, Co, bias):
     """linear.hip forward / dX kernels vs float64 torch, and BatchNorm fed from the GEMM epilogue records."""
     from crfconv_amd import ops
@@ -1620,6 +1639,7 @@ def test_deferred_weight_grads_equal_immediate():
     assert torch.isfinite(gw).all() and float(gw.abs().max()) > 0
 
 
+@pytest.mark.usefixtures('big_forms_from_4096')
 def test_deferred_weight_grads_into_the_flat_bucket():
     """ops.deferred_weight_grads(sink=bucket.view_of): the batched dW / db reduction writes straight into the flat
     gradient bucket.  Same values as without the sink, every Linear weight's .grad IS its bucket slice afterwards, pack()
@@ -1709,7 +1729,8 @@ def test_shared_weight_gradients_sum_inside_the_sink():
 
 def test_grid_barrier_failure_is_raised_and_disables_the_one_launch_path():
     """The sticky failure word of the grid-barrier workspace (set by a one-launch kernel whose barrier timed out) must
-    reach the host: ops.check_gridsync raises, zeroes the workspace and switches the one-launch MLP path off."""
+    reach the host: ops.check_gridsync raises, zeroes the workspace and switches the one-launch KERNEL off (the small-MLP nodes go
+    on with a launch-separated forward and give the same results)."""
     from crfconv_amd import _lib, ops
     dev = torch.device('cuda', 0)
     ws = ops.gridsync_ws(dev)
@@ -1721,12 +1742,30 @@ def test_grid_barrier_failure_is_raised_and_disables_the_one_launch_path():
         with pytest.raises(_lib.CrfConvError, match='grid barrier timed out'):
             ops.check_gridsync(dev)
         assert int(ws.abs().sum()) == 0 and ops._small_mlp_disabled
-        assert not ops._mlp_small_ok(1280, 512, 128)
         ops.check_gridsync(dev)
+        # the small-MLP nodes stay in use, with the forward as separate launches (product, BatchNorm) instead of the grid-barrier kernel
+        assert ops._mlp_small_ok(1280, 512, 128)
+        g = torch.Generator().manual_seed(2)
+        x = torch.randn(1280, 512, generator=g).to(DEV).requires_grad_(True)
+        W = (torch.randn(128, 512, generator=g) / 22).to(DEV).requires_grad_(True)
+        go = torch.randn(1280, 128, generator=g).to(DEV)
+
+        def run():
+            bn = nn.BatchNorm1d(128).to(DEV).train()
+            x.grad = W.grad = None
+            out = ops.mlp_block(x, W, bn, 0.1)
+            out.backward(go)
+            return out.detach().clone(), x.grad.clone(), W.grad.clone(), bn.weight.grad.clone(), bn.running_var.clone()
+        off = run()
+        ops._small_mlp_disabled = False
+        on = run()
+        for a, b, what in zip(off, on, ('out', 'dx', 'dW', 'dgamma', 'running_var')):
+            assert_close(a, b, 1e-5, 'launch-separated forward vs one-launch kernel: ' + what)
     finally:
         ops._small_mlp_disabled = was
 
 
+@pytest.mark.usefixtures('big_forms_from_4096')
 def test_two_training_forwards_before_backward_keep_their_own_dropout_masks():
     """The fused MLP -> Dropout node keys its mask on the BatchNorm's step counter, a device word later forwards advance: the
     backward of a call must use the counter value ITS forward saw (two forwards, then one backward -- multi-view losses,
