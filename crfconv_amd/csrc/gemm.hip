@@ -60,10 +60,14 @@ struct GemmPro {
     float* dbeta;              // [K] out
 };
 
-template <int WM, int WN, int WR, int WC, bool BNK, bool VEC, bool PRO = false>
+// STATS form (crfconv_gemm_stats): the epilogue also leaves BatchNorm statistic records of the tile it holds -- one
+// {shift, rows, sum (v - shift), sum (v - shift)^2} tuple per 16-row group and output channel, the layout
+// crfconv_bn_coef_from_records combines (Chan, float64) -- so the statistics pass over Y never runs.
+template <int WM, int WN, int WR, int WC, bool BNK, bool VEC, bool PRO = false, bool STATS = false>
 __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                         const float* __restrict__ bias, const float* __restrict__ addend,
-                                                        int M, int N, int K, float* __restrict__ C, const GemmPro pro = GemmPro()) {
+                                                        int M, int N, int K, float* __restrict__ C, const GemmPro pro = GemmPro(),
+                                                        float* __restrict__ stat_rec = nullptr) {
     static_assert(WR * WC * WAVE == GM_BLOCK, "four wavefronts");
     static_assert(!PRO || (VEC && !BNK), "the prologue form is the dX product of aligned widths");
     __shared__ float sPro[PRO ? 6 * GM_PRO_MAXK : 1];      // a | b | mean | rstd | sum g1 / M | sum g1 yh / M
@@ -236,6 +240,36 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
             }
         }
     }
+    if constexpr (STATS) {
+        static_assert(!STATS || (VEC && WM == 1), "statistic records: one 16-row group per wavefront, aligned widths");
+        // lane (rr, g) holds rows rr of the group and channels 4 g .. 4 g + 3 of each of its WN tiles: fold the 16 row lanes
+        const int row0 = m0 + 16 * wr * WM;                 // first row of this wavefront's group
+        const int nrows = row0 < M ? (M - row0 < 16 ? M - row0 : 16) : 0;
+        const bool rvalid = rr < nrows;
+        const int rec = (int)blockIdx.x * WR + wr;          // record = 16-row group
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + 16 * (wc * WN + j) + 4 * g;
+            float sv[4], s1[4], s2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sv[e] = __shfl(acc[0][j][e], lane & 0x30, WAVE);            // the group's first row: a sample as shift
+                const float d = rvalid ? acc[0][j][e] - sv[e] : 0.f;
+                s1[e] = d;
+                s2[e] = d * d;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    s1[e] += __shfl_xor(s1[e], o, WAVE);
+                    s2[e] += __shfl_xor(s2[e], o, WAVE);
+                }
+            }
+            if (rr == 0 && n < N) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    *reinterpret_cast<float4*>(stat_rec + ((int64_t)rec * N + n + e) * 4) = make_float4(sv[e], (float)nrows, s1[e], s2[e]);
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int row = m0 + 16 * (wr * WM + i) + rr;
@@ -350,6 +384,22 @@ extern "C" int crfconv_mlp_small_backward(const float* gA, const float* Y, const
     const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32)), blk(crf::GM_BLOCK);
     hipLaunchKernelGGL((crf::gemm_kernel<1, 1, 2, 2, false, true, true>), grid, blk, 0, st, gA, W, (const float*)nullptr, addend, (int)M, N, K,
                        dX, pro);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" size_t crfconv_gemm_stat_records(int64_t M) { return M < 1 ? 0 : (size_t)(2 * ((M + 31) / 32)); }
+
+// C [M, N] = A [M, K] B^T (B [N, K]: the F.linear weight) with BatchNorm statistic records of C from the epilogue: stat_rec
+// float [crfconv_gemm_stat_records(M)][N][4] = {shift, rows, sum (v - shift), sum (v - shift)^2} per 16-row group and channel,
+// to be combined by crfconv_bn_coef_from_records.  N, K multiples of 4.
+extern "C" int crfconv_gemm_stats(const float* A, const float* B, int64_t M, int N, int K, float* C, float* stat_rec, void* stream) {
+    CRF_REQUIRE(A && B && C && stat_rec, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(M >= 1 && M < ((int64_t)1 << 31) && N >= 4 && K >= 4 && N % 4 == 0 && K % 4 == 0, CRF_ERR_UNSUPPORTED,
+                "gemm_stats %lld x %d x %d: N and K must be multiples of 4", (long long)M, N, K);
+    const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32)), blk(crf::GM_BLOCK);
+    hipLaunchKernelGGL((crf::gemm_kernel<1, 1, 2, 2, true, true, false, true>), grid, blk, 0, crf::as_stream(stream), A, B,
+                       (const float*)nullptr, (const float*)nullptr, (int)M, N, K, C, crf::GemmPro(), stat_rec);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -1333,9 +1333,18 @@ extern "C" int crfconv_bn_coef_from_records(const float* stat_rec, int64_t M, in
                                             float eps, float* coef, crf_stream_t stream) {
     CRF_REQUIRE(stat_rec && gamma && beta && coef, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(M > 0 && C > 0, CRF_ERR_ARG, "bad shape");
-    const int nrec = (int)crfconv_linear_forward_stat_records(M);
-    hipLaunchKernelGGL(crf::bn_finalize_records_kernel, dim3((C + crf::FR_CH - 1) / crf::FR_CH), dim3(crf::FR_BLOCK), 0, crf::as_stream(stream), stat_rec, nrec,
-                       M, C, gamma, beta, eps, run_mean, run_var, momentum, coef);
+    return crfconv_bn_coef_from_nrecords(stat_rec, (int64_t)crfconv_linear_forward_stat_records(M), M, C, gamma, beta, run_mean, run_var,
+                                         momentum, eps, coef, stream);
+}
+
+// The same with an explicit record count (records of crfconv_gemm_stats: one per 16-row group).
+extern "C" int crfconv_bn_coef_from_nrecords(const float* stat_rec, int64_t nrec, int64_t M, int C, const float* gamma,
+                                             const float* beta, float* run_mean, float* run_var, float momentum,
+                                             float eps, float* coef, crf_stream_t stream) {
+    CRF_REQUIRE(stat_rec && gamma && beta && coef, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(M > 0 && C > 0 && nrec > 0 && nrec < ((int64_t)1 << 31), CRF_ERR_ARG, "bad shape");
+    hipLaunchKernelGGL(crf::bn_finalize_records_kernel, dim3((C + crf::FR_CH - 1) / crf::FR_CH), dim3(crf::FR_BLOCK), 0, crf::as_stream(stream), stat_rec,
+                       (int)nrec, M, C, gamma, beta, eps, run_mean, run_var, momentum, coef);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

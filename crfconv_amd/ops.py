@@ -1267,7 +1267,7 @@ def _small_bwd(gA, y, coef, W, addend, slope, dgamma, dbeta, need_dx):
 def _small_fwd(x, Wc, gamma, beta, run_mean, run_var, momentum, eps, slope, skip=None, join_slope=1.0):
     """(y, out, coef) of a coarse-level MLP block: the one-launch kernel of csrc/mlp_small.hip where its workgroups are co-resident
     (crfconv_mlp_small_supported), else -- the rows between that limit and the switch-over to the row-streaming forms -- the tiled
-    product followed by the BatchNorm launches (statistics, coefficients, apply; the join's add + LeakyReLU as one more pass)."""
+    product with statistic records in its epilogue, the coefficient launch and one apply pass (with the join's add + LeakyReLU)."""
     m, ci = x.shape
     co = Wc.shape[0]
     dev = x.device
@@ -1289,16 +1289,15 @@ def _small_fwd(x, Wc, gamma, beta, run_mean, run_var, momentum, eps, slope, skip
                       float(momentum), float(eps), float(slope), ptr(skip), float(join_slope), ptr(y), ptr(out), ptr(coef), ptr(ws),
                       nbytes, ptr(sync), sync.numel() * 4, stream_ptr())
         return y, out, coef
-    _lib.call('crfconv_gemm', ptr(x), ptr(Wc), None, None, m, co, ci, 1, ptr(y), stream_ptr())
-    nbytes = lib.crfconv_bn_workspace(m, co)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    # product with the BatchNorm statistic records in its epilogue -> coefficients -> apply (+ skip, the join): three launches
+    nrec = lib.crfconv_gemm_stat_records(m)
+    rec = torch.empty((nrec, co, 4), dtype=torch.float32, device=dev)
+    _lib.call('crfconv_gemm_stats', ptr(x), ptr(Wc), m, co, ci, ptr(y), ptr(rec), stream_ptr())
+    _lib.call('crfconv_bn_coef_from_nrecords', ptr(rec), nrec, m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var), float(momentum),
+              float(eps), ptr(coef), stream_ptr())
     if skip is None:
-        _lib.call('crfconv_bn_forward', ptr(y), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var), float(momentum), float(eps), 1,
-                  float(slope), ptr(coef), ptr(out), ptr(ws), nbytes, stream_ptr())
+        _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), stream_ptr())
     else:
-        tmp = torch.empty_like(y)                           # statistics + coefficients (+ an apply pass whose output the join pass replaces)
-        _lib.call('crfconv_bn_forward', ptr(y), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var), float(momentum), float(eps), 1,
-                  float(slope), ptr(coef), ptr(tmp), ptr(ws), nbytes, stream_ptr())
         _lib.call('crfconv_bn_apply_add', ptr(y), m, co, ptr(coef), ptr(skip), float(join_slope), ptr(out), stream_ptr())
     return y, out, coef
 

@@ -515,12 +515,21 @@ size_t crfconv_mlp_small_backward_workspace(int64_t M, int Co);
 int crfconv_mlp_small_backward(const float* gA, const float* Y, const float* coef, const float* W, const float* addend, int64_t M,
                                int Ci, int Co, int training, float slope, float* gY, float* dX, float* dgamma, float* dbeta,
                                void* workspace, size_t workspace_bytes, crf_stream_t stream);
+/* C [M, N] = A [M, K] B^T (B [N, K], the F.linear weight; N, K multiples of 4) on the same tiled kernel, with the BatchNorm statistic
+ * records of C written by the epilogue: stat_rec float [crfconv_gemm_stat_records(M)][N][4] = {shift, rows, sum (v - shift),
+ * sum (v - shift)^2} per 16-row group and channel -- the input of crfconv_bn_coef_from_records, so no statistics pass over C runs
+ * (the Linear + BatchNorm blocks between the one-launch kernel's row limit and the row-streaming forms). */
+size_t crfconv_gemm_stat_records(int64_t M);
+int crfconv_gemm_stats(const float* A, const float* B, int64_t M, int N, int K, float* C, float* stat_rec, crf_stream_t stream);
 int crfconv_gemm_supported(int64_t M, int N, int K);
 int crfconv_gemm(const float* A, const float* B, const float* bias, const float* addend, int64_t M, int N, int K,
                  int b_is_nk, float* C, crf_stream_t stream);
 int crfconv_bn_coef_from_records(const float* stat_rec, int64_t M, int C, const float* gamma, const float* beta,
                                  float* run_mean, float* run_var, float momentum, float eps, float* coef,
                                  crf_stream_t stream);
+/* The same with an explicit record count (the records of crfconv_gemm_stats: one per 16-row group). */
+int crfconv_bn_coef_from_nrecords(const float* stat_rec, int64_t nrec, int64_t M, int C, const float* gamma, const float* beta,
+                                  float* run_mean, float* run_var, float momentum, float eps, float* coef, crf_stream_t stream);
 
 /* Q = M^-1 for the symmetric positive definite M = I + c^T c of a CRF layer (H <= 64; Gauss-Jordan in
  * float64, one workgroup, no host sync -- capturable into a hipGraph, unlike a LAPACK-style inverse). */

@@ -1423,6 +1423,32 @@ def test_gemm_odd_widths(M, N, K, nk):
         assert_close(x.grad, add.double() @ B.double(), 2e-6, 'dX')
 
 
+@pytest.mark.parametrize('M,N,K', [(10240, 128, 256), (1000, 64, 32), (37, 8, 4), (4100, 132, 36)])
+def test_gemm_stats_records_feed_batchnorm(M, N, K):
+    """crfconv_gemm_stats: the product equals crfconv_gemm's bit for bit, and the statistic records of its epilogue (one per 16-row
+    group, ragged last group included) give the BatchNorm coefficients / running statistics of the float64 reference."""
+    from crfconv_amd import _lib, ops
+    from crfconv_amd.ops import ptr, stream_ptr
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.randn(M, K, generator=g) + 0.3).to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    y = torch.empty(M, N, device=DEV)
+    nrec = _lib.load().crfconv_gemm_stat_records(M)
+    rec = torch.full((nrec, N, 4), float('nan'), device=DEV)
+    _lib.call('crfconv_gemm_stats', ptr(A), ptr(W), M, N, K, ptr(y), ptr(rec), stream_ptr())
+    assert torch.equal(y, ops._gemm(A, W, nk=True))
+    assert int(rec[:, :, 1].sum(0).min()) == M and int(rec[:, :, 1].sum(0).max()) == M and not bool(torch.isnan(rec).any())
+    bn = nn.BatchNorm1d(N).to(DEV).train()
+    ref = nn.BatchNorm1d(N).to(DEV).double().train()
+    coef = torch.empty(4 * N, device=DEV)
+    _lib.call('crfconv_bn_coef_from_nrecords', ptr(rec), nrec, M, N, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+              0.1, 1e-5, ptr(coef), stream_ptr())
+    yr = ref(y.double())
+    assert_close(coef[:N] * y + coef[N:2 * N], yr, 1e-5, 'BatchNorm from the product\'s records')
+    assert_close(bn.running_mean, ref.running_mean, 1e-6, 'running_mean')
+    assert_close(bn.running_var, ref.running_var, 1e-6, 'running_var')
+
+
 @pytest.mark.parametrize('M,Ci,Co,slope,addend', [(2560, 256, 64, 0.1, False), (2560, 64, 256, 1.0, True), (640, 512, 128, 0.1, True),
                                                    (2561, 128, 512, 0.2, False), (100, 8, 4, 0.1, True), (3000, 36, 132, 1.0, False)])
 def test_mlp_small_backward_two_launch_form(M, Ci, Co, slope, addend):
