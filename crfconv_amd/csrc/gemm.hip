@@ -305,34 +305,37 @@ namespace crf {
 // (whole 256-byte row segments), 16 rows per pass; float32 inside a thread's eight rows, float64 across the 16 row threads.
 constexpr int BT_ROWS = 128, BT_CH = 64, BT_NR = BT_ROWS / 16;
 __global__ __launch_bounds__(256) void bn_bwd_tile_sums_kernel(const float* __restrict__ gA, const float* __restrict__ Y,
-                                                               const float* __restrict__ coef, int M, int K, float slope,
-                                                               double* __restrict__ partial) {
+                                                               const float* __restrict__ coef, int M, int K, int tile_rows,
+                                                               float slope, double* __restrict__ partial) {
     __shared__ float s_red[16][2][BT_CH];
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.y * BT_CH + 4 * cq;
-    const int row0 = blockIdx.x * BT_ROWS;
+    const int row0 = blockIdx.x * tile_rows;
+    const int row_end = row0 + tile_rows < M ? row0 + tile_rows : M;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     if (c < K) {
-        float4 g[BT_NR], y[BT_NR];                           // every load of the thread in flight at once: one round trip
-#pragma unroll
-        for (int u = 0; u < BT_NR; ++u) {
-            const int r = row0 + rl + 16 * u;
-            const bool in = r < M;
-            g[u] = in ? *reinterpret_cast<const float4*>(gA + (int64_t)r * K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            y[u] = in ? *reinterpret_cast<const float4*>(Y + (int64_t)r * K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
         const float4 ca = *reinterpret_cast<const float4*>(coef + c), cb = *reinterpret_cast<const float4*>(coef + K + c);
         const float4 mu = *reinterpret_cast<const float4*>(coef + 2 * K + c), rs = *reinterpret_cast<const float4*>(coef + 3 * K + c);
+        for (int base = row0; base < row_end; base += BT_ROWS) {      // one trip at <= 3072 rows (tiles of 128 rows)
+            float4 g[BT_NR], y[BT_NR];                       // every load of a trip in flight at once: one round trip
 #pragma unroll
-        for (int u = 0; u < BT_NR; ++u) {                    // (rows past the end hold g = 0: they add nothing)
-            float4 v = g[u];
-            v.x *= fmaf(ca.x, y[u].x, cb.x) > 0.f ? 1.f : slope;
-            v.y *= fmaf(ca.y, y[u].y, cb.y) > 0.f ? 1.f : slope;
-            v.z *= fmaf(ca.z, y[u].z, cb.z) > 0.f ? 1.f : slope;
-            v.w *= fmaf(ca.w, y[u].w, cb.w) > 0.f ? 1.f : slope;
-            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-            s2.x = fmaf(v.x, (y[u].x - mu.x) * rs.x, s2.x); s2.y = fmaf(v.y, (y[u].y - mu.y) * rs.y, s2.y);
-            s2.z = fmaf(v.z, (y[u].z - mu.z) * rs.z, s2.z); s2.w = fmaf(v.w, (y[u].w - mu.w) * rs.w, s2.w);
+            for (int u = 0; u < BT_NR; ++u) {
+                const int r = base + rl + 16 * u;
+                const bool in = r < row_end;
+                g[u] = in ? *reinterpret_cast<const float4*>(gA + (int64_t)r * K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                y[u] = in ? *reinterpret_cast<const float4*>(Y + (int64_t)r * K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < BT_NR; ++u) {                // (rows past the end hold g = 0: they add nothing)
+                float4 v = g[u];
+                v.x *= fmaf(ca.x, y[u].x, cb.x) > 0.f ? 1.f : slope;
+                v.y *= fmaf(ca.y, y[u].y, cb.y) > 0.f ? 1.f : slope;
+                v.z *= fmaf(ca.z, y[u].z, cb.z) > 0.f ? 1.f : slope;
+                v.w *= fmaf(ca.w, y[u].w, cb.w) > 0.f ? 1.f : slope;
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x = fmaf(v.x, (y[u].x - mu.x) * rs.x, s2.x); s2.y = fmaf(v.y, (y[u].y - mu.y) * rs.y, s2.y);
+                s2.z = fmaf(v.z, (y[u].z - mu.z) * rs.z, s2.z); s2.w = fmaf(v.w, (y[u].w - mu.w) * rs.w, s2.w);
+            }
         }
     }
     *reinterpret_cast<float4*>(&s_red[rl][0][4 * cq]) = s1;
@@ -353,9 +356,21 @@ extern "C" int crfconv_mlp_small_backward_supported(int64_t M, int Ci, int Co) {
     return (M >= 1 && M < (int64_t)1 << 24 && Ci >= 4 && Co >= 4 && Ci % 4 == 0 && Co % 4 == 0 && Co <= crf::GM_PRO_MAXK) ? 1 : 0;
 }
 
+// at most BT_MAXTILES row tiles (every workgroup of the product sums all of them in its prologue): 128-row tiles up to 3072
+// rows, proportionally longer ones above
+static void bt_plan(int64_t M, int& ntile, int& tile_rows) {
+    constexpr int BT_MAXTILES = 24;
+    int64_t rows = crf::BT_ROWS;
+    if ((M + rows - 1) / rows > BT_MAXTILES) rows = (((M + BT_MAXTILES - 1) / BT_MAXTILES + 15) / 16) * 16;
+    tile_rows = (int)rows;
+    ntile = (int)((M + rows - 1) / rows);
+}
+
 extern "C" size_t crfconv_mlp_small_backward_workspace(int64_t M, int Co) {
     if (M < 1 || Co < 1) return 0;
-    return sizeof(double) * 2 * (size_t)Co * (size_t)((M + crf::BT_ROWS - 1) / crf::BT_ROWS) + 256;
+    int ntile, tile_rows;
+    bt_plan(M, ntile, tile_rows);
+    return sizeof(double) * 2 * (size_t)Co * (size_t)ntile + 256;
 }
 
 // Backward of one coarse-level MLP block A = lrelu(BN(X W^T), slope) behind its one-launch forward (crfconv_mlp_small_forward),
@@ -371,9 +386,10 @@ extern "C" int crfconv_mlp_small_backward(const float* gA, const float* Y, const
     CRF_REQUIRE(workspace_bytes >= crfconv_mlp_small_backward_workspace(M, Co), CRF_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = crf::as_stream(stream);
     double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    const int ntile = (int)((M + crf::BT_ROWS - 1) / crf::BT_ROWS);
+    int ntile, tile_rows;
+    bt_plan(M, ntile, tile_rows);
     hipLaunchKernelGGL(crf::bn_bwd_tile_sums_kernel, dim3((unsigned)ntile, (unsigned)((Co + crf::BT_CH - 1) / crf::BT_CH)), dim3(256), 0, st,
-                       gA, Y, coef, (int)M, Co, slope, partial);
+                       gA, Y, coef, (int)M, Co, tile_rows, slope, partial);
     CRF_LAUNCH_CHECK();
     crf::GemmPro pro;
     pro.Y = Y; pro.coef = coef; pro.partial = partial; pro.ntile = ntile; pro.training = training; pro.slope = slope;
