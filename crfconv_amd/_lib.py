@@ -95,6 +95,8 @@ SIGNATURES = {
     'crfconv_bn_forward': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_bn_backward': (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_bn_apply': (_i, [_vp, _i64, _i, _vp, _f, _vp, _vp]),
+    'crfconv_linear_wgrad_nblk': (_i, [_i64, _i, _i]),
+    'crfconv_linear_wgrad_partial_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_linear_wgrad_partial': (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp, _vp]),
     'crfconv_morton_codes': (_i, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'crfconv_copy_jobs': (_i, [_vp, _i, _vp]),
@@ -167,6 +169,12 @@ class MlpDwJob(ctypes.Structure):
     """crf_mlp_dw_job of include/crfconv_amd.h."""
     _fields_ = [('workspace', ctypes.c_void_p), ('coef', ctypes.c_void_p), ('dW', ctypes.c_void_p), ('M', ctypes.c_int64),
                 ('Ci', ctypes.c_int32), ('Co', ctypes.c_int32)]
+
+
+class WgradJob(ctypes.Structure):
+    """crf_wgrad_job of include/crfconv_amd.h."""
+    _fields_ = [('G', ctypes.c_void_p), ('X', ctypes.c_void_p), ('M', ctypes.c_int64), ('Co', ctypes.c_int32), ('Ci', ctypes.c_int32),
+                ('want_bias', ctypes.c_int32), ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
 
 
 class RevJob(ctypes.Structure):

@@ -24,13 +24,11 @@ constexpr int WG_WAVES = WG_BLOCK / WAVE;
 
 // TCO x TCI tiles of 16x16 per block (output slab 16*TCO x 16*TCI at (co0, ci0) = blockIdx.y / z).
 template <int TCO, int TCI>
-__global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict__ G,
-                                                         const float* __restrict__ X, int64_t M, int Co,
-                                                         int Ci, int rows_per_block,
-                                                         float* __restrict__ partial /*[nblk][Co][Ci]*/,
-                                                         float* __restrict__ partial_b /*[nblk][Co] or null*/) {
+__device__ __forceinline__ void wgrad_body(const float* __restrict__ G, const float* __restrict__ X, int64_t M, int Co, int Ci,
+                                           int rows_per_block, float* __restrict__ partial /*[nblk][Co][Ci]*/,
+                                           float* __restrict__ partial_b /*[nblk][Co] or null*/, int bx, int by, int bz) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int co_base = blockIdx.y * 16 * TCO, ci_base = blockIdx.z * 16 * TCI;
+    const int co_base = by * 16 * TCO, ci_base = bz * 16 * TCI;
     const int kk = lane >> 4, cc = lane & 15;
     f32x4 acc[TCO][TCI];
 #pragma unroll
@@ -41,7 +39,7 @@ __global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict
 #pragma unroll
     for (int a = 0; a < TCO; ++a) bsum[a] = 0.f;
 
-    const int64_t row_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t row_begin = (int64_t)bx * rows_per_block;
     const int64_t row_end = row_begin + rows_per_block < M ? row_begin + rows_per_block : M;
     // waves interleave 16-row groups (4 k-steps) inside the block's slice; all operand loads of a group are issued
     // before its MFMAs, so each lane keeps 4 (TCO + TCI) dword loads in flight
@@ -88,7 +86,7 @@ __global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict
         if (kk == 0) s_b[wave][a * 16 + cc] = t;
     }
     __syncthreads();
-    const int64_t pb = (int64_t)blockIdx.x;
+    const int64_t pb = (int64_t)bx;
     for (int t = threadIdx.x; t < TCO * TCI * 256; t += WG_BLOCK) {
         float v = 0.f;
 #pragma unroll
@@ -97,7 +95,7 @@ __global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict
         const int co = co_base + 16 * a + i, ci = ci_base + 16 * b + j;
         if (co < Co && ci < Ci) partial[(pb * Co + co) * Ci + ci] = v;
     }
-    if (partial_b != nullptr && blockIdx.z == 0) {
+    if (partial_b != nullptr && bz == 0) {
         for (int t = threadIdx.x; t < TCO * 16; t += WG_BLOCK) {
             float v = 0.f;
 #pragma unroll
@@ -106,6 +104,42 @@ __global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict
             if (co < Co) partial_b[pb * Co + co] = v;
         }
     }
+}
+
+template <int TCO, int TCI>
+__global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict__ G,
+                                                         const float* __restrict__ X, int64_t M, int Co,
+                                                         int Ci, int rows_per_block,
+                                                         float* __restrict__ partial /*[nblk][Co][Ci]*/,
+                                                         float* __restrict__ partial_b /*[nblk][Co] or null*/) {
+    wgrad_body<TCO, TCI>(G, X, M, Co, Ci, rows_per_block, partial, partial_b, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The partial passes of SEVERAL layers in one launch (crfconv_linear_wgrad_partial_jobs): the weight gradients of the coarse
+// levels are ~9 us launches of a few workgroups each and nothing on the backward chain waits for them, so they are queued and
+// issued together once the chain is done -- the jobs' workgroups (laid end to end, job found by a binary search over the
+// prefix) run side by side.  Same partial slabs as one wgrad_kernel launch per job.
+constexpr int WJ_MAX = 32;
+struct WgJobTable {
+    const float* G[WJ_MAX];
+    const float* X[WJ_MAX];
+    float* partial[WJ_MAX];
+    float* partial_b[WJ_MAX];
+    int M[WJ_MAX], Co[WJ_MAX], Ci[WJ_MAX], rows_per_block[WJ_MAX], nblk[WJ_MAX], gy[WJ_MAX];
+    int blk_base[WJ_MAX + 1];
+    int njobs;
+};
+template <int TCO, int TCI>
+__global__ __launch_bounds__(WG_BLOCK) void wgrad_jobs_kernel(const WgJobTable t) {
+    int lo = 0, hi = t.njobs;                          // largest j with blk_base[j] <= blockIdx.x
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t.blk_base[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int local = (int)blockIdx.x - t.blk_base[lo];
+    const int bx = local % t.nblk[lo], rest = local / t.nblk[lo];
+    wgrad_body<TCO, TCI>(t.G[lo], t.X[lo], t.M[lo], t.Co[lo], t.Ci[lo], t.rows_per_block[lo], t.partial[lo], t.partial_b[lo], bx,
+                         rest % t.gy[lo], rest / t.gy[lo]);
 }
 
 // ====================================================================== backward of Linear -> BatchNorm -> LeakyReLU
@@ -509,6 +543,71 @@ extern "C" int crfconv_linear_wgrad_partial(const float* G, const float* X, int6
     float* partial_b = want_bias ? partial + (size_t)p.nblk * Co * Ci : nullptr;
     *nblk_out = p.nblk;
     return wgrad_launch(G, X, M, Co, Ci, p, partial, partial_b, as_stream(stream));
+}
+
+extern "C" int crfconv_linear_wgrad_nblk(int64_t M, int Co, int Ci) {
+    if (M <= 0 || Co <= 0 || Ci <= 0) return 0;
+    return wg_plan(M, Co, Ci).nblk;
+}
+
+// crfconv_linear_wgrad_partial for several layers at once (jobs: host array): one launch per tile class present among the jobs
+// (at most nine, typically one or two) instead of one per layer; identical partial slabs.
+extern "C" int crfconv_linear_wgrad_partial_jobs(const crf_wgrad_job* jobs, int njobs, crf_stream_t stream) {
+    CRF_REQUIRE(jobs || njobs == 0, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(njobs >= 0, CRF_ERR_ARG, "njobs=%d < 0", njobs);
+    hipStream_t st = as_stream(stream);
+    for (int j = 0; j < njobs; ++j) {
+        const crf_wgrad_job& jb = jobs[j];
+        CRF_REQUIRE(jb.G && jb.X && jb.workspace, CRF_ERR_ARG, "job %d: null pointer", j);
+        CRF_REQUIRE(jb.M > 0 && jb.M < ((int64_t)1 << 31) && jb.Co > 0 && jb.Ci > 0 && jb.Co <= 4096 && jb.Ci <= 4096, CRF_ERR_ARG,
+                    "job %d: bad shape M=%lld Co=%d Ci=%d", j, (long long)jb.M, jb.Co, jb.Ci);
+        CRF_REQUIRE((reinterpret_cast<uintptr_t>(jb.workspace) & 255) == 0, CRF_ERR_ARG, "job %d: workspace must be 256-byte aligned", j);
+        CRF_REQUIRE(jb.workspace_bytes >= crfconv_linear_wgrad_workspace(jb.M, jb.Co, jb.Ci), CRF_ERR_WORKSPACE, "job %d: workspace too small", j);
+    }
+    static const int classes[9][2] = {{4, 4}, {2, 2}, {4, 2}, {2, 4}, {1, 4}, {4, 1}, {1, 2}, {2, 1}, {1, 1}};
+    for (int c = 0; c < 9; ++c) {
+        int j = 0;
+        while (j < njobs) {
+            WgJobTable t;
+            int n = 0;
+            int64_t blocks = 0;
+            for (; j < njobs && n < WJ_MAX; ++j) {
+                const crf_wgrad_job& jb = jobs[j];
+                const WgPlan p = wg_plan(jb.M, jb.Co, jb.Ci);
+                if (p.tco != classes[c][0] || p.tci != classes[c][1]) continue;
+                float* partial = reinterpret_cast<float*>(jb.workspace);
+                t.G[n] = jb.G; t.X[n] = jb.X; t.partial[n] = partial;
+                t.partial_b[n] = jb.want_bias ? partial + (size_t)p.nblk * jb.Co * jb.Ci : nullptr;
+                t.M[n] = (int)jb.M; t.Co[n] = jb.Co; t.Ci[n] = jb.Ci; t.rows_per_block[n] = p.rows_per_block; t.nblk[n] = p.nblk; t.gy[n] = p.gy;
+                t.blk_base[n] = (int)blocks;
+                blocks += (int64_t)p.nblk * p.gy * p.gz;
+                CRF_REQUIRE(blocks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many workgroups in one batch");
+                ++n;
+            }
+            if (n == 0) break;
+            for (int k = n; k <= WJ_MAX; ++k) t.blk_base[k] = (int)blocks;
+            for (int k = n; k < WJ_MAX; ++k) {
+                t.G[k] = nullptr; t.X[k] = nullptr; t.partial[k] = nullptr; t.partial_b[k] = nullptr;
+                t.M[k] = 0; t.Co[k] = 1; t.Ci[k] = 1; t.rows_per_block[k] = 64; t.nblk[k] = 1; t.gy[k] = 1;
+            }
+            t.njobs = n;
+#define WJ(TA, TB) hipLaunchKernelGGL((wgrad_jobs_kernel<TA, TB>), dim3((unsigned)blocks), dim3(WG_BLOCK), 0, st, t)
+            switch (classes[c][0] * 10 + classes[c][1]) {
+                case 44: WJ(4, 4); break;
+                case 22: WJ(2, 2); break;
+                case 42: WJ(4, 2); break;
+                case 24: WJ(2, 4); break;
+                case 14: WJ(1, 4); break;
+                case 41: WJ(4, 1); break;
+                case 12: WJ(1, 2); break;
+                case 21: WJ(2, 1); break;
+                default: WJ(1, 1); break;
+            }
+#undef WJ
+            CRF_LAUNCH_CHECK();
+        }
+    }
+    return CRF_OK;
 }
 
 extern "C" int crfconv_reduce_jobs(const crf_reduce_job* jobs, int njobs, crf_stream_t stream) {

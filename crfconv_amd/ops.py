@@ -475,7 +475,7 @@ def discrete_meanfield(p, u, w, C, table, steps):
 # like DDP's) finishes all of them and installs / accumulates ``.grad`` of the weight and bias parameters directly.
 # Opt-in because it bypasses autograd for those leaves: ``torch.autograd.grad(loss, weight)`` sees nothing, and
 # gradient hooks on the weights do not fire.  ``loss.backward()`` + ``param.grad`` behave as usual.
-_DEFER = {'on': False, 'jobs': [], 'folds': [], 'mlpdw': [], 'armed': False, 'claimed': set()}
+_DEFER = {'on': False, 'jobs': [], 'partials': [], 'folds': [], 'mlpdw': [], 'armed': False, 'claimed': set()}
 
 
 class deferred_weight_grads:
@@ -535,16 +535,29 @@ def _param_ret(prm, buf, direct):
     return buf
 
 
+_WGRAD_BATCH_ROWS = int(__import__('os').environ.get('CRFCONV_WGRAD_BATCH_ROWS', 65536))     # A/B: 0 = every partial pass at once
+
+
 def _defer_weight_grad(g, x, params, has_bias):
     m, Co = g.shape
     Ci = x.shape[1]
-    nbytes = _lib.load().crfconv_linear_wgrad_workspace(m, Co, Ci)
+    lib = _lib.load()
+    nbytes = lib.crfconv_linear_wgrad_workspace(m, Co, Ci)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
-    nblk = ctypes.c_int(0)
     want_b = bool(has_bias and params[1].requires_grad)
-    _lib.call('crfconv_linear_wgrad_partial', ptr(g), ptr(x), m, Co, Ci, 1 if want_b else 0, ptr(ws), nbytes,
-              ctypes.byref(nblk), stream_ptr())
-    _DEFER['jobs'].append((params[0], params[1] if want_b else None, ws, nblk.value, Co, Ci))
+    if m <= _WGRAD_BATCH_ROWS:
+        # the PARTIAL pass waits too: nothing on the backward chain reads it, and the coarse levels' passes are ~9 us launches of a
+        # few workgroups each -- all of them go out in one launch per tile class at the end (crfconv_linear_wgrad_partial_jobs);
+        # g and x stay alive until then (small: that is the point)
+        g, x = g.contiguous(), x.contiguous()
+        _DEFER['partials'].append((_lib.WgradJob(g.data_ptr(), x.data_ptr(), m, Co, Ci, 1 if want_b else 0, ws.data_ptr(), nbytes), (g, x)))
+        nblk = lib.crfconv_linear_wgrad_nblk(m, Co, Ci)
+    else:
+        nb = ctypes.c_int(0)
+        _lib.call('crfconv_linear_wgrad_partial', ptr(g), ptr(x), m, Co, Ci, 1 if want_b else 0, ptr(ws), nbytes,
+                  ctypes.byref(nb), stream_ptr())
+        nblk = nb.value
+    _DEFER['jobs'].append((params[0], params[1] if want_b else None, ws, nblk, Co, Ci))
     _arm_flush()
 
 
@@ -625,6 +638,10 @@ def _flush_fold1_bwd():
 
 def _flush_weight_grads():
     jobs, _DEFER['jobs'], _DEFER['armed'] = _DEFER['jobs'], [], False
+    partials, _DEFER['partials'] = _DEFER.get('partials', []), []
+    if partials:
+        arr = (_lib.WgradJob * len(partials))(*[j for j, _ in partials])
+        _lib.call('crfconv_linear_wgrad_partial_jobs', ctypes.cast(arr, ctypes.c_void_p), len(partials), stream_ptr())
     _flush_fold1_bwd()
     _flush_mlp_dw()
     if not jobs:

@@ -399,6 +399,12 @@ int crfconv_linear_wgrad(const float* G, const float* X, int64_t M, int Co, int 
 typedef struct { const float* partial; float* out; int32_t nblk; int32_t nslots; } crf_reduce_job;
 int crfconv_linear_wgrad_partial(const float* G, const float* X, int64_t M, int Co, int Ci, int want_bias,
                                  void* workspace, size_t workspace_bytes, int* nblk_out, crf_stream_t stream);
+/* The partial passes of several layers in one launch per tile class (the coarse levels' weight gradients are ~9 us launches nothing
+ * on the backward chain waits for: queued, then issued together): identical partial slabs.  jobs is a host array; each workspace as
+ * for crfconv_linear_wgrad_partial; crfconv_linear_wgrad_nblk = the slab count of a shape (the reduction job needs it). */
+typedef struct { const float* G; const float* X; int64_t M; int Co; int Ci; int want_bias; void* workspace; size_t workspace_bytes; } crf_wgrad_job;
+int crfconv_linear_wgrad_nblk(int64_t M, int Co, int Ci);
+int crfconv_linear_wgrad_partial_jobs(const crf_wgrad_job* jobs, int njobs, crf_stream_t stream);
 int crfconv_reduce_jobs(const crf_reduce_job* jobs, int njobs, crf_stream_t stream);
 
 /* Linear -> BatchNorm(train) -> LeakyReLU of the coarse levels as ONE launch (csrc/mlp_small.hip): replaces the
