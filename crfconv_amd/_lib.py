@@ -95,6 +95,9 @@ SIGNATURES = {
     'crfconv_bn_forward': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_bn_backward': (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_bn_apply': (_i, [_vp, _i64, _i, _vp, _f, _vp, _vp]),
+    'crfconv_pointconv_bwd_params_slabs': (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+    'crfconv_pointconv_bwd_a1_nblk': (_i64, [_i64, _i]),
+    'crfconv_reduce_jobs_f64': (_i, [_vp, _i, _vp]),
     'crfconv_linear_wgrad_nblk': (_i, [_i64, _i, _i]),
     'crfconv_linear_wgrad_partial_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_linear_wgrad_partial': (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp, _vp]),
@@ -169,6 +172,12 @@ class MlpDwJob(ctypes.Structure):
     """crf_mlp_dw_job of include/crfconv_amd.h."""
     _fields_ = [('workspace', ctypes.c_void_p), ('coef', ctypes.c_void_p), ('dW', ctypes.c_void_p), ('M', ctypes.c_int64),
                 ('Ci', ctypes.c_int32), ('Co', ctypes.c_int32)]
+
+
+class Reduce64Job(ctypes.Structure):
+    """crf_reduce64_job of include/crfconv_amd.h."""
+    _fields_ = [('partial', ctypes.c_void_p), ('is_float', ctypes.c_int32), ('nblk', ctypes.c_int64), ('nslots', ctypes.c_int32),
+                ('out', ctypes.c_void_p)]
 
 
 class WgradJob(ctypes.Structure):

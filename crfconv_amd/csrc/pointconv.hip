@@ -272,6 +272,40 @@ __global__ __launch_bounds__(256) void reduce_partials_d_kernel(const double* __
     if (lane == 0) out[slot] = a;
 }
 
+// The same for SEVERAL reductions in one launch (crfconv_reduce_jobs_f64): the parameter-gradient partials of all PointConv layers
+// (dW2 float slabs and dA1 | db1 float64 slabs) are summed once, at the end of the backward pass, in front of the batched fold --
+// ten to fourteen single-purpose launches otherwise.  One wavefront per (job, slot); lane order and shuffle tree as above.
+constexpr int R64_MAX = 32;
+struct Reduce64Table {
+    const void* partial[R64_MAX];
+    double* out[R64_MAX];
+    int is_float[R64_MAX], nblk[R64_MAX], nslots[R64_MAX];
+    int wave_base[R64_MAX + 1];                        // prefix of nslots
+    int njobs;
+};
+__global__ __launch_bounds__(256) void reduce_jobs_f64_kernel(const Reduce64Table t) {
+    const int gw = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (gw >= t.wave_base[t.njobs]) return;
+    int lo = 0, hi = t.njobs;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t.wave_base[mid] <= gw) lo = mid; else hi = mid;
+    }
+    const int slot = gw - t.wave_base[lo], nslots = t.nslots[lo], nblk = t.nblk[lo];
+    double a = 0.0;
+    if (t.is_float[lo]) {
+        const float* __restrict__ p = reinterpret_cast<const float*>(t.partial[lo]);
+        for (int64_t b = lane; b < nblk; b += WAVE) a += (double)p[b * nslots + slot];
+    } else {
+        const double* __restrict__ p = reinterpret_cast<const double*>(t.partial[lo]);
+        for (int64_t b = lane; b < nblk; b += WAVE) a += p[b * nslots + slot];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
+    if (lane == 0) t.out[lo][slot] = a;
+}
+
 // ------------------------------------------------------------------ rel-pos moments
 __device__ __forceinline__ void moments_block(const float* __restrict__ pos_src, const float* __restrict__ pos_tgt,
                                               const int32_t* __restrict__ idx, int K, int64_t m_tgt, int64_t blk,
@@ -1383,8 +1417,8 @@ extern "C" int crfconv_pointconv_bwd_params(const float* x, const float* gout, c
                                             const float* cc, double* dW2, double* dA1b1, void* workspace,
                                             size_t workspace_bytes, crf_stream_t stream) {
     if (int rc = check_pc(m_tgt, K, d)) return rc;
-    CRF_REQUIRE(x && gout && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && ca && cb && cc && dW2 && dA1b1 &&
-                    workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(x && gout && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && ca && cb && cc && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE((dW2 == nullptr) == (dA1b1 == nullptr), CRF_ERR_ARG, "dW2 and dA1b1: both or neither (neither = the partial slabs only)");
     CRF_REQUIRE(d <= 16, CRF_ERR_UNSUPPORTED, "in-kernel parameter reduction covers d <= 16; use crfconv_pointconv_bwd_dump for d=%d", d);
     const int64_t nblk = blocks_for(m_tgt, d);
     const size_t fbytes = (sizeof(float) * (size_t)d * d * (size_t)nblk + 255) & ~(size_t)255;
@@ -1400,10 +1434,53 @@ extern "C" int crfconv_pointconv_bwd_params(const float* x, const float* gout, c
         default: hipLaunchKernelGGL(bwd_params_kernel<16>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, gout, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, partial, partial_d); break;
     }
     CRF_LAUNCH_CHECK();
+    if (dW2 == nullptr) return CRF_OK;                   // the caller sums the slabs later (crfconv_pointconv_bwd_params_slabs)
     if (int rc = reduce_partials(partial, nblk, d * d, dW2, st)) return rc;
     hipLaunchKernelGGL(reduce_partials_d_kernel, dim3((unsigned)cdiv(4 * d, 256 / WAVE)), dim3(256), 0, st, partial_d,
                        nblk, 4 * d, dA1b1);
     CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+// Where crfconv_pointconv_bwd_params left its partial slabs inside `workspace`: float [nblk][d*d] (dW2) and double [nblk][4d]
+// (dA1 | db1) -- for a caller that passed dW2 = dA1b1 = NULL and finishes the sums with crfconv_reduce_jobs_f64.
+extern "C" int crfconv_pointconv_bwd_params_slabs(void* workspace, int64_t m_tgt, int d, const float** slab_w2, const double** slab_a1,
+                                                  int64_t* nblk_out) {
+    CRF_REQUIRE(workspace && slab_w2 && slab_a1 && nblk_out && m_tgt > 0 && d >= 4 && d <= 16, CRF_ERR_ARG, "bad argument");
+    const int64_t nblk = blocks_for(m_tgt, d);
+    const size_t fbytes = (sizeof(float) * (size_t)d * d * (size_t)nblk + 255) & ~(size_t)255;
+    char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    *slab_w2 = reinterpret_cast<const float*>(base);
+    *slab_a1 = reinterpret_cast<const double*>(base + fbytes);
+    *nblk_out = nblk;
+    return CRF_OK;
+}
+
+extern "C" int crfconv_reduce_jobs_f64(const crf_reduce64_job* jobs, int njobs, crf_stream_t stream) {
+    CRF_REQUIRE(jobs || njobs == 0, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(njobs >= 0, CRF_ERR_ARG, "njobs=%d < 0", njobs);
+    hipStream_t st = as_stream(stream);
+    for (int j0 = 0; j0 < njobs; j0 += R64_MAX) {
+        Reduce64Table t;
+        const int n = njobs - j0 < R64_MAX ? njobs - j0 : R64_MAX;
+        int64_t waves = 0;
+        for (int j = 0; j <= R64_MAX; ++j) {
+            t.wave_base[j] = (int)waves;
+            if (j < n) {
+                const crf_reduce64_job& jb = jobs[j0 + j];
+                CRF_REQUIRE(jb.partial && jb.out && jb.nblk > 0 && jb.nblk < ((int64_t)1 << 31) && jb.nslots > 0, CRF_ERR_ARG,
+                            "job %d is malformed", j0 + j);
+                t.partial[j] = jb.partial; t.out[j] = jb.out; t.is_float[j] = jb.is_float; t.nblk[j] = (int)jb.nblk; t.nslots[j] = jb.nslots;
+                waves += jb.nslots;
+                CRF_REQUIRE(waves < ((int64_t)1 << 30), CRF_ERR_UNSUPPORTED, "too many slots in one batch");
+            } else if (j < R64_MAX) {
+                t.partial[j] = nullptr; t.out[j] = nullptr; t.is_float[j] = 0; t.nblk[j] = 0; t.nslots[j] = 0;
+            }
+        }
+        t.njobs = n;
+        hipLaunchKernelGGL(reduce_jobs_f64_kernel, dim3((unsigned)cdiv(waves, 256 / WAVE)), dim3(256), 0, st, t);
+        CRF_LAUNCH_CHECK();
+    }
     return CRF_OK;
 }
 
@@ -1451,7 +1528,7 @@ extern "C" size_t crfconv_pointconv_bwd_a1_workspace(int64_t n_edges, int d) {
 extern "C" int crfconv_pointconv_bwd_a1(const float* gw, const float* h1, const float* rel, int64_t n_edges, int d,
                                         float slope, double* dA1b1, void* workspace, size_t workspace_bytes,
                                         crf_stream_t stream) {
-    CRF_REQUIRE(gw && h1 && rel && dA1b1 && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(gw && h1 && rel && workspace, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(d == 8 || d == 16 || d == 32 || d == 64 || d == 128, CRF_ERR_UNSUPPORTED, "d=%d not in {8, 16, 32, 64, 128}", d);
     CRF_REQUIRE(n_edges > 0 && n_edges < ((int64_t)1 << 31), CRF_ERR_ARG, "n_edges=%lld out of range", (long long)n_edges);
     CRF_REQUIRE(workspace_bytes >= crfconv_pointconv_bwd_a1_workspace(n_edges, d), CRF_ERR_WORKSPACE, "workspace too small");
@@ -1466,10 +1543,17 @@ extern "C" int crfconv_pointconv_bwd_a1(const float* gw, const float* h1, const 
         default: hipLaunchKernelGGL(a1_reduce_kernel<128>, dim3((unsigned)nblk), dim3(256), 0, st, gw, h1, rel, n_edges, slope, partial_d); break;
     }
     CRF_LAUNCH_CHECK();
+    if (dA1b1 == nullptr) return CRF_OK;                 // slabs only: double [nblk][4d] at the 256-byte-aligned start of `workspace`,
+                                                         // nblk = crfconv_pointconv_bwd_a1_nblk; summed later by crfconv_reduce_jobs_f64
     hipLaunchKernelGGL(reduce_partials_d_kernel, dim3((unsigned)cdiv(4 * d, 256 / WAVE)), dim3(256), 0, st, partial_d,
                        nblk, 4 * d, dA1b1);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
+}
+
+extern "C" int64_t crfconv_pointconv_bwd_a1_nblk(int64_t n_edges, int d) {
+    if (n_edges <= 0 || d < 8) return 0;
+    return std::min<int64_t>(1024, cdiv(n_edges, 256 / (d / 4) * 8));
 }
 
 // ====================================================================== BatchNorm folding (tiny, one block)

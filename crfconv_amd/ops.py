@@ -475,7 +475,7 @@ def discrete_meanfield(p, u, w, C, table, steps):
 # like DDP's) finishes all of them and installs / accumulates ``.grad`` of the weight and bias parameters directly.
 # Opt-in because it bypasses autograd for those leaves: ``torch.autograd.grad(loss, weight)`` sees nothing, and
 # gradient hooks on the weights do not fire.  ``loss.backward()`` + ``param.grad`` behave as usual.
-_DEFER = {'on': False, 'jobs': [], 'partials': [], 'folds': [], 'mlpdw': [], 'armed': False, 'claimed': set()}
+_DEFER = {'on': False, 'jobs': [], 'partials': [], 'red64': [], 'folds': [], 'mlpdw': [], 'armed': False, 'claimed': set()}
 
 
 class deferred_weight_grads:
@@ -625,7 +625,18 @@ def _flush_mlp_dw():
         _install_grad(prm, gr, direct)
 
 
+def _defer_reduce64(partial_ptr, is_float, nblk, nslots, out, keep):
+    """Queues out[slot] = sum_b partial[b][slot] (float64; `keep`: the tensors the pointers refer to) for the one
+    crfconv_reduce_jobs_f64 launch in front of the batched fold at the end of the backward pass."""
+    _DEFER['red64'].append((_lib.Reduce64Job(partial_ptr, 1 if is_float else 0, int(nblk), int(nslots), out.data_ptr()), (out,) + tuple(keep)))
+    _arm_flush()
+
+
 def _flush_fold1_bwd():
+    red, _DEFER['red64'] = _DEFER.get('red64', []), []
+    if red:
+        arr = (_lib.Reduce64Job * len(red))(*[j for j, _ in red])
+        _lib.call('crfconv_reduce_jobs_f64', ctypes.cast(arr, ctypes.c_void_p), len(red), stream_ptr())
     folds, _DEFER['folds'] = _DEFER['folds'], []
     if not folds:
         return
@@ -1928,12 +1939,20 @@ class _PointConv(torch.autograd.Function):
                       d, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), ptr(coef[4]), st)
         # pass 2: parameter gradients
         dW2_64 = None
+        # the fold of this layer's parameter gradients waits for the end of the backward pass (below): then so can the SUMS of their
+        # partial slabs -- one crfconv_reduce_jobs_f64 launch for all PointConv layers instead of two / one per layer
+        late = (not _NO_LATE_SUMS_ENV) and all(_defer_ok((q, None)) for q in (pW1, pg1, pbe1, pW2))
         if d <= _PC_PARAMS_INKERNEL_MAX_D:
             dW2 = torch.empty(d * d, dtype=torch.float64, device=dev)
             dA1b1 = torch.empty((d, 4), dtype=torch.float64, device=dev)
             _lib.call('crfconv_pointconv_bwd_params', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32),
                       K, m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]),
-                      ptr(dW2), ptr(dA1b1), ptr(ws), nbytes, st)
+                      None if late else ptr(dW2), None if late else ptr(dA1b1), ptr(ws), nbytes, st)
+            if late:
+                sw, sa, nb = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
+                _lib.call('crfconv_pointconv_bwd_params_slabs', ptr(ws), m_tgt, d, ctypes.byref(sw), ctypes.byref(sa), ctypes.byref(nb))
+                _defer_reduce64(sw.value, True, nb.value, d * d, dW2, (ws,))
+                _defer_reduce64(sa.value, False, nb.value, 4 * d, dA1b1, (ws,))
             dW2_64, dW2 = dW2, torch.empty((d, d), dtype=torch.float32, device=dev)      # cast by the fold kernel below
         else:
             # wide, edge-poor levels: per-edge h1 / g_h2 / rel to HBM, contractions as dense GEMMs
@@ -1956,8 +1975,11 @@ class _PointConv(torch.autograd.Function):
             dA1b1 = torch.empty((d, 4), dtype=torch.float64, device=dev)
             abytes = _lib.load().crfconv_pointconv_bwd_a1_workspace(E, d)
             aws = torch.empty(abytes, dtype=torch.uint8, device=dev)
-            _lib.call('crfconv_pointconv_bwd_a1', ptr(gw), ptr(h1), ptr(rel), E, d, slope, ptr(dA1b1), ptr(aws), abytes,
-                      st)
+            _lib.call('crfconv_pointconv_bwd_a1', ptr(gw), ptr(h1), ptr(rel), E, d, slope, None if late else ptr(dA1b1), ptr(aws),
+                      abytes, st)
+            if late:
+                slab = (aws.data_ptr() + 255) & ~255
+                _defer_reduce64(slab, False, _lib.load().crfconv_pointconv_bwd_a1_nblk(E, d), 4 * d, dA1b1, (aws,))
         defer_fold = all(_defer_ok((q, None)) for q in (pW1, pg1, pbe1)) and (dW2_64 is None or _defer_ok((pW2, None)))
         if defer_fold:
             # nothing in this pass reads dW1 / dgamma1 / dbeta1 (or the float32 dW2 of the narrow layers): ONE batched fold launch
@@ -1988,6 +2010,7 @@ class _PointConv(torch.autograd.Function):
 
 
 _PC_D = (4, 8, 16, 32, 64, 128)
+_NO_LATE_SUMS_ENV = __import__('os').environ.get('CRFCONV_NO_LATE_SUMS') is not None      # A/B: every slab sum inside its own call
 _PC_PARAMS_INKERNEL_MAX_D = int(__import__('os').environ.get('CRFCONV_PC_INKERNEL_D', 16))   # wider: per-edge dump + MFMA reductions
 
 

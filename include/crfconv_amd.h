@@ -339,6 +339,16 @@ size_t crfconv_pointconv_bwd_a1_workspace(int64_t n_edges, int d);
 int crfconv_pointconv_bwd_a1(const float* gw, const float* h1, const float* rel, int64_t n_edges, int d,
                              float slope, double* dA1b1, void* workspace, size_t workspace_bytes,
                              crf_stream_t stream);
+/* Deferred sums.  crfconv_pointconv_bwd_params with dW2 = dA1b1 = NULL and crfconv_pointconv_bwd_a1 with dA1b1 = NULL leave their
+ * partial slabs only (crfconv_pointconv_bwd_params_slabs / the aligned start of the a1 workspace, crfconv_pointconv_bwd_a1_nblk slabs);
+ * crfconv_reduce_jobs_f64 then finishes ANY number of such sums in one launch per 32 jobs -- out[slot] = sum_b partial[b][slot] in
+ * float64, partial float (is_float != 0) or double, same lane order and shuffle tree as the in-call reductions (identical results).
+ * The parameter gradients of all PointConv layers of a backward pass are summed this way, once, in front of the batched fold. */
+typedef struct { const void* partial; int is_float; int64_t nblk; int nslots; double* out; } crf_reduce64_job;
+int crfconv_pointconv_bwd_params_slabs(void* workspace, int64_t m_tgt, int d, const float** slab_w2, const double** slab_a1,
+                                       int64_t* nblk_out);
+int64_t crfconv_pointconv_bwd_a1_nblk(int64_t n_edges, int d);
+int crfconv_reduce_jobs_f64(const crf_reduce64_job* jobs, int njobs, crf_stream_t stream);
 /* dx[j,c] = sum_{e=(i,k) in rev(j)} w_e[c] * gout[i,c]   (weight MLP recomputed per incoming edge). */
 int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const float* pos_tgt,
                                 const int32_t* rev_ptr, const int32_t* rev_eid, int K,
