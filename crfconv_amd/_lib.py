@@ -98,6 +98,9 @@ SIGNATURES = {
     'crfconv_pointconv_bwd_params_slabs': (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
     'crfconv_pointconv_bwd_a1_nblk': (_i64, [_i64, _i]),
     'crfconv_reduce_jobs_f64': (_i, [_vp, _i, _vp]),
+    'crfconv_pointconv_bwd_dump_jobs': (_i, [_vp, _i, _vp]),
+    'crfconv_pointconv_bwd_a1_jobs': (_i, [_vp, _i, _vp]),
+    'crfconv_gemm_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_linear_wgrad_nblk': (_i, [_i64, _i, _i]),
     'crfconv_linear_wgrad_partial_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_linear_wgrad_partial': (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp, _vp]),
@@ -172,6 +175,26 @@ class MlpDwJob(ctypes.Structure):
     """crf_mlp_dw_job of include/crfconv_amd.h."""
     _fields_ = [('workspace', ctypes.c_void_p), ('coef', ctypes.c_void_p), ('dW', ctypes.c_void_p), ('M', ctypes.c_int64),
                 ('Ci', ctypes.c_int32), ('Co', ctypes.c_int32)]
+
+
+class PcDumpJob(ctypes.Structure):
+    """crf_pc_dump_job of include/crfconv_amd.h."""
+    _fields_ = [('x', ctypes.c_void_p), ('gout', ctypes.c_void_p), ('pos_src', ctypes.c_void_p), ('pos_tgt', ctypes.c_void_p),
+                ('idx32', ctypes.c_void_p), ('K', ctypes.c_int32), ('m_tgt', ctypes.c_int64), ('d', ctypes.c_int32), ('A1', ctypes.c_void_p),
+                ('b1', ctypes.c_void_p), ('W2', ctypes.c_void_p), ('slope', ctypes.c_float), ('ca', ctypes.c_void_p), ('cb', ctypes.c_void_p),
+                ('cc', ctypes.c_void_p), ('h1', ctypes.c_void_p), ('gh2', ctypes.c_void_p), ('rel', ctypes.c_void_p)]
+
+
+class PcA1Job(ctypes.Structure):
+    """crf_pc_a1_job of include/crfconv_amd.h."""
+    _fields_ = [('gw', ctypes.c_void_p), ('h1', ctypes.c_void_p), ('rel', ctypes.c_void_p), ('n_edges', ctypes.c_int64), ('d', ctypes.c_int32),
+                ('slope', ctypes.c_float), ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
+
+
+class GemmJob(ctypes.Structure):
+    """crf_gemm_job of include/crfconv_amd.h."""
+    _fields_ = [('A', ctypes.c_void_p), ('B', ctypes.c_void_p), ('C', ctypes.c_void_p), ('M', ctypes.c_int64), ('N', ctypes.c_int32),
+                ('K', ctypes.c_int32)]
 
 
 class Reduce64Job(ctypes.Structure):

@@ -63,11 +63,11 @@ struct GemmPro {
 // STATS form (crfconv_gemm_stats): the epilogue also leaves BatchNorm statistic records of the tile it holds -- one
 // {shift, rows, sum (v - shift), sum (v - shift)^2} tuple per 16-row group and output channel, the layout
 // crfconv_bn_coef_from_records combines (Chan, float64) -- so the statistics pass over Y never runs.
-template <int WM, int WN, int WR, int WC, bool BNK, bool VEC, bool PRO = false, bool STATS = false>
-__global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                        const float* __restrict__ bias, const float* __restrict__ addend,
-                                                        int M, int N, int K, float* __restrict__ C, const GemmPro pro = GemmPro(),
-                                                        float* __restrict__ stat_rec = nullptr) {
+template <int WM, int WN, int WR, int WC, bool BNK, bool VEC, bool PRO, bool STATS>
+__device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const float* __restrict__ B,
+                                          const float* __restrict__ bias, const float* __restrict__ addend,
+                                          int M, int N, int K, float* __restrict__ C, const GemmPro& pro,
+                                          float* __restrict__ stat_rec, const unsigned bx, const unsigned by) {
     static_assert(WR * WC * WAVE == GM_BLOCK, "four wavefronts");
     static_assert(!PRO || (VEC && !BNK), "the prologue form is the dX product of aligned widths");
     __shared__ float sPro[PRO ? 6 * GM_PRO_MAXK : 1];      // a | b | mean | rstd | sum g1 / M | sum g1 yh / M
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rr = lane & 15, g = lane >> 4;
     const int wr = wave / WC, wc = wave - wr * WC;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     struct Regs { float4 a[PA], b[PB], y[PRO ? PA : 1]; int kc; };
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
                     av.y = ca.y * (g1.y - c2.y - (yv.y - mu.y) * rs.y * c3.y);
                     av.z = ca.z * (g1.z - c2.z - (yv.z - mu.z) * rs.z * c3.z);
                     av.w = ca.w * (g1.w - c2.w - (yv.w - mu.w) * rs.w * c3.w);
-                    if (blockIdx.y == 0) *reinterpret_cast<float4*>(pro.gY + (int64_t)row * K + k) = av;
+                    if (by == 0) *reinterpret_cast<float4*>(pro.gY + (int64_t)row * K + k) = av;
                 }
             }
             *reinterpret_cast<float4*>(sA[buf] + (q / (GM_BK / 4)) * LDA + 4 * (q % (GM_BK / 4))) = av;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
             sPro[3 * GM_PRO_MAXK + k] = pro.coef[3 * K + k];
             sPro[4 * GM_PRO_MAXK + k] = pro.training ? (float)(s1 * (double)pro.inv_m) : 0.f;
             sPro[5 * GM_PRO_MAXK + k] = pro.training ? (float)(s2 * (double)pro.inv_m) : 0.f;
-            if (blockIdx.x == 0 && blockIdx.y == 0) {
+            if (bx == 0 && by == 0) {
                 pro.dbeta[k] = (float)s1;
                 pro.dgamma[k] = (float)s2;
             }
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
         const int row0 = m0 + 16 * wr * WM;                 // first row of this wavefront's group
         const int nrows = row0 < M ? (M - row0 < 16 ? M - row0 : 16) : 0;
         const bool rvalid = rr < nrows;
-        const int rec = (int)blockIdx.x * WR + wr;          // record = 16-row group
+        const int rec = (int)bx * WR + wr;          // record = 16-row group
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int n = n0 + 16 * (wc * WN + j) + 4 * g;
@@ -294,6 +294,32 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
             }
         }
     }
+}
+
+template <int WM, int WN, int WR, int WC, bool BNK, bool VEC, bool PRO = false, bool STATS = false>
+__global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                        const float* __restrict__ bias, const float* __restrict__ addend,
+                                                        int M, int N, int K, float* __restrict__ C, const GemmPro pro = GemmPro(),
+                                                        float* __restrict__ stat_rec = nullptr) {
+    gemm_tile<WM, WN, WR, WC, BNK, VEC, PRO, STATS>(A, B, bias, addend, M, N, K, C, pro, stat_rec, blockIdx.x, blockIdx.y);
+}
+
+// SEVERAL products C_j = A_j B_j (B [K, N], aligned widths, 32 x 32 tiles) in one launch: the tiles of the jobs are laid end to
+// end, a workgroup finds its job by a scan over the (<= 8) prefix entries -- crfconv_gemm_jobs, the g_h1 = g_h2 W2 products of all
+// wide PointConv layers of a backward pass.
+constexpr int GJ_MAX = 8;
+struct GemmJobs {
+    const float* A[GJ_MAX]; const float* B[GJ_MAX]; float* C[GJ_MAX];
+    int M[GJ_MAX], N[GJ_MAX], K[GJ_MAX], tiles_x[GJ_MAX];
+    int tile_base[GJ_MAX + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(GM_BLOCK) void gemm_jobs_kernel(const GemmJobs t) {
+    int j = 0;
+    while (j + 1 < t.njobs && t.tile_base[j + 1] <= (int)blockIdx.x) ++j;
+    const unsigned local = blockIdx.x - (unsigned)t.tile_base[j];
+    gemm_tile<1, 1, 2, 2, false, true, false, false>(t.A[j], t.B[j], nullptr, nullptr, t.M[j], t.N[j], t.K[j], t.C[j], GemmPro(), nullptr,
+                                                     local % (unsigned)t.tiles_x[j], local / (unsigned)t.tiles_x[j]);
 }
 
 }  // namespace crf
@@ -417,6 +443,38 @@ extern "C" int crfconv_gemm_stats(const float* A, const float* B, int64_t M, int
     hipLaunchKernelGGL((crf::gemm_kernel<1, 1, 2, 2, true, true, false, true>), grid, blk, 0, crf::as_stream(stream), A, B,
                        (const float*)nullptr, (const float*)nullptr, (int)M, N, K, C, crf::GemmPro(), stat_rec);
     CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+// C_j [M_j, N_j] = A_j [M_j, K_j] B_j [K_j, N_j] for up to 8 products per launch (jobs: host array); N, K multiples of 4.  Same tiles
+// and summation order as crfconv_gemm on each job.
+extern "C" int crfconv_gemm_jobs(const crf_gemm_job* jobs, int njobs, void* stream) {
+    CRF_REQUIRE(jobs || njobs == 0, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(njobs >= 0, CRF_ERR_ARG, "njobs=%d < 0", njobs);
+    hipStream_t st = crf::as_stream(stream);
+    for (int j0 = 0; j0 < njobs; j0 += crf::GJ_MAX) {
+        crf::GemmJobs t;
+        const int n = njobs - j0 < crf::GJ_MAX ? njobs - j0 : crf::GJ_MAX;
+        int64_t tiles = 0;
+        for (int j = 0; j <= crf::GJ_MAX; ++j) {
+            t.tile_base[j] = (int)tiles;
+            if (j < n) {
+                const crf_gemm_job& jb = jobs[j0 + j];
+                CRF_REQUIRE(jb.A && jb.B && jb.C, CRF_ERR_ARG, "job %d: null pointer", j0 + j);
+                CRF_REQUIRE(jb.M >= 1 && jb.M < ((int64_t)1 << 31) && jb.N >= 4 && jb.K >= 4 && jb.N % 4 == 0 && jb.K % 4 == 0, CRF_ERR_UNSUPPORTED,
+                            "job %d: %lld x %d x %d (N, K multiples of 4)", j0 + j, (long long)jb.M, jb.N, jb.K);
+                t.A[j] = jb.A; t.B[j] = jb.B; t.C[j] = jb.C; t.M[j] = (int)jb.M; t.N[j] = jb.N; t.K[j] = jb.K;
+                t.tiles_x[j] = (int)((jb.M + 31) / 32);
+                tiles += (int64_t)t.tiles_x[j] * ((jb.N + 31) / 32);
+                CRF_REQUIRE(tiles < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many tiles in one batch");
+            } else if (j < crf::GJ_MAX) {
+                t.A[j] = nullptr; t.B[j] = nullptr; t.C[j] = nullptr; t.M[j] = 0; t.N[j] = 4; t.K[j] = 4; t.tiles_x[j] = 1;
+            }
+        }
+        t.njobs = n;
+        hipLaunchKernelGGL(crf::gemm_jobs_kernel, dim3((unsigned)tiles), dim3(crf::GM_BLOCK), 0, st, t);
+        CRF_LAUNCH_CHECK();
+    }
     return CRF_OK;
 }
 

@@ -181,15 +181,19 @@ struct Row {
 };
 
 template <int D>
-__device__ __forceinline__ Row my_row(int64_t m, int& lane, int& wave, int& q) {
+__device__ __forceinline__ Row my_row_at(int64_t m, unsigned block, int& lane, int& wave, int& q) {
     lane = threadIdx.x & 63;
     wave = threadIdx.x >> 6;
     q = lane % PC<D>::L;
-    const int64_t row = (int64_t)xcd_block_id() * PC<D>::PPB + (wave / PC<D>::KS) * PC<D>::PPW + lane / PC<D>::L;
+    const int64_t row = (int64_t)block * PC<D>::PPB + (wave / PC<D>::KS) * PC<D>::PPW + lane / PC<D>::L;
     Row o;
     o.valid = row < m;
     o.r = o.valid ? row : m - 1;
     return o;
+}
+template <int D>
+__device__ __forceinline__ Row my_row(int64_t m, int& lane, int& wave, int& q) {
+    return my_row_at<D>(m, xcd_block_id(), lane, wave, q);
 }
 
 // Sum `v` over all lanes of the wave that share the same quad index q (xor over the point bits).
@@ -907,7 +911,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
 // d >= 64 levels have few edges (<= 41k at config 2): write h1, g_h2 and rel per edge and let the
 // host contract them with dense GEMMs (dW2 = g_h2^T h1 etc.) instead of reducing d*d sums in-kernel.
 template <int D>
-__global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restrict__ x,
+__device__ __forceinline__ void bwd_dump_body(const float* __restrict__ x,
                                                           const float* __restrict__ gout,
                                                           const float* __restrict__ pos_src,
                                                           const float* __restrict__ pos_tgt,
@@ -920,12 +924,12 @@ __global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restric
                                                           const float* __restrict__ cc,
                                                           float* __restrict__ h1_out,
                                                           float* __restrict__ gh2_out,
-                                                          float* __restrict__ rel_out) {
+                                                          float* __restrict__ rel_out, unsigned block) {
     constexpr int EB = PC<D>::EB;
     __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     int lane, wave, q;
-    const Row rw = my_row<D>(m_tgt, lane, wave, q);
+    const Row rw = my_row_at<D>(m_tgt, block, lane, wave, q);
     EdgeMLP<D> mlp;
     mlp.init(A1, b1, W2, s_w2t, lane, q, slope);
     __syncthreads();
@@ -969,15 +973,49 @@ __global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restric
     }
 }
 
+template <int D>
+__global__ __launch_bounds__(PBLOCK) void bwd_dump_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+                                                          const float* __restrict__ pos_src, const float* __restrict__ pos_tgt,
+                                                          const int32_t* __restrict__ idx, int K, int64_t m_tgt,
+                                                          const float* __restrict__ A1, const float* __restrict__ b1,
+                                                          const float* __restrict__ W2, float slope, const float* __restrict__ ca,
+                                                          const float* __restrict__ cb, const float* __restrict__ cc,
+                                                          float* __restrict__ h1_out, float* __restrict__ gh2_out,
+                                                          float* __restrict__ rel_out) {
+    bwd_dump_body<D>(x, gout, pos_src, pos_tgt, idx, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, h1_out, gh2_out, rel_out, xcd_block_id());
+}
+
+// The dump pass of SEVERAL layers of the same width in one launch (the two ResNet blocks of a coarse level: a few workgroups
+// each, nothing on the backward chain waits for them -- crfconv_pointconv_wide_params_jobs).
+constexpr int PJ_MAX = 8;
+struct DumpJobs {
+    const float* x[PJ_MAX]; const float* gout[PJ_MAX]; const float* pos_src[PJ_MAX]; const float* pos_tgt[PJ_MAX];
+    const int32_t* idx[PJ_MAX];
+    const float* A1[PJ_MAX]; const float* b1[PJ_MAX]; const float* W2[PJ_MAX]; const float* ca[PJ_MAX]; const float* cb[PJ_MAX];
+    const float* cc[PJ_MAX];
+    float* h1[PJ_MAX]; float* gh2[PJ_MAX]; float* rel[PJ_MAX];
+    int K[PJ_MAX], m_tgt[PJ_MAX];
+    float slope[PJ_MAX];
+    int blk_base[PJ_MAX + 1];
+    int njobs;
+};
+template <int D>
+__global__ __launch_bounds__(PBLOCK) void bwd_dump_jobs_kernel(const DumpJobs t) {
+    int j = 0;
+    while (j + 1 < t.njobs && t.blk_base[j + 1] <= (int)blockIdx.x) ++j;
+    bwd_dump_body<D>(t.x[j], t.gout[j], t.pos_src[j], t.pos_tgt[j], t.idx[j], t.K[j], t.m_tgt[j], t.A1[j], t.b1[j], t.W2[j], t.slope[j],
+                     t.ca[j], t.cb[j], t.cc[j], t.h1[j], t.gh2[j], t.rel[j], blockIdx.x - (unsigned)t.blk_base[j]);
+}
+
 // ------------------------------------------------------------------ backward pass 2b for wide layers
 // dA1 | db1 of the dumped path: gp = (g_h2 W2) * lrelu'(h1) per edge, then the four float64 column sums
 // sum_e gp[e,c] * {rel_x, rel_y, rel_z, 1}.  gw = g_h2 W2 arrives from a dense GEMM; this is one streaming
 // pass over gw / h1 / rel (the float64 elementwise + reduction launches it replaces cost 0.6 ms a step).
 template <int D>
-__global__ __launch_bounds__(256) void a1_reduce_kernel(const float* __restrict__ gw,
+__device__ __forceinline__ void a1_reduce_body(const float* __restrict__ gw,
                                                         const float* __restrict__ h1,
                                                         const float* __restrict__ rel, int64_t E, float slope,
-                                                        double* __restrict__ partial_d) {
+                                                        double* __restrict__ partial_d, unsigned block, unsigned nblock) {
     constexpr int L = D / 4, RPB = 256 / L;
     __shared__ double s_acc[256 * 16];
     const int q = threadIdx.x % L, rl = threadIdx.x / L;
@@ -986,7 +1024,7 @@ __global__ __launch_bounds__(256) void a1_reduce_kernel(const float* __restrict_
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[c][t] = 0.0;
-    for (int64_t r = (int64_t)blockIdx.x * RPB + rl; r < E; r += (int64_t)gridDim.x * RPB) {
+    for (int64_t r = (int64_t)block * RPB + rl; r < E; r += (int64_t)nblock * RPB) {
         const float4 a = ld4(gw + r * D + 4 * q), h = ld4(h1 + r * D + 4 * q);
         const double rx = rel[3 * r], ry = rel[3 * r + 1], rz = rel[3 * r + 2];
         const float gp[4] = {a.x * (h.x > 0.f ? 1.f : slope), a.y * (h.y > 0.f ? 1.f : slope),
@@ -1005,8 +1043,29 @@ __global__ __launch_bounds__(256) void a1_reduce_kernel(const float* __restrict_
     for (int t = threadIdx.x; t < 4 * D; t += 256) {
         double a = 0.0;
         for (int i = 0; i < RPB; ++i) a += s_acc[i * (4 * D) + t];
-        partial_d[(int64_t)blockIdx.x * 4 * D + t] = a;        // [channel][x, y, z, bias]
+        partial_d[(int64_t)block * 4 * D + t] = a;        // [channel][x, y, z, bias]
     }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void a1_reduce_kernel(const float* __restrict__ gw, const float* __restrict__ h1,
+                                                        const float* __restrict__ rel, int64_t E, float slope,
+                                                        double* __restrict__ partial_d) {
+    a1_reduce_body<D>(gw, h1, rel, E, slope, partial_d, blockIdx.x, gridDim.x);
+}
+struct A1Jobs {
+    const float* gw[PJ_MAX]; const float* h1[PJ_MAX]; const float* rel[PJ_MAX];
+    double* partial_d[PJ_MAX];
+    int E[PJ_MAX], nblk[PJ_MAX];
+    float slope[PJ_MAX];
+    int blk_base[PJ_MAX + 1];
+    int njobs;
+};
+template <int D>
+__global__ __launch_bounds__(256) void a1_reduce_jobs_kernel(const A1Jobs t) {
+    int j = 0;
+    while (j + 1 < t.njobs && t.blk_base[j + 1] <= (int)blockIdx.x) ++j;
+    a1_reduce_body<D>(t.gw[j], t.h1[j], t.rel[j], t.E[j], t.slope[j], t.partial_d[j], blockIdx.x - (unsigned)t.blk_base[j], (unsigned)t.nblk[j]);
 }
 
 // ------------------------------------------------------------------ backward: input features
@@ -1516,6 +1575,100 @@ extern "C" int crfconv_pointconv_bwd_dump(const float* x, const float* gout, con
                            pos_src, pos_tgt, idx32, K, m_tgt, A1, b1, W2, slope, ca, cb, cc, h1, gh2, rel);
     });
     CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+// crfconv_pointconv_bwd_dump for several layers: one launch per width present among the jobs (the two ResNet blocks of a level
+// share one), workgroups of the jobs laid end to end.  Identical h1 / gh2 / rel.  jobs: host array.
+extern "C" int crfconv_pointconv_bwd_dump_jobs(const crf_pc_dump_job* jobs, int njobs, crf_stream_t stream) {
+    CRF_REQUIRE(jobs || njobs == 0, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(njobs >= 0, CRF_ERR_ARG, "njobs=%d < 0", njobs);
+    hipStream_t st = as_stream(stream);
+    for (int j = 0; j < njobs; ++j) {
+        const crf_pc_dump_job& jb = jobs[j];
+        if (int rc = check_pc(jb.m_tgt, jb.K, jb.d)) return rc;
+        CRF_REQUIRE(jb.x && jb.gout && jb.pos_src && jb.pos_tgt && jb.idx32 && jb.A1 && jb.b1 && jb.W2 && jb.ca && jb.cb && jb.cc && jb.h1 &&
+                        jb.gh2 && jb.rel, CRF_ERR_ARG, "job %d: null pointer", j);
+        CRF_REQUIRE(jb.m_tgt * jb.K < ((int64_t)1 << 31), CRF_ERR_ARG, "job %d: too many edges", j);
+    }
+    static const int widths[6] = {4, 8, 16, 32, 64, 128};
+    for (int w = 0; w < 6; ++w) {
+        const int d = widths[w];
+        int j = 0;
+        while (j < njobs) {
+            DumpJobs t;
+            int n = 0;
+            int64_t blocks = 0;
+            for (; j < njobs && n < PJ_MAX; ++j) {
+                const crf_pc_dump_job& jb = jobs[j];
+                if (jb.d != d) continue;
+                t.x[n] = jb.x; t.gout[n] = jb.gout; t.pos_src[n] = jb.pos_src; t.pos_tgt[n] = jb.pos_tgt; t.idx[n] = jb.idx32;
+                t.A1[n] = jb.A1; t.b1[n] = jb.b1; t.W2[n] = jb.W2; t.ca[n] = jb.ca; t.cb[n] = jb.cb; t.cc[n] = jb.cc;
+                t.h1[n] = jb.h1; t.gh2[n] = jb.gh2; t.rel[n] = jb.rel; t.K[n] = jb.K; t.m_tgt[n] = (int)jb.m_tgt; t.slope[n] = jb.slope;
+                t.blk_base[n] = (int)blocks;
+                blocks += blocks_for(jb.m_tgt, d);
+                ++n;
+            }
+            if (n == 0) break;
+            for (int k = n; k <= PJ_MAX; ++k) t.blk_base[k] = (int)blocks;
+            for (int k = n; k < PJ_MAX; ++k) {
+                t.x[k] = t.gout[k] = t.pos_src[k] = t.pos_tgt[k] = t.A1[k] = t.b1[k] = t.W2[k] = t.ca[k] = t.cb[k] = t.cc[k] = nullptr;
+                t.idx[k] = nullptr; t.h1[k] = t.gh2[k] = t.rel[k] = nullptr; t.K[k] = 1; t.m_tgt[k] = 0; t.slope[k] = 1.f;
+            }
+            t.njobs = n;
+            DISPATCH_D(d, { hipLaunchKernelGGL(bwd_dump_jobs_kernel<DD>, dim3((unsigned)blocks), dim3(PBLOCK), 0, st, t); });
+            CRF_LAUNCH_CHECK();
+        }
+    }
+    return CRF_OK;
+}
+
+// crfconv_pointconv_bwd_a1 (slabs only: the sums are the caller's, crfconv_reduce_jobs_f64) for several layers, one launch per
+// width.  Each job's workspace as for the one-layer call; slabs at its 256-byte-aligned start.
+extern "C" int crfconv_pointconv_bwd_a1_jobs(const crf_pc_a1_job* jobs, int njobs, crf_stream_t stream) {
+    CRF_REQUIRE(jobs || njobs == 0, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(njobs >= 0, CRF_ERR_ARG, "njobs=%d < 0", njobs);
+    hipStream_t st = as_stream(stream);
+    for (int j = 0; j < njobs; ++j) {
+        const crf_pc_a1_job& jb = jobs[j];
+        CRF_REQUIRE(jb.gw && jb.h1 && jb.rel && jb.workspace, CRF_ERR_ARG, "job %d: null pointer", j);
+        CRF_REQUIRE(jb.d == 8 || jb.d == 16 || jb.d == 32 || jb.d == 64 || jb.d == 128, CRF_ERR_UNSUPPORTED, "job %d: d=%d", j, jb.d);
+        CRF_REQUIRE(jb.n_edges > 0 && jb.n_edges < ((int64_t)1 << 31), CRF_ERR_ARG, "job %d: n_edges out of range", j);
+        CRF_REQUIRE(jb.workspace_bytes >= crfconv_pointconv_bwd_a1_workspace(jb.n_edges, jb.d), CRF_ERR_WORKSPACE, "job %d: workspace too small", j);
+    }
+    static const int widths[5] = {8, 16, 32, 64, 128};
+    for (int w = 0; w < 5; ++w) {
+        const int d = widths[w];
+        int j = 0;
+        while (j < njobs) {
+            A1Jobs t;
+            int n = 0;
+            int64_t blocks = 0;
+            for (; j < njobs && n < PJ_MAX; ++j) {
+                const crf_pc_a1_job& jb = jobs[j];
+                if (jb.d != d) continue;
+                const int64_t nblk = crfconv_pointconv_bwd_a1_nblk(jb.n_edges, d);
+                t.gw[n] = jb.gw; t.h1[n] = jb.h1; t.rel[n] = jb.rel;
+                t.partial_d[n] = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(jb.workspace) + 255) & ~(uintptr_t)255);
+                t.E[n] = (int)jb.n_edges; t.nblk[n] = (int)nblk; t.slope[n] = jb.slope;
+                t.blk_base[n] = (int)blocks;
+                blocks += nblk;
+                ++n;
+            }
+            if (n == 0) break;
+            for (int k = n; k <= PJ_MAX; ++k) t.blk_base[k] = (int)blocks;
+            for (int k = n; k < PJ_MAX; ++k) { t.gw[k] = t.h1[k] = t.rel[k] = nullptr; t.partial_d[k] = nullptr; t.E[k] = 0; t.nblk[k] = 1; t.slope[k] = 1.f; }
+            t.njobs = n;
+            switch (d) {
+                case 8: hipLaunchKernelGGL(a1_reduce_jobs_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, t); break;
+                case 16: hipLaunchKernelGGL(a1_reduce_jobs_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, t); break;
+                case 32: hipLaunchKernelGGL(a1_reduce_jobs_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, st, t); break;
+                case 64: hipLaunchKernelGGL(a1_reduce_jobs_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, st, t); break;
+                default: hipLaunchKernelGGL(a1_reduce_jobs_kernel<128>, dim3((unsigned)blocks), dim3(256), 0, st, t); break;
+            }
+            CRF_LAUNCH_CHECK();
+        }
+    }
     return CRF_OK;
 }
 

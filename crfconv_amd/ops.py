@@ -475,7 +475,7 @@ def discrete_meanfield(p, u, w, C, table, steps):
 # like DDP's) finishes all of them and installs / accumulates ``.grad`` of the weight and bias parameters directly.
 # Opt-in because it bypasses autograd for those leaves: ``torch.autograd.grad(loss, weight)`` sees nothing, and
 # gradient hooks on the weights do not fire.  ``loss.backward()`` + ``param.grad`` behave as usual.
-_DEFER = {'on': False, 'jobs': [], 'partials': [], 'red64': [], 'folds': [], 'mlpdw': [], 'armed': False, 'claimed': set()}
+_DEFER = {'on': False, 'jobs': [], 'partials': [], 'red64': [], 'pc_wide': [], 'folds': [], 'mlpdw': [], 'armed': False, 'claimed': set()}
 
 
 class deferred_weight_grads:
@@ -647,7 +647,46 @@ def _flush_fold1_bwd():
             _install_grad(prm, gr, direct)
 
 
+def _flush_pc_wide():
+    """The parameter pass of all wide PointConv layers of this backward pass: dumps (one launch per width), the g_h2^T h1 partials
+    (queued with every other weight-gradient partial pass), g_h1 = g_h2 W2 for all layers in one launch, the dA1 | db1 slab passes
+    (one launch per width), their sums queued for the float64 reduce launch."""
+    wide, _DEFER['pc_wide'] = _DEFER.get('pc_wide', []), []
+    if not wide:
+        return
+    st = stream_ptr()
+    lib = _lib.load()
+    dumps, gemms, a1s, keep = [], [], [], []
+    for w in wide:
+        d, E, dev = w['d'], w['m_tgt'] * w['K'], w['x'].device
+        h1 = torch.empty((E, d), dtype=torch.float32, device=dev)
+        gh2 = torch.empty((E, d), dtype=torch.float32, device=dev)
+        rel = torch.empty((E, 3), dtype=torch.float32, device=dev)
+        gw = torch.empty((E, d), dtype=torch.float32, device=dev)
+        abytes = lib.crfconv_pointconv_bwd_a1_workspace(E, d)
+        aws = torch.empty(abytes, dtype=torch.uint8, device=dev)
+        c = w['coef']
+        dumps.append(_lib.PcDumpJob(w['x'].data_ptr(), w['g'].data_ptr(), w['pos_src'].data_ptr(), w['pos_tgt'].data_ptr(), w['idx'].data_ptr(),
+                                    w['K'], w['m_tgt'], d, w['A1'].data_ptr(), w['b1'].data_ptr(), w['W2'].data_ptr(), float(w['slope']),
+                                    c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), h1.data_ptr(), gh2.data_ptr(), rel.data_ptr()))
+        gemms.append(_lib.GemmJob(gh2.data_ptr(), w['W2'].data_ptr(), gw.data_ptr(), E, d, d))
+        a1s.append(_lib.PcA1Job(gw.data_ptr(), h1.data_ptr(), rel.data_ptr(), E, d, float(w['slope']), aws.data_ptr(), abytes))
+        keep.append((w, h1, gh2, rel, gw, aws))
+    arr = (_lib.PcDumpJob * len(dumps))(*dumps)
+    _lib.call('crfconv_pointconv_bwd_dump_jobs', ctypes.cast(arr, ctypes.c_void_p), len(dumps), st)
+    for w, h1, gh2, rel, gw, aws in keep:
+        _defer_weight_grad(gh2, h1, (w['pW2'], None), False)          # (late mode implies the parameter is deferrable)
+    arr = (_lib.GemmJob * len(gemms))(*gemms)
+    _lib.call('crfconv_gemm_jobs', ctypes.cast(arr, ctypes.c_void_p), len(gemms), st)
+    arr = (_lib.PcA1Job * len(a1s))(*a1s)
+    _lib.call('crfconv_pointconv_bwd_a1_jobs', ctypes.cast(arr, ctypes.c_void_p), len(a1s), st)
+    for w, h1, gh2, rel, gw, aws in keep:
+        d, E = w['d'], w['m_tgt'] * w['K']
+        _defer_reduce64((aws.data_ptr() + 255) & ~255, False, lib.crfconv_pointconv_bwd_a1_nblk(E, d), 4 * d, w['dA1b1'], (aws, gw, h1, rel))
+
+
 def _flush_weight_grads():
+    _flush_pc_wide()                       # first: it queues weight-gradient partials and float64 sums of its own
     jobs, _DEFER['jobs'], _DEFER['armed'] = _DEFER['jobs'], [], False
     partials, _DEFER['partials'] = _DEFER.get('partials', []), []
     if partials:
@@ -1954,6 +1993,14 @@ class _PointConv(torch.autograd.Function):
                 _defer_reduce64(sw.value, True, nb.value, d * d, dW2, (ws,))
                 _defer_reduce64(sa.value, False, nb.value, 4 * d, dA1b1, (ws,))
             dW2_64, dW2 = dW2, torch.empty((d, d), dtype=torch.float32, device=dev)      # cast by the fold kernel below
+        elif late and not _NO_LATE_WIDE_ENV:
+            # wide, edge-poor levels: the WHOLE parameter pass (per-edge dump, g_h2^T h1 partials, g_h1 = g_h2 W2, dA1 | db1 slabs) waits
+            # for the end of the backward pass, where the passes of all wide layers go out as a handful of launches (_flush_pc_wide)
+            dA1b1 = torch.empty((d, 4), dtype=torch.float64, device=dev)
+            _DEFER['pc_wide'].append(dict(x=x, g=g, pos_src=pos_src, pos_tgt=pos_tgt, idx=table.idx32, K=K, m_tgt=m_tgt, d=d, A1=A1, b1=b1,
+                                          W2=W2, slope=slope, coef=coef, pW2=pW2, dA1b1=dA1b1))
+            _arm_flush()
+            dW2 = None
         else:
             # wide, edge-poor levels: per-edge h1 / g_h2 / rel to HBM, contractions as dense GEMMs
             E = m_tgt * K
@@ -2011,6 +2058,7 @@ class _PointConv(torch.autograd.Function):
 
 _PC_D = (4, 8, 16, 32, 64, 128)
 _NO_LATE_SUMS_ENV = __import__('os').environ.get('CRFCONV_NO_LATE_SUMS') is not None      # A/B: every slab sum inside its own call
+_NO_LATE_WIDE_ENV = __import__('os').environ.get('CRFCONV_NO_LATE_WIDE') is not None      # A/B: the wide layers' parameter pass inside their own backward
 _PC_PARAMS_INKERNEL_MAX_D = int(__import__('os').environ.get('CRFCONV_PC_INKERNEL_D', 16))   # wider: per-edge dump + MFMA reductions
 
 

@@ -339,6 +339,17 @@ size_t crfconv_pointconv_bwd_a1_workspace(int64_t n_edges, int d);
 int crfconv_pointconv_bwd_a1(const float* gw, const float* h1, const float* rel, int64_t n_edges, int d,
                              float slope, double* dA1b1, void* workspace, size_t workspace_bytes,
                              crf_stream_t stream);
+/* The wide layers' parameter pass for SEVERAL layers at once (nothing on the backward chain waits for it: queued, issued at the end):
+ * crfconv_pointconv_bwd_dump_jobs = crfconv_pointconv_bwd_dump of every job, one launch per width present (the two ResNet blocks of a
+ * level share a launch); crfconv_pointconv_bwd_a1_jobs = the slab pass of crfconv_pointconv_bwd_a1 of every job likewise (sums:
+ * crfconv_reduce_jobs_f64).  Identical outputs / slabs.  jobs are host arrays. */
+typedef struct { const float* x; const float* gout; const float* pos_src; const float* pos_tgt; const int32_t* idx32; int K; int64_t m_tgt;
+                 int d; const float* A1; const float* b1; const float* W2; float slope; const float* ca; const float* cb; const float* cc;
+                 float* h1; float* gh2; float* rel; } crf_pc_dump_job;
+typedef struct { const float* gw; const float* h1; const float* rel; int64_t n_edges; int d; float slope; void* workspace;
+                 size_t workspace_bytes; } crf_pc_a1_job;
+int crfconv_pointconv_bwd_dump_jobs(const crf_pc_dump_job* jobs, int njobs, crf_stream_t stream);
+int crfconv_pointconv_bwd_a1_jobs(const crf_pc_a1_job* jobs, int njobs, crf_stream_t stream);
 /* Deferred sums.  crfconv_pointconv_bwd_params with dW2 = dA1b1 = NULL and crfconv_pointconv_bwd_a1 with dA1b1 = NULL leave their
  * partial slabs only (crfconv_pointconv_bwd_params_slabs / the aligned start of the a1 workspace, crfconv_pointconv_bwd_a1_nblk slabs);
  * crfconv_reduce_jobs_f64 then finishes ANY number of such sums in one launch per 32 jobs -- out[slot] = sum_b partial[b][slot] in
@@ -537,6 +548,10 @@ int crfconv_mlp_small_backward(const float* gA, const float* Y, const float* coe
  * (the Linear + BatchNorm blocks between the one-launch kernel's row limit and the row-streaming forms). */
 size_t crfconv_gemm_stat_records(int64_t M);
 int crfconv_gemm_stats(const float* A, const float* B, int64_t M, int N, int K, float* C, float* stat_rec, crf_stream_t stream);
+/* Up to 8 independent products C_j = A_j B_j (B_j [K_j, N_j]; N, K multiples of 4) per launch -- the g_h1 = g_h2 W2 products of all wide
+ * PointConv layers of a backward pass; same tiles and summation order as crfconv_gemm on each.  jobs is a host array. */
+typedef struct { const float* A; const float* B; float* C; int64_t M; int N; int K; } crf_gemm_job;
+int crfconv_gemm_jobs(const crf_gemm_job* jobs, int njobs, crf_stream_t stream);
 int crfconv_gemm_supported(int64_t M, int N, int K);
 int crfconv_gemm(const float* A, const float* B, const float* bias, const float* addend, int64_t M, int N, int K,
                  int b_is_nk, float* C, crf_stream_t stream);
