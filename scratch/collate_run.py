@@ -18,10 +18,10 @@ y = torch.from_numpy(np.stack([c[2] for c in raw])).to(dev)
 for _ in range(3):
     cg.run(pos, x, y)
 torch.cuda.synchronize()
-mark = torch.zeros(4, dtype=torch.int64, device=dev)
-_lib.call('crfconv_add_i64', ptr(mark), 4, 1, stream_ptr())
+ma, mb, mo = torch.zeros(1, 4, device=dev), torch.zeros(1, 4, device=dev), torch.zeros(1, 8, device=dev)
+_lib.call('crfconv_cat2', ptr(ma), ptr(mb), 1, 4, 4, ptr(mo), stream_ptr())       # marker launch (cat2 is not part of the collate)
 for _ in range(10):
     cg.graph.replay()
-_lib.call('crfconv_add_i64', ptr(mark), 4, 1, stream_ptr())
+_lib.call('crfconv_cat2', ptr(ma), ptr(mb), 1, 4, 4, ptr(mo), stream_ptr())
 torch.cuda.synchronize()
 print('done')

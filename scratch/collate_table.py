@@ -1,7 +1,7 @@
 import sys, csv, glob, collections
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-marks = [i for i, r in enumerate(rows) if 'add_i64_kernel' in r['Kernel_Name']]
+marks = [i for i, r in enumerate(rows) if 'cat2_kernel' in r['Kernel_Name']]
 a, b = marks[-2], marks[-1]
 seg = rows[a + 1:b]
 agg = collections.OrderedDict()
