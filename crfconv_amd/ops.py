@@ -37,8 +37,9 @@ class _MeanField(torch.autograd.Function):
     table's columns k0..K-1  (models/continuous_crf_conv_big.py:49-54, 63-72)."""
 
     @staticmethod
-    def forward(ctx, z, y, Q, P, table, k0, steps):
+    def forward(ctx, z, y, Q, P, table, k0, steps, late=False):
         require_gpu(z, y, Q, P)
+        ctx.late = bool(late)      # (Q, P) come from crf_matrices_batched, whose backward can wait for the end of the pass: so can dP / dQ
         m, H = z.shape
         if m != table.m_tgt or y.shape[0] != m or table.m_src != m:
             raise _lib.CrfConvError('mean field: %d / %d rows for a table of %d targets over %d sources (the CRF graph '
@@ -76,7 +77,7 @@ class _MeanField(torch.autograd.Function):
         m, H = z.shape
         G = _f32c(gout)
         if T == 0:
-            return G, torch.zeros_like(y), torch.zeros_like(Q), torch.zeros_like(P), None, None, None
+            return G, torch.zeros_like(y), torch.zeros_like(Q), torch.zeros_like(P), None, None, None, None
         rev_ptr, rev_eid = table.reverse
         st = stream_ptr()
         lib = _lib.load()
@@ -108,9 +109,15 @@ class _MeanField(torch.autograd.Function):
                       ptr(P), T, ptr(Gs), ptr(dzq), ptr(mts), ptr(sumG), ptr(dz), ptr(w), ptr(dy_self), ptr(dy), ptr(dP),
                       ptr(dQ), ptr(ws), wsb, ptr(_ticket(dev)), st)
             if not inside:                                  # (Gs[0] = G was written by the edge launch)
-                skinny_tn(mts.view(T * m, H), Gs.view(T * m, H), dP)
-                skinny_tn(z, sumG, dQ)
-            return dz, dy, dQ, dP, None, None, None
+                if ctx.late and _DEFER['on'] and not _NO_LATE_CRF_ENV:
+                    # nothing on the chain reads dP / dQ, and their only consumer (the batched matrices backward) waits for the end
+                    # of the pass too: partial passes and sums join the batched launches there
+                    _defer_tn(mts.view(T * m, H), Gs.view(T * m, H), dP)
+                    _defer_tn(z, sumG, dQ)
+                else:
+                    skinny_tn(mts.view(T * m, H), Gs.view(T * m, H), dP)
+                    skinny_tn(z, sumG, dQ)
+            return dz, dy, dQ, dP, None, None, None, None
 
         # generic shapes (any K <= 64 / k0, padded variable-degree tables): one edge + one scatter launch per step
         gm = torch.empty_like(z)
@@ -140,7 +147,7 @@ class _MeanField(torch.autograd.Function):
         dy = torch.empty_like(y)
         _lib.call('crfconv_similarity_bwd_scatter', ptr(w), ptr(y), ptr(dy_self), ptr(rev_ptr), ptr(rev_eid),
                   table.K, k0, m, H, ptr(dy), st)
-        return dz, dy, dQ, dP, None, None, None
+        return dz, dy, dQ, dP, None, None, None, None
 
 
 class _SpdInverse(torch.autograd.Function):
@@ -203,6 +210,7 @@ class _CrfMatricesBatched(torch.autograd.Function):
         _lib.call('crfconv_crf_matrices_batched', _ptr_array(ccs), Hs, len(ccs), _ptr_array(Qs), _ptr_array(Ps), stream_ptr())
         ctx.save_for_backward(*ccs, *Qs)
         ctx.n = len(ccs)
+        ctx.cparams = cs                           # the parameter objects themselves (late gradients are installed, not returned)
         out = []
         for Q, P in zip(Qs, Ps):
             out += [Q, P]
@@ -214,8 +222,25 @@ class _CrfMatricesBatched(torch.autograd.Function):
         ccs, Qs = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
         gQ = [None if g is None else _f32c(g) for g in grads[0::2]]
         gP = [None if g is None else _f32c(g) for g in grads[1::2]]
-        dcs = [torch.empty_like(c) for c in ccs]
         Hs = (ctypes.c_int * n)(*[c.shape[0] for c in ccs])
+        late = (not _NO_LATE_CRF_ENV) and all(_defer_ok((c, None)) for c in ctx.cparams)
+        if late:
+            # the mean-field layers may have left dP / dQ to the batched sums at the end of the pass (_defer_tn): this launch goes
+            # behind them (dc is a parameter gradient: nothing reads it before the pass is over) and, like every deferred weight
+            # gradient, INSTALLS its results as .grad (autograd would copy a returned tensor that is still referenced here -- empty)
+            outs = [_param_out(c, tuple(c.shape), c.device) for c in ctx.cparams]
+            dcs = [o[0] for o in outs]
+            cparams = ctx.cparams
+
+            def launch():
+                _lib.call('crfconv_crf_matrices_backward_batched', _ptr_array(ccs), _ptr_array(Qs), _ptr_array(gQ), _ptr_array(gP), Hs, n,
+                          _ptr_array(dcs), stream_ptr())
+                for prm, (gr, direct) in zip(cparams, outs):
+                    _install_grad(prm, gr, direct)
+            _DEFER['late_calls'].append((launch, (ccs, Qs, gQ, gP, dcs)))
+            _arm_flush()
+            return (None,) * n
+        dcs = [torch.empty_like(c) for c in ccs]
         _lib.call('crfconv_crf_matrices_backward_batched', _ptr_array(ccs), _ptr_array(Qs), _ptr_array(gQ), _ptr_array(gP), Hs, n,
                   _ptr_array(dcs), stream_ptr())
         return tuple(dcs)
@@ -229,7 +254,11 @@ def crf_matrices_batched(cs):
     for lo in range(0, len(idx), 8):
         part = idx[lo:lo + 8]
         res = _CrfMatricesBatched.apply(*[cs[i] for i in part])
+        # (the same test as _defer_ok, minus the context: the node's backward installs late gradients only for leaf parameters)
+        leaf = all(isinstance(cs[i], torch.nn.Parameter) and cs[i].is_leaf and cs[i].requires_grad for i in part)
         for k, i in enumerate(part):
+            if leaf:
+                res[2 * k]._crf_late = True        # tells crf_meanfield that this Q's gradient may arrive at the end of the pass
             out[i] = (res[2 * k], res[2 * k + 1])
     return out
 
@@ -237,6 +266,7 @@ def crf_matrices_batched(cs):
 _CRF_H = (4, 8, 16, 32, 64)
 _CRF_WIDE_H = (128, 256)                    # one point per wavefront (crfconv_wide_*), H x H products as library GEMMs
 _OLD_BWD_ENV = __import__('os').environ.get('CRFCONV_OLD_BWD') is not None     # A/B: the step-by-step backward launches
+_NO_LATE_CRF_ENV = __import__('os').environ.get('CRFCONV_NO_LATE_CRF') is not None      # A/B: dP / dQ and the matrices backward inside the pass
 _FUSED_ENV = __import__('os').environ.get('CRFCONV_FUSED') is not None       # one-launch forward (crfconv_meanfield_forward_fused)
 _FUSED_WS = {}
 
@@ -375,7 +405,7 @@ def crf_meanfield(z, y, c, table, steps, k0=1, matrices=None):
     if Hp != H:                                 # zero channels stay zero through every step
         Q = torch.nn.functional.pad(Q, (0, Hp - H, 0, Hp - H))
         P = torch.nn.functional.pad(P, (0, Hp - H, 0, Hp - H))
-    out = _MeanField.apply(_pad_channels(z, Hp), _pad_channels(y, Hp), Q, P, table, k0, steps)
+    out = _MeanField.apply(_pad_channels(z, Hp), _pad_channels(y, Hp), Q, P, table, k0, steps, getattr(Q, '_crf_late', False))
     return out[:, :H] if Hp != H else out
 
 
@@ -475,7 +505,7 @@ def discrete_meanfield(p, u, w, C, table, steps):
 # like DDP's) finishes all of them and installs / accumulates ``.grad`` of the weight and bias parameters directly.
 # Opt-in because it bypasses autograd for those leaves: ``torch.autograd.grad(loss, weight)`` sees nothing, and
 # gradient hooks on the weights do not fire.  ``loss.backward()`` + ``param.grad`` behave as usual.
-_DEFER = {'on': False, 'jobs': [], 'partials': [], 'red64': [], 'pc_wide': [], 'folds': [], 'mlpdw': [], 'armed': False, 'claimed': set()}
+_DEFER = {'on': False, 'jobs': [], 'partials': [], 'red64': [], 'pc_wide': [], 'tn': [], 'late_calls': [], 'folds': [], 'mlpdw': [], 'armed': False, 'claimed': set()}
 
 
 class deferred_weight_grads:
@@ -495,6 +525,8 @@ class deferred_weight_grads:
         _DEFER['sink'] = self.sink
         if not self.prev:                 # outermost context: nothing of an earlier (failed) backward may linger
             _DEFER['jobs'], _DEFER['folds'], _DEFER['mlpdw'], _DEFER['armed'], _DEFER['claimed'] = [], [], [], False, set()
+            for k in ('partials', 'red64', 'pc_wide', 'tn', 'late_calls'):
+                _DEFER[k] = []
         return self
 
     def __exit__(self, exc_type, *exc):
@@ -504,6 +536,8 @@ class deferred_weight_grads:
             # the backward raised after arming the engine callback: drop its queued partials, or every later backward
             # would find 'armed' set, never queue the callback again and silently lose all Linear weight gradients
             _DEFER['jobs'], _DEFER['folds'], _DEFER['mlpdw'], _DEFER['armed'], _DEFER['claimed'] = [], [], [], False, set()
+            for k in ('partials', 'red64', 'pc_wide', 'tn', 'late_calls'):
+                _DEFER[k] = []
         return False
 
 
@@ -558,6 +592,20 @@ def _defer_weight_grad(g, x, params, has_bias):
                   ctypes.byref(nb), stream_ptr())
         nblk = nb.value
     _DEFER['jobs'].append((params[0], params[1] if want_b else None, ws, nblk, Co, Ci))
+    _arm_flush()
+
+
+def _defer_tn(A, B, out):
+    """out [Ca, Cb] = A^T B ([m, Ca] / [m, Cb] rows) finished at the end of the backward pass: the partial pass joins
+    crfconv_linear_wgrad_partial_jobs, the sum crfconv_reduce_jobs.  `out` is handed on now and filled then."""
+    m, ca = A.shape
+    cb = B.shape[1]
+    lib = _lib.load()
+    nbytes = lib.crfconv_linear_wgrad_workspace(m, ca, cb)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
+    A, B = A.contiguous(), B.contiguous()
+    _DEFER['partials'].append((_lib.WgradJob(A.data_ptr(), B.data_ptr(), m, ca, cb, 0, ws.data_ptr(), nbytes), (A, B)))
+    _DEFER['tn'].append((ws, lib.crfconv_linear_wgrad_nblk(m, ca, cb), ca * cb, out))
     _arm_flush()
 
 
@@ -694,10 +742,14 @@ def _flush_weight_grads():
         _lib.call('crfconv_linear_wgrad_partial_jobs', ctypes.cast(arr, ctypes.c_void_p), len(partials), stream_ptr())
     _flush_fold1_bwd()
     _flush_mlp_dw()
-    if not jobs:
+    tns, _DEFER['tn'] = _DEFER.get('tn', []), []
+    late_calls, _DEFER['late_calls'] = _DEFER.get('late_calls', []), []
+    if not jobs and not tns:
+        for fn, _ in late_calls:
+            fn()
         _DEFER['claimed'] = set()
         return
-    dev = jobs[0][2].device
+    dev = (jobs[0][2] if jobs else tns[0][0]).device
     sink = _DEFER.get('sink')
 
     def direct(prm):                       # the caller's own gradient storage for this parameter, if it can be used as is
@@ -712,8 +764,11 @@ def _flush_weight_grads():
     total = sum((Co * Ci if tw is None else 0) + (Co if (b is not None and tb is None) else 0)
                 for (_, b, _, _, Co, Ci), (tw, tb) in zip(jobs, targets))
     flat = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
-    table = (_lib.ReduceJob * (2 * len(jobs)))()
+    table = (_lib.ReduceJob * (2 * len(jobs) + len(tns)))()
     installs, n, o = [], 0, 0
+    for ws_t, nblk_t, nslots_t, out_t in tns:          # plain A^T B sums (the CRF layers' dP / dQ): no parameter to install
+        table[n] = _lib.ReduceJob(ws_t.data_ptr(), out_t.data_ptr(), nblk_t, nslots_t)
+        n += 1
     for (W, b, ws, nblk, Co, Ci), (tw, tb) in zip(jobs, targets):
         base = ws.data_ptr()
         dw = tw is not None
@@ -732,6 +787,8 @@ def _flush_weight_grads():
             installs.append((b, tb, db))
             n += 1
     _lib.call('crfconv_reduce_jobs', ctypes.cast(table, ctypes.c_void_p), n, stream_ptr())
+    for fn, _ in late_calls:                            # launches that read what the sums above produced
+        fn()
     for prm, gr, was_direct in installs:
         _install_grad(prm, gr, was_direct)
     _DEFER['claimed'] = set()
