@@ -1753,6 +1753,42 @@ def test_shared_weight_gradients_sum_inside_the_sink():
     assert_close(b.grad, torch.full((Co,), 3.0 * M, dtype=torch.float64), 1e-6, 'shared db')
 
 
+def test_crf_parameter_gradients_deferred_to_the_end_of_the_pass_equal_the_immediate_ones():
+    """Inside ops.deferred_weight_grads the CRF layers' dP / dQ (H >= 32: partial passes + sums in the batched launches) and the
+    batched matrices backward run at the END of the backward pass and install dc as .grad; values must equal the immediate form's
+    bit for bit (same kernels, same summation order), the activation gradients too."""
+    from crfconv_amd import ops
+    from crfconv_amd.graph import NeighborTable
+    res = {}
+    for mode in ('now', 'late'):
+        cs = [nn.Parameter((torch.randn(H, H, generator=torch.Generator().manual_seed(H)) * 0.1).to(DEV)) for H in (16, 32, 64)]
+        tabs, zs, ys = [], [], []
+        for H, n in zip((16, 32, 64), (4096, 2560, 640)):
+            gg = torch.Generator().manual_seed(n)
+            idx = torch.randint(0, n, (1, n, 16), generator=gg)
+            idx[0, :, 0] = torch.arange(n)
+            tabs.append(NeighborTable(idx.to(DEV), n))
+            zs.append(torch.randn(n, H, generator=gg).to(DEV).requires_grad_(True))
+            ys.append(torch.randn(n, H, generator=gg).to(DEV).requires_grad_(True))
+
+        def run():
+            mats = ops.crf_matrices_batched(cs)
+            loss = 0
+            for c, mat, tb, z, y in zip(cs, mats, tabs, zs, ys):
+                o = ops.crf_meanfield(z, y, c, tb, 3, k0=1, matrices=mat)
+                loss = loss + (o * torch.linspace(0, 1, o.numel(), device=DEV).reshape(o.shape)).sum()
+            return loss
+        if mode == 'late':
+            with ops.deferred_weight_grads():
+                run().backward()
+        else:
+            run().backward()
+        torch.cuda.synchronize()
+        res[mode] = [c.grad.clone() for c in cs] + [z.grad.clone() for z in zs] + [y.grad.clone() for y in ys]
+    for a, b in zip(res['now'], res['late']):
+        assert float(a.abs().max()) > 0 and torch.equal(a, b)
+
+
 def test_grid_barrier_failure_is_raised_and_disables_the_one_launch_path():
     """The sticky failure word of the grid-barrier workspace (set by a one-launch kernel whose barrier timed out) must
     reach the host: ops.check_gridsync raises, zeroes the workspace and switches the one-launch KERNEL off (the small-MLP nodes go
