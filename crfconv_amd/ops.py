@@ -738,6 +738,8 @@ def _flush_weight_grads():
     jobs, _DEFER['jobs'], _DEFER['armed'] = _DEFER['jobs'], [], False
     partials, _DEFER['partials'] = _DEFER.get('partials', []), []
     if partials:
+        # longest jobs first: their workgroups start first (the backward queues the fine levels -- the long jobs -- last)
+        partials.sort(key=lambda e: -(e[0].M * e[0].Co * e[0].Ci))
         arr = (_lib.WgradJob * len(partials))(*[j for j, _ in partials])
         _lib.call('crfconv_linear_wgrad_partial_jobs', ctypes.cast(arr, ctypes.c_void_p), len(partials), stream_ptr())
     _flush_fold1_bwd()
