@@ -1494,7 +1494,7 @@ def gridsync_ws(dev):
     return _stream_buf(_sync_ws, dev, lambda: torch.zeros(_lib.load().crfconv_gridsync_workspace() // 4, dtype=torch.int32, device=dev))
 
 
-_small_mlp_disabled = False       # set by check_gridsync after a barrier failure: the two-launch path from then on
+_small_mlp_disabled = __import__('os').environ.get('CRFCONV_NO_ONE_LAUNCH_MLP') is not None       # set by check_gridsync after a barrier failure (A/B: from the start): launch-separated forward from then on
 
 
 def _mlp_small_ok(m, ci, co):
