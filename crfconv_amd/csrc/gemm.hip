@@ -16,6 +16,11 @@
 // The B tile keeps the layout its storage order gives for free ([n][k] for B = W [N, K], [k][n] for B = W [K, N]): no
 // transposing scalar traffic.  The tile shape is picked per problem so that the grid covers the chip.  Summation order
 // over k is fixed by the shape alone: results are bitwise reproducible.
+//
+// Forms of the one tile routine (gemm_tile): plain (crfconv_gemm: bias / addend epilogue, any widths); STATS (crfconv_gemm_stats:
+// BatchNorm statistic records of C from the epilogue); PRO (crfconv_mlp_small_backward: the A operand is the BatchNorm-backward
+// gradient gY, formed from (gA, Y) and row-tile sums while it is loaded); jobs (crfconv_gemm_jobs: several independent products in
+// one launch).  bn_bwd_tile_sums_kernel, the PRO form's first launch, lives here too.
 #include "common.hpp"
 
 #include <cstdlib>
