@@ -123,6 +123,7 @@ SIGNATURES = {
     'crfconv_gemm_stats': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     'crfconv_gemm_supported': (_i, [_i64, _i, _i]),
     'crfconv_gemm': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    'crfconv_bn_apply_from_records': (_i, [_vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _f, _vp, _vp, _vp]),
     'crfconv_bn_coef_from_nrecords': (_i, [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
     'crfconv_bn_coef_from_records': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
     'crfconv_softmax_ce_workspace': (_sz, [_i64]),

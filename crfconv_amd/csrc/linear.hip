@@ -1256,14 +1256,15 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
 // channels per record-lane (256 contiguous bytes), 64 record-lanes per workgroup; record-lanes fold by shuffles
 // inside a wavefront and through LDS across the 16 wavefronts, always in the same order.
 constexpr int FR_BLOCK = 1024, FR_CH = 16, FR_RL = FR_BLOCK / FR_CH;
-__global__ __launch_bounds__(FR_BLOCK) void bn_finalize_records_kernel(const float* __restrict__ rec, int nrec, int64_t M,
-                                                                       int C, const float* __restrict__ gamma,
-                                                                       const float* __restrict__ beta, float eps,
-                                                                       float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                                       float momentum, float* __restrict__ coef) {
+// (device body: `slab` = which 16 channels; write != 0: this caller publishes coef / running statistics.  Threads < FR_CH of a valid
+// channel return with ab = {a, b}; every other thread returns false.)
+__device__ __forceinline__ bool bn_finalize_records_body(const float* __restrict__ rec, int nrec, int64_t M, int C,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                         float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
+                                                         float* __restrict__ coef, int slab, bool write, float (&ab)[2]) {
     __shared__ double s_red[FR_BLOCK / WAVE][2][FR_CH];
     const int cl = threadIdx.x & (FR_CH - 1), rl = threadIdx.x >> 4;
-    const int c = blockIdx.x * FR_CH + cl;
+    const int c = slab * FR_CH + cl;
     const bool cv = c < C;
     const int cc = cv ? c : C - 1;
     // every record is re-based on the shift of record 0 (a sample value, so |shift - mean| ~ sigma: no cancellation
@@ -1295,7 +1296,7 @@ __global__ __launch_bounds__(FR_BLOCK) void bn_finalize_records_kernel(const flo
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) < FR_CH) { s_red[wave][0][cl] = S1; s_red[wave][1][cl] = S2; }
     __syncthreads();
-    if (threadIdx.x >= FR_CH || !cv) return;
+    if (threadIdx.x >= FR_CH || !cv) return false;
     S1 = 0.0; S2 = 0.0;
     for (int w = 0; w < FR_BLOCK / WAVE; ++w) { S1 += s_red[w][0][cl]; S2 += s_red[w][1][cl]; }
     const double m1 = S1 / (double)M;
@@ -1305,14 +1306,77 @@ __global__ __launch_bounds__(FR_BLOCK) void bn_finalize_records_kernel(const flo
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
     const double a = (double)gamma[c] * rstd;
-    coef[c] = (float)a;
-    coef[C + c] = (float)((double)beta[c] - a * mean);
+    ab[0] = (float)a;
+    ab[1] = (float)((double)beta[c] - a * mean);
+    if (!write) return true;
+    coef[c] = ab[0];
+    coef[C + c] = ab[1];
     coef[2 * C + c] = (float)mean;
     coef[3 * C + c] = (float)rstd;
     if (run_mean != nullptr) {
         const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
         run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * mean);
         run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * unb);
+    }
+    return true;
+}
+__global__ __launch_bounds__(FR_BLOCK) void bn_finalize_records_kernel(const float* __restrict__ rec, int nrec, int64_t M,
+                                                                       int C, const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, float eps,
+                                                                       float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                       float momentum, float* __restrict__ coef) {
+    float ab[2];
+    bn_finalize_records_body(rec, nrec, M, C, gamma, beta, eps, run_mean, run_var, momentum, coef, blockIdx.x, true, ab);
+}
+
+// Coefficients AND apply in one launch (crfconv_bn_apply_from_records): a workgroup = one 16-channel slab x one row tile; it combines
+// the records of ITS slab exactly as bn_finalize_records_kernel does (same threads, same order: identical coefficients; the
+// workgroups of row tile 0 publish them and update the running statistics), then streams y = lrelu(a x + b) over its rows -- 64-byte
+// row pieces, four lanes per row.  The 512-record combine is redundant per row tile (131 KB of L2 reads per workgroup) and buys the
+// ~6 us coefficient launch that used to sit between every Linear and its BatchNorm apply pass.
+template <bool ADD>      // ADD: y = lrelu(a x + b + skip, slope) -- the ResNet join (crfconv_bn_apply_add's arithmetic)
+__global__ __launch_bounds__(FR_BLOCK) void bn_apply_records_kernel(const float* __restrict__ rec, int nrec, int64_t M, int C,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    float eps, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                    float momentum, float* __restrict__ coef, const float* __restrict__ x,
+                                                                    const float* __restrict__ skip, float slope, int rows_per_tile,
+                                                                    float* __restrict__ y) {
+    __shared__ float s_ab[2][FR_CH];
+    float ab[2];
+    if (bn_finalize_records_body(rec, nrec, M, C, gamma, beta, eps, run_mean, run_var, momentum, coef, blockIdx.x, blockIdx.y == 0, ab)) {
+        s_ab[0][threadIdx.x] = ab[0];
+        s_ab[1][threadIdx.x] = ab[1];
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 3, rl = threadIdx.x >> 2;            // 4 channel quads x 256 rows per pass
+    const int c = blockIdx.x * FR_CH + 4 * q;
+    if (c >= C) return;
+    const float4 a = *reinterpret_cast<const float4*>(&s_ab[0][4 * q]), b = *reinterpret_cast<const float4*>(&s_ab[1][4 * q]);
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_tile;
+    const int64_t r1 = r0 + rows_per_tile < M ? r0 + rows_per_tile : M;
+    for (int64_t rb = r0 + rl; rb < r1; rb += 4 * (FR_BLOCK / 4)) {
+        float4 v[4];
+        [[maybe_unused]] float4 k[ADD ? 4 : 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = rb + (int64_t)u * (FR_BLOCK / 4);
+            v[u] = r < r1 ? *reinterpret_cast<const float4*>(x + r * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (ADD) k[u] = r < r1 ? *reinterpret_cast<const float4*>(skip + r * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = rb + (int64_t)u * (FR_BLOCK / 4);
+            if (r >= r1) continue;
+            float4 o = make_float4(fmaf(a.x, v[u].x, b.x), fmaf(a.y, v[u].y, b.y), fmaf(a.z, v[u].z, b.z), fmaf(a.w, v[u].w, b.w));
+            if constexpr (ADD) {
+                o.x = add_rn(o.x, k[u].x); o.y = add_rn(o.y, k[u].y); o.z = add_rn(o.z, k[u].z); o.w = add_rn(o.w, k[u].w);
+            }
+            o.x = o.x > 0.f ? o.x : slope * o.x;
+            o.y = o.y > 0.f ? o.y : slope * o.y;
+            o.z = o.z > 0.f ? o.z : slope * o.z;
+            o.w = o.w > 0.f ? o.w : slope * o.w;
+            *reinterpret_cast<float4*>(y + r * C + c) = o;
+        }
     }
 }
 
@@ -1444,6 +1508,31 @@ extern "C" int crfconv_bn_coef_from_nrecords(const float* stat_rec, int64_t nrec
     CRF_REQUIRE(M > 0 && C > 0 && nrec > 0 && nrec < ((int64_t)1 << 31), CRF_ERR_ARG, "bad shape");
     hipLaunchKernelGGL(crf::bn_finalize_records_kernel, dim3((C + crf::FR_CH - 1) / crf::FR_CH), dim3(crf::FR_BLOCK), 0, crf::as_stream(stream), stat_rec,
                        (int)nrec, M, C, gamma, beta, eps, run_mean, run_var, momentum, coef);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+// crfconv_bn_coef_from_records followed by crfconv_bn_apply (skip == NULL) or crfconv_bn_apply_add (the ResNet join) in ONE launch:
+// identical coef / running statistics / y.  C % 4 == 0.
+extern "C" int crfconv_bn_apply_from_records(const float* stat_rec, int64_t nrec, const float* x, int64_t M, int C, const float* gamma,
+                                             const float* beta, float* run_mean, float* run_var, float momentum, float eps,
+                                             const float* skip, float slope, float* coef, float* y, crf_stream_t stream) {
+    CRF_REQUIRE(stat_rec && x && gamma && beta && coef && y, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(M > 0 && C >= 4 && C % 4 == 0 && nrec > 0 && nrec < ((int64_t)1 << 31), CRF_ERR_ARG, "bad shape");
+    const int slabs = (C + crf::FR_CH - 1) / crf::FR_CH;
+    // ~512 workgroups in all; a row tile is a multiple of the 1024 rows one pass covers
+    int64_t tiles = 512 / slabs;
+    if (tiles < 1) tiles = 1;
+    int64_t rows = (M + tiles - 1) / tiles;
+    rows = (rows + 1023) / 1024 * 1024;
+    tiles = (M + rows - 1) / rows;
+    const dim3 grid((unsigned)slabs, (unsigned)tiles), blk(crf::FR_BLOCK);
+    if (skip != nullptr)
+        hipLaunchKernelGGL(crf::bn_apply_records_kernel<true>, grid, blk, 0, crf::as_stream(stream), stat_rec, (int)nrec, M, C, gamma, beta, eps,
+                           run_mean, run_var, momentum, coef, x, skip, slope, (int)rows, y);
+    else
+        hipLaunchKernelGGL(crf::bn_apply_records_kernel<false>, grid, blk, 0, crf::as_stream(stream), stat_rec, (int)nrec, M, C, gamma, beta, eps,
+                           run_mean, run_var, momentum, coef, x, skip, slope, (int)rows, y);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -801,6 +801,7 @@ _MFMA_MIN_ROWS = int(__import__('os').environ.get('CRFCONV_MFMA_MIN_ROWS', 12288
 
 
 _VENDOR_ONLY = bool(__import__('os').environ.get('CRFCONV_VENDOR_GEMM'))     # A/B switch: forward / dX on rocBLAS
+_NO_APPLY_FROM_RECORDS_ENV = __import__('os').environ.get('CRFCONV_NO_APPLY_FROM_RECORDS') is not None      # A/B: coefficient launch + apply launch
 
 
 def _mfma_ok(m, ci, co):
@@ -981,9 +982,13 @@ class _BNAct(torch.autograd.Function):
         g, b = _f32c(gamma), _f32c(beta)
         if use_batch and records is not None:
             # statistics came out of the Linear kernel's epilogue: no pass over x for them
-            _lib.call('crfconv_bn_coef_from_records', ptr(records), m, C, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
-                      float(momentum), float(eps), ptr(coef), stream_ptr())
-            _lib.call('crfconv_bn_apply', ptr(x), m, C, ptr(coef), float(slope), ptr(y), stream_ptr())
+            if _NO_APPLY_FROM_RECORDS_ENV:
+                _lib.call('crfconv_bn_coef_from_records', ptr(records), m, C, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
+                          float(momentum), float(eps), ptr(coef), stream_ptr())
+                _lib.call('crfconv_bn_apply', ptr(x), m, C, ptr(coef), float(slope), ptr(y), stream_ptr())
+            else:
+                _lib.call('crfconv_bn_apply_from_records', ptr(records), records.shape[0], ptr(x), m, C, ptr(g), ptr(b), ptr(run_mean),
+                          ptr(run_var), float(momentum), float(eps), None, float(slope), ptr(coef), ptr(y), stream_ptr())
         else:
             nbytes = _lib.load().crfconv_bn_workspace(m, C)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -1044,10 +1049,14 @@ class _MLPBlock(torch.autograd.Function):
         y, rec = _mfma_matmul(x, Wc, None, False, True)
         coef = torch.empty(4 * co, dtype=torch.float32, device=x.device)
         g, b = _f32c(gamma), _f32c(beta)
-        _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
-                  float(momentum), float(eps), ptr(coef), stream_ptr())
         out = torch.empty_like(y)
-        _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), stream_ptr())
+        if _NO_APPLY_FROM_RECORDS_ENV:
+            _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
+                      float(momentum), float(eps), ptr(coef), stream_ptr())
+            _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), stream_ptr())
+        else:                                   # coefficients and apply in one launch (same values)
+            _lib.call('crfconv_bn_apply_from_records', ptr(rec), rec.shape[0], ptr(y), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
+                      float(momentum), float(eps), None, float(slope), ptr(coef), ptr(out), stream_ptr())
         ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef)
         ctx.slope = float(slope)
@@ -1091,10 +1100,14 @@ class _MLPBlockJoin(torch.autograd.Function):
         y, rec = _mfma_matmul(x, Wc, None, False, True)
         coef = torch.empty(4 * co, dtype=torch.float32, device=x.device)
         st = stream_ptr()
-        _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
-                  ptr(run_var), float(momentum), float(eps), ptr(coef), st)
         out = torch.empty_like(y)
-        _lib.call('crfconv_bn_apply_add', ptr(y), m, co, ptr(coef), ptr(skip), float(slope), ptr(out), st)
+        if _NO_APPLY_FROM_RECORDS_ENV:
+            _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
+                      ptr(run_var), float(momentum), float(eps), ptr(coef), st)
+            _lib.call('crfconv_bn_apply_add', ptr(y), m, co, ptr(coef), ptr(skip), float(slope), ptr(out), st)
+        else:
+            _lib.call('crfconv_bn_apply_from_records', ptr(rec), rec.shape[0], ptr(y), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)),
+                      ptr(run_mean), ptr(run_var), float(momentum), float(eps), ptr(skip), float(slope), ptr(coef), ptr(out), st)
         ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef, out)
         ctx.slope = float(slope)
@@ -1419,12 +1432,16 @@ def _small_fwd(x, Wc, gamma, beta, run_mean, run_var, momentum, eps, slope, skip
     nrec = lib.crfconv_gemm_stat_records(m)
     rec = torch.empty((nrec, co, 4), dtype=torch.float32, device=dev)
     _lib.call('crfconv_gemm_stats', ptr(x), ptr(Wc), m, co, ci, ptr(y), ptr(rec), stream_ptr())
-    _lib.call('crfconv_bn_coef_from_nrecords', ptr(rec), nrec, m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var), float(momentum),
-              float(eps), ptr(coef), stream_ptr())
-    if skip is None:
-        _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), stream_ptr())
+    if _NO_APPLY_FROM_RECORDS_ENV:
+        _lib.call('crfconv_bn_coef_from_nrecords', ptr(rec), nrec, m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var), float(momentum),
+                  float(eps), ptr(coef), stream_ptr())
+        if skip is None:
+            _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), stream_ptr())
+        else:
+            _lib.call('crfconv_bn_apply_add', ptr(y), m, co, ptr(coef), ptr(skip), float(join_slope), ptr(out), stream_ptr())
     else:
-        _lib.call('crfconv_bn_apply_add', ptr(y), m, co, ptr(coef), ptr(skip), float(join_slope), ptr(out), stream_ptr())
+        _lib.call('crfconv_bn_apply_from_records', ptr(rec), nrec, ptr(y), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
+                  float(momentum), float(eps), ptr(skip), float(slope if skip is None else join_slope), ptr(coef), ptr(out), stream_ptr())
     return y, out, coef
 
 

@@ -558,6 +558,12 @@ int crfconv_gemm(const float* A, const float* B, const float* bias, const float*
 int crfconv_bn_coef_from_records(const float* stat_rec, int64_t M, int C, const float* gamma, const float* beta,
                                  float* run_mean, float* run_var, float momentum, float eps, float* coef,
                                  crf_stream_t stream);
+/* crfconv_bn_coef_from_nrecords + crfconv_bn_apply in one launch (every workgroup combines the records of its own 16 channels, then
+ * applies y = lrelu(a x + b (+ skip), slope) to its row tile; skip != NULL = crfconv_bn_apply_add, the ResNet join): identical coef,
+ * running statistics and y. */
+int crfconv_bn_apply_from_records(const float* stat_rec, int64_t nrec, const float* x, int64_t M, int C, const float* gamma,
+                                  const float* beta, float* run_mean, float* run_var, float momentum, float eps, const float* skip,
+                                  float slope, float* coef, float* y, crf_stream_t stream);
 /* The same with an explicit record count (the records of crfconv_gemm_stats: one per 16-row group). */
 int crfconv_bn_coef_from_nrecords(const float* stat_rec, int64_t nrec, int64_t M, int C, const float* gamma, const float* beta,
                                   float* run_mean, float* run_var, float momentum, float eps, float* coef, crf_stream_t stream);
