@@ -1611,10 +1611,14 @@ class _MLPBlockCat(torch.autograd.Function):
         st = stream_ptr()
         _lib.call('crfconv_linear_forward_cat', ptr(xa), ptr(xb), split, ptr(Wc), None, m, ci, co, ptr(y), ptr(rec), st)
         coef = torch.empty(4 * co, dtype=torch.float32, device=xa.device)
-        _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
-                  ptr(run_var), float(momentum), float(eps), ptr(coef), st)
         out = torch.empty_like(y)
-        _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), st)
+        if _NO_APPLY_FROM_RECORDS_ENV:
+            _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
+                      ptr(run_var), float(momentum), float(eps), ptr(coef), st)
+            _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), st)
+        else:
+            _lib.call('crfconv_bn_apply_from_records', ptr(rec), nrec, ptr(y), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
+                      ptr(run_var), float(momentum), float(eps), None, float(slope), ptr(coef), ptr(out), st)
         ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(xa, xb, Wc, y, coef)
         ctx.slope = float(slope)
