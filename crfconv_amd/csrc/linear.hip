@@ -1343,16 +1343,19 @@ __global__ __launch_bounds__(FR_BLOCK) void bn_apply_records_kernel(const float*
                                                                     float* __restrict__ y) {
     __shared__ float s_ab[2][FR_CH];
     float ab[2];
-    if (bn_finalize_records_body(rec, nrec, M, C, gamma, beta, eps, run_mean, run_var, momentum, coef, blockIdx.x, blockIdx.y == 0, ab)) {
+    // grid = (row tiles, slabs): the workgroups that read the two / four 64-byte pieces of the same 128-byte lines are `tiles` apart in
+    // dispatch order, and tiles is a multiple of 8 -- they land on the same XCD, whose L2 then fetches each line from HBM once
+    const int slab = blockIdx.y, tile = blockIdx.x;
+    if (bn_finalize_records_body(rec, nrec, M, C, gamma, beta, eps, run_mean, run_var, momentum, coef, slab, tile == 0, ab)) {
         s_ab[0][threadIdx.x] = ab[0];
         s_ab[1][threadIdx.x] = ab[1];
     }
     __syncthreads();
     const int q = threadIdx.x & 3, rl = threadIdx.x >> 2;            // 4 channel quads x 256 rows per pass
-    const int c = blockIdx.x * FR_CH + 4 * q;
+    const int c = slab * FR_CH + 4 * q;
     if (c >= C) return;
     const float4 a = *reinterpret_cast<const float4*>(&s_ab[0][4 * q]), b = *reinterpret_cast<const float4*>(&s_ab[1][4 * q]);
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_tile;
+    const int64_t r0 = (int64_t)tile * rows_per_tile;
     const int64_t r1 = r0 + rows_per_tile < M ? r0 + rows_per_tile : M;
     for (int64_t rb = r0 + rl; rb < r1; rb += 4 * (FR_BLOCK / 4)) {
         float4 v[4];
@@ -1526,7 +1529,8 @@ extern "C" int crfconv_bn_apply_from_records(const float* stat_rec, int64_t nrec
     int64_t rows = (M + tiles - 1) / tiles;
     rows = (rows + 1023) / 1024 * 1024;
     tiles = (M + rows - 1) / rows;
-    const dim3 grid((unsigned)slabs, (unsigned)tiles), blk(crf::FR_BLOCK);
+    if (tiles > 8) tiles = (tiles + 7) / 8 * 8;          // (tiles past the end of the rows have nothing to apply; see the kernel for the 8)
+    const dim3 grid((unsigned)tiles, (unsigned)slabs), blk(crf::FR_BLOCK);
     if (skip != nullptr)
         hipLaunchKernelGGL(crf::bn_apply_records_kernel<true>, grid, blk, 0, crf::as_stream(stream), stat_rec, (int)nrec, M, C, gamma, beta, eps,
                            run_mean, run_var, momentum, coef, x, skip, slope, (int)rows, y);
