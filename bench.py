@@ -16,14 +16,58 @@ import os
 import sys
 import time
 
-import numpy as np
-import crfconv_amd        # noqa: F401  (first: picks the hardware-queue mapping for a launch under a process group, crfconv_amd/__init__.py)
-import torch
+
+def _self_launch():
+    """`python bench.py --gpus N` WITHOUT a launcher's environment (no WORLD_SIZE): this process only starts the N ranks -- fresh
+    children, one per GPU, with the torchrun variables (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT) --
+    BEFORE it imports torch or crfconv_amd or touches the GPU (never a re-exec of a process that has), relays their output
+    (rank 0 prints the JSON line), and exits non-zero if any rank fails.  N = 1 runs in-process as before unless --spawn asks
+    for the one-rank process group (RCCL path with one rank).  Under torchrun (WORLD_SIZE set) nothing happens here."""
+    import socket
+    import subprocess
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--spawn', action='store_true')
+    a, _ = ap.parse_known_args()
+    if 'WORLD_SIZE' in os.environ or (a.gpus <= 1 and not a.spawn):
+        return
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(max(1, a.gpus)):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(max(1, a.gpus)), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, t_fail = 0, None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if bad and t_fail is None:
+            rc, t_fail = bad[0], time.time()                     # a rank died: the others hang in their next collective
+        if t_fail is not None and time.time() - t_fail > 20:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                     # exactly the PIDs started above
+    for p in procs:
+        if p.returncode != 0 and rc == 0:
+            rc = p.returncode
+    sys.exit(rc if rc is not None else 1)
+
+
+if __name__ == '__main__':
+    _self_launch()
+
+import numpy as np        # noqa: E402
+import crfconv_amd        # noqa: E402,F401  (first: picks the hardware-queue mapping for a launch under a process group, crfconv_amd/__init__.py)
+import torch              # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12           # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+TRAFFIC_FWD, TRAFFIC_BWD = 'r4_meanfield_traffic.json', 'r4_meanfield_bwd_traffic.json'      # PMC passes, sha1-keyed to the kernel sources
 BOX = (8.0, 8.0, 3.0)
 VOX = 0.04
 
@@ -52,9 +96,9 @@ def make_batch(rank, B, N, dev, gen, sort='morton'):
     return data, time.perf_counter() - t0
 
 
-def _meanfield_problem(data, dev, H, seed=1):
+def _meanfield_problem(data, dev, H, seed=1, level=0):
     from crfconv_amd.graph import table_of
-    ms0 = data.multiscale[0]
+    ms0 = data.multiscale[level]
     B, N, K = ms0.neighbor_idx.shape
     m = B * N
     tab = table_of(ms0.neighbor_idx, N)
@@ -106,11 +150,12 @@ def _measured_traffic(name, config):
         return None, 'no usable measurement (%s)' % type(e).__name__
 
 
-def roofline_meanfield(data, dev, H=8, T=3):
-    """Level-0 CRF mean-field forward alone, HIP-event timed on the stream it is launched on."""
+def roofline_meanfield(data, dev, H=8, T=3, level=0):
+    """CRF mean-field forward of one level alone (level 0 = the kernel the north_star target is stated on), HIP-event timed on
+    the stream it is launched on."""
     from crfconv_amd import _lib
     from crfconv_amd.graph import ptr, stream_ptr
-    tab, m, K, z, y, Q, P, _ = _meanfield_problem(data, dev, H)
+    tab, m, K, z, y, Q, P, _ = _meanfield_problem(data, dev, H, level=level)
     s = torch.empty(m, K, device=dev)
     xs = torch.empty(T, m, H, device=dev)
     st = stream_ptr()
@@ -120,12 +165,17 @@ def roofline_meanfield(data, dev, H=8, T=3):
                   K, 1, m, H, ptr(Q), ptr(P), T, ptr(s), ptr(xs), st)
     avg, lo = _event_time(launch)
     alg_bytes = m * (4 * (K - 1) + 4 * H * (2 * T + 1))
-    traffic, note = _measured_traffic('r3_meanfield_traffic.json', {'m': m, 'H': H, 'K': K, 'T': T, 'u16': tab.idx16 is not None})
+    traffic, note = _measured_traffic(TRAFFIC_FWD, {'m': m, 'H': H, 'K': K, 'T': T, 'u16': tab.idx16 is not None})
     out = {'bound': 'hbm', 'achieved': alg_bytes / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
            'frac': alg_bytes / avg / HBM_PEAK, 'traffic': traffic, 'traffic_source': note,
-           'kernel': 'crfconv_meanfield_forward level-0 (sim_step_fast_kernel [similarity + step 1] + %d x step_fast_kernel, '
-                     'm=%d, H=%d, K=%d)' % (T - 1, m, H, K),
-           'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': avg * 1e6, 'min_launch_us': lo * 1e6}
+           'kernel': 'crfconv_meanfield_forward level-%d (sim_step_fast_kernel [similarity + step 1] + %d x step_fast_kernel, '
+                     'm=%d, H=%d, K=%d)' % (level, T - 1, m, H, K),
+           'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': avg * 1e6, 'min_launch_us': lo * 1e6,
+           'note': 'isolated synthetic problem, 10 back-to-back launches per event pair: the %.1f MB working set stays resident in '
+                   'the 256 MiB Infinity Cache between launches (as it does between the consecutive kernels of the real step, '
+                   'whose in-step times agree); peak = the 8 TB/s HBM3E figure' % (alg_bytes / 1e6)}
+    if level != 0:
+        return out
     # the one-launch variant of the same forward (crfconv_meanfield_forward_fused), measured beside it
     lib = _lib.load()
     if lib.crfconv_meanfield_fused_supported(m, H, K, 1, T) == 1:
@@ -139,16 +189,21 @@ def roofline_meanfield(data, dev, H=8, T=3):
     return out
 
 
-def roofline_meanfield_bwd(data, dev, H=8, T=3):
+def roofline_meanfield_bwd(data, dev, H=8, T=3, level=0):
     """Level-0 CRF mean-field BACKWARD (crfconv_meanfield_backward, csrc/crf_bwd.hip: T - 1 reverse walks | edge pass over
     all steps + softmax backward | last reverse walk with the dy scatter and the dP / dQ reduction), HIP-event timed.  Algorithmic bytes per point:
     twice the forward's compulsory bytes plus the reverse index, 2 (4 (K-1) + 4 H (2 T + 1)) + 4 K + 4."""
     from crfconv_amd import _lib, ops
     from crfconv_amd.graph import ptr, stream_ptr
-    tab, m, K, z, y, Q, P, g = _meanfield_problem(data, dev, H)
+    tab, m, K, z, y, Q, P, g = _meanfield_problem(data, dev, H, level=level)
     lib = _lib.load()
-    if lib.crfconv_meanfield_backward_supported(H, K, 1) != 1 or lib.crfconv_meanfield_backward_param_grads_inside(H) != 1:
+    if lib.crfconv_meanfield_backward_supported(H, K, 1) != 1:
         return None
+    # H >= 32: dP / dQ are not formed inside the last walk; the launches leave m_t and sum_t G_t for the row-reduction
+    # kernel (in the training step those partial passes ride in the batched weight-gradient launches at the end of the pass)
+    inside = lib.crfconv_meanfield_backward_param_grads_inside(H) == 1
+    mts = None if inside else torch.empty(T, m, H, device=dev)
+    sumG = None if inside else torch.empty(m, H, device=dev)
     rev_ptr, rev_eid = tab.reverse
     gout = torch.randn(m, H, generator=g).to(dev)
     s = torch.empty(m, K, device=dev)
@@ -166,16 +221,41 @@ def roofline_meanfield_bwd(data, dev, H=8, T=3):
 
     def launch():
         _lib.call('crfconv_meanfield_backward', ptr(gout), ptr(z), ptr(y), ptr(s), ptr(xs), ptr(tab.idx32), ptr(tab.idx16),
-                  tab.n_tgt, tab.n_src, ptr(rev_ptr), ptr(rev_eid), K, 1, m, H, ptr(Q), ptr(P), T, ptr(Gs), ptr(dzq), None,
-                  None, ptr(dz), ptr(w), ptr(dy_self), ptr(dy), ptr(dP), ptr(dQ), ptr(ws), wsb, ptr(ticket), st)
+                  tab.n_tgt, tab.n_src, ptr(rev_ptr), ptr(rev_eid), K, 1, m, H, ptr(Q), ptr(P), T, ptr(Gs), ptr(dzq), ptr(mts),
+                  ptr(sumG), ptr(dz), ptr(w), ptr(dy_self), ptr(dy), ptr(dP), ptr(dQ), ptr(ws), wsb, ptr(ticket), st)
     avg, lo = _event_time(launch, per=5)
     alg_bytes = m * (2 * (4 * (K - 1) + 4 * H * (2 * T + 1)) + 4 * K + 4)
-    traffic, note = _measured_traffic('r3_meanfield_bwd_traffic.json', {'m': m, 'H': H, 'K': K, 'T': T})
+    traffic, note = _measured_traffic(TRAFFIC_BWD, {'m': m, 'H': H, 'K': K, 'T': T})
     return {'bound': 'hbm', 'achieved': alg_bytes / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
             'frac': alg_bytes / avg / HBM_PEAK, 'traffic': traffic, 'traffic_source': note,
-            'kernel': 'crfconv_meanfield_backward level-0 (%d x bwd_rev<chain> + bwd_edge_all + bwd_rev<final>, '
-                      'm=%d, H=%d, K=%d)' % (T - 1, m, H, K),
+            'kernel': 'crfconv_meanfield_backward level-%d (%d x bwd_rev<chain> + bwd_edge_all + bwd_rev<final>, '
+                      'm=%d, H=%d, K=%d)' % (level, T - 1, m, H, K),
             'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': avg * 1e6, 'min_launch_us': lo * 1e6}
+
+
+def roofline_layer(data, dev, T=3, level0=None):
+    """The mean-field layer AS THE NETWORK RUNS IT: all four decoder levels (deconv1..deconv4: H = 8, 16, 32, 64 on
+    m = 163 840 ... 2 560 points at config 2), forward and forward + backward, algorithmic bytes of SURVEY 8(d) summed over the
+    levels (81.9 MB forward at config 2) against the summed times.  Each level is timed like `roofline` (isolated problem, HIP
+    events, back-to-back launches); levels 1-3 hold 6 % of the points but are launch-latency chains, so the layer figure is far
+    below the level-0 one -- that is the point of reporting it."""
+    per, tf, tb, af, ab = [], 0.0, 0.0, 0, 0
+    for level in range(min(4, len(data.multiscale) - 1)):
+        H = 8 << level
+        f = level0[0] if (level == 0 and level0) else roofline_meanfield(data, dev, H, T, level=level)
+        b = level0[1] if (level == 0 and level0) else roofline_meanfield_bwd(data, dev, H, T, level=level)
+        if b is None:
+            return None
+        per.append({'level': level, 'H': H, 'm': int(np.prod(data.multiscale[level].pos.shape[:2])), 'fwd_us': f['avg_launch_us'],
+                    'bwd_us': b['avg_launch_us'], 'fwd_alg_bytes': f['alg_bytes_per_launch'], 'bwd_alg_bytes': b['alg_bytes_per_launch']})
+        tf += f['avg_launch_us'] * 1e-6
+        tb += b['avg_launch_us'] * 1e-6
+        af += f['alg_bytes_per_launch']
+        ab += b['alg_bytes_per_launch']
+    return {'bound': 'hbm', 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'fwd_alg_bytes': af, 'fwd_us': tf * 1e6, 'fwd_frac': af / tf / HBM_PEAK,
+            'fwd_bwd_alg_bytes': af + ab, 'fwd_bwd_us': (tf + tb) * 1e6, 'achieved': (af + ab) / (tf + tb) / 1e9,
+            'frac': (af + ab) / (tf + tb) / HBM_PEAK, 'traffic': None, 'levels': per,
+            'kernel': 'mean-field layer, all %d decoder levels, forward + backward (frac / achieved); fwd_frac = forward only' % len(per)}
 
 
 def roofline_pointconv(data, dev, d=8):
@@ -342,9 +422,52 @@ def cpu_baseline(data, net, steps_T, labels, n_cls, dev):
     return out
 
 
+def reference_loop(net, data, cw, steps):
+    """The reference's training step, verbatim (trainval.py:99-106): optimizer.zero_grad(); y_pred = model(data);
+    y = data.y.reshape(-1) - 1; loss = F.cross_entropy(y_pred, y, weight, ignore_index=-1); loss.backward(); optimizer.step()
+    with torch.optim.SGD(lr=1e-2, momentum=0.95, weight_decay=1e-4) -- (a) eagerly, as a user who only swaps the import gets it,
+    (b) through crfconv_amd.train.CapturedStep (the same five lines as one hipGraph replay)."""
+    import torch.nn.functional as F
+    from crfconv_amd.train import CapturedStep
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2, momentum=0.95, weight_decay=1e-4)
+
+    def loss_fn(y_pred, d):
+        return F.cross_entropy(y_pred, d.y.reshape(-1) - 1, weight=cw, ignore_index=-1)
+
+    def one():
+        opt.zero_grad()
+        loss = loss_fn(net(data), data)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize()
+    eager = (time.perf_counter() - t0) / steps * 1e3
+    out = {'eager_ms_per_step': eager, 'eager_final_loss': float(loss),
+           'what': 'trainval.py:99-106 unchanged (zero_grad, model(data), F.cross_entropy(weight, ignore_index=-1), backward, '
+                   'torch.optim.SGD.step), %d timed steps after 3 warm-up' % steps}
+    step = CapturedStep(net, opt, loss_fn, data)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    out['captured_ms_per_step'] = (time.perf_counter() - t0) / steps * 1e3
+    out['captured_final_loss'] = float(loss)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--spawn', action='store_true', help='start the ranks as child processes even for --gpus 1 (one-rank RCCL group)')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=4, help='clouds per GPU')
@@ -362,7 +485,8 @@ def main():
 
     rank, world, local = D.init_from_env()
     torch.set_num_threads(max(1, min(torch.get_num_threads(), cpu_share() // max(1, world), 16)))     # 16 = the share per GPU of the pool's boxes
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher environment says WORLD_SIZE=%d' % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     B, N, T, n_cls = args.batch, args.points, args.crf_steps, 13
@@ -625,6 +749,34 @@ def main():
             torch.cuda.synchronize()
             pipe_ms = None
 
+    # ---- the all-reduce alone (HIP events around 20 calls on the launching stream), and what the group looks like
+    allreduce_us, backend_name = None, None
+    if grouped:
+        backend_name = torch.distributed.get_backend()
+        for _ in range(5):
+            collective()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            collective()
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_us = e0.elapsed_time(e1) / 20 * 1e3
+
+    # ---- what a caller of the UNCHANGED reference loop gets (trainval.py:99-106), on the same model and batch: no graph, no
+    # FlatSGD, no deferred weight gradients, no fused loss -- torch.optim.SGD and F.cross_entropy as the reference writes them;
+    # and the same loop handed to crfconv_amd.train.CapturedStep (one hipGraph replay per step, still torch.optim.SGD).
+    ref_loop = None
+    if rank == 0:
+        try:
+            ref_loop = reference_loop(net, data, cw, args.steps)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            torch.cuda.synchronize()
+            ref_loop = {'error': str(e).splitlines()[0][:200]}
+
     if rank == 0:
         out = {
             'metric': 'M points/sec fwd+bwd, S3DIS 40960-pt cloud, K=16, 3 CRF iters; mIoU parity',
@@ -646,6 +798,11 @@ def main():
             'value_incl_preprocessing': world * B * N / ((pipe_ms or per_batch_ms) * 1e-3) / 1e6,
             'fresh_batch_replay': fresh,
             'launch_mode': graph_note,
+            'rccl_ranks_seen': torch.distributed.get_world_size() if grouped else 1,
+            'dist_backend': backend_name, 'allreduce_us': allreduce_us,
+            'trainval_eager_ms_per_step': None if ref_loop is None else ref_loop.get('eager_ms_per_step'),
+            'trainval_captured_ms_per_step': None if ref_loop is None else ref_loop.get('captured_ms_per_step'),
+            'reference_loop': ref_loop,
         }
         out['roofline'] = roofline_meanfield(data, dev, 8, T)
         out['roofline']['measured_copy_GBps'] = copy_ceiling(dev)
@@ -661,6 +818,10 @@ def main():
                                        'frac': alg / t / HBM_PEAK, 'traffic': tr, 'alg_bytes_per_launch': alg,
                                        'avg_launch_us': t * 1e6,
                                        'kernel': 'level-0 mean-field forward + backward (roofline + roofline_bwd)'}
+        try:
+            out['roofline_layer'] = roofline_layer(data, dev, T, level0=(out['roofline'], out['roofline_bwd']) if out['roofline_bwd'] else None)
+        except Exception as e:                             # a measurement beside the contract line, never fatal
+            out['roofline_layer'] = {'error': str(e).splitlines()[0][:200]}
         try:
             out['roofline_pointconv'] = roofline_pointconv(data, dev, 8)
         except Exception as e:                             # a measurement beside the contract line, never fatal

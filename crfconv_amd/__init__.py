@@ -23,8 +23,8 @@ def _pick_hw_queues():
 
 _pick_hw_queues()
 
-from . import _lib, data, graph, models, ops, optim, utils          # noqa: E402
+from . import _lib, data, graph, models, ops, optim, train, utils          # noqa: E402
 from .data import Data, MultiScaleData, multiscale_compute
 
 __version__ = '0.1.0'
-__all__ = ['models', 'utils', 'ops', 'optim', 'graph', 'data', 'Data', 'MultiScaleData', 'multiscale_compute']
+__all__ = ['models', 'utils', 'ops', 'optim', 'train', 'graph', 'data', 'Data', 'MultiScaleData', 'multiscale_compute']

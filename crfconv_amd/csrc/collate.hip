@@ -96,7 +96,7 @@ __global__ __launch_bounds__(SUB_NT) void random_subsets_kernel(const SubsetJobs
 }
 
 // ------------------------------------------------------------------ stable argsort of 30-bit codes, per cloud
-constexpr int AS_BITS = 16, AS_SHIFT = 30 - AS_BITS, AS_BUCKETS = 1 << AS_BITS;
+constexpr int AS_BITS = 16, AS_SHIFT = 30 - AS_BITS, AS_BUCKETS = 1 << AS_BITS, AS_HUB = 256;
 
 __global__ __launch_bounds__(256) void as_zero_kernel(int32_t* __restrict__ p, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0;
@@ -120,20 +120,48 @@ __global__ __launch_bounds__(256) void as_fill_kernel(const long long* __restric
 __global__ __launch_bounds__(256) void as_rank_kernel(const long long* __restrict__ code, int64_t N, int64_t total,
                                                       const int32_t* __restrict__ ptrs, const int32_t* __restrict__ cnt,
                                                       const int32_t* __restrict__ tmp, long long* __restrict__ order) {
-    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (slot >= total) return;
+    const int64_t slot_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = slot_raw < total;                       // lanes past the end stay in the wavefront: they load hub tiles below
+    const int64_t slot = valid ? slot_raw : total - 1;
     const int b = (int)(slot / N);
     const int i = tmp[slot];
     const long long ci = code[b * N + i];
     const int64_t g = (int64_t)b * AS_BUCKETS + (int)((ci >> AS_SHIFT) & (AS_BUCKETS - 1));
     const int beg = ptrs[g], len = cnt[g];
+    const unsigned long long key = ((unsigned long long)ci << 32) | (unsigned)i;     // (code, index): the stable order
     int rank = 0;
-    for (int k = 0; k < len; ++k) {                            // buckets hold ~N / 65536 elements; a degenerate cloud (one
-        const int j = tmp[beg + k];                            // bucket) costs N^2 broadcast loads, bounded by the caller's N
-        const long long cj = code[b * N + j];
-        rank += (cj < ci || (cj == ci && j < i)) ? 1 : 0;
+    const bool hub = valid && len > AS_HUB;
+    if (valid && !hub) {
+        for (int k = 0; k < len; ++k) {                        // buckets hold ~N / 65536 elements
+            const int j = tmp[beg + k];
+            const long long cj = code[b * N + j];
+            rank += (cj < ci || (cj == ci && j < i)) ? 1 : 0;
+        }
     }
-    order[(int64_t)beg + rank] = i;                            // bucket offsets count from the start of ALL clouds: cloud b's slots are [b N, (b + 1) N)
+    // Hub buckets (a cloud of duplicated / near-degenerate points: up to N elements in one bucket): the per-element scan above
+    // would be len dependent load pairs per element (1.7e9 for 40 960 coincident points).  The wavefront ranks them together
+    // instead: the slots of a bucket are consecutive, so its lanes share (beg, len); 64 keys of the bucket per coalesced tile
+    // load, compared through lane broadcasts -- len / 64 loads and len compare steps per element, no dependent load.
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(hub);
+    while (todo != 0ull) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lbeg = __shfl(beg, leader, 64), llen = __shfl(len, leader, 64);
+        const int lb = __shfl(b, leader, 64);
+        const bool mine = hub && beg == lbeg;
+        for (int t0 = 0; t0 < llen; t0 += 64) {
+            const bool have = t0 + lane < llen;
+            const int j = have ? tmp[lbeg + t0 + lane] : 0;
+            const unsigned long long kj = have ? (((unsigned long long)code[(int64_t)lb * N + j] << 32) | (unsigned)j) : ~0ull;
+            const int nt = llen - t0 < 64 ? llen - t0 : 64;
+            for (int k = 0; k < nt; ++k) {
+                const unsigned lo = __shfl((unsigned)kj, k, 64), hi = __shfl((unsigned)(kj >> 32), k, 64);
+                rank += (mine && (((unsigned long long)hi << 32) | lo) < key) ? 1 : 0;
+            }
+        }
+        todo &= ~__ballot(mine);
+    }
+    if (valid) order[(int64_t)beg + rank] = i;                            // bucket offsets count from the start of ALL clouds: cloud b's slots are [b N, (b + 1) N)
 }
 
 

@@ -160,7 +160,12 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 // then follows a learning-rate schedule (trainval.py:73 ExponentialLR) -- launch scalars are frozen at capture time
 __global__ __launch_bounds__(256) void sgd_hyper_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ buf, int64_t n,
-                                                        const float* __restrict__ hyper, int nesterov, int first) {
+                                                        const float* __restrict__ hyper, int nesterov, int first,
+                                                        const unsigned* __restrict__ fail) {
+    // fail: the sticky failure word of the grid barrier (gridsync.hpp FW_FAIL), or null.  A one-launch kernel whose barrier
+    // gave up has NaN-poisoned its outputs, hence the gradient: the update is SKIPPED while the word is set (one uniform scalar
+    // load), so parameters and momentum survive until ops.check_gridsync reports the failure -- also in captured replays
+    if (fail != nullptr && *fail != 0u) return;
     // hyper[4] = gradient scale: 1 / world size when the bucket holds the all-reduce SUM of the ranks' gradients (the mean
     // then never exists as a pass of its own over the bucket); 1 otherwise (x * 1.0f is exact)
     const float lr = hyper[0], mu = hyper[1], damp = hyper[2], wd = hyper[3], gs = hyper[4];
@@ -184,7 +189,20 @@ extern "C" int crfconv_sgd_step_hyper(float* param, const float* grad, float* mo
     int64_t nb = cdiv(n, 256 * 4);
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(crf::sgd_hyper_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), param, grad, momentum_buf,
-                       n, hyper, nesterov, first_step);
+                       n, hyper, nesterov, first_step, (const unsigned*)nullptr);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_sgd_step_guarded(float* param, const float* grad, float* momentum_buf, int64_t n,
+                                        const float* hyper, int nesterov, int first_step, const unsigned* fail_word,
+                                        crf_stream_t stream) {
+    CRF_REQUIRE(param && grad && momentum_buf && hyper, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(n > 0, CRF_ERR_ARG, "n=%lld <= 0", (long long)n);
+    int64_t nb = cdiv(n, 256 * 4);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(crf::sgd_hyper_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), param, grad, momentum_buf,
+                       n, hyper, nesterov, first_step, fail_word);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

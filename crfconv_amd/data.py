@@ -302,7 +302,8 @@ class CollateGraph:
 
     Nothing runs on the host per batch (device_draw=True, the default): the random subsets of
     datasets/semantic3d_dataset.py:517 are drawn INSIDE the graph by a counter-based kernel (crfconv_random_subsets: seeded
-    from the caller's generator -- ``generator.initial_seed()`` -- and a device counter the graph advances, so every replay
+    by one draw on the caller's generator at construction -- ``state_dict()`` / ``load_state_dict()`` carry seed and counter
+    for a resume -- and a device counter the graph advances, so every replay
     draws new subsets; the draws are NOT ``torch.randperm``'s) and the Morton argsort is this library's own scratch-free
     sort (crfconv_argsort_codes).  ``run`` = three copies into the static inputs + one replay.  device_draw=False keeps
     round 2's form: ``torch.randperm`` with the caller's generator on the host + a pinned upload, outside the graph.
@@ -315,9 +316,12 @@ class CollateGraph:
     def __init__(self, target, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), generator=None, device_draw=True, slot=0):
         self.target, self.kernel_size, self.ratio, self.generator = target, tuple(kernel_size), tuple(ratio), generator
         self.device_draw = bool(device_draw)
-        # `slot`: several graphs fed from one generator (CollatePipeline's slots) must not draw the same subsets
-        self.seed = (int(generator.initial_seed() if generator is not None else torch.initial_seed())
-                     + 0x632BE59BD9B4E019 * int(slot)) & 0xFFFFFFFFFFFFFFFF
+        # The subset seed is a DRAW on the caller's generator (it advances the generator's state): graphs built one after the
+        # other from one generator -- rebuilt per epoch, after a resume, the slots of a CollatePipeline -- get different
+        # sequences, and a run re-started from the same generator state reproduces them.  (Keyed on initial_seed() alone, every
+        # graph built from a generator replayed the SAME subset sequence.)  `slot` separates graphs built from equal states.
+        drawn = int(torch.randint(0, 2 ** 62, (1,), generator=generator, dtype=torch.int64).item())
+        self.seed = (drawn + 0x632BE59BD9B4E019 * int(slot)) & 0xFFFFFFFFFFFFFFFF
         ms = target.multiscale
         dev = ms[0].pos.device
         self.pos = torch.empty_like(ms[0].pos)
@@ -334,6 +338,16 @@ class CollateGraph:
         self.graph = None
         self._uploaded = None                    # event after the last upload from the pinned buffers
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)      # batches collated so far (device_draw: keys the subsets)
+
+    def state_dict(self):
+        """What a checkpoint needs to continue this graph's subset sequence: the seed and the batch counter (device word)."""
+        return {'seed': int(self.seed), 'counter': int(self.counter.item())}
+
+    def load_state_dict(self, sd):
+        self.seed = int(sd['seed']) & 0xFFFFFFFFFFFFFFFF
+        self.counter.fill_(int(sd['counter']))
+        if self.graph is not None and self.device_draw:
+            self.graph = None                     # the seed is a launch scalar of the captured draw: capture again on the next run()
 
     def _draw(self):
         if self._uploaded is not None:
@@ -370,7 +384,9 @@ class CollateGraph:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                count = self.counter.clone()
                 self._work()                                  # warm-up outside the capture (allocator, lazy tables)
+                self.counter.copy_(count)                     # ... which must not consume a batch number (resume: load_state_dict)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()

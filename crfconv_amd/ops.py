@@ -39,7 +39,11 @@ class _MeanField(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, y, Q, P, table, k0, steps, late=False):
         require_gpu(z, y, Q, P)
-        ctx.late = bool(late)      # (Q, P) come from crf_matrices_batched, whose backward can wait for the end of the pass: so can dP / dQ
+        # `late`: the gradient box of crf_matrices_batched for this (Q, P) pair, or None.  With a box dP / dQ can wait for the end of the
+        # backward pass like the matrices backward that consumes them -- and then they travel OUT OF BAND (the box), never as
+        # autograd gradients: autograd would otherwise hold tensors that are only filled by the end-of-pass flush (a second
+        # consumer of Q / P, a hook, retain_grad or anomaly mode would sum or inspect garbage)
+        ctx.late = late if isinstance(late, dict) else None
         m, H = z.shape
         if m != table.m_tgt or y.shape[0] != m or table.m_src != m:
             raise _lib.CrfConvError('mean field: %d / %d rows for a table of %d targets over %d sources (the CRF graph '
@@ -109,11 +113,14 @@ class _MeanField(torch.autograd.Function):
                       ptr(P), T, ptr(Gs), ptr(dzq), ptr(mts), ptr(sumG), ptr(dz), ptr(w), ptr(dy_self), ptr(dy), ptr(dP),
                       ptr(dQ), ptr(ws), wsb, ptr(_ticket(dev)), st)
             if not inside:                                  # (Gs[0] = G was written by the edge launch)
-                if ctx.late and _DEFER['on'] and not _NO_LATE_CRF_ENV:
+                if _late_box_ok(ctx.late):
                     # nothing on the chain reads dP / dQ, and their only consumer (the batched matrices backward) waits for the end
-                    # of the pass too: partial passes and sums join the batched launches there
+                    # of the pass too: partial passes and sums join the batched launches there; the buffers reach the matrices
+                    # backward through the box, autograd gets None for Q and P
                     _defer_tn(mts.view(T * m, H), Gs.view(T * m, H), dP)
                     _defer_tn(z, sumG, dQ)
+                    ctx.late['bufs'].append((dQ, dP))
+                    return dz, dy, None, None, None, None, None, None
                 else:
                     skinny_tn(mts.view(T * m, H), Gs.view(T * m, H), dP)
                     skinny_tn(z, sumG, dQ)
@@ -211,6 +218,9 @@ class _CrfMatricesBatched(torch.autograd.Function):
         ctx.save_for_backward(*ccs, *Qs)
         ctx.n = len(ccs)
         ctx.cparams = cs                           # the parameter objects themselves (late gradients are installed, not returned)
+        ctx.set_materialize_grads(False)           # a layer whose dQ / dP arrive through its box gets None here, not zeros
+        # one gradient box per layer: the mean-field nodes that defer dP / dQ to the end of the pass park their buffers here
+        ctx.boxes = [{'bufs': [], 'cs': cs} for _ in ccs]
         out = []
         for Q, P in zip(Qs, Ps):
             out += [Q, P]
@@ -223,21 +233,34 @@ class _CrfMatricesBatched(torch.autograd.Function):
         gQ = [None if g is None else _f32c(g) for g in grads[0::2]]
         gP = [None if g is None else _f32c(g) for g in grads[1::2]]
         Hs = (ctypes.c_int * n)(*[c.shape[0] for c in ccs])
-        late = (not _NO_LATE_CRF_ENV) and all(_defer_ok((c, None)) for c in ctx.cparams)
+        boxes = ctx.boxes
+        late = _late_box_ok(boxes[0])              # the SAME predicate the mean-field nodes used in this pass (_late_box_ok)
         if late:
             # the mean-field layers may have left dP / dQ to the batched sums at the end of the pass (_defer_tn): this launch goes
             # behind them (dc is a parameter gradient: nothing reads it before the pass is over) and, like every deferred weight
-            # gradient, INSTALLS its results as .grad (autograd would copy a returned tensor that is still referenced here -- empty)
+            # gradient, INSTALLS its results as .grad.  Gradients of a layer = what autograd delivered (consumers that did not
+            # defer; None otherwise) + the buffers in its box (filled by the end-of-pass sums that run before this launch)
             outs = [_param_out(c, tuple(c.shape), c.device) for c in ctx.cparams]
             dcs = [o[0] for o in outs]
             cparams = ctx.cparams
+            parked = [list(b['bufs']) for b in boxes]
+            for b in boxes:
+                b['bufs'].clear()                  # (a retained graph run again starts with empty boxes)
+
+            def total(g, bufs):
+                parts = ([g] if g is not None else []) + bufs
+                if len(parts) <= 1:
+                    return parts[0] if parts else None
+                return torch.stack(parts).sum(0)   # several consumers of one (Q, P) pair: rare, a tiny eager sum
 
             def launch():
-                _lib.call('crfconv_crf_matrices_backward_batched', _ptr_array(ccs), _ptr_array(Qs), _ptr_array(gQ), _ptr_array(gP), Hs, n,
+                gQs = [total(g, [b[0] for b in bufs]) for g, bufs in zip(gQ, parked)]
+                gPs = [total(g, [b[1] for b in bufs]) for g, bufs in zip(gP, parked)]
+                _lib.call('crfconv_crf_matrices_backward_batched', _ptr_array(ccs), _ptr_array(Qs), _ptr_array(gQs), _ptr_array(gPs), Hs, n,
                           _ptr_array(dcs), stream_ptr())
                 for prm, (gr, direct) in zip(cparams, outs):
                     _install_grad(prm, gr, direct)
-            _DEFER['late_calls'].append((launch, (ccs, Qs, gQ, gP, dcs)))
+            _DEFER['late_calls'].append((launch, (ccs, Qs, gQ, gP, dcs, parked)))
             _arm_flush()
             return (None,) * n
         dcs = [torch.empty_like(c) for c in ccs]
@@ -254,13 +277,20 @@ def crf_matrices_batched(cs):
     for lo in range(0, len(idx), 8):
         part = idx[lo:lo + 8]
         res = _CrfMatricesBatched.apply(*[cs[i] for i in part])
-        # (the same test as _defer_ok, minus the context: the node's backward installs late gradients only for leaf parameters)
-        leaf = all(isinstance(cs[i], torch.nn.Parameter) and cs[i].is_leaf and cs[i].requires_grad for i in part)
+        node = res[0].grad_fn                      # the Function's ctx: carries one gradient box per layer
         for k, i in enumerate(part):
-            if leaf:
-                res[2 * k]._crf_late = True        # tells crf_meanfield that this Q's gradient may arrive at the end of the pass
+            if node is not None and hasattr(node, 'boxes'):
+                res[2 * k]._crf_late = node.boxes[k]   # tells crf_meanfield where dQ / dP of this pair may be parked until the end of the pass
             out[i] = (res[2 * k], res[2 * k + 1])
     return out
+
+
+def _late_box_ok(box):
+    """True when dP / dQ of a mean-field layer may wait for the end of the backward pass: the pair comes from
+    crf_matrices_batched (it has a gradient box), deferred weight gradients are on, and every factor of that batched node is a
+    leaf parameter whose gradient the node's late launch can install.  Evaluated by the mean-field nodes AND by the matrices
+    node inside one backward pass -- the same inputs, the same answer."""
+    return (box is not None and _DEFER['on'] and not _NO_LATE_CRF_ENV and all(_defer_ok((c, None)) for c in box['cs']))
 
 
 _CRF_H = (4, 8, 16, 32, 64)
@@ -277,8 +307,10 @@ _TICKETS = {}
 def _stream_key(device):
     """(device index, handle of the stream the caller launches on): the inter-workgroup scratch words below are per stream,
     so that launches on two streams of one device (a second training stream, evaluation beside training) never share
-    barrier / ticket counts.  Two hipGraphs CAPTURED on the same stream and replayed concurrently would still share --
-    capture each on its own stream."""
+    barrier / ticket counts.  CAPTURED launches of a device all use ONE buffer (created by the eager warm-up pass, whatever
+    stream the capture later runs on): hipGraphs that contain mean-field backward or one-launch MLP kernels must therefore be
+    replayed one after the other (the loops of this package do) -- replaying two of them CONCURRENTLY on different streams is
+    unsupported, their barrier and ticket counts would mix."""
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if torch.cuda.is_current_stream_capturing():
@@ -405,7 +437,7 @@ def crf_meanfield(z, y, c, table, steps, k0=1, matrices=None):
     if Hp != H:                                 # zero channels stay zero through every step
         Q = torch.nn.functional.pad(Q, (0, Hp - H, 0, Hp - H))
         P = torch.nn.functional.pad(P, (0, Hp - H, 0, Hp - H))
-    out = _MeanField.apply(_pad_channels(z, Hp), _pad_channels(y, Hp), Q, P, table, k0, steps, getattr(Q, '_crf_late', False))
+    out = _MeanField.apply(_pad_channels(z, Hp), _pad_channels(y, Hp), Q, P, table, k0, steps, getattr(Q, '_crf_late', None))
     return out[:, :H] if Hp != H else out
 
 
@@ -1529,9 +1561,14 @@ def check_gridsync(dev=None):
     """Raises CrfConvError when a one-launch kernel's grid barrier has timed out on `dev` since the last check (its
     workgroups were not all resident -- CU mask, reserved CUs; the launch's outputs were NaN-poisoned).  One 4-byte
     device read (a synchronisation): FlatSGD.step() calls it every `check_every` eager steps, a loop that replays
-    captured graphs should call it once per epoch / logging interval.  After a failure the one-launch KERNEL is
-    switched off for the rest of the process (the small-MLP nodes go on with a launch-separated forward: tiled product +
-    BatchNorm launches, _small_fwd), so a caller that catches the error can re-run the step."""
+    captured graphs should call it once per epoch / logging interval.  What survives a failure: PARAMETERS and the MOMENTUM
+    buffer -- FlatSGD's update kernel reads the same sticky word and changes nothing while it is set (eager steps and
+    captured replays alike), so every step since the failure was a no-op for them.  What does not: the BatchNorm RUNNING
+    statistics of the layers downstream of the failed launch saw NaN activations in those steps (the failed layer itself
+    skips its update) -- restore the model's buffers from the last checkpoint, or reset them, before going on.  After a
+    failure the one-launch KERNEL is switched off for the rest of the process (the small-MLP nodes go on with a
+    launch-separated forward: tiled product + BatchNorm launches, _small_fwd), so a caller that catches the error and has
+    repaired the buffers can re-run the step."""
     global _small_mlp_disabled
     word = _lib.load().crfconv_gridsync_fail_word()
     bad = []

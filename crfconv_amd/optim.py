@@ -24,7 +24,8 @@ from .graph import ptr, require_gpu, stream_ptr
 class FlatSGD(torch.optim.Optimizer):
     def __init__(self, bucket, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, check_every=64, grad_scale=1.0):
         """`bucket`: distributed.FlatGradAllReduce of the model (owns the flat gradient vector).  check_every: eager steps
-        between two reads of the grid-barrier failure flag (ops.check_gridsync; 0 = never).  grad_scale: factor on the
+        between two host reads of the grid-barrier failure flag (ops.check_gridsync; 0 = never -- the update kernel itself
+        reads the flag every step and skips the update while it is set, so nothing is lost in between).  grad_scale: factor on the
         gradient inside the update -- 1 / world size after ``bucket.allreduce_sum()`` (no separate averaging pass)."""
         if nesterov and (momentum <= 0 or dampening != 0):
             raise ValueError('Nesterov momentum requires a momentum and zero dampening')
@@ -91,12 +92,17 @@ class FlatSGD(torch.optim.Optimizer):
             raise _lib.CrfConvError('FlatSGD: dampening != 0 makes the first step special; capture is not supported')
         if not capturing:
             self.push_hyper()
-        _lib.call('crfconv_sgd_step_hyper', ptr(self.flat), ptr(self.bucket.flat), ptr(self.buf), self.flat.numel(),
-                  ptr(self._hyper), 1 if g['nesterov'] else 0, 1 if first else 0, stream_ptr())   # zero buffer: mu * 0 + g = g
+        from . import ops
+        # the update is guarded by the sticky grid-barrier failure word of this stream's barrier workspace: a step whose forward
+        # or backward ran a one-launch kernel that timed out (NaN-poisoned outputs -> NaN gradient) leaves parameters and
+        # momentum untouched, in eager steps and captured replays alike, until check_gridsync reports it
+        ws = ops.gridsync_ws(self.flat.device)
+        fail = ws.data_ptr() + 4 * _lib.load().crfconv_gridsync_fail_word()
+        _lib.call('crfconv_sgd_step_guarded', ptr(self.flat), ptr(self.bucket.flat), ptr(self.buf), self.flat.numel(),
+                  ptr(self._hyper), 1 if g['nesterov'] else 0, 1 if first else 0, fail, stream_ptr())   # zero buffer: mu * 0 + g = g
         self.steps += 1
         if not capturing and self.check_every > 0 and self.steps % self.check_every == 0:
-            from . import ops
-            ops.check_gridsync(self.flat.device)            # a one-launch kernel whose barrier gave up must not train on
+            ops.check_gridsync(self.flat.device)            # raises; the guarded updates since the failure changed nothing
         return loss
 
     def state_dict(self):

@@ -1,0 +1,51 @@
+"""The reference training step (trainval.py:99-106) as ONE hipGraph replay, for a caller that keeps its own loop.
+
+    step = CapturedStep(model, optimizer, loss_fn, batch)      # batch: a MultiScaleData that stays resident (static buffers)
+    for new_batch in loader:
+        loss = step(new_batch)                                 # batch.load_(new_batch) + replay; `loss` is a device scalar
+
+`optimizer` is any torch.optim optimizer whose step() is capturable as is (torch.optim.SGD with float hyper-parameters: a
+learning-rate change needs a new CapturedStep) or optim.FlatSGD (then pass after_backward=bucket.pack).  `loss_fn(logits,
+batch)` is the caller's, e.g. ``lambda o, d: F.cross_entropy(o, d.y.reshape(-1) - 1, weight=w, ignore_index=-1)``."""
+import torch
+
+
+class CapturedStep:
+    def __init__(self, model, optimizer, loss_fn, batch, after_backward=None, warmup=2):
+        self.model, self.optimizer, self.loss_fn, self.batch, self.after_backward = model, optimizer, loss_fn, batch, after_backward
+        # the warm-up steps (allocator, lazily built tables, momentum buffers) must not train: model state is put back afterwards,
+        # momentum restarts from zero (mu * 0 + g = g: torch's first step, for dampening = 0)
+        keep = [t.detach().clone() for t in list(model.parameters()) + list(model.buffers())]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._step()
+            with torch.no_grad():
+                for t, k in zip(list(model.parameters()) + list(model.buffers()), keep):
+                    t.copy_(k)
+                for st in optimizer.state.values():
+                    if torch.is_tensor(st.get('momentum_buffer')):
+                        st['momentum_buffer'].zero_()
+                if hasattr(optimizer, 'buf'):
+                    optimizer.buf.zero_()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+            self.loss = self._step()
+
+    def _step(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.loss_fn(self.model(self.batch), self.batch)
+        loss.backward()
+        if self.after_backward is not None:
+            self.after_backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, new_batch=None):
+        if new_batch is not None:
+            self.batch.load_(new_batch)          # into the static buffers; tables, reverse CSRs, moments refreshed in place
+        self.graph.replay()
+        return self.loss

@@ -659,6 +659,12 @@ int crfconv_sgd_step(float* param, const float* grad, float* momentum_buf, int64
  * when the bucket holds the all-reduce SUM; 1 otherwise); momentum_buf is required (zero-filled when momentum is 0). */
 int crfconv_sgd_step_hyper(float* param, const float* grad, float* momentum_buf, int64_t n, const float* hyper,
                            int nesterov, int first_step, crf_stream_t stream);
+/* The same, guarded by the grid-barrier failure word (crfconv_gridsync_fail_word() of the caller's barrier workspace, device
+ * memory; NULL = unguarded): while *fail_word != 0 the launch changes NOTHING -- a one-launch kernel whose barrier timed out has
+ * NaN-poisoned its outputs and therefore this step's gradient, and parameters / momentum must survive until the host reads the
+ * word (it is sticky; captured replays are protected too). */
+int crfconv_sgd_step_guarded(float* param, const float* grad, float* momentum_buf, int64_t n, const float* hyper,
+                             int nesterov, int first_step, const unsigned* fail_word, crf_stream_t stream);
 
 /* ---- device-side pieces of the collate (datasets/semantic3d_dataset.py:512-528), csrc/collate.hip
  * crfconv_random_subsets: for each level l < nlevels, out[l][0 .. s[l]) (device int64) = a uniformly random subset of

@@ -174,3 +174,29 @@ def test_bench_pipelined_loop_on_two_ranks(tmp_path):
     assert rec['pipelined_ms_per_batch'] is not None and rec['pipelined_ms_per_batch'] > 0
     assert rec['config']['global_batch'] == 4
     assert not [l for l in open(str(tmp_path / 'out.1')).read().splitlines() if l.startswith('{')]      # rank 0 alone reports
+
+
+def test_bench_self_launch_one_rank_over_rccl(tmp_path):
+    """`python bench.py --gpus 1 --spawn` WITHOUT a launcher environment: bench.py itself starts its rank as a child process
+    (before it imports torch or touches the GPU), the child builds the one-rank process group over the `nccl` backend (= RCCL)
+    and runs the whole benchmark through the grouped code path -- the flat all-reduce between the two captured graphs, its own
+    HIP-event time in the line -- and the parent relays the JSON line and the exit status.  The shape of the command the driver
+    uses for `--gpus N` on a multi-GPU node, at the one N this box can run."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'CRFCONV_DIST_BACKEND')}
+    env['OMP_NUM_THREADS'] = '4'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--spawn', '--steps', '4', '--warmup', '1', '--batch', '2',
+           '--points', '8192', '--no-cpu-baseline']
+    with open(str(tmp_path / 'out'), 'w') as fo, open(str(tmp_path / 'err'), 'w') as fe:
+        rc = subprocess.run(cmd, env=env, stdout=fo, stderr=fe, cwd=ROOT, timeout=900).returncode
+    assert rc == 0, open(str(tmp_path / 'err')).read()[-3000:]
+    lines = [l for l in open(str(tmp_path / 'out')).read().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 1 and rec['rccl_ranks_seen'] == 1 and rec['dist_backend'] == 'nccl'
+    assert rec['allreduce_us'] is not None and rec['allreduce_us'] > 0 and rec['value'] > 0
+    assert rec['trainval_eager_ms_per_step'] > 0 and rec['trainval_captured_ms_per_step'] > 0
+    # a failing rank must surface as a non-zero exit status of the parent
+    bad = subprocess.run(cmd + ['--points', '-5'], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT, timeout=600)
+    assert bad.returncode != 0

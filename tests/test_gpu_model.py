@@ -379,6 +379,19 @@ def test_collate_graph_replay_equals_eager_collate():
                     if tab_s._rev is not None:
                         assert all(torch.equal(u, v) for u, v in zip(tab_s.reverse, tab_r.reverse))
                     assert int(tab_s._bad.item()) == 0
+    # subset seeds: a draw on the caller's generator per graph (graphs rebuilt from one generator must not repeat
+    # the same subset sequence), reproducible from equal generator states, resumable through state_dict
+    g7 = torch.Generator().manual_seed(7)
+    a, b = CollateGraph(static, generator=g7), CollateGraph(static, generator=g7)
+    assert a.seed != b.seed and a.seed == cg.seed
+    sd = cg.state_dict()
+    assert sd['seed'] == cg.seed and sd['counter'] == 3
+    pos, x, y = clouds(540)
+    cg.run(pos, x, y)
+    want = [c.clone() for c in cg.choices]
+    b.load_state_dict(sd)                                   # another graph continues the first one's sequence
+    b.run(pos, x, y)
+    assert all(torch.equal(u, v) for u, v in zip(want, b.choices))
 
 
 def test_collate_pipeline_double_buffer_overlaps_without_races():
@@ -1787,6 +1800,121 @@ def test_crf_parameter_gradients_deferred_to_the_end_of_the_pass_equal_the_immed
         res[mode] = [c.grad.clone() for c in cs] + [z.grad.clone() for z in zs] + [y.grad.clone() for y in ys]
     for a, b in zip(res['now'], res['late']):
         assert float(a.abs().max()) > 0 and torch.equal(a, b)
+
+
+def test_captured_step_of_the_unchanged_reference_loop_equals_the_eager_loop():
+    """crfconv_amd.train.CapturedStep around the reference's own step (trainval.py:99-106: zero_grad, model(data),
+    F.cross_entropy(weight, ignore_index), backward, torch.optim.SGD.step) against the same loop run eagerly: three steps on
+    three different batches from equal initial state must leave equal parameters, BatchNorm buffers and losses."""
+    import crfconv_amd
+    import torch.nn.functional as F
+    from crfconv_amd import models
+    from crfconv_amd.train import CapturedStep
+    B, N = 2, 2048
+
+    def batch(seed):
+        pos = np.stack([S.make_cloud(seed + b, N, box=(2, 2, 1)) for b in range(B)])
+        feats = np.concatenate([pos, S.uniform(seed, 'rgb', (B, N, 3), 0, 1)], -1)
+        return crfconv_amd.multiscale_compute(t(pos), x=t(feats), y=t(S.integers(seed, 'y', (B, N), 0, 14)),
+                                              generator=torch.Generator().manual_seed(seed))
+    batches = [batch(900 + 10 * i) for i in range(3)]
+    cw = torch.linspace(0.5, 1.5, 13, device=DEV)
+
+    def loss_fn(out, d):
+        return F.cross_entropy(out, d.y.reshape(-1) - 1, weight=cw, ignore_index=-1)
+    torch.manual_seed(5)
+    ref = models.PointConvBig(6, 13, True, 3).to(DEV).train()
+    net = models.PointConvBig(6, 13, True, 3).to(DEV).train()
+    net.load_state_dict(ref.state_dict())
+    mk = lambda m: torch.optim.SGD(m.parameters(), lr=1e-2, momentum=0.95, weight_decay=1e-4)      # noqa: E731
+    ropt, opt = mk(ref), mk(net)
+    ref_losses = []
+    for d in batches:                                        # the reference loop, eagerly
+        ropt.zero_grad()
+        loss = loss_fn(ref(d), d)
+        loss.backward()
+        ropt.step()
+        ref_losses.append(float(loss))
+    static = batch(900)                                      # the resident batch the graph reads
+    step = CapturedStep(net, opt, loss_fn, static)
+    got_losses = [float(step(d)) for d in batches]
+    torch.cuda.synchronize()
+    for a, b in zip(got_losses, ref_losses):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (got_losses, ref_losses)
+    for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
+        assert_close(a.float(), b.float(), 2e-5, 'after 3 steps: ' + k)
+
+
+def test_crf_late_gradients_with_two_consumers_of_one_matrix_pair_and_a_hook():
+    """(Q, P) of crf_matrices_batched feeding TWO mean-field calls, a tensor hook on Q and another use of P, under
+    ops.deferred_weight_grads: the deferred dP / dQ travel out of band (the node's gradient boxes), so autograd never holds a
+    tensor that the end-of-pass flush has yet to fill -- dc must equal the immediate form's, and the hook must not see garbage."""
+    from crfconv_amd import ops
+    from crfconv_amd.graph import NeighborTable
+    H, n = 32, 2560
+    gg = torch.Generator().manual_seed(11)
+    idx = torch.randint(0, n, (1, n, 16), generator=gg)
+    idx[0, :, 0] = torch.arange(n)
+    tab = NeighborTable(idx.to(DEV), n)
+    z1, y1, z2, y2 = (torch.randn(n, H, generator=gg).to(DEV) for _ in range(4))
+    wgt = torch.linspace(0, 1, n * H, device=DEV).reshape(n, H)
+    res, seen = {}, {}
+    for mode in ('now', 'late'):
+        c = nn.Parameter((torch.eye(H) + 0.1 * torch.randn(H, H, generator=torch.Generator().manual_seed(5))).to(DEV))
+        za, ya, zb, yb = (v.clone().requires_grad_(True) for v in (z1, y1, z2, y2))
+
+        def run():
+            (mat,) = ops.crf_matrices_batched([c])
+            mat[0].register_hook(lambda g, mode=mode: seen.__setitem__(mode, None if g is None else g.detach().clone()))
+            o1 = ops.crf_meanfield(za, ya, c, tab, 3, k0=1, matrices=mat)
+            o2 = ops.crf_meanfield(zb, yb, c, tab, 2, k0=1, matrices=mat)
+            return (o1 * wgt).sum() + 0.5 * (o2 * wgt).sum() + (mat[1] * mat[1]).sum() + mat[0].sum()
+        if mode == 'late':
+            with ops.deferred_weight_grads():
+                run().backward()
+        else:
+            run().backward()
+        torch.cuda.synchronize()
+        res[mode] = [c.grad.clone(), za.grad.clone(), ya.grad.clone(), zb.grad.clone(), yb.grad.clone()]
+    for a, b, what in zip(res['now'], res['late'], ('dc', 'dz1', 'dy1', 'dz2', 'dy2')):
+        assert float(a.abs().max()) > 0 and bool(torch.isfinite(b).all())
+        assert_close(b, a, 1e-6, 'two consumers, late vs immediate: ' + what)
+    # the hook of the late pass saw only what autograd itself carried for Q (the direct use: d sum(Q) = ones), never unfilled memory
+    assert seen['late'] is not None and torch.equal(seen['late'], torch.ones(H, H, device=DEV))
+
+
+def test_flat_sgd_skips_the_update_while_the_barrier_failure_word_is_set():
+    """a step whose one-launch kernel timed out carries a NaN gradient; the update kernel reads the sticky failure
+    word and must leave parameters AND momentum untouched (eager and captured), until ops.check_gridsync clears it."""
+    from crfconv_amd import _lib, ops, optim
+    from crfconv_amd.distributed import FlatGradAllReduce
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(4)
+    net = torch.nn.Linear(9, 17).to(DEV)
+    bucket = FlatGradAllReduce(net)
+    opt = optim.FlatSGD(bucket, lr=0.1, momentum=0.9, weight_decay=1e-4, check_every=0)
+    ws = ops.gridsync_ws(dev)
+    ops.check_gridsync(dev)
+    word = _lib.load().crfconv_gridsync_fail_word()
+    was = ops._small_mlp_disabled
+    try:
+        bucket.flat.fill_(1.0)
+        opt.step()                                           # a healthy step first: momentum buffer is non-zero afterwards
+        p0, b0 = opt.flat.clone(), opt.buf.clone()
+        ws[word] = 0x101
+        bucket.flat.fill_(float('nan'))                      # what a poisoned forward / backward leaves behind
+        for _ in range(3):
+            opt.step()
+        torch.cuda.synchronize()
+        assert torch.equal(opt.flat, p0) and torch.equal(opt.buf, b0)
+        with pytest.raises(_lib.CrfConvError, match='grid barrier timed out'):
+            ops.check_gridsync(dev)
+        bucket.flat.fill_(1.0)
+        opt.step()                                           # word cleared: the update runs again, from intact state
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(opt.flat).all()) and not torch.equal(opt.flat, p0)
+    finally:
+        ops._small_mlp_disabled = was
 
 
 def test_grid_barrier_failure_is_raised_and_disables_the_one_launch_path():

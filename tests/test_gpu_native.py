@@ -299,6 +299,17 @@ def test_argsort_codes_equals_torch_stable_argsort():
         assert torch.equal(run(code), torch.argsort(code, dim=1, stable=True))
     pos = torch.rand(4, 40960, 3, generator=g).to('cuda')
     assert torch.equal(morton_order(pos), torch.argsort(morton_codes(pos), dim=1, stable=True))
+    # degenerate clouds at full size: every point in ONE bucket -- the wavefront-cooperative hub ranking, linear
+    # loads per element instead of N dependent load pairs; and hub + ordinary buckets inside one wavefront, ragged tail
+    dup = torch.full((4, 40960), 777 << 14).to('cuda')
+    assert torch.equal(run(dup), torch.arange(40960, device='cuda').expand(4, -1))
+    mixed = torch.randint(0, 1 << 30, (2, 1003), generator=g)
+    mixed[:, 100:480] = 5 << 14
+    mixed[1, 700:] = (9 << 14) + 3
+    mixed = mixed.to('cuda')
+    assert torch.equal(run(mixed), torch.argsort(mixed, dim=1, stable=True))
+    near = (torch.randint(0, 3, (2, 40960), generator=g) + (4242 << 14)).to('cuda')      # three distinct codes, one bucket
+    assert torch.equal(run(near), torch.argsort(near, dim=1, stable=True))
 
 
 def test_random_subsets_device():
