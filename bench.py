@@ -439,7 +439,7 @@ def reference_loop(net, data, cw, steps):
         loss = loss_fn(net(data), data)
         loss.backward()
         opt.step()
-        return loss
+        return loss.detach()      # (a live loss would keep this iteration's autograd nodes -- AccumulateGrad included -- alive)
     for _ in range(3):
         one()
     torch.cuda.synchronize()

@@ -15,6 +15,10 @@
 // Reference semantics: models/continuous_crf_conv_big.py:49-54 (similarity), :63-72 (loop).
 #include "crf_common.hpp"
 
+#ifndef CRF_GATHER_SRD
+#define CRF_GATHER_SRD 1      // neighbour rows through a buffer resource with 32-bit byte offsets (0: generic 64-bit pointers, the A/B baseline)
+#endif
+
 namespace crf {
 
 
@@ -39,8 +43,15 @@ __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_f
 
     // issue order = arrival order: the index row first (the gathers wait for nothing else), then the own rows and the
     // matrices, which are only needed behind the gathers
+#if CRF_GATHER_SRD
+    int off[K];                                   // byte offsets of the neighbour rows: buffer loads, 32-bit address arithmetic
+    load_index_offsets_t<K, U16, H>(idx, idx16, r, n_tgt, n_src, q, off);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y, (int)(m * H * 4));
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rz = make_rsrc(z, (int)(m * H * 4));
+#else
     int j[K];
     load_index_row_t<K, U16>(idx, idx16, r, n_tgt, n_src, j);
+#endif
     const float4 yi = ld4(y + r * H + 4 * q);
     [[maybe_unused]] float4 zi = make_float4(0.f, 0.f, 0.f, 0.f);
     [[maybe_unused]] MatStage<H> mq, mp;
@@ -51,7 +62,11 @@ __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_f
     }
     float4 nb[K];
 #pragma unroll
+#if CRF_GATHER_SRD
+    for (int k = 1; k < K; ++k) nb[k] = ld4_buf(ry, off[k]);
+#else
     for (int k = 1; k < K; ++k) nb[k] = ld4(y + (int64_t)j[k] * H + 4 * q);
+#endif
     float d[K];
     float dmin = 3.4e38f;
 #pragma unroll
@@ -62,7 +77,11 @@ __global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_f
     }
     if constexpr (WITH_STEP) {   // issue the z-row gathers before the exp chain
 #pragma unroll
+#if CRF_GATHER_SRD
+        for (int k = 1; k < K; ++k) nb[k] = ld4_buf(rz, off[k]);
+#else
         for (int k = 1; k < K; ++k) nb[k] = ld4(z + (int64_t)j[k] * H + 4 * q);
+#endif
         mq.park(sQ);
         mp.park(sP);
     }
@@ -103,9 +122,17 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
     int lane, q;
     bool valid;
     const int64_t r = my_point<H>(m, lane, q, valid);
-    int j[K];
     float w[K];
+#if CRF_GATHER_SRD
+    int off[K];
+    load_index_offsets_t<K, U16, H>(idx, idx16, r, n_tgt, n_src, q, off);  // first: the gathers wait for this row only
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xin, (int)(m * H * 4));
+#define CRF_GATHER_X(k) ld4_buf(rx, off[k])
+#else
+    int j[K];
     load_index_row_t<K, U16>(idx, idx16, r, n_tgt, n_src, j);              // first: the gathers wait for this row only
+#define CRF_GATHER_X(k) ld4(xin + (int64_t)j[k] * H + 4 * q)
+#endif
     load_row<K, float4>(s + r * K, w);
     const float4 zi = ld4(z + r * H + 4 * q);
     MatStage<H> mp, mq;
@@ -116,13 +143,13 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
     {
         float4 nb[K / 2];
 #pragma unroll
-        for (int k = 1; k < K / 2; ++k) nb[k] = ld4(xin + (int64_t)j[k] * H + 4 * q);
+        for (int k = 1; k < K / 2; ++k) nb[k] = CRF_GATHER_X(k);
         mp.park(sP);
         mq.park(sQ);
 #pragma unroll
         for (int k = 1; k < K / 2; ++k) msg = fma4(w[k], nb[k], msg);
 #pragma unroll
-        for (int k = 0; k < K / 2; ++k) nb[k] = ld4(xin + (int64_t)j[K / 2 + k] * H + 4 * q);
+        for (int k = 0; k < K / 2; ++k) nb[k] = CRF_GATHER_X(K / 2 + k);
 #pragma unroll
         for (int k = 0; k < K / 2; ++k) msg = fma4(w[K / 2 + k], nb[k], msg);
     }
@@ -131,6 +158,7 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
     const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
     const float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
     if (valid) st4(xout + r * H + 4 * q, o);
+#undef CRF_GATHER_X
 }
 
 // ====================================================================== fused forward: all T steps in ONE launch
@@ -1020,11 +1048,12 @@ static int meanfield_forward_impl(const float* z, const float* y, const int32_t*
     if (int rc = check_common(m, H, K, k0)) return rc;
     CRF_REQUIRE(z && y && idx32 && Q && P && (xs || T == 0), CRF_ERR_ARG, "null pointer");
     // s may be NULL when nothing reads it back: a single fused step (T == 1) on the fast path, no backward pass
-    CRF_REQUIRE(s || (T == 1 && k0 == 1 && (K == 16 || K == 32) && !g_use_window), CRF_ERR_ARG,
+    CRF_REQUIRE(s || (T == 1 && k0 == 1 && (K == 16 || K == 32) && !g_use_window && m * H * 4 < ((int64_t)1 << 31)), CRF_ERR_ARG,
                 "s == NULL needs T == 1 on the fused first-step kernel (K in {16, 32}, k0 == 1)");
     CRF_REQUIRE(T >= 0, CRF_ERR_ARG, "T=%d < 0", T);
     hipStream_t st = as_stream(stream);
-    const bool fast = (k0 == 1) && (K == 16 || K == 32);
+    // (the fast kernels address neighbour rows by 32-bit byte offsets: tables of 2 GiB and more take the generic kernels)
+    const bool fast = (k0 == 1) && (K == 16 || K == 32) && m * H * 4 < ((int64_t)1 << 31);
     DISPATCH_H(H, {
         const dim3 grid((unsigned)cdiv(m, Geo<HH>::PPB)), blk(BLOCK);
         int t0 = 0;

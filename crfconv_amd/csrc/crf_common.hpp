@@ -94,6 +94,35 @@ __device__ __forceinline__ void load_index_row_t(const int32_t* __restrict__ idx
         load_row<K, int4>(idx32 + r * K, j);
     }
 }
+// The same row as BYTE OFFSETS of this lane's 16-byte piece of each neighbour row ([*, H] float table: row j starts at
+// 4 H j, the lane's piece at + 16 q): what a buffer load through a resource descriptor takes as its 32-bit address operand.
+// One VGPR and one 32-bit shift-add per neighbour, where a generic 64-bit pointer costs two VGPRs and a 64-bit multiply-add
+// chain (the forward kernels issue 15-30 such gathers per point).  Needs rows * 4 H < 2^31 (the launcher checks).
+template <int K, bool U16, int H>
+__device__ __forceinline__ void load_index_offsets_t(const int32_t* __restrict__ idx32, const uint16_t* __restrict__ idx16,
+                                                     int64_t r, int n_tgt, int n_src, int q, int (&off)[K]) {
+    constexpr int RB = 4 * H;                                                  // bytes per row
+    if constexpr (U16) {
+        const int base = (int)((unsigned)r / (unsigned)n_tgt) * n_src * RB + 16 * q;
+        const uint4* p = reinterpret_cast<const uint4*>(idx16 + r * K);
+#pragma unroll
+        for (int c = 0; c < K / 8; ++c) {
+            const uint4 v = p[c];
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                off[8 * c + 2 * e] = base + (int)(w[e] & 0xffffu) * RB;
+                off[8 * c + 2 * e + 1] = base + (int)(w[e] >> 16) * RB;
+            }
+        }
+    } else {
+        int j[K];
+        load_row<K, int4>(idx32 + r * K, j);
+#pragma unroll
+        for (int k = 0; k < K; ++k) off[k] = j[k] * RB + 16 * q;
+    }
+}
+
 template <int K>
 __device__ __forceinline__ void load_index_row(const int32_t* __restrict__ idx32, const uint16_t* __restrict__ idx16,
                                                int64_t r, int n_tgt, int n_src, int (&j)[K]) {

@@ -6,7 +6,10 @@
 
 `optimizer` is any torch.optim optimizer whose step() is capturable as is (torch.optim.SGD with float hyper-parameters: a
 learning-rate change needs a new CapturedStep) or optim.FlatSGD (then pass after_backward=bucket.pack).  `loss_fn(logits,
-batch)` is the caller's, e.g. ``lambda o, d: F.cross_entropy(o, d.y.reshape(-1) - 1, weight=w, ignore_index=-1)``."""
+batch)` is the caller's, e.g. ``lambda o, d: F.cross_entropy(o, d.y.reshape(-1) - 1, weight=w, ignore_index=-1)``.
+Drop (or detach) losses of earlier EAGER steps of the same model before constructing it: a live loss keeps that step's
+autograd nodes -- the parameters' AccumulateGrad nodes, bound to the stream they were created on -- alive, and the capture
+would then have to synchronise with that stream."""
 import torch
 
 

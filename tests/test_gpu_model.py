@@ -1810,7 +1810,7 @@ def test_captured_step_of_the_unchanged_reference_loop_equals_the_eager_loop():
     import torch.nn.functional as F
     from crfconv_amd import models
     from crfconv_amd.train import CapturedStep
-    B, N = 2, 2048
+    B, N = 2, 8192
 
     def batch(seed):
         pos = np.stack([S.make_cloud(seed + b, N, box=(2, 2, 1)) for b in range(B)])
