@@ -113,8 +113,9 @@ def _meanfield_problem(data, dev, H, seed=1, level=0):
 
 
 def _event_time(launch, per=10, regions=20):
-    """Average duration of one `launch()` on the current stream, HIP events around `per` consecutive launches (an event
-    pair per launch adds ~3 us of record latency to a ~25 us region), over `regions` regions."""
+    """Average duration of one `launch()` on the current stream: HIP events around `per` consecutive launches (an event
+    pair per launch adds ~3 us of record latency to a ~25 us region) give one average per region; returns the median of
+    `regions` such averages and the smallest."""
     for _ in range(10):
         launch()
     torch.cuda.synchronize()
@@ -126,7 +127,9 @@ def _event_time(launch, per=10, regions=20):
         b.record()
     torch.cuda.synchronize()
     dur = np.array([a.elapsed_time(b) for a, b in evs]) * 1e-3 / per
-    return float(dur.mean()), float(dur.min())
+    # every region is already the AVERAGE over `per` launches; across regions the median, so that one region hit by an unrelated
+    # stall of the box (seen: a single 10 ms region among twenty ~25 us ones) does not decide the figure
+    return float(np.median(dur)), float(dur.min())
 
 
 def _measured_traffic(name, config):

@@ -28,6 +28,10 @@
 // record -> gather rounds (waves waited 62-66 % of their cycles, profiles/r2b_meanfield_pmc.md).
 #include "crf_common.hpp"
 
+#ifndef CRF_GATHER_SRD
+#define CRF_GATHER_SRD 1      // row gathers of the reverse walks through a buffer resource with 32-bit byte offsets (0: 64-bit pointers)
+#endif
+
 namespace crf {
 
 struct __attribute__((aligned(8))) RevEdge {
@@ -154,6 +158,10 @@ __global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE)) void bwd_rev_kernel(const
     if constexpr (FINAL) yj = ld4(a.y + row * H + 4 * q);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);                          // sum s G[i]
     [[maybe_unused]] float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);        // sum w (y_j - y_i)
+#if CRF_GATHER_SRD
+    const __amdgpu_buffer_rsrc_t rG = make_rsrc(a.Gin, (int)(m * H * 4));
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rY = make_rsrc(FINAL ? a.y : a.Gin, (int)(m * H * 4));
+#endif
 
     auto chunk = [&](const int c0) {
         // Phases 1 and 2 are BRANCH-FREE: every round is issued, rounds (lanes) past the wave's range re-read its last
@@ -189,9 +197,15 @@ __global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE)) void bwd_rev_kernel(const
             static_for<L>([&](auto SB) {
                 constexpr int sb = decltype(SB)::value;
                 const int ee = __float_as_int(group_bcast<L, sb>(__int_as_float(e[rr]), lane - q));
+#if CRF_GATHER_SRD
+                const int boff = (ee >> KSH) * (4 * H) + 16 * q;      // 32-bit byte offset on a buffer resource (see crf.hip)
+                g[rr][sb] = ld4_buf(rG, boff);
+                if constexpr (FINAL) gy[rr][sb] = ld4_buf(rY, boff);
+#else
                 const int64_t i = ee >> KSH;
                 g[rr][sb] = ld4(a.Gin + i * H + 4 * q);
                 if constexpr (FINAL) gy[rr][sb] = ld4(a.y + i * H + 4 * q);
+#endif
             });
         }
         if constexpr (FIRST) {
@@ -469,6 +483,8 @@ extern "C" int crfconv_meanfield_backward(const float* gout, const float* z, con
     CRF_REQUIRE(crfconv_meanfield_backward_supported(H, K, k0) == 1 && T >= 1, CRF_ERR_UNSUPPORTED,
                 "restructured mean-field backward: K=%d k0=%d T=%d not supported", K, k0, T);
     const bool inside = crfconv_meanfield_backward_param_grads_inside(H) == 1;
+    CRF_REQUIRE(m * H * 4 < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "m=%lld x H=%d: row tables of 2 GiB and more are not addressable "
+                "by the kernels' 32-bit byte offsets", (long long)m, H);
     CRF_REQUIRE(gout && z && y && s && xs && idx32 && rev_ptr && rev_eid && Q && P && Gs && dzq && dz && w && dy_self &&
                 dy && ws, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(inside ? (dP && dQ && ticket) : (mts && sumG), CRF_ERR_ARG,

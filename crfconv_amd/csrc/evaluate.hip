@@ -9,7 +9,7 @@
 // Integer / byte work and streaming reductions: HBM-bound, no LDS tiling beyond block-local histograms.
 #include "common.hpp"
 
-#include <rocprim/rocprim.hpp>
+#include "radix_sort.hpp"
 
 namespace crf {
 
@@ -221,13 +221,7 @@ __global__ __launch_bounds__(EV_BLOCK) void crop_update_kernel(const float* __re
 
 static size_t ev_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static size_t crop_sort_temp(int64_t n) {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                    (const unsigned int*)nullptr, (unsigned int*)nullptr, (size_t)n, 0, 64,
-                                    (hipStream_t)0);
-    return bytes;
-}
+static size_t crop_sort_temp(int64_t n) { return rsort_workspace(n); }      // this library's radix sort (radix_sort.hpp)
 
 constexpr int ARGMIN_BLOCKS = 1024;
 
@@ -334,7 +328,9 @@ extern "C" int crfconv_possibility_crop(const float* points, int64_t n, int64_t 
                        keys_in, ids_in);
     CRF_LAUNCH_CHECK();
     // stable LSD radix sort: equal distances keep ascending point order (the KD-tree's order on ties is unspecified)
-    CRF_HIP(rocprim::radix_sort_pairs(ws, temp_bytes, keys_in, keys_out, ids_in, ids_out, (size_t)n, 0, 64, st));
+    (void)temp_bytes;
+    if (rsort_pairs_u64(keys_in, ids_in, keys_out, ids_out, n, 0, 64, ws, st) == 0) ids_out = ids_in;      // float64 keys: all eight digits
+    CRF_LAUNCH_CHECK();
     hipLaunchKernelGGL(crop_dist_kernel, dim3((unsigned)nblk), dim3(EV_BLOCK), 0, st, points, ids_out, k, center, dist, pmax);
     CRF_LAUNCH_CHECK();
     hipLaunchKernelGGL(crop_update_kernel, dim3((unsigned)nblk), dim3(EV_BLOCK), 0, st, points, ids_out, perm, k, center,

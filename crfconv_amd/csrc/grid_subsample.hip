@@ -8,7 +8,7 @@
 // Output rows are in ascending voxel key (the reference: hash-map iteration order).
 #include "common.hpp"
 
-#include <rocprim/rocprim.hpp>
+#include "radix_sort.hpp"
 
 namespace crf {
 
@@ -180,11 +180,8 @@ static GsLayout gs_layout(int64_t N) {
     L.off_ord = o;   o += al(sizeof(int32_t) * N);
     L.off_start = o; o += al(sizeof(int32_t) * (N + 1));
     L.off_count = o; o += al(sizeof(int32_t));
-    size_t t1 = 0, t2 = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, t1, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                    (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)N, 0, 64, (hipStream_t)0);
-    (void)rocprim::exclusive_scan(nullptr, t2, (const int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)N,
-                                  rocprim::plus<int32_t>(), (hipStream_t)0);
+    // scratch of this library's radix sort (radix_sort.hpp) and of the scan over the voxel heads (scan.hpp)
+    const size_t t1 = rsort_workspace(N), t2 = sizeof(int32_t) * scan_block_sums(N) + 256;
     L.temp_bytes = t1 > t2 ? t1 : t2;
     L.off_temp = o;  o += al(L.temp_bytes);
     L.total = o + 256;
@@ -238,12 +235,18 @@ extern "C" int64_t crfconv_grid_subsample_dev(const float* points, int64_t N, co
     const dim3 flat((unsigned)cdiv(N, 256));
     hipLaunchKernelGGL(gs_keys_kernel, flat, dim3(256), 0, st, points, N, gd, keys, ids);
     CRF_LAUNCH_CHECK();
-    size_t tb = L.temp_bytes;
-    CRF_HIP(rocprim::radix_sort_pairs(temp, tb, keys, skeys, ids, sids, (size_t)N, 0, 64, st));
+    // stable sort of (voxel key, point id): points of a voxel stay in arrival order (grid_subsampling.cpp:58-63 sums in that order).
+    // All eight digits are sorted: how many key bits are in use is device data (GridDims), and a pass whose digit is the same for
+    // every point costs 32 B per point -- less than reading the answer back would
+    if (rsort_pairs_u64(keys, ids, skeys, sids, N, 0, 64, temp, st) == 0) {
+        auto* tk = keys; keys = skeys; skeys = tk;           // (eight passes end in the first pair of buffers)
+        auto* ti = ids; ids = sids; sids = ti;
+    }
+    CRF_LAUNCH_CHECK();
     hipLaunchKernelGGL(gs_heads_kernel, flat, dim3(256), 0, st, skeys, N, head);
     CRF_LAUNCH_CHECK();
-    tb = L.temp_bytes;
-    CRF_HIP(rocprim::exclusive_scan(temp, tb, head, ord, 0, (size_t)N, rocprim::plus<int32_t>(), st));
+    exclusive_scan_i32(head, ord, N, reinterpret_cast<int32_t*>(temp), st);
+    CRF_LAUNCH_CHECK();
     hipLaunchKernelGGL(gs_starts_kernel, flat, dim3(256), 0, st, head, ord, N, seg_start, count);
     CRF_LAUNCH_CHECK();
     // the reduce kernel reads M from device memory; launch for the worst case (M <= min(N, cap) rows written)

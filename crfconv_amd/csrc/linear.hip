@@ -729,45 +729,48 @@ __global__ __launch_bounds__(256) void spd_inverse_kernel(const float* __restric
 
 // The two loop-invariant matrices of a CRF layer from its compatibility factor c [H, H] in one launch:
 //   Q = (I + c^T c)^-1,   P = c^T c Q = I - Q            (continuous_crf_conv_big.py:67-72)
-// 1024-thread form of the Gauss-Jordan sweep above: 32 x 32 threads, a 2 x 2 tile of the (<= 64 x 64) matrix each -- four
-// float64 updates per thread and pivot instead of sixteen (the 64 pivots are sequential: 42 us with 256 threads).
-constexpr int CMF_BLOCK = 1024;
-__device__ __forceinline__ void gauss_jordan_tiles32(double (&t)[2][2], int H, double (*s_row)[64], double (*s_col)[64]) {
-    const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
+// The 64 pivots of the Gauss-Jordan sweep are sequential, and what a pivot costs is the INSTRUCTIONS every wavefront issues
+// around its handful of float64 multiply-adds (barrier, LDS traffic, the reciprocal, the selects that treat pivot row /
+// column / element apart) -- round 3's 1024-thread form (2 x 2 tiles, sixteen wavefronts on one CU) took 35 us for the four
+// layers of PointConvBig.  This form: 256 threads, a 4 x 4 cyclic tile each (one wavefront per SIMD: the per-pivot overhead is
+// paid once per SIMD, not four times), the pivot row and column in LDS in TILE-MAJOR order (a thread's four values are one
+// 32-byte segment), 1 / pivot by the hardware estimate + two Newton steps, and NO special cases in the update: with
+//   col'[p] = pivot - 1  (threads that own the pivot row)      row'[p] = 1 + 1 / pivot  (threads that own the pivot column)
+// the one fused multiply-add  t -= col' * row'  leaves row * (1 / pivot) in the pivot row, -col / pivot in the pivot column and
+// 1 / pivot in the pivot itself (pivot * (1 / pivot) = 1 up to float64 rounding).
+constexpr int CMF_BLOCK = 256;
+__device__ __forceinline__ void gauss_jordan_fma(double (&t)[4][4], int H, double (*s_row)[64], double (*s_col)[64]) {
+    const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
 #pragma unroll
-    for (int ip = 0; ip < 2; ++ip) {                     // pivot p = 32 ip + pp lives in local row / column ip
-        for (int pp = 0; pp < 32; ++pp) {
-            const int p = 32 * ip + pp;
+    for (int ip = 0; ip < 4; ++ip) {                     // pivot p = 16 ip + pp lives in local row / column ip
+        for (int pp = 0; pp < 16; ++pp) {
+            const int p = 16 * ip + pp;
             if (p >= H) break;                           // uniform: rows beyond H are identity already
             const int b = p & 1;
             if (tr == pp) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) s_row[b][tc + 32 * j] = t[ip][j];
+                for (int j = 0; j < 4; ++j) s_row[b][4 * tc + j] = t[ip][j];       // column tc + 16 j of row p
             }
             if (tc == pp) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) s_col[b][tr + 32 * i] = t[i][ip];
+                for (int i = 0; i < 4; ++i) s_col[b][4 * tr + i] = t[i][ip];       // row tr + 16 i of column p
             }
             __syncthreads();
-            // 1 / pivot: hardware estimate + two Newton steps (full double precision for a well-scaled SPD pivot) instead of
-            // the ~40-instruction IEEE division every thread would run on each of the 64 sequential pivots
-            const double pv = s_row[b][p];
+            const double pv = s_row[b][4 * pp + ip];                              // element (p, p)
             double piv = __builtin_amdgcn_rcp(pv);
             piv = fma(piv, fma(-pv, piv, 1.0), piv);
             piv = fma(piv, fma(-pv, piv, 1.0), piv);
-            double rowv[2], colv[2];
+            double rowv[4], colv[4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) rowv[j] = s_row[b][tc + 32 * j] * piv;
+            for (int j = 0; j < 4; ++j) rowv[j] = s_row[b][4 * tc + j] * piv;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) colv[i] = s_col[b][tr + 32 * i];
+            for (int i = 0; i < 4; ++i) colv[i] = s_col[b][4 * tr + i];
+            if (tc == pp) rowv[ip] = 1.0 + piv;
+            if (tr == pp) colv[ip] = pv - 1.0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const bool rp = (i == ip) && (tr == pp), cp = (j == ip) && (tc == pp);
-                    const double upd = t[i][j] - colv[i] * rowv[j];
-                    t[i][j] = rp ? (cp ? piv : rowv[j]) : (cp ? -colv[i] * piv : upd);
-                }
+                for (int j = 0; j < 4; ++j) t[i][j] = fma(-colv[i], rowv[j], t[i][j]);
         }
     }
 }
@@ -775,26 +778,33 @@ __device__ __forceinline__ void crf_matrices_body(const float* __restrict__ cmat
                                                   float* __restrict__ Qout, float* __restrict__ Pout) {
     __shared__ double s_row[2][64], s_col[2][64];
     __shared__ float s_c[64 * 65];
+    for (int e = threadIdx.x; e < 64 * 65; e += CMF_BLOCK) s_c[e] = 0.f;           // columns >= H of c: zero (M stays identity there)
+    __syncthreads();
     for (int e = threadIdx.x; e < H * H; e += CMF_BLOCK) s_c[(e / H) * 65 + (e % H)] = cmat[e];
     __syncthreads();
-    const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
-    double t[2][2];
+    const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
+    double t[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = tr + 32 * i, c = tc + 32 * j;
-            double a = r == c ? 1.0 : 0.0;
-            if (r < H && c < H)
-                for (int k = 0; k < H; ++k) a += (double)s_c[k * 65 + r] * (double)s_c[k * 65 + c];
-            t[i][j] = a;
-        }
-    gauss_jordan_tiles32(t, H, s_row, s_col);
+        for (int j = 0; j < 4; ++j) t[i][j] = (tr + 16 * i == tc + 16 * j) ? 1.0 : 0.0;
+    for (int k = 0; k < H; ++k) {                        // M = I + c^T c: eight LDS reads feed sixteen multiply-adds
+        double a[4], bq[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i) a[i] = (double)s_c[k * 65 + tr + 16 * i];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = tr + 32 * i, c = tc + 32 * j;
+        for (int j = 0; j < 4; ++j) bq[j] = (double)s_c[k * 65 + tc + 16 * j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[i][j] = fma(a[i], bq[j], t[i][j]);
+    }
+    gauss_jordan_fma(t, H, s_row, s_col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = tr + 16 * i, c = tc + 16 * j;
             if (r < H && c < H) {
                 Qout[r * H + c] = (float)t[i][j];
                 Pout[r * H + c] = (float)((r == c ? 1.0 : 0.0) - t[i][j]);
@@ -802,8 +812,6 @@ __device__ __forceinline__ void crf_matrices_body(const float* __restrict__ cmat
         }
 }
 
-// dc from dQ and dP (either may be NULL = zero).  With D = dQ - dP (P = I - Q), M = I + c^T c:
-//   dM = -Q^T D Q^T,   dc = c (dM + dM^T) = -c (S + S^T),   S = Q^T D Q^T.
 __global__ __launch_bounds__(CMF_BLOCK) void crf_matrices_kernel(const float* __restrict__ cmat, int H,
                                                            float* __restrict__ Qout, float* __restrict__ Pout) {
     crf_matrices_body(cmat, H, Qout, Pout);
@@ -821,56 +829,61 @@ struct CrfMatJobs {
     float* P[CM_MAX];
     float* dc[CM_MAX];
     int H[CM_MAX];
+    int slab_base[CM_MAX + 1];                     // backward: prefix of ceil(H / CMB_ROWS) -- first workgroup of each layer
 };
 __global__ __launch_bounds__(CMF_BLOCK) void crf_matrices_batched_kernel(const CrfMatJobs j) {
     const int b = blockIdx.x;
     crf_matrices_body(j.c[b], j.H[b], j.Q[b], j.P[b]);
 }
 
-constexpr int CMB_BLOCK = 1024;      // three H^3 float64 products: 4 output elements per thread at H = 64 (16 with 256 threads: 55 us)
-__device__ __forceinline__ void crf_matrices_bwd_body(const float* __restrict__ cmat, const float* __restrict__ Q,
+// dc from dQ and dP (either may be NULL = zero).  With D = dQ - dP (P = I - Q), M = I + c^T c:
+//   dM = -Q^T D Q^T,   dc = c (dM + dM^T) = -c (S + S^T),   S = Q^T D Q^T.
+// Q is symmetric (the inverse of a symmetric matrix; its float rounding included, to ~1e-8), so S + S^T = Q (D + D^T) Q and
+//   dc = -((c Q) (D + D^T)) Q
+// is a chain of three products in which every ROW of the result depends on the same row of c only: a workgroup takes a slab
+// of CMB_ROWS rows through all three products without ever meeting another workgroup (H / CMB_ROWS workgroups per layer,
+// float64 accumulation, operands as float in LDS).  The one-workgroup form (T = Q^T D, S = T Q^T, c (S + S^T): three full
+// H^3 float64 products on 1024 threads of ONE CU, 35 us for the four layers of PointConvBig) was instruction-bound.
+constexpr int CMB_ROWS = 8, CMB_BLOCK = CMB_ROWS * 64;
+__device__ __forceinline__ void crf_matrices_bwd_slab(const float* __restrict__ cmat, const float* __restrict__ Q,
                                                       const float* __restrict__ dQ, const float* __restrict__ dP,
-                                                      int H, float* __restrict__ dc) {
-    __shared__ float s_a[64 * 65], s_b[64 * 65], s_t[64 * 65];
+                                                      int H, int row0, float* __restrict__ dc) {
+    __shared__ float s_q[64 * 65], s_d[64 * 65];
+    __shared__ double s_t[2][CMB_ROWS][65];
     for (int e = threadIdx.x; e < H * H; e += CMB_BLOCK) {
         const int r = e / H, c = e % H;
-        s_a[r * 65 + c] = Q[c * H + r];                                       // Q^T
-        s_b[r * 65 + c] = (dQ ? dQ[e] : 0.f) - (dP ? dP[e] : 0.f);            // D
+        s_q[r * 65 + c] = Q[e];
+        s_d[r * 65 + c] = (dQ ? dQ[e] : 0.f) - (dP ? dP[e] : 0.f);            // D
     }
+    const int r = threadIdx.x >> 6, j = threadIdx.x & 63, row = row0 + r;
+    const bool live = row < H && j < H;
+    if (live) s_t[0][r][j] = (double)cmat[row * H + j];
     __syncthreads();
-    auto matmul = [&](const float* A, const float* B, float* out, bool sym_neg) {   // out = A B  (H x H, LDS stride 65)
-        for (int e = threadIdx.x; e < H * H; e += CMB_BLOCK) {
-            const int r = e / H, c = e % H;
-            double acc = 0.0;
-            for (int k = 0; k < H; ++k) acc += (double)A[r * 65 + k] * (double)B[k * 65 + c];
-            out[r * 65 + c] = (float)acc;
-        }
-        __syncthreads();
-    };
-    matmul(s_a, s_b, s_t, false);                        // T = Q^T D
-    matmul(s_t, s_a, s_b, false);                        // S = T Q^T          (s_b reused)
-    for (int e = threadIdx.x; e < H * H; e += CMB_BLOCK) {     // s_t = -(S + S^T)
-        const int r = e / H, c = e % H;
-        s_t[r * 65 + c] = -(s_b[r * 65 + c] + s_b[c * 65 + r]);
-    }
+    double acc = 0.0;
+    if (live)
+        for (int k = 0; k < H; ++k) acc += s_t[0][r][k] * (double)s_q[k * 65 + j];                 // (c Q)[row][j]
+    if (live) s_t[1][r][j] = acc;
     __syncthreads();
-    for (int e = threadIdx.x; e < H * H; e += CMB_BLOCK) s_a[(e / H) * 65 + (e % H)] = cmat[e];
+    acc = 0.0;
+    if (live)
+        for (int k = 0; k < H; ++k) acc += s_t[1][r][k] * ((double)s_d[k * 65 + j] + (double)s_d[j * 65 + k]);   // . (D + D^T)
+    if (live) s_t[0][r][j] = acc;
     __syncthreads();
-    for (int e = threadIdx.x; e < H * H; e += CMB_BLOCK) {
-        const int r = e / H, c = e % H;
-        double acc = 0.0;
-        for (int k = 0; k < H; ++k) acc += (double)s_a[r * 65 + k] * (double)s_t[k * 65 + c];
-        dc[e] = (float)acc;
+    acc = 0.0;
+    if (live) {
+        for (int k = 0; k < H; ++k) acc += s_t[0][r][k] * (double)s_q[k * 65 + j];                 // . Q
+        dc[row * H + j] = (float)(-acc);
     }
 }
 __global__ __launch_bounds__(CMB_BLOCK) void crf_matrices_bwd_kernel(const float* __restrict__ cmat, const float* __restrict__ Q,
                                                                const float* __restrict__ dQ, const float* __restrict__ dP,
                                                                int H, float* __restrict__ dc) {
-    crf_matrices_bwd_body(cmat, Q, dQ, dP, H, dc);
+    crf_matrices_bwd_slab(cmat, Q, dQ, dP, H, (int)blockIdx.x * CMB_ROWS, dc);
 }
 __global__ __launch_bounds__(CMB_BLOCK) void crf_matrices_bwd_batched_kernel(const CrfMatJobs j) {
-    const int b = blockIdx.x;
-    crf_matrices_bwd_body(j.c[b], j.Q_in[b], j.gQ[b], j.gP[b], j.H[b], j.dc[b]);
+    int b = 0;                                                  // layer of this workgroup: slab_base is a prefix over the layers
+    while (b + 1 < CM_MAX && (int)blockIdx.x >= j.slab_base[b + 1]) ++b;
+    crf_matrices_bwd_slab(j.c[b], j.Q_in[b], j.gQ[b], j.gP[b], j.H[b], ((int)blockIdx.x - j.slab_base[b]) * CMB_ROWS, j.dc[b]);
 }
 }  // namespace crf
 
@@ -895,8 +908,10 @@ extern "C" int crfconv_crf_matrices_backward_batched(const float* const* c, cons
     for (int i = 0; i < n; ++i) {
         CRF_REQUIRE(c[i] && Q[i] && dc[i] && H[i] >= 1 && H[i] <= 64, CRF_ERR_ARG, "job %d: null pointer or H=%d outside [1, 64]", i, H[i]);
         j.c[i] = c[i]; j.Q_in[i] = Q[i]; j.gQ[i] = gQ[i]; j.gP[i] = gP[i]; j.dc[i] = dc[i]; j.H[i] = H[i];
+        j.slab_base[i + 1] = j.slab_base[i] + (H[i] + crf::CMB_ROWS - 1) / crf::CMB_ROWS;
     }
-    hipLaunchKernelGGL(crf::crf_matrices_bwd_batched_kernel, dim3((unsigned)n), dim3(crf::CMB_BLOCK), 0, crf::as_stream(stream), j);
+    for (int i = n; i < crf::CM_MAX; ++i) j.slab_base[i + 1] = 0x7fffffff;      // (never reached by a block index)
+    hipLaunchKernelGGL(crf::crf_matrices_bwd_batched_kernel, dim3((unsigned)j.slab_base[n]), dim3(crf::CMB_BLOCK), 0, crf::as_stream(stream), j);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
@@ -921,7 +936,8 @@ extern "C" int crfconv_crf_matrices_backward(const float* c, const float* Q, con
                                              float* dc, crf_stream_t stream) {
     CRF_REQUIRE(c && Q && dc, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(H >= 1 && H <= 64, CRF_ERR_UNSUPPORTED, "H=%d outside [1, 64]", H);
-    hipLaunchKernelGGL(crf::crf_matrices_bwd_kernel, dim3(1), dim3(crf::CMB_BLOCK), 0, crf::as_stream(stream), c, Q, dQ, dP, H, dc);
+    hipLaunchKernelGGL(crf::crf_matrices_bwd_kernel, dim3((unsigned)((H + crf::CMB_ROWS - 1) / crf::CMB_ROWS)), dim3(crf::CMB_BLOCK), 0,
+                       crf::as_stream(stream), c, Q, dQ, dP, H, dc);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
