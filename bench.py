@@ -68,6 +68,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12           # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
 TRAFFIC_FWD, TRAFFIC_BWD = 'r4_meanfield_traffic.json', 'r4_meanfield_bwd_traffic.json'      # PMC passes, sha1-keyed to the kernel sources
+TRAFFIC_STEP, TRAFFIC_PC = 'r4_step_traffic.json', 'r4_pointconv_traffic.json'
 BOX = (8.0, 8.0, 3.0)
 VOX = 0.04
 
@@ -177,18 +178,6 @@ def roofline_meanfield(data, dev, H=8, T=3, level=0):
            'note': 'isolated synthetic problem, 10 back-to-back launches per event pair: the %.1f MB working set stays resident in '
                    'the 256 MiB Infinity Cache between launches (as it does between the consecutive kernels of the real step, '
                    'whose in-step times agree); peak = the 8 TB/s HBM3E figure' % (alg_bytes / 1e6)}
-    if level != 0:
-        return out
-    # the one-launch variant of the same forward (crfconv_meanfield_forward_fused), measured beside it
-    lib = _lib.load()
-    if lib.crfconv_meanfield_fused_supported(m, H, K, 1, T) == 1:
-        wsb = lib.crfconv_meanfield_fused_workspace()
-        ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
-
-        def launch_fused():
-            _lib.call('crfconv_meanfield_forward_fused', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src,
-                      K, 1, m, H, ptr(Q), ptr(P), T, ptr(s), ptr(xs), ptr(ws), wsb, st)
-        out['fused_one_launch_variant_us'] = _event_time(launch_fused)[0] * 1e6
     return out
 
 
@@ -261,6 +250,69 @@ def roofline_layer(data, dev, T=3, level0=None):
             'kernel': 'mean-field layer, all %d decoder levels, forward + backward (frac / achieved); fwd_frac = forward only' % len(per)}
 
 
+def step_byte_model(B, N, K, T, n_cls, in_channels=6, widths=(32, 64, 128, 256, 512), ratio=(4, 4, 4, 4, 2)):
+    """ALGORITHMIC bytes of ONE training step (fwd + loss + bwd + SGD) of PointConvBig at (B, N, K, T): every operator reads each of
+    its operands once and writes each result once, fp32 values, int32 indices -- BatchNorm statistics, activations, residual joins and
+    dropout counted as fused into the producing / consuming Linear (no pass of their own), nothing re-read.  The same accounting as
+    SURVEY 8(d) uses for the mean-field kernel, extended to the network (DESIGN.md 6 has the table).  Returns (total, per-group dict).
+      MLP(Ci -> Co) on m rows        fwd 4 m (Ci + Co)                bwd 4 m (2 Ci + 2 Co)   [gA, the saved output, X in; dX out]
+      gather / pool, m_t <- m_s, C   fwd 4 K' m_t + 4 C (m_s + m_t)   bwd the same + reverse list 4 K' m_t + 4 m_s
+      PointConv(d), m_t <- m_s       fwd m_t (4 K + 12 + 4 d) + m_s (12 + 4 d)    bwd 2 x fwd + reverse list
+      mean field (H), m rows         fwd m (4 (K-1) + 4 H (2 T + 1))  bwd 2 x fwd + m (4 K + 4)"""
+    m = [B * N]
+    for r in ratio[:len(widths) - 1]:
+        m.append(m[-1] // r)
+    g = {}
+
+    def add(name, f, b):
+        a = g.setdefault(name, [0, 0])
+        a[0] += f
+        a[1] += b
+
+    def mlp(name, rows, ci, co, extra_in=0):
+        add(name, 4 * rows * (ci + co + extra_in), 4 * rows * (2 * ci + 2 * co + extra_in))
+
+    def move(name, mt, ms, C, k):
+        f = 4 * k * mt + 4 * C * (ms + mt)
+        add(name, f, f + 4 * k * mt + 4 * ms)
+
+    def pconv(mt, ms, d):
+        f = mt * (4 * K + 12 + 4 * d) + ms * (12 + 4 * d)
+        add('pointconv', f, 2 * f + 4 * K * mt + 4 * ms)
+    cin = in_channels
+    for lvl, w in enumerate(widths):
+        for blk in range(2):
+            strided = blk == 0 and lvl > 0
+            ci = cin if blk == 0 else w
+            ms = m[lvl - 1] if strided else m[lvl]
+            mt = m[lvl]
+            d = w // 4
+            mlp('encoder_linear', ms, ci, d)                                     # lin_in
+            pconv(mt, ms, d)
+            mlp('encoder_linear', mt, d, w, extra_in=w)                          # lin_out + the residual it joins
+            if ci != w:
+                mlp('encoder_linear', ms, ci, w)                                 # shortcut
+            if strided:
+                move('pool_gather', mt, ms, w, K)                                # max-pool of the shortcut
+        cin = w
+    for lvl in range(len(widths) - 2, -1, -1):                                   # deconv4 .. deconv1
+        U, P = widths[lvl + 1], widths[lvl]
+        H, mc, mf = P // 4, m[lvl + 1], m[lvl]
+        mlp('decoder_linear', mc, U, H)
+        mlp('decoder_linear', mc, H, H)
+        mlp('decoder_linear', mf, P, H)
+        mlp('decoder_linear', mf, H, H)
+        move('pool_gather', mf, mc, H, 1)                                        # nearest up-sampling of the unary term
+        f = mf * (4 * (K - 1) + 4 * H * (2 * T + 1))
+        add('mean_field', f, 2 * f + mf * (4 * K + 4))
+        mlp('decoder_linear', mf, H, P)
+        mlp('decoder_linear', mf, 2 * P, P)
+    mlp('classifier_loss', m[0], widths[0], 4 * widths[0])
+    mlp('classifier_loss', m[0], 4 * widths[0], n_cls)
+    add('classifier_loss', m[0] * (4 * n_cls + 8), m[0] * (8 * n_cls + 8))
+    return sum(a[0] + a[1] for a in g.values()), {k: {'fwd': v[0], 'bwd': v[1]} for k, v in g.items()}
+
+
 def roofline_pointconv(data, dev, d=8):
     """Level-0 PointConv (d = 8: conv1_1 / conv1_2 of models/point_conv_big.py:116-117) in train mode, forward and
     forward + backward captured into hipGraphs (the op is four to ten launches; eagerly the host would be timed) and
@@ -306,8 +358,10 @@ def roofline_pointconv(data, dev, d=8):
     tf, tf_lo = _event_time(gf.replay, per=5)
     tfb, _ = _event_time(gfb.replay, per=5)
     alg = m * (4 * K + 12 + 4 * d + 12 + 4 * d)
+    pc_traffic, pc_note = _measured_traffic(TRAFFIC_PC, {'m': m, 'd': d, 'K': K})
     return {'bound': 'hbm', 'achieved': alg / tf / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': alg / tf / HBM_PEAK,
-            'traffic': None, 'kernel': 'PointConv level 0, d=%d, train mode (uvstats + combine; m=%d, K=%d), graph replay' % (d, m, K),
+            'traffic': pc_traffic, 'traffic_source': pc_note,
+            'kernel': 'PointConv level 0, d=%d, train mode (uvstats + combine; m=%d, K=%d), graph replay' % (d, m, K),
             'alg_bytes_per_launch': alg, 'avg_launch_us': tf * 1e6, 'min_launch_us': tf_lo * 1e6,
             'fwd_bwd_us': tfb * 1e6, 'bwd_frac_on_3x_bytes': 3 * alg / max(tfb - tf, 1e-9) / HBM_PEAK}
 
@@ -829,6 +883,19 @@ def main():
             out['roofline_pointconv'] = roofline_pointconv(data, dev, 8)
         except Exception as e:                             # a measurement beside the contract line, never fatal
             out['roofline_pointconv'] = {'error': str(e).splitlines()[0][:200]}
+        # the whole step against the HBM roofline: algorithmic bytes (step_byte_model + 20 B per parameter for SGD with momentum) beside
+        # the HBM-side traffic measured by rocprofv3 PMC passes of this build (profiles/, null when the sources changed since)
+        n_par = sum(p.numel() for p in net.parameters())
+        alg, groups = step_byte_model(B, N, 16, T, n_cls)
+        alg += 20 * n_par
+        step_traffic, step_note = _measured_traffic(TRAFFIC_STEP, {'B': B, 'N': N, 'K': 16, 'T': T})
+        out['roofline_step'] = {'bound': 'hbm', 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'alg_bytes_per_step': alg,
+                                'achieved': alg / (ms_per_step * 1e-3) / 1e9, 'frac': alg / (ms_per_step * 1e-3) / HBM_PEAK,
+                                'traffic': step_traffic, 'traffic_source': step_note,
+                                'waste_ratio': None if step_traffic is None else step_traffic / alg,
+                                'frac_on_measured_traffic': None if step_traffic is None else step_traffic / (ms_per_step * 1e-3) / HBM_PEAK,
+                                'groups': groups, 'ms_per_step': ms_per_step,
+                                'kernel': 'the whole captured training step (fwd + weighted CE + bwd + SGD), %d parameters' % n_par}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(data, net, T, data.y, n_cls, dev)
         print(json.dumps(out))

@@ -19,6 +19,10 @@
 #define CRF_GATHER_SRD 1      // neighbour rows through a buffer resource with 32-bit byte offsets (0: generic 64-bit pointers, the A/B baseline)
 #endif
 
+#ifndef SIM_WAVES_
+#define SIM_WAVES_ 4          // wavefronts per SIMD the level-0 first kernel is compiled for (A/B: 5 = the whole 4 x 40960 grid co-resident)
+#endif
+
 namespace crf {
 
 
@@ -26,7 +30,7 @@ namespace crf {
 // (K in {16, 32}, k0 == 1).  FIRST = similarity + z Q + first step fused: the index row is read
 // once, s never round-trips through memory before its first use.
 template <int H, int K, bool WITH_STEP, bool U16>
-__global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? 4 : 1) void sim_step_fast_kernel(const float* __restrict__ y,
+__global__ __launch_bounds__(BLOCK, (H == 8 && K == 16) ? SIM_WAVES_ : 1) void sim_step_fast_kernel(const float* __restrict__ y,
                                                               const float* __restrict__ z,
                                                               const int32_t* __restrict__ idx,
                                                               const uint16_t* __restrict__ idx16, int n_tgt, int n_src,
@@ -161,389 +165,9 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
 #undef CRF_GATHER_X
 }
 
-// ====================================================================== fused forward: all T steps in ONE launch
-// The per-step launches re-read the index row, the weight row and z of every point T times and write / re-read s; here
-// a point's index row, its softmax weights and z Q stay in REGISTERS of the lanes that own it for the whole loop, so
-// per step only x_{t-1} rows move (gathered) and x_t rows are written.  Step t needs every neighbour's x_{t-1}: a
-// grid-wide dependency, served by a two-level arrival barrier between steps (groups of blockIdx % 8 -- one XCD under the
-// dispatcher's round-robin placement, for speed only -- then one top counter).  Visibility across CUs / XCDs without
-// any cache flush: x rows are stored write-through (`sc1`) and drained (`s_waitcnt vmcnt(0)`) by every storing wave
-// before the workgroup arrives; they are only ever read by `sc1` buffer loads (L1 bypassed), and no line of xs[t] is
-// read by anyone before the barrier that follows its last store (MI355X_MICROARCH.md, inter-workgroup visibility).
-// Every workgroup must be resident at once: the host checks the grid against the occupancy query and refuses otherwise.
-// Thread mapping of the fused kernel: EIGHT channels per lane (two float4), so a point takes LPP = H/8 lanes (one lane
-// at H = 8 or 4).  At the headline shape (163 840 points, H = 8) that is 2560 wavefronts = ten per CU: one 640-thread
-// workgroup per CU, 256 arrivals per barrier.  (Four channels per lane, as the per-step kernels use, needs two 10-wave
-// workgroups per CU; their wavefronts are dealt 3,3,2,2 over the SIMDs from a varying start, so the pair does not fit
-// the per-SIMD register file although the occupancy query says it does -- measured: the barrier never completed.)
-template <int H>
-struct FGeo {
-    static constexpr int CPL = H >= 8 ? 8 : 4, NV = CPL / 4, LPP = H / CPL, PPW = WAVE / LPP;
-};
-
-// acc[c] += sum_h vfull[h] * M[h][c0 + c]  (h ascending: the summation order of matvec_acc), M row-major [H][H] floats
-// in LDS; vfull[h] sits in lane (group base + h / CPL), element h % CPL.
-template <int H>
-__device__ __forceinline__ void fused_matvec(const float (&v)[FGeo<H>::CPL], const float* sM, int lane, int q,
-                                             float (&acc)[FGeo<H>::CPL]) {
-    constexpr int CPL = FGeo<H>::CPL, LPP = FGeo<H>::LPP;
-    const int base = lane - q;
-#pragma unroll
-    for (int hl = 0; hl < LPP; ++hl) {
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) {
-            const float vh = LPP == 1 ? v[e] : __shfl(v[e], base + hl, WAVE);
-            const float* row = sM + (hl * CPL + e) * H + q * CPL;
-#pragma unroll
-            for (int c4 = 0; c4 < CPL / 4; ++c4) {
-                const float4 mr = *reinterpret_cast<const float4*>(row + 4 * c4);
-                acc[4 * c4 + 0] = fmaf(vh, mr.x, acc[4 * c4 + 0]);
-                acc[4 * c4 + 1] = fmaf(vh, mr.y, acc[4 * c4 + 1]);
-                acc[4 * c4 + 2] = fmaf(vh, mr.z, acc[4 * c4 + 2]);
-                acc[4 * c4 + 3] = fmaf(vh, mr.w, acc[4 * c4 + 3]);
-            }
-        }
-    }
-}
-
-// Gathers of rows that OTHER workgroups stored inside the same launch: aux 16 = sc1 (past L1).  -DFUSED_GATHER_AUX=0 reads
-// them through L1 -- no line of xs[t] can be in any L1 / foreign L2 before the barrier that follows its last store, and the
-// variant passed the bit-equality and staleness checks of scratch/mff_bench.py at 30.0 us (sc1: 40.5 us; per-step launches:
-// 25.0 us) -- but that argument leans on the kernel-boundary cache invalidation, so sc1 stays the default of this opt-in path.
-#ifndef FUSED_GATHER_AUX
-#define FUSED_GATHER_AUX 16
-#endif
-template <int CPL, int AUX>
-__device__ __forceinline__ void ld_row(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase, float (&v)[CPL]) {
-#pragma unroll
-    for (int c = 0; c < CPL / 4; ++c) {
-        const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, sbase + 16 * c, AUX);   // +16 on the
-        // SCALAR offset: added to the VGPR it is hoisted out of the step loop as one more live register per row
-        v[4 * c + 0] = __uint_as_float(u.x); v[4 * c + 1] = __uint_as_float(u.y);
-        v[4 * c + 2] = __uint_as_float(u.z); v[4 * c + 3] = __uint_as_float(u.w);
-    }
-}
-template <int CPL>
-__device__ __forceinline__ void st_row_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase, const float (&v)[CPL]) {
-#pragma unroll
-    for (int c = 0; c < CPL / 4; ++c) {
-        const u32x4_t u = {__float_as_uint(v[4 * c]), __float_as_uint(v[4 * c + 1]), __float_as_uint(v[4 * c + 2]),
-                           __float_as_uint(v[4 * c + 3])};
-        __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, sbase + 16 * c, 16);
-    }
-}
-
-// Orders the next gather batch behind the use of the current one: the empty statement makes the batch's row offsets
-// "results" of a value computed from the current batch, so neither the DAG builder nor the scheduler can hoist its
-// loads (hipcc otherwise issues all K-1 rows at once and spills: the rows of ONE batch are the register budget).
-template <int N, int K, int GB>
-__device__ __forceinline__ void fused_tie(float (&res)[N], int r0, int r1, int (&j)[K], int k_next) {
-    float dep = 0.f;
-#pragma unroll
-    for (int c = r0; c < r1 && c < N; ++c) asm volatile("" : "+v"(dep), "+v"(res[c]));      // every result of the batch
-#pragma unroll
-    for (int k = k_next; k < k_next + GB && k < K; ++k) asm volatile("" : "+v"(dep), "+v"(j[k]));
-}
-
-// STAMP: diagnostic build only (crfconv_meanfield_forward_fused_stamps): lane 0 of every workgroup writes 100 MHz
-// s_memrealtime stamps of its phases to dbg[block][8 + 8 t]; no output depends on them.
-#define FUSED_STAMP(slot)                                                                         \
-    do {                                                                                          \
-        if constexpr (STAMP) {                                                                    \
-            const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                       \
-            if (threadIdx.x == 0) dbg[(size_t)blockIdx.x * 64 + (slot)] = t_;                     \
-        }                                                                                         \
-    } while (0)
-
-template <int H, int K, int NT, bool STAMP = false>
-__global__ __launch_bounds__(NT) void mf_fused_kernel(const float* __restrict__ y, const float* __restrict__ z,
-                                                      const int32_t* __restrict__ idx,
-                                                      const uint16_t* __restrict__ idx16, int n_tgt, int n_src,
-                                                      const float* __restrict__ Q, const float* __restrict__ P,
-                                                      float* __restrict__ s, float* xs, int64_t m, int T,
-                                                      unsigned* ws, unsigned long long* dbg) {
-    FUSED_STAMP(0);
-    constexpr int CPL = FGeo<H>::CPL, LPP = FGeo<H>::LPP, PPW = FGeo<H>::PPW, PPB = PPW * (NT / WAVE);
-    constexpr int GB = (H <= 8 && K <= 16) ? 8 : 4;   // neighbour rows in flight per lane (register budget)
-    __shared__ __attribute__((aligned(16))) float sQ[H * H];
-    __shared__ __attribute__((aligned(16))) float sP[H * H];
-    __shared__ float4 tile[NT / WAVE][PPW * (K / 4)];   // s rows of a wavefront, written out as contiguous 1 KiB stores
-    __shared__ int s_ok;
-    for (int t = threadIdx.x; t < H * H; t += NT) { sQ[t] = Q[t]; sP[t] = P[t]; }
-    const int lane = threadIdx.x & 63, q = lane % LPP, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int row0 = (int)xcd_block_id() * PPB + wave * PPW;         // wave-uniform (SGPRs)
-    int r = row0 + lane / LPP;
-    const bool valid = r < (int)m;
-    if (!valid) r = (int)m - 1;
-
-    // neighbour rows as 32-bit byte offsets into the [m, H] arrays (y, z and every xs[t] share the row stride): buffer
-    // loads with an SGPR base keep one VGPR per address instead of a 64-bit pointer pair
-    int j[K];
-    load_index_row<K>(idx, idx16, r, n_tgt, n_src, j);
-    const int step_bytes = (int)(m * H * 4);
-    const int own = (r * H + q * CPL) * 4;
-#pragma unroll
-    for (int k = 1; k < K; ++k) j[k] = (j[k] * H + q * CPL) * 4;
-    const __amdgpu_buffer_rsrc_t yr = make_rsrc(y, step_bytes), zr = make_rsrc(z, step_bytes);
-    float yi[CPL], zi[CPL];
-    ld_row<CPL, 0>(yr, own, 0, yi);
-    ld_row<CPL, 0>(zr, own, 0, zi);
-    float d[K];
-    float dmin = 3.4e38f;
-#pragma unroll
-    for (int k0 = 1; k0 < K; k0 += GB) {
-        float g[GB][CPL];
-#pragma unroll
-        for (int k = k0; k < k0 + GB && k < K; ++k) ld_row<CPL, 0>(yr, j[k], 0, g[k - k0]);
-#pragma unroll
-        for (int k = k0; k < k0 + GB && k < K; ++k) {
-            float part = 0.f;
-#pragma unroll
-            for (int c4 = CPL / 4 - 1; c4 >= 0; --c4) {          // = dot4 per float4, quads added low to high
-                const float a0 = yi[4 * c4] - g[k - k0][4 * c4], a1 = yi[4 * c4 + 1] - g[k - k0][4 * c4 + 1];
-                const float a2 = yi[4 * c4 + 2] - g[k - k0][4 * c4 + 2], a3 = yi[4 * c4 + 3] - g[k - k0][4 * c4 + 3];
-                const float dq = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, a3 * a3)));
-                part = c4 == CPL / 4 - 1 ? dq : dq + part;
-            }
-            d[k] = group_sum<LPP>(part);
-            dmin = fminf(dmin, d[k]);
-        }
-        fused_tie<K, K, GB>(d, k0, k0 + GB, j, k0 + GB);             // the next batch's loads stay behind this batch's use
-    }
-    float den = 0.f;
-#pragma unroll
-    for (int k = 1; k < K; ++k) {
-        d[k] = __expf(dmin - d[k]);
-        den += d[k];
-    }
-    const float inv = 1.0f / den;
-    d[0] = 0.f;
-#pragma unroll
-    for (int k = 1; k < K; ++k) d[k] *= inv;
-    if (s != nullptr) {
-        constexpr int CPR = K / 4, NCH = PPW * CPR;
-        float4* mine = tile[wave];
-        const int pl = lane / LPP;
-#pragma unroll
-        for (int c = 0; c < CPR; ++c)
-            if ((c % LPP) == q) mine[pl * CPR + c] = make_float4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = lane; c < NCH; c += WAVE)
-            if (row0 + c / CPR < (int)m) st4(s + (int64_t)row0 * K + 4 * c, mine[c]);
-    }
-
-    float msg[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) msg[c] = 0.f;
-#pragma unroll
-    for (int k0 = 1; k0 < K; k0 += GB) {
-        float g[GB][CPL];
-#pragma unroll
-        for (int k = k0; k < k0 + GB && k < K; ++k) ld_row<CPL, 0>(zr, j[k], 0, g[k - k0]);
-#pragma unroll
-        for (int k = k0; k < k0 + GB && k < K; ++k)
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) msg[c] = fmaf(d[k], g[k - k0][c], msg[c]);
-        fused_tie<CPL, K, GB>(msg, 0, CPL, j, k0 + GB);
-    }
-    __syncthreads();                                    // sQ / sP
-    float zq[CPL], o[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) zq[c] = 0.f;
-    fused_matvec<H>(zi, sQ, lane, q, zq);
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) o[c] = zq[c];
-    fused_matvec<H>(msg, sP, lane, q, o);
-
-    const __amdgpu_buffer_rsrc_t xr = make_rsrc(xs, step_bytes * T);
-    FUSED_STAMP(1);
-    if (valid) st_row_sc1<CPL>(xr, own, 0, o);
-
-    const unsigned nblk = gridDim.x, grp = blockIdx.x & 7u;
-    const unsigned n_in_group = nblk / 8u + (grp < (nblk & 7u) ? 1u : 0u), n_groups = nblk < 8u ? nblk : 8u;
-    for (int t = 1; t < T; ++t) {
-        if constexpr (STAMP) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            FUSED_STAMP(8 * t + 0);                                  // own stores drained
-        }
-        if (!fused_grid_sync<STAMP>(ws, (unsigned)t, n_in_group, n_groups, &s_ok, dbg, blockIdx.x)) return;
-        FUSED_STAMP(8 * t + 1);                                      // barrier left
-        const int base = (t - 1) * step_bytes;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) msg[c] = 0.f;
-#pragma unroll
-        for (int k0 = 1; k0 < K; k0 += GB) {
-            float g[GB][CPL];
-#pragma unroll
-            for (int k = k0; k < k0 + GB && k < K; ++k) ld_row<CPL, FUSED_GATHER_AUX>(xr, j[k], base, g[k - k0]);
-#pragma unroll
-            for (int k = k0; k < k0 + GB && k < K; ++k)
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) msg[c] = fmaf(d[k], g[k - k0][c], msg[c]);
-            fused_tie<CPL, K, GB>(msg, 0, CPL, j, k0 + GB);
-        }
-        if constexpr (STAMP) {
-            float keep = msg[0];
-            asm volatile("" : "+v"(keep));
-            FUSED_STAMP(8 * t + 2);                                  // gathers consumed
-        }
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) o[c] = zq[c];
-        fused_matvec<H>(msg, sP, lane, q, o);
-        if (valid) st_row_sc1<CPL>(xr, own, base + step_bytes, o);
-        FUSED_STAMP(8 * t + 3);
-    }
-    if constexpr (STAMP) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        FUSED_STAMP(7);
-    }
-    fused_exit_reset(ws, nblk, T);
-}
-
-// ====================================================================== LDS-window forward kernels
-// With spatially sorted clouds (the device collate emits Morton order) ~80 % of a block's
-// neighbour rows lie within +-HALO rows of the block itself.  The block stages that contiguous
-// window with coalesced 16-byte loads and serves in-window neighbours from LDS (ds_read_b128);
-// only the rest goes through the vector-memory gather path.  Correct for any point order -- an
-// unsorted cloud just finds fewer neighbours in its window.
-template <int H, int NT, int HALO>
-struct Win {
-    static constexpr int L = H / 4, PPW = WAVE / L, PPB = NT / L, ROWS = PPB + 2 * HALO;
-    __device__ static __forceinline__ int64_t base(int64_t m) {
-        int64_t first = (int64_t)xcd_block_id() * PPB - HALO;
-        const int64_t hi = m - ROWS;
-        if (first > hi) first = hi;
-        if (first < 0) first = 0;
-        return first;
-    }
-    __device__ static __forceinline__ void stage(float4* dst, const float* __restrict__ src, int64_t w0, int64_t m) {
-        const float4* s4 = reinterpret_cast<const float4*>(src) + w0 * L;
-        const int64_t lim = (m - w0) * L;
-        for (int t = threadIdx.x; t < ROWS * L; t += NT)
-            dst[t] = t < lim ? s4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __device__ static __forceinline__ float4 fetch(const float4* lds, const float* __restrict__ src, int w0, int j, int q) {
-        const int jl = j - w0;
-        return (unsigned)jl < (unsigned)ROWS ? lds[jl * L + q] : ld4(src + (int64_t)j * H + 4 * q);
-    }
-    __device__ static __forceinline__ int64_t point(int64_t m, int& lane, int& q, bool& valid) {
-        lane = threadIdx.x & 63;
-        q = lane % L;
-        const int64_t row = (int64_t)xcd_block_id() * PPB + (threadIdx.x >> 6) * PPW + lane / L;
-        valid = row < m;
-        return valid ? row : m - 1;
-    }
-};
-
-template <int H, int NT>
-__device__ __forceinline__ void load_matrix_nt(float4* sM, const float* __restrict__ Mat, bool transpose) {
-    float* s = reinterpret_cast<float*>(sM);
-    for (int t = threadIdx.x; t < H * H; t += NT) {
-        const int h = t / H, c = t % H;
-        s[t] = transpose ? Mat[c * H + h] : Mat[t];
-    }
-}
-
-template <int H, int K, int NT, int HALO, bool WITH_STEP>
-__global__ __launch_bounds__(NT) void sim_step_win_kernel(const float* __restrict__ y,
-                                                          const float* __restrict__ z,
-                                                          const int32_t* __restrict__ idx,
-                                                          const float* __restrict__ Q,
-                                                          const float* __restrict__ P,
-                                                          float* __restrict__ s,
-                                                          float* __restrict__ x1, int64_t m) {
-    using W = Win<H, NT, HALO>;
-    constexpr int L = W::L;
-    __shared__ float4 sQ[H * L];
-    __shared__ float4 sP[WITH_STEP ? H * L : 1];
-    __shared__ float4 sY[W::ROWS * L];
-    __shared__ float4 sZ[WITH_STEP ? W::ROWS * L : 1];
-    const int64_t w0 = W::base(m);
-    load_matrix_nt<H, NT>(sQ, Q, false);
-    if constexpr (WITH_STEP) load_matrix_nt<H, NT>(sP, P, false);
-    W::stage(sY, y, w0, m);
-    if constexpr (WITH_STEP) W::stage(sZ, z, w0, m);
-    int lane, q;
-    bool valid;
-    const int64_t r = W::point(m, lane, q, valid);
-    int j[K];
-    load_row<K, int4>(idx + r * K, j);
-    const float4 yi = ld4(y + r * H + 4 * q);
-    const float4 zi = ld4(z + r * H + 4 * q);
-    __syncthreads();
-
-    float4 nb[K];
-#pragma unroll
-    for (int k = 1; k < K; ++k) nb[k] = W::fetch(sY, y, (int)w0, j[k], q);
-    float d[K];
-    float dmin = 3.4e38f;
-#pragma unroll
-    for (int k = 1; k < K; ++k) {
-        const float4 df = sub4(yi, nb[k]);
-        d[k] = group_sum<L>(dot4(df, df));
-        dmin = fminf(dmin, d[k]);
-    }
-    if constexpr (WITH_STEP) {
-#pragma unroll
-        for (int k = 1; k < K; ++k) nb[k] = W::fetch(sZ, z, (int)w0, j[k], q);
-    }
-    float den = 0.f;
-#pragma unroll
-    for (int k = 1; k < K; ++k) {
-        d[k] = __expf(dmin - d[k]);        // v_exp_f32 path: ~1e-7 relative, far inside the 1e-4 budget
-        den += d[k];
-    }
-    const float inv = 1.0f / den;
-    d[0] = 0.f;
-#pragma unroll
-    for (int k = 1; k < K; ++k) d[k] *= inv;
-#pragma unroll
-    for (int c = 0; c < K / 4; ++c)
-        if (valid && (c % L) == q) st4(s + r * K + 4 * c, make_float4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]));
-    if constexpr (WITH_STEP) {
-        const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
-        float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 1; k < K; ++k) msg = fma4(d[k], nb[k], msg);
-        const float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
-        if (valid) st4(x1 + r * H + 4 * q, o);
-    }
-}
-
-template <int H, int K, int NT, int HALO>
-__global__ __launch_bounds__(NT) void step_win_kernel(const float* __restrict__ xin,
-                                                      const float* __restrict__ z,
-                                                      const float* __restrict__ s,
-                                                      const int32_t* __restrict__ idx,
-                                                      const float* __restrict__ Q,
-                                                      const float* __restrict__ P,
-                                                      float* __restrict__ xout, int64_t m) {
-    using W = Win<H, NT, HALO>;
-    constexpr int L = W::L;
-    __shared__ float4 sP[H * L];
-    __shared__ float4 sQ[H * L];
-    __shared__ float4 sX[W::ROWS * L];
-    const int64_t w0 = W::base(m);
-    load_matrix_nt<H, NT>(sP, P, false);
-    load_matrix_nt<H, NT>(sQ, Q, false);
-    W::stage(sX, xin, w0, m);
-    int lane, q;
-    bool valid;
-    const int64_t r = W::point(m, lane, q, valid);
-    int j[K];
-    float w[K];
-    load_row<K, int4>(idx + r * K, j);
-    load_row<K, float4>(s + r * K, w);
-    const float4 zi = ld4(z + r * H + 4 * q);
-    __syncthreads();
-    const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
-    float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 1; k < K; ++k) msg = fma4(w[k], W::fetch(sX, xin, (int)w0, j[k], q), msg);
-    const float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
-    if (valid) st4(xout + r * H + 4 * q, o);
-}
+// (The one-launch forward -- all T steps behind grid barriers, mf_fused_kernel -- and the LDS-window kernels of rounds 1-3 were
+// measured slower than the per-step launches (39-40 us against 25 us; 43.0 against 39.5 us: DESIGN.md 5c, profiles/r2a_*) and
+// were removed in round 4; `git log -- crfconv_amd/csrc/crf.hip` has them.)
 
 // ====================================================================== generic forward kernels
 // any K <= 64, any k0: distances recomputed in a second sweep (rows are L1/L2 hot by then).
@@ -1000,7 +624,6 @@ __global__ __launch_bounds__(BLOCK) void wide_sim_bwd_kernel(const float* __rest
 // level-0 forward, profiles/r1b): after Morton ordering + XCD-contiguous blocks the gathers are L1/L2 hits
 // and the step is bound by the idx / weight / state streams, not by gather issue.  Kept for A/B runs:
 // CRFCONV_WINDOW=1 enables them.
-static const bool g_use_window = (getenv("CRFCONV_WINDOW") != nullptr);
 
 
 }  // namespace crf
@@ -1048,7 +671,7 @@ static int meanfield_forward_impl(const float* z, const float* y, const int32_t*
     if (int rc = check_common(m, H, K, k0)) return rc;
     CRF_REQUIRE(z && y && idx32 && Q && P && (xs || T == 0), CRF_ERR_ARG, "null pointer");
     // s may be NULL when nothing reads it back: a single fused step (T == 1) on the fast path, no backward pass
-    CRF_REQUIRE(s || (T == 1 && k0 == 1 && (K == 16 || K == 32) && !g_use_window && m * H * 4 < ((int64_t)1 << 31)), CRF_ERR_ARG,
+    CRF_REQUIRE(s || (T == 1 && k0 == 1 && (K == 16 || K == 32) && m * H * 4 < ((int64_t)1 << 31)), CRF_ERR_ARG,
                 "s == NULL needs T == 1 on the fused first-step kernel (K in {16, 32}, k0 == 1)");
     CRF_REQUIRE(T >= 0, CRF_ERR_ARG, "T=%d < 0", T);
     hipStream_t st = as_stream(stream);
@@ -1057,24 +680,6 @@ static int meanfield_forward_impl(const float* z, const float* y, const int32_t*
     DISPATCH_H(H, {
         const dim3 grid((unsigned)cdiv(m, Geo<HH>::PPB)), blk(BLOCK);
         int t0 = 0;
-        constexpr bool HAS_WIN = (HH == 8 || HH == 16);
-        constexpr int NT = HH == 8 ? 512 : 256, HALO = HH == 8 ? 128 : 96;
-        const bool win = fast && K == 16 && HAS_WIN && g_use_window;
-        if (win) {
-            if constexpr (HAS_WIN) {
-                using W = Win<HH, NT, HALO>;
-                const dim3 wgrid((unsigned)cdiv(m, W::PPB)), wblk(NT);
-                if (T > 0) hipLaunchKernelGGL((sim_step_win_kernel<HH, 16, NT, HALO, true>), wgrid, wblk, 0, st, y, z, idx32, Q, P, s, xs, m);
-                else hipLaunchKernelGGL((sim_step_win_kernel<HH, 16, NT, HALO, false>), wgrid, wblk, 0, st, y, z, idx32, Q, P, s, xs, m);
-                CRF_LAUNCH_CHECK();
-                for (int t = 1; t < T; ++t) {
-                    hipLaunchKernelGGL((step_win_kernel<HH, 16, NT, HALO>), wgrid, wblk, 0, st, xs + (int64_t)(t - 1) * m * HH,
-                                       z, s, idx32, Q, P, xs + (int64_t)t * m * HH, m);
-                    CRF_LAUNCH_CHECK();
-                }
-            }
-            return CRF_OK;
-        }
         if (fast) {
             float* x1 = T > 0 ? xs : nullptr;
             if (K == 16) {
@@ -1187,84 +792,7 @@ extern "C" int crfconv_similarity_bwd_scatter(const float* w, const float* y, co
     return CRF_OK;
 }
 
-// ---------------------------------------------------------------------- fused forward (one launch for all T steps)
-constexpr int FUSED_NT = 640;        // 10 wavefronts: 640 points (H = 8) per workgroup, one workgroup per CU at the headline shape
-
-template <int H, int K>
-static int fused_capacity() {        // workgroups that can be resident at once (occupancy query x CUs), -1 on error
-    static int cap = 0;
-    if (cap == 0) {
-        int per_cu = 0, dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_fused_kernel<H, K, FUSED_NT>, FUSED_NT, 0) != hipSuccess)
-            cap = -1;
-        else
-            cap = per_cu * cus;
-    }
-    return cap;
-}
-
-static int fused_check(int64_t m, int H, int K, int k0, int T) {
-    if (!(k0 == 1 && (K == 16 || K == 32) && T >= 1)) return 0;
-    if (!(H == 4 || H == 8 || (H == 16 && K == 16))) return 0;      // wider rows: the per-step kernels (register budget)
-    if (m <= 0 || m * H * 4 * (int64_t)T >= ((int64_t)1 << 31)) return 0;          // 32-bit buffer offsets
-    int cap = 0;
-    int64_t grid = 0;
-    DISPATCH_H(H, {
-        cap = K == 16 ? fused_capacity<HH, 16>() : fused_capacity<HH, 32>();
-        grid = cdiv(m, FGeo<HH>::PPW * (FUSED_NT / WAVE));
-    });
-    return cap > 0 && grid <= cap ? 1 : 0;
-}
-
-extern "C" size_t crfconv_meanfield_fused_workspace(void) { return FW_WORDS * sizeof(unsigned); }
-
-extern "C" int crfconv_meanfield_fused_supported(int64_t m, int H, int K, int k0, int T) {
-    return fused_check(m, H, K, k0, T);
-}
-
-extern "C" int crfconv_meanfield_forward_fused(const float* z, const float* y, const int32_t* idx32,
-                                               const uint16_t* idx16, int n_tgt, int n_src, int K, int k0, int64_t m,
-                                               int H, const float* Q, const float* P, int T, float* s, float* xs,
-                                               void* ws, size_t ws_bytes, crf_stream_t stream) {
-    if (int rc = check_common(m, H, K, k0)) return rc;
-    CRF_REQUIRE(z && y && idx32 && Q && P && xs && ws, CRF_ERR_ARG, "null pointer");
-    CRF_REQUIRE(ws_bytes >= FW_WORDS * sizeof(unsigned), CRF_ERR_ARG, "workspace of %zu bytes, need %zu", ws_bytes,
-                FW_WORDS * sizeof(unsigned));
-    CRF_REQUIRE(idx16 == nullptr || (n_tgt > 0 && n_src > 0 && n_src <= 65536 && m % n_tgt == 0), CRF_ERR_ARG,
-                "u16 table needs n_src <= 65536 and m a multiple of n_tgt (n_tgt=%d n_src=%d)", n_tgt, n_src);
-    CRF_REQUIRE(fused_check(m, H, K, k0, T) == 1, CRF_ERR_UNSUPPORTED,
-                "fused mean-field forward: shape not supported or grid not co-resident (m=%lld H=%d K=%d k0=%d T=%d)",
-                (long long)m, H, K, k0, T);
-    hipStream_t st = as_stream(stream);
-    DISPATCH_H(H, {
-        const dim3 grid((unsigned)cdiv(m, FGeo<HH>::PPW * (FUSED_NT / WAVE))), blk(FUSED_NT);
-        if (K == 16)
-            hipLaunchKernelGGL((mf_fused_kernel<HH, 16, FUSED_NT>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, (unsigned*)ws, (unsigned long long*)nullptr);
-        else
-            hipLaunchKernelGGL((mf_fused_kernel<HH, 32, FUSED_NT>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, (unsigned*)ws, (unsigned long long*)nullptr);
-        CRF_LAUNCH_CHECK();
-    });
-    return CRF_OK;
-}
-
-/* Diagnostic build of the fused forward (H = 8, K = 16 only): the same kernel with 100 MHz time stamps per workgroup in
- * dbg [grid][64] (uint64): [0] start, [1] phase-0 result ready, [7] end, per step t: [8t] own stores drained, [8t+1] left
- * the barrier, [8t+2] gathers consumed, [8t+3] x_t stored.  Not part of the product path (scratch/mff_bench.py). */
-extern "C" int crfconv_meanfield_forward_fused_stamps(const float* z, const float* y, const int32_t* idx32,
-                                                      const uint16_t* idx16, int n_tgt, int n_src, int64_t m,
-                                                      const float* Q, const float* P, int T, float* s, float* xs,
-                                                      void* ws, unsigned long long* dbg, crf_stream_t stream) {
-    CRF_REQUIRE(fused_check(m, 8, 16, 1, T) == 1 && T <= 7, CRF_ERR_UNSUPPORTED, "stamps: shape not supported");
-    hipStream_t st = as_stream(stream);
-    const dim3 grid((unsigned)cdiv(m, FGeo<8>::PPW * (FUSED_NT / WAVE))), blk(FUSED_NT);
-    hipLaunchKernelGGL((mf_fused_kernel<8, 16, FUSED_NT, true>), grid, blk, 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, (unsigned*)ws, dbg);
-    CRF_LAUNCH_CHECK();
-    return CRF_OK;
-}
-
-// ---------------------------------------------------------------------- wide rows (H in {128, 256}): graph kernels only
+// ---------------------------------------------------------------------- wide rows: host side
 #define DISPATCH_VW(H, ...)                                     \
     switch (H) {                                                \
         case 128: { constexpr int VV = 2; __VA_ARGS__; break; } \

@@ -54,17 +54,11 @@ class _MeanField(torch.autograd.Function):
         needs_grad = any(ctx.needs_input_grad[:4])
         # inference with one step: the similarity weights are consumed inside the fused first kernel and never
         # re-read -- skip their 4K bytes/point store (a third of that kernel's traffic)
-        keep_s = needs_grad or steps != 1 or k0 != 1 or table.K not in (16, 32) or _WINDOW_ENV
+        keep_s = needs_grad or steps != 1 or k0 != 1 or table.K not in (16, 32) or m * H * 4 >= 2 ** 31
         s = torch.empty((m, table.K), dtype=torch.float32, device=z.device) if keep_s else None   # s[i*K + k]
         xs = torch.empty((max(steps, 1), m, H), dtype=torch.float32, device=z.device)
-        if _FUSED_ENV and steps >= 1 and _lib.load().crfconv_meanfield_fused_supported(m, H, table.K, k0, steps) == 1:
-            # one launch for all steps: measured slower than the per-step launches, opt-in for A/B runs
-            _lib.call('crfconv_meanfield_forward_fused', ptr(z), ptr(y), ptr(table.idx32), ptr(table.idx16), table.n_tgt,
-                      table.n_src, table.K, k0, m, H, ptr(Q), ptr(P), steps, ptr(s), ptr(xs), ptr(_fused_ws(z.device)),
-                      _lib.load().crfconv_meanfield_fused_workspace(), stream_ptr())
-        else:
-            _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(table.idx32), ptr(table.idx16), table.n_tgt,
-                      table.n_src, table.K, k0, m, H, ptr(Q), ptr(P), steps, ptr(s), ptr(xs), stream_ptr())
+        _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(table.idx32), ptr(table.idx16), table.n_tgt,
+                  table.n_src, table.K, k0, m, H, ptr(Q), ptr(P), steps, ptr(s), ptr(xs), stream_ptr())
         ctx.table, ctx.k0, ctx.steps = table, k0, steps
         if needs_grad:
             ctx.save_for_backward(z, y, Q, P, s, xs)
@@ -297,8 +291,6 @@ _CRF_H = (4, 8, 16, 32, 64)
 _CRF_WIDE_H = (128, 256)                    # one point per wavefront (crfconv_wide_*), H x H products as library GEMMs
 _OLD_BWD_ENV = __import__('os').environ.get('CRFCONV_OLD_BWD') is not None     # A/B: the step-by-step backward launches
 _NO_LATE_CRF_ENV = __import__('os').environ.get('CRFCONV_NO_LATE_CRF') is not None      # A/B: dP / dQ and the matrices backward inside the pass
-_FUSED_ENV = __import__('os').environ.get('CRFCONV_FUSED') is not None       # one-launch forward (crfconv_meanfield_forward_fused)
-_FUSED_WS = {}
 
 
 _TICKETS = {}
@@ -333,15 +325,6 @@ def _stream_buf(table, device, make):
 def _ticket(device):
     """Zero words for the "last workgroup finishes" reductions (left zero by the kernels), per (device, stream)."""
     return _stream_buf(_TICKETS, device, lambda: torch.zeros(64, dtype=torch.int32, device=device))
-
-
-def _fused_ws(device):
-    """Barrier words of the fused forward: zero once, the kernel leaves them zeroed."""
-    ws = _FUSED_WS.get(device)
-    if ws is None:
-        ws = _FUSED_WS[device] = torch.zeros(_lib.load().crfconv_meanfield_fused_workspace(), dtype=torch.uint8, device=device)
-    return ws
-_WINDOW_ENV = __import__('os').environ.get('CRFCONV_WINDOW') is not None     # A/B kernels of csrc/crf.hip: always keep s
 
 
 class _MeanFieldWide(torch.autograd.Function):
@@ -832,21 +815,21 @@ def _flush_weight_grads():
 _MFMA_MIN_ROWS = int(__import__('os').environ.get('CRFCONV_MFMA_MIN_ROWS', 12288))      # below this the tiled product (gemm.hip) and the small-MLP nodes; swept on the step: 4096 -> 4.733 ms, 12288 (the 10 240-row level joins the small forms) -> 4.694 ms, 65536 -> 4.736 ms
 
 
-_VENDOR_ONLY = bool(__import__('os').environ.get('CRFCONV_VENDOR_GEMM'))     # A/B switch: forward / dX on rocBLAS
 _NO_APPLY_FROM_RECORDS_ENV = __import__('os').environ.get('CRFCONV_NO_APPLY_FROM_RECORDS') is not None      # A/B: coefficient launch + apply launch
 
 
 def _mfma_ok(m, ci, co):
-    return (not _VENDOR_ONLY) and m >= _MFMA_MIN_ROWS and bool(_lib.load().crfconv_linear_forward_supported(ci, co))
+    return m >= _MFMA_MIN_ROWS and bool(_lib.load().crfconv_linear_forward_supported(ci, co))
 
 
 def _gemm(A, B, bias=None, addend=None, nk=False):
     """A [M, K] @ B (+ bias) (+ addend) on the tiled fp32 MFMA kernel of gemm.hip -- the products the row-streaming kernel of
     linear.hip does not take (coarse levels, wide layers; any widths).  nk: B is [N, K] (the F.linear weight), else [K, N].
-    CRFCONV_VENDOR_GEMM=1 is the A/B switch to the vendor library."""
+    (Shapes outside the kernel's range -- crfconv_gemm_supported; none occurs in the networks of this package -- and empty operands
+    take the framework's product.)"""
     M, K = A.shape
     N = B.shape[0] if nk else B.shape[1]
-    if _VENDOR_ONLY or M == 0 or not _lib.load().crfconv_gemm_supported(M, N, K):
+    if M == 0 or not _lib.load().crfconv_gemm_supported(M, N, K):
         C = torch.nn.functional.linear(A, B, bias) if nk else (A @ B if bias is None else torch.addmm(bias, A, B))
         return C if addend is None else C.add_(addend)
     A, B = A.contiguous(), B.contiguous()
@@ -861,7 +844,7 @@ def _gemm_tn(A, B):
     linear.hip (crfconv_linear_wgrad), fixed summation order."""
     m, ca = A.shape
     cb = B.shape[1]
-    if _VENDOR_ONLY or m == 0:
+    if m == 0:
         return A.t() @ B
     A, B = A.contiguous(), B.contiguous()
     out = torch.empty((ca, cb), dtype=torch.float32, device=A.device)
@@ -1421,7 +1404,7 @@ def _small_bwd(gA, y, coef, W, addend, slope, dgamma, dbeta, need_dx):
     dev = y.device
     gY = torch.empty_like(y)
     lib = _lib.load()
-    if need_dx and not _NO_SMALL_BWD_ENV and not _VENDOR_ONLY and lib.crfconv_mlp_small_backward_supported(m, ci, co) == 1:
+    if need_dx and not _NO_SMALL_BWD_ENV and lib.crfconv_mlp_small_backward_supported(m, ci, co) == 1:
         dX = torch.empty((m, ci), dtype=torch.float32, device=dev)
         nbytes = lib.crfconv_mlp_small_backward_workspace(m, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -1573,7 +1556,7 @@ def check_gridsync(dev=None):
     word = _lib.load().crfconv_gridsync_fail_word()
     bad = []
     want = None if dev is None else torch.device(dev).index
-    for table in (_sync_ws, {(torch.device(d).index, 0): w.view(torch.int32) for d, w in _FUSED_WS.items()}):
+    for table in (_sync_ws,):
         for key, ws in list(table.items()):
             if want is not None and key[0] is not None and key[0] != want:
                 continue

@@ -158,25 +158,6 @@ int crfconv_meanfield_forward_u16(const float* z, const float* y, const int32_t*
                                   int n_tgt, int n_src, int K, int k0, int64_t m, int H, const float* Q,
                                   const float* P, int T, float* s, float* xs, crf_stream_t stream);
 
-/* The same forward as ONE launch for all T >= 1 steps (K in {16, 32}, k0 = 1, H in {4, 8}, or H = 16 with K = 16): a
- * point's index row, softmax weights and z Q stay in registers across the steps, x_t rows are exchanged between workgroups
- * inside the launch (write-through stores, L1-bypassing loads, a two-level arrival barrier between steps) --
- * models/continuous_crf_conv_big.py:63-72 without the per-step re-read of idx / s / z.  Results are bit-identical to
- * crfconv_meanfield_forward_u16 at H = 8.  MEASURED SLOWER than the per-step launches on MI355X (39 vs 25 us at
- * m = 163840, H = 8, T = 3: L1-bypassing gathers run at 0.6 rows/clk/CU against 1.45 through L1), so the
- * nn.Module path does not use it unless CRFCONV_FUSED=1; kept as the measured alternative and for its parity test.
- * s may be NULL for any T.  Every workgroup must be resident at once: crfconv_meanfield_fused_supported() says whether
- * (m, H, K, k0, T) fits this device (1) or not (0).  ws: crfconv_meanfield_fused_workspace() bytes of device scratch
- * that must be ZERO before the first call; the kernel leaves it zeroed (its last workgroup out resets the barrier words)
- * unless a workgroup gave up waiting -- then word 17*32 holds a non-zero code and the caller must zero ws again (cannot
- * happen when _supported() said 1). */
-size_t crfconv_meanfield_fused_workspace(void);
-int crfconv_meanfield_fused_supported(int64_t m, int H, int K, int k0, int T);
-int crfconv_meanfield_forward_fused(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16,
-                                    int n_tgt, int n_src, int K, int k0, int64_t m, int H, const float* Q,
-                                    const float* P, int T, float* s, float* xs, void* ws, size_t ws_bytes,
-                                    crf_stream_t stream);
-
 /* One backward step, edge half:  given G = dL/dx_t and x_{t-1}:
  *   gm  = G P^T                              [m, H]
  *   ds (+)= <gm_i, x_{t-1}[j(i,k)]>          [m, K]    (accumulate != 0 adds to ds)

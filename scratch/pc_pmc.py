@@ -1,4 +1,4 @@
-"""Level-0 (d = 8) and level-1 (d = 16) PointConv forward + backward in train mode, 5 eager calls each (for rocprofv3 --pmc passes)."""
+"""PointConv forward + backward in train mode at level 0 (d = 8), 1 (d = 16), 3 (d = 64) and 4 (d = 128), 5 eager calls each (for rocprofv3 --pmc passes)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
@@ -7,7 +7,7 @@ from crfconv_amd.graph import table_of
 dev = torch.device('cuda', 0)
 gen = torch.Generator().manual_seed(1234)
 data, _ = bench.make_batch(0, 4, 40960, dev, gen, 'morton')
-for lvl, d in ((0, 8), (1, 16)):
+for lvl, d in ((0, 8), (1, 16), (3, 64), (4, 128)):
     ms = data.multiscale[lvl]
     B, N, K = ms.neighbor_idx.shape
     tab = table_of(ms.neighbor_idx, N); tab.reverse

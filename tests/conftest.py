@@ -31,3 +31,23 @@ def sub(d, prefix):
     """Entries of a flat npz dict under 'prefix/' with the prefix stripped."""
     n = len(prefix) + 1
     return {k[n:]: v for k, v in d.items() if k.startswith(prefix + '/')}
+
+
+@pytest.fixture(autouse=True)
+def _tolerance_key(request):
+    """Names the running test for gpu_util.assert_close (its bounds are tied to the errors recorded per call site)."""
+    try:
+        import gpu_util
+    except Exception:                                      # CPU-only collection without torch extras: nothing to key
+        yield
+        return
+    gpu_util.set_current_test(request.node.nodeid)
+    yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    try:
+        import gpu_util
+        gpu_util.flush_recorded()
+    except Exception:
+        pass

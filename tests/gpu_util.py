@@ -20,11 +20,56 @@ def relerr(a, b):
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
 
 
+# ---- tolerances tied to MEASURED errors (bounds of 1e-4 ... 2e-4 against measured 1e-7 ... 1e-5 leave 100x slack).
+# tests/golden/tol_baseline.json holds the error every assert_close call measured on an MI355X (recorded by running the GPU suite
+# with CRFCONV_TOL_RECORD=<path>; key = pytest node id :: what # occurrence).  With the baseline present a call must stay within
+# min(its stated bound, 10 x its recorded error) -- and never below 1e-7, the float32 noise floor of a normalised comparison.
+_BASELINE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tol_baseline.json')
+_baseline = None
+_recorded = {}
+_current = {'node': '', 'seen': {}}
+TOL_FACTOR, TOL_FLOOR = 10.0, 1e-7
+
+
+def set_current_test(nodeid):
+    _current['node'] = nodeid
+    _current['seen'] = {}
+
+
+def _key(what):
+    n = _current['seen'].get(what, 0)
+    _current['seen'][what] = n + 1
+    return '%s::%s#%d' % (_current['node'], what, n)
+
+
+def flush_recorded():
+    path = os.environ.get('CRFCONV_TOL_RECORD')
+    if path and _recorded:
+        import json
+        with open(path, 'w') as f:
+            json.dump(_recorded, f, indent=0, sort_keys=True)
+
+
 def assert_close(a, b, tol, what=''):
+    global _baseline
     e = relerr(a, b)
+    key = _key(what)
+    if os.environ.get('CRFCONV_TOL_RECORD'):
+        _recorded[key] = e
+    bound, why = tol, ''
+    if _baseline is None:
+        try:
+            import json
+            _baseline = json.load(open(_BASELINE_PATH))
+        except (OSError, ValueError):
+            _baseline = {}
+    if key in _baseline and not os.environ.get('CRFCONV_TOL_RECORD'):
+        tight = max(TOL_FACTOR * float(_baseline[key]), TOL_FLOOR)
+        if tight < bound:
+            bound, why = tight, ' (= %g x the error recorded on MI355X, %.3e; stated bound %.1e)' % (TOL_FACTOR, _baseline[key], tol)
     if os.environ.get('CRFCONV_TEST_REPORT'):             # measured error beside the bound (pytest -s): how much room a bound has
-        print('[assert_close] %-44s err %.3e  tol %.1e' % (what, e, tol), flush=True)
-    assert e <= tol, '%s: max err (rel. to max(1,|ref|)) %.3e > %.1e' % (what, e, tol)
+        print('[assert_close] %-44s err %.3e  tol %.1e  enforced %.1e' % (what, e, tol, bound), flush=True)
+    assert e <= bound, '%s: max err (rel. to max(1,|ref|)) %.3e > %.1e%s' % (what, e, bound, why)
 
 
 def load_sd(module, sd_np):

@@ -568,58 +568,6 @@ def test_meanfield_single_step_inference_skips_s():
     assert torch.equal(a, b.detach())
 
 
-@pytest.mark.parametrize('H,K,T,B,N', [(8, 16, 3, 4, 40960), (8, 16, 5, 2, 5000), (8, 32, 3, 2, 4096), (4, 16, 2, 1, 3001),
-                                       (16, 16, 3, 2, 2560)])
-def test_meanfield_fused_launch_equals_per_step_launches(H, K, T, B, N):
-    """crfconv_meanfield_forward_fused (all steps in one launch, x_t rows exchanged between workgroups through
-    write-through stores and L1-bypassing loads) against the per-step launches: bit-identical at H <= 8 (same operation
-    order), 5e-6 (weights) / 5e-5 (states) at H = 16 (different reduction tree of the distances), on the SAME output buffers with inputs that change between
-    back-to-back launches -- a reader that picked up a stale x_{t-1} row would show up as a mismatch."""
-    from crfconv_amd import _lib
-    from crfconv_amd.graph import NeighborTable, ptr, stream_ptr
-    from crfconv_amd.utils import nearest_neighbors
-    lib = _lib.load()
-    m = B * N
-    if lib.crfconv_meanfield_fused_supported(m, H, K, 1, T) != 1:
-        pytest.skip('grid not co-resident on this device')
-    g = torch.Generator().manual_seed(H * K + T)
-    pos = (torch.rand(B, N, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])).to(DEV)
-    tab = NeighborTable(nearest_neighbors.knn_batch_device(pos, pos, K), N)
-    y = torch.randn(m, H, generator=g).to(DEV)
-    c = torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)
-    C = c.t() @ c
-    Q = torch.linalg.inv(torch.eye(H) + C)
-    P = (C @ Q).to(DEV).contiguous()
-    Q = Q.to(DEV).contiguous()
-    wsb = lib.crfconv_meanfield_fused_workspace()
-    ws = torch.zeros(wsb // 4, dtype=torch.int32, device=DEV)
-    st = stream_ptr()
-    zs = [torch.randn(m, H, generator=g).to(DEV) for _ in range(4)]
-    s_ref, xs_ref = torch.empty(m, K, device=DEV), torch.empty(T, m, H, device=DEV)
-    s_f, xs_f = torch.empty(m, K, device=DEV), torch.empty(T, m, H, device=DEV)
-    refs = []
-    for z in zs:
-        _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src, K, 1,
-                  m, H, ptr(Q), ptr(P), T, ptr(s_ref), ptr(xs_ref), st)
-        refs.append((s_ref.clone(), xs_ref.clone()))
-    outs = []
-    for rep in range(3):
-        for z in zs:                       # back to back, no host synchronisation in between
-            _lib.call('crfconv_meanfield_forward_fused', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src,
-                      K, 1, m, H, ptr(Q), ptr(P), T, ptr(s_f), ptr(xs_f), ptr(ws), wsb, st)
-            outs.append((s_f.clone(), xs_f.clone()))
-    torch.cuda.synchronize()
-    assert int(ws[17 * 32]) == 0, 'a workgroup gave up at the barrier'
-    assert int(ws.abs().sum()) == 0, 'barrier words not reset by the last workgroup out'
-    for i, (so, xo) in enumerate(outs):
-        sr, xr = refs[i % len(zs)]
-        if H <= 8:
-            assert torch.equal(so, sr) and torch.equal(xo, xr), 'launch %d differs' % i
-        else:
-            assert float((so - sr).abs().max()) < 5e-6 and float((xo - xr).abs().max()) < 5e-5, 'launch %d differs' % i
-
-
-# ------------------------------------------------------------------ the other BASELINE configs at their full sizes
 @pytest.mark.parametrize('name,B,N,K,T,H', [('C2 S3DIS batch (headline)', 4, 40960, 16, 3, 8), ('C3 KITTI scan', 1, 122880, 16, 1, 8), ('C4 ScanNet cloud', 4, 81920, 16, 3, 8),
                                             ('C5 Semantic3D crops', 2, 65536, 32, 5, 8), ('C5 level 1', 2, 16384, 32, 5, 16)])
 def test_meanfield_other_configs_full_size(name, B, N, K, T, H):
