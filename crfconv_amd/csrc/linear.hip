@@ -480,6 +480,10 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(const ReduceJobTable t
 struct WgPlan {
     int tco, tci, gy, gz, nblk, rows_per_block;
 };
+#ifndef WG_LONG_ROWS_
+#define WG_LONG_ROWS_ 256     // swept on the training step, one box, two runs each: 64 (round 3's plan) 4.413 ms, 128 4.398, 192 4.395, 256 4.386, 320 4.397, 384 4.409, 512 4.411
+#endif
+
 
 static WgPlan wg_plan(int64_t M, int Co, int Ci) {
     WgPlan p;
@@ -496,6 +500,17 @@ static WgPlan wg_plan(int64_t M, int Co, int Ci) {
     int64_t rows = (M + slices - 1) / slices;
     if (rows < 64) rows = 64;
     rows = (rows + 63) / 64 * 64;
+#if WG_LONG_ROWS_ > 64
+    // Longer slices for the layers whose partial passes share one launch (M <= 65536: crfconv_linear_wgrad_partial_jobs, ~22
+    // wavefronts per SIMD of work): every slice writes a Co x Ci slab that the reduce launch reads again -- 92 MB written and
+    // re-read per step with the 64 ... 192-row slices of the plan above; past 256 rows the launch's longest workgroups cost more
+    // than the slabs save
+    if (M <= 65536) {
+        int64_t want = WG_LONG_ROWS_;
+        if (M < 2 * want) want = ((M + 1) / 2 + 63) / 64 * 64;
+        if (rows < want) rows = want;
+    }
+#endif
     p.rows_per_block = (int)rows;
     p.nblk = (int)((M + rows - 1) / rows);
     return p;
