@@ -97,6 +97,9 @@ SIGNATURES = {
     'crfconv_reduce_jobs_f64': (_i, [_vp, _i, _vp]),
     'crfconv_pointconv_bwd_dump_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_pointconv_bwd_a1_jobs': (_i, [_vp, _i, _vp]),
+    'crfconv_pointconv_wide_params_supported': (_i, [_i64, _i, _i]),
+    'crfconv_pointconv_wide_params_nblk': (_i64, [_i64, _i]),
+    'crfconv_pointconv_wide_params_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_gemm_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_linear_wgrad_nblk': (_i, [_i64, _i, _i]),
     'crfconv_linear_wgrad_partial_jobs': (_i, [_vp, _i, _vp]),
@@ -182,6 +185,14 @@ class PcDumpJob(ctypes.Structure):
                 ('idx32', ctypes.c_void_p), ('K', ctypes.c_int32), ('m_tgt', ctypes.c_int64), ('d', ctypes.c_int32), ('A1', ctypes.c_void_p),
                 ('b1', ctypes.c_void_p), ('W2', ctypes.c_void_p), ('slope', ctypes.c_float), ('ca', ctypes.c_void_p), ('cb', ctypes.c_void_p),
                 ('cc', ctypes.c_void_p), ('h1', ctypes.c_void_p), ('gh2', ctypes.c_void_p), ('rel', ctypes.c_void_p)]
+
+
+class PcWideJob(ctypes.Structure):
+    """crf_pc_wide_job of include/crfconv_amd.h."""
+    _fields_ = [('x', ctypes.c_void_p), ('gout', ctypes.c_void_p), ('pos_src', ctypes.c_void_p), ('pos_tgt', ctypes.c_void_p),
+                ('idx32', ctypes.c_void_p), ('K', ctypes.c_int32), ('m_tgt', ctypes.c_int64), ('d', ctypes.c_int32), ('A1', ctypes.c_void_p),
+                ('b1', ctypes.c_void_p), ('W2', ctypes.c_void_p), ('slope', ctypes.c_float), ('ca', ctypes.c_void_p), ('cb', ctypes.c_void_p),
+                ('cc', ctypes.c_void_p), ('dw2_partial', ctypes.c_void_p), ('a1_partial', ctypes.c_void_p)]
 
 
 class PcA1Job(ctypes.Structure):

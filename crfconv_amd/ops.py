@@ -719,6 +719,30 @@ def _flush_pc_wide():
         return
     st = stream_ptr()
     lib = _lib.load()
+    # d = 32 / 64 with K = 16: the whole pass on the matrix pipe, no per-edge tensor (csrc/pointconv_wide.hip) -- one launch per width;
+    # its per-workgroup slabs join the batched sums below (dW2: crfconv_reduce_jobs, dA1 | db1: crfconv_reduce_jobs_f64)
+    mfma = [] if _NO_WIDE_MFMA_ENV else [w for w in wide if lib.crfconv_pointconv_wide_params_supported(w['m_tgt'], w['K'], w['d']) == 1]
+    if mfma:
+        wide = [w for w in wide if not any(w is v for v in mfma)]
+        jobs, keep_m = [], []
+        for w in mfma:
+            d, dev = w['d'], w['x'].device
+            nb = int(lib.crfconv_pointconv_wide_params_nblk(w['m_tgt'], d))
+            pw = torch.empty((nb, d * d), dtype=torch.float32, device=dev)
+            pa = torch.empty((nb, 4 * d), dtype=torch.float64, device=dev)
+            c = w['coef']
+            jobs.append(_lib.PcWideJob(w['x'].data_ptr(), w['g'].data_ptr(), w['pos_src'].data_ptr(), w['pos_tgt'].data_ptr(), w['idx'].data_ptr(),
+                                       w['K'], w['m_tgt'], d, w['A1'].data_ptr(), w['b1'].data_ptr(), w['W2'].data_ptr(), float(w['slope']),
+                                       c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), pw.data_ptr(), pa.data_ptr()))
+            keep_m.append((w, pw, pa, nb))
+        arr = (_lib.PcWideJob * len(jobs))(*jobs)
+        _lib.call('crfconv_pointconv_wide_params_jobs', ctypes.cast(arr, ctypes.c_void_p), len(jobs), st)
+        for w, pw, pa, nb in keep_m:
+            d = w['d']
+            _DEFER['jobs'].append((w['pW2'], None, pw, nb, d, d))          # dW2 = sum of the [d, d] slabs, installed with every other weight gradient
+            _defer_reduce64(pa.data_ptr(), False, nb, 4 * d, w['dA1b1'], (pa, w))
+        if not wide:
+            return
     dumps, gemms, a1s, keep = [], [], [], []
     for w in wide:
         d, E, dev = w['d'], w['m_tgt'] * w['K'], w['x'].device
@@ -2159,6 +2183,7 @@ class _PointConv(torch.autograd.Function):
 _PC_D = (4, 8, 16, 32, 64, 128)
 _NO_LATE_SUMS_ENV = __import__('os').environ.get('CRFCONV_NO_LATE_SUMS') is not None      # A/B: every slab sum inside its own call
 _NO_LATE_WIDE_ENV = __import__('os').environ.get('CRFCONV_NO_LATE_WIDE') is not None      # A/B: the wide layers' parameter pass inside their own backward
+_NO_WIDE_MFMA_ENV = __import__('os').environ.get('CRFCONV_NO_WIDE_MFMA') is not None      # A/B: d = 32 / 64 through the per-edge dump + GEMM passes as well
 _PC_PARAMS_INKERNEL_MAX_D = int(__import__('os').environ.get('CRFCONV_PC_INKERNEL_D', 16))   # wider: per-edge dump + MFMA reductions
 
 

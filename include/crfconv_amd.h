@@ -330,6 +330,17 @@ typedef struct { const float* x; const float* gout; const float* pos_src; const 
 typedef struct { const float* gw; const float* h1; const float* rel; int64_t n_edges; int d; float slope; void* workspace;
                  size_t workspace_bytes; } crf_pc_a1_job;
 int crfconv_pointconv_bwd_dump_jobs(const crf_pc_dump_job* jobs, int njobs, crf_stream_t stream);
+/* The same parameter pass for K = 16 and d in {32, 64} WITHOUT per-edge tensors (csrc/pointconv_wide.hip): one wavefront per
+ * target point, the three d x d products per edge (h2 = W2 h1, W2^T gh2, dW2 += gh2 (x) h1) on v_mfma_f32_16x16x4_f32.  Per
+ * workgroup b < crfconv_pointconv_wide_params_nblk(m_tgt, d): dw2_partial[b] [d, d] float (row = output channel of W2) and
+ * a1_partial[b] [d, 4] float64 ({dA1[c][0..2], db1[c]}); the caller sums the slabs (crfconv_reduce_jobs / crfconv_reduce_jobs_f64).
+ * ca, cb, cc: the per-channel coefficients of crfconv_pointconv_bwd_reduce_uv (as crf_pc_dump_job).  One launch per width. */
+typedef struct { const float* x; const float* gout; const float* pos_src; const float* pos_tgt; const int32_t* idx32; int K; int64_t m_tgt;
+                 int d; const float* A1; const float* b1; const float* W2; float slope; const float* ca; const float* cb; const float* cc;
+                 float* dw2_partial; double* a1_partial; } crf_pc_wide_job;
+int crfconv_pointconv_wide_params_supported(int64_t m_tgt, int K, int d);
+int64_t crfconv_pointconv_wide_params_nblk(int64_t m_tgt, int d);
+int crfconv_pointconv_wide_params_jobs(const crf_pc_wide_job* jobs, int njobs, crf_stream_t stream);
 int crfconv_pointconv_bwd_a1_jobs(const crf_pc_a1_job* jobs, int njobs, crf_stream_t stream);
 /* Deferred sums.  crfconv_pointconv_bwd_params with dW2 = dA1b1 = NULL and crfconv_pointconv_bwd_a1 with dA1b1 = NULL leave their
  * partial slabs only (crfconv_pointconv_bwd_params_slabs / the aligned start of the a1 workspace, crfconv_pointconv_bwd_a1_nblk slabs);

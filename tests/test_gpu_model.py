@@ -196,8 +196,13 @@ def test_pointconv_module_golden(golden, form, mode):
                 assert_close(sd[k], v, 1e-5, k)
 
 
-@pytest.mark.parametrize('d', [4, 16, 32, 64, 128])
-def test_pointconv_widths_vs_oracle(d):
+@pytest.mark.parametrize('d,deferred', [(4, False), (16, False), (32, False), (64, False), (128, False), (16, True), (32, True),
+                                        (64, True), (128, True)])
+def test_pointconv_widths_vs_oracle(d, deferred):
+    """PointConv forward, input gradient and every parameter gradient against the float32 oracle anchored on float64, all widths.
+    deferred: the backward under ops.deferred_weight_grads -- the wide layers' parameter pass then runs at the end of the pass, at
+    d = 32 / 64 as ONE matrix-pipe launch without per-edge tensors (csrc/pointconv_wide.hip), at d = 128 as dump + GEMM passes."""
+    from crfconv_amd import ops
     from crfconv_amd.models import PointConv
     B, N, K = 2, 200, 16
     pos, nbr = knn_tables(B, N, K, 60 + d)
@@ -218,7 +223,8 @@ def test_pointconv_widths_vs_oracle(d):
     m = m.to(DEV).train()
     xd = t(x).requires_grad_(True)
     out = m(xd, t(pos), t(nbr))
-    (out * t(gout)).sum().backward()
+    with ops.deferred_weight_grads(enabled=deferred):
+        (out * t(gout)).sum().backward()
     assert_close(out, ref, OUT_TOL, 'out')
     assert_close(xd.grad, xr.grad, GRAD_TOL, 'd_x')
     # LeakyReLU kink: a channel whose layer-1 pre-activation sits within fp32 rounding of 0 on some
