@@ -42,6 +42,12 @@ constexpr int PWAVES = PBLOCK / WAVE;
 #ifndef PC_KS_128
 #define PC_KS_128 2          // swept with PC_KS_64 on the training step: (4, 4) 5.285, (2, 2) 5.249, (2, 4) 5.267, (4, 2) 5.235, (1, 2) 5.271 ms
 #endif
+// matrix-pipe forms of the wide layers (pointconv_wide.hip)
+bool uvstats_mfma_ok(int K, int d);
+int uvstats_mfma_launch(const float* x, const float* pos_src, const float* pos_tgt, const int32_t* idx32, int64_t m_tgt, int d,
+                        const float* A1, const float* b1, const float* W2, float slope, const float* mean_rel3, float* shift, float* U,
+                        float* V, float* partial, int64_t max_blocks, int64_t* nblk_out, hipStream_t st);
+
 template <int D>
 struct PC {
     static constexpr int L = D / 4;
@@ -1384,10 +1390,17 @@ extern "C" int crfconv_pointconv_forward_uv(const float* x, const float* pos_src
     if (int rc = check_pc(m_tgt, K, d)) return rc;
     CRF_REQUIRE(x && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && mean_rel3 && shift && stats && U && V &&
                     workspace, CRF_ERR_ARG, "null pointer");
-    const int64_t nblk = blocks_for(m_tgt, d);
+    int64_t nblk = blocks_for(m_tgt, d);
     CRF_REQUIRE(workspace_bytes >= sizeof(float) * 2 * d * (size_t)nblk, CRF_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = as_stream(stream);
     float* partial = reinterpret_cast<float*>(workspace);
+    static const bool no_mfma = getenv("CRFCONV_NO_WIDE_MFMA") != nullptr;      // A/B: the vector-ALU pass at every width
+    if (!no_mfma && uvstats_mfma_ok(K, d) && m_tgt < ((int64_t)1 << 27)) {
+        // wide layers, K = 16: layer 2 of a point's sixteen edges on the matrix pipe (pointconv_wide.hip)
+        const int64_t room = (int64_t)(workspace_bytes / (sizeof(float) * 2 * d));
+        if (int rc = uvstats_mfma_launch(x, pos_src, pos_tgt, idx32, m_tgt, d, A1, b1, W2, slope, mean_rel3, shift, U, V, partial, room, &nblk, st)) return rc;
+        return reduce_partials(partial, nblk, 2 * d, stats, st);
+    }
     DISPATCH_D(d, {
         hipLaunchKernelGGL(uvstats_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, pos_src, pos_tgt, idx32, K,
                            m_tgt, A1, b1, W2, slope, mean_rel3, shift, U, V, partial);

@@ -45,13 +45,14 @@ struct WideJobs {
 template <int D>
 __global__ __launch_bounds__(WP_BLOCK) void wide_params_kernel(const WideJobs t) {
     constexpr int T16 = D / 16, S4 = D / 4, LDW = D + 4, LDG = D + 4, LDH = D + 16, K = 16;
+    constexpr int UNR = S4 > 16 ? 4 : S4;           // k-steps unrolled at a time (fully unrolled, the d = 128 form runs out of registers)
     __shared__ float s_w2[D * LDW];                       // W2[c][c'], row c padded to LDW
     __shared__ float4 s_a1[D];                            // {A1[c'][0..2], b1[c']}
     __shared__ float s_coef[3 * D];                       // ca | cb | cc
     __shared__ float s_g[WP_WAVES][K * LDG];              // GH2 tile of the wave's point  [edge][channel]
     __shared__ float s_h[WP_WAVES][K * LDH];              // H1 tile                        [edge][channel]
     __shared__ float4 s_rel[WP_WAVES][K];                 // {rel x, y, z, 1} per edge (zero row for a missing edge)
-    __shared__ float s_red[D * D];                        // block sum of dW2; reused for the [d, 4] sums
+    float* s_red = s_w2;                                  // block sums (dW2 [d, d], then the [d, 4] sums) reuse the W2 tile once the points are done
     int job = 0;
     while (job + 1 < t.njobs && t.blk_base[job + 1] <= (int)blockIdx.x) ++job;
     const int blk = (int)blockIdx.x - t.blk_base[job], nblk = t.nblk[job], m = t.m_tgt[job];
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(WP_BLOCK) void wide_params_kernel(const WideJobs t)
     const int per = (m + nblk - 1) / nblk;
     const int p0 = blk * per, p1 = p0 + per < m ? p0 + per : m;
     for (int p = p0 + wave; p < p1; p += WP_WAVES) {
-        // ---- layer 1 in A-fragment layout: lane (e, kq) -> H1[e][4 s + kq], s = 0 .. D/4 - 1
+        // ---- the lane's edge: lane (e, kq) evaluates layer 1 for H1[e][4 s + kq], s = 0 .. D/4 - 1 (the A-fragment layout)
         const int jraw = idx[(int64_t)p * K + e];
         const bool live = jraw >= 0;
         const int64_t j = live ? jraw : 0;
@@ -110,40 +111,50 @@ __global__ __launch_bounds__(WP_BLOCK) void wide_params_kernel(const WideJobs t)
             jr[r] = __shfl((int)j, 4 * kq + r, WAVE);            // lanes 0..15 hold the neighbour of edge `lane`
             lr[r] = __shfl(live ? 1 : 0, 4 * kq + r, WAVE) != 0;
         }
-        float xv[T16][4], gi[T16];
+        constexpr bool PRELOAD = D <= 64;
+        [[maybe_unused]] float xv[PRELOAD ? T16 : 1][4], gi[PRELOAD ? T16 : 1];
+        if constexpr (PRELOAD) {
 #pragma unroll
-        for (int tj = 0; tj < T16; ++tj) {
-            gi[tj] = gout[(int64_t)p * D + 16 * tj + e];
+            for (int tj = 0; tj < T16; ++tj) {
+                gi[tj] = gout[(int64_t)p * D + 16 * tj + e];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xv[tj][r] = x[(int64_t)jr[r] * D + 16 * tj + e];
-        }
-        float h1f[S4];
-#pragma unroll
-        for (int s = 0; s < S4; ++s) {
-            const float4 a = s_a1[4 * s + kq];
-            const float pre = fmaf(a.x, rx, fmaf(a.y, ry, fmaf(a.z, rz, a.w)));
-            const float h = pre > 0.f ? pre : slope * pre;
-            h1f[s] = live ? h : 0.f;
-            th[e * LDH + 4 * s + kq] = h1f[s];
+                for (int r = 0; r < 4; ++r) xv[tj][r] = x[(int64_t)jr[r] * D + 16 * tj + e];
+            }
         }
         if (kq == 0) trel[e] = live ? make_float4(rx, ry, rz, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-        // ---- (1) H2 = H1 W2^T: B[k = c'][j = c] = W2[c][c']
+        // ---- (1) H2 = H1 W2^T: B[k = c'][j = c] = W2[c][c'].  The A fragment of step s IS layer 1 evaluated for this lane's
+        // (edge, channel 4 s + kq): computed on the fly (five vector instructions against T16 MFMAs), stored to the H1 tile for (4), (5)
         f32x4w acc[T16];
 #pragma unroll
         for (int tj = 0; tj < T16; ++tj) acc[tj] = f32x4w{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < S4; ++s)
+#pragma unroll UNR
+        for (int s = 0; s < S4; ++s) {
+            const float4 a = s_a1[4 * s + kq];
+            const float pre = fmaf(a.x, rx, fmaf(a.y, ry, fmaf(a.z, rz, a.w)));
+            const float h = live ? (pre > 0.f ? pre : slope * pre) : 0.f;
+            th[e * LDH + 4 * s + kq] = h;
 #pragma unroll
             for (int tj = 0; tj < T16; ++tj)
-                acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1f[s], s_w2[(16 * tj + e) * LDW + 4 * s + kq], acc[tj], 0, 0, 0);
+                acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(h, s_w2[(16 * tj + e) * LDW + 4 * s + kq], acc[tj], 0, 0, 0);
+        }
         // ---- (2) gh2 in result layout: acc[tj][r] = H2[edge 4 kq + r][channel 16 tj + e]
 #pragma unroll
         for (int tj = 0; tj < T16; ++tj) {
             const int c = 16 * tj + e;
             const float va = s_coef[c], vb = s_coef[D + c], vc = s_coef[2 * D + c];
+            float gic, xc[4];
+            if constexpr (PRELOAD) {
+                gic = gi[tj];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xc[r] = xv[tj][r];
+            } else {
+                gic = gout[(int64_t)p * D + c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xc[r] = x[(int64_t)jr[r] * D + c];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float gh = fmaf(va, gi[tj] * xv[tj][r], fmaf(vb, acc[tj][r], vc));
+                const float gh = fmaf(va, gic * xc[r], fmaf(vb, acc[tj][r], vc));
                 tg[(4 * kq + r) * LDG + c] = lr[r] ? gh : 0.f;
             }
         }
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(WP_BLOCK) void wide_params_kernel(const WideJobs t)
         // ---- (3) GW = GH2 W2: A[i = edge][k = c] from the GH2 tile, B[k = c][j = c'] = W2[c][c']
 #pragma unroll
         for (int tj = 0; tj < T16; ++tj) acc[tj] = f32x4w{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll UNR
         for (int s = 0; s < S4; ++s) {
             const float a = tg[e * LDG + 4 * s + kq];
 #pragma unroll
@@ -193,6 +204,7 @@ __global__ __launch_bounds__(WP_BLOCK) void wide_params_kernel(const WideJobs t)
         __builtin_amdgcn_wave_barrier();                         // the next point overwrites the tiles
     }
     // ---- block sums.  dW2: accW[ti][tj][r] = dW2[c = 16 ti + 4 kq + r][c' = 16 tj + e]; the wavefronts add in turn (fixed order)
+    __syncthreads();                                             // every wavefront is done with W2
     for (int w = 0; w < WP_WAVES; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -235,10 +247,154 @@ __global__ __launch_bounds__(WP_BLOCK) void wide_params_kernel(const WideJobs t)
     }
 }
 
+// ------------------------------------------------------------------ forward statistics pass of the wide layers on the matrix pipe
+// uvstats_kernel's work (pointconv.hip: U = sum_k (h2 - shift) x_j, V = sum_k x_j and the BatchNorm-2 statistic partials of h2 - shift
+// from ONE pass over the edges) for K = 16, d in {32, 64, 128} with the d x d layer-2 product of a point's sixteen edges as
+// v_mfma_f32_16x16x4_f32 (product (1) above; layer 1 evaluated by the lanes in fragment layout).  These launches sit ON the chain
+// of the coarse levels (2 560 ... 10 240 points): on the vector ALU a wavefront walked a point's edges four at a time through an LDS
+// exchange, 17-21 us per launch whatever the level; here a point is d^2 / 64 MFMAs.
+template <int D>
+__global__ __launch_bounds__(WP_BLOCK) void uvstats_mfma_kernel(const float* __restrict__ x, const float* __restrict__ pos_src,
+                                                                const float* __restrict__ pos_tgt, const int32_t* __restrict__ idx,
+                                                                int m, int nblk, const float* __restrict__ A1,
+                                                                const float* __restrict__ b1, const float* __restrict__ W2, float slope,
+                                                                const float* __restrict__ mean_rel, float* __restrict__ shift_out,
+                                                                float* __restrict__ U, float* __restrict__ V, float* __restrict__ partial) {
+    constexpr int T16 = D / 16, S4 = D / 4, LDW = D + 4, K = 16;
+    constexpr int UNR = S4 > 16 ? 4 : S4;
+    __shared__ float s_w2[D * LDW];
+    __shared__ float4 s_a1[D];
+    __shared__ float s_shift[D];
+    __shared__ float s_h0[D];
+    __shared__ float s_red[WP_WAVES][2][D];
+    for (int i = threadIdx.x; i < D * D; i += WP_BLOCK) s_w2[(i / D) * LDW + (i % D)] = W2[i];
+    for (int c = threadIdx.x; c < D; c += WP_BLOCK) {
+        const float4 a = make_float4(A1[3 * c], A1[3 * c + 1], A1[3 * c + 2], b1[c]);
+        s_a1[c] = a;
+        const float pre = fmaf(a.x, mean_rel[0], fmaf(a.y, mean_rel[1], fmaf(a.z, mean_rel[2], a.w)));
+        s_h0[c] = pre > 0.f ? pre : slope * pre;
+    }
+    __syncthreads();
+    // shift = layer 2 at the mean relative position (the statistics are taken of h2 - shift: no cancellation in the variance);
+    // ascending channel order, the summation order of the vector kernels' h2_of
+    for (int c = threadIdx.x; c < D; c += WP_BLOCK) {
+        float a = 0.f;
+        for (int cp = 0; cp < D; ++cp) a = fmaf(s_h0[cp], s_w2[c * LDW + cp], a);
+        s_shift[c] = a;
+        if (blockIdx.x == 0) shift_out[c] = a;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = lane & 15, kq = lane >> 4;
+    float st1[T16], st2[T16];
+#pragma unroll
+    for (int tj = 0; tj < T16; ++tj) st1[tj] = st2[tj] = 0.f;
+    const int per = (m + nblk - 1) / nblk;
+    const int p0 = (int)blockIdx.x * per, p1 = p0 + per < m ? p0 + per : m;
+    for (int p = p0 + wave; p < p1; p += WP_WAVES) {
+        const int jraw = idx[(int64_t)p * K + e];
+        const bool live = jraw >= 0;
+        const int64_t j = live ? jraw : 0;
+        const float rx = pos_tgt[3 * (int64_t)p] - pos_src[3 * j], ry = pos_tgt[3 * (int64_t)p + 1] - pos_src[3 * j + 1],
+                    rz = pos_tgt[3 * (int64_t)p + 2] - pos_src[3 * j + 2];
+        int jr[4];
+        float lv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            jr[r] = __shfl((int)j, 4 * kq + r, WAVE);
+            lv[r] = __shfl(live ? 1.f : 0.f, 4 * kq + r, WAVE);
+        }
+        float xv[T16][4];
+#pragma unroll
+        for (int tj = 0; tj < T16; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xv[tj][r] = x[(int64_t)jr[r] * D + 16 * tj + e] * lv[r];
+        f32x4w acc[T16];
+#pragma unroll
+        for (int tj = 0; tj < T16; ++tj) acc[tj] = f32x4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll UNR
+        for (int s = 0; s < S4; ++s) {
+            const float4 a = s_a1[4 * s + kq];
+            const float pre = fmaf(a.x, rx, fmaf(a.y, ry, fmaf(a.z, rz, a.w)));
+            const float h = pre > 0.f ? pre : slope * pre;
+#pragma unroll
+            for (int tj = 0; tj < T16; ++tj)
+                acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(h, s_w2[(16 * tj + e) * LDW + 4 * s + kq], acc[tj], 0, 0, 0);
+        }
+        // acc[tj][r] = h2[edge 4 kq + r][channel 16 tj + e]
+#pragma unroll
+        for (int tj = 0; tj < T16; ++tj) {
+            const float sh = s_shift[16 * tj + e];
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dlt = (acc[tj][r] - sh) * lv[r];
+                st1[tj] += dlt;
+                st2[tj] = fmaf(dlt, dlt, st2[tj]);
+                u = fmaf(dlt, xv[tj][r], u);
+                v += xv[tj][r];
+            }
+            u += __shfl_xor(u, 16, WAVE); u += __shfl_xor(u, 32, WAVE);
+            v += __shfl_xor(v, 16, WAVE); v += __shfl_xor(v, 32, WAVE);
+            if (kq == 0) {
+                U[(int64_t)p * D + 16 * tj + e] = u;
+                V[(int64_t)p * D + 16 * tj + e] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int tj = 0; tj < T16; ++tj) {
+        float a = st1[tj], b = st2[tj];
+        a += __shfl_xor(a, 16, WAVE); a += __shfl_xor(a, 32, WAVE);
+        b += __shfl_xor(b, 16, WAVE); b += __shfl_xor(b, 32, WAVE);
+        if (kq == 0) { s_red[wave][0][16 * tj + e] = a; s_red[wave][1][16 * tj + e] = b; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += WP_BLOCK) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < WP_WAVES; ++w) a += s_red[w][i / D][i % D];
+        partial[(int64_t)blockIdx.x * 2 * D + i] = a;            // [block][sum | sum of squares][channel]: block_reduce_store<D, 2>'s layout
+    }
+}
+
+// Points per wavefront.  Every workgroup pays a prologue (W2 into LDS, the shift vector) before its first point, and a wavefront walks
+// its points one after the other (each a chain index row -> rows -> MFMAs -> stores that only OTHER wavefronts overlap): few points per
+// wavefront pay the prologue too often, many leave the chip without wavefronts.  By level size, swept on the training step on one box
+// (big, mid, small): (3, 3, 1) 4.292 ms, (4, 4, 1) 4.300, (4, 2, 1) 4.300, (3, 2, 1) 4.300, (3, 3, 2) 4.307, (4, 4, 4) 4.341; without the
+// matrix-pipe kernels 4.388:
+#ifndef WP_PPW_BIG_
+#define WP_PPW_BIG_ 3         // >= 8192 target points (the 10 240-point level)
+#endif
+#ifndef WP_PPW_MID_
+#define WP_PPW_MID_ 3         // >= 2048 (2 560 points)
+#endif
+#ifndef WP_PPW_SMALL_
+#define WP_PPW_SMALL_ 1       // below (640 points: 160 workgroups)
+#endif
+static int64_t wide_points_per_wave(int64_t m_tgt) {
+    return m_tgt >= 8192 ? WP_PPW_BIG_ : (m_tgt >= 2048 ? WP_PPW_MID_ : WP_PPW_SMALL_);
+}
+
+// 1 when the matrix-pipe statistics pass takes (K, d); *nblk: its workgroup count (<= max_blocks partial slabs of 2 d floats)
+bool uvstats_mfma_ok(int K, int d) { return K == 16 && (d == 32 || d == 64 || d == 128); }
+int uvstats_mfma_launch(const float* x, const float* pos_src, const float* pos_tgt, const int32_t* idx32, int64_t m_tgt, int d,
+                        const float* A1, const float* b1, const float* W2, float slope, const float* mean_rel3, float* shift, float* U,
+                        float* V, float* partial, int64_t max_blocks, int64_t* nblk_out, hipStream_t st) {
+    int64_t nb = cdiv(m_tgt, wide_points_per_wave(m_tgt) * WP_WAVES);
+    if (nb > max_blocks) nb = max_blocks;
+    if (nb < 1) nb = 1;
+    *nblk_out = nb;
+    if (d == 32) hipLaunchKernelGGL(uvstats_mfma_kernel<32>, dim3((unsigned)nb), dim3(WP_BLOCK), 0, st, x, pos_src, pos_tgt, idx32, (int)m_tgt, (int)nb, A1, b1, W2, slope, mean_rel3, shift, U, V, partial);
+    else if (d == 64) hipLaunchKernelGGL(uvstats_mfma_kernel<64>, dim3((unsigned)nb), dim3(WP_BLOCK), 0, st, x, pos_src, pos_tgt, idx32, (int)m_tgt, (int)nb, A1, b1, W2, slope, mean_rel3, shift, U, V, partial);
+    else hipLaunchKernelGGL(uvstats_mfma_kernel<128>, dim3((unsigned)nb), dim3(WP_BLOCK), 0, st, x, pos_src, pos_tgt, idx32, (int)m_tgt, (int)nb, A1, b1, W2, slope, mean_rel3, shift, U, V, partial);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
 static int64_t wide_nblk(int64_t m_tgt, int d) {
-    // about four target points per wavefront: every SIMD of the chip gets work at 2 560 points, the slabs stay small
     (void)d;
-    int64_t nb = cdiv(m_tgt, 4 * WP_WAVES);
+    int64_t nb = cdiv(m_tgt, wide_points_per_wave(m_tgt) * WP_WAVES);
     if (nb < 1) nb = 1;
     if (nb > 2048) nb = 2048;
     return nb;
@@ -249,6 +405,8 @@ static int64_t wide_nblk(int64_t m_tgt, int d) {
 using namespace crf;
 
 extern "C" int crfconv_pointconv_wide_params_supported(int64_t m_tgt, int K, int d) {
+    // (d = 128 compiles to 256 + 256 registers with a few spilled to scratch -- and scratch kernels cannot sit in a replayed hipGraph
+    // on ROCm 7.2: the 640-point level keeps the dump + GEMM passes)
     return (K == 16 && (d == 32 || d == 64) && m_tgt > 0 && m_tgt < ((int64_t)1 << 27)) ? 1 : 0;
 }
 
