@@ -620,12 +620,6 @@ __global__ __launch_bounds__(BLOCK) void wide_sim_bwd_kernel(const float* __rest
 }
 
 
-// The LDS-window kernels measured SLOWER than the plain gather kernels on MI355X (43.0 vs 39.5 us for the
-// level-0 forward, profiles/r1b): after Morton ordering + XCD-contiguous blocks the gathers are L1/L2 hits
-// and the step is bound by the idx / weight / state streams, not by gather issue.  Kept for A/B runs:
-// CRFCONV_WINDOW=1 enables them.
-
-
 }  // namespace crf
 
 using namespace crf;

@@ -243,6 +243,54 @@ def test_pointconv_widths_vs_oracle(d, deferred):
         assert_close_anchored(a, b, c, GRAD_TOL, 'grad ' + k)
 
 
+@pytest.mark.parametrize('d', [32, 64, 128])
+@pytest.mark.parametrize('deferred', [False, True])
+def test_pointconv_wide_layers_on_a_padded_table_with_missing_edges(d, deferred):
+    """The matrix-pipe kernels of the wide layers (csrc/pointconv_wide.hip: forward statistics pass at d >= 32, parameter pass at d = 32 / 64
+    under deferred weight gradients) take one target point = sixteen table entries per MFMA tile; entries < 0 (a padded, variable-degree
+    table: graph.table_from_edges) must contribute nothing.  Ragged in-degrees 3 .. 16, a target count that no workgroup partition divides,
+    separate source / target point sets; checked against a float64 restatement of models/point_conv_big.py:37-58 on the edge list."""
+    from crfconv_amd import ops
+    from crfconv_amd.graph import table_from_edges
+    g = torch.Generator().manual_seed(100 + d)
+    n_tgt, n_src = 333, 517
+    deg = torch.randint(3, 17, (n_tgt,), generator=g)
+    deg[7] = 16
+    tgt = torch.repeat_interleave(torch.arange(n_tgt), deg)
+    src = torch.cat([torch.randperm(n_src, generator=g)[:int(k)] for k in deg])
+    pos_s, pos_t = torch.rand(n_src, 3, generator=g), torch.rand(n_tgt, 3, generator=g)
+    x0 = torch.randn(n_src, d, generator=g)
+    gout = torch.randn(n_tgt, d, generator=g)
+    W1_0, W2_0 = torch.randn(d, 3, generator=g), torch.randn(d, d, generator=g) / d ** 0.5
+    gam1, bet1, gam2, bet2 = (torch.rand(d, generator=g) + 0.5 for _ in range(4))
+
+    def reference():
+        x, W1, W2, g1, b1, g2, b2 = (v.double().clone().requires_grad_(True) for v in (x0, W1_0, W2_0, gam1, bet1, gam2, bet2))
+
+        def bn(h, gm, bt):
+            return (h - h.mean(0)) / torch.sqrt(h.var(0, unbiased=False) + 1e-5) * gm + bt
+        rel = pos_t.double()[tgt] - pos_s.double()[src]
+        w = bn(torch.nn.functional.leaky_relu(bn(rel @ W1.t(), g1, b1), 0.1) @ W2.t(), g2, b2)
+        out = torch.zeros(n_tgt, d, dtype=torch.float64).index_add(0, tgt, w * x[src])
+        (out * gout.double()).sum().backward()
+        return out.detach(), [v.grad for v in (x, W1, W2, g1, b1, g2, b2)]
+    ref_out, ref_grads = reference()
+    table = table_from_edges(tgt.to(DEV), src.to(DEV), n_tgt, n_src)
+    assert table.K == 16 and bool((table.idx32 < 0).any())
+    x = x0.to(DEV).requires_grad_(True)
+    W1, W2 = nn.Parameter(W1_0.to(DEV)), nn.Parameter(W2_0.to(DEV))
+    bn1, bn2 = nn.BatchNorm1d(d).to(DEV).train(), nn.BatchNorm1d(d).to(DEV).train()
+    with torch.no_grad():
+        bn1.weight.copy_(gam1); bn1.bias.copy_(bet1); bn2.weight.copy_(gam2); bn2.bias.copy_(bet2)
+    out = ops.point_conv(x, pos_s.to(DEV), pos_t.to(DEV), table, W1, bn1, W2, bn2, True)
+    with ops.deferred_weight_grads(enabled=deferred):
+        (out * gout.to(DEV)).sum().backward()
+    assert_close(out, ref_out, OUT_TOL, 'out')
+    for got, want, name in zip((x.grad, W1.grad, W2.grad, bn1.weight.grad, bn1.bias.grad, bn2.weight.grad, bn2.bias.grad), ref_grads,
+                               ('dx', 'dW1', 'dW2', 'dgamma1', 'dbeta1', 'dgamma2', 'dbeta2')):
+        assert_close(got, want, GRAD_TOL, name)
+
+
 @pytest.mark.parametrize('name,mode', [('a', 'train'), ('a', 'eval'), ('b', 'train'), ('c', 'train'), ('c', 'eval')])
 def test_resblock_module_golden(golden, name, mode):
     from crfconv_amd.models import ResNetBBlock
