@@ -479,6 +479,60 @@ def cpu_baseline(data, net, steps_T, labels, n_cls, dev):
     return out
 
 
+def other_configs(dev, rank=0):
+    """Informational timings of the other BASELINE.json configs on ONE GPU (they are parity-test cases, tests/test_gpu_model.py, not bench
+    lines; `--other-configs` adds this block to the JSON line): C3 one 122 880-point scan, T = 1, inference; C4 4 x 81 920-point clouds, T = 3,
+    the training step (per-GPU share of the 8-GPU config); C5 one 65 536-point crop, K = 32, T = 5, inference.  hipGraph replays, HIP events."""
+    import crfconv_amd
+    from crfconv_amd import distributed as D
+    from crfconv_amd import models, ops
+    out = {}
+
+    def batch(B, N, K, seed):
+        clouds = [synth_cloud(seed + i, N) for i in range(B)]
+        pos = torch.from_numpy(np.stack([c[0] for c in clouds])).to(dev)
+        x = torch.cat([pos, torch.from_numpy(np.stack([c[1] for c in clouds])).to(dev)], -1)
+        y = torch.from_numpy(np.stack([c[2] for c in clouds])).to(dev)
+        return crfconv_amd.multiscale_compute(pos, x=x, y=y, kernel_size=(K,) * 5, generator=torch.Generator().manual_seed(seed), sort='morton')
+
+    def replay_time(fn, warm=3):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warm):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return _event_time(g.replay, per=5)[0]
+    for name, (B, N, K, T, C) in (('C3 KITTI-like scan, inference', (1, 122880, 16, 1, 19)), ('C5 Semantic3D crop, inference', (1, 65536, 32, 5, 8))):
+        data = batch(B, N, K, 300 + N % 97)
+        net = models.PointConvBig(6, C, use_crf=True, steps=T).to(dev).eval()
+        with torch.no_grad():
+            t = replay_time(lambda: net(data))
+        out[name] = {'points': B * N, 'K': K, 'T': T, 'ms': t * 1e3, 'M_points_per_s': B * N / t / 1e6}
+        del net, data
+    B, N, K, T, C = 4, 81920, 16, 3, 20
+    data = batch(B, N, K, 400)
+    net = models.PointConvBig(6, C, use_crf=True, steps=T).to(dev).train()
+    bucket = D.FlatGradAllReduce(net)
+    opt = crfconv_amd.optim.FlatSGD(bucket, lr=1e-2, momentum=0.95, weight_decay=1e-4)
+    cw, unit = torch.ones(C, device=dev), torch.ones((), device=dev)
+
+    def step():
+        opt.zero_grad()
+        loss = ops.training_loss(net(data), data.y, cw, ignore_index=-1)
+        with ops.deferred_weight_grads(sink=bucket.view_of):
+            loss.backward(unit)
+        bucket.pack()
+        opt.step()
+    t = replay_time(step)
+    out['C4 ScanNet-like batch (per-GPU share), training step'] = {'points': B * N, 'K': K, 'T': T, 'ms': t * 1e3, 'M_points_per_s': B * N / t / 1e6}
+    return out
+
+
 def reference_loop(net, data, cw, steps):
     """The reference's training step, verbatim (trainval.py:99-106): optimizer.zero_grad(); y_pred = model(data);
     y = data.y.reshape(-1) - 1; loss = F.cross_entropy(y_pred, y, weight, ignore_index=-1); loss.backward(); optimizer.step()
@@ -531,6 +585,7 @@ def main():
     ap.add_argument('--points', type=int, default=40960)
     ap.add_argument('--crf-steps', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--other-configs', action='store_true', help='also time BASELINE configs 3, 4 (per-GPU share) and 5 on this GPU (informational block)')
     ap.add_argument('--graph', type=int, default=1, help='capture the training step into a hipGraph (1) or run eagerly (0)')
     ap.add_argument('--sort', default='morton', choices=['morton', 'none'],
                     help="point order emitted by the device collate (kernels are order-agnostic)")
@@ -896,6 +951,14 @@ def main():
                                 'frac_on_measured_traffic': None if step_traffic is None else step_traffic / (ms_per_step * 1e-3) / HBM_PEAK,
                                 'groups': groups, 'ms_per_step': ms_per_step,
                                 'kernel': 'the whole captured training step (fwd + weighted CE + bwd + SGD), %d parameters' % n_par}
+        if args.other_configs:
+            try:
+                out['other_configs'] = other_configs(dev)
+            except Exception as e:
+                import traceback
+                traceback.print_exc()
+                torch.cuda.synchronize()
+                out['other_configs'] = {'error': str(e).splitlines()[0][:200]}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(data, net, T, data.y, n_cls, dev)
         print(json.dumps(out))
