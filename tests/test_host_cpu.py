@@ -150,3 +150,83 @@ def test_bn_counters_advance_as_one_vector():
     assert int(net[0].num_batches_tracked) == 3 and int(net[2].num_batches_tracked) == 8
     ops.tick(net[0])
     assert int(net[0].num_batches_tracked) == 4
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                           # (__name__ != '__main__': no self-launch, no benchmark)
+    return mod
+
+
+def test_step_byte_model_reproduces_the_survey_figures():
+    """bench.step_byte_model (the algorithmic bytes `roofline_step` is quoted on): the mean-field group must be SURVEY 8(d)'s
+    81.9 MB forward for config 2, and its level-0 share the 46.5 MB of `roofline`."""
+    bench = _load_bench()
+    total, groups = bench.step_byte_model(4, 40960, 16, 3, 13)
+    assert abs(groups['mean_field']['fwd'] - 81.9e6) < 0.1e6
+    m, H, K, T = 4 * 40960, 8, 16, 3
+    assert m * (4 * (K - 1) + 4 * H * (2 * T + 1)) == 46530560
+    assert groups['mean_field']['bwd'] == 2 * groups['mean_field']['fwd'] + sum(4 * 40960 // 4 ** l * (4 * K + 4) for l in range(4))
+    assert 3.3e9 < total < 3.7e9 and set(groups) == {'encoder_linear', 'pointconv', 'pool_gather', 'decoder_linear', 'mean_field', 'classifier_loss'}
+    # scaling sanity: twice the points, twice the bytes
+    assert abs(bench.step_byte_model(4, 81920, 16, 3, 13)[0] / total - 2.0) < 1e-9
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher_environment(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: N child processes with the torchrun variables on 127.0.0.1,
+    the parent's exit status = the first failing rank's; under a launcher (WORLD_SIZE set) or at N = 1 without --spawn: nothing."""
+    bench = _load_bench()
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env):
+            self.cmd, self.env, self.returncode = cmd, env, None
+            started.append(self)
+
+        def poll(self):
+            self.returncode = 3 if self.env['RANK'] == '1' else 0
+            return self.returncode
+
+        def kill(self):
+            pass
+    import subprocess as sp
+    monkeypatch.setattr(sp, 'Popen', FakeProc)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '2'])
+    with pytest.raises(SystemExit) as ex:
+        bench._self_launch()
+    assert ex.value.code == 3 and len(started) == 4
+    assert [p.env['RANK'] for p in started] == ['0', '1', '2', '3'] and [p.env['LOCAL_RANK'] for p in started] == ['0', '1', '2', '3']
+    assert all(p.env['WORLD_SIZE'] == '4' and p.env['MASTER_ADDR'] == '127.0.0.1' and p.env['MASTER_PORT'].isdigit() for p in started)
+    assert all(p.cmd[0] == sys.executable and p.cmd[1].endswith('bench.py') and p.cmd[2:] == ['--gpus', '4', '--steps', '2'] for p in started)
+    del started[:]
+    monkeypatch.setenv('WORLD_SIZE', '4')                   # under torchrun: this process IS a rank
+    assert bench._self_launch() is None and not started
+    monkeypatch.delenv('WORLD_SIZE')
+    monkeypatch.setattr(sys, 'argv', ['bench.py'])           # the default N = 1 run stays in-process
+    assert bench._self_launch() is None and not started
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '1', '--spawn'])
+    with pytest.raises(SystemExit):
+        bench._self_launch()
+    assert len(started) == 1 and started[0].env['WORLD_SIZE'] == '1'
+
+
+def test_tolerances_are_tied_to_the_recorded_errors(monkeypatch):
+    """tests/gpu_util.assert_close: with an entry in the baseline the enforced bound is min(stated, 10 x recorded, floor 1e-7)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import gpu_util
+    monkeypatch.delenv('CRFCONV_TOL_RECORD', raising=False)
+    gpu_util.set_current_test('tests/x.py::t')
+    monkeypatch.setattr(gpu_util, '_baseline', {'tests/x.py::t::a#0': 1e-6, 'tests/x.py::t::a#1': 0.0, 'tests/x.py::t::b#0': 1e-3})
+    ref = torch.ones(8)
+    gpu_util.assert_close(ref + 5e-6, ref, 1e-4, 'a')        # 5e-6 <= 10 x 1e-6
+    with pytest.raises(AssertionError, match='recorded on MI355X'):
+        gpu_util.assert_close(ref + 5e-6, ref, 1e-4, 'a')    # second call of the same site: recorded 0 -> floor 1e-7
+    gpu_util.assert_close(ref + 5e-5, ref, 1e-4, 'b')        # recorded error above the stated bound: the stated bound rules
+    with pytest.raises(AssertionError):
+        gpu_util.assert_close(ref + 5e-4, ref, 1e-4, 'b')
+    gpu_util.assert_close(ref + 5e-5, ref, 1e-4, 'unrecorded site')
+    baseline = gpu_util.json.load(open(gpu_util._BASELINE_PATH)) if hasattr(gpu_util, 'json') else __import__('json').load(open(gpu_util._BASELINE_PATH))
+    assert len(baseline) > 2000 and all(v >= 0 for v in baseline.values())
