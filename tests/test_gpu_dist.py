@@ -200,3 +200,22 @@ def test_bench_self_launch_one_rank_over_rccl(tmp_path):
     # a failing rank must surface as a non-zero exit status of the parent
     bad = subprocess.run(cmd + ['--points', '-5'], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT, timeout=600)
     assert bad.returncode != 0
+
+
+def test_bench_self_launch_two_ranks_sharing_the_gpu(tmp_path):
+    """`python bench.py --gpus 2` as the driver would type it on a multi-GPU node -- no launcher, bench.py starts both ranks itself -- here
+    with the two ranks on the one GPU over gloo (CRFCONV_DIST_BACKEND, inherited by the children): both ranks must finish, the parent must
+    relay exactly one JSON line with n_gpus = 2 and the group's size and backend in it."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(CRFCONV_DIST_BACKEND='gloo', OMP_NUM_THREADS='2')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '2', '--points', '8192',
+           '--no-cpu-baseline']
+    with open(str(tmp_path / 'out'), 'w') as fo, open(str(tmp_path / 'err'), 'w') as fe:
+        rc = subprocess.run(cmd, env=env, stdout=fo, stderr=fe, cwd=ROOT, timeout=900).returncode
+    assert rc == 0, open(str(tmp_path / 'err')).read()[-3000:]
+    lines = [l for l in open(str(tmp_path / 'out')).read().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['rccl_ranks_seen'] == 2 and rec['dist_backend'] == 'gloo' and rec['scaling'] == 'weak'
+    assert rec['config']['global_batch'] == 4 and rec['value'] > 0 and rec['allreduce_us'] > 0
