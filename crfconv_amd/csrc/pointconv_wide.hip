@@ -28,7 +28,10 @@
 namespace crf {
 
 using f32x4w = __attribute__((ext_vector_type(4))) float;
-constexpr int WP_BLOCK = 256, WP_WAVES = WP_BLOCK / WAVE, WP_MAX = 8;
+#ifndef WP_BLOCK_
+#define WP_BLOCK_ 512         // 8 wavefronts share one W2 staging (swept on the step, one box: 128 threads 4.337 ms, 256 4.297, 512 4.284)
+#endif
+constexpr int WP_BLOCK = WP_BLOCK_, WP_WAVES = WP_BLOCK / WAVE, WP_MAX = 8;
 
 struct WideJobs {
     const float* x[WP_MAX]; const float* gout[WP_MAX]; const float* pos_src[WP_MAX]; const float* pos_tgt[WP_MAX];
