@@ -165,88 +165,6 @@ __global__ __launch_bounds__(BLOCK) void step_fast_kernel(const float* __restric
 #undef CRF_GATHER_X
 }
 
-// ====================================================================== EXPERIMENT (round 4): coarse-level forward in one launch
-// VERDICT r3 #4c: the T forward launches of a coarse level (40 960 ... 2 560 points: latency chains on < 1 wavefront per SIMD) behind a
-// grid barrier.  The per-step kernels' bodies, one after the other: a point's byte offsets, soft-max weights and z Q stay in registers, x_t
-// rows are stored write-through and gathered past L1 (gridsync.hpp).  Same operations in the same order as sim_step_fast_kernel +
-// step_fast_kernel: bit-identical x_t.  Opt-in (CRFCONV_MF_COOP=1) for the measurement.
-template <int H, int K, bool U16>
-__global__ __launch_bounds__(BLOCK) void mf_coop_kernel(const float* __restrict__ y, const float* __restrict__ z,
-                                                        const int32_t* __restrict__ idx, const uint16_t* __restrict__ idx16, int n_tgt,
-                                                        int n_src, const float* __restrict__ Q, const float* __restrict__ P,
-                                                        float* __restrict__ s, float* __restrict__ xs, int64_t m, int T, unsigned* ws) {
-    constexpr int L = Geo<H>::L;
-    __shared__ float4 sQ[MatStage<H>::F4];
-    __shared__ float4 sP[MatStage<H>::F4];
-    __shared__ int s_ok;
-    int lane, q;
-    bool valid;
-    const int64_t r = my_point<H>(m, lane, q, valid);
-    int off[K];
-    load_index_offsets_t<K, U16, H>(idx, idx16, r, n_tgt, n_src, q, off);
-    const int tab_bytes = (int)(m * H * 4);
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y, tab_bytes), rz = make_rsrc(z, tab_bytes);
-    const float4 yi = ld4(y + r * H + 4 * q);
-    const float4 zi = ld4(z + r * H + 4 * q);
-    MatStage<H> mq, mp;
-    mq.fetch(Q, false);
-    mp.fetch(P, false);
-    float4 nb[K];
-#pragma unroll
-    for (int k = 1; k < K; ++k) nb[k] = ld4_buf(ry, off[k]);
-    float d[K];
-    float dmin = 3.4e38f;
-#pragma unroll
-    for (int k = 1; k < K; ++k) {
-        const float4 df = sub4(yi, nb[k]);
-        d[k] = group_sum<L>(dot4(df, df));
-        dmin = fminf(dmin, d[k]);
-    }
-#pragma unroll
-    for (int k = 1; k < K; ++k) nb[k] = ld4_buf(rz, off[k]);
-    mq.park(sQ);
-    mp.park(sP);
-    float den = 0.f;
-#pragma unroll
-    for (int k = 1; k < K; ++k) {
-        d[k] = __expf(dmin - d[k]);
-        den += d[k];
-    }
-    const float inv = 1.0f / den;
-    d[0] = 0.f;
-#pragma unroll
-    for (int k = 1; k < K; ++k) d[k] *= inv;
-    if (s != nullptr) store_rows_coalesced<H, K>(d, s, lane, q, m);
-    float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 1; k < K; ++k) msg = fma4(d[k], nb[k], msg);
-    __syncthreads();
-    const float4 zqi = matvec_acc<H>(zi, sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
-    float4 o = matvec_acc<H>(msg, sP, lane, q, zqi);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, (int)((int64_t)T * m * H * 4));
-    const int own = (int)(r * H * 4) + 16 * q;
-    if (valid) st4_sc1(rx, own, o);
-    const unsigned nblk = gridDim.x, bid = blockIdx.x;
-    unsigned n_in_group, n_groups;
-    grid_sync_groups(nblk, bid, n_in_group, n_groups);
-    for (int t = 1; t < T; ++t) {
-        if (!fused_grid_sync<false>(ws, (unsigned)t, n_in_group, n_groups, &s_ok, nullptr, bid)) {
-            const float qnan = __int_as_float(0x7fc00000);       // the barrier gave up: poison, count out (FW_FAIL is set)
-            if (valid) st4_sc1(rx, t * tab_bytes + own, make_float4(qnan, qnan, qnan, qnan));
-            continue;
-        }
-        const int sb = (t - 1) * tab_bytes;
-        msg = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 1; k < K; ++k) nb[k] = ld4_sc1(rx, off[k], sb);
-#pragma unroll
-        for (int k = 1; k < K; ++k) msg = fma4(d[k], nb[k], msg);
-        o = matvec_acc<H>(msg, sP, lane, q, zqi);
-        if (valid) st4_sc1(rx, t * tab_bytes + own, o);
-    }
-    fused_exit_reset(ws, nblk, T);
-}
-
 // (The one-launch forward -- all T steps behind grid barriers, mf_fused_kernel -- and the LDS-window kernels of rounds 1-3 were
 // measured slower than the per-step launches (39-40 us against 25 us; 43.0 against 39.5 us: DESIGN.md 5c, profiles/r2a_*) and
 // were removed in round 4; `git log -- crfconv_amd/csrc/crf.hip` has them.)
@@ -864,47 +782,6 @@ extern "C" int crfconv_similarity_bwd_scatter(const float* w, const float* y, co
         hipLaunchKernelGGL(sim_bwd_scatter_kernel<HH>, grid, dim3(BLOCK), 0, as_stream(stream), w, y,
                            dy_self, rev_ptr, rev_eid, K, kshift_of(K), dy, m_src);
         CRF_LAUNCH_CHECK();
-    });
-    return CRF_OK;
-}
-
-// ---------------------------------------------------------------------- experiment: coarse-level forward in one launch
-template <int H>
-static int coop_capacity() {
-    static int cap = -1;
-    if (cap < 0) {
-        int dev = 0, cus = 0, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_coop_kernel<H, 16, true>, BLOCK, 0) != hipSuccess)
-            return 0;
-        if (per_cu > 3) per_cu = 3;
-        cap = cus * per_cu;
-    }
-    return cap;
-}
-extern "C" int crfconv_meanfield_coop_supported(int64_t m, int H, int K, int k0, int T) {
-    if (!(k0 == 1 && K == 16 && T >= 2 && (H == 16 || H == 32 || H == 64))) return 0;
-    if (m <= 0 || m * H * 4 * (int64_t)T >= ((int64_t)1 << 31)) return 0;
-    int cap = 0;
-    int64_t grid = 0;
-    DISPATCH_H(H, { if constexpr (HH >= 16) { cap = coop_capacity<HH>(); grid = cdiv(m, Geo<HH>::PPB); } });
-    return cap > 0 && grid <= cap ? 1 : 0;
-}
-extern "C" int crfconv_meanfield_forward_coop(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16, int n_tgt,
-                                              int n_src, int K, int k0, int64_t m, int H, const float* Q, const float* P, int T, float* s,
-                                              float* xs, void* ws, size_t ws_bytes, crf_stream_t stream) {
-    if (int rc = check_common(m, H, K, k0)) return rc;
-    CRF_REQUIRE(z && y && idx32 && Q && P && xs && ws, CRF_ERR_ARG, "null pointer");
-    CRF_REQUIRE(ws_bytes >= FW_WORDS * sizeof(unsigned), CRF_ERR_ARG, "barrier workspace too small");
-    CRF_REQUIRE(crfconv_meanfield_coop_supported(m, H, K, k0, T) == 1, CRF_ERR_UNSUPPORTED, "coop forward: shape not supported / not co-resident");
-    hipStream_t st = as_stream(stream);
-    DISPATCH_H(H, {
-        if constexpr (HH >= 16) {
-            const dim3 grid((unsigned)cdiv(m, Geo<HH>::PPB));
-            if (idx16) hipLaunchKernelGGL((mf_coop_kernel<HH, 16, true>), grid, dim3(BLOCK), 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, (unsigned*)ws);
-            else hipLaunchKernelGGL((mf_coop_kernel<HH, 16, false>), grid, dim3(BLOCK), 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, (unsigned*)ws);
-            CRF_LAUNCH_CHECK();
-        }
     });
     return CRF_OK;
 }

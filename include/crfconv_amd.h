@@ -158,15 +158,6 @@ int crfconv_meanfield_forward_u16(const float* z, const float* y, const int32_t*
                                   int n_tgt, int n_src, int K, int k0, int64_t m, int H, const float* Q,
                                   const float* P, int T, float* s, float* xs, crf_stream_t stream);
 
-/* EXPERIMENT (round 4; not used by the nn.Module path): the same forward for a COARSE level (H in {16, 32, 64}, K = 16,
- * k0 = 1, T >= 2) as ONE launch -- the per-step kernels' bodies separated by grid barriers, x_t rows exchanged write-through / past L1.
- * Bit-identical to crfconv_meanfield_forward_u16.  ws: crfconv_gridsync_workspace() bytes, zero before the first launch.
- * crfconv_meanfield_coop_supported: 1 when the shape is taken and the grid is co-resident on this device. */
-int crfconv_meanfield_coop_supported(int64_t m, int H, int K, int k0, int T);
-int crfconv_meanfield_forward_coop(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16, int n_tgt, int n_src,
-                                   int K, int k0, int64_t m, int H, const float* Q, const float* P, int T, float* s, float* xs,
-                                   void* ws, size_t ws_bytes, crf_stream_t stream);
-
 /* One backward step, edge half:  given G = dL/dx_t and x_{t-1}:
  *   gm  = G P^T                              [m, H]
  *   ds (+)= <gm_i, x_{t-1}[j(i,k)]>          [m, K]    (accumulate != 0 adds to ds)
