@@ -52,9 +52,9 @@ SIGNATURES = {
     'crfconv_pointconv_moments_packed': (_i, [_vp, _vp, _vp, _i, _i64, ctypes.c_double, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_moments': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_stats': (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'crfconv_pointconv_forward_uv': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_pointconv_forward_uv': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'crfconv_pointconv_combine': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _f, _f, _i64, _i, _vp, _vp, _vp, _vp, _vp]),
-    'crfconv_pointconv_bwd_reduce_uv': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_pointconv_bwd_reduce_uv': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'crfconv_pointconv_forward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_bwd_reduce': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_bwd_params': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp,
@@ -83,11 +83,11 @@ SIGNATURES = {
     'crfconv_mlp_small_forward_join': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     'crfconv_mlp_backward_supported': (_i, [_i64, _i, _i]),
     'crfconv_mlp_backward_workspace': (_sz, [_i64, _i, _i]),
-    'crfconv_mlp_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_mlp_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'crfconv_linear_forward_cat': (_i, [_vp, _vp, _i, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     'crfconv_mlp_dw_jobs': (_i, [_vp, _i, _vp]),
-    'crfconv_mlp_backward_add': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'crfconv_mlp_backward_cat': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_mlp_backward_add': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    'crfconv_mlp_backward_cat': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'crfconv_bn_workspace': (_sz, [_i64, _i]),
     'crfconv_bn_forward': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_bn_backward': (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -93,4 +93,60 @@ __device__ __forceinline__ void fused_exit_reset(unsigned* ws, unsigned nblk, in
     }
 }
 
+// ------------------------------------------------------------------ "the last workgroup finishes"
+// A launch whose workgroups each leave a row of partial sums and whose LAST workgroup to finish adds the rows: the reduction
+// launch behind it disappears (4-5 us of stream time each on the coarse levels) and no co-residency is needed -- nobody waits.
+// Protocol as above: partial rows stored write-through (st1_sc1 / st4_sc1), drained, one ticket per workgroup; the workgroup that
+// draws the last ticket reads the rows past L1 (ld4_sc1) in a fixed order (bitwise reproducible) and zeroes the ticket for the
+// next launch.  ticket: one zero device word per stream (ops._ticket).
+__device__ __forceinline__ void st1_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, 16);
+}
+__device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned nblk, int* s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old + 1 == nblk;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = last;
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+// In the last workgroup (every thread of it calls; the first NT take part): s_tot[slot] = sum_b partial[b][slot] in double for
+// nslots (a multiple of 4, nslots / 4 dividing NT) slots of nblk rows.  Thread (group g, quad) adds rows g, g + groups, ... in
+// that order with LASTWG_INFLIGHT_ 16-byte loads in flight, then the groups are added in group order.  s_buf: 4 NT doubles.
+#ifndef LASTWG_INFLIGHT_
+#define LASTWG_INFLIGHT_ 8
+#endif
+template <int NT>
+__device__ __forceinline__ void sum_partial_rows_f64(__amdgpu_buffer_rsrc_t pr, int nblk, int nslots, double* s_buf, double* s_tot) {
+    constexpr int UF = LASTWG_INFLIGHT_;
+    const int nq = nslots >> 2, groups = NT / nq, t = threadIdx.x;
+    if (t < NT) {
+        const int grp = t / nq, quad = t % nq;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int b = grp; b < nblk; b += UF * groups) {
+            float4 v[UF];
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const int bb = b + u * groups;
+                v[u] = bb < nblk ? ld4_sc1(pr, (bb * nslots + 4 * quad) * 4, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < UF; ++u) { a0 += (double)v[u].x; a1 += (double)v[u].y; a2 += (double)v[u].z; a3 += (double)v[u].w; }
+        }
+        s_buf[t] = a0; s_buf[NT + t] = a1; s_buf[2 * NT + t] = a2; s_buf[3 * NT + t] = a3;
+    }
+    __syncthreads();
+    if (t < nslots) {
+        const int quad = t >> 2, e = t & 3;
+        double v = s_buf[e * NT + quad];
+        for (int g2 = 1; g2 < groups; ++g2) v += s_buf[e * NT + g2 * nq + quad];
+        s_tot[t] = v;
+    }
+    __syncthreads();
+}
+
 }  // namespace crf

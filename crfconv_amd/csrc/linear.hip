@@ -12,6 +12,7 @@
 // tiles stay in registers for the whole slice; waves of a block combine through LDS; block partials
 // are summed in a fixed order by a second kernel (bitwise reproducible, no float atomics).
 #include "common.hpp"
+#include "gridsync.hpp"
 
 #include <cstdlib>
 
@@ -152,7 +153,24 @@ __global__ __launch_bounds__(WG_BLOCK) void wgrad_jobs_kernel(const WgJobTable t
 // them into dgamma, dbeta, dW and the per-channel coefficients of gY; and dX = gY W is one more pass in which gY is
 // formed in registers from (gA, Y) while loading the operand (linear_fwd_kernel<.., true>).  The step-by-step form
 // (bn_bwd_reduce -> finalize -> bn_bwd_apply -> dX -> wgrad) reads or writes nine [M, C] arrays; this one six, with
-// three launches instead of five, and gY never reaches memory.
+// three launches instead of five, and gY never reaches memory.  (Two launches where the last workgroup of the first pass does the
+// finalize's channel part: crfconv_mlp_backward's ticket.)
+
+// dgamma, dbeta of channel c and the coefficients of  gY = alpha * lrelu'(a y + b) * gA + bet * y + del  (bcoef [5][Co] =
+// a | b | alpha | bet | del) from the two channel sums s1 = sum g1, s2 = sum g1 yh
+__device__ __forceinline__ void mlp_channel_part(int c, double s1, double s2, const float* __restrict__ coef, int64_t M, int Co,
+                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ bcoef) {
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    const double a = coef[c], mu = coef[2 * Co + c], rs = coef[3 * Co + c];
+    const double c2 = s1 / (double)M, c3 = s2 / (double)M;
+    bcoef[c] = coef[c];
+    bcoef[Co + c] = coef[Co + c];
+    bcoef[2 * Co + c] = (float)a;
+    bcoef[3 * Co + c] = (float)(-a * c3 * rs);
+    bcoef[4 * Co + c] = (float)(-a * c2 + a * c3 * rs * mu);
+}
+
 template <int TCO, int TCI>
 __global__ __launch_bounds__(WG_BLOCK) void mlp_bwd_p1_kernel(const float* __restrict__ GA, const float* __restrict__ Y,
                                                               const float* __restrict__ X,
@@ -162,7 +180,10 @@ __global__ __launch_bounds__(WG_BLOCK) void mlp_bwd_p1_kernel(const float* __res
                                                               float* __restrict__ PA /*[nblk][Co][Ci]*/,
                                                               float* __restrict__ PB /*[nblk][Co][Ci]*/,
                                                               float* __restrict__ PG /*[nblk][2][Co]*/,
-                                                              float* __restrict__ PX /*[nblk][Ci]*/) {
+                                                              float* __restrict__ PX /*[nblk][Ci]*/,
+                                                              unsigned* __restrict__ ticket /*null: mlp_bwd_finalize_kernel does the channel part*/,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ bcoef) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int co_base = blockIdx.y * 16 * TCO, ci_base = blockIdx.z * 16 * TCI;
     const int kk = lane >> 4, cc = lane & 15;
@@ -228,7 +249,7 @@ __global__ __launch_bounds__(WG_BLOCK) void mlp_bwd_p1_kernel(const float* __res
         }
     }
     // C/D layout of 16x16x4: col = lane & 15 (j = ci), row = 4 * (lane >> 4) + reg (i = co)
-    __shared__ float s_red[WG_WAVES][TCO * TCI * 256];
+    __shared__ __attribute__((aligned(16))) float s_red[WG_WAVES][TCO * TCI * 256];
     __shared__ float s_v[WG_WAVES][(2 * TCO + TCI) * 16];
     const int64_t pb = (int64_t)blockIdx.x;
     for (int pass = 0; pass < 2; ++pass) {
@@ -267,6 +288,7 @@ __global__ __launch_bounds__(WG_BLOCK) void mlp_bwd_p1_kernel(const float* __res
             if (co < Co && ci < Ci) dst[(pb * Co + co) * Ci + ci] = v;
         }
     }
+    const __amdgpu_buffer_rsrc_t pgr = make_rsrc(PG, (int)gridDim.x * 2 * Co * 4);
     for (int t = threadIdx.x; t < (2 * TCO + TCI) * 16; t += WG_BLOCK) {
         float v = 0.f;
 #pragma unroll
@@ -274,12 +296,22 @@ __global__ __launch_bounds__(WG_BLOCK) void mlp_bwd_p1_kernel(const float* __res
         const int grp = t >> 4, c16 = t & 15;
         if (grp < 2 * TCO) {                                   // sum g1 | sum g1 yh: slabs of ci-slab 0 only
             const int which = grp / TCO, co = co_base + 16 * (grp % TCO) + c16;
-            if (blockIdx.z == 0 && co < Co) PG[(pb * 2 + which) * Co + co] = v;
+            if (blockIdx.z == 0 && co < Co) st1_sc1(pgr, (((int)pb * 2 + which) * Co + co) * 4, v);   // write-through: summed in this launch
         } else {                                               // column sums of X: slabs of co-slab 0 only
             const int ci = ci_base + 16 * (grp - 2 * TCO) + c16;
             if (blockIdx.y == 0 && ci < Ci) PX[pb * Ci + ci] = v;
         }
     }
+    // The channel part of the finalize (dgamma, dbeta, the coefficients of gY for the dX pass) by the LAST workgroup of this launch
+    // to finish (gridsync.hpp): the launch between the two passes of the block's backward disappears.  2 Co <= WG_BLOCK slots.
+    constexpr bool ALIAS = TCO * TCI >= 3;                     // the 10 KB of sums inside s_red (everybody has left it by then)
+    __shared__ double s_own[ALIAS ? 1 : 5 * WG_BLOCK];
+    __shared__ int s_flag;
+    if (ticket == nullptr || !last_workgroup(ticket, gridDim.x * gridDim.y * gridDim.z, &s_flag)) return;
+    double* s_buf = ALIAS ? reinterpret_cast<double*>(&s_red[0][0]) : s_own;
+    double* s_tot = s_buf + 4 * WG_BLOCK;
+    sum_partial_rows_f64<WG_BLOCK>(pgr, (int)gridDim.x, 2 * Co, s_buf, s_tot);
+    if ((int)threadIdx.x < Co) mlp_channel_part(threadIdx.x, s_tot[threadIdx.x], s_tot[Co + threadIdx.x], coef, M, Co, dgamma, dbeta, bcoef);
 }
 
 // dW slots [64 block, 64 block + 64) of one MLP block's backward from its partial slabs (see mlp_bwd_finalize_kernel): shared by
@@ -372,16 +404,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mlp_bwd_finalize_kernel(const float*
             s1 += __shfl_xor(s1, o, WAVE);
             s2 += __shfl_xor(s2, o, WAVE);
         }
-        if (lane != 0) return;
-        dbeta[c] = (float)s1;
-        dgamma[c] = (float)s2;
-        const double a = coef[c], mu = coef[2 * Co + c], rs = coef[3 * Co + c];
-        const double c2 = s1 / (double)M, c3 = s2 / (double)M;
-        bcoef[c] = coef[c];
-        bcoef[Co + c] = coef[Co + c];
-        bcoef[2 * Co + c] = (float)a;
-        bcoef[3 * Co + c] = (float)(-a * c3 * rs);
-        bcoef[4 * Co + c] = (float)(-a * c2 + a * c3 * rs * mu);
+        if (lane == 0) mlp_channel_part(c, s1, s2, coef, M, Co, dgamma, dbeta, bcoef);
         return;
     }
     mlp_dw_slots(PA, PB, PG, PX, nblk, coef, M, Co, Ci, (int)blockIdx.x, dW);
@@ -1622,14 +1645,15 @@ extern "C" size_t crfconv_mlp_backward_workspace(int64_t M, int Ci, int Co) {
 
 static int mlp_backward_impl(const float* gA, const float* Y, const float* X, const float* Xb, int xsplit, const float* W,
                              const float* coef, float slope, int64_t M, int Ci, int Co, float* dX, float* dXb, float* dW,
-                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream,
-                             const float* dX_add = nullptr);
+                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, unsigned* ticket,
+                             crf_stream_t stream, const float* dX_add = nullptr);
 
 extern "C" int crfconv_mlp_backward(const float* gA, const float* Y, const float* X, const float* W, const float* coef,
                                     float slope, int64_t M, int Ci, int Co, float* dX, float* dW, float* dgamma,
-                                    float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream) {
+                                    float* dbeta, void* workspace, size_t workspace_bytes, unsigned* ticket,
+                                    crf_stream_t stream) {
     return mlp_backward_impl(gA, Y, X, nullptr, 0, W, coef, slope, M, Ci, Co, dX, nullptr, dW, dgamma, dbeta, workspace,
-                             workspace_bytes, stream);
+                             workspace_bytes, ticket, stream);
 }
 
 // dX = (the block's input gradient) + dX_add [M, Ci]: the block's input has a second consumer (the shortcut of a ResNet block)
@@ -1637,21 +1661,21 @@ extern "C" int crfconv_mlp_backward(const float* gA, const float* Y, const float
 extern "C" int crfconv_mlp_backward_add(const float* gA, const float* Y, const float* X, const float* W, const float* coef,
                                         float slope, int64_t M, int Ci, int Co, const float* dX_add, float* dX, float* dW,
                                         float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                                        crf_stream_t stream) {
+                                        unsigned* ticket, crf_stream_t stream) {
     CRF_REQUIRE(dX != nullptr || dX_add == nullptr, CRF_ERR_ARG, "dX_add without dX");
     return mlp_backward_impl(gA, Y, X, nullptr, 0, W, coef, slope, M, Ci, Co, dX, nullptr, dW, dgamma, dbeta, workspace,
-                             workspace_bytes, stream, dX_add);
+                             workspace_bytes, ticket, stream, dX_add);
 }
 
 // The block's input was the column concatenation [Xa | Xb]: dXa [M, split], dXb [M, Ci - split] (both or neither NULL).
 extern "C" int crfconv_mlp_backward_cat(const float* gA, const float* Y, const float* Xa, const float* Xb, int split,
                                         const float* W, const float* coef, float slope, int64_t M, int Ci, int Co,
                                         float* dXa, float* dXb, float* dW, float* dgamma, float* dbeta, void* workspace,
-                                        size_t workspace_bytes, crf_stream_t stream) {
+                                        size_t workspace_bytes, unsigned* ticket, crf_stream_t stream) {
     CRF_REQUIRE(Xb && split > 0 && split < Ci && split % 4 == 0 && Ci % 4 == 0 && ((dXa == nullptr) == (dXb == nullptr)),
                 CRF_ERR_ARG, "two-operand form: split=%d Ci=%d must be multiples of 4, dXa / dXb both or neither", split, Ci);
     return mlp_backward_impl(gA, Y, Xa, Xb, split, W, coef, slope, M, Ci, Co, dXa, dXb, dW, dgamma, dbeta, workspace,
-                             workspace_bytes, stream);
+                             workspace_bytes, ticket, stream);
 }
 
 // dW of any number of MLP blocks whose crfconv_mlp_backward(_add / _cat) call was given dW = NULL, from the workspaces those
@@ -1698,8 +1722,8 @@ extern "C" int crfconv_mlp_dw_jobs(const crf_mlp_dw_job* jobs, int njobs, crf_st
 
 static int mlp_backward_impl(const float* gA, const float* Y, const float* X, const float* Xb, int xsplit, const float* W,
                              const float* coef, float slope, int64_t M, int Ci, int Co, float* dX, float* dXb, float* dW,
-                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream,
-                             const float* dX_add) {
+                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, unsigned* ticket,
+                             crf_stream_t stream, const float* dX_add) {
     CRF_REQUIRE(gA && Y && X && W && coef && dgamma && dbeta && workspace, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(dX_add == nullptr || dXb == nullptr, CRF_ERR_ARG, "dX_add is for the one-operand form");
     CRF_REQUIRE(crfconv_mlp_backward_supported(M, Ci, Co) == 1, CRF_ERR_UNSUPPORTED, "shape M=%lld Ci=%d Co=%d not supported",
@@ -1715,9 +1739,11 @@ static int mlp_backward_impl(const float* gA, const float* Y, const float* X, co
     float* PX = reinterpret_cast<float*>(base + off[3]);
     float* pro = reinterpret_cast<float*>(base + off[4]);
     const crf::MlpPlan p = crf::mlp_plan(M, Co, Ci);
+    // the last workgroup of pass 1 does the channel part when its 2 Co sums fit one thread each in groups of whole quads
+    if (!(2 * Co <= crf::WG_BLOCK && crf::WG_BLOCK % (Co / 2) == 0 && (int64_t)p.nblk * 2 * Co * 4 < ((int64_t)1 << 31))) ticket = nullptr;
     {
         const dim3 grid((unsigned)p.nblk, (unsigned)p.gy, (unsigned)p.gz), blk(crf::WG_BLOCK);
-#define P1(TA, TB) hipLaunchKernelGGL((crf::mlp_bwd_p1_kernel<TA, TB>), grid, blk, 0, st, gA, Y, X, Xb, xsplit, coef, slope, M, Co, Ci, p.rows_per_block, PA, PB, PG, PX)
+#define P1(TA, TB) hipLaunchKernelGGL((crf::mlp_bwd_p1_kernel<TA, TB>), grid, blk, 0, st, gA, Y, X, Xb, xsplit, coef, slope, M, Co, Ci, p.rows_per_block, PA, PB, PG, PX, ticket, dgamma, dbeta, pro)
         switch (p.tco * 10 + p.tci) {
             case 11: P1(1, 1); break;
             case 12: P1(1, 2); break;
@@ -1733,9 +1759,12 @@ static int mlp_backward_impl(const float* gA, const float* Y, const float* X, co
     }
     // dW == NULL: the channel part only; the caller finishes dW later from the workspace (crfconv_mlp_dw_jobs)
     const int nw = dW != nullptr ? (int)crf::cdiv((int64_t)Co * Ci, 64) : 0;
-    hipLaunchKernelGGL(crf::mlp_bwd_finalize_kernel, dim3((unsigned)(nw + (Co + crf::MF_WAVES - 1) / crf::MF_WAVES)), dim3(crf::MF_BLOCK), 0, st, PA, PB, PG, PX,
-                       p.nblk, coef, M, Co, Ci, nw, dW, dgamma, dbeta, pro);
-    CRF_LAUNCH_CHECK();
+    const int nc = ticket != nullptr ? 0 : (Co + crf::MF_WAVES - 1) / crf::MF_WAVES;      // channel workgroups (none: done inside pass 1)
+    if (nw + nc > 0) {
+        hipLaunchKernelGGL(crf::mlp_bwd_finalize_kernel, dim3((unsigned)(nw + nc)), dim3(crf::MF_BLOCK), 0, st, PA, PB, PG, PX, p.nblk, coef, M, Co,
+                           Ci, nw, dW, dgamma, dbeta, pro);
+        CRF_LAUNCH_CHECK();
+    }
     if (dX != nullptr) {
         // dX [M, Ci] = gY [M, Co] W [Co, Ci]: the forward kernel with k = Co, outputs = Ci, W read transposed
         const int gCi = Co, gCo = Ci;

@@ -11,6 +11,7 @@
 // with shuffles against float4 rows of W2^T (registers for d <= 16, LDS above).
 #include "common.hpp"
 #include "outer_acc.hpp"
+#include "gridsync.hpp"
 #include <algorithm>
 
 namespace crf {
@@ -46,7 +47,7 @@ constexpr int PWAVES = PBLOCK / WAVE;
 bool uvstats_mfma_ok(int K, int d);
 int uvstats_mfma_launch(const float* x, const float* pos_src, const float* pos_tgt, const int32_t* idx32, int64_t m_tgt, int d,
                         const float* A1, const float* b1, const float* W2, float slope, const float* mean_rel3, float* shift, float* U,
-                        float* V, float* partial, int64_t max_blocks, int64_t* nblk_out, hipStream_t st);
+                        float* V, float* partial, int64_t max_blocks, int64_t* nblk_out, unsigned* ticket, double* stats, hipStream_t st);
 
 template <int D>
 struct PC {
@@ -232,7 +233,7 @@ __device__ __forceinline__ float4 ks_sum(float4 v, float4* s_ks, int lane, int w
 }
 
 // Block-level deterministic reduction of NV per-quad float4 values into partial[block][NV][D].
-template <int D, int NV>
+template <int D, int NV, bool WT = false>      // WT: rows stored write-through, for a last-workgroup sum in the same launch (gridsync.hpp)
 __device__ __forceinline__ void block_reduce_store(const float4 (&v)[NV], float* sred /*[PWAVES][NV][D]*/,
                                                    float* __restrict__ partial, int lane, int wave, int q) {
 #pragma unroll
@@ -249,7 +250,8 @@ __device__ __forceinline__ void block_reduce_store(const float4 (&v)[NV], float*
         float a = 0.f;
 #pragma unroll
         for (int w = 0; w < PWAVES; ++w) a += sred[w * NV * D + t];
-        partial[(int64_t)blockIdx.x * NV * D + t] = a;
+        if constexpr (WT) st1_sc1(make_rsrc(partial, (int)gridDim.x * NV * D * 4), ((int)blockIdx.x * NV * D + t) * 4, a);
+        else partial[(int64_t)blockIdx.x * NV * D + t] = a;
     }
 }
 
@@ -500,7 +502,8 @@ __global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict
                                                          const float* __restrict__ mean_rel,
                                                          float* __restrict__ shift_out,
                                                          float* __restrict__ U, float* __restrict__ V,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                         double* __restrict__ stats) {
     constexpr int EB = PC<D>::EB;
     __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
@@ -585,7 +588,13 @@ __global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict
         st4(U + rw.r * D + 4 * q, u);
         st4(V + rw.r * D + 4 * q, v);
     }
-    block_reduce_store<D, 2>(acc, sred, partial, lane, wave, q);
+    block_reduce_store<D, 2, true>(acc, sred, partial, lane, wave, q);
+    // with a ticket word the last workgroup to finish sums the rows into stats (reduce_partials_kernel's launch otherwise)
+    __shared__ double s_buf[4 * 256], s_tot[2 * D];
+    __shared__ int s_flag;
+    if (ticket == nullptr || !last_workgroup(ticket, gridDim.x, &s_flag)) return;
+    sum_partial_rows_f64<256>(make_rsrc(partial, (int)gridDim.x * 2 * D * 4), (int)gridDim.x, 2 * D, s_buf, s_tot);
+    if (threadIdx.x < 2 * D) stats[threadIdx.x] = s_tot[threadIdx.x];
 }
 
 // out = a2 U + (a2 shift + b2) V   over [m, d] rows (one thread per 4-channel quad).  BatchNorm-2's batch
@@ -636,10 +645,38 @@ __global__ __launch_bounds__(256) void uv_combine_kernel(const float* __restrict
 }
 
 // partial[blk][0][d] = sum_i g_i V_i, partial[blk][1][d] = sum_i g_i U_i over the block's row slice
+// BatchNorm-2 backward coefficients of channel c from the two sums (crfconv_pointconv_fold2_bwd's arithmetic)
+__device__ __forceinline__ void fold2_bwd_coef(int c, int d, double sum_gw, double sum_raw, const float* __restrict__ shift,
+                                               const double* __restrict__ aux2, const float* __restrict__ gamma, double n_edges,
+                                               int use_batch, float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc,
+                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const double mean = aux2[c], rstd = aux2[d + c], g = gamma[c];
+    const double sum_gwh = rstd * (sum_raw - (mean - (double)shift[c]) * sum_gw);    // sum g_w * hhat
+    dgamma[c] = (float)sum_gwh;
+    dbeta[c] = (float)sum_gw;
+    ca[c] = (float)(g * rstd);
+    if (use_batch) {
+        const double mgw = sum_gw / n_edges, mgh = sum_gwh / n_edges;
+        cb[c] = (float)(-g * rstd * rstd * mgh);
+        cc[c] = (float)(-g * rstd * mgw + g * rstd * rstd * mean * mgh);
+    } else {
+        cb[c] = 0.f;
+        cc[c] = 0.f;
+    }
+}
+
+// With a ticket word the LAST workgroup to finish adds the partial rows and derives the coefficients itself (gridsync.hpp:
+// fold2_bwd_partials_kernel's launch disappears); ticket == nullptr leaves the rows for that kernel.
 __global__ __launch_bounds__(256) void uv_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ U,
                                                             const float* __restrict__ V, int64_t m, int d,
-                                                            float* __restrict__ partial) {
+                                                            float* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                            const float* __restrict__ shift, const double* __restrict__ aux2,
+                                                            const float* __restrict__ gamma, double n_edges, int use_batch,
+                                                            float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
     extern __shared__ float s_uv[];                  // [rows per trip][2][d]
+    __shared__ double s_buf[4 * 256], s_tot[256];
+    __shared__ int s_flag;
     const int d4 = d >> 2, rpi = 256 / d4;
     const int q = threadIdx.x % d4, rl = threadIdx.x / d4;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
@@ -663,11 +700,17 @@ __global__ __launch_bounds__(256) void uv_bwd_reduce_kernel(const float* __restr
     st4(s_uv + (rl * 2 + 0) * d + 4 * q, s1);
     st4(s_uv + (rl * 2 + 1) * d + 4 * q, s2);
     __syncthreads();
+    const __amdgpu_buffer_rsrc_t pr = make_rsrc(partial, (int)gridDim.x * 2 * d * 4);
     for (int t = threadIdx.x; t < 2 * d; t += 256) {
         float a = 0.f;
         for (int i = 0; i < rpi; ++i) a += s_uv[i * 2 * d + t];
-        partial[(int64_t)blockIdx.x * 2 * d + t] = a;
+        st1_sc1(pr, ((int)blockIdx.x * 2 * d + t) * 4, a);
     }
+    if (ticket == nullptr || !last_workgroup(ticket, gridDim.x, &s_flag)) return;
+    sum_partial_rows_f64<256>(pr, (int)gridDim.x, 2 * d, s_buf, s_tot);
+    if ((int)threadIdx.x < d)
+        fold2_bwd_coef(threadIdx.x, d, s_tot[threadIdx.x], s_tot[d + threadIdx.x], shift, aux2, gamma, n_edges, use_batch, ca, cb, cc,
+                       dgamma, dbeta);
 }
 
 // ------------------------------------------------------------------ backward pass 1: reductions
@@ -1358,20 +1401,7 @@ __global__ __launch_bounds__(1024) void fold2_bwd_partials_kernel(const float* _
     __syncthreads();
     const int c = threadIdx.x;
     if (c >= d) return;
-    const double mean = aux2[c], rstd = aux2[d + c], g = gamma[c];
-    const double sum_gw = s_red[c];
-    const double sum_gwh = rstd * (s_red[d + c] - (mean - (double)shift[c]) * sum_gw);    // sum g_w * hhat
-    dgamma[c] = (float)sum_gwh;
-    dbeta[c] = (float)sum_gw;
-    ca[c] = (float)(g * rstd);
-    if (use_batch) {
-        const double mgw = sum_gw / n_edges, mgh = sum_gwh / n_edges;
-        cb[c] = (float)(-g * rstd * rstd * mgh);
-        cc[c] = (float)(-g * rstd * mgw + g * rstd * rstd * mean * mgh);
-    } else {
-        cb[c] = 0.f;
-        cc[c] = 0.f;
-    }
+    fold2_bwd_coef(c, d, s_red[c], s_red[d + c], shift, aux2, gamma, n_edges, use_batch, ca, cb, cc, dgamma, dbeta);
 }
 
 }  // namespace crf
@@ -1386,7 +1416,7 @@ extern "C" int crfconv_pointconv_forward_uv(const float* x, const float* pos_src
                                             const int32_t* idx32, int K, int64_t m_tgt, int d, const float* A1,
                                             const float* b1, const float* W2, float slope, const float* mean_rel3,
                                             float* shift, double* stats, float* U, float* V, void* workspace,
-                                            size_t workspace_bytes, crf_stream_t stream) {
+                                            size_t workspace_bytes, unsigned* ticket, crf_stream_t stream) {
     if (int rc = check_pc(m_tgt, K, d)) return rc;
     CRF_REQUIRE(x && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && mean_rel3 && shift && stats && U && V &&
                     workspace, CRF_ERR_ARG, "null pointer");
@@ -1398,15 +1428,16 @@ extern "C" int crfconv_pointconv_forward_uv(const float* x, const float* pos_src
     if (!no_mfma && uvstats_mfma_ok(K, d) && m_tgt < ((int64_t)1 << 27)) {
         // wide layers, K = 16: layer 2 of a point's sixteen edges on the matrix pipe (pointconv_wide.hip)
         const int64_t room = (int64_t)(workspace_bytes / (sizeof(float) * 2 * d));
-        if (int rc = uvstats_mfma_launch(x, pos_src, pos_tgt, idx32, m_tgt, d, A1, b1, W2, slope, mean_rel3, shift, U, V, partial, room, &nblk, st)) return rc;
-        return reduce_partials(partial, nblk, 2 * d, stats, st);
+        if (int rc = uvstats_mfma_launch(x, pos_src, pos_tgt, idx32, m_tgt, d, A1, b1, W2, slope, mean_rel3, shift, U, V, partial, room, &nblk, ticket, stats, st)) return rc;
+        return ticket != nullptr ? CRF_OK : reduce_partials(partial, nblk, 2 * d, stats, st);
     }
+    if (nblk * (d / 2) > 256 * 24) ticket = nullptr;    // the last workgroup's sum pays up to three rounds of eight 16-byte loads per thread
     DISPATCH_D(d, {
         hipLaunchKernelGGL(uvstats_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, pos_src, pos_tgt, idx32, K,
-                           m_tgt, A1, b1, W2, slope, mean_rel3, shift, U, V, partial);
+                           m_tgt, A1, b1, W2, slope, mean_rel3, shift, U, V, partial, ticket, stats);
     });
     CRF_LAUNCH_CHECK();
-    return reduce_partials(partial, nblk, 2 * d, stats, st);
+    return ticket != nullptr ? CRF_OK : reduce_partials(partial, nblk, 2 * d, stats, st);
 }
 
 extern "C" int crfconv_pointconv_combine(const float* U, const float* V, const double* stats, const float* shift,
@@ -1427,7 +1458,7 @@ extern "C" int crfconv_pointconv_bwd_reduce_uv(const float* gout, const float* U
                                                const float* shift, const double* aux2, const float* gamma2,
                                                double n_edges, int use_batch, float* ca, float* cb, float* cc,
                                                float* dgamma2, float* dbeta2, void* workspace, size_t workspace_bytes,
-                                               crf_stream_t stream) {
+                                               unsigned* ticket, crf_stream_t stream) {
     if (int rc = check_pc(m_tgt, 1, d)) return rc;
     CRF_REQUIRE(gout && U && V && shift && aux2 && gamma2 && ca && cb && cc && dgamma2 && dbeta2 && workspace,
                 CRF_ERR_ARG, "null pointer");
@@ -1437,8 +1468,9 @@ extern "C" int crfconv_pointconv_bwd_reduce_uv(const float* gout, const float* U
     float* partial = reinterpret_cast<float*>(workspace);
     const int rpi = 256 / (d / 4);
     hipLaunchKernelGGL(uv_bwd_reduce_kernel, dim3((unsigned)nblk), dim3(256), sizeof(float) * 2 * d * rpi, st, gout, U, V,
-                       m_tgt, d, partial);
+                       m_tgt, d, partial, ticket, shift, aux2, gamma2, n_edges, use_batch, ca, cb, cc, dgamma2, dbeta2);
     CRF_LAUNCH_CHECK();
+    if (ticket != nullptr) return CRF_OK;             // the last workgroup has derived the coefficients
     hipLaunchKernelGGL(fold2_bwd_partials_kernel, dim3(1), dim3(1024), 0, st, partial, (int)nblk, shift, aux2, gamma2,
                        n_edges, use_batch, d, ca, cb, cc, dgamma2, dbeta2);
     CRF_LAUNCH_CHECK();
@@ -1881,20 +1913,7 @@ __global__ __launch_bounds__(128) void fold2_bwd_kernel(const double* __restrict
                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int c = threadIdx.x;
     if (c >= d) return;
-    const double mean = aux2[c], rstd = aux2[d + c], g = gamma[c];
-    const double sum_gw = red[c];
-    const double sum_gwh = rstd * (red[d + c] - (mean - (double)shift[c]) * sum_gw);    // sum g_w * hhat
-    dgamma[c] = (float)sum_gwh;
-    dbeta[c] = (float)sum_gw;
-    ca[c] = (float)(g * rstd);
-    if (use_batch) {
-        const double mgw = sum_gw / n_edges, mgh = sum_gwh / n_edges;
-        cb[c] = (float)(-g * rstd * rstd * mgh);
-        cc[c] = (float)(-g * rstd * mgw + g * rstd * rstd * mean * mgh);
-    } else {
-        cb[c] = 0.f;
-        cc[c] = 0.f;
-    }
+    fold2_bwd_coef(c, d, red[c], red[d + c], shift, aux2, gamma, n_edges, use_batch, ca, cb, cc, dgamma, dbeta);
 }
 
 }  // namespace crf

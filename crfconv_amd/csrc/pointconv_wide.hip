@@ -24,6 +24,7 @@
 // Per workgroup: one float slab [d, d] (dW2) and one float64 slab [d, 4] (dA1 | db1); the sums over workgroups join the batched
 // reductions at the end of the backward pass (crfconv_reduce_jobs, crfconv_reduce_jobs_f64).
 #include "common.hpp"
+#include "gridsync.hpp"
 
 namespace crf {
 
@@ -262,10 +263,11 @@ __global__ __launch_bounds__(WP_BLOCK) void uvstats_mfma_kernel(const float* __r
                                                                 int m, int nblk, const float* __restrict__ A1,
                                                                 const float* __restrict__ b1, const float* __restrict__ W2, float slope,
                                                                 const float* __restrict__ mean_rel, float* __restrict__ shift_out,
-                                                                float* __restrict__ U, float* __restrict__ V, float* __restrict__ partial) {
+                                                                float* __restrict__ U, float* __restrict__ V, float* __restrict__ partial,
+                                                                unsigned* __restrict__ ticket, double* __restrict__ stats) {
     constexpr int T16 = D / 16, S4 = D / 4, LDW = D + 4, K = 16;
     constexpr int UNR = S4 > 16 ? 4 : S4;
-    __shared__ float s_w2[D * LDW];
+    __shared__ __attribute__((aligned(16))) float s_w2[D * LDW];
     __shared__ float4 s_a1[D];
     __shared__ float s_shift[D];
     __shared__ float s_h0[D];
@@ -353,12 +355,22 @@ __global__ __launch_bounds__(WP_BLOCK) void uvstats_mfma_kernel(const float* __r
         if (kq == 0) { s_red[wave][0][16 * tj + e] = a; s_red[wave][1][16 * tj + e] = b; }
     }
     __syncthreads();
+    const __amdgpu_buffer_rsrc_t pr = make_rsrc(partial, (int)gridDim.x * 2 * D * 4);
     for (int i = threadIdx.x; i < 2 * D; i += WP_BLOCK) {
         float a = 0.f;
 #pragma unroll
         for (int w = 0; w < WP_WAVES; ++w) a += s_red[w][i / D][i % D];
-        partial[(int64_t)blockIdx.x * 2 * D + i] = a;            // [block][sum | sum of squares][channel]: block_reduce_store<D, 2>'s layout
+        st1_sc1(pr, ((int)blockIdx.x * 2 * D + i) * 4, a);       // [block][sum | sum of squares][channel]: block_reduce_store<D, 2>'s layout
     }
+    // with a ticket word the last workgroup to finish sums the rows into stats (gridsync.hpp; reduce_partials_kernel's launch otherwise)
+    // (its 16 KB of LDS: at d = 128 inside the W2 tile, which every wavefront has left by then -- two workgroups per CU as before)
+    constexpr bool ALIAS = sizeof(float) * D * LDW >= sizeof(double) * 4 * WP_BLOCK;
+    __shared__ double s_own[ALIAS ? 1 : 4 * WP_BLOCK], s_tot[2 * D];
+    __shared__ int s_flag;
+    if (ticket == nullptr || !last_workgroup(ticket, gridDim.x, &s_flag)) return;
+    double* s_buf = ALIAS ? reinterpret_cast<double*>(s_w2) : s_own;
+    sum_partial_rows_f64<WP_BLOCK>(pr, (int)gridDim.x, 2 * D, s_buf, s_tot);
+    if (threadIdx.x < 2 * D) stats[threadIdx.x] = s_tot[threadIdx.x];
 }
 
 // Points per wavefront.  Every workgroup pays a prologue (W2 into LDS, the shift vector) before its first point, and a wavefront walks
@@ -383,14 +395,14 @@ static int64_t wide_points_per_wave(int64_t m_tgt) {
 bool uvstats_mfma_ok(int K, int d) { return K == 16 && (d == 32 || d == 64 || d == 128); }
 int uvstats_mfma_launch(const float* x, const float* pos_src, const float* pos_tgt, const int32_t* idx32, int64_t m_tgt, int d,
                         const float* A1, const float* b1, const float* W2, float slope, const float* mean_rel3, float* shift, float* U,
-                        float* V, float* partial, int64_t max_blocks, int64_t* nblk_out, hipStream_t st) {
+                        float* V, float* partial, int64_t max_blocks, int64_t* nblk_out, unsigned* ticket, double* stats, hipStream_t st) {
     int64_t nb = cdiv(m_tgt, wide_points_per_wave(m_tgt) * WP_WAVES);
     if (nb > max_blocks) nb = max_blocks;
     if (nb < 1) nb = 1;
     *nblk_out = nb;
-    if (d == 32) hipLaunchKernelGGL(uvstats_mfma_kernel<32>, dim3((unsigned)nb), dim3(WP_BLOCK), 0, st, x, pos_src, pos_tgt, idx32, (int)m_tgt, (int)nb, A1, b1, W2, slope, mean_rel3, shift, U, V, partial);
-    else if (d == 64) hipLaunchKernelGGL(uvstats_mfma_kernel<64>, dim3((unsigned)nb), dim3(WP_BLOCK), 0, st, x, pos_src, pos_tgt, idx32, (int)m_tgt, (int)nb, A1, b1, W2, slope, mean_rel3, shift, U, V, partial);
-    else hipLaunchKernelGGL(uvstats_mfma_kernel<128>, dim3((unsigned)nb), dim3(WP_BLOCK), 0, st, x, pos_src, pos_tgt, idx32, (int)m_tgt, (int)nb, A1, b1, W2, slope, mean_rel3, shift, U, V, partial);
+    if (d == 32) hipLaunchKernelGGL(uvstats_mfma_kernel<32>, dim3((unsigned)nb), dim3(WP_BLOCK), 0, st, x, pos_src, pos_tgt, idx32, (int)m_tgt, (int)nb, A1, b1, W2, slope, mean_rel3, shift, U, V, partial, ticket, stats);
+    else if (d == 64) hipLaunchKernelGGL(uvstats_mfma_kernel<64>, dim3((unsigned)nb), dim3(WP_BLOCK), 0, st, x, pos_src, pos_tgt, idx32, (int)m_tgt, (int)nb, A1, b1, W2, slope, mean_rel3, shift, U, V, partial, ticket, stats);
+    else hipLaunchKernelGGL(uvstats_mfma_kernel<128>, dim3((unsigned)nb), dim3(WP_BLOCK), 0, st, x, pos_src, pos_tgt, idx32, (int)m_tgt, (int)nb, A1, b1, W2, slope, mean_rel3, shift, U, V, partial, ticket, stats);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -327,6 +327,20 @@ def _ticket(device):
     return _stream_buf(_TICKETS, device, lambda: torch.zeros(64, dtype=torch.int32, device=device))
 
 
+_NO_PC_TICKET_ENV = __import__('os').environ.get('CRFCONV_NO_PC_TICKET') is not None     # A/B: PointConv's statistic / coefficient sums as launches of their own
+
+
+def _pc_ticket(device):
+    return None if _NO_PC_TICKET_ENV else ptr(_ticket(device))
+
+
+_NO_MLP_TICKET_ENV = __import__('os').environ.get('CRFCONV_NO_MLP_TICKET') is not None   # A/B: the MLP backward's channel part as a launch of its own
+
+
+def _mlp_ticket(device):
+    return None if _NO_MLP_TICKET_ENV else ptr(_ticket(device))
+
+
 class _MeanFieldWide(torch.autograd.Function):
     """The mean-field loop for H in {128, 256} (the 256- / 128-channel GCRFConv stages of the sparse networks,
     models/point_conv.py:318-339, on the coarsest point sets): the H x H tiles of csrc/crf.hip's kernels no longer fit
@@ -1118,7 +1132,7 @@ class _MLPBlock(torch.autograd.Function):
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward_add', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(add), ptr(dX),
-                  ptr(None if dfr else dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
+                  ptr(None if dfr else dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _mlp_ticket(dev), stream_ptr())
         return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, None, None
 
 
@@ -1168,7 +1182,7 @@ class _MLPBlockJoin(torch.autograd.Function):
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward', ptr(g1), ptr(y), ptr(x), ptr(W), ptr(coef), 1.0, m, ci, co, ptr(dX), ptr(None if dfr else dW),
-                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
+                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _mlp_ticket(dev), st)
         gskip = g1 if ctx.needs_input_grad[8] else None
         return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, gskip, None
 
@@ -1220,7 +1234,7 @@ class _MLPBlockDropout(torch.autograd.Function):
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(None if dfr else dW),
-                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
+                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _mlp_ticket(dev), st)
         return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, None, None, None, None
 
 
@@ -1278,7 +1292,7 @@ class _MLPDropoutLinear(torch.autograd.Function):
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), ctx.slope, m, ci, co, ptr(dX), ptr(None if dfr else dW),
-                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
+                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _mlp_ticket(dev), st)
         return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, None, None, None, None, dW2, db2
 
 
@@ -1394,7 +1408,7 @@ class _MLPBlockPool(torch.autograd.Function):
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward_add', ptr(gA), ptr(y), ptr(x), ptr(W), ptr(coef), 1.0, m, ci, co, ptr(add), ptr(dX),
-                  ptr(None if dfr else dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, st)
+                  ptr(None if dfr else dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _mlp_ticket(dev), st)
         return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, None, None
 
 
@@ -1683,7 +1697,7 @@ class _MLPBlockCat(torch.autograd.Function):
         nbytes = _lib.load().crfconv_mlp_backward_workspace(m, ci, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_mlp_backward_cat', ptr(gA), ptr(y), ptr(xa), ptr(xb), split, ptr(W), ptr(coef), ctx.slope, m, ci, co,
-                  ptr(dxa), ptr(dxb), ptr(None if dfr else dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
+                  ptr(dxa), ptr(dxb), ptr(None if dfr else dW), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _mlp_ticket(dev), stream_ptr())
         return (dxa if ctx.needs_input_grad[0] else None, dxb if ctx.needs_input_grad[1] else None,
                 *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef),
                 None, None, None, None, None)
@@ -2056,7 +2070,7 @@ class _PointConv(torch.autograd.Function):
             mean_rel = mom32 if mom32 is not None else mom[:3].float()
             _lib.call('crfconv_pointconv_forward_uv', ptr(x), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d,
                       ptr(A1), ptr(b1), ptr(W2c), slope, ptr(mean_rel), ptr(shift), ptr(stats), ptr(U), ptr(V), ptr(ws),
-                      nbytes, st)
+                      nbytes, _pc_ticket(dev), st)
         a2 = torch.empty(d, dtype=torch.float32, device=dev)
         b2 = torch.empty(d, dtype=torch.float32, device=dev)
         aux2 = torch.empty(2 * d, dtype=torch.float64, device=dev)
@@ -2093,7 +2107,7 @@ class _PointConv(torch.autograd.Function):
         if U is not None:                  # training forward left U, V: the reductions are row sums, no edge pass
             _lib.call('crfconv_pointconv_bwd_reduce_uv', ptr(g), ptr(U), ptr(V), m_tgt, d, ptr(shift), ptr(aux2), ptr(g2),
                       n_e, 1 if ctx.use2 else 0, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), ptr(coef[4]),
-                      ptr(ws), nbytes, st)
+                      ptr(ws), nbytes, _pc_ticket(dev), st)
         else:
             red = torch.empty(2 * d, dtype=torch.float64, device=dev)
             _lib.call('crfconv_pointconv_bwd_reduce', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,

@@ -276,7 +276,7 @@ int crfconv_pointconv_forward_uv(const float* x, const float* pos_src, const flo
                                  const int32_t* idx32, int K, int64_t m_tgt, int d, const float* A1,
                                  const float* b1, const float* W2, float slope, const float* mean_rel3,
                                  float* shift, double* stats, float* U, float* V, void* workspace,
-                                 size_t workspace_bytes, crf_stream_t stream);
+                                 size_t workspace_bytes, unsigned* ticket, crf_stream_t stream);
 int crfconv_pointconv_combine(const float* U, const float* V, const double* stats, const float* shift,
                               const float* gamma2, const float* beta2, double n_edges, float* run_mean,
                               float* run_var, float momentum, float eps, int64_t m_tgt, int d, float* a2, float* b2,
@@ -284,7 +284,7 @@ int crfconv_pointconv_combine(const float* U, const float* V, const double* stat
 int crfconv_pointconv_bwd_reduce_uv(const float* gout, const float* U, const float* V, int64_t m_tgt, int d,
                                     const float* shift, const double* aux2, const float* gamma2, double n_edges,
                                     int use_batch, float* ca, float* cb, float* cc, float* dgamma2, float* dbeta2,
-                                    void* workspace, size_t workspace_bytes, crf_stream_t stream);
+                                    void* workspace, size_t workspace_bytes, unsigned* ticket, crf_stream_t stream);
 int crfconv_pointconv_forward(const float* x, const float* pos_src, const float* pos_tgt,
                               const int32_t* idx32, int K, int64_t m_tgt, int d, const float* A1,
                               const float* b1, const float* W2, float slope, const float* a2, const float* b2,
@@ -453,12 +453,16 @@ int crfconv_mlp_small_forward_join(const float* X, const float* W, int64_t M, in
  * diag(dgamma / M) Yh^T X] and the per-channel coefficients of gY; pass 2 forms gY in registers while loading (gA, Y)
  * and writes dX = gY W (skipped when dX is NULL).  gA, Y [M, Co]; X [M, Ci]; W [Co, Ci]; coef = the [4, Co] block of
  * crfconv_bn_forward / crfconv_bn_coef_from_records for Y.  Same results as crfconv_bn_backward ->
- * crfconv_linear_forward(transpose) + crfconv_linear_wgrad up to summation order. */
+ * crfconv_linear_forward(transpose) + crfconv_linear_wgrad up to summation order.
+ * ticket (crfconv_mlp_backward / _add / _cat, crfconv_pointconv_forward_uv / _bwd_reduce_uv): one ZERO device word owned by the
+ * stream (the kernels leave it zero), or NULL.  With it the LAST workgroup of the first pass to finish adds the partial rows and
+ * does the finalize's channel part itself (write-through stores, one atomic ticket per workgroup, fixed summation order): one
+ * launch less on the chain (here, for Co in {4, 8, .., 128}, when dW is NULL: two launches).  NULL: the launch-separated form. */
 int crfconv_mlp_backward_supported(int64_t M, int Ci, int Co);
 size_t crfconv_mlp_backward_workspace(int64_t M, int Ci, int Co);
 int crfconv_mlp_backward(const float* gA, const float* Y, const float* X, const float* W, const float* coef, float slope,
                          int64_t M, int Ci, int Co, float* dX, float* dW, float* dgamma, float* dbeta, void* workspace,
-                         size_t workspace_bytes, crf_stream_t stream);
+                         size_t workspace_bytes, unsigned* ticket, crf_stream_t stream);
 /* dW may be NULL in crfconv_mlp_backward / _add / _cat: the finalize launch then does its channel part only (dgamma, dbeta, the
  * coefficients dX needs) and the weight gradient is finished later, for any number of blocks in ONE launch, from the
  * workspaces those calls left behind (which must be untouched since): nothing inside a backward pass reads a weight gradient. */
@@ -469,7 +473,7 @@ int crfconv_mlp_dw_jobs(const crf_mlp_dw_job* jobs, int njobs, crf_stream_t stre
  * consumer already sent back (NULL: as crfconv_mlp_backward).  Replaces the accumulation pass autograd would run. */
 int crfconv_mlp_backward_add(const float* gA, const float* Y, const float* X, const float* W, const float* coef, float slope,
                              int64_t M, int Ci, int Co, const float* dX_add, float* dX, float* dW, float* dgamma, float* dbeta,
-                             void* workspace, size_t workspace_bytes, crf_stream_t stream);
+                             void* workspace, size_t workspace_bytes, unsigned* ticket, crf_stream_t stream);
 /* The block whose input is the column concatenation [Xa | Xb] (the CRF layers' fusion_nn(cat[x, pairwise]),
  * models/continuous_crf_conv_big.py:76) without materialising it: Xa [M, split], Xb [M, Ci - split], split % 4 == 0;
  * the forward product is crfconv_linear_forward_cat, the backward writes dXa / dXb separately. */
@@ -477,7 +481,8 @@ int crfconv_linear_forward_cat(const float* Xa, const float* Xb, int split, cons
                                int Ci, int Co, float* Y, float* stat_rec, crf_stream_t stream);
 int crfconv_mlp_backward_cat(const float* gA, const float* Y, const float* Xa, const float* Xb, int split, const float* W,
                              const float* coef, float slope, int64_t M, int Ci, int Co, float* dXa, float* dXb, float* dW,
-                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, crf_stream_t stream);
+                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, unsigned* ticket,
+                             crf_stream_t stream);
 
 /* Fused BatchNorm (+ LeakyReLU) over rows x [M, C] (models/common.py:31,36-37; C % 4 == 0, C <= 1024).
  * forward:  use_batch_stats != 0 -> statistics of x (biased variance), running stats updated in place when non-NULL
