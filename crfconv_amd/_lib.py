@@ -81,6 +81,7 @@ SIGNATURES = {
     'crfconv_mlp_small_workspace': (_sz, [_i64, _i]),
     'crfconv_mlp_small_forward': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     'crfconv_mlp_small_forward_join': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    'crfconv_ticket_bytes': (_sz, []),
     'crfconv_mlp_backward_supported': (_i, [_i64, _i, _i]),
     'crfconv_mlp_backward_workspace': (_sz, [_i64, _i, _i]),
     'crfconv_mlp_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),

@@ -93,21 +93,46 @@ __device__ __forceinline__ void fused_exit_reset(unsigned* ws, unsigned nblk, in
     }
 }
 
+#ifndef LASTWG_GROUPS_
+#define LASTWG_GROUPS_ 32
+#endif
+#ifndef LASTWG_FLAT_
+#define LASTWG_FLAT_ 64
+#endif
 // ------------------------------------------------------------------ "the last workgroup finishes"
 // A launch whose workgroups each leave a row of partial sums and whose LAST workgroup to finish adds the rows: the reduction
 // launch behind it disappears (4-5 us of stream time each on the coarse levels) and no co-residency is needed -- nobody waits.
 // Protocol as above: partial rows stored write-through (st1_sc1 / st4_sc1), drained, one ticket per workgroup; the workgroup that
 // draws the last ticket reads the rows past L1 (ld4_sc1) in a fixed order (bitwise reproducible) and zeroes the ticket for the
-// next launch.  ticket: one zero device word per stream (ops._ticket).
+// next launch.  ticket: LW_TICKET_WORDS zero device words per stream (ops._ticket).
 __device__ __forceinline__ void st1_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, 16);
 }
+// A burst of tickets on ONE word is served one after the other (~7 ns each from eight XCDs: 1 280 workgroups that finish together
+// cost 9 us, measured on uvstats_kernel<8>), so launches of more than LW_FLAT workgroups draw in two levels: workgroup b takes a
+// ticket of group b % LW_GROUPS (one 128-byte line each), the last of a group one of the top word.
+// ticket: LW_TICKET_WORDS zero words (all left zero).
+constexpr unsigned LW_GROUPS = LASTWG_GROUPS_, LW_FLAT = LASTWG_FLAT_, LW_TICKET_WORDS = (1 + 32) * FW_LINE;
+static_assert(LW_GROUPS <= 32, "ticket lines");
 __device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned nblk, int* s_flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = old + 1 == nblk;
+        int last = 0;
+        if (nblk <= LW_FLAT) {
+            const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = old + 1 == nblk;
+        } else {
+            const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const unsigned g = bid % LW_GROUPS, n_in_group = nblk / LW_GROUPS + (g < nblk % LW_GROUPS ? 1u : 0u);
+            unsigned* gt = ticket + (1 + g) * FW_LINE;
+            const unsigned old = __hip_atomic_fetch_add(gt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1 == n_in_group) {
+                __hip_atomic_store(gt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned old2 = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = old2 + 1 == LW_GROUPS;
+            }
+        }
         if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_flag = last;
     }

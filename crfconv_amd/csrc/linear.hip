@@ -1631,6 +1631,8 @@ static size_t mlp_ws_layout(int64_t M, int Co, int Ci, size_t off[5]) {
 }
 }  // namespace crf
 
+extern "C" size_t crfconv_ticket_bytes(void) { return sizeof(unsigned) * crf::LW_TICKET_WORDS; }
+
 extern "C" int crfconv_mlp_backward_supported(int64_t M, int Ci, int Co) {
     if (!(M > 0 && Co % 4 == 0 && Ci >= 1 && Co >= 4 && Co <= 1024 && Ci <= 1024)) return 0;
     // dX runs on linear_fwd_kernel<., true> with k = Co inputs and Ci outputs: its LDS must fit 64 KB

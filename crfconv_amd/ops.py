@@ -324,7 +324,7 @@ def _stream_buf(table, device, make):
 
 def _ticket(device):
     """Zero words for the "last workgroup finishes" reductions (left zero by the kernels), per (device, stream)."""
-    return _stream_buf(_TICKETS, device, lambda: torch.zeros(64, dtype=torch.int32, device=device))
+    return _stream_buf(_TICKETS, device, lambda: torch.zeros(_lib.load().crfconv_ticket_bytes() // 4, dtype=torch.int32, device=device))
 
 
 _NO_PC_TICKET_ENV = __import__('os').environ.get('CRFCONV_NO_PC_TICKET') is not None     # A/B: PointConv's statistic / coefficient sums as launches of their own

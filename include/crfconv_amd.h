@@ -454,10 +454,12 @@ int crfconv_mlp_small_forward_join(const float* X, const float* W, int64_t M, in
  * and writes dX = gY W (skipped when dX is NULL).  gA, Y [M, Co]; X [M, Ci]; W [Co, Ci]; coef = the [4, Co] block of
  * crfconv_bn_forward / crfconv_bn_coef_from_records for Y.  Same results as crfconv_bn_backward ->
  * crfconv_linear_forward(transpose) + crfconv_linear_wgrad up to summation order.
- * ticket (crfconv_mlp_backward / _add / _cat, crfconv_pointconv_forward_uv / _bwd_reduce_uv): one ZERO device word owned by the
- * stream (the kernels leave it zero), or NULL.  With it the LAST workgroup of the first pass to finish adds the partial rows and
+ * ticket (crfconv_mlp_backward / _add / _cat, crfconv_pointconv_forward_uv / _bwd_reduce_uv): crfconv_ticket_bytes() ZERO device
+ * bytes owned by the stream (the kernels leave them zero; large launches draw their tickets in two levels, one 128-byte line per
+ * group), or NULL.  With it the LAST workgroup of the first pass to finish adds the partial rows and
  * does the finalize's channel part itself (write-through stores, one atomic ticket per workgroup, fixed summation order): one
  * launch less on the chain (here, for Co in {4, 8, .., 128}, when dW is NULL: two launches).  NULL: the launch-separated form. */
+size_t crfconv_ticket_bytes(void);
 int crfconv_mlp_backward_supported(int64_t M, int Ci, int Co);
 size_t crfconv_mlp_backward_workspace(int64_t M, int Ci, int Co);
 int crfconv_mlp_backward(const float* gA, const float* Y, const float* X, const float* W, const float* coef, float slope,

@@ -18,3 +18,14 @@ for r, n in zip(step, sn):
     d[n] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 for n, k in sorted(c.items(), key=lambda kv: -d[kv[0]])[:top]:
     print('%-72s x%3d  %8.1f us total  %6.1f avg' % (n[:72], k, d[n], d[n] / k))
+
+# the launches in order (a file next to the trace directory): index, start offset, duration, grid / workgroup size, name
+try:
+    with open(sys.argv[1].rstrip('/') + '_sequence.txt', 'w') as fh:
+        for i, (r, n) in enumerate(zip(step, sn)):
+            gx = int(r.get('Grid_Size_X', r.get('Grid_Size', 0)) or 0) * max(int(r.get('Grid_Size_Y', 1) or 1), 1) * max(int(r.get('Grid_Size_Z', 1) or 1), 1)
+            wx = int(r.get('Workgroup_Size_X', r.get('Workgroup_Size', 0)) or 0) * max(int(r.get('Workgroup_Size_Y', 1) or 1), 1) * max(int(r.get('Workgroup_Size_Z', 1) or 1), 1)
+            fh.write('%3d  +%8.1f us  %6.1f us  wg %6d x %4d  vgpr %3s lds %6s  %s\n' % (i, (int(r['Start_Timestamp']) - t0) / 1e3,
+                     (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, gx // max(wx, 1), wx, r.get('VGPR_Count', '?'), r.get('LDS_Block_Size', '?'), n[:110]))
+except Exception as e:
+    print('sequence not written:', e)
