@@ -1400,26 +1400,37 @@ __global__ __launch_bounds__(FR_BLOCK) void bn_apply_records_kernel(const float*
     // grid = (row tiles, slabs): the workgroups that read the two / four 64-byte pieces of the same 128-byte lines are `tiles` apart in
     // dispatch order, and tiles is a multiple of 8 -- they land on the same XCD, whose L2 then fetches each line from HBM once
     const int slab = blockIdx.y, tile = blockIdx.x;
+    const int q = threadIdx.x & 3, rl = threadIdx.x >> 2;            // 4 channel quads x 256 rows per pass
+    const int c = slab * FR_CH + 4 * q;
+    const bool cok = c < C;
+    const int64_t r0 = (int64_t)tile * rows_per_tile;
+    const int64_t r1 = r0 + rows_per_tile < M ? r0 + rows_per_tile : M;
+    // the rows of the FIRST pass (the only one at <= 1024 rows per tile) are requested before the records are combined: their round
+    // trip runs beside the combine's two instead of behind them
+    float4 v[4];
+    [[maybe_unused]] float4 k[ADD ? 4 : 1];
+    auto request = [&](int64_t rb) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = rb + (int64_t)u * (FR_BLOCK / 4);
+            const bool in = cok && r < r1;
+            v[u] = in ? *reinterpret_cast<const float4*>(x + r * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (ADD) k[u] = in ? *reinterpret_cast<const float4*>(skip + r * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+#ifndef BN_APPLY_PREFETCH_
+#define BN_APPLY_PREFETCH_ 1
+#endif
+    if (BN_APPLY_PREFETCH_) request(r0 + rl);
     if (bn_finalize_records_body(rec, nrec, M, C, gamma, beta, eps, run_mean, run_var, momentum, coef, slab, tile == 0, ab)) {
         s_ab[0][threadIdx.x] = ab[0];
         s_ab[1][threadIdx.x] = ab[1];
     }
     __syncthreads();
-    const int q = threadIdx.x & 3, rl = threadIdx.x >> 2;            // 4 channel quads x 256 rows per pass
-    const int c = slab * FR_CH + 4 * q;
-    if (c >= C) return;
+    if (!cok) return;
     const float4 a = *reinterpret_cast<const float4*>(&s_ab[0][4 * q]), b = *reinterpret_cast<const float4*>(&s_ab[1][4 * q]);
-    const int64_t r0 = (int64_t)tile * rows_per_tile;
-    const int64_t r1 = r0 + rows_per_tile < M ? r0 + rows_per_tile : M;
     for (int64_t rb = r0 + rl; rb < r1; rb += 4 * (FR_BLOCK / 4)) {
-        float4 v[4];
-        [[maybe_unused]] float4 k[ADD ? 4 : 1];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t r = rb + (int64_t)u * (FR_BLOCK / 4);
-            v[u] = r < r1 ? *reinterpret_cast<const float4*>(x + r * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (ADD) k[u] = r < r1 ? *reinterpret_cast<const float4*>(skip + r * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        if (!BN_APPLY_PREFETCH_ || rb != r0 + rl) request(rb);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t r = rb + (int64_t)u * (FR_BLOCK / 4);
@@ -1577,8 +1588,13 @@ extern "C" int crfconv_bn_apply_from_records(const float* stat_rec, int64_t nrec
     CRF_REQUIRE(stat_rec && x && gamma && beta && coef && y, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(M > 0 && C >= 4 && C % 4 == 0 && nrec > 0 && nrec < ((int64_t)1 << 31), CRF_ERR_ARG, "bad shape");
     const int slabs = (C + crf::FR_CH - 1) / crf::FR_CH;
-    // ~512 workgroups in all; a row tile is a multiple of the 1024 rows one pass covers
-    int64_t tiles = 512 / slabs;
+    // ~BN_APPLY_WGS_ workgroups in all -- one per CU: 116-128 registers x 1024 threads is one workgroup per CU, and every workgroup
+    // pays the records' combine (step, one box: 128 workgroups 4.163 ms, 192 4.136, 256 4.136, 320 4.159, 512 4.153); a row tile is a
+    // multiple of the 1024 rows one pass covers
+#ifndef BN_APPLY_WGS_
+#define BN_APPLY_WGS_ 256
+#endif
+    int64_t tiles = BN_APPLY_WGS_ / slabs;
     if (tiles < 1) tiles = 1;
     int64_t rows = (M + tiles - 1) / tiles;
     rows = (rows + 1023) / 1024 * 1024;
