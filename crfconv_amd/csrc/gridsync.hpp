@@ -83,12 +83,25 @@ __device__ __forceinline__ void grid_sync_groups(unsigned nblk, unsigned bid, un
     n_groups = nblk < 8u ? nblk : 8u;
 }
 
-__device__ __forceinline__ void fused_exit_reset(unsigned* ws, unsigned nblk, int T) {
+__device__ __forceinline__ void fused_exit_reset(unsigned* ws, unsigned nblk, int T, unsigned bid) {
     if (threadIdx.x == 0 && T > 1) {
-        const unsigned old = __hip_atomic_fetch_add(ws + FW_EXIT * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1 == nblk) {
+        // counted out in the barrier's two levels (word 1 of the group's line, then FW_EXIT): hundreds of workgroups that finish
+        // together and count on ONE word are served one after the other (~7 ns each) at the end of the kernel
+        unsigned n_in_group, n_groups;
+        grid_sync_groups(nblk, bid, n_in_group, n_groups);
+#ifdef FW_FLAT_EXIT_       // A/B: the round-3 form
+        if (__hip_atomic_fetch_add(ws + FW_EXIT * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == nblk)
             for (int l = 0; l < FW_WORDS / FW_LINE; ++l)
                 if (l != FW_FAIL) __hip_atomic_store(ws + l * FW_LINE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+#endif
+        const unsigned old = __hip_atomic_fetch_add(ws + (FW_CNT + (bid & 7u)) * FW_LINE + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 != n_in_group) return;
+        const unsigned old2 = __hip_atomic_fetch_add(ws + FW_EXIT * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old2 + 1 == n_groups) {
+            for (int l = 0; l < FW_WORDS / FW_LINE; ++l)
+                if (l != FW_FAIL) __hip_atomic_store(ws + l * FW_LINE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int g = 0; g < 8; ++g) __hip_atomic_store(ws + (FW_CNT + g) * FW_LINE + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

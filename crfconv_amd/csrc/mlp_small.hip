@@ -167,7 +167,7 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
 #pragma unroll
             for (int t = 0; t < TCO; ++t) st4(A + (int64_t)r * Co + co_base + 16 * t + 4 * g, make_float4(qnan, qnan, qnan, qnan));
         }
-        fused_exit_reset(sync_ws, nblk, 2);
+        fused_exit_reset(sync_ws, nblk, 2, bid);
         return;
     }
 
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(SM_BLOCK) void mlp_small_fwd_kernel(const float* __
             st4(A + (int64_t)r * Co + co_base + 16 * t + 4 * g, o);
         }
     }
-    fused_exit_reset(sync_ws, nblk, 2);
+    fused_exit_reset(sync_ws, nblk, 2, bid);
 }
 
 // Workgroups of the forward kernel that can be resident at once on this device (the barrier needs every one of them).
