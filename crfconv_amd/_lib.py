@@ -137,6 +137,13 @@ SIGNATURES = {
     'crfconv_add_lrelu': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
     'crfconv_bn_apply_add': (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp]),
     'crfconv_bn_apply_dropout': (_i, [_vp, _i64, _i, _vp, _f, _f, _u64, _vp, _vp, _vp, _vp]),
+    'crfconv_head_stats': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
+    'crfconv_head_stat_records': (_sz, [_i64]),
+    'crfconv_head_supported': (_i, [_i64, _i, _i, _i]),
+    'crfconv_head_mask_words': (_sz, [_i64]),
+    'crfconv_head_backward_workspace': (_sz, [_i64, _i, _i, _i]),
+    'crfconv_head_forward': (_i, [_vp, _vp, _vp, _f, _f, _u64, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'crfconv_head_backward': (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i64, _i, _i, _i] + [_vp] * 7 + [_sz, _vp]),
     'crfconv_linear_forward_dropout': (_i, [_vp, _vp, _i64, _i, _i, _i, _f, _u64, _vp, _vp, _vp]),
     'crfconv_dropout_backward': (_i, [_vp, _i64, _f, _u64, _vp, _vp, _vp]),
     'crfconv_add_lrelu_backward': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),

@@ -156,15 +156,33 @@ __device__ __forceinline__ float comp(const float4& v, int i) {
 }
 
 // Counter-based dropout mask shared by the forward and the backward pass: element e of the call with (seed, *counter) is kept
-// iff the top 32 bits of a splitmix64 round of (seed, counter, e) reach `threshold` = p 2^32.  *counter is a DEVICE word that
-// the caller advances between training steps (the classifier BatchNorm's num_batches_tracked), so a captured hipGraph draws a
-// new mask at every replay while forward and backward of one step agree without a stored mask.
-__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long ctr, unsigned long long e, unsigned threshold) {
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1ull) + e * 0xD1B54A32D192ED03ull;
+// iff a keyed 32-bit integer hash of e reaches `threshold` = p 2^32.  The two 32-bit keys are the halves of one splitmix64 round
+// of (seed, counter) -- uniform per call, so the compiler hoists them out of every loop --; per element: the two-multiply
+// "lowbias32" finalizer (x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15; x *= 0x846ca68b; x ^= x >> 16) with the second key added
+// in front of the second multiply.  (Round 4: the 64-bit splitmix round per ELEMENT this replaces is ~190 cycles per wavefront
+// on gfx950 -- eight quarter-rate 32-bit multiplies -- and bound every kernel that draws a mask: bn_apply_dropout 26 us for
+// 21 M elements; this one is ~60.)  *counter is a DEVICE word that the caller advances between training steps (the classifier
+// BatchNorm's num_batches_tracked), so a captured hipGraph draws a new mask at every replay while forward and backward of one
+// step agree without a stored mask.  Host twin: ops.dropout_keep_mask.
+__device__ __forceinline__ unsigned long long dropout_keys(unsigned long long seed, unsigned long long ctr) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (unsigned)(z >> 32) >= threshold;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ bool dropout_keep_keyed(unsigned long long keys, unsigned long long e, unsigned threshold) {
+    const unsigned hi = (unsigned)(e >> 32);
+    unsigned x = (unsigned)e + (unsigned)keys + ((hi << 13) | (hi >> 19));
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x += (unsigned)(keys >> 32);
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x >= threshold;
+}
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long ctr, unsigned long long e, unsigned threshold) {
+    return dropout_keep_keyed(dropout_keys(seed, ctr), e, threshold);
 }
 
 inline unsigned dropout_threshold(float p) {

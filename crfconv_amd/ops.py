@@ -1296,6 +1296,60 @@ class _MLPDropoutLinear(torch.autograd.Function):
         return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, None, None, None, None, dW2, db2
 
 
+_NO_HEAD_ENV = __import__('os').environ.get('CRFCONV_NO_HEAD_RECOMPUTE') is not None     # A/B: the classifier with stored [m, 4 C] tensors
+
+
+class _HeadRecompute(torch.autograd.Function):
+    """The same classifier -- logits = dropout(lrelu(BN_train(x W1^T), slope), p) W2^T + b2 (models/point_conv_big.py:131-134) --
+    without a stored [m, 4 C] tensor (csrc/head.hip): the statistics pass keeps only the BatchNorm records, every later pass
+    recomputes x W1^T from the [m, C] input on the matrix pipe, and the dropout mask travels as one bit per element.  Logits are
+    bit-identical to _MLPDropoutLinear's (same products in the same order, same mask); the parameter gradients are summed in
+    float64 from per-workgroup partials."""
+
+    @staticmethod
+    def forward(ctx, x, W, gamma, beta, run_mean, run_var, momentum, eps, slope, p, seed, counter, W2, b2):
+        x, Wc, W2c = x.contiguous(), W.contiguous(), W2.contiguous()
+        m, ci = x.shape
+        co, c2 = Wc.shape[0], W2c.shape[0]
+        dev = x.device
+        lib = _lib.load()
+        st = stream_ptr()
+        nrec = lib.crfconv_head_stat_records(m)
+        rec = torch.empty((nrec, co, 4), dtype=torch.float32, device=dev)
+        _lib.call('crfconv_head_stats', ptr(x), ptr(Wc), m, ci, co, ptr(rec), st)
+        coef = torch.empty(4 * co, dtype=torch.float32, device=dev)
+        _lib.call('crfconv_bn_coef_from_nrecords', ptr(rec), nrec, m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
+                  ptr(run_var), float(momentum), float(eps), ptr(coef), st)
+        logits = torch.empty((m, c2), dtype=torch.float32, device=dev)
+        mask = torch.empty(lib.crfconv_head_mask_words(m), dtype=torch.int32, device=dev)
+        b2c = None if b2 is None else b2.contiguous()
+        _lib.call('crfconv_head_forward', ptr(x), ptr(Wc), ptr(coef), float(slope), float(p), int(seed), ptr(counter), ptr(W2c),
+                  ptr(b2c), m, ci, co, c2, ptr(logits), ptr(mask), None, st)
+        ctx.prm = (W, gamma, beta, W2, b2)
+        ctx.save_for_backward(x, Wc, coef, mask, W2c)
+        ctx.slope, ctx.p = float(slope), float(p)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, coef, mask, W2 = ctx.saved_tensors
+        m, ci = x.shape
+        co, c2 = W.shape[0], W2.shape[0]
+        dev = x.device
+        g = g.contiguous()
+        Wp, gp, bp, W2p, b2p = ctx.prm
+        outs = [_param_out(Wp, (co, ci), dev), _param_out(gp, (co,), dev), _param_out(bp, (co,), dev), _param_out(W2p, (c2, co), dev)]
+        ob2 = _param_out(b2p, (c2,), dev) if b2p is not None else (None, False)
+        dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        nbytes = _lib.load().crfconv_head_backward_workspace(m, ci, co, c2)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.call('crfconv_head_backward', ptr(g), ptr(x), ptr(W), ptr(coef), ctx.slope, ctx.p, ptr(W2), ptr(mask), m, ci, co, c2,
+                  ptr(dX), ptr(outs[0][0]), ptr(outs[1][0]), ptr(outs[2][0]), ptr(outs[3][0]), ptr(ob2[0]), ptr(ws), nbytes, stream_ptr())
+        rets = [_param_ret(prm, o[0], o[1]) for prm, o in zip((Wp, gp, bp, W2p), outs)]
+        rb2 = _param_ret(b2p, ob2[0], ob2[1]) if b2p is not None else None
+        return dX, rets[0], rets[1], rets[2], None, None, None, None, None, None, None, None, rets[3], rb2
+
+
 def dropout_seed(ci, co):
     """Seed of the counter-based dropout mask of a fused MLP -> Dropout block with `ci` inputs and `co` outputs (a
     function of torch.initial_seed() and the layer shape)."""
@@ -1304,26 +1358,36 @@ def dropout_seed(ci, co):
 
 def dropout_keep_mask(seed, counter, n, p):
     """The mask csrc/common.hpp::dropout_keep draws for elements 0 .. n-1 of the call with (seed, counter), evaluated on
-    the HOST (numpy bool array, True = kept): element e is kept iff the top 32 bits of a splitmix64 round of
-    (seed, counter, e) reach p 2^32.  `counter` = the classifier BatchNorm's num_batches_tracked AFTER the forward (the
-    forward advances it before the kernel reads it).  A caller -- the parity tests -- hands the same mask to another
-    implementation of the network."""
+    the HOST (numpy bool array, True = kept): two 32-bit keys = the halves of one splitmix64 round of (seed, counter); element e
+    is kept iff the keyed lowbias32 hash of e reaches p 2^32.  `counter` = the classifier BatchNorm's num_batches_tracked AFTER
+    the forward (the forward advances it before the kernel reads it).  A caller -- the parity tests -- hands the same mask to
+    another implementation of the network."""
     import numpy as np
     t = float(p) * 4294967296.0
-    thr = np.uint64(0xffffffff if t >= 4294967295.0 else (0 if t <= 0.0 else int(t)))
+    thr = np.uint32(0xffffffff if t >= 4294967295.0 else (0 if t <= 0.0 else int(t)))
+    mask64 = 0xFFFFFFFFFFFFFFFF
+    z = (int(seed) + 0x9E3779B97F4A7C15 * (int(counter) + 1)) & mask64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask64
+    z ^= z >> 31
+    k0, k1 = np.uint32(z & 0xFFFFFFFF), np.uint32(z >> 32)
     with np.errstate(over='ignore'):
         e = np.arange(int(n), dtype=np.uint64)
-        z = (e * np.uint64(0xD1B54A32D192ED03)
-             + np.uint64((int(seed) + 0x9E3779B97F4A7C15 * (int(counter) + 1)) & 0xFFFFFFFFFFFFFFFF))
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z ^= z >> np.uint64(31)
-    return (z >> np.uint64(32)) >= thr
+        hi = (e >> np.uint64(32)).astype(np.uint32)
+        x = e.astype(np.uint32) + k0 + ((hi << np.uint32(13)) | (hi >> np.uint32(19)))
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x7feb352d)
+        x ^= x >> np.uint32(15)
+        x += k1
+        x *= np.uint32(0x846ca68b)
+        x ^= x >> np.uint32(16)
+    return x >= thr
 
 
-def mlp_dropout_linear(x, W, bn, slope, p, W2, b2):
-    """Linear(dropout(lrelu(BatchNorm_train(x W^T), slope), p)) as one node (see _MLPDropoutLinear) where the fused dropout
-    block and the MFMA Linear both apply, else None."""
+def mlp_dropout_linear(x, W, bn, slope, p, W2, b2, recompute=None):
+    """Linear(dropout(lrelu(BatchNorm_train(x W^T), slope), p)) as one node where the fused dropout block and the MFMA Linear
+    both apply, else None: _HeadRecompute (no [m, 4 C] tensor is ever stored) for the shapes csrc/head.hip covers, else
+    _MLPDropoutLinear.  recompute: None = that choice, False = the stored form, True = insist on the recomputing one."""
     if _NO_DROPOUT_FUSION_ENV or _NO_DROPOUT_LINEAR_ENV or not (0.0 <= p < 1.0) or bn.num_batches_tracked is None:
         return None
     m = x.numel() // x.shape[-1]
@@ -1335,7 +1399,13 @@ def mlp_dropout_linear(x, W, bn, slope, p, W2, b2):
     tick(bn)
     mom = 0.1 if bn.momentum is None else bn.momentum
     seed = dropout_seed(ci, co)                          # as mlp_block_dropout
-    out = _MLPDropoutLinear.apply(x.reshape(-1, ci), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, slope,
+    node = _MLPDropoutLinear
+    head_ok = bool(_lib.load().crfconv_head_supported(m, ci, co, c2))
+    if recompute and not head_ok:
+        return None
+    if head_ok and (recompute or (recompute is None and not _NO_HEAD_ENV)):
+        node = _HeadRecompute                            # no [m, 4 C] tensor at all
+    out = node.apply(x.reshape(-1, ci), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, slope,
                                   p, seed, bn.num_batches_tracked, W2, b2)
     return out.reshape(x.shape[:-1] + (c2,))
 

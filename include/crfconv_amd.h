@@ -624,6 +624,31 @@ int crfconv_dropout_backward(const float* g, int64_t n, float p, uint64_t seed, 
  * models/point_conv_big.py:131-134), so that no separate pass over [M, Co] runs.  Shapes as crfconv_linear_forward. */
 int crfconv_linear_forward_dropout(const float* X, const float* W, int64_t M, int Ci, int Co, int transpose_w, float p,
                                    uint64_t seed, const int64_t* counter, float* Y, crf_stream_t stream);
+/* The per-point classifier, models/point_conv_big.py:131-134: MLP(Ci -> Co = 4 Ci: Linear, BatchNorm, LeakyReLU) -> nn.Dropout(p)
+ * -> nn.Linear(Co -> C2), training mode, without ever storing a [M, Co] tensor: every pass recomputes X W1^T on the matrix pipe
+ * (bit-identical each time).  Supported: Co = 128, Ci in {16, 32}, C2 <= 16.
+ *   stats:    stat_rec [crfconv_head_stat_records(M)][Co][4] = the BatchNorm statistic records of X W1^T (the tuples of
+ *             crfconv_linear_forward) WITHOUT the product being stored; crfconv_bn_coef_from_nrecords turns them into
+ *   forward:  coef [4, Co];
+ *             logits [M, C2] = dropout(lrelu(a (X W1^T) + b, slope)) W2^T + b2 (b2 may be NULL) with the counter-based mask of
+ *             crfconv_bn_apply_dropout (same seed / counter / element numbering e = row * Co + channel: identical logits);
+ *             mask_bits [crfconv_head_mask_words(M)] uint32 receives the mask (one bit per element) for the backward;
+ *             counter_used as in crfconv_bn_apply_dropout.
+ *   backward: g [M, C2] = d loss / d logits  ->  dX [M, Ci] (may be NULL), dW1 [Co, Ci], dgamma / dbeta [Co], dW2 [C2, Co],
+ *             db2 [C2] (may be NULL); workspace of crfconv_head_backward_workspace bytes.  Four launches: partial pass, float64
+ *             totals, dX, parameters. */
+int crfconv_head_supported(int64_t M, int Ci, int Co, int C2);
+size_t crfconv_head_mask_words(int64_t M);
+size_t crfconv_head_stat_records(int64_t M);
+int crfconv_head_stats(const float* X, const float* W1, int64_t M, int Ci, int Co, float* stat_rec, crf_stream_t stream);
+size_t crfconv_head_backward_workspace(int64_t M, int Ci, int Co, int C2);
+int crfconv_head_forward(const float* X, const float* W1, const float* coef, float slope, float p, uint64_t seed,
+                         const int64_t* counter, const float* W2, const float* b2, int64_t M, int Ci, int Co, int C2,
+                         float* logits, uint32_t* mask_bits, int64_t* counter_used, crf_stream_t stream);
+int crfconv_head_backward(const float* g, const float* X, const float* W1, const float* coef, float slope, float p,
+                          const float* W2, const uint32_t* mask_bits, int64_t M, int Ci, int Co, int C2, float* dX, float* dW1,
+                          float* dgamma, float* dbeta, float* dW2, float* db2, void* workspace, size_t workspace_bytes,
+                          crf_stream_t stream);
 /* The ResNet join of models/point_conv_big.py:84-88 in one pass: out = lrelu(a x + b + skip, slope), coef = the [4, C]
  * block of crfconv_bn_forward / crfconv_bn_coef_from_records for x (a BatchNorm without activation), skip / out [M, C].
  * Same arithmetic as crfconv_bn_apply(slope 1) followed by crfconv_add_lrelu, without the intermediate tensor. */

@@ -1076,7 +1076,7 @@ def test_classifier_dropout_backward_folded_into_last_linear():
         x, W, W2, b2 = (v.clone().requires_grad_(True) for v in (x0, W0, W20, b20))
         bn = torch.nn.BatchNorm1d(Co).to(DEV).train()
         if fused:
-            out = ops.mlp_dropout_linear(x, W, bn, slope, 0.5, W2, b2)
+            out = ops.mlp_dropout_linear(x, W, bn, slope, 0.5, W2, b2, recompute=False)
             assert out is not None and '_MLPDropoutLinear' in out.grad_fn.next_functions[0][0].name()
         else:
             out = ops.linear(ops.mlp_block_dropout(x, W, bn, slope, 0.5), W2, b2)
@@ -1090,11 +1090,80 @@ def test_classifier_dropout_backward_folded_into_last_linear():
     W2, b2 = torch.nn.Parameter(W20.clone()), torch.nn.Parameter(b20.clone())
     bn = torch.nn.BatchNorm1d(Co).to(DEV).train()
     with ops.deferred_weight_grads():
-        ops.mlp_dropout_linear(x, W, bn, slope, 0.5, W2, b2).backward(go)
+        ops.mlp_dropout_linear(x, W, bn, slope, 0.5, W2, b2, recompute=False).backward(go)
     assert_close(W2.grad, res[0][3], 1e-6, 'deferred dW2')
     assert_close(b2.grad, res[0][4], 1e-6, 'deferred db2')
     assert torch.equal(x.grad, res[0][1])
     assert ops.mlp_dropout_linear(x[:100], W, bn, slope, 0.5, W2, b2) is None      # below the MFMA row count: caller's path
+
+
+@pytest.mark.parametrize('M,Ci,C2,bias', [(40960, 32, 13, True), (20001, 32, 13, True), (12288, 16, 8, False), (16400, 16, 16, True)])
+def test_classifier_head_recompute(M, Ci, C2, bias):
+    """ops._HeadRecompute (csrc/head.hip): the classifier MLP -> Dropout -> Linear without a stored [M, 4 C] tensor.  Logits, dX
+    and the parameter gradients agree with the stored form (_MLPDropoutLinear: same products in the same order, same mask) to
+    float32 rounding and with a float64 evaluation of the same function given the same mask
+    (ops.dropout_keep_mask).  Ragged row counts, 16 / 32 inputs, with and without the last bias; deferred weight gradients
+    with a flat-bucket sink land in the sink."""
+    from crfconv_amd import ops
+    Co, slope, p = 128, 0.1, 0.5
+    g = torch.Generator().manual_seed(11 + Ci + C2)
+    x0 = torch.randn(M, Ci, generator=g).to(DEV)
+    W0 = (torch.randn(Co, Ci, generator=g) / 6).to(DEV)
+    W20 = (torch.randn(C2, Co, generator=g) / 11).to(DEV)
+    b20 = torch.randn(C2, generator=g).to(DEV) if bias else None
+    gam0, bet0 = (torch.rand(Co, generator=g) + 0.5).to(DEV), (torch.randn(Co, generator=g) * 0.3).to(DEV)
+    go = torch.randn(M, C2, generator=g).to(DEV)
+    res = []
+    for rec in (True, False):
+        x, W, W2 = (v.clone().requires_grad_(True) for v in (x0, W0, W20))
+        b2 = b20.clone().requires_grad_(True) if bias else None
+        bn = torch.nn.BatchNorm1d(Co).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.copy_(gam0); bn.bias.copy_(bet0)
+        out = ops.mlp_dropout_linear(x, W, bn, slope, p, W2, b2, recompute=rec)
+        assert out is not None and ('_HeadRecompute' if rec else '_MLPDropoutLinear') in out.grad_fn.next_functions[0][0].name()
+        out.backward(go)
+        res.append(dict(logits=out.detach().clone(), dx=x.grad.clone(), dW=W.grad.clone(), dW2=W2.grad.clone(),
+                        db2=b2.grad.clone() if bias else None, dgamma=bn.weight.grad.clone(), dbeta=bn.bias.grad.clone(),
+                        rm=bn.running_mean.clone(), rv=bn.running_var.clone()))
+    new, old = res
+    # same products in the same order and the same mask; the statistic records are cut differently (other workgroup shapes), so
+    # the BatchNorm coefficients may differ in the last bit
+    assert_close(new['logits'], old['logits'], 2e-6, 'head logits vs stored form')
+    assert_close(new['rm'], old['rm'], 1e-6, 'head running mean')
+    assert_close(new['rv'], old['rv'], 1e-6, 'head running var')
+    # float64 evaluation with the same mask
+    keep = torch.from_numpy(ops.dropout_keep_mask(ops.dropout_seed(Ci, Co), 1, M * Co, p).reshape(M, Co)).to(DEV)
+    xd, Wd, W2d = (v.double().requires_grad_(True) for v in (x0, W0, W20))
+    gd, bd = gam0.double().requires_grad_(True), bet0.double().requires_grad_(True)
+    b2d = b20.double().requires_grad_(True) if bias else None
+    y = xd @ Wd.t()
+    yn = (y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + 1e-5) * gd + bd
+    h = torch.nn.functional.leaky_relu(yn, slope) * keep / (1 - p)
+    ref = h @ W2d.t() + (b2d if bias else 0)
+    ref.backward(go.double())
+    ref64 = dict(logits=ref.detach(), dx=xd.grad, dW=Wd.grad, dW2=W2d.grad, db2=b2d.grad if bias else None, dgamma=gd.grad, dbeta=bd.grad)
+    for k in ('logits', 'dx', 'dW', 'dW2', 'db2', 'dgamma', 'dbeta'):
+        if new[k] is None:
+            continue
+        assert_close(new[k], ref64[k], 2e-5, 'head %s vs float64' % k)
+        assert_close(new[k], old[k], 2e-5, 'head %s vs stored form' % k)
+    # deferred weight gradients with a sink: every parameter gradient is written straight into the caller's storage
+    x = x0.clone().requires_grad_(True)
+    W, W2 = torch.nn.Parameter(W0.clone()), torch.nn.Parameter(W20.clone())
+    b2 = torch.nn.Parameter(b20.clone()) if bias else None
+    bn = torch.nn.BatchNorm1d(Co).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.copy_(gam0); bn.bias.copy_(bet0)
+    params = [W, bn.weight, bn.bias, W2] + ([b2] if bias else [])
+    store = {id(q): torch.full_like(q, float('nan')) for q in params}
+    with ops.deferred_weight_grads(sink=lambda q: store.get(id(q))):
+        ops.mlp_dropout_linear(x, W, bn, slope, p, W2, b2, recompute=True).backward(go)
+    for q, k in zip(params, ('dW', 'dgamma', 'dbeta', 'dW2', 'db2')):
+        assert q.grad.data_ptr() == store[id(q)].data_ptr(), k
+        assert torch.equal(q.grad, new[k]), k
+    assert torch.equal(x.grad, new['dx'])
+    assert ops.mlp_dropout_linear(x0, W0[:64], torch.nn.BatchNorm1d(64).to(DEV).train(), slope, p, W20[:, :64], b20, recompute=True) is None
 
 
 def test_pointconv_prefold_one_launch_equals_per_layer_folds():
