@@ -207,15 +207,18 @@ __global__ __launch_bounds__(HD_BLOCK, 2) void head_fwd_kernel(const float* __re
 #pragma unroll
         for (int t = 0; t < HD_T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
+        for (int c = 0; c < NCH; ++c) {          // the eight tiles' products of a k-step side by side: no MFMA waits for its predecessor
+            float4 wv[HD_T];
 #pragma unroll
-            for (int t = 0; t < HD_T; ++t) {
-                const float4 wv = ld4(sW1 + (16 * t + rr) * Cip + 16 * c + 4 * g);
-                acc[t] = HD_MFMA(wv.x, cur[c].x, acc[t]);
-                acc[t] = HD_MFMA(wv.y, cur[c].y, acc[t]);
-                acc[t] = HD_MFMA(wv.z, cur[c].z, acc[t]);
-                acc[t] = HD_MFMA(wv.w, cur[c].w, acc[t]);
-            }
+            for (int t = 0; t < HD_T; ++t) wv[t] = ld4(sW1 + (16 * t + rr) * Cip + 16 * c + 4 * g);
+#pragma unroll
+            for (int t = 0; t < HD_T; ++t) acc[t] = HD_MFMA(wv[t].x, cur[c].x, acc[t]);
+#pragma unroll
+            for (int t = 0; t < HD_T; ++t) acc[t] = HD_MFMA(wv[t].y, cur[c].y, acc[t]);
+#pragma unroll
+            for (int t = 0; t < HD_T; ++t) acc[t] = HD_MFMA(wv[t].z, cur[c].z, acc[t]);
+#pragma unroll
+            for (int t = 0; t < HD_T; ++t) acc[t] = HD_MFMA(wv[t].w, cur[c].w, acc[t]);
         }
         unsigned bits = 0u;
         f32x4 lg = f32x4{bias2[0], bias2[1], bias2[2], bias2[3]};
@@ -630,24 +633,33 @@ __global__ __launch_bounds__(HD_BLOCK, 2) void head_bwd_dx_kernel(const float* _
             gh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
+        for (int c = 0; c < NCH; ++c) {          // the eight tiles' products of a k-step side by side: no MFMA waits for its predecessor
+            float4 wv[HD_T];
 #pragma unroll
-            for (int t = 0; t < HD_T; ++t) {
-                const float4 wv = ld4(sW1 + (16 * t + rr) * Cip + 16 * c + 4 * g);
-                acc[t] = HD_MFMA(wv.x, cur.xv[c].x, acc[t]);
-                acc[t] = HD_MFMA(wv.y, cur.xv[c].y, acc[t]);
-                acc[t] = HD_MFMA(wv.z, cur.xv[c].z, acc[t]);
-                acc[t] = HD_MFMA(wv.w, cur.xv[c].w, acc[t]);
-            }
-        }
+            for (int t = 0; t < HD_T; ++t) wv[t] = ld4(sW1 + (16 * t + rr) * Cip + 16 * c + 4 * g);
 #pragma unroll
-        for (int t = 0; t < HD_T; ++t) {
-            const float4 w2 = ld4(sW2T + (16 * t + rr) * W2LD + 4 * g);      // channel 16 t + rr, classes 4 g + s
-            gh[t] = HD_MFMA(w2.x, cur.g4[0], gh[t]);
-            gh[t] = HD_MFMA(w2.y, cur.g4[1], gh[t]);
-            gh[t] = HD_MFMA(w2.z, cur.g4[2], gh[t]);
-            gh[t] = HD_MFMA(w2.w, cur.g4[3], gh[t]);
+            for (int t = 0; t < HD_T; ++t) acc[t] = HD_MFMA(wv[t].x, cur.xv[c].x, acc[t]);
+#pragma unroll
+            for (int t = 0; t < HD_T; ++t) acc[t] = HD_MFMA(wv[t].y, cur.xv[c].y, acc[t]);
+#pragma unroll
+            for (int t = 0; t < HD_T; ++t) acc[t] = HD_MFMA(wv[t].z, cur.xv[c].z, acc[t]);
+#pragma unroll
+            for (int t = 0; t < HD_T; ++t) acc[t] = HD_MFMA(wv[t].w, cur.xv[c].w, acc[t]);
         }
+        {
+            float4 w2[HD_T];                     // channel 16 t + rr, classes 4 g + s
+#pragma unroll
+            for (int t = 0; t < HD_T; ++t) w2[t] = ld4(sW2T + (16 * t + rr) * W2LD + 4 * g);
+#pragma unroll
+            for (int t = 0; t < HD_T; ++t) gh[t] = HD_MFMA(w2[t].x, cur.g4[0], gh[t]);
+#pragma unroll
+            for (int t = 0; t < HD_T; ++t) gh[t] = HD_MFMA(w2[t].y, cur.g4[1], gh[t]);
+#pragma unroll
+            for (int t = 0; t < HD_T; ++t) gh[t] = HD_MFMA(w2[t].z, cur.g4[2], gh[t]);
+#pragma unroll
+            for (int t = 0; t < HD_T; ++t) gh[t] = HD_MFMA(w2[t].w, cur.g4[3], gh[t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 dx[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) dx[c] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -27,7 +27,8 @@ constexpr int WG_WAVES = WG_BLOCK / WAVE;
 template <int TCO, int TCI>
 __device__ __forceinline__ void wgrad_body(const float* __restrict__ G, const float* __restrict__ X, int64_t M, int Co, int Ci,
                                            int rows_per_block, float* __restrict__ partial /*[nblk][Co][Ci]*/,
-                                           float* __restrict__ partial_b /*[nblk][Co] or null*/, int bx, int by, int bz) {
+                                           float* __restrict__ partial_b /*[nblk][Co] or null*/, int bx, int by, int bz,
+                                           float* __restrict__ s_red_ /*[waves][TCO TCI 256]*/, float* __restrict__ s_b_ /*[waves][16 TCO]*/) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int co_base = by * 16 * TCO, ci_base = bz * 16 * TCI;
     const int kk = lane >> 4, cc = lane & 15;
@@ -72,8 +73,9 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ G, const fl
             }
     }
     // C/D layout of 16x16x4: col = lane & 15 (j = ci), row = 4 * (lane >> 4) + reg (i = co)
-    __shared__ float s_red[WG_WAVES][TCO * TCI * 256];
-    __shared__ float s_b[WG_WAVES][TCO * 16];
+    // LDS of the caller (a kernel that serves several tile classes owns ONE buffer of the largest class's size)
+    float (*s_red)[TCO * TCI * 256] = reinterpret_cast<float (*)[TCO * TCI * 256]>(s_red_);
+    float (*s_b)[TCO * 16] = reinterpret_cast<float (*)[TCO * 16]>(s_b_);
 #pragma unroll
     for (int a = 0; a < TCO; ++a) {
 #pragma unroll
@@ -113,7 +115,9 @@ __global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict
                                                          int Ci, int rows_per_block,
                                                          float* __restrict__ partial /*[nblk][Co][Ci]*/,
                                                          float* __restrict__ partial_b /*[nblk][Co] or null*/) {
-    wgrad_body<TCO, TCI>(G, X, M, Co, Ci, rows_per_block, partial, partial_b, blockIdx.x, blockIdx.y, blockIdx.z);
+    __shared__ float s_red[WG_WAVES * TCO * TCI * 256];
+    __shared__ float s_b[WG_WAVES * TCO * 16];
+    wgrad_body<TCO, TCI>(G, X, M, Co, Ci, rows_per_block, partial, partial_b, blockIdx.x, blockIdx.y, blockIdx.z, s_red, s_b);
 }
 
 // The partial passes of SEVERAL layers in one launch (crfconv_linear_wgrad_partial_jobs): the weight gradients of the coarse
@@ -129,6 +133,7 @@ struct WgJobTable {
     int M[WJ_MAX], Co[WJ_MAX], Ci[WJ_MAX], rows_per_block[WJ_MAX], nblk[WJ_MAX], gy[WJ_MAX];
     int blk_base[WJ_MAX + 1];
     int njobs;
+    unsigned char cls[WJ_MAX];                         // 10 TCO + TCI (wgrad_jobs_any_kernel)
 };
 template <int TCO, int TCI>
 __global__ __launch_bounds__(WG_BLOCK) void wgrad_jobs_kernel(const WgJobTable t) {
@@ -139,8 +144,39 @@ __global__ __launch_bounds__(WG_BLOCK) void wgrad_jobs_kernel(const WgJobTable t
     }
     const int local = (int)blockIdx.x - t.blk_base[lo];
     const int bx = local % t.nblk[lo], rest = local / t.nblk[lo];
+    __shared__ float s_red[WG_WAVES * TCO * TCI * 256];
+    __shared__ float s_b[WG_WAVES * TCO * 16];
     wgrad_body<TCO, TCI>(t.G[lo], t.X[lo], t.M[lo], t.Co[lo], t.Ci[lo], t.rows_per_block[lo], t.partial[lo], t.partial_b[lo], bx,
-                         rest % t.gy[lo], rest / t.gy[lo]);
+                         rest % t.gy[lo], rest / t.gy[lo], s_red, s_b);
+}
+
+// Every tile class in ONE launch (round 4): the jobs of the small classes -- five launches of 40-240 workgroups, 7-12 us each, behind
+// the <4, 4> launch of the step -- run beside the large ones.  The workgroup looks its job up as above and dispatches on the job's
+// class; one LDS buffer of the largest class (64 KB), the register budget of the largest (the small classes' jobs are few).
+__global__ __launch_bounds__(WG_BLOCK) void wgrad_jobs_any_kernel(const WgJobTable t) {
+    __shared__ float s_red[WG_WAVES * 4 * 4 * 256];
+    __shared__ float s_b[WG_WAVES * 4 * 16];
+    int lo = 0, hi = t.njobs;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t.blk_base[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int local = (int)blockIdx.x - t.blk_base[lo];
+    const int bx = local % t.nblk[lo], rest = local / t.nblk[lo];
+    const int by = rest % t.gy[lo], bz = rest / t.gy[lo];
+#define WB(TA, TB) wgrad_body<TA, TB>(t.G[lo], t.X[lo], t.M[lo], t.Co[lo], t.Ci[lo], t.rows_per_block[lo], t.partial[lo], t.partial_b[lo], bx, by, bz, s_red, s_b)
+    switch (t.cls[lo]) {
+        case 44: WB(4, 4); break;
+        case 22: WB(2, 2); break;
+        case 42: WB(4, 2); break;
+        case 24: WB(2, 4); break;
+        case 14: WB(1, 4); break;
+        case 41: WB(4, 1); break;
+        case 12: WB(1, 2); break;
+        case 21: WB(2, 1); break;
+        default: WB(1, 1); break;
+    }
+#undef WB
 }
 
 // ====================================================================== backward of Linear -> BatchNorm -> LeakyReLU
@@ -601,6 +637,36 @@ extern "C" int crfconv_linear_wgrad_partial_jobs(const crf_wgrad_job* jobs, int 
                     "job %d: bad shape M=%lld Co=%d Ci=%d", j, (long long)jb.M, jb.Co, jb.Ci);
         CRF_REQUIRE((reinterpret_cast<uintptr_t>(jb.workspace) & 255) == 0, CRF_ERR_ARG, "job %d: workspace must be 256-byte aligned", j);
         CRF_REQUIRE(jb.workspace_bytes >= crfconv_linear_wgrad_workspace(jb.M, jb.Co, jb.Ci), CRF_ERR_WORKSPACE, "job %d: workspace too small", j);
+    }
+    static const bool one_launch = getenv("CRFCONV_WGRAD_PER_CLASS") == nullptr;      // A/B: one launch per tile class (round 3)
+    if (one_launch) {
+        // jobs in the caller's order (longest first), WJ_MAX per launch
+        for (int j0 = 0; j0 < njobs; j0 += WJ_MAX) {
+            WgJobTable t;
+            const int n = njobs - j0 < WJ_MAX ? njobs - j0 : WJ_MAX;
+            int64_t blocks = 0;
+            for (int k = 0; k < n; ++k) {
+                const crf_wgrad_job& jb = jobs[j0 + k];
+                const WgPlan p = wg_plan(jb.M, jb.Co, jb.Ci);
+                float* partial = reinterpret_cast<float*>(jb.workspace);
+                t.G[k] = jb.G; t.X[k] = jb.X; t.partial[k] = partial;
+                t.partial_b[k] = jb.want_bias ? partial + (size_t)p.nblk * jb.Co * jb.Ci : nullptr;
+                t.M[k] = (int)jb.M; t.Co[k] = jb.Co; t.Ci[k] = jb.Ci; t.rows_per_block[k] = p.rows_per_block; t.nblk[k] = p.nblk; t.gy[k] = p.gy;
+                t.cls[k] = (unsigned char)(10 * p.tco + p.tci);
+                t.blk_base[k] = (int)blocks;
+                blocks += (int64_t)p.nblk * p.gy * p.gz;
+                CRF_REQUIRE(blocks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many workgroups in one batch");
+            }
+            for (int k = n; k <= WJ_MAX; ++k) t.blk_base[k] = (int)blocks;
+            for (int k = n; k < WJ_MAX; ++k) {
+                t.G[k] = nullptr; t.X[k] = nullptr; t.partial[k] = nullptr; t.partial_b[k] = nullptr;
+                t.M[k] = 0; t.Co[k] = 1; t.Ci[k] = 1; t.rows_per_block[k] = 64; t.nblk[k] = 1; t.gy[k] = 1; t.cls[k] = 11;
+            }
+            t.njobs = n;
+            hipLaunchKernelGGL(wgrad_jobs_any_kernel, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, st, t);
+            CRF_LAUNCH_CHECK();
+        }
+        return CRF_OK;
     }
     static const int classes[9][2] = {{4, 4}, {2, 2}, {4, 2}, {2, 4}, {1, 4}, {4, 1}, {1, 2}, {2, 1}, {1, 1}};
     for (int c = 0; c < 9; ++c) {
