@@ -1070,7 +1070,13 @@ constexpr int LF_BLOCK = LF_BLOCK_, LF_WAVES = LF_BLOCK / WAVE;
 // EPI: 0 plain store; 1 (PRO) Y += addend; 2 (not PRO) dropout mask on Y.  Template forms, so that the common kernels keep their
 // register budget (as run-time branches the two epilogues cost <2, false> and <4, true> one wavefront per SIMD each).
 constexpr int EPI_NONE = 0, EPI_ADD = 1, EPI_DROPOUT = 2;
-template <int TCO, bool PRO = false, bool VEC4 = true, int EPI = EPI_NONE>  // 16 * TCO output channels per block slab (blockIdx.y picks the slab)
+// NCH > 0 (round 4; Ci <= 16 NCH, VEC4): the operand fragments of ALL k chunks of a row group are requested at once and those of
+// the wavefront's NEXT row group before the current group's products (NCH <= LF_PF_MAX) -- the rolled loop (NCH = 0) pays one
+// dependent memory round trip per chunk, eight per group at 128 inputs, with two to four wavefronts per SIMD to hide them.
+#ifndef LF_PF_MAX_
+#define LF_PF_MAX_ 4
+#endif
+template <int TCO, bool PRO = false, bool VEC4 = true, int EPI = EPI_NONE, int NCH = 0>  // 16 * TCO output channels per block slab (blockIdx.y picks the slab)
 __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                               const float* __restrict__ bias, int64_t M, int Ci, int Co,
                                                               int transpose_w, float* __restrict__ Y,
@@ -1186,13 +1192,56 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
     // (Issuing the operand loads of four row groups in one burst, or prefetching the next group, measured no faster: the
     // write-heavy shapes run at the ~2.7 TB/s HBM WRITE rate -- 163840 x 8 -> 32 moves 21 MB out in 13 us -- not at a
     // per-wavefront latency limit.)
-    for (int64_t row0 = ((int64_t)blockIdx.x * (LF_BLOCK / WAVE) + wave) * 16; row0 < M;
-         row0 += (int64_t)gridDim.x * (LF_BLOCK / WAVE) * 16) {
+    constexpr int NCA = NCH > 0 ? NCH : 1;
+    constexpr bool PF = NCH > 0 && NCH <= LF_PF_MAX_;                 // next group's fragments in flight too
+    const int64_t row_stride = (int64_t)gridDim.x * (LF_BLOCK / WAVE) * 16;
+    [[maybe_unused]] float4 fa[NCA], fb[PRO ? NCA : 1], na[PF ? NCA : 1], nb[(PF && PRO) ? NCA : 1];
+    [[maybe_unused]] auto load_group = [&](int64_t rw0, float4 (&xa)[NCA], float4 (&xb)[PRO ? NCA : 1]) {
+        const int64_t rq = rw0 + rr;
+        const bool ok = rw0 < M && rq < M;
+#pragma unroll
+        for (int c = 0; c < NCA; ++c) {
+            float4 t0, t1;
+            load_raw(rq, ok, c, t0, t1);
+            xa[c] = t0;
+            if constexpr (PRO) xb[c] = t1;
+        }
+    };
+    if constexpr (PF) load_group(((int64_t)blockIdx.x * (LF_BLOCK / WAVE) + wave) * 16, fa, fb);
+    for (int64_t row0 = ((int64_t)blockIdx.x * (LF_BLOCK / WAVE) + wave) * 16; row0 < M; row0 += row_stride) {
         const int64_t r = row0 + rr;
         const bool rv = r < M;
         f32x4 acc[TCO];
 #pragma unroll
         for (int t = 0; t < TCO; ++t) acc[t] = f32x4{bsel[t][0], bsel[t][1], bsel[t][2], bsel[t][3]};
+        if constexpr (NCH > 0) {
+            if constexpr (PF) {
+                if constexpr (PRO) load_group(row0 + row_stride, na, nb);
+                else load_group(row0 + row_stride, na, fb);
+            } else {
+                load_group(row0, fa, fb);
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int k0 = 16 * c + 4 * g;
+                const float4 xv = operand(rv, c, fa[c], fb[PRO ? c : 0]);
+#pragma unroll
+                for (int t = 0; t < TCO; ++t) {
+                    const float4 wv = *reinterpret_cast<const float4*>(sW + (16 * t + rr) * Cip + k0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc[t], 0, 0, 0);
+                }
+            }
+            if constexpr (PF) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    fa[c] = na[c];
+                    if constexpr (PRO) fb[c] = nb[c];
+                }
+            }
+        } else {
         for (int c = 0; c < nchunk; ++c) {
             const int k0 = 16 * c + 4 * g;
             float4 ra, rb;
@@ -1207,6 +1256,7 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc[t], 0, 0, 0);
             }
+        }
         }
         // lane holds Y[row = row0 + rr][co = co_base + 16 t + 4 g + e], e = 0..3
         if constexpr (TCO >= 2) {
@@ -1548,6 +1598,13 @@ static int lf_tco(int Ci, int Co, bool pro) {
     return tco;
 }
 static size_t lf_lds_bytes(int Ci, int Co, bool pro) { return lf_lds_bytes_at(Ci, lf_tco(Ci, Co, pro), pro); }
+// k chunks of the hoisted operand loop (linear_fwd_kernel<.., NCH>): Ci <= 128 in 16-byte pieces; else 0 = the rolled loop
+static int lf_hoist_chunks(int Ci, bool vec4) {
+    static const bool off = getenv("CRFCONV_LF_NO_HOIST") != nullptr;      // A/B
+    if (off || !vec4 || Ci > 128) return 0;
+    const int n = (Ci + 15) / 16;
+    return n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8));
+}
 
 extern "C" int crfconv_linear_forward_supported(int Ci, int Co) {
     if (Ci < 1 || Co < 1) return 0;
@@ -1580,9 +1637,11 @@ static int linear_forward_impl(const float* X, const float* Xb, int xsplit, cons
     const size_t lds = lf_lds_bytes(Ci, Co, false);
     hipStream_t st = crf::as_stream(stream);
     const bool vec4 = (Ci % 4) == 0 && (Co % 4) == 0;
-#define LF3(T, V, E) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, false, V, E>), grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec, (const float*)nullptr, (const float*)nullptr, 1.f, Xb, xsplit, (float*)nullptr, 0, (const float*)nullptr, drop.counter, drop.seed, drop.threshold, drop.scale)
-#define LF2(T, V) do { if (drop.counter != nullptr) LF3(T, V, crf::EPI_DROPOUT); else LF3(T, V, crf::EPI_NONE); } while (0)
-#define LF(T) do { if (vec4) LF2(T, true); else LF2(T, false); } while (0)
+    const int nch = lf_hoist_chunks(Ci, vec4);       // 1 / 2 / 4 / 8 chunks: the hoisted loop; 0: the rolled one
+#define LF4(T, V, E, N) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, false, V, E, N>), grid, blk, lds, st, X, W, bias, M, Ci, Co, transpose_w, Y, stat_rec, (const float*)nullptr, (const float*)nullptr, 1.f, Xb, xsplit, (float*)nullptr, 0, (const float*)nullptr, drop.counter, drop.seed, drop.threshold, drop.scale)
+#define LF3(T, V, E) do { if (V && nch == 1) LF4(T, V, E, 1); else if (V && nch == 2) LF4(T, V, E, 2); else if (V && nch == 4) LF4(T, V, E, 4); else if (V && nch == 8) LF4(T, V, E, 8); else LF4(T, V, E, 0); } while (0)
+#define LF2(T, V) do { if (drop.counter != nullptr) LF4(T, V, crf::EPI_DROPOUT, 0); else LF3(T, V, crf::EPI_NONE); } while (0)
+#define LF(T) do { if (vec4) LF2(T, true); else if (drop.counter != nullptr) LF4(T, false, crf::EPI_DROPOUT, 0); else LF4(T, false, crf::EPI_NONE, 0); } while (0)
     switch (tco) {
         case 1: LF(1); break;
         case 2: LF(2); break;
@@ -1592,6 +1651,7 @@ static int linear_forward_impl(const float* X, const float* Xb, int xsplit, cons
 #undef LF
 #undef LF2
 #undef LF3
+#undef LF4
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
@@ -1858,9 +1918,11 @@ static int mlp_backward_impl(const float* gA, const float* Y, const float* X, co
         const dim3 grid((unsigned)crf::lf_blocks(M), (unsigned)gy), blk(crf::LF_BLOCK);
         const size_t lds = lf_lds_bytes(gCi, gCo, true);
         const bool vec4 = (gCi % 4) == 0 && (gCo % 4) == 0;
-#define DX3(T, V, E) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, true, V, E>), grid, blk, lds, st, gA, W, (const float*)nullptr, M, gCi, gCo, 1, dX, (float*)nullptr, Y, pro, slope, (const float*)nullptr, 0, dXb, xsplit, dX_add)
+        const int nch = lf_hoist_chunks(gCi, vec4);
+#define DX4(T, V, E, N) hipLaunchKernelGGL((crf::linear_fwd_kernel<T, true, V, E, N>), grid, blk, lds, st, gA, W, (const float*)nullptr, M, gCi, gCo, 1, dX, (float*)nullptr, Y, pro, slope, (const float*)nullptr, 0, dXb, xsplit, dX_add)
+#define DX3(T, V, E) do { if (V && nch == 1) DX4(T, V, E, 1); else if (V && nch == 2) DX4(T, V, E, 2); else if (V && nch == 4) DX4(T, V, E, 4); else if (V && nch == 8) DX4(T, V, E, 8); else DX4(T, V, E, 0); } while (0)
 #define DX2(T, V) do { if (dX_add != nullptr) DX3(T, V, crf::EPI_ADD); else DX3(T, V, crf::EPI_NONE); } while (0)
-#define DX(T) do { if (vec4) DX2(T, true); else DX2(T, false); } while (0)
+#define DX(T) do { if (vec4) DX2(T, true); else if (dX_add != nullptr) DX4(T, false, crf::EPI_ADD, 0); else DX4(T, false, crf::EPI_NONE, 0); } while (0)
         switch (tco) {
             case 1: DX(1); break;
             case 2: DX(2); break;
@@ -1870,6 +1932,7 @@ static int mlp_backward_impl(const float* gA, const float* Y, const float* X, co
 #undef DX
 #undef DX2
 #undef DX3
+#undef DX4
         CRF_LAUNCH_CHECK();
     }
     return CRF_OK;
