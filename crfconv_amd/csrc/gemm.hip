@@ -29,7 +29,10 @@ namespace crf {
 
 using gf32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int GM_BLOCK = 256, GM_BK = 32;
+#ifndef GM_BK_
+#define GM_BK_ 32
+#endif
+constexpr int GM_BLOCK = 256, GM_BK = GM_BK_;      // k columns per chunk (a multiple of 16)
 
 // four consecutive floats of which the first `valid` exist (VEC: widths are multiples of 4, so it is all or nothing and the
 // address is 16-byte aligned; else element by element -- odd widths such as the 13-class logits)

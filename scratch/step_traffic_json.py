@@ -18,6 +18,6 @@ with open(os.path.join(ROOT, 'profiles', 'r4h_step_traffic.md'), 'w') as f:
             'Two separate `rocprofv3 --pmc` passes (`FETCH_SIZE`, `WRITE_SIZE`; `scratch/run_step_pmc.sh`) over `scratch/step_pmc.py N` -- the same calls as\n'
             '`bench.py`\'s step, run eagerly -- with N = 2 and N = 5; per-step figures = (N = 5 minus N = 2) / 3.  Bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB, the\n'
             'gfx950 correction of the micro-architecture guide.  4 x 40 960 points, K = 16, T = 3, fp32.  **%.2f GB per step in %d launches**; the algorithmic byte\n'
-            'model of `bench.py::step_byte_model` gives 3.49 GB: waste ratio %.2f (DESIGN.md 7 lists where the factor goes).  Round 3: 7.35 GB in 361 launches.\n\n```\n%s\n```\n'
+            'model of `bench.py::step_byte_model` gives 3.49 GB: waste ratio %.2f (DESIGN.md 7 lists where the factor goes).  Round 3: 7.35 GB in 361 launches; round 4 before the classifier head stopped storing its [M, 4C] tensors: 6.70 GB in 357.\n\n```\n%s\n```\n'
             % (mb / 1e3, launches, mb * 1e6 / 3.49e9, txt.strip()))
 print('step traffic %.1f MB, %d launches' % (mb, launches))
