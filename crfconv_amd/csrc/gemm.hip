@@ -431,9 +431,23 @@ extern "C" int crfconv_mlp_small_backward(const float* gA, const float* Y, const
     const int N = Ci, K = Co;
     // 32 x 32 tiles as the plain product (32 x 64 for wide outputs, where every column slab forms the gY tile of its rows again,
     // measured the same: 4.75 ms per step either way)
-    const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32)), blk(crf::GM_BLOCK);
-    hipLaunchKernelGGL((crf::gemm_kernel<1, 1, 2, 2, false, true, true>), grid, blk, 0, st, gA, W, (const float*)nullptr, addend, (int)M, N, K,
-                       dX, pro);
+    // CRFCONV_PRO_BIG_BLOCKS=n (A/B): products of more than |n| 32 x 32 tiles take 64 x 64 (n > 0) / 32 x 64 (n < 0) ones
+    static const int big_env = getenv("CRFCONV_PRO_BIG_BLOCKS") ? atoi(getenv("CRFCONV_PRO_BIG_BLOCKS")) : 0;       // n: 64 x 64 above n tiles; -n: 32 x 64
+    static const int big_blocks = big_env < 0 ? -big_env : big_env, big_shape = big_env < 0 ? 1 : 0;
+    const dim3 blk(crf::GM_BLOCK);
+    if (big_blocks > 0 && N >= 64 && ((M + 31) / 32) * (int64_t)((N + 31) / 32) > big_blocks) {
+        if (big_shape == 0) {
+            const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
+            hipLaunchKernelGGL((crf::gemm_kernel<2, 2, 2, 2, false, true, true>), grid, blk, 0, st, gA, W, (const float*)nullptr, addend, (int)M, N, K, dX, pro);
+        } else {
+            const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 63) / 64));
+            hipLaunchKernelGGL((crf::gemm_kernel<1, 2, 2, 2, false, true, true>), grid, blk, 0, st, gA, W, (const float*)nullptr, addend, (int)M, N, K, dX, pro);
+        }
+    } else {
+        const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32));
+        hipLaunchKernelGGL((crf::gemm_kernel<1, 1, 2, 2, false, true, true>), grid, blk, 0, st, gA, W, (const float*)nullptr, addend, (int)M, N, K,
+                           dX, pro);
+    }
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -230,3 +230,25 @@ def test_tolerances_are_tied_to_the_recorded_errors(monkeypatch):
     gpu_util.assert_close(ref + 5e-5, ref, 1e-4, 'unrecorded site')
     baseline = gpu_util.json.load(open(gpu_util._BASELINE_PATH)) if hasattr(gpu_util, 'json') else __import__('json').load(open(gpu_util._BASELINE_PATH))
     assert len(baseline) > 2000 and all(v >= 0 for v in baseline.values())
+
+
+def test_dropout_mask_host_twin_is_a_keyed_bernoulli_stream():
+    """ops.dropout_keep_mask -- the host twin of csrc/common.hpp::dropout_keep (two 32-bit keys per (seed, counter) from one
+    splitmix64 round, a two-multiply 32-bit finalizer per element): deterministic, keep rate 1 - p, another mask for another
+    counter or seed, no correlation between neighbouring elements or rows, element numbering beyond 2^32 defined."""
+    import numpy as np
+    from crfconv_amd import ops
+    n = 1 << 18
+    m = ops.dropout_keep_mask(1234, 7, n, 0.5)
+    assert m.dtype == np.bool_ and m.shape == (n,)
+    assert np.array_equal(m, ops.dropout_keep_mask(1234, 7, n, 0.5))
+    assert abs(m.mean() - 0.5) < 5e-3
+    assert abs(ops.dropout_keep_mask(1234, 7, n, 0.3).mean() - 0.7) < 5e-3
+    assert ops.dropout_keep_mask(1234, 7, n, 0.0).all()
+    for other in (ops.dropout_keep_mask(1234, 8, n, 0.5), ops.dropout_keep_mask(1235, 7, n, 0.5)):
+        assert abs((m != other).mean() - 0.5) < 5e-3                # independent fair coins differ half of the time
+    for lag in (1, 2, 16, 128):
+        c = np.corrcoef(m[:-lag].astype(np.float64), m[lag:].astype(np.float64))[0, 1]
+        assert abs(c) < 1e-2, (lag, c)
+    # a mask is a function of (seed, counter, element) only: a longer call starts with the shorter one
+    assert np.array_equal(ops.dropout_keep_mask(99, 1, 1000, 0.5), ops.dropout_keep_mask(99, 1, 4000, 0.5)[:1000])
