@@ -6,8 +6,8 @@
 // y = x W1^T from the 21 MB input on the matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 products, the same k order as
 // linear_fwd_kernel, so y is bit-identical in every pass) and keeps everything 128-wide in registers:
 //
-//   forward   crfconv_linear_forward_stats (linear.hip)   BatchNorm statistic records of y, nothing stored
-//             crfconv_bn_coef_from_records                coefficients + running statistics
+//   forward   head_stats_kernel                           BatchNorm statistic records of y (the tuples of linear_fwd_kernel), nothing stored
+//             crfconv_bn_coef_from_nrecords (linear.hip)  coefficients + running statistics
 //             head_fwd_kernel                             y -> lrelu(a y + b) -> mask -> logits = h W2^T + b2; one mask WORD per
 //                                                         (row, lane group) = the 32 channels a lane holds (2.6 MB instead of h)
 //   backward  head_bwd_p1_kernel    y, gh = g W2 recomputed in the TRANSPOSED accumulator layout (rows in registers, channels on
@@ -24,6 +24,9 @@
 //   "row-major" (backward pass 1):  A = rows, B = weights   ->  lane (rr, g) holds channel 16 t + rr, rows 4 g + e = the operand
 //       of a product over ROWS whose k-step e takes row 4 g + e from every lane (any fixed bijection rows <-> (step, lane
 //       group) serves a sum over all sixteen rows, as long as both operands use the same one).
+// Every row-streaming kernel requests a wavefront's operand rows two groups ahead.  The vector ALU and the matrix pipe of a SIMD do
+// not overlap (scratch/mfma_peak.hip: 32.8 + 4 V cycles per MFMA with V vector instructions beside it), so the kernels' time is
+// 32 x MFMAs + 4 x vector instructions per wavefront: matrix-pipe utilisation 0.39 (forward: the mask hash) .. 0.57 (profiles/r4j_head_pmc.md).
 #include "common.hpp"
 
 #include <cstdlib>
