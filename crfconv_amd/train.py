@@ -14,8 +14,12 @@ import torch
 
 
 class CapturedStep:
-    def __init__(self, model, optimizer, loss_fn, batch, after_backward=None, warmup=2):
+    def __init__(self, model, optimizer, loss_fn, batch, after_backward=None, warmup=2, defer_weight_grads=True):
+        """defer_weight_grads: run the backward inside ``ops.deferred_weight_grads()`` -- the ~150 weight-gradient launches of the
+        pass (partial pass + sum per layer) go out as a dozen batched ones at its end; ``.grad`` of every parameter is set before
+        ``optimizer.step()`` as usual (same partial slabs, fixed summation order).  False: the backward exactly as the caller wrote it."""
         self.model, self.optimizer, self.loss_fn, self.batch, self.after_backward = model, optimizer, loss_fn, batch, after_backward
+        self.defer_weight_grads = bool(defer_weight_grads)
         # the warm-up steps (allocator, lazily built tables, momentum buffers) must not train: model state is put back afterwards,
         # momentum restarts from zero (mu * 0 + g = g: torch's first step, for dampening = 0)
         keep = [t.detach().clone() for t in list(model.parameters()) + list(model.buffers())]
@@ -41,7 +45,12 @@ class CapturedStep:
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.loss_fn(self.model(self.batch), self.batch)
-        loss.backward()
+        if self.defer_weight_grads:
+            from . import ops
+            with ops.deferred_weight_grads():
+                loss.backward()
+        else:
+            loss.backward()
         if self.after_backward is not None:
             self.after_backward()
         self.optimizer.step()

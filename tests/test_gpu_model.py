@@ -1873,10 +1873,13 @@ def test_crf_parameter_gradients_deferred_to_the_end_of_the_pass_equal_the_immed
         assert float(a.abs().max()) > 0 and torch.equal(a, b)
 
 
-def test_captured_step_of_the_unchanged_reference_loop_equals_the_eager_loop():
+@pytest.mark.parametrize('defer', [False, True])
+def test_captured_step_of_the_unchanged_reference_loop_equals_the_eager_loop(defer):
     """crfconv_amd.train.CapturedStep around the reference's own step (trainval.py:99-106: zero_grad, model(data),
     F.cross_entropy(weight, ignore_index), backward, torch.optim.SGD.step) against the same loop run eagerly: three steps on
-    three different batches from equal initial state must leave equal parameters, BatchNorm buffers and losses."""
+    three different batches from equal initial state must leave equal parameters, BatchNorm buffers and losses.  defer: the
+    class's default -- the backward's weight-gradient launches batched at its end (ops.deferred_weight_grads inside the capture;
+    another summation order of the same partial slabs) -- or the backward exactly as written (bit-equal to the eager loop)."""
     import crfconv_amd
     import torch.nn.functional as F
     from crfconv_amd import models
@@ -1907,13 +1910,13 @@ def test_captured_step_of_the_unchanged_reference_loop_equals_the_eager_loop():
         ropt.step()
         ref_losses.append(float(loss))
     static = batch(900)                                      # the resident batch the graph reads
-    step = CapturedStep(net, opt, loss_fn, static)
+    step = CapturedStep(net, opt, loss_fn, static, defer_weight_grads=defer)
     got_losses = [float(step(d)) for d in batches]
     torch.cuda.synchronize()
     for a, b in zip(got_losses, ref_losses):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (got_losses, ref_losses)
     for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
-        assert_close(a.float(), b.float(), 2e-5, 'after 3 steps: ' + k)
+        assert_close(a.float(), b.float(), 2e-5, ('after 3 steps (batched weight gradients): ' if defer else 'after 3 steps: ') + k)
 
 
 def test_crf_late_gradients_with_two_consumers_of_one_matrix_pair_and_a_hook():
