@@ -16,7 +16,10 @@ namespace crf {
 using f32x4s = __attribute__((ext_vector_type(4))) float;
 
 constexpr int SM_BLOCK = 256, SM_ROWS = 64, SM_COLS = 64, SM_KC = 64, SM_LD = SM_KC + 4;   // SM_COLS: the widest tile
-constexpr int64_t SM_MAX_ROWS = 4096;
+#ifndef SM_MAX_ROWS_
+#define SM_MAX_ROWS_ 4096
+#endif
+constexpr int64_t SM_MAX_ROWS = SM_MAX_ROWS_;      // (A/B: 10 240 = the third level joins the one-launch form, profiles/r4_ab_runs.md)
 #ifndef SM_MIN_BLOCKS
 #define SM_MIN_BLOCKS 256
 #endif
