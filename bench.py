@@ -632,6 +632,8 @@ def main():
         with ops.deferred_weight_grads(sink=bucket.view_of):     # one batched launch finishes all 74 dW / db reductions, into the bucket
             loss.backward(unit)
         bucket.pack()                                     # one batched copy into the flat bucket; .grad -> bucket views
+        if world > 1:
+            bucket.publish_guard()                        # this rank's barrier-failure flag into the slot the all-reduce sums with the gradients
         return loss.detach()
 
     def part_b():
@@ -641,7 +643,7 @@ def main():
 
     def collective():
         if grouped:
-            torch.distributed.all_reduce(bucket.flat, op=torch.distributed.ReduceOp.SUM)     # the 1 / world factor sits in the SGD kernel
+            bucket.allreduce_packed()                     # ONE all-reduce (sum) of gradients + failure flag; the 1 / world factor sits in the SGD kernel
 
     def step():
         loss = part_a()

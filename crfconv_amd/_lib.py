@@ -150,7 +150,10 @@ SIGNATURES = {
     'crfconv_sgd_step': (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _i, _vp]),
     'crfconv_sgd_step_hyper': (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp]),
     'crfconv_sgd_step_guarded': (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp, _vp]),
+    'crfconv_sgd_step_guarded_all': (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    'crfconv_sgd_guard_publish': (_i, [_vp, _i, _vp, _vp]),
     'crfconv_spd_inverse': (_i, [_vp, _i, _vp, _vp]),
+    'crfconv_spd_inverse_wide': (_i, [_vp, _i, _vp, _vp]),
     'crfconv_neighbor_maxpool_forward': (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp]),
     'crfconv_neighbor_maxpool_affine_forward': (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp]),
     'crfconv_neighbor_maxpool_backward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),

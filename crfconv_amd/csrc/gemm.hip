@@ -32,7 +32,12 @@ using gf32x4 = __attribute__((ext_vector_type(4))) float;
 #ifndef GM_BK_
 #define GM_BK_ 32
 #endif
+#ifndef GM_PF_
+#define GM_PF_ 2
+#endif
 constexpr int GM_BLOCK = 256, GM_BK = GM_BK_;      // k columns per chunk (a multiple of 16)
+constexpr int GM_PF = GM_PF_;                      // operand chunks in flight per workgroup (register sets; even)
+static_assert(GM_PF >= 2 && GM_PF % 2 == 0, "an even number of register sets (the LDS buffers alternate)");
 
 // four consecutive floats of which the first `valid` exist (VEC: widths are multiples of 4, so it is all or nothing and the
 // address is 16-byte aligned; else element by element -- odd widths such as the 13-class logits)
@@ -200,9 +205,13 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const flo
     };
 
     const int nchunk = (K + GM_BK - 1) / GM_BK;
-    Regs r0, r1;
-    fetch(0, r0);
-    if (nchunk > 1) fetch(GM_BK, r1);
+    // GM_PF register sets: chunks c + 1 .. c + GM_PF - 1 sit in registers (or are on their way) while chunk c is on the matrix
+    // pipe, chunk c + GM_PF is requested as soon as the set of chunk c has been parked.  A 512-input product is sixteen dependent
+    // LDS hand-overs; with two sets (rounds 1-4) each of them also was a memory round trip.
+    Regs rs[GM_PF];
+#pragma unroll
+    for (int d = 0; d < GM_PF; ++d)
+        if (d == 0 || d < nchunk) fetch(GM_BK * d, rs[d]);
     if constexpr (PRO) {                                 // behind the first operand loads' issue: channel coefficients into LDS
         for (int k = threadIdx.x; k < K; k += GM_BLOCK) {
             double s1 = 0.0, s2 = 0.0;
@@ -230,20 +239,19 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const flo
         }
         __syncthreads();
     }
-    park(0, r0);
+    park(0, rs[0]);
     __syncthreads();
-    // iteration c: chunk c sits in LDS buffer c & 1, chunk c + 1 in registers (fetched one iteration ago), chunk c + 2 is
-    // requested now; two iterations per trip so the two register sets keep their names
-    for (int c = 0; c < nchunk; c += 2) {
-        if (c + 2 < nchunk) fetch(GM_BK * (c + 2), r0);
-        compute(0);
-        if (c + 1 < nchunk) {
-            park(1, r1);                                 // buffer 1: its readers passed the barrier that ended chunk c - 1
-            __syncthreads();
-            if (c + 3 < nchunk) fetch(GM_BK * (c + 3), r1);
-            compute(1);
-            if (c + 2 < nchunk) {
-                park(0, r0);
+    // iteration c = cb + d: chunk c sits in LDS buffer d & 1 (GM_PF is even), its register set d is free again and takes chunk
+    // c + GM_PF; the set of chunk c + 1 is parked behind the products of chunk c
+    for (int cb = 0; cb < nchunk; cb += GM_PF) {
+#pragma unroll
+        for (int d = 0; d < GM_PF; ++d) {
+            const int c = cb + d;
+            if (c >= nchunk) break;
+            if (c + GM_PF < nchunk) fetch(GM_BK * (c + GM_PF), rs[d]);
+            compute(d & 1);
+            if (c + 1 < nchunk) {
+                park((d + 1) & 1, rs[(d + 1) % GM_PF]);   // that buffer's readers passed the barrier that ended chunk c - 1
                 __syncthreads();
             }
         }
@@ -429,25 +437,12 @@ extern "C" int crfconv_mlp_small_backward(const float* gA, const float* Y, const
     pro.Y = Y; pro.coef = coef; pro.partial = partial; pro.ntile = ntile; pro.training = training; pro.slope = slope;
     pro.inv_m = (float)(1.0 / (double)M); pro.gY = gY; pro.dgamma = dgamma; pro.dbeta = dbeta;
     const int N = Ci, K = Co;
-    // 32 x 32 tiles as the plain product (32 x 64 for wide outputs, where every column slab forms the gY tile of its rows again,
-    // measured the same: 4.75 ms per step either way)
-    // CRFCONV_PRO_BIG_BLOCKS=n (A/B): products of more than |n| 32 x 32 tiles take 64 x 64 (n > 0) / 32 x 64 (n < 0) ones
-    static const int big_env = getenv("CRFCONV_PRO_BIG_BLOCKS") ? atoi(getenv("CRFCONV_PRO_BIG_BLOCKS")) : 0;       // n: 64 x 64 above n tiles; -n: 32 x 64
-    static const int big_blocks = big_env < 0 ? -big_env : big_env, big_shape = big_env < 0 ? 1 : 0;
+    // 32 x 32 tiles as the plain product (32 x 64 / 64 x 64 tiles for wide outputs, where every column slab forms the gY tile of its
+    // rows again, measured the same or slower: DESIGN 9)
     const dim3 blk(crf::GM_BLOCK);
-    if (big_blocks > 0 && N >= 64 && ((M + 31) / 32) * (int64_t)((N + 31) / 32) > big_blocks) {
-        if (big_shape == 0) {
-            const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
-            hipLaunchKernelGGL((crf::gemm_kernel<2, 2, 2, 2, false, true, true>), grid, blk, 0, st, gA, W, (const float*)nullptr, addend, (int)M, N, K, dX, pro);
-        } else {
-            const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 63) / 64));
-            hipLaunchKernelGGL((crf::gemm_kernel<1, 2, 2, 2, false, true, true>), grid, blk, 0, st, gA, W, (const float*)nullptr, addend, (int)M, N, K, dX, pro);
-        }
-    } else {
-        const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32));
-        hipLaunchKernelGGL((crf::gemm_kernel<1, 1, 2, 2, false, true, true>), grid, blk, 0, st, gA, W, (const float*)nullptr, addend, (int)M, N, K,
-                           dX, pro);
-    }
+    const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32));
+    hipLaunchKernelGGL((crf::gemm_kernel<1, 1, 2, 2, false, true, true>), grid, blk, 0, st, gA, W, (const float*)nullptr, addend, (int)M, N, K,
+                       dX, pro);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
@@ -513,14 +508,12 @@ extern "C" int crfconv_gemm(const float* A, const float* B, const float* bias, c
     // tile shapes (rows x columns per workgroup): 64 x 64, 32 x 64, 64 x 32, 32 x 32 -- the largest that still gives the
     // grid `min_blocks` workgroups.  Measured on the shapes of the training step (scratch/gemm_bench.py, graph replays): 32 x 32 is the
     // fastest or within 0.5 us of it from 640 x 64 to 163 840 x 32 -- these launches are latency-bound, many short wavefronts win
-    static const int min_blocks = getenv("CRFCONV_GEMM_MIN_BLOCKS") ? atoi(getenv("CRFCONV_GEMM_MIN_BLOCKS")) : 4096;
-    static const int force = getenv("CRFCONV_GEMM_TILE") ? atoi(getenv("CRFCONV_GEMM_TILE")) : -1;
+    constexpr int min_blocks = 4096;
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (int64_t)((N + bn - 1) / bn); };
     int shape = 3;
     if (N > 32 && blocks(64, 64) >= min_blocks) shape = 0;
     else if (N > 32 && blocks(32, 64) >= min_blocks) shape = 1;
     else if (blocks(64, 32) >= min_blocks) shape = 2;
-    if (force >= 0 && force <= 3) shape = force;
     hipStream_t st = crf::as_stream(stream);
     const dim3 blk(crf::GM_BLOCK);
     const bool vec = N % 4 == 0 && K % 4 == 0;           // 16-byte accesses; odd widths (13-class logits) go element by element

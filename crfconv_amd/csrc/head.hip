@@ -745,14 +745,11 @@ static int hd_grid_cap(int64_t M, int cap) {
     if (nb > cap) nb = cap;
     return (int)(nb < 1 ? 1 : nb);
 }
-static int hd_env(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-static int hd_grid(int64_t M) { static const int cap = hd_env("CRFCONV_HD_GRID", 512); return hd_grid_cap(M, cap); }          // forward
-static int hd_grid_dx(int64_t M) { static const int cap = hd_env("CRFCONV_HD_GRID_DX", 512); return hd_grid_cap(M, cap); }
-static int hd_grid_p1(int64_t M) { static const int cap = hd_env("CRFCONV_HD_GRID_P1", 256); return hd_grid_cap(M, cap); }    // x 2 slabs
-static int hd_grid_st(int64_t M) { static const int cap = hd_env("CRFCONV_HD_GRID_ST", 256); return hd_grid_cap(M, cap); }    // x 2 slabs
+// workgroups per launch (swept 256 .. 1024 on the training step, DESIGN 9 HD3: all within 2 us)
+static int hd_grid(int64_t M) { return hd_grid_cap(M, 512); }          // forward
+static int hd_grid_dx(int64_t M) { return hd_grid_cap(M, 512); }
+static int hd_grid_p1(int64_t M) { return hd_grid_cap(M, 256); }    // x 2 slabs
+static int hd_grid_st(int64_t M) { return hd_grid_cap(M, 256); }    // x 2 slabs
 
 }  // namespace crf
 

@@ -625,14 +625,7 @@ __global__ __launch_bounds__(BRUTE_BLOCK) void knn_brute_kernel(const float* __r
 
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static double knn_points_per_cell() {
-    static const double v = [] {
-        const char* e = getenv("CRFCONV_KNN_PPC");
-        const double x = e ? atof(e) : 0.6;      // sweep 0.35 .. 16 on the bench clouds: flat optimum around 0.6
-        return x > 0.0 ? x : 0.6;
-    }();
-    return v;
-}
+static double knn_points_per_cell() { return 0.6; }      // sweep 0.35 .. 16 on the bench clouds: flat optimum around 0.6
 
 static int grid_g0(size_t npts) {
     int g = (int)floor(cbrt((double)npts / knn_points_per_cell()));
@@ -699,8 +692,7 @@ extern "C" int crfconv_knn_batch_dev(const float* pts, size_t batch_size, size_t
     const KnnLayout L = knn_layout(batch_size, npts);
     CRF_REQUIRE(workspace_bytes >= L.total, CRF_ERR_WORKSPACE, "knn workspace %zu < %zu", workspace_bytes, L.total);
     hipStream_t st = as_stream(stream);
-    static const bool no_brute = getenv("CRFCONV_KNN_NO_BRUTE") != nullptr;       // A/B: always the grid search
-    if (!no_brute && npts <= (size_t)BRUTE_MAX && (K == 1 || K == 8 || K == 16 || K == 32)) {
+    if (npts <= (size_t)BRUTE_MAX && (K == 1 || K == 8 || K == 16 || K == 32)) {
         const dim3 bgrid((unsigned)cdiv((int64_t)nqueries, BRUTE_QPB), (unsigned)batch_size);
 #define KNN_BRUTE(KM)                                                                                       \
     hipLaunchKernelGGL(knn_brute_kernel<KM>, bgrid, dim3(BRUTE_BLOCK), 0, st, pts, (int64_t)npts, queries, \
@@ -746,8 +738,7 @@ extern "C" int crfconv_knn_batch_dev(const float* pts, size_t batch_size, size_t
 #define KNN_LAUNCH(KM)                                                                                     \
     hipLaunchKernelGGL(knn_query_kernel<KM>, qgrid, dim3(QBLOCK), 0, st, queries, (int64_t)nqueries,       \
                        (int64_t)npts, (int)K, info, L.ncell_alloc, starts, sorted, out_i64, out_i32)
-    static const bool no_coop = getenv("CRFCONV_KNN_NO_COOP") != nullptr;         // A/B: one lane per query
-    if (!no_coop && K > 1 && K <= 16) {
+    if (K > 1 && K <= 16) {
         const dim3 cgrid((unsigned)cdiv((int64_t)nqueries, CO_QPB), (unsigned)batch_size);
         hipLaunchKernelGGL(knn_coop_kernel<16>, cgrid, dim3(CO_BLOCK), 0, st, queries, (int64_t)nqueries, (int)K, info,
                            L.ncell_alloc, starts, sorted, out_i64, out_i32);

@@ -135,21 +135,6 @@ struct WgJobTable {
     int njobs;
     unsigned char cls[WJ_MAX];                         // 10 TCO + TCI (wgrad_jobs_any_kernel)
 };
-template <int TCO, int TCI>
-__global__ __launch_bounds__(WG_BLOCK) void wgrad_jobs_kernel(const WgJobTable t) {
-    int lo = 0, hi = t.njobs;                          // largest j with blk_base[j] <= blockIdx.x
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (t.blk_base[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
-    }
-    const int local = (int)blockIdx.x - t.blk_base[lo];
-    const int bx = local % t.nblk[lo], rest = local / t.nblk[lo];
-    __shared__ float s_red[WG_WAVES * TCO * TCI * 256];
-    __shared__ float s_b[WG_WAVES * TCO * 16];
-    wgrad_body<TCO, TCI>(t.G[lo], t.X[lo], t.M[lo], t.Co[lo], t.Ci[lo], t.rows_per_block[lo], t.partial[lo], t.partial_b[lo], bx,
-                         rest % t.gy[lo], rest / t.gy[lo], s_red, s_b);
-}
-
 // Every tile class in ONE launch (round 4): the jobs of the small classes -- five launches of 40-240 workgroups, 7-12 us each, behind
 // the <4, 4> launch of the step -- run beside the large ones.  The workgroup looks its job up as above and dispatches on the job's
 // class; one LDS buffer of the largest class (64 KB), the register budget of the largest (the small classes' jobs are few).
@@ -638,8 +623,7 @@ extern "C" int crfconv_linear_wgrad_partial_jobs(const crf_wgrad_job* jobs, int 
         CRF_REQUIRE((reinterpret_cast<uintptr_t>(jb.workspace) & 255) == 0, CRF_ERR_ARG, "job %d: workspace must be 256-byte aligned", j);
         CRF_REQUIRE(jb.workspace_bytes >= crfconv_linear_wgrad_workspace(jb.M, jb.Co, jb.Ci), CRF_ERR_WORKSPACE, "job %d: workspace too small", j);
     }
-    static const bool one_launch = getenv("CRFCONV_WGRAD_PER_CLASS") == nullptr;      // A/B: one launch per tile class (round 3)
-    if (one_launch) {
+    {
         // jobs in the caller's order (longest first), WJ_MAX per launch
         for (int j0 = 0; j0 < njobs; j0 += WJ_MAX) {
             WgJobTable t;
@@ -664,50 +648,6 @@ extern "C" int crfconv_linear_wgrad_partial_jobs(const crf_wgrad_job* jobs, int 
             }
             t.njobs = n;
             hipLaunchKernelGGL(wgrad_jobs_any_kernel, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, st, t);
-            CRF_LAUNCH_CHECK();
-        }
-        return CRF_OK;
-    }
-    static const int classes[9][2] = {{4, 4}, {2, 2}, {4, 2}, {2, 4}, {1, 4}, {4, 1}, {1, 2}, {2, 1}, {1, 1}};
-    for (int c = 0; c < 9; ++c) {
-        int j = 0;
-        while (j < njobs) {
-            WgJobTable t;
-            int n = 0;
-            int64_t blocks = 0;
-            for (; j < njobs && n < WJ_MAX; ++j) {
-                const crf_wgrad_job& jb = jobs[j];
-                const WgPlan p = wg_plan(jb.M, jb.Co, jb.Ci);
-                if (p.tco != classes[c][0] || p.tci != classes[c][1]) continue;
-                float* partial = reinterpret_cast<float*>(jb.workspace);
-                t.G[n] = jb.G; t.X[n] = jb.X; t.partial[n] = partial;
-                t.partial_b[n] = jb.want_bias ? partial + (size_t)p.nblk * jb.Co * jb.Ci : nullptr;
-                t.M[n] = (int)jb.M; t.Co[n] = jb.Co; t.Ci[n] = jb.Ci; t.rows_per_block[n] = p.rows_per_block; t.nblk[n] = p.nblk; t.gy[n] = p.gy;
-                t.blk_base[n] = (int)blocks;
-                blocks += (int64_t)p.nblk * p.gy * p.gz;
-                CRF_REQUIRE(blocks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many workgroups in one batch");
-                ++n;
-            }
-            if (n == 0) break;
-            for (int k = n; k <= WJ_MAX; ++k) t.blk_base[k] = (int)blocks;
-            for (int k = n; k < WJ_MAX; ++k) {
-                t.G[k] = nullptr; t.X[k] = nullptr; t.partial[k] = nullptr; t.partial_b[k] = nullptr;
-                t.M[k] = 0; t.Co[k] = 1; t.Ci[k] = 1; t.rows_per_block[k] = 64; t.nblk[k] = 1; t.gy[k] = 1;
-            }
-            t.njobs = n;
-#define WJ(TA, TB) hipLaunchKernelGGL((wgrad_jobs_kernel<TA, TB>), dim3((unsigned)blocks), dim3(WG_BLOCK), 0, st, t)
-            switch (classes[c][0] * 10 + classes[c][1]) {
-                case 44: WJ(4, 4); break;
-                case 22: WJ(2, 2); break;
-                case 42: WJ(4, 2); break;
-                case 24: WJ(2, 4); break;
-                case 14: WJ(1, 4); break;
-                case 41: WJ(4, 1); break;
-                case 12: WJ(1, 2); break;
-                case 21: WJ(2, 1); break;
-                default: WJ(1, 1); break;
-            }
-#undef WJ
             CRF_LAUNCH_CHECK();
         }
     }
@@ -1016,6 +956,46 @@ extern "C" int crfconv_crf_matrices_backward_batched(const float* const* c, cons
     }
     for (int i = n; i < crf::CM_MAX; ++i) j.slab_base[i + 1] = 0x7fffffff;      // (never reached by a block index)
     hipLaunchKernelGGL(crf::crf_matrices_bwd_batched_kernel, dim3((unsigned)j.slab_base[n]), dim3(crf::CMB_BLOCK), 0, crf::as_stream(stream), j);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+namespace crf {
+// Q = M^-1 for a symmetric positive definite M [H, H] with 64 < H <= 512 (the 128- / 256-channel CRF stages of the sparse networks,
+// models/point_conv.py:318-339: M = I + c^T c, eigenvalues >= 1): in-place Gauss-Jordan WITHOUT pivoting on the copy in Q, one
+// workgroup, the matrix in global memory behind this CU's caches (256 KB at H = 256 -- it does not fit LDS), pivot row and column
+// staged in LDS per step.  H steps of one read-modify-write pass each: ~0.1 ms at H = 128, ~1 ms at H = 256 -- once per forward of
+// a layer whose reference recomputes torch.inverse in every mean-field step (continuous_crf_conv.py:66).
+constexpr int SW_BLOCK = 1024, SW_MAXH = 512;
+__global__ __launch_bounds__(SW_BLOCK) void spd_inverse_wide_kernel(const float* __restrict__ M, int H, float* __restrict__ Q) {
+    __shared__ float s_row[SW_MAXH], s_col[SW_MAXH];
+    const int n = H * H;
+    for (int e = threadIdx.x; e < n; e += SW_BLOCK) Q[e] = M[e];
+    __syncthreads();
+    for (int k = 0; k < H; ++k) {
+        for (int t = threadIdx.x; t < H; t += SW_BLOCK) {
+            s_row[t] = Q[k * H + t];
+            s_col[t] = Q[t * H + k];
+        }
+        __syncthreads();
+        const float inv = 1.0f / s_row[k];
+        for (int e = threadIdx.x; e < n; e += SW_BLOCK) {
+            const int i = e / H, j = e - i * H;
+            float v;
+            if (i == k) v = j == k ? inv : s_row[j] * inv;
+            else if (j == k) v = -s_col[i] * inv;
+            else v = fmaf(-s_col[i] * inv, s_row[j], Q[e]);
+            Q[e] = v;
+        }
+        __syncthreads();
+    }
+}
+}  // namespace crf
+
+extern "C" int crfconv_spd_inverse_wide(const float* M, int H, float* Q, crf_stream_t stream) {
+    CRF_REQUIRE(M && Q && M != Q, CRF_ERR_ARG, "null pointer / aliased operands");
+    CRF_REQUIRE(H >= 1 && H <= crf::SW_MAXH, CRF_ERR_UNSUPPORTED, "H=%d outside [1, %d]", H, crf::SW_MAXH);
+    hipLaunchKernelGGL(crf::spd_inverse_wide_kernel, dim3(1), dim3(crf::SW_BLOCK), 0, crf::as_stream(stream), M, H, Q);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
@@ -1565,7 +1545,7 @@ __global__ __launch_bounds__(FR_BLOCK) void bn_apply_records_kernel(const float*
 }
 
 static int lf_blocks(int64_t M) {
-    static const int cap = getenv("CRFCONV_LF_BLOCKS") ? atoi(getenv("CRFCONV_LF_BLOCKS")) : 512;   // swept 128..2048 on the training step: 512 (two blocks per CU, half the statistic records of 1024) is the optimum
+    constexpr int cap = 512;   // swept 128..2048 on the training step: 512 (two blocks per CU, half the statistic records of 1024) is the optimum
     int64_t nb = (M + 16 * LF_WAVES - 1) / (16 * LF_WAVES);           // 16 rows per wave and iteration; two blocks per CU keep
     if (nb > cap) nb = cap;               // enough 16-byte loads in flight; one statistics record per block
     return (int)(nb < 1 ? 1 : nb);
@@ -1590,7 +1570,7 @@ static size_t lf_lds_bytes_at(int Ci, int tco, bool pro) {
 // Output tiles per workgroup: by Co, then halved until the slab of k = Ci inputs fits 64 KB (256 inputs: 32 channels per
 // workgroup, 512: 16 -- the operand rows are then read once per column slab, from L2).
 static int lf_tco(int Ci, int Co, bool pro) {
-    static const int max_tco = getenv("CRFCONV_LF_MAX_TCO") ? atoi(getenv("CRFCONV_LF_MAX_TCO")) : 4;
+    constexpr int max_tco = 4;
     const int tiles = (Co + 15) / 16;
     int tco = tiles >= 8 ? 8 : (tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1));
     if (tco > max_tco) tco = max_tco;
@@ -1600,8 +1580,7 @@ static int lf_tco(int Ci, int Co, bool pro) {
 static size_t lf_lds_bytes(int Ci, int Co, bool pro) { return lf_lds_bytes_at(Ci, lf_tco(Ci, Co, pro), pro); }
 // k chunks of the hoisted operand loop (linear_fwd_kernel<.., NCH>): Ci <= 128 in 16-byte pieces; else 0 = the rolled loop
 static int lf_hoist_chunks(int Ci, bool vec4) {
-    static const bool off = getenv("CRFCONV_LF_NO_HOIST") != nullptr;      // A/B
-    if (off || !vec4 || Ci > 128) return 0;
+    if (!vec4 || Ci > 128) return 0;
     const int n = (Ci + 15) / 16;
     return n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8));
 }
@@ -1750,7 +1729,7 @@ static MlpPlan mlp_plan(int64_t M, int Co, int Ci) {
     if (p.tco * p.tci == 16) p.tci = 2;              // two accumulator sets: at most 8 tiles (64 registers) each
     p.gy = (t_co + p.tco - 1) / p.tco;
     p.gz = (t_ci + p.tci - 1) / p.tci;
-    static const int target = getenv("CRFCONV_MLP_SLICES") ? atoi(getenv("CRFCONV_MLP_SLICES")) : 512;
+    constexpr int target = 512;                      // slices x column slabs per launch (256 / 1024 measured slower: DESIGN 9 C4)
     int64_t slices = target / ((int64_t)p.gy * p.gz);
     if (slices < 32) slices = 32;
     int64_t rows = (M + slices - 1) / slices;

@@ -158,14 +158,38 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 }
 // the same update with {lr, momentum, dampening, weight_decay} read from device memory: a captured hipGraph of the step
 // then follows a learning-rate schedule (trainval.py:73 ExponentialLR) -- launch scalars are frozen at capture time
+// the sticky failure words a guarded update looks at: the grid-barrier words of every barrier workspace of the device (a step may
+// have run eagerly on one stream and as a captured graph on another: each has its own words) and, under data parallelism, the
+// REDUCED flag -- a float slot behind the flat gradient bucket that every rank fills with its own state before the all-reduce, so
+// that all replicas skip the update of a step in which ANY rank failed (its NaN gradient was summed into everybody's bucket)
+constexpr int SGD_MAX_FAIL = 8;
+struct SgdGuard {
+    const unsigned* words[SGD_MAX_FAIL];
+    int nwords;
+    const float* reduced;      // may be null
+};
+__device__ __forceinline__ bool sgd_guard_set(const SgdGuard& gd) {
+    bool bad = false;
+    for (int i = 0; i < gd.nwords; ++i) bad |= *gd.words[i] != 0u;
+    if (gd.reduced != nullptr) bad |= !(*gd.reduced == 0.f);          // (a NaN slot counts as set)
+    return bad;
+}
+// slot = 1 when any of the local words is set, else 0 (one thread: the words are a handful)
+__global__ void sgd_guard_publish_kernel(const SgdGuard gd, float* __restrict__ slot) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        bool bad = false;
+        for (int i = 0; i < gd.nwords; ++i) bad |= *gd.words[i] != 0u;
+        *slot = bad ? 1.f : 0.f;
+    }
+}
 __global__ __launch_bounds__(256) void sgd_hyper_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ buf, int64_t n,
                                                         const float* __restrict__ hyper, int nesterov, int first,
-                                                        const unsigned* __restrict__ fail) {
-    // fail: the sticky failure word of the grid barrier (gridsync.hpp FW_FAIL), or null.  A one-launch kernel whose barrier
-    // gave up has NaN-poisoned its outputs, hence the gradient: the update is SKIPPED while the word is set (one uniform scalar
-    // load), so parameters and momentum survive until ops.check_gridsync reports the failure -- also in captured replays
-    if (fail != nullptr && *fail != 0u) return;
+                                                        const SgdGuard guard) {
+    // guard: sticky failure words (gridsync.hpp FW_FAIL) and the rank-reduced flag.  A one-launch kernel whose barrier
+    // gave up has NaN-poisoned its outputs, hence the gradient: the update is SKIPPED while any of them is set (uniform scalar
+    // loads), so parameters and momentum survive until ops.check_gridsync reports the failure -- also in captured replays
+    if (sgd_guard_set(guard)) return;
     // hyper[4] = gradient scale: 1 / world size when the bucket holds the all-reduce SUM of the ranks' gradients (the mean
     // then never exists as a pass of its own over the bucket); 1 otherwise (x * 1.0f is exact)
     const float lr = hyper[0], mu = hyper[1], damp = hyper[2], wd = hyper[3], gs = hyper[4];
@@ -182,27 +206,60 @@ __global__ __launch_bounds__(256) void sgd_hyper_kernel(float* __restrict__ p, c
 }
 }  // namespace crf
 
-extern "C" int crfconv_sgd_step_hyper(float* param, const float* grad, float* momentum_buf, int64_t n,
-                                      const float* hyper, int nesterov, int first_step, crf_stream_t stream) {
+static int sgd_guard_of(const unsigned* const* fail_words, int nwords, const float* reduced, crf::SgdGuard& gd) {
+    CRF_REQUIRE(nwords >= 0 && nwords <= crf::SGD_MAX_FAIL, CRF_ERR_ARG, "%d failure words (at most %d)", nwords, crf::SGD_MAX_FAIL);
+    CRF_REQUIRE(nwords == 0 || fail_words != nullptr, CRF_ERR_ARG, "null pointer");
+    for (int i = 0; i < crf::SGD_MAX_FAIL; ++i) gd.words[i] = nullptr;
+    for (int i = 0; i < nwords; ++i) {
+        CRF_REQUIRE(fail_words[i] != nullptr, CRF_ERR_ARG, "failure word %d: null pointer", i);
+        gd.words[i] = fail_words[i];
+    }
+    gd.nwords = nwords;
+    gd.reduced = reduced;
+    return CRF_OK;
+}
+
+static int sgd_launch(float* param, const float* grad, float* momentum_buf, int64_t n, const float* hyper, int nesterov,
+                      int first_step, const crf::SgdGuard& gd, crf_stream_t stream) {
     CRF_REQUIRE(param && grad && momentum_buf && hyper, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(n > 0, CRF_ERR_ARG, "n=%lld <= 0", (long long)n);
     int64_t nb = cdiv(n, 256 * 4);
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(crf::sgd_hyper_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), param, grad, momentum_buf,
-                       n, hyper, nesterov, first_step, (const unsigned*)nullptr);
+                       n, hyper, nesterov, first_step, gd);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
+}
+
+extern "C" int crfconv_sgd_step_hyper(float* param, const float* grad, float* momentum_buf, int64_t n,
+                                      const float* hyper, int nesterov, int first_step, crf_stream_t stream) {
+    crf::SgdGuard gd;
+    if (int rc = sgd_guard_of(nullptr, 0, nullptr, gd)) return rc;
+    return sgd_launch(param, grad, momentum_buf, n, hyper, nesterov, first_step, gd, stream);
 }
 
 extern "C" int crfconv_sgd_step_guarded(float* param, const float* grad, float* momentum_buf, int64_t n,
                                         const float* hyper, int nesterov, int first_step, const unsigned* fail_word,
                                         crf_stream_t stream) {
-    CRF_REQUIRE(param && grad && momentum_buf && hyper, CRF_ERR_ARG, "null pointer");
-    CRF_REQUIRE(n > 0, CRF_ERR_ARG, "n=%lld <= 0", (long long)n);
-    int64_t nb = cdiv(n, 256 * 4);
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(crf::sgd_hyper_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), param, grad, momentum_buf,
-                       n, hyper, nesterov, first_step, fail_word);
+    crf::SgdGuard gd;
+    if (int rc = sgd_guard_of(&fail_word, fail_word ? 1 : 0, nullptr, gd)) return rc;
+    return sgd_launch(param, grad, momentum_buf, n, hyper, nesterov, first_step, gd, stream);
+}
+
+extern "C" int crfconv_sgd_step_guarded_all(float* param, const float* grad, float* momentum_buf, int64_t n,
+                                            const float* hyper, int nesterov, int first_step,
+                                            const unsigned* const* fail_words, int n_fail_words, const float* reduced_flag,
+                                            crf_stream_t stream) {
+    crf::SgdGuard gd;
+    if (int rc = sgd_guard_of(fail_words, n_fail_words, reduced_flag, gd)) return rc;
+    return sgd_launch(param, grad, momentum_buf, n, hyper, nesterov, first_step, gd, stream);
+}
+
+extern "C" int crfconv_sgd_guard_publish(const unsigned* const* fail_words, int n_fail_words, float* slot, crf_stream_t stream) {
+    CRF_REQUIRE(slot, CRF_ERR_ARG, "null pointer");
+    crf::SgdGuard gd;
+    if (int rc = sgd_guard_of(fail_words, n_fail_words, nullptr, gd)) return rc;
+    hipLaunchKernelGGL(crf::sgd_guard_publish_kernel, dim3(1), dim3(64), 0, as_stream(stream), gd, slot);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

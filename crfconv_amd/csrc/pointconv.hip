@@ -1424,8 +1424,7 @@ extern "C" int crfconv_pointconv_forward_uv(const float* x, const float* pos_src
     CRF_REQUIRE(workspace_bytes >= sizeof(float) * 2 * d * (size_t)nblk, CRF_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = as_stream(stream);
     float* partial = reinterpret_cast<float*>(workspace);
-    static const bool no_mfma = getenv("CRFCONV_NO_WIDE_MFMA") != nullptr;      // A/B: the vector-ALU pass at every width
-    if (!no_mfma && uvstats_mfma_ok(K, d) && m_tgt < ((int64_t)1 << 27)) {
+    if (uvstats_mfma_ok(K, d) && m_tgt < ((int64_t)1 << 27)) {
         // wide layers, K = 16: layer 2 of a point's sixteen edges on the matrix pipe (pointconv_wide.hip)
         const int64_t room = (int64_t)(workspace_bytes / (sizeof(float) * 2 * d));
         if (int rc = uvstats_mfma_launch(x, pos_src, pos_tgt, idx32, m_tgt, d, A1, b1, W2, slope, mean_rel3, shift, U, V, partial, room, &nblk, ticket, stats, st)) return rc;

@@ -49,7 +49,10 @@ class FlatGradAllReduce:
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        # one slot behind the gradients: the step's failure flag (see publish_guard).  `wire` = what travels in the all-reduce
+        self.wire = torch.zeros(n + 1, dtype=torch.float32, device=self.params[0].device)
+        self.flat = self.wire[:n]
+        self.guard = self.wire[n:]
         self.views = []
         o = 0
         for p in self.params:
@@ -82,21 +85,59 @@ class FlatGradAllReduce:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
+    def publish_guard(self):
+        """guard slot <- 1 when a one-launch kernel of this rank's step gave up at its grid barrier (its outputs, hence this
+        rank's gradient, are NaN-poisoned), else 0.  Runs in front of the all-reduce, which sums the slot with the gradients: the
+        reduced slot is non-zero on EVERY rank when ANY rank failed, and FlatSGD's update kernel skips on it -- all replicas keep
+        their parameters and momentum together (the failed rank's NaN is in everybody's bucket by then).  One tiny launch,
+        capture-safe; a CPU bucket (gloo tests without a GPU) has no barrier words and publishes 0."""
+        if not self.flat.is_cuda:
+            self.guard.zero_()
+            return
+        import ctypes
+        from . import _lib, ops
+        from .graph import ptr, stream_ptr
+        words = ops.fail_word_ptrs(self.flat.device)
+        arr = (ctypes.c_void_p * max(len(words), 1))(*words)
+        _lib.call('crfconv_sgd_guard_publish', ctypes.cast(arr, ctypes.c_void_p), len(words), ptr(self.guard), stream_ptr())
+
+    def _world(self):
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def allreduce_packed(self):
+        """ONE all-reduce (sum) of gradients + guard slot; for a caller that ran pack() and publish_guard() itself (inside its
+        captured graph).  Nothing at world size 1."""
+        if self._world() > 1:
+            dist.all_reduce(self.wire, op=dist.ReduceOp.SUM)
+
     def allreduce_sum(self):
         """pack() + ONE all-reduce (sum) of the flat bucket.  The mean is taken inside the optimizer's kernel:
         ``FlatSGD(bucket, ..., grad_scale=1 / world_size)`` -- no separate pass over the bucket."""
         self.pack()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if self._world() > 1:
+            self.publish_guard()
+            dist.all_reduce(self.wire, op=dist.ReduceOp.SUM)
 
     def allreduce_mean(self):
         self.pack()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(dist.get_world_size())
+        if self._world() > 1:
+            self.publish_guard()
+            dist.all_reduce(self.wire, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())        # (the guard slot keeps its sum: any non-zero value means "skip")
 
 
 def broadcast_parameters(module, src=0):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src)
+    """Rank `src`'s parameters and buffers to every rank: ONE broadcast per dtype (values packed into a flat vector and copied
+    back), not one per tensor (PointConvBig: ~300)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    by_dtype = {}
+    for t in list(module.parameters()) + list(module.buffers()):
+        by_dtype.setdefault(t.dtype, []).append(t.data)
+    for dtype, ts in by_dtype.items():
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        dist.broadcast(flat, src)
+        o = 0
+        for t in ts:
+            t.copy_(flat[o:o + t.numel()].view_as(t))
+            o += t.numel()

@@ -3,7 +3,6 @@
 reference imports (BatchNorm1d kept as ``.batch_norm``, statistics over every leading dim)."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..graph import require_gpu
@@ -18,13 +17,10 @@ class FastBatchNorm1d(nn.Module):
         if x.dim() not in (2, 3):
             raise ValueError('Non supported number of dimensions {}'.format(x.dim()))
         bn = self.batch_norm
-        shape = x.shape
-        use_batch = self.training or bn.running_mean is None
-        if self.training:
-            ops.tick(bn)
-        y = F.batch_norm(x.reshape(-1, shape[-1]), bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                         use_batch, bn.momentum, bn.eps)
-        return y.reshape(shape)
+        if not bn.affine or x.dtype != torch.float32:
+            raise ops._lib.CrfConvError('FastBatchNorm1d: affine float32 BatchNorm only (the kernels of csrc/bn.hip); got affine=%s, %s'
+                                        % (bn.affine, x.dtype))
+        return ops.bn_act(x, bn, self.training)          # statistics over every leading dim, one stats + one apply pass (csrc/bn.hip)
 
 
 class MLP(nn.Module):
@@ -55,9 +51,9 @@ class MLP(nn.Module):
             return ops.bn_act(x, self.bn.batch_norm, self.training, slope, records=records)
         x = ops.linear(x, self.lin.weight, self.lin.bias)
         if self.bn is not None:
-            x = self.bn(x)
+            x = self.bn(x)                                # FastBatchNorm1d: ops.bn_act (raises for what csrc/bn.hip does not take)
         if self.activation is not None:
-            x = self.activation(x)
+            x = self.activation(x)                        # an activation module other than LeakyReLU is the caller's own
         return x
 
 

@@ -7,7 +7,6 @@ reference's.  The variable-degree graph is packed into a padded neighbour table
 with "no neighbour" entries)."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..graph import table_from_edges
@@ -49,7 +48,7 @@ class GuideGaussianCRFConv(nn.Module):
         n = pos.shape[0]
         field = ops.crf_meanfield(ops.run_lin_bn(self.unary, x), ops.run_lin_bn(self.pairwise, y), self.c,
                                   table_from_edges(tgt, src, n, n), self.steps, k0=0)
-        return F.leaky_relu(field)
+        return ops.leaky_relu(field, 0.01)                  # F.leaky_relu's default slope (reference :69)
 
 
 class ContinuousGaussianCRFConv(nn.Module):
@@ -75,4 +74,4 @@ class ContinuousGaussianCRFConv(nn.Module):
         table = table_from_edges(edge_index[0], edge_index[1], n, n)
         field = ops.crf_meanfield(ops.run_lin_bn(self.unary_net, x), ops.run_lin_bn(self.pairwise_net, y), self.c, table,
                                   self.steps, k0=0)
-        return ops.run_lin_bn(self.fusion_net, torch.cat([ops.run_lin_bn(self.mlp, field), y], dim=-1))
+        return ops.run_lin_bn(self.fusion_net, ops.cat2(ops.run_lin_bn(self.mlp, field), y))

@@ -35,6 +35,6 @@ class DiscreteCRFConv(nn.Module):
             edge_index = graph_ops.radius_graph(pos, self.radius, batch, loop=False, max_num_neighbors=self.kernel_size)
         table = table_from_edges(edge_index[1], edge_index[0], n, n)
         G, D, H = self.F.shape
-        fk = f @ self.F.permute(1, 0, 2).reshape(D, G * H)            # f F_g for every kernel g: [N, G * H]
+        fk = ops.linear(f, self.F.permute(0, 2, 1).reshape(G * H, D))  # f F_g for every kernel g: [N, G * H], on the library's products
         w = ops.kernel_weights(fk, self.W.reshape(-1), table, G, H)   # [N, Kp], 0 on missing entries
         return ops.discrete_meanfield(p, -torch.log(p), w, self.C, table, self.steps)

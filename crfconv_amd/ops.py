@@ -86,7 +86,7 @@ class _MeanField(torch.autograd.Function):
             wws = torch.empty(wbytes, dtype=torch.uint8, device=z.device)
             _lib.call('crfconv_linear_wgrad', ptr(A), ptr(B), rows, H, H, ptr(out), None, ptr(wws), wbytes, st)
 
-        if lib.crfconv_meanfield_backward_supported(H, table.K, k0) == 1 and not _OLD_BWD_ENV:
+        if lib.crfconv_meanfield_backward_supported(H, table.K, k0) == 1:
             # T + 1 launches (csrc/crf_bwd.hip): T - 1 reverse walks | one edge pass over all steps + softmax backward |
             # the last reverse walk with the dy scatter and the dP / dQ reduction riding along
             dev = z.device
@@ -166,7 +166,7 @@ class _SpdInverse(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gQ):
         (Q,) = ctx.saved_tensors
-        return -(Q.t() @ gQ @ Q.t())
+        return -_gemm(_gemm(Q, _f32c(gQ), nk=True), Q).t()     # Q^T gQ Q^T = (Q gQ^T Q)^T, both products on the library's tiled kernel
 
 
 class _CrfMatrices(torch.autograd.Function):
@@ -190,6 +190,36 @@ class _CrfMatrices(torch.autograd.Function):
         dc = torch.empty_like(cc)
         _lib.call('crfconv_crf_matrices_backward', ptr(cc), ptr(Q), ptr(gQ), ptr(gP), cc.shape[0], ptr(dc), stream_ptr())
         return dc
+
+
+class _CrfMatricesWide(torch.autograd.Function):
+    """c [H, H] -> Q = (I + c^T c)^-1, P = I - Q for 64 < H <= 512 (the wide stages of the sparse networks): c^T c on the row-reduction
+    kernel, the inverse by crfconv_spd_inverse_wide, the backward dc = -c (T + T^T), T = Q (gQ - gP) Q, on the tiled product.  The
+    only framework ops are element-wise ones on H x H parameter-sized matrices (identity, differences)."""
+
+    @staticmethod
+    def forward(ctx, c):
+        require_gpu(c)
+        cc = _f32c(c)
+        H = cc.shape[0]
+        M = _gemm_tn(cc, cc)
+        M.diagonal().add_(1.0)
+        Q = torch.empty_like(M)
+        _lib.call('crfconv_spd_inverse_wide', ptr(M), H, ptr(Q), stream_ptr())
+        P = Q.neg()
+        P.diagonal().add_(1.0)
+        ctx.save_for_backward(cc, Q)
+        return Q, P
+
+    @staticmethod
+    def backward(ctx, gQ, gP):
+        cc, Q = ctx.saved_tensors
+        if gQ is None and gP is None:
+            return None
+        G = _f32c(gQ) if gP is None else (-_f32c(gP) if gQ is None else _f32c(gQ) - _f32c(gP))
+        T = _gemm(_gemm(Q, G), Q)                          # d M = -Q^T G Q^T; Q is symmetric up to rounding
+        dc = _gemm(cc, T, addend=_gemm(cc, T), nk=True)      # c T + c T^T
+        return dc.neg_()
 
 
 def _ptr_array(tensors):
@@ -284,13 +314,11 @@ def _late_box_ok(box):
     crf_matrices_batched (it has a gradient box), deferred weight gradients are on, and every factor of that batched node is a
     leaf parameter whose gradient the node's late launch can install.  Evaluated by the mean-field nodes AND by the matrices
     node inside one backward pass -- the same inputs, the same answer."""
-    return (box is not None and _DEFER['on'] and not _NO_LATE_CRF_ENV and all(_defer_ok((c, None)) for c in box['cs']))
+    return (box is not None and _DEFER['on'] and all(_defer_ok((c, None)) for c in box['cs']))
 
 
 _CRF_H = (4, 8, 16, 32, 64)
 _CRF_WIDE_H = (128, 256)                    # one point per wavefront (crfconv_wide_*), H x H products as library GEMMs
-_OLD_BWD_ENV = __import__('os').environ.get('CRFCONV_OLD_BWD') is not None     # A/B: the step-by-step backward launches
-_NO_LATE_CRF_ENV = __import__('os').environ.get('CRFCONV_NO_LATE_CRF') is not None      # A/B: dP / dQ and the matrices backward inside the pass
 
 
 _TICKETS = {}
@@ -327,18 +355,16 @@ def _ticket(device):
     return _stream_buf(_TICKETS, device, lambda: torch.zeros(_lib.load().crfconv_ticket_bytes() // 4, dtype=torch.int32, device=device))
 
 
-_NO_PC_TICKET_ENV = __import__('os').environ.get('CRFCONV_NO_PC_TICKET') is not None     # A/B: PointConv's statistic / coefficient sums as launches of their own
 
 
 def _pc_ticket(device):
-    return None if _NO_PC_TICKET_ENV else ptr(_ticket(device))
+    return ptr(_ticket(device))
 
 
-_NO_MLP_TICKET_ENV = __import__('os').environ.get('CRFCONV_NO_MLP_TICKET') is not None   # A/B: the MLP backward's channel part as a launch of its own
 
 
 def _mlp_ticket(device):
-    return None if _NO_MLP_TICKET_ENV else ptr(_ticket(device))
+    return ptr(_ticket(device))
 
 
 class _MeanFieldWide(torch.autograd.Function):
@@ -419,11 +445,9 @@ def crf_meanfield(z, y, c, table, steps, k0=1, matrices=None):
     if H > _CRF_WIDE_H[-1]:
         raise _lib.CrfConvError('mean field: H = %d exceeds the widest kernel (%d)' % (H, _CRF_WIDE_H[-1]))
     if H > _CRF_H[-1]:
-        # Q = (I + c^T c)^-1 and P = I - Q by the library inverse (H x H, once per call); zero-padded channels stay zero
+        # Q = (I + c^T c)^-1 and P = I - Q (H x H, once per call: csrc/linear.hip spd_inverse_wide_kernel); zero-padded channels stay zero
         Hp = _next_supported(H, _CRF_WIDE_H)
-        eye = torch.eye(H, dtype=c.dtype, device=c.device)
-        Q = torch.linalg.inv(eye + c.t() @ c)
-        P = eye - Q
+        Q, P = _CrfMatricesWide.apply(c)
         if Hp != H:
             Q = torch.nn.functional.pad(Q, (0, Hp - H, 0, Hp - H))
             P = torch.nn.functional.pad(P, (0, Hp - H, 0, Hp - H))
@@ -598,7 +622,7 @@ def _param_ret(prm, buf, direct):
     return buf
 
 
-_WGRAD_BATCH_ROWS = int(__import__('os').environ.get('CRFCONV_WGRAD_BATCH_ROWS', 65536))     # A/B: 0 = every partial pass at once
+_WGRAD_BATCH_ROWS = 65536          # partial passes of layers up to this many rows wait for the batched launch (0 / 200 000 rows measured no better)
 
 
 def _defer_weight_grad(g, x, params, has_bias):
@@ -735,7 +759,7 @@ def _flush_pc_wide():
     lib = _lib.load()
     # d = 32 / 64 with K = 16: the whole pass on the matrix pipe, no per-edge tensor (csrc/pointconv_wide.hip) -- one launch per width;
     # its per-workgroup slabs join the batched sums below (dW2: crfconv_reduce_jobs, dA1 | db1: crfconv_reduce_jobs_f64)
-    mfma = [] if _NO_WIDE_MFMA_ENV else [w for w in wide if lib.crfconv_pointconv_wide_params_supported(w['m_tgt'], w['K'], w['d']) == 1]
+    mfma = [w for w in wide if lib.crfconv_pointconv_wide_params_supported(w['m_tgt'], w['K'], w['d']) == 1]
     if mfma:
         wide = [w for w in wide if not any(w is v for v in mfma)]
         jobs, keep_m = [], []
@@ -850,10 +874,9 @@ def _flush_weight_grads():
 
 
 # ------------------------------------------------------------------------------ per-point Linear
-_MFMA_MIN_ROWS = int(__import__('os').environ.get('CRFCONV_MFMA_MIN_ROWS', 12288))      # below this the tiled product (gemm.hip) and the small-MLP nodes; swept on the step: 4096 -> 4.733 ms, 12288 (the 10 240-row level joins the small forms) -> 4.694 ms, 65536 -> 4.736 ms
+_MFMA_MIN_ROWS = 12288      # below this the tiled product (gemm.hip) and the small-MLP nodes; swept on the step: 4096 -> 4.733 ms, 12288 (the 10 240-row level joins the small forms) -> 4.694 ms, 65536 -> 4.736 ms
 
 
-_NO_APPLY_FROM_RECORDS_ENV = __import__('os').environ.get('CRFCONV_NO_APPLY_FROM_RECORDS') is not None      # A/B: coefficient launch + apply launch
 
 
 def _mfma_ok(m, ci, co):
@@ -863,13 +886,13 @@ def _mfma_ok(m, ci, co):
 def _gemm(A, B, bias=None, addend=None, nk=False):
     """A [M, K] @ B (+ bias) (+ addend) on the tiled fp32 MFMA kernel of gemm.hip -- the products the row-streaming kernel of
     linear.hip does not take (coarse levels, wide layers; any widths).  nk: B is [N, K] (the F.linear weight), else [K, N].
-    (Shapes outside the kernel's range -- crfconv_gemm_supported; none occurs in the networks of this package -- and empty operands
-    take the framework's product.)"""
+    Shapes outside the kernel's range (crfconv_gemm_supported: dimensions of 2^24 and more) raise; there is no framework product behind it."""
     M, K = A.shape
     N = B.shape[0] if nk else B.shape[1]
-    if M == 0 or not _lib.load().crfconv_gemm_supported(M, N, K):
-        C = torch.nn.functional.linear(A, B, bias) if nk else (A @ B if bias is None else torch.addmm(bias, A, B))
-        return C if addend is None else C.add_(addend)
+    if M == 0:
+        return A.new_empty((0, N))
+    if not _lib.load().crfconv_gemm_supported(M, N, K):
+        raise _lib.CrfConvError('product %d x %d x %d is outside the tiled kernel\'s range (crfconv_gemm_supported)' % (M, N, K))
     A, B = A.contiguous(), B.contiguous()
     C = torch.empty((M, N), dtype=torch.float32, device=A.device)
     _lib.call('crfconv_gemm', ptr(A), ptr(B), ptr(None if bias is None else bias.contiguous()),
@@ -883,7 +906,7 @@ def _gemm_tn(A, B):
     m, ca = A.shape
     cb = B.shape[1]
     if m == 0:
-        return A.t() @ B
+        return A.new_zeros((ca, cb))
     A, B = A.contiguous(), B.contiguous()
     out = torch.empty((ca, cb), dtype=torch.float32, device=A.device)
     wbytes = _lib.load().crfconv_linear_wgrad_workspace(m, ca, cb)
@@ -963,9 +986,8 @@ def linear(x, W, b=None, want_stats=False):
     """Drop-in for F.linear on [..., Ci] CUDA tensors (CPU tensors are refused: there is no CPU path).  With
     want_stats=True returns (y, records) where `records` feeds bn_act(..., records=records) (empty if unused)."""
     require_gpu(x, W)
-    if x.dtype != torch.float32:
-        y = torch.nn.functional.linear(x, W, b)
-        return (y, None) if want_stats else y
+    if x.dtype != torch.float32 or W.dtype != torch.float32:
+        raise _lib.CrfConvError('linear: float32 only (got %s x %s): the path computes in the reference\'s arithmetic' % (x.dtype, W.dtype))
     shape = x.shape
     out = _Linear.apply(x.reshape(-1, shape[-1]), W, b, want_stats)
     if want_stats:
@@ -1035,13 +1057,8 @@ class _BNAct(torch.autograd.Function):
         g, b = _f32c(gamma), _f32c(beta)
         if use_batch and records is not None:
             # statistics came out of the Linear kernel's epilogue: no pass over x for them
-            if _NO_APPLY_FROM_RECORDS_ENV:
-                _lib.call('crfconv_bn_coef_from_records', ptr(records), m, C, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
-                          float(momentum), float(eps), ptr(coef), stream_ptr())
-                _lib.call('crfconv_bn_apply', ptr(x), m, C, ptr(coef), float(slope), ptr(y), stream_ptr())
-            else:
-                _lib.call('crfconv_bn_apply_from_records', ptr(records), records.shape[0], ptr(x), m, C, ptr(g), ptr(b), ptr(run_mean),
-                          ptr(run_var), float(momentum), float(eps), None, float(slope), ptr(coef), ptr(y), stream_ptr())
+            _lib.call('crfconv_bn_apply_from_records', ptr(records), records.shape[0], ptr(x), m, C, ptr(g), ptr(b), ptr(run_mean),
+                      ptr(run_var), float(momentum), float(eps), None, float(slope), ptr(coef), ptr(y), stream_ptr())
         else:
             nbytes = _lib.load().crfconv_bn_workspace(m, C)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -1081,7 +1098,6 @@ def bn_act(x, bn, training, slope=1.0, records=None):
 
 
 # ------------------------------------------------------------------------------ Linear -> BatchNorm -> LeakyReLU as one op
-_UNFUSED_MLP_ENV = __import__('os').environ.get('CRFCONV_UNFUSED_MLP') is not None      # A/B: separate Linear / BatchNorm ops
 
 
 class _MLPBlock(torch.autograd.Function):
@@ -1103,13 +1119,9 @@ class _MLPBlock(torch.autograd.Function):
         coef = torch.empty(4 * co, dtype=torch.float32, device=x.device)
         g, b = _f32c(gamma), _f32c(beta)
         out = torch.empty_like(y)
-        if _NO_APPLY_FROM_RECORDS_ENV:
-            _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
-                      float(momentum), float(eps), ptr(coef), stream_ptr())
-            _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), stream_ptr())
-        else:                                   # coefficients and apply in one launch (same values)
-            _lib.call('crfconv_bn_apply_from_records', ptr(rec), rec.shape[0], ptr(y), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
-                      float(momentum), float(eps), None, float(slope), ptr(coef), ptr(out), stream_ptr())
+        # coefficients and apply in one launch (same values)
+        _lib.call('crfconv_bn_apply_from_records', ptr(rec), rec.shape[0], ptr(y), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
+                  float(momentum), float(eps), None, float(slope), ptr(coef), ptr(out), stream_ptr())
         ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef)
         ctx.slope = float(slope)
@@ -1136,7 +1148,7 @@ class _MLPBlock(torch.autograd.Function):
         return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, None, None
 
 
-_NO_JOIN_ENV = __import__('os').environ.get('CRFCONV_NO_JOIN_FUSION') is not None      # A/B: bn_apply + add_lrelu as two passes
+_NO_JOIN_ENV = False      # tests: True = lin_out, bn_apply and add_lrelu as separate nodes (the fused nodes must give the same results)
 
 
 class _MLPBlockJoin(torch.autograd.Function):
@@ -1154,13 +1166,8 @@ class _MLPBlockJoin(torch.autograd.Function):
         coef = torch.empty(4 * co, dtype=torch.float32, device=x.device)
         st = stream_ptr()
         out = torch.empty_like(y)
-        if _NO_APPLY_FROM_RECORDS_ENV:
-            _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
-                      ptr(run_var), float(momentum), float(eps), ptr(coef), st)
-            _lib.call('crfconv_bn_apply_add', ptr(y), m, co, ptr(coef), ptr(skip), float(slope), ptr(out), st)
-        else:
-            _lib.call('crfconv_bn_apply_from_records', ptr(rec), rec.shape[0], ptr(y), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)),
-                      ptr(run_mean), ptr(run_var), float(momentum), float(eps), ptr(skip), float(slope), ptr(coef), ptr(out), st)
+        _lib.call('crfconv_bn_apply_from_records', ptr(rec), rec.shape[0], ptr(y), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)),
+                  ptr(run_mean), ptr(run_var), float(momentum), float(eps), ptr(skip), float(slope), ptr(coef), ptr(out), st)
         ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(x, Wc, y, coef, out)
         ctx.slope = float(slope)
@@ -1187,8 +1194,6 @@ class _MLPBlockJoin(torch.autograd.Function):
         return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, gskip, None
 
 
-_NO_DROPOUT_FUSION_ENV = __import__('os').environ.get('CRFCONV_NO_DROPOUT_FUSION') is not None     # A/B: bn_apply + nn.Dropout
-_NO_DROPOUT_LINEAR_ENV = __import__('os').environ.get('CRFCONV_NO_DROPOUT_LINEAR') is not None     # A/B: dropout backward as its own pass
 
 
 class _MLPBlockDropout(torch.autograd.Function):
@@ -1296,7 +1301,6 @@ class _MLPDropoutLinear(torch.autograd.Function):
         return dX, *_mlp_param_rets(ctx.prm, outs, dfr, ws, m, ci, co, coef), None, None, None, None, None, None, None, None, dW2, db2
 
 
-_NO_HEAD_ENV = __import__('os').environ.get('CRFCONV_NO_HEAD_RECOMPUTE') is not None     # A/B: the classifier with stored [m, 4 C] tensors
 
 
 class _HeadRecompute(torch.autograd.Function):
@@ -1388,7 +1392,7 @@ def mlp_dropout_linear(x, W, bn, slope, p, W2, b2, recompute=None):
     """Linear(dropout(lrelu(BatchNorm_train(x W^T), slope), p)) as one node where the fused dropout block and the MFMA Linear
     both apply, else None: _HeadRecompute (no [m, 4 C] tensor is ever stored) for the shapes csrc/head.hip covers, else
     _MLPDropoutLinear.  recompute: None = that choice, False = the stored form, True = insist on the recomputing one."""
-    if _NO_DROPOUT_FUSION_ENV or _NO_DROPOUT_LINEAR_ENV or not (0.0 <= p < 1.0) or bn.num_batches_tracked is None:
+    if not (0.0 <= p < 1.0) or bn.num_batches_tracked is None:
         return None
     m = x.numel() // x.shape[-1]
     ci, co, c2 = x.shape[-1], W.shape[0], W2.shape[0]
@@ -1403,7 +1407,7 @@ def mlp_dropout_linear(x, W, bn, slope, p, W2, b2, recompute=None):
     head_ok = bool(_lib.load().crfconv_head_supported(m, ci, co, c2))
     if recompute and not head_ok:
         return None
-    if head_ok and (recompute or (recompute is None and not _NO_HEAD_ENV)):
+    if head_ok and (recompute or recompute is None):
         node = _HeadRecompute                            # no [m, 4 C] tensor at all
     out = node.apply(x.reshape(-1, ci), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, slope,
                                   p, seed, bn.num_batches_tracked, W2, b2)
@@ -1414,7 +1418,7 @@ def mlp_block_dropout(x, W, bn, slope, p):
     """dropout(lrelu(BatchNorm_train(x W^T), slope), p) as one node where the big-level fused block applies, else None (the
     caller then runs its own MLP and nn.Dropout).  The mask stream is seeded from torch.initial_seed() and advances with the
     BatchNorm's num_batches_tracked -- reproducible under torch.manual_seed, but NOT the draws nn.Dropout would have made."""
-    if _NO_DROPOUT_FUSION_ENV or not (0.0 <= p < 1.0) or bn.num_batches_tracked is None:
+    if not (0.0 <= p < 1.0) or bn.num_batches_tracked is None:
         return None
     m = x.numel() // x.shape[-1]
     ci, co = x.shape[-1], W.shape[0]
@@ -1500,7 +1504,6 @@ def mlp_block_pool(x, W, bn, table, fork=False):
     return (out, x) if fork else out
 
 
-_NO_SMALL_BWD_ENV = __import__('os').environ.get('CRFCONV_NO_SMALL_BWD_FUSION') is not None      # A/B: bn_backward + gemm
 
 
 def _small_bwd(gA, y, coef, W, addend, slope, dgamma, dbeta, need_dx):
@@ -1512,7 +1515,7 @@ def _small_bwd(gA, y, coef, W, addend, slope, dgamma, dbeta, need_dx):
     dev = y.device
     gY = torch.empty_like(y)
     lib = _lib.load()
-    if need_dx and not _NO_SMALL_BWD_ENV and lib.crfconv_mlp_small_backward_supported(m, ci, co) == 1:
+    if need_dx and lib.crfconv_mlp_small_backward_supported(m, ci, co) == 1:
         dX = torch.empty((m, ci), dtype=torch.float32, device=dev)
         nbytes = lib.crfconv_mlp_small_backward_workspace(m, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -1555,16 +1558,8 @@ def _small_fwd(x, Wc, gamma, beta, run_mean, run_var, momentum, eps, slope, skip
     nrec = lib.crfconv_gemm_stat_records(m)
     rec = torch.empty((nrec, co, 4), dtype=torch.float32, device=dev)
     _lib.call('crfconv_gemm_stats', ptr(x), ptr(Wc), m, co, ci, ptr(y), ptr(rec), stream_ptr())
-    if _NO_APPLY_FROM_RECORDS_ENV:
-        _lib.call('crfconv_bn_coef_from_nrecords', ptr(rec), nrec, m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var), float(momentum),
-                  float(eps), ptr(coef), stream_ptr())
-        if skip is None:
-            _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), stream_ptr())
-        else:
-            _lib.call('crfconv_bn_apply_add', ptr(y), m, co, ptr(coef), ptr(skip), float(join_slope), ptr(out), stream_ptr())
-    else:
-        _lib.call('crfconv_bn_apply_from_records', ptr(rec), nrec, ptr(y), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
-                  float(momentum), float(eps), ptr(skip), float(slope if skip is None else join_slope), ptr(coef), ptr(out), stream_ptr())
+    _lib.call('crfconv_bn_apply_from_records', ptr(rec), nrec, ptr(y), m, co, ptr(g), ptr(b), ptr(run_mean), ptr(run_var),
+              float(momentum), float(eps), ptr(skip), float(slope if skip is None else join_slope), ptr(coef), ptr(out), stream_ptr())
     return y, out, coef
 
 
@@ -1624,7 +1619,6 @@ def mlp_block_join(x, W, bn, skip, slope):
     return out.reshape(x.shape[:-1] + (co,))
 
 
-_NO_SMALL_MLP_ENV = __import__('os').environ.get('CRFCONV_NO_SMALL_MLP') is not None      # A/B: vendor GEMM + bn_small at the coarse levels
 _sync_ws = {}
 
 
@@ -1638,7 +1632,7 @@ _small_mlp_disabled = __import__('os').environ.get('CRFCONV_NO_ONE_LAUNCH_MLP') 
 
 
 def _mlp_small_ok(m, ci, co):
-    if _NO_SMALL_MLP_ENV or m >= _MFMA_MIN_ROWS:
+    if m >= _MFMA_MIN_ROWS:
         return False
     lib = _lib.load()
     if not _small_mlp_disabled and lib.crfconv_mlp_small_supported(m, ci, co) == 1:
@@ -1648,18 +1642,32 @@ def _mlp_small_ok(m, ci, co):
     return ci % 4 == 0 and co % 4 == 0 and lib.crfconv_mlp_small_backward_supported(m, ci, co) == 1
 
 
-def check_gridsync(dev=None):
+def fail_word_ptrs(dev):
+    """Device addresses of the sticky barrier-failure words of every barrier workspace of `dev` (at most 8: the kernel-side guard's
+    capacity; the capture buffer and the most recent streams' first)."""
+    want = torch.device(dev).index
+    if want is None:
+        want = torch.cuda.current_device()
+    word = _lib.load().crfconv_gridsync_fail_word()
+    keys = [k for k in _sync_ws if k[0] == want]
+    keys.sort(key=lambda k: 0 if k[1] == 'capture' else 1)
+    return [_sync_ws[k].data_ptr() + 4 * word for k in keys[:8]]
+
+
+def check_gridsync(dev=None, reduced_flag=None):
     """Raises CrfConvError when a one-launch kernel's grid barrier has timed out on `dev` since the last check (its
     workgroups were not all resident -- CU mask, reserved CUs; the launch's outputs were NaN-poisoned).  One 4-byte
-    device read (a synchronisation): FlatSGD.step() calls it every `check_every` eager steps, a loop that replays
-    captured graphs should call it once per epoch / logging interval.  What survives a failure: PARAMETERS and the MOMENTUM
-    buffer -- FlatSGD's update kernel reads the same sticky word and changes nothing while it is set (eager steps and
-    captured replays alike), so every step since the failure was a no-op for them.  What does not: the BatchNorm RUNNING
-    statistics of the layers downstream of the failed launch saw NaN activations in those steps (the failed layer itself
-    skips its update) -- restore the model's buffers from the last checkpoint, or reset them, before going on.  After a
-    failure the one-launch KERNEL is switched off for the rest of the process (the small-MLP nodes go on with a
-    launch-separated forward: tiled product + BatchNorm launches, _small_fwd), so a caller that catches the error and has
-    repaired the buffers can re-run the step."""
+    device read per barrier workspace (a synchronisation): FlatSGD.step() calls it every `check_every` eager steps, a loop that
+    replays captured graphs should call it once per epoch / logging interval.  `reduced_flag`: the guard slot of the gradient bucket
+    (distributed.FlatGradAllReduce.guard) -- under data parallelism it holds the SUM of the ranks' flags after the all-reduce, so
+    every rank raises in the same step, not only the one whose kernel failed (the others would hang in the next collective).
+    What survives a failure: PARAMETERS and the MOMENTUM buffer on every rank -- FlatSGD's update kernel reads the same sticky
+    words and the reduced slot and changes nothing while one is set (eager steps and captured replays alike), so every step
+    since the failure was a no-op for them.  What does not: the BatchNorm RUNNING statistics of the layers downstream of the failed
+    launch saw NaN activations in those steps (the failed layer itself skips its update) -- restore the model's buffers from the
+    last checkpoint, or reset them, before going on.  After a failure the one-launch KERNEL is switched off for the rest of the
+    process (the small-MLP nodes go on with a launch-separated forward: tiled product + BatchNorm launches, _small_fwd), so a
+    caller that catches the error and has repaired the buffers can re-run the step."""
     global _small_mlp_disabled
     word = _lib.load().crfconv_gridsync_fail_word()
     bad = []
@@ -1672,12 +1680,18 @@ def check_gridsync(dev=None):
             if code != 0:
                 ws.zero_()                                    # barrier counts and the flag: a clean slate for the retry
                 bad.append((key, code))
-    if bad:
+    remote = False
+    if reduced_flag is not None and reduced_flag.numel():
+        v = float(reduced_flag.reshape(-1)[0].item())
+        remote = not (v == 0.0)
+        if remote:
+            reduced_flag.zero_()
+    if bad or remote:
         _small_mlp_disabled = True
-        raise _lib.CrfConvError('grid barrier timed out on device(s) %s (code 0x%x): a one-launch kernel could not get all its '
+        where = ('device(s) %s (code 0x%x)' % (sorted({k[0] for k, _ in bad}), bad[0][1])) if bad else 'another rank of the process group'
+        raise _lib.CrfConvError('grid barrier timed out on %s: a one-launch kernel could not get all its '
                                 'workgroups resident; its outputs were poisoned with NaN.  The one-launch MLP path is now '
-                                'disabled for this process (CRFCONV_NO_SMALL_MLP=1 does the same up front).'
-                                % (sorted({k[0] for k, _ in bad}), bad[0][1]))
+                                'disabled for this process (CRFCONV_NO_ONE_LAUNCH_MLP=1 does the same up front).' % where)
 
 
 class _MLPSmall(torch.autograd.Function):
@@ -1720,7 +1734,6 @@ class _MLPSmall(torch.autograd.Function):
         return dX, dW, *(_param_ret(q, o, k) for q, (o, k) in zip(ctx.prm[1:], outs)), None, None, None, None, None, None
 
 
-_NO_CAT_ENV = __import__('os').environ.get('CRFCONV_NO_CAT_FUSION') is not None      # A/B: materialise torch.cat
 
 
 class _MLPBlockCat(torch.autograd.Function):
@@ -1740,13 +1753,8 @@ class _MLPBlockCat(torch.autograd.Function):
         _lib.call('crfconv_linear_forward_cat', ptr(xa), ptr(xb), split, ptr(Wc), None, m, ci, co, ptr(y), ptr(rec), st)
         coef = torch.empty(4 * co, dtype=torch.float32, device=xa.device)
         out = torch.empty_like(y)
-        if _NO_APPLY_FROM_RECORDS_ENV:
-            _lib.call('crfconv_bn_coef_from_records', ptr(rec), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
-                      ptr(run_var), float(momentum), float(eps), ptr(coef), st)
-            _lib.call('crfconv_bn_apply', ptr(y), m, co, ptr(coef), float(slope), ptr(out), st)
-        else:
-            _lib.call('crfconv_bn_apply_from_records', ptr(rec), nrec, ptr(y), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
-                      ptr(run_var), float(momentum), float(eps), None, float(slope), ptr(coef), ptr(out), st)
+        _lib.call('crfconv_bn_apply_from_records', ptr(rec), nrec, ptr(y), m, co, ptr(_f32c(gamma)), ptr(_f32c(beta)), ptr(run_mean),
+                  ptr(run_var), float(momentum), float(eps), None, float(slope), ptr(coef), ptr(out), st)
         ctx.prm = (W, gamma, beta)
         ctx.save_for_backward(xa, xb, Wc, y, coef)
         ctx.slope = float(slope)
@@ -1813,7 +1821,7 @@ def mlp_block_cat(xa, xb, W, bn, training, slope=1.0):
     """lrelu(BatchNorm(cat[xa, xb] W^T), slope): the two-pointer fused block where it applies (training, MFMA-sized rows,
     widths multiples of 4), else torch.cat + the one-operand path.  Returns None when the caller should run its own
     module path (so that non-fusable configurations keep their exact semantics)."""
-    if _NO_CAT_ENV or xa.dim() != xb.dim() or xa.shape[:-1] != xb.shape[:-1]:
+    if xa.dim() != xb.dim() or xa.shape[:-1] != xb.shape[:-1]:
         return None
     ca, cb = xa.shape[-1], xb.shape[-1]
     m = xa.numel() // ca
@@ -1831,7 +1839,7 @@ def mlp_block_cat(xa, xb, W, bn, training, slope=1.0):
 
 def mlp_block_ok(x, W, bias, bn, training):
     """The fused block applies to the training-mode MLPs of the fine levels (MFMA-sized rows, affine BatchNorm, no bias)."""
-    if _UNFUSED_MLP_ENV or not training or bias is not None or x.dtype != torch.float32 or not bn.affine:
+    if not training or bias is not None or x.dtype != torch.float32 or not bn.affine:
         return False
     m = x.numel() // x.shape[-1]
     ci, co = x.shape[-1], W.shape[0]
@@ -1843,7 +1851,7 @@ def mlp_block_ok(x, W, bias, bn, training):
             and _lib.load().crfconv_mlp_backward_supported(m, ci, co) == 1)
 
 
-_NO_FORK_ENV = __import__('os').environ.get('CRFCONV_NO_FORK_FUSION') is not None      # A/B: autograd's own accumulation pass
+_NO_FORK_ENV = False      # tests: True = autograd's own accumulation pass instead of the fork chain
 
 
 def mlp_block(x, W, bn, slope=1.0, fork=False):
@@ -1893,9 +1901,11 @@ def run_lin_bn(seq, x):
         else:
             x = linear(x, lin.weight, lin.bias)
             if bn is not None:
-                x = bn(x)
-            if act is not None:
-                x = torch.nn.functional.leaky_relu(x, slope)
+                if not bn.affine:
+                    raise _lib.CrfConvError('run_lin_bn: affine BatchNorm only (csrc/bn.hip)')
+                x = bn_act(x, bn, seq.training, slope)         # any width: the statistics + apply kernels of csrc/bn.hip
+            elif act is not None:
+                x = _LRelu.apply(x, slope)
         i = j + (act is not None)
     return x
 
@@ -1922,12 +1932,50 @@ class _AddLRelu(torch.autograd.Function):
 
 
 def add_lrelu(a, b, slope=0.01):
-    """leaky_relu(a + b, slope) in one pass (ResNet residual join) on CUDA tensors; shapes the kernel does not take
-    (numel not a multiple of 4, broadcasting, non-float32) run as the two device ops of the framework."""
+    """leaky_relu(a + b, slope) in one pass (ResNet residual join) on float32 CUDA tensors of equal shape (any element count: the
+    flat vectors are padded to the kernel's 16-byte granularity when needed)."""
     require_gpu(a, b)
-    if a.shape != b.shape or a.numel() % 4 or a.numel() == 0 or a.dtype != torch.float32 or b.dtype != torch.float32:
-        return torch.nn.functional.leaky_relu(a + b, slope)
+    if a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise _lib.CrfConvError('add_lrelu: two float32 tensors of one shape (got %s %s, %s %s)' % (tuple(a.shape), a.dtype, tuple(b.shape), b.dtype))
+    if a.numel() == 0:
+        return a.clone()
+    if a.numel() % 4:
+        n, shape = a.numel(), a.shape
+        pad = 4 - n % 4
+        fa, fb = torch.nn.functional.pad(a.reshape(-1), (0, pad)), torch.nn.functional.pad(b.reshape(-1), (0, pad))
+        return _AddLRelu.apply(fa, fb, slope)[:n].reshape(shape)
     return _AddLRelu.apply(a, b, slope)
+
+
+class _LRelu(torch.autograd.Function):
+    """leaky_relu(x, slope) alone (a sparse-network Sequential whose Linear has no BatchNorm): the join kernel with a zero addend
+    would read a second array; this is the backward kernel's mask applied forward (out = x * lrelu'(x))."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        require_gpu(x)
+        x = _f32c(x)
+        n = x.numel()
+        out = torch.empty_like(x)
+        if n % 4 or n == 0:
+            raise _lib.CrfConvError('leaky_relu: element count %d must be a positive multiple of 4' % n)
+        _lib.call('crfconv_add_lrelu_backward', ptr(x), ptr(x), n, float(slope), ptr(out), stream_ptr())
+        ctx.save_for_backward(out)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = _f32c(g)
+        gin = torch.empty_like(out)
+        _lib.call('crfconv_add_lrelu_backward', ptr(g), ptr(out), out.numel(), ctx.slope, ptr(gin), stream_ptr())
+        return gin, None
+
+
+def leaky_relu(x, slope=0.01):
+    """F.leaky_relu(x, slope) on a float32 CUDA tensor (element count a multiple of 4) as one library launch."""
+    return _LRelu.apply(x, slope)
 
 
 # ------------------------------------------------------------------------------ gather / max-pool
@@ -2188,7 +2236,7 @@ class _PointConv(torch.autograd.Function):
         dW2_64 = None
         # the fold of this layer's parameter gradients waits for the end of the backward pass (below): then so can the SUMS of their
         # partial slabs -- one crfconv_reduce_jobs_f64 launch for all PointConv layers instead of two / one per layer
-        late = (not _NO_LATE_SUMS_ENV) and all(_defer_ok((q, None)) for q in (pW1, pg1, pbe1, pW2))
+        late = all(_defer_ok((q, None)) for q in (pW1, pg1, pbe1, pW2))
         if d <= _PC_PARAMS_INKERNEL_MAX_D:
             dW2 = torch.empty(d * d, dtype=torch.float64, device=dev)
             dA1b1 = torch.empty((d, 4), dtype=torch.float64, device=dev)
@@ -2201,7 +2249,7 @@ class _PointConv(torch.autograd.Function):
                 _defer_reduce64(sw.value, True, nb.value, d * d, dW2, (ws,))
                 _defer_reduce64(sa.value, False, nb.value, 4 * d, dA1b1, (ws,))
             dW2_64, dW2 = dW2, torch.empty((d, d), dtype=torch.float32, device=dev)      # cast by the fold kernel below
-        elif late and not _NO_LATE_WIDE_ENV:
+        elif late:
             # wide, edge-poor levels: the WHOLE parameter pass (per-edge dump, g_h2^T h1 partials, g_h1 = g_h2 W2, dA1 | db1 slabs) waits
             # for the end of the backward pass, where the passes of all wide layers go out as a handful of launches (_flush_pc_wide)
             dA1b1 = torch.empty((d, 4), dtype=torch.float64, device=dev)
@@ -2265,10 +2313,7 @@ class _PointConv(torch.autograd.Function):
 
 
 _PC_D = (4, 8, 16, 32, 64, 128)
-_NO_LATE_SUMS_ENV = __import__('os').environ.get('CRFCONV_NO_LATE_SUMS') is not None      # A/B: every slab sum inside its own call
-_NO_LATE_WIDE_ENV = __import__('os').environ.get('CRFCONV_NO_LATE_WIDE') is not None      # A/B: the wide layers' parameter pass inside their own backward
-_NO_WIDE_MFMA_ENV = __import__('os').environ.get('CRFCONV_NO_WIDE_MFMA') is not None      # A/B: d = 32 / 64 through the per-edge dump + GEMM passes as well
-_PC_PARAMS_INKERNEL_MAX_D = int(__import__('os').environ.get('CRFCONV_PC_INKERNEL_D', 16))   # wider: per-edge dump + MFMA reductions
+_PC_PARAMS_INKERNEL_MAX_D = 16          # wider: the matrix-pipe parameter pass (d = 32, 64) / per-edge dump + MFMA reductions (d = 128)
 
 
 def pack_moments(moments):
@@ -2277,7 +2322,7 @@ def pack_moments(moments):
     return torch.cat([mean.reshape(3), cov.reshape(9)]).contiguous()
 
 
-_NO_PREFOLD_ENV = __import__('os').environ.get('CRFCONV_NO_PREFOLD') is not None      # A/B: one fold launch inside every PointConv layer
+_NO_PREFOLD_ENV = False      # tests: True = one fold launch inside every PointConv layer
 
 
 def _bn_state(bn, training, momentum, advance=True):

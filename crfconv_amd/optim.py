@@ -93,16 +93,24 @@ class FlatSGD(torch.optim.Optimizer):
         if not capturing:
             self.push_hyper()
         from . import ops
-        # the update is guarded by the sticky grid-barrier failure word of this stream's barrier workspace: a step whose forward
-        # or backward ran a one-launch kernel that timed out (NaN-poisoned outputs -> NaN gradient) leaves parameters and
-        # momentum untouched, in eager steps and captured replays alike, until check_gridsync reports it
-        ws = ops.gridsync_ws(self.flat.device)
-        fail = ws.data_ptr() + 4 * _lib.load().crfconv_gridsync_fail_word()
-        _lib.call('crfconv_sgd_step_guarded', ptr(self.flat), ptr(self.bucket.flat), ptr(self.buf), self.flat.numel(),
-                  ptr(self._hyper), 1 if g['nesterov'] else 0, 1 if first else 0, fail, stream_ptr())   # zero buffer: mu * 0 + g = g
+        # the update is guarded by EVERY sticky grid-barrier failure word of this device (the stream this step runs on, other
+        # eager streams, the buffer captured graphs use -- an eager step() behind a captured forward / backward sees that one too)
+        # and by the bucket's guard slot, which under data parallelism holds the ranks' REDUCED flag (FlatGradAllReduce.
+        # publish_guard): a step in which a one-launch kernel timed out anywhere (NaN-poisoned outputs -> NaN gradient, summed into
+        # every rank's bucket) leaves parameters and momentum untouched on ALL ranks, in eager steps and captured replays alike,
+        # until check_gridsync reports it
+        import ctypes
+        ops.gridsync_ws(self.flat.device)                    # (creates this stream's words and the capture buffer on first use)
+        words = ops.fail_word_ptrs(self.flat.device)
+        arr = (ctypes.c_void_p * max(len(words), 1))(*words)
+        guard = getattr(self.bucket, 'guard', None)
+        _lib.call('crfconv_sgd_step_guarded_all', ptr(self.flat), ptr(self.bucket.flat), ptr(self.buf), self.flat.numel(),
+                  ptr(self._hyper), 1 if g['nesterov'] else 0, 1 if first else 0, ctypes.cast(arr, ctypes.c_void_p), len(words),
+                  ptr(guard), stream_ptr())   # zero buffer: mu * 0 + g = g
         self.steps += 1
         if not capturing and self.check_every > 0 and self.steps % self.check_every == 0:
-            ops.check_gridsync(self.flat.device)            # raises; the guarded updates since the failure changed nothing
+            # raises on EVERY rank when any rank failed (the reduced slot); the guarded updates since the failure changed nothing
+            ops.check_gridsync(self.flat.device, reduced_flag=getattr(self.bucket, 'guard', None))
         return loss
 
     def state_dict(self):

@@ -570,6 +570,9 @@ int crfconv_bn_coef_from_nrecords(const float* stat_rec, int64_t nrec, int64_t M
 /* Q = M^-1 for the symmetric positive definite M = I + c^T c of a CRF layer (H <= 64; Gauss-Jordan in
  * float64, one workgroup, no host sync -- capturable into a hipGraph, unlike a LAPACK-style inverse). */
 int crfconv_spd_inverse(const float* M, int H, float* Q, crf_stream_t stream);
+/* The same for 64 < H <= 512 (the wide CRF stages of the sparse networks, models/point_conv.py:318-339): Gauss-Jordan without
+ * pivoting on one workgroup, matrix in global memory; M symmetric positive definite (M = I + c^T c), M != Q. */
+int crfconv_spd_inverse_wide(const float* M, int H, float* Q, crf_stream_t stream);
 /* Both loop-invariant matrices of a CRF layer from its compatibility factor c [H, H] (C = c^T c) in one launch:
  *   Q = (I + C)^-1,  P = C Q = I - Q          (continuous_crf_conv_big.py:67-72: (z + m C)(I + C)^-1 = z Q + m P)
  * and the matching backward: dc from dQ / dP (either may be NULL). */
@@ -689,6 +692,16 @@ int crfconv_sgd_step_hyper(float* param, const float* grad, float* momentum_buf,
  * word (it is sticky; captured replays are protected too). */
 int crfconv_sgd_step_guarded(float* param, const float* grad, float* momentum_buf, int64_t n, const float* hyper,
                              int nesterov, int first_step, const unsigned* fail_word, crf_stream_t stream);
+/* The guard over SEVERAL sticky words (fail_words: HOST array of n_fail_words <= 8 device pointers -- every barrier workspace of
+ * the device: eager streams and the captured-graph buffer each have their own) and over reduced_flag (device float, may be NULL):
+ * the slot behind the flat gradient bucket that every rank fills with crfconv_sgd_guard_publish BEFORE the gradient all-reduce and
+ * that the all-reduce sums with the bucket -- non-zero on every rank when any rank's step failed, so all replicas skip together
+ * (the failed rank's NaN gradient is in everybody's bucket by then). */
+int crfconv_sgd_step_guarded_all(float* param, const float* grad, float* momentum_buf, int64_t n, const float* hyper,
+                                 int nesterov, int first_step, const unsigned* const* fail_words, int n_fail_words,
+                                 const float* reduced_flag, crf_stream_t stream);
+/* *slot = 1.0f when any of the words is set, else 0.0f (one tiny launch; capture-safe). */
+int crfconv_sgd_guard_publish(const unsigned* const* fail_words, int n_fail_words, float* slot, crf_stream_t stream);
 
 /* ---- device-side pieces of the collate (datasets/semantic3d_dataset.py:512-528), csrc/collate.hip
  * crfconv_random_subsets: for each level l < nlevels, out[l][0 .. s[l]) (device int64) = a uniformly random subset of

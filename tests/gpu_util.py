@@ -21,25 +21,28 @@ def relerr(a, b):
 
 
 # ---- tolerances tied to MEASURED errors (bounds of 1e-4 ... 2e-4 against measured 1e-7 ... 1e-5 leave 100x slack).
-# tests/golden/tol_baseline.json holds the error every assert_close call measured on an MI355X (recorded by running the GPU suite
-# with CRFCONV_TOL_RECORD=<path>; key = pytest node id :: what # occurrence).  With the baseline present a call must stay within
-# min(its stated bound, 10 x its recorded error) -- and never below 1e-7, the float32 noise floor of a normalised comparison.
+# tests/golden/tol_baseline.json holds the LARGEST error the assert_close calls of one (test, `what`) pair measured on an MI355X.
+# Re-record after adding / renaming tests or `what` strings (one GPU run, then commit the file):
+#     CRFCONV_TOL_RECORD=tests/golden/tol_baseline.json python -m pytest tests -m gpu -q
+# Key = pytest node id :: what (round 5: no occurrence counter -- inserting a call no longer shifts the keys behind it).  With the
+# baseline present a call must stay within min(its stated bound, TOL_FACTOR x the recorded error), never below the float32 noise
+# floor of a normalised comparison: 1e-7, or 16 eps where the recorded run happened to be bit-exact (another summation order, ROCm
+# version or GPU moves such a site off zero legitimately).  A call whose key is missing falls back to its stated bound and WARNS
+# (new or renamed test, pytest started from another rootdir); CRFCONV_TOL_STRICT=1 turns that into a failure.
 _BASELINE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tol_baseline.json')
 _baseline = None
 _recorded = {}
-_current = {'node': '', 'seen': {}}
-TOL_FACTOR, TOL_FLOOR = 10.0, 1e-7
+_current = {'node': ''}
+_warned = set()
+TOL_FACTOR, TOL_FLOOR, TOL_FLOOR_EXACT = 10.0, 1e-7, 16 * 1.1920929e-07
 
 
 def set_current_test(nodeid):
     _current['node'] = nodeid
-    _current['seen'] = {}
 
 
 def _key(what):
-    n = _current['seen'].get(what, 0)
-    _current['seen'][what] = n + 1
-    return '%s::%s#%d' % (_current['node'], what, n)
+    return '%s::%s' % (_current['node'], what)
 
 
 def flush_recorded():
@@ -50,23 +53,40 @@ def flush_recorded():
             json.dump(_recorded, f, indent=0, sort_keys=True)
 
 
+def enforced_bound(key, tol, baseline):
+    """(bound, note) for a call with stated bound `tol`: tightened by the recorded error of its key, if there is one."""
+    if key not in baseline:
+        return tol, None
+    rec = float(baseline[key])
+    tight = max(TOL_FACTOR * rec, TOL_FLOOR_EXACT if rec == 0.0 else TOL_FLOOR)
+    if tight < tol:
+        return tight, ' (= max(%g x the error recorded on MI355X, %.3e, noise floor); stated bound %.1e)' % (TOL_FACTOR, rec, tol)
+    return tol, ''
+
+
 def assert_close(a, b, tol, what=''):
     global _baseline
     e = relerr(a, b)
     key = _key(what)
-    if os.environ.get('CRFCONV_TOL_RECORD'):
-        _recorded[key] = e
-    bound, why = tol, ''
+    recording = bool(os.environ.get('CRFCONV_TOL_RECORD'))
+    if recording:
+        _recorded[key] = max(_recorded.get(key, 0.0), e)
     if _baseline is None:
         try:
             import json
             _baseline = json.load(open(_BASELINE_PATH))
         except (OSError, ValueError):
             _baseline = {}
-    if key in _baseline and not os.environ.get('CRFCONV_TOL_RECORD'):
-        tight = max(TOL_FACTOR * float(_baseline[key]), TOL_FLOOR)
-        if tight < bound:
-            bound, why = tight, ' (= %g x the error recorded on MI355X, %.3e; stated bound %.1e)' % (TOL_FACTOR, _baseline[key], tol)
+    bound, why = (tol, '') if recording else enforced_bound(key, tol, _baseline)
+    if why is None:                                       # no recorded error for this call site
+        why = ''
+        if _baseline and not recording and key not in _warned:
+            _warned.add(key)
+            msg = 'assert_close: no recorded error for %r in tests/golden/tol_baseline.json -- only the stated bound %.1e is enforced' % (key, tol)
+            if os.environ.get('CRFCONV_TOL_STRICT'):
+                raise AssertionError(msg + ' (CRFCONV_TOL_STRICT)')
+            import warnings
+            warnings.warn(msg)
     if os.environ.get('CRFCONV_TEST_REPORT'):             # measured error beside the bound (pytest -s): how much room a bound has
         print('[assert_close] %-44s err %.3e  tol %.1e  enforced %.1e' % (what, e, tol, bound), flush=True)
     assert e <= bound, '%s: max err (rel. to max(1,|ref|)) %.3e > %.1e%s' % (what, e, bound, why)

@@ -219,3 +219,103 @@ def test_bench_self_launch_two_ranks_sharing_the_gpu(tmp_path):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['rccl_ranks_seen'] == 2 and rec['dist_backend'] == 'gloo' and rec['scaling'] == 'weak'
     assert rec['config']['global_batch'] == 4 and rec['value'] > 0 and rec['allreduce_us'] > 0
+
+
+GUARD_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch
+import crfconv_amd
+from crfconv_amd import _lib, distributed as D, ops, optim
+rank, world, local = D.init_from_env()
+dev = torch.device('cuda', local)
+torch.cuda.set_device(dev)
+torch.manual_seed(3)
+net = torch.nn.Linear(9, 17).to(dev)
+D.broadcast_parameters(net)
+bucket = D.FlatGradAllReduce(net)
+opt = optim.FlatSGD(bucket, lr=0.1, momentum=0.9, weight_decay=1e-4, check_every=0, grad_scale=1.0 / world)
+ws = ops.gridsync_ws(dev)
+word = _lib.load().crfconv_gridsync_fail_word()
+def one_step(value):
+    opt.zero_grad()
+    for p in net.parameters():
+        p.grad = torch.full_like(p, value)
+    bucket.allreduce_sum()
+    opt.step()
+one_step(1.0)                                   # a healthy step: momentum is non-zero afterwards
+p0, b0 = opt.flat.clone(), opt.buf.clone()
+if rank == 1:
+    ws[word] = 0x101                            # rank 1's one-launch kernel "timed out": its gradient is NaN
+for _ in range(2):
+    one_step(float('nan') if rank == 1 else 1.0)
+torch.cuda.synchronize()
+kept = bool(torch.equal(opt.flat, p0) and torch.equal(opt.buf, b0))
+raised = False
+try:
+    ops.check_gridsync(dev, reduced_flag=bucket.guard)
+except _lib.CrfConvError:
+    raised = True
+one_step(1.0)                                   # flags cleared on both ranks: the update runs again, from intact state
+torch.cuda.synchronize()
+moved = bool(torch.isfinite(opt.flat).all()) and not torch.equal(opt.flat, p0)
+torch.save({'kept': kept, 'raised': raised, 'moved': moved, 'flat': opt.flat.cpu()}, os.environ['OUT'] + '.%%d' %% rank)
+D.dist.barrier()
+D.dist.destroy_process_group()
+'''
+
+
+def test_a_barrier_failure_on_one_rank_stops_the_update_on_every_rank(tmp_path):
+    """ADVICE r4: the failed rank's NaN gradient is summed into every rank's bucket by the all-reduce, so the guard must be
+    global: the flag travels as one more slot of the bucket (FlatGradAllReduce.publish_guard), every rank's update kernel skips
+    on the reduced slot, and check_gridsync(reduced_flag=...) raises on every rank in the same step."""
+    script = tmp_path / 'worker.py'
+    script.write_text(GUARD_WORKER % ROOT)
+    env = dict(os.environ, OUT=str(tmp_path / 'g'), MASTER_ADDR='127.0.0.1', MASTER_PORT='29547', WORLD_SIZE='2',
+               CRFCONV_DIST_BACKEND='gloo', OMP_NUM_THREADS='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r0, r1 = (torch.load(str(tmp_path / ('g.%d' % r))) for r in range(2))
+    for r in (r0, r1):
+        assert r['kept'] and r['raised'] and r['moved'], r
+    assert torch.equal(r0['flat'], r1['flat'])                  # replicas never diverged
+
+
+def test_an_eager_update_sees_the_failure_word_of_the_captured_graph_buffer():
+    """ADVICE r4: captured kernels poison the 'capture' barrier workspace; an EAGER optimizer.step() behind them reads the
+    current stream's -- the guard now looks at every workspace of the device."""
+    from crfconv_amd import _lib, ops, optim
+    from crfconv_amd.distributed import FlatGradAllReduce
+    dev = torch.device('cuda', 0)
+    net = torch.nn.Linear(5, 7).to(DEV)
+    bucket = FlatGradAllReduce(net)
+    opt = optim.FlatSGD(bucket, lr=0.1, momentum=0.9, check_every=0)
+    ops.gridsync_ws(dev)
+    ops.check_gridsync(dev)
+    cap = ops._sync_ws[(0, 'capture')]
+    word = _lib.load().crfconv_gridsync_fail_word()
+    was = ops._small_mlp_disabled
+    try:
+        bucket.flat.fill_(1.0)
+        opt.step()
+        p0 = opt.flat.clone()
+        cap[word] = 0x102
+        bucket.flat.fill_(float('nan'))
+        opt.step()
+        torch.cuda.synchronize()
+        assert torch.equal(opt.flat, p0)
+        with pytest.raises(_lib.CrfConvError, match='grid barrier timed out'):
+            ops.check_gridsync(dev)
+        bucket.guard.fill_(2.0)                                  # the reduced slot alone stops the update too
+        bucket.flat.fill_(1.0)
+        opt.step()
+        torch.cuda.synchronize()
+        assert torch.equal(opt.flat, p0)
+        with pytest.raises(_lib.CrfConvError, match='another rank'):
+            ops.check_gridsync(dev, reduced_flag=bucket.guard)
+        opt.step()
+        torch.cuda.synchronize()
+        assert not torch.equal(opt.flat, p0)
+    finally:
+        ops._small_mlp_disabled = was

@@ -103,6 +103,11 @@ bucket.zero()
 torch.nn.functional.cross_entropy(net(x[shard]), y[shard]).backward()
 bucket.allreduce_mean()
 torch.save(torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone(), os.environ['OUT'] + '.%%d' %% rank)
+# the failure flag travels with the gradients: rank 1 alone publishes 1, both ranks must see a non-zero slot afterwards
+assert float(bucket.guard) == 0.0 and bucket.wire.numel() == bucket.flat.numel() + 1
+bucket.publish_guard = lambda: bucket.guard.fill_(float(rank))
+bucket.allreduce_sum()
+assert float(bucket.guard) == 1.0, float(bucket.guard)
 if rank == 0:
     ref = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.LeakyReLU(0.1), torch.nn.Linear(16, 5))
     ref.load_state_dict(net.state_dict())
@@ -214,22 +219,34 @@ def test_bench_starts_its_own_ranks_without_a_launcher_environment(monkeypatch):
 
 
 def test_tolerances_are_tied_to_the_recorded_errors(monkeypatch):
-    """tests/gpu_util.assert_close: with an entry in the baseline the enforced bound is min(stated, 10 x recorded, floor 1e-7)."""
+    """tests/gpu_util.assert_close: with an entry in the baseline (key = test :: what, no occurrence counter) the enforced bound is
+    min(stated, max(10 x recorded, noise floor)); the floor is 16 eps where the recorded run was bit-exact; a missing key warns (and
+    fails under CRFCONV_TOL_STRICT)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import gpu_util
     monkeypatch.delenv('CRFCONV_TOL_RECORD', raising=False)
+    monkeypatch.delenv('CRFCONV_TOL_STRICT', raising=False)
     gpu_util.set_current_test('tests/x.py::t')
-    monkeypatch.setattr(gpu_util, '_baseline', {'tests/x.py::t::a#0': 1e-6, 'tests/x.py::t::a#1': 0.0, 'tests/x.py::t::b#0': 1e-3})
+    monkeypatch.setattr(gpu_util, '_baseline', {'tests/x.py::t::a': 1e-6, 'tests/x.py::t::z': 0.0, 'tests/x.py::t::b': 1e-3})
+    monkeypatch.setattr(gpu_util, '_warned', set())
     ref = torch.ones(8)
     gpu_util.assert_close(ref + 5e-6, ref, 1e-4, 'a')        # 5e-6 <= 10 x 1e-6
+    gpu_util.assert_close(ref + 5e-6, ref, 1e-4, 'a')        # a second call of the same site has the same key, the same bound
     with pytest.raises(AssertionError, match='recorded on MI355X'):
-        gpu_util.assert_close(ref + 5e-6, ref, 1e-4, 'a')    # second call of the same site: recorded 0 -> floor 1e-7
+        gpu_util.assert_close(ref + 5e-5, ref, 1e-4, 'a')
+    gpu_util.assert_close(ref + 1e-6, ref, 1e-4, 'z')        # recorded 0: floor 16 eps = 1.9e-6, not 1e-7
+    with pytest.raises(AssertionError, match='recorded on MI355X'):
+        gpu_util.assert_close(ref + 5e-6, ref, 1e-4, 'z')
     gpu_util.assert_close(ref + 5e-5, ref, 1e-4, 'b')        # recorded error above the stated bound: the stated bound rules
     with pytest.raises(AssertionError):
         gpu_util.assert_close(ref + 5e-4, ref, 1e-4, 'b')
-    gpu_util.assert_close(ref + 5e-5, ref, 1e-4, 'unrecorded site')
-    baseline = gpu_util.json.load(open(gpu_util._BASELINE_PATH)) if hasattr(gpu_util, 'json') else __import__('json').load(open(gpu_util._BASELINE_PATH))
-    assert len(baseline) > 2000 and all(v >= 0 for v in baseline.values())
+    with pytest.warns(UserWarning, match='no recorded error'):
+        gpu_util.assert_close(ref + 5e-5, ref, 1e-4, 'unrecorded site')
+    monkeypatch.setenv('CRFCONV_TOL_STRICT', '1')
+    with pytest.raises(AssertionError, match='CRFCONV_TOL_STRICT'):
+        gpu_util.assert_close(ref + 5e-5, ref, 1e-4, 'another unrecorded site')
+    baseline = __import__('json').load(open(gpu_util._BASELINE_PATH))
+    assert len(baseline) > 2000 and all(v >= 0 for v in baseline.values()) and not any(k.rsplit('#', 1)[-1].isdigit() and '#' in k.rsplit('::', 1)[-1][-4:] for k in baseline)
 
 
 def test_dropout_mask_host_twin_is_a_keyed_bernoulli_stream():
