@@ -69,6 +69,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12           # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
 TRAFFIC_FWD, TRAFFIC_BWD = 'r4_meanfield_traffic.json', 'r4_meanfield_bwd_traffic.json'      # PMC passes, sha1-keyed to the kernel sources
 TRAFFIC_STEP, TRAFFIC_PC = 'r4_step_traffic.json', 'r4_pointconv_traffic.json'
+ROCPROF_MF = 'r5_meanfield_rocprof.json'      # rocprofv3 --kernel-trace average durations of the level-0 mean-field kernels, sha1-keyed
 BOX = (8.0, 8.0, 3.0)
 VOX = 0.04
 
@@ -154,6 +155,26 @@ def _measured_traffic(name, config):
         return None, 'no usable measurement (%s)' % type(e).__name__
 
 
+def _rocprof_durations(config):
+    """{'fwd_us', 'bwd_us'}: sums of the rocprofv3 --kernel-trace AVERAGE durations of the level-0 mean-field kernels (committed under
+    profiles/ with the sha1 of the kernel sources, like the PMC traffic): the profiler's own clock beside the HIP-event one of this
+    run -- `frac_rocprof` in the roofline objects.  (None, reason) when the sources changed since or the shape differs."""
+    import hashlib
+    path = os.path.join(ROOT, 'profiles', ROCPROF_MF)
+    try:
+        rec = json.load(open(path))
+        h = hashlib.sha1()
+        for src in rec['source']:
+            h.update(open(os.path.join(ROOT, src), 'rb').read())
+        if h.hexdigest() != rec['source_sha1']:
+            return None, 'stale: %s changed since the kernel trace of %s' % (', '.join(rec['source']), ROCPROF_MF)
+        if any(rec['config'].get(k) != v for k, v in config.items()):
+            return None, 'the kernel trace of %s covers %s only' % (ROCPROF_MF, rec['config'])
+        return rec, 'rocprofv3 --kernel-trace --stats, %s' % rec.get('profile', ROCPROF_MF)
+    except (OSError, KeyError, ValueError) as e:
+        return None, 'no usable kernel trace (%s)' % type(e).__name__
+
+
 def roofline_meanfield(data, dev, H=8, T=3, level=0):
     """CRF mean-field forward of one level alone (level 0 = the kernel the north_star target is stated on), HIP-event timed on
     the stream it is launched on."""
@@ -178,6 +199,11 @@ def roofline_meanfield(data, dev, H=8, T=3, level=0):
            'note': 'isolated synthetic problem, 10 back-to-back launches per event pair: the %.1f MB working set stays resident in '
                    'the 256 MiB Infinity Cache between launches (as it does between the consecutive kernels of the real step, '
                    'whose in-step times agree); peak = the 8 TB/s HBM3E figure' % (alg_bytes / 1e6)}
+    if level == 0:
+        rec, why = _rocprof_durations({'m': m, 'H': H, 'K': K, 'T': T})
+        out['frac_rocprof'] = None if rec is None else alg_bytes / (rec['fwd_us'] * 1e-6) / HBM_PEAK
+        out['rocprof_launch_us'] = None if rec is None else rec['fwd_us']
+        out['frac_rocprof_source'] = why + ' (sum of the three kernels\' average durations; frac = HIP events of this run: the profiler adds ~1 us per dispatch)'
     return out
 
 
@@ -218,14 +244,20 @@ def roofline_meanfield_bwd(data, dev, H=8, T=3, level=0):
     avg, lo = _event_time(launch, per=5)
     alg_bytes = m * (2 * (4 * (K - 1) + 4 * H * (2 * T + 1)) + 4 * K + 4)
     traffic, note = _measured_traffic(TRAFFIC_BWD, {'m': m, 'H': H, 'K': K, 'T': T})
-    return {'bound': 'hbm', 'achieved': alg_bytes / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-            'frac': alg_bytes / avg / HBM_PEAK, 'traffic': traffic, 'traffic_source': note,
-            'kernel': 'crfconv_meanfield_backward level-%d (%d x bwd_rev<chain> + bwd_edge_all + bwd_rev<final>, '
-                      'm=%d, H=%d, K=%d)' % (level, T - 1, m, H, K),
-            'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': avg * 1e6, 'min_launch_us': lo * 1e6}
+    out = {'bound': 'hbm', 'achieved': alg_bytes / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+           'frac': alg_bytes / avg / HBM_PEAK, 'traffic': traffic, 'traffic_source': note,
+           'kernel': 'crfconv_meanfield_backward level-%d (%d x bwd_rev<chain> + bwd_edge_all + bwd_rev<final>, '
+                     'm=%d, H=%d, K=%d)' % (level, T - 1, m, H, K),
+           'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': avg * 1e6, 'min_launch_us': lo * 1e6}
+    if level == 0:
+        rec, why = _rocprof_durations({'m': m, 'H': H, 'K': K, 'T': T})
+        out['frac_rocprof'] = None if rec is None else alg_bytes / (rec['bwd_us'] * 1e-6) / HBM_PEAK
+        out['rocprof_launch_us'] = None if rec is None else rec['bwd_us']
+        out['frac_rocprof_source'] = why
+    return out
 
 
-def roofline_layer(data, dev, T=3, level0=None):
+def roofline_layer(data, dev, T=3, level0=None, backward=True):
     """The mean-field layer AS THE NETWORK RUNS IT: all four decoder levels (deconv1..deconv4: H = 8, 16, 32, 64 on
     m = 163 840 ... 2 560 points at config 2), forward and forward + backward, algorithmic bytes of SURVEY 8(d) summed over the
     levels (81.9 MB forward at config 2) against the summed times.  Each level is timed like `roofline` (isolated problem, HIP
@@ -235,6 +267,12 @@ def roofline_layer(data, dev, T=3, level0=None):
     for level in range(min(4, len(data.multiscale) - 1)):
         H = 8 << level
         f = level0[0] if (level == 0 and level0) else roofline_meanfield(data, dev, H, T, level=level)
+        if not backward:                                  # an inference configuration: the forward layer alone
+            per.append({'level': level, 'H': H, 'm': int(np.prod(data.multiscale[level].pos.shape[:2])), 'fwd_us': f['avg_launch_us'],
+                        'fwd_alg_bytes': f['alg_bytes_per_launch']})
+            tf += f['avg_launch_us'] * 1e-6
+            af += f['alg_bytes_per_launch']
+            continue
         b = level0[1] if (level == 0 and level0) else roofline_meanfield_bwd(data, dev, H, T, level=level)
         if b is None:
             return None
@@ -244,6 +282,10 @@ def roofline_layer(data, dev, T=3, level0=None):
         tb += b['avg_launch_us'] * 1e-6
         af += f['alg_bytes_per_launch']
         ab += b['alg_bytes_per_launch']
+    if not backward:
+        return {'bound': 'hbm', 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'fwd_alg_bytes': af, 'fwd_us': tf * 1e6, 'fwd_frac': af / tf / HBM_PEAK,
+                'achieved': af / tf / 1e9, 'frac': af / tf / HBM_PEAK, 'traffic': None, 'levels': per,
+                'kernel': 'mean-field layer, all %d decoder levels, forward (inference configuration)' % len(per)}
     return {'bound': 'hbm', 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'fwd_alg_bytes': af, 'fwd_us': tf * 1e6, 'fwd_frac': af / tf / HBM_PEAK,
             'fwd_bwd_alg_bytes': af + ab, 'fwd_bwd_us': (tf + tb) * 1e6, 'achieved': (af + ab) / (tf + tb) / 1e9,
             'frac': (af + ab) / (tf + tb) / HBM_PEAK, 'traffic': None, 'levels': per,
@@ -512,7 +554,8 @@ def other_configs(dev, rank=0):
         net = models.PointConvBig(6, C, use_crf=True, steps=T).to(dev).eval()
         with torch.no_grad():
             t = replay_time(lambda: net(data))
-        out[name] = {'points': B * N, 'K': K, 'T': T, 'ms': t * 1e3, 'M_points_per_s': B * N / t / 1e6}
+        out[name] = {'points': B * N, 'K': K, 'T': T, 'ms': t * 1e3, 'M_points_per_s': B * N / t / 1e6,
+                     'roofline_meanfield_layer': _layer_summary(roofline_layer(data, dev, T, backward=False))}
         del net, data
     B, N, K, T, C = 4, 81920, 16, 3, 20
     data = batch(B, N, K, 400)
@@ -529,8 +572,18 @@ def other_configs(dev, rank=0):
         bucket.pack()
         opt.step()
     t = replay_time(step)
-    out['C4 ScanNet-like batch (per-GPU share), training step'] = {'points': B * N, 'K': K, 'T': T, 'ms': t * 1e3, 'M_points_per_s': B * N / t / 1e6}
+    out['C4 ScanNet-like batch (per-GPU share), training step'] = {'points': B * N, 'K': K, 'T': T, 'ms': t * 1e3, 'M_points_per_s': B * N / t / 1e6,
+                                                                      'roofline_meanfield_layer': _layer_summary(roofline_layer(data, dev, T))}
     return out
+
+
+def _layer_summary(r):
+    """The mean-field layer of one configuration against the HBM roofline on SURVEY 8(d)'s algorithmic bytes (C3 31.2 MB, C4 159.9 MB
+    per GPU, C5 824.7 MB / 16 crops = 51.5 MB per crop, forward): every decoder level timed alone with HIP events, as `roofline_layer`."""
+    if r is None:
+        return None
+    keep = ('bound', 'peak', 'unit', 'fwd_alg_bytes', 'fwd_us', 'fwd_frac', 'fwd_bwd_alg_bytes', 'fwd_bwd_us', 'achieved', 'frac', 'kernel')
+    return {k: r[k] for k in keep if k in r}
 
 
 def reference_loop(net, data, cw, steps):
@@ -589,7 +642,8 @@ def main():
     ap.add_argument('--points', type=int, default=40960)
     ap.add_argument('--crf-steps', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--other-configs', action='store_true', help='also time BASELINE configs 3, 4 (per-GPU share) and 5 on this GPU (informational block)')
+    ap.add_argument('--other-configs', action='store_true', help='(default since round 5; kept for old command lines)')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the block that times BASELINE configs 3, 4 (per-GPU share) and 5 on this GPU')
     ap.add_argument('--graph', type=int, default=1, help='capture the training step into a hipGraph (1) or run eagerly (0)')
     ap.add_argument('--sort', default='morton', choices=['morton', 'none'],
                     help="point order emitted by the device collate (kernels are order-agnostic)")
@@ -958,7 +1012,7 @@ def main():
                                 'frac_on_measured_traffic': None if step_traffic is None else step_traffic / (ms_per_step * 1e-3) / HBM_PEAK,
                                 'groups': groups, 'ms_per_step': ms_per_step,
                                 'kernel': 'the whole captured training step (fwd + weighted CE + bwd + SGD), %d parameters' % n_par}
-        if args.other_configs:
+        if world == 1 and not args.no_other_configs:          # every BASELINE config in the line: a few seconds on one GPU
             try:
                 out['other_configs'] = other_configs(dev)
             except Exception as e:

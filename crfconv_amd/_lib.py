@@ -118,6 +118,9 @@ SIGNATURES = {
     'crfconv_split2': (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
     'crfconv_add_i64': (_i, [_vp, _i64, _i64, _vp]),
     'crfconv_mlp_small_backward_supported': (_i, [_i64, _i, _i]),
+    'crfconv_gemm_stats_jobs': (_i, [_vp, _i, _vp]),
+    'crfconv_bn_apply_from_records_jobs': (_i, [_vp, _i, _vp]),
+    'crfconv_mlp_small_backward_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_mlp_small_backward_workspace': (_sz, [_i64, _i]),
     'crfconv_mlp_small_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_gemm_stat_records': (_sz, [_i64]),
@@ -216,6 +219,28 @@ class GemmJob(ctypes.Structure):
     """crf_gemm_job of include/crfconv_amd.h."""
     _fields_ = [('A', ctypes.c_void_p), ('B', ctypes.c_void_p), ('C', ctypes.c_void_p), ('M', ctypes.c_int64), ('N', ctypes.c_int32),
                 ('K', ctypes.c_int32)]
+
+
+class GemmStatsJob(ctypes.Structure):
+    """crf_gemm_stats_job of include/crfconv_amd.h."""
+    _fields_ = [('A', ctypes.c_void_p), ('B', ctypes.c_void_p), ('M', ctypes.c_int64), ('N', ctypes.c_int32), ('K', ctypes.c_int32),
+                ('C', ctypes.c_void_p), ('stat_rec', ctypes.c_void_p)]
+
+
+class BnApplyJob(ctypes.Structure):
+    """crf_bn_apply_job of include/crfconv_amd.h."""
+    _fields_ = [('stat_rec', ctypes.c_void_p), ('nrec', ctypes.c_int64), ('x', ctypes.c_void_p), ('M', ctypes.c_int64), ('C', ctypes.c_int32),
+                ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p), ('run_mean', ctypes.c_void_p), ('run_var', ctypes.c_void_p),
+                ('momentum', ctypes.c_float), ('eps', ctypes.c_float), ('skip', ctypes.c_void_p), ('slope', ctypes.c_float),
+                ('coef', ctypes.c_void_p), ('y', ctypes.c_void_p)]
+
+
+class MlpBwdJob(ctypes.Structure):
+    """crf_mlp_bwd_job of include/crfconv_amd.h."""
+    _fields_ = [('gA', ctypes.c_void_p), ('Y', ctypes.c_void_p), ('coef', ctypes.c_void_p), ('W', ctypes.c_void_p), ('addend', ctypes.c_void_p),
+                ('M', ctypes.c_int64), ('Ci', ctypes.c_int32), ('Co', ctypes.c_int32), ('training', ctypes.c_int32), ('slope', ctypes.c_float),
+                ('gY', ctypes.c_void_p), ('dX', ctypes.c_void_p), ('dgamma', ctypes.c_void_p), ('dbeta', ctypes.c_void_p),
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
 
 
 class Reduce64Job(ctypes.Structure):

@@ -11,6 +11,23 @@
 
 namespace crf {
 
+// A value the whole wavefront agrees on (e.g. an entry of a by-value job table picked by blockIdx), pinned into scalar registers:
+// without the hint the entries of a dynamically indexed kernel-argument array can end up replicated in vector registers.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+template <typename T>
+__device__ __forceinline__ T* uni(T* p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long long uni(long long v) {
+    const unsigned long long a = (unsigned long long)v;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+
 constexpr int WAVE = 64;  // gfx950 wavefront
 
 // ----------------------------------------------------------------------------- errors

@@ -338,6 +338,45 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_jobs_kernel(const GemmJobs t) {
                                                      local % (unsigned)t.tiles_x[j], local / (unsigned)t.tiles_x[j]);
 }
 
+// INDEPENDENT coarse-level MLP blocks in one launch (round 5): the STATS product of each job (crfconv_gemm_stats_jobs) and the PRO
+// product of each job's backward (crfconv_mlp_small_backward_jobs).  A coarse launch is a dependent chain of memory round trips on
+// a grid that covers a fraction of the chip; two blocks whose inputs are both ready -- unary_nn[i] / pairwise_nn[i] of a CRF layer
+// (models/continuous_crf_conv_big.py:56-60), shortcut / lin_in of a strided ResNet block (models/point_conv_big.py:79-88) -- run side
+// by side for the price of the longer one.  Same tiles, same summation order as the one-job launches.
+constexpr int GG_MAX = 4;
+struct GemmStatsJobs {
+    const float* A[GG_MAX]; const float* B[GG_MAX]; float* C[GG_MAX]; float* rec[GG_MAX];
+    int M[GG_MAX], N[GG_MAX], K[GG_MAX], tiles_x[GG_MAX];
+    int tile_base[GG_MAX + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(GM_BLOCK) void gemm_stats_jobs_kernel(const GemmStatsJobs t) {
+    int j = 0;
+    while (j + 1 < t.njobs && t.tile_base[j + 1] <= (int)blockIdx.x) ++j;
+    const unsigned local = blockIdx.x - (unsigned)t.tile_base[j];
+    gemm_tile<1, 1, 2, 2, true, true, false, true>(t.A[j], t.B[j], nullptr, nullptr, t.M[j], t.N[j], t.K[j], t.C[j], GemmPro(), t.rec[j],
+                                                   local % (unsigned)t.tiles_x[j], local / (unsigned)t.tiles_x[j]);
+}
+struct GemmProJobs {
+    const float* A[GG_MAX]; const float* B[GG_MAX]; const float* addend[GG_MAX]; float* C[GG_MAX];
+    GemmPro pro[GG_MAX];
+    int M[GG_MAX], N[GG_MAX], K[GG_MAX], tiles_x[GG_MAX];
+    int tile_base[GG_MAX + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(GM_BLOCK) void gemm_pro_jobs_kernel(const GemmProJobs t) {
+    int j = 0;
+    while (j + 1 < t.njobs && t.tile_base[j + 1] <= (int)blockIdx.x) ++j;
+    const unsigned local = blockIdx.x - (unsigned)t.tile_base[j];
+    GemmPro pro;                                        // the job's entry, pinned into scalar registers
+    pro.Y = uni(t.pro[j].Y); pro.coef = uni(t.pro[j].coef); pro.partial = uni(t.pro[j].partial); pro.ntile = uni(t.pro[j].ntile);
+    pro.training = uni(t.pro[j].training); pro.slope = uni(t.pro[j].slope); pro.inv_m = uni(t.pro[j].inv_m); pro.gY = uni(t.pro[j].gY);
+    pro.dgamma = uni(t.pro[j].dgamma); pro.dbeta = uni(t.pro[j].dbeta);
+    const unsigned tx = (unsigned)uni(t.tiles_x[j]);
+    gemm_tile<1, 1, 2, 2, false, true, true, false>(uni(t.A[j]), uni(t.B[j]), nullptr, uni(t.addend[j]), uni(t.M[j]), uni(t.N[j]), uni(t.K[j]), uni(t.C[j]),
+                                                    pro, nullptr, (unsigned)uni((int)(local % tx)), (unsigned)uni((int)(local / tx)));
+}
+
 }  // namespace crf
 
 namespace crf {
@@ -346,13 +385,13 @@ namespace crf {
 // BT_ROWS rows (g1 = gA lrelu'(a y + b), yh = (y - mean) rstd).  A workgroup = one tile x 64 channels: 16 lanes x 16 bytes per row
 // (whole 256-byte row segments), 16 rows per pass; float32 inside a thread's eight rows, float64 across the 16 row threads.
 constexpr int BT_ROWS = 128, BT_CH = 64, BT_NR = BT_ROWS / 16;
-__global__ __launch_bounds__(256) void bn_bwd_tile_sums_kernel(const float* __restrict__ gA, const float* __restrict__ Y,
-                                                               const float* __restrict__ coef, int M, int K, int tile_rows,
-                                                               float slope, double* __restrict__ partial) {
+__device__ __forceinline__ void bn_bwd_tile_sums_body(const float* __restrict__ gA, const float* __restrict__ Y,
+                                                       const float* __restrict__ coef, int M, int K, int tile_rows,
+                                                       float slope, double* __restrict__ partial, const int bx, const int by) {
     __shared__ float s_red[16][2][BT_CH];
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.y * BT_CH + 4 * cq;
-    const int row0 = blockIdx.x * tile_rows;
+    const int c = by * BT_CH + 4 * cq;
+    const int row0 = bx * tile_rows;
     const int row_end = row0 + tile_rows < M ? row0 + tile_rows : M;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     if (c < K) {
@@ -388,8 +427,27 @@ __global__ __launch_bounds__(256) void bn_bwd_tile_sums_kernel(const float* __re
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) t += (double)s_red[w][which][ch];           // fixed order
-        if (blockIdx.y * BT_CH + ch < K) partial[((int64_t)blockIdx.x * 2 + which) * K + blockIdx.y * BT_CH + ch] = t;
+        if (by * BT_CH + ch < K) partial[((int64_t)bx * 2 + which) * K + by * BT_CH + ch] = t;
     }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_tile_sums_kernel(const float* __restrict__ gA, const float* __restrict__ Y,
+                                                               const float* __restrict__ coef, int M, int K, int tile_rows,
+                                                               float slope, double* __restrict__ partial) {
+    bn_bwd_tile_sums_body(gA, Y, coef, M, K, tile_rows, slope, partial, blockIdx.x, blockIdx.y);
+}
+struct TileSumJobs {
+    const float* gA[GG_MAX]; const float* Y[GG_MAX]; const float* coef[GG_MAX]; double* partial[GG_MAX];
+    int M[GG_MAX], K[GG_MAX], tile_rows[GG_MAX], ntile[GG_MAX];
+    float slope[GG_MAX];
+    int blk_base[GG_MAX + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void bn_bwd_tile_sums_jobs_kernel(const TileSumJobs t) {
+    int j = 0;
+    while (j + 1 < t.njobs && t.blk_base[j + 1] <= (int)blockIdx.x) ++j;
+    const int local = (int)blockIdx.x - t.blk_base[j];
+    bn_bwd_tile_sums_body(t.gA[j], t.Y[j], t.coef[j], t.M[j], t.K[j], t.tile_rows[j], t.slope[j], t.partial[j], local % t.ntile[j], local / t.ntile[j]);
 }
 
 }  // namespace crf
@@ -447,6 +505,54 @@ extern "C" int crfconv_mlp_small_backward(const float* gA, const float* Y, const
     return CRF_OK;
 }
 
+// The backward of up to 4 INDEPENDENT coarse-level MLP blocks (crf_mlp_bwd_job: the arguments of crfconv_mlp_small_backward per
+// block) in TWO launches for all of them: the row-tile sums of every block, then every block's dX product.  Results per block are
+// bit-identical to crfconv_mlp_small_backward's.
+extern "C" int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int njobs, void* stream) {
+    CRF_REQUIRE(jobs && njobs >= 1 && njobs <= crf::GG_MAX, CRF_ERR_ARG, "1 .. %d jobs (got %d)", crf::GG_MAX, njobs);
+    crf::TileSumJobs ts;
+    crf::GemmProJobs gp;
+    int64_t blocks = 0, tiles = 0;
+    for (int j = 0; j <= crf::GG_MAX; ++j) {
+        ts.blk_base[j] = (int)blocks;
+        gp.tile_base[j] = (int)tiles;
+        if (j >= crf::GG_MAX) break;
+        if (j >= njobs) {
+            ts.gA[j] = nullptr; ts.Y[j] = nullptr; ts.coef[j] = nullptr; ts.partial[j] = nullptr; ts.M[j] = 0; ts.K[j] = 4; ts.tile_rows[j] = crf::BT_ROWS;
+            ts.ntile[j] = 1; ts.slope[j] = 1.f;
+            gp.A[j] = nullptr; gp.B[j] = nullptr; gp.addend[j] = nullptr; gp.C[j] = nullptr; gp.pro[j] = crf::GemmPro(); gp.M[j] = 0; gp.N[j] = 4; gp.K[j] = 4;
+            gp.tiles_x[j] = 1;
+            continue;
+        }
+        const crf_mlp_bwd_job& b = jobs[j];
+        CRF_REQUIRE(b.gA && b.Y && b.coef && b.W && b.gY && b.dX && b.dgamma && b.dbeta && b.workspace, CRF_ERR_ARG, "job %d: null pointer", j);
+        CRF_REQUIRE(crfconv_mlp_small_backward_supported(b.M, b.Ci, b.Co), CRF_ERR_UNSUPPORTED,
+                    "job %d: mlp_small_backward %lld x %d -> %d: widths must be multiples of 4, Co <= %d", j, (long long)b.M, b.Ci, b.Co, crf::GM_PRO_MAXK);
+        CRF_REQUIRE(b.workspace_bytes >= crfconv_mlp_small_backward_workspace(b.M, b.Co), CRF_ERR_WORKSPACE, "job %d: workspace too small", j);
+        double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(b.workspace) + 255) & ~(uintptr_t)255);
+        int ntile, tile_rows;
+        bt_plan(b.M, ntile, tile_rows);
+        ts.gA[j] = b.gA; ts.Y[j] = b.Y; ts.coef[j] = b.coef; ts.partial[j] = partial; ts.M[j] = (int)b.M; ts.K[j] = b.Co; ts.tile_rows[j] = tile_rows;
+        ts.ntile[j] = ntile; ts.slope[j] = b.slope;
+        blocks += (int64_t)ntile * ((b.Co + crf::BT_CH - 1) / crf::BT_CH);
+        crf::GemmPro pro;
+        pro.Y = b.Y; pro.coef = b.coef; pro.partial = partial; pro.ntile = ntile; pro.training = b.training; pro.slope = b.slope;
+        pro.inv_m = (float)(1.0 / (double)b.M); pro.gY = b.gY; pro.dgamma = b.dgamma; pro.dbeta = b.dbeta;
+        gp.A[j] = b.gA; gp.B[j] = b.W; gp.addend[j] = b.addend; gp.C[j] = b.dX; gp.pro[j] = pro; gp.M[j] = (int)b.M; gp.N[j] = b.Ci; gp.K[j] = b.Co;
+        gp.tiles_x[j] = (int)((b.M + 31) / 32);
+        tiles += (int64_t)gp.tiles_x[j] * ((b.Ci + 31) / 32);
+        CRF_REQUIRE(tiles < ((int64_t)1 << 31) && blocks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many tiles in one batch");
+    }
+    ts.njobs = njobs;
+    gp.njobs = njobs;
+    hipStream_t st = crf::as_stream(stream);
+    hipLaunchKernelGGL(crf::bn_bwd_tile_sums_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ts);
+    CRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(crf::gemm_pro_jobs_kernel, dim3((unsigned)tiles), dim3(crf::GM_BLOCK), 0, st, gp);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
 extern "C" size_t crfconv_gemm_stat_records(int64_t M) { return M < 1 ? 0 : (size_t)(2 * ((M + 31) / 32)); }
 
 // C [M, N] = A [M, K] B^T (B [N, K]: the F.linear weight) with BatchNorm statistic records of C from the epilogue: stat_rec
@@ -459,6 +565,33 @@ extern "C" int crfconv_gemm_stats(const float* A, const float* B, int64_t M, int
     const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32)), blk(crf::GM_BLOCK);
     hipLaunchKernelGGL((crf::gemm_kernel<1, 1, 2, 2, true, true, false, true>), grid, blk, 0, crf::as_stream(stream), A, B,
                        (const float*)nullptr, (const float*)nullptr, (int)M, N, K, C, crf::GemmPro(), stat_rec);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+// crfconv_gemm_stats for up to 4 independent products in ONE launch: C_j = A_j B_j^T with the statistic records of each C_j.
+extern "C" int crfconv_gemm_stats_jobs(const crf_gemm_stats_job* jobs, int njobs, void* stream) {
+    CRF_REQUIRE(jobs && njobs >= 1 && njobs <= crf::GG_MAX, CRF_ERR_ARG, "1 .. %d jobs (got %d)", crf::GG_MAX, njobs);
+    crf::GemmStatsJobs t;
+    int64_t tiles = 0;
+    for (int j = 0; j <= crf::GG_MAX; ++j) {
+        t.tile_base[j] = (int)tiles;
+        if (j >= crf::GG_MAX) break;
+        if (j >= njobs) {
+            t.A[j] = nullptr; t.B[j] = nullptr; t.C[j] = nullptr; t.rec[j] = nullptr; t.M[j] = 0; t.N[j] = 4; t.K[j] = 4; t.tiles_x[j] = 1;
+            continue;
+        }
+        const crf_gemm_stats_job& b = jobs[j];
+        CRF_REQUIRE(b.A && b.B && b.C && b.stat_rec, CRF_ERR_ARG, "job %d: null pointer", j);
+        CRF_REQUIRE(b.M >= 1 && b.M < ((int64_t)1 << 31) && b.N >= 4 && b.K >= 4 && b.N % 4 == 0 && b.K % 4 == 0, CRF_ERR_UNSUPPORTED,
+                    "job %d: gemm_stats %lld x %d x %d: N and K must be multiples of 4", j, (long long)b.M, b.N, b.K);
+        t.A[j] = b.A; t.B[j] = b.B; t.C[j] = b.C; t.rec[j] = b.stat_rec; t.M[j] = (int)b.M; t.N[j] = b.N; t.K[j] = b.K;
+        t.tiles_x[j] = (int)((b.M + 31) / 32);
+        tiles += (int64_t)t.tiles_x[j] * ((b.N + 31) / 32);
+        CRF_REQUIRE(tiles < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many tiles in one batch");
+    }
+    t.njobs = njobs;
+    hipLaunchKernelGGL(crf::gemm_stats_jobs_kernel, dim3((unsigned)tiles), dim3(crf::GM_BLOCK), 0, crf::as_stream(stream), t);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

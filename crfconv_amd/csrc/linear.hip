@@ -1408,6 +1408,8 @@ __global__ __launch_bounds__(LF_BLOCK) void linear_fwd_kernel(const float* __res
 constexpr int FR_BLOCK = 1024, FR_CH = 16, FR_RL = FR_BLOCK / FR_CH;
 // (device body: `slab` = which 16 channels; write != 0: this caller publishes coef / running statistics.  Threads < FR_CH of a valid
 // channel return with ab = {a, b}; every other thread returns false.)
+template <int FR_UN = 8>      // tuples of a thread in flight at once (nrec <= 1024: two round trips instead of four dependent ones; the
+                               // order a thread visits its tuples in -- hence every sum -- does not depend on it)
 __device__ __forceinline__ bool bn_finalize_records_body(const float* __restrict__ rec, int nrec, int64_t M, int C,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                          float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
@@ -1421,8 +1423,7 @@ __device__ __forceinline__ bool bn_finalize_records_body(const float* __restrict
     // problem in float64)
     const double s0 = rec[(int64_t)cc * 4];
     double S1 = 0.0, S2 = 0.0;
-    constexpr int FR_UN = 8;                                // eight tuples of a thread in flight at once (nrec <= 1024: two
-    for (int r0 = rl; r0 < nrec; r0 += FR_UN * FR_RL) {     // round trips instead of four dependent ones)
+    for (int r0 = rl; r0 < nrec; r0 += FR_UN * FR_RL) {
         float4 v[FR_UN];
 #pragma unroll
         for (int u = 0; u < FR_UN; ++u) {
@@ -1484,18 +1485,17 @@ __global__ __launch_bounds__(FR_BLOCK) void bn_finalize_records_kernel(const flo
 // workgroups of row tile 0 publish them and update the running statistics), then streams y = lrelu(a x + b) over its rows -- 64-byte
 // row pieces, four lanes per row.  The 512-record combine is redundant per row tile (131 KB of L2 reads per workgroup) and buys the
 // ~6 us coefficient launch that used to sit between every Linear and its BatchNorm apply pass.
-template <bool ADD>      // ADD: y = lrelu(a x + b + skip, slope) -- the ResNet join (crfconv_bn_apply_add's arithmetic)
-__global__ __launch_bounds__(FR_BLOCK) void bn_apply_records_kernel(const float* __restrict__ rec, int nrec, int64_t M, int C,
-                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                    float eps, float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                                    float momentum, float* __restrict__ coef, const float* __restrict__ x,
-                                                                    const float* __restrict__ skip, float slope, int rows_per_tile,
-                                                                    float* __restrict__ y) {
+template <bool ADD, int UN = 8>      // ADD: y = lrelu(a x + b + skip, slope) -- the ResNet join (crfconv_bn_apply_add's arithmetic)
+__device__ __forceinline__ void bn_apply_records_body(const float* __restrict__ rec, int nrec, int64_t M, int C,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                      float momentum, float* __restrict__ coef, const float* __restrict__ x,
+                                                      const float* __restrict__ skip, float slope, int rows_per_tile,
+                                                      float* __restrict__ y, const int slab, const int tile) {
     __shared__ float s_ab[2][FR_CH];
     float ab[2];
     // grid = (row tiles, slabs): the workgroups that read the two / four 64-byte pieces of the same 128-byte lines are `tiles` apart in
     // dispatch order, and tiles is a multiple of 8 -- they land on the same XCD, whose L2 then fetches each line from HBM once
-    const int slab = blockIdx.y, tile = blockIdx.x;
     const int q = threadIdx.x & 3, rl = threadIdx.x >> 2;            // 4 channel quads x 256 rows per pass
     const int c = slab * FR_CH + 4 * q;
     const bool cok = c < C;
@@ -1518,7 +1518,7 @@ __global__ __launch_bounds__(FR_BLOCK) void bn_apply_records_kernel(const float*
 #define BN_APPLY_PREFETCH_ 1
 #endif
     if (BN_APPLY_PREFETCH_) request(r0 + rl);
-    if (bn_finalize_records_body(rec, nrec, M, C, gamma, beta, eps, run_mean, run_var, momentum, coef, slab, tile == 0, ab)) {
+    if (bn_finalize_records_body<UN>(rec, nrec, M, C, gamma, beta, eps, run_mean, run_var, momentum, coef, slab, tile == 0, ab)) {
         s_ab[0][threadIdx.x] = ab[0];
         s_ab[1][threadIdx.x] = ab[1];
     }
@@ -1542,6 +1542,43 @@ __global__ __launch_bounds__(FR_BLOCK) void bn_apply_records_kernel(const float*
             *reinterpret_cast<float4*>(y + r * C + c) = o;
         }
     }
+}
+
+template <bool ADD>
+__global__ __launch_bounds__(FR_BLOCK) void bn_apply_records_kernel(const float* __restrict__ rec, int nrec, int64_t M, int C,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    float eps, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                    float momentum, float* __restrict__ coef, const float* __restrict__ x,
+                                                                    const float* __restrict__ skip, float slope, int rows_per_tile,
+                                                                    float* __restrict__ y) {
+    bn_apply_records_body<ADD>(rec, nrec, M, C, gamma, beta, eps, run_mean, run_var, momentum, coef, x, skip, slope, rows_per_tile, y,
+                               blockIdx.y, blockIdx.x);
+}
+// The same for up to 4 independent layers in one launch (crfconv_bn_apply_from_records_jobs): the workgroups of the jobs laid end to end.
+constexpr int BA_MAX = 4;
+struct BnApplyJobs {
+    const float* rec[BA_MAX]; const float* gamma[BA_MAX]; const float* beta[BA_MAX]; float* run_mean[BA_MAX]; float* run_var[BA_MAX];
+    float* coef[BA_MAX]; const float* x[BA_MAX]; const float* skip[BA_MAX]; float* y[BA_MAX];
+    long long M[BA_MAX];
+    int nrec[BA_MAX], C[BA_MAX], rows_per_tile[BA_MAX], tiles[BA_MAX];
+    float eps[BA_MAX], momentum[BA_MAX], slope[BA_MAX];
+    int blk_base[BA_MAX + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(FR_BLOCK) void bn_apply_records_jobs_kernel(const BnApplyJobs t) {
+    int j = 0;
+    while (j + 1 < t.njobs && t.blk_base[j + 1] <= (int)blockIdx.x) ++j;
+    const int local = (int)blockIdx.x - t.blk_base[j];
+    const int tiles = uni(t.tiles[j]);
+    const int tile = uni(local % tiles), slab = uni(local / tiles);
+    const float* rec = uni(t.rec[j]); const float* gamma = uni(t.gamma[j]); const float* beta = uni(t.beta[j]);
+    float* run_mean = uni(t.run_mean[j]); float* run_var = uni(t.run_var[j]); float* coef = uni(t.coef[j]);
+    const float* x = uni(t.x[j]); const float* skip = uni(t.skip[j]); float* y = uni(t.y[j]);
+    const long long M = uni(t.M[j]);
+    const int nrec = uni(t.nrec[j]), C = uni(t.C[j]), rows = uni(t.rows_per_tile[j]);
+    const float eps = uni(t.eps[j]), momentum = uni(t.momentum[j]), slope = uni(t.slope[j]);
+    if (skip != nullptr) bn_apply_records_body<true, 4>(rec, nrec, M, C, gamma, beta, eps, run_mean, run_var, momentum, coef, x, skip, slope, rows, y, slab, tile);
+    else bn_apply_records_body<false, 4>(rec, nrec, M, C, gamma, beta, eps, run_mean, run_var, momentum, coef, x, nullptr, slope, rows, y, slab, tile);
 }
 
 static int lf_blocks(int64_t M) {
@@ -1687,24 +1724,30 @@ extern "C" int crfconv_bn_coef_from_nrecords(const float* stat_rec, int64_t nrec
 
 // crfconv_bn_coef_from_records followed by crfconv_bn_apply (skip == NULL) or crfconv_bn_apply_add (the ResNet join) in ONE launch:
 // identical coef / running statistics / y.  C % 4 == 0.
+// row tiles of one apply launch: ~`wgs` workgroups in all -- one per CU: 116-128 registers x 1024 threads is one workgroup per CU, and
+// every workgroup pays the records' combine (step, one box: 128 workgroups 4.163 ms, 192 4.136, 256 4.136, 320 4.159, 512 4.153); a
+// row tile is a multiple of the 1024 rows one pass covers
+#ifndef BN_APPLY_WGS_
+#define BN_APPLY_WGS_ 256
+#endif
+static void bn_apply_plan(int64_t M, int C, int wgs, int64_t& tiles, int64_t& rows) {
+    const int slabs = (C + crf::FR_CH - 1) / crf::FR_CH;
+    tiles = wgs / slabs;
+    if (tiles < 1) tiles = 1;
+    rows = (M + tiles - 1) / tiles;
+    rows = (rows + 1023) / 1024 * 1024;
+    tiles = (M + rows - 1) / rows;
+    if (tiles > 8) tiles = (tiles + 7) / 8 * 8;          // (tiles past the end of the rows have nothing to apply; see the kernel for the 8)
+}
+
 extern "C" int crfconv_bn_apply_from_records(const float* stat_rec, int64_t nrec, const float* x, int64_t M, int C, const float* gamma,
                                              const float* beta, float* run_mean, float* run_var, float momentum, float eps,
                                              const float* skip, float slope, float* coef, float* y, crf_stream_t stream) {
     CRF_REQUIRE(stat_rec && x && gamma && beta && coef && y, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(M > 0 && C >= 4 && C % 4 == 0 && nrec > 0 && nrec < ((int64_t)1 << 31), CRF_ERR_ARG, "bad shape");
     const int slabs = (C + crf::FR_CH - 1) / crf::FR_CH;
-    // ~BN_APPLY_WGS_ workgroups in all -- one per CU: 116-128 registers x 1024 threads is one workgroup per CU, and every workgroup
-    // pays the records' combine (step, one box: 128 workgroups 4.163 ms, 192 4.136, 256 4.136, 320 4.159, 512 4.153); a row tile is a
-    // multiple of the 1024 rows one pass covers
-#ifndef BN_APPLY_WGS_
-#define BN_APPLY_WGS_ 256
-#endif
-    int64_t tiles = BN_APPLY_WGS_ / slabs;
-    if (tiles < 1) tiles = 1;
-    int64_t rows = (M + tiles - 1) / tiles;
-    rows = (rows + 1023) / 1024 * 1024;
-    tiles = (M + rows - 1) / rows;
-    if (tiles > 8) tiles = (tiles + 7) / 8 * 8;          // (tiles past the end of the rows have nothing to apply; see the kernel for the 8)
+    int64_t tiles, rows;
+    bn_apply_plan(M, C, BN_APPLY_WGS_, tiles, rows);
     const dim3 grid((unsigned)tiles, (unsigned)slabs), blk(crf::FR_BLOCK);
     if (skip != nullptr)
         hipLaunchKernelGGL(crf::bn_apply_records_kernel<true>, grid, blk, 0, crf::as_stream(stream), stat_rec, (int)nrec, M, C, gamma, beta, eps,
@@ -1712,6 +1755,36 @@ extern "C" int crfconv_bn_apply_from_records(const float* stat_rec, int64_t nrec
     else
         hipLaunchKernelGGL(crf::bn_apply_records_kernel<false>, grid, blk, 0, crf::as_stream(stream), stat_rec, (int)nrec, M, C, gamma, beta, eps,
                            run_mean, run_var, momentum, coef, x, skip, slope, (int)rows, y);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_bn_apply_from_records_jobs(const crf_bn_apply_job* jobs, int njobs, crf_stream_t stream) {
+    CRF_REQUIRE(jobs && njobs >= 1 && njobs <= crf::BA_MAX, CRF_ERR_ARG, "1 .. %d jobs (got %d)", crf::BA_MAX, njobs);
+    crf::BnApplyJobs t;
+    int64_t blocks = 0;
+    for (int j = 0; j <= crf::BA_MAX; ++j) {
+        t.blk_base[j] = (int)blocks;
+        if (j >= crf::BA_MAX) break;
+        if (j >= njobs) {
+            t.rec[j] = nullptr; t.gamma[j] = nullptr; t.beta[j] = nullptr; t.run_mean[j] = nullptr; t.run_var[j] = nullptr; t.coef[j] = nullptr;
+            t.x[j] = nullptr; t.skip[j] = nullptr; t.y[j] = nullptr; t.M[j] = 0; t.nrec[j] = 0; t.C[j] = 4; t.rows_per_tile[j] = 1024; t.tiles[j] = 1;
+            t.eps[j] = 0.f; t.momentum[j] = 0.f; t.slope[j] = 1.f;
+            continue;
+        }
+        const crf_bn_apply_job& b = jobs[j];
+        CRF_REQUIRE(b.stat_rec && b.x && b.gamma && b.beta && b.coef && b.y, CRF_ERR_ARG, "job %d: null pointer", j);
+        CRF_REQUIRE(b.M > 0 && b.C >= 4 && b.C % 4 == 0 && b.nrec > 0 && b.nrec < ((int64_t)1 << 31), CRF_ERR_ARG, "job %d: bad shape", j);
+        int64_t tiles, rows;
+        bn_apply_plan(b.M, b.C, BN_APPLY_WGS_ / njobs, tiles, rows);
+        t.rec[j] = b.stat_rec; t.gamma[j] = b.gamma; t.beta[j] = b.beta; t.run_mean[j] = b.run_mean; t.run_var[j] = b.run_var; t.coef[j] = b.coef;
+        t.x[j] = b.x; t.skip[j] = b.skip; t.y[j] = b.y; t.M[j] = (long long)b.M; t.nrec[j] = (int)b.nrec; t.C[j] = b.C; t.rows_per_tile[j] = (int)rows;
+        t.tiles[j] = (int)tiles; t.eps[j] = b.eps; t.momentum[j] = b.momentum; t.slope[j] = b.slope;
+        blocks += tiles * ((b.C + crf::FR_CH - 1) / crf::FR_CH);
+        CRF_REQUIRE(blocks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many workgroups in one batch");
+    }
+    t.njobs = njobs;
+    hipLaunchKernelGGL(crf::bn_apply_records_jobs_kernel, dim3((unsigned)blocks), dim3(crf::FR_BLOCK), 0, crf::as_stream(stream), t);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

@@ -71,6 +71,29 @@ def mlp_fork(mlp, x):
     return mlp(x), x
 
 
+def _group_spec(mlp, x):
+    """(W, BatchNorm1d, slope) of an MLP that the fused training-mode blocks take -- Linear without bias, affine BatchNorm, no or a
+    LeakyReLU activation --, else None."""
+    if not (isinstance(mlp, MLP) and mlp.training and mlp.bn is not None and mlp.lin.bias is None and x.dtype == torch.float32
+            and mlp.bn.batch_norm.affine and (mlp.activation is None or isinstance(mlp.activation, nn.LeakyReLU))):
+        return None
+    return mlp.lin.weight, mlp.bn.batch_norm, (1.0 if mlp.activation is None else mlp.activation.negative_slope)
+
+
+def mlp_group(pairs, shared=False):
+    """[(mlp, x, fork)] -> [mlp(x) or (mlp(x), x_alias)] with all the MLPs in ONE autograd node of two launches each way
+    (ops.mlp_group: coarse-level training blocks whose inputs are all ready), or None when that form does not apply to every member
+    -- the caller then runs them one by one."""
+    blocks = []
+    for mlp, x, fork in pairs:
+        spec = _group_spec(mlp, x)
+        if spec is None:
+            return None
+        require_gpu(x)
+        blocks.append((x, spec[0], spec[1], spec[2], fork))
+    return ops.mlp_group(blocks, shared=shared)
+
+
 def mlp_join(mlp, x, skip, slope=0.01):
     """leaky_relu(mlp(x) + skip, slope) for an MLP without activation -- the tail of a ResNet block
     (models/point_conv_big.py:84-88).  One fused node (BatchNorm + add + LeakyReLU in a single pass) where it applies

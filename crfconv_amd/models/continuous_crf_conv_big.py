@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..graph import table_of
-from .common import MLP, mlp_fork
+from .common import MLP, mlp_fork, mlp_group
 
 
 def _embed(cin, hidden):
@@ -41,10 +41,22 @@ class ContinuousGaussianCRFConv(nn.Module):
         (Q, P) = ((I + c^T c)^-1, I - Q) when the network has computed all its layers' in one launch."""
         B, N, _ = pairwise.shape
         H = self.hidden_channels
-        coarse = self.unary_nn(unary).reshape(-1, H)
-        # `pairwise` feeds pairwise_nn and fusion_nn: the second reads the alias the first hands on (common.mlp_fork)
-        guide, pairwise = mlp_fork(self.pairwise_nn[0], pairwise)
-        guide = self.pairwise_nn[1](guide).reshape(-1, H)
+        # unary_nn (coarse rows) and pairwise_nn (this level's rows) are independent chains of two blocks: where both are coarse-level
+        # launches (latency chains on a fraction of the chip) block i of the one runs beside block i of the other (common.mlp_group)
+        first = mlp_group([(self.unary_nn[0], unary, False), (self.pairwise_nn[0], pairwise, True)])
+        second = None
+        if first is not None:
+            c0, (g0, pairwise) = first
+            second = mlp_group([(self.unary_nn[1], c0, False), (self.pairwise_nn[1], g0, False)])
+            if second is None:
+                coarse, guide = self.unary_nn[1](c0).reshape(-1, H), self.pairwise_nn[1](g0).reshape(-1, H)
+            else:
+                coarse, guide = second[0].reshape(-1, H), second[1].reshape(-1, H)
+        else:
+            coarse = self.unary_nn(unary).reshape(-1, H)
+            # `pairwise` feeds pairwise_nn and fusion_nn: the second reads the alias the first hands on (common.mlp_fork)
+            guide, pairwise = mlp_fork(self.pairwise_nn[0], pairwise)
+            guide = self.pairwise_nn[1](guide).reshape(-1, H)
         z = ops.gather_rows(coarse, table_of(up_idx, unary.shape[1]))                      # up-sample the unary term
         field = ops.crf_meanfield(z, guide, self.c, table_of(neighbor_idx, N), self.steps, k0=1,      # k0 = 1: no self edge
                                   matrices=matrices)

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..graph import table_of
-from .common import MLP, Base, mlp_fork, mlp_join
+from .common import MLP, Base, mlp_fork, mlp_group, mlp_join
 from .continuous_crf_conv_big import ContinuousGaussianCRFConv as CRFConv
 
 WIDTHS = (32, 64, 128, 256, 512)          # channel width of encoder level 0..4 (reference :113)
@@ -93,6 +93,17 @@ class ResNetBBlock(nn.Module):
         strided = not torch.is_tensor(pos)
         skip = None
         sc = self.shortcut
+        grouped = None
+        if isinstance(sc, MLP):
+            # lin_in and the shortcut read the same tensor: at the coarse levels ONE node runs both (two launches each way instead of four)
+            grouped = mlp_group([(self.lin_in, x, True), (sc, x, False)], shared=True)
+        if grouped is not None:
+            (h_in, x), skip = grouped
+            if strided:
+                skip = self.max_pooling(skip, neighbor_idx)
+            y = self.point_conv(h_in, pos, neighbor_idx, prefold=prefold)
+            out = mlp_join(self.lin_out, y, skip, 0.01)
+            return (out, x) if return_input_alias else out
         h_in, x = mlp_fork(self.lin_in, x)                 # x: now the alias whose gradient lin_in's backward adds to its own
         if (strided and self.training and isinstance(sc, MLP) and sc.bn is not None and sc.activation is None
                 and sc.lin.bias is None and x.dtype == torch.float32 and sc.bn.batch_norm.affine):

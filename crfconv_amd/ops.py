@@ -1085,15 +1085,28 @@ class _BNAct(torch.autograd.Function):
 
 def bn_act(x, bn, training, slope=1.0, records=None):
     """FastBatchNorm1d semantics (statistics over every leading dim of x [..., C]) fused with LeakyReLU(slope);
-    `bn` is the torch.nn.BatchNorm1d holding the affine parameters and running statistics."""
+    `bn` is the torch.nn.BatchNorm1d holding the affine parameters and running statistics.  A channel count that is not a
+    multiple of 4 (the kernels' 16-byte granularity; e.g. a 13-class layer) is zero-padded: the pad channels normalise to
+    beta = 0 and are cut off again, the running statistics of the real channels are updated in place."""
     shape = x.shape
     C = shape[-1]
     use_batch = training or bn.running_mean is None
     if training:
         tick(bn)
     mom = 0.1 if bn.momentum is None else bn.momentum
-    y = _BNAct.apply(x.reshape(-1, C), bn.weight, bn.bias, bn.running_mean if (training or not use_batch) else None,
-                     bn.running_var if (training or not use_batch) else None, mom, bn.eps, use_batch, slope, records)
+    keep_stats = training or not use_batch
+    rm, rv = (bn.running_mean, bn.running_var) if keep_stats else (None, None)
+    if C % 4:
+        Cp = (C + 3) // 4 * 4
+        pad = lambda t, v: None if t is None else torch.nn.functional.pad(t, (0, Cp - C), value=v)
+        rmp, rvp = pad(rm, 0.0), pad(rv, 1.0)
+        y = _BNAct.apply(pad(x.reshape(-1, C), 0.0), pad(bn.weight, 1.0), pad(bn.bias, 0.0), rmp, rvp, mom, bn.eps, use_batch, slope, None)
+        if training and rm is not None:
+            with torch.no_grad():
+                rm.copy_(rmp[:C])
+                rv.copy_(rvp[:C])
+        return y[:, :C].reshape(shape)
+    y = _BNAct.apply(x.reshape(-1, C), bn.weight, bn.bias, rm, rv, mom, bn.eps, use_batch, slope, records)
     return y.reshape(shape)
 
 
@@ -1734,6 +1747,144 @@ class _MLPSmall(torch.autograd.Function):
         return dX, dW, *(_param_ret(q, o, k) for q, (o, k) in zip(ctx.prm[1:], outs)), None, None, None, None, None, None
 
 
+
+
+class _MLPSmallGroup(torch.autograd.Function):
+    """n INDEPENDENT coarse-level MLP blocks (each _MLPSmall's arithmetic) as one node: the forward is ONE product launch with the
+    BatchNorm statistic records of every block (crfconv_gemm_stats_jobs) and ONE coefficient + apply launch
+    (crfconv_bn_apply_from_records_jobs), the backward TWO launches for all blocks (crfconv_mlp_small_backward_jobs) -- a coarse launch is
+    a latency chain on a fraction of the chip, so blocks whose inputs are both ready run side by side for the price of the longer one:
+    unary_nn[i] / pairwise_nn[i] of a CRF layer (models/continuous_crf_conv_big.py:56-60), shortcut / lin_in of a strided ResNet block
+    (models/point_conv_big.py:79-88).  Per block: (x, W, gamma, beta, run_mean, run_var, momentum, eps, slope, fork); a block with
+    fork returns (out, x_alias) as _MLPBlock does.  shared: blocks 0 and 1 read the SAME tensor -- their input gradients are summed by
+    one library launch here and returned once (autograd would add them with a framework kernel)."""
+
+    NARG = 10
+
+    @staticmethod
+    def forward(ctx, shared, *args):
+        n = len(args) // _MLPSmallGroup.NARG
+        jobs = [args[i * _MLPSmallGroup.NARG:(i + 1) * _MLPSmallGroup.NARG] for i in range(n)]
+        lib = _lib.load()
+        st = stream_ptr()
+        keep, outs, prm, slopes, forks, tmp = [], [], [], [], [], []
+        gs = (_lib.GemmStatsJob * n)()
+        ba = (_lib.BnApplyJob * n)()
+        for i, (x_in, W, gamma, beta, rm, rv, mom, eps, slope, fork) in enumerate(jobs):
+            x, Wc = x_in.contiguous(), W.contiguous()
+            m, ci = x.shape
+            co = Wc.shape[0]
+            dev = x.device
+            y = torch.empty((m, co), dtype=torch.float32, device=dev)
+            out = torch.empty_like(y)
+            coef = torch.empty(4 * co, dtype=torch.float32, device=dev)
+            nrec = lib.crfconv_gemm_stat_records(m)
+            rec = torch.empty((nrec, co, 4), dtype=torch.float32, device=dev)
+            g, b = _f32c(gamma), _f32c(beta)
+            gs[i] = _lib.GemmStatsJob(x.data_ptr(), Wc.data_ptr(), m, co, ci, y.data_ptr(), rec.data_ptr())
+            ba[i] = _lib.BnApplyJob(rec.data_ptr(), nrec, y.data_ptr(), m, co, g.data_ptr(), b.data_ptr(),
+                                    None if rm is None else rm.data_ptr(), None if rv is None else rv.data_ptr(), float(mom), float(eps),
+                                    None, float(slope), coef.data_ptr(), out.data_ptr())
+            keep += [x, Wc, y, coef]
+            prm.append((W, gamma, beta))
+            slopes.append(float(slope))
+            forks.append(bool(fork))
+            outs.append(out)
+            if fork:
+                outs.append(x_in)
+            tmp.append((rec, g, b))                    # alive until the launches below are queued
+        _lib.call('crfconv_gemm_stats_jobs', ctypes.cast(gs, ctypes.c_void_p), n, st)
+        _lib.call('crfconv_bn_apply_from_records_jobs', ctypes.cast(ba, ctypes.c_void_p), n, st)
+        del tmp
+        ctx.n, ctx.prm, ctx.slopes, ctx.forks, ctx.shared = n, prm, slopes, forks, bool(shared)
+        ctx.save_for_backward(*keep)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        lib = _lib.load()
+        st = stream_ptr()
+        jobs = (_lib.MlpBwdJob * n)()
+        per, gi = [], 0
+        for i in range(n):
+            x, W, y, coef = saved[4 * i:4 * i + 4]
+            m, ci = x.shape
+            co = W.shape[0]
+            dev = x.device
+            gA = grads[gi]
+            gi += 1
+            g_alias = None
+            if ctx.forks[i]:
+                g_alias = grads[gi]
+                gi += 1
+            gA = torch.zeros_like(y) if gA is None else gA.contiguous()
+            need_dx = ctx.needs_input_grad[1 + i * _MLPSmallGroup.NARG]
+            outs = [_param_out(q, (co,), dev) for q in ctx.prm[i][1:]]      # (dgamma, dbeta) targets
+            gY = torch.empty_like(y)
+            dX = torch.empty((m, ci), dtype=torch.float32, device=dev)
+            nbytes = lib.crfconv_mlp_small_backward_workspace(m, co)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            add = None if g_alias is None else _f32c(g_alias).reshape(m, ci)
+            jobs[i] = _lib.MlpBwdJob(gA.data_ptr(), y.data_ptr(), coef.data_ptr(), W.data_ptr(), None if add is None else add.data_ptr(), m, ci, co, 1,
+                                     ctx.slopes[i], gY.data_ptr(), dX.data_ptr(), outs[0][0].data_ptr(), outs[1][0].data_ptr(), ws.data_ptr(), nbytes)
+            per.append((x, W, gY, dX, outs, need_dx, (gA, add, ws)))
+        _lib.call('crfconv_mlp_small_backward_jobs', ctypes.cast(jobs, ctypes.c_void_p), n, st)
+        rets = [None]
+        dxs = [p[3] if p[5] else None for p in per]
+        if ctx.shared and dxs[0] is not None and dxs[1] is not None:
+            tot = torch.empty_like(dxs[0])
+            _lib.call('crfconv_add_lrelu', ptr(dxs[0]), ptr(dxs[1]), tot.numel(), 1.0, ptr(tot), st)
+            dxs[0], dxs[1] = tot, None
+        for i, (x, W, gY, dX, outs, need_dx, _) in enumerate(per):
+            m, ci = x.shape
+            co = W.shape[0]
+            Wp, gp, bp = ctx.prm[i]
+            if _defer_ok((Wp, None)):
+                _defer_weight_grad(gY, x, (Wp, None), False)
+                dW = None
+            else:
+                dW = torch.empty((co, ci), dtype=torch.float32, device=x.device)
+                nb = lib.crfconv_linear_wgrad_workspace(m, co, ci)
+                wsw = torch.empty(nb, dtype=torch.uint8, device=x.device)
+                _lib.call('crfconv_linear_wgrad', ptr(gY), ptr(x), m, co, ci, ptr(dW), None, ptr(wsw), nb, st)
+            rets += [dxs[i], dW, _param_ret(gp, outs[0][0], outs[0][1]), _param_ret(bp, outs[1][0], outs[1][1]), None, None, None, None, None, None]
+        return tuple(rets)
+
+
+def mlp_group(blocks, shared=False):
+    """[(x [.., Ci], W, bn, slope, fork)] -> per block its output (or (out, x_alias) with fork), all blocks in ONE node -- or None when
+    the group form does not apply to every block (training-mode coarse-level blocks: _mlp_small_ok rows, affine float32 BatchNorm with
+    running statistics, widths the two-launch backward takes).  shared: blocks 0 and 1 read the same tensor."""
+    if not (2 <= len(blocks) <= 4):
+        return None
+    lib = _lib.load()
+    args, shapes = [], []
+    for x, W, bn, slope, fork in blocks:
+        ci, co = x.shape[-1], W.shape[0]
+        m = x.numel() // max(ci, 1)
+        if not (x.is_cuda and x.dtype == torch.float32 and W.dtype == torch.float32 and bn.affine and bn.running_mean is not None
+                and m >= 1 and _mlp_small_ok(m, ci, co) and ci % 4 == 0 and co % 4 == 0
+                and lib.crfconv_mlp_small_backward_supported(m, ci, co) == 1):
+            return None
+    for x, W, bn, slope, fork in blocks:
+        tick(bn)
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        use_fork = bool(fork and x.requires_grad and torch.is_grad_enabled() and not _NO_FORK_ENV)
+        args += [x.reshape(-1, x.shape[-1]), W, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, float(slope), use_fork]
+        shapes.append((x.shape, W.shape[0], fork, use_fork))
+    res = list(_MLPSmallGroup.apply(bool(shared), *args))
+    out = []
+    for (xs, co, fork, use_fork), (x, _, _, _, _) in zip(shapes, blocks):
+        o = res.pop(0).reshape(xs[:-1] + (co,))
+        if fork:
+            alias = res.pop(0).reshape(xs) if use_fork else x
+            out.append((o, alias))
+        else:
+            out.append(o)
+    return out
 
 
 class _MLPBlockCat(torch.autograd.Function):

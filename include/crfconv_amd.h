@@ -547,6 +547,24 @@ int crfconv_mlp_small_backward(const float* gA, const float* Y, const float* coe
  * (the Linear + BatchNorm blocks between the one-launch kernel's row limit and the row-streaming forms). */
 size_t crfconv_gemm_stat_records(int64_t M);
 int crfconv_gemm_stats(const float* A, const float* B, int64_t M, int N, int K, float* C, float* stat_rec, crf_stream_t stream);
+/* ---- several INDEPENDENT coarse-level MLP blocks per launch (round 5).  A coarse launch is a chain of dependent memory round trips
+ * on a grid that covers a fraction of the chip, so two blocks whose inputs are both ready -- unary_nn[i] and pairwise_nn[i] of a CRF
+ * layer (models/continuous_crf_conv_big.py:56-60), shortcut and lin_in of a strided ResNet block (models/point_conv_big.py:79-88) --
+ * run side by side for the price of the longer one.  jobs: host arrays of 1 .. 4 entries; per job the same tiles, summation order
+ * and results as the one-block calls above / below.
+ *   crfconv_gemm_stats_jobs              = crfconv_gemm_stats per job, one launch
+ *   crfconv_bn_apply_from_records_jobs   = crfconv_bn_apply_from_records per job, one launch
+ *   crfconv_mlp_small_backward_jobs      = crfconv_mlp_small_backward per job, two launches in all */
+typedef struct { const float* A; const float* B; int64_t M; int N; int K; float* C; float* stat_rec; } crf_gemm_stats_job;
+int crfconv_gemm_stats_jobs(const crf_gemm_stats_job* jobs, int njobs, crf_stream_t stream);
+typedef struct { const float* stat_rec; int64_t nrec; const float* x; int64_t M; int C; const float* gamma; const float* beta;
+                 float* run_mean; float* run_var; float momentum; float eps; const float* skip; float slope; float* coef; float* y;
+} crf_bn_apply_job;
+int crfconv_bn_apply_from_records_jobs(const crf_bn_apply_job* jobs, int njobs, crf_stream_t stream);
+typedef struct { const float* gA; const float* Y; const float* coef; const float* W; const float* addend; int64_t M; int Ci; int Co;
+                 int training; float slope; float* gY; float* dX; float* dgamma; float* dbeta; void* workspace; size_t workspace_bytes;
+} crf_mlp_bwd_job;
+int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int njobs, crf_stream_t stream);
 /* Up to 8 independent products C_j = A_j B_j (B_j [K_j, N_j]; N, K multiples of 4) per launch -- the g_h1 = g_h2 W2 products of all wide
  * PointConv layers of a backward pass; same tiles and summation order as crfconv_gemm on each.  jobs is a host array. */
 typedef struct { const float* A; const float* B; float* C; int64_t M; int N; int K; } crf_gemm_job;

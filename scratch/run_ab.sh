@@ -14,7 +14,7 @@ for rep in 1 2; do
       env:*) pre="${v#env:}" ;;
       *) export CRFCONV_LIB=$GRAFT_REPO_ROOT/scratch/variants/lib_$v.so ;;
     esac
-    env $pre timeout -k 10 300 python3 bench.py --no-cpu-baseline --steps 40 > gpurun_out/ab/$tag.$rep.json 2> gpurun_out/ab/$tag.$rep.err || { echo "$v failed"; tail -3 gpurun_out/ab/$tag.$rep.err | cut -c1-300; continue; }
+    env $pre timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-other-configs --steps 40 > gpurun_out/ab/$tag.$rep.json 2> gpurun_out/ab/$tag.$rep.err || { echo "$v failed"; tail -3 gpurun_out/ab/$tag.$rep.err | cut -c1-300; continue; }
     python3 -c "
 import json,sys; r=json.load(open('gpurun_out/ab/$tag.$rep.json')); print('%-36s rep $rep  ms_per_step %.4f  value %.2f  pipelined %.3f' % ('$v', r['ms_per_step'], r['value'], r['pipelined_ms_per_batch'] or 0))"
   done

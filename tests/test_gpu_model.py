@@ -1575,6 +1575,67 @@ def test_mlp_small_backward_two_launch_form(M, Ci, Co, slope, addend):
     assert torch.equal(ops._small_bwd(gA, y, coef, W, add, slope, dgamma, dbeta, True)[1], dX)       # reproducible
 
 
+@pytest.mark.parametrize('shared', [False, True])
+def test_mlp_group_equals_the_separate_coarse_blocks(shared):
+    """ops.mlp_group (round 5): two / three independent coarse-level Linear + BatchNorm + LeakyReLU blocks as ONE node -- one product
+    launch with statistic records and one apply launch forward, two launches backward -- against the same blocks run one by one
+    (ops.mlp_block: _MLPSmall): outputs, running statistics, input gradients (incl. the fork alias and, shared, the summed gradient of
+    the common input), parameter gradients immediate and deferred."""
+    from crfconv_amd import ops
+    g = torch.Generator().manual_seed(17 + shared)
+    shapes = [(2560, 128, 64, 0.1, True), (2560, 128, 256, 1.0, False)] if shared else [(640, 512, 64, 0.1, False), (2560, 256, 64, 0.1, True), (10240, 32, 32, 1.0, False)]
+    x0 = torch.randn(shapes[0][0], shapes[0][1], generator=g).to(DEV)
+
+    def build():
+        blocks = []
+        for i, (m, ci, co, slope, fork) in enumerate(shapes):
+            x = (x0 if (shared or i == 0) else torch.randn(m, ci, generator=torch.Generator().manual_seed(100 + i)).to(DEV)).clone().requires_grad_(True)
+            lin = torch.nn.Linear(ci, co, bias=False).to(DEV)
+            bn = torch.nn.BatchNorm1d(co).to(DEV).train()
+            with torch.no_grad():
+                lin.weight.copy_(torch.randn(co, ci, generator=torch.Generator().manual_seed(200 + i)) / ci ** 0.5)
+                bn.weight.copy_(torch.rand(co, generator=torch.Generator().manual_seed(300 + i)) + 0.5)
+                bn.bias.copy_(torch.randn(co, generator=torch.Generator().manual_seed(400 + i)))
+            blocks.append([x, lin, bn, slope, fork])
+        if shared:
+            blocks[1][0] = blocks[0][0]
+        return blocks
+
+    def run(blocks, group, defer):
+        gouts = [torch.randn(b[0].shape[0], b[1].out_features, generator=torch.Generator().manual_seed(500 + i)).to(DEV) for i, b in enumerate(blocks)]
+        galias = torch.randn(blocks[0][0].shape if shared else blocks[1][0].shape, generator=torch.Generator().manual_seed(600)).to(DEV)
+        if group:
+            res = ops.mlp_group([(x, lin.weight, bn, slope, fork) for x, lin, bn, slope, fork in blocks], shared=shared)
+            assert res is not None
+        else:
+            res = [ops.mlp_block(x, lin.weight, bn, slope, fork=fork) if fork else ops.mlp_block(x, lin.weight, bn, slope) for x, lin, bn, slope, fork in blocks]
+        loss, outs = 0.0, []
+        for r, b, go in zip(res, blocks, gouts):
+            o, alias = r if b[4] else (r, None)
+            outs.append(o)
+            loss = loss + (o * go).sum()
+            if alias is not None:
+                loss = loss + (alias * galias).sum()
+        with ops.deferred_weight_grads(enabled=defer):
+            loss.backward()
+        xs = [b[0] for b in blocks[:1]] if shared else [b[0] for b in blocks]
+        return outs, [x.grad for x in xs], [(b[1].weight.grad, b[2].weight.grad, b[2].bias.grad, b[2].running_mean.clone(), b[2].running_var.clone()) for b in blocks]
+
+    ref = run(build(), False, False)
+    for defer in (False, True):
+        got = run(build(), True, defer)
+        for i, (a, b) in enumerate(zip(got[0], ref[0])):
+            assert_close(a, b, 2e-6, 'out %d' % i)
+        for i, (a, b) in enumerate(zip(got[1], ref[1])):
+            assert_close(a, b, 1e-5, 'dx %d' % i)
+        for i, (pa, pb) in enumerate(zip(got[2], ref[2])):
+            for name, a, b in zip(('dW', 'dgamma', 'dbeta', 'running_mean', 'running_var'), pa, pb):
+                assert_close(a, b, 1e-5, '%s %d' % (name, i))
+    # the node is used where it should be: strided coarse ResNet blocks and the coarse CRF layers of the network
+    from crfconv_amd import models
+    assert ops.mlp_group([(torch.zeros(163840, 32, device=DEV), torch.zeros(16, 32, device=DEV), torch.nn.BatchNorm1d(16).to(DEV), 0.1, False)] * 2) is None
+
+
 @pytest.mark.parametrize('m,ca,cb', [(2560, 256, 256), (10240, 128, 128), (7, 4, 12), (1, 8, 4)])
 def test_cat2_and_its_backward(m, ca, cb):
     """ops.cat2 (rows.hip) == torch.cat, forward and backward (contiguous gradients), 3-D leading shape kept."""
