@@ -632,6 +632,68 @@ def reference_loop(net, data, cw, steps):
     return out
 
 
+def rehearse(args):
+    """`bench.py --gpus N --rehearse`: the rank plumbing of the N-GPU run WITHOUT a GPU -- every rank joins a gloo group on the CPU
+    (no HIP call: a box allows six processes on its card, an 8-GPU node is not ours to launch on), replicas are broadcast from rank
+    0, K steps of [forward, backward, pack + failure flag, ONE flat all-reduce, update] run on a small CPU network through the SAME
+    FlatGradAllReduce / broadcast_parameters / barrier + MAX-over-ranks timing code the real run uses, and rank 0 prints one JSON
+    line.  What it catches before a multi-GPU lease is spent on it: port / environment propagation of the self-launch, a rank that
+    never joins, unequal replicas, the straggler handling, thread oversubscription (N ranks x host threads).  It measures NOTHING
+    about the kernels or RCCL: no scaling number exists until the driver's SCALE_r*.json has N > 1."""
+    from crfconv_amd import distributed as D
+    rank, world, local = D.init_from_env(use_gpu=False)
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher environment says WORLD_SIZE=%d' % (args.gpus, world))
+    torch.set_num_threads(1)
+    torch.manual_seed(100 + rank)                            # different initial replicas: the broadcast must make them equal
+    net = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.LeakyReLU(0.1), torch.nn.Linear(32, 13))
+    D.broadcast_parameters(net)
+    bucket = D.FlatGradAllReduce(net)
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()
+    g = torch.Generator().manual_seed(7 + rank)
+    x, y = torch.randn(args.points, 6, generator=g), torch.randint(0, 13, (args.points,), generator=g)
+
+    def step():
+        bucket.zero()
+        loss = torch.nn.functional.cross_entropy(net(x), y)
+        loss.backward()
+        bucket.pack()
+        bucket.publish_guard()
+        bucket.allreduce_packed()
+        with torch.no_grad():
+            for p, gview in zip(bucket.params, bucket.views):
+                p.add_(gview, alpha=-1e-2 / world)
+        return loss.detach()
+    for _ in range(args.warmup):
+        step()
+    if grouped:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if grouped:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    spread = torch.zeros(1, dtype=torch.float64)
+    if grouped:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+        lo, hi = flat.clone(), flat.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        spread[0] = float((hi - lo).abs().max())
+    if rank == 0:
+        print(json.dumps({'rehearsal': True, 'metric': 'rank plumbing only (CPU, gloo): NOT a benchmark', 'world': world, 'n_gpus': 0,
+                          'dist_backend': torch.distributed.get_backend() if grouped else None, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': dt / max(args.steps, 1) * 1e3, 'replica_spread': float(spread[0]), 'guard_slot': float(bucket.guard),
+                          'final_loss': float(loss), 'points_per_rank': args.points}))
+    if grouped:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -642,12 +704,15 @@ def main():
     ap.add_argument('--points', type=int, default=40960)
     ap.add_argument('--crf-steps', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rehearse', action='store_true', help='rank plumbing only, on the CPU over gloo (no GPU call, no benchmark): see rehearse()')
     ap.add_argument('--other-configs', action='store_true', help='(default since round 5; kept for old command lines)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the block that times BASELINE configs 3, 4 (per-GPU share) and 5 on this GPU')
     ap.add_argument('--graph', type=int, default=1, help='capture the training step into a hipGraph (1) or run eagerly (0)')
     ap.add_argument('--sort', default='morton', choices=['morton', 'none'],
                     help="point order emitted by the device collate (kernels are order-agnostic)")
     args = ap.parse_args()
+    if args.rehearse:
+        return rehearse(args)
 
     import crfconv_amd
     from crfconv_amd import distributed as D

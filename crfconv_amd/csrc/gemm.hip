@@ -22,6 +22,7 @@
 // gradient gY, formed from (gA, Y) and row-tile sums while it is loaded); jobs (crfconv_gemm_jobs: several independent products in
 // one launch).  bn_bwd_tile_sums_kernel, the PRO form's first launch, lives here too.
 #include "common.hpp"
+#include "wgrad_body.hpp"
 
 #include <cstdlib>
 
@@ -449,6 +450,23 @@ __global__ __launch_bounds__(256) void bn_bwd_tile_sums_jobs_kernel(const TileSu
     const int local = (int)blockIdx.x - t.blk_base[j];
     bn_bwd_tile_sums_body(t.gA[j], t.Y[j], t.coef[j], t.M[j], t.K[j], t.tile_rows[j], t.slope[j], t.partial[j], local % t.ntile[j], local / t.ntile[j]);
 }
+// The same launch carrying SIDE work (round 5): behind the tile-sum workgroups of the chain's blocks -- a few dozen, on a chip of 256
+// CUs -- come the workgroups of pending weight-gradient partial passes (wgrad_body.hpp), which nothing on the backward chain waits
+// for: they used to go out as chip-filling launches of their own at the end of the pass (~0.11 ms per step), now they fill the CUs a
+// coarse launch leaves idle.  Same slabs, same sums.
+static_assert(WG_BLOCK == 256, "the side jobs run in the tile-sum launch's workgroups");
+__global__ __launch_bounds__(256) void bn_bwd_tile_sums_side_kernel(const TileSumJobs t, const WgJobTable w, const int own_blocks) {
+    if ((int)blockIdx.x < own_blocks) {
+        int j = 0;
+        while (j + 1 < t.njobs && t.blk_base[j + 1] <= (int)blockIdx.x) ++j;
+        const int local = (int)blockIdx.x - t.blk_base[j];
+        bn_bwd_tile_sums_body(t.gA[j], t.Y[j], t.coef[j], t.M[j], t.K[j], t.tile_rows[j], t.slope[j], t.partial[j], local % t.ntile[j], local / t.ntile[j]);
+        return;
+    }
+    __shared__ float s_red[WG_WAVES * 4 * 4 * 256];
+    __shared__ float s_b[WG_WAVES * 4 * 16];
+    wgrad_any_run(w, (int)blockIdx.x - own_blocks, s_red, s_b);
+}
 
 }  // namespace crf
 
@@ -508,8 +526,17 @@ extern "C" int crfconv_mlp_small_backward(const float* gA, const float* Y, const
 // The backward of up to 4 INDEPENDENT coarse-level MLP blocks (crf_mlp_bwd_job: the arguments of crfconv_mlp_small_backward per
 // block) in TWO launches for all of them: the row-tile sums of every block, then every block's dX product.  Results per block are
 // bit-identical to crfconv_mlp_small_backward's.
-extern "C" int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int njobs, void* stream) {
+extern "C" int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int njobs, const crf_wgrad_job* side, int n_side, void* stream) {
     CRF_REQUIRE(jobs && njobs >= 1 && njobs <= crf::GG_MAX, CRF_ERR_ARG, "1 .. %d jobs (got %d)", crf::GG_MAX, njobs);
+    CRF_REQUIRE(n_side >= 0 && n_side <= crf::WJ_MAX && (n_side == 0 || side != nullptr), CRF_ERR_ARG, "0 .. %d side jobs (got %d)", crf::WJ_MAX, n_side);
+    for (int j = 0; j < n_side; ++j) {
+        const crf_wgrad_job& jb = side[j];
+        CRF_REQUIRE(jb.G && jb.X && jb.workspace, CRF_ERR_ARG, "side job %d: null pointer", j);
+        CRF_REQUIRE(jb.M > 0 && jb.M < ((int64_t)1 << 31) && jb.Co > 0 && jb.Ci > 0 && jb.Co <= 4096 && jb.Ci <= 4096, CRF_ERR_ARG,
+                    "side job %d: bad shape M=%lld Co=%d Ci=%d", j, (long long)jb.M, jb.Co, jb.Ci);
+        CRF_REQUIRE((reinterpret_cast<uintptr_t>(jb.workspace) & 255) == 0, CRF_ERR_ARG, "side job %d: workspace must be 256-byte aligned", j);
+        CRF_REQUIRE(jb.workspace_bytes >= crfconv_linear_wgrad_workspace(jb.M, jb.Co, jb.Ci), CRF_ERR_WORKSPACE, "side job %d: workspace too small", j);
+    }
     crf::TileSumJobs ts;
     crf::GemmProJobs gp;
     int64_t blocks = 0, tiles = 0;
@@ -546,7 +573,15 @@ extern "C" int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int 
     ts.njobs = njobs;
     gp.njobs = njobs;
     hipStream_t st = crf::as_stream(stream);
-    hipLaunchKernelGGL(crf::bn_bwd_tile_sums_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ts);
+    if (n_side > 0) {
+        crf::WgJobTable wt;
+        int64_t side_blocks = 0;
+        crf::wg_fill_table(side, n_side, wt, side_blocks);
+        CRF_REQUIRE(blocks + side_blocks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many workgroups in one batch");
+        hipLaunchKernelGGL(crf::bn_bwd_tile_sums_side_kernel, dim3((unsigned)(blocks + side_blocks)), dim3(256), 0, st, ts, wt, (int)blocks);
+    } else {
+        hipLaunchKernelGGL(crf::bn_bwd_tile_sums_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ts);
+    }
     CRF_LAUNCH_CHECK();
     hipLaunchKernelGGL(crf::gemm_pro_jobs_kernel, dim3((unsigned)tiles), dim3(crf::GM_BLOCK), 0, st, gp);
     CRF_LAUNCH_CHECK();

@@ -13,101 +13,11 @@
 // are summed in a fixed order by a second kernel (bitwise reproducible, no float atomics).
 #include "common.hpp"
 #include "gridsync.hpp"
+#include "wgrad_body.hpp"
 
 #include <cstdlib>
 
 namespace crf {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int WG_BLOCK = 256;
-constexpr int WG_WAVES = WG_BLOCK / WAVE;
-
-// TCO x TCI tiles of 16x16 per block (output slab 16*TCO x 16*TCI at (co0, ci0) = blockIdx.y / z).
-template <int TCO, int TCI>
-__device__ __forceinline__ void wgrad_body(const float* __restrict__ G, const float* __restrict__ X, int64_t M, int Co, int Ci,
-                                           int rows_per_block, float* __restrict__ partial /*[nblk][Co][Ci]*/,
-                                           float* __restrict__ partial_b /*[nblk][Co] or null*/, int bx, int by, int bz,
-                                           float* __restrict__ s_red_ /*[waves][TCO TCI 256]*/, float* __restrict__ s_b_ /*[waves][16 TCO]*/) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int co_base = by * 16 * TCO, ci_base = bz * 16 * TCI;
-    const int kk = lane >> 4, cc = lane & 15;
-    f32x4 acc[TCO][TCI];
-#pragma unroll
-    for (int a = 0; a < TCO; ++a)
-#pragma unroll
-        for (int b = 0; b < TCI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum[TCO];
-#pragma unroll
-    for (int a = 0; a < TCO; ++a) bsum[a] = 0.f;
-
-    const int64_t row_begin = (int64_t)bx * rows_per_block;
-    const int64_t row_end = row_begin + rows_per_block < M ? row_begin + rows_per_block : M;
-    // waves interleave 16-row groups (4 k-steps) inside the block's slice; all operand loads of a group are issued
-    // before its MFMAs, so each lane keeps 4 (TCO + TCI) dword loads in flight
-    for (int64_t r0 = row_begin + 16 * wave; r0 < row_end; r0 += 16 * WG_WAVES) {
-        float av[4][TCO], bv[4][TCI];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t r = r0 + 4 * u + kk;
-            const bool rv = r < row_end;
-#pragma unroll
-            for (int a = 0; a < TCO; ++a) {
-                const int co = co_base + 16 * a + cc;
-                av[u][a] = (rv && co < Co) ? G[r * Co + co] : 0.f;
-            }
-#pragma unroll
-            for (int b = 0; b < TCI; ++b) {
-                const int ci = ci_base + 16 * b + cc;
-                bv[u][b] = (rv && ci < Ci) ? X[r * Ci + ci] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int a = 0; a < TCO; ++a) {
-                bsum[a] += av[u][a];
-#pragma unroll
-                for (int b = 0; b < TCI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
-            }
-    }
-    // C/D layout of 16x16x4: col = lane & 15 (j = ci), row = 4 * (lane >> 4) + reg (i = co)
-    // LDS of the caller (a kernel that serves several tile classes owns ONE buffer of the largest class's size)
-    float (*s_red)[TCO * TCI * 256] = reinterpret_cast<float (*)[TCO * TCI * 256]>(s_red_);
-    float (*s_b)[TCO * 16] = reinterpret_cast<float (*)[TCO * 16]>(s_b_);
-#pragma unroll
-    for (int a = 0; a < TCO; ++a) {
-#pragma unroll
-        for (int b = 0; b < TCI; ++b)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) s_red[wave][(a * TCI + b) * 256 + (4 * kk + g) * 16 + cc] = acc[a][b][g];
-        // bias: lanes with the same cc over the 4 k-groups
-        float t = bsum[a];
-        t += __shfl_xor(t, 16, WAVE);
-        t += __shfl_xor(t, 32, WAVE);
-        if (kk == 0) s_b[wave][a * 16 + cc] = t;
-    }
-    __syncthreads();
-    const int64_t pb = (int64_t)bx;
-    for (int t = threadIdx.x; t < TCO * TCI * 256; t += WG_BLOCK) {
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < WG_WAVES; ++w) v += s_red[w][t];
-        const int tile = t >> 8, a = tile / TCI, b = tile % TCI, i = (t >> 4) & 15, j = t & 15;
-        const int co = co_base + 16 * a + i, ci = ci_base + 16 * b + j;
-        if (co < Co && ci < Ci) partial[(pb * Co + co) * Ci + ci] = v;
-    }
-    if (partial_b != nullptr && bz == 0) {
-        for (int t = threadIdx.x; t < TCO * 16; t += WG_BLOCK) {
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < WG_WAVES; ++w) v += s_b[w][t];
-            const int co = co_base + t;
-            if (co < Co) partial_b[pb * Co + co] = v;
-        }
-    }
-}
 
 template <int TCO, int TCI>
 __global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict__ G,
@@ -120,48 +30,13 @@ __global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict
     wgrad_body<TCO, TCI>(G, X, M, Co, Ci, rows_per_block, partial, partial_b, blockIdx.x, blockIdx.y, blockIdx.z, s_red, s_b);
 }
 
-// The partial passes of SEVERAL layers in one launch (crfconv_linear_wgrad_partial_jobs): the weight gradients of the coarse
-// levels are ~9 us launches of a few workgroups each and nothing on the backward chain waits for them, so they are queued and
-// issued together once the chain is done -- the jobs' workgroups (laid end to end, job found by a binary search over the
-// prefix) run side by side.  Same partial slabs as one wgrad_kernel launch per job.
-constexpr int WJ_MAX = 32;
-struct WgJobTable {
-    const float* G[WJ_MAX];
-    const float* X[WJ_MAX];
-    float* partial[WJ_MAX];
-    float* partial_b[WJ_MAX];
-    int M[WJ_MAX], Co[WJ_MAX], Ci[WJ_MAX], rows_per_block[WJ_MAX], nblk[WJ_MAX], gy[WJ_MAX];
-    int blk_base[WJ_MAX + 1];
-    int njobs;
-    unsigned char cls[WJ_MAX];                         // 10 TCO + TCI (wgrad_jobs_any_kernel)
-};
 // Every tile class in ONE launch (round 4): the jobs of the small classes -- five launches of 40-240 workgroups, 7-12 us each, behind
 // the <4, 4> launch of the step -- run beside the large ones.  The workgroup looks its job up as above and dispatches on the job's
 // class; one LDS buffer of the largest class (64 KB), the register budget of the largest (the small classes' jobs are few).
 __global__ __launch_bounds__(WG_BLOCK) void wgrad_jobs_any_kernel(const WgJobTable t) {
     __shared__ float s_red[WG_WAVES * 4 * 4 * 256];
     __shared__ float s_b[WG_WAVES * 4 * 16];
-    int lo = 0, hi = t.njobs;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (t.blk_base[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
-    }
-    const int local = (int)blockIdx.x - t.blk_base[lo];
-    const int bx = local % t.nblk[lo], rest = local / t.nblk[lo];
-    const int by = rest % t.gy[lo], bz = rest / t.gy[lo];
-#define WB(TA, TB) wgrad_body<TA, TB>(t.G[lo], t.X[lo], t.M[lo], t.Co[lo], t.Ci[lo], t.rows_per_block[lo], t.partial[lo], t.partial_b[lo], bx, by, bz, s_red, s_b)
-    switch (t.cls[lo]) {
-        case 44: WB(4, 4); break;
-        case 22: WB(2, 2); break;
-        case 42: WB(4, 2); break;
-        case 24: WB(2, 4); break;
-        case 14: WB(1, 4); break;
-        case 41: WB(4, 1); break;
-        case 12: WB(1, 2); break;
-        case 21: WB(2, 1); break;
-        default: WB(1, 1); break;
-    }
-#undef WB
+    wgrad_any_run(t, (int)blockIdx.x, s_red, s_b);
 }
 
 // ====================================================================== backward of Linear -> BatchNorm -> LeakyReLU
@@ -521,45 +396,6 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(const ReduceJobTable t
     reduce_slab64(tbl.partial[lo], tbl.nblk[lo], tbl.nslots[lo], (g - tbl.group_begin[lo]) * 64, tbl.out[lo], s_part);
 }
 
-struct WgPlan {
-    int tco, tci, gy, gz, nblk, rows_per_block;
-};
-#ifndef WG_LONG_ROWS_
-#define WG_LONG_ROWS_ 256     // swept on the training step, one box, two runs each: 64 (round 3's plan) 4.413 ms, 128 4.398, 192 4.395, 256 4.386, 320 4.397, 384 4.409, 512 4.411
-#endif
-
-
-static WgPlan wg_plan(int64_t M, int Co, int Ci) {
-    WgPlan p;
-    const int t_co = (Co + 15) / 16, t_ci = (Ci + 15) / 16;
-    p.tco = t_co >= 4 ? 4 : (t_co >= 2 ? 2 : 1);
-    p.tci = t_ci >= 4 ? 4 : (t_ci >= 2 ? 2 : 1);
-    p.gy = (t_co + p.tco - 1) / p.tco;
-    p.gz = (t_ci + p.tci - 1) / p.tci;
-    // ~512 workgroups over the chip = row-slices x (gy x gz output slabs); at least 32 slices, at least 64 rows
-    // (one 16-row group per wave) each: the partial slabs the second kernel sums stay a small fraction of the
-    // operand bytes
-    int64_t slices = 512 / ((int64_t)p.gy * p.gz);
-    if (slices < 32) slices = 32;
-    int64_t rows = (M + slices - 1) / slices;
-    if (rows < 64) rows = 64;
-    rows = (rows + 63) / 64 * 64;
-#if WG_LONG_ROWS_ > 64
-    // Longer slices for the layers whose partial passes share one launch (M <= 65536: crfconv_linear_wgrad_partial_jobs, ~22
-    // wavefronts per SIMD of work): every slice writes a Co x Ci slab that the reduce launch reads again -- 92 MB written and
-    // re-read per step with the 64 ... 192-row slices of the plan above; past 256 rows the launch's longest workgroups cost more
-    // than the slabs save
-    if (M <= 65536) {
-        int64_t want = WG_LONG_ROWS_;
-        if (M < 2 * want) want = ((M + 1) / 2 + 63) / 64 * 64;
-        if (rows < want) rows = want;
-    }
-#endif
-    p.rows_per_block = (int)rows;
-    p.nblk = (int)((M + rows - 1) / rows);
-    return p;
-}
-
 }  // namespace crf
 
 using namespace crf;
@@ -623,33 +459,15 @@ extern "C" int crfconv_linear_wgrad_partial_jobs(const crf_wgrad_job* jobs, int 
         CRF_REQUIRE((reinterpret_cast<uintptr_t>(jb.workspace) & 255) == 0, CRF_ERR_ARG, "job %d: workspace must be 256-byte aligned", j);
         CRF_REQUIRE(jb.workspace_bytes >= crfconv_linear_wgrad_workspace(jb.M, jb.Co, jb.Ci), CRF_ERR_WORKSPACE, "job %d: workspace too small", j);
     }
-    {
-        // jobs in the caller's order (longest first), WJ_MAX per launch
-        for (int j0 = 0; j0 < njobs; j0 += WJ_MAX) {
-            WgJobTable t;
-            const int n = njobs - j0 < WJ_MAX ? njobs - j0 : WJ_MAX;
-            int64_t blocks = 0;
-            for (int k = 0; k < n; ++k) {
-                const crf_wgrad_job& jb = jobs[j0 + k];
-                const WgPlan p = wg_plan(jb.M, jb.Co, jb.Ci);
-                float* partial = reinterpret_cast<float*>(jb.workspace);
-                t.G[k] = jb.G; t.X[k] = jb.X; t.partial[k] = partial;
-                t.partial_b[k] = jb.want_bias ? partial + (size_t)p.nblk * jb.Co * jb.Ci : nullptr;
-                t.M[k] = (int)jb.M; t.Co[k] = jb.Co; t.Ci[k] = jb.Ci; t.rows_per_block[k] = p.rows_per_block; t.nblk[k] = p.nblk; t.gy[k] = p.gy;
-                t.cls[k] = (unsigned char)(10 * p.tco + p.tci);
-                t.blk_base[k] = (int)blocks;
-                blocks += (int64_t)p.nblk * p.gy * p.gz;
-                CRF_REQUIRE(blocks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many workgroups in one batch");
-            }
-            for (int k = n; k <= WJ_MAX; ++k) t.blk_base[k] = (int)blocks;
-            for (int k = n; k < WJ_MAX; ++k) {
-                t.G[k] = nullptr; t.X[k] = nullptr; t.partial[k] = nullptr; t.partial_b[k] = nullptr;
-                t.M[k] = 0; t.Co[k] = 1; t.Ci[k] = 1; t.rows_per_block[k] = 64; t.nblk[k] = 1; t.gy[k] = 1; t.cls[k] = 11;
-            }
-            t.njobs = n;
-            hipLaunchKernelGGL(wgrad_jobs_any_kernel, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, st, t);
-            CRF_LAUNCH_CHECK();
-        }
+    // jobs in the caller's order (longest first), WJ_MAX per launch
+    for (int j0 = 0; j0 < njobs; j0 += WJ_MAX) {
+        WgJobTable t;
+        int64_t blocks = 0;
+        const int n = njobs - j0 < WJ_MAX ? njobs - j0 : WJ_MAX;
+        wg_fill_table(jobs + j0, n, t, blocks);
+        CRF_REQUIRE(blocks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many workgroups in one batch");
+        hipLaunchKernelGGL(wgrad_jobs_any_kernel, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, st, t);
+        CRF_LAUNCH_CHECK();
     }
     return CRF_OK;
 }

@@ -8,13 +8,16 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract). Returns (rank, world, local_rank)."""
+def init_from_env(backend=None, use_gpu=True):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract). Returns (rank, world, local_rank).
+    use_gpu=False: a CPU-only group (gloo) that never touches the HIP runtime -- the many-rank rehearsal of bench.py."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     backend = backend or os.environ.get('CRFCONV_DIST_BACKEND')       # e.g. gloo: several ranks sharing one GPU in tests
-    if backend == 'gloo' and torch.cuda.is_available():
+    if not use_gpu:
+        backend = 'gloo'
+    elif backend == 'gloo' and torch.cuda.is_available():
         local %= torch.cuda.device_count()
     # under torchrun (WORLD_SIZE exported) the group is created even for one rank: same code path at every N
     if (world > 1 or 'WORLD_SIZE' in os.environ) and not dist.is_initialized():

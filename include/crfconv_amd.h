@@ -564,7 +564,10 @@ int crfconv_bn_apply_from_records_jobs(const crf_bn_apply_job* jobs, int njobs, 
 typedef struct { const float* gA; const float* Y; const float* coef; const float* W; const float* addend; int64_t M; int Ci; int Co;
                  int training; float slope; float* gY; float* dX; float* dgamma; float* dbeta; void* workspace; size_t workspace_bytes;
 } crf_mlp_bwd_job;
-int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int njobs, crf_stream_t stream);
+/* side (may be NULL, n_side <= 32): pending weight-gradient partial passes (crf_wgrad_job, the jobs of crfconv_linear_wgrad_partial_jobs)
+ * that ride in the first of the two launches, behind the blocks' own tile-sum workgroups -- nothing on the backward chain waits for
+ * them and a coarse launch leaves most of the chip idle. */
+int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int njobs, const crf_wgrad_job* side, int n_side, crf_stream_t stream);
 /* Up to 8 independent products C_j = A_j B_j (B_j [K_j, N_j]; N, K multiples of 4) per launch -- the g_h1 = g_h2 W2 products of all wide
  * PointConv layers of a backward pass; same tiles and summation order as crfconv_gemm on each.  jobs is a host array. */
 typedef struct { const float* A; const float* B; float* C; int64_t M; int N; int K; } crf_gemm_job;

@@ -218,6 +218,29 @@ def test_bench_starts_its_own_ranks_without_a_launcher_environment(monkeypatch):
     assert len(started) == 1 and started[0].env['WORLD_SIZE'] == '1'
 
 
+def test_eight_rank_rehearsal_of_the_bench_launch_on_the_cpu(tmp_path):
+    """`python bench.py --gpus 8 --rehearse` as the driver would type the 8-GPU command -- no launcher environment,
+    bench.py starts the eight ranks itself -- with every rank on the CPU over gloo (eight processes may not share one GPU on this
+    pool, and an 8-GPU node is not ours to launch on): port and environment propagation, all ranks joining, the broadcast making the
+    replicas equal, the flat all-reduce with its failure-flag slot, the MAX-over-ranks timing and exactly ONE JSON line from rank 0."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'CRFCONV_DIST_BACKEND')}
+    env['OMP_NUM_THREADS'] = '1'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--rehearse', '--steps', '3', '--warmup', '1', '--points', '4096']
+    with open(str(tmp_path / 'out'), 'w') as fo, open(str(tmp_path / 'err'), 'w') as fe:
+        rc = subprocess.run(cmd, env=env, stdout=fo, stderr=fe, cwd=ROOT, timeout=300).returncode
+    assert rc == 0, open(str(tmp_path / 'err')).read()[-3000:]
+    lines = [l for l in open(str(tmp_path / 'out')).read().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['rehearsal'] is True and rec['world'] == 8 and rec['dist_backend'] == 'gloo' and rec['n_gpus'] == 0
+    assert rec['replica_spread'] == 0.0 and rec['guard_slot'] == 0.0 and rec['ms_per_step'] > 0
+    # a rank that fails must surface as the parent's exit status (and the others must not be left behind)
+    bad = subprocess.run(cmd + ['--points', '-5'], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT, timeout=300)
+    assert bad.returncode != 0
+
+
 def test_tolerances_are_tied_to_the_recorded_errors(monkeypatch):
     """tests/gpu_util.assert_close: with an entry in the baseline (key = test :: what, no occurrence counter) the enforced bound is
     min(stated, max(10 x recorded, noise floor)); the floor is 16 eps where the recorded run was bit-exact; a missing key warns (and
