@@ -120,9 +120,9 @@ SIGNATURES = {
     'crfconv_mlp_small_backward_supported': (_i, [_i64, _i, _i]),
     'crfconv_gemm_stats_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_bn_apply_from_records_jobs': (_i, [_vp, _i, _vp]),
-    'crfconv_mlp_small_backward_jobs': (_i, [_vp, _i, _vp, _i, _vp]),
+    'crfconv_mlp_small_backward_jobs': (_i, [_vp, _i, _vp, _vp]),
     'crfconv_mlp_small_backward_workspace': (_sz, [_i64, _i]),
-    'crfconv_mlp_small_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_mlp_small_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'crfconv_gemm_stat_records': (_sz, [_i64]),
     'crfconv_gemm_stats': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     'crfconv_gemm_supported': (_i, [_i64, _i, _i]),

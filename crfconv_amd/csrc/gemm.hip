@@ -22,7 +22,7 @@
 // gradient gY, formed from (gA, Y) and row-tile sums while it is loaded); jobs (crfconv_gemm_jobs: several independent products in
 // one launch).  bn_bwd_tile_sums_kernel, the PRO form's first launch, lives here too.
 #include "common.hpp"
-#include "wgrad_body.hpp"
+#include "gridsync.hpp"
 
 #include <cstdlib>
 
@@ -58,20 +58,17 @@ __device__ __forceinline__ float4 gm_ld4(const float* __restrict__ p, int valid)
 
 // PRO form (crfconv_mlp_small_backward): the A operand is not read but FORMED while it is loaded -- gY, the gradient in front of a
 // train-mode BatchNorm + LeakyReLU, from (gA, Y) and per-channel coefficients: g1 = gA * lrelu'(a y + b), yh = (y - mean) rstd,
-// gY = a (g1 - sum g1 / M - yh sum g1 yh / M).  Every workgroup first sums the row-tile partials of the two channel sums
-// (bn_bwd_tile_sums_kernel, float64) for all K channels into LDS; the workgroups of the first column slab also store the gY tiles
-// they form (the weight gradient needs them), workgroup (0, 0) dgamma / dbeta.
+// gY = a (g1 - sum g1 / M - yh sum g1 yh / M).  The two channel means come finished from the tile-sum launch (its last workgroup per
+// column slab adds the row-tile partials in float64, round 5: until then EVERY workgroup of the product re-summed all of them --
+// 98 KB of partials per workgroup at 256 channels, 2 560 workgroups for a 10 240-row layer); the workgroups of the first column
+// slab also store the gY tiles they form (the weight gradient needs them).
 constexpr int GM_PRO_MAXK = 512;
 struct GemmPro {
     const float* Y;            // [M, K] pre-BatchNorm activations
     const float* coef;         // [4][K]: a | b | mean | rstd
-    const double* partial;     // [ntile][2][K]: sum g1, sum g1 yh per row tile
-    int ntile;
-    int training;              // eval-mode BatchNorm: the two mean terms vanish
-    float slope, inv_m;
+    const float* fin;          // [2][K]: sum g1 / M | sum g1 yh / M (zeros for an eval-mode BatchNorm), left by the tile-sum launch
+    float slope;
     float* gY;                 // [M, K] out
-    float* dgamma;             // [K] out
-    float* dbeta;              // [K] out
 };
 
 // STATS form (crfconv_gemm_stats): the epilogue also leaves BatchNorm statistic records of the tile it holds -- one
@@ -215,28 +212,12 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const flo
         if (d == 0 || d < nchunk) fetch(GM_BK * d, rs[d]);
     if constexpr (PRO) {                                 // behind the first operand loads' issue: channel coefficients into LDS
         for (int k = threadIdx.x; k < K; k += GM_BLOCK) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int t0 = 0; t0 < pro.ntile; t0 += 24) {    // 24 tiles (3072 rows) of both sums in flight: one round trip; tile order
-                double v1[24], v2[24];
-#pragma unroll
-                for (int u = 0; u < 24; ++u) {
-                    const bool in = t0 + u < pro.ntile;
-                    v1[u] = in ? pro.partial[((int64_t)(t0 + u) * 2) * K + k] : 0.0;
-                    v2[u] = in ? pro.partial[((int64_t)(t0 + u) * 2 + 1) * K + k] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < 24; ++u) { s1 += v1[u]; s2 += v2[u]; }
-            }
             sPro[k] = pro.coef[k];
             sPro[GM_PRO_MAXK + k] = pro.coef[K + k];
             sPro[2 * GM_PRO_MAXK + k] = pro.coef[2 * K + k];
             sPro[3 * GM_PRO_MAXK + k] = pro.coef[3 * K + k];
-            sPro[4 * GM_PRO_MAXK + k] = pro.training ? (float)(s1 * (double)pro.inv_m) : 0.f;
-            sPro[5 * GM_PRO_MAXK + k] = pro.training ? (float)(s2 * (double)pro.inv_m) : 0.f;
-            if (bx == 0 && by == 0) {
-                pro.dbeta[k] = (float)s1;
-                pro.dgamma[k] = (float)s2;
-            }
+            sPro[4 * GM_PRO_MAXK + k] = pro.fin[k];
+            sPro[5 * GM_PRO_MAXK + k] = pro.fin[K + k];
         }
         __syncthreads();
     }
@@ -370,9 +351,7 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_pro_jobs_kernel(const GemmProJo
     while (j + 1 < t.njobs && t.tile_base[j + 1] <= (int)blockIdx.x) ++j;
     const unsigned local = blockIdx.x - (unsigned)t.tile_base[j];
     GemmPro pro;                                        // the job's entry, pinned into scalar registers
-    pro.Y = uni(t.pro[j].Y); pro.coef = uni(t.pro[j].coef); pro.partial = uni(t.pro[j].partial); pro.ntile = uni(t.pro[j].ntile);
-    pro.training = uni(t.pro[j].training); pro.slope = uni(t.pro[j].slope); pro.inv_m = uni(t.pro[j].inv_m); pro.gY = uni(t.pro[j].gY);
-    pro.dgamma = uni(t.pro[j].dgamma); pro.dbeta = uni(t.pro[j].dbeta);
+    pro.Y = uni(t.pro[j].Y); pro.coef = uni(t.pro[j].coef); pro.fin = uni(t.pro[j].fin); pro.slope = uni(t.pro[j].slope); pro.gY = uni(t.pro[j].gY);
     const unsigned tx = (unsigned)uni(t.tiles_x[j]);
     gemm_tile<1, 1, 2, 2, false, true, true, false>(uni(t.A[j]), uni(t.B[j]), nullptr, uni(t.addend[j]), uni(t.M[j]), uni(t.N[j]), uni(t.K[j]), uni(t.C[j]),
                                                     pro, nullptr, (unsigned)uni((int)(local % tx)), (unsigned)uni((int)(local / tx)));
@@ -386,10 +365,23 @@ namespace crf {
 // BT_ROWS rows (g1 = gA lrelu'(a y + b), yh = (y - mean) rstd).  A workgroup = one tile x 64 channels: 16 lanes x 16 bytes per row
 // (whole 256-byte row segments), 16 rows per pass; float32 inside a thread's eight rows, float64 across the 16 row threads.
 constexpr int BT_ROWS = 128, BT_CH = 64, BT_NR = BT_ROWS / 16;
+// what the LAST workgroup of a column slab leaves for the product launch and the caller
+struct TileSumFin {
+    unsigned* ticket;          // this slab's ticket word (zero; left zero)
+    int ntile;                 // workgroups (row tiles) of the slab
+    int training;
+    float inv_m;
+    float* fin;                // [2][K]
+    float* dgamma;             // [K]
+    float* dbeta;              // [K]
+};
+typedef unsigned int bt_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void bn_bwd_tile_sums_body(const float* __restrict__ gA, const float* __restrict__ Y,
                                                        const float* __restrict__ coef, int M, int K, int tile_rows,
-                                                       float slope, double* __restrict__ partial, const int bx, const int by) {
+                                                       float slope, double* __restrict__ partial, const int bx, const int by,
+                                                       const TileSumFin f) {
     __shared__ float s_red[16][2][BT_CH];
+    __shared__ int s_last;
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = by * BT_CH + 4 * cq;
     const int row0 = bx * tile_rows;
@@ -423,51 +415,72 @@ __device__ __forceinline__ void bn_bwd_tile_sums_body(const float* __restrict__ 
     *reinterpret_cast<float4*>(&s_red[rl][0][4 * cq]) = s1;
     *reinterpret_cast<float4*>(&s_red[rl][1][4 * cq]) = s2;
     __syncthreads();
-    if (threadIdx.x < 2 * BT_CH) {
-        const int which = threadIdx.x / BT_CH, ch = threadIdx.x - which * BT_CH;
+    // partial [ntile][2][K] doubles, stored write-through: the slab's last workgroup (another CU, maybe another XCD) reads them
+    const __amdgpu_buffer_rsrc_t pr = make_rsrc(partial, f.ntile * 2 * K * 8);
+    const int which = threadIdx.x / BT_CH, ch = threadIdx.x - which * BT_CH;
+    const bool mine = threadIdx.x < 2 * BT_CH && by * BT_CH + ch < K;
+    if (mine) {
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) t += (double)s_red[w][which][ch];           // fixed order
-        if (by * BT_CH + ch < K) partial[((int64_t)bx * 2 + which) * K + by * BT_CH + ch] = t;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(t);
+        const bt_u32x2 u = {(unsigned)bits, (unsigned)(bits >> 32)};
+        __builtin_amdgcn_raw_buffer_store_b64(u, pr, ((bx * 2 + which) * K + by * BT_CH + ch) * 8, 0, 16);
     }
+    // "the last workgroup finishes" (gridsync.hpp), per column slab: its row tiles draw tickets on the slab's word
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old + 1 == (unsigned)f.ntile;
+        if (last) __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last || !mine) return;
+    // the row-tile partials of this thread's (sum, channel) in tile order, all loads of a 24-tile round in flight (one round at <= 3072
+    // rows): the order -- hence every bit -- of the sums the product launch used to form per workgroup
+    const int cg = by * BT_CH + ch;
+    double tot = 0.0;
+    for (int t0 = 0; t0 < f.ntile; t0 += 24) {
+        double v[24];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const int tt = t0 + u < f.ntile ? t0 + u : f.ntile - 1;
+            const bt_u32x2 w2 = __builtin_amdgcn_raw_buffer_load_b64(pr, ((tt * 2 + which) * K + cg) * 8, 0, 16);
+            const double d = __longlong_as_double((long long)(((unsigned long long)w2.y << 32) | w2.x));
+            v[u] = t0 + u < f.ntile ? d : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 24; ++u) tot += v[u];
+    }
+    (which == 0 ? f.dbeta : f.dgamma)[cg] = (float)tot;
+    f.fin[which * K + cg] = f.training ? (float)(tot * (double)f.inv_m) : 0.f;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_tile_sums_kernel(const float* __restrict__ gA, const float* __restrict__ Y,
-                                                               const float* __restrict__ coef, int M, int K, int tile_rows,
-                                                               float slope, double* __restrict__ partial) {
-    bn_bwd_tile_sums_body(gA, Y, coef, M, K, tile_rows, slope, partial, blockIdx.x, blockIdx.y);
-}
 struct TileSumJobs {
     const float* gA[GG_MAX]; const float* Y[GG_MAX]; const float* coef[GG_MAX]; double* partial[GG_MAX];
-    int M[GG_MAX], K[GG_MAX], tile_rows[GG_MAX], ntile[GG_MAX];
-    float slope[GG_MAX];
+    float* fin[GG_MAX]; float* dgamma[GG_MAX]; float* dbeta[GG_MAX];
+    int M[GG_MAX], K[GG_MAX], tile_rows[GG_MAX], ntile[GG_MAX], training[GG_MAX];
+    float slope[GG_MAX], inv_m[GG_MAX];
+    unsigned* ticket;          // BT_SLABS lines per job
     int blk_base[GG_MAX + 1];
     int njobs;
 };
-__global__ __launch_bounds__(256) void bn_bwd_tile_sums_jobs_kernel(const TileSumJobs t) {
+constexpr int BT_SLABS = GM_PRO_MAXK / BT_CH;      // column slabs of a job at most (8): job j, slab s draws on ticket line 8 j + s
+__device__ __forceinline__ void bn_bwd_tile_sums_job(const TileSumJobs& t, const int blk) {
     int j = 0;
-    while (j + 1 < t.njobs && t.blk_base[j + 1] <= (int)blockIdx.x) ++j;
-    const int local = (int)blockIdx.x - t.blk_base[j];
-    bn_bwd_tile_sums_body(t.gA[j], t.Y[j], t.coef[j], t.M[j], t.K[j], t.tile_rows[j], t.slope[j], t.partial[j], local % t.ntile[j], local / t.ntile[j]);
+    while (j + 1 < t.njobs && t.blk_base[j + 1] <= blk) ++j;
+    const int local = blk - t.blk_base[j];
+    const int ntile = uni(t.ntile[j]);
+    const int bx = local % ntile, by = local / ntile;
+    TileSumFin f;
+    f.ticket = uni(t.ticket) + (j * BT_SLABS + by) * FW_LINE; f.ntile = ntile; f.training = uni(t.training[j]); f.inv_m = uni(t.inv_m[j]);
+    f.fin = uni(t.fin[j]); f.dgamma = uni(t.dgamma[j]); f.dbeta = uni(t.dbeta[j]);
+    bn_bwd_tile_sums_body(uni(t.gA[j]), uni(t.Y[j]), uni(t.coef[j]), uni(t.M[j]), uni(t.K[j]), uni(t.tile_rows[j]), uni(t.slope[j]), uni(t.partial[j]),
+                          bx, by, f);
 }
-// The same launch carrying SIDE work (round 5): behind the tile-sum workgroups of the chain's blocks -- a few dozen, on a chip of 256
-// CUs -- come the workgroups of pending weight-gradient partial passes (wgrad_body.hpp), which nothing on the backward chain waits
-// for: they used to go out as chip-filling launches of their own at the end of the pass (~0.11 ms per step), now they fill the CUs a
-// coarse launch leaves idle.  Same slabs, same sums.
-static_assert(WG_BLOCK == 256, "the side jobs run in the tile-sum launch's workgroups");
-__global__ __launch_bounds__(256) void bn_bwd_tile_sums_side_kernel(const TileSumJobs t, const WgJobTable w, const int own_blocks) {
-    if ((int)blockIdx.x < own_blocks) {
-        int j = 0;
-        while (j + 1 < t.njobs && t.blk_base[j + 1] <= (int)blockIdx.x) ++j;
-        const int local = (int)blockIdx.x - t.blk_base[j];
-        bn_bwd_tile_sums_body(t.gA[j], t.Y[j], t.coef[j], t.M[j], t.K[j], t.tile_rows[j], t.slope[j], t.partial[j], local % t.ntile[j], local / t.ntile[j]);
-        return;
-    }
-    __shared__ float s_red[WG_WAVES * 4 * 4 * 256];
-    __shared__ float s_b[WG_WAVES * 4 * 16];
-    wgrad_any_run(w, (int)blockIdx.x - own_blocks, s_red, s_b);
-}
-
+__global__ __launch_bounds__(256) void bn_bwd_tile_sums_jobs_kernel(const TileSumJobs t) { bn_bwd_tile_sums_job(t, (int)blockIdx.x); }
 }  // namespace crf
 
 extern "C" int crfconv_mlp_small_backward_supported(int64_t M, int Ci, int Co) {
@@ -484,11 +497,13 @@ static void bt_plan(int64_t M, int& ntile, int& tile_rows) {
     ntile = (int)((M + rows - 1) / rows);
 }
 
+// partials [ntile][2][Co] doubles | the finished means [2][Co] floats (each 256-byte aligned)
+static size_t bt_fin_offset(int Co, int ntile) { return (sizeof(double) * 2 * (size_t)Co * (size_t)ntile + 255) & ~(size_t)255; }
 extern "C" size_t crfconv_mlp_small_backward_workspace(int64_t M, int Co) {
     if (M < 1 || Co < 1) return 0;
     int ntile, tile_rows;
     bt_plan(M, ntile, tile_rows);
-    return sizeof(double) * 2 * (size_t)Co * (size_t)ntile + 256;
+    return bt_fin_offset(Co, ntile) + sizeof(float) * 2 * (size_t)Co + 512;
 }
 
 // Backward of one coarse-level MLP block A = lrelu(BN(X W^T), slope) behind its one-launch forward (crfconv_mlp_small_forward),
@@ -497,46 +512,18 @@ extern "C" size_t crfconv_mlp_small_backward_workspace(int64_t M, int Co) {
 // crfconv_bn_backward followed by crfconv_gemm up to summation order.  coef: the [4][Co] block of the forward.
 extern "C" int crfconv_mlp_small_backward(const float* gA, const float* Y, const float* coef, const float* W, const float* addend,
                                           int64_t M, int Ci, int Co, int training, float slope, float* gY, float* dX, float* dgamma,
-                                          float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
-    CRF_REQUIRE(gA && Y && coef && W && gY && dX && dgamma && dbeta && workspace, CRF_ERR_ARG, "null pointer");
-    CRF_REQUIRE(crfconv_mlp_small_backward_supported(M, Ci, Co), CRF_ERR_UNSUPPORTED,
-                "mlp_small_backward %lld x %d -> %d: widths must be multiples of 4, Co <= %d", (long long)M, Ci, Co, crf::GM_PRO_MAXK);
-    CRF_REQUIRE(workspace_bytes >= crfconv_mlp_small_backward_workspace(M, Co), CRF_ERR_WORKSPACE, "workspace too small");
-    hipStream_t st = crf::as_stream(stream);
-    double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    int ntile, tile_rows;
-    bt_plan(M, ntile, tile_rows);
-    hipLaunchKernelGGL(crf::bn_bwd_tile_sums_kernel, dim3((unsigned)ntile, (unsigned)((Co + crf::BT_CH - 1) / crf::BT_CH)), dim3(256), 0, st,
-                       gA, Y, coef, (int)M, Co, tile_rows, slope, partial);
-    CRF_LAUNCH_CHECK();
-    crf::GemmPro pro;
-    pro.Y = Y; pro.coef = coef; pro.partial = partial; pro.ntile = ntile; pro.training = training; pro.slope = slope;
-    pro.inv_m = (float)(1.0 / (double)M); pro.gY = gY; pro.dgamma = dgamma; pro.dbeta = dbeta;
-    const int N = Ci, K = Co;
-    // 32 x 32 tiles as the plain product (32 x 64 / 64 x 64 tiles for wide outputs, where every column slab forms the gY tile of its
-    // rows again, measured the same or slower: DESIGN 9)
-    const dim3 blk(crf::GM_BLOCK);
-    const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32));
-    hipLaunchKernelGGL((crf::gemm_kernel<1, 1, 2, 2, false, true, true>), grid, blk, 0, st, gA, W, (const float*)nullptr, addend, (int)M, N, K,
-                       dX, pro);
-    CRF_LAUNCH_CHECK();
-    return CRF_OK;
+                                          float* dbeta, void* workspace, size_t workspace_bytes, unsigned* ticket, void* stream) {
+    crf_mlp_bwd_job job;
+    job.gA = gA; job.Y = Y; job.coef = coef; job.W = W; job.addend = addend; job.M = M; job.Ci = Ci; job.Co = Co; job.training = training;
+    job.slope = slope; job.gY = gY; job.dX = dX; job.dgamma = dgamma; job.dbeta = dbeta; job.workspace = workspace; job.workspace_bytes = workspace_bytes;
+    return crfconv_mlp_small_backward_jobs(&job, 1, ticket, stream);
 }
 
 // The backward of up to 4 INDEPENDENT coarse-level MLP blocks (crf_mlp_bwd_job: the arguments of crfconv_mlp_small_backward per
 // block) in TWO launches for all of them: the row-tile sums of every block, then every block's dX product.  Results per block are
 // bit-identical to crfconv_mlp_small_backward's.
-extern "C" int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int njobs, const crf_wgrad_job* side, int n_side, void* stream) {
-    CRF_REQUIRE(jobs && njobs >= 1 && njobs <= crf::GG_MAX, CRF_ERR_ARG, "1 .. %d jobs (got %d)", crf::GG_MAX, njobs);
-    CRF_REQUIRE(n_side >= 0 && n_side <= crf::WJ_MAX && (n_side == 0 || side != nullptr), CRF_ERR_ARG, "0 .. %d side jobs (got %d)", crf::WJ_MAX, n_side);
-    for (int j = 0; j < n_side; ++j) {
-        const crf_wgrad_job& jb = side[j];
-        CRF_REQUIRE(jb.G && jb.X && jb.workspace, CRF_ERR_ARG, "side job %d: null pointer", j);
-        CRF_REQUIRE(jb.M > 0 && jb.M < ((int64_t)1 << 31) && jb.Co > 0 && jb.Ci > 0 && jb.Co <= 4096 && jb.Ci <= 4096, CRF_ERR_ARG,
-                    "side job %d: bad shape M=%lld Co=%d Ci=%d", j, (long long)jb.M, jb.Co, jb.Ci);
-        CRF_REQUIRE((reinterpret_cast<uintptr_t>(jb.workspace) & 255) == 0, CRF_ERR_ARG, "side job %d: workspace must be 256-byte aligned", j);
-        CRF_REQUIRE(jb.workspace_bytes >= crfconv_linear_wgrad_workspace(jb.M, jb.Co, jb.Ci), CRF_ERR_WORKSPACE, "side job %d: workspace too small", j);
-    }
+extern "C" int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int njobs, unsigned* ticket, void* stream) {
+    CRF_REQUIRE(jobs && ticket && njobs >= 1 && njobs <= crf::GG_MAX, CRF_ERR_ARG, "1 .. %d jobs (got %d) and the ticket words", crf::GG_MAX, njobs);
     crf::TileSumJobs ts;
     crf::GemmProJobs gp;
     int64_t blocks = 0, tiles = 0;
@@ -546,7 +533,7 @@ extern "C" int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int 
         if (j >= crf::GG_MAX) break;
         if (j >= njobs) {
             ts.gA[j] = nullptr; ts.Y[j] = nullptr; ts.coef[j] = nullptr; ts.partial[j] = nullptr; ts.M[j] = 0; ts.K[j] = 4; ts.tile_rows[j] = crf::BT_ROWS;
-            ts.ntile[j] = 1; ts.slope[j] = 1.f;
+            ts.ntile[j] = 1; ts.slope[j] = 1.f; ts.fin[j] = nullptr; ts.dgamma[j] = nullptr; ts.dbeta[j] = nullptr; ts.training[j] = 0; ts.inv_m[j] = 0.f;
             gp.A[j] = nullptr; gp.B[j] = nullptr; gp.addend[j] = nullptr; gp.C[j] = nullptr; gp.pro[j] = crf::GemmPro(); gp.M[j] = 0; gp.N[j] = 4; gp.K[j] = 4;
             gp.tiles_x[j] = 1;
             continue;
@@ -560,28 +547,22 @@ extern "C" int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int 
         int ntile, tile_rows;
         bt_plan(b.M, ntile, tile_rows);
         ts.gA[j] = b.gA; ts.Y[j] = b.Y; ts.coef[j] = b.coef; ts.partial[j] = partial; ts.M[j] = (int)b.M; ts.K[j] = b.Co; ts.tile_rows[j] = tile_rows;
-        ts.ntile[j] = ntile; ts.slope[j] = b.slope;
+        float* fin = reinterpret_cast<float*>(reinterpret_cast<char*>(partial) + bt_fin_offset(b.Co, ntile));
+        ts.ntile[j] = ntile; ts.slope[j] = b.slope; ts.fin[j] = fin; ts.dgamma[j] = b.dgamma; ts.dbeta[j] = b.dbeta; ts.training[j] = b.training;
+        ts.inv_m[j] = (float)(1.0 / (double)b.M);
         blocks += (int64_t)ntile * ((b.Co + crf::BT_CH - 1) / crf::BT_CH);
         crf::GemmPro pro;
-        pro.Y = b.Y; pro.coef = b.coef; pro.partial = partial; pro.ntile = ntile; pro.training = b.training; pro.slope = b.slope;
-        pro.inv_m = (float)(1.0 / (double)b.M); pro.gY = b.gY; pro.dgamma = b.dgamma; pro.dbeta = b.dbeta;
+        pro.Y = b.Y; pro.coef = b.coef; pro.fin = fin; pro.slope = b.slope; pro.gY = b.gY;
         gp.A[j] = b.gA; gp.B[j] = b.W; gp.addend[j] = b.addend; gp.C[j] = b.dX; gp.pro[j] = pro; gp.M[j] = (int)b.M; gp.N[j] = b.Ci; gp.K[j] = b.Co;
         gp.tiles_x[j] = (int)((b.M + 31) / 32);
         tiles += (int64_t)gp.tiles_x[j] * ((b.Ci + 31) / 32);
         CRF_REQUIRE(tiles < ((int64_t)1 << 31) && blocks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many tiles in one batch");
     }
     ts.njobs = njobs;
+    ts.ticket = ticket;
     gp.njobs = njobs;
     hipStream_t st = crf::as_stream(stream);
-    if (n_side > 0) {
-        crf::WgJobTable wt;
-        int64_t side_blocks = 0;
-        crf::wg_fill_table(side, n_side, wt, side_blocks);
-        CRF_REQUIRE(blocks + side_blocks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many workgroups in one batch");
-        hipLaunchKernelGGL(crf::bn_bwd_tile_sums_side_kernel, dim3((unsigned)(blocks + side_blocks)), dim3(256), 0, st, ts, wt, (int)blocks);
-    } else {
-        hipLaunchKernelGGL(crf::bn_bwd_tile_sums_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ts);
-    }
+    hipLaunchKernelGGL(crf::bn_bwd_tile_sums_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ts);
     CRF_LAUNCH_CHECK();
     hipLaunchKernelGGL(crf::gemm_pro_jobs_kernel, dim3((unsigned)tiles), dim3(crf::GM_BLOCK), 0, st, gp);
     CRF_LAUNCH_CHECK();

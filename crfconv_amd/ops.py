@@ -662,28 +662,6 @@ def _defer_tn(A, B, out):
     _arm_flush()
 
 
-_SIDE_US = 8.0          # full-chip time (us, at ~40 TFLOP/s of the partial pass) of pending weight-gradient passes one coarse launch takes along
-
-
-def _take_side_partials():
-    """Pending weight-gradient partial passes (queued by _defer_weight_grad / _defer_tn) for ONE coarse-level backward launch to carry
-    as side jobs (crfconv_mlp_small_backward_jobs): oldest first, up to ~_SIDE_US of chip time, at most 32.  Returns (ctypes array or
-    None, count, keep-alive) -- the jobs leave the queue; their slab sums stay with the end-of-pass reductions as before."""
-    q = _DEFER.get('partials') or []
-    if not _DEFER['on'] or not q:
-        return None, 0, None
-    take, used = [], 0.0
-    while q and len(take) < 32:
-        j = q[0][0]
-        cost = 2.0 * j.M * j.Co * j.Ci / 40e6
-        if take and used + cost > _SIDE_US:
-            break
-        take.append(q.pop(0))
-        used += cost
-    arr = (_lib.WgradJob * len(take))(*[j for j, _ in take])
-    return arr, len(take), take
-
-
 def _arm_flush():
     if not _DEFER['armed']:
         _DEFER['armed'] = True
@@ -1554,18 +1532,8 @@ def _small_bwd(gA, y, coef, W, addend, slope, dgamma, dbeta, need_dx):
         dX = torch.empty((m, ci), dtype=torch.float32, device=dev)
         nbytes = lib.crfconv_mlp_small_backward_workspace(m, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        addend = None if addend is None else addend.contiguous()
-        side, n_side, side_keep = _take_side_partials()       # pending weight-gradient passes ride in the tile-sum launch
-        if n_side:
-            gAc = gA.contiguous()
-            job = (_lib.MlpBwdJob * 1)(_lib.MlpBwdJob(gAc.data_ptr(), y.data_ptr(), coef.data_ptr(), W.data_ptr(), None if addend is None else addend.data_ptr(),
-                                                     m, ci, co, 1, float(slope), gY.data_ptr(), dX.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                                     ws.data_ptr(), nbytes))
-            _lib.call('crfconv_mlp_small_backward_jobs', ctypes.cast(job, ctypes.c_void_p), 1, ctypes.cast(side, ctypes.c_void_p), n_side, stream_ptr())
-            del side_keep
-        else:
-            _lib.call('crfconv_mlp_small_backward', ptr(gA), ptr(y), ptr(coef), ptr(W), ptr(addend),
-                      m, ci, co, 1, float(slope), ptr(gY), ptr(dX), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr())
+        _lib.call('crfconv_mlp_small_backward', ptr(gA), ptr(y), ptr(coef), ptr(W), ptr(None if addend is None else addend.contiguous()),
+                  m, ci, co, 1, float(slope), ptr(gY), ptr(dX), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, ptr(_ticket(dev)), stream_ptr())
         return gY, dX
     nbytes = lib.crfconv_bn_workspace(m, co)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -1865,10 +1833,7 @@ class _MLPSmallGroup(torch.autograd.Function):
             jobs[i] = _lib.MlpBwdJob(gA.data_ptr(), y.data_ptr(), coef.data_ptr(), W.data_ptr(), None if add is None else add.data_ptr(), m, ci, co, 1,
                                      ctx.slopes[i], gY.data_ptr(), dX.data_ptr(), outs[0][0].data_ptr(), outs[1][0].data_ptr(), ws.data_ptr(), nbytes)
             per.append((x, W, gY, dX, outs, need_dx, (gA, add, ws)))
-        side, n_side, side_keep = _take_side_partials()       # pending weight-gradient passes ride in the tile-sum launch
-        _lib.call('crfconv_mlp_small_backward_jobs', ctypes.cast(jobs, ctypes.c_void_p), n, None if side is None else ctypes.cast(side, ctypes.c_void_p),
-                  n_side, st)
-        del side_keep
+        _lib.call('crfconv_mlp_small_backward_jobs', ctypes.cast(jobs, ctypes.c_void_p), n, ptr(_ticket(per[0][0].device)), st)
         rets = [None]
         dxs = [p[3] if p[5] else None for p in per]
         if ctx.shared and dxs[0] is not None and dxs[1] is not None:

@@ -540,7 +540,10 @@ int crfconv_mlp_small_backward_supported(int64_t M, int Ci, int Co);
 size_t crfconv_mlp_small_backward_workspace(int64_t M, int Co);
 int crfconv_mlp_small_backward(const float* gA, const float* Y, const float* coef, const float* W, const float* addend, int64_t M,
                                int Ci, int Co, int training, float slope, float* gY, float* dX, float* dgamma, float* dbeta,
-                               void* workspace, size_t workspace_bytes, crf_stream_t stream);
+                               void* workspace, size_t workspace_bytes, unsigned* ticket, crf_stream_t stream);
+/* ticket: crfconv_ticket_bytes() of zero device words per stream (left zero): the last workgroup of each column slab of the first
+ * launch finishes the two channel sums (float64, row-tile order), so the product launch loads finished means instead of every one
+ * of its workgroups re-summing all row-tile partials (round 5). */
 /* C [M, N] = A [M, K] B^T (B [N, K], the F.linear weight; N, K multiples of 4) on the same tiled kernel, with the BatchNorm statistic
  * records of C written by the epilogue: stat_rec float [crfconv_gemm_stat_records(M)][N][4] = {shift, rows, sum (v - shift),
  * sum (v - shift)^2} per 16-row group and channel -- the input of crfconv_bn_coef_from_records, so no statistics pass over C runs
@@ -564,10 +567,7 @@ int crfconv_bn_apply_from_records_jobs(const crf_bn_apply_job* jobs, int njobs, 
 typedef struct { const float* gA; const float* Y; const float* coef; const float* W; const float* addend; int64_t M; int Ci; int Co;
                  int training; float slope; float* gY; float* dX; float* dgamma; float* dbeta; void* workspace; size_t workspace_bytes;
 } crf_mlp_bwd_job;
-/* side (may be NULL, n_side <= 32): pending weight-gradient partial passes (crf_wgrad_job, the jobs of crfconv_linear_wgrad_partial_jobs)
- * that ride in the first of the two launches, behind the blocks' own tile-sum workgroups -- nothing on the backward chain waits for
- * them and a coarse launch leaves most of the chip idle. */
-int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int njobs, const crf_wgrad_job* side, int n_side, crf_stream_t stream);
+int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int njobs, unsigned* ticket, crf_stream_t stream);
 /* Up to 8 independent products C_j = A_j B_j (B_j [K_j, N_j]; N, K multiples of 4) per launch -- the g_h1 = g_h2 W2 products of all wide
  * PointConv layers of a backward pass; same tiles and summation order as crfconv_gemm on each.  jobs is a host array. */
 typedef struct { const float* A; const float* B; float* C; int64_t M; int N; int K; } crf_gemm_job;

@@ -1311,15 +1311,19 @@ def test_resnet_fork_input_gradient_added_inside_the_block_backward():
                 ops._NO_FORK_ENV = False
             res.append((out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}))
         (o1, gx1, gp1), (o2, gx2, gp2) = res
-        assert torch.equal(o1, o2)
         small = B * n_in < ops._MFMA_MIN_ROWS
+        grouped = small and cin != cout                     # round 5: lin_in and the shortcut of such a block run as ONE node (ops.mlp_group:
+        if grouped:                                         # the tiled product with statistic records), the un-forked graph as two
+            assert_close(o1, o2, 2e-6, 'out (coarse level, grouped vs one by one)')      # one-launch kernels: another summation order
+        else:
+            assert torch.equal(o1, o2)
         if small:
-            assert_close(gx1, gx2, 1e-6, 'dX (coarse level)')
+            assert_close(gx1, gx2, 1e-5 if grouped else 1e-6, 'dX (coarse level)')
         else:
             assert torch.equal(gx1, gx2), (lv, cin, cout, strided)
         for k in gp1:
-            if 'point_conv' in k and 'weight_nn.1.lin' in k:
-                assert_close(gp1[k], gp2[k], 1e-6, k)
+            if grouped or ('point_conv' in k and 'weight_nn.1.lin' in k):
+                assert_close(gp1[k], gp2[k], 1e-5 if grouped else 1e-6, k)
             else:
                 assert torch.equal(gp1[k], gp2[k]), k
 
