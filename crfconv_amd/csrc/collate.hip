@@ -30,6 +30,7 @@ struct SubsetJobs {
     int n[SUB_MAX_LEVELS];
     int s[SUB_MAX_LEVELS];
     long long* out[SUB_MAX_LEVELS];
+    int* rank[SUB_MAX_LEVELS];        // may be null: rank[i] = position of point i in the subset, -1 for a point outside it
     int nlevels;
 };
 
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(SUB_NT) void random_subsets_kernel(const SubsetJobs
     const int level = blockIdx.x;
     const int n = jobs.n[level], s = jobs.s[level];
     long long* __restrict__ out = jobs.out[level];
+    int* __restrict__ rank = jobs.rank[level];
     if (s <= 0) return;
     const unsigned long long ctr = (unsigned long long)counter[0];
     __shared__ int s_hist[256];
@@ -88,11 +90,74 @@ __global__ __launch_bounds__(SUB_NT) void random_subsets_kernel(const SubsetJobs
         __syncthreads();
     }
     int pos = s_cnt[tid] - c;
-    for (int i = lo; i < hi; ++i)
-        if ((subset_key(seed, ctr, level, i) & mask) <= prefix) {
-            if (pos < s) out[pos] = i;
-            ++pos;
+    for (int i = lo; i < hi; ++i) {
+        const bool in = (subset_key(seed, ctr, level, i) & mask) <= prefix && pos < s;
+        if (in) out[pos] = i;
+        if (rank != nullptr) rank[i] = in ? pos : -1;
+        if ((subset_key(seed, ctr, level, i) & mask) <= prefix) ++pos;
+    }
+}
+
+// ------------------------------------------------------------------ up-index from the fine level's own neighbour table
+// up_idx[b][i] = the subset member nearest to point i (datasets/semantic3d_dataset.py:524: knn_batch(sub_pos, pos, 1), the order
+// (distance, subset position) of utils/nearest_neighbors).  The level's K-nearest table (distance order, the point itself first) already
+// holds the answer for almost every point: the nearest member overall is the nearest member IN the table whenever one is there strictly
+// closer than the table's last entry -- at ratio 4 and K = 16 all but (3/4)^16 = 1 % of the points.  For the rest the wavefront scans the
+// subset together, one such point at a time (same arithmetic as csrc/knn.hip: singly-rounded x, y, z accumulation, key = distance bits
+// << 32 | position).  One launch per level instead of a grid build + search (round 4: 120 us of the 0.93 ms collate).
+__device__ __forceinline__ float up_sqdist(float qx, float qy, float qz, float px, float py, float pz) {
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    return add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+}
+constexpr unsigned long long UP_KEY_INF = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;
+__global__ __launch_bounds__(256) void upindex_table_kernel(const float* __restrict__ pos, const long long* __restrict__ nbr, int K,
+                                                            const int* __restrict__ rank, const long long* __restrict__ choice, int N, int S,
+                                                            long long* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int i0 = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i0 < N;
+    const int i = valid ? i0 : N - 1;
+    const float* P = pos + (size_t)b * N * 3;
+    const float qx = P[3 * i], qy = P[3 * i + 1], qz = P[3 * i + 2];
+    const long long* row = nbr + ((size_t)b * N + i) * K;
+    unsigned long long best = UP_KEY_INF;
+    float dlast = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int j = (int)row[k];
+        const int r = rank[j];
+        if (r >= 0 || k == K - 1) {
+            const float d = up_sqdist(qx, qy, qz, P[3 * j], P[3 * j + 1], P[3 * j + 2]);
+            if (r >= 0) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)r;
+                best = key < best ? key : best;
+            }
+            if (k == K - 1) dlast = d;
         }
+    }
+    // settled when a member of the table is strictly closer than the table's last entry (every point outside the table is at least that far)
+    bool need = valid && !(best != UP_KEY_INF && __uint_as_float((unsigned)(best >> 32)) < dlast);
+    const int lane = threadIdx.x & 63;
+    unsigned long long pending = __ballot(need);
+    while (pending != 0ull) {
+        const int src = __ffsll((long long)pending) - 1;
+        const float sx = __shfl(qx, src, 64), sy = __shfl(qy, src, 64), sz = __shfl(qz, src, 64);
+        unsigned long long mine = UP_KEY_INF;
+        for (int t = lane; t < S; t += 64) {
+            const int c = (int)choice[t];
+            const float d = up_sqdist(sx, sy, sz, P[3 * c], P[3 * c + 1], P[3 * c + 2]);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
+            mine = key < mine ? key : mine;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)mine, o, 64), hi32 = (unsigned)__shfl_xor((int)(unsigned)(mine >> 32), o, 64);
+            const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
+            mine = other < mine ? other : mine;
+        }
+        if (lane == src) { best = mine; need = false; }
+        pending &= pending - 1ull;
+    }
+    if (valid) out[(size_t)b * N + i] = (long long)(best & 0xffffffffull);
 }
 
 // ------------------------------------------------------------------ stable argsort of 30-bit codes, per cloud
@@ -196,18 +261,31 @@ __global__ __launch_bounds__(256) void gather_rows_batched_kernel(const GatherRo
 
 using namespace crf;
 
-extern "C" int crfconv_random_subsets(const int* n, const int* s, int64_t* const* out, int nlevels, uint64_t seed,
+extern "C" int crfconv_upindex_from_table(const float* pos, const int64_t* neighbor_idx, const int32_t* rank, const int64_t* choice,
+                                          int64_t B, int64_t N, int K, int64_t S, int64_t* up_idx, crf_stream_t stream) {
+    CRF_REQUIRE(pos && neighbor_idx && rank && choice && up_idx, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && N < ((int64_t)1 << 30) && S >= 1 && S <= N && K >= 1 && K <= 64 && K <= N, CRF_ERR_ARG,
+                "bad shape B=%lld N=%lld K=%d S=%lld", (long long)B, (long long)N, K, (long long)S);
+    hipLaunchKernelGGL(upindex_table_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, as_stream(stream), pos,
+                       reinterpret_cast<const long long*>(neighbor_idx), K, rank, reinterpret_cast<const long long*>(choice), (int)N, (int)S,
+                       reinterpret_cast<long long*>(up_idx));
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+extern "C" int crfconv_random_subsets(const int* n, const int* s, int64_t* const* out, int32_t* const* rank, int nlevels, uint64_t seed,
                                       const int64_t* counter, crf_stream_t stream) {
     CRF_REQUIRE(n && s && out && counter, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(nlevels >= 1 && nlevels <= SUB_MAX_LEVELS, CRF_ERR_ARG, "nlevels=%d outside [1, %d]", nlevels, SUB_MAX_LEVELS);
     SubsetJobs jobs;
     jobs.nlevels = nlevels;
     for (int l = 0; l < SUB_MAX_LEVELS; ++l) {
-        jobs.n[l] = 0; jobs.s[l] = 0; jobs.out[l] = nullptr;
+        jobs.n[l] = 0; jobs.s[l] = 0; jobs.out[l] = nullptr; jobs.rank[l] = nullptr;
         if (l < nlevels) {
             CRF_REQUIRE(n[l] >= 1 && n[l] <= (1 << 20) && s[l] >= 0 && s[l] <= n[l] && (s[l] == 0 || out[l]), CRF_ERR_ARG,
                         "level %d: n=%d s=%d (1 <= n <= 2^20, 0 <= s <= n)", l, n[l], s[l]);
             jobs.n[l] = n[l]; jobs.s[l] = s[l]; jobs.out[l] = reinterpret_cast<long long*>(out[l]);
+            jobs.rank[l] = rank ? rank[l] : nullptr;
         }
     }
     hipLaunchKernelGGL(random_subsets_kernel, dim3((unsigned)nlevels), dim3(SUB_NT), 0, as_stream(stream), jobs,

@@ -71,6 +71,12 @@ struct GemmPro {
     float* gY;                 // [M, K] out
 };
 
+template <int WM, int WN, int WR, int WC, bool BNK, bool PRO>
+constexpr int gemm_lds_floats() {
+    constexpr int BM = 16 * WM * WR, BN = 16 * WN * WC;
+    return (PRO ? 6 * GM_PRO_MAXK : 0) + 2 * BM * (GM_BK + 4) + 2 * (BNK ? BN * (GM_BK + 4) : GM_BK * (BN + 4));
+}
+
 // STATS form (crfconv_gemm_stats): the epilogue also leaves BatchNorm statistic records of the tile it holds -- one
 // {shift, rows, sum (v - shift), sum (v - shift)^2} tuple per 16-row group and output channel, the layout
 // crfconv_bn_coef_from_records combines (Chan, float64) -- so the statistics pass over Y never runs.
@@ -78,10 +84,10 @@ template <int WM, int WN, int WR, int WC, bool BNK, bool VEC, bool PRO, bool STA
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const float* __restrict__ B,
                                           const float* __restrict__ bias, const float* __restrict__ addend,
                                           int M, int N, int K, float* __restrict__ C, const GemmPro& pro,
-                                          float* __restrict__ stat_rec, const unsigned bx, const unsigned by) {
+                                          float* __restrict__ stat_rec, const unsigned bx, const unsigned by,
+                                          float* __restrict__ lds /*gemm_lds_floats<...>() floats, 16-byte aligned: the kernel's ONE buffer*/) {
     static_assert(WR * WC * WAVE == GM_BLOCK, "four wavefronts");
     static_assert(!PRO || (VEC && !BNK), "the prologue form is the dX product of aligned widths");
-    __shared__ float sPro[PRO ? 6 * GM_PRO_MAXK : 1];      // a | b | mean | rstd | sum g1 / M | sum g1 yh / M
     constexpr int BM = 16 * WM * WR, BN = 16 * WN * WC;
     constexpr int LDA = GM_BK + 4;                      // [BM][LDA]: 16-byte fragment reads along k, 8 lanes cover the 32 banks
     constexpr int LDN = GM_BK + 4;                      // BNK: [BN][LDN], read like A
@@ -89,8 +95,10 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const flo
     constexpr int TA = BM * LDA, TB = BNK ? BN * LDN : GM_BK * LDK;
     constexpr int NA4 = BM * GM_BK / 4, NB4 = BN * GM_BK / 4;       // float4 per tile
     constexpr int PA = (NA4 + GM_BLOCK - 1) / GM_BLOCK, PB = (NB4 + GM_BLOCK - 1) / GM_BLOCK;
-    __shared__ float sA[2][TA];
-    __shared__ float sB[2][TB];
+    // a kernel that serves several tile classes (the job forms) owns one LDS buffer of the largest: static arrays here would add up
+    float* const sPro = lds;                            // PRO: a | b | mean | rstd | sum g1 / M | sum g1 yh / M
+    float (*sA)[TA] = reinterpret_cast<float (*)[TA]>(lds + (PRO ? 6 * GM_PRO_MAXK : 0));
+    float (*sB)[TB] = reinterpret_cast<float (*)[TB]>(lds + (PRO ? 6 * GM_PRO_MAXK : 0) + 2 * TA);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rr = lane & 15, g = lane >> 4;
     const int wr = wave / WC, wc = wave - wr * WC;
@@ -299,7 +307,8 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_kernel(const float* __restrict_
                                                         const float* __restrict__ bias, const float* __restrict__ addend,
                                                         int M, int N, int K, float* __restrict__ C, const GemmPro pro = GemmPro(),
                                                         float* __restrict__ stat_rec = nullptr) {
-    gemm_tile<WM, WN, WR, WC, BNK, VEC, PRO, STATS>(A, B, bias, addend, M, N, K, C, pro, stat_rec, blockIdx.x, blockIdx.y);
+    __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<WM, WN, WR, WC, BNK, PRO>()];
+    gemm_tile<WM, WN, WR, WC, BNK, VEC, PRO, STATS>(A, B, bias, addend, M, N, K, C, pro, stat_rec, blockIdx.x, blockIdx.y, lds);
 }
 
 // SEVERAL products C_j = A_j B_j (B [K, N], aligned widths, 32 x 32 tiles) in one launch: the tiles of the jobs are laid end to
@@ -316,8 +325,9 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_jobs_kernel(const GemmJobs t) {
     int j = 0;
     while (j + 1 < t.njobs && t.tile_base[j + 1] <= (int)blockIdx.x) ++j;
     const unsigned local = blockIdx.x - (unsigned)t.tile_base[j];
+    __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<1, 1, 2, 2, false, false>()];
     gemm_tile<1, 1, 2, 2, false, true, false, false>(t.A[j], t.B[j], nullptr, nullptr, t.M[j], t.N[j], t.K[j], t.C[j], GemmPro(), nullptr,
-                                                     local % (unsigned)t.tiles_x[j], local / (unsigned)t.tiles_x[j]);
+                                                     local % (unsigned)t.tiles_x[j], local / (unsigned)t.tiles_x[j], lds);
 }
 
 // INDEPENDENT coarse-level MLP blocks in one launch (round 5): the STATS product of each job (crfconv_gemm_stats_jobs) and the PRO
@@ -326,9 +336,18 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_jobs_kernel(const GemmJobs t) {
 // (models/continuous_crf_conv_big.py:56-60), shortcut / lin_in of a strided ResNet block (models/point_conv_big.py:79-88) -- run side
 // by side for the price of the longer one.  Same tiles, same summation order as the one-job launches.
 constexpr int GG_MAX = 4;
+// wide[j]: the job's tiles are 32 rows x 64 columns (a wavefront owns 16 x 32: the A fragment feeds two products, half the
+// workgroups pay the load -> LDS -> store chain) -- the flop-heavy layers (GM_WIDE_MIN_N_ columns and GM_WIDE_MIN_TILES_ 32 x 32 tiles).
+#ifndef GM_WIDE_MIN_N_
+#define GM_WIDE_MIN_N_ 128
+#endif
+#ifndef GM_WIDE_MIN_TILES_
+#define GM_WIDE_MIN_TILES_ 1024
+#endif
+static inline bool gm_wide(int64_t M, int N) { return N >= GM_WIDE_MIN_N_ && ((M + 31) / 32) * (int64_t)((N + 31) / 32) >= GM_WIDE_MIN_TILES_; }
 struct GemmStatsJobs {
     const float* A[GG_MAX]; const float* B[GG_MAX]; float* C[GG_MAX]; float* rec[GG_MAX];
-    int M[GG_MAX], N[GG_MAX], K[GG_MAX], tiles_x[GG_MAX];
+    int M[GG_MAX], N[GG_MAX], K[GG_MAX], tiles_x[GG_MAX], wide[GG_MAX];
     int tile_base[GG_MAX + 1];
     int njobs;
 };
@@ -336,13 +355,20 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_stats_jobs_kernel(const GemmSta
     int j = 0;
     while (j + 1 < t.njobs && t.tile_base[j + 1] <= (int)blockIdx.x) ++j;
     const unsigned local = blockIdx.x - (unsigned)t.tile_base[j];
-    gemm_tile<1, 1, 2, 2, true, true, false, true>(t.A[j], t.B[j], nullptr, nullptr, t.M[j], t.N[j], t.K[j], t.C[j], GemmPro(), t.rec[j],
-                                                   local % (unsigned)t.tiles_x[j], local / (unsigned)t.tiles_x[j]);
+    const unsigned tx = (unsigned)uni(t.tiles_x[j]);
+    const unsigned bx = (unsigned)uni((int)(local % tx)), by = (unsigned)uni((int)(local / tx));
+    __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<1, 2, 2, 2, true, false>()];
+    if (uni(t.wide[j]))
+        gemm_tile<1, 2, 2, 2, true, true, false, true>(uni(t.A[j]), uni(t.B[j]), nullptr, nullptr, uni(t.M[j]), uni(t.N[j]), uni(t.K[j]), uni(t.C[j]), GemmPro(),
+                                                       uni(t.rec[j]), bx, by, lds);
+    else
+        gemm_tile<1, 1, 2, 2, true, true, false, true>(uni(t.A[j]), uni(t.B[j]), nullptr, nullptr, uni(t.M[j]), uni(t.N[j]), uni(t.K[j]), uni(t.C[j]), GemmPro(),
+                                                       uni(t.rec[j]), bx, by, lds);
 }
 struct GemmProJobs {
     const float* A[GG_MAX]; const float* B[GG_MAX]; const float* addend[GG_MAX]; float* C[GG_MAX];
     GemmPro pro[GG_MAX];
-    int M[GG_MAX], N[GG_MAX], K[GG_MAX], tiles_x[GG_MAX];
+    int M[GG_MAX], N[GG_MAX], K[GG_MAX], tiles_x[GG_MAX], wide[GG_MAX];
     int tile_base[GG_MAX + 1];
     int njobs;
 };
@@ -353,8 +379,14 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_pro_jobs_kernel(const GemmProJo
     GemmPro pro;                                        // the job's entry, pinned into scalar registers
     pro.Y = uni(t.pro[j].Y); pro.coef = uni(t.pro[j].coef); pro.fin = uni(t.pro[j].fin); pro.slope = uni(t.pro[j].slope); pro.gY = uni(t.pro[j].gY);
     const unsigned tx = (unsigned)uni(t.tiles_x[j]);
-    gemm_tile<1, 1, 2, 2, false, true, true, false>(uni(t.A[j]), uni(t.B[j]), nullptr, uni(t.addend[j]), uni(t.M[j]), uni(t.N[j]), uni(t.K[j]), uni(t.C[j]),
-                                                    pro, nullptr, (unsigned)uni((int)(local % tx)), (unsigned)uni((int)(local / tx)));
+    const unsigned bx = (unsigned)uni((int)(local % tx)), by = (unsigned)uni((int)(local / tx));
+    __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<1, 2, 2, 2, false, true>()];
+    if (uni(t.wide[j]))
+        gemm_tile<1, 2, 2, 2, false, true, true, false>(uni(t.A[j]), uni(t.B[j]), nullptr, uni(t.addend[j]), uni(t.M[j]), uni(t.N[j]), uni(t.K[j]), uni(t.C[j]),
+                                                        pro, nullptr, bx, by, lds);
+    else
+        gemm_tile<1, 1, 2, 2, false, true, true, false>(uni(t.A[j]), uni(t.B[j]), nullptr, uni(t.addend[j]), uni(t.M[j]), uni(t.N[j]), uni(t.K[j]), uni(t.C[j]),
+                                                        pro, nullptr, bx, by, lds);
 }
 
 }  // namespace crf
@@ -535,7 +567,7 @@ extern "C" int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int 
             ts.gA[j] = nullptr; ts.Y[j] = nullptr; ts.coef[j] = nullptr; ts.partial[j] = nullptr; ts.M[j] = 0; ts.K[j] = 4; ts.tile_rows[j] = crf::BT_ROWS;
             ts.ntile[j] = 1; ts.slope[j] = 1.f; ts.fin[j] = nullptr; ts.dgamma[j] = nullptr; ts.dbeta[j] = nullptr; ts.training[j] = 0; ts.inv_m[j] = 0.f;
             gp.A[j] = nullptr; gp.B[j] = nullptr; gp.addend[j] = nullptr; gp.C[j] = nullptr; gp.pro[j] = crf::GemmPro(); gp.M[j] = 0; gp.N[j] = 4; gp.K[j] = 4;
-            gp.tiles_x[j] = 1;
+            gp.tiles_x[j] = 1; gp.wide[j] = 0;
             continue;
         }
         const crf_mlp_bwd_job& b = jobs[j];
@@ -555,7 +587,8 @@ extern "C" int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int 
         pro.Y = b.Y; pro.coef = b.coef; pro.fin = fin; pro.slope = b.slope; pro.gY = b.gY;
         gp.A[j] = b.gA; gp.B[j] = b.W; gp.addend[j] = b.addend; gp.C[j] = b.dX; gp.pro[j] = pro; gp.M[j] = (int)b.M; gp.N[j] = b.Ci; gp.K[j] = b.Co;
         gp.tiles_x[j] = (int)((b.M + 31) / 32);
-        tiles += (int64_t)gp.tiles_x[j] * ((b.Ci + 31) / 32);
+        gp.wide[j] = crf::gm_wide(b.M, b.Ci) ? 1 : 0;
+        tiles += (int64_t)gp.tiles_x[j] * ((b.Ci + (gp.wide[j] ? 63 : 31)) / (gp.wide[j] ? 64 : 32));
         CRF_REQUIRE(tiles < ((int64_t)1 << 31) && blocks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many tiles in one batch");
     }
     ts.njobs = njobs;
@@ -575,14 +608,9 @@ extern "C" size_t crfconv_gemm_stat_records(int64_t M) { return M < 1 ? 0 : (siz
 // float [crfconv_gemm_stat_records(M)][N][4] = {shift, rows, sum (v - shift), sum (v - shift)^2} per 16-row group and channel,
 // to be combined by crfconv_bn_coef_from_records.  N, K multiples of 4.
 extern "C" int crfconv_gemm_stats(const float* A, const float* B, int64_t M, int N, int K, float* C, float* stat_rec, void* stream) {
-    CRF_REQUIRE(A && B && C && stat_rec, CRF_ERR_ARG, "null pointer");
-    CRF_REQUIRE(M >= 1 && M < ((int64_t)1 << 31) && N >= 4 && K >= 4 && N % 4 == 0 && K % 4 == 0, CRF_ERR_UNSUPPORTED,
-                "gemm_stats %lld x %d x %d: N and K must be multiples of 4", (long long)M, N, K);
-    const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32)), blk(crf::GM_BLOCK);
-    hipLaunchKernelGGL((crf::gemm_kernel<1, 1, 2, 2, true, true, false, true>), grid, blk, 0, crf::as_stream(stream), A, B,
-                       (const float*)nullptr, (const float*)nullptr, (int)M, N, K, C, crf::GemmPro(), stat_rec);
-    CRF_LAUNCH_CHECK();
-    return CRF_OK;
+    crf_gemm_stats_job job;
+    job.A = A; job.B = B; job.M = M; job.N = N; job.K = K; job.C = C; job.stat_rec = stat_rec;
+    return crfconv_gemm_stats_jobs(&job, 1, stream);
 }
 
 // crfconv_gemm_stats for up to 4 independent products in ONE launch: C_j = A_j B_j^T with the statistic records of each C_j.
@@ -594,7 +622,7 @@ extern "C" int crfconv_gemm_stats_jobs(const crf_gemm_stats_job* jobs, int njobs
         t.tile_base[j] = (int)tiles;
         if (j >= crf::GG_MAX) break;
         if (j >= njobs) {
-            t.A[j] = nullptr; t.B[j] = nullptr; t.C[j] = nullptr; t.rec[j] = nullptr; t.M[j] = 0; t.N[j] = 4; t.K[j] = 4; t.tiles_x[j] = 1;
+            t.A[j] = nullptr; t.B[j] = nullptr; t.C[j] = nullptr; t.rec[j] = nullptr; t.M[j] = 0; t.N[j] = 4; t.K[j] = 4; t.tiles_x[j] = 1; t.wide[j] = 0;
             continue;
         }
         const crf_gemm_stats_job& b = jobs[j];
@@ -603,7 +631,8 @@ extern "C" int crfconv_gemm_stats_jobs(const crf_gemm_stats_job* jobs, int njobs
                     "job %d: gemm_stats %lld x %d x %d: N and K must be multiples of 4", j, (long long)b.M, b.N, b.K);
         t.A[j] = b.A; t.B[j] = b.B; t.C[j] = b.C; t.rec[j] = b.stat_rec; t.M[j] = (int)b.M; t.N[j] = b.N; t.K[j] = b.K;
         t.tiles_x[j] = (int)((b.M + 31) / 32);
-        tiles += (int64_t)t.tiles_x[j] * ((b.N + 31) / 32);
+        t.wide[j] = crf::gm_wide(b.M, b.N) ? 1 : 0;
+        tiles += (int64_t)t.tiles_x[j] * ((b.N + (t.wide[j] ? 63 : 31)) / (t.wide[j] ? 64 : 32));
         CRF_REQUIRE(tiles < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many tiles in one batch");
     }
     t.njobs = njobs;

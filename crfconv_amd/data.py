@@ -159,10 +159,11 @@ def morton_order(pos, out=None):
     return order
 
 
-def random_subsets_device(sizes, counts, seed, counter, outs):
+def random_subsets_device(sizes, counts, seed, counter, outs, ranks=None):
     """outs[l] [counts[l]] int64 (device) <- a uniformly random subset of range(sizes[l]) in ascending order, one launch for all
     levels (csrc/collate.hip: crfconv_random_subsets).  A function of (seed, counter[0], l): `counter` is a one-element int64
-    DEVICE tensor the caller advances per batch.  Not torch.randperm's draws."""
+    DEVICE tensor the caller advances per batch.  Not torch.randperm's draws.  ranks[l] [sizes[l]] int32 (optional): the membership
+    table of the subset (position of a point in it, -1 outside) for up_index_from_table."""
     import ctypes
     from . import _lib
     from .graph import stream_ptr
@@ -173,8 +174,32 @@ def random_subsets_device(sizes, counts, seed, counter, outs):
     for t, c in zip(outs, counts):
         if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.numel() >= c):
             raise _lib.CrfConvError('random_subsets_device: outputs must be contiguous int64 device tensors of the subset sizes')
+    r = None
+    if ranks is not None:
+        for t, c in zip(ranks, sizes):
+            if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() >= c):
+                raise _lib.CrfConvError('random_subsets_device: ranks must be contiguous int32 device tensors of the level sizes')
+        r = ctypes.cast((ctypes.c_void_p * L)(*[t.data_ptr() for t in ranks]), ctypes.c_void_p)
     _lib.call('crfconv_random_subsets', ctypes.cast(n, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p),
-              ctypes.cast(o, ctypes.c_void_p), L, int(seed) & 0xFFFFFFFFFFFFFFFF, counter.data_ptr(), stream_ptr())
+              ctypes.cast(o, ctypes.c_void_p), r, L, int(seed) & 0xFFFFFFFFFFFFFFFF, counter.data_ptr(), stream_ptr())
+
+
+def up_index_from_table(pos, neighbor_idx, choice, rank=None):
+    """up_idx [B, N, 1] int64 = knn_batch(pos[:, choice], pos, 1) (datasets/semantic3d_dataset.py:524), bit-identical, from the level's own
+    K-nearest table (csrc/collate.hip: crfconv_upindex_from_table).  choice [S] int64: the subset shared by the clouds; rank [N] int32:
+    its membership table (built here when the caller has none)."""
+    from . import _lib
+    from .graph import ptr, stream_ptr
+    B, N, K = neighbor_idx.shape
+    S = choice.numel()
+    if rank is None:
+        rank = torch.full((N,), -1, dtype=torch.int32, device=pos.device)
+        rank[choice] = torch.arange(S, dtype=torch.int32, device=pos.device)
+    pos = pos.detach().to(torch.float32).contiguous()
+    out = torch.empty((B, N, 1), dtype=torch.int64, device=pos.device)
+    _lib.call('crfconv_upindex_from_table', ptr(pos), ptr(neighbor_idx.contiguous()), ptr(rank), ptr(choice.contiguous()), B, N, K, S, ptr(out),
+              stream_ptr())
+    return out
 
 
 def _fps_choice(pos, n_sample):
@@ -236,7 +261,7 @@ def pick_rows(tensors, index, per_cloud):
 
 def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kernel_size=(16, 16, 16, 16, 16),
                        ratio=(4, 4, 4, 4, 2), num_scales=5, generator=None, choices=None, sort=None,
-                       sample_method='random', order=None):
+                       sample_method='random', order=None, ranks=None):
     """The reference collate on the device (datasets/semantic3d_dataset.py:512-528):
     per scale  neighbor_idx = knn(pos, pos, K);  one random subset shared by all clouds;
     sub_idx = neighbor_idx[:, choice];  up_idx = knn(sub_pos, pos, 1).
@@ -288,7 +313,12 @@ def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kern
                 choice = choice.sort().values
             choice = choice.to(pos.device)
         sub_pos, sub_idx = pick_rows([pos, neighbor_idx], choice, per_cloud=False)
-        up_idx = nearest_neighbors.knn_batch_device(sub_pos, pos, 1)
+        if kernel_size[i] >= 4:
+            # the nearest subset member of a point is almost always one of its own K nearest neighbours: answered from the table
+            # (bit-identical to the K = 1 search; `ranks`: the subsets' membership tables where the caller has them)
+            up_idx = up_index_from_table(pos, neighbor_idx, choice, None if ranks is None else ranks[i])
+        else:
+            up_idx = nearest_neighbors.knn_batch_device(sub_pos, pos, 1)
         multiscale.append(Data(pos=pos, neighbor_idx=neighbor_idx, sub_idx=sub_idx, up_idx=up_idx))
         pos = sub_pos
     return MultiScaleData(x=x, y=y, point_idx=point_idx, cloud_idx=cloud_idx, multiscale=multiscale, order=order)
@@ -330,6 +360,7 @@ class CollateGraph:
         self.sizes = [lvl.pos.shape[1] for lvl in ms]
         self.order = torch.empty(ms[0].pos.shape[:2], dtype=torch.int64, device=dev)
         self.choices = [torch.empty(n // r, dtype=torch.int64, device=dev) for n, r in zip(self.sizes, self.ratio)]
+        self.ranks = [torch.empty(n, dtype=torch.int32, device=dev) for n in self.sizes]      # membership tables of the subsets (device draw)
         self._pinned = [torch.empty(c.shape, dtype=torch.int64).pin_memory() for c in self.choices]
         # host buffers allocated once: a process that holds GPU memory pays for every large host malloc/free pair (the
         # unmap goes through the driver's MMU notifier -- measured 70-90 ms stalls in a loop that allocated per batch)
@@ -365,10 +396,11 @@ class CollateGraph:
             from . import _lib
             from .graph import ptr, stream_ptr
             _lib.call('crfconv_add_i64', ptr(self.counter), 1, 1, stream_ptr())       # counter += 1 (a library launch: no framework kernel in the graph)
-            random_subsets_device(self.sizes, [c.numel() for c in self.choices], self.seed, self.counter, self.choices)
+            random_subsets_device(self.sizes, [c.numel() for c in self.choices], self.seed, self.counter, self.choices, ranks=self.ranks)
             morton_order(self.pos, out=self.order)
         new = multiscale_compute(self.pos, x=self.x, y=self.y, kernel_size=self.kernel_size, ratio=self.ratio,
-                                 num_scales=len(self.sizes), choices=self.choices, sort='morton', order=self.order)
+                                 num_scales=len(self.sizes), choices=self.choices, sort='morton', order=self.order,
+                                 ranks=self.ranks if self.device_draw else None)
         self.target.load_(new)
 
     def run(self, pos, x=None, y=None):

@@ -732,8 +732,17 @@ int crfconv_sgd_guard_publish(const unsigned* const* fail_words, int n_fail_word
  *   n, s, out are host arrays; n[l] <= 2^20; nlevels <= 8.
  * crfconv_argsort_codes: order [B, N] int64 = per-cloud stable argsort of code [B, N] int64 (30-bit Morton codes):
  *   bit-identical to torch.argsort(code, dim=1, stable=True), without scratch memory (capturable on ROCm 7.2). */
-int crfconv_random_subsets(const int* n, const int* s, int64_t* const* out, int nlevels, uint64_t seed,
+int crfconv_random_subsets(const int* n, const int* s, int64_t* const* out, int32_t* const* rank, int nlevels, uint64_t seed,
                            const int64_t* counter, crf_stream_t stream);
+/* rank (host array of device int32 [n[l]] pointers, or NULL; entries may be NULL): rank[l][i] = position of point i in subset l, -1
+ * outside -- the membership table of crfconv_upindex_from_table.
+ * crfconv_upindex_from_table: up_idx [B, N] int64 = for every point of a level the position (in `choice` [S] int64, the subset shared by
+ *   the B clouds) of the nearest subset member -- knn_batch(sub_pos, pos, 1) of datasets/semantic3d_dataset.py:524, bit-identical incl.
+ *   the (distance, position) order on ties --, answered from the level's own K-nearest table neighbor_idx [B, N, K] int64 (distance
+ *   order, as crfconv_knn_batch_dev writes it) where a member is in it, by a wavefront-wide scan of the subset for the ~1 % of points
+ *   where none is (round 5: one launch per level instead of a grid build + search). */
+int crfconv_upindex_from_table(const float* pos, const int64_t* neighbor_idx, const int32_t* rank, const int64_t* choice, int64_t B,
+                               int64_t N, int K, int64_t S, int64_t* up_idx, crf_stream_t stream);
 /* Rows of up to 8 [B, N, row_bytes[j]] tensors picked by one index list in one launch: dst[j][b][s] = src[j][b][index[s]]
  * (index [S], shared by all clouds: datasets/semantic3d_dataset.py:524-526 pos[:, choice], neighbor_idx[:, choice]) or
  * src[j][b][index[b][s]] (per_cloud != 0: the Morton permutation, farthest-point picks).  row_bytes multiples of 4; src, dst,

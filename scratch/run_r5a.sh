@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 tag=${1:-r5a}
 mkdir -p gpurun_out/$tag
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/$tag/tests.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/$tag/tests.log | cut -c1-300
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/$tag/tests.log 2>&1; echo "pytest rc=$?"; grep -E "^FAILED|passed|failed" gpurun_out/$tag/tests.log | tail -8 | cut -c1-200
 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-other-configs --steps 40 > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err || { echo "bench failed"; tail -5 gpurun_out/$tag/bench.err | cut -c1-300; }
 python3 -c "
 import json; r=json.load(open('gpurun_out/$tag/bench.json')); print('ms_per_step %.4f  value %.2f  pipelined %.3f  eager %.2f captured %.2f' % (r['ms_per_step'], r['value'], r['pipelined_ms_per_batch'] or 0, r['trainval_eager_ms_per_step'] or 0, r['trainval_captured_ms_per_step'] or 0))"

@@ -341,6 +341,45 @@ def test_random_subsets_device():
     assert abs(float(hits.float().mean()) - 50.0) < 1e-6 and int(hits.min()) >= 20 and int(hits.max()) <= 85
 
 
+def test_up_index_from_the_neighbour_table_equals_the_k1_search():
+    """data.up_index_from_table (round 5: the nearest subset member of a point read off its own K-nearest table, a wavefront-wide
+    scan of the subset for the points without a member in the table) must be bit-identical to knn_batch(sub_pos, pos, 1)
+    (datasets/semantic3d_dataset.py:524): random clouds, an UNSORTED subset (ties go to the lower subset position), tie-heavy lattice
+    coordinates, a short table, a subset so thin that most points take the scan, the membership table of the device draw."""
+    from crfconv_amd.data import random_subsets_device, up_index_from_table
+    from crfconv_amd.utils.nearest_neighbors import knn_batch_device
+    g = torch.Generator().manual_seed(77)
+
+    def check(pos, choice, K, rank=None, what=''):
+        nbr = knn_batch_device(pos, pos, K)
+        want = knn_batch_device(pos[:, choice].contiguous(), pos, 1)
+        got = up_index_from_table(pos, nbr, choice, rank)
+        assert got.shape == want.shape and got.dtype == torch.int64
+        assert torch.equal(got, want), (what, int((got != want).sum()))
+    for B, N, ratio, K in ((4, 40960, 4, 16), (2, 10240, 4, 16), (3, 2560, 2, 16), (2, 4096, 64, 16), (2, 4096, 4, 4), (1, 777, 3, 16), (2, 100, 4, 32)):
+        pos = torch.rand(B, N, 3, generator=g).to('cuda')
+        choice = torch.randperm(N, generator=g)[: N // ratio].to('cuda')
+        check(pos, choice, K, what='unsorted %s' % ((B, N, ratio, K),))
+        check(pos, choice.sort().values, K, what='sorted %s' % ((B, N, ratio, K),))
+    lat = (torch.randint(0, 32, (2, 8192, 3), generator=g).float() / 32).to('cuda')          # many equal distances, duplicate points
+    for ratio in (4, 16):
+        choice = torch.randperm(8192, generator=g)[: 8192 // ratio].to('cuda')
+        check(lat, choice, 16, what='lattice unsorted %d' % ratio)
+        check(lat, choice.sort().values, 16, what='lattice sorted %d' % ratio)
+    # the membership tables the device draw leaves
+    sizes, counts = [40960, 10240], [10240, 2560]
+    ctr = torch.ones(1, dtype=torch.int64, device='cuda')
+    outs = [torch.empty(c, dtype=torch.int64, device='cuda') for c in counts]
+    ranks = [torch.full((n,), -7, dtype=torch.int32, device='cuda') for n in sizes]
+    random_subsets_device(sizes, counts, 5, ctr, outs, ranks=ranks)
+    for n, c, o, r in zip(sizes, counts, outs, ranks):
+        ref = torch.full((n,), -1, dtype=torch.int32, device='cuda')
+        ref[o] = torch.arange(c, dtype=torch.int32, device='cuda')
+        assert torch.equal(r, ref)
+    pos = torch.rand(4, 40960, 3, generator=g).to('cuda')
+    check(pos, outs[0], 16, rank=ranks[0], what='device draw')
+
+
 def test_reverse_csr_batched_equals_one_by_one():
     """graph.batched_reverse: the reverse CSRs of several tables of different shapes (a hub row, K = 1, K = 32)
     built by one crfconv_reverse_csr_batched call must equal the one-table-at-a-time builds bit for bit."""
