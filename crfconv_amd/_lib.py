@@ -63,6 +63,8 @@ SIGNATURES = {
     'crfconv_pointconv_bwd_a1_workspace': (_sz, [_i64, _i]),
     'crfconv_pointconv_bwd_a1': (_i, [_vp, _vp, _vp, _i64, _i, _f, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_bwd_input': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    'crfconv_pointconv_bwd_input_reduce': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i,
+                                                _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'crfconv_pointconv_fold1': (_i, [_vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_fold1_batched': (_i, [_vp, _i, _vp]),
     'crfconv_pointconv_fold1_bwd_batched': (_i, [_vp, _i, _vp]),

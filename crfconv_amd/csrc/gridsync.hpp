@@ -127,7 +127,8 @@ __device__ __forceinline__ void st1_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, 
 // ticket: LW_TICKET_WORDS zero words (all left zero).
 constexpr unsigned LW_GROUPS = LASTWG_GROUPS_, LW_FLAT = LASTWG_FLAT_, LW_TICKET_WORDS = (1 + 32) * FW_LINE;
 static_assert(LW_GROUPS <= 32, "ticket lines");
-__device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned nblk, int* s_flag) {
+// bid: this workgroup's index among the nblk that draw on `ticket` (a launch that hosts a second job numbers each job's workgroups itself)
+__device__ __forceinline__ bool last_workgroup_of(unsigned* ticket, unsigned nblk, int* s_flag, const unsigned bid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -136,7 +137,6 @@ __device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned nblk, 
             const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last = old + 1 == nblk;
         } else {
-            const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
             const unsigned g = bid % LW_GROUPS, n_in_group = nblk / LW_GROUPS + (g < nblk % LW_GROUPS ? 1u : 0u);
             unsigned* gt = ticket + (1 + g) * FW_LINE;
             const unsigned old = __hip_atomic_fetch_add(gt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -151,6 +151,9 @@ __device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned nblk, 
     }
     __syncthreads();
     return *s_flag != 0;
+}
+__device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned nblk, int* s_flag) {
+    return last_workgroup_of(ticket, nblk, s_flag, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 // In the last workgroup (every thread of it calls; the first NT take part): s_tot[slot] = sum_b partial[b][slot] in double for
 // nslots (a multiple of 4, nslots / 4 dividing NT) slots of nblk rows.  Thread (group g, quad) adds rows g, g + groups, ... in

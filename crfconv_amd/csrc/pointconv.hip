@@ -667,51 +667,61 @@ __device__ __forceinline__ void fold2_bwd_coef(int c, int d, double sum_gw, doub
 
 // With a ticket word the LAST workgroup to finish adds the partial rows and derives the coefficients itself (gridsync.hpp:
 // fold2_bwd_partials_kernel's launch disappears); ticket == nullptr leaves the rows for that kernel.
-__global__ __launch_bounds__(256) void uv_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ U,
-                                                            const float* __restrict__ V, int64_t m, int d,
-                                                            float* __restrict__ partial, unsigned* __restrict__ ticket,
-                                                            const float* __restrict__ shift, const double* __restrict__ aux2,
-                                                            const float* __restrict__ gamma, double n_edges, int use_batch,
-                                                            float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    extern __shared__ float s_uv[];                  // [rows per trip][2][d]
+struct UvRed {                      // arguments of the BatchNorm-2 backward reduction of one PointConv layer (uv_bwd_reduce_body)
+    const float* g; const float* U; const float* V;
+    long long m;
+    int d, nblk;
+    float* partial;
+    unsigned* ticket;
+    const float* shift; const double* aux2; const float* gamma;
+    double n_edges;
+    int use_batch;
+    float* ca; float* cb; float* cc; float* dgamma; float* dbeta;
+};
+// bid of r.nblk workgroups of 256 threads.  (2 d (256 / (d / 4)) = 2048 floats of LDS whatever d is.)
+__device__ __forceinline__ void uv_bwd_reduce_body(const UvRed& r, const unsigned bid) {
+    __shared__ float s_uv[2048];                     // [rows per trip][2][d]
     __shared__ double s_buf[4 * 256], s_tot[256];
     __shared__ int s_flag;
+    const float* __restrict__ g = r.g; const float* __restrict__ U = r.U; const float* __restrict__ V = r.V;
+    const int64_t m = r.m;
+    const int d = r.d;
     const int d4 = d >> 2, rpi = 256 / d4;
     const int q = threadIdx.x % d4, rl = threadIdx.x / d4;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-    const int64_t stride = (int64_t)gridDim.x * rpi;
+    const int64_t stride = (int64_t)r.nblk * rpi;
     auto add = [&](const float4 gg, const float4 uu, const float4 vv) {
         s1 = make_float4(fmaf(gg.x, vv.x, s1.x), fmaf(gg.y, vv.y, s1.y), fmaf(gg.z, vv.z, s1.z), fmaf(gg.w, vv.w, s1.w));
         s2 = make_float4(fmaf(gg.x, uu.x, s2.x), fmaf(gg.y, uu.y, s2.y), fmaf(gg.z, uu.z, s2.z), fmaf(gg.w, uu.w, s2.w));
     };
-    int64_t r = (int64_t)blockIdx.x * rpi + rl;
-    for (; r + stride < m; r += 2 * stride) {        // two rows (six 16-byte loads) in flight per thread
-        const int64_t o0 = r * d + 4 * q, o1 = (r + stride) * d + 4 * q;
+    int64_t row = (int64_t)bid * rpi + rl;
+    for (; row + stride < m; row += 2 * stride) {        // two rows (six 16-byte loads) in flight per thread
+        const int64_t o0 = row * d + 4 * q, o1 = (row + stride) * d + 4 * q;
         const float4 g0 = ld4(g + o0), u0 = ld4(U + o0), v0 = ld4(V + o0);
         const float4 g1 = ld4(g + o1), u1 = ld4(U + o1), v1 = ld4(V + o1);
         add(g0, u0, v0);
         add(g1, u1, v1);
     }
-    for (; r < m; r += stride) {
-        const int64_t o0 = r * d + 4 * q;
+    for (; row < m; row += stride) {
+        const int64_t o0 = row * d + 4 * q;
         add(ld4(g + o0), ld4(U + o0), ld4(V + o0));
     }
     st4(s_uv + (rl * 2 + 0) * d + 4 * q, s1);
     st4(s_uv + (rl * 2 + 1) * d + 4 * q, s2);
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t pr = make_rsrc(partial, (int)gridDim.x * 2 * d * 4);
+    const __amdgpu_buffer_rsrc_t pr = make_rsrc(r.partial, r.nblk * 2 * d * 4);
     for (int t = threadIdx.x; t < 2 * d; t += 256) {
         float a = 0.f;
         for (int i = 0; i < rpi; ++i) a += s_uv[i * 2 * d + t];
-        st1_sc1(pr, ((int)blockIdx.x * 2 * d + t) * 4, a);
+        st1_sc1(pr, ((int)bid * 2 * d + t) * 4, a);
     }
-    if (ticket == nullptr || !last_workgroup(ticket, gridDim.x, &s_flag)) return;
-    sum_partial_rows_f64<256>(pr, (int)gridDim.x, 2 * d, s_buf, s_tot);
+    if (r.ticket == nullptr || !last_workgroup_of(r.ticket, (unsigned)r.nblk, &s_flag, bid)) return;
+    sum_partial_rows_f64<256>(pr, r.nblk, 2 * d, s_buf, s_tot);
     if ((int)threadIdx.x < d)
-        fold2_bwd_coef(threadIdx.x, d, s_tot[threadIdx.x], s_tot[d + threadIdx.x], shift, aux2, gamma, n_edges, use_batch, ca, cb, cc,
-                       dgamma, dbeta);
+        fold2_bwd_coef(threadIdx.x, d, s_tot[threadIdx.x], s_tot[d + threadIdx.x], r.shift, r.aux2, r.gamma, r.n_edges, r.use_batch, r.ca, r.cb, r.cc,
+                       r.dgamma, r.dbeta);
 }
+__global__ __launch_bounds__(256) void uv_bwd_reduce_kernel(const UvRed r) { uv_bwd_reduce_body(r, blockIdx.x); }
 
 // ------------------------------------------------------------------ backward pass 1: reductions
 template <int D>
@@ -1129,12 +1139,21 @@ __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restri
                                                            const float* __restrict__ W2, float slope,
                                                            const float* __restrict__ a2,
                                                            const float* __restrict__ b2,
-                                                           float* __restrict__ dx) {
+                                                           float* __restrict__ dx, const UvRed red, const int n_own) {
+    // round 5: the launch also HOSTS the layer's BatchNorm-2 backward reduction (the workgroups behind the first n_own; red.nblk = 0:
+    // none): the two are independent -- dx needs the forward coefficients only -- and the reduction was a launch of its own in front
+    // (ten ~8 us launches per step, most of them on grids of a few dozen workgroups)
+    if ((int)blockIdx.x >= n_own) {
+        uv_bwd_reduce_body(red, blockIdx.x - (unsigned)n_own);
+        return;
+    }
     constexpr int EB = PC<D>::EB;
     __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     int lane, wave, q;
-    const Row rw = my_row<D>(m_src, lane, wave, q);
+    const unsigned nb = (unsigned)n_own, bb = blockIdx.x;                  // xcd_block_id() of the first n_own workgroups
+    const unsigned xcd = bb & 7u, within = bb >> 3, base = nb >> 3, rem = nb & 7u;
+    const Row rw = my_row_at<D>(m_src, xcd * base + (xcd < rem ? xcd : rem) + within, lane, wave, q);
     EdgeMLP<D> mlp;
     mlp.init(A1, b1, W2, s_w2t, lane, q, slope);
     __syncthreads();
@@ -1453,24 +1472,33 @@ extern "C" int crfconv_pointconv_combine(const float* U, const float* V, const d
     return CRF_OK;
 }
 
-extern "C" int crfconv_pointconv_bwd_reduce_uv(const float* gout, const float* U, const float* V, int64_t m_tgt, int d,
-                                               const float* shift, const double* aux2, const float* gamma2,
-                                               double n_edges, int use_batch, float* ca, float* cb, float* cc,
-                                               float* dgamma2, float* dbeta2, void* workspace, size_t workspace_bytes,
-                                               unsigned* ticket, crf_stream_t stream) {
+static int uv_red_args(const float* gout, const float* U, const float* V, int64_t m_tgt, int d, const float* shift, const double* aux2,
+                       const float* gamma2, double n_edges, int use_batch, float* ca, float* cb, float* cc, float* dgamma2, float* dbeta2,
+                       void* workspace, size_t workspace_bytes, unsigned* ticket, UvRed& r) {
     if (int rc = check_pc(m_tgt, 1, d)) return rc;
     CRF_REQUIRE(gout && U && V && shift && aux2 && gamma2 && ca && cb && cc && dgamma2 && dbeta2 && workspace,
                 CRF_ERR_ARG, "null pointer");
     const int64_t nblk = uv_reduce_blocks(m_tgt, d);
     CRF_REQUIRE(workspace_bytes >= sizeof(float) * 2 * d * (size_t)nblk, CRF_ERR_WORKSPACE, "workspace too small");
+    r.g = gout; r.U = U; r.V = V; r.m = m_tgt; r.d = d; r.nblk = (int)nblk; r.partial = reinterpret_cast<float*>(workspace); r.ticket = ticket;
+    r.shift = shift; r.aux2 = aux2; r.gamma = gamma2; r.n_edges = n_edges; r.use_batch = use_batch; r.ca = ca; r.cb = cb; r.cc = cc;
+    r.dgamma = dgamma2; r.dbeta = dbeta2;
+    return CRF_OK;
+}
+
+extern "C" int crfconv_pointconv_bwd_reduce_uv(const float* gout, const float* U, const float* V, int64_t m_tgt, int d,
+                                               const float* shift, const double* aux2, const float* gamma2,
+                                               double n_edges, int use_batch, float* ca, float* cb, float* cc,
+                                               float* dgamma2, float* dbeta2, void* workspace, size_t workspace_bytes,
+                                               unsigned* ticket, crf_stream_t stream) {
+    UvRed r;
+    if (int rc = uv_red_args(gout, U, V, m_tgt, d, shift, aux2, gamma2, n_edges, use_batch, ca, cb, cc, dgamma2, dbeta2, workspace,
+                             workspace_bytes, ticket, r)) return rc;
     hipStream_t st = as_stream(stream);
-    float* partial = reinterpret_cast<float*>(workspace);
-    const int rpi = 256 / (d / 4);
-    hipLaunchKernelGGL(uv_bwd_reduce_kernel, dim3((unsigned)nblk), dim3(256), sizeof(float) * 2 * d * rpi, st, gout, U, V,
-                       m_tgt, d, partial, ticket, shift, aux2, gamma2, n_edges, use_batch, ca, cb, cc, dgamma2, dbeta2);
+    hipLaunchKernelGGL(uv_bwd_reduce_kernel, dim3((unsigned)r.nblk), dim3(256), 0, st, r);
     CRF_LAUNCH_CHECK();
     if (ticket != nullptr) return CRF_OK;             // the last workgroup has derived the coefficients
-    hipLaunchKernelGGL(fold2_bwd_partials_kernel, dim3(1), dim3(1024), 0, st, partial, (int)nblk, shift, aux2, gamma2,
+    hipLaunchKernelGGL(fold2_bwd_partials_kernel, dim3(1), dim3(1024), 0, st, r.partial, r.nblk, shift, aux2, gamma2,
                        n_edges, use_batch, d, ca, cb, cc, dgamma2, dbeta2);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
@@ -1587,21 +1615,46 @@ extern "C" int crfconv_reduce_jobs_f64(const crf_reduce64_job* jobs, int njobs, 
     return CRF_OK;
 }
 
-extern "C" int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const float* pos_tgt,
-                                           const int32_t* rev_ptr, const int32_t* rev_eid, int K,
-                                           int64_t m_src, int d, const float* A1, const float* b1,
-                                           const float* W2, float slope, const float* a2, const float* b2, float* dx,
-                                           crf_stream_t stream) {
+static int bwd_input_launch(const float* gout, const float* pos_src, const float* pos_tgt, const int32_t* rev_ptr, const int32_t* rev_eid,
+                            int K, int64_t m_src, int d, const float* A1, const float* b1, const float* W2, float slope, const float* a2,
+                            const float* b2, float* dx, const UvRed& red, crf_stream_t stream) {
     if (int rc = check_pc(m_src, K, d)) return rc;
     CRF_REQUIRE(gout && pos_src && pos_tgt && rev_ptr && rev_eid && A1 && b1 && W2 && a2 && b2 && dx,
                 CRF_ERR_ARG, "null pointer");
     const int64_t nblk = blocks_for(m_src, d);
     DISPATCH_D(d, {
-        hipLaunchKernelGGL(bwd_input_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, as_stream(stream), gout,
-                           pos_src, pos_tgt, rev_ptr, rev_eid, K, m_src, A1, b1, W2, slope, a2, b2, dx);
+        hipLaunchKernelGGL(bwd_input_kernel<DD>, dim3((unsigned)(nblk + red.nblk)), dim3(PBLOCK), 0, as_stream(stream), gout,
+                           pos_src, pos_tgt, rev_ptr, rev_eid, K, m_src, A1, b1, W2, slope, a2, b2, dx, red, (int)nblk);
     });
     CRF_LAUNCH_CHECK();
     return CRF_OK;
+}
+
+extern "C" int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const float* pos_tgt,
+                                           const int32_t* rev_ptr, const int32_t* rev_eid, int K,
+                                           int64_t m_src, int d, const float* A1, const float* b1,
+                                           const float* W2, float slope, const float* a2, const float* b2, float* dx,
+                                           crf_stream_t stream) {
+    UvRed none{};
+    none.nblk = 0;
+    return bwd_input_launch(gout, pos_src, pos_tgt, rev_ptr, rev_eid, K, m_src, d, A1, b1, W2, slope, a2, b2, dx, none, stream);
+}
+
+// crfconv_pointconv_bwd_input and crfconv_pointconv_bwd_reduce_uv (ticketed) of one layer in ONE launch: the input gradient needs the
+// forward coefficients only, the reduction's outputs (ca, cb, cc: the parameter pass's; dgamma2, dbeta2) are not read before the
+// next launch.  Same results as the two calls.
+extern "C" int crfconv_pointconv_bwd_input_reduce(const float* gout, const float* pos_src, const float* pos_tgt, const int32_t* rev_ptr,
+                                                  const int32_t* rev_eid, int K, int64_t m_src, int64_t m_tgt, int d, const float* A1,
+                                                  const float* b1, const float* W2, float slope, const float* a2, const float* b2, float* dx,
+                                                  const float* U, const float* V, const float* shift, const double* aux2,
+                                                  const float* gamma2, double n_edges, int use_batch, float* ca, float* cb, float* cc,
+                                                  float* dgamma2, float* dbeta2, void* workspace, size_t workspace_bytes, unsigned* ticket,
+                                                  crf_stream_t stream) {
+    CRF_REQUIRE(ticket, CRF_ERR_ARG, "null pointer");
+    UvRed r;
+    if (int rc = uv_red_args(gout, U, V, m_tgt, d, shift, aux2, gamma2, n_edges, use_batch, ca, cb, cc, dgamma2, dbeta2, workspace,
+                             workspace_bytes, ticket, r)) return rc;
+    return bwd_input_launch(gout, pos_src, pos_tgt, rev_ptr, rev_eid, K, m_src, d, A1, b1, W2, slope, a2, b2, dx, r, stream);
 }
 
 extern "C" int crfconv_pointconv_bwd_dump(const float* x, const float* gout, const float* pos_src,

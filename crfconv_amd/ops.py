@@ -2378,11 +2378,17 @@ class _PointConv(torch.autograd.Function):
         # pass 1: sum g_w and sum g_w (h2 - shift)  ->  BatchNorm-2 backward coefficients
         coef = torch.empty((5, d), dtype=torch.float32, device=dev)       # ca, cb, cc, dgamma2, dbeta2
         U, V = ctx.uv
-        if U is not None:                  # training forward left U, V: the reductions are row sums, no edge pass
-            _lib.call('crfconv_pointconv_bwd_reduce_uv', ptr(g), ptr(U), ptr(V), m_tgt, d, ptr(shift), ptr(aux2), ptr(g2),
-                      n_e, 1 if ctx.use2 else 0, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), ptr(coef[4]),
-                      ptr(ws), nbytes, _pc_ticket(dev), st)
+        rev_ptr, rev_eid = table.reverse
+        dx = torch.empty((table.m_src, d), dtype=torch.float32, device=dev)
+        if U is not None:                  # training forward left U, V: the reductions are row sums, no edge pass --
+            # and they ride in the input-gradient launch (source-major gather over the reverse table), which needs none of their results
+            _lib.call('crfconv_pointconv_bwd_input_reduce', ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(rev_ptr), ptr(rev_eid), K, table.m_src, m_tgt, d,
+                      ptr(A1), ptr(b1), ptr(W2), slope, ptr(a2), ptr(b2), ptr(dx), ptr(U), ptr(V), ptr(shift), ptr(aux2), ptr(g2), n_e,
+                      1 if ctx.use2 else 0, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), ptr(coef[4]), ptr(ws), nbytes,
+                      _pc_ticket(dev), st)       # (its partial rows in `ws` are consumed inside the launch; the parameter pass reuses `ws`)
         else:
+            _lib.call('crfconv_pointconv_bwd_input', ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(rev_ptr), ptr(rev_eid), K,
+                      table.m_src, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(a2), ptr(b2), ptr(dx), st)
             red = torch.empty(2 * d, dtype=torch.float64, device=dev)
             _lib.call('crfconv_pointconv_bwd_reduce', ptr(x), ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K,
                       m_tgt, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(shift), ptr(red), ptr(ws), nbytes, st)
@@ -2460,11 +2466,6 @@ class _PointConv(torch.autograd.Function):
             dbe1 = torch.empty(d, dtype=torch.float32, device=dev)
             _lib.call('crfconv_pointconv_fold1_bwd', ptr(W1), ptr(g1), ptr(mom), ptr(aux1), ptr(dA1b1), float(ctx.eps1),
                       1 if ctx.use1 else 0, d, ptr(dW1), ptr(dg1), ptr(dbe1), ptr(dW2_64), ptr(dW2) if dW2_64 is not None else None, st)
-        # input gradient (source-major gather over the reverse table)
-        rev_ptr, rev_eid = table.reverse
-        dx = torch.empty((table.m_src, d), dtype=torch.float32, device=dev)
-        _lib.call('crfconv_pointconv_bwd_input', ptr(g), ptr(pos_src), ptr(pos_tgt), ptr(rev_ptr), ptr(rev_eid), K,
-                  table.m_src, d, ptr(A1), ptr(b1), ptr(W2), slope, ptr(a2), ptr(b2), ptr(dx), st)
         return (dx, dW1, dg1, dbe1, dW2, coef[3], coef[4], None, None, None, None, None, None, None, None, None)
 
 

@@ -358,6 +358,14 @@ int crfconv_pointconv_bwd_input(const float* gout, const float* pos_src, const f
                                 int64_t m_src, int d, const float* A1, const float* b1,
                                 const float* W2, float slope, const float* a2, const float* b2, float* dx,
                                 crf_stream_t stream);
+/* crfconv_pointconv_bwd_input and the ticketed crfconv_pointconv_bwd_reduce_uv of one layer in ONE launch (round 5): the input gradient
+ * needs the forward coefficients only and nothing reads the reduction's outputs before the next launch.  Same results as the two calls. */
+int crfconv_pointconv_bwd_input_reduce(const float* gout, const float* pos_src, const float* pos_tgt, const int32_t* rev_ptr,
+                                       const int32_t* rev_eid, int K, int64_t m_src, int64_t m_tgt, int d, const float* A1, const float* b1,
+                                       const float* W2, float slope, const float* a2, const float* b2, float* dx, const float* U,
+                                       const float* V, const float* shift, const double* aux2, const float* gamma2, double n_edges,
+                                       int use_batch, float* ca, float* cb, float* cc, float* dgamma2, float* dbeta2, void* workspace,
+                                       size_t workspace_bytes, unsigned* ticket, crf_stream_t stream);
 
 /* BatchNorm folding of the weight MLP (one tiny workgroup each; d <= 128):
  *  fold1      W1 [d,3], gamma1/beta1, mom = {mean[3], cov[9]} of rel (float64) -> A1 [d,3], b1 [d];
