@@ -74,7 +74,8 @@ SIGNATURES = {
     'crfconv_linear_wgrad_workspace': (_sz, [_i64, _i, _i]),
     'crfconv_linear_wgrad': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_random_subsets': (_i, [_vp, _vp, _vp, _vp, _i, _u64, _vp, _vp]),
-    'crfconv_upindex_from_table': (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i, _i64, _vp, _vp]),
+    'crfconv_upindex_workspace': (_sz, [_i64, _i64]),
+    'crfconv_upindex_from_table': (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i, _i64, _vp, _vp, _sz, _vp]),
     'crfconv_gather_rows_batched': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i64, _i64, _i64, _vp]),
     'crfconv_argsort_codes_workspace': (_sz, [_i64, _i64]),
     'crfconv_argsort_codes': (_i, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),

@@ -102,17 +102,19 @@ __global__ __launch_bounds__(SUB_NT) void random_subsets_kernel(const SubsetJobs
 // up_idx[b][i] = the subset member nearest to point i (datasets/semantic3d_dataset.py:524: knn_batch(sub_pos, pos, 1), the order
 // (distance, subset position) of utils/nearest_neighbors).  The level's K-nearest table (distance order, the point itself first) already
 // holds the answer for almost every point: the nearest member overall is the nearest member IN the table whenever one is there strictly
-// closer than the table's last entry -- at ratio 4 and K = 16 all but (3/4)^16 = 1 % of the points.  For the rest the wavefront scans the
-// subset together, one such point at a time (same arithmetic as csrc/knn.hip: singly-rounded x, y, z accumulation, key = distance bits
-// << 32 | position).  One launch per level instead of a grid build + search (round 4: 120 us of the 0.93 ms collate).
+// closer than the table's last entry -- at ratio 4 and K = 16 all but (3/4)^16 = 1 % of the points.  Those go onto a list, and a second
+// launch gives each of them a wavefront that scans the subset's positions (same arithmetic as csrc/knn.hip: singly-rounded x, y, z
+// accumulation, key = distance bits << 32 | position).  Two launches per level instead of a grid build + search (round 4: 120 us of
+// the 0.93 ms collate).
 __device__ __forceinline__ float up_sqdist(float qx, float qy, float qz, float px, float py, float pz) {
     const float dx = qx - px, dy = qy - py, dz = qz - pz;
     return add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
 }
 constexpr unsigned long long UP_KEY_INF = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;
+// state: {list length, wavefronts of the scan launch that are done} -- zero before the first use, left zero by the scan launch
 __global__ __launch_bounds__(256) void upindex_table_kernel(const float* __restrict__ pos, const long long* __restrict__ nbr, int K,
-                                                            const int* __restrict__ rank, const long long* __restrict__ choice, int N, int S,
-                                                            long long* __restrict__ out) {
+                                                            const int* __restrict__ rank, int N, long long* __restrict__ out,
+                                                            int* __restrict__ state, int* __restrict__ list) {
     const int b = blockIdx.y;
     const int i0 = blockIdx.x * 256 + threadIdx.x;
     const bool valid = i0 < N;
@@ -135,18 +137,43 @@ __global__ __launch_bounds__(256) void upindex_table_kernel(const float* __restr
         }
     }
     // settled when a member of the table is strictly closer than the table's last entry (every point outside the table is at least that far)
-    bool need = valid && !(best != UP_KEY_INF && __uint_as_float((unsigned)(best >> 32)) < dlast);
+    const bool need = valid && !(best != UP_KEY_INF && __uint_as_float((unsigned)(best >> 32)) < dlast);
+    if (valid && !need) out[(size_t)b * N + i] = (long long)(best & 0xffffffffull);
+    const unsigned long long pending = __ballot(need);
+    if (pending != 0ull) {                                       // one counter update per wavefront, positions by lane order
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == __ffsll((long long)pending) - 1) base = atomicAdd(state, __popcll(pending));
+        base = __shfl(base, __ffsll((long long)pending) - 1, 64);
+        if (need) list[base + __popcll(pending & ((1ull << lane) - 1ull))] = b * N + i;
+    }
+}
+// one wavefront per listed point, a fixed grid that loops when a batch lists more than it has wavefronts
+constexpr int UP_SCAN_WGS = 512;
+__global__ __launch_bounds__(256) void upindex_scan_kernel(const float* __restrict__ pos, const float* __restrict__ sub_pos, int N, int S,
+                                                           long long* __restrict__ out, int* __restrict__ state, const int* __restrict__ list) {
     const int lane = threadIdx.x & 63;
-    unsigned long long pending = __ballot(need);
-    while (pending != 0ull) {
-        const int src = __ffsll((long long)pending) - 1;
-        const float sx = __shfl(qx, src, 64), sy = __shfl(qy, src, 64), sz = __shfl(qz, src, 64);
+    const int count = state[0];
+    for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < count; w += 4 * (int)gridDim.x) {
+        const int gi = list[w], b = gi / N;
+        const float qx = pos[3 * (size_t)gi], qy = pos[3 * (size_t)gi + 1], qz = pos[3 * (size_t)gi + 2];
+        const float* SP = sub_pos + (size_t)b * S * 3;
         unsigned long long mine = UP_KEY_INF;
-        for (int t = lane; t < S; t += 64) {
-            const int c = (int)choice[t];
-            const float d = up_sqdist(sx, sy, sz, P[3 * c], P[3 * c + 1], P[3 * c + 2]);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
-            mine = key < mine ? key : mine;
+        constexpr int UN = 8;                                    // positions of eight candidates per lane in flight
+        for (int t0 = lane; t0 < S; t0 += 64 * UN) {
+            float px[UN], py[UN], pz[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int t = t0 + 64 * u, tc = t < S ? t : S - 1;
+                px[u] = SP[3 * tc]; py[u] = SP[3 * tc + 1]; pz[u] = SP[3 * tc + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int t = t0 + 64 * u;
+                const float d = up_sqdist(qx, qy, qz, px[u], py[u], pz[u]);
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
+                mine = (t < S && key < mine) ? key : mine;
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -154,10 +181,13 @@ __global__ __launch_bounds__(256) void upindex_table_kernel(const float* __restr
             const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
             mine = other < mine ? other : mine;
         }
-        if (lane == src) { best = mine; need = false; }
-        pending &= pending - 1ull;
+        if (lane == 0) out[gi] = (long long)(mine & 0xffffffffull);
     }
-    if (valid) out[(size_t)b * N + i] = (long long)(best & 0xffffffffull);
+    __syncthreads();                                             // (every wavefront has read the list length)
+    if (threadIdx.x == 0) {                                      // the last workgroup out leaves the state zero for the next use
+        const int done = atomicAdd(state + 1, 1);
+        if (done + 1 == (int)gridDim.x) { state[0] = 0; state[1] = 0; }
+    }
 }
 
 // ------------------------------------------------------------------ stable argsort of 30-bit codes, per cloud
@@ -261,14 +291,28 @@ __global__ __launch_bounds__(256) void gather_rows_batched_kernel(const GatherRo
 
 using namespace crf;
 
-extern "C" int crfconv_upindex_from_table(const float* pos, const int64_t* neighbor_idx, const int32_t* rank, const int64_t* choice,
-                                          int64_t B, int64_t N, int K, int64_t S, int64_t* up_idx, crf_stream_t stream) {
-    CRF_REQUIRE(pos && neighbor_idx && rank && choice && up_idx, CRF_ERR_ARG, "null pointer");
-    CRF_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && N < ((int64_t)1 << 30) && S >= 1 && S <= N && K >= 1 && K <= 64 && K <= N, CRF_ERR_ARG,
+extern "C" size_t crfconv_upindex_workspace(int64_t B, int64_t N) {
+    if (B < 1 || N < 1) return 0;
+    return 256 + sizeof(int32_t) * (size_t)(B * N);              // {list length, done} | the list (worst case: every point)
+}
+
+extern "C" int crfconv_upindex_from_table(const float* pos, const float* sub_pos, const int64_t* neighbor_idx, const int32_t* rank,
+                                          int64_t B, int64_t N, int K, int64_t S, int64_t* up_idx, void* workspace, size_t workspace_bytes,
+                                          crf_stream_t stream) {
+    CRF_REQUIRE(pos && sub_pos && neighbor_idx && rank && up_idx && workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && B * N < ((int64_t)1 << 30) && S >= 1 && S <= N && K >= 1 && K <= 64 && K <= N, CRF_ERR_ARG,
                 "bad shape B=%lld N=%lld K=%d S=%lld", (long long)B, (long long)N, K, (long long)S);
-    hipLaunchKernelGGL(upindex_table_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, as_stream(stream), pos,
-                       reinterpret_cast<const long long*>(neighbor_idx), K, rank, reinterpret_cast<const long long*>(choice), (int)N, (int)S,
-                       reinterpret_cast<long long*>(up_idx));
+    CRF_REQUIRE(workspace_bytes >= crfconv_upindex_workspace(B, N) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, CRF_ERR_WORKSPACE,
+                "workspace too small or misaligned");
+    hipStream_t st = as_stream(stream);
+    int* state = reinterpret_cast<int*>(workspace);
+    int* list = reinterpret_cast<int*>(static_cast<char*>(workspace) + 256);
+    hipLaunchKernelGGL(upindex_table_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, st, pos,
+                       reinterpret_cast<const long long*>(neighbor_idx), K, rank, (int)N, reinterpret_cast<long long*>(up_idx), state, list);
+    CRF_LAUNCH_CHECK();
+    // the list holds ~(1 - S / N)^K of the points (1 % at ratio 4, K = 16): a fixed grid of 2048 wavefronts, looping beyond that
+    hipLaunchKernelGGL(upindex_scan_kernel, dim3(UP_SCAN_WGS), dim3(256), 0, st, pos, sub_pos, (int)N, (int)S,
+                       reinterpret_cast<long long*>(up_idx), state, list);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

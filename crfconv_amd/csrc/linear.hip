@@ -105,8 +105,11 @@ __global__ __launch_bounds__(WG_BLOCK) void mlp_bwd_p1_kernel(const float* __res
 
     const int64_t row_begin = (int64_t)blockIdx.x * rows_per_block;
     const int64_t row_end = row_begin + rows_per_block < M ? row_begin + rows_per_block : M;
-    for (int64_t r0 = row_begin + 16 * wave; r0 < row_end; r0 += 16 * WG_WAVES) {
-        float gv[4][TCO], yv[4][TCO], bv[4][TCI];
+#ifndef P1_PREFETCH_
+#define P1_PREFETCH_ 0
+#endif
+    struct Frag { float gv[4][TCO], yv[4][TCO], bv[4][TCI]; };
+    auto load = [&](int64_t r0, Frag& f) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t r = r0 + 4 * u + kk;
@@ -115,33 +118,51 @@ __global__ __launch_bounds__(WG_BLOCK) void mlp_bwd_p1_kernel(const float* __res
             for (int a = 0; a < TCO; ++a) {
                 const int co = co_base + 16 * a + cc;
                 const bool ok = rv && co < Co;
-                gv[u][a] = ok ? GA[r * Co + co] : 0.f;
-                yv[u][a] = ok ? Y[r * Co + co] : cm[a];          // yh = 0 on padding
+                f.gv[u][a] = ok ? GA[r * Co + co] : 0.f;
+                f.yv[u][a] = ok ? Y[r * Co + co] : cm[a];          // yh = 0 on padding
             }
 #pragma unroll
             for (int b = 0; b < TCI; ++b) {
                 const int ci = ci_base + 16 * b + cc;
                 float xv = 0.f;
                 if (rv && ci < Ci) xv = (X2 == nullptr || ci < split) ? X[r * (X2 ? split : Ci) + ci] : X2[r * (Ci - split) + (ci - split)];
-                bv[u][b] = xv;
+                f.bv[u][b] = xv;
             }
         }
+    };
+    auto compute = [&](const Frag& f) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int b = 0; b < TCI; ++b) sx[b] += bv[u][b];
+            for (int b = 0; b < TCI; ++b) sx[b] += f.bv[u][b];
 #pragma unroll
             for (int a = 0; a < TCO; ++a) {
-                const float g1 = gv[u][a] * (fmaf(ca[a], yv[u][a], cb[a]) > 0.f ? 1.f : slope);
-                const float yh = (yv[u][a] - cm[a]) * cr[a];
+                const float g1 = f.gv[u][a] * (fmaf(ca[a], f.yv[u][a], cb[a]) > 0.f ? 1.f : slope);
+                const float yh = (f.yv[u][a] - cm[a]) * cr[a];
                 sg[a] += g1;
                 sgy[a] = fmaf(g1, yh, sgy[a]);
 #pragma unroll
                 for (int b = 0; b < TCI; ++b) {
-                    accA[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1, bv[u][b], accA[a][b], 0, 0, 0);
-                    accB[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(yh, bv[u][b], accB[a][b], 0, 0, 0);
+                    accA[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1, f.bv[u][b], accA[a][b], 0, 0, 0);
+                    accB[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(yh, f.bv[u][b], accB[a][b], 0, 0, 0);
                 }
             }
+        }
+    };
+    if constexpr (P1_PREFETCH_ != 0) {
+        // the next 16-row group's fragments are requested before this group's products (rows past the slice load nothing)
+        Frag cur, nxt;
+        load(row_begin + 16 * wave, cur);
+        for (int64_t r0 = row_begin + 16 * wave; r0 < row_end; r0 += 16 * WG_WAVES) {
+            load(r0 + 16 * WG_WAVES, nxt);
+            compute(cur);
+            cur = nxt;
+        }
+    } else {
+        for (int64_t r0 = row_begin + 16 * wave; r0 < row_end; r0 += 16 * WG_WAVES) {
+            Frag f;
+            load(r0, f);
+            compute(f);
         }
     }
     // C/D layout of 16x16x4: col = lane & 15 (j = ci), row = 4 * (lane >> 4) + reg (i = co)

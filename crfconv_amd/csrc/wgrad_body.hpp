@@ -33,8 +33,11 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ G, const fl
     const int64_t row_end = row_begin + rows_per_block < M ? row_begin + rows_per_block : M;
     // waves interleave 16-row groups (4 k-steps) inside the block's slice; all operand loads of a group are issued
     // before its MFMAs, so each lane keeps 4 (TCO + TCI) dword loads in flight
-    for (int64_t r0 = row_begin + 16 * wave; r0 < row_end; r0 += 16 * WG_WAVES) {
-        float av[4][TCO], bv[4][TCI];
+#ifndef WG_PREFETCH_
+#define WG_PREFETCH_ 0
+#endif
+    struct Frag { float av[4][TCO], bv[4][TCI]; };
+    auto load = [&](int64_t r0, Frag& f) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t r = r0 + 4 * u + kk;
@@ -42,23 +45,40 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ G, const fl
 #pragma unroll
             for (int a = 0; a < TCO; ++a) {
                 const int co = co_base + 16 * a + cc;
-                av[u][a] = (rv && co < Co) ? G[r * Co + co] : 0.f;
+                f.av[u][a] = (rv && co < Co) ? G[r * Co + co] : 0.f;
             }
 #pragma unroll
             for (int b = 0; b < TCI; ++b) {
                 const int ci = ci_base + 16 * b + cc;
-                bv[u][b] = (rv && ci < Ci) ? X[r * Ci + ci] : 0.f;
+                f.bv[u][b] = (rv && ci < Ci) ? X[r * Ci + ci] : 0.f;
             }
         }
+    };
+    auto compute = [&](const Frag& f) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int a = 0; a < TCO; ++a) {
-                bsum[a] += av[u][a];
+                bsum[a] += f.av[u][a];
 #pragma unroll
                 for (int b = 0; b < TCI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.av[u][a], f.bv[u][b], acc[a][b], 0, 0, 0);
             }
+    };
+    if constexpr (WG_PREFETCH_ != 0) {
+        Frag cur, nxt;                                  // the next group's operands on their way while this group is on the matrix pipe
+        load(row_begin + 16 * wave, cur);
+        for (int64_t r0 = row_begin + 16 * wave; r0 < row_end; r0 += 16 * WG_WAVES) {
+            load(r0 + 16 * WG_WAVES, nxt);
+            compute(cur);
+            cur = nxt;
+        }
+    } else {
+        for (int64_t r0 = row_begin + 16 * wave; r0 < row_end; r0 += 16 * WG_WAVES) {
+            Frag f;
+            load(r0, f);
+            compute(f);
+        }
     }
     // C/D layout of 16x16x4: col = lane & 15 (j = ci), row = 4 * (lane >> 4) + reg (i = co)
     // LDS of the caller (a kernel that serves several tile classes owns ONE buffer of the largest class's size)

@@ -184,20 +184,34 @@ def random_subsets_device(sizes, counts, seed, counter, outs, ranks=None):
               ctypes.cast(o, ctypes.c_void_p), r, L, int(seed) & 0xFFFFFFFFFFFFFFFF, counter.data_ptr(), stream_ptr())
 
 
-def up_index_from_table(pos, neighbor_idx, choice, rank=None):
+_UP_WS = {}
+
+
+def up_index_from_table(pos, neighbor_idx, choice, rank=None, sub_pos=None):
     """up_idx [B, N, 1] int64 = knn_batch(pos[:, choice], pos, 1) (datasets/semantic3d_dataset.py:524), bit-identical, from the level's own
     K-nearest table (csrc/collate.hip: crfconv_upindex_from_table).  choice [S] int64: the subset shared by the clouds; rank [N] int32:
-    its membership table (built here when the caller has none)."""
+    its membership table, sub_pos [B, S, 3] its positions (both built here when the caller has none)."""
     from . import _lib
     from .graph import ptr, stream_ptr
     B, N, K = neighbor_idx.shape
     S = choice.numel()
+    dev = pos.device
     if rank is None:
-        rank = torch.full((N,), -1, dtype=torch.int32, device=pos.device)
-        rank[choice] = torch.arange(S, dtype=torch.int32, device=pos.device)
+        rank = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        rank[choice] = torch.arange(S, dtype=torch.int32, device=dev)
     pos = pos.detach().to(torch.float32).contiguous()
-    out = torch.empty((B, N, 1), dtype=torch.int64, device=pos.device)
-    _lib.call('crfconv_upindex_from_table', ptr(pos), ptr(neighbor_idx.contiguous()), ptr(rank), ptr(choice.contiguous()), B, N, K, S, ptr(out),
+    sub_pos = pos[:, choice].contiguous() if sub_pos is None else sub_pos.detach().to(torch.float32).contiguous()
+    out = torch.empty((B, N, 1), dtype=torch.int64, device=dev)
+    nbytes = _lib.load().crfconv_upindex_workspace(B, N)
+    # per (device, shape) workspace: its state words are zero between uses (never shared by launches in flight on two streams)
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (dev.index, 'capture' if capturing else int(torch.cuda.current_stream(dev).cuda_stream), B, N)
+    ws = _UP_WS.get(key)
+    if ws is None:
+        ws = _UP_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        if not capturing and (dev.index, 'capture', B, N) not in _UP_WS:      # the eager warm-up also makes the buffer captured launches
+            _UP_WS[(dev.index, 'capture', B, N)] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)      # use: a capture never allocates
+    _lib.call('crfconv_upindex_from_table', ptr(pos), ptr(sub_pos), ptr(neighbor_idx.contiguous()), ptr(rank), B, N, K, S, ptr(out), ptr(ws), nbytes,
               stream_ptr())
     return out
 
@@ -316,7 +330,7 @@ def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kern
         if kernel_size[i] >= 4:
             # the nearest subset member of a point is almost always one of its own K nearest neighbours: answered from the table
             # (bit-identical to the K = 1 search; `ranks`: the subsets' membership tables where the caller has them)
-            up_idx = up_index_from_table(pos, neighbor_idx, choice, None if ranks is None else ranks[i])
+            up_idx = up_index_from_table(pos, neighbor_idx, choice, None if ranks is None else ranks[i], sub_pos=sub_pos)
         else:
             up_idx = nearest_neighbors.knn_batch_device(sub_pos, pos, 1)
         multiscale.append(Data(pos=pos, neighbor_idx=neighbor_idx, sub_idx=sub_idx, up_idx=up_idx))

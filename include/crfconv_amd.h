@@ -744,13 +744,16 @@ int crfconv_random_subsets(const int* n, const int* s, int64_t* const* out, int3
                            const int64_t* counter, crf_stream_t stream);
 /* rank (host array of device int32 [n[l]] pointers, or NULL; entries may be NULL): rank[l][i] = position of point i in subset l, -1
  * outside -- the membership table of crfconv_upindex_from_table.
- * crfconv_upindex_from_table: up_idx [B, N] int64 = for every point of a level the position (in `choice` [S] int64, the subset shared by
- *   the B clouds) of the nearest subset member -- knn_batch(sub_pos, pos, 1) of datasets/semantic3d_dataset.py:524, bit-identical incl.
+ * crfconv_upindex_from_table: up_idx [B, N] int64 = for every point of a level the position (in the subset shared by the B clouds, whose
+ *   positions are sub_pos) of the nearest subset member -- knn_batch(sub_pos, pos, 1) of datasets/semantic3d_dataset.py:524, bit-identical incl.
  *   the (distance, position) order on ties --, answered from the level's own K-nearest table neighbor_idx [B, N, K] int64 (distance
- *   order, as crfconv_knn_batch_dev writes it) where a member is in it, by a wavefront-wide scan of the subset for the ~1 % of points
- *   where none is (round 5: one launch per level instead of a grid build + search). */
-int crfconv_upindex_from_table(const float* pos, const int64_t* neighbor_idx, const int32_t* rank, const int64_t* choice, int64_t B,
-                               int64_t N, int K, int64_t S, int64_t* up_idx, crf_stream_t stream);
+ *   order, as crfconv_knn_batch_dev writes it) where a member is in it; the ~1 % of points without one go onto a list and a second launch
+ *   gives each a wavefront that scans sub_pos [B, S, 3] (round 5: two launches per level instead of a grid build + search).
+ *   rank [N] int32: the subset's membership table (position in the subset, -1 outside; crfconv_random_subsets writes it).
+ *   workspace: crfconv_upindex_workspace(B, N) bytes whose first 8 are ZERO before the first use (the launches leave them zero). */
+size_t crfconv_upindex_workspace(int64_t B, int64_t N);
+int crfconv_upindex_from_table(const float* pos, const float* sub_pos, const int64_t* neighbor_idx, const int32_t* rank, int64_t B, int64_t N,
+                               int K, int64_t S, int64_t* up_idx, void* workspace, size_t workspace_bytes, crf_stream_t stream);
 /* Rows of up to 8 [B, N, row_bytes[j]] tensors picked by one index list in one launch: dst[j][b][s] = src[j][b][index[s]]
  * (index [S], shared by all clouds: datasets/semantic3d_dataset.py:524-526 pos[:, choice], neighbor_idx[:, choice]) or
  * src[j][b][index[b][s]] (per_cloud != 0: the Morton permutation, farthest-point picks).  row_bytes multiples of 4; src, dst,

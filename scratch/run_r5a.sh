@@ -12,3 +12,7 @@ out=gpurun_out/$tag
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $out/trace -o t -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs > $out/trace.log 2>&1 || { tail -20 $out/trace.log | cut -c1-300; exit 1; }
 python3 scratch/step_table.py $out/trace 400 10 > $out/step_table.txt 2>&1; head -3 $out/step_table.txt
 rm -rf $out/trace
+# optional A/B behind the batch: the variants listed in scratch/ab_next.txt (one line, space separated)
+if [ -s scratch/ab_next.txt ]; then
+  bash scratch/run_ab.sh $(cat scratch/ab_next.txt) > gpurun_out/$tag/ab.log 2>&1; tail -12 gpurun_out/$tag/ab.log | cut -c1-160
+fi
