@@ -91,10 +91,10 @@ __global__ __launch_bounds__(SUB_NT) void random_subsets_kernel(const SubsetJobs
     }
     int pos = s_cnt[tid] - c;
     for (int i = lo; i < hi; ++i) {
-        const bool in = (subset_key(seed, ctr, level, i) & mask) <= prefix && pos < s;
-        if (in) out[pos] = i;
-        if (rank != nullptr) rank[i] = in ? pos : -1;
-        if ((subset_key(seed, ctr, level, i) & mask) <= prefix) ++pos;
+        const bool member = (subset_key(seed, ctr, level, i) & mask) <= prefix;
+        if (member && pos < s) out[pos] = i;
+        if (rank != nullptr) rank[i] = (member && pos < s) ? pos : -1;
+        pos += member ? 1 : 0;
     }
 }
 
@@ -112,6 +112,7 @@ __device__ __forceinline__ float up_sqdist(float qx, float qy, float qz, float p
 }
 constexpr unsigned long long UP_KEY_INF = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;
 // state: {list length, wavefronts of the scan launch that are done} -- zero before the first use, left zero by the scan launch
+template <int KT>      // KT > 0: the table width is known (K == KT): index row and membership entries are all requested at once
 __global__ __launch_bounds__(256) void upindex_table_kernel(const float* __restrict__ pos, const long long* __restrict__ nbr, int K,
                                                             const int* __restrict__ rank, int N, long long* __restrict__ out,
                                                             int* __restrict__ state, int* __restrict__ list) {
@@ -124,9 +125,7 @@ __global__ __launch_bounds__(256) void upindex_table_kernel(const float* __restr
     const long long* row = nbr + ((size_t)b * N + i) * K;
     unsigned long long best = UP_KEY_INF;
     float dlast = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const int j = (int)row[k];
-        const int r = rank[j];
+    auto offer = [&](int k, int j, int r) {
         if (r >= 0 || k == K - 1) {
             const float d = up_sqdist(qx, qy, qz, P[3 * j], P[3 * j + 1], P[3 * j + 2]);
             if (r >= 0) {
@@ -134,6 +133,23 @@ __global__ __launch_bounds__(256) void upindex_table_kernel(const float* __restr
                 best = key < best ? key : best;
             }
             if (k == K - 1) dlast = d;
+        }
+    };
+    if constexpr (KT > 0) {
+        int jj[KT], rr[KT];
+#pragma unroll
+        for (int k = 0; k < KT; k += 2) {
+            const longlong2 v = *reinterpret_cast<const longlong2*>(row + k);       // rows are K * 8 bytes: 16-byte aligned for even K
+            jj[k] = (int)v.x; jj[k + 1] = (int)v.y;
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) rr[k] = rank[jj[k]];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) offer(k, jj[k], rr[k]);
+    } else {
+        for (int k = 0; k < K; ++k) {
+            const int j = (int)row[k];
+            offer(k, j, rank[j]);
         }
     }
     // settled when a member of the table is strictly closer than the table's last entry (every point outside the table is at least that far)
@@ -307,8 +323,13 @@ extern "C" int crfconv_upindex_from_table(const float* pos, const float* sub_pos
     hipStream_t st = as_stream(stream);
     int* state = reinterpret_cast<int*>(workspace);
     int* list = reinterpret_cast<int*>(static_cast<char*>(workspace) + 256);
-    hipLaunchKernelGGL(upindex_table_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, st, pos,
-                       reinterpret_cast<const long long*>(neighbor_idx), K, rank, (int)N, reinterpret_cast<long long*>(up_idx), state, list);
+    const dim3 tgrid((unsigned)((N + 255) / 256), (unsigned)B);
+    if (K == 16)
+        hipLaunchKernelGGL(upindex_table_kernel<16>, tgrid, dim3(256), 0, st, pos, reinterpret_cast<const long long*>(neighbor_idx), K, rank, (int)N,
+                           reinterpret_cast<long long*>(up_idx), state, list);
+    else
+        hipLaunchKernelGGL(upindex_table_kernel<0>, tgrid, dim3(256), 0, st, pos, reinterpret_cast<const long long*>(neighbor_idx), K, rank, (int)N,
+                           reinterpret_cast<long long*>(up_idx), state, list);
     CRF_LAUNCH_CHECK();
     // the list holds ~(1 - S / N)^K of the points (1 % at ratio 4, K = 16): a fixed grid of 2048 wavefronts, looping beyond that
     hipLaunchKernelGGL(upindex_scan_kernel, dim3(UP_SCAN_WGS), dim3(256), 0, st, pos, sub_pos, (int)N, (int)S,

@@ -40,26 +40,29 @@ struct WideJobs {
     const float* A1[WP_MAX]; const float* b1[WP_MAX]; const float* W2[WP_MAX]; const float* ca[WP_MAX]; const float* cb[WP_MAX];
     const float* cc[WP_MAX];
     float* dw2_partial[WP_MAX]; double* a1_partial[WP_MAX];
-    int m_tgt[WP_MAX], nblk[WP_MAX];
+    int m_tgt[WP_MAX], nblk[WP_MAX], d[WP_MAX];
     float slope[WP_MAX];
     int blk_base[WP_MAX + 1];
     int njobs;
 };
 
+// LDS of one workgroup of the parameter pass at width D (floats): the kernel that serves both widths owns ONE buffer of the larger
 template <int D>
-__global__ __launch_bounds__(WP_BLOCK) void wide_params_kernel(const WideJobs t) {
+constexpr int wide_params_lds_floats() {
+    return D * (D + 4) + 4 * D + 3 * D + WP_WAVES * 16 * (D + 4) + WP_WAVES * 16 * (D + 16) + 4 * WP_WAVES * 16;
+}
+template <int D>
+__device__ __forceinline__ void wide_params_body(const WideJobs& t, const int job, const int blk, float* __restrict__ lds) {
     constexpr int T16 = D / 16, S4 = D / 4, LDW = D + 4, LDG = D + 4, LDH = D + 16, K = 16;
     constexpr int UNR = S4 > 16 ? 4 : S4;           // k-steps unrolled at a time (fully unrolled, the d = 128 form runs out of registers)
-    __shared__ float s_w2[D * LDW];                       // W2[c][c'], row c padded to LDW
-    __shared__ float4 s_a1[D];                            // {A1[c'][0..2], b1[c']}
-    __shared__ float s_coef[3 * D];                       // ca | cb | cc
-    __shared__ float s_g[WP_WAVES][K * LDG];              // GH2 tile of the wave's point  [edge][channel]
-    __shared__ float s_h[WP_WAVES][K * LDH];              // H1 tile                        [edge][channel]
-    __shared__ float4 s_rel[WP_WAVES][K];                 // {rel x, y, z, 1} per edge (zero row for a missing edge)
+    float* const s_w2 = lds;                                                            // W2[c][c'], row c padded to LDW
+    float4* const s_a1 = reinterpret_cast<float4*>(s_w2 + D * LDW);                     // {A1[c'][0..2], b1[c']}
+    float* const s_coef = reinterpret_cast<float*>(s_a1 + D);                           // ca | cb | cc
+    float (*s_g)[K * LDG] = reinterpret_cast<float (*)[K * LDG]>(s_coef + 3 * D);       // GH2 tile of the wave's point  [edge][channel]
+    float (*s_h)[K * LDH] = reinterpret_cast<float (*)[K * LDH]>(s_coef + 3 * D + WP_WAVES * K * LDG);      // H1 tile [edge][channel]
+    float4 (*s_rel)[K] = reinterpret_cast<float4 (*)[K]>(s_coef + 3 * D + WP_WAVES * K * (LDG + LDH));      // {rel x, y, z, 1} per edge (zero row for a missing edge)
     float* s_red = s_w2;                                  // block sums (dW2 [d, d], then the [d, 4] sums) reuse the W2 tile once the points are done
-    int job = 0;
-    while (job + 1 < t.njobs && t.blk_base[job + 1] <= (int)blockIdx.x) ++job;
-    const int blk = (int)blockIdx.x - t.blk_base[job], nblk = t.nblk[job], m = t.m_tgt[job];
+    const int nblk = t.nblk[job], m = t.m_tgt[job];
     const float* __restrict__ x = t.x[job];
     const float* __restrict__ gout = t.gout[job];
     const float* __restrict__ pos_src = t.pos_src[job];
@@ -249,6 +252,18 @@ __global__ __launch_bounds__(WP_BLOCK) void wide_params_kernel(const WideJobs t)
             outd[i] = a;                                         // [channel][x, y, z, bias]
         }
     }
+}
+
+// Both widths in ONE launch (round 5): the d = 32 layers (854 workgroups at config 2) and the d = 64 ones (214) used to be two launches
+// of ~41 us each at the end of the backward pass, neither of which fills the chip; a workgroup looks its job up and dispatches on the
+// job's width.
+__global__ __launch_bounds__(WP_BLOCK) void wide_params_any_kernel(const WideJobs t) {
+    __shared__ __attribute__((aligned(16))) float lds[wide_params_lds_floats<64>()];
+    int job = 0;
+    while (job + 1 < t.njobs && t.blk_base[job + 1] <= (int)blockIdx.x) ++job;
+    const int blk = (int)blockIdx.x - t.blk_base[job];
+    if (t.d[job] == 32) wide_params_body<32>(t, job, blk, lds);
+    else wide_params_body<64>(t, job, blk, lds);
 }
 
 // ------------------------------------------------------------------ forward statistics pass of the wide layers on the matrix pipe
@@ -441,36 +456,35 @@ extern "C" int crfconv_pointconv_wide_params_jobs(const crf_pc_wide_job* jobs, i
         CRF_REQUIRE(jb.x && jb.gout && jb.pos_src && jb.pos_tgt && jb.idx32 && jb.A1 && jb.b1 && jb.W2 && jb.ca && jb.cb && jb.cc &&
                         jb.dw2_partial && jb.a1_partial, CRF_ERR_ARG, "job %d: null pointer", j);
     }
-    static const int widths[2] = {32, 64};
-    for (int w = 0; w < 2; ++w) {
-        const int d = widths[w];
-        int j = 0;
-        while (j < njobs) {
-            WideJobs t;
-            int n = 0;
-            int64_t blocks = 0;
-            for (; j < njobs && n < WP_MAX; ++j) {
-                const crf_pc_wide_job& jb = jobs[j];
-                if (jb.d != d) continue;
-                t.x[n] = jb.x; t.gout[n] = jb.gout; t.pos_src[n] = jb.pos_src; t.pos_tgt[n] = jb.pos_tgt; t.idx[n] = jb.idx32;
-                t.A1[n] = jb.A1; t.b1[n] = jb.b1; t.W2[n] = jb.W2; t.ca[n] = jb.ca; t.cb[n] = jb.cb; t.cc[n] = jb.cc;
-                t.dw2_partial[n] = jb.dw2_partial; t.a1_partial[n] = jb.a1_partial;
-                t.m_tgt[n] = (int)jb.m_tgt; t.nblk[n] = (int)wide_nblk(jb.m_tgt, d); t.slope[n] = jb.slope;
-                t.blk_base[n] = (int)blocks;
-                blocks += t.nblk[n];
-                ++n;
-            }
-            if (n == 0) break;
-            for (int k = n; k <= WP_MAX; ++k) t.blk_base[k] = (int)blocks;
-            for (int k = n; k < WP_MAX; ++k) {
-                t.x[k] = t.gout[k] = t.pos_src[k] = t.pos_tgt[k] = t.A1[k] = t.b1[k] = t.W2[k] = t.ca[k] = t.cb[k] = t.cc[k] = nullptr;
-                t.idx[k] = nullptr; t.dw2_partial[k] = nullptr; t.a1_partial[k] = nullptr; t.m_tgt[k] = 0; t.nblk[k] = 1; t.slope[k] = 1.f;
-            }
-            t.njobs = n;
-            if (d == 32) hipLaunchKernelGGL(wide_params_kernel<32>, dim3((unsigned)blocks), dim3(WP_BLOCK), 0, st, t);
-            else hipLaunchKernelGGL(wide_params_kernel<64>, dim3((unsigned)blocks), dim3(WP_BLOCK), 0, st, t);
-            CRF_LAUNCH_CHECK();
+    // the jobs in the caller's order, WP_MAX per launch, both widths together (the longest-running width first: its workgroups start first)
+    int order[2] = {64, 32};
+    int idx[64];
+    int nidx = 0;
+    for (int w = 0; w < 2; ++w)
+        for (int j = 0; j < njobs && nidx < 64; ++j)
+            if (jobs[j].d == order[w]) idx[nidx++] = j;
+    CRF_REQUIRE(nidx == njobs, CRF_ERR_UNSUPPORTED, "at most 64 jobs per call");
+    for (int j0 = 0; j0 < nidx; j0 += WP_MAX) {
+        WideJobs t;
+        const int n = nidx - j0 < WP_MAX ? nidx - j0 : WP_MAX;
+        int64_t blocks = 0;
+        for (int k = 0; k < n; ++k) {
+            const crf_pc_wide_job& jb = jobs[idx[j0 + k]];
+            t.x[k] = jb.x; t.gout[k] = jb.gout; t.pos_src[k] = jb.pos_src; t.pos_tgt[k] = jb.pos_tgt; t.idx[k] = jb.idx32;
+            t.A1[k] = jb.A1; t.b1[k] = jb.b1; t.W2[k] = jb.W2; t.ca[k] = jb.ca; t.cb[k] = jb.cb; t.cc[k] = jb.cc;
+            t.dw2_partial[k] = jb.dw2_partial; t.a1_partial[k] = jb.a1_partial;
+            t.m_tgt[k] = (int)jb.m_tgt; t.nblk[k] = (int)wide_nblk(jb.m_tgt, jb.d); t.slope[k] = jb.slope; t.d[k] = jb.d;
+            t.blk_base[k] = (int)blocks;
+            blocks += t.nblk[k];
         }
+        for (int k = n; k <= WP_MAX; ++k) t.blk_base[k] = (int)blocks;
+        for (int k = n; k < WP_MAX; ++k) {
+            t.x[k] = t.gout[k] = t.pos_src[k] = t.pos_tgt[k] = t.A1[k] = t.b1[k] = t.W2[k] = t.ca[k] = t.cb[k] = t.cc[k] = nullptr;
+            t.idx[k] = nullptr; t.dw2_partial[k] = nullptr; t.a1_partial[k] = nullptr; t.m_tgt[k] = 0; t.nblk[k] = 1; t.slope[k] = 1.f; t.d[k] = 32;
+        }
+        t.njobs = n;
+        hipLaunchKernelGGL(wide_params_any_kernel, dim3((unsigned)blocks), dim3(WP_BLOCK), 0, st, t);
+        CRF_LAUNCH_CHECK();
     }
     return CRF_OK;
 }

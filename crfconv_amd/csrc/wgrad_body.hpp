@@ -121,7 +121,7 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ G, const fl
 // levels are ~9 us launches of a few workgroups each and nothing on the backward chain waits for them, so they are queued and
 // issued together once the chain is done -- the jobs' workgroups (laid end to end, job found by a binary search over the
 // prefix) run side by side.  Same partial slabs as one wgrad_kernel launch per job.
-constexpr int WJ_MAX = 32;
+constexpr int WJ_MAX = 48;          // (48 x 61 bytes of table in the kernel arguments; config 2 queues 35 passes: one launch)
 struct WgJobTable {
     const float* G[WJ_MAX];
     const float* X[WJ_MAX];
