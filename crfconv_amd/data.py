@@ -364,7 +364,11 @@ class CollateGraph:
         # other from one generator -- rebuilt per epoch, after a resume, the slots of a CollatePipeline -- get different
         # sequences, and a run re-started from the same generator state reproduces them.  (Keyed on initial_seed() alone, every
         # graph built from a generator replayed the SAME subset sequence.)  `slot` separates graphs built from equal states.
-        drawn = int(torch.randint(0, 2 ** 62, (1,), generator=generator, dtype=torch.int64).item())
+        if generator is None:
+            # no caller's generator: a private one seeded from the process seed -- constructing a graph (a CollatePipeline builds one
+            # per slot) must not advance the GLOBAL default generator (later initialisation / dropout / randperm draws would shift)
+            generator = torch.Generator().manual_seed(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)
+        drawn = int(torch.randint(0, 2 ** 62, (1,), generator=generator, dtype=torch.int64, device=generator.device).item())
         self.seed = (drawn + 0x632BE59BD9B4E019 * int(slot)) & 0xFFFFFFFFFFFFFFFF
         ms = target.multiscale
         dev = ms[0].pos.device
@@ -478,6 +482,16 @@ class CollatePipeline:
         self.stream = torch.cuda.Stream(priority=priority)
         self._ready = [torch.cuda.Event() for _ in self.batches]
         self._free = [None for _ in self.batches]
+
+    def state_dict(self):
+        """Seeds and batch counters of the slots' graphs (CollateGraph.state_dict): what a checkpoint needs to continue the subset sequences."""
+        return {'graphs': [g.state_dict() for g in self.graphs]}
+
+    def load_state_dict(self, sd):
+        if len(sd['graphs']) != len(self.graphs):
+            raise ValueError('CollatePipeline.load_state_dict: %d slots in the checkpoint, %d here' % (len(sd['graphs']), len(self.graphs)))
+        for g, s in zip(self.graphs, sd['graphs']):
+            g.load_state_dict(s)
 
     def submit(self, slot, pos, x=None, y=None, wait_current=True):
         """Queue the collate of `pos` / `x` / `y` into slot `slot` on the side stream.  wait_current=False: the inputs are

@@ -52,6 +52,10 @@ class _MeanField(torch.autograd.Function):
             raise _lib.CrfConvError('a padded (variable-degree) table has no self column: use k0 = 0')
         z, y, Q, P = _f32c(z), _f32c(y), _f32c(Q), _f32c(P)
         needs_grad = any(ctx.needs_input_grad[:4])
+        if needs_grad and m * H * 4 >= 2 ** 31 and _lib.load().crfconv_meanfield_backward_supported(H, table.K, k0) == 1:
+            # the backward kernels address row tables by 32-bit byte offsets: say so BEFORE any work is done, not after a forward that worked
+            raise _lib.CrfConvError('mean field: a row table of %d x %d floats (>= 2 GiB) cannot be trained on (the backward addresses rows by '
+                                    '32-bit byte offsets); split the batch' % (m, H))
         # inference with one step: the similarity weights are consumed inside the fused first kernel and never
         # re-read -- skip their 4K bytes/point store (a third of that kernel's traffic)
         keep_s = needs_grad or steps != 1 or k0 != 1 or table.K not in (16, 32) or m * H * 4 >= 2 ** 31

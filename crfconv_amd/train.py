@@ -22,7 +22,16 @@ class CapturedStep:
         self.defer_weight_grads = bool(defer_weight_grads)
         # the warm-up steps (allocator, lazily built tables, momentum buffers) must not train: model state is put back afterwards,
         # momentum restarts from zero (mu * 0 + g = g: torch's first step, for dampening = 0)
+        import copy
+        supported = isinstance(optimizer, torch.optim.SGD) or type(optimizer).__name__ == 'FlatSGD'
+        if supported and any(float(g.get('dampening', 0.0)) != 0.0 for g in optimizer.param_groups):
+            supported = False                                   # (a zeroed momentum buffer gives (1 - d) g, not torch's first step g)
+        if not supported and warmup > 0:
+            raise TypeError('CapturedStep: the warm-up steps are undone for SGD-type optimizers without dampening only (torch.optim.SGD, '
+                            'optim.FlatSGD); got %s -- pass warmup=0 and warm the caches up yourself' % type(optimizer).__name__)
         keep = [t.detach().clone() for t in list(model.parameters()) + list(model.buffers())]
+        opt_state = copy.deepcopy(optimizer.state_dict())       # step counters, schedulers' view of the groups, any other state
+        flat_steps = getattr(optimizer, 'steps', None)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -31,11 +40,19 @@ class CapturedStep:
             with torch.no_grad():
                 for t, k in zip(list(model.parameters()) + list(model.buffers()), keep):
                     t.copy_(k)
+                had = bool(opt_state.get('state'))
+                if had:
+                    optimizer.load_state_dict(opt_state)          # an optimizer that had stepped before: exactly its old state
                 for st in optimizer.state.values():
-                    if torch.is_tensor(st.get('momentum_buffer')):
-                        st['momentum_buffer'].zero_()
+                    if not had and torch.is_tensor(st.get('momentum_buffer')):
+                        st['momentum_buffer'].zero_()             # fresh optimizer: mu * 0 + g = g is torch's first step
                 if hasattr(optimizer, 'buf'):
-                    optimizer.buf.zero_()
+                    if 'flat_momentum' in opt_state:
+                        optimizer.buf.copy_(opt_state['flat_momentum'])
+                    else:
+                        optimizer.buf.zero_()
+                if flat_steps is not None:
+                    optimizer.steps = flat_steps                  # FlatSGD's own counter (its check_every cadence)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
