@@ -67,8 +67,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12           # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
-TRAFFIC_FWD, TRAFFIC_BWD = 'r4_meanfield_traffic.json', 'r4_meanfield_bwd_traffic.json'      # PMC passes, sha1-keyed to the kernel sources
-TRAFFIC_STEP, TRAFFIC_PC = 'r4_step_traffic.json', 'r4_pointconv_traffic.json'
+TRAFFIC_FWD, TRAFFIC_BWD = 'r5_meanfield_traffic.json', 'r5_meanfield_bwd_traffic.json'      # PMC passes, sha1-keyed to the kernel sources
+TRAFFIC_STEP, TRAFFIC_PC = 'r5_step_traffic.json', 'r5_pointconv_traffic.json'
 ROCPROF_MF = 'r5_meanfield_rocprof.json'      # rocprofv3 --kernel-trace average durations of the level-0 mean-field kernels, sha1-keyed
 BOX = (8.0, 8.0, 3.0)
 VOX = 0.04

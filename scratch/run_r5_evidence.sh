@@ -10,8 +10,8 @@ CRFCONV_TOL_RECORD=$GRAFT_REPO_ROOT/gpurun_out/$tag/tol_recorded.json timeout -k
 echo "tests rc=$?"; grep -E "^FAILED|passed|failed" gpurun_out/$tag/tests.log | tail -5 | cut -c1-200
 fi
 if [ $part = all ] || [ $part = mf ]; then
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$tag/mftrace -o t -- python3 scratch/mf_pmc.py > gpurun_out/$tag/mftrace.log 2>&1 && python3 scratch/mf_rocprof_json.py gpurun_out/$tag/mftrace
-rm -rf gpurun_out/$tag/mftrace
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$tag/mftrace -o t -- python3 scratch/mf_pmc.py > gpurun_out/$tag/mftrace.log 2>&1
+find gpurun_out/$tag/mftrace -type f ! -name '*kernel_trace.csv' -delete      # (the trace CSV travels back: scratch/mf_rocprof_json.py runs where profiles/ is tracked)
 bash scratch/pmc.sh gpurun_out/$tag/mfpmc 'sim_step_fast|step_fast|bwd_rev|bwd_edge_all' scratch/mf_pmc.py > gpurun_out/$tag/mfpmc_summary.txt 2>&1; echo "mf pmc done"; tail -2 gpurun_out/$tag/mfpmc_summary.txt | cut -c1-160
 rm -rf gpurun_out/$tag/mfpmc
 fi
@@ -25,6 +25,11 @@ fi
 if [ $part = all ] || [ $part = steppmc ]; then
 bash scratch/run_step_pmc.sh > gpurun_out/$tag/step_pmc.log 2>&1; echo "step pmc done"; tail -3 gpurun_out/$tag/step_pmc.log | cut -c1-200
 rm -rf gpurun_out/step_pmc/FETCH_SIZE_* gpurun_out/step_pmc/WRITE_SIZE_*
+fi
+if [ $part = all ] || [ $part = pmc2 ]; then
+bash scratch/run_pcpmc.sh > gpurun_out/$tag/pcpmc.log 2>&1; echo "pointconv pmc done"; rm -rf gpurun_out/pmc_pc
+bash scratch/pmc_mfma.sh gpurun_out/$tag/pmc_mfma > gpurun_out/$tag/pmc_mfma_summary.txt 2>&1; echo "mfma pmc done"; tail -2 gpurun_out/$tag/pmc_mfma_summary.txt | cut -c1-160
+rm -rf gpurun_out/$tag/pmc_mfma
 fi
 if [ $part = all ] || [ $part = bench ]; then
 timeout -k 10 600 python3 bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err; echo "bench rc=$?"
