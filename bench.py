@@ -629,6 +629,21 @@ def reference_loop(net, data, cw, steps):
         out[key] = (time.perf_counter() - t0) / steps * 1e3
         del step
     out['captured_final_loss'] = float(loss)
+    # (c) the five lines verbatim again, on the model wrapped ONCE in crfconv_amd.train.GraphedModel: model(data) and loss.backward()
+    # are one hipGraph replay each, F.cross_entropy and torch.optim.SGD.step stay the caller's eager code
+    from crfconv_amd.train import GraphedModel
+    bare, net = net, GraphedModel(net)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2, momentum=0.95, weight_decay=1e-4)
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize()
+    out['graphed_module_ms_per_step'] = (time.perf_counter() - t0) / steps * 1e3
+    out['graphed_module_final_loss'] = float(loss)
+    net = bare
     return out
 
 
@@ -1042,6 +1057,7 @@ def main():
             'dist_backend': backend_name, 'allreduce_us': allreduce_us,
             'trainval_eager_ms_per_step': None if ref_loop is None else ref_loop.get('eager_ms_per_step'),
             'trainval_captured_ms_per_step': None if ref_loop is None else ref_loop.get('captured_ms_per_step'),
+            'trainval_graphed_module_ms_per_step': None if ref_loop is None else ref_loop.get('graphed_module_ms_per_step'),
             'trainval_captured_as_written_ms_per_step': None if ref_loop is None else ref_loop.get('captured_as_written_ms_per_step'),
             'reference_loop': ref_loop,
         }

@@ -519,10 +519,11 @@ extern "C" int crfconv_mlp_small_backward_supported(int64_t M, int Ci, int Co) {
     return (M >= 1 && M < (int64_t)1 << 24 && Ci >= 4 && Co >= 4 && Ci % 4 == 0 && Co % 4 == 0 && Co <= crf::GM_PRO_MAXK) ? 1 : 0;
 }
 
-// at most BT_MAXTILES row tiles (every workgroup of the product sums all of them in its prologue): 128-row tiles up to 3072
-// rows, proportionally longer ones above
+// at most BT_MAXTILES row tiles of 128 rows or proportionally more.  The slab's last workgroup sums them (24 loads in flight per
+// round), so the cap trades rounds of that sum against trips of every tile's row loop: 24 tiles was the cap while every workgroup of
+// the PRODUCT re-summed them; with the finished means 48 measured 3.836 ms against 3.868 (96 and 192: the same) -- DESIGN 9, T1.
 static void bt_plan(int64_t M, int& ntile, int& tile_rows) {
-    constexpr int BT_MAXTILES = 24;
+    constexpr int BT_MAXTILES = 48;
     int64_t rows = crf::BT_ROWS;
     if ((M + rows - 1) / rows > BT_MAXTILES) rows = (((M + BT_MAXTILES - 1) / BT_MAXTILES + 15) / 16) * 16;
     tile_rows = (int)rows;

@@ -55,11 +55,12 @@ class MultiScaleData(Data):
     def __init__(self, x=None, y=None, point_idx=None, cloud_idx=None, multiscale=None, **kwargs):
         super().__init__(x=x, y=y, point_idx=point_idx, cloud_idx=cloud_idx, multiscale=multiscale, **kwargs)
 
-    def load_(self, other):
+    def load_(self, other, defer_check=False):
         """Copies another batch of the SAME shapes into this batch's tensors (in place) and refreshes the neighbour
         tables / reverse CSRs / rel-pos moments derived from them into their existing buffers.  This batch's tensors
         are thereby static buffers: a hipGraph captured on a training step over ``self`` trains on ``other`` at its
-        next replay.  (All table sizes are fixed for fixed B, N, K and ratios.)"""
+        next replay.  (All table sizes are fixed for fixed B, N, K and ratios.)  defer_check: the tables' range check without its
+        host synchronisation (one per table otherwise): graph.check_pending() -- run by the next load_ -- raises instead."""
         from .graph import table_of
 
         pairs, tables = [], []
@@ -104,7 +105,7 @@ class MultiScaleData(Data):
             for dst, _ in pairs:                           # written by a custom kernel: the version counters (table / moments
                 torch.autograd.graph.increment_version(dst)    # memos compare them) must say so
         from .graph import batched_reverse
-        with batched_reverse():                            # every table's reverse CSR in one set of launches at the end
+        with batched_reverse(defer_check=defer_check):     # every table's reverse CSR in one set of launches at the end
             for a, n_src in tables:                        # after the copies: the refreshes read the new content
                 table_of(a, n_src)
         return self

@@ -136,7 +136,29 @@ class NeighborTable:
         return self._rev
 
 
-_BATCH = {'on': False, 'jobs': [], 'narrow': [], 'moments': []}
+_BATCH = {'on': False, 'jobs': [], 'narrow': [], 'moments': [], 'defer_check': False}
+_PENDING_CHECKS = []          # (event, pinned counts, tables): validations whose device -> host copy is still in flight
+
+
+def check_pending(wait=False):
+    """Raises IndexError for tables refreshed under ``batched_reverse(defer_check=True)`` that held out-of-range entries (they
+    were clamped: nothing faulted, but that batch's results were meaningless).  Looks only at copies that have arrived unless
+    `wait`; no device synchronisation either way."""
+    keep, bad = [], []
+    for ev, host, tables in _PENDING_CHECKS:
+        if not wait and not ev.query():
+            keep.append((ev, host, tables))
+            continue
+        ev.synchronize()
+        for n, t in zip(host.tolist(), tables):
+            if n:
+                t._bad.zero_()
+                bad.append((n, t.n_src))
+            else:
+                t._checked = True
+    _PENDING_CHECKS[:] = keep
+    if bad:
+        raise IndexError('; '.join('%d neighbour indices outside [0, %d)' % b for b in bad) + ' (in an earlier refreshed batch)')
 
 
 class batched_reverse:
@@ -144,15 +166,23 @@ class batched_reverse:
     NeighborTable.refresh_ are collected and issued on exit as batched calls with the same results -- ONE index-narrowing
     launch (crfconv_index_narrow_batched), the reverse CSRs by ONE crfconv_reverse_csr_batched call (five launches instead of
     seven per table), the rel-pos moments of the PointConv layers by ONE crfconv_pointconv_moments_batched call (two launches
-    instead of two per table).  Nothing may read the refreshed tables before the exit."""
+    instead of two per table).  Nothing may read the refreshed tables before the exit.
+    defer_check: the range check of the refreshed tables without a host synchronisation -- their bad-entry counts travel to pinned
+    memory behind the launches and ``check_pending()`` (called by the next exit, or by the caller) raises once they have arrived."""
+
+    def __init__(self, defer_check=False):
+        self.defer_check = bool(defer_check)
 
     def __enter__(self):
         self.prev = _BATCH['on']
+        self.prev_defer = _BATCH['defer_check']
         _BATCH['on'] = True
+        _BATCH['defer_check'] = self.defer_check or self.prev_defer
         return self
 
     def __exit__(self, exc_type, *exc):
         _BATCH['on'] = self.prev
+        defer, _BATCH['defer_check'] = _BATCH['defer_check'], self.prev_defer
         if self.prev:
             return False                       # nested: the outermost context flushes
         narrow, _BATCH['narrow'] = _BATCH['narrow'], []
@@ -185,9 +215,18 @@ class batched_reverse:
             _lib.call('crfconv_pointconv_moments_batched', p, len(part), ptr(ws), nbytes, stream_ptr())
             for entry, _ in part:
                 entry.mark_fresh()
-        for t, _, check in narrow:             # (one host sync per table outside a capture, as refresh_ does on its own)
-            if check:
-                t.validate()
+        checks = [t for t, _, check in narrow if check]
+        if defer and checks and not torch.cuda.is_current_stream_capturing():
+            check_pending()                    # what earlier batches left behind and has arrived by now
+            counts = torch.cat([t._bad for t in checks])
+            host = torch.empty(len(checks), dtype=torch.int32, pin_memory=True)
+            host.copy_(counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            _PENDING_CHECKS.append((ev, host, checks))
+            return False
+        for t in checks:                       # (one host sync per table outside a capture, as refresh_ does on its own)
+            t.validate()
         return False
 
 

@@ -78,3 +78,116 @@ class CapturedStep:
             self.batch.load_(new_batch)          # into the static buffers; tables, reverse CSRs, moments refreshed in place
         self.graph.replay()
         return self.loss
+
+
+class _GraphedPass(torch.autograd.Function):
+    """model(batch) as one forward replay; the gradient of whatever the caller computed from its output as one backward replay."""
+
+    @staticmethod
+    def forward(ctx, gm, *params):
+        gm.fwd_graph.replay()
+        ctx.gm = gm
+        return gm.static_out.detach()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        gm = ctx.gm
+        for p, sg in zip(gm.params, gm.static_grads):
+            # a caller who accumulates over several backward passes holds last pass's static buffer as .grad: the replay is about
+            # to overwrite it, so it moves to storage of its own first (zero_grad() in between -- the reference loop -- skips this)
+            if sg is not None and p.grad is not None and p.grad.data_ptr() == sg.data_ptr():
+                p.grad = p.grad.clone()
+        gm.static_gout.copy_(g)
+        gm.bwd_graph.replay()
+        return (None,) + tuple(gm.static_grads)
+
+
+class GraphedModel(torch.nn.Module):
+    """The reference loop UNCHANGED (trainval.py:99-106: zero_grad, model(data), the caller's loss, loss.backward(), optimizer.step())
+    at replay cost: wrap the model once,
+
+        net = GraphedModel(models.PointConvBig(6, 13, use_crf=True))       # the loop below it stays as written
+
+    and every training-mode ``net(batch)`` is ONE hipGraph replay of the forward, ``loss.backward()`` ONE replay of the backward
+    (the weight-gradient launches batched as in CapturedStep), with the loss and the optimizer the caller's own eager code in
+    between -- about 300 library launches per step leave the host as two.  The first training call captures (after `warmup` eager
+    passes on a side stream whose effect on BatchNorm statistics and dropout counters is undone); later batches of the SAME shapes
+    are copied into the captured batch's buffers (MultiScaleData.load_: one copy launch + the table refreshes).  A batch of other
+    shapes, eval mode and no_grad calls run the wrapped model eagerly.  Parameter gradients come back through autograd (hooks,
+    accumulation over several backward passes and DistributedDataParallel see ordinary gradients); the output aliases a static
+    buffer that the next call overwrites, as with torch.cuda.make_graphed_callables."""
+
+    def __init__(self, model, warmup=2, defer_weight_grads=True):
+        super().__init__()
+        self.model = model
+        self.warmup, self.defer_weight_grads = int(warmup), bool(defer_weight_grads)
+        self.fwd_graph = self.bwd_graph = None
+        self.static = self.static_out = self.static_gout = None
+        self.params, self.static_grads, self._sig = [], [], None
+
+    @staticmethod
+    def _signature(batch):
+        sig = []
+
+        def visit(t):
+            sig.append((tuple(t.shape), t.dtype))
+            return t
+        batch._apply(visit)
+        return tuple(sig)
+
+    def _backward(self):
+        if self.defer_weight_grads:
+            from . import ops
+            with ops.deferred_weight_grads():
+                self.static_out.backward(self.static_gout)
+        else:
+            self.static_out.backward(self.static_gout)
+
+    def _capture(self, batch):
+        model = self.model
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.static = batch._apply(torch.clone)
+        self._sig = self._signature(batch)
+        user_grads = [p.grad for p in self.params]
+        keep = [b.detach().clone() for b in model.buffers()]      # BatchNorm statistics, dropout counters: the warm-up must not count
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(self.warmup, 1)):                    # (at least one: lazily built tables, allocator, kernel modules)
+                for p in self.params:
+                    p.grad = None
+                self.static_out = model(self.static)
+                self.static_gout = torch.zeros_like(self.static_out)
+                self._backward()
+            with torch.no_grad():
+                for b, k in zip(model.buffers(), keep):
+                    b.copy_(k)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for p in self.params:
+            p.grad = None
+        self.fwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd_graph, capture_error_mode='thread_local'):
+            self.static_out = model(self.static)
+        self.static_gout = torch.zeros_like(self.static_out)
+        self.bwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), capture_error_mode='thread_local'):
+            self._backward()
+        self.static_grads = [p.grad for p in self.params]          # static buffers of the capture pool (None: not reached)
+        # the captured autograd graph goes: it holds the parameters' AccumulateGrad nodes, created on the capture's stream, and a
+        # node bound to another stream than its caller's costs a stream synchronisation per parameter in every later backward
+        self.static_out = self.static_out.detach()
+        for p, g in zip(self.params, user_grads):
+            p.grad = g
+
+    def forward(self, batch):
+        if not (self.training and torch.is_grad_enabled()):
+            return self.model(batch)
+        if self.fwd_graph is None:
+            self._capture(batch)
+        elif batch is not self.static and self._signature(batch) != self._sig:
+            return self.model(batch)
+        if batch is not self.static:
+            self.static.load_(batch, defer_check=True)          # (no host synchronisation: a bad table raises at the next call)
+        return _GraphedPass.apply(self, *self.params)

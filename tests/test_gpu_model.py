@@ -84,6 +84,30 @@ def test_table_rejects_bad_indices():
         NeighborTable(idx, 10)          # CPU tensor: no CPU path
 
 
+def test_deferred_table_check_raises_without_a_host_sync_in_the_refresh():
+    """batched_reverse(defer_check=True) -- MultiScaleData.load_(.., defer_check=True), the refresh in front of every
+    train.GraphedModel replay: a refreshed table with out-of-range entries is reported by graph.check_pending() once its count has
+    reached the host, not by a synchronising .item() per table inside the refresh; good tables pass and are marked checked."""
+    from crfconv_amd.graph import NeighborTable, batched_reverse, check_pending, _PENDING_CHECKS
+    good = torch.randint(0, 9, (1, 64, 4))
+    bad = good.clone()
+    bad[0, 5, 2] = 9
+    bad[0, 7, 1] = -3
+    ta, tb = NeighborTable(good.to(DEV), 9), NeighborTable(good.to(DEV), 9)
+    with batched_reverse(defer_check=True):
+        ta.refresh_(good.flip(1).to(DEV))
+        tb.refresh_(bad.to(DEV))
+    assert len(_PENDING_CHECKS) == 1 and not tb._checked
+    with pytest.raises(IndexError, match='2 neighbour indices outside'):
+        check_pending(wait=True)
+    assert ta._checked and not _PENDING_CHECKS and int(tb._bad) == 0
+    check_pending(wait=True)                                  # nothing pending: no error
+    with batched_reverse(defer_check=True):
+        tb.refresh_(good.to(DEV))
+    check_pending(wait=True)
+    assert tb._checked
+
+
 @pytest.mark.parametrize('K', [1, 5, 16, 32, 40])
 def test_table_columns_sorted_keep_row_content(K):
     """The device table re-orders columns 1.. of a row by ascending source id (locality of the gathers): same
@@ -1982,6 +2006,65 @@ def test_captured_step_of_the_unchanged_reference_loop_equals_the_eager_loop(def
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (got_losses, ref_losses)
     for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
         assert_close(a.float(), b.float(), 2e-5, ('after 3 steps (batched weight gradients): ' if defer else 'after 3 steps: ') + k)
+
+
+def test_graphed_model_in_the_unchanged_reference_loop_equals_the_eager_loop():
+    """crfconv_amd.train.GraphedModel: the reference's five lines VERBATIM (trainval.py:99-106) on a model wrapped once -- every
+    model(data) one forward replay, loss.backward() one backward replay, F.cross_entropy and torch.optim.SGD the caller's own
+    eager code -- against the same loop on the bare model: three batches from equal initial state leave equal losses, parameters
+    and BatchNorm buffers.  Then: gradient ACCUMULATION over two backward passes without zero_grad (the wrapper's static gradient
+    buffers must not alias what the caller holds), an eval-mode call and a no_grad call (both the wrapped model's eager path)."""
+    import crfconv_amd
+    import torch.nn.functional as F
+    from crfconv_amd import models
+    from crfconv_amd.train import GraphedModel
+    B, N = 2, 8192
+
+    def batch(seed):
+        pos = np.stack([S.make_cloud(seed + b, N, box=(2, 2, 1)) for b in range(B)])
+        feats = np.concatenate([pos, S.uniform(seed, 'rgb', (B, N, 3), 0, 1)], -1)
+        return crfconv_amd.multiscale_compute(t(pos), x=t(feats), y=t(S.integers(seed, 'y', (B, N), 0, 14)),
+                                              generator=torch.Generator().manual_seed(seed))
+    batches = [batch(700 + 10 * i) for i in range(3)]
+    cw = torch.linspace(0.5, 1.5, 13, device=DEV)
+    torch.manual_seed(6)
+    ref = models.PointConvBig(6, 13, True, 3).to(DEV).train()
+    inner = models.PointConvBig(6, 13, True, 3).to(DEV).train()
+    inner.load_state_dict(ref.state_dict())
+    net = GraphedModel(inner)
+    mk = lambda m: torch.optim.SGD(m.parameters(), lr=1e-2, momentum=0.95, weight_decay=1e-4)      # noqa: E731
+    losses = {}
+    for name, model, optimizer in (('eager', ref, mk(ref)), ('graphed', net, mk(net))):
+        losses[name] = []
+        for data in batches:
+            optimizer.zero_grad()
+            y_pred = model(data)
+            y = data.y.reshape(-1) - 1
+            loss = F.cross_entropy(y_pred, y, weight=cw, ignore_index=-1)
+            loss.backward()
+            optimizer.step()
+            losses[name].append(float(loss))
+    assert net.fwd_graph is not None and net.bwd_graph is not None
+    for a, b in zip(losses['graphed'], losses['eager']):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), losses
+    for (k, a), b in zip(inner.state_dict().items(), ref.state_dict().values()):
+        assert_close(a.float(), b.float(), 2e-5, 'graphed module, after 3 steps: ' + k)
+    # accumulation: two backward passes on two batches, no zero_grad in between (from EQUAL state: what remains is summation order)
+    inner.load_state_dict(ref.state_dict())
+    for model in (ref, net):
+        for p in model.parameters():
+            p.grad = None
+        for data in batches[:2]:
+            F.cross_entropy(model(data), data.y.reshape(-1) - 1, weight=cw, ignore_index=-1).backward()
+    for (k, a), b in zip(inner.named_parameters(), ref.parameters()):
+        assert_close(a.grad, b.grad, 2e-5, 'graphed module, accumulated gradient: ' + k)
+    # eval / no_grad: the wrapped model itself
+    with torch.no_grad():
+        a, b = net(batches[0]), ref(batches[0])
+    assert_close(a, b, 2e-5, 'graphed module, no_grad call')
+    net.eval(), ref.eval()
+    a, b = net(batches[1]), ref(batches[1])
+    assert_close(a, b, 2e-5, 'graphed module, eval call')
 
 
 def test_crf_late_gradients_with_two_consumers_of_one_matrix_pair_and_a_hook():
