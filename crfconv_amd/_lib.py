@@ -53,6 +53,9 @@ SIGNATURES = {
     'crfconv_pointconv_moments': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_stats': (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'crfconv_pointconv_forward_uv': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    'crfconv_pointconv_forward_uv_hosts': (_i, [_i, _i]),
+    'crfconv_pointconv_forward_uv_hosting': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp,
+                                                  _vp, _vp, _i, _vp, _vp, _vp]),
     'crfconv_pointconv_combine': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _f, _f, _i64, _i, _vp, _vp, _vp, _vp, _vp]),
     'crfconv_pointconv_bwd_reduce_uv': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'crfconv_pointconv_forward': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
@@ -332,5 +335,14 @@ def check(rc, what=''):
     return rc
 
 
+_FN = {}          # name -> bound foreign function (the eager path makes ~300 calls per training step: no lookup chain per call)
+
+
 def call(name, *args):
-    return check(getattr(load(), name)(*args), name)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    rc = fn(*args)
+    if rc < 0:
+        check(rc, name)
+    return rc

@@ -12,6 +12,7 @@
 #include "common.hpp"
 #include "outer_acc.hpp"
 #include "gridsync.hpp"
+#include "crf_matrices_body.hpp"
 #include <algorithm>
 
 namespace crf {
@@ -235,7 +236,8 @@ __device__ __forceinline__ float4 ks_sum(float4 v, float4* s_ks, int lane, int w
 // Block-level deterministic reduction of NV per-quad float4 values into partial[block][NV][D].
 template <int D, int NV, bool WT = false>      // WT: rows stored write-through, for a last-workgroup sum in the same launch (gridsync.hpp)
 __device__ __forceinline__ void block_reduce_store(const float4 (&v)[NV], float* sred /*[PWAVES][NV][D]*/,
-                                                   float* __restrict__ partial, int lane, int wave, int q) {
+                                                   float* __restrict__ partial, int lane, int wave, int q,
+                                                   const unsigned bid = blockIdx.x, const unsigned nblk = gridDim.x) {
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
         float4 t = v[n];
@@ -250,8 +252,8 @@ __device__ __forceinline__ void block_reduce_store(const float4 (&v)[NV], float*
         float a = 0.f;
 #pragma unroll
         for (int w = 0; w < PWAVES; ++w) a += sred[w * NV * D + t];
-        if constexpr (WT) st1_sc1(make_rsrc(partial, (int)gridDim.x * NV * D * 4), ((int)blockIdx.x * NV * D + t) * 4, a);
-        else partial[(int64_t)blockIdx.x * NV * D + t] = a;
+        if constexpr (WT) st1_sc1(make_rsrc(partial, (int)nblk * NV * D * 4), ((int)bid * NV * D + t) * 4, a);
+        else partial[(int64_t)bid * NV * D + t] = a;
     }
 }
 
@@ -492,7 +494,18 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
 // convolution finishes with an elementwise combine.  U and V also carry everything BatchNorm-2's backward
 // needs (sum_e g_w = sum_i g_i V_i,  sum_e g_w (h2 - shift) = sum_i g_i U_i): no edge pass there either.
 template <int D>
-__global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict__ x,
+struct UvLds {
+    float4 w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
+    float4 scr[PC<D>::SCR_SIZE];
+    float red[PWAVES * 2 * D];
+    float4 ks[PC<D>::KS > 1 ? PWAVES * WAVE : 1];
+    double buf[4 * 256], tot[2 * D];
+    int flag;
+};
+// (bid of n_own: this workgroup among the launch's workgroups that run this body -- all of them, or all but the riders of
+// uvstats_hosting_kernel)
+template <int D>
+__device__ __forceinline__ void uvstats_body(const float* __restrict__ x,
                                                          const float* __restrict__ pos_src,
                                                          const float* __restrict__ pos_tgt,
                                                          const int32_t* __restrict__ idx, int K,
@@ -503,18 +516,19 @@ __global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict
                                                          float* __restrict__ shift_out,
                                                          float* __restrict__ U, float* __restrict__ V,
                                                          float* __restrict__ partial, unsigned* __restrict__ ticket,
-                                                         double* __restrict__ stats) {
+                                                         double* __restrict__ stats, UvLds<D>& L, const unsigned bid, const unsigned n_own) {
     constexpr int EB = PC<D>::EB;
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
-    __shared__ float4 s_scr[PC<D>::SCR_SIZE];
-    __shared__ float sred[PWAVES * 2 * D];
+    float4* s_w2t = L.w2t;
+    float4* s_scr = L.scr;
+    float* sred = L.red;
     int lane, wave, q;
-    const Row rw = my_row<D>(m_tgt, lane, wave, q);
+    const unsigned xcd = bid & 7u, base = n_own >> 3, rem = n_own & 7u;                 // xcd_block_id() over the n_own workgroups
+    const Row rw = my_row_at<D>(m_tgt, xcd * base + (xcd < rem ? xcd : rem) + (bid >> 3), lane, wave, q);
     EdgeMLP<D> mlp;
     mlp.init(A1, b1, W2, s_w2t, lane, q, slope);
     __syncthreads();
     const float4 shift = mlp.h2_of(mean_rel[0], mean_rel[1], mean_rel[2]);
-    if (blockIdx.x == 0 && threadIdx.x < PC<D>::L) st4(shift_out + 4 * q, shift);
+    if (bid == 0 && threadIdx.x < PC<D>::L) st4(shift_out + 4 * q, shift);
 
     const float px = pos_tgt[3 * rw.r], py = pos_tgt[3 * rw.r + 1], pz = pos_tgt[3 * rw.r + 2];
     const int32_t* irow = idx + rw.r * K;
@@ -581,20 +595,52 @@ __global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict
             v.x += xj[e].x; v.y += xj[e].y; v.z += xj[e].z; v.w += xj[e].w;
         }
     }
-    __shared__ float4 s_ks[PC<D>::KS > 1 ? PWAVES * WAVE : 1];
+    float4* s_ks = L.ks;
     u = ks_sum<D>(u, s_ks, lane, wave);
     v = ks_sum<D>(v, s_ks, lane, wave);
     if (rw.valid && (wave % PC<D>::KS == 0)) {
         st4(U + rw.r * D + 4 * q, u);
         st4(V + rw.r * D + 4 * q, v);
     }
-    block_reduce_store<D, 2, true>(acc, sred, partial, lane, wave, q);
+    block_reduce_store<D, 2, true>(acc, sred, partial, lane, wave, q, bid, n_own);
     // with a ticket word the last workgroup to finish sums the rows into stats (reduce_partials_kernel's launch otherwise)
-    __shared__ double s_buf[4 * 256], s_tot[2 * D];
-    __shared__ int s_flag;
-    if (ticket == nullptr || !last_workgroup(ticket, gridDim.x, &s_flag)) return;
-    sum_partial_rows_f64<256>(make_rsrc(partial, (int)gridDim.x * 2 * D * 4), (int)gridDim.x, 2 * D, s_buf, s_tot);
-    if (threadIdx.x < 2 * D) stats[threadIdx.x] = s_tot[threadIdx.x];
+    if (ticket == nullptr || !last_workgroup(ticket, n_own, &L.flag)) return;
+    sum_partial_rows_f64<256>(make_rsrc(partial, (int)n_own * 2 * D * 4), (int)n_own, 2 * D, L.buf, L.tot);
+    if (threadIdx.x < 2 * D) stats[threadIdx.x] = L.tot[threadIdx.x];
+}
+template <int D>
+__global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict__ x, const float* __restrict__ pos_src,
+                                                         const float* __restrict__ pos_tgt, const int32_t* __restrict__ idx, int K,
+                                                         int64_t m_tgt, const float* __restrict__ A1, const float* __restrict__ b1,
+                                                         const float* __restrict__ W2, float slope, const float* __restrict__ mean_rel,
+                                                         float* __restrict__ shift_out, float* __restrict__ U, float* __restrict__ V,
+                                                         float* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                         double* __restrict__ stats) {
+    __shared__ UvLds<D> L;
+    uvstats_body<D>(x, pos_src, pos_tgt, idx, K, m_tgt, A1, b1, W2, slope, mean_rel, shift_out, U, V, partial, ticket, stats, L, blockIdx.x, gridDim.x);
+}
+// The same launch CARRYING the CRF layers' matrices (crf_matrices_body.hpp): Q = (I + c^T c)^-1, P = I - Q depend on parameters only,
+// yet as a launch of their own (one workgroup per layer, a 27 us chain of 64 dependent pivots) they sat in the middle of the forward's
+// launch chain.  Here their workgroups are the FIRST n_side of the grid of the network's first PointConv statistics pass (31 us; four
+// workgroups per CU are resident, so only the first ones dispatched are certain to start at once), and nothing waits for them.  The two
+// bodies SHARE their LDS (the union below): the riders must not cost the host's workgroups an occupancy step.
+template <int D>
+__global__ __launch_bounds__(PBLOCK) void uvstats_hosting_kernel(const float* __restrict__ x, const float* __restrict__ pos_src,
+                                                                 const float* __restrict__ pos_tgt, const int32_t* __restrict__ idx, int K,
+                                                                 int64_t m_tgt, const float* __restrict__ A1, const float* __restrict__ b1,
+                                                                 const float* __restrict__ W2, float slope, const float* __restrict__ mean_rel,
+                                                                 float* __restrict__ shift_out, float* __restrict__ U, float* __restrict__ V,
+                                                                 float* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                                 double* __restrict__ stats, const CrfMatJobs side, const int n_side) {
+    static_assert(PBLOCK == CMF_BLOCK, "the riders are workgroups of the host's size");
+    __shared__ __attribute__((aligned(16))) union Both { UvLds<D> uv; char mats[CMF_LDS_BYTES]; } L;
+    if ((int)blockIdx.x < n_side) {
+        const int b = (int)blockIdx.x;
+        crf_matrices_body(uni(side.c[b]), uni(side.H[b]), uni(side.Q[b]), uni(side.P[b]), L.mats);
+        return;
+    }
+    uvstats_body<D>(x, pos_src, pos_tgt, idx, K, m_tgt, A1, b1, W2, slope, mean_rel, shift_out, U, V, partial, ticket, stats, L.uv,
+                    blockIdx.x - (unsigned)n_side, gridDim.x - (unsigned)n_side);
 }
 
 // out = a2 U + (a2 shift + b2) V   over [m, d] rows (one thread per 4-channel quad).  BatchNorm-2's batch
@@ -1454,6 +1500,37 @@ extern "C" int crfconv_pointconv_forward_uv(const float* x, const float* pos_src
         hipLaunchKernelGGL(uvstats_kernel<DD>, dim3((unsigned)nblk), dim3(PBLOCK), 0, st, x, pos_src, pos_tgt, idx32, K,
                            m_tgt, A1, b1, W2, slope, mean_rel3, shift, U, V, partial, ticket, stats);
     });
+    CRF_LAUNCH_CHECK();
+    return ticket != nullptr ? CRF_OK : reduce_partials(partial, nblk, 2 * d, stats, st);
+}
+
+// crfconv_pointconv_forward_uv whose launch also CARRIES crfconv_crf_matrices_batched(c, H, n, Q, P) as its last n workgroups
+// (uvstats_hosting_kernel: the riders come first in the grid): for the layer widths crfconv_pointconv_forward_uv_hosts() names -- d = 8, the first PointConv of the
+// reference networks (models/point_conv_big.py:107).  Results of both are those of the two separate calls.
+extern "C" int crfconv_pointconv_forward_uv_hosts(int K, int d) { return (d == 8 && !uvstats_mfma_ok(K, d)) ? 1 : 0; }
+extern "C" int crfconv_pointconv_forward_uv_hosting(const float* x, const float* pos_src, const float* pos_tgt,
+                                                    const int32_t* idx32, int K, int64_t m_tgt, int d, const float* A1,
+                                                    const float* b1, const float* W2, float slope, const float* mean_rel3,
+                                                    float* shift, double* stats, float* U, float* V, void* workspace,
+                                                    size_t workspace_bytes, unsigned* ticket, const float* const* c, const int* H,
+                                                    int n, float* const* Q, float* const* P, crf_stream_t stream) {
+    if (int rc = check_pc(m_tgt, K, d)) return rc;
+    CRF_REQUIRE(crfconv_pointconv_forward_uv_hosts(K, d) == 1, CRF_ERR_UNSUPPORTED, "forward_uv_hosting: d=%d K=%d is not a hosting width", d, K);
+    CRF_REQUIRE(x && pos_src && pos_tgt && idx32 && A1 && b1 && W2 && mean_rel3 && shift && stats && U && V &&
+                    workspace, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(c && H && Q && P && n >= 1 && n <= CM_MAX, CRF_ERR_ARG, "null pointer or n=%d outside [1, %d]", n, CM_MAX);
+    CrfMatJobs side = {};
+    for (int i = 0; i < n; ++i) {
+        CRF_REQUIRE(c[i] && Q[i] && P[i] && H[i] >= 1 && H[i] <= 64, CRF_ERR_ARG, "rider %d: null pointer or H=%d outside [1, 64]", i, H[i]);
+        side.c[i] = c[i]; side.Q[i] = Q[i]; side.P[i] = P[i]; side.H[i] = H[i];
+    }
+    const int64_t nblk = blocks_for(m_tgt, d);
+    CRF_REQUIRE(workspace_bytes >= sizeof(float) * 2 * d * (size_t)nblk, CRF_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* partial = reinterpret_cast<float*>(workspace);
+    if (nblk * (d / 2) > 256 * 24) ticket = nullptr;
+    hipLaunchKernelGGL(uvstats_hosting_kernel<8>, dim3((unsigned)(nblk + n)), dim3(PBLOCK), 0, st, x, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1,
+                       W2, slope, mean_rel3, shift, U, V, partial, ticket, stats, side, n);
     CRF_LAUNCH_CHECK();
     return ticket != nullptr ? CRF_OK : reduce_partials(partial, nblk, 2 * d, stats, st);
 }

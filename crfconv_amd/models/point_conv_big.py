@@ -177,6 +177,13 @@ class PointConvResNet(Base):
             fine, coarse = ms[lvl - 1], ms[lvl]
             plan.append((getattr(self, 'conv%d_1' % (lvl + 1)), (fine.pos, coarse.pos), fine.sub_idx))
             plan.append((getattr(self, 'conv%d_2' % (lvl + 1)), coarse.pos, coarse.neighbor_idx))
+        decoders = [getattr(self, 'deconv%d' % (lvl + 1)) for lvl in range(len(WIDTHS) - 2, -1, -1)]
+        mats = [None] * len(decoders)
+        if all(isinstance(d, CRFConv) for d in decoders):
+            # (I + c^T c)^-1 of every CRF layer: ONE launch (and one back).  The matrices depend on parameters only, so the launch is
+            # queued HERE: the first PointConv's statistics pass carries its workgroups (ops.crf_matrices_batched(ride=True)) and
+            # the 27 us chain of dependent pivots leaves the forward's launch sequence; flush_riders() below covers eval mode
+            mats = ops.crf_matrices_batched([d.c for d in decoders], ride=self.training and data.x.is_cuda)
         pre = [None] * len(plan)
         if self.training and data.x.is_cuda and not ops._NO_PREFOLD_ENV:      # BatchNorm-1 of all ten weight MLPs folded in ONE launch, up front
             pre = ops.point_conv_prefold([blk.point_conv.prefold_entry(p, i) for blk, p, i in plan], True)
@@ -189,10 +196,7 @@ class PointConvResNet(Base):
             h, skips[-1] = b1(h, p1, i1, return_input_alias=True, prefold=pre[2 * lvl])
             h = b2(h, p2, i2, prefold=pre[2 * lvl + 1])
             skips.append(h)
-        decoders = [getattr(self, 'deconv%d' % (lvl + 1)) for lvl in range(len(WIDTHS) - 2, -1, -1)]
-        mats = [None] * len(decoders)
-        if all(isinstance(d, CRFConv) for d in decoders):      # (I + c^T c)^-1 of every CRF layer: ONE launch (and one back)
-            mats = ops.crf_matrices_batched([d.c for d in decoders])
+        ops.flush_riders()
         for d, mat, lvl in zip(decoders, mats, range(len(WIDTHS) - 2, -1, -1)):
             if mat is not None:
                 h = d(h, skips[lvl], ms[lvl].up_idx, ms[lvl].neighbor_idx, matrices=mat)

@@ -14,6 +14,8 @@ BN_EPS = 1e-5
 
 
 def _f32c(t):
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t.detach()
     return t.detach().to(torch.float32).contiguous()
 
 
@@ -236,13 +238,19 @@ class _CrfMatricesBatched(torch.autograd.Function):
     (PointConvBig: four ~20 us single-workgroup launches each way become one)."""
 
     @staticmethod
-    def forward(ctx, *cs):
+    def forward(ctx, ride, *cs):
         require_gpu(*cs)
         ccs = [_f32c(c) for c in cs]
         Qs = [torch.empty_like(c) for c in ccs]
         Ps = [torch.empty_like(c) for c in ccs]
         Hs = (ctypes.c_int * len(ccs))(*[c.shape[0] for c in ccs])
-        _lib.call('crfconv_crf_matrices_batched', _ptr_array(ccs), Hs, len(ccs), _ptr_array(Qs), _ptr_array(Ps), stream_ptr())
+        if ride:
+            # the launch is QUEUED: the next PointConv statistics pass of a hosting width carries it (its workgroups ride along in
+            # that launch: _take_riders), or flush_riders() -- called before anything reads Q / P -- issues it on its own
+            flush_riders()
+            _RIDERS['mats'] = (ccs, Hs, Qs, Ps)
+        else:
+            _lib.call('crfconv_crf_matrices_batched', _ptr_array(ccs), Hs, len(ccs), _ptr_array(Qs), _ptr_array(Ps), stream_ptr())
         ctx.save_for_backward(*ccs, *Qs)
         ctx.n = len(ccs)
         ctx.cparams = cs                           # the parameter objects themselves (late gradients are installed, not returned)
@@ -290,21 +298,42 @@ class _CrfMatricesBatched(torch.autograd.Function):
                     _install_grad(prm, gr, direct)
             _DEFER['late_calls'].append((launch, (ccs, Qs, gQ, gP, dcs, parked)))
             _arm_flush()
-            return (None,) * n
+            return (None,) * (n + 1)
         dcs = [torch.empty_like(c) for c in ccs]
         _lib.call('crfconv_crf_matrices_backward_batched', _ptr_array(ccs), _ptr_array(Qs), _ptr_array(gQ), _ptr_array(gP), Hs, n,
                   _ptr_array(dcs), stream_ptr())
-        return tuple(dcs)
+        return (None,) + tuple(dcs)
 
 
-def crf_matrices_batched(cs):
+_RIDERS = {'mats': None}      # a queued crf_matrices_batched launch (crf_matrices_batched(ride=True)) waiting for a launch to ride in
+
+
+def flush_riders():
+    """Issues a queued crf_matrices_batched launch on its own (no hosting launch came by): call before the first use of Q / P."""
+    job, _RIDERS['mats'] = _RIDERS['mats'], None
+    if job is not None:
+        ccs, Hs, Qs, Ps = job
+        _lib.call('crfconv_crf_matrices_batched', _ptr_array(ccs), Hs, len(ccs), _ptr_array(Qs), _ptr_array(Ps), stream_ptr())
+
+
+def _take_riders(K, d):
+    """The queued matrices launch for a PointConv statistics pass of this shape to carry (csrc/pointconv.hip:
+    uvstats_hosting_kernel), or None."""
+    if _RIDERS['mats'] is None or _lib.load().crfconv_pointconv_forward_uv_hosts(K, d) != 1:
+        return None
+    job, _RIDERS['mats'] = _RIDERS['mats'], None
+    return job
+
+
+def crf_matrices_batched(cs, ride=False):
     """[(Q, P)] for the compatibility factors `cs` (each [H, H], H <= 64) in one launch; None where a layer's H is wider
-    (crf_meanfield then falls back to its own path)."""
+    (crf_meanfield then falls back to its own path).  ride: the launch is queued for the next PointConv statistics pass to carry
+    (at most 8 layers; the caller runs flush_riders() before the first use of the matrices -- models/point_conv_big.py)."""
     idx = [i for i, c in enumerate(cs) if c.shape[0] <= _CRF_H[-1]]
     out = [None] * len(cs)
     for lo in range(0, len(idx), 8):
         part = idx[lo:lo + 8]
-        res = _CrfMatricesBatched.apply(*[cs[i] for i in part])
+        res = _CrfMatricesBatched.apply(bool(ride) and len(idx) <= 8, *[cs[i] for i in part])
         node = res[0].grad_fn                      # the Function's ctx: carries one gradient box per layer
         for k, i in enumerate(part):
             if node is not None and hasattr(node, 'boxes'):
@@ -445,6 +474,8 @@ class _MeanFieldWide(torch.autograd.Function):
 def crf_meanfield(z, y, c, table, steps, k0=1, matrices=None):
     """z, y: [m, H] (flattened clouds);  c: [H, H] compatibility factor (C = c^T c).  `matrices` = (Q, P) of this c when
     the caller already has them (crf_matrices_batched)."""
+    if _RIDERS['mats'] is not None:
+        flush_riders()                  # queued matrices nobody carried: they must exist before this layer reads them
     H = z.shape[-1]
     if H > _CRF_WIDE_H[-1]:
         raise _lib.CrfConvError('mean field: H = %d exceeds the widest kernel (%d)' % (H, _CRF_WIDE_H[-1]))
@@ -2346,9 +2377,16 @@ class _PointConv(torch.autograd.Function):
             U = torch.empty((m_tgt, d), dtype=torch.float32, device=dev)
             V = torch.empty((m_tgt, d), dtype=torch.float32, device=dev)
             mean_rel = mom32 if mom32 is not None else mom[:3].float()
-            _lib.call('crfconv_pointconv_forward_uv', ptr(x), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d,
-                      ptr(A1), ptr(b1), ptr(W2c), slope, ptr(mean_rel), ptr(shift), ptr(stats), ptr(U), ptr(V), ptr(ws),
-                      nbytes, _pc_ticket(dev), st)
+            riders = _take_riders(K, d)
+            if riders is not None:                   # the CRF layers' matrices ride along in this launch (crf_matrices_batched(ride=True))
+                rc, rH, rQ, rP = riders
+                _lib.call('crfconv_pointconv_forward_uv_hosting', ptr(x), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d,
+                          ptr(A1), ptr(b1), ptr(W2c), slope, ptr(mean_rel), ptr(shift), ptr(stats), ptr(U), ptr(V), ptr(ws),
+                          nbytes, _pc_ticket(dev), _ptr_array(rc), rH, len(rc), _ptr_array(rQ), _ptr_array(rP), st)
+            else:
+                _lib.call('crfconv_pointconv_forward_uv', ptr(x), ptr(pos_src), ptr(pos_tgt), ptr(table.idx32), K, m_tgt, d,
+                          ptr(A1), ptr(b1), ptr(W2c), slope, ptr(mean_rel), ptr(shift), ptr(stats), ptr(U), ptr(V), ptr(ws),
+                          nbytes, _pc_ticket(dev), st)
         a2 = torch.empty(d, dtype=torch.float32, device=dev)
         b2 = torch.empty(d, dtype=torch.float32, device=dev)
         aux2 = torch.empty(2 * d, dtype=torch.float64, device=dev)

@@ -277,6 +277,16 @@ int crfconv_pointconv_forward_uv(const float* x, const float* pos_src, const flo
                                  const float* b1, const float* W2, float slope, const float* mean_rel3,
                                  float* shift, double* stats, float* U, float* V, void* workspace,
                                  size_t workspace_bytes, unsigned* ticket, crf_stream_t stream);
+/* The same launch CARRYING crfconv_crf_matrices_batched(c, H, n, Q, P) as n extra workgroups (round 5): the CRF layers' matrices depend
+ * on parameters only, yet as a launch of their own (a 27 us chain of 64 dependent pivots on n workgroups) they sat in the forward's
+ * launch chain; in the 31 us statistics pass of the network's first PointConv nothing waits for them.  For the widths
+ * crfconv_pointconv_forward_uv_hosts(K, d) names (d = 8); results of both parts are those of the two separate calls. */
+int crfconv_pointconv_forward_uv_hosts(int K, int d);
+int crfconv_pointconv_forward_uv_hosting(const float* x, const float* pos_src, const float* pos_tgt, const int32_t* idx32, int K,
+                                         int64_t m_tgt, int d, const float* A1, const float* b1, const float* W2, float slope,
+                                         const float* mean_rel3, float* shift, double* stats, float* U, float* V, void* workspace,
+                                         size_t workspace_bytes, unsigned* ticket, const float* const* c, const int* H, int n,
+                                         float* const* Q, float* const* P, crf_stream_t stream);
 int crfconv_pointconv_combine(const float* U, const float* V, const double* stats, const float* shift,
                               const float* gamma2, const float* beta2, double n_edges, float* run_mean,
                               float* run_var, float momentum, float eps, int64_t m_tgt, int d, float* a2, float* b2,

@@ -1926,6 +1926,44 @@ def test_shared_weight_gradients_sum_inside_the_sink():
     assert_close(b.grad, torch.full((Co,), 3.0 * M, dtype=torch.float64), 1e-6, 'shared db')
 
 
+def test_crf_matrices_riding_in_the_first_pointconv_launch_equal_the_launch_of_their_own():
+    """ops.crf_matrices_batched(cs, ride=True): the (Q, P) launch of the CRF layers is queued and CARRIED by the next PointConv
+    statistics pass of a hosting width (d = 8: uvstats_hosting_kernel, the riders' workgroups first in the grid) -- Q, P, the
+    PointConv output, every gradient must equal the two separate launches bit for bit.  A queued launch nobody carries (a d = 16
+    PointConv) is issued by flush_riders() / by the first mean-field call."""
+    from crfconv_amd import ops
+    from crfconv_amd.graph import NeighborTable
+    g = torch.Generator().manual_seed(21)
+    n, K = 3000, 16
+    idx = torch.randint(0, n, (1, n, K), generator=g)
+    idx[0, :, 0] = torch.arange(n)
+    table = NeighborTable(idx.to(DEV), n)
+    pos = torch.rand(n, 3, generator=g).to(DEV)
+    res = {}
+    for d in (8, 16):
+        for ride in (False, True):
+            cs = [nn.Parameter((torch.eye(H) + 0.1 * torch.randn(H, H, generator=torch.Generator().manual_seed(H))).to(DEV)) for H in (64, 32, 16, 8)]
+            gg = torch.Generator().manual_seed(d)
+            x = torch.randn(n, d, generator=gg).to(DEV).requires_grad_(True)
+            W1, W2 = nn.Parameter(torch.randn(d, 3, generator=gg).to(DEV)), nn.Parameter((torch.randn(d, d, generator=gg) / d ** 0.5).to(DEV))
+            bn1, bn2 = nn.BatchNorm1d(d).to(DEV).train(), nn.BatchNorm1d(d).to(DEV).train()
+            mats = ops.crf_matrices_batched(cs, ride=ride)
+            assert (ops._RIDERS['mats'] is not None) == ride
+            out = ops.point_conv(x, pos, pos, table, W1, bn1, W2, bn2, True)
+            assert (ops._RIDERS['mats'] is not None) == (ride and d != 8)       # carried by the d = 8 launch only
+            if d == 8:
+                ops.flush_riders()                                               # nothing left: no launch
+            else:
+                z = torch.randn(n, 8, generator=gg).to(DEV)
+                ops.crf_meanfield(z, z, cs[3], table, 1, matrices=mats[3])       # the first consumer flushes
+                assert ops._RIDERS['mats'] is None
+            loss = (out * out).sum() + sum((Q * Q).sum() + (P * Q).sum() for Q, P in mats)
+            loss.backward()
+            res[d, ride] = [out.detach()] + [t_.detach() for m in mats for t_ in m] + [x.grad, W1.grad, W2.grad] + [c.grad for c in cs]
+        for a, b in zip(res[d, False], res[d, True]):
+            assert float(a.abs().max()) > 0 and torch.equal(a, b)
+
+
 def test_crf_parameter_gradients_deferred_to_the_end_of_the_pass_equal_the_immediate_ones():
     """Inside ops.deferred_weight_grads the CRF layers' dP / dQ (H >= 32: partial passes + sums in the batched launches) and the
     batched matrices backward run at the END of the backward pass and install dc as .grad; values must equal the immediate form's
