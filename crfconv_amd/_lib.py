@@ -117,6 +117,7 @@ SIGNATURES = {
     'crfconv_index_narrow_batched': (_i, [_vp, _i, _vp]),
     'crfconv_pointconv_moments_batched_workspace': (_sz, [_vp, _i]),
     'crfconv_pointconv_moments_batched': (_i, [_vp, _i, _vp, _sz, _vp]),
+    'crfconv_reduce_jobs_both': (_i, [_vp, _i, _vp, _i, _vp]),
     'crfconv_reduce_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_linear_forward_supported': (_i, [_i, _i]),
     'crfconv_linear_forward_stat_records': (_sz, [_i64]),
@@ -138,7 +139,7 @@ SIGNATURES = {
     'crfconv_bn_coef_from_nrecords': (_i, [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
     'crfconv_bn_coef_from_records': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
     'crfconv_softmax_ce_workspace': (_sz, [_i64]),
-    'crfconv_softmax_ce_forward': (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'crfconv_softmax_ce_forward': (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'crfconv_softmax_ce_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _vp, _vp]),
     'crfconv_crf_matrices': (_i, [_vp, _i, _vp, _vp, _vp]),
     'crfconv_crf_matrices_backward': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),

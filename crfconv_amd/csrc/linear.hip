@@ -15,6 +15,7 @@
 #include "gridsync.hpp"
 #include "wgrad_body.hpp"
 #include "crf_matrices_body.hpp"
+#include "reduce64_body.hpp"
 
 #include <cstdlib>
 
@@ -418,6 +419,25 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(const ReduceJobTable t
     reduce_slab64(tbl.partial[lo], tbl.nblk[lo], tbl.nslots[lo], (g - tbl.group_begin[lo]) * 64, tbl.out[lo], s_part);
 }
 
+
+// crfconv_reduce_jobs AND crfconv_reduce_jobs_f64 in one launch (the end of a backward pass runs both, on independent inputs: the
+// float64 sums are ~650 wavefront-per-slot workgroups of latency, the float ones ~12 000 workgroups of bandwidth): the first n64
+// workgroups take the float64 table -- they start first --, the others the float one.
+__global__ __launch_bounds__(256) void reduce_both_kernel(const ReduceJobTable tbl, const Reduce64Table t64, const int n64) {
+    __shared__ float s_part[4][64];
+    if ((int)blockIdx.x < n64) {
+        reduce_jobs_f64_body(t64, blockIdx.x);
+        return;
+    }
+    const int g = (int)blockIdx.x - n64;
+    int lo = 0, hi = tbl.njobs;                       // largest j with group_begin[j] <= g
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tbl.group_begin[mid] <= g) lo = mid; else hi = mid;
+    }
+    reduce_slab64(tbl.partial[lo], tbl.nblk[lo], tbl.nslots[lo], (g - tbl.group_begin[lo]) * 64, tbl.out[lo], s_part);
+}
+
 }  // namespace crf
 
 using namespace crf;
@@ -519,6 +539,50 @@ extern "C" int crfconv_reduce_jobs(const crf_reduce_job* jobs, int njobs, crf_st
         hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)total), dim3(256), 0, st, tbl);
         CRF_LAUNCH_CHECK();
     }
+    return CRF_OK;
+}
+
+extern "C" int crfconv_reduce_jobs_f64(const crf_reduce64_job* jobs, int njobs, crf_stream_t stream);      // pointconv.hip
+// Both kinds of sums of a backward pass in ONE launch when each fits one table (96 float jobs, 32 float64 jobs): same results as the
+// two calls.  Larger batches: the two calls.
+extern "C" int crfconv_reduce_jobs_both(const crf_reduce_job* jobs, int njobs, const crf_reduce64_job* jobs64, int njobs64,
+                                        crf_stream_t stream) {
+    CRF_REQUIRE((jobs || njobs == 0) && (jobs64 || njobs64 == 0) && njobs >= 0 && njobs64 >= 0, CRF_ERR_ARG, "null pointer or negative count");
+    if (njobs == 0 || njobs64 == 0 || njobs > RJ_MAX || njobs64 > R64_MAX) {
+        if (njobs64 > 0)
+            if (int rc = crfconv_reduce_jobs_f64(jobs64, njobs64, stream)) return rc;
+        return njobs > 0 ? crfconv_reduce_jobs(jobs, njobs, stream) : CRF_OK;
+    }
+    ReduceJobTable tbl;
+    int64_t total = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const crf_reduce_job& jb = jobs[j];
+        CRF_REQUIRE(jb.partial && jb.out && jb.nblk > 0 && jb.nslots > 0, CRF_ERR_ARG, "job %d is malformed", j);
+        tbl.partial[j] = jb.partial; tbl.out[j] = jb.out; tbl.nblk[j] = jb.nblk; tbl.nslots[j] = jb.nslots;
+        tbl.group_begin[j] = (int)total;
+        total += (jb.nslots + 63) / 64;
+    }
+    for (int j = njobs; j <= RJ_MAX; ++j) tbl.group_begin[j] = (int)total;
+    for (int j = njobs; j < RJ_MAX; ++j) { tbl.partial[j] = nullptr; tbl.out[j] = nullptr; tbl.nblk[j] = 0; tbl.nslots[j] = 0; }
+    tbl.njobs = njobs;
+    Reduce64Table t;
+    int64_t waves = 0;
+    for (int j = 0; j <= R64_MAX; ++j) {
+        t.wave_base[j] = (int)waves;
+        if (j < njobs64) {
+            const crf_reduce64_job& jb = jobs64[j];
+            CRF_REQUIRE(jb.partial && jb.out && jb.nblk > 0 && jb.nblk < ((int64_t)1 << 31) && jb.nslots > 0, CRF_ERR_ARG, "float64 job %d is malformed", j);
+            t.partial[j] = jb.partial; t.out[j] = jb.out; t.is_float[j] = jb.is_float; t.nblk[j] = (int)jb.nblk; t.nslots[j] = jb.nslots;
+            waves += jb.nslots;
+        } else if (j < R64_MAX) {
+            t.partial[j] = nullptr; t.out[j] = nullptr; t.is_float[j] = 0; t.nblk[j] = 0; t.nslots[j] = 0;
+        }
+    }
+    t.njobs = njobs64;
+    const int64_t n64 = cdiv(waves, 256 / WAVE);
+    CRF_REQUIRE(total + n64 < ((int64_t)1 << 30), CRF_ERR_UNSUPPORTED, "too many slots in one batch");
+    hipLaunchKernelGGL(reduce_both_kernel, dim3((unsigned)(total + n64)), dim3(256), 0, as_stream(stream), tbl, t, (int)n64);
+    CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
 

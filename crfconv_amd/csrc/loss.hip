@@ -6,6 +6,7 @@
 // cache lines), per-block float64 partials, a last single-block kernel folds them in fixed order.
 // The framework's nll_loss kernels reduce on ONE workgroup (126 us forward + 126 us backward at 164 k rows).
 #include "common.hpp"
+#include "gridsync.hpp"
 
 namespace crf {
 
@@ -16,8 +17,10 @@ __global__ __launch_bounds__(CE_BLOCK) void ce_fwd_kernel(const float* __restric
                                                           const float* __restrict__ weight, int64_t m, int C,
                                                           int64_t ignore_index, int64_t label_shift,
                                                           float* __restrict__ lse,
-                                                          double* __restrict__ partial) {
+                                                          double* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                          double* __restrict__ sums, float* __restrict__ loss) {
     __shared__ double s_red[3][CE_BLOCK / WAVE];
+    __shared__ int s_flag;
     const int64_t r = (int64_t)blockIdx.x * CE_BLOCK + threadIdx.x;
     double num = 0.0, den = 0.0, bad = 0.0;
     if (r < m) {
@@ -47,10 +50,37 @@ __global__ __launch_bounds__(CE_BLOCK) void ce_fwd_kernel(const float* __restric
         if ((threadIdx.x & 63) == 0) s_red[i][threadIdx.x >> 6] = v[i];
     }
     __syncthreads();
+    typedef unsigned int ce_u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t pr = make_rsrc(partial, (int)gridDim.x * 3 * 8);
     if (threadIdx.x < 3) {
         double a = 0.0;
         for (int w = 0; w < CE_BLOCK / WAVE; ++w) a += s_red[threadIdx.x][w];
-        partial[(int64_t)blockIdx.x * 3 + threadIdx.x] = a;
+        // write-through: with a ticket the launch's last workgroup (another CU, maybe another XCD) reads the rows below
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(a);
+        const ce_u32x2 u = {(unsigned)bits, (unsigned)(bits >> 32)};
+        __builtin_amdgcn_raw_buffer_store_b64(u, pr, ((int)blockIdx.x * 3 + (int)threadIdx.x) * 8, 0, 16);
+    }
+    // "the last workgroup finishes" (gridsync.hpp): ce_finalize_kernel's arithmetic, in its order, without its launch
+    if (ticket == nullptr || !last_workgroup(ticket, gridDim.x, &s_flag)) return;
+    double t[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += CE_BLOCK)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const ce_u32x2 w2 = __builtin_amdgcn_raw_buffer_load_b64(pr, (b * 3 + i) * 8, 0, 16);
+            t[i] += __longlong_as_double((long long)(((unsigned long long)w2.y << 32) | w2.x));
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t[i] += __shfl_xor(t[i], o, WAVE);
+        if ((threadIdx.x & 63) == 0) s_red[i][threadIdx.x >> 6] = t[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a[3];
+        for (int i = 0; i < 3; ++i) a[i] = s_red[i][0] + s_red[i][1] + s_red[i][2] + s_red[i][3];
+        sums[0] = a[0]; sums[1] = a[1]; sums[2] = a[2];
+        *loss = (float)(a[0] / a[1]);
     }
 }
 
@@ -108,7 +138,7 @@ extern "C" size_t crfconv_softmax_ce_workspace(int64_t m) {
 extern "C" int crfconv_softmax_ce_forward(const float* logits, const int64_t* target, const float* weight,
                                           int64_t m, int C, int64_t ignore_index, int64_t label_shift, float* lse,
                                           double* sums, float* loss, void* workspace, size_t workspace_bytes,
-                                          crf_stream_t stream) {
+                                          unsigned* ticket, crf_stream_t stream) {
     CRF_REQUIRE(logits && target && lse && sums && loss && workspace, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(m > 0 && C >= 1 && C <= 4096 && m * C < ((int64_t)1 << 40), CRF_ERR_ARG, "m=%lld C=%d out of range",
                 (long long)m, C);
@@ -116,11 +146,14 @@ extern "C" int crfconv_softmax_ce_forward(const float* logits, const int64_t* ta
     double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     const int64_t nblk = cdiv(m, CE_BLOCK);
     hipStream_t st = as_stream(stream);
+    if (nblk * 3 * 8 >= ((int64_t)1 << 31)) ticket = nullptr;             // (the partial rows are addressed through a 32-bit buffer descriptor)
     hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)nblk), dim3(CE_BLOCK), 0, st, logits, target, weight, m, C,
-                       ignore_index, label_shift, lse, partial);
+                       ignore_index, label_shift, lse, partial, ticket, sums, loss);
     CRF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, sums, loss);
-    CRF_LAUNCH_CHECK();
+    if (ticket == nullptr) {                                               // no ticket words: the fold as a launch of its own
+        hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, sums, loss);
+        CRF_LAUNCH_CHECK();
+    }
     return CRF_OK;
 }
 

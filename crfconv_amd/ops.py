@@ -768,11 +768,16 @@ def _defer_reduce64(partial_ptr, is_float, nblk, nslots, out, keep):
     _arm_flush()
 
 
-def _flush_fold1_bwd():
+def _take_red64():
+    """The queued float64 sums (the PointConv layers' parameter-gradient slabs) as a job array for the end-of-pass sum launch."""
     red, _DEFER['red64'] = _DEFER.get('red64', []), []
-    if red:
-        arr = (_lib.Reduce64Job * len(red))(*[j for j, _ in red])
-        _lib.call('crfconv_reduce_jobs_f64', ctypes.cast(arr, ctypes.c_void_p), len(red), stream_ptr())
+    if not red:
+        return None, 0, None
+    return (_lib.Reduce64Job * len(red))(*[j for j, _ in red]), len(red), red
+
+
+def _flush_fold1_bwd():
+    """The batched BatchNorm-1 fold backward of all PointConv layers: AFTER the float64 sums it reads."""
     folds, _DEFER['folds'] = _DEFER['folds'], []
     if not folds:
         return
@@ -854,11 +859,15 @@ def _flush_weight_grads():
         partials.sort(key=lambda e: -(e[0].M * e[0].Co * e[0].Ci))
         arr = (_lib.WgradJob * len(partials))(*[j for j, _ in partials])
         _lib.call('crfconv_linear_wgrad_partial_jobs', ctypes.cast(arr, ctypes.c_void_p), len(partials), stream_ptr())
-    _flush_fold1_bwd()
-    _flush_mlp_dw()
+    arr64, n64, keep64 = _take_red64()
     tns, _DEFER['tn'] = _DEFER.get('tn', []), []
     late_calls, _DEFER['late_calls'] = _DEFER.get('late_calls', []), []
+    st = stream_ptr()
     if not jobs and not tns:
+        if n64:
+            _lib.call('crfconv_reduce_jobs_f64', ctypes.cast(arr64, ctypes.c_void_p), n64, st)
+        _flush_fold1_bwd()
+        _flush_mlp_dw()
         for fn, _ in late_calls:
             fn()
         _DEFER['claimed'] = set()
@@ -900,7 +909,11 @@ def _flush_weight_grads():
             table[n] = _lib.ReduceJob(base + 4 * nblk * Co * Ci, tb.data_ptr(), nblk, Co)
             installs.append((b, tb, db))
             n += 1
-    _lib.call('crfconv_reduce_jobs', ctypes.cast(table, ctypes.c_void_p), n, stream_ptr())
+    # every sum of the pass -- the float weight-gradient slabs and the PointConv layers' float64 slabs -- in ONE launch
+    _lib.call('crfconv_reduce_jobs_both', ctypes.cast(table, ctypes.c_void_p), n, None if not n64 else ctypes.cast(arr64, ctypes.c_void_p), n64, st)
+    del keep64
+    _flush_fold1_bwd()                                  # reads the float64 sums
+    _flush_mlp_dw()
     for fn, _ in late_calls:                            # launches that read what the sums above produced
         fn()
     for prm, gr, was_direct in installs:
@@ -2259,7 +2272,7 @@ class _SoftmaxCE(torch.autograd.Function):
         nbytes = _lib.load().crfconv_softmax_ce_workspace(m)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call('crfconv_softmax_ce_forward', ptr(z), ptr(tgt), ptr(w), m, C, int(ignore_index), int(label_shift),
-                  ptr(lse), ptr(sums), ptr(loss), ptr(ws), nbytes, stream_ptr())
+                  ptr(lse), ptr(sums), ptr(loss), ptr(ws), nbytes, ptr(_ticket(dev)), stream_ptr())
         ctx.save_for_backward(z, tgt, w, lse, sums)
         ctx.args = (int(ignore_index), int(label_shift))
         return loss

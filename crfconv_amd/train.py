@@ -126,6 +126,20 @@ class GraphedModel(torch.nn.Module):
         self.static = self.static_out = self.static_gout = None
         self.params, self.static_grads, self._sig = [], [], None
 
+    # the wrapper is transparent for checkpoints and for the wrapped class's own attributes (Base.save / load, `.C`, ...):
+    # state_dict keys are the wrapped model's (reference checkpoints load with strict=True, as on the bare model)
+    def state_dict(self, *args, **kwargs):
+        return self.model.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        return self.model.load_state_dict(state_dict, *args, **kwargs)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__('model'), name)
+
     @staticmethod
     def _signature(batch):
         sig = []

@@ -437,6 +437,9 @@ typedef struct { const float* G; const float* X; int64_t M; int Co; int Ci; int 
 int crfconv_linear_wgrad_nblk(int64_t M, int Co, int Ci);
 int crfconv_linear_wgrad_partial_jobs(const crf_wgrad_job* jobs, int njobs, crf_stream_t stream);
 int crfconv_reduce_jobs(const crf_reduce_job* jobs, int njobs, crf_stream_t stream);
+/* crfconv_reduce_jobs and crfconv_reduce_jobs_f64 (below / above: independent inputs, both at the end of a backward pass) in ONE launch
+ * when each batch fits one table (96 / 32 jobs), else the two calls; identical results. */
+int crfconv_reduce_jobs_both(const crf_reduce_job* jobs, int njobs, const crf_reduce64_job* jobs64, int njobs64, crf_stream_t stream);
 
 /* Linear -> BatchNorm(train) -> LeakyReLU of the coarse levels as ONE launch (csrc/mlp_small.hip): replaces the
  * nn.Linear + FastBatchNorm1d + activation chain of models/common.py:34-40 where m <= 4096 rows (encoder / decoder
@@ -710,7 +713,9 @@ int crfconv_add_lrelu_backward(const float* gout, const float* out, int64_t n, f
 size_t crfconv_softmax_ce_workspace(int64_t m);
 int crfconv_softmax_ce_forward(const float* logits, const int64_t* target, const float* weight, int64_t m, int C,
                                int64_t ignore_index, int64_t label_shift, float* lse, double* sums, float* loss,
-                               void* workspace, size_t workspace_bytes, crf_stream_t stream);
+                               void* workspace, size_t workspace_bytes, unsigned* ticket, crf_stream_t stream);
+/* ticket: crfconv_ticket_bytes() of zero device words per stream (left zero) -- the last workgroup of the forward folds the per-block
+ * sums (one launch); NULL: the fold as a second launch.  Same sums, same order, either way. */
 int crfconv_softmax_ce_backward(const float* logits, const int64_t* target, const float* weight, const float* lse,
                                 const double* sums, const float* grad_loss, int64_t m, int C, int64_t ignore_index,
                                 int64_t label_shift, float* dlogits, crf_stream_t stream);

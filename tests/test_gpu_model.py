@@ -2083,6 +2083,7 @@ def test_graphed_model_in_the_unchanged_reference_loop_equals_the_eager_loop():
             optimizer.step()
             losses[name].append(float(loss))
     assert net.fwd_graph is not None and net.bwd_graph is not None
+    assert list(net.state_dict().keys()) == list(ref.state_dict().keys()) and net.C == ref.C       # transparent for checkpoints / attributes
     for a, b in zip(losses['graphed'], losses['eager']):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), losses
     for (k, a), b in zip(inner.state_dict().items(), ref.state_dict().values()):
