@@ -719,6 +719,8 @@ def main():
     ap.add_argument('--points', type=int, default=40960)
     ap.add_argument('--crf-steps', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pipe-gate', default='backward', choices=['off', 'forward', 'backward'],
+                    help="the pipelined loop's device-side gate: the collate graph starts when the training step's forward ('forward') / backward ('backward') reaches its coarse levels, or wherever the launches fall ('off')")
     ap.add_argument('--mfma-min-rows', type=int, default=0, help='EXPERIMENT knob (A/B runs only): rows from which the row-streaming Linear forms take over from the tiled ones (ops._MFMA_MIN_ROWS; 0 = the shipped 12288)')
     ap.add_argument('--rehearse', action='store_true', help='rank plumbing only, on the CPU over gloo (no GPU call, no benchmark): see rehearse()')
     ap.add_argument('--other-configs', action='store_true', help='(default since round 5; kept for old command lines)')
@@ -944,6 +946,7 @@ def main():
     # i+1 on a side stream while the captured step of batch i trains (data.CollatePipeline).  EVERY iteration collates a
     # batch (host subset draw + Morton argsort + kNN at 5 scales + table / reverse-CSR / moment refresh) and trains on it.
     pipe_ms = None
+    pipe_gate = None
     if t_graph is not None and graph_note.startswith('hipGraph'):
         try:
             from crfconv_amd.data import CollatePipeline
@@ -954,6 +957,7 @@ def main():
             with torch.cuda.graph(ga2, pool=ga.pool(), capture_error_mode='thread_local'):
                 part_a(data2)
             gas = (ga, ga2)
+            gate = args.pipe_gate != 'off'
             raws = [(pos_r, x_r, y_r)]
             raw = [synth_cloud(9000 + rank * B + i, N) for i in range(B)]
             pos_q = torch.from_numpy(np.stack([c[0] for c in raw])).to(dev)
@@ -961,9 +965,23 @@ def main():
                          torch.from_numpy(np.stack([c[2] for c in raw])).to(dev)))
             prio = os.environ.get('CRFCONV_BENCH_COLLATE_PRIORITY')     # A/B: side-stream priority (default: the lowest)
             pipe = CollatePipeline([data, data2], generator=torch.Generator().manual_seed(77 + rank),
-                                   priority=None if prio is None else int(prio))
+                                   priority=None if prio is None else int(prio), gate=gate)
             pipe.submit(0, *raws[0])
             pipe.submit(1, *raws[1])                      # both collate graphs captured
+            if gate:
+                # the training graphs of the pipelined loop carry ONE more launch: a mark where the forward reaches its coarse levels
+                # (PointConvBig.phase_hook); the collate graph on the side stream starts behind a bounded wait for it, so its kernels
+                # fall beside the step's coarse-level launches (most of the chip idle) instead of beside its fine-level ones
+                net.phase_hook = pipe.mark_on('coarse' if args.pipe_gate == 'forward' else 'coarse_backward')
+                gated = []
+                for d in (data, data2):
+                    gg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gg, pool=ga.pool(), capture_error_mode='thread_local'):
+                        part_a(d)
+                    gated.append(gg)
+                net.phase_hook = None
+                gas = tuple(gated)
+                pipe.enable_gate(True)
 
             def run_pipe(n, i0):
                 for i in range(i0, i0 + n):
@@ -998,6 +1016,8 @@ def main():
                 tt = torch.tensor([pipe_ms], device=dev, dtype=torch.float64)
                 torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
                 pipe_ms = float(tt.item())
+            pipe_gate = {'mode': args.pipe_gate, 'timeouts': pipe.gate_timeouts(), 'still_on': pipe.gate_is_on()}
+            pipe.enable_gate(False)
         except Exception:
             import traceback
             traceback.print_exc()
@@ -1049,7 +1069,7 @@ def main():
             'table_refresh_ms_per_batch': fresh['table_refresh_ms_per_batch'],
             'preprocess_plus_refresh_graph_ms_per_batch': fresh['collate_plus_refresh_graph_ms_per_batch'],
             'value_incl_preprocessing_serial': world * B * N / (per_batch_ms * 1e-3) / 1e6,
-            'pipelined_ms_per_batch': pipe_ms,
+            'pipelined_ms_per_batch': pipe_ms, 'pipelined_gate': pipe_gate,
             'value_incl_preprocessing': world * B * N / ((pipe_ms or per_batch_ms) * 1e-3) / 1e6,
             'fresh_batch_replay': fresh,
             'launch_mode': graph_note,

@@ -125,6 +125,8 @@ SIGNATURES = {
     'crfconv_cat2': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     'crfconv_split2': (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
     'crfconv_add_i64': (_i, [_vp, _i64, _i64, _vp]),
+    'crfconv_gate_mark': (_i, [_vp, _vp]),
+    'crfconv_gate_wait': (_i, [_vp, _i, _vp]),
     'crfconv_mlp_small_backward_supported': (_i, [_i64, _i, _i]),
     'crfconv_gemm_stats_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_bn_apply_from_records_jobs': (_i, [_vp, _i, _vp]),

@@ -358,9 +358,10 @@ class CollateGraph:
         train_graph.replay()
     """
 
-    def __init__(self, target, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), generator=None, device_draw=True, slot=0):
+    def __init__(self, target, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), generator=None, device_draw=True, slot=0, gate=None):
         self.target, self.kernel_size, self.ratio, self.generator = target, tuple(kernel_size), tuple(ratio), generator
         self.device_draw = bool(device_draw)
+        self.gate = gate                         # 4 int64 device words (crfconv_gate_wait): the graph's first launch waits for a mark of the training stream
         # The subset seed is a DRAW on the caller's generator (it advances the generator's state): graphs built one after the
         # other from one generator -- rebuilt per epoch, after a resume, the slots of a CollatePipeline -- get different
         # sequences, and a run re-started from the same generator state reproduces them.  (Keyed on initial_seed() alone, every
@@ -411,6 +412,10 @@ class CollateGraph:
         self._uploaded.record()
 
     def _work(self):
+        if self.gate is not None:
+            from . import _lib
+            from .graph import ptr, stream_ptr
+            _lib.call('crfconv_gate_wait', ptr(self.gate), CollatePipeline.GATE_MAX_WAIT_US, stream_ptr())
         if self.device_draw:
             from . import _lib
             from .graph import ptr, stream_ptr
@@ -464,8 +469,17 @@ class CollatePipeline:
             pipe.release(s)                        # slot s may be overwritten once the work queued so far has run
     """
 
+    GATE_MAX_WAIT_US = 3000       # a gated collate goes ahead after this long without a mark (crfconv_gate_wait)
+
     def __init__(self, batches, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), generator=None, device_draw=True,
-                 priority=None):
+                 priority=None, gate=False):
+        """gate: the collate graphs START with a bounded device-side wait for a mark of the training stream (``self.mark()``,
+        called inside the captured training step where its coarse levels begin -- e.g. PointConvBig.phase_hook): the side stream's
+        kernels then fall into the part of the step whose launches leave most of the chip idle instead of beside its fine-level
+        kernels (``mark_on('coarse_backward')``: 4.36 -> 4.25 ms per batch at 4 x 40 960 points; the forward's window or the collate as
+        two gated graphs, one per window: 4.33 / 4.27).  Off until ``enable_gate(True)``; a collate that sees no mark within
+        GATE_MAX_WAIT_US goes ahead, and after three such waits in a row the gate switches itself off (a marking stream that shares
+        the side stream's hardware queue can never run beside the wait)."""
         import os
         import warnings
         if (torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -475,14 +489,66 @@ class CollatePipeline:
                           'hardware queue with the collate stream (measured 7.1 instead of 5.8 ms per iteration); import '
                           'crfconv_amd before torch initialises the GPU, or export GPU_MAX_HW_QUEUES=8')
         self.batches = list(batches)
-        self.graphs = [CollateGraph(b, kernel_size, ratio, generator, device_draw=device_draw, slot=k) for k, b in enumerate(self.batches)]
+        self.gate = torch.zeros(4, dtype=torch.int64, device=self.batches[0].multiscale[0].pos.device) if gate else None
+        self.graphs = [CollateGraph(b, kernel_size, ratio, generator, device_draw=device_draw, slot=k, gate=self.gate)
+                       for k, b in enumerate(self.batches)]
         # the side stream at the LOWEST priority the device offers by default: the collate fills the CUs the training step
         # leaves idle (its many small launches) instead of taking turns with it
         if priority is None:
             priority = max(torch.cuda.Stream.priority_range())
         self.stream = torch.cuda.Stream(priority=priority)
+        if self.gate is not None:
+            # the gate needs a side stream that RUNS BESIDE the caller's: HIP maps streams onto a few hardware queues, and a wait on
+            # the queue of the stream that is to mark it just times out (crfconv_gate_wait then switches the gate off).  Probe.
+            for _ in range(8):
+                if self.runs_beside_current(self.stream):
+                    break
+                self.stream = torch.cuda.Stream(priority=priority)
+            else:
+                warnings.warn('CollatePipeline(gate=True): no side stream found that runs beside the current one; the gate stays off')
+                self.gate = None
+                for g in self.graphs:
+                    g.gate = None
         self._ready = [torch.cuda.Event() for _ in self.batches]
         self._free = [None for _ in self.batches]
+
+    @staticmethod
+    def runs_beside_current(stream, wait_us=5000):
+        """True when a kernel on `stream` can wait for one launched later on the current stream (a gate handshake; a few milliseconds
+        when it cannot)."""
+        from . import _lib
+        from .graph import ptr, stream_ptr
+        probe = torch.zeros(4, dtype=torch.int64, device=torch.cuda.current_device())
+        probe[2] = 1
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            _lib.call('crfconv_gate_wait', ptr(probe), int(wait_us), stream_ptr())
+        _lib.call('crfconv_gate_mark', ptr(probe), stream_ptr())
+        torch.cuda.synchronize()
+        return int(probe[1].item()) == 1
+
+    def mark(self, *_):
+        """One mark on the gate from the CURRENT stream (a tiny launch): call it inside the captured training step."""
+        if self.gate is not None:
+            from . import _lib
+            from .graph import ptr, stream_ptr
+            _lib.call('crfconv_gate_mark', ptr(self.gate), stream_ptr())
+
+    def mark_on(self, phase):
+        """A phase hook (PointConvBig.phase_hook) that marks the gate when the model announces `phase`."""
+        return lambda name, *_: self.mark() if name == phase else None
+
+    def enable_gate(self, on=True):
+        if self.gate is not None:
+            self.gate[2] = 1 if on else 0
+            self.gate[1] = self.gate[0]          # marks of the past open nothing
+
+    def gate_timeouts(self):
+        return 0 if self.gate is None else int(self.gate[3].item())
+
+    def gate_is_on(self):
+        """False once the gate has switched itself off (three waits in a row without a mark: see crfconv_gate_wait)."""
+        return self.gate is not None and int(self.gate[2].item()) != 0
 
     def state_dict(self):
         """Seeds and batch counters of the slots' graphs (CollateGraph.state_dict): what a checkpoint needs to continue the subset sequences."""

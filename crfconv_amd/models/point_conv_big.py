@@ -163,6 +163,11 @@ class PointConvResNet(Base):
         self.classifier = nn.Sequential(MLP(WIDTHS[0], WIDTHS[0] * 4, activation=_lrelu()), nn.Dropout(p=0.5),
                                         nn.Linear(WIDTHS[0] * 4, n_classes))
 
+    # optional callable(name), invoked while the step is being issued (and hence captured) where a phase begins: 'coarse' in front of
+    # the forward's first level-2 block, 'coarse_backward' when the backward reaches the decoder's level 2 (a tensor hook).
+    # data.CollatePipeline(gate=True).mark_on(name) makes one: the side stream's collate graph waits for that mark.
+    phase_hook = None
+
     def forward(self, data):
         if self.training:
             with ops.advance_counters(self):              # every BatchNorm below runs exactly once per forward
@@ -191,6 +196,8 @@ class PointConvResNet(Base):
         h = plan[1][0](h, plan[1][1], plan[1][2], prefold=pre[1])
         skips = [h]
         for lvl in range(1, len(WIDTHS)):
+            if lvl == 2 and self.phase_hook is not None:
+                self.phase_hook('coarse')                      # from here to the decoder's level 1 the launches are coarse-level ones
             (b1, p1, i1), (b2, p2, i2) = plan[2 * lvl], plan[2 * lvl + 1]
             # the level's output has three consumers (this block's lin_in and shortcut, the decoder): one fork chain, no add pass
             h, skips[-1] = b1(h, p1, i1, return_input_alias=True, prefold=pre[2 * lvl])
@@ -202,6 +209,9 @@ class PointConvResNet(Base):
                 h = d(h, skips[lvl], ms[lvl].up_idx, ms[lvl].neighbor_idx, matrices=mat)
             else:
                 h = d(h, skips[lvl], ms[lvl].up_idx, ms[lvl].neighbor_idx)
+            if lvl == 2 and self.phase_hook is not None and h.requires_grad:
+                # the gradient of the level-2 decoder output arrives when the backward leaves the fine levels: its coarse window begins
+                h.register_hook(lambda g, f=self.phase_hook: (f('coarse_backward'), None)[1])
         head, drop, last = self.classifier[0], self.classifier[1], self.classifier[2]
         fused = logits = None
         if (self.training and type(drop) is nn.Dropout and not drop.inplace and isinstance(head, MLP) and head.bn is not None

@@ -543,6 +543,14 @@ int crfconv_linear_forward(const float* X, const float* W, const float* bias, in
 int crfconv_cat2(const float* xa, const float* xb, int64_t m, int ca, int cb, float* out, crf_stream_t stream);
 int crfconv_split2(const float* g, int64_t m, int ca, int cb, float* ga, float* gb, crf_stream_t stream);
 int crfconv_add_i64(int64_t* x, int64_t n, int64_t delta, crf_stream_t stream);
+/* A bounded device-side gate between two streams (csrc/rows.hip): gate = 4 zeroed uint64 device words (mark | consumed | enabled |
+ * timeouts).  crfconv_gate_mark (inside the training graph, where its coarse levels begin) adds one mark; crfconv_gate_wait (first
+ * launch of the collate graph on the side stream) holds its stream until an unconsumed mark exists -- for at most max_wait_us
+ * (<= 100 000) microseconds, then goes ahead and counts a timeout (three in a row switch the gate off: gate[2] = 0); it returns at
+ * once while gate[2] == 0.  No host involvement, no event: a wait on an event recorded INSIDE a replayed graph sees the previous
+ * replay's record. */
+int crfconv_gate_mark(uint64_t* gate, crf_stream_t stream);
+int crfconv_gate_wait(uint64_t* gate, int max_wait_us, crf_stream_t stream);
 
 /* C [M, N] = A [M, K] B (+ bias [N]) (+ addend [M, N]) on fp32 MFMA for the shapes crfconv_linear_forward does not take:
  * the coarse-level Linear forward (models/common.py:30,35 at 640 .. 10 240 rows, up to 512 channels), every dX = gY W of

@@ -472,11 +472,15 @@ def test_collate_graph_replay_equals_eager_collate():
     assert all(torch.equal(u, v) for u, v in zip(want, b.choices))
 
 
-def test_collate_pipeline_double_buffer_overlaps_without_races():
+@pytest.mark.parametrize('gate', [False, True])
+def test_collate_pipeline_double_buffer_overlaps_without_races(gate):
     """data.CollatePipeline: the collate graph of batch i+1 runs on a side stream while the consumer of batch i runs on the
     caller's stream.  Six batches through two slots; what the consumer sees after acquire() must equal an eager collate of
     the clouds submitted for that slot with the subsets drawn for it -- also with a slow consumer (a long kernel queue on
-    the caller's stream between acquire and release) and a slot that is overwritten right after release."""
+    the caller's stream between acquire and release) and a slot that is overwritten right after release.  gate: the collate graphs
+    start behind the bounded device-side wait (crfconv_gate_wait) for a mark the consumer's stream makes (pipe.mark()) -- every
+    second batch here, so that both the opened gate and the timed-out one (no mark: the collate goes ahead after GATE_MAX_WAIT_US)
+    are seen; the batches must be the same either way."""
     import crfconv_amd
     from crfconv_amd import models, ops
     from crfconv_amd.data import CollatePipeline
@@ -494,14 +498,18 @@ def test_collate_pipeline_double_buffer_overlaps_without_races():
         st = crfconv_amd.multiscale_compute(pos0, x=x0, y=y0, generator=torch.Generator().manual_seed(k))
         ops.training_loss(net(st), st.y, None, ignore_index=-1).backward()
         statics.append(st)
-    pipe = CollatePipeline(statics, generator=torch.Generator().manual_seed(3))
+    pipe = CollatePipeline(statics, generator=torch.Generator().manual_seed(3), gate=gate)
     inputs = [clouds(700 + 10 * i) for i in range(7)]
+    pipe.submit(1, *inputs[0])                                      # (first use of a slot captures its graph: both before the gate is on)
     pipe.submit(0, *inputs[0])
+    pipe.enable_gate(True)
     seen = []
     burn = torch.randn(2048, 2048, device=DEV)
     for i in range(6):
         s = i % 2
         pipe.submit(1 - s, *inputs[i + 1])
+        if i % 2 == 0:
+            pipe.mark()                                              # (the training step's mark: opens the gate of the collate just queued)
         batch = pipe.acquire(s)
         for _ in range(4 if i % 3 == 0 else 0):
             burn = torch.tanh(burn @ burn * 1e-3)                      # a slow consumer: the batch must stay intact under it
@@ -512,6 +520,8 @@ def test_collate_pipeline_double_buffer_overlaps_without_races():
         pipe.release(s)
         seen.append(snap)
     torch.cuda.synchronize()
+    assert pipe.gate_timeouts() == (3 if gate else 0)                # the three collates without a mark went ahead on their own
+    assert pipe.gate_is_on() == bool(gate)                           # (never three in a row: the gate stayed on)
     for i, snap in enumerate(seen):
         pos, x, y = inputs[i]
         ref = crfconv_amd.multiscale_compute(pos, x=x, y=y, choices=snap['choices'], sort='morton')
@@ -522,6 +532,53 @@ def test_collate_pipeline_double_buffer_overlaps_without_races():
             assert tabs
             for key, idx32 in tabs:
                 assert torch.equal(idx32, table_of(lv_r.neighbor_idx, key[0]).idx32), (i, key)
+
+
+def test_gate_mark_and_bounded_wait():
+    """crfconv_gate_mark / crfconv_gate_wait (csrc/rows.hip): a disabled gate never waits; an enabled one holds its stream until an
+    unconsumed mark exists -- one mark opens it once -- and for at most max_wait_us when none comes (counted as a timeout); three
+    timeouts in a row switch it off.  The waiting stream is one that runs BESIDE the marking stream (CollatePipeline.runs_beside_current,
+    the probe the pipeline itself uses): HIP maps streams onto a few hardware queues, and on a shared queue the mark stays behind the
+    wait -- which is what the self-switch-off is for."""
+    import time
+    from crfconv_amd import _lib
+    from crfconv_amd.graph import ptr, stream_ptr
+    from crfconv_amd.data import CollatePipeline
+    gate = torch.zeros(4, dtype=torch.int64, device=DEV)
+    for _ in range(8):
+        side = torch.cuda.Stream(priority=max(torch.cuda.Stream.priority_range()))
+        if CollatePipeline.runs_beside_current(side):
+            break
+    else:
+        pytest.skip('no stream that runs beside the current one')
+
+    def wait(us):
+        with torch.cuda.stream(side):
+            _lib.call('crfconv_gate_wait', ptr(gate), us, stream_ptr())
+    wait(50000)                                                    # disabled: returns at once
+    torch.cuda.synchronize()
+    assert gate.tolist() == [0, 0, 0, 0]
+    gate[2] = 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wait(20000)                                                    # no mark: 20 ms, then ahead
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert 0.015 < dt < 0.2 and gate.tolist() == [0, 0, 1 | (1 << 8), 1], (dt, gate.tolist())
+    wait(100000)                                                   # waits on the side stream ...
+    time.sleep(0.005)
+    assert not side.query()
+    _lib.call('crfconv_gate_mark', ptr(gate), stream_ptr())        # ... until the caller's stream marks
+    torch.cuda.synchronize()
+    assert gate.tolist() == [1, 1, 1, 1]                           # opened: the run of timeouts is forgotten
+    for k in range(3):                                             # the mark is consumed: three waits in a row time out ...
+        wait(2000)
+    torch.cuda.synchronize()
+    assert gate.tolist() == [1, 1, 0, 4]                           # ... and the gate has switched itself off
+    t0 = time.perf_counter()
+    wait(100000)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.05 and gate.tolist() == [1, 1, 0, 4]
 
 
 def test_multiscale_compute_fps_branch():
