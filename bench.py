@@ -721,7 +721,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pipe-gate', default='backward', choices=['off', 'forward', 'backward'],
                     help="the pipelined loop's device-side gate: the collate graph starts when the training step's forward ('forward') / backward ('backward') reaches its coarse levels, or wherever the launches fall ('off')")
-    ap.add_argument('--mfma-min-rows', type=int, default=0, help='EXPERIMENT knob (A/B runs only): rows from which the row-streaming Linear forms take over from the tiled ones (ops._MFMA_MIN_ROWS; 0 = the shipped 12288)')
+    ap.add_argument('--mfma-min-rows', type=int, default=0, help='EXPERIMENT knob (A/B runs only): rows from which the row-streaming Linear forms take over from the tiled ones (ops.state.mfma_min_rows; 0 = the shipped 12288)')
     ap.add_argument('--rehearse', action='store_true', help='rank plumbing only, on the CPU over gloo (no GPU call, no benchmark): see rehearse()')
     ap.add_argument('--other-configs', action='store_true', help='(default since round 5; kept for old command lines)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the block that times BASELINE configs 3, 4 (per-GPU share) and 5 on this GPU')
@@ -737,7 +737,7 @@ def main():
     from crfconv_amd import models, ops
 
     if args.mfma_min_rows > 0:
-        ops._MFMA_MIN_ROWS = args.mfma_min_rows
+        ops.state.mfma_min_rows = args.mfma_min_rows
     rank, world, local = D.init_from_env()
     torch.set_num_threads(max(1, min(torch.get_num_threads(), cpu_share() // max(1, world), 16)))     # 16 = the share per GPU of the pool's boxes
     if world != args.gpus:

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(BLOCK) void sim_bwd_scatter_kernel(const float* __r
 // The 128- and 256-channel decoder stages of the sparse networks (models/point_conv.py:318-339: GCRFConv(512, 256),
 // GCRFConv(256, 128)) sit on the coarsest point sets (a few thousand points at most).  Their H x H matrices no longer
 // fit the LDS tiles of the kernels above, and the H x H products are genuinely dense [m, H] x [H, H] contractions: they
-// run as plain library GEMMs (ops.py), while everything that touches the graph stays here -- ONE point per wavefront,
+// run as plain library GEMMs (ops/crf.py), while everything that touches the graph stays here -- ONE point per wavefront,
 // VW = H / 64 channels per lane, any K <= 64 / k0, entries < 0 = no neighbour:
 //   wide_sim      s = softmax_k(-|y_i - y_j|^2)            wide_agg          m_i = sum_k s_ik x_j
 //   wide_bwd_edge ds (+)= <gm_i, x_j>                      wide_bwd_scatter  G'[j] = sum_{e in rev(j)} s[e] gm[e / K]

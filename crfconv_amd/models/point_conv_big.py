@@ -190,7 +190,7 @@ class PointConvResNet(Base):
             # the 27 us chain of dependent pivots leaves the forward's launch sequence; flush_riders() below covers eval mode
             mats = ops.crf_matrices_batched([d.c for d in decoders], ride=self.training and data.x.is_cuda)
         pre = [None] * len(plan)
-        if self.training and data.x.is_cuda and not ops._NO_PREFOLD_ENV:      # BatchNorm-1 of all ten weight MLPs folded in ONE launch, up front
+        if self.training and data.x.is_cuda and not ops.state.no_prefold:      # BatchNorm-1 of all ten weight MLPs folded in ONE launch, up front
             pre = ops.point_conv_prefold([blk.point_conv.prefold_entry(p, i) for blk, p, i in plan], True)
         h = plan[0][0](data.x, plan[0][1], plan[0][2], prefold=pre[0])
         h = plan[1][0](h, plan[1][1], plan[1][2], prefold=pre[1])

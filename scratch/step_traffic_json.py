@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 txt = open(os.path.join(ROOT, 'gpurun_out', 'step_pmc', 'summary.txt')).read()
 mb = float(re.search(r'KiB\): ([\d.]+) MB', txt).group(1))
 launches = int(float(re.search(r'-> (\d+) per step', txt).group(1)))
-srcs = sorted(os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, 'crfconv_amd', 'csrc', '*.h*'))) + ['crfconv_amd/ops.py']
+srcs = sorted(os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, 'crfconv_amd', 'csrc', '*.h*'))) + sorted(os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, 'crfconv_amd', 'ops', '*.py')))
 h = hashlib.sha1()
 for s_ in srcs:
     h.update(open(os.path.join(ROOT, s_), 'rb').read())

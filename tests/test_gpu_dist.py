@@ -295,7 +295,7 @@ def test_an_eager_update_sees_the_failure_word_of_the_captured_graph_buffer():
     ops.check_gridsync(dev)
     cap = ops._sync_ws[(0, 'capture')]
     word = _lib.load().crfconv_gridsync_fail_word()
-    was = ops._small_mlp_disabled
+    was = ops.state.small_mlp_disabled
     try:
         bucket.flat.fill_(1.0)
         opt.step()
@@ -318,4 +318,4 @@ def test_an_eager_update_sees_the_failure_word_of_the_captured_graph_buffer():
         torch.cuda.synchronize()
         assert not torch.equal(opt.flat, p0)
     finally:
-        ops._small_mlp_disabled = was
+        ops.state.small_mlp_disabled = was

@@ -20,9 +20,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture
 def big_forms_from_4096(monkeypatch):
     """Kernel-level tests of the row-streaming (big-level) forms use 4 100 ... 10 240 rows to stay quick; the shipped switch-over
-    between the small and the big forms is at 12 288 rows (ops._MFMA_MIN_ROWS, swept on the training step), so they pin it."""
+    between the small and the big forms is at 12 288 rows (ops.state.mfma_min_rows, swept on the training step), so they pin it."""
     from crfconv_amd import ops
-    monkeypatch.setattr(ops, '_MFMA_MIN_ROWS', 4096)
+    monkeypatch.setattr(ops.state, 'mfma_min_rows', 4096)
 
 OUT_TOL = 1e-4
 GRAD_TOL = 2e-4
@@ -1059,7 +1059,7 @@ def test_mlp_block_fused_backward(M, Ci, Co, slope, need_dx, min_rows, monkeypat
     with torch.no_grad():
         bn.weight.copy_(torch.rand(Co, generator=g) + 0.5); bn.bias.copy_(torch.rand(Co, generator=g) * 0.6 - 0.3)
     bn = bn.to(DEV).train()
-    monkeypatch.setattr(ops, '_MFMA_MIN_ROWS', min_rows)      # 4096: the row-streaming forms from 4 100 rows on; 12 288: the shipped switch-over
+    monkeypatch.setattr(ops.state, 'mfma_min_rows', min_rows)      # 4096: the row-streaming forms from 4 100 rows on; 12 288: the shipped switch-over
     small = ops._mlp_small_ok(M, Ci, Co)
     if not ops.mlp_block_ok(x, W, None, bn, True):
         # between the one-launch kernel's co-residency limit and the switch-over no fused block applies (the layer runs as
@@ -1264,13 +1264,13 @@ def test_pointconv_prefold_one_launch_equals_per_layer_folds():
     res = []
     for pre in (True, False):
         net = copy.deepcopy(net0)
-        ops._NO_PREFOLD_ENV = not pre
+        ops.state.no_prefold = not pre
         try:
             torch.manual_seed(9)                                     # same dropout stream
             logits = net(data)
             ops.training_loss(logits, labels, None, ignore_index=-1).backward()
         finally:
-            ops._NO_PREFOLD_ENV = False
+            ops.state.no_prefold = False
         res.append((logits.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()},
                     {k: b.clone() for k, b in net.named_buffers()}))
     (l1, g1, b1), (l2, g2, b2) = res
@@ -1308,7 +1308,7 @@ def test_resnet_join_fused_equals_two_passes():
         go = torch.randn(B, n_out, cout, generator=torch.Generator().manual_seed(10)).to(DEV)
         res = []
         for fused in (True, False):
-            ops._NO_JOIN_ENV = not fused
+            ops.state.no_join = not fused
             for p in blk.parameters():
                 p.grad = None
             for m in blk.modules():                                  # same running statistics in both runs
@@ -1326,11 +1326,11 @@ def test_resnet_join_fused_equals_two_passes():
                     names.add(f)
                     stack.extend(g for g, _ in f.next_functions)
                 # (the strided block's output level here has 2048 rows: there the join is folded into the one-launch MLP)
-                assert any(('_MLPBlockJoin' if B * n_out >= ops._MFMA_MIN_ROWS else '_MLPSmallJoin') in f.name() for f in names)
+                assert any(('_MLPBlockJoin' if B * n_out >= ops.state.mfma_min_rows else '_MLPSmallJoin') in f.name() for f in names)
                 assert any('_MLPBlockPool' in f.name() for f in names) == strided
             out.backward(go)
             res.append((out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}))
-        ops._NO_JOIN_ENV = False
+        ops.state.no_join = False
         (o1, gx1, gp1), (o2, gx2, gp2) = res
         assert torch.equal(o1, o2) and torch.equal(gx1, gx2)
         for k in gp1:
@@ -1366,7 +1366,7 @@ def test_resnet_fork_input_gradient_added_inside_the_block_backward():
         go = torch.randn(B, n_out, cout, generator=torch.Generator().manual_seed(20)).to(DEV)
         res = []
         for fork in (True, False):
-            ops._NO_FORK_ENV = not fork
+            ops.state.no_fork = not fork
             try:
                 for p in blk.parameters():
                     p.grad = None
@@ -1389,10 +1389,10 @@ def test_resnet_fork_input_gradient_added_inside_the_block_backward():
                 assert users == (1 if fork else 2), (users, fork, lv, cin, cout, strided)   # forked: lin_in's node is the only consumer of the input
                 out.backward(go)
             finally:
-                ops._NO_FORK_ENV = False
+                ops.state.no_fork = False
             res.append((out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}))
         (o1, gx1, gp1), (o2, gx2, gp2) = res
-        small = B * n_in < ops._MFMA_MIN_ROWS
+        small = B * n_in < ops.state.mfma_min_rows
         grouped = small and cin != cout                     # round 5: lin_in and the shortcut of such a block run as ONE node (ops.mlp_group:
         if grouped:                                         # the tiled product with statistic records), the un-forked graph as two
             assert_close(o1, o2, 2e-6, 'out (coarse level, grouped vs one by one)')      # one-launch kernels: another summation order
@@ -2214,7 +2214,7 @@ def test_flat_sgd_skips_the_update_while_the_barrier_failure_word_is_set():
     ws = ops.gridsync_ws(dev)
     ops.check_gridsync(dev)
     word = _lib.load().crfconv_gridsync_fail_word()
-    was = ops._small_mlp_disabled
+    was = ops.state.small_mlp_disabled
     try:
         bucket.flat.fill_(1.0)
         opt.step()                                           # a healthy step first: momentum buffer is non-zero afterwards
@@ -2232,7 +2232,7 @@ def test_flat_sgd_skips_the_update_while_the_barrier_failure_word_is_set():
         torch.cuda.synchronize()
         assert bool(torch.isfinite(opt.flat).all()) and not torch.equal(opt.flat, p0)
     finally:
-        ops._small_mlp_disabled = was
+        ops.state.small_mlp_disabled = was
 
 
 def test_grid_barrier_failure_is_raised_and_disables_the_one_launch_path():
@@ -2244,12 +2244,12 @@ def test_grid_barrier_failure_is_raised_and_disables_the_one_launch_path():
     ws = ops.gridsync_ws(dev)
     ops.check_gridsync(dev)                                 # clean: no exception
     word = _lib.load().crfconv_gridsync_fail_word()
-    was = ops._small_mlp_disabled
+    was = ops.state.small_mlp_disabled
     try:
         ws[word] = 0x101
         with pytest.raises(_lib.CrfConvError, match='grid barrier timed out'):
             ops.check_gridsync(dev)
-        assert int(ws.abs().sum()) == 0 and ops._small_mlp_disabled
+        assert int(ws.abs().sum()) == 0 and ops.state.small_mlp_disabled
         ops.check_gridsync(dev)
         # the small-MLP nodes stay in use, with the forward as separate launches (product, BatchNorm) instead of the grid-barrier kernel
         assert ops._mlp_small_ok(1280, 512, 128)
@@ -2265,12 +2265,12 @@ def test_grid_barrier_failure_is_raised_and_disables_the_one_launch_path():
             out.backward(go)
             return out.detach().clone(), x.grad.clone(), W.grad.clone(), bn.weight.grad.clone(), bn.running_var.clone()
         off = run()
-        ops._small_mlp_disabled = False
+        ops.state.small_mlp_disabled = False
         on = run()
         for a, b, what in zip(off, on, ('out', 'dx', 'dW', 'dgamma', 'running_var')):
             assert_close(a, b, 1e-5, 'launch-separated forward vs one-launch kernel: ' + what)
     finally:
-        ops._small_mlp_disabled = was
+        ops.state.small_mlp_disabled = was
 
 
 @pytest.mark.usefixtures('big_forms_from_4096')
