@@ -890,8 +890,10 @@ def test_config2_headline_inference_matches_oracle():
     _eval_net_vs_oracle(pos, feats, 6, 13, 3, 12, 'config-2', g)
 
 
-def test_benchmarked_training_step_replayed_graph_matches_oracle_config2():
-    """The path bench.py TIMES, end to end, against the oracle at BASELINE config 2 (4 x 40 960 points, K = 16, T = 3):
+@pytest.mark.parametrize('cfg,B,N,ncls', [('config-2', 4, 40960, 13), ('config-4', 4, 81920, 20)])
+def test_benchmarked_training_step_replayed_graph_matches_oracle(cfg, B, N, ncls):
+    """The path bench.py TIMES, end to end, against the oracle at BASELINE config 2 (4 x 40 960 points, K = 16, T = 3) and at
+    config 4's per-GPU share (4 x 81 920 points, 20 classes: the whole net in TRAIN mode, not only its components):
     `part_a` exactly as bench.py builds it -- zero grads, PointConvBig forward in train mode (BatchNorm-1 prefold, fork
     chain, classifier MLP -> Dropout -> Linear as ONE node with the counter-based mask), weighted cross entropy, backward
     under ``deferred_weight_grads(sink=bucket.view_of)``, ``bucket.pack()`` -- captured into a hipGraph and REPLAYED.  The
@@ -902,7 +904,7 @@ def test_benchmarked_training_step_replayed_graph_matches_oracle_config2():
     import crfconv_amd
     from crfconv_amd import distributed as D
     from crfconv_amd import models, ops
-    B, N, T, ncls = 4, 40960, 3, 13
+    T = 3
     dev = torch.device('cuda', 0)
     gen = torch.Generator().manual_seed(77)
     data, _ = bench.make_batch(0, B, N, dev, gen, 'morton')
@@ -964,9 +966,9 @@ def test_benchmarked_training_step_replayed_graph_matches_oracle_config2():
         res[tag] = (ref_t.detach(), ref_loss.detach(), torch.cat([prm[k].grad.reshape(-1) for k in names]).detach())
         del prm, msx, ref_t, ref_loss
     (t32, l32, g32), (t64, l64, g64) = res['f32'], res['f64']
-    _report_err('config-2 replayed train logits', logits, t64)
-    _report_err('config-2 replayed loss', loss, l64)
-    _report_err('config-2 replayed flat gradient bucket', flat, g64)
+    _report_err(cfg + ' replayed train logits', logits, t64)
+    _report_err(cfg + ' replayed loss', loss, l64)
+    _report_err(cfg + ' replayed flat gradient bucket', flat, g64)
     assert_close_anchored(logits, t32, t64, OUT_TOL, 'replayed train logits')       # the stated 1e-4 (measured: 2e-6 normalised, 7e-5 absolute)
     assert_close_anchored(loss, l32, l64, 1e-5, 'replayed loss')
     assert flat.numel() == g64.numel()
