@@ -34,41 +34,69 @@ struct SubsetJobs {
     int nlevels;
 };
 
-// One workgroup per level.  Radix select (8-bit digits from the top) of the s-th smallest key, the keys recomputed in
-// every pass instead of stored; it stops as soon as the selected bin is taken whole (two or three passes for uniform
-// 64-bit keys).  Then flags -> block scan -> ascending indices.
-__global__ __launch_bounds__(SUB_NT) void random_subsets_kernel(const SubsetJobs jobs, unsigned long long seed,
-                                                                const long long* __restrict__ counter) {
-    const int level = blockIdx.x;
-    const int n = jobs.n[level], s = jobs.s[level];
-    long long* __restrict__ out = jobs.out[level];
-    int* __restrict__ rank = jobs.rank[level];
-    if (s <= 0) return;
-    const unsigned long long ctr = (unsigned long long)counter[0];
-    __shared__ int s_hist[256];
-    __shared__ int s_sel[2];                                   // selected digit, keys strictly below the selected bin so far
-    __shared__ int s_cnt[SUB_NT];
+// One workgroup per level.  Radix select (8-bit digits from the top) of the s-th smallest key; it stops as soon as the selected bin is
+// taken whole (two or three passes for uniform 64-bit keys).  Then flags -> block scan -> ascending indices.  A thread owns a
+// contiguous chunk of `per` points and goes over it five times (the passes, the count, the write): up to SUB_CACHE keys per thread are
+// hashed ONCE and their HIGH words kept in registers (CACHED: levels of up to 40 960 points -- the level-0 workgroup spent 60 us
+// hashing every key five times on one CU).  The high word decides every pass down to bit 32 and the final membership test whenever
+// the selection stopped there (it does for uniform keys: two or three passes); a pass below bit 32, and larger levels, recompute.
+constexpr int SUB_CACHE = 40;
+template <bool CACHED>
+__device__ __forceinline__ void random_subset_level(const int n, const int s, long long* __restrict__ out, int* __restrict__ rank,
+                                                    const unsigned long long seed, const unsigned long long ctr, const int level,
+                                                    int* s_hist, int* s_sel, int* s_cnt) {
     const int tid = threadIdx.x;
     const int per = (n + SUB_NT - 1) / SUB_NT, lo = tid * per, hi = lo + per < n ? lo + per : n;   // a contiguous chunk per thread
+    [[maybe_unused]] unsigned kc[CACHED ? SUB_CACHE : 1];
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int j = 0; j < SUB_CACHE; ++j) kc[j] = (unsigned)(subset_key(seed, ctr, level, lo + j) >> 32);      // (entries past the chunk: never looked at)
+    }
+    // visit(low, f): f(i, key) for every point of the chunk in ascending order; low (uniform) = f looks at bits below 32
+    auto visit = [&](const bool low, auto&& f) {
+        if constexpr (CACHED) {
+            if (!low) {
+                int cnt = hi - lo, lo2 = lo;
+                asm volatile("" : "+v"(cnt), "+v"(lo2));        // (re-derived per pass: forty hoisted lane masks / point indices from the hashing loop would be kept alive -- and spilled)
+#pragma unroll
+                for (int j = 0; j < SUB_CACHE; ++j) {
+                    if (j < cnt) f(lo2 + j, (unsigned long long)kc[j] << 32);
+                    __builtin_amdgcn_sched_barrier(0);          // one point at a time: forty interleaved bodies spill at 128 registers
+                }
+                return;
+            }
+        }
+        for (int i = lo; i < hi; ++i) f(i, subset_key(seed, ctr, level, i));
+    };
     unsigned long long prefix = 0ull, mask = 0ull;             // keys with (key & mask) == prefix are still candidates
     int need = s;                                              // how many of the candidates belong to the subset
     bool whole = (s >= n);                                     // every candidate is in: nothing left to select
     for (int shift = 56; shift >= 0 && !whole; shift -= 8) {
         if (tid < 256) s_hist[tid] = 0;
         __syncthreads();
-        for (int i = lo; i < hi; ++i) {
-            const unsigned long long k = subset_key(seed, ctr, level, i);
+        visit(shift < 32, [&](int, unsigned long long k) {
             if ((k & mask) == prefix) atomicAdd(&s_hist[(int)((k >> shift) & 0xFF)], 1);
-        }
+        });
         __syncthreads();
-        if (tid == 0) {
-            int below = 0, d = 0;
-            for (; d < 256; ++d) {
-                if (below + s_hist[d] >= need) break;
-                below += s_hist[d];
+        {
+            // the bin that holds the need-th candidate: an inclusive scan over the 256 bins by the first four wavefronts (one thread
+            // walking the bins was 256 dependent LDS reads per pass: 12 of the kernel's 16 us per pass)
+            const int h = tid < 256 ? s_hist[tid] : 0;
+            int incl = h;
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) {
+                const int v = __shfl_up(incl, o, WAVE);
+                if ((tid & 63) >= o) incl += v;
             }
-            s_sel[0] = d;
-            s_sel[1] = below;
+            if (tid < 256 && (tid & 63) == 63) s_sel[2 + (tid >> 6)] = incl;
+            __syncthreads();
+            if (tid < 256) {
+                for (int w = 0; w < (tid >> 6); ++w) incl += s_sel[2 + w];
+                if (incl >= need && incl - h < need) {         // exactly one bin (need >= 1, the bins sum to >= need)
+                    s_sel[0] = tid;
+                    s_sel[1] = incl - h;
+                }
+            }
         }
         __syncthreads();
         const int d = s_sel[0], below = s_sel[1], in_bin = s_hist[d];
@@ -80,7 +108,8 @@ __global__ __launch_bounds__(SUB_NT) void random_subsets_kernel(const SubsetJobs
     }
     // subset = {k : (k & mask) <= prefix}  (equal prefix = the last selected bin, taken whole)
     int c = 0;
-    for (int i = lo; i < hi; ++i) c += ((subset_key(seed, ctr, level, i) & mask) <= prefix) ? 1 : 0;
+    const bool low = (mask & 0xFFFFFFFFull) != 0ull;
+    visit(low, [&](int, unsigned long long k) { c += ((k & mask) <= prefix) ? 1 : 0; });
     s_cnt[tid] = c;
     __syncthreads();
     for (int o = 1; o < SUB_NT; o <<= 1) {                     // inclusive scan of the per-thread counts
@@ -90,12 +119,24 @@ __global__ __launch_bounds__(SUB_NT) void random_subsets_kernel(const SubsetJobs
         __syncthreads();
     }
     int pos = s_cnt[tid] - c;
-    for (int i = lo; i < hi; ++i) {
-        const bool member = (subset_key(seed, ctr, level, i) & mask) <= prefix;
+    visit(low, [&](int i, unsigned long long k) {
+        const bool member = (k & mask) <= prefix;
         if (member && pos < s) out[pos] = i;
         if (rank != nullptr) rank[i] = (member && pos < s) ? pos : -1;
         pos += member ? 1 : 0;
-    }
+    });
+}
+__global__ __launch_bounds__(SUB_NT) void random_subsets_kernel(const SubsetJobs jobs, unsigned long long seed,
+                                                                const long long* __restrict__ counter) {
+    const int level = blockIdx.x;
+    const int n = jobs.n[level], s = jobs.s[level];
+    if (s <= 0) return;
+    const unsigned long long ctr = (unsigned long long)counter[0];
+    __shared__ int s_hist[256];
+    __shared__ int s_sel[6];                                   // selected digit, keys strictly below the selected bin so far | the scan's four wavefront totals
+    __shared__ int s_cnt[SUB_NT];
+    if ((n + SUB_NT - 1) / SUB_NT <= SUB_CACHE) random_subset_level<true>(n, s, jobs.out[level], jobs.rank[level], seed, ctr, level, s_hist, s_sel, s_cnt);
+    else random_subset_level<false>(n, s, jobs.out[level], jobs.rank[level], seed, ctr, level, s_hist, s_sel, s_cnt);
 }
 
 // ------------------------------------------------------------------ up-index from the fine level's own neighbour table
