@@ -2156,6 +2156,18 @@ def test_graphed_model_in_the_unchanged_reference_loop_equals_the_eager_loop():
             F.cross_entropy(model(data), data.y.reshape(-1) - 1, weight=cw, ignore_index=-1).backward()
     for (k, a), b in zip(inner.named_parameters(), ref.parameters()):
         assert_close(a.grad, b.grad, 2e-5, 'graphed module, accumulated gradient: ' + k)
+    # a batch of another shape: the wrapped model runs eagerly, the captured graphs stay what they were
+    other = crfconv_amd.multiscale_compute(t(np.stack([S.make_cloud(990 + b, N // 2, box=(2, 2, 1)) for b in range(B)])),
+                                           x=t(S.uniform(991, 'f', (B, N // 2, 6), 0, 1)), y=t(S.integers(992, 'y', (B, N // 2), 0, 14)),
+                                           generator=torch.Generator().manual_seed(9))
+    inner.load_state_dict(ref.state_dict())
+    outs = []
+    for model in (net, ref):
+        torch.manual_seed(123)          # (8 192 rows: the classifier runs the module's own nn.Dropout here -- Philox draws of the global generator)
+        outs.append(model(other))
+    a, b = outs
+    assert a.shape == b.shape == (B * (N // 2), 13) and a.grad_fn is not None
+    assert_close(a, b, 2e-5, 'graphed module, other shape (eager path)')
     # eval / no_grad: the wrapped model itself
     with torch.no_grad():
         a, b = net(batches[0]), ref(batches[0])

@@ -484,3 +484,88 @@ def test_batched_refresh_equals_table_by_table():
             with pytest.raises(IndexError):
                 b[1].validate()
             b[1].validate()                                   # the count was reset by the raise
+
+
+@pytest.mark.parametrize('n32,n64', [(7, 3), (100, 5), (4, 40), (0, 2), (3, 0)])
+def test_reduce_jobs_both_equals_the_two_launches(n32, n64):
+    """crfconv_reduce_jobs_both: the float weight-gradient sums and the float64 sums of a backward pass in ONE launch (both tables
+    fit: <= 96 / <= 32 jobs) or as the two launches (more jobs than a table holds, or one kind absent) -- bit-identical to
+    crfconv_reduce_jobs + crfconv_reduce_jobs_f64 either way."""
+    import ctypes
+    from crfconv_amd import _lib
+    from crfconv_amd.graph import stream_ptr
+    g = torch.Generator().manual_seed(n32 * 100 + n64)
+    p32, p64, shapes32, shapes64 = [], [], [], []
+    for j in range(n32):
+        nblk, nslots = int(torch.randint(1, 70, (1,), generator=g)), int(torch.randint(1, 700, (1,), generator=g))
+        p32.append(torch.randn(nblk, nslots, generator=g).to(DEV))
+    for j in range(n64):
+        nblk, nslots = int(torch.randint(1, 200, (1,), generator=g)), int(torch.randint(1, 40, (1,), generator=g))
+        isf = j % 2 == 0
+        p64.append(torch.randn(nblk, nslots, generator=g, dtype=torch.float32 if isf else torch.float64).to(DEV))
+    res = {}
+    for mode in ('both', 'two'):
+        o32 = [torch.full((p.shape[1],), float('nan'), device=DEV) for p in p32]
+        o64 = [torch.full((p.shape[1],), float('nan'), device=DEV, dtype=torch.float64) for p in p64]
+        a32 = (_lib.ReduceJob * max(n32, 1))(*[_lib.ReduceJob(p.data_ptr(), o.data_ptr(), p.shape[0], p.shape[1]) for p, o in zip(p32, o32)])
+        a64 = (_lib.Reduce64Job * max(n64, 1))(*[_lib.Reduce64Job(p.data_ptr(), 1 if p.dtype == torch.float32 else 0, p.shape[0], p.shape[1], o.data_ptr())
+                                                  for p, o in zip(p64, o64)])
+        v32 = ctypes.cast(a32, ctypes.c_void_p) if n32 else None
+        v64 = ctypes.cast(a64, ctypes.c_void_p) if n64 else None
+        if mode == 'both':
+            _lib.call('crfconv_reduce_jobs_both', v32, n32, v64, n64, stream_ptr())
+        else:
+            if n32:
+                _lib.call('crfconv_reduce_jobs', v32, n32, stream_ptr())
+            if n64:
+                _lib.call('crfconv_reduce_jobs_f64', v64, n64, stream_ptr())
+        torch.cuda.synchronize()
+        res[mode] = o32 + o64
+    for a, b in zip(res['both'], res['two']):
+        assert torch.equal(a, b) and not bool(torch.isnan(a).any())
+    for p, o in zip(p32 + p64, res['both']):
+        want = p.double().sum(0)
+        assert float((o.double() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
+def test_loss_forward_fold_with_and_without_ticket_words():
+    """crfconv_softmax_ce_forward: with ticket words the forward's last workgroup folds the per-block sums, without them a second
+    launch does (ce_finalize_kernel) -- same arithmetic, same order: sums and loss bit for bit."""
+    from crfconv_amd import _lib, ops
+    from crfconv_amd.graph import ptr, stream_ptr
+    g = torch.Generator().manual_seed(4)
+    m, C = 70001, 13
+    z = torch.randn(m, C, generator=g).to(DEV)
+    tgt = torch.randint(-1, C, (m,), generator=g).to(DEV)
+    w = (0.5 + torch.rand(C, generator=g)).to(DEV)
+    out = {}
+    for name, ticket in (('ticket', ops._ticket(DEV)), ('launch', None)):
+        lse = torch.empty(m, device=DEV)
+        sums = torch.empty(3, dtype=torch.float64, device=DEV)
+        loss = torch.empty((), device=DEV)
+        nbytes = _lib.load().crfconv_softmax_ce_workspace(m)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        for _ in range(2):                                         # twice: the ticket words must be left zero
+            _lib.call('crfconv_softmax_ce_forward', ptr(z), ptr(tgt), ptr(w), m, C, -1, 0, ptr(lse), ptr(sums), ptr(loss), ptr(ws), nbytes,
+                      ptr(ticket), stream_ptr())
+        torch.cuda.synchronize()
+        out[name] = (lse, sums, loss)
+    for a, b in zip(out['ticket'], out['launch']):
+        assert torch.equal(a, b)
+    ref = torch.nn.functional.cross_entropy(z.double(), tgt, weight=w.double(), ignore_index=-1)
+    assert abs(float(out['ticket'][2]) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    assert int(ops._ticket(DEV).abs().sum()) == 0
+
+
+def test_uv_hosting_refuses_other_widths():
+    """crfconv_pointconv_forward_uv_hosting is for the widths crfconv_pointconv_forward_uv_hosts() names (d = 8): another width is an
+    error of the call, never a silently different launch."""
+    from crfconv_amd import _lib
+    lib = _lib.load()
+    assert lib.crfconv_pointconv_forward_uv_hosts(16, 8) == 1 and lib.crfconv_pointconv_forward_uv_hosts(16, 16) == 0
+    assert lib.crfconv_pointconv_forward_uv_hosts(16, 64) == 0
+    dummy = torch.zeros(64, device=DEV)
+    with pytest.raises(_lib.CrfConvError):
+        _lib.call('crfconv_pointconv_forward_uv_hosting', dummy.data_ptr(), dummy.data_ptr(), dummy.data_ptr(), dummy.data_ptr(), 16, 4, 16,
+                  dummy.data_ptr(), dummy.data_ptr(), dummy.data_ptr(), 0.1, dummy.data_ptr(), dummy.data_ptr(), dummy.data_ptr(), dummy.data_ptr(),
+                  dummy.data_ptr(), dummy.data_ptr(), 64, None, None, None, 1, None, None, None)
