@@ -331,8 +331,14 @@ def mlp_block_dropout(x, W, bn, slope, p):
         return None
     m = x.numel() // x.shape[-1]
     ci, co = x.shape[-1], W.shape[0]
-    if not (mlp_block_ok(x, W, None, bn, True) and not _mlp_small_ok(m, ci, co)):
+    if not mlp_block_ok(x, W, None, bn, True):
         return None
+    if _mlp_small_ok(m, ci, co):
+        # below the row-streaming forms' switch-over the node still runs on them when they TAKE the shape (they do for every width
+        # of the reference networks): the counter-based mask at every size, not the module's nn.Dropout with the framework's draws
+        lib = _lib.load()
+        if not (co % 4 == 0 and lib.crfconv_linear_forward_supported(ci, co) and lib.crfconv_mlp_backward_supported(m, ci, co) == 1):
+            return None
     require_gpu(x, W)
     tick(bn)                                              # advances the counter the mask is keyed on (unless the model already did)
     mom = 0.1 if bn.momentum is None else bn.momentum

@@ -986,8 +986,8 @@ def test_benchmarked_training_step_replayed_graph_matches_oracle(cfg, B, N, ncls
 
 def test_config1_shape_eval_and_train_vs_oracle():
     """BASELINE.json config 1's exact shape: 2 x 2048 points on the unit sphere's interior, xyz + unit normals
-    (in_channels 6), K = 16, ONE mean-field step, 50 part classes: eval logits + confusion, then train-mode logits,
-    loss and every parameter gradient against the oracle."""
+    (in_channels 6), K = 16, ONE mean-field step, 50 part classes: eval logits + confusion, then train-mode logits (WITH the
+    classifier's dropout: the oracle gets the mask the kernel drew), loss and every parameter gradient against the oracle."""
     g = torch.Generator().manual_seed(1)
     B, N, ncls = 2, 2048, 50
     pos = torch.rand(B, N, 3, generator=g) - 0.5
@@ -1000,12 +1000,16 @@ def test_config1_shape_eval_and_train_vs_oracle():
     data, net, sd, ms = _eval_net_vs_oracle(pos, feats, 6, ncls, 1, 21, 'config-1', g, ratio=(2, 2, 2, 2, 2))
     labels = torch.randint(0, ncls + 1, (B, N), generator=g)
     net.train()
-    net.classifier[1] = nn.Identity()                      # dropout draws from different RNG streams: compare without
-    logits = net(data)
+    assert type(net.classifier[1]) is nn.Dropout           # the classifier's dropout stays: its mask is a function of (seed, step counter,
+    logits = net(data)                                     # element) at every size, so the oracle can be handed the same one
     loss = torch.nn.functional.cross_entropy(logits, labels.reshape(-1).to(DEV) - 1, ignore_index=-1)
     loss.backward()
+    from crfconv_amd import ops
+    ctr = int(net.classifier[0].bn.batch_norm.num_batches_tracked)
+    keep = ops.dropout_keep_mask(ops.dropout_seed(32, 128), ctr, B * N * 128, 0.5).reshape(B, N, 128)
+    assert 0.49 < float(keep.mean()) < 0.51
     prm = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
-    mask = torch.full((B, N, 128), 0.5)                    # oracle: h * mask * 2 = identity
+    mask = torch.from_numpy(keep).float()
     ref_t = O.pointconv_resnet(prm, data.x.cpu(), ms, 1, True, True, dropout_mask=mask)
     ref_loss = O.training_loss(ref_t, labels)
     ref_loss.backward()
@@ -1138,7 +1142,9 @@ def test_mlp_block_dropout_fused_mask_is_consistent():
         graph.replay()
         masks.append((static_out != 0).clone())
     assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
-    assert ops.mlp_block_dropout(x[:100], W, bn, slope, 0.5) is None             # below the fused block's row count: caller's path
+    # below the row-streaming forms' switch-over the node runs all the same (the counter-based mask at every size)
+    small = ops.mlp_block_dropout(x[:100].detach(), W.detach(), bn, slope, 0.5)
+    assert small is not None and 0.35 < float((small != 0).float().mean()) < 0.65
 
 
 def test_classifier_dropout_backward_folded_into_last_linear():
