@@ -115,7 +115,8 @@ class GraphedModel(torch.nn.Module):
     passes on a side stream whose effect on BatchNorm statistics and dropout counters is undone); later batches of the SAME shapes
     are copied into the captured batch's buffers (MultiScaleData.load_: one copy launch + the table refreshes).  A batch of other
     shapes, eval mode and no_grad calls run the wrapped model eagerly.  Parameter gradients come back through autograd (hooks,
-    accumulation over several backward passes and DistributedDataParallel see ordinary gradients); the output aliases a static
+    accumulation over several backward passes see ordinary gradients -- tested; a hook-based wrapper such as DistributedDataParallel
+    should too, untested); the output aliases a static
     buffer that the next call overwrites, as with torch.cuda.make_graphed_callables."""
 
     def __init__(self, model, warmup=2, defer_weight_grads=True):
