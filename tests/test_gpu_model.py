@@ -2155,11 +2155,16 @@ def test_graphed_model_in_the_unchanged_reference_loop_equals_the_eager_loop():
         assert_close(a.float(), b.float(), 2e-5, 'graphed module, after 3 steps: ' + k)
     # accumulation: two backward passes on two batches, no zero_grad in between (from EQUAL state: what remains is summation order)
     inner.load_state_dict(ref.state_dict())
+    seen = []
+    hook = inner.conv1_1.lin_in.lin.weight.register_hook(lambda g: seen.append(g.clone()))      # a parameter hook sees each pass's gradient
     for model in (ref, net):
         for p in model.parameters():
             p.grad = None
         for data in batches[:2]:
             F.cross_entropy(model(data), data.y.reshape(-1) - 1, weight=cw, ignore_index=-1).backward()
+    hook.remove()
+    assert len(seen) == 2 and float(seen[0].abs().max()) > 0
+    assert_close(seen[0] + seen[1], inner.conv1_1.lin_in.lin.weight.grad, 1e-6, 'graphed module, hook gradients sum to .grad')
     for (k, a), b in zip(inner.named_parameters(), ref.parameters()):
         assert_close(a.grad, b.grad, 2e-5, 'graphed module, accumulated gradient: ' + k)
     # a batch of another shape: the wrapped model runs eagerly, the captured graphs stay what they were
