@@ -574,7 +574,9 @@ __device__ __forceinline__ void uvstats_body(const float* __restrict__ x,
     }
     block_reduce_store<D, 2, true>(acc, sred, partial, lane, wave, q, bid, n_own);
     // with a ticket word the last workgroup to finish sums the rows into stats (reduce_partials_kernel's launch otherwise)
-    if (ticket == nullptr || !last_workgroup(ticket, n_own, &L.flag)) return;
+    // (the ticket group comes from bid, this workgroup's number among the n_own -- NOT from blockIdx.x: behind the riders of
+    // uvstats_hosting_kernel the two differ, and groups counted on blockIdx.x never fill when n_own % LW_GROUPS != 0)
+    if (ticket == nullptr || !last_workgroup_of(ticket, n_own, &L.flag, bid)) return;
     sum_partial_rows_f64<256>(make_rsrc(partial, (int)n_own * 2 * D * 4), (int)n_own, 2 * D, L.buf, L.tot);
     if (threadIdx.x < 2 * D) stats[threadIdx.x] = L.tot[threadIdx.x];
 }
@@ -594,6 +596,7 @@ __global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict
 // launch chain.  Here their workgroups are the FIRST n_side of the grid of the network's first PointConv statistics pass (31 us; four
 // workgroups per CU are resident, so only the first ones dispatched are certain to start at once), and nothing waits for them.  The two
 // bodies SHARE their LDS (the union below): the riders must not cost the host's workgroups an occupancy step.
+#define HOST_PAD(n) (((unsigned)(n) + 7u) & ~7u)
 template <int D>
 __global__ __launch_bounds__(PBLOCK) void uvstats_hosting_kernel(const float* __restrict__ x, const float* __restrict__ pos_src,
                                                                  const float* __restrict__ pos_tgt, const int32_t* __restrict__ idx, int K,
@@ -604,13 +607,16 @@ __global__ __launch_bounds__(PBLOCK) void uvstats_hosting_kernel(const float* __
                                                                  double* __restrict__ stats, const CrfMatJobs side, const int n_side) {
     static_assert(PBLOCK == CMF_BLOCK, "the riders are workgroups of the host's size");
     __shared__ __attribute__((aligned(16))) union Both { UvLds<D> uv; char mats[CMF_LDS_BYTES]; } L;
-    if ((int)blockIdx.x < n_side) {
+    // the riders' slots are padded to a multiple of 8 (HOST_PAD(n_side) workgroups, the surplus ones leave at once): the host's
+    // workgroup bid then sits on XCD blockIdx.x % 8 == bid % 8, which is what uvstats_body's XCD-contiguous row order assumes
+    const unsigned n_pad = HOST_PAD(n_side);
+    if (blockIdx.x < n_pad) {
         const int b = (int)blockIdx.x;
-        crf_matrices_body(uni(side.c[b]), uni(side.H[b]), uni(side.Q[b]), uni(side.P[b]), L.mats);
+        if (b < n_side) crf_matrices_body(uni(side.c[b]), uni(side.H[b]), uni(side.Q[b]), uni(side.P[b]), L.mats);
         return;
     }
     uvstats_body<D>(x, pos_src, pos_tgt, idx, K, m_tgt, A1, b1, W2, slope, mean_rel, shift_out, U, V, partial, ticket, stats, L.uv,
-                    blockIdx.x - (unsigned)n_side, gridDim.x - (unsigned)n_side);
+                    blockIdx.x - n_pad, gridDim.x - n_pad);
 }
 
 // out = a2 U + (a2 shift + b2) V   over [m, d] rows (one thread per 4-channel quad).  BatchNorm-2's batch
@@ -1499,7 +1505,7 @@ extern "C" int crfconv_pointconv_forward_uv_hosting(const float* x, const float*
     hipStream_t st = as_stream(stream);
     float* partial = reinterpret_cast<float*>(workspace);
     if (nblk * (d / 2) > 256 * 24) ticket = nullptr;
-    hipLaunchKernelGGL(uvstats_hosting_kernel<8>, dim3((unsigned)(nblk + n)), dim3(PBLOCK), 0, st, x, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1,
+    hipLaunchKernelGGL(uvstats_hosting_kernel<8>, dim3((unsigned)nblk + HOST_PAD(n)), dim3(PBLOCK), 0, st, x, pos_src, pos_tgt, idx32, K, m_tgt, A1, b1,
                        W2, slope, mean_rel3, shift, U, V, partial, ticket, stats, side, n);
     CRF_LAUNCH_CHECK();
     return ticket != nullptr ? CRF_OK : reduce_partials(partial, nblk, 2 * d, stats, st);

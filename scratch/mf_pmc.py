@@ -1,4 +1,4 @@
-"""Level-0 mean-field forward + backward, 5 calls each (for the rocprofv3 --pmc passes of scratch/pmc.sh)."""
+"""Level-0 mean-field forward + backward, N calls each (argv[1], default 5) (for the rocprofv3 --pmc passes of scratch/pmc.sh)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
@@ -14,7 +14,7 @@ z = torch.randn(m, H, generator=g).to(dev).requires_grad_()
 y = (0.5 * torch.randn(m, H, generator=g)).to(dev).requires_grad_()
 c = (torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)).to(dev).requires_grad_()
 gout = torch.randn(m, H, generator=g).to(dev)
-for it in range(5):
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     for t in (z, y, c): t.grad = None
     ops.crf_meanfield(z, y, c, tab, T).backward(gout)
 torch.cuda.synchronize()

@@ -2029,6 +2029,40 @@ def test_crf_matrices_riding_in_the_first_pointconv_launch_equal_the_launch_of_t
             assert float(a.abs().max()) > 0 and torch.equal(a, b)
 
 
+@pytest.mark.parametrize('n', [20000, 40000, 40960])
+def test_riders_in_a_statistics_pass_of_many_workgroups_leave_the_tickets_clean(n):
+    """The hosting launch at sizes where the host's workgroups draw their tickets in groups (more than 64 workgroups) and their number
+    is NOT a multiple of the group count (20 000 points = 157 workgroups, 40 000 = 313): the ticket group of a workgroup must come from
+    its number among the host's workgroups, not from blockIdx.x behind the riders -- otherwise no workgroup is ever 'last', the
+    BatchNorm-2 statistics are never written and the stream's ticket words stay dirty for every later launch.
+    Output, running statistics and gradients must equal the launch without riders bit for bit; every ticket word must be zero."""
+    from crfconv_amd import ops
+    from crfconv_amd.ops._base import _ticket
+    from crfconv_amd.graph import NeighborTable
+    g = torch.Generator().manual_seed(n)
+    K, d = 16, 8
+    idx = torch.randint(0, n, (1, n, K), generator=g)
+    idx[0, :, 0] = torch.arange(n)
+    table = NeighborTable(idx.to(DEV), n)
+    pos = torch.rand(n, 3, generator=g).to(DEV)
+    res = {}
+    for ride in (False, True):
+        cs = [nn.Parameter((torch.eye(H) + 0.1 * torch.randn(H, H, generator=torch.Generator().manual_seed(H))).to(DEV)) for H in (64, 32, 16, 8)]
+        gg = torch.Generator().manual_seed(d)
+        x = torch.randn(n, d, generator=gg).to(DEV).requires_grad_(True)
+        W1, W2 = nn.Parameter(torch.randn(d, 3, generator=gg).to(DEV)), nn.Parameter((torch.randn(d, d, generator=gg) / d ** 0.5).to(DEV))
+        bn1, bn2 = nn.BatchNorm1d(d).to(DEV).train(), nn.BatchNorm1d(d).to(DEV).train()
+        mats = ops.crf_matrices_batched(cs, ride=ride)
+        out = ops.point_conv(x, pos, pos, table, W1, bn1, W2, bn2, True)
+        assert ops._RIDERS['mats'] is None
+        (out * out).sum().backward()
+        torch.cuda.synchronize()
+        assert int(_ticket(torch.device(DEV)).abs().sum()) == 0, 'ticket words left non-zero (ride=%s)' % ride
+        res[ride] = [out.detach(), bn2.running_mean.clone(), bn2.running_var.clone(), x.grad, W1.grad, W2.grad] + [t_.detach() for m in mats for t_ in m]
+    for a, b in zip(res[False], res[True]):
+        assert bool(torch.isfinite(a).all()) and float(a.abs().max()) > 0 and torch.equal(a, b)
+
+
 def test_crf_parameter_gradients_deferred_to_the_end_of_the_pass_equal_the_immediate_ones():
     """Inside ops.deferred_weight_grads the CRF layers' dP / dQ (H >= 32: partial passes + sums in the batched launches) and the
     batched matrices backward run at the END of the backward pass and install dc as .grad; values must equal the immediate form's
