@@ -155,6 +155,10 @@ class _State:
     # below this many rows the tiled product (gemm.hip) and the small-MLP nodes; swept on the step: 4096 -> 4.733 ms, 12288 (the
     # 10 240-row level joins the small forms) -> 4.694 ms, 65536 -> 4.736 ms
     mfma_min_rows = 12288
+    # the mean-field forward as one launch with block-resident rows (csrc/crf_block.hip; ops.crf._block_rows): 'auto' | 'on' | 'off'
+    mf_block = 'auto'
+    mf_block_min_rows = 65536        # below: too few workgroups of 256+ rows to fill the chip
+    mf_block_min_locality = 0.6      # fraction of table entries inside the target's own block (Morton-sorted clouds: ~0.8)
 
 
 state = _State()

@@ -5,9 +5,35 @@ import torch
 
 from .. import _lib
 from ..graph import NeighborTable, ptr, require_gpu, stream_ptr
-from ._base import _f32c, _next_supported, _pad_channels, _ptr_array, _ticket
+from ._base import _f32c, _next_supported, _pad_channels, _ptr_array, _ticket, gridsync_ws, state
 
 # ------------------------------------------------------------------------------ CRF mean field
+def _block_rows(table, m, H, k0, steps):
+    """Rows per workgroup when this forward is to run as ONE launch with block-resident rows (csrc/crf_block.hip), else 0.
+    `ops.state.mf_block`: 'off' never, 'on' whenever the shape is covered (tests), 'auto' (default) when in addition the launch can
+    fill the chip (>= state.mf_block_min_rows rows) and the table is LOCAL: at least state.mf_block_min_locality of its entries
+    point into the target's own block of consecutive rows -- true of spatially sorted clouds (the device collate emits Morton
+    order), not of shuffled ones, whose neighbours the form would fetch past L1.  The fraction is measured once per table (one
+    small launch and one host read, never inside a capture -- an unmeasured table takes the per-step kernels) and kept in
+    table.cache: a table refreshed in place (MultiScaleData.load_, CollateGraph) keeps the verdict of its first batch."""
+    mode = state.mf_block
+    if mode == 'off' or table.padded or steps < 1:
+        return 0
+    rows = _lib.load().crfconv_meanfield_forward_block_rows(m, H, table.K, k0, steps)
+    if rows <= 0 or mode == 'on':
+        return rows
+    if m < state.mf_block_min_rows:
+        return 0
+    frac = table.cache.get(('block_locality', rows))
+    if frac is None:
+        if torch.cuda.is_current_stream_capturing():
+            return 0
+        count = torch.zeros(1, dtype=torch.int64, device=table.idx32.device)
+        _lib.call('crfconv_block_locality', ptr(table.idx32), m, table.K, k0, rows, ptr(count), stream_ptr())
+        frac = table.cache[('block_locality', rows)] = float(count.item()) / float(m * (table.K - k0))
+    return rows if frac >= state.mf_block_min_locality else 0
+
+
 class _MeanField(torch.autograd.Function):
     """x_T of  x_0 = z,  x_t = z Q + (A x_{t-1}) P  with A = row-softmax(-|y_i - y_j|^2) over the
     table's columns k0..K-1  (models/continuous_crf_conv_big.py:49-54, 63-72)."""
@@ -37,8 +63,12 @@ class _MeanField(torch.autograd.Function):
         keep_s = needs_grad or steps != 1 or k0 != 1 or table.K not in (16, 32) or m * H * 4 >= 2 ** 31
         s = torch.empty((m, table.K), dtype=torch.float32, device=z.device) if keep_s else None   # s[i*K + k]
         xs = torch.empty((max(steps, 1), m, H), dtype=torch.float32, device=z.device)
-        _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(table.idx32), ptr(table.idx16), table.n_tgt,
-                  table.n_src, table.K, k0, m, H, ptr(Q), ptr(P), steps, ptr(s), ptr(xs), stream_ptr())
+        if _block_rows(table, m, H, k0, steps) > 0:
+            _lib.call('crfconv_meanfield_forward_block', ptr(z), ptr(y), ptr(table.idx32), ptr(table.idx16), table.n_tgt,
+                      table.n_src, table.K, k0, m, H, ptr(Q), ptr(P), steps, ptr(s), ptr(xs), ptr(gridsync_ws(z.device)), stream_ptr())
+        else:
+            _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(table.idx32), ptr(table.idx16), table.n_tgt,
+                      table.n_src, table.K, k0, m, H, ptr(Q), ptr(P), steps, ptr(s), ptr(xs), stream_ptr())
         ctx.table, ctx.k0, ctx.steps = table, k0, steps
         if needs_grad:
             ctx.save_for_backward(z, y, Q, P, s, xs)

@@ -1,7 +1,6 @@
 #!/bin/bash
-# usage: scratch/res_usage.sh <file.hip> [filter] [-DFLAG ...]  -- VGPRs / scratch / LDS / occupancy of every kernel of one translation unit
-f=$1; shift; flt=${1:-.}; shift
-cd "$(dirname "$0")/../crfconv_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed "$@" -c $f -o /tmp/res_usage.o -Rpass-analysis=kernel-resource-usage 2>&1 \
- | grep -E "Function Name|VGPRs:|AGPRs:|ScratchSize|Occupancy|LDS Size" | sed -E 's/.*remark: [^ ]+ +//; s/ \[-Rpass.*//' | paste - - - - - - \
- | sed -E 's/Function Name: //' | while IFS=$'\t' read n a b c d e; do echo "$(echo $n | c++filt | sed -E 's/\(.*//; s/crf:://' | cut -c1-70) | $a | $b | $c | $d | $e"; done | grep -E "$flt"
+# usage: scratch/res_usage.sh <file.hip> [extra flags]  -- registers / scratch / LDS of every kernel of one translation unit
+cd /root/repo/crfconv_amd/csrc
+f=$1; shift
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed -Rpass-analysis=kernel-resource-usage "$@" -c $f -o /tmp/res_usage.o 2>&1 \
+ | grep -E "Function Name|VGPRs:|ScratchSize|VGPRs Spill|LDS Size|error|warning:" | sed -e 's/.*remark: *//' -e 's/\[-Rpass.*//' | paste - - - - - | sed -e 's/Function Name: //' | c++filt | cut -c1-260

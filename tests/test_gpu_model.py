@@ -152,6 +152,98 @@ def test_meanfield_vs_oracle(H, K, steps, B):
     assert_close(zero(cd.grad, cd), zero(cr.grad, cr), GRAD_TOL, 'dc')
 
 
+def _local_table(B, N, K, seed, spread):
+    """[B, N, K] int64 neighbours: column 0 = self, the others within +-spread rows of the target (a spatially sorted cloud in
+    miniature) or anywhere (spread = 0: a shuffled cloud)."""
+    g = torch.Generator().manual_seed(seed)
+    i = torch.arange(N).reshape(1, N, 1)
+    if spread:
+        j = (i + torch.randint(-spread, spread + 1, (B, N, K), generator=g)).clamp_(0, N - 1)
+    else:
+        j = torch.randint(0, N, (B, N, K), generator=g)
+    j[:, :, 0] = torch.arange(N)
+    return j
+
+
+@pytest.mark.parametrize('B,N,spread,steps,big', [(2, 5000, 300, 3, False), (1, 3000, 0, 3, False), (3, 4099, 150, 1, False), (2, 700, 40, 5, False),
+                                                   (4, 40960, 400, 3, False), (2, 70001, 500, 2, True)])
+def test_block_resident_meanfield_forward_equals_the_per_step_launches(B, N, spread, steps, big):
+    """csrc/crf_block.hip (one launch, block-resident rows, grid barriers between the steps) against csrc/crf.hip's per-step launches:
+    weights s and every iterate x_t bit for bit -- local tables (most neighbours served from LDS), a shuffled one (every neighbour from
+    the row tables past L1), ragged last blocks, one to five steps, uint16 and int32 (clouds of more than 65 536 points) index rows;
+    the barrier words are left zero, no failure code; and the gradients through ops.crf_meanfield agree (same saved tensors)."""
+    from crfconv_amd import _lib, ops
+    from crfconv_amd.graph import NeighborTable, ptr, stream_ptr
+    from crfconv_amd.ops._base import gridsync_ws
+    H, K = 8, 16
+    m = B * N
+    tab = NeighborTable(_local_table(B, N, K, N + steps, spread).to(DEV), N)
+    assert (tab.idx16 is None) == big
+    g = torch.Generator().manual_seed(N)
+    z = torch.randn(m, H, generator=g).to(DEV)
+    y = (0.7 * torch.randn(m, H, generator=g)).to(DEV)
+    c = torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)
+    C = c.t() @ c
+    Q = torch.linalg.inv(torch.eye(H) + C)
+    P = (C @ Q).to(DEV).contiguous()
+    Q = Q.to(DEV).contiguous()
+    rows = _lib.load().crfconv_meanfield_forward_block_rows(m, H, K, 1, steps)
+    assert rows > 0 and rows % 64 == 0
+    ws = gridsync_ws(torch.device(DEV))
+    res = []
+    for form in ('steps', 'block', 'block'):           # the block form twice: the barrier words of the first launch serve the second
+        s_ = torch.full((m, K), float('nan'), device=DEV)
+        xs = torch.full((steps, m, H), float('nan'), device=DEV)
+        if form == 'block':
+            _lib.call('crfconv_meanfield_forward_block', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src, K, 1, m, H,
+                      ptr(Q), ptr(P), steps, ptr(s_), ptr(xs), ptr(ws), stream_ptr())
+        else:
+            _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src, K, 1, m, H,
+                      ptr(Q), ptr(P), steps, ptr(s_), ptr(xs), stream_ptr())
+        torch.cuda.synchronize()
+        res.append((s_, xs))
+    assert int(ws.abs().sum()) == 0, 'barrier words not left zero (failure word: %d)' % int(ws[_lib.load().crfconv_gridsync_fail_word()])
+    for s_, xs in res[1:]:
+        assert bool(torch.isfinite(xs).all()) and torch.equal(s_, res[0][0])
+        for t_ in range(steps):
+            assert torch.equal(xs[t_], res[0][1][t_]), 'x_%d differs' % (t_ + 1)
+    # inference with one step: no weight store
+    if steps == 1:
+        xs = torch.empty((1, m, H), device=DEV)
+        _lib.call('crfconv_meanfield_forward_block', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src, K, 1, m, H,
+                  ptr(Q), ptr(P), 1, None, ptr(xs), ptr(ws), stream_ptr())
+        assert torch.equal(xs, res[0][1])
+    # through the operator: 'on' forces the block form, 'off' the per-step launches; outputs and gradients agree bit for bit
+    outs = {}
+    for mode in ('off', 'on'):
+        ops.state.mf_block = mode
+        try:
+            zd, yd, cd = z.clone().requires_grad_(True), y.clone().requires_grad_(True), c.to(DEV).requires_grad_(True)
+            out = ops.crf_meanfield(zd, yd, cd, tab, steps)
+            (out * torch.linspace(-1, 1, out.numel(), device=DEV).reshape(out.shape)).sum().backward()
+            outs[mode] = (out.detach(), zd.grad, yd.grad, cd.grad)
+        finally:
+            ops.state.mf_block = 'auto'
+    for a, b in zip(outs['off'], outs['on']):
+        assert torch.equal(a, b)
+
+
+def test_block_resident_meanfield_is_chosen_for_local_tables_only():
+    """ops.crf._block_rows ('auto'): a table whose entries stay inside the target's block of rows takes the one-launch form, a shuffled
+    one and a small one do not; the measured fraction is cached on the table."""
+    from crfconv_amd import ops
+    from crfconv_amd.graph import NeighborTable
+    from crfconv_amd.ops.crf import _block_rows
+    B, N = 2, 40960
+    near = NeighborTable(_local_table(B, N, 16, 1, 100).to(DEV), N)
+    far = NeighborTable(_local_table(B, N, 16, 2, 0).to(DEV), N)
+    small = NeighborTable(_local_table(1, 4096, 16, 3, 50).to(DEV), 4096)
+    assert ops.state.mf_block == 'auto'
+    assert _block_rows(near, B * N, 8, 1, 3) > 0 and near.cache[('block_locality', _block_rows(near, B * N, 8, 1, 3))] > 0.7
+    assert _block_rows(far, B * N, 8, 1, 3) == 0 and list(far.cache.values())[0] < 0.05
+    assert _block_rows(small, 4096, 8, 1, 3) == 0 and _block_rows(near, B * N, 16, 1, 3) == 0 and _block_rows(near, B * N, 8, 1, 0) == 0
+
+
 def test_meanfield_fp64_anchor(golden):
     from crfconv_amd import ops
     from crfconv_amd.graph import NeighborTable
