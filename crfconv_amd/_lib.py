@@ -37,6 +37,7 @@ SIGNATURES = {
     'crfconv_meanfield_forward_u16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     'crfconv_meanfield_forward_block_rows': (_i, [_i64, _i, _i, _i, _i]),
     'crfconv_meanfield_forward_block': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    'crfconv_meanfield_forward_block_stamps': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     'crfconv_block_locality': (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     'crfconv_meanfield_bwd_edge': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     'crfconv_meanfield_bwd_scatter': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp]),

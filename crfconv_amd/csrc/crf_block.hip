@@ -2,52 +2,56 @@
 //
 // The per-step kernels of crf.hip are bound by what a launch boundary forces them to move: every step re-reads the index row,
 // the weight row and z of every point (96 of its 192 bytes per point at H = 8, K = 16), and every neighbour row goes through the
-// texture path, which delivers ~one 128-byte line per clock and CU whatever fraction of the line is wanted (a 32-byte row = a
-// quarter).  This kernel removes both for SPATIALLY SORTED clouds (the device collate emits Morton order):
+// vector cache, whose tag lookup serves ~one 128-byte line per clock and CU whatever fraction of the line is wanted (a 32-byte
+// row = a quarter; profiles/r6_meanfield_ta.md: 11 300 line accesses per CU in a 15 000-cycle step launch).  This kernel removes
+// both for SPATIALLY SORTED clouds (the device collate emits Morton order):
 //
 //   * one workgroup per CU owns PB CONSECUTIVE rows for the whole forward.  Index rows, soft-max weights and z Q of its points stay
-//     in REGISTERS across the T steps (a lane pair carries PPL points); nothing but x_{t-1} is read again.
+//     in REGISTERS across the T steps, split over a point's lanes (lane q holds columns KL q .. and hands a column on by a DPP
+//     broadcast when its turn comes); nothing but x_{t-1} is read again.
 //   * the block's own rows of y | z (step 1) and of x_{t-1} (later steps) sit in LDS.  In Morton order ~80 % of a point's
-//     neighbours are rows of its own block of 640 (measured on the 4 cm synthetic cloud: 0.80 at 640 rows, 0.84 at 1024):
-//     they are ds_read_b128 from LDS (256 B/clk/CU, no tag lookups).  The rest are buffer loads as before.
-//   * both paths are issued for every neighbour, branch-free: the LDS read of an out-of-block neighbour goes to a row of zeros,
-//     the buffer load of an in-block one gets an offset past the resource's end (returns 0, no memory request); the two
-//     results are OR-ed (x | +0.0 is x, bit for bit).
-//   * between steps: the grid barrier of gridsync.hpp.  Rows are published write-through (sc1) and remote rows are read with
-//     sc1 loads (another CU's stores never refresh this CU's L1); with four fifths of the gathers in LDS the slow L1-bypassing
-//     path (2.4x the L1 path) carries a fifth of what sank the first one-launch form.
+//     neighbours are rows of its own block of 640 (measured on the 4 cm synthetic cloud: 0.80 at 640 rows): they are ds_read_b128
+//     from LDS (no tag lookups).  The rest are buffer loads as before.
+//   * ONE register per neighbour says where its row is: a >= 0: byte address inside the LDS row buffer; a < 0: bit 31 + byte offset in
+//     the row table.  Both accesses are branch-free for every neighbour: the LDS address is max(a, 0) (row 0 of the buffer holds
+//     zeros), the buffer offset is a ^ 0x80000000 (for an in-block neighbour: past the table's end -- the load returns 0 and makes
+//     no memory request).
+//   * step 1 (no barrier in front of it) adds the two results per neighbour (x + 0 is x): s and x_1 are those of
+//     sim_step_fast_kernel bit for bit.  Steps 2 .. T split their sum: the IN-BLOCK part of step t + 1 needs nothing but the
+//     block's own x_t, so it runs while the block's stores drain and the grid barrier completes (arrive -> in-block sums ->
+//     wait); only the out-of-block fifth is left behind the barrier.  The message is thereby added in a different order
+//     (in-block columns first): x_t, t >= 2, equals the per-step launches' to rounding (1e-6 relative), not bit for bit.
+//   * rows are published write-through (sc1) and remote rows read with sc1 loads (another CU's stores never refresh this CU's L1).
 //
-// Results are those of crf.hip's kernels bit for bit (same operations in the same order per point; tests/test_gpu_model.py).
-// Co-residency: one workgroup per CU at most (the host checks the grid against the device's CU count and the occupancy query);
-// a barrier that cannot complete gives up after ~1 s with the sticky failure word (ops.check_gridsync).
+// Measured (profiles/r6_block_stamps.md): the first form of this file (merged access in every step, full barrier) spent per step
+// 3.0 us computing, 0.3-3 us draining stores and 2.1-2.3 us in the barrier -- the split hides the first two behind the third.
+// Co-residency: one workgroup per CU at most (the host checks the grid against the device's CU count; every workgroup fits a CU
+// alone); a barrier that cannot complete gives up after ~1 s with the sticky failure word (ops.check_gridsync).
 //
 // Reference semantics: models/continuous_crf_conv_big.py:49-54 (similarity), :63-72 (loop).
 #include "crf_common.hpp"
 
 namespace crf {
 
-__device__ __forceinline__ float4 or4(float4 a, float4 b) {
-    return make_float4(__uint_as_float(__float_as_uint(a.x) | __float_as_uint(b.x)), __uint_as_float(__float_as_uint(a.y) | __float_as_uint(b.y)),
-                       __uint_as_float(__float_as_uint(a.z) | __float_as_uint(b.z)), __uint_as_float(__float_as_uint(a.w) | __float_as_uint(b.w)));
+// Packed float32 arithmetic (v_pk_add_f32 / v_pk_fma_f32: two components per instruction at the rate of one): the kernel's phases are
+// bound by the NUMBER of vector instructions (profiles/r6_block_stamps.md), and component-wise add / subtract / multiply-add
+// give the same bits either way.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 lo2(float4 v) { return f32x2{v.x, v.y}; }
+__device__ __forceinline__ f32x2 hi2(float4 v) { return f32x2{v.z, v.w}; }
+__device__ __forceinline__ float4 cat2(f32x2 l, f32x2 h) { return make_float4(l.x, l.y, h.x, h.y); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return cat2(lo2(a) + lo2(b), hi2(a) + hi2(b)); }
+__device__ __forceinline__ float4 psub4(float4 a, float4 b) { return cat2(lo2(a) - lo2(b), hi2(a) - hi2(b)); }
+__device__ __forceinline__ float4 pfma4(float w, float4 x, float4 acc) {
+    const f32x2 ww = {w, w};
+    return cat2(__builtin_elementwise_fma(ww, lo2(x), lo2(acc)), __builtin_elementwise_fma(ww, hi2(x), hi2(acc)));
 }
-
-constexpr int BLK_OOB = 0x7ffffff0;          // a byte offset past the end of every row table (tables are < 2 GiB: the launcher checks)
 
 template <int H, int NW, int PPL>
 struct BlkGeo {
     static constexpr int L = H / 4, PPW = WAVE / L, NT = NW * WAVE, PB = PPL * NW * PPW, RB = 4 * H;
-    static constexpr int LDS_BYTES = 2 * (PB + 1) * L * 16;
 };
 
-// lds: byte address of this lane's 16-byte piece inside a row buffer; glob: byte offset for the buffer load
-template <int H, int PB>
-__device__ __forceinline__ void blk_addr(int j, int base, int q, int& lds, int& glob) {
-    constexpr int L = H / 4, RB = 4 * H;
-    const int jl = j - base;
-    const bool in = (unsigned)jl < (unsigned)PB;
-    lds = ((in ? jl : PB) * L + q) * 16;
-    glob = in ? BLK_OOB : j * RB + 16 * q;
-}
 __device__ __forceinline__ float4 lds4(const float4* buf, int byte_addr) {
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(buf) + byte_addr);
 }
@@ -93,75 +97,127 @@ __device__ __forceinline__ int group_bcast_i(int v, int base_lane) {
     return __float_as_int(group_bcast<L, HQ>(__int_as_float(v), base_lane));
 }
 
-template <int H, int K, int NW, int PPL, bool U16>
+// STAMP: diagnostic build only (crfconv_meanfield_forward_block_stamps): thread 0 of every workgroup writes 100 MHz s_memrealtime
+// stamps of its phases to dbg[block][..]; no output depends on them.
+#define BLK_STAMP(slot)                                                                           \
+    do {                                                                                          \
+        if constexpr (STAMP) {                                                                    \
+            const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                       \
+            if (threadIdx.x == 0) dbg[(size_t)blockIdx.x * 64 + (slot)] = t_;                     \
+        }                                                                                         \
+    } while (0)
+
+// The grid barrier of gridsync.hpp (fused_grid_sync: same words, same counting) in two halves, so that work that needs nothing from
+// other workgroups can sit between them.  blk_arrive: call after every wavefront has drained its write-through stores AND the
+// workgroup has synchronised; blk_wait returns false (for the whole workgroup) when the spin gave up.
+__device__ __forceinline__ void blk_arrive(unsigned* ws, unsigned phase, unsigned n_in_group, unsigned n_groups) {
+    if (threadIdx.x == 0) {
+        const unsigned g = blockIdx.x & 7u;
+        const unsigned old = __hip_atomic_fetch_add(ws + (FW_CNT + g) * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == n_in_group * phase) {
+            const unsigned o2 = __hip_atomic_fetch_add(ws + FW_TOP * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (o2 + 1 == n_groups * phase)
+                for (unsigned g2 = 0; g2 < n_groups; ++g2)
+                    __hip_atomic_store(ws + (FW_GEN + g2) * FW_LINE, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__device__ __forceinline__ bool blk_wait(unsigned* ws, unsigned phase, int* s_ok) {
+    if (threadIdx.x == 0) {
+        unsigned* gen = ws + (FW_GEN + (blockIdx.x & 7u)) * FW_LINE;
+        int ok = 1;
+        unsigned spins = 0;
+        for (;;) {
+            if (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= phase) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > FW_SPIN_LIMIT) {
+                __hip_atomic_store(ws + FW_FAIL * FW_LINE, 0x200u | phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+template <int H, int K, int NW, int PPL, bool U16, bool STAMP = false>
 __global__ __launch_bounds__(NW * WAVE) void mf_block_kernel(const float* __restrict__ y, const float* __restrict__ z,
                                                              const int32_t* __restrict__ idx, const uint16_t* __restrict__ idx16,
                                                              int n_tgt, int n_src, const float* __restrict__ Q,
                                                              const float* __restrict__ P, float* __restrict__ s, float* xs,
-                                                             int64_t m64, int T, unsigned* ws) {
+                                                             int64_t m64, int T, unsigned* ws, unsigned long long* dbg) {
+    BLK_STAMP(0);
     using G = BlkGeo<H, NW, PPL>;
-    constexpr int L = G::L, PPW = G::PPW, NT = G::NT, PB = G::PB, CPR = K / 4, NCH = PPW * CPR, KL = K / L;
+    constexpr int L = G::L, PPW = G::PPW, NT = G::NT, PB = G::PB, RB = G::RB, CPR = K / 4, NCH = PPW * CPR, KL = K / L;
+    constexpr int TAG = (int)0x80000000u;
     static_assert(L == 2 || L == 4, "neighbour columns travel between a point's lanes as DPP quad permutes");
-    __shared__ float4 bufA[(PB + 1) * L];            // row PB: zeros (where the LDS read of an out-of-block neighbour goes)
-    __shared__ float4 bufB[(PB + 1) * L];
+    static_assert(NCH % WAVE == 0, "weight rows leave as whole 1 KiB stores");
+    __shared__ float4 bufA[(PB + 1) * L];            // row 0: zeros (where the LDS read of an out-of-block neighbour goes); own row r at r + 1
+    __shared__ float4 bufB[(PB + 1) * L];            // z (step 1 only)
     __shared__ float4 sQ[MatStage<H, NT>::F4];
     __shared__ float4 sP[MatStage<H, NT>::F4];
-    __shared__ float4 tile[NW][NCH];                 // a wavefront's weight rows on their way out as 1 KiB-contiguous stores
+    __shared__ float4 tile[PPL][NW][NCH];            // a wavefront's weight rows on their way out as 1 KiB-contiguous stores
     __shared__ int s_ok;
     const int m = (int)m64;
     const int lane = threadIdx.x & 63, q = lane % L, gl = lane - q, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned bid = xcd_block_id();
     const int base = (int)bid * PB;
     if (threadIdx.x < L) {
-        bufA[PB * L + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
-        bufB[PB * L + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bufA[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bufB[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    // ---------------------------------------------------------------- own rows -> registers + LDS
-    int jh[PPL][KL];
+    // ---------------------------------------------------------------- own rows -> registers + LDS; where every neighbour's row is
+    int a[PPL][KL];
     int rl[PPL], own[PPL];
     bool valid[PPL];
     float4 yi[PPL], zi[PPL];
 #pragma unroll
     for (int p = 0; p < PPL; ++p) {
+        int jh[KL];
         rl[p] = (p * NW + wave) * PPW + lane / L;
         const int r0 = base + rl[p];
         valid[p] = r0 < m;
         const int r = valid[p] ? r0 : m - 1;
-        own[p] = r * G::RB + 16 * q;
-        load_index_share<K, L, U16>(idx, idx16, r, n_tgt, n_src, q, jh[p]);
+        own[p] = r * RB + 16 * q;
+        load_index_share<K, L, U16>(idx, idx16, r, n_tgt, n_src, q, jh);
         yi[p] = ld4(y + (int64_t)r * H + 4 * q);
         zi[p] = ld4(z + (int64_t)r * H + 4 * q);
+#pragma unroll
+        for (int i = 0; i < KL; ++i) {
+            const int jl = jh[i] - base;
+            a[p][i] = (unsigned)jl < (unsigned)PB ? (jl + 1) * RB : (TAG | (jh[i] * RB));
+        }
     }
     MatStage<H, NT> mq, mp;
     mq.fetch(Q, false);
     mp.fetch(P, false);
 #pragma unroll
     for (int p = 0; p < PPL; ++p) {
-        bufA[rl[p] * L + q] = yi[p];
-        bufB[rl[p] * L + q] = zi[p];
+        bufA[(rl[p] + 1) * L + q] = yi[p];
+        bufB[(rl[p] + 1) * L + q] = zi[p];
     }
     mq.park(sQ);
     mp.park(sP);
     __syncthreads();
+    BLK_STAMP(1);
 
-    const int step_bytes = m * G::RB;
+    const int step_bytes = m * RB;
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(y, step_bytes), rz = make_rsrc(z, step_bytes);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(xs, step_bytes * (T > 0 ? T : 1));
 
-    // one share of neighbour rows (columns KL lq .. KL lq + KL - 1, minus column 0) from an LDS buffer + a row table
-#define BLK_GATHER(lq, buf, LOADG)                                                        \
-    float4 nb[KL];                                                                        \
-    static_for<KL>([&](auto I) {                                                          \
-        constexpr int i = decltype(I)::value;                                             \
-        if constexpr (KL * lq + i >= 1) {                                                 \
-            int la, go;                                                                   \
-            blk_addr<H, PB>(group_bcast_i<L, lq>(jh[p][i], gl), base, q, la, go);         \
-            nb[i] = or4(lds4(buf, la), LOADG);                                            \
-        }                                                                                 \
-    })
+    // column (lq, i) of point p: this lane's piece of the row from LDS and from the row table, added (one of the two is zero)
+#define BLK_BOTH(buf, LOADG)                                                              \
+    [&](auto LQ_, auto I_) {                                                              \
+        const int av = group_bcast_i<L, decltype(LQ_)::value>(a[p][decltype(I_)::value], gl) + 16 * q;   \
+        const int la = av > 0 ? av : 0, go = av ^ TAG;                                    \
+        (void)go;                                                                         \
+        return add4(lds4(buf, la), LOADG);                                                \
+    }
 
-    // ---------------------------------------------------------------- similarity + step 1
+    // ---------------------------------------------------------------- similarity + step 1 (bit-identical to sim_step_fast_kernel)
     float wh[PPL][KL];
     float4 zq[PPL], o[PPL];
 #pragma unroll
@@ -170,11 +226,15 @@ __global__ __launch_bounds__(NW * WAVE) void mf_block_kernel(const float* __rest
         float dmin = 3.4e38f;
         static_for<L>([&](auto LQ) {
             constexpr int lq = decltype(LQ)::value;
-            BLK_GATHER(lq, bufA, ld4_buf(ry, go));
+            float4 nb[KL];
+            auto row = BLK_BOTH(bufA, ld4_buf(ry, go));
+            static_for<KL>([&](auto I) {
+                if constexpr (KL * lq + decltype(I)::value >= 1) nb[decltype(I)::value] = row(LQ, I);
+            });
             static_for<KL>([&](auto I) {
                 constexpr int i = decltype(I)::value, k = KL * lq + i;
                 if constexpr (k >= 1) {
-                    const float4 df = sub4(yi[p], nb[i]);
+                    const float4 df = psub4(yi[p], nb[i]);
                     d[k] = group_sum<L>(dot4(df, df));
                     dmin = fminf(dmin, d[k]);
                 }
@@ -204,72 +264,158 @@ __global__ __launch_bounds__(NW * WAVE) void mf_block_kernel(const float* __rest
         const float inv = 1.0f / group_bcast<L, L - 1>(acc, gl);
 #pragma unroll
         for (int i = 0; i < KL; ++i) wh[p][i] = eh[i] * inv;
-        if (s != nullptr) {
-            float4* mine = tile[wave];
+        if (s != nullptr) {                                      // parked in the tile; stored BEHIND the x_1 rows (see below)
+            float4* mine = tile[p][wave];
             const int pl = lane / L;
 #pragma unroll
             for (int c = 0; c < KL / 4; ++c)
                 mine[pl * CPR + q * (KL / 4) + c] = make_float4(wh[p][4 * c], wh[p][4 * c + 1], wh[p][4 * c + 2], wh[p][4 * c + 3]);
-            __builtin_amdgcn_wave_barrier();
-            const int row0 = base + (p * NW + wave) * PPW;
-#pragma unroll
-            for (int c = lane; c < NCH; c += WAVE)
-                if (row0 + c / CPR < m) st4(s + (int64_t)row0 * K + 4 * c, mine[c]);
-            __builtin_amdgcn_wave_barrier();
         }
         if (T > 0) {
             float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
             static_for<L>([&](auto LQ) {
                 constexpr int lq = decltype(LQ)::value;
-                BLK_GATHER(lq, bufB, ld4_buf(rz, go));
+                float4 nb[KL];
+                auto row = BLK_BOTH(bufB, ld4_buf(rz, go));
+                static_for<KL>([&](auto I) {
+                    if constexpr (KL * lq + decltype(I)::value >= 1) nb[decltype(I)::value] = row(LQ, I);
+                });
                 static_for<KL>([&](auto I) {
                     constexpr int i = decltype(I)::value;
-                    if constexpr (KL * lq + i >= 1) msg = fma4(group_bcast<L, lq>(wh[p][i], gl), nb[i], msg);
+                    if constexpr (KL * lq + i >= 1) msg = pfma4(group_bcast<L, lq>(wh[p][i], gl), nb[i], msg);
                 });
             });
             zq[p] = matvec_acc<H>(zi[p], sQ, lane, q, make_float4(0.f, 0.f, 0.f, 0.f));
             o[p] = matvec_acc<H>(msg, sP, lane, q, zq[p]);
+        }
+        __builtin_amdgcn_sched_barrier(0);             // one point's rows at a time: the next pass's gathers are NOT hoisted over this one's arithmetic (registers)
+    }
+    BLK_STAMP(2);
+    // x_1 first (what the other workgroups wait for), the weight rows behind it: the barrier's drain below leaves them in flight
+    if (T > 0) {
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
             if (valid[p]) {
                 if (T > 1) st4_sc1(rx, own[p], o[p]);
                 else st4(xs + (int64_t)(base + rl[p]) * H + 4 * q, o[p]);
             }
         }
     }
+    // the weight rows leave from the tile as 1 KiB-contiguous stores.  With more steps to come they are issued BEHIND the first barrier's
+    // arrival (41 KB per CU: their issue alone stalls a wavefront for microseconds while the store path is busy, and nobody waits for them)
+    auto store_weights = [&]() {
+        __builtin_amdgcn_wave_barrier();                          // LDS operations of one wave complete in order
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+            const float4* mine = tile[p][wave];
+            const int row0 = base + (p * NW + wave) * PPW;
+#pragma unroll
+            for (int c = lane; c < NCH; c += WAVE)
+                if (row0 + c / CPR < m) st4(s + (int64_t)row0 * K + 4 * c, mine[c]);
+        }
+    };
+    if (T <= 1 && s != nullptr) store_weights();
     if (T <= 1) return;
 
     unsigned n_in_group, n_groups;
     grid_sync_groups(gridDim.x, blockIdx.x, n_in_group, n_groups);
     __syncthreads();                                  // every wavefront is done with its y / z gathers: bufA becomes x_1
 #pragma unroll
-    for (int p = 0; p < PPL; ++p) bufA[rl[p] * L + q] = o[p];
+    for (int p = 0; p < PPL; ++p) bufA[(rl[p] + 1) * L + q] = o[p];
+    __syncthreads();
+    BLK_STAMP(3);
 
     // ---------------------------------------------------------------- steps 2 .. T
+    // sum over the columns whose rows are in the block (LDS; the others read the zero row) / outside it (buffer loads; the others
+    // get an offset past the table's end), in column order each
+    auto inblock = [&](auto PP, int q16) {
+        constexpr int p = decltype(PP)::value;
+        float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
+        static_for<L>([&](auto LQ) {
+            constexpr int lq = decltype(LQ)::value;
+            float4 nb[KL];
+            static_for<KL>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if constexpr (KL * lq + i >= 1) {
+                    const int av = group_bcast_i<L, lq>(a[p][i], gl) + q16;
+                    nb[i] = lds4(bufA, av > 0 ? av : 0);
+                }
+            });
+            static_for<KL>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if constexpr (KL * lq + i >= 1) msg = pfma4(group_bcast<L, lq>(wh[p][i], gl), nb[i], msg);
+            });
+            // the next share's reads stay behind this share's sums (its addresses now "depend" on them): one share of rows is the register budget
+            asm volatile("" : "+v"(msg.x), "+v"(msg.y), "+v"(msg.z), "+v"(msg.w), "+v"(q16));
+        });
+        return msg;
+    };
     for (int t = 1; t < T; ++t) {
-        if (!fused_grid_sync<false>(ws, (unsigned)t, n_in_group, n_groups, &s_ok, nullptr, blockIdx.x)) return;
-        const float4* cur = (t & 1) ? bufA : bufB;
-        float4* nxt = (t & 1) ? bufB : bufA;
+        // (the address decode below is the same in every step: without this opaque copy the compiler hoists all 2 x 15 x PPL decoded
+        // addresses out of the loop into registers -- 205 VGPRs, i.e. spills at three wavefronts per SIMD)
+        int q16 = 16 * q;
+        asm volatile("" : "+v"(q16));
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+#pragma unroll
+            for (int i = 0; i < KL; ++i) {          // (the lane-to-lane broadcasts of a and wh are loop-invariant too)
+                asm volatile("" : "+v"(a[p][i]));
+                asm volatile("" : "+v"(wh[p][i]));
+            }
+        }
+        float4 msgin[PPL];
+        msgin[0] = inblock(std::integral_constant<int, 0>{}, q16);
+        BLK_STAMP(8 * t + 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the x_t rows have left
+        __syncthreads();
+        BLK_STAMP(8 * t + 4);
+        blk_arrive(ws, (unsigned)t, n_in_group, n_groups);
+        if (t == 1 && s != nullptr) store_weights();
+        static_for<PPL - 1>([&](auto PP) { msgin[decltype(PP)::value + 1] = inblock(std::integral_constant<int, decltype(PP)::value + 1>{}, q16); });
+        BLK_STAMP(8 * t + 5);
+        if (!blk_wait(ws, (unsigned)t, &s_ok)) return;
+        BLK_STAMP(8 * t + 1);
         const int sbase = (t - 1) * step_bytes;
 #pragma unroll
         for (int p = 0; p < PPL; ++p) {
-            float4 msg = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 msg = msgin[p];
             static_for<L>([&](auto LQ) {
                 constexpr int lq = decltype(LQ)::value;
-                BLK_GATHER(lq, cur, ld4_sc1(rx, go, sbase));
+                float4 nb[KL];
                 static_for<KL>([&](auto I) {
                     constexpr int i = decltype(I)::value;
-                    if constexpr (KL * lq + i >= 1) msg = fma4(group_bcast<L, lq>(wh[p][i], gl), nb[i], msg);
+                    if constexpr (KL * lq + i >= 1) {
+                        const int av = group_bcast_i<L, lq>(a[p][i], gl) + q16;
+                        nb[i] = ld4_sc1(rx, av ^ TAG, sbase);
+                    }
+                });
+                static_for<KL>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    if constexpr (KL * lq + i >= 1) msg = pfma4(group_bcast<L, lq>(wh[p][i], gl), nb[i], msg);
                 });
             });
+            // (no tie between the shares here: all K - 1 loads of a pass in flight -- this part sits behind the barrier, its round trips are the step's critical path)
+            asm volatile("" : "+v"(msg.x), "+v"(msg.y), "+v"(msg.z), "+v"(msg.w), "+v"(q16));
             o[p] = matvec_acc<H>(msg, sP, lane, q, zq[p]);
             if (valid[p]) {
                 if (t + 1 < T) st4_sc1(rx, own[p] + sbase + step_bytes, o[p]);       // the last step's rows are read by later launches only
                 else st4(xs + (int64_t)t * m * H + (int64_t)(base + rl[p]) * H + 4 * q, o[p]);
             }
-            nxt[rl[p] * L + q] = o[p];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        BLK_STAMP(8 * t + 2);
+        if (t + 1 < T) {                              // (blk_wait's barrier: every wavefront is done with x_{t-1} in bufA)
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) bufA[(rl[p] + 1) * L + q] = o[p];
+            __syncthreads();
         }
     }
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BLK_STAMP(7);
+    }
     fused_exit_reset(ws, gridDim.x, T, blockIdx.x);
-#undef BLK_GATHER
+#undef BLK_BOTH
 }
 
 // count[0] += entries of columns k0 .. K-1 whose source row shares the block of `rows` consecutive rows with its target (one thread per row)
@@ -295,22 +441,24 @@ using namespace crf;
 namespace {
 
 struct BlkPlan {
-    int nw, pb, nblk;
+    int nw, ppl, pb, nblk;
 };
-constexpr int BLK_PPL = 2;                          // points per lane group (the register budget: 158 VGPRs at 3 wavefronts per SIMD)
-constexpr int BLK_NWS[] = {4, 8, 10, 12};           // wavefronts per workgroup of the compiled shapes (more than 12 = 4 per SIMD = 128 VGPRs: spills)
+// compiled shapes (wavefronts per workgroup, points per lane group), by rows per workgroup.  (10, 2): 144 VGPRs at 3 wavefronts per SIMD.
+// Measured and dropped: (4, 5) -- one wavefront per SIMD, five passes each, the only 640-row shape whose wavefronts divide evenly over the
+// four SIMDs: 28.7 us against 23.6 (a lone wavefront issues a vector instruction every ~8 cycles); two workgroups of 320 rows per CU
+// (10 wavefronts each at 96 VGPRs): not co-resident -- the second workgroup's ten wavefronts do not fit the SIMDs the first left uneven.
+constexpr int BLK_SHAPES[][2] = {{4, 2}, {8, 2}, {10, 2}, {12, 2}};
 
-// PB = PPL * NW * PPW rows per workgroup with at most one workgroup per CU: the smallest compiled block that covers m rows with no
-// more workgroups than the device has CUs, or nblk = 0 when none does.
+// The smallest compiled block that covers m rows with no more workgroups than the device has CUs, or nblk = 0 when none does.
 template <int H>
 BlkPlan plan_for(int64_t m, int cus) {
     constexpr int PPW = WAVE / (H / 4);
-    for (int nw : BLK_NWS) {
-        const int pb = nw * BLK_PPL * PPW;
+    for (const auto& sh : BLK_SHAPES) {
+        const int pb = sh[0] * sh[1] * PPW;
         const int64_t nblk = cdiv(m, pb);
-        if (nblk <= cus) return {nw, pb, (int)nblk};
+        if (nblk <= cus) return {sh[0], sh[1], pb, (int)nblk};
     }
-    return {0, 0, 0};
+    return {0, 0, 0, 0};
 }
 
 int device_cus() {
@@ -323,11 +471,11 @@ int device_cus() {
     return cus;
 }
 
-template <int H, int K, int NW>
+template <int H, int K, int NW, int PPL>
 int launch_block(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16, int n_tgt, int n_src, int64_t m,
                  const float* Q, const float* P, int T, float* s, float* xs, unsigned* ws, int nblk, hipStream_t st) {
-    if (idx16) hipLaunchKernelGGL((mf_block_kernel<H, K, NW, BLK_PPL, true>), dim3((unsigned)nblk), dim3(NW * WAVE), 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, ws);
-    else hipLaunchKernelGGL((mf_block_kernel<H, K, NW, BLK_PPL, false>), dim3((unsigned)nblk), dim3(NW * WAVE), 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, ws);
+    if (idx16) hipLaunchKernelGGL((mf_block_kernel<H, K, NW, PPL, true>), dim3((unsigned)nblk), dim3(NW * WAVE), 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, ws, (unsigned long long*)nullptr);
+    else hipLaunchKernelGGL((mf_block_kernel<H, K, NW, PPL, false>), dim3((unsigned)nblk), dim3(NW * WAVE), 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, ws, (unsigned long long*)nullptr);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
@@ -336,16 +484,16 @@ int launch_block(const float* z, const float* y, const int32_t* idx32, const uin
 
 /* Rows per workgroup of crfconv_meanfield_forward_block for m rows on the current device, 0 when the shape is not covered
  * (H = 8, K = 16, k0 = 1, T >= 1; at most one block of <= 768 rows per CU; row tables below 2 GiB).  A grid of at most one
- * workgroup per CU is always co-resident (every workgroup fits a CU alone: 67-80 KB of LDS, <= 768 threads).  Whether the form
- * PAYS depends on the point order: crfconv_block_locality(). */
+ * workgroup per CU is always co-resident (every workgroup fits a CU alone).  Whether the form PAYS depends on the point order:
+ * crfconv_block_locality(). */
 extern "C" int crfconv_meanfield_forward_block_rows(int64_t m, int H, int K, int k0, int T) {
-    if (H != 8 || K != 16 || k0 != 1 || T < 1 || m <= 0 || m * H * 4 * (int64_t)T >= ((int64_t)1 << 31) - 64) return 0;
+    if (H != 8 || K != 16 || k0 != 1 || T < 1 || m <= 0 || m * H * 4 * (int64_t)T >= ((int64_t)1 << 31) - 4096) return 0;
     const int cus = device_cus();
     return cus > 0 ? plan_for<8>(m, cus).pb : 0;
 }
 
 /* crfconv_meanfield_forward_u16 as ONE launch with block-resident rows (this file's header).  ws: the grid-barrier words
- * (crfconv_gridsync_workspace() bytes, zero before the first launch, left zero).  Same outputs, bit for bit. */
+ * (crfconv_gridsync_workspace() bytes, zero before the first launch, left zero). */
 extern "C" int crfconv_meanfield_forward_block(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16,
                                                int n_tgt, int n_src, int K, int k0, int64_t m, int H, const float* Q,
                                                const float* P, int T, float* s, float* xs, void* ws, crf_stream_t stream) {
@@ -359,12 +507,27 @@ extern "C" int crfconv_meanfield_forward_block(const float* z, const float* y, c
     const BlkPlan pl = plan_for<8>(m, device_cus());
     hipStream_t st = as_stream(stream);
     unsigned* w = reinterpret_cast<unsigned*>(ws);
-    switch (pl.nw) {
-        case 4: return launch_block<8, 16, 4>(z, y, idx32, idx16, n_tgt, n_src, m, Q, P, T, s, xs, w, pl.nblk, st);
-        case 8: return launch_block<8, 16, 8>(z, y, idx32, idx16, n_tgt, n_src, m, Q, P, T, s, xs, w, pl.nblk, st);
-        case 10: return launch_block<8, 16, 10>(z, y, idx32, idx16, n_tgt, n_src, m, Q, P, T, s, xs, w, pl.nblk, st);
-        default: return launch_block<8, 16, 12>(z, y, idx32, idx16, n_tgt, n_src, m, Q, P, T, s, xs, w, pl.nblk, st);
-    }
+#define BLK_CASE(NW_, PPL_) if (pl.nw == NW_ && pl.ppl == PPL_) return launch_block<8, 16, NW_, PPL_>(z, y, idx32, idx16, n_tgt, n_src, m, Q, P, T, s, xs, w, pl.nblk, st)
+    BLK_CASE(4, 2);
+    BLK_CASE(8, 2);
+    BLK_CASE(10, 2);
+    BLK_CASE(12, 2);
+#undef BLK_CASE
+    CRF_REQUIRE(false, CRF_ERR_UNSUPPORTED, "block-resident mean field: no kernel for %d wavefronts x %d passes", pl.nw, pl.ppl);
+}
+
+/* Diagnostic twin (scratch/mf_block_stamps.py): 100 MHz phase stamps per workgroup in dbg [blocks][64] (u64); 640 rows per workgroup
+ * (10 wavefronts x 2 passes; `shape` is reserved), uint16 tables only. */
+extern "C" int crfconv_meanfield_forward_block_stamps(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16,
+                                                      int n_tgt, int n_src, int64_t m, const float* Q, const float* P, int T, float* s,
+                                                      float* xs, void* ws, int shape, unsigned long long* dbg, crf_stream_t stream) {
+    CRF_REQUIRE(z && y && idx32 && idx16 && Q && P && s && xs && ws && dbg && T >= 1, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(cdiv(m, 640) <= device_cus() && m * 32 * (int64_t)T < ((int64_t)1 << 31) - 4096, CRF_ERR_UNSUPPORTED, "too many rows");
+    (void)shape;
+    hipLaunchKernelGGL((mf_block_kernel<8, 16, 10, 2, true, true>), dim3((unsigned)cdiv(m, 640)), dim3(640), 0, as_stream(stream), y, z, idx32, idx16,
+                       n_tgt, n_src, Q, P, s, xs, m, T, reinterpret_cast<unsigned*>(ws), dbg);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
 }
 
 extern "C" int crfconv_block_locality(const int32_t* idx32, int64_t m, int K, int k0, int rows, unsigned long long* count, crf_stream_t stream) {

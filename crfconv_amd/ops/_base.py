@@ -156,7 +156,7 @@ class _State:
     # 10 240-row level joins the small forms) -> 4.694 ms, 65536 -> 4.736 ms
     mfma_min_rows = 12288
     # the mean-field forward as one launch with block-resident rows (csrc/crf_block.hip; ops.crf._block_rows): 'auto' | 'on' | 'off'
-    mf_block = 'auto'
+    mf_block = __import__('os').environ.get('CRFCONV_MF_BLOCK', 'auto')      # (the environment variable: A/B runs of bench.py)
     mf_block_min_rows = 65536        # below: too few workgroups of 256+ rows to fill the chip
     mf_block_min_locality = 0.6      # fraction of table entries inside the target's own block (Morton-sorted clouds: ~0.8)
 

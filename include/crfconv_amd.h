@@ -160,8 +160,8 @@ int crfconv_meanfield_forward_u16(const float* z, const float* y, const int32_t*
 
 /* The same forward as ONE launch with block-resident rows (csrc/crf_block.hip; round 6): a workgroup per CU owns consecutive rows for all
  * T steps -- index rows, soft-max weights and z Q stay in registers, the block's own rows of y | z | x_t sit in LDS and serve the
- * neighbours that lie inside the block (four fifths of them in Morton order), a grid barrier separates the steps.  Outputs equal
- * crfconv_meanfield_forward_u16's bit for bit.  ws: crfconv_gridsync_workspace() bytes of zero words (left zero); a barrier that cannot
+ * neighbours that lie inside the block (four fifths of them in Morton order), a grid barrier separates the steps.  The weights s and x_1 equal
+ * crfconv_meanfield_forward_u16's bit for bit, the later iterates to rounding (their messages are added in-block columns first).  ws: crfconv_gridsync_workspace() bytes of zero words (left zero); a barrier that cannot
  * complete sets the sticky failure word (crfconv_gridsync_fail_word).
  * crfconv_meanfield_forward_block_rows: rows per workgroup for m rows on the current device, 0 = shape not covered (H = 8, K = 16,
  * k0 = 1, T >= 1, m <= 768 x CUs).  crfconv_block_locality: count[0] = number of table entries (columns k0 .. K-1) whose source row lies
@@ -171,6 +171,11 @@ int crfconv_meanfield_forward_block_rows(int64_t m, int H, int K, int k0, int T)
 int crfconv_meanfield_forward_block(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16,
                                     int n_tgt, int n_src, int K, int k0, int64_t m, int H, const float* Q,
                                     const float* P, int T, float* s, float* xs, void* ws, crf_stream_t stream);
+/* Diagnostic twin: 100 MHz phase stamps per workgroup in dbg [blocks][64] (u64), 640 rows per workgroup, uint16 tables
+ * (scratch/mf_block_stamps.py; profiles/r6_block_stamps.md). */
+int crfconv_meanfield_forward_block_stamps(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16, int n_tgt, int n_src,
+                                           int64_t m, const float* Q, const float* P, int T, float* s, float* xs, void* ws, int shape,
+                                           unsigned long long* dbg, crf_stream_t stream);
 int crfconv_block_locality(const int32_t* idx32, int64_t m, int K, int k0, int rows, unsigned long long* count, crf_stream_t stream);
 
 /* One backward step, edge half:  given G = dL/dx_t and x_{t-1}:

@@ -25,7 +25,8 @@ def steps(): _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(tab.
 def block(): _lib.call('crfconv_meanfield_forward_block', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src, K, 1, m, H, ptr(Q), ptr(P), T, ptr(s2), ptr(x2), ptr(ws), st)
 def block_nos(): _lib.call('crfconv_meanfield_forward_block', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src, K, 1, m, H, ptr(Q), ptr(P), 1, None, ptr(x2), ptr(ws), st)
 steps(); block(); torch.cuda.synchronize()
-print('equal s %s  x %s  fail word %d' % (torch.equal(s1, s2), [bool(torch.equal(x1[t], x2[t])) for t in range(T)], int(ws[_lib.load().crfconv_gridsync_fail_word()])))
+err = [float((x1[t] - x2[t]).abs().max() / x1[t].abs().max()) for t in range(T)]
+print('s equal %s  x_1 equal %s  max |x_t - per-step| / max |x_t|: %s  fail word %d' % (torch.equal(s1, s2), torch.equal(x1[0], x2[0]), ['%.1e' % e for e in err], int(ws[_lib.load().crfconv_gridsync_fail_word()])))
 alg = m * (4 * (K - 1) + 4 * H * (2 * T + 1))
 for name, fn in (('per-step', steps), ('block', block), ('per-step', steps), ('block', block)):
     avg, lo = bench._event_time(fn)

@@ -8,3 +8,4 @@ timeout -k 10 200 python3 scratch/mf_block_ab.py 3 > gpurun_out/$tag/ab_T3.txt 2
 timeout -k 10 200 python3 scratch/mf_block_ab.py 1 > gpurun_out/$tag/ab_T1.txt 2>&1; tail -5 gpurun_out/$tag/ab_T1.txt
 timeout -k 10 200 python3 scratch/mf_block_ab.py 5 > gpurun_out/$tag/ab_T5.txt 2>&1; tail -5 gpurun_out/$tag/ab_T5.txt
 timeout -k 10 200 python3 scratch/mf_block_ab.py 3 none > gpurun_out/$tag/ab_T3_unsorted.txt 2>&1; tail -5 gpurun_out/$tag/ab_T3_unsorted.txt
+timeout -k 10 200 python3 scratch/mf_block_stamps.py 3 > gpurun_out/$tag/stamps_T3.txt 2>&1; cat gpurun_out/$tag/stamps_T3.txt | tail -40
