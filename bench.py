@@ -67,9 +67,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12           # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
-TRAFFIC_FWD, TRAFFIC_BWD = 'r5_meanfield_traffic.json', 'r5_meanfield_bwd_traffic.json'      # PMC passes, sha1-keyed to the kernel sources
+TRAFFIC_FWD, TRAFFIC_BWD = 'r6_meanfield_traffic.json', 'r6_meanfield_bwd_traffic.json'      # PMC passes, sha1-keyed to the kernel sources
 TRAFFIC_STEP, TRAFFIC_PC = 'r5_step_traffic.json', 'r5_pointconv_traffic.json'
-ROCPROF_MF = 'r5_meanfield_rocprof.json'      # rocprofv3 --kernel-trace average durations of the level-0 mean-field kernels, sha1-keyed
+ROCPROF_MF = 'r6_meanfield_rocprof.json'      # rocprofv3 --kernel-trace average durations of the level-0 mean-field kernels, sha1-keyed
 BOX = (8.0, 8.0, 3.0)
 VOX = 0.04
 
@@ -175,35 +175,59 @@ def _rocprof_durations(config):
         return None, 'no usable kernel trace (%s)' % type(e).__name__
 
 
-def roofline_meanfield(data, dev, H=8, T=3, level=0):
+def roofline_meanfield(data, dev, H=8, T=3, level=0, form=None):
     """CRF mean-field forward of one level alone (level 0 = the kernel the north_star target is stated on), HIP-event timed on
-    the stream it is launched on."""
+    the stream it is launched on.  form: 'block' (one launch, block-resident rows: csrc/crf_block.hip) / 'steps' (one launch per
+    step: csrc/crf.hip) / None = what ops.crf_meanfield picks for this table (block where the shape is covered and the table is
+    local); the other form's time is reported beside it."""
     from crfconv_amd import _lib
     from crfconv_amd.graph import ptr, stream_ptr
+    from crfconv_amd.ops._base import gridsync_ws
+    from crfconv_amd.ops.crf import _block_rows
     tab, m, K, z, y, Q, P, _ = _meanfield_problem(data, dev, H, level=level)
     s = torch.empty(m, K, device=dev)
     xs = torch.empty(T, m, H, device=dev)
     st = stream_ptr()
+    ws = gridsync_ws(dev)
+    can_block = _lib.load().crfconv_meanfield_forward_block_rows(m, H, K, 1, T) > 0
+    if form is None:
+        form = 'block' if _block_rows(tab, m, H, 1, T) > 0 else 'steps'
+    elif form == 'block' and not can_block:
+        return None
 
-    def launch():
+    def launch_steps():
         _lib.call('crfconv_meanfield_forward_u16', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src,
                   K, 1, m, H, ptr(Q), ptr(P), T, ptr(s), ptr(xs), st)
+
+    def launch_block():
+        _lib.call('crfconv_meanfield_forward_block', ptr(z), ptr(y), ptr(tab.idx32), ptr(tab.idx16), tab.n_tgt, tab.n_src,
+                  K, 1, m, H, ptr(Q), ptr(P), T, ptr(s), ptr(xs), ptr(ws), st)
+    launch = launch_block if form == 'block' else launch_steps
     avg, lo = _event_time(launch)
+    other = None
+    if level == 0 and (form == 'steps' and can_block or form == 'block'):
+        other = _event_time(launch_steps if form == 'block' else launch_block)[0]
     alg_bytes = m * (4 * (K - 1) + 4 * H * (2 * T + 1))
     traffic, note = _measured_traffic(TRAFFIC_FWD, {'m': m, 'H': H, 'K': K, 'T': T, 'u16': tab.idx16 is not None})
     out = {'bound': 'hbm', 'achieved': alg_bytes / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
            'frac': alg_bytes / avg / HBM_PEAK, 'traffic': traffic, 'traffic_source': note,
-           'kernel': 'crfconv_meanfield_forward level-%d (sim_step_fast_kernel [similarity + step 1] + %d x step_fast_kernel, '
-                     'm=%d, H=%d, K=%d)' % (level, T - 1, m, H, K),
+           'kernel': ('crfconv_meanfield_forward_block level-%d (mf_block_kernel: ONE launch, block-resident rows, %d grid barriers, m=%d, H=%d, K=%d)'
+                      % (level, T - 1, m, H, K)) if form == 'block' else
+                     ('crfconv_meanfield_forward level-%d (sim_step_fast_kernel [similarity + step 1] + %d x step_fast_kernel, '
+                      'm=%d, H=%d, K=%d)' % (level, T - 1, m, H, K)),
+           'form': form, 'other_form_launch_us': None if other is None else other * 1e6,
+           'block_locality': tab.cache.get(('block_locality', 640)),
            'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': avg * 1e6, 'min_launch_us': lo * 1e6,
            'note': 'isolated synthetic problem, 10 back-to-back launches per event pair: the %.1f MB working set stays resident in '
                    'the 256 MiB Infinity Cache between launches (as it does between the consecutive kernels of the real step, '
                    'whose in-step times agree); peak = the 8 TB/s HBM3E figure' % (alg_bytes / 1e6)}
     if level == 0:
         rec, why = _rocprof_durations({'m': m, 'H': H, 'K': K, 'T': T})
-        out['frac_rocprof'] = None if rec is None else alg_bytes / (rec['fwd_us'] * 1e-6) / HBM_PEAK
-        out['rocprof_launch_us'] = None if rec is None else rec['fwd_us']
-        out['frac_rocprof_source'] = why + ' (sum of the three kernels\' average durations; frac = HIP events of this run: the profiler adds ~1 us per dispatch)'
+        key = 'fwd_us' if form == 'block' else 'fwd_steps_us'
+        out['frac_rocprof'] = None if rec is None else alg_bytes / (rec[key] * 1e-6) / HBM_PEAK
+        out['rocprof_launch_us'] = None if rec is None else rec[key]
+        out['rocprof_other_form_launch_us'] = None if rec is None else rec['fwd_steps_us' if form == 'block' else 'fwd_us']
+        out['frac_rocprof_source'] = why + ' (sum of the average durations of the kernels of this form; frac = HIP events of this run: the profiler adds ~1 us per dispatch)'
     return out
 
 

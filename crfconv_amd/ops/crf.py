@@ -8,6 +8,20 @@ from ..graph import NeighborTable, ptr, require_gpu, stream_ptr
 from ._base import _f32c, _next_supported, _pad_channels, _ptr_array, _ticket, gridsync_ws, state
 
 # ------------------------------------------------------------------------------ CRF mean field
+def _table_is_local(table, m, k0, rows):
+    """True when at least state.mf_block_min_locality of the table's entries point into the target's own block of `rows` consecutive
+    rows (spatially sorted clouds).  Measured once per table and block size (one small launch + one host read, never inside a
+    capture: an unmeasured table is 'not local'), kept in table.cache -- a table refreshed in place keeps its first verdict."""
+    frac = table.cache.get(('block_locality', rows))
+    if frac is None:
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        count = torch.zeros(1, dtype=torch.int64, device=table.idx32.device)
+        _lib.call('crfconv_block_locality', ptr(table.idx32), m, table.K, k0, rows, ptr(count), stream_ptr())
+        frac = table.cache[('block_locality', rows)] = float(count.item()) / float(m * (table.K - k0))
+    return frac >= state.mf_block_min_locality
+
+
 def _block_rows(table, m, H, k0, steps):
     """Rows per workgroup when this forward is to run as ONE launch with block-resident rows (csrc/crf_block.hip), else 0.
     `ops.state.mf_block`: 'off' never, 'on' whenever the shape is covered (tests), 'auto' (default) when in addition the launch can
@@ -24,14 +38,7 @@ def _block_rows(table, m, H, k0, steps):
         return rows
     if m < state.mf_block_min_rows:
         return 0
-    frac = table.cache.get(('block_locality', rows))
-    if frac is None:
-        if torch.cuda.is_current_stream_capturing():
-            return 0
-        count = torch.zeros(1, dtype=torch.int64, device=table.idx32.device)
-        _lib.call('crfconv_block_locality', ptr(table.idx32), m, table.K, k0, rows, ptr(count), stream_ptr())
-        frac = table.cache[('block_locality', rows)] = float(count.item()) / float(m * (table.K - k0))
-    return rows if frac >= state.mf_block_min_locality else 0
+    return rows if _table_is_local(table, m, k0, rows) else 0
 
 
 class _MeanField(torch.autograd.Function):

@@ -219,6 +219,7 @@ int crfconv_meanfield_backward(const float* gout, const float* z, const float* y
                                float* dz, float* w, float* dy_self, float* dy, float* dP, float* dQ, void* ws,
                                size_t ws_bytes, unsigned* ticket, crf_stream_t stream);
 
+
 /* Wide rows, H in {128, 256} (the GCRFConv(512, 256) / (256, 128) stages of the sparse networks,
  * models/point_conv.py:318-339): the graph part of the mean-field loop and its backward, one point per wavefront, any
  * K <= 64 / k0, entries of idx32 < 0 = no neighbour.  The H x H products of a step (x = z Q + m P) are plain dense GEMMs

@@ -1,4 +1,4 @@
-"""Level-0 mean-field forward + backward, N calls each (argv[1], default 5) (for the rocprofv3 --pmc passes of scratch/pmc.sh)."""
+"""Level-0 mean-field forward + backward, N calls in each forward form (argv[1], default 5) (for the rocprofv3 --pmc passes of scratch/pmc.sh)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
@@ -14,8 +14,11 @@ z = torch.randn(m, H, generator=g).to(dev).requires_grad_()
 y = (0.5 * torch.randn(m, H, generator=g)).to(dev).requires_grad_()
 c = (torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)).to(dev).requires_grad_()
 gout = torch.randn(m, H, generator=g).to(dev)
-for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
-    for t in (z, y, c): t.grad = None
-    ops.crf_meanfield(z, y, c, tab, T).backward(gout)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+for mode in ('auto', 'off'):          # auto: the forward as ONE launch with block-resident rows (the table is local); off: one launch per step
+    ops.state.mf_block = mode
+    for it in range(n):
+        for t in (z, y, c): t.grad = None
+        ops.crf_meanfield(z, y, c, tab, T).backward(gout)
 torch.cuda.synchronize()
 print('done')

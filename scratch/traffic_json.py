@@ -1,6 +1,6 @@
 """Turns the summary of scratch/pmc.sh (level-0 mean-field passes of scratch/mf_pmc.py) into the committed provenance
-files: profiles/r5_meanfield_traffic.json, profiles/r5_meanfield_bwd_traffic.json (HBM-side bytes per launch + sha1 of the
-kernel source they were measured on) and profiles/r5a_meanfield_pmc.md (the raw counter means).
+files: profiles/r6_meanfield_traffic.json, profiles/r6_meanfield_bwd_traffic.json (HBM-side bytes per launch + sha1 of the
+kernel source they were measured on) and profiles/r6a_meanfield_pmc.md (the raw counter means).
 usage: python3 scratch/traffic_json.py gpurun_out/r5k/mfpmc_summary.txt"""
 import hashlib, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,9 +19,11 @@ FWD_FIRST, FWD_STEP = 'crf::sim_step_fast_kernel<8, 16, true, true>', 'crf::step
 REV_FIRST, REV_CHAIN, REV_FINAL = ('crf::bwd_rev_kernel<8, 2, 3, 0, true, 4>', 'crf::bwd_rev_kernel<8, 2, 3, 0, false, 4>',
                                    'crf::bwd_rev_kernel<8, 4, 2, 1, false, 4>')
 EDGE = 'crf::bwd_edge_all_kernel<8, 16, true>'
-fwd = hbm_bytes(FWD_FIRST) + (T - 1) * hbm_bytes(FWD_STEP)
+FWD_BLOCK = 'crf::mf_block_kernel<8, 16, 10, 2, true, false>'
+fwd = hbm_bytes(FWD_BLOCK)                     # the product's forward on a local table (round 6): ONE launch
+fwd_steps = hbm_bytes(FWD_FIRST) + (T - 1) * hbm_bytes(FWD_STEP)
 bwd = hbm_bytes(REV_FIRST) + (T - 2) * hbm_bytes(REV_CHAIN) + hbm_bytes(EDGE) + hbm_bytes(REV_FINAL)
-fsrc = ['crfconv_amd/csrc/crf.hip', 'crfconv_amd/csrc/crf_common.hpp']
+fsrc = ['crfconv_amd/csrc/crf_block.hip', 'crfconv_amd/csrc/crf.hip', 'crfconv_amd/csrc/crf_common.hpp']
 bsrc = ['crfconv_amd/csrc/crf_bwd.hip', 'crfconv_amd/csrc/crf_common.hpp']
 
 
@@ -35,16 +37,16 @@ def sha_of(srcs):
 how = ('rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (scratch/pmc.sh, scratch/mf_pmc.py, scratch/traffic_json.py); '
        'bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per the gfx950 correction of MI355X_MICROARCH.md; ')
 cfg = {'m': 163840, 'H': 8, 'K': 16, 'T': T, 'u16': True}
-for name, val, srcs, what in (('r5_meanfield_traffic.json', fwd, fsrc, 'sim_step_fast_kernel + 2 x step_fast_kernel'),
-                              ('r5_meanfield_bwd_traffic.json', bwd, bsrc, 'bwd_rev<chain, first> + bwd_rev<chain> + bwd_edge_all + bwd_rev<final>')):
+for name, val, srcs, what in (('r6_meanfield_traffic.json', fwd, fsrc, 'mf_block_kernel (one launch; the per-step launches of the same problem: %.1f MB)' % (fwd_steps / 1e6)),
+                              ('r6_meanfield_bwd_traffic.json', bwd, bsrc, 'bwd_rev<chain, first> + bwd_rev<chain> + bwd_edge_all + bwd_rev<final>')):
     json.dump({'config': cfg, 'source': srcs, 'source_sha1': sha_of(srcs), 'traffic_bytes_per_launch': val,
-               'profile': 'profiles/r5a_meanfield_pmc.md', 'how': how + what}, open(os.path.join(ROOT, 'profiles', name), 'w'), indent=1)
+               'profile': 'profiles/r6a_meanfield_pmc.md', 'how': how + what}, open(os.path.join(ROOT, 'profiles', name), 'w'), indent=1)
     print(name, '%.1f MB' % (val / 1e6))
-with open(os.path.join(ROOT, 'profiles', 'r5a_meanfield_pmc.md'), 'w') as f:
-    f.write('# rocprofv3 --pmc passes, level-0 mean-field forward + backward (m = 163840, H = 8, K = 16, T = 3), MI355X, round 5\n'
+with open(os.path.join(ROOT, 'profiles', 'r6a_meanfield_pmc.md'), 'w') as f:
+    f.write('# rocprofv3 --pmc passes, level-0 mean-field forward + backward (m = 163840, H = 8, K = 16, T = 3), MI355X, round 6\n'
             '# scratch/pmc.sh <outdir> <regex> scratch/mf_pmc.py ; FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE counts half the bytes on gfx950;\n'
             '# SQ_* counters as rocprofv3 reports them (counter units not converted).  sha1 forward sources %s, backward sources %s\n'
-            '# forward HBM-side bytes per call = %.1f MB, backward = %.1f MB (algorithmic: 46.5 MB / 104.2 MB)\n\n' % (sha_of(fsrc), sha_of(bsrc), fwd / 1e6, bwd / 1e6))
+            '# forward HBM-side bytes per call = %.1f MB as one launch (mf_block_kernel), %.1f MB as three (sim_step_fast + 2 x step_fast); backward = %.1f MB (algorithmic: 46.5 MB / 104.2 MB)\n\n' % (sha_of(fsrc), sha_of(bsrc), fwd / 1e6, fwd_steps / 1e6, bwd / 1e6))
     f.write('| kernel | waves | SQ_WAVE_CYCLES / SQ_WAVES | waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES) | vector-memory reads | fetched MB | written MB |\n|---|---|---|---|---|---|---|\n')
     for k in sorted(blocks):
         d = blocks[k]

@@ -225,7 +225,7 @@ def test_block_resident_meanfield_forward_equals_the_per_step_launches(B, N, spr
             outs[mode] = (out.detach(), zd.grad, yd.grad, cd.grad)
         finally:
             ops.state.mf_block = 'auto'
-    for a, b, what in zip(outs['off'], outs['on'], ('x_T', 'dz', 'dy', 'dc')):
+    for a, b, what in zip(outs['off'], outs['on'], ('x_T', 'dz', 'dy', 'dc')):       # ('on': the backward's edge pass in block form too)
         assert_close(b, a, 5e-6, 'block-resident mean field vs per-step launches: ' + what)
 
 
