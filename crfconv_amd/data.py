@@ -339,6 +339,15 @@ def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kern
     return MultiScaleData(x=x, y=y, point_idx=point_idx, cloud_idx=cloud_idx, multiscale=multiscale, order=order)
 
 
+_PRIVATE_GEN = []
+
+
+def _private_generator():
+    if not _PRIVATE_GEN:
+        _PRIVATE_GEN.append(torch.Generator().manual_seed(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF))
+    return _PRIVATE_GEN[0]
+
+
 class CollateGraph:
     """The per-batch preprocessing of a FIXED batch shape as ONE hipGraph replay: the device collate
     (``multiscale_compute``: Morton sort, kNN at every scale, subsets, up-indices) followed by ``target.load_`` (copies into
@@ -367,9 +376,12 @@ class CollateGraph:
         # sequences, and a run re-started from the same generator state reproduces them.  (Keyed on initial_seed() alone, every
         # graph built from a generator replayed the SAME subset sequence.)  `slot` separates graphs built from equal states.
         if generator is None:
-            # no caller's generator: a private one seeded from the process seed -- constructing a graph (a CollatePipeline builds one
-            # per slot) must not advance the GLOBAL default generator (later initialisation / dropout / randperm draws would shift)
-            generator = torch.Generator().manual_seed(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)
+            # no caller's generator: ONE private generator per process, seeded once from the process seed and drawn from by every
+            # graph built without a generator -- constructing a graph (a CollatePipeline builds one per slot) must not advance the
+            # GLOBAL default generator (later initialisation / dropout / randperm draws would shift), and graphs built one after
+            # the other (rebuilt per epoch, a second pipeline) must not replay the same subset sequence
+            generator = _private_generator()
+        self.generator = generator               # (device_draw=False draws its permutations from the same generator)
         drawn = int(torch.randint(0, 2 ** 62, (1,), generator=generator, dtype=torch.int64, device=generator.device).item())
         self.seed = (drawn + 0x632BE59BD9B4E019 * int(slot)) & 0xFFFFFFFFFFFFFFFF
         ms = target.multiscale

@@ -92,15 +92,22 @@ def gridsync_ws(dev):
 
 
 def fail_word_ptrs(dev):
-    """Device addresses of the sticky barrier-failure words of every barrier workspace of `dev` (at most 8: the kernel-side guard's
-    capacity; the capture buffer and the most recent streams' first)."""
+    """Device addresses of the sticky barrier-failure words of the barrier workspaces of `dev`, at most 8 (the kernel-side guard's
+    capacity): ALWAYS the buffer captured graphs use and the current stream's, then the other streams' newest first.  A process that has
+    used more than that many eager streams gets a warning -- the guard then does not see the oldest streams' words (check_gridsync
+    still does: it reads every workspace)."""
     want = torch.device(dev).index
     if want is None:
         want = torch.cuda.current_device()
     word = _lib.load().crfconv_gridsync_fail_word()
-    keys = [k for k in _sync_ws if k[0] == want]
-    keys.sort(key=lambda k: 0 if k[1] == 'capture' else 1)
-    return [_sync_ws[k].data_ptr() + 4 * word for k in keys[:8]]
+    keys = [k for k in _sync_ws if k[0] == want]            # dict order = creation order
+    first = [k for k in ((want, 'capture'), (want, int(torch.cuda.current_stream(want).cuda_stream))) if k in _sync_ws]
+    rest = [k for k in reversed(keys) if k not in first]
+    if len(first) + len(rest) > 8:
+        import warnings
+        warnings.warn('fail_word_ptrs: %d barrier workspaces on device %d, the update guard watches 8 (capture buffer, current stream, '
+                      'newest streams); ops.check_gridsync() reads all of them' % (len(first) + len(rest), want))
+    return [_sync_ws[k].data_ptr() + 4 * word for k in (first + rest)[:8]]
 
 
 def check_gridsync(dev=None, reduced_flag=None):

@@ -126,14 +126,23 @@ class GraphedModel(torch.nn.Module):
         self.fwd_graph = self.bwd_graph = None
         self.static = self.static_out = self.static_gout = None
         self.params, self.static_grads, self._sig = [], [], None
+        self._register_state_dict_hook(GraphedModel._strip_prefix_hook.__get__(self))
+        self._register_load_state_dict_pre_hook(self._add_prefix_hook)
 
-    # the wrapper is transparent for checkpoints and for the wrapped class's own attributes (Base.save / load, `.C`, ...):
-    # state_dict keys are the wrapped model's (reference checkpoints load with strict=True, as on the bare model)
-    def state_dict(self, *args, **kwargs):
-        return self.model.state_dict(*args, **kwargs)
+    # The wrapper is transparent for checkpoints: state_dict keys are the wrapped model's (reference checkpoints load with strict=True,
+    # as on the bare model) -- through the module's OWN hooks (the 'model.' prefix is stripped on the way out and put back on the way
+    # in), so that a GraphedModel that is a SUBMODULE of something else saves and loads symmetrically too (overriding state_dict /
+    # load_state_dict covered the top-level call only: a parent's load recursed past the override and expected 'net.model.<key>').
+    def _strip_prefix_hook(self, module, state_dict, prefix, local_metadata):
+        inner = prefix + 'model.'
+        for k in [k for k in state_dict if k.startswith(inner)]:
+            state_dict[prefix + k[len(inner):]] = state_dict.pop(k)
+        return state_dict
 
-    def load_state_dict(self, state_dict, *args, **kwargs):
-        return self.model.load_state_dict(state_dict, *args, **kwargs)
+    def _add_prefix_hook(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        inner = prefix + 'model.'
+        for k in [k for k in state_dict if k.startswith(prefix) and not k.startswith(inner)]:
+            state_dict[inner + k[len(prefix):]] = state_dict.pop(k)
 
     def __getattr__(self, name):
         try:

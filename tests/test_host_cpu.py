@@ -292,3 +292,31 @@ def test_dropout_mask_host_twin_is_a_keyed_bernoulli_stream():
         assert abs(c) < 1e-2, (lag, c)
     # a mask is a function of (seed, counter, element) only: a longer call starts with the shorter one
     assert np.array_equal(ops.dropout_keep_mask(99, 1, 1000, 0.5), ops.dropout_keep_mask(99, 1, 4000, 0.5)[:1000])
+
+
+def test_graphed_model_state_dict_is_symmetric_as_a_submodule():
+    """GraphedModel is transparent for checkpoints -- keys are the wrapped model's -- also when it is a submodule of another module:
+    the parent's state_dict() and load_state_dict(strict=True) must agree on the keys (overriding the two methods covered the
+    top-level call only)."""
+    import torch
+    from crfconv_amd.train import GraphedModel
+
+    class Inner(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin, self.bn = torch.nn.Linear(3, 2), torch.nn.BatchNorm1d(2)
+
+    class Outer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net, self.head = GraphedModel(Inner()), torch.nn.Linear(2, 2)
+
+    inner = Inner()
+    g = GraphedModel(inner)
+    assert list(g.state_dict().keys()) == list(inner.state_dict().keys())
+    g.load_state_dict(inner.state_dict(), strict=True)
+    a, b = Outer(), Outer()
+    sd = a.state_dict()
+    assert 'net.lin.weight' in sd and not any('.model.' in k for k in sd)
+    b.load_state_dict(sd, strict=True)
+    assert torch.equal(b.net.model.lin.weight, a.net.model.lin.weight) and torch.equal(b.net.model.bn.running_var, a.net.model.bn.running_var)
