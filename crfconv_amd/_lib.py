@@ -182,6 +182,8 @@ SIGNATURES = {
     'crfconv_kernel_weights_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp]),
     'crfconv_confusion_accumulate': (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp]),
     'crfconv_vote_accumulate': (_i, [_vp, _vp, _vp, _i64, _i, _d, _vp, _i64, _vp, _vp]),
+    'crfconv_vote_accumulate_counted': (_i, [_vp, _vp, _vp, _i64, _i, _d, _vp, _i64, _vp, _vp, _vp]),
+    'crfconv_vote_fold': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _d, _vp]),
     'crfconv_vote_project': (_i, [_vp, _vp, _i64, _i, _i64, _i, _vp, _vp, _vp]),
     'crfconv_argmin_workspace': (_sz, []),
     'crfconv_argmin_f64': (_i, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),

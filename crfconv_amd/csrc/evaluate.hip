@@ -64,11 +64,12 @@ __global__ __launch_bounds__(EV_BLOCK) void vote_kernel(const float* __restrict_
                                                         const float* __restrict__ logits,
                                                         const int64_t* __restrict__ point_idx, int64_t n_rows, int C,
                                                         float smooth, float one_minus, float* __restrict__ test_probs,
-                                                        int64_t n_cloud, int32_t* __restrict__ bad) {
+                                                        int64_t n_cloud, int32_t* __restrict__ bad, int32_t* __restrict__ visits) {
     const int64_t r = (int64_t)blockIdx.x * EV_BLOCK + threadIdx.x;
     if (r >= n_rows) return;
     const int64_t p = point_idx[r];
     if (p < 0 || p >= n_cloud) { atomicAdd(bad, 1); return; }
+    if (visits != nullptr) visits[p] += 1;               // (rows of one call are distinct points: no two threads share p)
     float* dst = test_probs + p * C;
     if (logits) {
         const float* row = logits + r * C;
@@ -248,9 +249,53 @@ extern "C" int crfconv_confusion_accumulate(const int64_t* y_true, const int64_t
     return CRF_OK;
 }
 
+static int vote_accumulate_impl(const float* probs, const float* logits, const int64_t* point_idx, int64_t n_rows, int C, double smooth,
+                                float* test_probs, int64_t n_cloud, int32_t* bad_count, int32_t* visits, crf_stream_t stream);
+
 extern "C" int crfconv_vote_accumulate(const float* probs, const float* logits, const int64_t* point_idx,
                                        int64_t n_rows, int C, double smooth, float* test_probs, int64_t n_cloud,
                                        int32_t* bad_count, crf_stream_t stream) {
+    return vote_accumulate_impl(probs, logits, point_idx, n_rows, C, smooth, test_probs, n_cloud, bad_count, nullptr, stream);
+}
+
+// The same, counting the updates of every point in visits [n_cloud] (int32): what crfconv_vote_fold needs to merge tables that
+// were accumulated apart (crops of one scene sharded over ranks).
+extern "C" int crfconv_vote_accumulate_counted(const float* probs, const float* logits, const int64_t* point_idx,
+                                               int64_t n_rows, int C, double smooth, float* test_probs, int64_t n_cloud,
+                                               int32_t* bad_count, int32_t* visits, crf_stream_t stream) {
+    CRF_REQUIRE(visits, CRF_ERR_ARG, "null pointer");
+    return vote_accumulate_impl(probs, logits, point_idx, n_rows, C, smooth, test_probs, n_cloud, bad_count, visits, stream);
+}
+
+// acc <- the table that results from applying `later`'s updates AFTER acc's:  a running mean v <- s v + (1 - s) p applied n times
+// scales what was there by s^n, so  acc[p] = acc[p] s^later_visits[p] + later[p]  (s^n by n rounded multiplications, as the
+// sequential updates round), acc_visits += later_visits.  Merging per-rank tables in rank order gives the table of ONE accumulator
+// that saw rank 0's crops first, then rank 1's, ... -- the reference's order-dependent update (trainval.py:188-189) in that order.
+__global__ __launch_bounds__(EV_BLOCK) void vote_fold_kernel(float* __restrict__ acc, int32_t* __restrict__ acc_visits,
+                                                             const float* __restrict__ later, const int32_t* __restrict__ later_visits,
+                                                             int64_t n, int C, float smooth) {
+    const int64_t p = (int64_t)blockIdx.x * EV_BLOCK + threadIdx.x;
+    if (p >= n) return;
+    const int nv = later_visits[p];
+    float d = 1.0f;
+    for (int i = 0; i < nv; ++i) d = mul_rn(d, smooth);
+    for (int c = 0; c < C; ++c) acc[p * C + c] = add_rn(mul_rn(acc[p * C + c], d), later[p * C + c]);
+    acc_visits[p] += nv;
+}
+
+extern "C" int crfconv_vote_fold(float* acc, int32_t* acc_visits, const float* later, const int32_t* later_visits, int64_t n, int C,
+                                 double smooth, crf_stream_t stream) {
+    CRF_REQUIRE(acc && acc_visits && later && later_visits, CRF_ERR_ARG, "null pointer");
+    CRF_REQUIRE(C >= 1 && n >= 0, CRF_ERR_ARG, "C=%d n=%lld invalid", C, (long long)n);
+    if (n == 0) return CRF_OK;
+    hipLaunchKernelGGL(vote_fold_kernel, dim3((unsigned)cdiv(n, EV_BLOCK)), dim3(EV_BLOCK), 0, as_stream(stream), acc, acc_visits, later,
+                       later_visits, n, C, (float)smooth);
+    CRF_LAUNCH_CHECK();
+    return CRF_OK;
+}
+
+static int vote_accumulate_impl(const float* probs, const float* logits, const int64_t* point_idx, int64_t n_rows, int C, double smooth,
+                                float* test_probs, int64_t n_cloud, int32_t* bad_count, int32_t* visits, crf_stream_t stream) {
     CRF_REQUIRE((probs || logits) && point_idx && test_probs && bad_count, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(C >= 1 && n_cloud > 0, CRF_ERR_ARG, "C=%d n_cloud=%lld invalid", C, (long long)n_cloud);
     if (n_rows <= 0) return CRF_OK;
@@ -258,7 +303,7 @@ extern "C" int crfconv_vote_accumulate(const float* probs, const float* logits, 
     // both coefficients are python floats (float64) that numpy rounds to float32 when they meet the float32 table
     const float one_minus = (float)(1.0 - smooth);
     hipLaunchKernelGGL(vote_kernel, dim3((unsigned)cdiv(n_rows, EV_BLOCK)), dim3(EV_BLOCK), 0, as_stream(stream), probs,
-                       logits, point_idx, n_rows, C, (float)smooth, one_minus, test_probs, n_cloud, bad_count);
+                       logits, point_idx, n_rows, C, (float)smooth, one_minus, test_probs, n_cloud, bad_count, visits);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

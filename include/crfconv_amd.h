@@ -846,6 +846,16 @@ int crfconv_confusion_accumulate(const int64_t* y_true, const int64_t* y_pred, c
  * point_idx int64 [n_rows], distinct within one call; entries outside [0, n_cloud) are skipped and counted. */
 int crfconv_vote_accumulate(const float* probs, const float* logits, const int64_t* point_idx, int64_t n_rows, int C,
                             double smooth, float* test_probs, int64_t n_cloud, int32_t* bad_count, crf_stream_t stream);
+/* The same, counting the updates of every point in visits [n_cloud] (int32, the caller's zeros at the start), and the merge of two tables
+ * accumulated apart:  acc <- what ONE accumulator holds that applied acc's updates first and `later`'s after them (a running mean
+ * v <- s v + (1 - s) p applied n times scales what was there by s^n:  acc[p] = acc[p] s^later_visits[p] + later[p];  acc_visits +=
+ * later_visits).  crfconv_amd.sampling.VoteAccumulator.merge() folds the ranks' tables in rank order after an all-gather: crops of one
+ * scene sharded over GPUs give the votes of a single GPU that saw rank 0's crops first, then rank 1's (trainval.py:188-189 is
+ * order-dependent; this fixes the order). */
+int crfconv_vote_accumulate_counted(const float* probs, const float* logits, const int64_t* point_idx, int64_t n_rows, int C, double smooth,
+                                    float* test_probs, int64_t n_cloud, int32_t* bad_count, int32_t* visits, crf_stream_t stream);
+int crfconv_vote_fold(float* acc, int32_t* acc_visits, const float* later, const int32_t* later_visits, int64_t n, int C, double smooth,
+                      crf_stream_t stream);
 
 /* Re-projection, trainval.py:200-203: preds[i] = uint8(first arg-max of test_probs[proj_idx[i]]) + label_offset. */
 int crfconv_vote_project(const float* test_probs, const int64_t* proj_idx, int64_t n_proj, int C, int64_t n_cloud,
