@@ -598,7 +598,108 @@ def other_configs(dev, rank=0):
     t = replay_time(step)
     out['C4 ScanNet-like batch (per-GPU share), training step'] = {'points': B * N, 'K': K, 'T': T, 'ms': t * 1e3, 'M_points_per_s': B * N / t / 1e6,
                                                                       'roofline_meanfield_layer': _layer_summary(roofline_layer(data, dev, T))}
+    del net, data, bucket, opt
+    out['pipelines'] = config_pipelines(dev)
     return out
+
+
+def config_pipelines(dev):
+    """Config 5 and config 3 as the PIPELINES north_star names them, eagerly as a user would call them:
+    C5: one 1 048 576-point scene (60 x 60 x 15 m) -> PossibilitySampler (16 crops of 65 536 points) -> multiscale_compute(K = 32) ->
+        PointConvBig(T = 5) eval -> VoteAccumulator.update -> project onto a 2 M-point raw cloud (trainval.py:170-203,
+        datasets/semantic3d_dataset.py:423-460): whole-pipeline scene points/s and per-stage milliseconds;
+    C3: one 122 880-point scan: multiscale_compute(K = 16) + PointConvBig(T = 1) eval."""
+    import crfconv_amd
+    from crfconv_amd import models
+    from crfconv_amd.sampling import PossibilitySampler, VoteAccumulator, vote_scene
+    from crfconv_amd.utils import nearest_neighbors
+    out = {}
+    g = torch.Generator().manual_seed(50)
+    n_scene, n_crop, n_crops, K, T, C = 1 << 20, 65536, 16, 32, 5, 8
+    pts = (torch.rand(n_scene, 3, generator=g) * torch.tensor([60.0, 60.0, 15.0])).to(dev)
+    rgb = torch.rand(n_scene, 3, generator=g).to(dev)
+    raw = (torch.rand(2 * n_scene, 3, generator=g) * torch.tensor([60.0, 60.0, 15.0])).to(dev)
+    net = models.PointConvBig(6, C, use_crf=True, steps=T).to(dev).eval()
+
+    def run(timings):
+        smp = PossibilitySampler([pts], rgb=[rgb], num_points=n_crop, split='test', generator=torch.Generator().manual_seed(51))
+        votes = VoteAccumulator([n_scene], C, device=dev)
+        vote_scene(smp, net, votes, n_crops, kernel_size=(K,) * 5, generator=torch.Generator().manual_seed(52), timings=timings)
+        return votes
+    run(None)                                              # warm-up (allocator, lazily built tables, kernel modules)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    votes = run(None)
+    torch.cuda.synchronize()
+    t_loop = time.perf_counter() - t0
+    stages = {}
+    run(stages)                                            # the same again with a device synchronisation around every stage
+    t0 = time.perf_counter()
+    proj = nearest_neighbors.knn_batch_device(pts.unsqueeze(0), raw.unsqueeze(0), 1).reshape(-1)      # offline in the reference (sklearn KDTree.query)
+    torch.cuda.synchronize()
+    t_proj_idx = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    labels = votes.project(0, proj)
+    torch.cuda.synchronize()
+    t_project = time.perf_counter() - t0
+    votes.check()
+    covered = float((votes.test_probs[0].sum(1) > 0).float().mean())
+    out['C5 Semantic3D-like scene, tiled inference'] = {
+        'scene_points': n_scene, 'crops': n_crops, 'crop_points': n_crop, 'K': K, 'T': T, 'classes': C,
+        'loop_ms': t_loop * 1e3, 'ms_per_crop': t_loop * 1e3 / n_crops, 'crop_points_per_s_M': n_crops * n_crop / t_loop / 1e6,
+        'scene_points_per_s_M': n_scene / (t_loop + t_project) / 1e6,
+        'stage_ms_per_crop_synchronised': {k: v / n_crops for k, v in stages.items()},
+        'project_ms': t_project * 1e3, 'raw_points_projected': int(raw.shape[0]), 'projection_index_ms_offline': t_proj_idx * 1e3,
+        'scene_fraction_voted': covered, 'labels_histogram': torch.bincount(labels.long(), minlength=C + 1).tolist(),
+        'what': 'sampler -> multiscale_compute(K=32) -> PointConvBig(T=5).eval() -> votes for 16 crops (eager, B = 1 per crop as the sampler yields '
+                'them), then the arg-max re-projection onto a raw cloud; loop_ms is wall time without per-stage synchronisation, the stage '
+                'figures come from a second run that synchronises around every stage; scene_points_per_s = scene points / (loop + projection)'}
+    del net, votes
+    # C3: one scan, collate + network
+    N3, C3 = 122880, 19
+    cl = synth_cloud(310, N3)
+    pos3 = torch.from_numpy(cl[0]).to(dev).unsqueeze(0)
+    x3 = torch.cat([pos3, torch.from_numpy(cl[1]).to(dev).unsqueeze(0)], -1)
+    net3 = models.PointConvBig(6, C3, use_crf=True, steps=1).to(dev).eval()
+
+    def scan():
+        d = crfconv_amd.multiscale_compute(pos3, x=x3, kernel_size=(16,) * 5, generator=torch.Generator().manual_seed(5), sort='morton')
+        with torch.no_grad():
+            return net3(d)
+    for _ in range(3):
+        scan()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        scan()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    t3 = float(np.median(ts))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        d3 = crfconv_amd.multiscale_compute(pos3, x=x3, kernel_size=(16,) * 5, generator=torch.Generator().manual_seed(5), sort='morton')
+    torch.cuda.synchronize()
+    t_col = (time.perf_counter() - t0) / 5
+    out['C3 KITTI-like scan, collate + inference'] = {'points': N3, 'K': 16, 'T': 1, 'ms': t3 * 1e3, 'M_points_per_s': N3 / t3 / 1e6,
+                                                       'collate_ms': t_col * 1e3,
+                                                       'what': 'eager multiscale_compute (Morton sort, kNN at five scales, subsets, up-indices) + PointConvBig(T=1).eval() '
+                                                               'forward per scan, wall clock, median of 10'}
+    return out
+
+
+def _parity_report():
+    """ABSOLUTE logit error per BASELINE config (north_star: per-point logits within 1e-4 fp32): written by the -m gpu suite
+    (tests/test_gpu_model.py::_eval_net_vs_oracle under CRFCONV_PARITY_RECORD, whole PointConvBig in eval mode at each config's full
+    size against the float64 run of the CPU oracle) and committed as tests/golden/parity_report.json -- max |logit - oracle|, the same
+    normalised by max(1, max |logit|), rows beyond 1e-4 absolute, and the float32 ORACLE's own distance from float64 beside them."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'parity_report.json')))
+    except (OSError, ValueError) as e:
+        return {'error': 'tests/golden/parity_report.json: %s' % type(e).__name__}
+    rec['source'] = 'tests/golden/parity_report.json (recorded by `CRFCONV_PARITY_RECORD=... pytest tests -m gpu` on an MI355X; the tests assert these bounds in every run)'
+    return rec
 
 
 def _layer_summary(r):
@@ -667,7 +768,73 @@ def reference_loop(net, data, cw, steps):
     torch.cuda.synchronize()
     out['graphed_module_ms_per_step'] = (time.perf_counter() - t0) / steps * 1e3
     out['graphed_module_final_loss'] = float(loss)
+    # (d) the loop the reference actually runs: `for data in train_loader:` (trainval.py:96) hands over a NEW collated batch every
+    # step.  Here the collate is crfconv_amd.multiscale_compute on the device (the reference's runs in the DataLoader on the host,
+    # datasets/semantic3d_dataset.py:501-534).  Four different raw batches take turns.
+    import crfconv_amd
+    from crfconv_amd.data import CollateGraph
+    B, N = data.x.shape[:2]
+    pool = []
+    for r in range(4):
+        clouds = [synth_cloud(9000 + 10 * r + i, N) for i in range(B)]
+        pos_r = torch.from_numpy(np.stack([c[0] for c in clouds])).to(data.x.device)
+        pool.append((pos_r, torch.cat([pos_r, torch.from_numpy(np.stack([c[1] for c in clouds])).to(pos_r.device)], -1),
+                     torch.from_numpy(np.stack([c[2] for c in clouds])).to(pos_r.device)))
+    gen = torch.Generator().manual_seed(4242)
+
+    def one_on(d):
+        opt.zero_grad()
+        loss = loss_fn(net(d), d)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    def timed(body, n):
+        for i in range(3):
+            body(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            loss = body(3 + i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, float(loss)
+    # (d1) GraphedModel: the next batch's collate as a graph on a side stream while this step trains, its load into the captured batch as a
+    # second graph between two steps (CollateGraph.collate / .load)
+    cg = CollateGraph(net.static, generator=gen)
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    staged, loaded = torch.cuda.Event(), torch.cuda.Event()
+    cg.collate(*pool[0])                      # captures both graphs, stages batch 0
+    staged.record()
+
+    def graphed_fresh(i):
+        main.wait_event(staged)
+        cg.load()                             # captured batch <- staged batch (copy + in-place table refresh: one replay)
+        loaded.record()
+        side.wait_event(loaded)
+        with torch.cuda.stream(side):
+            cg.collate(*pool[(i + 1) % 4])    # kNN etc. of the NEXT batch beside this step
+            staged.record()
+        return one_on(net.static)
+    out['fresh_graphed_ms_per_step'], out['fresh_graphed_final_loss'] = timed(graphed_fresh, steps)
+    torch.cuda.synchronize()
+    # (d2) the same, everything on one stream (collate graph, then the step)
+    cg1 = CollateGraph(net.static, generator=gen)
+
+    def graphed_fresh_serial(i):
+        cg1.run(*pool[i % 4])
+        return one_on(net.static)
+    out['fresh_graphed_one_stream_ms_per_step'], _ = timed(graphed_fresh_serial, steps)
     net = bare
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2, momentum=0.95, weight_decay=1e-4)
+    # (d3) nothing wrapped, nothing captured: eager collate + the five lines on the bare model
+    def eager_fresh(i):
+        pos_r, x_r, y_r = pool[i % 4]
+        return one_on(crfconv_amd.multiscale_compute(pos_r, x=x_r, y=y_r, generator=gen, sort='morton'))
+    out['fresh_eager_ms_per_step'], out['fresh_eager_final_loss'] = timed(eager_fresh, steps)
+    out['fresh_what'] = ('a NEW batch every step (4 x 40 960-point clouds, device collate = the reference\'s _multiscale_compute_fn): fresh_eager = '
+                         'crfconv_amd.multiscale_compute + the unchanged five lines on the bare model; fresh_graphed = train.GraphedModel + '
+                         'data.CollateGraph.collate (side stream, beside the step) / .load (between steps); ..._one_stream = CollateGraph.run then the step')
     return out
 
 
@@ -879,14 +1046,34 @@ def main():
         torch.cuda.synchronize()
         return d, time.perf_counter() - t0
 
-    t_collate, t_load = [], []
-    for rep in range(3):
+    # MultiScaleData.load_ of a fresh batch into the static buffers: device time by HIP events, host time of the call, and the wall time
+    # per batch of a loop that loads batch after batch with ONE synchronisation at its end (what a training loop pays: it does not
+    # synchronise per batch; load_(defer_check=True) makes no host synchronisation of its own).  A synchronising call right behind a
+    # single load_ is reported too: on this stack a device synchronisation behind a short burst of work returns after 10 or 20 ms
+    # (timer-tick granularity of the blocking wait) -- that, not the refresh, was round 5's "22 ms per fresh batch".
+    fresh_pool, t_collate = [], []
+    for rep in range(4):
         nd, tc = new_batch(5000 + 100 * rep)
-        t0 = time.perf_counter()
-        data.load_(nd)
-        torch.cuda.synchronize()
+        fresh_pool.append(nd)
         t_collate.append(tc)
-        t_load.append(time.perf_counter() - t0)
+    t_load_host, t_load_dev, t_load_sync = [], [], []
+    for rep in range(8):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        data.load_(fresh_pool[rep % 4], defer_check=True)
+        e1.record()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t_load_sync.append(time.perf_counter() - t0)
+        t_load_host.append(t1 - t0)
+        t_load_dev.append(e0.elapsed_time(e1) * 1e-3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for rep in range(16):
+        data.load_(fresh_pool[rep % 4], defer_check=True)
+    torch.cuda.synchronize()
+    t_load = [(time.perf_counter() - t0) / 16]
     # the same per-batch work as ONE hipGraph replay (data.CollateGraph: collate + in-place refresh of the static batch)
     from crfconv_amd.data import CollateGraph
     t_graph, cg_parts = None, None
@@ -923,7 +1110,8 @@ def main():
         import traceback
         traceback.print_exc()
         torch.cuda.synchronize()
-    data.load_(nd)                                        # back to the batch of seed 5200 for the comparison below
+    nd, _ = new_batch(5200)
+    data.load_(nd)                                        # the batch of seed 5200 for the comparison below
     torch.cuda.synchronize()
     buffers = {k: v.clone() for k, v in net.named_buffers()}
     flat0, mom0 = opt.flat.clone(), opt.buf.clone()
@@ -956,7 +1144,9 @@ def main():
              'loss_eager_same_weights': loss_eager,
              'max_param_diff_after_step': float((opt.flat - flat_graph).abs().max()),
              'collate_ms_per_batch': float(np.median(t_collate)) * 1e3,
-             'table_refresh_ms_per_batch': float(np.median(t_load)) * 1e3,
+             'table_refresh_ms_per_batch': float(np.median(t_load)) * 1e3, 'table_refresh_host_ms_per_batch': float(np.median(t_load_host)) * 1e3,
+             'table_refresh_device_ms_per_batch': float(np.median(t_load_dev)) * 1e3,
+             'table_refresh_plus_device_synchronize_ms': [round(v * 1e3, 2) for v in t_load_sync],
              'note': 'fresh batch -> MultiScaleData.load_ into the static buffers -> hipGraph replay, against an eager step '
                      'from the same weights and BatchNorm counters on an independent collate of the same clouds; the classifier\'s dropout mask '
                      'is keyed on (seed, step counter, element), so both runs draw the same mask and the losses agree; the refreshed '
@@ -1104,6 +1294,7 @@ def main():
             'trainval_graphed_module_ms_per_step': None if ref_loop is None else ref_loop.get('graphed_module_ms_per_step'),
             'trainval_captured_as_written_ms_per_step': None if ref_loop is None else ref_loop.get('captured_as_written_ms_per_step'),
             'reference_loop': ref_loop,
+            'parity': _parity_report(),
         }
         out['roofline'] = roofline_meanfield(data, dev, 8, T)
         out['roofline']['measured_copy_GBps'] = copy_ceiling(dev)

@@ -423,7 +423,7 @@ class CollateGraph:
             self._uploaded = torch.cuda.Event()
         self._uploaded.record()
 
-    def _work(self):
+    def _work_collate(self):
         if self.gate is not None:
             from . import _lib
             from .graph import ptr, stream_ptr
@@ -434,12 +434,14 @@ class CollateGraph:
             _lib.call('crfconv_add_i64', ptr(self.counter), 1, 1, stream_ptr())       # counter += 1 (a library launch: no framework kernel in the graph)
             random_subsets_device(self.sizes, [c.numel() for c in self.choices], self.seed, self.counter, self.choices, ranks=self.ranks)
             morton_order(self.pos, out=self.order)
-        new = multiscale_compute(self.pos, x=self.x, y=self.y, kernel_size=self.kernel_size, ratio=self.ratio,
-                                 num_scales=len(self.sizes), choices=self.choices, sort='morton', order=self.order,
-                                 ranks=self.ranks if self.device_draw else None)
-        self.target.load_(new)
+        return multiscale_compute(self.pos, x=self.x, y=self.y, kernel_size=self.kernel_size, ratio=self.ratio,
+                                  num_scales=len(self.sizes), choices=self.choices, sort='morton', order=self.order,
+                                  ranks=self.ranks if self.device_draw else None)
 
-    def run(self, pos, x=None, y=None):
+    def _work(self):
+        self.target.load_(self._work_collate())
+
+    def _inputs(self, pos, x, y):
         self.pos.copy_(pos)
         if self.x is not None:
             self.x.copy_(x)
@@ -448,6 +450,9 @@ class CollateGraph:
         if not self.device_draw:
             self._draw()                          # host torch.randperm + pinned upload; the argsort eagerly in front of the graph
             morton_order(self.pos, out=self.order)
+
+    def run(self, pos, x=None, y=None):
+        self._inputs(pos, x, y)
         if self.graph is None:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -461,6 +466,35 @@ class CollateGraph:
             with torch.cuda.graph(self.graph):
                 self._work()
         self.graph.replay()
+        return self.target
+
+    # ---- the same work as TWO graphs, for a loop that trains on `target` itself (train.GraphedModel's static batch): the collate of the
+    # NEXT batch (collate(): kNN etc. into this object's own staging tensors) may run on a side stream while the step of the current batch
+    # still reads `target`; load() -- the copy into `target` and the in-place refresh of its tables, a fraction of the work -- then runs
+    # on the training stream between two steps.  collate() of batch i + 2 must wait for load() of batch i + 1 (it overwrites the staging).
+    def collate(self, pos, x=None, y=None):
+        self._inputs(pos, x, y)
+        if getattr(self, 'graph_collate', None) is None:
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                count = self.counter.clone()
+                self.target.load_(self._work_collate())       # warm-up of BOTH halves outside the captures
+                self.counter.copy_(count)
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph_collate = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_collate):
+                self._staged = self._work_collate()
+            self.graph_load = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_load, pool=self.graph_collate.pool()):
+                self.target.load_(self._staged)
+        self.graph_collate.replay()
+
+    def load(self):
+        """target <- the batch collate() staged last (one replay on the current stream)."""
+        self.graph_load.replay()
         return self.target
 
 

@@ -66,8 +66,25 @@ class NeighborTable:
         self.padded = False      # True: entries < 0 mean "no neighbour" (table_from_edges) -> generic kernels only
         self.n_edges = self.B * self.n_tgt * self.K
         self.cache = {}          # per-table memo (e.g. rel-pos moments shared by two ResNet blocks)
-        if check:
+        if check == 'defer':
+            self._validate_later()
+        elif check:
             self.validate()
+
+    def _validate_later(self):
+        """The range check WITHOUT a host synchronisation: the bad-entry count travels to pinned memory behind the launch and
+        ``check_pending()`` -- polled by the next table that is built or refreshed, callable by the user (``wait=True``) -- raises once
+        it has arrived.  What ``table_of`` uses for the tables a model builds inside its forward: a synchronising ``.item()`` per table
+        (thirteen per fresh batch) waits for everything queued before it and turns an asynchronous eager step into a synchronous one.
+        Out-of-range entries were clamped by the narrowing kernel, so nothing can fault in the meantime; only the error comes later."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        check_pending()
+        host = _pinned_slot()
+        host.copy_(self._bad, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _PENDING_CHECKS.append((ev, host, [self]))
 
     def refresh_(self, idx64, check=True):
         """New index values of the SAME shape into the SAME device buffers (narrowed table, and the reverse CSR and
@@ -146,6 +163,17 @@ class NeighborTable:
 
 _BATCH = {'on': False, 'jobs': [], 'narrow': [], 'moments': [], 'defer_check': False}
 _PENDING_CHECKS = []          # (event, pinned counts, tables): validations whose device -> host copy is still in flight
+_PINNED = {'ring': None, 'next': 0}
+
+
+def _pinned_slot():
+    """One int32 of pinned host memory out of a ring of 1024 (allocated once: a pinned allocation per table would cost more than the
+    synchronisation it replaces; a slot is reused long after its check has been read)."""
+    if _PINNED['ring'] is None:
+        _PINNED['ring'] = torch.zeros(1024, dtype=torch.int32).pin_memory()
+    i = _PINNED['next']
+    _PINNED['next'] = (i + 1) % 1024
+    return _PINNED['ring'][i:i + 1]
 
 
 def check_pending(wait=False):
@@ -302,7 +330,7 @@ def table_of(idx, n_src):
     key = (int(n_src), idx.data_ptr(), tuple(idx.shape))
     hit = cache.get(key)
     if hit is None:
-        tab = NeighborTable(idx, n_src)
+        tab = NeighborTable(idx, n_src, check='defer')       # (the range check without a host synchronisation: NeighborTable._validate_later)
         cache.clear()
         cache[key] = [tab, idx._version]
         return tab

@@ -111,10 +111,13 @@ class VoteAccumulator:
     """``test_probs`` of trainval.py:58 (one float32 [n_c, n_classes] table per cloud, zeros) with the update of
     :186-189 and the projection of :198-203."""
 
-    def __init__(self, cloud_sizes, num_classes, smooth=0.98, device='cuda'):
+    def __init__(self, cloud_sizes, num_classes, smooth=0.98, device='cuda', track_visits=False):
+        """track_visits: count the updates of every point (int32 tables beside the votes) -- what ``merge`` needs when the crops of a
+        scene are spread over several accumulators (ranks)."""
         self.num_classes = int(num_classes)
         self.smooth = float(smooth)
         self.test_probs = [torch.zeros((int(n), self.num_classes), dtype=torch.float32, device=device) for n in cloud_sizes]
+        self.visits = [torch.zeros(int(n), dtype=torch.int32, device=device) for n in cloud_sizes] if track_visits else None
         self._bad = torch.zeros(1, dtype=torch.int32, device=device)
 
     def update(self, point_idx, cloud_idx, probs=None, logits=None):
@@ -128,9 +131,52 @@ class VoteAccumulator:
         clouds = cloud_idx.reshape(B, -1)[:, 0].tolist()
         for b in range(B):
             tp = self.test_probs[int(clouds[b])]
-            _lib.call('crfconv_vote_accumulate', ptr(src[b]) if probs is not None else None,
-                      ptr(src[b]) if probs is None else None, ptr(point_idx[b]), N, self.num_classes, self.smooth,
-                      ptr(tp), tp.shape[0], ptr(self._bad), stream_ptr())
+            if self.visits is None:
+                _lib.call('crfconv_vote_accumulate', ptr(src[b]) if probs is not None else None,
+                          ptr(src[b]) if probs is None else None, ptr(point_idx[b]), N, self.num_classes, self.smooth,
+                          ptr(tp), tp.shape[0], ptr(self._bad), stream_ptr())
+            else:
+                _lib.call('crfconv_vote_accumulate_counted', ptr(src[b]) if probs is not None else None,
+                          ptr(src[b]) if probs is None else None, ptr(point_idx[b]), N, self.num_classes, self.smooth,
+                          ptr(tp), tp.shape[0], ptr(self._bad), ptr(self.visits[int(clouds[b])]), stream_ptr())
+
+    def fold_(self, later_probs, later_visits):
+        """self <- the tables ONE accumulator would hold that applied self's updates first and then those behind `later_probs` /
+        `later_visits` (lists like self.test_probs / self.visits): trainval.py:188-189 is a running mean v <- s v + (1 - s) p, and
+        n later updates of a point scale what was there by s^n (csrc/evaluate.hip: vote_fold_kernel)."""
+        if self.visits is None:
+            raise _lib.CrfConvError('VoteAccumulator.fold_ needs track_visits=True on both sides')
+        for tp, vi, lp, lv in zip(self.test_probs, self.visits, later_probs, later_visits):
+            lp = lp.to(tp.device, torch.float32).contiguous()
+            lv = lv.to(tp.device, torch.int32).contiguous()
+            if lp.shape != tp.shape or lv.shape != vi.shape:
+                raise ValueError('fold_: tables of %s / %s against %s / %s' % (tuple(lp.shape), tuple(lv.shape), tuple(tp.shape), tuple(vi.shape)))
+            _lib.call('crfconv_vote_fold', ptr(tp), ptr(vi), ptr(lp), ptr(lv), tp.shape[0], self.num_classes, self.smooth, stream_ptr())
+
+    def merge(self, group=None):
+        """Crops of one scene sharded over the ranks of a process group (each rank voted its own crops into its own tables): every rank
+        leaves with the SAME merged tables -- those of a single accumulator that saw rank 0's crops first, then rank 1's, ... (the
+        reference's update is order-dependent; sharding only fixes this order, it does not change the rule).  One all-gather of the
+        tables and the visit counts per cloud, folded in rank order.  No-op without a process group."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return self
+        if self.visits is None:
+            raise _lib.CrfConvError('VoteAccumulator.merge needs track_visits=True')
+        world = dist.get_world_size(group)
+        on_host = dist.get_backend(group) == 'gloo'            # (gloo moves host tensors; RCCL device tensors)
+        for c, (tp, vi) in enumerate(zip(self.test_probs, self.visits)):
+            send_p, send_v = (tp.cpu(), vi.cpu()) if on_host else (tp, vi)
+            all_p = [torch.empty_like(send_p) for _ in range(world)]
+            all_v = [torch.empty_like(send_v) for _ in range(world)]
+            dist.all_gather(all_p, send_p, group=group)
+            dist.all_gather(all_v, send_v, group=group)
+            tp.copy_(all_p[0])
+            vi.copy_(all_v[0])
+            for r in range(1, world):
+                _lib.call('crfconv_vote_fold', ptr(tp), ptr(vi), ptr(all_p[r].to(tp.device).contiguous()),
+                          ptr(all_v[r].to(tp.device).contiguous()), tp.shape[0], self.num_classes, self.smooth, stream_ptr())
+        return self
 
     def project(self, cloud, proj_idx, label_offset=1):
         """uint8 labels of the original points: arg-max of the votes of their nearest sub-sampled point, + 1 because
@@ -147,3 +193,48 @@ class VoteAccumulator:
         bad = int(self._bad.item())
         if bad:
             raise IndexError('%d point indices outside their cloud' % bad)
+
+
+def vote_scene(sampler, net, votes, n_crops, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), rank=0, world=1, generator=None,
+               timings=None):
+    """The inference loop of trainval.py:170-189 on the device for ``n_crops`` crops of the sampler's clouds: crop (possibility
+    sampler) -> ``multiscale_compute`` (kNN at every scale) -> ``net`` (eval, no grad) -> soft-max votes into ``votes``.  One crop per
+    batch (B = 1: datasets/semantic3d_dataset.py:453-458 yields single crops; the loader's batch dimension only stacks them).
+    Features = [xyz, rgb] as the reference's collate builds them (datasets/semantic3d_dataset.py:507-510).
+
+    world > 1: EVERY rank draws the whole crop sequence (the sampler is cheap and its possibilities must evolve as on one GPU), crop i is
+    run through the network by rank i % world only; ``votes.merge()`` afterwards gives every rank the full tables.
+    timings: a dict that receives the summed milliseconds per stage (host clock around device-synchronised stages: a diagnostic mode --
+    it serialises host and device)."""
+    import time
+    from .data import multiscale_compute
+    dev = sampler.device
+
+    def stage(name, fn):
+        if timings is None:
+            return fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        timings[name] = timings.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+        return out
+    was_training = net.training
+    net.eval()
+    try:
+        for i in range(n_crops):
+            crop = stage('sample', sampler.get_random)
+            if i % world != rank:
+                continue
+            pos = crop.pos.unsqueeze(0)
+            rgb = crop.rgb if crop.rgb is not None else torch.zeros_like(crop.pos)
+            x = torch.cat([crop.pos, rgb], -1).unsqueeze(0)
+            data = stage('collate', lambda: multiscale_compute(pos, x=x, point_idx=crop.point_idx.unsqueeze(0), cloud_idx=crop.cloud_idx.reshape(1, 1),
+                                                               kernel_size=kernel_size, ratio=ratio, generator=generator, sort='morton'))
+            with torch.no_grad():
+                logits = stage('network', lambda: net(data))
+            # the collate reordered the crop along its Morton curve: point_idx travelled with it (multiscale_compute permutes x, y, point_idx alike)
+            stage('vote', lambda: votes.update(data.point_idx, data.cloud_idx, logits=logits))
+    finally:
+        net.train(was_training)
+    return votes

@@ -319,3 +319,62 @@ def test_an_eager_update_sees_the_failure_word_of_the_captured_graph_buffer():
         assert not torch.equal(opt.flat, p0)
     finally:
         ops.state.small_mlp_disabled = was
+
+
+VOTE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests', 'golden'))
+import numpy as np, torch
+import _seeded as S
+import crfconv_amd
+from crfconv_amd import distributed as D, models
+from crfconv_amd.sampling import PossibilitySampler, VoteAccumulator, vote_scene
+rank, world, local = D.init_from_env()
+dev = torch.device('cuda', local)
+torch.cuda.set_device(dev)
+n, crop, n_crops, C = 24000, 6000, 6, 8
+rng = np.random.default_rng(11)
+pts = (rng.random((n, 3)) * np.array([4.0, 4.0, 2.0])).astype(np.float32)
+rgb = rng.random((n, 3)).astype(np.float32)
+poss0 = np.random.default_rng(5).standard_normal(n) * 1e-3
+net = models.PointConvBig(6, C, use_crf=True, steps=3)
+net.load_state_dict(S.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 9))
+net = net.to(dev).eval()
+def run(r, w):
+    smp = PossibilitySampler([torch.from_numpy(pts).to(dev)], rgb=[torch.from_numpy(rgb).to(dev)], num_points=crop, split='test',
+                             generator=torch.Generator().manual_seed(77), possibility=[poss0])
+    votes = VoteAccumulator([n], C, device=dev, track_visits=True)
+    vote_scene(smp, net, votes, n_crops, rank=r, world=w, generator=torch.Generator().manual_seed(3))
+    return smp, votes
+smp, votes = run(rank, world)                  # this rank's crops only (every rank draws the whole crop sequence)
+votes.merge()                                  # all-gather + fold in rank order
+# what ONE accumulator holds that ran rank 0's crops first, then rank 1's: folded locally from the two single-rank runs
+parts = [run(r, world) for r in range(world)]
+one = parts[0][1]
+for r in range(1, world):
+    one.fold_(parts[r][1].test_probs, parts[r][1].visits)
+torch.cuda.synchronize()
+torch.save({'merged': votes.test_probs[0].cpu(), 'visits': votes.visits[0].cpu(), 'one': one.test_probs[0].cpu(), 'one_visits': one.visits[0].cpu(),
+            'poss': smp.possibility[0].cpu(), 'poss_full': parts[0][0].possibility[0].cpu()}, os.environ['OUT'] + '.%%d' %% rank)
+D.dist.barrier()
+D.dist.destroy_process_group()
+'''
+
+
+def test_scene_crops_sharded_over_two_ranks_merge_to_one_vote_table(tmp_path):
+    """Config 5's sharding (crops of one scene over the ranks; SURVEY 8(e): inference needs no collective UNTIL the votes are read):
+    `vote_scene(rank, world)` + `VoteAccumulator.merge()` on two gloo ranks sharing the GPU.  Both ranks end with the same table, equal
+    to one accumulator that applied rank 0's crops first, then rank 1's; the sampler's possibilities evolve as on one GPU on every rank."""
+    script = tmp_path / 'vote_worker.py'
+    script.write_text(VOTE_WORKER % (ROOT, ROOT))
+    env = dict(os.environ, OUT=str(tmp_path / 'v'), MASTER_ADDR='127.0.0.1', MASTER_PORT='29547', WORLD_SIZE='2',
+               CRFCONV_DIST_BACKEND='gloo', OMP_NUM_THREADS='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r0, r1 = (torch.load(str(tmp_path / ('v.%d' % r))) for r in range(2))
+    assert torch.equal(r0['merged'], r1['merged']) and torch.equal(r0['visits'], r1['visits'])
+    assert torch.equal(r0['visits'], r0['one_visits']) and int(r0['visits'].sum()) == 6 * 6000
+    assert torch.equal(r0['merged'], r0['one'])              # the same fold kernel on the same operands: bit for bit
+    assert torch.equal(r0['poss'], r1['poss']) and torch.equal(r0['poss'], r0['poss_full'])
+    assert float(r0['merged'].abs().max()) > 0

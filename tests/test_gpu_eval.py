@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+import _seeded as S
 from gpu_util import DEV, t
 from oracle import eval_oracle as E
 
@@ -141,3 +142,98 @@ def test_running_score_shapenet_golden(golden):
     assert np.isnan(mp) and np.isnan(float(g['mpIoU']))
     assert np.allclose([cls[k] for k in sorted(cls)], g['cls'], rtol=1e-6, equal_nan=True)
     assert list(sorted(cls)) == list(g['cls_names'])
+
+
+def _scene(n, seed):
+    rng = np.random.default_rng(seed)
+    pts = (rng.random((n, 3)) * np.array([6.0, 6.0, 2.0])).astype(np.float32)
+    rgb = rng.random((n, 3)).astype(np.float32)
+    return pts, rgb
+
+
+def test_tiled_scene_pipeline_against_the_oracle_chain():
+    """Config 5 / 3 as a PIPELINE on a small scene: possibility sampler -> multiscale_compute -> PointConvBig (eval) ->
+    soft-max votes -> re-projection (trainval.py:170-203, datasets/semantic3d_dataset.py:423-460), `sampling.vote_scene` against the
+    oracle chain on the SAME draws: oracle/eval_oracle.py possibility_draw (crop membership and possibilities bit-exact), oracle/crf_oracle.py
+    network on the device collate's tables (kNN parity is test_gpu_native's), vote_update / vote_project.  Vote tables within 1e-5, final
+    per-point labels equal wherever the two best votes are not a near-tie."""
+    from crfconv_amd import models
+    from crfconv_amd.data import multiscale_compute
+    from crfconv_amd.sampling import PossibilitySampler, VoteAccumulator, vote_scene
+    from oracle import crf_oracle as O
+    n, crop, n_crops, C, K, T = 24000, 6000, 4, 8, 16, 3
+    pts, rgb = _scene(n, 11)
+    net = models.PointConvBig(6, C, use_crf=True, steps=T)
+    sd = S.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 9)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    poss0 = (np.random.default_rng(5).standard_normal(n) * 1e-3)
+    smp = PossibilitySampler([t(pts)], rgb=[t(rgb)], num_points=crop, split='test', generator=torch.Generator().manual_seed(77), possibility=[poss0])
+    votes = VoteAccumulator([n], C, device=DEV)
+    # the oracle side replays the same draws: the sampler takes randn(3) * noise_scale and randperm(k) from its generator, in that order
+    gen = torch.Generator().manual_seed(77)
+    poss = poss0.astype(np.float64).copy()
+    ref_votes = np.zeros((n, C), np.float32)
+    prm = {k: v.clone() for k, v in sd.items()}
+    # device run, crop by crop, keeping each crop's collate for the oracle network
+    crops = []
+    orig = multiscale_compute
+
+    def spy(*a, **kw):
+        d = orig(*a, **kw)
+        crops.append(d)
+        return d
+    import crfconv_amd.data as D
+    D.multiscale_compute = spy
+    try:
+        vote_scene(smp, net, votes, n_crops, kernel_size=(K,) * 5, generator=torch.Generator().manual_seed(3))
+    finally:
+        D.multiscale_compute = orig
+    votes.check()
+    assert len(crops) == n_crops
+    for d in crops:
+        noise = (torch.randn(3, dtype=torch.float64, generator=gen) * smp.noise_scale).numpy()
+        torch.randperm(crop, generator=gen)                                   # (the shuffle: order inside the crop, irrelevant to the votes)
+        order, xyz, _ = E.possibility_draw(pts, poss, crop, noise)
+        got_idx = d.point_idx.reshape(-1).cpu().numpy()
+        assert np.array_equal(np.sort(got_idx), np.sort(order))               # the same crop
+        ms = [{k: getattr(l, k).cpu() for k in ('pos', 'neighbor_idx', 'sub_idx', 'up_idx')} for l in d.multiscale]
+        with torch.no_grad():
+            ref_logits = O.pointconv_resnet(prm, d.x.cpu(), ms, T, False, True)
+        E.vote_update(ref_votes, got_idx, E.softmax32(ref_logits.numpy()), 0.98)
+    assert np.array_equal(smp.possibility[0].cpu().numpy(), poss)             # float64 possibilities: bit-exact
+    got = votes.test_probs[0].cpu().numpy()
+    assert np.abs(got - ref_votes).max() < 1e-5, np.abs(got - ref_votes).max()
+    proj = np.random.default_rng(2).integers(0, n, 50000)
+    labels = votes.project(0, t(proj)).cpu().numpy()
+    ref_labels = E.vote_project(ref_votes, proj)
+    top2 = np.sort(ref_votes[proj], axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-5
+    assert clear.mean() > 0.5 and np.array_equal(labels[clear], ref_labels[clear])
+    visited = ref_votes.sum(1) > 0
+    assert 0.3 < visited.mean() <= 1.0
+
+
+def test_votes_merged_over_two_accumulators_equal_one_accumulator_in_rank_order():
+    """Crops sharded over ranks: rank r votes the crops i % world == r into its own tables (visit counts beside them),
+    `fold_` / `merge` combine them in rank order.  The result must equal ONE accumulator that applied rank 0's crops first, then rank 1's
+    (the reference's update is a running mean, trainval.py:188-189: order-dependent; the merge fixes the order, not the rule)."""
+    from crfconv_amd.sampling import VoteAccumulator
+    n, C, k = 5000, 8, 1500
+    rng = np.random.default_rng(4)
+    crops = [(rng.choice(n, k, replace=False), rng.standard_normal((k, C)).astype(np.float32)) for _ in range(7)]
+    parts = [VoteAccumulator([n], C, device=DEV, track_visits=True) for _ in range(2)]
+    for i, (idx, logits) in enumerate(crops):
+        parts[i % 2].update(t(idx).reshape(1, -1), torch.tensor([[0]], device=DEV), logits=t(logits))
+    one = VoteAccumulator([n], C, device=DEV, track_visits=True)
+    for r in range(2):
+        for i, (idx, logits) in enumerate(crops):
+            if i % 2 == r:
+                one.update(t(idx).reshape(1, -1), torch.tensor([[0]], device=DEV), logits=t(logits))
+    parts[0].fold_(parts[1].test_probs, parts[1].visits)
+    assert torch.equal(parts[0].visits[0], one.visits[0]) and int(one.visits[0].sum()) == 7 * k
+    err = float((parts[0].test_probs[0] - one.test_probs[0]).abs().max())
+    assert err < 2e-7, err
+    proj = t(rng.integers(0, n, 20000))
+    a, b = parts[0].project(0, proj), one.project(0, proj)
+    assert float((a == b).float().mean()) > 0.9999

@@ -108,6 +108,24 @@ def test_deferred_table_check_raises_without_a_host_sync_in_the_refresh():
     assert tb._checked
 
 
+def test_tables_built_inside_a_forward_are_checked_without_a_host_sync():
+    """graph.table_of (what every layer calls on the batch's index tensors) builds its tables with the range check DEFERRED: no .item()
+    per table -- thirteen of them per fresh batch serialised an eager step --; a bad table is reported by check_pending() once its count
+    has reached the host (and by the next table_of / load_ that polls it).  NeighborTable(...) called directly still raises at once."""
+    from crfconv_amd.graph import check_pending, table_of, _PENDING_CHECKS
+    check_pending(wait=True)
+    good = torch.randint(0, 9, (1, 64, 4)).to(DEV)
+    bad = good.clone()
+    bad[0, 3, 1] = 11
+    tg = table_of(good, 9)
+    tb = table_of(bad, 9)                                      # no error here: the count is still on its way
+    assert not tb._checked and len(_PENDING_CHECKS) >= 1
+    with pytest.raises(IndexError, match='1 neighbour indices outside'):
+        check_pending(wait=True)
+    assert tg._checked and not _PENDING_CHECKS
+    assert int(tb.idx32.max()) <= 8                            # the entry was clamped: nothing could fault meanwhile
+
+
 @pytest.mark.parametrize('K', [1, 5, 16, 32, 40])
 def test_table_columns_sorted_keep_row_content(K):
     """The device table re-orders columns 1.. of a row by ascending source id (locality of the gathers): same
@@ -904,7 +922,30 @@ def _eval_net_vs_oracle(pos, feats, in_ch, ncls, steps, seed, name, g, ratio=(4,
     _report_err(name + ' eval logits', logits, ref64)
     assert_close_anchored(logits, ref, ref64, OUT_TOL, name + ' logits')
     scale = max(1.0, float(ref64.abs().max()))
-    row_err = (logits.detach().cpu().double() - ref64).abs().max(1).values / scale
+    # ABSOLUTE figures (north_star: "per-point logits within 1e-4"), recorded per BASELINE config (tests/golden/parity_report.json, read by
+    # bench.py's `parity`): the largest |logit - float64 oracle|, the same for the float32 ORACLE, rows beyond 1e-4 absolute.  Wherever the
+    # float32 oracle itself stays within 1e-4 of its float64 run, so must the kernels -- in absolute terms, no normalisation.
+    abs_row = (logits.detach().cpu().double() - ref64).abs().max(1).values
+    abs_row32 = (ref.double() - ref64).abs().max(1).values
+    rec = {'max_abs': float(abs_row.max()), 'max_normalised': float(abs_row.max()) / scale, 'max_abs_logit': float(ref64.abs().max()),
+           'rows': int(abs_row.numel()), 'rows_beyond_1e-4_abs': int((abs_row > 1e-4).sum()),
+           'f32_oracle_max_abs_vs_f64': float(abs_row32.max()), 'f32_oracle_rows_beyond_1e-4_abs': int((abs_row32 > 1e-4).sum())}
+    print('[parity] %s %s' % (name, rec), flush=True)
+    if os.environ.get('CRFCONV_PARITY_RECORD'):
+        import json
+        path = os.environ['CRFCONV_PARITY_RECORD']
+        try:
+            allrec = json.load(open(path))
+        except (OSError, ValueError):
+            allrec = {}
+        allrec[name] = rec
+        json.dump(allrec, open(path, 'w'), indent=1, sort_keys=True)
+    if rec['f32_oracle_max_abs_vs_f64'] <= 1e-4:
+        assert rec['max_abs'] <= 1e-4, '%s: max |logit - oracle| %.3e absolute although the float32 oracle is within %.3e of float64' % (
+            name, rec['max_abs'], rec['f32_oracle_max_abs_vs_f64'])
+    ok32 = abs_row32 <= 1e-4                               # row by row as well: a row the float32 oracle gets within 1e-4 ...
+    assert float(abs_row[ok32].max()) <= 4e-4 and float((abs_row[ok32] > 1e-4).double().mean()) <= 1e-3      # ... is within 1e-4 here too, bar the 0.1 % of ill-conditioned sums (never beyond 4e-4)
+    row_err = abs_row / scale
     assert float((row_err > OUT_TOL).double().mean()) <= 1e-3, '%s: %d rows beyond 1e-4' % (name, int((row_err > OUT_TOL).sum()))
     labels = torch.randint(0, ncls, (B * N,), generator=g)
     a, b = runningScore(ncls), runningScore(ncls)

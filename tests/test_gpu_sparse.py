@@ -138,6 +138,39 @@ def test_graph_builders():
     assert bool((batch[eb[0]] == sub_batch[eb[1]]).all())
 
 
+def test_dilated_graph_picks_k_of_the_k_times_d_nearest():
+    """build_graph(method='knn', dilation=d): the reference searches k * d neighbours (loop=True) and keeps k of them per node, drawn with
+    replacement by torch.randint (models/point_conv.py:355-364).  Values, not shapes: every kept neighbour of node i is one
+    of i's OWN k * d nearest (oracle kNN, inside i's cloud), k per node in node order, the draw covers the far half of the list too, and the
+    pick is exactly  nearest[i, randint(k d, (n, k))]  for the generator's draws."""
+    from crfconv_amd.models import build_graph, graph_ops
+    k, d = 6, 3
+    pos_np = np.concatenate([S.make_cloud(15, 500), S.make_cloud(16, 260) + 4.0]).astype(np.float32)
+    batch_np = np.concatenate([np.zeros(500, np.int64), np.ones(260, np.int64)])
+    pos, batch = t(pos_np), t(batch_np)
+    n = len(pos_np)
+    near = np.concatenate([onative.oracle_knn(pos_np[:500], pos_np[:500], k * d), onative.oracle_knn(pos_np[500:], pos_np[500:], k * d) + 500])
+    torch.manual_seed(123)
+    ei = build_graph(pos, batch, method='knn', k=k, dilation=d).cpu().numpy()
+    assert ei.shape == (2, n * k) and np.array_equal(ei[1], np.repeat(np.arange(n), k))
+    kept = ei[0].reshape(n, k)
+    member = (kept[:, :, None] == near[:, None, :]).any(-1)
+    assert member.all()                                                    # within the node's own k * d nearest
+    rank = (kept[:, :, None] == near[:, None, :]).argmax(-1)
+    assert rank.max() >= k * d - 2 and (rank >= k).mean() > 0.5            # dilated: most picks lie beyond the k nearest
+    assert (batch_np[kept] == batch_np[:, None]).all()
+    # the pick itself, for a generator whose draws the test repeats (per cloud: randint(k d, (n_c, k)))
+    g1 = torch.Generator(device=DEV).manual_seed(7)
+    row, col = graph_ops.knn_dilated(pos, pos, k, d, batch, batch, generator=g1)
+    g2 = torch.Generator(device=DEV).manual_seed(7)
+    want = []
+    for lo, hi in ((0, 500), (500, 760)):
+        pick = torch.randint(k * d, (hi - lo, k), dtype=torch.long, device=DEV, generator=g2).cpu().numpy()
+        want.append(np.take_along_axis(near[lo:hi], pick, 1))
+    assert np.array_equal(col.cpu().numpy().reshape(n, k), np.concatenate(want))
+    assert np.array_equal(row.cpu().numpy(), np.repeat(np.arange(n), k))
+
+
 def test_sparse_equals_dense_on_device():
     """Same kNN graph through the dense fast path (fixed-K table, k0 = 1) and the padded edge-list path."""
     from crfconv_amd import ops
