@@ -47,9 +47,15 @@ __device__ __forceinline__ float4 pfma4(float w, float4 x, float4 acc) {
     return cat2(__builtin_elementwise_fma(ww, lo2(x), lo2(acc)), __builtin_elementwise_fma(ww, hi2(x), hi2(acc)));
 }
 
-template <int H, int NW, int PPL>
+// A workgroup of NW wavefronts owns PB = HP * (NW / 2) * PPW rows: HP "half passes" -- every wavefront carries HP / 2 points per lane
+// group, and when HP is odd the FIRST half of the wavefronts one more.  (8 wavefronts, HP = 5) = 640 rows with five wavefront-passes on
+// every SIMD (a workgroup's wavefronts w and w + 4 share a SIMD); ten wavefronts of two passes each left two SIMDs with six and the
+// other two waiting for them (profiles/r6_block_stamps.md).
+template <int H, int NW, int HP>
 struct BlkGeo {
-    static constexpr int L = H / 4, PPW = WAVE / L, NT = NW * WAVE, PB = PPL * NW * PPW, RB = 4 * H;
+    static_assert(NW % 2 == 0, "half passes");
+    static constexpr int L = H / 4, PPW = WAVE / L, NT = NW * WAVE, PPL = (HP + 1) / 2, PB = HP * (NW / 2) * PPW, RB = 4 * H;
+    static constexpr bool HALF = (HP & 1) != 0;
 };
 
 __device__ __forceinline__ float4 lds4(const float4* buf, int byte_addr) {
@@ -142,15 +148,15 @@ __device__ __forceinline__ bool blk_wait(unsigned* ws, unsigned phase, int* s_ok
     return *s_ok != 0;
 }
 
-template <int H, int K, int NW, int PPL, bool U16, bool STAMP = false>
+template <int H, int K, int NW, int HP, bool U16, bool STAMP = false>
 __global__ __launch_bounds__(NW * WAVE) void mf_block_kernel(const float* __restrict__ y, const float* __restrict__ z,
                                                              const int32_t* __restrict__ idx, const uint16_t* __restrict__ idx16,
                                                              int n_tgt, int n_src, const float* __restrict__ Q,
                                                              const float* __restrict__ P, float* __restrict__ s, float* xs,
                                                              int64_t m64, int T, unsigned* ws, unsigned long long* dbg) {
     BLK_STAMP(0);
-    using G = BlkGeo<H, NW, PPL>;
-    constexpr int L = G::L, PPW = G::PPW, NT = G::NT, PB = G::PB, RB = G::RB, CPR = K / 4, NCH = PPW * CPR, KL = K / L;
+    using G = BlkGeo<H, NW, HP>;
+    constexpr int L = G::L, PPW = G::PPW, NT = G::NT, PB = G::PB, RB = G::RB, PPL = G::PPL, CPR = K / 4, NCH = PPW * CPR, KL = K / L;
     constexpr int TAG = (int)0x80000000u;
     static_assert(L == 2 || L == 4, "neighbour columns travel between a point's lanes as DPP quad permutes");
     static_assert(NCH % WAVE == 0, "weight rows leave as whole 1 KiB stores");
@@ -164,6 +170,8 @@ __global__ __launch_bounds__(NW * WAVE) void mf_block_kernel(const float* __rest
     const int lane = threadIdx.x & 63, q = lane % L, gl = lane - q, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned bid = xcd_block_id();
     const int base = (int)bid * PB;
+    // the last pass of an odd number of half passes belongs to the first half of the wavefronts only (wave-uniform)
+    auto act = [&](const int p) { return !(G::HALF && p == PPL - 1) || wave < NW / 2; };
     if (threadIdx.x < L) {
         bufA[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
         bufB[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -177,9 +185,9 @@ __global__ __launch_bounds__(NW * WAVE) void mf_block_kernel(const float* __rest
 #pragma unroll
     for (int p = 0; p < PPL; ++p) {
         int jh[KL];
-        rl[p] = (p * NW + wave) * PPW + lane / L;
+        rl[p] = act(p) ? (p * NW + wave) * PPW + lane / L : 0;
         const int r0 = base + rl[p];
-        valid[p] = r0 < m;
+        valid[p] = act(p) && r0 < m;
         const int r = valid[p] ? r0 : m - 1;
         own[p] = r * RB + 16 * q;
         load_index_share<K, L, U16>(idx, idx16, r, n_tgt, n_src, q, jh);
@@ -196,8 +204,10 @@ __global__ __launch_bounds__(NW * WAVE) void mf_block_kernel(const float* __rest
     mp.fetch(P, false);
 #pragma unroll
     for (int p = 0; p < PPL; ++p) {
-        bufA[(rl[p] + 1) * L + q] = yi[p];
-        bufB[(rl[p] + 1) * L + q] = zi[p];
+        if (act(p)) {
+            bufA[(rl[p] + 1) * L + q] = yi[p];
+            bufB[(rl[p] + 1) * L + q] = zi[p];
+        }
     }
     mq.park(sQ);
     mp.park(sP);
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(NW * WAVE) void mf_block_kernel(const float* __rest
     float4 zq[PPL], o[PPL];
 #pragma unroll
     for (int p = 0; p < PPL; ++p) {
+        if (!act(p)) continue;
         float d[K];
         float dmin = 3.4e38f;
         static_for<L>([&](auto LQ) {
@@ -307,6 +318,7 @@ __global__ __launch_bounds__(NW * WAVE) void mf_block_kernel(const float* __rest
         __builtin_amdgcn_wave_barrier();                          // LDS operations of one wave complete in order
 #pragma unroll
         for (int p = 0; p < PPL; ++p) {
+            if (!act(p)) continue;
             const float4* mine = tile[p][wave];
             const int row0 = base + (p * NW + wave) * PPW;
 #pragma unroll
@@ -321,7 +333,8 @@ __global__ __launch_bounds__(NW * WAVE) void mf_block_kernel(const float* __rest
     grid_sync_groups(gridDim.x, blockIdx.x, n_in_group, n_groups);
     __syncthreads();                                  // every wavefront is done with its y / z gathers: bufA becomes x_1
 #pragma unroll
-    for (int p = 0; p < PPL; ++p) bufA[(rl[p] + 1) * L + q] = o[p];
+    for (int p = 0; p < PPL; ++p)
+        if (act(p)) bufA[(rl[p] + 1) * L + q] = o[p];
     __syncthreads();
     BLK_STAMP(3);
 
@@ -371,13 +384,17 @@ __global__ __launch_bounds__(NW * WAVE) void mf_block_kernel(const float* __rest
         BLK_STAMP(8 * t + 4);
         blk_arrive(ws, (unsigned)t, n_in_group, n_groups);
         if (t == 1 && s != nullptr) store_weights();
-        static_for<PPL - 1>([&](auto PP) { msgin[decltype(PP)::value + 1] = inblock(std::integral_constant<int, decltype(PP)::value + 1>{}, q16); });
+        static_for<PPL - 1>([&](auto PP) {
+            constexpr int p1 = decltype(PP)::value + 1;
+            if (act(p1)) msgin[p1] = inblock(std::integral_constant<int, p1>{}, q16);
+        });
         BLK_STAMP(8 * t + 5);
         if (!blk_wait(ws, (unsigned)t, &s_ok)) return;
         BLK_STAMP(8 * t + 1);
         const int sbase = (t - 1) * step_bytes;
 #pragma unroll
         for (int p = 0; p < PPL; ++p) {
+            if (!act(p)) continue;
             float4 msg = msgin[p];
             static_for<L>([&](auto LQ) {
                 constexpr int lq = decltype(LQ)::value;
@@ -406,7 +423,8 @@ __global__ __launch_bounds__(NW * WAVE) void mf_block_kernel(const float* __rest
         BLK_STAMP(8 * t + 2);
         if (t + 1 < T) {                              // (blk_wait's barrier: every wavefront is done with x_{t-1} in bufA)
 #pragma unroll
-            for (int p = 0; p < PPL; ++p) bufA[(rl[p] + 1) * L + q] = o[p];
+            for (int p = 0; p < PPL; ++p)
+                if (act(p)) bufA[(rl[p] + 1) * L + q] = o[p];
             __syncthreads();
         }
     }
@@ -441,20 +459,20 @@ using namespace crf;
 namespace {
 
 struct BlkPlan {
-    int nw, ppl, pb, nblk;
+    int nw, ppl, pb, nblk;         // (ppl: half passes)
 };
 // compiled shapes (wavefronts per workgroup, points per lane group), by rows per workgroup.  (10, 2): 144 VGPRs at 3 wavefronts per SIMD.
 // Measured and dropped: (4, 5) -- one wavefront per SIMD, five passes each, the only 640-row shape whose wavefronts divide evenly over the
 // four SIMDs: 28.7 us against 23.6 (a lone wavefront issues a vector instruction every ~8 cycles); two workgroups of 320 rows per CU
 // (10 wavefronts each at 96 VGPRs): not co-resident -- the second workgroup's ten wavefronts do not fit the SIMDs the first left uneven.
-constexpr int BLK_SHAPES[][2] = {{4, 2}, {8, 2}, {10, 2}, {12, 2}};
+constexpr int BLK_SHAPES[][2] = {{4, 4}, {8, 4}, {8, 5}, {12, 4}};      // (wavefronts, half passes): 256 | 512 | 640 | 768 rows
 
 // The smallest compiled block that covers m rows with no more workgroups than the device has CUs, or nblk = 0 when none does.
 template <int H>
 BlkPlan plan_for(int64_t m, int cus) {
     constexpr int PPW = WAVE / (H / 4);
     for (const auto& sh : BLK_SHAPES) {
-        const int pb = sh[0] * sh[1] * PPW;
+        const int pb = sh[1] * (sh[0] / 2) * PPW;
         const int64_t nblk = cdiv(m, pb);
         if (nblk <= cus) return {sh[0], sh[1], pb, (int)nblk};
     }
@@ -471,11 +489,11 @@ int device_cus() {
     return cus;
 }
 
-template <int H, int K, int NW, int PPL>
+template <int H, int K, int NW, int HP>
 int launch_block(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16, int n_tgt, int n_src, int64_t m,
                  const float* Q, const float* P, int T, float* s, float* xs, unsigned* ws, int nblk, hipStream_t st) {
-    if (idx16) hipLaunchKernelGGL((mf_block_kernel<H, K, NW, PPL, true>), dim3((unsigned)nblk), dim3(NW * WAVE), 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, ws, (unsigned long long*)nullptr);
-    else hipLaunchKernelGGL((mf_block_kernel<H, K, NW, PPL, false>), dim3((unsigned)nblk), dim3(NW * WAVE), 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, ws, (unsigned long long*)nullptr);
+    if (idx16) hipLaunchKernelGGL((mf_block_kernel<H, K, NW, HP, true>), dim3((unsigned)nblk), dim3(NW * WAVE), 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, ws, (unsigned long long*)nullptr);
+    else hipLaunchKernelGGL((mf_block_kernel<H, K, NW, HP, false>), dim3((unsigned)nblk), dim3(NW * WAVE), 0, st, y, z, idx32, idx16, n_tgt, n_src, Q, P, s, xs, m, T, ws, (unsigned long long*)nullptr);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
@@ -508,24 +526,27 @@ extern "C" int crfconv_meanfield_forward_block(const float* z, const float* y, c
     hipStream_t st = as_stream(stream);
     unsigned* w = reinterpret_cast<unsigned*>(ws);
 #define BLK_CASE(NW_, PPL_) if (pl.nw == NW_ && pl.ppl == PPL_) return launch_block<8, 16, NW_, PPL_>(z, y, idx32, idx16, n_tgt, n_src, m, Q, P, T, s, xs, w, pl.nblk, st)
-    BLK_CASE(4, 2);
-    BLK_CASE(8, 2);
-    BLK_CASE(10, 2);
-    BLK_CASE(12, 2);
+    BLK_CASE(4, 4);
+    BLK_CASE(8, 4);
+    BLK_CASE(8, 5);
+    BLK_CASE(12, 4);
 #undef BLK_CASE
     CRF_REQUIRE(false, CRF_ERR_UNSUPPORTED, "block-resident mean field: no kernel for %d wavefronts x %d passes", pl.nw, pl.ppl);
 }
 
 /* Diagnostic twin (scratch/mf_block_stamps.py): 100 MHz phase stamps per workgroup in dbg [blocks][64] (u64); 640 rows per workgroup
- * (10 wavefronts x 2 passes; `shape` is reserved), uint16 tables only. */
+ * (shape 0: 8 wavefronts x 5 half passes -- the shipped shape; 1: 10 wavefronts x 2 passes), uint16 tables only. */
 extern "C" int crfconv_meanfield_forward_block_stamps(const float* z, const float* y, const int32_t* idx32, const uint16_t* idx16,
                                                       int n_tgt, int n_src, int64_t m, const float* Q, const float* P, int T, float* s,
                                                       float* xs, void* ws, int shape, unsigned long long* dbg, crf_stream_t stream) {
     CRF_REQUIRE(z && y && idx32 && idx16 && Q && P && s && xs && ws && dbg && T >= 1, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(cdiv(m, 640) <= device_cus() && m * 32 * (int64_t)T < ((int64_t)1 << 31) - 4096, CRF_ERR_UNSUPPORTED, "too many rows");
-    (void)shape;
-    hipLaunchKernelGGL((mf_block_kernel<8, 16, 10, 2, true, true>), dim3((unsigned)cdiv(m, 640)), dim3(640), 0, as_stream(stream), y, z, idx32, idx16,
-                       n_tgt, n_src, Q, P, s, xs, m, T, reinterpret_cast<unsigned*>(ws), dbg);
+    if (shape == 1)
+        hipLaunchKernelGGL((mf_block_kernel<8, 16, 10, 4, true, true>), dim3((unsigned)cdiv(m, 640)), dim3(640), 0, as_stream(stream), y, z, idx32, idx16,
+                           n_tgt, n_src, Q, P, s, xs, m, T, reinterpret_cast<unsigned*>(ws), dbg);
+    else
+        hipLaunchKernelGGL((mf_block_kernel<8, 16, 8, 5, true, true>), dim3((unsigned)cdiv(m, 640)), dim3(512), 0, as_stream(stream), y, z, idx32, idx16,
+                           n_tgt, n_src, Q, P, s, xs, m, T, reinterpret_cast<unsigned*>(ws), dbg);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }

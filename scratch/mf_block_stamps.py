@@ -13,7 +13,7 @@ tab, m, K, z, y, Q, P, _ = bench._meanfield_problem(data, dev, 8)
 H = 8
 ws = gridsync_ws(dev)
 s_ = torch.empty(m, K, device=dev); xs = torch.empty(T, m, H, device=dev)
-for shape in (0,):
+for shape in (0, 1):
     rows = 640
     nblk = -(-m // rows)
     dbg = torch.zeros(nblk, 64, dtype=torch.int64, device=dev)
@@ -28,7 +28,7 @@ for shape in (0,):
         v = (d[:, col] - t0) / 100.0
         print('  %-44s min %6.2f  median %6.2f  max %6.2f us' % (name, v.min(), np.median(v), v.max()))
     print('shape %d (%s): %d rows per workgroup, %d workgroups, T = %d, fail word %d (thread 0 of every workgroup, 100 MHz clock, relative to the first start)'
-          % (shape, '10 wavefronts x 2 passes', rows, nblk, T, int(ws[_lib.load().crfconv_gridsync_fail_word()])))
+          % (shape, ('8 wavefronts x 5 half passes', '10 wavefronts x 2 passes')[shape], rows, nblk, T, int(ws[_lib.load().crfconv_gridsync_fail_word()])))
     line('start', 0); line('own rows staged (sync)', 1); line('similarity + step 1 computed', 2); line('x_1 in LDS (two syncs later)', 3)
     for t in range(1, T):
         line('step %d: in-block sums of pass 0 done' % (t + 1), 8 * t); line('step %d: x_%d drained, arrive' % (t + 1, t), 8 * t + 4)

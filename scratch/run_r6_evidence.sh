@@ -5,7 +5,8 @@ tag=${1:-r6k}
 part=${2:-all}
 mkdir -p gpurun_out/$tag
 if [ $part = all ] || [ $part = tests ]; then
-CRFCONV_TOL_RECORD=$GRAFT_REPO_ROOT/gpurun_out/$tag/tol_recorded.json timeout -k 10 1000 python3 -m pytest tests -m gpu -q > gpurun_out/$tag/tests.log 2>&1
+rm -f gpurun_out/$tag/parity_report.json
+CRFCONV_PARITY_RECORD=$GRAFT_REPO_ROOT/gpurun_out/$tag/parity_report.json CRFCONV_TOL_RECORD=$GRAFT_REPO_ROOT/gpurun_out/$tag/tol_recorded.json timeout -k 10 1000 python3 -m pytest tests -m gpu -q > gpurun_out/$tag/tests.log 2>&1
 echo "tests rc=$?"; grep -E "^FAILED|passed|failed" gpurun_out/$tag/tests.log | tail -5 | cut -c1-200
 fi
 if [ $part = all ] || [ $part = mf ]; then
