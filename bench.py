@@ -1022,10 +1022,12 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    if grouped:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    rank_ms = {'min': dt / args.steps * 1e3, 'max': dt / args.steps * 1e3}
+    if grouped:                           # the contract's figure = MAX over ranks; min and max are both on the line so that a straggler shows
+        tt = torch.tensor([dt, -dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = float(tt[0].item())
+        rank_ms = {'min': -float(tt[1].item()) / args.steps * 1e3, 'max': dt / args.steps * 1e3}
     ms_per_step = dt / args.steps * 1e3
     value = world * B * N / (dt / args.steps) / 1e6
 
@@ -1239,7 +1241,7 @@ def main():
             pipe_ms = None
 
     # ---- the all-reduce alone (HIP events around 20 calls on the launching stream), and what the group looks like
-    allreduce_us, backend_name = None, None
+    allreduce_us, allreduce_host_us, backend_name = None, None, None
     if grouped:
         backend_name = torch.distributed.get_backend()
         for _ in range(5):
@@ -1252,6 +1254,11 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         allreduce_us = e0.elapsed_time(e1) / 20 * 1e3
+        t0 = time.perf_counter()          # ... and what ISSUING it costs the host (the call sits between two graph replays)
+        for _ in range(20):
+            collective()
+        allreduce_host_us = (time.perf_counter() - t0) / 20 * 1e6
+        torch.cuda.synchronize()
 
     # ---- what a caller of the UNCHANGED reference loop gets (trainval.py:99-106), on the same model and batch: no graph, no
     # FlatSGD, no deferred weight gradients, no fused loss -- torch.optim.SGD and F.cross_entropy as the reference writes them;
@@ -1288,7 +1295,8 @@ def main():
             'fresh_batch_replay': fresh,
             'launch_mode': graph_note,
             'rccl_ranks_seen': torch.distributed.get_world_size() if grouped else 1,
-            'dist_backend': backend_name, 'allreduce_us': allreduce_us,
+            'dist_backend': backend_name, 'allreduce_us': allreduce_us, 'allreduce_host_issue_us': allreduce_host_us,
+            'rank_ms_per_step': rank_ms, 'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
             'trainval_eager_ms_per_step': None if ref_loop is None else ref_loop.get('eager_ms_per_step'),
             'trainval_captured_ms_per_step': None if ref_loop is None else ref_loop.get('captured_ms_per_step'),
             'trainval_graphed_module_ms_per_step': None if ref_loop is None else ref_loop.get('graphed_module_ms_per_step'),

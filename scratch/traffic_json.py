@@ -19,7 +19,7 @@ FWD_FIRST, FWD_STEP = 'crf::sim_step_fast_kernel<8, 16, true, true>', 'crf::step
 REV_FIRST, REV_CHAIN, REV_FINAL = ('crf::bwd_rev_kernel<8, 2, 3, 0, true, 4>', 'crf::bwd_rev_kernel<8, 2, 3, 0, false, 4>',
                                    'crf::bwd_rev_kernel<8, 4, 2, 1, false, 4>')
 EDGE = 'crf::bwd_edge_all_kernel<8, 16, true>'
-FWD_BLOCK = 'crf::mf_block_kernel<8, 16, 10, 2, true, false>'
+FWD_BLOCK = 'crf::mf_block_kernel<8, 16, 8, 5, true, false>'
 fwd = hbm_bytes(FWD_BLOCK)                     # the product's forward on a local table (round 6): ONE launch
 fwd_steps = hbm_bytes(FWD_FIRST) + (T - 1) * hbm_bytes(FWD_STEP)
 bwd = hbm_bytes(REV_FIRST) + (T - 2) * hbm_bytes(REV_CHAIN) + hbm_bytes(EDGE) + hbm_bytes(REV_FINAL)
