@@ -47,5 +47,5 @@ if '--pointconv-json' in sys.argv:
                'how': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (scratch/run_pcpmc.sh, scratch/pc_pmc.py, scratch/pmc_table.py); '
                       'bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB; the dominant forward kernel uvstats_kernel<8> (the combine / reduce launches of the '
                       'forward are shared names across widths in the counter files and are listed in the profile, not added here)'},
-              open(os.path.join(ROOT, 'profiles', 'r5_pointconv_traffic.json'), 'w'), indent=1)
+              open(os.path.join(ROOT, 'profiles', 'r6_pointconv_traffic.json'), 'w'), indent=1)
     print('pointconv uvstats<8> HBM-side bytes per launch: %.1f MB' % (fwd / 1e6))

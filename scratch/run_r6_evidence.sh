@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6 evidence batches.  usage: scratch/run_r6_evidence.sh <tag> <all|tests|mf|tables|bench>
+# round 6 evidence batches.  usage: scratch/run_r6_evidence.sh <tag> <all|tests|mf|tables|steppmc|pmc2|bench|spawn>
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=${1:-r6k}
 part=${2:-all}
@@ -21,6 +21,16 @@ out=gpurun_out/$tag
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $out/trace -o t -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs > $out/trace.log 2>&1 || { tail -20 $out/trace.log | cut -c1-300; }
 python3 scratch/step_table.py $out/trace 400 10 > $out/step_table.txt 2>&1; head -3 $out/step_table.txt
 rm -rf $out/trace
+fi
+if [ $part = all ] || [ $part = steppmc ]; then
+bash scratch/run_step_pmc.sh > gpurun_out/$tag/step_pmc.log 2>&1; echo "step pmc done"; tail -3 gpurun_out/$tag/step_pmc.log | cut -c1-200
+rm -rf gpurun_out/step_pmc/FETCH_SIZE_* gpurun_out/step_pmc/WRITE_SIZE_*
+fi
+if [ $part = all ] || [ $part = pmc2 ]; then
+bash scratch/run_pcpmc.sh > gpurun_out/$tag/pcpmc.log 2>&1; echo "pointconv pmc done"; rm -rf gpurun_out/pmc_pc
+fi
+if [ $part = all ] || [ $part = spawn ]; then
+timeout -k 10 400 python3 bench.py --gpus 1 --spawn --steps 30 --no-cpu-baseline --no-other-configs > gpurun_out/$tag/bench_spawn1.json 2> gpurun_out/$tag/bench_spawn1.err; echo "spawn bench rc=$?"
 fi
 if [ $part = all ] || [ $part = bench ]; then
 timeout -k 10 900 python3 bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err; echo "bench rc=$?"; tail -3 gpurun_out/$tag/bench.err | cut -c1-300
