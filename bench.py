@@ -129,16 +129,40 @@ def rehearse(args):
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         spread[0] = float((hi - lo).abs().max())
     if rank == 0:
-        print(json.dumps({'rehearsal': True, 'metric': 'rank plumbing only (CPU, gloo): NOT a benchmark', 'world': world, 'n_gpus': 0,
+        _print_json_line({'rehearsal': True, 'metric': 'rank plumbing only (CPU, gloo): NOT a benchmark', 'world': world, 'n_gpus': 0,
                           'dist_backend': torch.distributed.get_backend() if grouped else None, 'steps': args.steps, 'warmup': args.warmup,
                           'ms_per_step': dt / max(args.steps, 1) * 1e3, 'replica_spread': float(spread[0]), 'guard_slot': float(bucket.guard),
-                          'final_loss': float(loss), 'points_per_rank': args.points}))
+                          'final_loss': float(loss), 'points_per_rank': args.points})
     if grouped:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 
+_JSON_FD = None
+
+
+def _keep_stdout_for_the_json_line():
+    """Under a process group the collective library writes a version banner to the process's stdout (RCCL 2.26: five lines per rank).  The
+    contract is ONE JSON line on stdout: file descriptor 1 is pointed at stderr for the life of the process and the line goes out through a
+    duplicate of the original descriptor."""
+    global _JSON_FD
+    if _JSON_FD is None and 'WORLD_SIZE' in os.environ:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _print_json_line(obj):
+    line = json.dumps(obj) + '\n'
+    if _JSON_FD is None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line.encode())
+
+
 def main():
+    _keep_stdout_for_the_json_line()
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--spawn', action='store_true', help='start the ranks as child processes even for --gpus 1 (one-rank RCCL group)')
@@ -591,7 +615,7 @@ def main():
                 out['other_configs'] = {'error': str(e).splitlines()[0][:200]}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(data, net, T, data.y, n_cls, dev)
-        print(json.dumps(out))
+        _print_json_line(out)
     if grouped:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
