@@ -23,6 +23,7 @@ def roofline_meanfield(data, dev, H=8, T=3, level=0, form=None):
     ws = gridsync_ws(dev)
     can_block = _lib.load().crfconv_meanfield_forward_block_rows(m, H, K, 1, T) > 0
     if form is None:
+        _block_rows(tab, m, H, 1, T)            # (the first question about a table only starts the locality measurement: ops.crf._table_is_local)
         form = 'block' if _block_rows(tab, m, H, 1, T) > 0 else 'steps'
     elif form == 'block' and not can_block:
         return None

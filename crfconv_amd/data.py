@@ -320,13 +320,14 @@ def multiscale_compute(pos, x=None, y=None, point_idx=None, cloud_idx=None, kern
             multiscale.append(Data(pos=pos, neighbor_idx=neighbor_idx, sub_idx=sub_idx, up_idx=up_idx))
             pos = sub_pos
             continue
+        from .graph import to_device
         if choices is not None:
-            choice = choices[i].to(pos.device)
+            choice = to_device(choices[i], pos.device)
         else:
             choice = torch.randperm(n, generator=generator)[: n // ratio[i]]
             if sort == 'morton':
                 choice = choice.sort().values
-            choice = choice.to(pos.device)
+            choice = to_device(choice.contiguous(), pos.device)        # (no stream synchronisation: graph.to_device)
         sub_pos, sub_idx = pick_rows([pos, neighbor_idx], choice, per_cloud=False)
         if kernel_size[i] >= 4:
             # the nearest subset member of a point is almost always one of its own K nearest neighbours: answered from the table

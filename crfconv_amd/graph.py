@@ -31,6 +31,16 @@ def stream_ptr():
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
+def to_device(t, device):
+    """Host tensor -> device WITHOUT a stream synchronisation: through pinned memory with a non-blocking copy (torch's host allocator keeps
+    the pinned block alive until the copy has run).  ``t.to(device)`` from pageable memory waits for the stream -- per call: five times per
+    eager collate (the subset draws), twice per crop (jitter, shuffle) --, and on this stack a wait behind a short burst of work can
+    return on a 10 ms tick.  Device tensors pass through."""
+    if t.is_cuda:
+        return t
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def require_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -166,14 +176,15 @@ _PENDING_CHECKS = []          # (event, pinned counts, tables): validations whos
 _PINNED = {'ring': None, 'next': 0}
 
 
-def _pinned_slot():
-    """One int32 of pinned host memory out of a ring of 1024 (allocated once: a pinned allocation per table would cost more than the
-    synchronisation it replaces; a slot is reused long after its check has been read)."""
+def _pinned_slot(dtype=torch.int32):
+    """One int32 (or int64) of pinned host memory out of a ring of 1024 slots (allocated once: a pinned allocation per table would cost
+    more than the synchronisation it replaces; a slot is reused long after its value has been read)."""
     if _PINNED['ring'] is None:
-        _PINNED['ring'] = torch.zeros(1024, dtype=torch.int32).pin_memory()
+        _PINNED['ring'] = torch.zeros(1024, dtype=torch.int64).pin_memory()
     i = _PINNED['next']
     _PINNED['next'] = (i + 1) % 1024
-    return _PINNED['ring'][i:i + 1]
+    slot = _PINNED['ring'][i:i + 1]
+    return slot if dtype == torch.int64 else slot.view(torch.int32)[:1]
 
 
 def check_pending(wait=False):

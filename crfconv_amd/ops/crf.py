@@ -10,15 +10,31 @@ from ._base import _f32c, _next_supported, _pad_channels, _ptr_array, _ticket, g
 # ------------------------------------------------------------------------------ CRF mean field
 def _table_is_local(table, m, k0, rows):
     """True when at least state.mf_block_min_locality of the table's entries point into the target's own block of `rows` consecutive
-    rows (spatially sorted clouds).  Measured once per table and block size (one small launch + one host read, never inside a
-    capture: an unmeasured table is 'not local'), kept in table.cache -- a table refreshed in place keeps its first verdict."""
-    frac = table.cache.get(('block_locality', rows))
+    rows (spatially sorted clouds).  Measured once per table and block size by one small launch whose count travels to pinned memory
+    WITHOUT a host synchronisation: the FIRST forward over a table answers 'not local' (per-step launches -- equally fast)
+    and leaves the measurement in flight; the second forward over the same table (a resident / static batch: the warm-up passes in front
+    of a graph capture) reads it, waiting for it if it has to, and the verdict stays in table.cache -- a table refreshed in place keeps
+    its first verdict.  A loop that builds a new table per step never waits.  Never measured inside a capture."""
+    key = ('block_locality', rows)
+    frac = table.cache.get(key)
     if frac is None:
         if torch.cuda.is_current_stream_capturing():
             return False
-        count = torch.zeros(1, dtype=torch.int64, device=table.idx32.device)
-        _lib.call('crfconv_block_locality', ptr(table.idx32), m, table.K, k0, rows, ptr(count), stream_ptr())
-        frac = table.cache[('block_locality', rows)] = float(count.item()) / float(m * (table.K - k0))
+        pend = table.cache.get(('block_locality_pending', rows))
+        if pend is None:
+            from ..graph import _pinned_slot
+            count = torch.zeros(1, dtype=torch.int64, device=table.idx32.device)
+            _lib.call('crfconv_block_locality', ptr(table.idx32), m, table.K, k0, rows, ptr(count), stream_ptr())
+            host = _pinned_slot(torch.int64)
+            host.copy_(count, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            table.cache[('block_locality_pending', rows)] = (ev, host, count)
+            return False
+        ev, host, _ = pend
+        ev.synchronize()
+        frac = table.cache[key] = float(host[0]) / float(m * (table.K - k0))
+        del table.cache[('block_locality_pending', rows)]
     return frac >= state.mf_block_min_locality
 
 

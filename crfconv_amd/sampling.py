@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from .data import Data
-from .graph import ptr, require_gpu, stream_ptr
+from .graph import ptr, require_gpu, stream_ptr, to_device
 
 
 def _ws(nbytes, device):
@@ -77,15 +77,16 @@ class PossibilitySampler:
         """One crop.  ``noise`` float64 [3] and ``perm`` int64 [k] override the Gaussian jitter and the shuffle (tests
         feed the reference's draws); otherwise they come from ``self.generator``.  Returns ``Data(pos, rgb, y,
         point_idx, cloud_idx)`` with the reference's field meanings (:453-458), all on the device."""
-        c = int(torch.argmin(self._minv).item())           # :424 -- the loop's only host decision (which cloud)
+        # :424 -- which cloud: the loop's only host decision (a device -> host read; none with a single cloud)
+        c = 0 if len(self.points) == 1 else int(torch.argmin(self._minv).item())
         pts = self.points[c]
         n, k = pts.shape[0], min(self.num_points, pts.shape[0])
         if noise is None:
             noise = torch.randn(3, dtype=torch.float64, generator=self.generator) * self.noise_scale
-        noise = torch.as_tensor(noise, dtype=torch.float64).to(self.device).contiguous()
+        noise = to_device(torch.as_tensor(noise, dtype=torch.float64).contiguous(), self.device)
         if perm is None:
             perm = torch.randperm(k, generator=self.generator)
-        perm = None if perm is False else torch.as_tensor(perm, dtype=torch.int64).to(self.device).contiguous()
+        perm = None if perm is False else to_device(torch.as_tensor(perm, dtype=torch.int64).contiguous(), self.device)
         key = (n, k)
         if key not in self._crop_ws:
             self._crop_ws[key] = _ws(_lib.load().crfconv_possibility_crop_workspace(n, k), self.device)
@@ -104,6 +105,7 @@ class PossibilitySampler:
             y = self.labels[c][idx]
         out = Data(pos=xyz, rgb=rgb, y=y, point_idx=idx, cloud_idx=torch.tensor([c], dtype=torch.long, device=self.device))
         out.center = center
+        out.cloud = c                                        # the same as a host int (VoteAccumulator.update takes it without a device read)
         return out
 
 
@@ -128,7 +130,8 @@ class VoteAccumulator:
         B, N = point_idx.shape
         src = src.reshape(B, N, self.num_classes).float().contiguous()
         point_idx = point_idx.long().contiguous()
-        clouds = cloud_idx.reshape(B, -1)[:, 0].tolist()
+        # cloud ids: host ints / a list of them are taken as they are; a device tensor costs one device -> host read per call
+        clouds = cloud_idx.reshape(B, -1)[:, 0].tolist() if torch.is_tensor(cloud_idx) else ([int(cloud_idx)] if isinstance(cloud_idx, int) else [int(c) for c in cloud_idx])
         for b in range(B):
             tp = self.test_probs[int(clouds[b])]
             if self.visits is None:
@@ -195,8 +198,35 @@ class VoteAccumulator:
             raise IndexError('%d point indices outside their cloud' % bad)
 
 
+class _GraphedCrops:
+    """Collate + eval forward of one crop SHAPE as two hipGraph replays (vote_scene(graphed=True)): the first crop of a shape runs eagerly and
+    becomes the static batch; ``data.CollateGraph`` (Morton order, kNN at every scale, counter-based subsets, in-place refresh of the static
+    batch's tables) and the captured ``net(static)`` serve every later crop of that shape.  Eagerly a crop is ~250 library launches of
+    host-bound Python (4.7 ms of network + 2.5 ms of collate at 65 536 points, K = 32, T = 5); replayed it is their kernel time."""
+
+    def __init__(self, net, first, kernel_size, ratio, generator):
+        from .data import CollateGraph
+        first.point_idx = first.cloud_idx = None         # (per-crop bookkeeping, not inputs of the network: the caller keeps them)
+        self.static = first
+        self.cg = CollateGraph(first, kernel_size=kernel_size, ratio=ratio, generator=generator)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            net(first)                                   # warm-up outside the capture (lazily built tables, allocator)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.logits = net(first)
+
+    def run(self, pos, x):
+        self.cg.run(pos, x)                              # static batch <- this crop (its own Morton order: self.cg.order)
+        self.graph.replay()
+        return self.logits, self.cg.order
+
+
 def vote_scene(sampler, net, votes, n_crops, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), rank=0, world=1, generator=None,
-               timings=None):
+               timings=None, graphed=False, on_crop=None):
     """The inference loop of trainval.py:170-189 on the device for ``n_crops`` crops of the sampler's clouds: crop (possibility
     sampler) -> ``multiscale_compute`` (kNN at every scale) -> ``net`` (eval, no grad) -> soft-max votes into ``votes``.  One crop per
     batch (B = 1: datasets/semantic3d_dataset.py:453-458 yields single crops; the loader's batch dimension only stacks them).
@@ -204,8 +234,11 @@ def vote_scene(sampler, net, votes, n_crops, kernel_size=(16, 16, 16, 16, 16), r
 
     world > 1: EVERY rank draws the whole crop sequence (the sampler is cheap and its possibilities must evolve as on one GPU), crop i is
     run through the network by rank i % world only; ``votes.merge()`` afterwards gives every rank the full tables.
+    graphed: collate and forward of every crop after the first of its shape as hipGraph replays (_GraphedCrops); the random subsets of the
+    coarse levels then come from the collate graph's counter-based draw instead of ``torch.randperm`` (any subset is a valid one).
     timings: a dict that receives the summed milliseconds per stage (host clock around device-synchronised stages: a diagnostic mode --
-    it serialises host and device)."""
+    it serialises host and device).  on_crop(data, logits, point_idx): called per crop with the collated batch (static buffers when graphed:
+    clone what is to be kept), the logits and the crop's point ids in the batch's row order (tests)."""
     import time
     from .data import multiscale_compute
     dev = sampler.device
@@ -221,6 +254,7 @@ def vote_scene(sampler, net, votes, n_crops, kernel_size=(16, 16, 16, 16, 16), r
         return out
     was_training = net.training
     net.eval()
+    graphs = {}
     try:
         for i in range(n_crops):
             crop = stage('sample', sampler.get_random)
@@ -229,12 +263,27 @@ def vote_scene(sampler, net, votes, n_crops, kernel_size=(16, 16, 16, 16, 16), r
             pos = crop.pos.unsqueeze(0)
             rgb = crop.rgb if crop.rgb is not None else torch.zeros_like(crop.pos)
             x = torch.cat([crop.pos, rgb], -1).unsqueeze(0)
-            data = stage('collate', lambda: multiscale_compute(pos, x=x, point_idx=crop.point_idx.unsqueeze(0), cloud_idx=crop.cloud_idx.reshape(1, 1),
-                                                               kernel_size=kernel_size, ratio=ratio, generator=generator, sort='morton'))
-            with torch.no_grad():
-                logits = stage('network', lambda: net(data))
-            # the collate reordered the crop along its Morton curve: point_idx travelled with it (multiscale_compute permutes x, y, point_idx alike)
-            stage('vote', lambda: votes.update(data.point_idx, data.cloud_idx, logits=logits))
+            shape = tuple(pos.shape)
+            if graphed and shape in graphs:
+                logits, order = stage('collate+network (replays)', lambda: graphs[shape].run(pos, x))
+                data = graphs[shape].static
+                point_idx = crop.point_idx[order.reshape(-1)].unsqueeze(0)          # the batch's rows are the crop's points in Morton order
+            else:
+                data = stage('collate', lambda: multiscale_compute(pos, x=x, point_idx=crop.point_idx.unsqueeze(0), cloud_idx=crop.cloud_idx.reshape(1, 1),
+                                                                   kernel_size=kernel_size, ratio=ratio, generator=generator, sort='morton'))
+                with torch.no_grad():
+                    logits = stage('network', lambda: net(data))
+                # the collate reordered the crop along its Morton curve: point_idx travelled with it (multiscale_compute permutes x, y, point_idx alike)
+                point_idx = data.point_idx
+                if graphed:
+                    votes.update(point_idx, crop.cloud, logits=logits)
+                    if on_crop is not None:
+                        on_crop(data, logits, point_idx)
+                    graphs[shape] = _GraphedCrops(net, data, kernel_size, ratio, generator)
+                    continue
+            stage('vote', lambda: votes.update(point_idx, crop.cloud, logits=logits))
+            if on_crop is not None:
+                on_crop(data, logits, point_idx)
     finally:
         net.train(was_training)
     return votes

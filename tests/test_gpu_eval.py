@@ -151,14 +151,15 @@ def _scene(n, seed):
     return pts, rgb
 
 
-def test_tiled_scene_pipeline_against_the_oracle_chain():
+@pytest.mark.parametrize('graphed', [False, True])
+def test_tiled_scene_pipeline_against_the_oracle_chain(graphed):
     """Config 5 / 3 as a PIPELINE on a small scene: possibility sampler -> multiscale_compute -> PointConvBig (eval) ->
     soft-max votes -> re-projection (trainval.py:170-203, datasets/semantic3d_dataset.py:423-460), `sampling.vote_scene` against the
     oracle chain on the SAME draws: oracle/eval_oracle.py possibility_draw (crop membership and possibilities bit-exact), oracle/crf_oracle.py
     network on the device collate's tables (kNN parity is test_gpu_native's), vote_update / vote_project.  Vote tables within 1e-5, final
-    per-point labels equal wherever the two best votes are not a near-tie."""
+    per-point labels equal wherever the two best votes are not a near-tie.  graphed: collate and forward of the crops after the first as
+    hipGraph replays (static batch refreshed in place per crop)."""
     from crfconv_amd import models
-    from crfconv_amd.data import multiscale_compute
     from crfconv_amd.sampling import PossibilitySampler, VoteAccumulator, vote_scene
     from oracle import crf_oracle as O
     n, crop, n_crops, C, K, T = 24000, 6000, 4, 8, 16, 3
@@ -175,31 +176,21 @@ def test_tiled_scene_pipeline_against_the_oracle_chain():
     poss = poss0.astype(np.float64).copy()
     ref_votes = np.zeros((n, C), np.float32)
     prm = {k: v.clone() for k, v in sd.items()}
-    # device run, crop by crop, keeping each crop's collate for the oracle network
     crops = []
-    orig = multiscale_compute
 
-    def spy(*a, **kw):
-        d = orig(*a, **kw)
-        crops.append(d)
-        return d
-    import crfconv_amd.data as D
-    D.multiscale_compute = spy
-    try:
-        vote_scene(smp, net, votes, n_crops, kernel_size=(K,) * 5, generator=torch.Generator().manual_seed(3))
-    finally:
-        D.multiscale_compute = orig
+    def keep(data, logits, point_idx):           # (graphed: `data` is the static batch, overwritten by the next crop)
+        crops.append((data.x.cpu().clone(), [{k: getattr(l, k).cpu().clone() for k in ('pos', 'neighbor_idx', 'sub_idx', 'up_idx')} for l in data.multiscale],
+                      point_idx.reshape(-1).cpu().numpy().copy()))
+    vote_scene(smp, net, votes, n_crops, kernel_size=(K,) * 5, generator=torch.Generator().manual_seed(3), graphed=graphed, on_crop=keep)
     votes.check()
     assert len(crops) == n_crops
-    for d in crops:
+    for x_c, ms, got_idx in crops:
         noise = (torch.randn(3, dtype=torch.float64, generator=gen) * smp.noise_scale).numpy()
         torch.randperm(crop, generator=gen)                                   # (the shuffle: order inside the crop, irrelevant to the votes)
         order, xyz, _ = E.possibility_draw(pts, poss, crop, noise)
-        got_idx = d.point_idx.reshape(-1).cpu().numpy()
         assert np.array_equal(np.sort(got_idx), np.sort(order))               # the same crop
-        ms = [{k: getattr(l, k).cpu() for k in ('pos', 'neighbor_idx', 'sub_idx', 'up_idx')} for l in d.multiscale]
         with torch.no_grad():
-            ref_logits = O.pointconv_resnet(prm, d.x.cpu(), ms, T, False, True)
+            ref_logits = O.pointconv_resnet(prm, x_c, ms, T, False, True)
         E.vote_update(ref_votes, got_idx, E.softmax32(ref_logits.numpy()), 0.98)
     assert np.array_equal(smp.possibility[0].cpu().numpy(), poss)             # float64 possibilities: bit-exact
     got = votes.test_probs[0].cpu().numpy()
