@@ -21,10 +21,46 @@ def _pick_hw_queues():
         _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 
+def _host_cpu_share():
+    """CPUs this process may really run on: the cgroup quota when there is one, else the affinity mask."""
+    n = len(_os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()                       # cgroup v2
+    except (OSError, ValueError):
+        try:
+            quota = open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read().strip()               # cgroup v1
+            period = open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read().strip()
+        except OSError:
+            return n
+    if quota not in ('max', '-1'):
+        n = min(n, max(1, int(quota) // int(period)))
+    return n
+
+
+def _fit_host_threads():
+    """A container that shows all of the host's cores but grants a share of them (cgroup CPU quota; the MI355X boxes of this pool: 16 of
+    128+) gets the WHOLE process throttled for the rest of a scheduler period once its threads have used the quota -- and torch's intra-op
+    pool, sized from the core count, burns it by idle-spinning behind every small host op (the `torch.randperm` / `sort` of an eager
+    collate, of a crop's shuffle).  Measured (`scratch/sync_probe.py`): one call in eight of an eager crop loop took 65-90 ms instead of
+    1-6 ms; 16 crops of config 5 in 800 ms instead of 140.  At import the pool is cut to the quota when it is larger (never raised);
+    CRFCONV_FIT_THREADS=0 leaves it alone."""
+    if _os.environ.get('CRFCONV_FIT_THREADS', '1') == '0':
+        return
+    try:
+        import torch
+        share = _host_cpu_share()
+        if torch.get_num_threads() > share:
+            torch.set_num_threads(max(1, share))
+    except Exception:        # noqa: BLE001  (never let a tuning step break the import)
+        pass
+
+
 _pick_hw_queues()
 
 from . import _lib, data, graph, models, ops, optim, train, utils          # noqa: E402
 from .data import Data, MultiScaleData, multiscale_compute
+
+_fit_host_threads()
 
 __version__ = '0.1.0'
 __all__ = ['models', 'utils', 'ops', 'optim', 'train', 'graph', 'data', 'Data', 'MultiScaleData', 'multiscale_compute']

@@ -259,9 +259,12 @@ def test_block_resident_meanfield_is_chosen_for_local_tables_only():
     small = NeighborTable(_local_table(1, 4096, 16, 3, 50).to(DEV), 4096)
     assert ops.state.mf_block == 'auto'
     # the first question about a table leaves the measurement in flight and answers 'per-step launches' (no host synchronisation); the second reads it
-    assert _block_rows(near, B * N, 8, 1, 3) == 0 and ('block_locality_pending', 640) in near.cache
-    assert _block_rows(near, B * N, 8, 1, 3) == 640 and near.cache[('block_locality', 640)] > 0.7 and ('block_locality_pending', 640) not in near.cache
-    assert _block_rows(far, B * N, 8, 1, 3) == 0 and _block_rows(far, B * N, 8, 1, 3) == 0 and far.cache[('block_locality', 640)] < 0.05
+    from crfconv_amd import _lib
+    rows = _lib.load().crfconv_meanfield_forward_block_rows(B * N, 8, 16, 1, 3)
+    assert rows > 0
+    assert _block_rows(near, B * N, 8, 1, 3) == 0 and ('block_locality_pending', rows) in near.cache
+    assert _block_rows(near, B * N, 8, 1, 3) == rows and near.cache[('block_locality', rows)] > 0.7 and ('block_locality_pending', rows) not in near.cache
+    assert _block_rows(far, B * N, 8, 1, 3) == 0 and _block_rows(far, B * N, 8, 1, 3) == 0 and far.cache[('block_locality', rows)] < 0.05
     assert _block_rows(small, 4096, 8, 1, 3) == 0 and _block_rows(near, B * N, 16, 1, 3) == 0 and _block_rows(near, B * N, 8, 1, 0) == 0
 
 
