@@ -84,10 +84,13 @@ def config_pipelines(dev):
     raw = (torch.rand(2 * n_scene, 3, generator=g) * torch.tensor([60.0, 60.0, 15.0])).to(dev)
     net = models.PointConvBig(6, C, use_crf=True, steps=T).to(dev).eval()
 
-    def run(timings, graphed=False):
+    cache = {}
+
+    def run(timings, graphed=False, keep=False):
         smp = PossibilitySampler([pts], rgb=[rgb], num_points=n_crop, split='test', generator=torch.Generator().manual_seed(51))
         votes = VoteAccumulator([n_scene], C, device=dev)
-        vote_scene(smp, net, votes, n_crops, kernel_size=(K,) * 5, generator=torch.Generator().manual_seed(52), timings=timings, graphed=graphed)
+        vote_scene(smp, net, votes, n_crops, kernel_size=(K,) * 5, generator=torch.Generator().manual_seed(52), timings=timings, graphed=graphed,
+                   graph_cache=cache if keep else None)
         return votes
     run(None)                                              # warm-up (allocator, lazily built tables, kernel modules)
     torch.cuda.synchronize()
@@ -106,6 +109,12 @@ def config_pipelines(dev):
     stages_g = {}
     run(stages_g, graphed=True)
     del votes_g
+    run(None, graphed=True, keep=True)                     # ... and with the graphs kept across scenes (graph_cache): no capture in the timed run
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(None, graphed=True, keep=True)
+    torch.cuda.synchronize()
+    t_loop_gk = time.perf_counter() - t0
     t0 = time.perf_counter()
     proj = nearest_neighbors.knn_batch_device(pts.unsqueeze(0), raw.unsqueeze(0), 1).reshape(-1)      # offline in the reference (sklearn KDTree.query)
     torch.cuda.synchronize()
@@ -122,12 +131,13 @@ def config_pipelines(dev):
         'scene_points_per_s_M': n_scene / (t_loop + t_project) / 1e6,
         'graphed_loop_ms': t_loop_g * 1e3, 'graphed_scene_points_per_s_M': n_scene / (t_loop_g + t_project) / 1e6,
         'graphed_stage_ms_total_synchronised': stages_g,
+        'graphed_cached_loop_ms': t_loop_gk * 1e3, 'graphed_cached_scene_points_per_s_M': n_scene / (t_loop_gk + t_project) / 1e6,
         'stage_ms_per_crop_synchronised': {k: v / n_crops for k, v in stages.items()},
         'project_ms': t_project * 1e3, 'raw_points_projected': int(raw.shape[0]), 'projection_index_ms_offline': t_proj_idx * 1e3,
         'scene_fraction_voted': covered, 'labels_histogram': torch.bincount(labels.long(), minlength=C + 1).tolist(),
         'what': 'sampler -> multiscale_compute(K=32) -> PointConvBig(T=5).eval() -> votes for 16 crops (eager, B = 1 per crop as the sampler yields '
                 'them), then the arg-max re-projection onto a raw cloud; graphed_*: vote_scene(graphed=True) -- the first crop runs eagerly and captures, '
-                'crops 2 .. 16 are two replays each, the capture included in graphed_loop_ms; loop_ms is wall time without per-stage synchronisation, the stage '
+                'crops 2 .. 16 are two replays each, the capture included in graphed_loop_ms (graphed_cached_*: graphs kept across scenes, graph_cache=, no capture); loop_ms is wall time without per-stage synchronisation, the stage '
                 'figures come from a second run that synchronises around every stage; scene_points_per_s = scene points / (loop + projection)'}
     del net, votes
     # C3: one scan, collate + network

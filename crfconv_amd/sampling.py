@@ -226,7 +226,7 @@ class _GraphedCrops:
 
 
 def vote_scene(sampler, net, votes, n_crops, kernel_size=(16, 16, 16, 16, 16), ratio=(4, 4, 4, 4, 2), rank=0, world=1, generator=None,
-               timings=None, graphed=False, on_crop=None):
+               timings=None, graphed=False, on_crop=None, graph_cache=None):
     """The inference loop of trainval.py:170-189 on the device for ``n_crops`` crops of the sampler's clouds: crop (possibility
     sampler) -> ``multiscale_compute`` (kNN at every scale) -> ``net`` (eval, no grad) -> soft-max votes into ``votes``.  One crop per
     batch (B = 1: datasets/semantic3d_dataset.py:453-458 yields single crops; the loader's batch dimension only stacks them).
@@ -236,6 +236,7 @@ def vote_scene(sampler, net, votes, n_crops, kernel_size=(16, 16, 16, 16, 16), r
     run through the network by rank i % world only; ``votes.merge()`` afterwards gives every rank the full tables.
     graphed: collate and forward of every crop after the first of its shape as hipGraph replays (_GraphedCrops); the random subsets of the
     coarse levels then come from the collate graph's counter-based draw instead of ``torch.randperm`` (any subset is a valid one).
+    graph_cache: a dict the captured graphs are kept in across calls (same net, same crop shapes: further scenes pay no capture).
     timings: a dict that receives the summed milliseconds per stage (host clock around device-synchronised stages: a diagnostic mode --
     it serialises host and device).  on_crop(data, logits, point_idx): called per crop with the collated batch (static buffers when graphed:
     clone what is to be kept), the logits and the crop's point ids in the batch's row order (tests)."""
@@ -254,7 +255,7 @@ def vote_scene(sampler, net, votes, n_crops, kernel_size=(16, 16, 16, 16, 16), r
         return out
     was_training = net.training
     net.eval()
-    graphs = {}
+    graphs = graph_cache if graph_cache is not None else {}
     try:
         for i in range(n_crops):
             crop = stage('sample', sampler.get_random)
