@@ -135,6 +135,7 @@ SIGNATURES = {
     'crfconv_gemm_stats_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_bn_apply_from_records_jobs': (_i, [_vp, _i, _vp]),
     'crfconv_mlp_small_backward_jobs': (_i, [_vp, _i, _vp, _vp]),
+    'crfconv_mlp_small_backward_jobs_one_launch': (_i, [_vp, _i, _vp, _vp, _vp]),
     'crfconv_mlp_small_backward_workspace': (_sz, [_i64, _i]),
     'crfconv_mlp_small_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'crfconv_gemm_stat_records': (_sz, [_i64]),

@@ -36,6 +36,9 @@ using gf32x4 = __attribute__((ext_vector_type(4))) float;
 #ifndef GM_PF_
 #define GM_PF_ 2
 #endif
+#ifndef GM_WAIT_SLEEP_
+#define GM_WAIT_SLEEP_ 4       // s_sleep argument (64 clocks each) between two polls of an in-launch wait
+#endif
 constexpr int GM_BLOCK = 256, GM_BK = GM_BK_;      // k columns per chunk (a multiple of 16)
 constexpr int GM_PF = GM_PF_;                      // operand chunks in flight per workgroup (register sets; even)
 static_assert(GM_PF >= 2 && GM_PF % 2 == 0, "an even number of register sets (the LDS buffers alternate)");
@@ -69,12 +72,19 @@ struct GemmPro {
     const float* fin;          // [2][K]: sum g1 / M | sum g1 yh / M (zeros for an eval-mode BatchNorm), left by the tile-sum launch
     float slope;
     float* gY;                 // [M, K] out
+    // one-launch form (mlp_small_bwd_jobs_kernel): `fin` is written by tile-sum workgroups of the SAME launch.  sync: the job slot's wait
+    // block (gridsync.hpp WL_*: replicas of the finished-slab count -- wait for `need` --, exit tickets of the `nprod` product workgroups,
+    // the last of which zeroes the block); fail: the sticky word of gridsync.hpp.  sync == nullptr: `fin` was left by an earlier launch.
+    unsigned* sync = nullptr;
+    unsigned need = 0, nprod = 0;
+    unsigned* fail = nullptr;
 };
+constexpr int GM_PRO_LDS = 6 * GM_PRO_MAXK + 4;     // a | b | mean | rstd | sum g1 / M | sum g1 yh / M | one flag word
 
 template <int WM, int WN, int WR, int WC, bool BNK, bool PRO>
 constexpr int gemm_lds_floats() {
     constexpr int BM = 16 * WM * WR, BN = 16 * WN * WC;
-    return (PRO ? 6 * GM_PRO_MAXK : 0) + 2 * BM * (GM_BK + 4) + 2 * (BNK ? BN * (GM_BK + 4) : GM_BK * (BN + 4));
+    return (PRO ? GM_PRO_LDS : 0) + 2 * BM * (GM_BK + 4) + 2 * (BNK ? BN * (GM_BK + 4) : GM_BK * (BN + 4));
 }
 
 // STATS form (crfconv_gemm_stats): the epilogue also leaves BatchNorm statistic records of the tile it holds -- one
@@ -85,7 +95,8 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const flo
                                           const float* __restrict__ bias, const float* __restrict__ addend,
                                           int M, int N, int K, float* __restrict__ C, const GemmPro& pro,
                                           float* __restrict__ stat_rec, const unsigned bx, const unsigned by,
-                                          float* __restrict__ lds /*gemm_lds_floats<...>() floats, 16-byte aligned: the kernel's ONE buffer*/) {
+                                          float* __restrict__ lds /*gemm_lds_floats<...>() floats, 16-byte aligned: the kernel's ONE buffer*/,
+                                          const unsigned gridx = 0 /*PRO with pro.sync: row tiles of the job*/) {
     static_assert(WR * WC * WAVE == GM_BLOCK, "four wavefronts");
     static_assert(!PRO || (VEC && !BNK), "the prologue form is the dX product of aligned widths");
     constexpr int BM = 16 * WM * WR, BN = 16 * WN * WC;
@@ -97,8 +108,8 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const flo
     constexpr int PA = (NA4 + GM_BLOCK - 1) / GM_BLOCK, PB = (NB4 + GM_BLOCK - 1) / GM_BLOCK;
     // a kernel that serves several tile classes (the job forms) owns one LDS buffer of the largest: static arrays here would add up
     float* const sPro = lds;                            // PRO: a | b | mean | rstd | sum g1 / M | sum g1 yh / M
-    float (*sA)[TA] = reinterpret_cast<float (*)[TA]>(lds + (PRO ? 6 * GM_PRO_MAXK : 0));
-    float (*sB)[TB] = reinterpret_cast<float (*)[TB]>(lds + (PRO ? 6 * GM_PRO_MAXK : 0) + 2 * TA);
+    float (*sA)[TA] = reinterpret_cast<float (*)[TA]>(lds + (PRO ? GM_PRO_LDS : 0));
+    float (*sB)[TB] = reinterpret_cast<float (*)[TB]>(lds + (PRO ? GM_PRO_LDS : 0) + 2 * TA);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rr = lane & 15, g = lane >> 4;
     const int wr = wave / WC, wc = wave - wr * WC;
@@ -224,8 +235,39 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const flo
             sPro[GM_PRO_MAXK + k] = pro.coef[K + k];
             sPro[2 * GM_PRO_MAXK + k] = pro.coef[2 * K + k];
             sPro[3 * GM_PRO_MAXK + k] = pro.coef[3 * K + k];
-            sPro[4 * GM_PRO_MAXK + k] = pro.fin[k];
-            sPro[5 * GM_PRO_MAXK + k] = pro.fin[K + k];
+        }
+        if (pro.sync == nullptr) {
+            for (int k = threadIdx.x; k < K; k += GM_BLOCK) {
+                sPro[4 * GM_PRO_MAXK + k] = pro.fin[k];
+                sPro[5 * GM_PRO_MAXK + k] = pro.fin[K + k];
+            }
+        } else {
+            // the two channel means come from tile-sum workgroups of this launch (lower workgroup indices: dispatched before this one, they
+            // wait for nobody): thread 0 polls its replica of the job's slab count, bounded like the grid barrier's spin
+            int* const s_ok = reinterpret_cast<int*>(sPro + 6 * GM_PRO_MAXK);
+            if (threadIdx.x == 0) {
+                int ok = 1;
+                unsigned spins = 0;
+                const unsigned* rep = pro.sync + ((bx + by * 7u) % (unsigned)WL_REPL) * FW_LINE;
+                while (__hip_atomic_load(rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pro.need) {
+                    __builtin_amdgcn_s_sleep(GM_WAIT_SLEEP_);
+                    if (++spins > FW_SPIN_LIMIT) {
+                        __hip_atomic_store(pro.fail, 0x300u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+                *s_ok = ok;
+            }
+            __syncthreads();
+            const bool ok = *s_ok != 0;
+            const __amdgpu_buffer_rsrc_t fr = make_rsrc(pro.fin, 2 * K * 4);         // written write-through on another CU: read past L2
+            for (int k = threadIdx.x; k < K; k += GM_BLOCK) {
+                const float c2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(fr, 4 * k, 0, 16));
+                const float c3 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(fr, 4 * (K + k), 0, 16));
+                sPro[4 * GM_PRO_MAXK + k] = ok ? c2 : __builtin_nanf("");            // a spin that gave up poisons this workgroup's tiles
+                sPro[5 * GM_PRO_MAXK + k] = c3;
+            }
         }
         __syncthreads();
     }
@@ -297,6 +339,24 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const flo
                 if (n + 1 < N) cp[1] = o.y;
                 if (n + 2 < N) cp[2] = o.z;
                 if (n + 3 < N) cp[3] = o.w;
+            }
+        }
+    }
+    if constexpr (PRO) {
+        // exit tickets in two levels (a burst on one word is served one by one, ~7 ns each); the job's last product workgroup out zeroes
+        // the replicas for the next launch -- every other one has left its wait by then
+        if (pro.sync != nullptr && threadIdx.x == 0) {
+            const unsigned local = bx + by * gridx, g = local % (unsigned)WL_GROUPS;
+            const unsigned n_in_group = pro.nprod / WL_GROUPS + (g < pro.nprod % WL_GROUPS ? 1u : 0u);
+            unsigned* gt = pro.sync + (WL_REPL + g) * FW_LINE;
+            if (__hip_atomic_fetch_add(gt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == n_in_group) {
+                __hip_atomic_store(gt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned* top = pro.sync + (WL_REPL + WL_GROUPS) * FW_LINE;
+                const unsigned groups = pro.nprod < (unsigned)WL_GROUPS ? pro.nprod : (unsigned)WL_GROUPS;
+                if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == groups) {
+                    __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int r = 0; r < WL_REPL; ++r) __hip_atomic_store(pro.sync + r * FW_LINE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     }
@@ -383,10 +443,10 @@ __global__ __launch_bounds__(GM_BLOCK) void gemm_pro_jobs_kernel(const GemmProJo
     __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<1, 2, 2, 2, false, true>()];
     if (uni(t.wide[j]))
         gemm_tile<1, 2, 2, 2, false, true, true, false>(uni(t.A[j]), uni(t.B[j]), nullptr, uni(t.addend[j]), uni(t.M[j]), uni(t.N[j]), uni(t.K[j]), uni(t.C[j]),
-                                                        pro, nullptr, bx, by, lds);
+                                                        pro, nullptr, bx, by, lds, tx);
     else
         gemm_tile<1, 1, 2, 2, false, true, true, false>(uni(t.A[j]), uni(t.B[j]), nullptr, uni(t.addend[j]), uni(t.M[j]), uni(t.N[j]), uni(t.K[j]), uni(t.C[j]),
-                                                        pro, nullptr, bx, by, lds);
+                                                        pro, nullptr, bx, by, lds, tx);
 }
 
 }  // namespace crf
@@ -406,14 +466,16 @@ struct TileSumFin {
     float* fin;                // [2][K]
     float* dgamma;             // [K]
     float* dbeta;              // [K]
+    unsigned* done = nullptr;  // one-launch form: the job's slab count (GemmPro::sync[0]); `fin` then goes out write-through
 };
+struct TileSumLds { float red[16][2][64]; int last; };
 typedef unsigned int bt_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void bn_bwd_tile_sums_body(const float* __restrict__ gA, const float* __restrict__ Y,
                                                        const float* __restrict__ coef, int M, int K, int tile_rows,
                                                        float slope, double* __restrict__ partial, const int bx, const int by,
-                                                       const TileSumFin f) {
-    __shared__ float s_red[16][2][BT_CH];
-    __shared__ int s_last;
+                                                       const TileSumFin f, TileSumLds& L) {
+    float (&s_red)[16][2][64] = L.red;
+    int& s_last = L.last;
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = by * BT_CH + 4 * cq;
     const int row0 = bx * tile_rows;
@@ -469,7 +531,8 @@ __device__ __forceinline__ void bn_bwd_tile_sums_body(const float* __restrict__ 
         s_last = last;
     }
     __syncthreads();
-    if (!s_last || !mine) return;
+    if (!s_last) return;
+    if (mine) {
     // the row-tile partials of this thread's (sum, channel) in tile order, all loads of a 24-tile round in flight (one round at <= 3072
     // rows): the order -- hence every bit -- of the sums the product launch used to form per workgroup
     const int cg = by * BT_CH + ch;
@@ -487,7 +550,15 @@ __device__ __forceinline__ void bn_bwd_tile_sums_body(const float* __restrict__ 
         for (int u = 0; u < 24; ++u) tot += v[u];
     }
     (which == 0 ? f.dbeta : f.dgamma)[cg] = (float)tot;
-    f.fin[which * K + cg] = f.training ? (float)(tot * (double)f.inv_m) : 0.f;
+    const float mean = f.training ? (float)(tot * (double)f.inv_m) : 0.f;
+    if (f.done == nullptr) f.fin[which * K + cg] = mean;
+    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mean), make_rsrc(f.fin, 2 * K * 4), 4 * (which * K + cg), 0, 16);
+    }
+    if (f.done != nullptr) {                             // the product workgroups of this launch wait for the job's slabs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x < WL_REPL) __hip_atomic_fetch_add(f.done + threadIdx.x * FW_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 struct TileSumJobs {
@@ -500,7 +571,7 @@ struct TileSumJobs {
     int njobs;
 };
 constexpr int BT_SLABS = GM_PRO_MAXK / BT_CH;      // column slabs of a job at most (8): job j, slab s draws on ticket line 8 j + s
-__device__ __forceinline__ void bn_bwd_tile_sums_job(const TileSumJobs& t, const int blk) {
+__device__ __forceinline__ void bn_bwd_tile_sums_job(const TileSumJobs& t, const int blk, TileSumLds& L, unsigned* const* done = nullptr) {
     int j = 0;
     while (j + 1 < t.njobs && t.blk_base[j + 1] <= blk) ++j;
     const int local = blk - t.blk_base[j];
@@ -509,10 +580,45 @@ __device__ __forceinline__ void bn_bwd_tile_sums_job(const TileSumJobs& t, const
     TileSumFin f;
     f.ticket = uni(t.ticket) + (j * BT_SLABS + by) * FW_LINE; f.ntile = ntile; f.training = uni(t.training[j]); f.inv_m = uni(t.inv_m[j]);
     f.fin = uni(t.fin[j]); f.dgamma = uni(t.dgamma[j]); f.dbeta = uni(t.dbeta[j]);
+    f.done = done != nullptr ? uni(done[j]) : nullptr;
     bn_bwd_tile_sums_body(uni(t.gA[j]), uni(t.Y[j]), uni(t.coef[j]), uni(t.M[j]), uni(t.K[j]), uni(t.tile_rows[j]), uni(t.slope[j]), uni(t.partial[j]),
-                          bx, by, f);
+                          bx, by, f, L);
 }
-__global__ __launch_bounds__(256) void bn_bwd_tile_sums_jobs_kernel(const TileSumJobs t) { bn_bwd_tile_sums_job(t, (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void bn_bwd_tile_sums_jobs_kernel(const TileSumJobs t) {
+    __shared__ TileSumLds L;
+    bn_bwd_tile_sums_job(t, (int)blockIdx.x, L);
+}
+
+// BOTH launches of crfconv_mlp_small_backward_jobs as ONE (round 6): workgroups 0 .. nsum - 1 are the tile-sum workgroups, the rest the
+// product's.  A product workgroup requests its first operand chunks, then waits until its job's column slabs have left the two channel
+// means (GemmPro::sync) -- the tile-sum workgroups have the lower indices, are dispatched first and wait for nobody, so the wait ends
+// whatever part of the grid is resident.  What it saves is the launch boundary (drain, cache write-back, dispatch: 4-5 us of stream time
+// on launches whose own work is 2-6 us, 21 times per training step).  Same arithmetic in the same order: results are bit-identical to
+// the two launches'.
+struct SmallBwdSync { unsigned* done[GG_MAX]; int nsum; };
+__global__ __launch_bounds__(GM_BLOCK) void mlp_small_bwd_jobs_kernel(const TileSumJobs ts, const GemmProJobs t, const SmallBwdSync sy) {
+    __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<1, 2, 2, 2, false, true>()];
+    static_assert(sizeof(TileSumLds) <= sizeof(lds), "the tile-sum workgroups use the product's buffer");
+    if ((int)blockIdx.x < sy.nsum) {
+        bn_bwd_tile_sums_job(ts, (int)blockIdx.x, *reinterpret_cast<TileSumLds*>(lds), sy.done);
+        return;
+    }
+    const int blk = (int)blockIdx.x - sy.nsum;
+    int j = 0;
+    while (j + 1 < t.njobs && t.tile_base[j + 1] <= blk) ++j;
+    const unsigned local = (unsigned)(blk - t.tile_base[j]);
+    GemmPro pro;
+    pro.Y = uni(t.pro[j].Y); pro.coef = uni(t.pro[j].coef); pro.fin = uni(t.pro[j].fin); pro.slope = uni(t.pro[j].slope); pro.gY = uni(t.pro[j].gY);
+    pro.sync = uni(t.pro[j].sync); pro.need = (unsigned)uni((int)t.pro[j].need); pro.nprod = (unsigned)uni((int)t.pro[j].nprod); pro.fail = uni(t.pro[j].fail);
+    const unsigned tx = (unsigned)uni(t.tiles_x[j]);
+    const unsigned bx = (unsigned)uni((int)(local % tx)), by = (unsigned)uni((int)(local / tx));
+    if (uni(t.wide[j]))
+        gemm_tile<1, 2, 2, 2, false, true, true, false>(uni(t.A[j]), uni(t.B[j]), nullptr, uni(t.addend[j]), uni(t.M[j]), uni(t.N[j]), uni(t.K[j]), uni(t.C[j]),
+                                                        pro, nullptr, bx, by, lds, tx);
+    else
+        gemm_tile<1, 1, 2, 2, false, true, true, false>(uni(t.A[j]), uni(t.B[j]), nullptr, uni(t.addend[j]), uni(t.M[j]), uni(t.N[j]), uni(t.K[j]), uni(t.C[j]),
+                                                        pro, nullptr, bx, by, lds, tx);
+}
 }  // namespace crf
 
 extern "C" int crfconv_mlp_small_backward_supported(int64_t M, int Ci, int Co) {
@@ -555,10 +661,24 @@ extern "C" int crfconv_mlp_small_backward(const float* gA, const float* Y, const
 // The backward of up to 4 INDEPENDENT coarse-level MLP blocks (crf_mlp_bwd_job: the arguments of crfconv_mlp_small_backward per
 // block) in TWO launches for all of them: the row-tile sums of every block, then every block's dX product.  Results per block are
 // bit-identical to crfconv_mlp_small_backward's.
+static int mlp_small_backward_jobs_impl(const crf_mlp_bwd_job* jobs, int njobs, unsigned* ticket, unsigned* sync_ws, void* stream);
 extern "C" int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int njobs, unsigned* ticket, void* stream) {
+    return mlp_small_backward_jobs_impl(jobs, njobs, ticket, nullptr, stream);
+}
+// The same as ONE launch (mlp_small_bwd_jobs_kernel): the product's workgroups wait inside the launch for the tile-sum workgroups of
+// their job.  sync_ws: the barrier words of crfconv_gridsync_workspace() (zero, left zero; its sticky failure word reports a wait that
+// gave up -- that launch's dX / gY are NaN).  Bit-identical results.
+extern "C" int crfconv_mlp_small_backward_jobs_one_launch(const crf_mlp_bwd_job* jobs, int njobs, unsigned* ticket, unsigned* sync_ws, void* stream) {
+    CRF_REQUIRE(sync_ws != nullptr, CRF_ERR_ARG, "null barrier workspace");
+    return mlp_small_backward_jobs_impl(jobs, njobs, ticket, sync_ws, stream);
+}
+static int mlp_small_backward_jobs_impl(const crf_mlp_bwd_job* jobs, int njobs, unsigned* ticket, unsigned* sync_ws, void* stream) {
     CRF_REQUIRE(jobs && ticket && njobs >= 1 && njobs <= crf::GG_MAX, CRF_ERR_ARG, "1 .. %d jobs (got %d) and the ticket words", crf::GG_MAX, njobs);
     crf::TileSumJobs ts;
     crf::GemmProJobs gp;
+    crf::SmallBwdSync sy;
+    for (int j = 0; j < crf::GG_MAX; ++j) sy.done[j] = nullptr;
+    sy.nsum = 0;
     int64_t blocks = 0, tiles = 0;
     for (int j = 0; j <= crf::GG_MAX; ++j) {
         ts.blk_base[j] = (int)blocks;
@@ -589,13 +709,27 @@ extern "C" int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int 
         gp.A[j] = b.gA; gp.B[j] = b.W; gp.addend[j] = b.addend; gp.C[j] = b.dX; gp.pro[j] = pro; gp.M[j] = (int)b.M; gp.N[j] = b.Ci; gp.K[j] = b.Co;
         gp.tiles_x[j] = (int)((b.M + 31) / 32);
         gp.wide[j] = crf::gm_wide(b.M, b.Ci) ? 1 : 0;
-        tiles += (int64_t)gp.tiles_x[j] * ((b.Ci + (gp.wide[j] ? 63 : 31)) / (gp.wide[j] ? 64 : 32));
-        CRF_REQUIRE(tiles < ((int64_t)1 << 31) && blocks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many tiles in one batch");
+        const int64_t jt = (int64_t)gp.tiles_x[j] * ((b.Ci + (gp.wide[j] ? 63 : 31)) / (gp.wide[j] ? 64 : 32));
+        tiles += jt;
+        CRF_REQUIRE(tiles + blocks < ((int64_t)1 << 31), CRF_ERR_UNSUPPORTED, "too many tiles in one batch");
+        if (sync_ws != nullptr) {                       // the job slot's wait block behind the barrier words
+            gp.pro[j].sync = sync_ws + (crf::FW_WAIT + j * crf::WL_LINES) * crf::FW_LINE;
+            gp.pro[j].need = (unsigned)((b.Co + crf::BT_CH - 1) / crf::BT_CH);
+            gp.pro[j].nprod = (unsigned)jt;
+            gp.pro[j].fail = sync_ws + crf::FW_FAIL * crf::FW_LINE;
+            sy.done[j] = gp.pro[j].sync;
+        }
     }
     ts.njobs = njobs;
     ts.ticket = ticket;
     gp.njobs = njobs;
     hipStream_t st = crf::as_stream(stream);
+    if (sync_ws != nullptr) {
+        sy.nsum = (int)blocks;
+        hipLaunchKernelGGL(crf::mlp_small_bwd_jobs_kernel, dim3((unsigned)(blocks + tiles)), dim3(crf::GM_BLOCK), 0, st, ts, gp, sy);
+        CRF_LAUNCH_CHECK();
+        return CRF_OK;
+    }
     hipLaunchKernelGGL(crf::bn_bwd_tile_sums_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ts);
     CRF_LAUNCH_CHECK();
     hipLaunchKernelGGL(crf::gemm_pro_jobs_kernel, dim3((unsigned)tiles), dim3(crf::GM_BLOCK), 0, st, gp);

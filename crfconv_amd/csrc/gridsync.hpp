@@ -14,6 +14,11 @@ namespace crf {
 
 constexpr int FW_LINE = 32;                   // words per 128-byte line
 constexpr int FW_CNT = 0, FW_TOP = 8, FW_GEN = 9, FW_FAIL = 17, FW_EXIT = 18, FW_WORDS = 19 * FW_LINE;
+// In-launch waits of one producer / consumer pair per job slot (gemm.hip mlp_small_bwd_jobs_kernel): behind the barrier words, per job slot
+// (4) a block of WL_LINES lines -- WL_REPL replicas of the producers' count (a consumer polls replica index % WL_REPL: ~30 pollers per
+// line instead of 1 000), WL_GROUPS exit-ticket lines and their top word (the last consumer out zeroes the block).
+constexpr int WL_REPL = 32, WL_GROUPS = 16, WL_LINES = 64, WL_JOBS = 4, FW_WAIT = 19;
+constexpr int FW_TOTAL_WORDS = (FW_WAIT + WL_JOBS * WL_LINES) * FW_LINE;
 constexpr unsigned FW_SPIN_LIMIT = 1u << 21;  // ~1 s: a stranded workgroup gives up with a code instead of hanging
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));

@@ -281,7 +281,7 @@ static int mlp_small_tco(int64_t M, int Co, int cap) {
 
 using namespace crf;
 
-extern "C" size_t crfconv_gridsync_workspace(void) { return FW_WORDS * sizeof(unsigned); }
+extern "C" size_t crfconv_gridsync_workspace(void) { return FW_TOTAL_WORDS * sizeof(unsigned); }
 
 // index (in 32-bit words) of the sticky failure word inside a barrier workspace: non-zero after a launch whose grid
 // barrier gave up (0x100 | phase).  The host reads it once per step / every few steps and raises.

@@ -421,6 +421,16 @@ def mlp_block_pool(x, W, bn, table, fork=False):
 
 
 
+def _small_bwd_jobs(jobs, n, dev, st):
+    """The BatchNorm(+LeakyReLU) backward + dX product of up to four coarse-level blocks: ONE launch whose product workgroups wait for
+    its tile-sum workgroups (crfconv_mlp_small_backward_jobs_one_launch), or -- state.small_bwd_one_launch off, or after a wait inside
+    a one-launch kernel has ever given up (check_gridsync) -- the two launches.  Bit-identical results."""
+    if state.small_bwd_one_launch and not state.small_mlp_disabled:
+        _lib.call('crfconv_mlp_small_backward_jobs_one_launch', ctypes.cast(jobs, ctypes.c_void_p), n, ptr(_ticket(dev)), ptr(gridsync_ws(dev)), st)
+    else:
+        _lib.call('crfconv_mlp_small_backward_jobs', ctypes.cast(jobs, ctypes.c_void_p), n, ptr(_ticket(dev)), st)
+
+
 def _small_bwd(gA, y, coef, W, addend, slope, dgamma, dbeta, need_dx):
     """(gY, dX) of a coarse-level MLP block: BatchNorm(+LeakyReLU) backward and dX = gY W (+ addend) as TWO launches
     (crfconv_mlp_small_backward: tile sums, then the product with gY formed in its operand load), else -- no dX wanted, widths the
@@ -434,8 +444,11 @@ def _small_bwd(gA, y, coef, W, addend, slope, dgamma, dbeta, need_dx):
         dX = torch.empty((m, ci), dtype=torch.float32, device=dev)
         nbytes = lib.crfconv_mlp_small_backward_workspace(m, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.call('crfconv_mlp_small_backward', ptr(gA), ptr(y), ptr(coef), ptr(W), ptr(None if addend is None else addend.contiguous()),
-                  m, ci, co, 1, float(slope), ptr(gY), ptr(dX), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, ptr(_ticket(dev)), stream_ptr())
+        add = None if addend is None else addend.contiguous()
+        jobs = (_lib.MlpBwdJob * 1)()
+        jobs[0] = _lib.MlpBwdJob(gA.data_ptr(), y.data_ptr(), coef.data_ptr(), W.data_ptr(), None if add is None else add.data_ptr(), m, ci, co, 1,
+                                 float(slope), gY.data_ptr(), dX.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nbytes)
+        _small_bwd_jobs(jobs, 1, dev, stream_ptr())
         return gY, dX
     nbytes = lib.crfconv_bn_workspace(m, co)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -671,7 +684,7 @@ class _MLPSmallGroup(torch.autograd.Function):
             jobs[i] = _lib.MlpBwdJob(gA.data_ptr(), y.data_ptr(), coef.data_ptr(), W.data_ptr(), None if add is None else add.data_ptr(), m, ci, co, 1,
                                      ctx.slopes[i], gY.data_ptr(), dX.data_ptr(), outs[0][0].data_ptr(), outs[1][0].data_ptr(), ws.data_ptr(), nbytes)
             per.append((x, W, gY, dX, outs, need_dx, (gA, add, ws)))
-        _lib.call('crfconv_mlp_small_backward_jobs', ctypes.cast(jobs, ctypes.c_void_p), n, ptr(_ticket(per[0][0].device)), st)
+        _small_bwd_jobs(jobs, n, per[0][0].device, st)
         rets = [None]
         dxs = [p[3] if p[5] else None for p in per]
         if ctx.shared and dxs[0] is not None and dxs[1] is not None:

@@ -618,6 +618,11 @@ typedef struct { const float* gA; const float* Y; const float* coef; const float
                  int training; float slope; float* gY; float* dX; float* dgamma; float* dbeta; void* workspace; size_t workspace_bytes;
 } crf_mlp_bwd_job;
 int crfconv_mlp_small_backward_jobs(const crf_mlp_bwd_job* jobs, int njobs, unsigned* ticket, crf_stream_t stream);
+/* The same in ONE launch (round 6): tile-sum workgroups first, the product's workgroups wait inside the launch for their job's channel
+ * means (bounded; a wait that gives up sets the sticky failure word of sync_ws and leaves NaN in that tile).  sync_ws: the zeroed words of
+ * crfconv_gridsync_workspace(), left zero.  Bit-identical to the two launches. */
+int crfconv_mlp_small_backward_jobs_one_launch(const crf_mlp_bwd_job* jobs, int njobs, unsigned* ticket, unsigned* sync_ws,
+                                               crf_stream_t stream);
 /* Up to 8 independent products C_j = A_j B_j (B_j [K_j, N_j]; N, K multiples of 4) per launch -- the g_h1 = g_h2 W2 products of all wide
  * PointConv layers of a backward pass; same tiles and summation order as crfconv_gemm on each.  jobs is a host array. */
 typedef struct { const float* A; const float* B; float* C; int64_t M; int N; int K; } crf_gemm_job;

@@ -1820,6 +1820,82 @@ def test_mlp_small_backward_two_launch_form(M, Ci, Co, slope, addend):
     assert_close(gY, gY0, 1e-5, 'gY vs bn_backward')
     assert_close(dX, ops._gemm(gY0, W, addend=add), 1e-5, 'dX vs bn_backward + gemm')
     assert torch.equal(ops._small_bwd(gA, y, coef, W, add, slope, dgamma, dbeta, True)[1], dX)       # reproducible
+    # the one-launch form (the default: product workgroups wait inside the launch for the tile sums) against the two launches: every bit
+    dg2, db2 = torch.empty(Co, device=DEV), torch.empty(Co, device=DEV)
+    assert ops.state.small_bwd_one_launch
+    ops.state.small_bwd_one_launch = False
+    try:
+        gY2, dX2 = ops._small_bwd(gA, y, coef, W, add, slope, dg2, db2, True)
+    finally:
+        ops.state.small_bwd_one_launch = True
+    assert torch.equal(gY2, gY) and torch.equal(dX2, dX) and torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
+    assert int(ops.gridsync_ws(DEV).abs().sum()) == 0         # wait words left zero, no failure code
+
+
+def test_mlp_small_backward_one_launch_four_jobs_replayed():
+    """crfconv_mlp_small_backward_jobs_one_launch with four jobs of different shapes (1 .. 8 column slabs, narrow and wide product tiles),
+    launched twenty times back to back and replayed from a hipGraph: bit-identical to crfconv_mlp_small_backward_jobs every time, the
+    wait words zero afterwards."""
+    import ctypes
+    from crfconv_amd import ops, _lib
+    from crfconv_amd.ops import ptr, stream_ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77)
+    shapes = [(10240, 128, 256), (2560, 256, 512), (640, 512, 64), (333, 36, 132)]
+
+    def problem(M, Ci, Co):
+        y = (torch.randn(M, Co, generator=g) * 1.5 + 0.3).to(DEV)
+        gA = torch.randn(M, Co, generator=g).to(DEV)
+        W = (torch.randn(Co, Ci, generator=g) / Co ** 0.5).to(DEV)
+        add = torch.randn(M, Ci, generator=g).to(DEV)
+        mean, var = y.double().mean(0), y.double().var(0, unbiased=False)
+        rstd = 1.0 / torch.sqrt(var + 1e-5)
+        coef = torch.cat([rstd, -rstd * mean, mean, rstd]).float().contiguous()
+        return y, gA, W, add, coef
+    probs = [problem(*s_) for s_ in shapes]
+
+    def outputs():
+        return [(torch.full((M, Co), float('nan'), device=DEV), torch.full((M, Ci), float('nan'), device=DEV), torch.empty(Co, device=DEV),
+                 torch.empty(Co, device=DEV), torch.empty(lib.crfconv_mlp_small_backward_workspace(M, Co), dtype=torch.uint8, device=DEV))
+                for M, Ci, Co in shapes]
+
+    def jobs_of(outs):
+        jobs = (_lib.MlpBwdJob * 4)()
+        for i, ((M, Ci, Co), (y, gA, W, add, coef), (gY, dX, dg, db, ws)) in enumerate(zip(shapes, probs, outs)):
+            jobs[i] = _lib.MlpBwdJob(gA.data_ptr(), y.data_ptr(), coef.data_ptr(), W.data_ptr(), add.data_ptr(), M, Ci, Co, 1, 0.1,
+                                     gY.data_ptr(), dX.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel())
+        return jobs
+    ref = outputs()
+    _lib.call('crfconv_mlp_small_backward_jobs', ctypes.cast(jobs_of(ref), ctypes.c_void_p), 4, ptr(ops._ticket(DEV)), stream_ptr())
+    ws = ops.gridsync_ws(DEV)
+    for trial in range(20):
+        got = outputs()
+        _lib.call('crfconv_mlp_small_backward_jobs_one_launch', ctypes.cast(jobs_of(got), ctypes.c_void_p), 4, ptr(ops._ticket(DEV)), ptr(ws), stream_ptr())
+        for r, o in zip(ref, got):
+            for a, b in zip(r[:4], o[:4]):
+                assert torch.equal(a, b), trial
+    assert int(ws.abs().sum()) == 0
+    got = outputs()
+    jb = jobs_of(got)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _lib.call('crfconv_mlp_small_backward_jobs_one_launch', ctypes.cast(jb, ctypes.c_void_p), 4, ptr(ops._ticket(DEV)), ptr(ws), stream_ptr())
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        wsc = ops.gridsync_ws(DEV)
+        _lib.call('crfconv_mlp_small_backward_jobs_one_launch', ctypes.cast(jb, ctypes.c_void_p), 4, ptr(ops._ticket(DEV)), ptr(wsc), stream_ptr())
+    for trial in range(5):
+        for o in got:
+            o[0].fill_(float('nan'))
+            o[1].fill_(float('nan'))
+        graph.replay()
+        for r, o in zip(ref, got):
+            for a, b in zip(r[:4], o[:4]):
+                assert torch.equal(a, b), ('replay', trial)
+    assert int(wsc.abs().sum()) == 0 and int(ws.abs().sum()) == 0
 
 
 @pytest.mark.parametrize('shared', [False, True])
