@@ -98,6 +98,7 @@ SIGNATURES = {
     'crfconv_mlp_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'crfconv_linear_forward_cat': (_i, [_vp, _vp, _i, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     'crfconv_mlp_dw_jobs': (_i, [_vp, _i, _vp]),
+    'crfconv_mlp_dw_jobs_hosting': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'crfconv_mlp_backward_add': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'crfconv_mlp_backward_cat': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'crfconv_bn_workspace': (_sz, [_i64, _i]),

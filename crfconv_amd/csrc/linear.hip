@@ -702,13 +702,13 @@ __device__ __forceinline__ void crf_matrices_bwd_slab(const float* __restrict__ 
                                                       int H, int row0, float* __restrict__ dc) {
     __shared__ float s_q[64 * 65], s_d[64 * 65];
     __shared__ double s_t[2][CMB_ROWS][65];
-    for (int e = threadIdx.x; e < H * H; e += CMB_BLOCK) {
+    for (int e = threadIdx.x; e < H * H; e += (int)blockDim.x) {              // (a rider in a launch of larger workgroups: mlp_dw_jobs_hosting_kernel)
         const int r = e / H, c = e % H;
         s_q[r * 65 + c] = Q[e];
         s_d[r * 65 + c] = (dQ ? dQ[e] : 0.f) - (dP ? dP[e] : 0.f);            // D
     }
-    const int r = threadIdx.x >> 6, j = threadIdx.x & 63, row = row0 + r;
-    const bool live = row < H && j < H;
+    const int r = (threadIdx.x >> 6) & (CMB_ROWS - 1), j = threadIdx.x & 63, row = row0 + r;
+    const bool live = (int)threadIdx.x < CMB_BLOCK && row < H && j < H;
     if (live) s_t[0][r][j] = (double)cmat[row * H + j];
     __syncthreads();
     double acc = 0.0;
@@ -737,6 +737,26 @@ __global__ __launch_bounds__(CMB_BLOCK) void crf_matrices_bwd_batched_kernel(con
     while (b + 1 < CM_MAX && (int)blockIdx.x >= j.slab_base[b + 1]) ++b;
     crf_matrices_bwd_slab(j.c[b], j.Q_in[b], j.gQ[b], j.gP[b], j.H[b], ((int)blockIdx.x - j.slab_base[b]) * CMB_ROWS, j.dc[b]);
 }
+// mlp_dw_jobs_kernel CARRYING the slabs of crf_matrices_bwd_batched_kernel as its first n_side workgroups (round 6): both are
+// end-of-pass parameter work that nothing waits for; on its own the matrices' backward is a 13 us chain of three dependent float64
+// products on 15 workgroups.  A rider uses the first CMB_BLOCK threads of its (MF_BLOCK-thread) workgroup.
+static_assert(MF_BLOCK >= CMB_BLOCK, "a rider fits the host's workgroup");
+__global__ __launch_bounds__(MF_BLOCK) void mlp_dw_jobs_hosting_kernel(const MlpDwTable t, const CrfMatJobs j, const int n_side) {
+    if ((int)blockIdx.x < n_side) {
+        int b = 0;
+        while (b + 1 < CM_MAX && (int)blockIdx.x >= j.slab_base[b + 1]) ++b;
+        crf_matrices_bwd_slab(j.c[b], j.Q_in[b], j.gQ[b], j.gP[b], j.H[b], ((int)blockIdx.x - j.slab_base[b]) * CMB_ROWS, j.dc[b]);
+        return;
+    }
+    const int g = (int)blockIdx.x - n_side;
+    int lo = 0, hi = t.njobs;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t.group_begin[mid] <= g) lo = mid; else hi = mid;
+    }
+    mlp_dw_slots(t.PA[lo], t.PB[lo], t.PG[lo], t.PX[lo], t.nblk[lo], t.coef[lo], (int64_t)t.M[lo], t.Co[lo], t.Ci[lo],
+                 g - t.group_begin[lo], t.dW[lo]);
+}
 }  // namespace crf
 
 extern "C" int crfconv_crf_matrices_batched(const float* const* c, const int* H, int n, float* const* Q, float* const* P,
@@ -752,18 +772,26 @@ extern "C" int crfconv_crf_matrices_batched(const float* const* c, const int* H,
     return CRF_OK;
 }
 
-extern "C" int crfconv_crf_matrices_backward_batched(const float* const* c, const float* const* Q, const float* const* gQ,
-                                                     const float* const* gP, const int* H, int n, float* const* dc,
-                                                     crf_stream_t stream) {
+static int crf_matrices_bwd_jobs(const float* const* c, const float* const* Q, const float* const* gQ, const float* const* gP, const int* H, int n,
+                                 float* const* dc, crf::CrfMatJobs& j, int& nslab) {
     CRF_REQUIRE(c && Q && gQ && gP && H && dc && n >= 1 && n <= crf::CM_MAX, CRF_ERR_ARG, "null pointer or n=%d outside [1, %d]", n, crf::CM_MAX);
-    crf::CrfMatJobs j = {};
+    j = crf::CrfMatJobs();
     for (int i = 0; i < n; ++i) {
         CRF_REQUIRE(c[i] && Q[i] && dc[i] && H[i] >= 1 && H[i] <= 64, CRF_ERR_ARG, "job %d: null pointer or H=%d outside [1, 64]", i, H[i]);
         j.c[i] = c[i]; j.Q_in[i] = Q[i]; j.gQ[i] = gQ[i]; j.gP[i] = gP[i]; j.dc[i] = dc[i]; j.H[i] = H[i];
         j.slab_base[i + 1] = j.slab_base[i] + (H[i] + crf::CMB_ROWS - 1) / crf::CMB_ROWS;
     }
+    nslab = j.slab_base[n];
     for (int i = n; i < crf::CM_MAX; ++i) j.slab_base[i + 1] = 0x7fffffff;      // (never reached by a block index)
-    hipLaunchKernelGGL(crf::crf_matrices_bwd_batched_kernel, dim3((unsigned)j.slab_base[n]), dim3(crf::CMB_BLOCK), 0, crf::as_stream(stream), j);
+    return CRF_OK;
+}
+extern "C" int crfconv_crf_matrices_backward_batched(const float* const* c, const float* const* Q, const float* const* gQ,
+                                                     const float* const* gP, const int* H, int n, float* const* dc,
+                                                     crf_stream_t stream) {
+    crf::CrfMatJobs j;
+    int nslab = 0;
+    if (int rc = crf_matrices_bwd_jobs(c, Q, gQ, gP, H, n, dc, j, nslab)) return rc;
+    hipLaunchKernelGGL(crf::crf_matrices_bwd_batched_kernel, dim3((unsigned)nslab), dim3(crf::CMB_BLOCK), 0, crf::as_stream(stream), j);
     CRF_LAUNCH_CHECK();
     return CRF_OK;
 }
@@ -1684,7 +1712,7 @@ extern "C" int crfconv_mlp_backward_cat(const float* gA, const float* Y, const f
 
 // dW of any number of MLP blocks whose crfconv_mlp_backward(_add / _cat) call was given dW = NULL, from the workspaces those
 // calls left behind (untouched since), in ONE launch.
-extern "C" int crfconv_mlp_dw_jobs(const crf_mlp_dw_job* jobs, int njobs, crf_stream_t stream) {
+static int mlp_dw_jobs_impl(const crf_mlp_dw_job* jobs, int njobs, const crf::CrfMatJobs* side, int nside, crf_stream_t stream) {
     CRF_REQUIRE(jobs || njobs == 0, CRF_ERR_ARG, "null pointer");
     CRF_REQUIRE(njobs >= 0, CRF_ERR_ARG, "njobs=%d < 0", njobs);
     hipStream_t st = crf::as_stream(stream);
@@ -1718,10 +1746,27 @@ extern "C" int crfconv_mlp_dw_jobs(const crf_mlp_dw_job* jobs, int njobs, crf_st
         }
         t.group_begin[crf::MDW_MAX] = (int)total;
         t.njobs = n;
-        hipLaunchKernelGGL(crf::mlp_dw_jobs_kernel, dim3((unsigned)total), dim3(crf::MF_BLOCK), 0, st, t);
+        if (side != nullptr && j0 == 0)
+            hipLaunchKernelGGL(crf::mlp_dw_jobs_hosting_kernel, dim3((unsigned)(total + nside)), dim3(crf::MF_BLOCK), 0, st, t, *side, nside);
+        else
+            hipLaunchKernelGGL(crf::mlp_dw_jobs_kernel, dim3((unsigned)total), dim3(crf::MF_BLOCK), 0, st, t);
         CRF_LAUNCH_CHECK();
     }
     return CRF_OK;
+}
+extern "C" int crfconv_mlp_dw_jobs(const crf_mlp_dw_job* jobs, int njobs, crf_stream_t stream) {
+    return mlp_dw_jobs_impl(jobs, njobs, nullptr, 0, stream);
+}
+// crfconv_mlp_dw_jobs whose (first) launch also CARRIES crfconv_crf_matrices_backward_batched(c, Q, gQ, gP, H, n, dc) as its first
+// workgroups: results of both are those of the two separate calls.
+extern "C" int crfconv_mlp_dw_jobs_hosting(const crf_mlp_dw_job* jobs, int njobs, const float* const* c, const float* const* Q,
+                                           const float* const* gQ, const float* const* gP, const int* H, int n, float* const* dc,
+                                           crf_stream_t stream) {
+    CRF_REQUIRE(njobs >= 1, CRF_ERR_ARG, "a hosting launch needs at least one job of its own (got %d)", njobs);
+    crf::CrfMatJobs j;
+    int nslab = 0;
+    if (int rc = crf_matrices_bwd_jobs(c, Q, gQ, gP, H, n, dc, j, nslab)) return rc;
+    return mlp_dw_jobs_impl(jobs, njobs, &j, nslab, stream);
 }
 
 static int mlp_backward_impl(const float* gA, const float* Y, const float* X, const float* Xb, int xsplit, const float* W,

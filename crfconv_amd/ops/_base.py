@@ -162,6 +162,8 @@ class _State:
     # the two launches of a coarse-level MLP backward (tile sums, dX product) as one whose product workgroups wait for the sums inside
     # the launch (csrc/gemm.hip mlp_small_bwd_jobs_kernel); CRFCONV_SMALL_BWD_TWO_LAUNCHES=1: A/B runs of bench.py
     small_bwd_one_launch = __import__('os').environ.get('CRFCONV_SMALL_BWD_TWO_LAUNCHES') is None
+    # the backward of the CRF layers' matrices as riders of the MLP blocks' end-of-pass weight-gradient launch (defer._flush_mlp_dw)
+    dw_hosts_mats = __import__('os').environ.get('CRFCONV_NO_TAIL_RIDERS') is None
     # below this many rows the tiled product (gemm.hip) and the small-MLP nodes; swept on the step: 4096 -> 4.733 ms, 12288 (the
     # 10 240-row level joins the small forms) -> 4.694 ms, 65536 -> 4.736 ms
     mfma_min_rows = 12288

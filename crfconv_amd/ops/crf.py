@@ -312,14 +312,18 @@ class _CrfMatricesBatched(torch.autograd.Function):
                     return parts[0] if parts else None
                 return torch.stack(parts).sum(0)   # several consumers of one (Q, P) pair: rare, a tiny eager sum
 
-            def launch():
+            def arguments():
+                # (c, Q, gQ, gP, H, n, dc) of crfconv_crf_matrices_backward_batched, and what they point into: the end-of-pass flush
+                # issues the launch -- on its own, or as the riders of the MLP blocks' weight-gradient launch (defer._flush_mlp_dw)
                 gQs = [total(g, [b[0] for b in bufs]) for g, bufs in zip(gQ, parked)]
                 gPs = [total(g, [b[1] for b in bufs]) for g, bufs in zip(gP, parked)]
-                _lib.call('crfconv_crf_matrices_backward_batched', _ptr_array(ccs), _ptr_array(Qs), _ptr_array(gQs), _ptr_array(gPs), Hs, n,
-                          _ptr_array(dcs), stream_ptr())
+                arrays = (_ptr_array(ccs), _ptr_array(Qs), _ptr_array(gQs), _ptr_array(gPs), Hs, n, _ptr_array(dcs))
+                return arrays, (gQs, gPs)
+
+            def install():
                 for prm, (gr, direct) in zip(cparams, outs):
                     _install_grad(prm, gr, direct)
-            _DEFER['late_calls'].append((launch, (ccs, Qs, gQ, gP, dcs, parked)))
+            _DEFER['late_mats'].append((arguments, install, (ccs, Qs, gQ, gP, dcs, parked)))
             _arm_flush()
             return (None,) * (n + 1)
         dcs = [torch.empty_like(c) for c in ccs]

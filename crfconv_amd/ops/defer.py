@@ -5,6 +5,7 @@ import torch
 
 from .. import _lib
 from ..graph import NeighborTable, ptr, require_gpu, stream_ptr
+from ._base import state
 
 # ------------------------------------------------------------------------------ deferred weight gradients
 # Every Linear's dW = G^T X ends in a small "sum the row-slice partials" launch; PointConvBig has 74 of them per
@@ -13,7 +14,8 @@ from ..graph import NeighborTable, ptr, require_gpu, stream_ptr
 # like DDP's) finishes all of them and installs / accumulates ``.grad`` of the weight and bias parameters directly.
 # Opt-in because it bypasses autograd for those leaves: ``torch.autograd.grad(loss, weight)`` sees nothing, and
 # gradient hooks on the weights do not fire.  ``loss.backward()`` + ``param.grad`` behave as usual.
-_DEFER = {'on': False, 'jobs': [], 'partials': [], 'red64': [], 'pc_wide': [], 'tn': [], 'late_calls': [], 'folds': [], 'mlpdw': [], 'armed': False, 'claimed': set()}
+_DEFER = {'on': False, 'jobs': [], 'partials': [], 'red64': [], 'pc_wide': [], 'tn': [], 'late_calls': [], 'late_mats': [], 'folds': [], 'mlpdw': [], 'armed': False,
+          'claimed': set()}
 
 
 class deferred_weight_grads:
@@ -33,7 +35,7 @@ class deferred_weight_grads:
         _DEFER['sink'] = self.sink
         if not self.prev:                 # outermost context: nothing of an earlier (failed) backward may linger
             _DEFER['jobs'], _DEFER['folds'], _DEFER['mlpdw'], _DEFER['armed'], _DEFER['claimed'] = [], [], [], False, set()
-            for k in ('partials', 'red64', 'pc_wide', 'tn', 'late_calls'):
+            for k in ('partials', 'red64', 'pc_wide', 'tn', 'late_calls', 'late_mats'):
                 _DEFER[k] = []
         return self
 
@@ -44,7 +46,7 @@ class deferred_weight_grads:
             # the backward raised after arming the engine callback: drop its queued partials, or every later backward
             # would find 'armed' set, never queue the callback again and silently lose all Linear weight gradients
             _DEFER['jobs'], _DEFER['folds'], _DEFER['mlpdw'], _DEFER['armed'], _DEFER['claimed'] = [], [], [], False, set()
-            for k in ('partials', 'red64', 'pc_wide', 'tn', 'late_calls'):
+            for k in ('partials', 'red64', 'pc_wide', 'tn', 'late_calls', 'late_mats'):
                 _DEFER[k] = []
         return False
 
@@ -172,13 +174,29 @@ def _install_grad(prm, gr, direct):
 
 
 def _flush_mlp_dw():
+    """The weight gradients of all fused MLP blocks (crfconv_mlp_dw_jobs) and the queued backward of the CRF layers' matrices
+    (ops.crf: 'late_mats' -- it reads the dP / dQ sums of the launch in front) -- as ONE launch when both are there: the matrices'
+    slabs ride as the first workgroups of the weight-gradient launch (crfconv_mlp_dw_jobs_hosting)."""
     jobs, _DEFER['mlpdw'] = _DEFER['mlpdw'], []
-    if not jobs:
-        return
-    table = (_lib.MlpDwJob * len(jobs))(*[j[0] for j in jobs])
-    _lib.call('crfconv_mlp_dw_jobs', ctypes.cast(table, ctypes.c_void_p), len(jobs), stream_ptr())
-    for _, _, (prm, gr, direct) in jobs:
-        _install_grad(prm, gr, direct)
+    mats, _DEFER['late_mats'] = _DEFER.get('late_mats', []), []
+    st = stream_ptr()
+    if jobs:
+        table = (_lib.MlpDwJob * len(jobs))(*[j[0] for j in jobs])
+        if mats and state.dw_hosts_mats:
+            arguments, install, _ = mats.pop(0)
+            arrays, keep = arguments()
+            _lib.call('crfconv_mlp_dw_jobs_hosting', ctypes.cast(table, ctypes.c_void_p), len(jobs), *arrays, st)
+            del keep
+            install()
+        else:
+            _lib.call('crfconv_mlp_dw_jobs', ctypes.cast(table, ctypes.c_void_p), len(jobs), st)
+        for _, _, (prm, gr, direct) in jobs:
+            _install_grad(prm, gr, direct)
+    for arguments, install, _ in mats:
+        arrays, keep = arguments()
+        _lib.call('crfconv_crf_matrices_backward_batched', *arrays, st)
+        del keep
+        install()
 
 
 def _defer_reduce64(partial_ptr, is_float, nblk, nslots, out, keep):

@@ -512,6 +512,12 @@ int crfconv_mlp_backward(const float* gA, const float* Y, const float* X, const 
  * workspaces those calls left behind (which must be untouched since): nothing inside a backward pass reads a weight gradient. */
 typedef struct { const void* workspace; const float* coef; float* dW; int64_t M; int32_t Ci; int32_t Co; } crf_mlp_dw_job;
 int crfconv_mlp_dw_jobs(const crf_mlp_dw_job* jobs, int njobs, crf_stream_t stream);
+/* The same launch CARRYING crfconv_crf_matrices_backward_batched(c, Q, gQ, gP, H, n, dc) (below) as its first workgroups (round 6: both are
+ * end-of-pass parameter work; the matrices' backward alone is a 13 us dependent chain on 15 workgroups).  njobs >= 1.  Results of both
+ * are those of the two separate calls. */
+int crfconv_mlp_dw_jobs_hosting(const crf_mlp_dw_job* jobs, int njobs, const float* const* c, const float* const* Q,
+                                const float* const* gQ, const float* const* gP, const int* H, int n, float* const* dc,
+                                crf_stream_t stream);
 /* The same backward for a block whose input x has a second consumer -- the shortcut of a ResNet block
  * (models/point_conv_big.py:83-88: lin_in(x) and shortcut(x)): dX = gY W + dX_add, dX_add [M, Ci] the gradient that other
  * consumer already sent back (NULL: as crfconv_mlp_backward).  Replaces the accumulation pass autograd would run. */

@@ -1447,6 +1447,50 @@ def test_pointconv_prefold_one_launch_equals_per_layer_folds():
     assert any('point_conv.weight_nn.0.bn.batch_norm.running_var' in k and not torch.equal(b1[k], torch.ones_like(b1[k])) for k in b1)
 
 
+def test_end_of_pass_launch_carrying_the_crf_matrices_backward():
+    """ops.deferred_weight_grads: the backward of the CRF layers' matrices rides in the MLP blocks' weight-gradient launch
+    (crfconv_mlp_dw_jobs_hosting, the default) -- against the two launches (state.dw_hosts_mats off) and against the pass without
+    deferral: every gradient of the network, bit for bit between the two deferred forms."""
+    import copy
+    import crfconv_amd
+    from crfconv_amd import models, ops
+    B, N = 2, 4096
+    pos = np.stack([S.make_cloud(130 + b, N, box=(2, 2, 1)) for b in range(B)])
+    feats = np.concatenate([pos, S.uniform(130, 'rgb', (B, N, 3), 0, 1)], -1)
+    data = crfconv_amd.multiscale_compute(t(pos), t(feats), generator=torch.Generator().manual_seed(6))
+    labels = t(S.integers(130, 'y', (B, N), 0, 14))
+    torch.manual_seed(4)
+    net0 = models.PointConvBig(6, 13, use_crf=True, steps=2).to(DEV).train()
+    with torch.no_grad():
+        for m in net0.modules():
+            if hasattr(m, 'c') and isinstance(m.c, torch.nn.Parameter):
+                m.c.add_(0.1 * torch.randn_like(m.c))               # off the identity: dc has no zeros to hide behind
+    res = []
+    for mode in ('riders', 'two launches', 'no deferral'):
+        net = copy.deepcopy(net0)
+        ops.state.dw_hosts_mats = mode == 'riders'
+        try:
+            torch.manual_seed(9)
+            loss = ops.training_loss(net(data), labels, None, ignore_index=-1)
+            if mode == 'no deferral':
+                loss.backward()
+            else:
+                with ops.deferred_weight_grads():
+                    loss.backward()
+        finally:
+            ops.state.dw_hosts_mats = True
+        res.append({k: p.grad.clone() for k, p in net.named_parameters()})
+    g1, g2, g3 = res
+    n_c = 0
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+        if k.endswith('.c'):
+            n_c += 1
+            assert float(g1[k].abs().max()) > 0
+            assert_close(g1[k], g3[k], 1e-5, k)
+    assert n_c == 4
+
+
 @pytest.mark.usefixtures('big_forms_from_4096')
 def test_resnet_join_fused_equals_two_passes():
     """models.common.mlp_join: lin_out's BatchNorm + the residual add + LeakyReLU as ONE pass (crfconv_bn_apply_add, one
