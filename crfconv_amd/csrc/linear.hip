@@ -27,16 +27,16 @@ __global__ __launch_bounds__(WG_BLOCK) void wgrad_kernel(const float* __restrict
                                                          int Ci, int rows_per_block,
                                                          float* __restrict__ partial /*[nblk][Co][Ci]*/,
                                                          float* __restrict__ partial_b /*[nblk][Co] or null*/) {
-    __shared__ float s_red[WG_WAVES * TCO * TCI * 256];
+    __shared__ float s_red[WG_RED_BUFS * TCO * TCI * 256];
     __shared__ float s_b[WG_WAVES * TCO * 16];
     wgrad_body<TCO, TCI>(G, X, M, Co, Ci, rows_per_block, partial, partial_b, blockIdx.x, blockIdx.y, blockIdx.z, s_red, s_b);
 }
 
 // Every tile class in ONE launch (round 4): the jobs of the small classes -- five launches of 40-240 workgroups, 7-12 us each, behind
 // the <4, 4> launch of the step -- run beside the large ones.  The workgroup looks its job up as above and dispatches on the job's
-// class; one LDS buffer of the largest class (64 KB), the register budget of the largest (the small classes' jobs are few).
+// class; one LDS buffer of the largest class (32 KB: wgrad_body's two-round sum), the register budget of the largest (the small classes' jobs are few).
 __global__ __launch_bounds__(WG_BLOCK) void wgrad_jobs_any_kernel(const WgJobTable t) {
-    __shared__ float s_red[WG_WAVES * 4 * 4 * 256];
+    __shared__ float s_red[WG_RED_BUFS * 4 * 4 * 256];
     __shared__ float s_b[WG_WAVES * 4 * 16];
     wgrad_any_run(t, (int)blockIdx.x, s_red, s_b);
 }
@@ -1638,7 +1638,10 @@ static MlpPlan mlp_plan(int64_t M, int Co, int Ci) {
     if (p.tco * p.tci == 16) p.tci = 2;              // two accumulator sets: at most 8 tiles (64 registers) each
     p.gy = (t_co + p.tco - 1) / p.tco;
     p.gz = (t_ci + p.tci - 1) / p.tci;
-    constexpr int target = 512;                      // slices x column slabs per launch (256 / 1024 measured slower: DESIGN 9 C4)
+#ifndef MLP_P1_TARGET_
+#define MLP_P1_TARGET_ 512
+#endif
+    constexpr int target = MLP_P1_TARGET_;           // slices x column slabs per launch (256 / 1024 measured slower: DESIGN 9 C4)
     int64_t slices = target / ((int64_t)p.gy * p.gz);
     if (slices < 32) slices = 32;
     int64_t rows = (M + slices - 1) / slices;

@@ -10,13 +10,17 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int WG_BLOCK = 256;
 constexpr int WG_WAVES = WG_BLOCK / WAVE;
+#ifndef WG_RED_BUFS_
+#define WG_RED_BUFS_ 2       // wave-sized LDS buffers of the cross-wave sum (1, 2 or 4 = one round)
+#endif
+constexpr int WG_RED_BUFS = WG_RED_BUFS_;
 
 // TCO x TCI tiles of 16x16 per block (output slab 16*TCO x 16*TCI at (co0, ci0) = blockIdx.y / z).
 template <int TCO, int TCI>
 __device__ __forceinline__ void wgrad_body(const float* __restrict__ G, const float* __restrict__ X, int64_t M, int Co, int Ci,
                                            int rows_per_block, float* __restrict__ partial /*[nblk][Co][Ci]*/,
                                            float* __restrict__ partial_b /*[nblk][Co] or null*/, int bx, int by, int bz,
-                                           float* __restrict__ s_red_ /*[waves][TCO TCI 256]*/, float* __restrict__ s_b_ /*[waves][16 TCO]*/) {
+                                           float* __restrict__ s_red_ /*[WG_RED_BUFS][TCO TCI 256]*/, float* __restrict__ s_b_ /*[waves][16 TCO]*/) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int co_base = by * 16 * TCO, ci_base = bz * 16 * TCI;
     const int kk = lane >> 4, cc = lane & 15;
@@ -81,30 +85,51 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ G, const fl
         }
     }
     // C/D layout of 16x16x4: col = lane & 15 (j = ci), row = 4 * (lane >> 4) + reg (i = co)
-    // LDS of the caller (a kernel that serves several tile classes owns ONE buffer of the largest class's size)
-    float (*s_red)[TCO * TCI * 256] = reinterpret_cast<float (*)[TCO * TCI * 256]>(s_red_);
+    // LDS of the caller (a kernel that serves several tile classes owns ONE buffer of the largest class's size).  The four waves' tiles
+    // go through WG_RED_BUFS wave-sized buffers in rounds (round 6; one buffer per wave until then: 64 KB for the <4, 4> class, two
+    // workgroups = two waves per SIMD on a CU whatever the job's class): the waves of a round park, every thread adds them to its slots,
+    // ((s0 + s1) + s2) + s3 -- the order of the one-round sum, every bit.
+    constexpr int NSLOT = TCO * TCI * 256, PER = NSLOT / WG_BLOCK;
+    static_assert(NSLOT % WG_BLOCK == 0 && WG_WAVES % WG_RED_BUFS == 0, "slots per thread; whole rounds");
+    float (*s_red)[NSLOT] = reinterpret_cast<float (*)[NSLOT]>(s_red_);
     float (*s_b)[TCO * 16] = reinterpret_cast<float (*)[TCO * 16]>(s_b_);
+    auto park = [&]() {
+#pragma unroll
+        for (int a = 0; a < TCO; ++a)
+#pragma unroll
+            for (int b = 0; b < TCI; ++b)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) s_red[wave % WG_RED_BUFS][(a * TCI + b) * 256 + (4 * kk + g) * 16 + cc] = acc[a][b][g];
+    };
 #pragma unroll
     for (int a = 0; a < TCO; ++a) {
-#pragma unroll
-        for (int b = 0; b < TCI; ++b)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) s_red[wave][(a * TCI + b) * 256 + (4 * kk + g) * 16 + cc] = acc[a][b][g];
         // bias: lanes with the same cc over the 4 k-groups
         float t = bsum[a];
         t += __shfl_xor(t, 16, WAVE);
         t += __shfl_xor(t, 32, WAVE);
         if (kk == 0) s_b[wave][a * 16 + cc] = t;
     }
-    __syncthreads();
-    const int64_t pb = (int64_t)bx;
-    for (int t = threadIdx.x; t < TCO * TCI * 256; t += WG_BLOCK) {
-        float v = 0.f;
+    // rounds of WG_RED_BUFS waves: park, every thread adds the parked tiles to its running slots in wave order
+    float v[PER];
 #pragma unroll
-        for (int w = 0; w < WG_WAVES; ++w) v += s_red[w][t];
-        const int tile = t >> 8, a = tile / TCI, b = tile % TCI, i = (t >> 4) & 15, j = t & 15;
-        const int co = co_base + 16 * a + i, ci = ci_base + 16 * b + j;
-        if (co < Co && ci < Ci) partial[(pb * Co + co) * Ci + ci] = v;
+    for (int rd = 0; rd < WG_WAVES / WG_RED_BUFS; ++rd) {
+        if (rd > 0) __syncthreads();                    // the previous round's readers are done with the buffers
+        if (wave / WG_RED_BUFS == rd) park();
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int t = threadIdx.x + WG_BLOCK * i;
+#pragma unroll
+            for (int b = 0; b < WG_RED_BUFS; ++b) v[i] = (rd == 0 && b == 0) ? s_red[0][t] : v[i] + s_red[b][t];
+        }
+    }
+    const int64_t pb = (int64_t)bx;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int t = threadIdx.x + WG_BLOCK * i;
+        const int tile = t >> 8, a = tile / TCI, b = tile % TCI, r = (t >> 4) & 15, j = t & 15;
+        const int co = co_base + 16 * a + r, ci = ci_base + 16 * b + j;
+        if (co < Co && ci < Ci) partial[(pb * Co + co) * Ci + ci] = v[i];
     }
     if (partial_b != nullptr && bz == 0) {
         for (int t = threadIdx.x; t < TCO * 16; t += WG_BLOCK) {
@@ -133,7 +158,7 @@ struct WgJobTable {
     unsigned char cls[WJ_MAX];                         // 10 TCO + TCI (wgrad_jobs_any_kernel)
 };
 // One workgroup of a job table: looks its job up (binary search over the prefix), dispatches on the job's tile class; the caller owns
-// ONE LDS buffer of the largest class (s_red: WG_WAVES * 4 * 4 * 256 floats, s_b: WG_WAVES * 4 * 16).
+// ONE LDS buffer of the largest class (s_red: WG_RED_BUFS * 4 * 4 * 256 floats, s_b: WG_WAVES * 4 * 16).
 __device__ __forceinline__ void wgrad_any_run(const WgJobTable& t, int blk, float* s_red, float* s_b) {
     int lo = 0, hi = t.njobs;
     while (hi - lo > 1) {
