@@ -2053,7 +2053,7 @@ def test_training_loss_matches_oracle(weighted):
     lc = logits.detach().cpu().requires_grad_()
     ref = O.training_loss(lc, labels.cpu(), None if w is None else w.cpu(), -1)
     (ref * 1.7).backward()
-    assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-6 * max(1.0, abs(float(ref.detach())))
     assert_close(logits.grad, lc.grad, 1e-5, 'dlogits')
     assert float(logits.grad[labels == 0].abs().max()) == 0.0                 # ignored rows get no gradient
 
@@ -2454,7 +2454,7 @@ def test_graphed_model_in_the_unchanged_reference_loop_equals_the_eager_loop():
             loss = F.cross_entropy(y_pred, y, weight=cw, ignore_index=-1)
             loss.backward()
             optimizer.step()
-            losses[name].append(float(loss))
+            losses[name].append(float(loss.detach()))
     assert net.fwd_graph is not None and net.bwd_graph is not None
     assert list(net.state_dict().keys()) == list(ref.state_dict().keys()) and net.C == ref.C       # transparent for checkpoints / attributes
     for a, b in zip(losses['graphed'], losses['eager']):
