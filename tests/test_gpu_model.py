@@ -2456,6 +2456,8 @@ def test_graphed_model_in_the_unchanged_reference_loop_equals_the_eager_loop():
             optimizer.step()
             losses[name].append(float(loss.detach()))
     assert net.fwd_graph is not None and net.bwd_graph is not None
+    # the gradients autograd installed ARE the replay's static buffers (handed over as fresh tensor objects: no copy launch per parameter)
+    assert all(q.grad is not None and q.grad.data_ptr() == sg.data_ptr() for q, sg in zip(net.params, net.static_grads) if sg is not None)
     assert list(net.state_dict().keys()) == list(ref.state_dict().keys()) and net.C == ref.C       # transparent for checkpoints / attributes
     for a, b in zip(losses['graphed'], losses['eager']):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), losses
