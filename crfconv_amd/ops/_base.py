@@ -35,6 +35,7 @@ def _ptr_array(tensors):
 
 
 _TICKETS = {}
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
 def _stream_key(device):
@@ -44,10 +45,14 @@ def _stream_key(device):
     stream the capture later runs on): hipGraphs that contain mean-field backward or one-launch MLP kernels must therefore be
     replayed one after the other (the loops of this package do) -- replaying two of them CONCURRENTLY on different streams is
     unsupported, their barrier and ticket counts would mix."""
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    idx = getattr(device, 'index', None)          # (a torch.device in every call of this package: no torch.device() round trip)
+    if idx is None:
+        dev = torch.device(device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if torch.cuda.is_current_stream_capturing():
         return idx, 'capture'                      # captured launches: one buffer per device, created by the eager warm-up pass
+    if _raw_stream is not None:                    # the raw-handle query (a torch.cuda.Stream object per call costs ~3 us, ~100 calls a step)
+        return idx, int(_raw_stream(idx))
     return idx, int(torch.cuda.current_stream(idx).cuda_stream)
 
 

@@ -30,6 +30,10 @@ for _ in range(20):
     one()
 torch.cuda.synchronize()
 print('eager ms per step: %.3f' % ((time.perf_counter() - t0) / 20 * 1e3))
+if os.environ.get('PROFILE_BACKWARD'):
+    # the engine's device thread runs the backward functions: on the calling thread instead, so that the profile sees them
+    torch.autograd.set_multithreading_enabled(False)
+    one()
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(20):
