@@ -16,7 +16,9 @@ _vp = _lib.ctypes.c_void_p
 
 
 def ptr(t):
-    return None if t is None else _vp(t.data_ptr())
+    """The device address of `t` for a C-ABI pointer argument (None = NULL).  A plain int: every entry point has its ctypes argtypes
+    set (_lib.SIGNATURES), which take it as a pointer -- a c_void_p object per argument cost ~2 000 constructions per eager step."""
+    return None if t is None else t.data_ptr()
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)

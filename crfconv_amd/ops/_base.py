@@ -45,7 +45,7 @@ def _stream_key(device):
     stream the capture later runs on): hipGraphs that contain mean-field backward or one-launch MLP kernels must therefore be
     replayed one after the other (the loops of this package do) -- replaying two of them CONCURRENTLY on different streams is
     unsupported, their barrier and ticket counts would mix."""
-    idx = getattr(device, 'index', None)          # (a torch.device in every call of this package: no torch.device() round trip)
+    idx = device.index if isinstance(device, torch.device) else None      # (what this package passes: no torch.device() round trip)
     if idx is None:
         dev = torch.device(device)
         idx = dev.index if dev.index is not None else torch.cuda.current_device()

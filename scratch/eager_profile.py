@@ -40,6 +40,11 @@ for _ in range(20):
     one()
 torch.cuda.synchronize()
 pr.disable()
+if os.environ.get('PROFILE_CALLERS'):
+    s = io.StringIO()
+    st = pstats.Stats(pr, stream=s)
+    st.sort_stats('tottime').print_callers('torch.empty|empty_like|zeros')
+    print(s.getvalue()[:12000])
 for key in ('tottime', 'cumulative'):
     s = io.StringIO()
     pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
