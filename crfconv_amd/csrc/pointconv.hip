@@ -57,10 +57,19 @@ struct PC {
     static constexpr int PPW = WAVE / L;
     static constexpr int KS = D >= 128 ? PC_KS_128 : (D >= 64 ? PC_KS_64 : (D >= 32 ? PC_KS_32 : 1));       // wavefronts sharing a point's edges (1, 2 or 4)
     static constexpr int PPB = PPW * PWAVES / KS;
-    static constexpr bool W2_IN_REGS = (D <= 16);
+#ifndef PC_W2_REGS_MAX_D
+#define PC_W2_REGS_MAX_D 8       // layers up to this width keep W2^T in registers (0: every width reads it from LDS)
+#endif
+#ifndef PC_NARROW_WAVES
+#define PC_NARROW_WAVES 1        // minimum waves per SIMD asked for the narrow statistics kernels
+#endif
+    static constexpr bool W2_IN_REGS = (D <= PC_W2_REGS_MAX_D);
     // W2^T rows in LDS: [D input channels][L + 1 float4] -- one float4 of padding per row, so that the transposing stage
     // (coalesced global reads of W2 rows, scattered LDS writes) spreads over eight banks instead of one
     static constexpr int W2LD = L + 1;
+    // narrow layers (d <= 16) whose W2^T lives in LDS keep layer 1's rows {A1[c][0..2], b1[c]} there too (behind W2^T): 16 registers
+    static constexpr bool A1_IN_LDS = !W2_IN_REGS && D <= 16;
+    static constexpr int W2T_F4 = W2_IN_REGS ? 1 : D * W2LD + (A1_IN_LDS ? D : 0);      // float4 of the kernels' LDS weight array
     // Wide layers evaluate layer 2 for EB = 4 edges at a time: each W2^T row fetched from LDS then feeds 16 FMAs
     // per lane instead of 4, and h1 is exchanged through a per-wave LDS scratch (broadcast reads) instead of
     // one cross-lane shuffle per input channel -- the d x d product becomes VALU-bound instead of LDS-bound.
@@ -86,10 +95,15 @@ struct EdgeMLP {
         lane = lane_;
         q = q_;
         slope = slope_;
+        if constexpr (PC<D>::A1_IN_LDS) {
+            if ((int)threadIdx.x < D)
+                lds_w2t[D * PC<D>::W2LD + threadIdx.x] = make_float4(A1[threadIdx.x * 3 + 0], A1[threadIdx.x * 3 + 1], A1[threadIdx.x * 3 + 2], b1[threadIdx.x]);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int ch = 4 * q + c;
-            a1[c] = make_float4(A1[ch * 3 + 0], A1[ch * 3 + 1], A1[ch * 3 + 2], b1[ch]);
+            for (int c = 0; c < 4; ++c) {
+                const int ch = 4 * q + c;
+                a1[c] = make_float4(A1[ch * 3 + 0], A1[ch * 3 + 1], A1[ch * 3 + 2], b1[ch]);
+            }
         }
         if constexpr (PC<D>::W2_IN_REGS) {
 #pragma unroll
@@ -112,10 +126,19 @@ struct EdgeMLP {
 
     // pre-activation and activation of layer 1 for this lane's quad
     __device__ __forceinline__ void layer1(float rx, float ry, float rz, float4& pre, float4& h1) const {
-        pre.x = fmaf(a1[0].x, rx, fmaf(a1[0].y, ry, fmaf(a1[0].z, rz, a1[0].w)));
-        pre.y = fmaf(a1[1].x, rx, fmaf(a1[1].y, ry, fmaf(a1[1].z, rz, a1[1].w)));
-        pre.z = fmaf(a1[2].x, rx, fmaf(a1[2].y, ry, fmaf(a1[2].z, rz, a1[2].w)));
-        pre.w = fmaf(a1[3].x, rx, fmaf(a1[3].y, ry, fmaf(a1[3].z, rz, a1[3].w)));
+        float4 r0, r1, r2, r3;
+        if constexpr (PC<D>::A1_IN_LDS) {
+            int ao = 0;
+            asm volatile("" : "+v"(ao));                 // (read per edge, as W2^T: see layer2)
+            const float4* ar = w2t_lds + D * PC<D>::W2LD + 4 * q + ao;
+            r0 = ar[0]; r1 = ar[1]; r2 = ar[2]; r3 = ar[3];
+        } else {
+            r0 = a1[0]; r1 = a1[1]; r2 = a1[2]; r3 = a1[3];
+        }
+        pre.x = fmaf(r0.x, rx, fmaf(r0.y, ry, fmaf(r0.z, rz, r0.w)));
+        pre.y = fmaf(r1.x, rx, fmaf(r1.y, ry, fmaf(r1.z, rz, r1.w)));
+        pre.z = fmaf(r2.x, rx, fmaf(r2.y, ry, fmaf(r2.z, rz, r2.w)));
+        pre.w = fmaf(r3.x, rx, fmaf(r3.y, ry, fmaf(r3.z, rz, r3.w)));
         h1 = make_float4(lrelu(pre.x, slope), lrelu(pre.y, slope), lrelu(pre.z, slope), lrelu(pre.w, slope));
     }
 
@@ -135,10 +158,13 @@ struct EdgeMLP {
                 acc = fma4(v2, w2t_reg[4 * hq + 2], acc);
                 acc = fma4(v3, w2t_reg[4 * hq + 3], acc);
             } else {
-                acc = fma4(v0, w2t_lds[(4 * hq + 0) * PC<D>::W2LD + q], acc);
-                acc = fma4(v1, w2t_lds[(4 * hq + 1) * PC<D>::W2LD + q], acc);
-                acc = fma4(v2, w2t_lds[(4 * hq + 2) * PC<D>::W2LD + q], acc);
-                acc = fma4(v3, w2t_lds[(4 * hq + 3) * PC<D>::W2LD + q], acc);
+                int wo = 0;
+                if constexpr (D <= 16) asm volatile("" : "+v"(wo));    // (narrow layers: keep the reads inside the edge loop -- hoisted they are W2 in registers again)
+                const float4* w = w2t_lds + wo;
+                acc = fma4(v0, w[(4 * hq + 0) * PC<D>::W2LD + q], acc);
+                acc = fma4(v1, w[(4 * hq + 1) * PC<D>::W2LD + q], acc);
+                acc = fma4(v2, w[(4 * hq + 2) * PC<D>::W2LD + q], acc);
+                acc = fma4(v3, w[(4 * hq + 3) * PC<D>::W2LD + q], acc);
             }
         });
         return acc;
@@ -367,7 +393,7 @@ __global__ __launch_bounds__(PBLOCK) void stats_kernel(const float* __restrict__
                                                        float* __restrict__ shift_out,
                                                        float* __restrict__ partial) {
     constexpr int EB = PC<D>::EB;
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
+    __shared__ float4 s_w2t[PC<D>::W2T_F4];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     __shared__ float sred[PWAVES * 2 * D];
     int lane, wave, q;
@@ -418,7 +444,7 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
                                                          const float* __restrict__ b2,
                                                          float* __restrict__ out) {
     constexpr int EB = PC<D>::EB;
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
+    __shared__ float4 s_w2t[PC<D>::W2T_F4];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     int lane, wave, q;
     const Row rw = my_row<D>(m_tgt, lane, wave, q);
@@ -465,7 +491,7 @@ __global__ __launch_bounds__(PBLOCK) void forward_kernel(const float* __restrict
 // needs (sum_e g_w = sum_i g_i V_i,  sum_e g_w (h2 - shift) = sum_i g_i U_i): no edge pass there either.
 template <int D>
 struct UvLds {
-    float4 w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
+    float4 w2t[PC<D>::W2T_F4];
     float4 scr[PC<D>::SCR_SIZE];
     float red[PWAVES * 2 * D];
     float4 ks[PC<D>::KS > 1 ? PWAVES * WAVE : 1];
@@ -581,7 +607,7 @@ __device__ __forceinline__ void uvstats_body(const float* __restrict__ x,
     if (threadIdx.x < 2 * D) stats[threadIdx.x] = L.tot[threadIdx.x];
 }
 template <int D>
-__global__ __launch_bounds__(PBLOCK) void uvstats_kernel(const float* __restrict__ x, const float* __restrict__ pos_src,
+__global__ __launch_bounds__(PBLOCK, (D <= 16 ? PC_NARROW_WAVES : 1)) void uvstats_kernel(const float* __restrict__ x, const float* __restrict__ pos_src,
                                                          const float* __restrict__ pos_tgt, const int32_t* __restrict__ idx, int K,
                                                          int64_t m_tgt, const float* __restrict__ A1, const float* __restrict__ b1,
                                                          const float* __restrict__ W2, float slope, const float* __restrict__ mean_rel,
@@ -758,7 +784,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ shift_p,
                                                             float* __restrict__ partial) {
     constexpr int EB = PC<D>::EB;
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
+    __shared__ float4 s_w2t[PC<D>::W2T_F4];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     __shared__ float sred[PWAVES * 2 * D];
     int lane, wave, q;
@@ -823,7 +849,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_params_kernel(const float* __restr
     __shared__ float s_ored[ACC_MFMA ? PWAVES * D * D : 1];
     [[maybe_unused]] OuterAcc<ACC_MFMA ? D : 8, PBLOCK> oa;
     __shared__ double s_accd[PWAVES][4 * D];
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
+    __shared__ float4 s_w2t[PC<D>::W2T_F4];
     constexpr bool W2_LDS = (D <= 64);            // d = 128: the 64 KB of rows stay in L1/L2 instead
     __shared__ float4 s_w2[W2_LDS ? D * L : 1];   // W2 rows as float4: s_w2[c * L + q'] = W2[c][4q'..]
     __shared__ float s_acc[NSLOT];                // block totals
@@ -1007,7 +1033,7 @@ __device__ __forceinline__ void bwd_dump_body(const float* __restrict__ x,
                                                           float* __restrict__ gh2_out,
                                                           float* __restrict__ rel_out, unsigned block) {
     constexpr int EB = PC<D>::EB;
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
+    __shared__ float4 s_w2t[PC<D>::W2T_F4];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     int lane, wave, q;
     const Row rw = my_row_at<D>(m_tgt, block, lane, wave, q);
@@ -1170,7 +1196,7 @@ __global__ __launch_bounds__(PBLOCK) void bwd_input_kernel(const float* __restri
         return;
     }
     constexpr int EB = PC<D>::EB;
-    __shared__ float4 s_w2t[PC<D>::W2_IN_REGS ? 1 : D * PC<D>::W2LD];
+    __shared__ float4 s_w2t[PC<D>::W2T_F4];
     __shared__ float4 s_scr[PC<D>::SCR_SIZE];
     int lane, wave, q;
     const unsigned nb = (unsigned)n_own, bb = blockIdx.x;                  // xcd_block_id() of the first n_own workgroups
