@@ -58,6 +58,12 @@ struct Rev {
     static constexpr int CAP = 64 * MAXRR;
 };
 
+#ifndef REV_PAD_OOB
+#define REV_PAD_OOB 1          // padding lanes of the reverse walks address out of range (no line lookup) instead of re-reading the last record
+#endif
+#ifndef REV_PAIR
+#define REV_PAIR 1             // H = 8: pairs of consecutive edges summed by the gathering lanes before the tile
+#endif
 #ifndef REV_EP_CHAIN
 #define REV_EP_CHAIN 2
 #endif
@@ -114,16 +120,32 @@ struct RevArgs {
     int n_reduce;
 };
 
-template <int H, int EPV, int TR, int MODE, bool FIRST, int KSH>
+// PAD_OOB: the lanes of a load round past the wave's range (a quarter to a third of the slots: MAXRR rounds carry 25 % head
+// room over the AVERAGE in-degree) address their record, weight and rows OUT OF RANGE of a buffer resource: the load
+// returns zeros without a request to the vector cache.  (Re-reading the range's last record instead -- the first
+// branch-free form -- is an L1 hit, but every hit is a line lookup, and the lookup rate is what binds these walks:
+// profiles/r6_meanfield_ta_table.md.)  Needs the edge tables below 4 GiB (the launcher checks; else PAD_OOB = false).
+constexpr int OOB_OFF = (int)0xFFFFFFF0u;
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int H, int EPV, int TR, int MODE, bool FIRST, int KSH, bool PAD_OOB>
 __global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE)) void bwd_rev_kernel(const RevArgs a) {
     using RV = Rev<H, EPV>;
     constexpr int L = RV::L, EP = RV::EP, R = RV::R, MAXRR = RV::MAXRR, CAP = RV::CAP;
     constexpr bool FINAL = MODE == REV_FINAL;
-    constexpr int TRR = TR < MAXRR ? TR : MAXRR, TE = 64 * TRR;            // tile entries
+    // PAIR (L = 2): a lane pair gathers TWO CONSECUTIVE edges per load round; fifteen times out of sixteen they belong to the
+    // same row, so the pair multiplies by the weights itself and hands ONE partial row to the tile (half the LDS traffic
+    // of the walk, no weight tile in the chain walks).  A pair that straddles a row start keeps its halves apart: the
+    // first in the tile, the second in the starting row's side slot.  One tile phase per chunk.
+    constexpr bool PAIR = REV_PAIR && L == 2;
+    constexpr int TRR = PAIR ? MAXRR : (TR < MAXRR ? TR : MAXRR), TE = 64 * TRR;      // tile entries (edges)
+    constexpr int TEP = TE / 2;                                             // PAIR: tile entries (pairs); then R side slots
     constexpr int NW = RV::NW;
     __shared__ float4 sM[H * L];                                           // P^T
-    __shared__ float4 s_rows[NW][(FINAL ? 2 : 1) * TE * L];                // gathered G (and y) rows, entry-major
-    __shared__ float s_wt[NW][(FINAL ? 2 : 1) * TE];                       // s (and w) per entry
+    __shared__ float4 s_rows[NW][(FINAL ? 2 : 1) * (PAIR ? TEP + R : TE) * L];      // gathered G (and y) rows, entry-major
+    __shared__ float s_wt[NW][PAIR ? (FINAL ? TEP + R : 1) : (FINAL ? 2 : 1) * TE];  // s (and w) per entry; PAIR: sums of w
+    __shared__ uint2 s_flag[PAIR ? NW : 1][PAIR ? WAVE : 1];               // PAIR: per position of the chunk, 1 + local row that starts there
+    static_assert(!PAIR || CAP + 2 <= 8 * WAVE, "flag bytes of a chunk");
     if constexpr (FINAL) {
         if ((int)blockIdx.x < a.n_reduce) {                                // dP / dQ block partials -> dP, dQ
             reduce_small_body(a.j0, a.j1, a.nslots, a.scratch, a.ticket, blockIdx.x, (unsigned)a.n_reduce);
@@ -157,11 +179,17 @@ __global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE)) void bwd_rev_kernel(const
     [[maybe_unused]] float4 yj = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (FINAL) yj = ld4(a.y + row * H + 4 * q);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);                          // sum s G[i]
-    [[maybe_unused]] float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);        // sum w (y_j - y_i)
+    [[maybe_unused]] float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);        // sum w (y_j - y_i); PAIR: sum w y_i, with
+    [[maybe_unused]] float accw = 0.f;                                     //   accw = sum w
 #if CRF_GATHER_SRD
     const __amdgpu_buffer_rsrc_t rG = make_rsrc(a.Gin, (int)(m * H * 4));
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rY = make_rsrc(FINAL ? a.y : a.Gin, (int)(m * H * 4));
 #endif
+    // PAD_OOB: the edge tables as buffer resources ([m K] edges: 4 bytes per id / weight, 8 per record)
+    const unsigned n_edge = (unsigned)m << KSH;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rE = make_rsrc(FIRST ? (const void*)a.rev_eid : (const void*)a.rec_in, (int)(n_edge * (FIRST ? 4u : 8u)));
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rS = make_rsrc(FIRST ? a.s : a.Gin, (int)(n_edge * 4u));
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rW = make_rsrc(FINAL ? a.w : a.Gin, (int)(n_edge * 4u));
 
     auto chunk = [&](const int c0) {
         // Phases 1 and 2 are BRANCH-FREE: every round is issued, rounds (lanes) past the wave's range re-read its last
@@ -173,8 +201,16 @@ __global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE)) void bwd_rev_kernel(const
         [[maybe_unused]] float wv[MAXRR];
 #pragma unroll
         for (int rr = 0; rr < MAXRR; ++rr) {
-            const int p = c0 + 64 * rr + lane, pl = p < Eend ? p : Eend - 1, pc = pl > 0 ? pl : 0;
-            if constexpr (FIRST) {
+            const int p = c0 + 64 * rr + lane;
+            [[maybe_unused]] const int pl = p < Eend ? p : Eend - 1, pc = pl > 0 ? pl : 0;
+            if constexpr (PAD_OOB) {
+                if constexpr (FIRST) {
+                    e[rr] = (int)__builtin_amdgcn_raw_buffer_load_b32(rE, p < Eend ? p * 4 : OOB_OFF, 0, 0);
+                } else {
+                    const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rE, p < Eend ? p * 8 : OOB_OFF, 0, 0);
+                    e[rr] = (int)t.x; sv[rr] = __uint_as_float(t.y);
+                }
+            } else if constexpr (FIRST) {
                 e[rr] = a.rev_eid[pc];
             } else {
                 const RevEdge t = a.rec_in[pc];
@@ -183,11 +219,41 @@ __global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE)) void bwd_rev_kernel(const
         }
         if constexpr (FIRST) {
 #pragma unroll
-            for (int rr = 0; rr < MAXRR; ++rr) sv[rr] = a.s[e[rr]];
+            for (int rr = 0; rr < MAXRR; ++rr) {
+#ifdef EXP_FREE
+                e[rr] = (c0 + 64 * rr + lane < Eend ? c0 + 64 * rr + lane : 0);
+#endif
+                if constexpr (PAD_OOB) sv[rr] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rS, c0 + 64 * rr + lane < Eend ? e[rr] * 4 : OOB_OFF, 0, 0));
+                else sv[rr] = a.s[e[rr]];
+            }
         }
         if constexpr (FINAL) {
 #pragma unroll
-            for (int rr = 0; rr < MAXRR; ++rr) wv[rr] = a.w[e[rr]];
+            for (int rr = 0; rr < MAXRR; ++rr) {
+#ifdef EXP_FREE
+                e[rr] = (c0 + 64 * rr + lane < Eend ? c0 + 64 * rr + lane : 0);
+#endif
+                if constexpr (PAD_OOB) wv[rr] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rW, c0 + 64 * rr + lane < Eend ? e[rr] * 4 : OOB_OFF, 0, 0));
+                else wv[rr] = a.w[e[rr]];
+            }
+        }
+        [[maybe_unused]] int fl[MAXRR];
+        if constexpr (PAIR) {
+            // row starts of the chunk as bytes in LDS (needs rev_ptr only: runs while the records are in flight)
+            unsigned char* fb = reinterpret_cast<unsigned char*>(s_flag[wave]);
+            s_flag[wave][lane] = make_uint2(0u, 0u);
+            __builtin_amdgcn_wave_barrier();
+            const int rel = beg - c0;
+            if (lane % (L * EP) == 0 && beg < end && rel >= 0 && rel < CAP) fb[rel] = (unsigned char)(1 + lane / (L * EP));
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int rr = 0; rr < MAXRR; ++rr) fl[rr] = fb[64 * rr + slot * 2 + 1];
+#pragma unroll
+            for (int rr = 0; rr < MAXRR; ++rr) {                           // (lanes past the range: weight 0 whatever they loaded)
+                const bool in = c0 + 64 * rr + lane < Eend;
+                sv[rr] = in ? sv[rr] : 0.f;
+                if constexpr (FINAL) wv[rr] = in ? wv[rr] : 0.f;
+            }
         }
         // ---- phase 2: row gathers, L sub-rounds per load round (slot k of sub-round sb takes the edge lane k L + sb loaded)
         float4 g[MAXRR][L];
@@ -198,7 +264,11 @@ __global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE)) void bwd_rev_kernel(const
                 constexpr int sb = decltype(SB)::value;
                 const int ee = __float_as_int(group_bcast<L, sb>(__int_as_float(e[rr]), lane - q));
 #if CRF_GATHER_SRD
-                const int boff = (ee >> KSH) * (4 * H) + 16 * q;      // 32-bit byte offset on a buffer resource (see crf.hip)
+                int boff = (ee >> KSH) * (4 * H) + 16 * q;            // 32-bit byte offset on a buffer resource (see crf.hip)
+                if constexpr (PAD_OOB) boff = c0 + 64 * rr + (lane - q) + sb < Eend ? boff : OOB_OFF;      // (this slot's edge: lane slot L + sb of the round)
+#ifdef EXP_FREE      // timing experiment only (wrong results): every gather reads the lane's own row / consecutive words
+                boff = (int)row0 * (4 * H) + 16 * lane;
+#endif
                 g[rr][sb] = ld4_buf(rG, boff);
                 if constexpr (FINAL) gy[rr][sb] = ld4_buf(rY, boff);
 #else
@@ -219,6 +289,84 @@ __global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE)) void bwd_rev_kernel(const
                     }
                 }
             }
+        }
+#ifdef EXP_NOLDS     // timing experiment only (wrong results): no tile, every lane sums what it gathered
+#pragma unroll
+        for (int rr = 0; rr < MAXRR; ++rr) {
+            static_for<L>([&](auto SB) {
+                constexpr int sb = decltype(SB)::value;
+                acc = fma4(sv[rr], g[rr][sb], acc);
+                if constexpr (FINAL) acc2 = fma4(wv[rr], sub4(yj, gy[rr][sb]), acc2);
+            });
+        }
+        if (true) return;
+#endif
+        if constexpr (PAIR) {
+            constexpr int YO = (TEP + R) * L;                              // FINAL: the y table behind the G table
+#pragma unroll
+            for (int rr = 0; rr < MAXRR; ++rr) {
+                const float s0 = group_bcast<L, 0>(sv[rr], lane - q), s1 = group_bcast<L, 1>(sv[rr], lane - q);
+                const float4 lo = make_float4(s0 * g[rr][0].x, s0 * g[rr][0].y, s0 * g[rr][0].z, s0 * g[rr][0].w);
+                const float4 hi = make_float4(s1 * g[rr][1].x, s1 * g[rr][1].y, s1 * g[rr][1].z, s1 * g[rr][1].w);
+                const int pi = 32 * rr + slot;
+                const bool split = fl[rr] != 0;
+                trow[pi * L + q] = split ? lo : make_float4(lo.x + hi.x, lo.y + hi.y, lo.z + hi.z, lo.w + hi.w);
+                if (split) trow[(TEP + fl[rr] - 1) * L + q] = hi;
+                if constexpr (FINAL) {
+                    const float w0 = group_bcast<L, 0>(wv[rr], lane - q), w1 = group_bcast<L, 1>(wv[rr], lane - q);
+                    const float4 ylo = make_float4(w0 * gy[rr][0].x, w0 * gy[rr][0].y, w0 * gy[rr][0].z, w0 * gy[rr][0].w);
+                    const float4 yhi = make_float4(w1 * gy[rr][1].x, w1 * gy[rr][1].y, w1 * gy[rr][1].z, w1 * gy[rr][1].w);
+                    trow[YO + pi * L + q] = split ? ylo : make_float4(ylo.x + yhi.x, ylo.y + yhi.y, ylo.z + yhi.z, ylo.w + yhi.w);
+                    twt[pi] = split ? w0 : w0 + w1;
+                    if (split) {
+                        trow[YO + (TEP + fl[rr] - 1) * L + q] = yhi;
+                        twt[TEP + fl[rr] - 1] = w1;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                               // LDS operations of one wave complete in order
+            const int w1e = c0 + CAP < Eend ? c0 + CAP : Eend;
+            const int lo = beg > c0 ? beg : c0, hi = end < w1e ? end : w1e;
+            const int rl = lo - c0, rh = hi - c0;
+            if (lo < hi && (rl & 1) && el == 0) {                          // the row starts on a pair's second edge: its side slot
+                const int sl = TEP + lane / (L * EP);
+                const float4 c = trow[sl * L + q];
+                acc = make_float4(acc.x + c.x, acc.y + c.y, acc.z + c.z, acc.w + c.w);
+                if constexpr (FINAL) {
+                    const float4 cy = trow[YO + sl * L + q];
+                    acc2 = make_float4(acc2.x + cy.x, acc2.y + cy.y, acc2.z + cy.z, acc2.w + cy.w);
+                    accw += twt[sl];
+                }
+            }
+            const int pb = lo < hi ? (rh + 1) >> 1 : 0;                    // pairs [ceil(rl / 2), ceil(rh / 2)) hold the row's other edges
+            for (int pi = ((rl + 1) >> 1) + el; pi < pb; pi += 4 * EP) {
+                float4 c[4];
+                [[maybe_unused]] float4 cy[4];
+                [[maybe_unused]] float cw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pp = pi + u * EP;
+                    const bool ok = pp < pb;
+                    const int ent = ok ? pp : pi;
+                    c[u] = trow[ent * L + q];
+                    if (!ok) c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (FINAL) {
+                        cy[u] = trow[YO + ent * L + q];
+                        cw[u] = ok ? twt[ent] : 0.f;
+                        if (!ok) cy[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc = make_float4(acc.x + c[u].x, acc.y + c[u].y, acc.z + c[u].z, acc.w + c[u].w);
+                    if constexpr (FINAL) {
+                        acc2 = make_float4(acc2.x + cy[u].x, acc2.y + cy[u].y, acc2.z + cy[u].z, acc2.w + cy[u].w);
+                        accw += cw[u];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            return;
         }
         // ---- phase 3: through the LDS tile, TRR load rounds at a time; rows sum their own entries in edge order
 #pragma unroll
@@ -278,6 +426,10 @@ __global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE)) void bwd_rev_kernel(const
     for (int c0 = B + CAP; c0 < Eend; c0 += CAP) chunk(c0);
     acc = fold_halves<L, EP>(acc);
     if constexpr (FINAL) acc2 = fold_halves<L, EP>(acc2);
+    if constexpr (FINAL && PAIR) {                                         // sum w (y_j - y_i) = y_j sum w - sum w y_i
+        accw = fold_halves<L, EP>(make_float4(accw, 0.f, 0.f, 0.f)).x;
+        acc2 = make_float4(yj.x * accw - acc2.x, yj.y * accw - acc2.y, yj.z * accw - acc2.z, yj.w * accw - acc2.w);
+    }
     if constexpr (EARLY_M) {
         if (threadIdx.x < H * H) reinterpret_cast<float*>(sM)[threadIdx.x] = pm;
     } else {
@@ -334,6 +486,10 @@ __global__ __launch_bounds__(BLOCK, (H <= 16 && K == 16) ? EDGE_LB : 1) void bwd
         load_index_row_t<K, U16>(idx, idx16, r, n_tgt, n_src, j);
 #pragma unroll
         for (int k = 0; k < K; ++k) boff[k] = ((unsigned)j[k] * H + 4 * q) * 4u;
+#ifdef EXP_FREE
+#pragma unroll
+        for (int k = 0; k < K; ++k) boff[k] = ((unsigned)r * H + 4 * q) * 4u;
+#endif
     }
     MatStage<H> mp, mq;                              // P^T, Q^T: fetched now, parked behind the first gathers' issue
     mp.fetch(P, true);
@@ -461,8 +617,14 @@ static void launch_rev(const RevArgs& ra, int64_t m, hipStream_t st) {
     // LDS tile of a wave: 64 TR entries x 4 H bytes (x 2 + in the final walk): 6-9 KiB, so that four workgroups fit a CU
     constexpr int TR = MODE == REV_FINAL ? (HH <= 8 ? REV_TR_FINAL : 1) : (HH <= 8 ? REV_TR_CHAIN : (HH == 16 ? 2 : 8));
     const unsigned nb = (unsigned)cdiv(m, Rev<HH, EPV>::RPB) + (MODE == REV_FINAL ? (unsigned)ra.n_reduce : 0u);
-    if (ra.K == 16) hipLaunchKernelGGL((bwd_rev_kernel<HH, EPV, TR, MODE, FIRST, 4>), dim3(nb), dim3(Rev<HH, EPV>::NW * WAVE), 0, st, ra);
-    else hipLaunchKernelGGL((bwd_rev_kernel<HH, EPV, TR, MODE, FIRST, 5>), dim3(nb), dim3(Rev<HH, EPV>::NW * WAVE), 0, st, ra);
+    const bool oob = REV_PAD_OOB && CRF_GATHER_SRD && m * ra.K * 8 < (int64_t)0xFFFFFFF0u;      // the record table as one buffer resource
+    if (ra.K == 16) {
+        if (oob) hipLaunchKernelGGL((bwd_rev_kernel<HH, EPV, TR, MODE, FIRST, 4, true>), dim3(nb), dim3(Rev<HH, EPV>::NW * WAVE), 0, st, ra);
+        else hipLaunchKernelGGL((bwd_rev_kernel<HH, EPV, TR, MODE, FIRST, 4, false>), dim3(nb), dim3(Rev<HH, EPV>::NW * WAVE), 0, st, ra);
+    } else {
+        if (oob) hipLaunchKernelGGL((bwd_rev_kernel<HH, EPV, TR, MODE, FIRST, 5, true>), dim3(nb), dim3(Rev<HH, EPV>::NW * WAVE), 0, st, ra);
+        else hipLaunchKernelGGL((bwd_rev_kernel<HH, EPV, TR, MODE, FIRST, 5, false>), dim3(nb), dim3(Rev<HH, EPV>::NW * WAVE), 0, st, ra);
+    }
 }
 
 template <int HH, int KK, typename... A>
