@@ -48,13 +48,16 @@ __device__ __forceinline__ unsigned xcd_block_id_of(unsigned b, unsigned nb) {
 // Geometry of a reverse walk: L lanes per row (one float4 each), EP lane groups per row in the tile reduction (a row's
 // entries alternate between them by position in the row), R rows per wavefront, MAXRR coalesced record loads (64
 // edges each) issued before the first wait, TR of them per LDS tile.
+#ifndef REV_HEAD
+#define REV_HEAD 125           // load rounds of a wavefront cover this many per cent of R average rows (16 reverse edges each)
+#endif
 template <int H, int EPV>
 struct Rev {
     static constexpr int NW = H >= 32 ? 1 : BLOCK / WAVE;      // wavefronts per workgroup (wide rows: the tile of ONE wave fills the LDS budget)
     static constexpr int L = H / 4, EP = EPV, R = WAVE / (L * EP), RPB = R * NW;
     static_assert(R >= 1 && R * L * EP == WAVE, "row groups must tile the wavefront");
     // an average row has K = 16 reverse edges (self column included): 25 % head room, then a second chunk
-    static constexpr int MAXRR = (R * 16 * 5 / 4 + 63) / 64;
+    static constexpr int MAXRR = (R * 16 * REV_HEAD / 100 + 63) / 64;
     static constexpr int CAP = 64 * MAXRR;
 };
 
@@ -62,13 +65,16 @@ struct Rev {
 #define REV_PAD_OOB 1          // padding lanes of the reverse walks address out of range (no line lookup) instead of re-reading the last record
 #endif
 #ifndef REV_PAIR
-#define REV_PAIR 1             // H = 8: pairs of consecutive edges summed by the gathering lanes before the tile
+#define REV_PAIR 1             // pairs of consecutive edges summed by the gathering lanes before the tile ...
+#endif
+#ifndef REV_PAIR_MAXL
+#define REV_PAIR_MAXL 4        // ... for rows of up to 4 lanes (H <= 16)
 #endif
 #ifndef REV_EP_CHAIN
 #define REV_EP_CHAIN 2
 #endif
 #ifndef REV_EP_FINAL
-#define REV_EP_FINAL 4
+#define REV_EP_FINAL 2
 #endif
 #ifndef REV_TR_CHAIN
 #define REV_TR_CHAIN 3         // load rounds per LDS tile, chain walks (H = 8: 192 entries x 32 B = 6 KiB per wave)
@@ -128,24 +134,28 @@ struct RevArgs {
 constexpr int OOB_OFF = (int)0xFFFFFFF0u;
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
+#ifndef REV_WPE
+#define REV_WPE 1              // waves per SIMD asked of the register allocator (narrow rows)
+#endif
 template <int H, int EPV, int TR, int MODE, bool FIRST, int KSH, bool PAD_OOB>
-__global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE)) void bwd_rev_kernel(const RevArgs a) {
+__global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE), (H <= 8 ? REV_WPE : 1)) void bwd_rev_kernel(const RevArgs a) {
     using RV = Rev<H, EPV>;
     constexpr int L = RV::L, EP = RV::EP, R = RV::R, MAXRR = RV::MAXRR, CAP = RV::CAP;
     constexpr bool FINAL = MODE == REV_FINAL;
-    // PAIR (L = 2): a lane pair gathers TWO CONSECUTIVE edges per load round; fifteen times out of sixteen they belong to the
-    // same row, so the pair multiplies by the weights itself and hands ONE partial row to the tile (half the LDS traffic
-    // of the walk, no weight tile in the chain walks).  A pair that straddles a row start keeps its halves apart: the
-    // first in the tile, the second in the starting row's side slot.  One tile phase per chunk.
-    constexpr bool PAIR = REV_PAIR && L == 2;
+    // PAIR: a slot (the L lanes of a row piece) gathers L CONSECUTIVE edges per load round; fifteen times out of sixteen two
+    // neighbours in that run belong to the same row, so the slot multiplies by the weights itself and hands ONE partial
+    // row per PAIR of edges to the tile (half the LDS traffic of the walk, no weight tile in the chain walks).  A pair
+    // that straddles a row start keeps its halves apart: the first in the tile, the second in the starting row's side
+    // slot.  One tile phase per chunk.
+    constexpr bool PAIR = REV_PAIR && L >= 2 && L <= REV_PAIR_MAXL;
     constexpr int TRR = PAIR ? MAXRR : (TR < MAXRR ? TR : MAXRR), TE = 64 * TRR;      // tile entries (edges)
     constexpr int TEP = TE / 2;                                             // PAIR: tile entries (pairs); then R side slots
     constexpr int NW = RV::NW;
     __shared__ float4 sM[H * L];                                           // P^T
     __shared__ float4 s_rows[NW][(FINAL ? 2 : 1) * (PAIR ? TEP + R : TE) * L];      // gathered G (and y) rows, entry-major
     __shared__ float s_wt[NW][PAIR ? (FINAL ? TEP + R : 1) : (FINAL ? 2 : 1) * TE];  // s (and w) per entry; PAIR: sums of w
-    __shared__ uint2 s_flag[PAIR ? NW : 1][PAIR ? WAVE : 1];               // PAIR: per position of the chunk, 1 + local row that starts there
-    static_assert(!PAIR || CAP + 2 <= 8 * WAVE, "flag bytes of a chunk");
+    constexpr int FLW = (CAP + 8 + 511) / 512 * 64;                        // (whole 64-lane stores of 8 bytes)
+    __shared__ uint2 s_flag[PAIR ? NW : 1][PAIR ? FLW : 1];                // PAIR: per position of the chunk, 1 + local row that starts there
     if constexpr (FINAL) {
         if ((int)blockIdx.x < a.n_reduce) {                                // dP / dQ block partials -> dP, dQ
             reduce_small_body(a.j0, a.j1, a.nslots, a.scratch, a.ticket, blockIdx.x, (unsigned)a.n_reduce);
@@ -237,17 +247,20 @@ __global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE)) void bwd_rev_kernel(const
                 else wv[rr] = a.w[e[rr]];
             }
         }
-        [[maybe_unused]] int fl[MAXRR];
+        [[maybe_unused]] int fl[MAXRR][L >= 2 ? L / 2 : 1];
         if constexpr (PAIR) {
             // row starts of the chunk as bytes in LDS (needs rev_ptr only: runs while the records are in flight)
             unsigned char* fb = reinterpret_cast<unsigned char*>(s_flag[wave]);
-            s_flag[wave][lane] = make_uint2(0u, 0u);
+#pragma unroll
+            for (int i = 0; i < FLW; i += WAVE) s_flag[wave][i + lane] = make_uint2(0u, 0u);
             __builtin_amdgcn_wave_barrier();
             const int rel = beg - c0;
             if (lane % (L * EP) == 0 && beg < end && rel >= 0 && rel < CAP) fb[rel] = (unsigned char)(1 + lane / (L * EP));
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int rr = 0; rr < MAXRR; ++rr) fl[rr] = fb[64 * rr + slot * 2 + 1];
+            for (int rr = 0; rr < MAXRR; ++rr)
+#pragma unroll
+                for (int h = 0; h < L / 2; ++h) fl[rr][h] = fb[64 * rr + slot * L + 2 * h + 1];
 #pragma unroll
             for (int rr = 0; rr < MAXRR; ++rr) {                           // (lanes past the range: weight 0 whatever they loaded)
                 const bool in = c0 + 64 * rr + lane < Eend;
@@ -303,26 +316,29 @@ __global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE)) void bwd_rev_kernel(const
 #endif
         if constexpr (PAIR) {
             constexpr int YO = (TEP + R) * L;                              // FINAL: the y table behind the G table
+            auto mul4 = [](float f, float4 v) { return make_float4(f * v.x, f * v.y, f * v.z, f * v.w); };
+            auto add4 = [](float4 u, float4 v) { return make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w); };
 #pragma unroll
             for (int rr = 0; rr < MAXRR; ++rr) {
-                const float s0 = group_bcast<L, 0>(sv[rr], lane - q), s1 = group_bcast<L, 1>(sv[rr], lane - q);
-                const float4 lo = make_float4(s0 * g[rr][0].x, s0 * g[rr][0].y, s0 * g[rr][0].z, s0 * g[rr][0].w);
-                const float4 hi = make_float4(s1 * g[rr][1].x, s1 * g[rr][1].y, s1 * g[rr][1].z, s1 * g[rr][1].w);
-                const int pi = 32 * rr + slot;
-                const bool split = fl[rr] != 0;
-                trow[pi * L + q] = split ? lo : make_float4(lo.x + hi.x, lo.y + hi.y, lo.z + hi.z, lo.w + hi.w);
-                if (split) trow[(TEP + fl[rr] - 1) * L + q] = hi;
-                if constexpr (FINAL) {
-                    const float w0 = group_bcast<L, 0>(wv[rr], lane - q), w1 = group_bcast<L, 1>(wv[rr], lane - q);
-                    const float4 ylo = make_float4(w0 * gy[rr][0].x, w0 * gy[rr][0].y, w0 * gy[rr][0].z, w0 * gy[rr][0].w);
-                    const float4 yhi = make_float4(w1 * gy[rr][1].x, w1 * gy[rr][1].y, w1 * gy[rr][1].z, w1 * gy[rr][1].w);
-                    trow[YO + pi * L + q] = split ? ylo : make_float4(ylo.x + yhi.x, ylo.y + yhi.y, ylo.z + yhi.z, ylo.w + yhi.w);
-                    twt[pi] = split ? w0 : w0 + w1;
-                    if (split) {
-                        trow[YO + (TEP + fl[rr] - 1) * L + q] = yhi;
-                        twt[TEP + fl[rr] - 1] = w1;
+                static_for<L / 2>([&](auto HP) {                           // the slot's L consecutive edges of the round, pair by pair
+                    constexpr int h = decltype(HP)::value;
+                    const float s0 = group_bcast<L, 2 * h>(sv[rr], lane - q), s1 = group_bcast<L, 2 * h + 1>(sv[rr], lane - q);
+                    const float4 lo = mul4(s0, g[rr][2 * h]), hi = mul4(s1, g[rr][2 * h + 1]);
+                    const int pi = 32 * rr + slot * (L / 2) + h, side = TEP + fl[rr][h] - 1;
+                    const bool split = fl[rr][h] != 0;
+                    trow[pi * L + q] = split ? lo : add4(lo, hi);
+                    if (split) trow[side * L + q] = hi;
+                    if constexpr (FINAL) {
+                        const float w0 = group_bcast<L, 2 * h>(wv[rr], lane - q), w1 = group_bcast<L, 2 * h + 1>(wv[rr], lane - q);
+                        const float4 ylo = mul4(w0, gy[rr][2 * h]), yhi = mul4(w1, gy[rr][2 * h + 1]);
+                        trow[YO + pi * L + q] = split ? ylo : add4(ylo, yhi);
+                        twt[pi] = split ? w0 : w0 + w1;
+                        if (split) {
+                            trow[YO + side * L + q] = yhi;
+                            twt[side] = w1;
+                        }
                     }
-                }
+                });
             }
             __builtin_amdgcn_wave_barrier();                               // LDS operations of one wave complete in order
             const int w1e = c0 + CAP < Eend ? c0 + CAP : Eend;

@@ -1,4 +1,4 @@
-"""Level-0 mean-field forward + backward, N calls in each forward form (argv[1], default 5) (for the rocprofv3 --pmc passes of scratch/pmc.sh)."""
+"""Level-0 (argv[2]: another level) mean-field forward + backward, N calls in each forward form (argv[1], default 5) (for the rocprofv3 --pmc passes of scratch/pmc.sh)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
@@ -7,9 +7,11 @@ from crfconv_amd.graph import table_of
 dev = torch.device('cuda', 0)
 gen = torch.Generator().manual_seed(1234)
 data, _ = bench.make_batch(0, 4, 40960, dev, gen, 'morton')
-tab = table_of(data.multiscale[0].neighbor_idx, 40960); tab.reverse
+lvl = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # decoder level: 0 (the roofline's subject), 1, 2, 3
+npc = 40960 >> (2 * lvl)
+tab = table_of(data.multiscale[lvl].neighbor_idx, npc); tab.reverse
 g = torch.Generator().manual_seed(1)
-m, H, T = 4 * 40960, 8, 3
+m, H, T = 4 * npc, 8 << lvl, 3
 z = torch.randn(m, H, generator=g).to(dev).requires_grad_()
 y = (0.5 * torch.randn(m, H, generator=g)).to(dev).requires_grad_()
 c = (torch.eye(H) + 0.1 * torch.randn(H, H, generator=g)).to(dev).requires_grad_()

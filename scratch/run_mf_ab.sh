@@ -14,7 +14,7 @@ for rep in 1 2; do
     unset CRFCONV_LIB
     [ $v = default ] || export CRFCONV_LIB=$GRAFT_REPO_ROOT/scratch/variants/lib_$v.so
     d=gpurun_out/$tag/tr_${v}_$rep
-    timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $d -o t -- python3 scratch/mf_pmc.py 20 > $d.log 2>&1 || { echo "$v failed"; tail -5 $d.log | cut -c1-300; exit 1; }
+    timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $d -o t -- python3 scratch/mf_pmc.py 20 ${MF_LEVEL:-0} > $d.log 2>&1 || { echo "$v failed"; tail -5 $d.log | cut -c1-300; exit 1; }
     echo "== $v rep $rep"; python3 scratch/trace_avg.py $d 'bwd_rev|bwd_edge|mf_block|step_fast' | tee -a gpurun_out/$tag/ab.txt
     rm -rf $d
   done
