@@ -68,7 +68,7 @@ struct Rev {
 #define REV_PAIR 1             // pairs of consecutive edges summed by the gathering lanes before the tile ...
 #endif
 #ifndef REV_PAIR_MAXL
-#define REV_PAIR_MAXL 4        // ... for rows of up to 4 lanes (H <= 16)
+#define REV_PAIR_MAXL 4        // ... in the final walk for rows of up to 4 lanes only (H = 32 / 64: chain walks 11.0 -> 9.5 / 9.4 -> 7.7 us, final walk 14.5 -> 15.5 / 11.6 -> 13.6)
 #endif
 #ifndef REV_EP_CHAIN
 #define REV_EP_CHAIN 2
@@ -147,7 +147,7 @@ __global__ __launch_bounds__((Rev<H, EPV>::NW * WAVE), (H <= 8 ? REV_WPE : 1)) v
     // row per PAIR of edges to the tile (half the LDS traffic of the walk, no weight tile in the chain walks).  A pair
     // that straddles a row start keeps its halves apart: the first in the tile, the second in the starting row's side
     // slot.  One tile phase per chunk.
-    constexpr bool PAIR = REV_PAIR && L >= 2 && L <= REV_PAIR_MAXL;
+    constexpr bool PAIR = REV_PAIR && L >= 2 && (L <= REV_PAIR_MAXL || !FINAL);
     constexpr int TRR = PAIR ? MAXRR : (TR < MAXRR ? TR : MAXRR), TE = 64 * TRR;      // tile entries (edges)
     constexpr int TEP = TE / 2;                                             // PAIR: tile entries (pairs); then R side slots
     constexpr int NW = RV::NW;
