@@ -26,6 +26,17 @@
 // ascending edge order (fixed summation order: results are bitwise reproducible).  In-degrees of a kNN graph spread from
 // 0 to ~40 around K; the row-per-lane-group form (round 2) kept every wave alive for the longest row's chain of
 // record -> gather rounds (waves waited 62-66 % of their cycles, profiles/r2b_meanfield_pmc.md).
+//
+// Round 6, what the walks cost beyond their streaming traffic (diagnostic builds -DEXP_FREE / -DEXP_NOLDS below, level 0:
+// chain / first / final walk 12.4 / 15.7 / 27.2 us; gathers made free 11.0 / 14.9 / 24.4; tile removed 9.1 / 13.9 / 20.7;
+// both 6.2 / 9.3 / 11.8): the LDS tile and the gathers each hide behind the other, so the tile had to shrink first.
+//   * PAIR: the gathering lanes multiply by the weights and add the two (L = 4: two pairs of) CONSECUTIVE edges they hold
+//     before the tile: half the tile traffic, no weight tile in the chain walks, one tile phase per chunk
+//     (chain 12.4 -> 10.0, final 26.9 -> 24.0 us).
+//   * the final walk with two lane groups per row instead of four (16 rows and five load rounds per wavefront, 25 %
+//     of the slots padding instead of 50 %: 24.2 -> 20.9 us) -- a vector-memory instruction costs the same whether a
+//     quarter, half or all of its lanes carry a request (measured on step_fast_kernel with lanes masked by EXEC or
+//     addressed out of range: -2 ... -13 % of the gather time for half the lanes; whole instructions out of range: free).
 #include "crf_common.hpp"
 
 #ifndef CRF_GATHER_SRD
@@ -56,7 +67,8 @@ struct Rev {
     static constexpr int NW = H >= 32 ? 1 : BLOCK / WAVE;      // wavefronts per workgroup (wide rows: the tile of ONE wave fills the LDS budget)
     static constexpr int L = H / 4, EP = EPV, R = WAVE / (L * EP), RPB = R * NW;
     static_assert(R >= 1 && R * L * EP == WAVE, "row groups must tile the wavefront");
-    // an average row has K = 16 reverse edges (self column included): 25 % head room, then a second chunk
+    // an average row has K = 16 reverse edges (self column included): REV_HEAD - 100 = 25 % head room, then a second chunk
+    // (R = 8: 3 rounds for 2 -- half the slots padding; R = 16: 5 for 4; 10 % head room at R = 32 overflows too often: 10.4 -> 11.2 us)
     static constexpr int MAXRR = (R * 16 * REV_HEAD / 100 + 63) / 64;
     static constexpr int CAP = 64 * MAXRR;
 };
@@ -77,10 +89,10 @@ struct Rev {
 #define REV_EP_FINAL 2
 #endif
 #ifndef REV_TR_CHAIN
-#define REV_TR_CHAIN 3         // load rounds per LDS tile, chain walks (H = 8: 192 entries x 32 B = 6 KiB per wave)
+#define REV_TR_CHAIN 3         // load rounds per LDS tile, chain walks WITHOUT pair sums (H = 8: 192 entries x 32 B = 6 KiB per wave)
 #endif
 #ifndef REV_TR_FINAL
-#define REV_TR_FINAL 2         // final walk (H = 8: 128 entries x 72 B = 9 KiB per wave)
+#define REV_TR_FINAL 2         // final walk without pair sums (with them: one tile of all the chunk's rounds)
 #endif
 
 template <int L, int EP>
@@ -129,8 +141,9 @@ struct RevArgs {
 // PAD_OOB: the lanes of a load round past the wave's range (a quarter to a third of the slots: MAXRR rounds carry 25 % head
 // room over the AVERAGE in-degree) address their record, weight and rows OUT OF RANGE of a buffer resource: the load
 // returns zeros without a request to the vector cache.  (Re-reading the range's last record instead -- the first
-// branch-free form -- is an L1 hit, but every hit is a line lookup, and the lookup rate is what binds these walks:
-// profiles/r6_meanfield_ta_table.md.)  Needs the edge tables below 4 GiB (the launcher checks; else PAD_OOB = false).
+// branch-free form -- is an L1 hit.  Measured the SAME to 0.1 us in all three walks: what a load instruction costs does not
+// depend on how many of its lanes ask for something.  Kept: padding slots hold zeros whatever a table's last record is.)
+// Needs the edge tables below 4 GiB (the launcher checks; else PAD_OOB = false).
 constexpr int OOB_OFF = (int)0xFFFFFFF0u;
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
@@ -631,6 +644,7 @@ template <int HH, int MODE, bool FIRST>
 static void launch_rev(const RevArgs& ra, int64_t m, hipStream_t st) {
     constexpr int EPV = (HH == 4) ? 4 : (MODE == REV_FINAL && HH <= 16 ? REV_EP_FINAL : (HH <= 8 ? REV_EP_CHAIN : 2));
     // LDS tile of a wave: 64 TR entries x 4 H bytes (x 2 + in the final walk): 6-9 KiB, so that four workgroups fit a CU
+    // (the pair-sum form ignores TR: 32 MAXRR pair entries + R side slots per table)
     constexpr int TR = MODE == REV_FINAL ? (HH <= 8 ? REV_TR_FINAL : 1) : (HH <= 8 ? REV_TR_CHAIN : (HH == 16 ? 2 : 8));
     const unsigned nb = (unsigned)cdiv(m, Rev<HH, EPV>::RPB) + (MODE == REV_FINAL ? (unsigned)ra.n_reduce : 0u);
     const bool oob = REV_PAD_OOB && CRF_GATHER_SRD && m * ra.K * 8 < (int64_t)0xFFFFFFF0u;      // the record table as one buffer resource

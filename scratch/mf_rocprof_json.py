@@ -13,8 +13,8 @@ avg = {k: sum(v) / len(v) for k, v in dur.items()}
 T = 3
 FWD_STEPS = [('crf::sim_step_fast_kernel<8, 16, true, true>', 1), ('crf::step_fast_kernel<8, 16, true>', T - 1)]
 FWD = [('crf::mf_block_kernel<8, 16, 8, 5, true, false>', 1)]       # the product's forward on a local table (round 6): one launch
-BWD = [('crf::bwd_rev_kernel<8, 2, 3, 0, true, 4>', 1), ('crf::bwd_rev_kernel<8, 2, 3, 0, false, 4>', T - 2), ('crf::bwd_edge_all_kernel<8, 16, true>', 1),
-       ('crf::bwd_rev_kernel<8, 4, 2, 1, false, 4>', 1)]
+BWD = [('crf::bwd_rev_kernel<8, 2, 3, 0, true, 4, true>', 1), ('crf::bwd_rev_kernel<8, 2, 3, 0, false, 4, true>', T - 2), ('crf::bwd_edge_all_kernel<8, 16, true>', 1),
+       ('crf::bwd_rev_kernel<8, 2, 2, 1, false, 4, true>', 1)]
 fwd = sum(avg[k] * n for k, n in FWD)
 fwd_steps = sum(avg[k] * n for k, n in FWD_STEPS)
 bwd = sum(avg[k] * n for k, n in BWD)

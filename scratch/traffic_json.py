@@ -16,8 +16,8 @@ def hbm_bytes(name):           # FETCH_SIZE counts half the bytes on gfx950 (MI3
 
 T = 3
 FWD_FIRST, FWD_STEP = 'crf::sim_step_fast_kernel<8, 16, true, true>', 'crf::step_fast_kernel<8, 16, true>'
-REV_FIRST, REV_CHAIN, REV_FINAL = ('crf::bwd_rev_kernel<8, 2, 3, 0, true, 4>', 'crf::bwd_rev_kernel<8, 2, 3, 0, false, 4>',
-                                   'crf::bwd_rev_kernel<8, 4, 2, 1, false, 4>')
+REV_FIRST, REV_CHAIN, REV_FINAL = ('crf::bwd_rev_kernel<8, 2, 3, 0, true, 4, true>', 'crf::bwd_rev_kernel<8, 2, 3, 0, false, 4, true>',
+                                   'crf::bwd_rev_kernel<8, 2, 2, 1, false, 4, true>')
 EDGE = 'crf::bwd_edge_all_kernel<8, 16, true>'
 FWD_BLOCK = 'crf::mf_block_kernel<8, 16, 8, 5, true, false>'
 fwd = hbm_bytes(FWD_BLOCK)                     # the product's forward on a local table (round 6): ONE launch
