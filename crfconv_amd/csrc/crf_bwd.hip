@@ -88,6 +88,12 @@ struct Rev {
 #ifndef REV_EP_FINAL
 #define REV_EP_FINAL 2
 #endif
+#ifndef REV_EP_FINAL16
+#define REV_EP_FINAL16 2       // final walk of H = 16 (one lane group per row: 97 KB of LDS per workgroup, 17.3 -> 20.7 us)
+#endif
+#ifndef REV_EP_CHAIN16
+#define REV_EP_CHAIN16 1       // chain walks of H >= 16 and the final walks of H >= 32: one lane group per row (H = 32: chain 9.6 -> 8.0, first 11.2 -> 9.9 us; H = 64 final 11.6 -> 10.6; H = 16 chain 7.2 -> 6.9)
+#endif
 #ifndef REV_TR_CHAIN
 #define REV_TR_CHAIN 3         // load rounds per LDS tile, chain walks WITHOUT pair sums (H = 8: 192 entries x 32 B = 6 KiB per wave)
 #endif
@@ -642,7 +648,7 @@ extern "C" size_t crfconv_meanfield_backward_workspace(int64_t m, int H, int K) 
 
 template <int HH, int MODE, bool FIRST>
 static void launch_rev(const RevArgs& ra, int64_t m, hipStream_t st) {
-    constexpr int EPV = (HH == 4) ? 4 : (MODE == REV_FINAL && HH <= 16 ? REV_EP_FINAL : (HH <= 8 ? REV_EP_CHAIN : 2));
+    constexpr int EPV = (HH == 4) ? 4 : (MODE == REV_FINAL && HH <= 16 ? (HH == 16 ? REV_EP_FINAL16 : REV_EP_FINAL) : (HH <= 8 ? REV_EP_CHAIN : REV_EP_CHAIN16));
     // LDS tile of a wave: 64 TR entries x 4 H bytes (x 2 + in the final walk): 6-9 KiB, so that four workgroups fit a CU
     // (the pair-sum form ignores TR: 32 MAXRR pair entries + R side slots per table)
     constexpr int TR = MODE == REV_FINAL ? (HH <= 8 ? REV_TR_FINAL : 1) : (HH <= 8 ? REV_TR_CHAIN : (HH == 16 ? 2 : 8));
