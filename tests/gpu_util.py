@@ -64,12 +64,15 @@ def enforced_bound(key, tol, baseline):
     return tol, ''
 
 
-def assert_close(a, b, tol, what=''):
+def assert_close(a, b, tol, what='', tighten=True):
+    """tighten=False: the stated bound only, whatever the baseline recorded -- for comparisons of two TRAJECTORIES (parameters after several
+    optimizer steps of two launch sequences that differ in a summation order): their distance is the seed rounding error times whatever the
+    steps in between amplify it by, and differs between two runs of the same code on two builds by orders of magnitude (1e-10 ... 1e-6)."""
     global _baseline
     e = relerr(a, b)
     key = _key(what)
-    recording = bool(os.environ.get('CRFCONV_TOL_RECORD'))
-    if recording:
+    recording = bool(os.environ.get('CRFCONV_TOL_RECORD')) or not tighten
+    if os.environ.get('CRFCONV_TOL_RECORD'):
         _recorded[key] = max(_recorded.get(key, 0.0), e)
     if _baseline is None:
         try:

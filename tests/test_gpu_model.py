@@ -2416,7 +2416,8 @@ def test_captured_step_of_the_unchanged_reference_loop_equals_the_eager_loop(def
     for a, b in zip(got_losses, ref_losses):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (got_losses, ref_losses)
     for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
-        assert_close(a.float(), b.float(), 2e-5, ('after 3 steps (batched weight gradients): ' if defer else 'after 3 steps: ') + k)
+        assert_close(a.float(), b.float(), 2e-5, ('after 3 steps (batched weight gradients): ' if defer else 'after 3 steps: ') + k,
+                     tighten=not defer)     # (batched weight gradients sum in another order: two trajectories, see assert_close)
 
 
 def test_graphed_model_in_the_unchanged_reference_loop_equals_the_eager_loop():
@@ -2462,7 +2463,7 @@ def test_graphed_model_in_the_unchanged_reference_loop_equals_the_eager_loop():
     for a, b in zip(losses['graphed'], losses['eager']):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), losses
     for (k, a), b in zip(inner.state_dict().items(), ref.state_dict().values()):
-        assert_close(a.float(), b.float(), 2e-5, 'graphed module, after 3 steps: ' + k)
+        assert_close(a.float(), b.float(), 2e-5, 'graphed module, after 3 steps: ' + k, tighten=False)
     # accumulation: two backward passes on two batches, no zero_grad in between (from EQUAL state: what remains is summation order)
     inner.load_state_dict(ref.state_dict())
     seen = []
