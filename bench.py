@@ -61,6 +61,8 @@ if __name__ == '__main__':
 
 import numpy as np        # noqa: E402
 import crfconv_amd        # noqa: E402,F401  (first: picks the hardware-queue mapping for a launch under a process group, crfconv_amd/__init__.py)
+import crfconv_amd.train  # noqa: E402
+crfconv_amd.train.set_autograph(False)      # this script captures its steps itself; reference_loop switches the models' own capture on for the legs that measure it
 import torch              # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

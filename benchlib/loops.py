@@ -35,7 +35,26 @@ def reference_loop(net, data, cw, steps):
     eager = (time.perf_counter() - t0) / steps * 1e3
     out = {'eager_ms_per_step': eager, 'eager_final_loss': float(loss),
            'what': 'trainval.py:99-106 unchanged (zero_grad, model(data), F.cross_entropy(weight, ignore_index=-1), backward, '
-                   'torch.optim.SGD.step), %d timed steps after 3 warm-up' % steps}
+                   'torch.optim.SGD.step), %d timed steps after 3 warm-up; eager_* : every launch issued by the host (train.set_autograph(False)); '
+                   'bare_autograph_* : the same lines on the same bare model with the product default (the model captures its training forward / '
+                   'backward itself, crfconv_amd.train)' % steps}
+    # (a2) the SAME five lines on the SAME bare model, the product's default: the model hands its training forward to a private graph runner
+    from crfconv_amd import train
+    train.set_autograph(True)
+    try:
+        for _ in range(3):
+            one()                              # (the first call captures)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = one()
+        torch.cuda.synchronize()
+        out['bare_autograph_ms_per_step'] = (time.perf_counter() - t0) / steps * 1e3
+        out['bare_autograph_final_loss'] = float(loss)
+        out['bare_autograph_replays'] = bool(getattr(net.__dict__.get('_autograph'), 'fwd_graph', None) is not None)
+    finally:
+        train.set_autograph(False)
+        net.__dict__.pop('_autograph', None)
     for key, defer in (('captured_as_written_ms_per_step', False), ('captured_ms_per_step', True)):
         # CapturedStep's default batches the ~150 weight-gradient launches of the backward (ops.deferred_weight_grads inside the
         # capture; the caller's five lines are untouched); "as written" = the backward exactly as autograd issues it
@@ -128,6 +147,13 @@ def reference_loop(net, data, cw, steps):
         pos_r, x_r, y_r = pool[i % 4]
         return one_on(crfconv_amd.multiscale_compute(pos_r, x=x_r, y=y_r, generator=gen, sort='morton'))
     out['fresh_eager_ms_per_step'], out['fresh_eager_final_loss'] = timed(eager_fresh, steps)
+    # (d4) the same with the product default: eager collate, the bare model capturing itself (each new batch is loaded into the captured one)
+    train.set_autograph(True)
+    try:
+        out['fresh_bare_autograph_ms_per_step'], _ = timed(eager_fresh, steps)
+    finally:
+        train.set_autograph(False)
+        net.__dict__.pop('_autograph', None)
     out['fresh_what'] = ('a NEW batch every step (4 x 40 960-point clouds, device collate = the reference\'s _multiscale_compute_fn): fresh_eager = '
                          'crfconv_amd.multiscale_compute + the unchanged five lines on the bare model; fresh_graphed = train.GraphedModel + '
                          'data.CollateGraph.collate (side stream, beside the step) / .load (between steps); ..._one_stream = CollateGraph.run then the step')

@@ -112,5 +112,17 @@ class Base(nn.Module):
     def save(self, filename):
         torch.save(self.state_dict(), filename)
 
+    # A self-capturing model (train.autograph_forward) keeps its private graph runner in its instance dictionary, outside the module
+    # tree.  The runner's graphs hold device addresses: a copy of the model starts without it, and whatever moves or casts the
+    # parameters (to(), float(), cuda()) drops it -- the next training call captures again.
+    def __getstate__(self):
+        state = dict(super().__getstate__())
+        state.pop('_autograph', None)
+        return state
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop('_autograph', None)
+        return super()._apply(fn, *args, **kwargs)
+
     def load(self, filename):
         self.load_state_dict(torch.load(filename))

@@ -170,6 +170,11 @@ class PointConvResNet(Base):
 
     def forward(self, data):
         if self.training:
+            from .. import train
+            if train.autograph_wanted(data):                # the reference loop unwrapped: the step as two hipGraph replays (train.py)
+                out = train.autograph_forward(self, data)
+                if out is not None:
+                    return out
             with ops.advance_counters(self):              # every BatchNorm below runs exactly once per forward
                 return self._forward(data)
         return self._forward(data)

@@ -9,8 +9,66 @@ learning-rate change needs a new CapturedStep) or optim.FlatSGD (then pass after
 batch)` is the caller's, e.g. ``lambda o, d: F.cross_entropy(o, d.y.reshape(-1) - 1, weight=w, ignore_index=-1)``.
 Drop (or detach) losses of earlier EAGER steps of the same model before constructing it: a live loss keeps that step's
 autograd nodes -- the parameters' AccumulateGrad nodes, bound to the stream they were created on -- alive, and the capture
-would then have to synchronise with that stream."""
+would then have to synchronise with that stream.
+
+Round 6: the dense network captures ITSELF (``autograph``).  ``models.PointConvBig`` in training mode hands its forward to a private
+GraphedModel (below) the first time it is called on a device batch, so the reference loop with nothing wrapped -- trainval.py:96-106 as
+written -- runs as two hipGraph replays per step from its second iteration on.  What does not fit runs eagerly, silently and correctly:
+eval mode, ``no_grad``, a batch of other shapes, a forward whose predecessor has not been through ``backward()`` yet (its output is still
+in use: the replay would overwrite it), a model with forward / backward hooks on any submodule, a call during another stream capture.
+``set_autograph(False)`` / ``CRFCONV_AUTOGRAPH=0`` / ``with no_autograph():`` switch it off (every launch issued by the host: 2-3 x the step
+time); ``DistributedDataParallel`` around the model is untested -- switch it off there."""
+import os
+
 import torch
+
+_AUTO = {'on': os.environ.get('CRFCONV_AUTOGRAPH', '1').strip().lower() not in ('0', 'false', 'off', 'no', ''), 'bypass': 0}
+
+
+def set_autograph(on):
+    """Process-wide switch of the self-capturing training forward (default on; CRFCONV_AUTOGRAPH=0 starts with it off)."""
+    _AUTO['on'] = bool(on)
+
+
+class no_autograph:
+    """``with no_autograph():`` -- models called inside run eagerly (CapturedStep and GraphedModel use it around their own captures)."""
+
+    def __enter__(self):
+        _AUTO['bypass'] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _AUTO['bypass'] -= 1
+        return False
+
+
+def autograph_wanted(batch):
+    if not _AUTO['on'] or _AUTO['bypass'] or not torch.is_grad_enabled():
+        return False
+    x = getattr(batch, 'x', None)
+    if not (torch.is_tensor(x) and x.is_cuda and hasattr(batch, 'load_') and hasattr(batch, '_apply')):
+        return False
+    return not torch.cuda.is_current_stream_capturing()
+
+
+def _has_hooks(model):
+    for m in model.modules():
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, '_backward_pre_hooks', None):
+            return True
+    return False
+
+
+def autograph_forward(model, batch):
+    """The training-mode forward of a self-capturing model: the output of its private GraphedModel, or None -- run eagerly."""
+    runner = model.__dict__.get('_autograph')
+    if runner is None:
+        if _has_hooks(model):
+            return None
+        runner = GraphedModel(model, guard_pending=True)
+        object.__setattr__(model, '_autograph', runner)      # (not a submodule of the model: the model is the runner's)
+    elif runner.training is not model.training:
+        runner.training = model.training                     # (the runner is outside the model's tree: train() / eval() do not reach it)
+    return runner(batch)
 
 
 class CapturedStep:
@@ -20,6 +78,11 @@ class CapturedStep:
         ``optimizer.step()`` as usual (same partial slabs, fixed summation order).  False: the backward exactly as the caller wrote it."""
         self.model, self.optimizer, self.loss_fn, self.batch, self.after_backward = model, optimizer, loss_fn, batch, after_backward
         self.defer_weight_grads = bool(defer_weight_grads)
+        with no_autograph():                                    # (the model's forward is issued launch by launch inside THIS capture)
+            self._build(warmup)
+
+    def _build(self, warmup):
+        model, optimizer = self.model, self.optimizer
         # the warm-up steps (allocator, lazily built tables, momentum buffers) must not train: model state is put back afterwards,
         # momentum restarts from zero (mu * 0 + g = g: torch's first step, for dampening = 0)
         import copy
@@ -87,12 +150,14 @@ class _GraphedPass(torch.autograd.Function):
     def forward(ctx, gm, *params):
         gm.fwd_graph.replay()
         ctx.gm = gm
+        gm._pending = True                 # this output lives in the static buffer until its backward has run (autograph's guard)
         return gm.static_out.detach()
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         gm = ctx.gm
+        gm._pending = False
         gm._keep_accumulated_grads()
         gm.static_gout.copy_(g)
         gm.bwd_graph.replay()
@@ -119,10 +184,13 @@ class GraphedModel(torch.nn.Module):
     ``.grad`` -- aliases a static buffer that the next call overwrites, as with torch.cuda.make_graphed_callables (gradients still held as ``.grad``
     at the next call are moved out first: _keep_accumulated_grads)."""
 
-    def __init__(self, model, warmup=2, defer_weight_grads=True):
+    def __init__(self, model, warmup=2, defer_weight_grads=True, guard_pending=False):
+        """guard_pending (the self-capturing models' setting): a training call whose predecessor's output has not been through
+        ``backward()`` runs the model eagerly instead of replaying over it."""
         super().__init__()
         self.model = model
         self.warmup, self.defer_weight_grads = int(warmup), bool(defer_weight_grads)
+        self.guard_pending, self._pending = bool(guard_pending), False
         self.fwd_graph = self.bwd_graph = None
         self.static = self.static_out = self.static_gout = None
         self.params, self.static_grads, self._sig = [], [], None
@@ -169,8 +237,13 @@ class GraphedModel(torch.nn.Module):
             self.static_out.backward(self.static_gout)
 
     def _capture(self, batch):
+        with no_autograph():                                    # (the wrapped model's forward is issued launch by launch inside this capture)
+            self._capture_eagerly_issued(batch)
+
+    def _capture_eagerly_issued(self, batch):
         model = self.model
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self._frozen = tuple(p.requires_grad for p in model.parameters())
         self.static = batch._apply(torch.clone)
         self._sig = self._signature(batch)
         user_grads = [p.grad for p in self.params]
@@ -214,13 +287,21 @@ class GraphedModel(torch.nn.Module):
             if sg is not None and p.grad is not None and p.grad.data_ptr() == sg.data_ptr():
                 p.grad = p.grad.clone()
 
+    def _eager(self, batch):
+        with no_autograph():
+            return self.model(batch)
+
     def forward(self, batch):
         if not (self.training and torch.is_grad_enabled()):
-            return self.model(batch)
+            return self._eager(batch)
+        if self.guard_pending and self._pending:
+            return self._eager(batch)                           # the previous output is still in use: nothing may be replayed over it
         if self.fwd_graph is None:
             self._capture(batch)
         elif batch is not self.static and self._signature(batch) != self._sig:
-            return self.model(batch)
+            return self._eager(batch)
+        elif self.guard_pending and self._frozen != tuple(p.requires_grad for p in self.model.parameters()):
+            return self._eager(batch)                           # parameters frozen / thawed since the capture
         self._keep_accumulated_grads()
         if batch is not self.static:
             self.static.load_(batch, defer_check=True)          # (no host synchronisation: a bad table raises at the next call)

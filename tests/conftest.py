@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# The suite checks the launches the modules issue one by one: the self-capturing training forward (crfconv_amd.train: autograph) stays
+# off unless a test switches it on for itself (test_gpu_model.py: ..._captures_itself_...).
+os.environ.setdefault('CRFCONV_AUTOGRAPH', '0')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 for p in (ROOT, GOLDEN):

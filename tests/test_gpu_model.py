@@ -2499,6 +2499,105 @@ def test_graphed_model_in_the_unchanged_reference_loop_equals_the_eager_loop():
     assert_close(a, b, 2e-5, 'graphed module, eval call')
 
 
+def test_bare_model_captures_itself_in_the_unchanged_reference_loop():
+    """Round 6: with crfconv_amd.train's autograph on (the product's default; the suite runs with it off), the reference's five lines
+    VERBATIM on the BARE model -- nothing wrapped -- are two hipGraph replays per step from the second iteration on: three batches from
+    equal state leave the losses / parameters / buffers of the launch-by-launch loop.  Everything that does not fit runs eagerly and
+    correctly: a forward whose predecessor has not been through backward() (its output must survive), eval / no_grad, another batch
+    shape, a model with a forward hook; a deep copy starts without graphs and captures for itself; to() drops the graphs."""
+    import copy
+    import crfconv_amd
+    import torch.nn.functional as F
+    from crfconv_amd import models, train
+    B, N = 2, 8192
+
+    def batch(seed, n=N):
+        pos = np.stack([S.make_cloud(seed + b, n, box=(2, 2, 1)) for b in range(B)])
+        feats = np.concatenate([pos, S.uniform(seed, 'rgb', (B, n, 3), 0, 1)], -1)
+        return crfconv_amd.multiscale_compute(t(pos), x=t(feats), y=t(S.integers(seed, 'y', (B, n), 0, 14)),
+                                              generator=torch.Generator().manual_seed(seed))
+    batches = [batch(700 + 10 * i) for i in range(3)]
+    cw = torch.linspace(0.5, 1.5, 13, device=DEV)
+    torch.manual_seed(6)
+    ref = models.PointConvBig(6, 13, True, 3).to(DEV).train()
+    net = models.PointConvBig(6, 13, True, 3).to(DEV).train()
+    net.load_state_dict(ref.state_dict())
+    mk = lambda m: torch.optim.SGD(m.parameters(), lr=1e-2, momentum=0.95, weight_decay=1e-4)      # noqa: E731
+
+    def loop(model, optimizer):
+        out = []
+        for data in batches:
+            optimizer.zero_grad()
+            y_pred = model(data)
+            y = data.y.reshape(-1) - 1
+            loss = F.cross_entropy(y_pred, y, weight=cw, ignore_index=-1)
+            loss.backward()
+            optimizer.step()
+            out.append(float(loss.detach()))
+        return out
+    assert not train._AUTO['on'], 'the suite runs with autograph off (tests/conftest.py)'
+    eager = loop(ref, mk(ref))
+    assert '_autograph' not in ref.__dict__
+    train.set_autograph(True)
+    try:
+        auto = loop(net, mk(net))
+        runner = net.__dict__.get('_autograph')
+        assert runner is not None and runner.fwd_graph is not None and runner.bwd_graph is not None
+        assert list(net.state_dict().keys()) == list(ref.state_dict().keys())        # the runner is not part of the model's tree
+        for a, b in zip(auto, eager):
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (auto, eager)
+        for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
+            assert_close(a.float(), b.float(), 2e-5, 'self-capturing model, after 3 steps: ' + k, tighten=False)
+        # two forwards before one backward: the first output must survive the second call (which therefore runs eagerly)
+        net.load_state_dict(ref.state_dict())
+        for p in list(net.parameters()) + list(ref.parameters()):
+            p.grad = None
+        o1 = net(batches[0])
+        keep = o1.detach().clone()
+        o2 = net(batches[1])
+        assert o2.grad_fn is not None and torch.equal(o1.detach(), keep), 'a replay overwrote an output that was still in use'
+        (o1.sum() + o2.sum()).backward()
+        with train.no_autograph():
+            (ref(batches[0]).sum() + ref(batches[1]).sum()).backward()
+        for (k, a), b in zip(net.named_parameters(), ref.parameters()):
+            assert_close(a.grad, b.grad, 2e-5, 'self-capturing model, two forwards one backward: ' + k)
+        # after that backward the replays are back
+        before = runner.fwd_graph
+        o3 = net(batches[2])
+        assert type(o3.grad_fn).__name__.startswith('_GraphedPass') and runner.fwd_graph is before
+        o3.sum().backward()
+        # another shape, no_grad, eval: the launches one by one
+        other = batch(990, N // 2)
+        net.load_state_dict(ref.state_dict())           # (equal BatchNorm / dropout counters again: net has been through more forwards)
+        torch.manual_seed(123)
+        a = net(other)
+        torch.manual_seed(123)
+        with train.no_autograph():
+            b = ref(other)
+        assert a.grad_fn is not None and not type(a.grad_fn).__name__.startswith('_GraphedPass')
+        assert_close(a, b, 2e-5, 'self-capturing model, other shape (eager path)')
+        with torch.no_grad():
+            assert_close(net(batches[0]), ref(batches[0]), 2e-5, 'self-capturing model, no_grad call')
+        net.eval(), ref.eval()
+        assert_close(net(batches[1]), ref(batches[1]), 2e-5, 'self-capturing model, eval call')
+        net.train(), ref.train()
+        # a deep copy has no graphs and captures for itself; a hook keeps a model eager; to() drops the graphs
+        twin = copy.deepcopy(net)
+        assert '_autograph' not in twin.__dict__
+        o = twin(batches[0])
+        assert type(o.grad_fn).__name__.startswith('_GraphedPass') and twin.__dict__['_autograph'] is not runner
+        o.sum().backward()
+        hooked = copy.deepcopy(net)
+        h = hooked.conv1_1.register_forward_hook(lambda m, i, o_: None)
+        o = hooked(batches[0])
+        assert '_autograph' not in hooked.__dict__ and not type(o.grad_fn).__name__.startswith('_GraphedPass')
+        h.remove()
+        net.to(DEV)
+        assert '_autograph' not in net.__dict__
+    finally:
+        train.set_autograph(False)
+
+
 def test_crf_late_gradients_with_two_consumers_of_one_matrix_pair_and_a_hook():
     """(Q, P) of crf_matrices_batched feeding TWO mean-field calls, a tensor hook on Q and another use of P, under
     ops.deferred_weight_grads: the deferred dP / dQ travel out of band (the node's gradient boxes), so autograd never holds a
