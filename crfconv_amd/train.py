@@ -190,7 +190,7 @@ class GraphedModel(torch.nn.Module):
         super().__init__()
         self.model = model
         self.warmup, self.defer_weight_grads = int(warmup), bool(defer_weight_grads)
-        self.guard_pending, self._pending = bool(guard_pending), False
+        self.guard_pending, self._pending, self._last_out = bool(guard_pending), False, None
         self.fwd_graph = self.bwd_graph = None
         self.static = self.static_out = self.static_gout = None
         self.params, self.static_grads, self._sig = [], [], None
@@ -295,7 +295,10 @@ class GraphedModel(torch.nn.Module):
         if not (self.training and torch.is_grad_enabled()):
             return self._eager(batch)
         if self.guard_pending and self._pending:
-            return self._eager(batch)                           # the previous output is still in use: nothing may be replayed over it
+            if self._last_out is not None and self._last_out() is None:
+                self._pending = False                           # ... unless nobody holds it any more (a step that skipped its backward)
+            else:
+                return self._eager(batch)                       # the previous output is still in use: nothing may be replayed over it
         if self.fwd_graph is None:
             self._capture(batch)
         elif batch is not self.static and self._signature(batch) != self._sig:
@@ -305,4 +308,8 @@ class GraphedModel(torch.nn.Module):
         self._keep_accumulated_grads()
         if batch is not self.static:
             self.static.load_(batch, defer_check=True)          # (no host synchronisation: a bad table raises at the next call)
-        return _GraphedPass.apply(self, *self.params)
+        out = _GraphedPass.apply(self, *self.params)
+        if self.guard_pending:
+            import weakref
+            self._last_out = weakref.ref(out)
+        return out

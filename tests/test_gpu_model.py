@@ -2566,6 +2566,16 @@ def test_bare_model_captures_itself_in_the_unchanged_reference_loop():
         o3 = net(batches[2])
         assert type(o3.grad_fn).__name__.startswith('_GraphedPass') and runner.fwd_graph is before
         o3.sum().backward()
+        # a step that skips its backward (say, a NaN loss): the next call runs eagerly while the orphaned output is alive, then replays return
+        o4 = net(batches[0])
+        assert type(o4.grad_fn).__name__.startswith('_GraphedPass')
+        o5 = net(batches[1])                            # o4 is still referenced: eager
+        assert not type(o5.grad_fn).__name__.startswith('_GraphedPass')
+        del o4, o5
+        o6 = net(batches[2])
+        assert type(o6.grad_fn).__name__.startswith('_GraphedPass')
+        o6.sum().backward()
+        del o6
         # another shape, no_grad, eval: the launches one by one
         other = batch(990, N // 2)
         net.load_state_dict(ref.state_dict())           # (equal BatchNorm / dropout counters again: net has been through more forwards)
