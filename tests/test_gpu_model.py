@@ -170,6 +170,38 @@ def test_meanfield_vs_oracle(H, K, steps, B):
     assert_close(zero(cd.grad, cd), zero(cr.grad, cr), GRAD_TOL, 'dc')
 
 
+@pytest.mark.parametrize('H,K,steps', [(8, 16, 3), (16, 16, 3), (32, 16, 2), (64, 16, 2), (8, 32, 2), (8, 16, 1)])
+def test_meanfield_backward_hub_rows_and_rows_without_in_edges(H, K, steps):
+    """Reverse walks over very uneven in-degrees: three columns of every row point at rows 5, 6 and N - 1 of its cloud (in-degrees of
+    ~N: a wavefront's range of the reverse edge list spans many chunks, rows continue across chunk boundaries, pair sums straddle
+    them), the rest at a narrow band of rows, so that most rows have NO in-edge at all; N is odd and no multiple of the rows per
+    wavefront.  Forward and every gradient against the float32 oracle (crf_oracle.crf_meanfield)."""
+    from crfconv_amd import ops
+    from crfconv_amd.graph import NeighborTable
+    B, N = 2, 1237
+    rng = np.random.default_rng(100 + H + K)
+    nbr = rng.integers(40, 90, (B, N, K))                     # a band of 50 rows takes almost every edge
+    nbr[:, :, 0] = np.arange(N)
+    nbr[:, :, 3], nbr[:, :, 7], nbr[:, :, K - 1] = 5, 6, N - 1  # hubs
+    nbr[:, ::7, 2] = rng.integers(0, N, (B, len(range(0, N, 7))))      # a few edges anywhere
+    z = S.uniform(H, 'z', (B, N, H))
+    y = S.uniform(H, 'y', (B, N, H))
+    c = (np.eye(H) + 0.1 * S.uniform(H, 'c', (H, H))).astype(np.float32)
+    g = S.uniform(H, 'g', (B, N, H))
+    zr, yr, cr = (torch.from_numpy(a).requires_grad_(True) for a in (z, y, c))
+    ref = O.crf_meanfield(zr, yr, torch.from_numpy(nbr)[:, :, 1:], cr, steps)
+    (ref * torch.from_numpy(g)).sum().backward()
+    tab = NeighborTable(t(nbr), N)
+    zd, yd, cd = (t(a).requires_grad_(True) for a in (z, y, c))
+    out = ops.crf_meanfield(zd.reshape(-1, H), yd.reshape(-1, H), cd, tab, steps, k0=1)
+    (out.reshape(B, N, H) * t(g)).sum().backward()
+    assert_close(out.reshape(B, N, H), ref, OUT_TOL, 'hub table: x_T')
+    # (hub rows sum ~N terms: the comparison is relative to the largest gradient entry, as everywhere)
+    assert_close(zd.grad, zr.grad, GRAD_TOL, 'hub table: dz')
+    assert_close(yd.grad, yr.grad, GRAD_TOL, 'hub table: dy')
+    assert_close(cd.grad, cr.grad, GRAD_TOL, 'hub table: dc')
+
+
 def _local_table(B, N, K, seed, spread):
     """[B, N, K] int64 neighbours: column 0 = self, the others within +-spread rows of the target (a spatially sorted cloud in
     miniature) or anywhere (spread = 0: a shuffled cloud)."""
